@@ -1,0 +1,302 @@
+"""TEST INFRASTRUCTURE -- generate tests/golden/*.npz by EXECUTING the unmodified
+reference (/root/reference) in the build container.
+
+    python oracle/make_golden.py            # writes tests/golden/{gae,model,ppo_lag_trace,cpo_trace}.npz
+
+The reference is Python and cannot travel to the GPU box, so its outputs are committed
+as small fixtures together with this script (task brief section 3).  Every array stored
+here is produced by reference code: VectorizedOnPolicyBuffer.store/finish_path/get,
+ActorVCritic.step, and complete runs of safepo.single_agent.{ppo_lag,cpo}.main on the
+seeded host SynthEnv, observed through wrappers that record but do not alter values.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import ref_shim  # noqa: E402
+from oracle.synth_env import Space, SynthEnv  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def _np(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+# ------------------------------------------------------------------ GAE
+def golden_gae():
+    P = ref_shim.load_reference("ppo_lag")
+    Buf = P.VectorizedOnPolicyBuffer
+    out = {}
+    for tag, (N, T, p_seg, seed) in {"a": (8, 48, 1 / 8, 1), "b": (16, 128, 1 / 32, 2),
+                                      "c": (3, 7, 0.4, 3), "d": (5, 1, 0.0, 4)}.items():
+        rng = np.random.default_rng(seed)
+        reward = rng.standard_normal((N, T)).astype(np.float32)
+        cost = (rng.random((N, T)) < 0.3).astype(np.float32)
+        v_r = rng.standard_normal((N, T)).astype(np.float32)
+        v_c = rng.standard_normal((N, T)).astype(np.float32)
+        seg = rng.random((N, T)) < p_seg
+        seg[:, T - 1] = True
+        term = seg & (rng.random((N, T)) < 0.5)
+        boot_r = np.where(seg & ~term, rng.standard_normal((N, T)), 0).astype(np.float32)
+        boot_c = np.where(seg & ~term, rng.standard_normal((N, T)), 0).astype(np.float32)
+        obs = rng.standard_normal((N, T, 6)).astype(np.float32)
+        act = rng.standard_normal((N, T, 2)).astype(np.float32)
+        logp = rng.standard_normal((N, T)).astype(np.float32)
+        buf = Buf(obs_space=Space(6), act_space=Space(2), size=T, num_envs=N, gamma=0.99)
+        for t in range(T):
+            buf.store(obs=torch.from_numpy(obs[:, t]), act=torch.from_numpy(act[:, t]),
+                      reward=torch.from_numpy(reward[:, t]), cost=torch.from_numpy(cost[:, t]),
+                      value_r=torch.from_numpy(v_r[:, t]), value_c=torch.from_numpy(v_c[:, t]),
+                      log_prob=torch.from_numpy(logp[:, t]))
+            for n in range(N):
+                if seg[n, t]:
+                    buf.finish_path(last_value_r=torch.tensor([boot_r[n, t]]),
+                                    last_value_c=torch.tensor([boot_c[n, t]]), idx=n)
+        raw = {k: np.stack([b[k].numpy().copy() for b in buf.buffers]) for k in
+               ("adv_r", "adv_c", "target_value_r", "target_value_c")}
+        data = _np(buf.get())
+        for k, v in dict(reward=reward, cost=cost, value_r=v_r, value_c=v_c, seg_end=seg.astype(np.uint8),
+                         boot_r=boot_r, boot_c=boot_c, obs=obs, act=act, log_prob=logp).items():
+            out[f"{tag}_in_{k}"] = v
+        for k, v in raw.items():
+            out[f"{tag}_raw_{k}"] = v
+        for k, v in data.items():
+            out[f"{tag}_get_{k}"] = v
+    np.savez_compressed(os.path.join(OUT, "gae.npz"), **out)
+    print("gae.npz", len(out), "arrays")
+
+
+# ------------------------------------------------------------------ model
+def golden_model():
+    P = ref_shim.load_reference("ppo_lag")
+    torch.manual_seed(7)
+    pol = P.ActorVCritic(obs_dim=60, act_dim=8, hidden_sizes=[64, 64])
+    out = {f"sd_{k}": v.numpy().copy() for k, v in pol.state_dict().items()}
+    obs = torch.randn(33, 60)
+    torch.manual_seed(11)
+    with torch.no_grad():
+        act, logp, v_r, v_c = pol.step(obs, deterministic=False)
+        dist = pol.actor(obs)
+        eps = (act - dist.mean) / dist.stddev
+        act_d, logp_d, _, _ = pol.step(obs, deterministic=True)
+        a1, l1, r1, c1 = pol.step(obs[5], deterministic=True)       # single row (bootstrap call shape)
+    out.update(_np(dict(obs=obs, act=act, logp=logp, v_r=v_r, v_c=v_c, mean=dist.mean, eps=eps,
+                        act_det=act_d, logp_det=logp_d, row5_v_r=r1, row5_v_c=c1)))
+    np.savez_compressed(os.path.join(OUT, "model.npz"), **out)
+    print("model.npz", len(out), "arrays")
+
+
+# ------------------------------------------------------------------ full-main traces
+class Recorder:
+    def __init__(self):
+        self.a = {}
+
+    def put(self, key, val):
+        self.a[key] = val.detach().cpu().numpy().copy() if torch.is_tensor(val) else np.asarray(val).copy()
+
+
+def _instrument(P, rec: Recorder, env_kw: dict, algo: str):
+    """Wrap (not modify) the names main() looks up in its module globals."""
+    state = {"epoch": 0, "policy": None, "perm_i": 0}
+    RealPolicy, RealBuf, RealLogger = P.ActorVCritic, P.VectorizedOnPolicyBuffer, P.EpochLogger
+    RealDS, RealDL = P.TensorDataset, P.DataLoader
+
+    def policy_factory(*a, **k):
+        pol = RealPolicy(*a, **k)
+        state["policy"] = pol
+        for kk, v in pol.state_dict().items():
+            rec.put(f"init_sd_{kk}", v)
+        return pol
+
+    class Buf(RealBuf):
+        def get(self):
+            e = state["epoch"]
+            for k in ("obs", "act", "reward", "cost", "value_r", "value_c", "log_prob", "adv_r", "adv_c",
+                      "target_value_r", "target_value_c"):
+                rec.put(f"e{e}_raw_{k}", torch.stack([b[k] for b in self.buffers]))
+            rec.put(f"e{e}_seg_end", np.stack(self._seg_log))
+            rec.put(f"e{e}_boot_r", np.stack(self._boot_r_log))
+            rec.put(f"e{e}_boot_c", np.stack(self._boot_c_log))
+            for kk, v in state["policy"].state_dict().items():
+                rec.put(f"e{e}_sd_before_{kk}", v)
+            data = super().get()
+            for k in ("adv_r", "adv_c"):
+                rec.put(f"e{e}_get_{k}", data[k])
+            self._reset_logs()
+            return data
+
+        def _reset_logs(self):
+            size = self.buffers[0]["reward"].shape[0]
+            self._seg_log = [np.zeros(size, np.uint8) for _ in range(self.num_envs)]
+            self._boot_r_log = [np.zeros(size, np.float32) for _ in range(self.num_envs)]
+            self._boot_c_log = [np.zeros(size, np.float32) for _ in range(self.num_envs)]
+
+        def finish_path(self, last_value_r=None, last_value_c=None, idx=0):
+            if not hasattr(self, "_seg_log"):
+                self._reset_logs()
+            t = self.ptr_list[idx] - 1
+            self._seg_log[idx][t] = 1
+            self._boot_r_log[idx][t] = float(last_value_r.reshape(-1)[0])
+            self._boot_c_log[idx][t] = float(last_value_c.reshape(-1)[0])
+            return super().finish_path(last_value_r, last_value_c, idx)
+
+    class Log(RealLogger):
+        def __init__(self, *a, **k):
+            k["use_tensorboard"] = False
+            super().__init__(*a, **k)
+            self._mb = []
+
+        def store(self, add_value=False, **kw):
+            if "Loss/Loss_reward_critic" in kw:
+                self._mb.append([kw.get("Loss/Loss_reward_critic", np.nan), kw.get("Loss/Loss_cost_critic", np.nan),
+                                 kw.get("Loss/Loss_actor", np.nan)])
+            if "Misc/Alpha" in kw:                       # CPO: right after the actor update
+                e = state["epoch"]
+                for k, v in kw.items():
+                    rec.put(f"e{e}_{k.replace('/', '_')}", np.float64(v))
+                for kk, v in state["policy"].actor.state_dict().items():
+                    rec.put(f"e{e}_actor_after_{kk}", v)
+            return super().store(add_value=add_value, **kw)
+
+        def get_stats(self, key):
+            v = super().get_stats(key)
+            rec.put(f"e{state['epoch']}_get_stats_{key.replace('/', '_')}", np.float64(v))
+            return v
+
+        def dump_tabular(self):
+            e = state["epoch"]
+            for k, v in self.log_current_row.items():
+                rec.put(f"e{e}_row_{k.replace('/', '_')}", np.float64(v))
+            self._flush_mb()
+            super().dump_tabular()
+
+        def _flush_mb(self):
+            if self._mb:
+                rec.put(f"e{state['epoch']}_mb_losses", np.asarray(self._mb, np.float64))
+                self._mb = []
+
+        def close(self):
+            self._flush_mb()
+            super().close()
+
+    def ds_factory(*tensors):
+        return RealDS(*tensors, torch.arange(tensors[0].shape[0]))
+
+    class DL:
+        def __init__(self, dataset, batch_size, shuffle):
+            self.inner = RealDL(dataset=dataset, batch_size=batch_size, shuffle=shuffle)
+            rec.put(f"e{state['epoch']}_batch_size", np.int64(batch_size))
+            self.passes = 0
+
+        def __iter__(self):
+            idxs = []
+            for batch in self.inner:
+                idxs.append(batch[-1])
+                yield batch[:-1]
+            rec.put(f"e{state['epoch']}_perm{self.passes}", torch.cat(idxs))
+            self.passes += 1
+
+    P.ActorVCritic = policy_factory
+    P.VectorizedOnPolicyBuffer = Buf
+    P.EpochLogger = Log
+    P.TensorDataset = ds_factory
+    P.DataLoader = DL
+    ref_shim.set_env_factory(P, lambda n, env_id, seed: (
+        SynthEnv(n, seed=(0 if seed is None else seed), **env_kw), Space(env_kw["obs_dim"]), Space(env_kw["act_dim"])))
+    return state, (RealPolicy, RealBuf, RealLogger, RealDS, RealDL)
+
+
+def _restore(P, saved):
+    P.ActorVCritic, P.VectorizedOnPolicyBuffer, P.EpochLogger, P.TensorDataset, P.DataLoader = saved
+
+
+def golden_trace(algo: str, fname: str, num_envs: int, T: int, epochs: int, env_kw: dict, cfg_over: dict,
+                 fvp_calls: int = 0, args_over: dict | None = None):
+    P = ref_shim.load_reference(algo)
+    rec = Recorder()
+    state, saved = _instrument(P, rec, env_kw, algo)
+    cfg_saved = dict(P.default_cfg)
+    P.default_cfg.update(cfg_over)
+    real_fvp = getattr(P, "fvp", None)
+    if real_fvp is not None and fvp_calls:
+        calls = {"n": 0}
+
+        def fvp_rec(params, policy, fvp_obs):
+            out = real_fvp(params, policy, fvp_obs)
+            if calls["n"] < fvp_calls and float(params.abs().sum()) > 0:
+                rec.put(f"fvp_in{calls['n']}", params)
+                rec.put(f"fvp_out{calls['n']}", out)
+                for kk, v in policy.actor.state_dict().items():
+                    rec.put(f"fvp_sd{calls['n']}_{kk}", v)
+                calls["n"] += 1
+            return out
+        P.fvp = fvp_rec
+    # epoch counter: bump when LinearLR.step()/buffer.get cycle completes -> hook update_end via logger rows
+    RealBufGet = P.VectorizedOnPolicyBuffer.get
+
+    def counting_get(self):
+        d = RealBufGet(self)
+        return d
+    steps = num_envs * T
+    args = ref_shim.make_args(num_envs=num_envs, steps_per_epoch=steps, total_steps=steps * epochs, seed=0,
+                              log_dir=f"/tmp/oracle_runs/{algo}/task/run", **(args_over or {}))
+    for k in ("cost_limit", "lagrangian_multiplier_init", "lagrangian_multiplier_lr"):
+        rec.put(f"meta_arg_{k}", np.float64(getattr(args, k)))
+    # main() has no epoch hook; advance our counter from the rollout loop by wrapping env.step count:
+    env_holder = {}
+    fac = P.make_sa_mujoco_env
+
+    def fac2(num_envs, env_id, seed=None):
+        env, o, a = fac(num_envs, env_id, seed)
+        if "train" not in env_holder:
+            env_holder["train"] = env
+            real_step = env.step
+
+            def step(action):
+                state["epoch"] = env.n_steps // T
+                return real_step(action)
+            env.step = step
+        return env, o, a
+    P.make_sa_mujoco_env = fac2
+    try:
+        P.main(args, {})
+    finally:
+        _restore(P, saved)
+        P.default_cfg.clear()
+        P.default_cfg.update(cfg_saved)
+        if real_fvp is not None:
+            P.fvp = real_fvp
+    pol = state["policy"]
+    for kk, v in pol.state_dict().items():
+        rec.put(f"final_sd_{kk}", v)
+    rec.put("meta_num_envs", np.int64(num_envs))
+    rec.put("meta_T", np.int64(T))
+    rec.put("meta_epochs", np.int64(epochs))
+    for k, v in env_kw.items():
+        rec.put(f"meta_env_{k}", np.float64(v))
+    for k, v in {**cfg_saved, **cfg_over}.items():
+        if not isinstance(v, (list, tuple)):
+            rec.put(f"meta_cfg_{k}", np.float64(v))
+    np.savez_compressed(os.path.join(OUT, fname), **rec.a)
+    print(fname, len(rec.a), "arrays")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(1)
+    golden_gae()
+    golden_model()
+    env_kw = dict(obs_dim=60, act_dim=8, p_term=0.03, p_cost=0.3, trunc_len=20)
+    golden_trace("ppo_lag", "ppo_lag_trace.npz", num_envs=4, T=48, epochs=3, env_kw=env_kw,
+                 cfg_over={"learning_iters": 6, "target_kl": 0.004},
+                 args_over={"cost_limit": 1.0, "lagrangian_multiplier_init": 0.5})
+    golden_trace("cpo", "cpo_trace.npz", num_envs=4, T=48, epochs=2, env_kw=env_kw,
+                 cfg_over={"learning_iters": 2, "batch_size": 64}, fvp_calls=3,
+                 args_over={"cost_limit": 3.0})

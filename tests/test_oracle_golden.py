@@ -1,0 +1,201 @@
+"""Pins the CPU oracle (oracle/restatement.py) to outputs of the UNMODIFIED reference
+captured by oracle/make_golden.py (tests/golden/*.npz).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import restatement as R
+
+torch.set_num_threads(1)
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _policy_from(z, prefix, obs_dim=60, act_dim=8):
+    pol = R.OraclePolicy(obs_dim, act_dim)
+    sd = {k[len(prefix):]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith(prefix)}
+    pol.load_state_dict(sd)
+    return pol
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_gae_bit_exact_vs_reference_buffer(golden_dir, tag):
+    z = _load(golden_dir, "gae.npz")
+    i = lambda k: z[f"{tag}_in_{k}"]
+    adv_r, adv_c, tgt_r, tgt_c = R.gae_dense(i("reward"), i("cost"), i("value_r"), i("value_c"), i("seg_end"),
+                                              i("boot_r"), i("boot_c"), 0.99, 0.95, 0.95)
+    for got, key in ((adv_r, "adv_r"), (adv_c, "adv_c"), (tgt_r, "target_value_r"), (tgt_c, "target_value_c")):
+        ref = z[f"{tag}_raw_{key}"]
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), key
+    # per-path scalar restatement agrees too (first env, first path)
+    seg = i("seg_end")[0]
+    e = int(np.argmax(seg))
+    vals = np.concatenate([i("value_r")[0, :e + 1], [i("boot_r")[0, e]]])
+    rews = np.concatenate([i("reward")[0, :e + 1], [0.0]])
+    a, t = R.gae_path(vals, rews, 0.99, 0.95)
+    assert np.array_equal(a, z[f"{tag}_raw_adv_r"][0, :e + 1])
+    assert np.array_equal(t, z[f"{tag}_raw_target_value_r"][0, :e + 1])
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_get_standardisation_vs_reference(golden_dir, tag):
+    z = _load(golden_dir, "gae.npz")
+    N, T = z[f"{tag}_in_reward"].shape
+    adv_r = torch.from_numpy(z[f"{tag}_raw_adv_r"].reshape(-1))
+    adv_c = torch.from_numpy(z[f"{tag}_raw_adv_c"].reshape(-1))
+    sr, sc = R.adv_standardize(adv_r, adv_c)
+    assert np.array_equal(sr.numpy(), z[f"{tag}_get_adv_r"])
+    assert np.array_equal(sc.numpy(), z[f"{tag}_get_adv_c"])
+    # env-major flattening of get() (buffer.py:149-153)
+    assert np.array_equal(z[f"{tag}_get_obs"], z[f"{tag}_in_obs"].reshape(N * T, -1))
+    assert np.array_equal(z[f"{tag}_get_reward"], z[f"{tag}_in_reward"].reshape(-1))
+
+
+def test_model_step_vs_reference(golden_dir):
+    z = _load(golden_dir, "model.npz")
+    pol = _policy_from(z, "sd_")
+    # parameter registration order = reference order
+    names = [n for n, _ in pol.named_parameters()]
+    assert names[0] == "reward_critic.critic.0.weight" and names[12] == "actor.log_std"
+    assert sum(p.numel() for p in pol.parameters()) == 24850
+    with torch.no_grad():
+        act, logp, v_r, v_c = pol.step_with_eps(torch.from_numpy(z["obs"]), torch.from_numpy(z["eps"]))
+    np.testing.assert_allclose(act.numpy(), z["act"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(logp.numpy(), z["logp"], rtol=1e-6, atol=1e-6)
+    assert np.array_equal(v_r.numpy(), z["v_r"]) and np.array_equal(v_c.numpy(), z["v_c"])
+    with torch.no_grad():
+        _, _, r5, c5 = pol.step_with_eps(torch.from_numpy(z["obs"][5]), torch.zeros(8))
+    np.testing.assert_allclose(r5.numpy(), z["row5_v_r"], rtol=1e-6)
+    np.testing.assert_allclose(c5.numpy(), z["row5_v_c"], rtol=1e-6)
+
+
+def _epoch_data(z, e):
+    raw = lambda k: z[f"e{e}_raw_{k}"]
+    N, T = raw("reward").shape
+    adv_r, adv_c, tgt_r, tgt_c = R.gae_dense(raw("reward"), raw("cost"), raw("value_r"), raw("value_c"),
+                                              z[f"e{e}_seg_end"], z[f"e{e}_boot_r"], z[f"e{e}_boot_c"],
+                                              float(z["meta_cfg_gamma"]), 0.95, 0.95)
+    return N, T, adv_r, adv_c, tgt_r, tgt_c
+
+
+def test_ppo_lag_main_trace(golden_dir):
+    """Replays 3 epochs of the reference ppo_lag.main() (recorded buffers, shuffles and initial
+    weights) through the oracle: GAE bits, get() standardisation, lambda, per-minibatch losses,
+    early-stop iteration, KL and parameters after every epoch."""
+    z = _load(golden_dir, "ppo_lag_trace.npz")
+    epochs = int(z["meta_epochs"])
+    pol = _policy_from(z, "init_sd_")
+    upd = R.PPOLagUpdater(pol, epochs=epochs)
+    lag = R.OracleLagrange(float(z["meta_arg_cost_limit"]), float(z["meta_arg_lagrangian_multiplier_init"]),
+                           float(z["meta_arg_lagrangian_multiplier_lr"]))
+    for e in range(epochs):
+        for k, v in pol.state_dict().items():
+            np.testing.assert_allclose(v.numpy(), z[f"e{e}_sd_before_{k}"], rtol=2e-6, atol=1e-7, err_msg=k)
+        N, T, adv_r, adv_c, tgt_r, tgt_c = _epoch_data(z, e)
+        for got, key in ((adv_r, "adv_r"), (adv_c, "adv_c"), (tgt_r, "target_value_r"), (tgt_c, "target_value_c")):
+            assert np.array_equal(got, z[f"e{e}_raw_{key}"]), (e, key)
+        # every row's last step ends a path; boundary flags recorded from finish_path calls
+        assert z[f"e{e}_seg_end"][:, -1].all()
+        lag.update_lagrange_multiplier(float(z[f"e{e}_get_stats_Metrics_EpCost"]))
+        assert lag.lagrangian_multiplier == pytest.approx(float(z[f"e{e}_row_Train_LagragianMultiplier"]), rel=1e-6)
+        sr, sc = R.adv_standardize(torch.from_numpy(adv_r.reshape(-1)), torch.from_numpy(adv_c.reshape(-1)))
+        assert np.array_equal(sr.numpy(), z[f"e{e}_get_adv_r"])
+        assert np.array_equal(sc.numpy(), z[f"e{e}_get_adv_c"])
+        flat = lambda k: torch.from_numpy(z[f"e{e}_raw_{k}"].reshape(N * T, *z[f"e{e}_raw_{k}"].shape[2:]))
+        data = {"obs": flat("obs"), "act": flat("act"), "log_prob": flat("log_prob"),
+                "target_value_r": torch.from_numpy(tgt_r.reshape(-1)),
+                "target_value_c": torch.from_numpy(tgt_c.reshape(-1)), "adv_r": sr, "adv_c": sc}
+        n_perm = len([k for k in z.files if k.startswith(f"e{e}_perm")])
+        perms = [z[f"e{e}_perm{i}"] for i in range(n_perm)]
+        perms += [perms[-1]] * (6 - n_perm)
+        out = R.ppo_lag_update(pol, upd, data, lag.lagrangian_multiplier, perms,
+                               learning_iters=int(z["meta_cfg_learning_iters"]),
+                               batch_size=int(z[f"e{e}_batch_size"]), target_kl=float(z["meta_cfg_target_kl"]))
+        assert out["stop_iter"] == int(z[f"e{e}_row_Train_StopIter"]) == n_perm
+        assert out["kl"] == pytest.approx(float(z[f"e{e}_row_Train_KL"]), rel=1e-4)
+        np.testing.assert_allclose(out["losses"], z[f"e{e}_mb_losses"], rtol=2e-5, atol=1e-7)
+    for k, v in pol.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), z[f"final_sd_{k}"], rtol=2e-5, atol=2e-7, err_msg=k)
+
+
+def test_cpo_main_trace(golden_dir):
+    """Replays the reference cpo.main(): FVP known answers, the actor update (CG, case analysis,
+    line search) and the critic fit, epoch by epoch."""
+    z = _load(golden_dir, "cpo_trace.npz")
+    # FVP known-answer vectors recorded from the reference's fvp()
+    for i in range(3):
+        pol = R.OraclePolicy(60, 8)
+        pol.actor.load_state_dict({k[len(f"fvp_sd{i}_"):]: torch.from_numpy(z[k].copy())
+                                   for k in z.files if k.startswith(f"fvp_sd{i}_")})
+        obs = torch.from_numpy(z["e0_raw_obs"].reshape(-1, 60))
+        got = R.cpo_fvp(torch.from_numpy(z[f"fvp_in{i}"]), pol, obs)
+        np.testing.assert_allclose(got.numpy(), z[f"fvp_out{i}"], rtol=1e-5, atol=1e-8)
+    epochs = int(z["meta_epochs"])
+    pol = _policy_from(z, "init_sd_")
+    fit = R.CriticFitter(pol)
+    cases = []
+    for e in range(epochs):
+        for k, v in pol.state_dict().items():
+            np.testing.assert_allclose(v.numpy(), z[f"e{e}_sd_before_{k}"], rtol=1e-4, atol=2e-6, err_msg=k)
+        N, T, adv_r, adv_c, tgt_r, tgt_c = _epoch_data(z, e)
+        assert np.array_equal(adv_r, z[f"e{e}_raw_adv_r"]) and np.array_equal(tgt_c, z[f"e{e}_raw_target_value_c"])
+        sr, sc = R.adv_standardize(torch.from_numpy(adv_r.reshape(-1)), torch.from_numpy(adv_c.reshape(-1)))
+        flat = lambda k: torch.from_numpy(z[f"e{e}_raw_{k}"].reshape(N * T, *z[f"e{e}_raw_{k}"].shape[2:]))
+        data = {"obs": flat("obs"), "act": flat("act"), "log_prob": flat("log_prob"),
+                "target_value_r": torch.from_numpy(tgt_r.reshape(-1)),
+                "target_value_c": torch.from_numpy(tgt_c.reshape(-1)), "adv_r": sr, "adv_c": sc}
+        ep_costs = float(z[f"e{e}_get_stats_Metrics_EpCost"]) - float(z["meta_arg_cost_limit"])
+        out = R.cpo_policy_update(pol, data, ep_costs, target_kl=float(z["meta_cfg_target_kl"]))
+        cases.append(out["case"])
+        assert out["accept"] == int(z[f"e{e}_Misc_AcceptanceStep"])
+        assert float(out["xHx"]) == pytest.approx(float(z[f"e{e}_Misc_xHx"]), rel=1e-3)
+        assert float(out["x"].norm()) == pytest.approx(float(z[f"e{e}_Misc_H_inv_g"]), rel=1e-3)
+        assert float(out["g"].norm()) == pytest.approx(float(z[f"e{e}_Misc_gradient_norm"]), rel=1e-4)
+        assert float(out["step_direction"].norm()) == pytest.approx(float(z[f"e{e}_Misc_FinalStepNorm"]), rel=1e-3)
+        assert out["kl"] == pytest.approx(float(z[f"e{e}_Train_KL"]), rel=1e-3)
+        for k, v in pol.actor.state_dict().items():
+            np.testing.assert_allclose(v.numpy(), z[f"e{e}_actor_after_{k}"], rtol=1e-3, atol=2e-6, err_msg=k)
+        # critic fit with the recorded shuffles
+        bs = int(z[f"e{e}_batch_size"])
+        # the actor's stale .grad (= cost gradient b) takes part in clip_grad_norm_ (cpo.py:557)
+        R.actor_set_flat_params(pol.actor, R.actor_flat_params(pol.actor))
+        i = 0
+        for (_, prm) in pol.actor.named_parameters():
+            prm.grad = out["b"][i:i + prm.numel()].view(prm.shape).clone()
+            i += prm.numel()
+        losses = []
+        for it in range(int(z["meta_cfg_learning_iters"])):
+            perm = torch.from_numpy(z[f"e{e}_perm{it}"])
+            for s in range(0, N * T, bs):
+                idx = perm[s:s + bs]
+                losses.append(fit.minibatch_step(data["obs"][idx], data["target_value_r"][idx],
+                                                 data["target_value_c"][idx]))
+        np.testing.assert_allclose(np.asarray(losses), z[f"e{e}_mb_losses"][:, :2], rtol=1e-4, atol=1e-7)
+    assert cases[1] in (0, 1), "epoch 1 of the fixture is an infeasible-recovery case"
+    for k, v in pol.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), z[f"final_sd_{k}"], rtol=1e-3, atol=5e-6, err_msg=k)
+
+
+def test_boundary_logic_matches_trace(golden_dir):
+    """a-4: done -> bootstrap 0; epoch end and time-out both end a path (ppo_lag.py:198-234)."""
+    z = _load(golden_dir, "ppo_lag_trace.npz")
+    from oracle.synth_env import SynthEnv
+    env = SynthEnv(int(z["meta_num_envs"]), seed=0, obs_dim=60, act_dim=8, p_term=float(z["meta_env_p_term"]),
+                   p_cost=float(z["meta_env_p_cost"]), trunc_len=int(z["meta_env_trunc_len"]))
+    env.reset()
+    T = int(z["meta_T"])
+    for e in range(int(z["meta_epochs"])):
+        for t in range(T):
+            obs, rew, cost, term, trunc, info = env.step(None)
+            dummy = np.full(env.num_envs, 7.0, np.float32)
+            seg, br, bc = R.boundary_step(term, trunc, t == T - 1, dummy, dummy, dummy + 1, dummy + 1)
+            assert np.array_equal(seg.astype(np.uint8), z[f"e{e}_seg_end"][:, t]), (e, t)
+            assert np.all(br[term] == 0) and np.all(br[~seg] == 0), "terminated envs bootstrap with 0"
+            assert np.array_equal(rew, z[f"e{e}_raw_reward"][:, t])
+            # recorded bootstrap is zero exactly where the episode terminated
+            assert np.all(z[f"e{e}_boot_r"][:, t][term] == 0)
+            assert np.all(br[trunc] == 8.0) and np.all(br[seg & ~term & ~trunc] == 7.0)
