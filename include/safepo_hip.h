@@ -1,0 +1,157 @@
+/*
+ * safepo_hip.h -- C ABI of libsafepo_hip.so (gfx950 / MI355X).
+ *
+ * The reference (PKU-Alignment/Safe-Policy-Optimization) has NO native layer: the path
+ * this library replaces is Python.  Each entry point below names the
+ * reference Python function (file:line relative to /root/reference) whose arithmetic it
+ * replaces; the Python host mirror (safe-policy-optimization_amd/safepo) binds them with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - no allocation, no ownership transfer, no implicit synchronisation; work is enqueued on
+ *     `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - return value: 0 ok, <0 argument error (see spo_last_error()), >0 a hipError_t;
+ *   - re-entrant per stream; one host thread per GPU.
+ *
+ * Dense on-policy buffer layout (replaces the list of per-env dicts,
+ * safepo/common/buffer.py:53-73): scalars are [num_envs, T] env-major (flat row = env*T + t,
+ * the order VectorizedOnPolicyBuffer.get() concatenates in, buffer.py:149-153), obs
+ * [num_envs, T, obs_dim], act [num_envs, T, act_dim]; path ends are a u8 mask seg_end[N,T]
+ * with the bootstrap values of finish_path() in boot_r/boot_c[N,T].
+ *
+ * Flat parameter vector `theta` (fp32): policy.parameters() order of ActorVCritic
+ * (safepo/common/model.py:131-135): reward_critic {W1[H,D],b1,W2[H,H],b2,W3[1,H],b3},
+ * cost_critic {same}, actor {log_std[A], W1[H,D],b1,W2[H,H],b2,W3[A,H],b3}; nn.Linear
+ * row-major [out,in].  H = 64 (default_cfg hidden_sizes, ppo_lag.py:45-52).
+ */
+#ifndef SAFEPO_HIP_H
+#define SAFEPO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPO_ABI_VERSION 1
+#define SPO_HIDDEN 64          /* hidden width the MLP kernels are specialised for          */
+#define SPO_MAX_ACT 16         /* act_dim <= 16 (one MFMA output tile)                       */
+#define SPO_MAX_OBS 128        /* obs_dim <= 128                                             */
+#define SPO_GAE_PARTIAL_STRIDE 4 /* doubles per block written by spo_gae_fused               */
+
+int spo_abi_version(void);
+const char* spo_last_error(void);
+
+/* ---- a-5: VectorizedOnPolicyBuffer.finish_path -> calculate_adv_and_value_targets ->
+ *      discount_cumsum (safepo/common/buffer.py:97-140,191-201,167-188), for ALL paths of
+ *      ALL envs and for reward and cost in one launch.
+ * delta in fp32 (three separately rounded ops, gamma rounded to fp32), segmented backward
+ * scan in fp64 with discount gamma*lam formed in double, results rounded to fp32.
+ * Steps after the last seg_end of a row (unfinished path) get adv = target = 0.
+ * partials: [spo_gae_num_blocks(N,T)][4] doubles {sum adv_r, sum adv_r^2, sum adv_c, count}. */
+int spo_gae_num_blocks(int64_t num_envs, int64_t T);
+int spo_gae_fused(const float* reward, const float* cost, const float* value_r, const float* value_c,
+                  const uint8_t* seg_end, const float* boot_r, const float* boot_c,
+                  float* adv_r, float* adv_c, float* target_r, float* target_c,
+                  double* partials, int64_t num_envs, int64_t T,
+                  double gamma, double lam, double lam_c, void* stream);
+
+/* ---- a-6: statistics of VectorizedOnPolicyBuffer.get() (buffer.py:154-160).
+ * spo_adv_reduce: partials -> sums[4] = {sum adv_r, sum adv_r^2, sum adv_c, count} (fixed order,
+ * deterministic).  Multi-GPU: all-reduce(sum) sums[] between the two calls.
+ * spo_adv_apply: adv_r <- (adv_r-mean)/(std_unbiased+1e-8) if standardize_r; adv_c <- adv_c-mean_c
+ * if standardize_c; a-8 (ppo_lag.py:280-281): adv_mix = (adv_r - lambda*adv_c)/(lambda+1) when
+ * adv_mix != NULL.  stats_out (optional, 3 floats): mean_r, std_r, mean_c. */
+int spo_adv_reduce(const double* partials, int num_blocks, double* sums, void* stream);
+int spo_adv_apply(float* adv_r, float* adv_c, float* adv_mix, const double* sums, int64_t count,
+                  double lagrangian_multiplier, int standardize_r, int standardize_c,
+                  float* stats_out, void* stream);
+
+/* ---- a-1/a-3: ActorVCritic.step (safepo/common/model.py:149-170) + buffer.store
+ * (buffer.py:84-95) for step t of every env.  act = mean + exp(log_std)*eps (rsample with the
+ * noise supplied; eps == NULL -> deterministic, act = mean).  Outputs act/logp/v_r/v_c [N,...];
+ * when buf_* are non-NULL the same values (and obs) are also written to slot t of the dense
+ * buffer. */
+int spo_policy_step(const float* theta, const float* obs, const float* eps,
+                    float* act, float* logp, float* v_r, float* v_c,
+                    float* buf_obs, float* buf_act, float* buf_logp, float* buf_v_r, float* buf_v_c,
+                    int64_t num_envs, int64_t T, int64_t t, int obs_dim, int act_dim, void* stream);
+
+/* critics only (bootstrap values of ppo_lag.py:201-215): v_r, v_c for `rows` observations. */
+int spo_values(const float* theta, const float* obs, float* v_r, float* v_c,
+               int64_t rows, int obs_dim, int act_dim, void* stream);
+
+/* ---- a-4: path-boundary logic of the collect loop (ppo_lag.py:198-234) for step t:
+ * seg_end = epoch_end | terminated | truncated; boot = 0 if terminated, else value(next obs) at
+ * epoch end, overridden by value(final obs) if truncated.  Also stores reward/cost of the step,
+ * accumulates ep_ret/ep_cost/ep_len (ppo_lag.py:168-170) and appends one record
+ * {t*num_envs + env, ep_ret, ep_cost, ep_len} (4 doubles) per finished episode to `events`, in
+ * env order (the order of the reference's Python loop); events_count is a device int advanced
+ * by the single block that runs this kernel. */
+int spo_boundary_step(const float* reward, const float* cost, const float* terminated, const float* truncated,
+                      const float* v_next_r, const float* v_next_c, const float* v_final_r, const float* v_final_c,
+                      float* buf_reward, float* buf_cost, uint8_t* seg_end, float* boot_r, float* boot_c,
+                      double* ep_ret, double* ep_cost, double* ep_len, double* events, int* events_count,
+                      int events_capacity, int64_t num_envs, int64_t T, int64_t t, int epoch_end, void* stream);
+
+/* ---- a-9/a-10: one learning iteration of the PPO-Lagrangian update (ppo_lag.py:297-336):
+ * for each consecutive chunk of `batch` indices of perm[M] (last partial chunk kept): gather,
+ * 3x MLP fwd, loss_r/loss_c (MSE + 0.001*L2 if use_critic_norm), clipped surrogate, backward,
+ * joint clip_grad_norm_(max_grad_norm, eps 1e-6), 3x Adam (betas .9/.999, eps 1e-8).
+ * Persistent kernel, 3 workgroups (one per network) for the whole iteration; weights in LDS,
+ * Adam moments in registers for the launch (loaded from / stored to adam_m, adam_v).
+ * adam_step_host: number of optimiser steps already taken (bias correction continues from it).
+ * losses_out: [num_minibatches][3] = loss_r, loss_c, loss_pi per minibatch (ppo_lag.py:330-336).
+ * sync_ws: >= 64 bytes of device scratch, zeroed by this call.                                */
+typedef struct {
+  int obs_dim, act_dim, batch;
+  int use_critic_norm;          /* config.get("use_critic_norm", True)                        */
+  int use_value_coefficient;    /* total = loss_pi + 2*loss_r + loss_c                        */
+  float clip;                   /* 0.2                                                         */
+  float max_grad_norm;          /* 40.0                                                        */
+  float lr_actor, lr_critic;    /* 3e-4 * LinearLR factor, 3e-4                                */
+  float beta1, beta2, adam_eps; /* 0.9, 0.999, 1e-8                                            */
+  float l2_coef;                /* 0.001                                                       */
+} spo_ppo_cfg;
+
+int spo_ppo_lag_update_iter(float* theta, float* adam_m, float* adam_v, int64_t adam_step_host,
+                            const float* obs, const float* act, const float* logp_old,
+                            const float* target_r, const float* target_c, const float* adv,
+                            const int32_t* perm, int64_t M, const spo_ppo_cfg* cfg_host,
+                            float* losses_out, void* sync_ws, void* stream);
+
+/* Split form of the same step for data-parallel training: gradient of ONE
+ * minibatch into flat_grad[P] (+ losses[3]); the caller all-reduces flat_grad and then
+ * applies clip + Adam.  `grad_scale` multiplies the gradient (1/world_size for averaging). */
+int spo_ppo_lag_grad(const float* theta, const float* obs, const float* act, const float* logp_old,
+                     const float* target_r, const float* target_c, const float* adv,
+                     const int32_t* idx, int n_idx, int64_t mean_count, const spo_ppo_cfg* cfg_host,
+                     float* flat_grad, float* losses3, void* stream);
+int spo_clip_adam(float* theta, float* adam_m, float* adam_v, const float* flat_grad, int64_t adam_step_host,
+                  float grad_scale, const spo_ppo_cfg* cfg_host, void* stream);
+
+/* ---- a-11: full-batch actor forward + KL early-stop statistic (ppo_lag.py:277,338-345).
+ * spo_actor_mean: mean_out[M,act_dim] = actor.mean(obs).  spo_actor_kl: partial sums of
+ * KL(N(mu_old, exp(log_std_old)) || N(mu_new, exp(log_std_new))).sum(-1) over rows into
+ * kl_sum (1 double, fixed-order reduction); caller divides by the (global) row count. */
+int spo_actor_mean(const float* theta, const float* obs, float* mean_out, int64_t rows,
+                   int obs_dim, int act_dim, void* stream);
+int spo_actor_kl(const float* theta, const float* obs, const float* mean_old, const float* log_std_old,
+                 double* kl_partials, int kl_partials_capacity, double* kl_sum, int64_t rows,
+                 int obs_dim, int act_dim, void* stream);
+
+/* parameter-vector geometry helpers (host) */
+int64_t spo_param_count(int obs_dim, int act_dim);
+int64_t spo_param_offset(int obs_dim, int act_dim, int net /*0 r-critic,1 c-critic,2 actor*/);
+
+/* ---- bench/test utility (NOT a reference function): device-resident synthetic env
+ * (SURVEY.md 8d): obs'~N(0,1), reward~N(0,1), cost~Bernoulli(p_cost), terminated~Bernoulli(p_term),
+ * truncated = episode length >= trunc_len; counter-based RNG keyed by (seed, step, env). */
+int spo_synth_env_step(float* next_obs, float* final_obs, float* reward, float* cost, float* terminated,
+                       float* truncated, int* t_env, int64_t num_envs, int obs_dim, uint64_t seed,
+                       uint64_t step, float p_term, float p_cost, int trunc_len, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAFEPO_HIP_H */

@@ -1,0 +1,37 @@
+// Shared host-side helpers for libsafepo_hip.so (gfx950 only; no CUDA paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+
+namespace spo {
+
+extern thread_local char g_err[512];
+
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+inline int hip_check(hipError_t e, const char* what) {
+  if (e == hipSuccess) return 0;
+  snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+  return (int)e;
+}
+
+#define SPO_LAUNCH_CHECK(what)                                    \
+  do {                                                            \
+    int _rc = ::spo::hip_check(hipGetLastError(), what);          \
+    if (_rc) return _rc;                                          \
+  } while (0)
+
+#define SPO_REQUIRE(cond, ...)                                    \
+  do {                                                            \
+    if (!(cond)) return ::spo::fail(-1, __VA_ARGS__);             \
+  } while (0)
+
+}  // namespace spo

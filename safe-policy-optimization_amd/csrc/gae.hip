@@ -1,0 +1,335 @@
+// Fused reward + cost GAE(lambda) over the dense [num_envs, T] on-policy buffer, gfx950.
+//
+// Replaces VectorizedOnPolicyBuffer.finish_path -> calculate_adv_and_value_targets ->
+// discount_cumsum (reference safepo/common/buffer.py:97-140,191-201,167-188): a Python loop of
+// 2*L 0-dim tensor ops per path.  Here: one launch for every path of every env, reward and cost
+// together; HBM-bound (33 algorithmic bytes per (env,step): 16 B in, 1 B mask, 16 B out).
+//
+// Mapping: env-major rows; LPR lanes x VEC elements cover one row chunk, 64/LPR rows per wave,
+// 4 waves per block, >= 2 blocks per CU at N=4096,T=128 (512 blocks).  Loads are 16 B/lane
+// coalesced (VEC=4).  The recurrence c_t = delta_t + (gamma*lam)*c_{t+1}, reset at seg_end, is a
+// segmented backward scan of affine maps: in-lane sequential (reference order), cross-lane
+// Hillis-Steele over the row's lanes with wave shuffles in fp64, then an in-lane replay with the
+// incoming carry so every element's final value is produced by the reference's own
+// `delta + disc*c` step.  delta is formed in fp32 with three separately rounded ops and gamma
+// rounded to fp32 (buffer.py:198); fp contraction is disabled for this file.
+#include "common.h"
+#include "../../include/safepo_hip.h"
+
+namespace {
+
+template <int LPR>
+__device__ __forceinline__ double shfl_down_d(double x, int off) {
+  return __shfl_down(x, off, LPR);
+}
+
+struct GaeArgs {
+  const float* reward; const float* cost; const float* value_r; const float* value_c;
+  const uint8_t* seg_end; const float* boot_r; const float* boot_c;
+  float* adv_r; float* adv_c; float* target_r; float* target_c;
+  double* partials;
+  int64_t N; int64_t T;
+  float gamma32; double disc_r; double disc_c;
+};
+
+template <int VEC> struct VecT;
+template <> struct VecT<4> { using f = float4; using u = uchar4; };
+template <> struct VecT<1> { using f = float;  using u = uint8_t; };
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* p, bool ok, float (&o)[VEC]) {
+  if constexpr (VEC == 4) {
+    float4 v = ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  } else {
+    o[0] = ok ? *p : 0.f;
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* p, bool ok, const float (&o)[VEC]) {
+  if (!ok) return;
+  if constexpr (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+  else *p = o[0];
+}
+
+// One affine map c_out = A*c_in + B, composed right-to-left.
+template <int VEC, int LPR>
+__global__ __launch_bounds__(256) void gae_kernel(GaeArgs a) {
+  constexpr int ROWS_PER_WAVE = 64 / LPR;
+  constexpr int CHUNK = LPR * VEC;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int sub = lane / LPR;
+  const int sl = lane % LPR;
+  const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * ROWS_PER_WAVE + sub;
+  const bool row_ok = row < a.N;
+  const int64_t T = a.T;
+  const int64_t rbase = row * T;
+
+  double carry_c[2] = {0.0, 0.0};       // c at the first element of the chunk to the right
+  float carry_v[2] = {0.f, 0.f};        // value at that element (v_{t+1} across the chunk edge)
+  bool carry_any = false;               // a seg_end exists to the right of this chunk
+  double s_r = 0.0, s_r2 = 0.0, s_c = 0.0, s_n = 0.0;
+  const double disc[2] = {a.disc_r, a.disc_c};
+
+  const int nchunks = (int)((T + CHUNK - 1) / CHUNK);
+  for (int ch = nchunks - 1; ch >= 0; --ch) {
+    const int64_t t0 = (int64_t)ch * CHUNK + (int64_t)sl * VEC;
+    // VEC==4 requires T%4==0, so a lane's elements are all valid or all invalid.
+    const bool ok = row_ok && (t0 < T);
+    float rw[2][VEC], vv[2][VEC];
+    load_vec<VEC>(a.reward + rbase + t0, ok, rw[0]);
+    load_vec<VEC>(a.cost + rbase + t0, ok, rw[1]);
+    load_vec<VEC>(a.value_r + rbase + t0, ok, vv[0]);
+    load_vec<VEC>(a.value_c + rbase + t0, ok, vv[1]);
+    bool seg[VEC];
+    if constexpr (VEC == 4) {
+      uchar4 s4 = ok ? *reinterpret_cast<const uchar4*>(a.seg_end + rbase + t0) : make_uchar4(0, 0, 0, 0);
+      seg[0] = s4.x != 0; seg[1] = s4.y != 0; seg[2] = s4.z != 0; seg[3] = s4.w != 0;
+    } else {
+      seg[0] = ok ? (a.seg_end[rbase + t0] != 0) : false;
+    }
+    bool lane_seg = false;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) lane_seg |= seg[e];
+
+    // which lanes of my row hold a segment end (wave-wide ballot, then my row's slice)
+    const unsigned long long ball = __ballot(lane_seg);
+    unsigned long long grp = (LPR == 64) ? ball : ((ball >> (sub * LPR)) & ((1ull << LPR) - 1ull));
+    const bool any_right_lane = (sl + 1 < LPR) ? ((grp >> (sl + 1)) != 0ull) : false;
+
+    // v_{t+1} of my last element comes from the lane to the right (or the chunk carry)
+    float vnext_edge[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      float nb = __shfl_down(vv[k][0], 1, LPR);
+      vnext_edge[k] = (sl == LPR - 1) ? carry_v[k] : nb;
+    }
+
+    double delta[2][VEC];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float* boot = k == 0 ? a.boot_r : a.boot_c;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float vn = (e == VEC - 1) ? vnext_edge[k] : vv[k][e + 1];
+        if (seg[e]) vn = boot[rbase + t0 + e];                 // predicated: only at path ends
+        // deltas = rewards[:-1] + gamma * values[1:] - values[:-1]   (fp32, buffer.py:198)
+        float d = __fsub_rn(__fadd_rn(rw[k][e], __fmul_rn(a.gamma32, vn)), vv[k][e]);
+        delta[k][e] = (double)d;
+      }
+    }
+
+    // lane composite (A,B): c_first_of_lane = A*c_in + B
+    double A[2], B[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      A[k] = 1.0; B[k] = 0.0;
+      if (ok) {
+#pragma unroll
+        for (int e = VEC - 1; e >= 0; --e) {
+          if (seg[e]) { A[k] = 0.0; B[k] = delta[k][e]; }
+          else { B[k] = __dadd_rn(delta[k][e], __dmul_rn(disc[k], B[k])); A[k] = __dmul_rn(disc[k], A[k]); }
+        }
+      }
+    }
+    // inclusive suffix scan over the row's lanes
+#pragma unroll
+    for (int off = 1; off < LPR; off <<= 1) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        double An = shfl_down_d<LPR>(A[k], off);
+        double Bn = shfl_down_d<LPR>(B[k], off);
+        if (sl + off < LPR) {
+          B[k] = __dadd_rn(B[k], __dmul_rn(A[k], Bn));
+          A[k] = __dmul_rn(A[k], An);
+        }
+      }
+    }
+    // c entering my lane from the right = c_first(sl+1) evaluated with the chunk carry
+    double cin[2], cfirst[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      cfirst[k] = __dadd_rn(__dmul_rn(A[k], carry_c[k]), B[k]);
+      double nb = shfl_down_d<LPR>(cfirst[k], 1);
+      cin[k] = (sl == LPR - 1) ? carry_c[k] : nb;
+    }
+
+    // replay in reference order and emit
+    float oadv[2][VEC], otgt[2][VEC];
+    bool fin_right = any_right_lane || carry_any;            // a path end exists right of my lane
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      double c = cin[k];
+      bool fin = fin_right;
+#pragma unroll
+      for (int e = VEC - 1; e >= 0; --e) {
+        c = seg[e] ? delta[k][e] : __dadd_rn(delta[k][e], __dmul_rn(disc[k], c));   // buffer.py:186
+        fin |= seg[e];
+        float adv = fin ? (float)c : 0.f;
+        float tgt = fin ? (float)__dadd_rn(c, (double)vv[k][e]) : 0.f;              // buffer.py:200
+        oadv[k][e] = adv; otgt[k][e] = tgt;
+      }
+    }
+    store_vec<VEC>(a.adv_r + rbase + t0, ok, oadv[0]);
+    store_vec<VEC>(a.adv_c + rbase + t0, ok, oadv[1]);
+    store_vec<VEC>(a.target_r + rbase + t0, ok, otgt[0]);
+    store_vec<VEC>(a.target_c + rbase + t0, ok, otgt[1]);
+    if (ok) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        double x = (double)oadv[0][e];
+        s_r += x; s_r2 += x * x; s_c += (double)oadv[1][e]; s_n += 1.0;
+      }
+    }
+    // carries for the chunk to the left: values at the first lane of my row group
+    const int src = sub * LPR;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      carry_c[k] = __shfl(cfirst[k], src);
+      carry_v[k] = __shfl(vv[k][0], src);
+    }
+    carry_any = carry_any || (grp != 0ull);
+  }
+
+  // block reduction in a fixed order -> partials[block][4]
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    s_r += __shfl_xor(s_r, off); s_r2 += __shfl_xor(s_r2, off);
+    s_c += __shfl_xor(s_c, off); s_n += __shfl_xor(s_n, off);
+  }
+  __shared__ double red[4][4];
+  if (lane == 0) { red[wave][0] = s_r; red[wave][1] = s_r2; red[wave][2] = s_c; red[wave][3] = s_n; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    a.partials[(int64_t)blockIdx.x * SPO_GAE_PARTIAL_STRIDE + threadIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void adv_reduce_kernel(const double* partials, int nb, double* sums) {
+  // fixed-order tree: thread i sums partials i, i+256, ...; then a shared-memory tree.
+  __shared__ double sh[4][256];
+  double acc[4] = {0, 0, 0, 0};
+  for (int b = threadIdx.x; b < nb; b += 256)
+    for (int k = 0; k < 4; ++k) acc[k] += partials[(int64_t)b * SPO_GAE_PARTIAL_STRIDE + k];
+  for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] = acc[k];
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) {
+    if ((int)threadIdx.x < s)
+      for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) sums[threadIdx.x] = sh[threadIdx.x][0];
+}
+
+__global__ __launch_bounds__(256) void adv_apply_kernel(float* adv_r, float* adv_c, float* adv_mix, const double* sums,
+                                                       int64_t count, float lam32, float lam_p1_32, int std_r,
+                                                       int std_c, float* stats_out) {
+  // buffer.py:154-160: mean, UNBIASED std (+1e-8), adv_c only centred.  Statistics in fp64 from
+  // exact sums of the fp32 values, rounded once to fp32 (torch reduces in fp32: <= 1e-6 rel apart).
+  const double n = sums[3];
+  const double mean_r = sums[0] / n;
+  double var = (sums[1] - sums[0] * sums[0] / n) / (n - 1.0);
+  if (var < 0) var = 0;
+  const float mr = (float)mean_r, sd = (float)sqrt(var), mc = (float)(sums[2] / n);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && stats_out) { stats_out[0] = mr; stats_out[1] = sd; stats_out[2] = mc; }
+  const float den = __fadd_rn(sd, 1e-8f);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < count; i += stride) {
+    float r[4], c[4], m[4];
+    const int nv = (count - i) >= 4 ? 4 : (int)(count - i);
+    if (nv == 4) {
+      float4 a = *reinterpret_cast<float4*>(adv_r + i), b = *reinterpret_cast<float4*>(adv_c + i);
+      r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; c[0] = b.x; c[1] = b.y; c[2] = b.z; c[3] = b.w;
+    } else {
+      for (int e = 0; e < 4; ++e) { r[e] = e < nv ? adv_r[i + e] : 0.f; c[e] = e < nv ? adv_c[i + e] : 0.f; }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (std_r) r[e] = __fdiv_rn(__fsub_rn(r[e], mr), den);
+      if (std_c) c[e] = __fsub_rn(c[e], mc);
+      // ppo_lag.py:280-281: advantage = adv_r - lambda*adv_c ; advantage /= (lambda + 1)
+      m[e] = __fdiv_rn(__fsub_rn(r[e], __fmul_rn(lam32, c[e])), lam_p1_32);
+    }
+    if (nv == 4) {
+      *reinterpret_cast<float4*>(adv_r + i) = make_float4(r[0], r[1], r[2], r[3]);
+      *reinterpret_cast<float4*>(adv_c + i) = make_float4(c[0], c[1], c[2], c[3]);
+      if (adv_mix) *reinterpret_cast<float4*>(adv_mix + i) = make_float4(m[0], m[1], m[2], m[3]);
+    } else {
+      for (int e = 0; e < nv; ++e) { adv_r[i + e] = r[e]; adv_c[i + e] = c[e]; if (adv_mix) adv_mix[i + e] = m[e]; }
+    }
+  }
+}
+
+struct GaeGeom { int vec; int lpr; int rows_per_block; };
+inline GaeGeom gae_geom(int64_t T) {
+  GaeGeom g;
+  g.vec = (T % 4 == 0) ? 4 : 1;
+  int64_t need = (T + g.vec - 1) / g.vec;
+  int lpr = 1;
+  while (lpr < need && lpr < 64) lpr <<= 1;
+  g.lpr = lpr;
+  g.rows_per_block = 4 * (64 / lpr);
+  return g;
+}
+
+template <int VEC>
+int launch_gae(const GaeGeom& g, const GaeArgs& a, int blocks, hipStream_t st) {
+  switch (g.lpr) {
+#define SPO_CASE(L) case L: hipLaunchKernelGGL((gae_kernel<VEC, L>), dim3(blocks), dim3(256), 0, st, a); break;
+    SPO_CASE(1) SPO_CASE(2) SPO_CASE(4) SPO_CASE(8) SPO_CASE(16) SPO_CASE(32) SPO_CASE(64)
+#undef SPO_CASE
+    default: return spo::fail(-1, "gae: bad lanes-per-row %d", g.lpr);
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int spo_gae_num_blocks(int64_t num_envs, int64_t T) {
+  if (num_envs <= 0 || T <= 0) return 0;
+  GaeGeom g = gae_geom(T);
+  return (int)((num_envs + g.rows_per_block - 1) / g.rows_per_block);
+}
+
+extern "C" int spo_gae_fused(const float* reward, const float* cost, const float* value_r, const float* value_c,
+                             const uint8_t* seg_end, const float* boot_r, const float* boot_c, float* adv_r,
+                             float* adv_c, float* target_r, float* target_c, double* partials, int64_t num_envs,
+                             int64_t T, double gamma, double lam, double lam_c, void* stream) {
+  SPO_REQUIRE(num_envs >= 0 && T >= 0, "gae: negative size");
+  if (num_envs == 0 || T == 0) return 0;
+  SPO_REQUIRE(reward && cost && value_r && value_c && seg_end && boot_r && boot_c && adv_r && adv_c && target_r &&
+                  target_c && partials, "gae: null pointer");
+  GaeGeom g = gae_geom(T);
+  GaeArgs a{reward, cost, value_r, value_c, seg_end, boot_r, boot_c, adv_r, adv_c, target_r, target_c, partials,
+            num_envs, T, (float)gamma, gamma * lam, gamma * lam_c};
+  const int blocks = spo_gae_num_blocks(num_envs, T);
+  hipStream_t st = (hipStream_t)stream;
+  int rc = g.vec == 4 ? launch_gae<4>(g, a, blocks, st) : launch_gae<1>(g, a, blocks, st);
+  if (rc) return rc;
+  SPO_LAUNCH_CHECK("spo_gae_fused");
+  return 0;
+}
+
+extern "C" int spo_adv_reduce(const double* partials, int num_blocks, double* sums, void* stream) {
+  SPO_REQUIRE(partials && sums && num_blocks > 0, "adv_reduce: bad args");
+  hipLaunchKernelGGL(adv_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, num_blocks, sums);
+  SPO_LAUNCH_CHECK("spo_adv_reduce");
+  return 0;
+}
+
+extern "C" int spo_adv_apply(float* adv_r, float* adv_c, float* adv_mix, const double* sums, int64_t count,
+                             double lagrangian_multiplier, int standardize_r, int standardize_c, float* stats_out,
+                             void* stream) {
+  SPO_REQUIRE(adv_r && adv_c && sums && count > 0, "adv_apply: bad args");
+  int64_t blocks = (count / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  const float lam32 = (float)lagrangian_multiplier;
+  const float lam_p1 = (float)(lagrangian_multiplier + 1.0);
+  hipLaunchKernelGGL(adv_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, adv_r, adv_c,
+                     adv_mix, sums, count, lam32, lam_p1, standardize_r, standardize_c, stats_out);
+  SPO_LAUNCH_CHECK("spo_adv_apply");
+  return 0;
+}

@@ -1,0 +1,161 @@
+// MFMA building blocks for SafePO's tanh MLPs (hidden 64x64) on gfx950.
+//
+// The reference's actor / critics are `Linear-Tanh-Linear-Tanh-Linear` with hidden [64,64]
+// (safepo/common/model.py:30-48, ppo_lag.py:45-52).  A minibatch is 64 rows, so each layer is a
+// 64x64x64 fp32 GEMM: far too small for a tiled-GEMM launch, but a single CU running a chain
+// of 327 680 dependent optimiser steps per epoch IS bound by its fp32 matrix rate.  We therefore
+// use the exact-fp32 MFMA `v_mfma_f32_16x16x4_f32` (bitwise an fmaf chain; no TF32 on gfx950)
+// with a "transposed chaining" layout that needs NO data movement between layers:
+//
+//   C[row = output feature][col = batch]  = sum_k W[feature][k] * X[batch][k]
+//
+//   A operand (weights, from LDS):   lane l supplies W[16*mt + (l&15)][k(s, l>>4)]
+//   B operand (activations, regs):   lane l supplies X[batch (l&15)][k(s, l>>4)]
+//   C/D (accumulator):               lane l holds rows 4*(l>>4)+reg, col (l&15)
+//
+// With the reduction index enumerated as k = 16*nt + 4*(l>>4) + reg, the C registers of layer
+// n ARE the B operand registers of layer n+1 (tile nt, step reg), and the matching A operand is
+// one 16-byte LDS read `W[row][16*nt + 4*(l>>4) .. +3]`.  fp32 sums are re-associated relative
+// to a BLAS dot product (rounding-level differences only; parity tolerance is 1e-5 rel).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace spo {
+
+using f4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int HID = 64;        // hidden width
+constexpr int LDH = HID + 4;   // LDS row stride (floats) of 64-wide weight rows (16 B aligned, bank-rotated)
+constexpr int OUTP = 16;       // output layer padded to one 16-row tile
+
+__device__ __forceinline__ f4 mfma4(float a, float b, f4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// Geometry of one network inside the flat parameter vector (nn.Linear row-major [out,in]).
+struct NetGeom {
+  int D;        // obs_dim
+  int OUT;      // 1 (critic) or act_dim (actor)
+  int off;      // offset of W1 in theta (floats); actor: log_std sits at off - OUT
+  __host__ __device__ int w1() const { return off; }
+  __host__ __device__ int b1() const { return off + HID * D; }
+  __host__ __device__ int w2() const { return b1() + HID; }
+  __host__ __device__ int b2() const { return w2() + HID * HID; }
+  __host__ __device__ int w3() const { return b2() + HID; }
+  __host__ __device__ int b3() const { return w3() + OUT * HID; }
+  __host__ __device__ int end() const { return b3() + OUT; }
+};
+
+__host__ __device__ inline int critic_size(int D) { return HID * D + HID + HID * HID + HID + HID + 1; }
+__host__ __device__ inline int actor_size(int D, int A) { return A + HID * D + HID + HID * HID + HID + A * HID + A; }
+__host__ __device__ inline NetGeom net_geom(int D, int A, int net) {
+  NetGeom g;
+  g.D = D;
+  if (net == 0) { g.OUT = 1; g.off = 0; }
+  else if (net == 1) { g.OUT = 1; g.off = critic_size(D); }
+  else { g.OUT = A; g.off = 2 * critic_size(D) + A; }
+  return g;
+}
+
+// LDS image of one network (floats).  KIN = obs_dim padded to a multiple of 16.
+template <int KIN>
+struct NetLds {
+  static constexpr int LD1 = KIN + 4;
+  static constexpr int W1 = 0;
+  static constexpr int B1 = W1 + HID * LD1;
+  static constexpr int W2 = B1 + HID;
+  static constexpr int B2 = W2 + HID * LDH;
+  static constexpr int W3 = B2 + HID;
+  static constexpr int B3 = W3 + OUTP * LDH;
+  static constexpr int SIZE = B3 + OUTP;       // multiple of 4 floats
+};
+
+// Cooperative copy of one network from the flat vector into its padded LDS image (pads zeroed).
+template <int KIN>
+__device__ inline void stage_net(const float* __restrict__ theta, const NetGeom g, float* lds, int tid, int nthr) {
+  using L = NetLds<KIN>;
+  for (int i = tid; i < L::SIZE; i += nthr) lds[i] = 0.f;
+  __syncthreads();
+  const int D = g.D;
+  for (int i = tid; i < HID * D; i += nthr) lds[L::W1 + (i / D) * L::LD1 + (i % D)] = theta[g.w1() + i];
+  for (int i = tid; i < HID * HID; i += nthr) lds[L::W2 + (i / HID) * LDH + (i % HID)] = theta[g.w2() + i];
+  for (int i = tid; i < g.OUT * HID; i += nthr) lds[L::W3 + (i / HID) * LDH + (i % HID)] = theta[g.w3() + i];
+  for (int i = tid; i < HID; i += nthr) { lds[L::B1 + i] = theta[g.b1() + i]; lds[L::B2 + i] = theta[g.b2() + i]; }
+  for (int i = tid; i < g.OUT; i += nthr) lds[L::B3 + i] = theta[g.b3() + i];
+}
+
+// B-operand tiles of one observation row: x[nt][reg] = obs[16*nt + 4*q + reg] (0 beyond D).
+template <int KIN>
+__device__ __forceinline__ void load_obs_tiles(const float* __restrict__ row, int D, int q, f4 (&x)[KIN / 16]) {
+#pragma unroll
+  for (int nt = 0; nt < KIN / 16; ++nt) {
+    const int c = 16 * nt + 4 * q;
+    if ((D & 3) == 0) {
+      x[nt] = (c < D) ? *reinterpret_cast<const f4*>(row + c) : f4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      f4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (c + e < D) ? row[c + e] : 0.f;
+      x[nt] = v;
+    }
+  }
+}
+
+// Hidden layer: out[mt] (rows 16mt+4q+reg, col batch) = tanh?(W in + b).
+template <int NT_IN, bool TANH>
+__device__ __forceinline__ void layer_hidden(const float* Wl, int ld, const float* bl, const f4 (&in)[NT_IN],
+                                             f4 (&out)[HID / 16], int j, int q) {
+#pragma unroll
+  for (int mt = 0; mt < HID / 16; ++mt) {
+    f4 acc = *reinterpret_cast<const f4*>(bl + 16 * mt + 4 * q);
+#pragma unroll
+    for (int nt = 0; nt < NT_IN; ++nt) {
+      const f4 a = *reinterpret_cast<const f4*>(Wl + (16 * mt + j) * ld + 16 * nt + 4 * q);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = mfma4(a[r], in[nt][r], acc);
+    }
+    if (TANH) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = tanhf(acc[r]);
+    }
+    out[mt] = acc;
+  }
+}
+
+// Output layer (one padded 16-row tile): rows 4q+reg = output unit.
+__device__ __forceinline__ f4 layer_out(const float* Wl, const float* bl, const f4 (&in)[HID / 16], int j, int q) {
+  f4 acc = *reinterpret_cast<const f4*>(bl + 4 * q);
+#pragma unroll
+  for (int nt = 0; nt < HID / 16; ++nt) {
+    const f4 a = *reinterpret_cast<const f4*>(Wl + j * LDH + 16 * nt + 4 * q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = mfma4(a[r], in[nt][r], acc);
+  }
+  return acc;
+}
+
+// Full forward of one network for the 16 batch columns of a wave.
+template <int KIN>
+__device__ __forceinline__ f4 net_forward(const float* lds_net, const f4 (&x)[KIN / 16], f4 (&h1)[4], f4 (&h2)[4],
+                                          int j, int q) {
+  using L = NetLds<KIN>;
+  layer_hidden<KIN / 16, true>(lds_net + L::W1, L::LD1, lds_net + L::B1, x, h1, j, q);
+  layer_hidden<4, true>(lds_net + L::W2, LDH, lds_net + L::B2, h1, h2, j, q);
+  return layer_out(lds_net + L::W3, lds_net + L::B3, h2, j, q);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;   // math.log(math.sqrt(2*math.pi))
+
+}  // namespace spo

@@ -1,0 +1,423 @@
+// Collect-side kernels: ActorVCritic.step + buffer.store, bootstrap values, path-boundary logic,
+// full-batch actor forward and KL early-stop statistic, synthetic device env.  gfx950 only.
+//
+// References (relative to /root/reference):
+//   safepo/common/model.py:149-170   ActorVCritic.step          -> policy_step_kernel
+//   safepo/common/buffer.py:84-95    VectorizedOnPolicyBuffer.store (fused into the same kernel)
+//   safepo/single_agent/ppo_lag.py:198-234  boundary / bootstrap / episode stats -> boundary_kernel
+//   safepo/single_agent/ppo_lag.py:277,338-345  old/new distribution + KL      -> actor_kl_kernel
+#include "common.h"
+#include "mlp_mfma.h"
+#include "../../include/safepo_hip.h"
+
+namespace {
+using namespace spo;
+
+struct StepArgs {
+  const float* theta; const float* obs; const float* eps;
+  float* act; float* logp; float* v_r; float* v_c;
+  float* buf_obs; float* buf_act; float* buf_logp; float* buf_v_r; float* buf_v_c;
+  int64_t N; int64_t T; int64_t t; int D; int A;
+};
+
+// 256 threads = 4 waves; wave w owns rows [64*block + 16w, +16).  Networks are staged through one
+// LDS image in turn (critic_r, critic_c, actor) so obs_dim up to 128 fits.
+template <int KIN, bool WITH_ACTOR>
+__global__ __launch_bounds__(256) void policy_step_kernel(StepArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[NetLds<KIN>::SIZE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+  const int D = a.D, A = a.A;
+  const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * 16 + j;
+  const bool valid = row < a.N;
+  const int64_t rrow = valid ? row : a.N - 1;
+  f4 x[KIN / 16];
+  load_obs_tiles<KIN>(a.obs + rrow * D, D, q, x);
+  float vout[2] = {0.f, 0.f};
+  f4 mu = {0.f, 0.f, 0.f, 0.f};
+  constexpr int NNET = WITH_ACTOR ? 3 : 2;
+  for (int net = 0; net < NNET; ++net) {
+    if (net > 0) __syncthreads();
+    stage_net<KIN>(a.theta, net_geom(D, A, net), lds, tid, 256);
+    __syncthreads();
+    f4 h1[4], h2[4];
+    f4 o = net_forward<KIN>(lds, x, h1, h2, j, q);
+    if (net < 2) vout[net] = o[0]; else mu = o;
+  }
+  const int64_t slot = rrow * a.T + a.t;
+  if (valid && q == 0) {
+    a.v_r[row] = vout[0];
+    a.v_c[row] = vout[1];
+    if (a.buf_v_r) { a.buf_v_r[slot] = vout[0]; a.buf_v_c[slot] = vout[1]; }
+  }
+  if (a.buf_obs && valid) {
+#pragma unroll
+    for (int nt = 0; nt < KIN / 16; ++nt) {
+      const int c = 16 * nt + 4 * q;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c + e < D) a.buf_obs[slot * D + c + e] = x[nt][e];
+    }
+  }
+  if constexpr (WITH_ACTOR) {
+    const int ls_off = 2 * critic_size(D);
+    float lp = 0.f;
+    float av[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ai = 4 * q + r;
+      if (ai < A) {
+        const float sd = expf(a.theta[ls_off + ai]);            // std = exp(log_std)   model.py:80
+        float ac = mu[r];
+        if (a.eps) ac = mu[r] + a.eps[rrow * A + ai] * sd;       // rsample: loc + eps*scale
+        const float diff = ac - mu[r];
+        const float var = sd * sd;
+        lp += -(diff * diff) / (2.f * var) - logf(sd) - LOG_SQRT_2PI;   // Normal.log_prob
+        av[r] = ac;
+      }
+    }
+    lp += __shfl_xor(lp, 16);
+    lp += __shfl_xor(lp, 32);                                    // .sum(axis=-1)   model.py:167
+    if (valid) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ai = 4 * q + r;
+        if (ai < A) {
+          a.act[row * A + ai] = av[r];
+          if (a.buf_act) a.buf_act[slot * A + ai] = av[r];
+        }
+      }
+      if (q == 0) {
+        a.logp[row] = lp;
+        if (a.buf_logp) a.buf_logp[slot] = lp;
+      }
+    }
+  }
+}
+
+struct KlArgs {
+  const float* theta; const float* obs; const float* mean_old; const float* log_std_old;
+  float* mean_out; double* partials; int64_t rows; int D; int A;
+};
+
+// MODE 0: write means; MODE 1: accumulate KL(old || new).sum(-1) over rows.
+template <int KIN, int MODE>
+__global__ __launch_bounds__(256) void actor_full_kernel(KlArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[NetLds<KIN>::SIZE];
+  __shared__ double red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+  const int D = a.D, A = a.A;
+  stage_net<KIN>(a.theta, net_geom(D, A, 2), lds, tid, 256);
+  __syncthreads();
+  const int ls_off = 2 * critic_size(D);
+  float sd_new[4], sd_old[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ai = 4 * q + r;
+    sd_new[r] = ai < A ? expf(a.theta[ls_off + ai]) : 1.f;
+    sd_old[r] = (MODE == 1 && ai < A) ? expf(a.log_std_old[ai]) : 1.f;
+  }
+  double acc = 0.0;
+  const int64_t ntiles = (a.rows + 15) / 16;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t row = tile * 16 + j;
+    const bool valid = row < a.rows;
+    const int64_t rrow = valid ? row : a.rows - 1;
+    f4 x[KIN / 16];
+    load_obs_tiles<KIN>(a.obs + rrow * D, D, q, x);
+    f4 h1[4], h2[4];
+    const f4 mu = net_forward<KIN>(lds, x, h1, h2, j, q);
+    if (MODE == 0) {
+      if (valid) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (4 * q + r < A) a.mean_out[row * A + 4 * q + r] = mu[r];
+      }
+    } else {
+      float kl = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ai = 4 * q + r;
+        if (ai < A) {
+          // torch.distributions.kl._kl_normal_normal(p=old, q=new)
+          const float ratio = sd_old[r] / sd_new[r];
+          const float var_ratio = ratio * ratio;
+          const float dm = (a.mean_old[rrow * A + ai] - mu[r]) / sd_new[r];
+          const float t1 = dm * dm;
+          kl += 0.5f * (var_ratio + t1 - 1.f - logf(var_ratio));
+        }
+      }
+      if (valid) acc += (double)kl;
+    }
+  }
+  if (MODE == 1) {
+    acc = wave_sum_d(acc);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (tid == 0) a.partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  }
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* partials, int n, double* out) {
+  __shared__ double sh[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+struct BoundaryArgs {
+  const float* reward; const float* cost; const float* terminated; const float* truncated;
+  const float* v_next_r; const float* v_next_c; const float* v_final_r; const float* v_final_c;
+  float* buf_reward; float* buf_cost; uint8_t* seg_end; float* boot_r; float* boot_c;
+  double* ep_ret; double* ep_cost; double* ep_len; double* events; int* events_count; int events_capacity;
+  int64_t N; int64_t T; int64_t t; int epoch_end;
+};
+
+// ONE block: finished episodes are appended in env order, the order of the reference's Python
+// loop `for idx, (done, time_out) in enumerate(zip(terminated, truncated))` (ppo_lag.py:199).
+__global__ __launch_bounds__(256) void boundary_kernel(BoundaryArgs a) {
+  __shared__ int wave_cnt[4];
+  __shared__ int base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) base = *a.events_count;
+  __syncthreads();
+  for (int64_t c0 = 0; c0 < a.N; c0 += 256) {
+    const int64_t i = c0 + tid;
+    const bool in = i < a.N;
+    bool fin = false;
+    double ret = 0, cst = 0, len = 0;
+    if (in) {
+      const float rw = a.reward[i], cs = a.cost[i];
+      const bool done = a.terminated[i] != 0.f, tout = a.truncated[i] != 0.f;
+      ret = a.ep_ret[i] + (double)rw;           // ep_ret += reward  (float64 accumulators, ppo_lag.py:168-170)
+      cst = a.ep_cost[i] + (double)cs;
+      len = a.ep_len[i] + 1.0;
+      const bool boundary = a.epoch_end || done || tout;
+      float br = 0.f, bc = 0.f;
+      if (boundary && !done) {
+        if (a.epoch_end) { br = a.v_next_r[i]; bc = a.v_next_c[i]; }
+        if (tout) { br = a.v_final_r[i]; bc = a.v_final_c[i]; }     // final_observation wins (ppo_lag.py:209-213)
+      }
+      const int64_t slot = i * a.T + a.t;
+      a.buf_reward[slot] = rw;
+      a.buf_cost[slot] = cs;
+      a.seg_end[slot] = boundary ? 1 : 0;
+      a.boot_r[slot] = br;
+      a.boot_c[slot] = bc;
+      fin = done || tout;
+      a.ep_ret[i] = fin ? 0.0 : ret;
+      a.ep_cost[i] = fin ? 0.0 : cst;
+      a.ep_len[i] = fin ? 0.0 : len;
+    }
+    const unsigned long long ball = __ballot(fin);
+    const int before = __popcll(ball & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wave] = __popcll(ball);
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wave_cnt[w];
+    if (fin) {
+      const int pos = base + woff + before;
+      if (pos < a.events_capacity) {
+        double* e = a.events + (int64_t)pos * 4;
+        e[0] = (double)(a.t * a.N + i);
+        e[1] = ret; e[2] = cst; e[3] = len;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  if (tid == 0) *a.events_count = base;
+}
+
+// ---------------------------------------------------------------- synthetic env (bench/test utility)
+__device__ __forceinline__ void philox4x32(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ void normal4(uint64_t seed, uint32_t a, uint32_t b, uint32_t c, uint32_t d, float (&o)[4]) {
+  uint32_t ctr[4] = {a, b, c, d};
+  philox4x32(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const float r0 = sqrtf(-2.f * logf(u01(ctr[0]))), r1 = sqrtf(-2.f * logf(u01(ctr[2])));
+  const float t0 = 6.283185307179586f * u01(ctr[1]), t1 = 6.283185307179586f * u01(ctr[3]);
+  o[0] = r0 * cosf(t0); o[1] = r0 * sinf(t0); o[2] = r1 * cosf(t1); o[3] = r1 * sinf(t1);
+}
+
+__global__ void synth_flags_kernel(float* reward, float* cost, float* terminated, float* truncated, int* t_env,
+                                   int64_t N, uint64_t seed, uint64_t step, float p_term, float p_cost, int trunc_len) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  uint32_t ctr[4] = {(uint32_t)i, (uint32_t)step, 0x5eedf1a6u, (uint32_t)(step >> 32)};
+  philox4x32(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+  float nrm[4];
+  normal4(seed, (uint32_t)i, (uint32_t)step, 0x72657761u, (uint32_t)(step >> 32), nrm);
+  const int te = t_env[i] + 1;
+  const bool term = u01(ctr[0]) < p_term;
+  const bool trunc = (te >= trunc_len) && !term;
+  reward[i] = nrm[0];
+  cost[i] = u01(ctr[1]) < p_cost ? 1.f : 0.f;
+  terminated[i] = term ? 1.f : 0.f;
+  truncated[i] = trunc ? 1.f : 0.f;
+  t_env[i] = (term || trunc) ? 0 : te;
+}
+
+__global__ void synth_obs_kernel(float* next_obs, float* final_obs, const float* terminated, const float* truncated,
+                                 int64_t N, int D, uint64_t seed, uint64_t step) {
+  const int chunks = (D + 3) / 4;
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= N * chunks) return;
+  const int64_t i = g / chunks;
+  const int c = (int)(g % chunks) * 4;
+  float o[4], f[4];
+  normal4(seed, (uint32_t)i, (uint32_t)step, 0x6f627330u + (uint32_t)c, (uint32_t)(step >> 32), o);
+  const bool fin = terminated[i] != 0.f || truncated[i] != 0.f;
+  if (fin) normal4(seed, (uint32_t)i, (uint32_t)step, 0x66696e30u + (uint32_t)c, (uint32_t)(step >> 32), f);
+  for (int e = 0; e < 4 && c + e < D; ++e) {
+    next_obs[i * D + c + e] = o[e];
+    final_obs[i * D + c + e] = fin ? f[e] : 0.f;
+  }
+}
+
+int pick_kin(int D) { return D <= 16 ? 16 : D <= 32 ? 32 : D <= 64 ? 64 : 128; }
+
+template <bool WITH_ACTOR>
+int launch_step(const StepArgs& a, hipStream_t st) {
+  const unsigned blocks = (unsigned)((a.N + 63) / 64);
+  switch (pick_kin(a.D)) {
+    case 16: hipLaunchKernelGGL((policy_step_kernel<16, WITH_ACTOR>), dim3(blocks), dim3(256), 0, st, a); break;
+    case 32: hipLaunchKernelGGL((policy_step_kernel<32, WITH_ACTOR>), dim3(blocks), dim3(256), 0, st, a); break;
+    case 64: hipLaunchKernelGGL((policy_step_kernel<64, WITH_ACTOR>), dim3(blocks), dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((policy_step_kernel<128, WITH_ACTOR>), dim3(blocks), dim3(256), 0, st, a); break;
+  }
+  return 0;
+}
+
+template <int MODE>
+int launch_full(const KlArgs& a, unsigned blocks, hipStream_t st) {
+  switch (pick_kin(a.D)) {
+    case 16: hipLaunchKernelGGL((actor_full_kernel<16, MODE>), dim3(blocks), dim3(256), 0, st, a); break;
+    case 32: hipLaunchKernelGGL((actor_full_kernel<32, MODE>), dim3(blocks), dim3(256), 0, st, a); break;
+    case 64: hipLaunchKernelGGL((actor_full_kernel<64, MODE>), dim3(blocks), dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((actor_full_kernel<128, MODE>), dim3(blocks), dim3(256), 0, st, a); break;
+  }
+  return 0;
+}
+
+int check_dims(int D, int A) {
+  if (D < 1 || D > SPO_MAX_OBS) return spo::fail(-2, "obs_dim %d outside [1,%d]", D, SPO_MAX_OBS);
+  if (A < 1 || A > SPO_MAX_ACT) return spo::fail(-2, "act_dim %d outside [1,%d]", A, SPO_MAX_ACT);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t spo_param_count(int obs_dim, int act_dim) {
+  return 2 * (int64_t)spo::critic_size(obs_dim) + spo::actor_size(obs_dim, act_dim);
+}
+extern "C" int64_t spo_param_offset(int obs_dim, int act_dim, int net) {
+  if (net == 0) return 0;
+  if (net == 1) return spo::critic_size(obs_dim);
+  return 2 * (int64_t)spo::critic_size(obs_dim);
+}
+
+extern "C" int spo_policy_step(const float* theta, const float* obs, const float* eps, float* act, float* logp,
+                               float* v_r, float* v_c, float* buf_obs, float* buf_act, float* buf_logp,
+                               float* buf_v_r, float* buf_v_c, int64_t num_envs, int64_t T, int64_t t, int obs_dim,
+                               int act_dim, void* stream) {
+  if (int rc = check_dims(obs_dim, act_dim)) return rc;
+  SPO_REQUIRE(theta && obs && act && logp && v_r && v_c, "policy_step: null pointer");
+  SPO_REQUIRE(num_envs > 0, "policy_step: num_envs must be > 0");
+  const bool buf = buf_obs || buf_act || buf_logp || buf_v_r || buf_v_c;
+  if (buf) {
+    SPO_REQUIRE(buf_obs && buf_act && buf_logp && buf_v_r && buf_v_c, "policy_step: all buffer slots or none");
+    SPO_REQUIRE(t >= 0 && t < T, "Buffer overflow");          /* reference assert, buffer.py:92 */
+  }
+  StepArgs a{theta, obs, eps, act, logp, v_r, v_c, buf_obs, buf_act, buf_logp, buf_v_r, buf_v_c,
+             num_envs, T > 0 ? T : 1, buf ? t : 0, obs_dim, act_dim};
+  launch_step<true>(a, (hipStream_t)stream);
+  SPO_LAUNCH_CHECK("spo_policy_step");
+  return 0;
+}
+
+extern "C" int spo_values(const float* theta, const float* obs, float* v_r, float* v_c, int64_t rows, int obs_dim,
+                          int act_dim, void* stream) {
+  if (int rc = check_dims(obs_dim, act_dim)) return rc;
+  SPO_REQUIRE(theta && obs && v_r && v_c && rows > 0, "values: bad args");
+  StepArgs a{theta, obs, nullptr, nullptr, nullptr, v_r, v_c, nullptr, nullptr, nullptr, nullptr, nullptr,
+             rows, 1, 0, obs_dim, act_dim};
+  launch_step<false>(a, (hipStream_t)stream);
+  SPO_LAUNCH_CHECK("spo_values");
+  return 0;
+}
+
+extern "C" int spo_boundary_step(const float* reward, const float* cost, const float* terminated,
+                                 const float* truncated, const float* v_next_r, const float* v_next_c,
+                                 const float* v_final_r, const float* v_final_c, float* buf_reward, float* buf_cost,
+                                 uint8_t* seg_end, float* boot_r, float* boot_c, double* ep_ret, double* ep_cost,
+                                 double* ep_len, double* events, int* events_count, int events_capacity,
+                                 int64_t num_envs, int64_t T, int64_t t, int epoch_end, void* stream) {
+  SPO_REQUIRE(reward && cost && terminated && truncated && buf_reward && buf_cost && seg_end && boot_r && boot_c &&
+                  ep_ret && ep_cost && ep_len && events && events_count, "boundary: null pointer");
+  SPO_REQUIRE(v_next_r && v_next_c && v_final_r && v_final_c, "boundary: null value pointer");
+  SPO_REQUIRE(t >= 0 && t < T, "Buffer overflow");
+  BoundaryArgs a{reward, cost, terminated, truncated, v_next_r, v_next_c, v_final_r, v_final_c, buf_reward, buf_cost,
+                 seg_end, boot_r, boot_c, ep_ret, ep_cost, ep_len, events, events_count,
+                 events_capacity, num_envs, T, t, epoch_end};
+  hipLaunchKernelGGL(boundary_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+  SPO_LAUNCH_CHECK("spo_boundary_step");
+  return 0;
+}
+
+extern "C" int spo_actor_mean(const float* theta, const float* obs, float* mean_out, int64_t rows, int obs_dim,
+                              int act_dim, void* stream) {
+  if (int rc = check_dims(obs_dim, act_dim)) return rc;
+  SPO_REQUIRE(theta && obs && mean_out && rows > 0, "actor_mean: bad args");
+  KlArgs a{theta, obs, nullptr, nullptr, mean_out, nullptr, rows, obs_dim, act_dim};
+  int64_t blocks = (rows + 63) / 64;
+  if (blocks > 1024) blocks = 1024;
+  launch_full<0>(a, (unsigned)blocks, (hipStream_t)stream);
+  SPO_LAUNCH_CHECK("spo_actor_mean");
+  return 0;
+}
+
+extern "C" int spo_actor_kl(const float* theta, const float* obs, const float* mean_old, const float* log_std_old,
+                            double* kl_partials, int kl_partials_capacity, double* kl_sum, int64_t rows, int obs_dim,
+                            int act_dim, void* stream) {
+  if (int rc = check_dims(obs_dim, act_dim)) return rc;
+  SPO_REQUIRE(theta && obs && mean_old && log_std_old && kl_partials && kl_sum && rows > 0, "actor_kl: bad args");
+  int64_t blocks = (rows + 63) / 64;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks > kl_partials_capacity) blocks = kl_partials_capacity;
+  SPO_REQUIRE(blocks >= 1, "actor_kl: partials capacity must be >= 1");
+  KlArgs a{theta, obs, mean_old, log_std_old, nullptr, kl_partials, rows, obs_dim, act_dim};
+  launch_full<1>(a, (unsigned)blocks, (hipStream_t)stream);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, kl_partials, (int)blocks, kl_sum);
+  SPO_LAUNCH_CHECK("spo_actor_kl");
+  return 0;
+}
+
+extern "C" int spo_synth_env_step(float* next_obs, float* final_obs, float* reward, float* cost, float* terminated,
+                                  float* truncated, int* t_env, int64_t num_envs, int obs_dim, uint64_t seed,
+                                  uint64_t step, float p_term, float p_cost, int trunc_len, void* stream) {
+  SPO_REQUIRE(next_obs && final_obs && reward && cost && terminated && truncated && t_env && num_envs > 0 && obs_dim > 0,
+              "synth_env: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(synth_flags_kernel, dim3((unsigned)((num_envs + 255) / 256)), dim3(256), 0, st, reward, cost,
+                     terminated, truncated, t_env, num_envs, seed, step, p_term, p_cost, trunc_len);
+  const int64_t work = num_envs * ((obs_dim + 3) / 4);
+  hipLaunchKernelGGL(synth_obs_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, next_obs, final_obs,
+                     terminated, truncated, num_envs, obs_dim, seed, step);
+  SPO_LAUNCH_CHECK("spo_synth_env_step");
+  return 0;
+}

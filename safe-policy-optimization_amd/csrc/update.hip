@@ -1,0 +1,639 @@
+// PPO-Lagrangian / critic minibatch update kernels, gfx950.
+//
+// Replaces the inline update loop of safepo/single_agent/ppo_lag.py:297-336 (and the critic fit of
+// cpo.py:534-571): per minibatch of 64 rows the reference runs ~150 tiny torch ops (3 MLP fwd/bwd,
+// 24 L2 terms, clip_grad_norm_, 3x Adam) = 3.8 ms on CPU, 327 680 strictly sequential times per
+// epoch.  Here one PERSISTENT launch runs a whole learning iteration (all minibatches):
+//
+//   grid = one workgroup per network (reward critic, cost critic, actor), 4 waves each;
+//   the network's weights live in LDS (the fp32 master copy) for the whole launch,
+//   Adam moments live in REGISTERS, laid out exactly like the MFMA accumulator tiles that produce
+//   the weight gradients, so the optimiser step needs no data movement at all;
+//   per step the three workgroups exchange ONE scalar each (their ||grad||^2, for the joint
+//   clip_grad_norm_) through 8-byte {tag,value} granules with relaxed agent-scope atomics.
+//
+// Wave w owns batch columns [16w,16w+16) in forward/backward (transposed chaining, mlp_mfma.h) and
+// rows [16w,16w+16) of every weight-gradient tile (reduction over the 64 batch columns staged
+// through LDS as [feature][batch]).
+#include "common.h"
+#include "mlp_mfma.h"
+#include "../../include/safepo_hip.h"
+
+namespace {
+using namespace spo;
+
+constexpr int LDB = 64 + 4;     // [feature][batch] LDS row stride (floats)
+constexpr int RED_FLOATS = 160;
+
+template <int KIN>
+struct UpdLds {
+  using L = NetLds<KIN>;
+  static constexpr int XT = L::SIZE;
+  static constexpr int H1T = XT + KIN * LDB;
+  static constexpr int H2T = H1T + HID * LDB;
+  static constexpr int DZ1T = H2T + HID * LDB;
+  static constexpr int DZ2T = DZ1T + HID * LDB;
+  static constexpr int DOT = DZ2T + HID * LDB;
+  static constexpr int RED = DOT + OUTP * LDB;
+  static constexpr int SIZE = RED + RED_FLOATS;
+};
+
+struct UpdArgs {
+  float* theta; float* adam_m; float* adam_v;
+  const float* obs; const float* act; const float* logp_old; const float* tgt_r; const float* tgt_c;
+  const float* adv; const int32_t* perm; int64_t M;
+  spo_ppo_cfg cfg;
+  float* losses;                 // [nsteps][3]
+  unsigned long long* slots;     // [2][4] granules
+  int* err;                      // slots + 8
+  double pow_b1, pow_b2;         // beta^adam_step at launch
+  int first_net, n_nets;         // PPO-Lag: 0,3   CPO critic fit: 0,2
+  float stale_sq;                // CPO: ||stale actor grad||^2 taking part in the joint clip
+  float* stale_sq_out;
+  // split (data-parallel) form
+  float* flat_grad; int64_t mean_count;
+};
+
+__device__ __forceinline__ unsigned long long ld_granule(unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_granule(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Adam on one scalar (torch.optim.Adam single-tensor path: lerp, addcmul, sqrt/bc2_sqrt + eps, addcdiv).
+struct AdamOut { float p, m, v; };
+__device__ __forceinline__ AdamOut adam1(float p, float g, float m, float v, float b1, float b2, float eps,
+                                         float step_size, float bc2_sqrt) {
+  AdamOut o;
+  o.m = m + (1.f - b1) * (g - m);
+  o.v = v * b2 + (1.f - b2) * g * g;
+  const float denom = sqrtf(o.v) / bc2_sqrt + eps;
+  o.p = p - step_size * (o.m / denom);
+  return o;
+}
+// DST = updated parameter; M, V (vector elements or scalars) updated in place.
+#define SPO_ADAM(DST, P, G, M, V)                                                    \
+  {                                                                                  \
+    const AdamOut _o = adam1((P), (G), (M), (V), b1c, b2c, eps, step_size, bc2s);    \
+    (M) = _o.m; (V) = _o.v; (DST) = _o.p;                                            \
+  }
+
+template <int KIN, bool PERSIST>
+__global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  using U = UpdLds<KIN>;
+  using L = NetLds<KIN>;
+  constexpr int NT1 = KIN / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+  const int net = a.first_net + blockIdx.x;
+  const int D = a.cfg.obs_dim, A = a.cfg.act_dim, B = a.cfg.batch;
+  const NetGeom g = net_geom(D, A, net);
+  const bool is_actor = (net == 2);
+  const int OUT = g.OUT;
+  const int ls_off = g.off - A;          // actor only
+  float* const red = lds + U::RED;
+  stage_net<KIN>(a.theta, g, lds, tid, 256);
+  if (is_actor && tid < A) red[128 + tid] = a.theta[ls_off + tid];     // log_std mirror
+  __syncthreads();
+
+  // ---- ownership (C layout of the weight-gradient tiles) and optimiser state in registers
+  const int orow = 16 * wave + 4 * q;        // + r : row of W1/W2 tiles
+  f4 mW1[NT1], vW1[NT1], mW2[4], vW2[4], mW3, vW3, mls, vls;
+  float mb1 = 0, vb1 = 0, mb2 = 0, vb2 = 0, mb3 = 0, vb3 = 0;
+  const bool own_b = (q == 0);
+  const bool own_b3 = (wave == 0 && q == 0 && j < OUT);
+  const bool own_ls = is_actor && wave == 0 && j == 0;
+  if (PERSIST) {
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * nt + j;
+        const int idx = g.w1() + (orow + r) * D + i;
+        mW1[nt][r] = i < D ? a.adam_m[idx] : 0.f;
+        vW1[nt][r] = i < D ? a.adam_v[idx] : 0.f;
+      }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int idx = g.w2() + (orow + r) * HID + 16 * nt + j;
+        mW2[nt][r] = a.adam_m[idx];
+        vW2[nt][r] = a.adam_v[idx];
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = 4 * q + r;
+      const int idx = g.w3() + o * HID + 16 * wave + j;
+      mW3[r] = o < OUT ? a.adam_m[idx] : 0.f;
+      vW3[r] = o < OUT ? a.adam_v[idx] : 0.f;
+      const int ai = 4 * q + r;
+      mls[r] = (own_ls && ai < A) ? a.adam_m[ls_off + ai] : 0.f;
+      vls[r] = (own_ls && ai < A) ? a.adam_v[ls_off + ai] : 0.f;
+    }
+    if (own_b) {
+      mb1 = a.adam_m[g.b1() + 16 * wave + j]; vb1 = a.adam_v[g.b1() + 16 * wave + j];
+      mb2 = a.adam_m[g.b2() + 16 * wave + j]; vb2 = a.adam_v[g.b2() + 16 * wave + j];
+    }
+    if (own_b3) { mb3 = a.adam_m[g.b3() + j]; vb3 = a.adam_v[g.b3() + j]; }
+  }
+
+  const float b1c = a.cfg.beta1, b2c = a.cfg.beta2;
+  double pw1 = a.pow_b1, pw2 = a.pow_b2;
+  const float lr = is_actor ? a.cfg.lr_actor : a.cfg.lr_critic;
+  const float l2 = (!is_actor && a.cfg.use_critic_norm) ? a.cfg.l2_coef : 0.f;
+  const float vcoef = (net == 0 && a.cfg.use_value_coefficient) ? 2.f : 1.f;
+  float stale_sq = a.stale_sq;
+  const float* tgt = (net == 0) ? a.tgt_r : a.tgt_c;
+
+  // log_std dependent constants are recomputed every step (log_std is a parameter)
+  const int64_t nsteps = PERSIST ? (a.M + B - 1) / B : 1;
+  const int nhalf = (B + 63) / 64;
+
+  for (int64_t s = 0; s < nsteps; ++s) {
+    const int64_t base = s * B;
+    const int ncols = PERSIST ? (int)((a.M - base) < B ? (a.M - base) : B) : (int)a.M;
+    const float inv_n = 1.f / (float)(PERSIST ? ncols : (int)a.mean_count);
+
+    f4 aW1[NT1], aW2[4], aW3 = {0.f, 0.f, 0.f, 0.f}, dls = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt) aW1[nt] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) aW2[nt] = f4{0.f, 0.f, 0.f, 0.f};
+    float db1 = 0.f, db2 = 0.f, db3 = 0.f, lsum = 0.f;
+
+    // std = exp(log_std) from the LDS mirror of log_std (a parameter: changes every step)
+    float sd[4], var[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ai = 4 * q + r;
+      sd[r] = (is_actor && ai < A) ? expf(red[128 + ai]) : 1.f;
+      var[r] = sd[r] * sd[r];
+    }
+
+    for (int h = 0; h < nhalf; ++h) {
+      const int col = 64 * h + 16 * wave + j;
+      const bool cv = col < ncols;
+      const int64_t smp = (int64_t)a.perm[base + (cv ? col : 0)];
+      f4 x[NT1];
+      load_obs_tiles<KIN>(a.obs + smp * D, D, q, x);
+      f4 h1[4], h2[4];
+      const f4 o = net_forward<KIN>(lds, x, h1, h2, j, q);
+
+      // ---- loss and d(loss)/d(output), C layout (rows = output unit 4q+r, col = batch)
+      f4 dO = {0.f, 0.f, 0.f, 0.f};
+      if (!is_actor) {
+        // mse_loss(critic(obs), target)  (ppo_lag.py:307-309)
+        const float diff = o[0] - tgt[smp];
+        if (q == 0 && cv) { lsum += diff * diff; dO[0] = 2.f * diff * inv_n; }
+      } else {
+        float lp = 0.f, dif[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ai = 4 * q + r;
+          dif[r] = 0.f;
+          if (ai < A) {
+            dif[r] = a.act[smp * A + ai] - o[r];
+            lp += -(dif[r] * dif[r]) / (2.f * var[r]) - logf(sd[r]) - LOG_SQRT_2PI;
+          }
+        }
+        lp += __shfl_xor(lp, 16);
+        lp += __shfl_xor(lp, 32);
+        const float adv = a.adv[smp];
+        const float ratio = expf(lp - a.logp_old[smp]);                      // ppo_lag.py:317
+        const float lo = 1.f - a.cfg.clip, hi = 1.f + a.cfg.clip;
+        const float rc = fminf(fmaxf(ratio, lo), hi);                        // torch.clamp
+        const float s1 = ratio * adv, s2 = rc * adv;
+        const bool inr = (ratio >= lo) && (ratio <= hi);
+        // backward of torch.min(s1, s2): ties split the gradient; clamp passes it inside [lo,hi]
+        float gr;
+        if (s1 < s2) gr = adv;
+        else if (s1 > s2) gr = inr ? adv : 0.f;
+        else gr = 0.5f * adv + (inr ? 0.5f * adv : 0.f);
+        const float dlp = cv ? -(gr * ratio) * inv_n : 0.f;                  // loss_pi = -mean(min(...))
+        if (q == 0 && cv) lsum += fminf(s1, s2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (4 * q + r < A) {
+            dO[r] = dlp * (dif[r] / var[r]);
+            dls[r] += dlp * (dif[r] * dif[r] / var[r] - 1.f);
+          }
+        }
+      }
+
+      // ---- backward through the MLP (transposed chaining, weights read as columns)
+      f4 dz2[4], dz1[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = mfma4(lds[L::W3 + (4 * q + r) * LDH + 16 * mt + j], dO[r], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] *= (1.f - h2[mt][r] * h2[mt][r]);
+        dz2[mt] = acc;
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            acc = mfma4(lds[L::W2 + (16 * nt + 4 * q + r) * LDH + 16 * mt + j], dz2[nt][r], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] *= (1.f - h1[mt][r] * h1[mt][r]);
+        dz1[mt] = acc;
+      }
+
+      // ---- stage [feature][batch] images for the weight-gradient GEMMs
+      const int cl = 16 * wave + j;
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lds[U::XT + (16 * nt + 4 * q + e) * LDB + cl] = x[nt][e];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = (16 * mt + 4 * q + r) * LDB + cl;
+          lds[U::H1T + f] = h1[mt][r];
+          lds[U::H2T + f] = h2[mt][r];
+          lds[U::DZ1T + f] = dz1[mt][r];
+          lds[U::DZ2T + f] = dz2[mt][r];
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lds[U::DOT + (4 * q + r) * LDB + cl] = dO[r];
+      __syncthreads();
+
+      // ---- dW[o][i] = sum_b dZ[b][o] * Hprev[b][i]; wave w owns rows 16w..16w+15
+      {
+        f4 az[4];
+        float rs = 0.f;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          az[r4] = *reinterpret_cast<const f4*>(lds + U::DZ1T + (16 * wave + j) * LDB + 16 * r4 + 4 * q);
+          rs += az[r4][0] + az[r4][1] + az[r4][2] + az[r4][3];
+        }
+        db1 += rs;
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const f4 bh = *reinterpret_cast<const f4*>(lds + U::XT + (16 * nt + j) * LDB + 16 * r4 + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) aW1[nt] = mfma4(az[r4][e], bh[e], aW1[nt]);
+          }
+        rs = 0.f;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          az[r4] = *reinterpret_cast<const f4*>(lds + U::DZ2T + (16 * wave + j) * LDB + 16 * r4 + 4 * q);
+          rs += az[r4][0] + az[r4][1] + az[r4][2] + az[r4][3];
+        }
+        db2 += rs;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const f4 bh = *reinterpret_cast<const f4*>(lds + U::H1T + (16 * nt + j) * LDB + 16 * r4 + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) aW2[nt] = mfma4(az[r4][e], bh[e], aW2[nt]);
+          }
+        rs = 0.f;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          az[r4] = *reinterpret_cast<const f4*>(lds + U::DOT + j * LDB + 16 * r4 + 4 * q);
+          rs += az[r4][0] + az[r4][1] + az[r4][2] + az[r4][3];
+          const f4 bh = *reinterpret_cast<const f4*>(lds + U::H2T + (16 * wave + j) * LDB + 16 * r4 + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) aW3 = mfma4(az[r4][e], bh[e], aW3);
+        }
+        db3 += rs;
+      }
+      __syncthreads();
+    }  // halves
+
+    // ---- bias gradients: sum over the 4 k-slots (q) -> every lane of row j has the total
+    db1 += __shfl_xor(db1, 16); db1 += __shfl_xor(db1, 32);
+    db2 += __shfl_xor(db2, 16); db2 += __shfl_xor(db2, 32);
+    db3 += __shfl_xor(db3, 16); db3 += __shfl_xor(db3, 32);
+    // log_std gradient: sum over the wave's 16 columns, then over waves through LDS
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float t = dls[r];
+      t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
+      dls[r] = t;
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) red[wave] = lsum;
+    if (is_actor && j == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[16 + wave * 16 + 4 * q + r] = dls[r];
+    }
+    __syncthreads();
+    const float loss_data = (red[0] + red[1] + red[2] + red[3]) * inv_n;
+    if (own_ls) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ai = 4 * q + r;
+        dls[r] = red[16 + ai] + red[32 + ai] + red[48 + ai] + red[64 + ai];
+      }
+    }
+
+    // ---- L2 regulariser of the critics (weights AND biases, ppo_lag.py:310-314), grad norm
+    float gsq = 0.f, psq = 0.f;
+    f4 pW1[NT1], pW2[4], pW3;
+    float pb1 = 0.f, pb2 = 0.f, pb3 = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = (16 * nt + j) < D;
+        const float p = lds[L::W1 + (orow + r) * L::LD1 + 16 * nt + j];
+        pW1[nt][r] = p;
+        float gg = ok ? vcoef * (aW1[nt][r] + 2.f * l2 * p) : 0.f;
+        aW1[nt][r] = gg; gsq += gg * gg; psq += ok ? p * p : 0.f;
+      }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = lds[L::W2 + (orow + r) * LDH + 16 * nt + j];
+        pW2[nt][r] = p;
+        const float gg = vcoef * (aW2[nt][r] + 2.f * l2 * p);
+        aW2[nt][r] = gg; gsq += gg * gg; psq += p * p;
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = (4 * q + r) < OUT;
+      const float p = lds[L::W3 + (4 * q + r) * LDH + 16 * wave + j];
+      pW3[r] = p;
+      const float gg = ok ? vcoef * (aW3[r] + 2.f * l2 * p) : 0.f;
+      aW3[r] = gg; gsq += gg * gg; psq += ok ? p * p : 0.f;
+    }
+    if (own_b) {
+      pb1 = lds[L::B1 + 16 * wave + j]; pb2 = lds[L::B2 + 16 * wave + j];
+      db1 = vcoef * (db1 + 2.f * l2 * pb1); db2 = vcoef * (db2 + 2.f * l2 * pb2);
+      gsq += db1 * db1 + db2 * db2; psq += pb1 * pb1 + pb2 * pb2;
+    }
+    if (own_b3) {
+      pb3 = lds[L::B3 + j];
+      db3 = vcoef * (db3 + 2.f * l2 * pb3);
+      gsq += db3 * db3; psq += pb3 * pb3;
+    }
+    if (own_ls) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (4 * q + r < A) gsq += dls[r] * dls[r];
+    }
+    gsq = wave_sum(gsq);
+    psq = wave_sum(psq);
+    if (lane == 0) { red[4 + wave] = gsq; red[8 + wave] = psq; }
+    __syncthreads();
+    const float my_sq = red[4] + red[5] + red[6] + red[7];
+    const float loss = is_actor ? -loss_data : loss_data + l2 * (red[8] + red[9] + red[10] + red[11]);
+    if (tid == 0) a.losses[s * 3 + net] = loss;
+
+    if (!PERSIST) {
+      // split form: emit the flat gradient (reference parameter order) and stop
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * nt + j < D) a.flat_grad[g.w1() + (orow + r) * D + 16 * nt + j] = aW1[nt][r];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.flat_grad[g.w2() + (orow + r) * HID + 16 * nt + j] = aW2[nt][r];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * q + r < OUT) a.flat_grad[g.w3() + (4 * q + r) * HID + 16 * wave + j] = aW3[r];
+      if (own_b) { a.flat_grad[g.b1() + 16 * wave + j] = db1; a.flat_grad[g.b2() + 16 * wave + j] = db2; }
+      if (own_b3) a.flat_grad[g.b3() + j] = db3;
+      if (own_ls) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (4 * q + r < A) a.flat_grad[ls_off + 4 * q + r] = dls[r];
+      }
+      return;
+    }
+
+    // ---- joint clip_grad_norm_ over all networks: exchange ||g||^2 (one granule per workgroup)
+    {
+      unsigned long long* row = a.slots + (s & 1) * 4;
+      const unsigned tag = (unsigned)(s + 1);
+      if (tid == 0) st_granule(row + blockIdx.x, ((unsigned long long)tag << 32) | __float_as_uint(my_sq));
+      if (tid < a.n_nets) {
+        unsigned long long v = 0;
+        unsigned spins = 0;
+        for (;;) {
+          v = ld_granule(row + tid);
+          if ((unsigned)(v >> 32) == tag) break;
+          if (++spins > (1u << 24)) { *a.err = 1; break; }          // bounded: never hang the GPU
+          __builtin_amdgcn_s_sleep(1);
+        }
+        red[96 + tid] = __uint_as_float((unsigned)v);
+      }
+      __syncthreads();
+    }
+    float total_sq = stale_sq;
+    for (int k = 0; k < a.n_nets; ++k) total_sq += red[96 + k];
+    const float norm = sqrtf(total_sq);
+    float coef = a.cfg.max_grad_norm / (norm + 1e-6f);                // clip_grad_norm_ (torch): eps 1e-6
+    coef = coef > 1.f ? 1.f : coef;
+    stale_sq *= coef * coef;                                         // stale actor grads are scaled in place too
+
+    // ---- Adam (bias corrections in double from the running beta powers)
+    pw1 *= (double)b1c; pw2 *= (double)b2c;
+    const float step_size = (float)((double)lr / (1.0 - pw1));
+    const float bc2s = (float)sqrt(1.0 - pw2);
+    const float eps = a.cfg.adam_eps;
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * nt + j < D)
+          SPO_ADAM(lds[L::W1 + (orow + r) * L::LD1 + 16 * nt + j], pW1[nt][r], aW1[nt][r] * coef, mW1[nt][r], vW1[nt][r])
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        SPO_ADAM(lds[L::W2 + (orow + r) * LDH + 16 * nt + j], pW2[nt][r], aW2[nt][r] * coef, mW2[nt][r], vW2[nt][r])
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (4 * q + r < OUT)
+        SPO_ADAM(lds[L::W3 + (4 * q + r) * LDH + 16 * wave + j], pW3[r], aW3[r] * coef, mW3[r], vW3[r])
+    if (own_b) {
+      SPO_ADAM(lds[L::B1 + 16 * wave + j], pb1, db1 * coef, mb1, vb1)
+      SPO_ADAM(lds[L::B2 + 16 * wave + j], pb2, db2 * coef, mb2, vb2)
+    }
+    if (own_b3) SPO_ADAM(lds[L::B3 + j], pb3, db3 * coef, mb3, vb3)
+    if (own_ls) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * q + r < A)
+          SPO_ADAM(red[128 + 4 * q + r], red[128 + 4 * q + r], dls[r] * coef, mls[r], vls[r])
+    }
+    __syncthreads();
+  }  // steps
+
+  if (PERSIST) {
+    // ---- write back parameters and optimiser state (flat reference order)
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * nt + j;
+        if (i < D) {
+          const int idx = g.w1() + (orow + r) * D + i;
+          a.theta[idx] = lds[L::W1 + (orow + r) * L::LD1 + i];
+          a.adam_m[idx] = mW1[nt][r]; a.adam_v[idx] = vW1[nt][r];
+        }
+      }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int idx = g.w2() + (orow + r) * HID + 16 * nt + j;
+        a.theta[idx] = lds[L::W2 + (orow + r) * LDH + 16 * nt + j];
+        a.adam_m[idx] = mW2[nt][r]; a.adam_v[idx] = vW2[nt][r];
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = 4 * q + r;
+      if (o < OUT) {
+        const int idx = g.w3() + o * HID + 16 * wave + j;
+        a.theta[idx] = lds[L::W3 + o * LDH + 16 * wave + j];
+        a.adam_m[idx] = mW3[r]; a.adam_v[idx] = vW3[r];
+      }
+      if (own_ls && o < A) {
+        a.theta[ls_off + o] = red[128 + o];
+        a.adam_m[ls_off + o] = mls[r]; a.adam_v[ls_off + o] = vls[r];
+      }
+    }
+    if (own_b) {
+      const int o = 16 * wave + j;
+      a.theta[g.b1() + o] = lds[L::B1 + o]; a.adam_m[g.b1() + o] = mb1; a.adam_v[g.b1() + o] = vb1;
+      a.theta[g.b2() + o] = lds[L::B2 + o]; a.adam_m[g.b2() + o] = mb2; a.adam_v[g.b2() + o] = vb2;
+    }
+    if (own_b3) { a.theta[g.b3() + j] = lds[L::B3 + j]; a.adam_m[g.b3() + j] = mb3; a.adam_v[g.b3() + j] = vb3; }
+    if (tid == 0 && blockIdx.x == 0 && a.stale_sq_out) *a.stale_sq_out = stale_sq;
+  }
+}
+
+// Split form, second half: joint clip + Adam over the flat vector (one workgroup; P ~ 25k).
+struct AdamArgs {
+  float* theta; float* m; float* v; const float* grad; int64_t P; float gscale;
+  float max_norm, lr_actor, lr_critic, b1, b2, eps; double pow_b1, pow_b2; int64_t actor_begin;
+};
+__global__ __launch_bounds__(1024) void clip_adam_kernel(AdamArgs a) {
+  __shared__ float sh[16];
+  const int tid = threadIdx.x;
+  float sq = 0.f;
+  for (int64_t i = tid; i < a.P; i += 1024) { const float g = a.grad[i] * a.gscale; sq += g * g; }
+  sq = wave_sum(sq);
+  if ((tid & 63) == 0) sh[tid >> 6] = sq;
+  __syncthreads();
+  float tot = 0.f;
+  for (int k = 0; k < 16; ++k) tot += sh[k];
+  float coef = a.max_norm / (sqrtf(tot) + 1e-6f);
+  coef = coef > 1.f ? 1.f : coef;
+  const double pw1 = a.pow_b1 * (double)a.b1, pw2 = a.pow_b2 * (double)a.b2;
+  const float bc2s = (float)sqrt(1.0 - pw2);
+  const float ss_a = (float)((double)a.lr_actor / (1.0 - pw1)), ss_c = (float)((double)a.lr_critic / (1.0 - pw1));
+  for (int64_t i = tid; i < a.P; i += 1024) {
+    const float g = a.grad[i] * a.gscale * coef;
+    const AdamOut o = adam1(a.theta[i], g, a.m[i], a.v[i], a.b1, a.b2, a.eps, i >= a.actor_begin ? ss_a : ss_c, bc2s);
+    a.theta[i] = o.p; a.m[i] = o.m; a.v[i] = o.v;
+  }
+}
+
+int pick_kin(int D) { return D <= 16 ? 16 : D <= 32 ? 32 : 64; }
+
+template <bool PERSIST>
+int launch_update(const UpdArgs& a, int blocks, hipStream_t st) {
+  const int kin = pick_kin(a.cfg.obs_dim);
+#define SPO_LAUNCH(K)                                                                                   \
+  {                                                                                                     \
+    const size_t sh = UpdLds<K>::SIZE * sizeof(float);                                                  \
+    static bool attr_done = false;                                                                      \
+    if (!attr_done) {                                                                                   \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_update_kernel<K, PERSIST>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);          \
+      if (e != hipSuccess) return spo::hip_check(e, "hipFuncSetAttribute(update)");                     \
+      attr_done = true;                                                                                 \
+    }                                                                                                   \
+    hipLaunchKernelGGL((ppo_update_kernel<K, PERSIST>), dim3(blocks), dim3(256), sh, st, a);            \
+  }
+  if (kin == 16) SPO_LAUNCH(16) else if (kin == 32) SPO_LAUNCH(32) else SPO_LAUNCH(64)
+#undef SPO_LAUNCH
+  return 0;
+}
+
+int check_cfg(const spo_ppo_cfg* c) {
+  if (!c) return spo::fail(-1, "update: cfg is NULL");
+  if (c->obs_dim < 1 || c->obs_dim > 64)
+    return spo::fail(-2, "update: obs_dim %d outside [1,64] (update kernels; collect supports up to %d)", c->obs_dim,
+                     SPO_MAX_OBS);
+  if (c->act_dim < 1 || c->act_dim > SPO_MAX_ACT) return spo::fail(-2, "update: act_dim %d outside [1,16]", c->act_dim);
+  if (c->batch < 1) return spo::fail(-2, "update: batch must be >= 1");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int spo_ppo_lag_update_iter(float* theta, float* adam_m, float* adam_v, int64_t adam_step_host,
+                                       const float* obs, const float* act, const float* logp_old,
+                                       const float* target_r, const float* target_c, const float* adv,
+                                       const int32_t* perm, int64_t M, const spo_ppo_cfg* cfg_host, float* losses_out,
+                                       void* sync_ws, void* stream) {
+  if (int rc = check_cfg(cfg_host)) return rc;
+  SPO_REQUIRE(theta && adam_m && adam_v && obs && act && logp_old && target_r && target_c && adv && perm &&
+                  losses_out && sync_ws, "update_iter: null pointer");
+  SPO_REQUIRE(M > 0 && adam_step_host >= 0, "update_iter: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = spo::hip_check(hipMemsetAsync(sync_ws, 0, 72, st), "hipMemsetAsync(sync_ws)")) return rc;
+  UpdArgs a{};
+  a.theta = theta; a.adam_m = adam_m; a.adam_v = adam_v;
+  a.obs = obs; a.act = act; a.logp_old = logp_old; a.tgt_r = target_r; a.tgt_c = target_c; a.adv = adv;
+  a.perm = perm; a.M = M; a.cfg = *cfg_host; a.losses = losses_out;
+  a.slots = reinterpret_cast<unsigned long long*>(sync_ws);
+  a.err = reinterpret_cast<int*>(reinterpret_cast<char*>(sync_ws) + 64);
+  a.pow_b1 = pow((double)cfg_host->beta1, (double)adam_step_host);
+  a.pow_b2 = pow((double)cfg_host->beta2, (double)adam_step_host);
+  a.first_net = 0; a.n_nets = 3; a.stale_sq = 0.f; a.stale_sq_out = nullptr;
+  a.flat_grad = nullptr; a.mean_count = 0;
+  if (int rc = launch_update<true>(a, 3, st)) return rc;
+  SPO_LAUNCH_CHECK("spo_ppo_lag_update_iter");
+  return 0;
+}
+
+extern "C" int spo_ppo_lag_grad(const float* theta, const float* obs, const float* act, const float* logp_old,
+                                const float* target_r, const float* target_c, const float* adv, const int32_t* idx,
+                                int n_idx, int64_t mean_count, const spo_ppo_cfg* cfg_host, float* flat_grad,
+                                float* losses3, void* stream) {
+  if (int rc = check_cfg(cfg_host)) return rc;
+  SPO_REQUIRE(theta && obs && act && logp_old && target_r && target_c && adv && idx && flat_grad && losses3,
+              "ppo_lag_grad: null pointer");
+  SPO_REQUIRE(n_idx > 0 && n_idx <= cfg_host->batch && mean_count > 0, "ppo_lag_grad: bad n_idx/mean_count");
+  UpdArgs a{};
+  a.theta = const_cast<float*>(theta);
+  a.obs = obs; a.act = act; a.logp_old = logp_old; a.tgt_r = target_r; a.tgt_c = target_c; a.adv = adv;
+  a.perm = idx; a.M = n_idx; a.cfg = *cfg_host; a.losses = losses3;
+  a.first_net = 0; a.n_nets = 3; a.flat_grad = flat_grad; a.mean_count = mean_count;
+  if (int rc = launch_update<false>(a, 3, (hipStream_t)stream)) return rc;
+  SPO_LAUNCH_CHECK("spo_ppo_lag_grad");
+  return 0;
+}
+
+extern "C" int spo_clip_adam(float* theta, float* adam_m, float* adam_v, const float* flat_grad,
+                             int64_t adam_step_host, float grad_scale, const spo_ppo_cfg* cfg_host, void* stream) {
+  if (int rc = check_cfg(cfg_host)) return rc;
+  SPO_REQUIRE(theta && adam_m && adam_v && flat_grad && adam_step_host >= 0, "clip_adam: bad args");
+  AdamArgs a{theta, adam_m, adam_v, flat_grad, spo_param_count(cfg_host->obs_dim, cfg_host->act_dim), grad_scale,
+             cfg_host->max_grad_norm, cfg_host->lr_actor, cfg_host->lr_critic, cfg_host->beta1, cfg_host->beta2,
+             cfg_host->adam_eps, pow((double)cfg_host->beta1, (double)adam_step_host),
+             pow((double)cfg_host->beta2, (double)adam_step_host),
+             spo_param_offset(cfg_host->obs_dim, cfg_host->act_dim, 2)};
+  hipLaunchKernelGGL(clip_adam_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+  SPO_LAUNCH_CHECK("spo_clip_adam");
+  return 0;
+}

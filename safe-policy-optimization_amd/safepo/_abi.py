@@ -1,0 +1,99 @@
+"""ctypes binding of libsafepo_hip.so (C ABI declared in include/safepo_hip.h).
+
+The library is built in-tree by `__graft_entry__.build()` (hipcc --offload-arch=gfx950) into
+safepo/_lib/.  Loading fails LOUDLY: there is no Python/CPU implementation behind these calls.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libsafepo_hip.so")
+
+
+class SpoError(RuntimeError):
+    pass
+
+
+class PpoCfg(Structure):
+    """spo_ppo_cfg (include/safepo_hip.h)."""
+    _fields_ = [("obs_dim", c_int), ("act_dim", c_int), ("batch", c_int), ("use_critic_norm", c_int),
+                ("use_value_coefficient", c_int), ("clip", c_float), ("max_grad_norm", c_float),
+                ("lr_actor", c_float), ("lr_critic", c_float), ("beta1", c_float), ("beta2", c_float),
+                ("adam_eps", c_float), ("l2_coef", c_float)]
+
+
+P = c_void_p
+# name -> (restype, argtypes); must list every symbol declared in include/safepo_hip.h
+PROTOTYPES = {
+    "spo_abi_version": (c_int, []),
+    "spo_last_error": (c_char_p, []),
+    "spo_gae_num_blocks": (c_int, [c_int64, c_int64]),
+    "spo_gae_fused": (c_int, [P] * 12 + [c_int64, c_int64, c_double, c_double, c_double, P]),
+    "spo_adv_reduce": (c_int, [P, c_int, P, P]),
+    "spo_adv_apply": (c_int, [P, P, P, P, c_int64, c_double, c_int, c_int, P, P]),
+    "spo_policy_step": (c_int, [P] * 12 + [c_int64, c_int64, c_int64, c_int, c_int, P]),
+    "spo_values": (c_int, [P, P, P, P, c_int64, c_int, c_int, P]),
+    "spo_boundary_step": (c_int, [P] * 18 + [c_int, c_int64, c_int64, c_int64, c_int, P]),
+    "spo_ppo_lag_update_iter": (c_int, [P, P, P, c_int64] + [P] * 7 + [c_int64, POINTER(PpoCfg), P, P, P]),
+    "spo_ppo_lag_grad": (c_int, [P] * 8 + [c_int, c_int64, POINTER(PpoCfg), P, P, P]),
+    "spo_clip_adam": (c_int, [P, P, P, P, c_int64, c_float, POINTER(PpoCfg), P]),
+    "spo_actor_mean": (c_int, [P, P, P, c_int64, c_int, c_int, P]),
+    "spo_actor_kl": (c_int, [P, P, P, P, P, c_int, P, c_int64, c_int, c_int, P]),
+    "spo_param_count": (c_int64, [c_int, c_int]),
+    "spo_param_offset": (c_int64, [c_int, c_int, c_int]),
+    "spo_synth_env_step": (c_int, [P] * 7 + [c_int64, c_int, c_uint64, c_uint64, c_float, c_float, c_int, P]),
+}
+
+_lib = None
+
+
+def load(path: str | None = None):
+    """Load the shared library and bind every prototype.  Needs no GPU (symbol check only)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise SpoError(
+            f"{p} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "at the repo root (hipcc --offload-arch=gfx950). There is no CPU fallback for this path.")
+    lib = ctypes.CDLL(p)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.spo_abi_version() != 1:
+        raise SpoError(f"ABI version mismatch: library {lib.spo_abi_version()} != binding 1")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().spo_last_error()
+        raise SpoError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu_tensor(t, name: str, dtype=None):
+    import torch
+    if not torch.is_tensor(t) or not t.is_cuda:
+        raise SpoError(f"{name} must be a GPU tensor (this path runs only on the HIP device; no CPU fallback)")
+    if not t.is_contiguous():
+        raise SpoError(f"{name} must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise SpoError(f"{name} must have dtype {dtype}, got {t.dtype}")
+    return t

@@ -1,0 +1,121 @@
+"""VectorizedOnPolicyBuffer: dense device-resident on-policy buffer + fused HIP GAE.
+
+Same constructor / store / finish_path / get surface as the reference
+(safepo/common/buffer.py:24-164), different storage: instead of a Python list of `num_envs` dicts
+of per-env tensors and a Python reverse loop per path, the data lives in dense [num_envs, T]
+tensors in HBM (env-major: flat row = env*T + t, the order reference get() concatenates in,
+buffer.py:149-153), path ends are a u8 mask `seg_end[N,T]` plus bootstrap values `boot_r/boot_c`,
+and ALL paths (reward and cost) are scanned by one kernel launch at get() time
+(spo_gae_fused, csrc/gae.hip).  get() returns zero-copy flattened views.
+"""
+from __future__ import annotations
+
+import torch
+
+from safepo import _abi
+
+SCALAR_KEYS = ("reward", "cost", "done", "value_r", "value_c", "adv_r", "adv_c", "target_value_r",
+               "target_value_c", "log_prob")
+
+
+class VectorizedOnPolicyBuffer:
+    def __init__(self, obs_space, act_space, size: int, gamma: float = 0.99, lam: float = 0.95,
+                 lam_c: float = 0.95, standardized_adv_r: bool = True, standardized_adv_c: bool = True,
+                 device="cpu", num_envs: int = 1) -> None:
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise _abi.SpoError(
+                "VectorizedOnPolicyBuffer (MI355X) stores its data in HBM and computes GAE with a HIP kernel; "
+                f"device={device!r} is not a GPU (no CPU fallback)")
+        self._lib = _abi.load()
+        self.num_envs, self.size = int(num_envs), int(size)
+        self.obs_dim = int(obs_space.shape[0]) if len(obs_space.shape) else 1
+        self.act_dim = int(act_space.shape[0]) if len(act_space.shape) else 1
+        N, T = self.num_envs, self.size
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.data = {"obs": torch.zeros((N, T, *obs_space.shape), **f32),
+                     "act": torch.zeros((N, T, *act_space.shape), **f32)}
+        for k in SCALAR_KEYS:
+            self.data[k] = torch.zeros((N, T), **f32)
+        self.seg_end = torch.zeros((N, T), dtype=torch.uint8, device=dev)
+        self.boot_r = torch.zeros((N, T), **f32)
+        self.boot_c = torch.zeros((N, T), **f32)
+        self.adv_mix = torch.zeros((N, T), **f32)
+        self._partials = torch.zeros((max(self._lib.spo_gae_num_blocks(N, T), 1), 4), dtype=torch.float64, device=dev)
+        self.sums = torch.zeros(4, dtype=torch.float64, device=dev)
+        self.stats = torch.zeros(3, **f32)
+        self._gamma, self._lam, self._lam_c = gamma, lam, lam_c
+        self._standardized_adv_r, self._standardized_adv_c = standardized_adv_r, standardized_adv_c
+        self._device = dev
+        self.ptr = 0
+        self.ptr_list = [0] * N                 # kept for API parity (all entries equal self.ptr)
+        self.path_start_idx_list = [0] * N
+
+    # ------------------------------------------------------------------ reference API
+    def store(self, **data: torch.Tensor) -> None:
+        """Write one vector step (buffer.py:84-95).  The fused collect kernel writes the same slots
+        directly (safepo.common.engine); this method is the API-compatible path."""
+        assert self.ptr < self.size, "Buffer overflow"
+        for key, value in data.items():
+            self.data[key][:, self.ptr] = torch.as_tensor(value, dtype=torch.float32, device=self._device)
+        self.advance()
+
+    def advance(self) -> None:
+        self.ptr += 1
+        self.ptr_list = [self.ptr] * self.num_envs
+
+    def finish_path(self, last_value_r: torch.Tensor | None = None, last_value_c: torch.Tensor | None = None,
+                    idx: int = 0) -> None:
+        """Mark the end of env `idx`'s current path and remember its bootstrap values
+        (buffer.py:97-140).  The scan itself is deferred to get()."""
+        if self.ptr == 0 or self.path_start_idx_list[idx] >= self.ptr:
+            return
+        t = self.ptr - 1
+        self.seg_end[idx, t] = 1
+        self.boot_r[idx, t] = 0.0 if last_value_r is None else torch.as_tensor(last_value_r).reshape(-1)[0]
+        self.boot_c[idx, t] = 0.0 if last_value_c is None else torch.as_tensor(last_value_c).reshape(-1)[0]
+        self.path_start_idx_list[idx] = self.ptr
+
+    def compute_gae(self, lagrangian_multiplier: float | None = None, comm=None) -> None:
+        """All paths, reward + cost, one launch; then the get() statistics (buffer.py:154-160) and,
+        if a multiplier is given, the PPO-Lag advantage mix (ppo_lag.py:280-281) into self.adv_mix.
+        `comm`: optional safepo.parallel.Comm -- statistics are all-reduced over the env shards."""
+        d, lib, st = self.data, self._lib, _abi.stream_ptr()
+        N, T = self.num_envs, self.size
+        _abi.check(lib.spo_gae_fused(
+            _abi.ptr(d["reward"]), _abi.ptr(d["cost"]), _abi.ptr(d["value_r"]), _abi.ptr(d["value_c"]),
+            _abi.ptr(self.seg_end), _abi.ptr(self.boot_r), _abi.ptr(self.boot_c), _abi.ptr(d["adv_r"]),
+            _abi.ptr(d["adv_c"]), _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]),
+            _abi.ptr(self._partials), N, T, self._gamma, self._lam, self._lam_c, st), "spo_gae_fused")
+        _abi.check(lib.spo_adv_reduce(_abi.ptr(self._partials), self._partials.shape[0], _abi.ptr(self.sums), st),
+                   "spo_adv_reduce")
+        if comm is not None and comm.world_size > 1:
+            comm.all_reduce_sum_(self.sums)
+        lam = 0.0 if lagrangian_multiplier is None else float(lagrangian_multiplier)
+        _abi.check(lib.spo_adv_apply(
+            _abi.ptr(d["adv_r"]), _abi.ptr(d["adv_c"]),
+            _abi.ptr(self.adv_mix) if lagrangian_multiplier is not None else None,
+            _abi.ptr(self.sums), N * T, lam, int(self._standardized_adv_r), int(self._standardized_adv_c),
+            _abi.ptr(self.stats), st), "spo_adv_apply")
+
+    def get(self, lagrangian_multiplier: float | None = None, comm=None) -> dict[str, torch.Tensor]:
+        """Flattened [N*T, ...] views in env-major order with adv_r standardised and adv_c centred
+        (buffer.py:142-164); resets the write pointer.  Views alias the buffer: they are valid
+        until the next epoch's stores."""
+        self.compute_gae(lagrangian_multiplier, comm)
+        M = self.num_envs * self.size
+        out = {k: v.reshape(M, *v.shape[2:]) for k, v in self.data.items()}
+        if lagrangian_multiplier is not None:
+            out["advantage"] = self.adv_mix.reshape(M)
+        self.reset()
+        return out
+
+    def reset(self) -> None:
+        self.ptr = 0
+        self.ptr_list = [0] * self.num_envs
+        self.path_start_idx_list = [0] * self.num_envs
+
+    def clear_boundaries(self) -> None:
+        self.seg_end.zero_()
+        self.boot_r.zero_()
+        self.boot_c.zero_()

@@ -1,0 +1,315 @@
+"""Device-resident engine for the single-agent hot path: collect -> GAE -> PPO-Lagrangian update.
+
+Host-side orchestration of the HIP kernels behind the C ABI (include/safepo_hip.h).  It replaces
+the three hot loops of the reference main():
+  loop 1 (per-step Python loops over num_envs in buffer.store and the done-scan,
+          ppo_lag.py:162-234)         -> spo_policy_step + spo_values + spo_boundary_step
+  loop 2 (per-path Python scalar GAE, buffer.py:182-188) -> spo_gae_fused (+ adv statistics)
+  loop 3 (learning_iters x N*T/64 torch minibatch steps, ppo_lag.py:297-336)
+                                      -> spo_ppo_lag_update_iter (persistent kernel) and
+                                         spo_actor_kl for the early-stop test (ppo_lag.py:338-348)
+No step of the rollout synchronises with the host: episode statistics are appended to a device
+event log and replayed on the host once per epoch, in the reference's (step, env) order.
+"""
+from __future__ import annotations
+
+from collections import deque
+
+import numpy as np
+import torch
+
+from safepo import _abi
+from safepo.common.buffer import VectorizedOnPolicyBuffer
+from safepo.common.model import ActorVCritic
+from safepo.parallel import Comm
+
+
+class _Space:
+    def __init__(self, dim):
+        self.shape = (int(dim),)
+
+
+class PPOLagEngine:
+    """Owns the dense buffer, optimiser state and scratch for one GPU (one env shard)."""
+
+    def __init__(self, policy: ActorVCritic, num_envs: int, steps: int, config: dict, device,
+                 comm: Comm | None = None, lr: float = 3e-4, critic_lr: float | None = None):
+        policy._require_kernels()
+        self.policy, self.N, self.T = policy, int(num_envs), int(steps)
+        self.D, self.A = policy.obs_dim, policy.act_dim
+        self.cfg = config
+        self.dev = torch.device(device)
+        self.comm = comm or Comm()
+        self.lib = _abi.load()
+        N, T, D, A = self.N, self.T, self.D, self.A
+        self.buffer = VectorizedOnPolicyBuffer(_Space(D), _Space(A), size=T, num_envs=N, device=self.dev,
+                                               gamma=config["gamma"], lam=config.get("lam", 0.95),
+                                               lam_c=config.get("lam_c", 0.95))
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        f64 = dict(dtype=torch.float64, device=self.dev)
+        self.act_out = torch.empty((N, A), **f32)
+        self.logp = torch.empty(N, **f32)
+        self.v_r, self.v_c = torch.empty(N, **f32), torch.empty(N, **f32)
+        self.vnext_r, self.vnext_c = torch.zeros(N, **f32), torch.zeros(N, **f32)
+        self.vfinal_r, self.vfinal_c = torch.zeros(N, **f32), torch.zeros(N, **f32)
+        self.ep_ret, self.ep_cost, self.ep_len = torch.zeros(N, **f64), torch.zeros(N, **f64), torch.zeros(N, **f64)
+        self.events_cap = N * T
+        self.events = torch.zeros((self.events_cap, 4), **f64)
+        self.events_count = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        # optimiser state (flat, same order as policy.theta)
+        P = policy.theta.numel()
+        self.adam_m, self.adam_v = torch.zeros(P, **f32), torch.zeros(P, **f32)
+        self.adam_step = 0
+        self.lr_actor0, self.lr_critic = lr, (lr if critic_lr is None else critic_lr)
+        self.lr_factor = 1.0
+        self.M = N * T
+        self.mean_old = torch.empty((self.M, A), **f32)
+        self.logstd_old = torch.empty(A, **f32)
+        self.kl_partials = torch.zeros(1024, **f64)
+        self.kl_sum = torch.zeros(1, **f64)
+        self.sync_ws = torch.zeros(32, dtype=torch.int64, device=self.dev)
+        self.flat_grad = torch.zeros(P, **f32)
+        self.losses3 = torch.zeros(3, **f32)
+        self._losses = None
+        self.rew_deque, self.cost_deque, self.len_deque = deque(maxlen=50), deque(maxlen=50), deque(maxlen=50)
+
+    # ------------------------------------------------------------------ collect
+    def collect_step(self, t: int, obs: torch.Tensor, eps: torch.Tensor | None = None,
+                     deterministic: bool = False) -> torch.Tensor:
+        """policy.step(obs) + buffer.store(obs, act, value_r, value_c, log_prob) for step t
+        (ppo_lag.py:163-164,187-195) in one kernel.  Returns the sampled action [N, A] (device)."""
+        b = self.buffer
+        assert t == b.ptr and t < self.T, "Buffer overflow"
+        obs = _abi.require_gpu_tensor(obs, "obs", torch.float32)
+        if not deterministic and eps is None:
+            eps = torch.randn((self.N, self.A), device=self.dev, dtype=torch.float32)
+        d = b.data
+        _abi.check(self.lib.spo_policy_step(
+            _abi.ptr(self.policy.theta), _abi.ptr(obs), _abi.ptr(eps), _abi.ptr(self.act_out), _abi.ptr(self.logp),
+            _abi.ptr(self.v_r), _abi.ptr(self.v_c), _abi.ptr(d["obs"]), _abi.ptr(d["act"]), _abi.ptr(d["log_prob"]),
+            _abi.ptr(d["value_r"]), _abi.ptr(d["value_c"]), self.N, self.T, t, self.D, self.A, _abi.stream_ptr()),
+            "spo_policy_step")
+        return self.act_out
+
+    def post_step(self, t: int, next_obs, reward, cost, terminated, truncated, final_obs=None) -> None:
+        """Everything after env.step for step t (ppo_lag.py:168-234): reward/cost store, episode
+        accumulators, boundary flags, bootstrap values, finish_path marks."""
+        b, st = self.buffer, _abi.stream_ptr()
+        epoch_end = t >= self.T - 1
+        tens = [_abi.require_gpu_tensor(x, n, torch.float32) for x, n in
+                ((reward, "reward"), (cost, "cost"), (terminated, "terminated"), (truncated, "truncated"))]
+        if epoch_end:
+            next_obs = _abi.require_gpu_tensor(next_obs, "next_obs", torch.float32)
+            _abi.check(self.lib.spo_values(_abi.ptr(self.policy.theta), _abi.ptr(next_obs), _abi.ptr(self.vnext_r),
+                                           _abi.ptr(self.vnext_c), self.N, self.D, self.A, st), "spo_values")
+        if final_obs is not None:
+            final_obs = _abi.require_gpu_tensor(final_obs, "final_observation", torch.float32)
+            _abi.check(self.lib.spo_values(_abi.ptr(self.policy.theta), _abi.ptr(final_obs), _abi.ptr(self.vfinal_r),
+                                           _abi.ptr(self.vfinal_c), self.N, self.D, self.A, st), "spo_values")
+        d = b.data
+        _abi.check(self.lib.spo_boundary_step(
+            _abi.ptr(tens[0]), _abi.ptr(tens[1]), _abi.ptr(tens[2]), _abi.ptr(tens[3]),
+            _abi.ptr(self.vnext_r), _abi.ptr(self.vnext_c), _abi.ptr(self.vfinal_r), _abi.ptr(self.vfinal_c),
+            _abi.ptr(d["reward"]), _abi.ptr(d["cost"]), _abi.ptr(b.seg_end), _abi.ptr(b.boot_r), _abi.ptr(b.boot_c),
+            _abi.ptr(self.ep_ret), _abi.ptr(self.ep_cost), _abi.ptr(self.ep_len), _abi.ptr(self.events),
+            _abi.ptr(self.events_count), self.events_cap, self.N, self.T, t, int(epoch_end), st), "spo_boundary_step")
+        b.advance()
+
+    def drain_episode_events(self, logger=None):
+        """Replay finished episodes on the host in the reference's (step, env) order
+        (ppo_lag.py:216-230: deques of 50, running means stored per finished episode).
+        One device->host copy per epoch.  Returns the number of finished episodes."""
+        n = int(self.events_count.item())
+        if n > self.events_cap:
+            raise _abi.SpoError(f"episode event log overflow ({n} > {self.events_cap})")
+        ev = self.events[:n].cpu().numpy() if n else np.zeros((0, 4))
+        self.events_count.zero_()
+        for k in range(n):
+            self.rew_deque.append(ev[k, 1])
+            self.cost_deque.append(ev[k, 2])
+            self.len_deque.append(ev[k, 3])
+            if logger is not None:
+                logger.store(**{"Metrics/EpRet": np.mean(self.rew_deque), "Metrics/EpCost": np.mean(self.cost_deque),
+                                "Metrics/EpLen": np.mean(self.len_deque)})
+        if n and logger is not None:
+            logger.logged = False
+        return n
+
+    # ------------------------------------------------------------------ update
+    def _cfg_struct(self) -> _abi.PpoCfg:
+        c = self.cfg
+        M = self.M
+        batch = c.get("batch_size", max(M // c.get("num_mini_batch", 1), 1))
+        return _abi.PpoCfg(obs_dim=self.D, act_dim=self.A, batch=int(batch),
+                           use_critic_norm=int(c.get("use_critic_norm", True)),
+                           use_value_coefficient=int(c.get("use_value_coefficient", False)),
+                           clip=float(c.get("clip", 0.2)), max_grad_norm=float(c["max_grad_norm"]),
+                           lr_actor=float(self.lr_actor0 * self.lr_factor), lr_critic=float(self.lr_critic),
+                           beta1=0.9, beta2=0.999, adam_eps=1e-8, l2_coef=0.001)
+
+    def snapshot_old_distribution(self) -> None:
+        """old_distribution = policy.actor(data["obs"]) (ppo_lag.py:277)."""
+        obs = self.buffer.data["obs"]
+        _abi.check(self.lib.spo_actor_mean(_abi.ptr(self.policy.theta), _abi.ptr(obs), _abi.ptr(self.mean_old),
+                                           self.M, self.D, self.A, _abi.stream_ptr()), "spo_actor_mean")
+        off = self.policy.log_std_offset
+        self.logstd_old.copy_(self.policy.theta[off:off + self.A])
+
+    def kl_to_old(self) -> float:
+        """KL(old || new).sum(-1).mean() over the (global) batch (ppo_lag.py:338-345)."""
+        obs = self.buffer.data["obs"]
+        _abi.check(self.lib.spo_actor_kl(_abi.ptr(self.policy.theta), _abi.ptr(obs), _abi.ptr(self.mean_old),
+                                         _abi.ptr(self.logstd_old), _abi.ptr(self.kl_partials),
+                                         self.kl_partials.numel(), _abi.ptr(self.kl_sum), self.M, self.D, self.A,
+                                         _abi.stream_ptr()), "spo_actor_kl")
+        self.comm.all_reduce_sum_(self.kl_sum)
+        return float(self.kl_sum.item()) / float(self.M * self.comm.world_size)
+
+    def learning_iter(self, perm: torch.Tensor) -> torch.Tensor:
+        """All minibatches of one pass over the data (ppo_lag.py:298-336).  `perm`: int32 device
+        permutation of [0, M).  Returns per-minibatch losses [n_mb, 3] (device)."""
+        cfg = self._cfg_struct()
+        perm = _abi.require_gpu_tensor(perm, "perm", torch.int32)
+        d, b = self.buffer.data, self.buffer
+        M = self.M
+        n_mb = (M + cfg.batch - 1) // cfg.batch
+        losses = torch.empty((n_mb, 3), dtype=torch.float32, device=self.dev)
+        st = _abi.stream_ptr()
+        th = self.policy.theta
+        if self.comm.world_size == 1:
+            _abi.check(self.lib.spo_ppo_lag_update_iter(
+                _abi.ptr(th), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), self.adam_step, _abi.ptr(d["obs"]),
+                _abi.ptr(d["act"]), _abi.ptr(d["log_prob"]), _abi.ptr(d["target_value_r"]),
+                _abi.ptr(d["target_value_c"]), _abi.ptr(b.adv_mix), _abi.ptr(perm), M, cfg, _abi.ptr(losses),
+                _abi.ptr(self.sync_ws), st), "spo_ppo_lag_update_iter")
+            self.adam_step += n_mb
+        else:
+            # data-parallel: local minibatch gradient -> all-reduce (RCCL) -> identical clip+Adam on every rank
+            scale = 1.0 / self.comm.world_size
+            for k in range(n_mb):
+                lo = k * cfg.batch
+                n_idx = min(cfg.batch, M - lo)
+                _abi.check(self.lib.spo_ppo_lag_grad(
+                    _abi.ptr(th), _abi.ptr(d["obs"]), _abi.ptr(d["act"]), _abi.ptr(d["log_prob"]),
+                    _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]), _abi.ptr(b.adv_mix),
+                    perm.data_ptr() + 4 * lo, n_idx, n_idx, cfg, _abi.ptr(self.flat_grad), _abi.ptr(losses[k]), st),
+                    "spo_ppo_lag_grad")
+                self.comm.all_reduce_sum_(self.flat_grad)
+                _abi.check(self.lib.spo_clip_adam(_abi.ptr(th), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v),
+                                                  _abi.ptr(self.flat_grad), self.adam_step, scale, cfg, st),
+                           "spo_clip_adam")
+                self.adam_step += 1
+            self.comm.all_reduce_sum_(losses)
+            losses *= scale
+        return losses
+
+    def check_sync_error(self):
+        if int(self.sync_ws[8].item()) & 0xFFFFFFFF:
+            raise _abi.SpoError("update kernel: inter-workgroup exchange timed out")
+
+    def update(self, lagrangian_multiplier: float, perm_fn=None):
+        """GAE + statistics + mix, then the PPO-Lag update with KL early stopping
+        (ppo_lag.py:275-349).  Returns dict(stop_iter, kl, loss means)."""
+        c = self.cfg
+        self.buffer.compute_gae(lagrangian_multiplier, self.comm)
+        self.snapshot_old_distribution()
+        if perm_fn is None:
+            perm_fn = lambda it: torch.randperm(self.M, device=self.dev).to(torch.int32)
+        all_losses = []
+        stop_iter, kl = 0, 1.0
+        for it in range(c["learning_iters"]):
+            all_losses.append(self.learning_iter(perm_fn(it)))
+            kl = self.kl_to_old()
+            stop_iter += 1
+            if kl > c["target_kl"]:
+                break
+        self.check_sync_error()
+        self.buffer.reset()
+        if all_losses:
+            means = torch.cat(all_losses, 0).mean(0).tolist()
+        else:
+            means = [float("nan")] * 3
+        return {"stop_iter": stop_iter, "kl": kl, "loss_r": means[0], "loss_c": means[1], "loss_pi": means[2],
+                "losses": all_losses}
+
+
+# ---------------------------------------------------------------------- smoke check (uses the oracle as CHECKER)
+def smoke_check(verbose: bool = False, num_envs: int = 8, steps: int = 32, seed: int = 0) -> None:
+    """Tiny collect -> GAE -> update on cuda:0, compared with oracle/restatement.py."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from oracle import restatement as R
+    from oracle.synth_env import SynthEnv
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(seed)
+    D, A = 60, 8
+    cfg = {"hidden_sizes": [64, 64], "gamma": 0.99, "target_kl": 0.02, "batch_size": 64, "learning_iters": 2,
+           "max_grad_norm": 40.0}
+    policy = ActorVCritic(D, A).to(dev)
+    ref = R.OraclePolicy(D, A)
+    ref.load_state_dict({k: v.detach().cpu().clone() for k, v in policy.state_dict().items()})
+    eng = PPOLagEngine(policy, num_envs, steps, cfg, dev)
+    env = SynthEnv(num_envs, D, A, seed=seed, p_term=0.05, trunc_len=10)
+    obs_h, _ = env.reset()
+    obs = torch.as_tensor(obs_h, device=dev)
+    gen = torch.Generator().manual_seed(seed + 1)
+    rec = {k: [] for k in ("obs", "eps", "reward", "cost", "seg", "boot_r", "boot_c", "act", "logp", "v_r", "v_c")}
+    for t in range(steps):
+        eps = torch.randn((num_envs, A), generator=gen)
+        act = eng.collect_step(t, obs, eps.to(dev))
+        with torch.no_grad():
+            a_ref, lp_ref, vr_ref, vc_ref = ref.step_with_eps(torch.as_tensor(obs_h), eps)
+        nobs, rew, cost, term, trunc, info = env.step(act.cpu().numpy())
+        fo = None
+        vfr = vfc = np.zeros(num_envs, np.float32)
+        if "final_observation" in info:
+            fo_h = np.stack([a if a is not None else np.zeros(D, np.float32) for a in info["final_observation"]])
+            fo = torch.as_tensor(fo_h, dtype=torch.float32, device=dev)
+            with torch.no_grad():
+                vfr, vfc = ref.reward_critic(torch.as_tensor(fo_h)).numpy(), ref.cost_critic(torch.as_tensor(fo_h)).numpy()
+        with torch.no_grad():
+            vnr, vnc = ref.reward_critic(torch.as_tensor(nobs)).numpy(), ref.cost_critic(torch.as_tensor(nobs)).numpy()
+        seg, br, bc = R.boundary_step(term, trunc, t == steps - 1, vnr, vnc, vfr, vfc)
+        eng.post_step(t, torch.as_tensor(nobs, device=dev), torch.as_tensor(rew, device=dev),
+                      torch.as_tensor(cost, device=dev), torch.as_tensor(term, dtype=torch.float32, device=dev),
+                      torch.as_tensor(trunc, dtype=torch.float32, device=dev), fo)
+        for k, v in (("obs", obs_h), ("eps", eps.numpy()), ("reward", rew), ("cost", cost), ("seg", seg),
+                     ("boot_r", br), ("boot_c", bc), ("act", a_ref.numpy()), ("logp", lp_ref.numpy()),
+                     ("v_r", vr_ref.numpy()), ("v_c", vc_ref.numpy())):
+            rec[k].append(np.asarray(v))
+        obs_h, obs = nobs, torch.as_tensor(nobs, device=dev)
+    st = {k: np.stack(v, 1) for k, v in rec.items()}          # [N, T, ...]
+    b = eng.buffer
+    assert np.array_equal(b.seg_end.cpu().numpy(), st["seg"].astype(np.uint8)), "segment mask differs"
+    np.testing.assert_allclose(b.data["value_r"].cpu().numpy(), st["v_r"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(b.data["log_prob"].cpu().numpy(), st["logp"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(b.boot_r.cpu().numpy(), st["boot_r"], rtol=1e-4, atol=1e-5)
+    # GAE against the oracle on the DEVICE-produced inputs (bit pattern)
+    inp = {k: b.data[k].cpu().numpy() for k in ("reward", "cost", "value_r", "value_c")}
+    o = R.gae_dense(inp["reward"], inp["cost"], inp["value_r"], inp["value_c"], b.seg_end.cpu().numpy(),
+                    b.boot_r.cpu().numpy(), b.boot_c.cpu().numpy(), 0.99, 0.95, 0.95)
+    lam = 0.37
+    out = eng.update(lam, perm_fn=lambda it: torch.arange(eng.M - 1, -1, -1, device=dev, dtype=torch.int32))
+    # (update() ran the GAE kernel first; raw advantages were standardised in place -> recompute reference)
+    sr, sc = R.adv_standardize(torch.from_numpy(o[0].reshape(-1)), torch.from_numpy(o[1].reshape(-1)))
+    np.testing.assert_allclose(b.data["adv_r"].cpu().numpy().reshape(-1), sr.numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_array_equal(b.data["target_value_r"].cpu().numpy(), o[2])
+    # oracle update on the same data / same shuffles
+    M = eng.M
+    data = {"obs": torch.from_numpy(st["obs"].reshape(M, D)), "act": b.data["act"].cpu().reshape(M, A),
+            "log_prob": b.data["log_prob"].cpu().reshape(M), "target_value_r": torch.from_numpy(o[2].reshape(M)),
+            "target_value_c": torch.from_numpy(o[3].reshape(M)), "adv_r": sr, "adv_c": sc}
+    upd = R.PPOLagUpdater(ref, epochs=1)
+    perms = [np.arange(M - 1, -1, -1)] * 2
+    ro = R.ppo_lag_update(ref, upd, data, lam, perms, learning_iters=2, batch_size=64, target_kl=0.02)
+    got = torch.cat(out["losses"], 0).cpu().numpy()
+    np.testing.assert_allclose(got, ro["losses"][:len(got)], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(policy.theta.cpu().numpy(), R.flat_params(ref).numpy(), rtol=1e-3, atol=2e-6)
+    assert abs(out["kl"] - ro["kl"]) <= 1e-4 * max(1.0, abs(ro["kl"])) + 1e-7
+    if verbose:
+        print(f"smoke: seg/boot/GAE/update parity ok; kl={out['kl']:.3e} (oracle {ro['kl']:.3e}), "
+              f"loss_pi={out['loss_pi']:.4f}")

@@ -1,0 +1,107 @@
+"""Environment factories.
+
+`make_sa_mujoco_env(num_envs, env_id, seed)` keeps the reference contract
+(safepo/common/env.py:35-80): returns (env, obs_space, act_space) where
+    env.reset() -> (obs[N, obs_dim], info)
+    env.step(action[N, act_dim]) -> (obs, reward[N], cost[N], terminated[N], truncated[N], info)
+    info["final_observation"] present when an episode ended; env.obs_rms is checkpointed.
+Safety-Gymnasium tasks are created exactly like the reference when that package is installed
+(simulators are out of scope of this build and are not vendored).  Task ids starting with "Synth"
+select the device-resident synthetic env of SURVEY.md 8(d) (Isaac-Gym style: tensors stay in HBM).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from safepo import _abi
+
+
+class Box:
+    """Minimal observation/action space: only `.shape` is consumed by the training loop."""
+
+    def __init__(self, dim: int, low: float = -np.inf, high: float = np.inf):
+        self.shape = (int(dim),)
+        self.low, self.high = low, high
+
+
+class SynthDeviceEnv:
+    """obs' ~ N(0,1), reward ~ N(0,1), cost ~ Bernoulli(p_cost), terminated ~ Bernoulli(p_term),
+    truncated = (episode length >= trunc_len); counter-based RNG on the GPU (spo_synth_env_step).
+    Returns device tensors, including a dense `final_observation` [N, obs_dim]."""
+
+    is_device_env = True
+
+    def __init__(self, num_envs: int, obs_dim: int = 60, act_dim: int = 8, seed: int = 0, p_term: float = 0.0,
+                 p_cost: float = 0.1, trunc_len: int = 64, device="cuda:0"):
+        self.num_envs, self.obs_dim, self.act_dim = int(num_envs), int(obs_dim), int(act_dim)
+        self.seed, self.p_term, self.p_cost, self.trunc_len = int(seed or 0), float(p_term), float(p_cost), int(trunc_len)
+        self.dev = torch.device(device)
+        self.lib = _abi.load()
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        N, D = self.num_envs, self.obs_dim
+        self.obs = torch.zeros((N, D), **f32)
+        self.final_obs = torch.zeros((N, D), **f32)
+        self.reward, self.cost = torch.zeros(N, **f32), torch.zeros(N, **f32)
+        self.terminated, self.truncated = torch.zeros(N, **f32), torch.zeros(N, **f32)
+        self.t_env = torch.zeros(N, dtype=torch.int32, device=self.dev)
+        self.step_count = 0
+        self.obs_rms = {"mean": np.zeros(D), "var": np.ones(D), "count": 1e-4}   # identity normaliser
+        self.single_observation_space, self.single_action_space = Box(D), Box(act_dim, -1.0, 1.0)
+
+    def _advance(self):
+        self.step_count += 1
+        _abi.check(self.lib.spo_synth_env_step(
+            _abi.ptr(self.obs), _abi.ptr(self.final_obs), _abi.ptr(self.reward), _abi.ptr(self.cost),
+            _abi.ptr(self.terminated), _abi.ptr(self.truncated), _abi.ptr(self.t_env), self.num_envs, self.obs_dim,
+            self.seed, self.step_count, self.p_term, self.p_cost, self.trunc_len, _abi.stream_ptr()),
+            "spo_synth_env_step")
+
+    def reset(self, seed=None):
+        if seed is not None:
+            self.seed = int(seed)
+        self.t_env.zero_()
+        p_term, self.p_term = self.p_term, 0.0
+        self._advance()
+        self.p_term = p_term
+        self.t_env.zero_()
+        return self.obs, {}
+
+    def step(self, action):
+        self._advance()
+        info = {"final_observation": self.final_obs}
+        return self.obs, self.reward, self.cost, self.terminated, self.truncated, info
+
+
+def make_sa_mujoco_env(num_envs: int, env_id: str, seed: int | None = None, device="cuda:0", **synth_kw):
+    """(env, obs_space, act_space) -- reference signature plus `device` for synthetic tasks."""
+    if env_id.startswith("Synth"):
+        env = SynthDeviceEnv(num_envs, seed=seed or 0, device=device, **synth_kw)
+        return env, env.single_observation_space, env.single_action_space
+    try:
+        import safety_gymnasium
+        from safety_gymnasium.vector.async_vector_env import SafetyAsyncVectorEnv
+        from safety_gymnasium.wrappers import SafeAutoResetWrapper, SafeRescaleAction, SafeUnsqueeze
+        from gymnasium.wrappers.normalize import NormalizeObservation
+    except ImportError as e:  # simulators are not part of this image
+        raise ImportError(
+            f"task {env_id!r} needs safety_gymnasium/gymnasium (not installed here). "
+            "Use a 'Synth*' task id for the synthetic device env.") from e
+
+    class SafeNormalizeObservation(NormalizeObservation):
+        def step(self, action):
+            obs, rews, costs, terminateds, truncateds, infos = self.env.step(action)
+            obs = self.normalize(obs) if self.is_vector_env else self.normalize(np.array([obs]))[0]
+            return obs, rews, costs, terminateds, truncateds, infos
+
+    if num_envs > 1:
+        def create_env():
+            return SafeRescaleAction(safety_gymnasium.make(env_id), -1.0, 1.0)
+        env = SafeNormalizeObservation(SafetyAsyncVectorEnv([create_env for _ in range(num_envs)]))
+        env.reset(seed=seed)
+        return env, env.single_observation_space, env.single_action_space
+    env = safety_gymnasium.make(env_id)
+    env.reset(seed=seed)
+    obs_space, act_space = env.observation_space, env.action_space
+    env = SafeUnsqueeze(SafeNormalizeObservation(SafeRescaleAction(SafeAutoResetWrapper(env), -1.0, 1.0)))
+    return env, obs_space, act_space

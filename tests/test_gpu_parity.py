@@ -1,0 +1,411 @@
+"""GPU parity tests (run with -m gpu on an MI355X): HIP path, through the C ABI, against
+(a) golden fixtures produced by the unmodified reference and (b) the CPU oracle on seeded inputs.
+
+Tolerances (north_star): segment masks / indices bit-exact; fp32 losses, gradients and parameters
+within 1e-5 relative (absolute floors stated per test); GAE values: bit-pattern equal to the
+sequential fp64 reference except where the re-associated fp64 scan lands within 1e-16 of an fp32
+rounding boundary (<= 1 ulp, expected frequency ~1e-8 per element)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import restatement as R  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _ulp_diff(a, b):
+    ai = a.view(np.int32).astype(np.int64)
+    bi = b.view(np.int32).astype(np.int64)
+    ai = np.where(ai < 0, -(ai & 0x7FFFFFFF), ai)
+    bi = np.where(bi < 0, -(bi & 0x7FFFFFFF), bi)
+    return np.abs(ai - bi)
+
+
+def _run_gae(dev, reward, cost, v_r, v_c, seg, boot_r, boot_c, gamma=0.99, lam=0.95, lam_c=0.95):
+    from safepo.common.buffer import VectorizedOnPolicyBuffer
+    from safepo.common.engine import _Space
+    N, T = reward.shape
+    buf = VectorizedOnPolicyBuffer(_Space(3), _Space(2), size=T, num_envs=N, device=dev, gamma=gamma, lam=lam, lam_c=lam_c)
+    put = lambda k, v: buf.data[k].copy_(torch.from_numpy(np.ascontiguousarray(v)))
+    put("reward", reward); put("cost", cost); put("value_r", v_r); put("value_c", v_c)
+    buf.seg_end.copy_(torch.from_numpy(np.ascontiguousarray(seg.astype(np.uint8))))
+    buf.boot_r.copy_(torch.from_numpy(boot_r)); buf.boot_c.copy_(torch.from_numpy(boot_c))
+    return buf
+
+
+def _raw_gae(buf):
+    """Launch only the scan (no standardisation) and return host arrays."""
+    from safepo import _abi
+    d = buf.data
+    _abi.check(buf._lib.spo_gae_fused(
+        _abi.ptr(d["reward"]), _abi.ptr(d["cost"]), _abi.ptr(d["value_r"]), _abi.ptr(d["value_c"]),
+        _abi.ptr(buf.seg_end), _abi.ptr(buf.boot_r), _abi.ptr(buf.boot_c), _abi.ptr(d["adv_r"]), _abi.ptr(d["adv_c"]),
+        _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]), _abi.ptr(buf._partials), buf.num_envs, buf.size,
+        buf._gamma, buf._lam, buf._lam_c, _abi.stream_ptr()), "gae")
+    torch.cuda.synchronize()
+    return tuple(d[k].cpu().numpy() for k in ("adv_r", "adv_c", "target_value_r", "target_value_c"))
+
+
+def _assert_gae_close(got, ref, what):
+    for g, r, name in zip(got, ref, ("adv_r", "adv_c", "tgt_r", "tgt_c")):
+        ulp = _ulp_diff(np.ascontiguousarray(g), np.ascontiguousarray(r))
+        bad = int((ulp > 0).sum())
+        assert ulp.max() <= 1, f"{what}/{name}: max ulp diff {ulp.max()}"
+        assert bad <= max(1, int(1e-5 * g.size)), f"{what}/{name}: {bad}/{g.size} elements differ by 1 ulp"
+        np.testing.assert_allclose(g, r, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_gae_golden_reference_buffer(dev, golden_dir, tag):
+    z = np.load(os.path.join(golden_dir, "gae.npz"))
+    i = lambda k: z[f"{tag}_in_{k}"]
+    buf = _run_gae(dev, i("reward"), i("cost"), i("value_r"), i("value_c"), i("seg_end"), i("boot_r"), i("boot_c"))
+    got = _raw_gae(buf)
+    ref = tuple(z[f"{tag}_raw_{k}"] for k in ("adv_r", "adv_c", "target_value_r", "target_value_c"))
+    _assert_gae_close(got, ref, f"golden {tag}")
+    if tag != "d":
+        data = buf.get(lagrangian_multiplier=0.25)
+        np.testing.assert_allclose(data["adv_r"].cpu().numpy(), z[f"{tag}_get_adv_r"], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(data["adv_c"].cpu().numpy(), z[f"{tag}_get_adv_c"], rtol=1e-5, atol=2e-6)
+        mix = R.adv_mix(torch.from_numpy(z[f"{tag}_get_adv_r"]), torch.from_numpy(z[f"{tag}_get_adv_c"]), 0.25)
+        np.testing.assert_allclose(data["advantage"].cpu().numpy(), mix.numpy(), rtol=1e-5, atol=2e-6)
+
+
+def _random_case(N, T, p_seg, seed, finish_last=True):
+    rng = np.random.default_rng(seed)
+    reward = rng.standard_normal((N, T)).astype(np.float32)
+    cost = (rng.random((N, T)) < 0.1).astype(np.float32)
+    v_r = rng.standard_normal((N, T)).astype(np.float32)
+    v_c = rng.standard_normal((N, T)).astype(np.float32)
+    seg = rng.random((N, T)) < p_seg
+    if finish_last:
+        seg[:, T - 1] = True
+    term = seg & (rng.random((N, T)) < 0.3)
+    boot_r = np.where(seg & ~term, rng.standard_normal((N, T)), 0).astype(np.float32)
+    boot_c = np.where(seg & ~term, rng.standard_normal((N, T)), 0).astype(np.float32)
+    return reward, cost, v_r, v_c, seg, boot_r, boot_c
+
+
+@pytest.mark.parametrize("N,T,p", [(257, 128, 1 / 64), (33, 1000, 1 / 100), (10, 2000, 1 / 500), (65, 77, 0.05),
+                                   (7, 300, 0.0), (1, 4, 0.5), (130, 16, 0.2), (5, 129, 0.01), (4096, 128, 1 / 64)])
+def test_gae_vs_oracle_random(dev, N, T, p):
+    case = _random_case(N, T, p, seed=N * 1000 + T)
+    buf = _run_gae(dev, *case)
+    got = _raw_gae(buf)
+    ref = R.gae_dense(*case, 0.99, 0.95, 0.95)
+    _assert_gae_close(got, ref, f"N={N},T={T}")
+
+
+def test_gae_segment_mask_edge_cases(dev):
+    # every step ends a path / single long path / all-terminated bootstraps / -0.0 deltas
+    N, T = 9, 64
+    reward, cost, v_r, v_c, seg, boot_r, boot_c = _random_case(N, T, 0.0, 5)
+    seg[:] = True
+    ref = R.gae_dense(reward, cost, v_r, v_c, seg, boot_r, boot_c, 0.99, 0.95, 0.95)
+    got = _raw_gae(_run_gae(dev, reward, cost, v_r, v_c, seg, boot_r, boot_c))
+    for g, r in zip(got, ref):
+        assert np.array_equal(g.view(np.uint32), r.view(np.uint32))       # no scan involved: exact
+    z = np.zeros((N, T), np.float32)
+    nz = -z
+    seg[:] = False; seg[:, -1] = True
+    got = _raw_gae(_run_gae(dev, nz, nz, z, z, seg, z, z))
+    ref = R.gae_dense(nz, nz, z, z, seg, z, z, 0.99, 0.95, 0.95)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g.view(np.uint32), r.view(np.uint32))       # sign of zero preserved
+
+
+def test_gae_unfinished_tail_is_zero(dev):
+    N, T = 6, 128
+    case = list(_random_case(N, T, 0.0, 11, finish_last=False))
+    case[4][:, 50] = True                      # only one path end, at t=50
+    got = _raw_gae(_run_gae(dev, *case))
+    for g in got:
+        assert np.all(g[:, 51:] == 0)
+    seg2 = case[4].copy(); seg2[:, -1] = True
+    ref = R.gae_dense(case[0], case[1], case[2], case[3], seg2, case[5], case[6], 0.99, 0.95, 0.95)
+    for g, r in zip(got, ref):
+        _assert_gae_close((g[:, :51],), (r[:, :51],), "finished prefix")
+
+
+def test_gae_full_size_properties(dev):
+    """BASELINE config 2 size: linearity in (reward, bootstrap) at fixed values==0, and the
+    advantage-statistics kernel against numpy."""
+    N, T = 4096, 128
+    r1, c1, v_r, v_c, seg, b_r, b_c = _random_case(N, T, 1 / 64, 99)
+    z = np.zeros_like(r1)
+    a1 = _raw_gae(_run_gae(dev, r1, c1, z, z, seg, b_r, b_c))[0]
+    a2 = _raw_gae(_run_gae(dev, 2 * r1, c1, z, z, seg, 2 * b_r, b_c))[0]
+    np.testing.assert_allclose(a2, 2 * a1, rtol=1e-6, atol=1e-6)
+    buf = _run_gae(dev, r1, c1, v_r, v_c, seg, b_r, b_c)
+    raw = _raw_gae(buf)
+    data = buf.get(lagrangian_multiplier=0.5)
+    sr, sc = R.adv_standardize(torch.from_numpy(raw[0].reshape(-1)), torch.from_numpy(raw[1].reshape(-1)))
+    np.testing.assert_allclose(data["adv_r"].cpu().numpy(), sr.numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(data["adv_c"].cpu().numpy(), sc.numpy(), rtol=1e-5, atol=2e-6)
+    assert abs(float(data["adv_r"].mean())) < 1e-5 and abs(float(data["adv_r"].std()) - 1) < 1e-4
+
+
+def _policy_from_npz(z, prefix, dev, obs_dim=60, act_dim=8):
+    from safepo.common.model import ActorVCritic
+    pol = ActorVCritic(obs_dim, act_dim).to(dev)
+    sd = {k[len(prefix):]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith(prefix)}
+    pol.load_state_dict(sd)
+    return pol
+
+
+def test_policy_step_golden(dev, golden_dir):
+    z = np.load(os.path.join(golden_dir, "model.npz"))
+    pol = _policy_from_npz(z, "sd_", dev)
+    # flat vector is the reference parameter order
+    ref = R.OraclePolicy(60, 8)
+    ref.load_state_dict({k[3:]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith("sd_")})
+    assert np.array_equal(pol.theta.cpu().numpy(), R.flat_params(ref).numpy())
+    obs = torch.from_numpy(z["obs"]).to(dev)
+    act, logp, v_r, v_c = pol.step(obs, eps=torch.from_numpy(z["eps"]).to(dev))
+    np.testing.assert_allclose(act.cpu().numpy(), z["act"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(logp.cpu().numpy(), z["logp"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(v_r.cpu().numpy(), z["v_r"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(v_c.cpu().numpy(), z["v_c"], rtol=1e-5, atol=2e-6)
+    a, l, r5, c5 = pol.step(obs[5], deterministic=True)
+    np.testing.assert_allclose(r5.cpu().numpy(), z["row5_v_r"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(a.cpu().numpy(), z["act_det"][5], rtol=1e-5, atol=2e-6)
+    vr, vc = pol.values(obs)
+    np.testing.assert_allclose(vr.cpu().numpy(), z["v_r"], rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("obs_dim,act_dim,n", [(6, 2, 5), (17, 6, 70), (60, 8, 4096), (100, 16, 33), (33, 1, 64)])
+def test_policy_step_shapes_vs_oracle(dev, obs_dim, act_dim, n):
+    from safepo.common.model import ActorVCritic
+    torch.manual_seed(obs_dim)
+    pol = ActorVCritic(obs_dim, act_dim).to(dev)
+    with torch.no_grad():
+        pol.actor.log_std.copy_(torch.randn(act_dim) * 0.3)
+    ref = R.OraclePolicy(obs_dim, act_dim)
+    ref.load_state_dict({k: v.cpu().clone() for k, v in pol.state_dict().items()})
+    obs, eps = torch.randn(n, obs_dim), torch.randn(n, act_dim)
+    act, logp, v_r, v_c = pol.step(obs.to(dev), eps=eps.to(dev))
+    with torch.no_grad():
+        a, l, r, c = ref.step_with_eps(obs, eps)
+    np.testing.assert_allclose(act.cpu().numpy(), a.numpy(), rtol=1e-5, atol=3e-6)
+    np.testing.assert_allclose(logp.cpu().numpy(), l.numpy(), rtol=1e-5, atol=3e-5)
+    np.testing.assert_allclose(v_r.cpu().numpy(), r.numpy(), rtol=1e-5, atol=3e-6)
+    np.testing.assert_allclose(v_c.cpu().numpy(), c.numpy(), rtol=1e-5, atol=3e-6)
+
+
+def _load_epoch_into_engine(z, e, eng, dev):
+    b = eng.buffer
+    N, T = b.num_envs, b.size
+    for k in ("obs", "act", "reward", "cost", "value_r", "value_c", "log_prob"):
+        b.data[k].copy_(torch.from_numpy(z[f"e{e}_raw_{k}"]))
+    b.seg_end.copy_(torch.from_numpy(z[f"e{e}_seg_end"]))
+    b.boot_r.copy_(torch.from_numpy(z[f"e{e}_boot_r"]))
+    b.boot_c.copy_(torch.from_numpy(z[f"e{e}_boot_c"]))
+    b.ptr = T
+
+
+def test_ppo_lag_update_vs_reference_main_trace(dev, golden_dir):
+    """3 epochs of the reference ppo_lag.main(): same buffers, same shuffles, same initial weights ->
+    per-minibatch losses, early-stop iteration, KL and parameters after every epoch."""
+    from safepo.common.engine import PPOLagEngine
+    z = np.load(os.path.join(golden_dir, "ppo_lag_trace.npz"))
+    N, T, epochs = int(z["meta_num_envs"]), int(z["meta_T"]), int(z["meta_epochs"])
+    pol = _policy_from_npz(z, "init_sd_", dev)
+    cfg = {"hidden_sizes": [64, 64], "gamma": float(z["meta_cfg_gamma"]), "target_kl": float(z["meta_cfg_target_kl"]),
+           "batch_size": int(z["e0_batch_size"]), "learning_iters": int(z["meta_cfg_learning_iters"]),
+           "max_grad_norm": float(z["meta_cfg_max_grad_norm"])}
+    eng = PPOLagEngine(pol, N, T, cfg, dev)
+    for e in range(epochs):
+        sd = pol.state_dict()
+        for k in sd:
+            np.testing.assert_allclose(sd[k].cpu().numpy(), z[f"e{e}_sd_before_{k}"], rtol=2e-4, atol=2e-6, err_msg=f"e{e} {k}")
+        _load_epoch_into_engine(z, e, eng, dev)
+        lam = float(z[f"e{e}_row_Train_LagragianMultiplier"])
+        n_perm = len([k for k in z.files if k.startswith(f"e{e}_perm")])
+        perms = [torch.from_numpy(z[f"e{e}_perm{i}"].astype(np.int32)).to(dev) for i in range(n_perm)]
+        eng.lr_factor = 1.0 - e / epochs
+        out = eng.update(lam, perm_fn=lambda it: perms[min(it, n_perm - 1)])
+        b = eng.buffer
+        assert np.array_equal(b.data["target_value_r"].cpu().numpy(), z[f"e{e}_raw_target_value_r"])
+        np.testing.assert_allclose(b.data["adv_r"].cpu().numpy().reshape(-1), z[f"e{e}_get_adv_r"], rtol=1e-5, atol=2e-6)
+        got = torch.cat(out["losses"], 0).cpu().numpy()
+        ref = z[f"e{e}_mb_losses"]
+        assert out["stop_iter"] == int(z[f"e{e}_row_Train_StopIter"]), (out["stop_iter"], out["kl"])
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-6)
+        assert out["kl"] == pytest.approx(float(z[f"e{e}_row_Train_KL"]), rel=2e-3, abs=1e-7)
+    for k, v in pol.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), z[f"final_sd_{k}"], rtol=5e-4, atol=5e-6, err_msg=k)
+
+
+def _synthetic_update_problem(M, D, A, seed):
+    g = torch.Generator().manual_seed(seed)
+    obs = torch.randn(M, D, generator=g)
+    act = torch.randn(M, A, generator=g)
+    logp = -A * 0.9 - 0.5 * (act ** 2).sum(-1) + 0.1 * torch.randn(M, generator=g)
+    tgt_r, tgt_c = torch.randn(M, generator=g), torch.rand(M, generator=g)
+    adv = torch.randn(M, generator=g)
+    return obs, act, logp, tgt_r, tgt_c, adv
+
+
+@pytest.mark.parametrize("M,D,A,batch", [(256, 60, 8, 64), (150, 60, 8, 64), (200, 12, 2, 64), (64, 33, 5, 64),
+                                         (300, 60, 8, 128), (40, 20, 3, 64)])
+def test_minibatch_grad_and_step_vs_oracle(dev, M, D, A, batch):
+    """First-minibatch gradient (pre-clip), losses, and parameters after one full pass
+    (partial last batch included) against torch autograd + Adam on the CPU oracle."""
+    from safepo import _abi
+    from safepo.common.engine import PPOLagEngine
+    from safepo.common.model import ActorVCritic
+    torch.manual_seed(M + D)
+    pol = ActorVCritic(D, A).to(dev)
+    with torch.no_grad():
+        pol.actor.log_std.copy_(torch.randn(A) * 0.2)
+    ref = R.OraclePolicy(D, A)
+    ref.load_state_dict({k: v.cpu().clone() for k, v in pol.state_dict().items()})
+    obs, act, logp, tgt_r, tgt_c, adv = _synthetic_update_problem(M, D, A, seed=M)
+    cfg = {"hidden_sizes": [64, 64], "gamma": 0.99, "target_kl": 1e9, "batch_size": batch, "learning_iters": 1,
+           "max_grad_norm": 0.5 if M == 256 else 40.0}          # one case with the clip active
+    eng = PPOLagEngine(pol, 1, M, cfg, dev)
+    b = eng.buffer
+    b.data["obs"].copy_(obs.view(1, M, D)); b.data["act"].copy_(act.view(1, M, A))
+    b.data["log_prob"].copy_(logp.view(1, M)); b.data["target_value_r"].copy_(tgt_r.view(1, M))
+    b.data["target_value_c"].copy_(tgt_c.view(1, M)); b.adv_mix.copy_(adv.view(1, M))
+    perm = torch.randperm(M, generator=torch.Generator().manual_seed(3))
+    # --- split kernel: gradient of the first minibatch
+    c = eng._cfg_struct()
+    nb = min(batch, M)
+    idx = perm[:nb].to(torch.int32).to(dev)
+    d = b.data
+    _abi.check(eng.lib.spo_ppo_lag_grad(_abi.ptr(pol.theta), _abi.ptr(d["obs"]), _abi.ptr(d["act"]), _abi.ptr(d["log_prob"]),
+                                        _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]), _abi.ptr(b.adv_mix),
+                                        _abi.ptr(idx), nb, nb, c, _abi.ptr(eng.flat_grad), _abi.ptr(eng.losses3),
+                                        _abi.stream_ptr()), "grad")
+    upd = R.PPOLagUpdater(ref, epochs=1, max_grad_norm=cfg["max_grad_norm"])
+    ref0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    rec = {}
+    ii = perm[:nb]
+    l3 = upd.minibatch_step(obs[ii], act[ii], logp[ii], tgt_r[ii], tgt_c[ii], adv[ii], record=rec)
+    g_ref = rec["grad_preclip"].numpy()
+    g_got = eng.flat_grad.cpu().numpy()
+    scale = np.abs(g_ref).max()
+    np.testing.assert_allclose(g_got, g_ref, rtol=1e-4, atol=1e-5 * scale)
+    np.testing.assert_allclose(eng.losses3.cpu().numpy(), np.asarray(l3), rtol=1e-5, atol=1e-6)
+    # --- persistent kernel: one full pass, compare with the oracle restarted from the same weights
+    ref.load_state_dict(ref0)
+    upd = R.PPOLagUpdater(ref, epochs=1, max_grad_norm=cfg["max_grad_norm"])
+    losses_ref = []
+    for s in range(0, M, batch):
+        ii = perm[s:s + batch]
+        losses_ref.append(upd.minibatch_step(obs[ii], act[ii], logp[ii], tgt_r[ii], tgt_c[ii], adv[ii]))
+    losses = eng.learning_iter(perm.to(torch.int32).to(dev))
+    eng.check_sync_error()
+    np.testing.assert_allclose(losses.cpu().numpy(), np.asarray(losses_ref), rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(pol.theta.cpu().numpy(), R.flat_params(ref).numpy(), rtol=2e-4, atol=2e-6)
+    # optimiser state round-trips through adam_m / adam_v
+    m_ref = torch.cat([upd.opt_r.state[p]["exp_avg"].reshape(-1) for p in ref.reward_critic.parameters()])
+    np.testing.assert_allclose(eng.adam_m[:m_ref.numel()].cpu().numpy(), m_ref.numpy(), rtol=1e-3, atol=1e-7)
+
+
+def test_split_path_equals_persistent(dev):
+    """spo_ppo_lag_grad + spo_clip_adam (data-parallel form, world size 1) == persistent kernel."""
+    from safepo import _abi
+    from safepo.common.engine import PPOLagEngine
+    from safepo.common.model import ActorVCritic
+    M, D, A = 192, 60, 8
+    obs, act, logp, tgt_r, tgt_c, adv = _synthetic_update_problem(M, D, A, seed=1)
+    cfg = {"hidden_sizes": [64, 64], "gamma": 0.99, "target_kl": 1e9, "batch_size": 64, "learning_iters": 1, "max_grad_norm": 40.0}
+    thetas = []
+    for mode in ("persistent", "split"):
+        torch.manual_seed(5)
+        pol = ActorVCritic(D, A).to(dev)
+        eng = PPOLagEngine(pol, 1, M, cfg, dev)
+        b = eng.buffer
+        b.data["obs"].copy_(obs.view(1, M, D)); b.data["act"].copy_(act.view(1, M, A))
+        b.data["log_prob"].copy_(logp.view(1, M)); b.data["target_value_r"].copy_(tgt_r.view(1, M))
+        b.data["target_value_c"].copy_(tgt_c.view(1, M)); b.adv_mix.copy_(adv.view(1, M))
+        perm = torch.arange(M, dtype=torch.int32, device=dev).flip(0).contiguous()
+        if mode == "persistent":
+            eng.learning_iter(perm)
+        else:
+            c = eng._cfg_struct()
+            d = b.data
+            for k in range(M // 64):
+                _abi.check(eng.lib.spo_ppo_lag_grad(_abi.ptr(pol.theta), _abi.ptr(d["obs"]), _abi.ptr(d["act"]),
+                                                    _abi.ptr(d["log_prob"]), _abi.ptr(d["target_value_r"]),
+                                                    _abi.ptr(d["target_value_c"]), _abi.ptr(b.adv_mix),
+                                                    perm.data_ptr() + 4 * 64 * k, 64, 64, c, _abi.ptr(eng.flat_grad),
+                                                    _abi.ptr(eng.losses3), _abi.stream_ptr()), "grad")
+                _abi.check(eng.lib.spo_clip_adam(_abi.ptr(pol.theta), _abi.ptr(eng.adam_m), _abi.ptr(eng.adam_v),
+                                                 _abi.ptr(eng.flat_grad), k, 1.0, c, _abi.stream_ptr()), "adam")
+        thetas.append(pol.theta.cpu().numpy())
+    np.testing.assert_allclose(thetas[0], thetas[1], rtol=1e-5, atol=1e-7)
+
+
+def test_actor_kl_vs_oracle(dev):
+    from safepo.common.engine import PPOLagEngine
+    from safepo.common.model import ActorVCritic
+    torch.manual_seed(2)
+    M, D, A = 1000, 60, 8
+    pol = ActorVCritic(D, A).to(dev)
+    cfg = {"hidden_sizes": [64, 64], "gamma": 0.99, "target_kl": 0.02, "batch_size": 64, "learning_iters": 1, "max_grad_norm": 40.0}
+    eng = PPOLagEngine(pol, 1, M, cfg, dev)
+    obs = torch.randn(M, D)
+    eng.buffer.data["obs"].copy_(obs.view(1, M, D))
+    ref = R.OraclePolicy(D, A)
+    ref.load_state_dict({k: v.cpu().clone() for k, v in pol.state_dict().items()})
+    eng.snapshot_old_distribution()
+    with torch.no_grad():
+        od = ref.actor(obs)
+        old_mean, old_std = od.mean.clone(), od.stddev.clone()
+    np.testing.assert_allclose(eng.mean_old.cpu().numpy(), old_mean.numpy(), rtol=1e-5, atol=2e-6)
+    with torch.no_grad():
+        pol.theta.add_(0.01 * torch.randn_like(pol.theta))
+    ref.load_state_dict({k: v.cpu().clone() for k, v in pol.state_dict().items()})
+    kl = eng.kl_to_old()
+    assert kl == pytest.approx(R.actor_kl(ref, obs, old_mean, old_std), rel=1e-4)
+
+
+@pytest.mark.parametrize("n,steps", [(8, 32), (70, 20), (3, 130)])
+def test_collect_boundary_update_end_to_end(dev, n, steps):
+    from safepo.common.engine import smoke_check
+    smoke_check(num_envs=n, steps=steps, seed=n)
+
+
+def test_ppo_lag_main_entrypoint_synthetic(dev, tmp_path):
+    """safepo.single_agent.ppo_lag.main on the device-resident synthetic env: runs, logs the
+    reference's columns, writes progress.csv / config.json / torch_save/model0.pt."""
+    import argparse
+    import csv
+    from safepo.single_agent import ppo_lag
+    args = argparse.Namespace(seed=0, use_eval=False, task="SynthSafe-v0", num_envs=16, experiment="t",
+                              log_dir=str(tmp_path / "exp" / "task" / "run"), device="cuda", device_id=0,
+                              write_terminal=True, headless=False, total_steps=2 * 16 * 64, steps_per_epoch=16 * 64,
+                              randomize=False, cost_limit=25.0, lagrangian_multiplier_init=0.001,
+                              lagrangian_multiplier_lr=0.035, cfg_override={"learning_iters": 3},
+                              env_kwargs={"trunc_len": 16})
+    ppo_lag.main(args, {})
+    rows = list(csv.DictReader(open(tmp_path / "exp" / "task" / "run" / "progress.csv")))
+    assert len(rows) == 2
+    for col in ("Metrics/EpRet", "Metrics/EpCost", "Metrics/EpLen", "Train/Epoch", "Train/TotalSteps", "Train/StopIter",
+                "Train/KL", "Train/LagragianMultiplier", "Train/LR", "Loss/Loss_reward_critic", "Loss/Loss_cost_critic",
+                "Loss/Loss_actor", "Time/Rollout", "Time/Update", "Time/Total", "Value/RewardAdv", "Value/CostAdv"):
+        assert col in rows[0], col
+    assert float(rows[0]["Metrics/EpLen"]) == 16.0
+    sd = torch.load(tmp_path / "exp" / "task" / "run" / "torch_save" / "model0.pt")
+    assert set(sd) == {"log_std", "mean.0.weight", "mean.0.bias", "mean.2.weight", "mean.2.bias", "mean.4.weight", "mean.4.bias"}
+    assert os.path.exists(tmp_path / "exp" / "task" / "run" / "config.json")
+
+
+def test_library_is_loaded_from_tree(dev):
+    from safepo import _abi
+    _abi.load()
+    maps = open("/proc/self/maps").read()
+    assert "libsafepo_hip.so" in maps
