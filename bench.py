@@ -1,0 +1,223 @@
+"""bench.py -- env-steps/sec (collect + GAE + update) of the PPO-Lagrangian hot path.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one epoch of BASELINE.json config[1] per GPU: 4096 synthetic envs x 128 steps
+(obs 60, act 8), device-resident env, collect -> fused reward/cost GAE -> 40 learning iterations
+of 8192 minibatches of 64 (default_cfg of the reference, ppo_lag.py:45-52; KL early stopping
+disabled so the work per step is fixed).  N > 1: one process per GPU, 4096 envs per
+rank (weak scaling), flat-gradient all-reduce (RCCL) at every minibatch step.
+Prints ONE JSON line (rank 0) with the driver's fields plus `roofline` (GAE scan kernel, HBM
+bound, 33 algorithmic bytes per (env, step)) and `cpu_baseline` (oracle port of the reference
+loop timed on host cores, rank 0 at N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "safe-policy-optimization_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+GAE_BYTES_PER_ELEM = 33.0       # 4 f32 in + 1 u8 mask + 4 f32 out
+
+
+def cpu_baseline(sample_envs: int, T: int, threads: int = 4):
+    """Oracle port of the reference epoch (oracle/restatement.ppo_lag_epoch_port: per-env Python
+    store loop, per-path Python GAE, DataLoader minibatches, torch CPU) on a bounded sample of the
+    same workload: `sample_envs` envs x T steps, full default_cfg (batch 64, 40 iterations)."""
+    from collections import deque
+    from oracle import restatement as R
+    from oracle.synth_env import SynthEnv
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    cfg = {"gamma": 0.99, "target_kl": float("inf"), "batch_size": 64, "learning_iters": 40}
+    env = SynthEnv(sample_envs, 60, 8, seed=0, p_term=0.0, trunc_len=64)
+    pol = R.OraclePolicy(60, 8)
+    upd = R.PPOLagUpdater(pol, epochs=1)
+    lag = R.OracleLagrange(25.0, 0.001, 0.035)
+    stats = R.StatsLog()
+    obs, _ = env.reset()
+    obs = torch.as_tensor(obs)
+    timers = {}
+    t0 = time.time()
+    R.ppo_lag_epoch_port(env, pol, upd, lag, obs, sample_envs, T, stats,
+                         (deque(maxlen=50), deque(maxlen=50), deque(maxlen=50)),
+                         (np.zeros(sample_envs), np.zeros(sample_envs), np.zeros(sample_envs)), cfg, timers)
+    wall = time.time() - t0
+    steps = sample_envs * T
+    return {"value": steps / (timers["rollout"] + timers["update"]), "unit": "env-steps/s", "cores": threads,
+            "kind": "port",
+            "sample": f"1 epoch of {sample_envs} envs x {T} steps (={steps} env-steps), batch 64, 40 learning iters, "
+                      f"torch CPU {threads} threads; rollout {timers['rollout']:.2f}s update {timers['update']:.2f}s wall {wall:.2f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--num-envs", type=int, default=4096, help="envs PER GPU")
+    ap.add_argument("--num-steps", type=int, default=128)
+    ap.add_argument("--learning-iters", type=int, default=40)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-envs", type=int, default=32)
+    ap.add_argument("--stream-envs", type=int, default=262144, help="extra GAE roofline point that streams from HBM")
+    a = ap.parse_args()
+
+    from safepo import _abi
+    from safepo.common.engine import PPOLagEngine
+    from safepo.common.env import SynthDeviceEnv
+    from safepo.common.model import ActorVCritic
+    from safepo.parallel import init_from_env
+
+    comm = init_from_env()
+    world = comm.world_size
+    assert world == max(a.gpus, 1) or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    torch.manual_seed(0)
+    N, T, D, A = a.num_envs, a.num_steps, 60, 8
+    cfg = {"hidden_sizes": [64, 64], "gamma": 0.99, "target_kl": float("inf"), "batch_size": 64,
+           "learning_iters": a.learning_iters, "max_grad_norm": 40.0}
+    policy = ActorVCritic(D, A).to(dev)
+    comm.broadcast_(policy.theta, 0)
+    eng = PPOLagEngine(policy, N, T, cfg, dev, comm=comm)
+    env = SynthDeviceEnv(N, D, A, seed=1234 + comm.rank, p_term=0.0, p_cost=0.1, trunc_len=64, device=dev)
+    obs, _ = env.reset()
+    lam = 0.001
+    gae_events = []
+
+    def epoch(timed: bool):
+        nonlocal obs
+        t0 = time.time()
+        for t in range(T):
+            act = eng.collect_step(t, obs)
+            nobs, rew, cost, term, trunc, info = env.step(act)
+            eng.post_step(t, nobs, rew, cost, term, trunc, info["final_observation"])
+            obs = nobs
+        n_ep = eng.drain_episode_events(None)
+        torch.cuda.synchronize(dev)
+        t1 = time.time()
+        if timed:   # HIP events around the GAE scan kernel of this epoch (same stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            eng.buffer._gae_events = (e0, e1)
+            gae_events.append((e0, e1))
+        out = eng.update(lam)
+        eng.buffer._gae_events = None
+        torch.cuda.synchronize(dev)
+        t2 = time.time()
+        return t1 - t0, t2 - t1, out, n_ep
+
+    for _ in range(a.warmup):
+        epoch(False)
+    comm.barrier()
+    torch.cuda.synchronize(dev)
+    t_start = time.time()
+    roll = upd = 0.0
+    last = None
+    for _ in range(a.steps):
+        r, u, last, n_ep = epoch(True)
+        roll += r
+        upd += u
+    comm.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.time() - t_start
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    comm.all_reduce_max_(tmax)
+    elapsed = float(tmax.item())
+
+    if comm.rank != 0:
+        return
+    total_env_steps = world * N * T * a.steps
+    value = total_env_steps / elapsed
+    n_mb = (N * T + 63) // 64
+    gae_ms = [e0.elapsed_time(e1) for e0, e1 in gae_events]
+    gae_avg_s = (sum(gae_ms) / len(gae_ms)) * 1e-3 if gae_ms else float("nan")
+    seg_ends = int(eng.buffer.seg_end.sum().item())
+    gae_bytes = GAE_BYTES_PER_ELEM * N * T + 8.0 * seg_ends
+    achieved = gae_bytes / gae_avg_s / 1e9
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_gae_pmc.json")
+    if os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch_n4096")
+        except Exception:
+            traffic = None
+    roofline = {"kernel": "gae_kernel<4,32> (spo_gae_fused)", "bound": "hbm", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "bytes_per_launch": gae_bytes, "avg_launch_us": round(gae_avg_s * 1e6, 2), "launches_timed": len(gae_ms)}
+
+    # extra roofline point on a buffer that cannot sit in the 256 MiB Infinity Cache (untimed, after the run)
+    stream = None
+    try:
+        from safepo.common.buffer import VectorizedOnPolicyBuffer
+        from safepo.common.engine import _Space
+        Ns = a.stream_envs
+        big = VectorizedOnPolicyBuffer(_Space(1), _Space(1), size=T, num_envs=Ns, device=dev)
+        for k in ("reward", "cost", "value_r", "value_c"):
+            big.data[k].normal_()
+        big.seg_end[:, T - 1] = 1
+        big.seg_end[:, T // 2 - 1] = 1
+        big.compute_gae(None)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        d = big.data
+        e0.record()
+        for _ in range(reps):
+            _abi.check(big._lib.spo_gae_fused(
+                _abi.ptr(d["reward"]), _abi.ptr(d["cost"]), _abi.ptr(d["value_r"]), _abi.ptr(d["value_c"]),
+                _abi.ptr(big.seg_end), _abi.ptr(big.boot_r), _abi.ptr(big.boot_c), _abi.ptr(d["adv_r"]),
+                _abi.ptr(d["adv_c"]), _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]),
+                _abi.ptr(big._partials), Ns, T, 0.99, 0.95, 0.95, _abi.stream_ptr()), "gae")
+        e1.record()
+        torch.cuda.synchronize(dev)
+        t_s = e0.elapsed_time(e1) * 1e-3 / reps
+        b = GAE_BYTES_PER_ELEM * Ns * T + 8.0 * 2 * Ns
+        stream = {"num_envs": Ns, "bytes_per_launch": b, "avg_launch_us": round(t_s * 1e6, 1),
+                  "achieved": round(b / t_s / 1e9, 1), "unit": "GB/s", "frac": round(b / t_s / 1e9 / HBM_PEAK_GBS, 4)}
+        del big
+    except Exception as e:  # pragma: no cover
+        stream = {"error": str(e)[:200]}
+
+    cpu = None
+    if world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.cpu_sample_envs, T)
+
+    line = {
+        "metric": "env-steps/sec (collect+GAE+update) at num_envs=4096, 1/2/4/8 GPU",
+        "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"ppo_lag synthetic env (obs=60, act=8), num_envs={N} per GPU, num_steps={T}, "
+                               f"default_cfg batch 64 x {a.learning_iters} learning iters (target_kl=inf: all iters run), "
+                               f"device-resident env", "global_envs": world * N,
+                   "parallelism": f"dp{world} over num_envs, per-minibatch flat-grad all-reduce" if world > 1 else "single GPU",
+                   "minibatch_steps_per_epoch": n_mb * a.learning_iters},
+        "roofline": roofline,
+        "roofline_hbm_streaming": stream,
+        "cpu_baseline": cpu,
+        "phases": {"rollout_s_per_epoch": round(roll / a.steps, 4), "update_s_per_epoch": round(upd / a.steps, 4),
+                   "update_us_per_minibatch_step": round(upd / a.steps / (n_mb * a.learning_iters) * 1e6, 3),
+                   "stop_iter": last["stop_iter"], "kl": last["kl"], "episodes_per_epoch": n_ep},
+    }
+    if cpu:
+        line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

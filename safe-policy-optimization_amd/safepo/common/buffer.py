@@ -82,11 +82,16 @@ class VectorizedOnPolicyBuffer:
         `comm`: optional safepo.parallel.Comm -- statistics are all-reduced over the env shards."""
         d, lib, st = self.data, self._lib, _abi.stream_ptr()
         N, T = self.num_envs, self.size
+        ev = getattr(self, "_gae_events", None)      # optional (start, end) HIP events around the scan (bench.py)
+        if ev:
+            ev[0].record()
         _abi.check(lib.spo_gae_fused(
             _abi.ptr(d["reward"]), _abi.ptr(d["cost"]), _abi.ptr(d["value_r"]), _abi.ptr(d["value_c"]),
             _abi.ptr(self.seg_end), _abi.ptr(self.boot_r), _abi.ptr(self.boot_c), _abi.ptr(d["adv_r"]),
             _abi.ptr(d["adv_c"]), _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]),
             _abi.ptr(self._partials), N, T, self._gamma, self._lam, self._lam_c, st), "spo_gae_fused")
+        if ev:
+            ev[1].record()
         _abi.check(lib.spo_adv_reduce(_abi.ptr(self._partials), self._partials.shape[0], _abi.ptr(self.sums), st),
                    "spo_adv_reduce")
         if comm is not None and comm.world_size > 1:
