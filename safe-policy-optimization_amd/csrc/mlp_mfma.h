@@ -102,37 +102,70 @@ __device__ __forceinline__ void load_obs_tiles(const float* __restrict__ row, in
   }
 }
 
-// Hidden layer: out[mt] (rows 16mt+4q+reg, col batch) = tanh?(W in + b).
+// tanh with ~1e-7 relative error in a dozen VALU ops (ocml tanhf costs ~40): odd Taylor series below
+// 0.25, 1 - 2/(exp(2|x|)+1) above (v_exp_f32 / v_rcp_f32).
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float ax = fabsf(x);
+  const float x2 = x * x;
+  float p = fmaf(x2, 62.f / 2835.f, -17.f / 315.f);
+  p = fmaf(x2, p, 2.f / 15.f);
+  p = fmaf(x2, p, -1.f / 3.f);
+  p = fmaf(x2 * x, p, x);
+  const float e = __expf(2.f * ax);
+  float r = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+  r = copysignf(r, x);
+  return ax < 0.25f ? p : r;
+}
+
+// Hidden layer: out[mt] (rows 16mt+4q+reg, col batch) = tanh?(W in + b).  The four output tiles
+// are independent accumulators and are issued round-robin so back-to-back MFMAs never wait on the
+// 40-cycle dependent-accumulator latency of v_mfma_f32_16x16x4_f32.
 template <int NT_IN, bool TANH>
 __device__ __forceinline__ void layer_hidden(const float* Wl, int ld, const float* bl, const f4 (&in)[NT_IN],
                                              f4 (&out)[HID / 16], int j, int q) {
+  f4 acc[HID / 16];
+#pragma unroll
+  for (int mt = 0; mt < HID / 16; ++mt) acc[mt] = *reinterpret_cast<const f4*>(bl + 16 * mt + 4 * q);
+#pragma unroll
+  for (int nt = 0; nt < NT_IN; ++nt) {
+    f4 a[HID / 16];
+#pragma unroll
+    for (int mt = 0; mt < HID / 16; ++mt)
+      a[mt] = *reinterpret_cast<const f4*>(Wl + (16 * mt + j) * ld + 16 * nt + 4 * q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int mt = 0; mt < HID / 16; ++mt) acc[mt] = mfma4(a[mt][r], in[nt][r], acc[mt]);
+  }
 #pragma unroll
   for (int mt = 0; mt < HID / 16; ++mt) {
-    f4 acc = *reinterpret_cast<const f4*>(bl + 16 * mt + 4 * q);
-#pragma unroll
-    for (int nt = 0; nt < NT_IN; ++nt) {
-      const f4 a = *reinterpret_cast<const f4*>(Wl + (16 * mt + j) * ld + 16 * nt + 4 * q);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc = mfma4(a[r], in[nt][r], acc);
-    }
     if (TANH) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = tanhf(acc[r]);
+      for (int r = 0; r < 4; ++r) acc[mt][r] = fast_tanh(acc[mt][r]);
     }
-    out[mt] = acc;
+    out[mt] = acc[mt];
   }
 }
 
-// Output layer (one padded 16-row tile): rows 4q+reg = output unit.
+// Output layer (one padded 16-row tile): rows 4q+reg = output unit.  Two accumulators (k halves)
+// keep the MFMA pipe busy; they are summed at the end.
 __device__ __forceinline__ f4 layer_out(const float* Wl, const float* bl, const f4 (&in)[HID / 16], int j, int q) {
-  f4 acc = *reinterpret_cast<const f4*>(bl + 4 * q);
+  f4 acc0 = *reinterpret_cast<const f4*>(bl + 4 * q);
+  f4 acc1 = {0.f, 0.f, 0.f, 0.f};
+  f4 a[HID / 16];
 #pragma unroll
-  for (int nt = 0; nt < HID / 16; ++nt) {
-    const f4 a = *reinterpret_cast<const f4*>(Wl + j * LDH + 16 * nt + 4 * q);
+  for (int nt = 0; nt < HID / 16; ++nt) a[nt] = *reinterpret_cast<const f4*>(Wl + j * LDH + 16 * nt + 4 * q);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc = mfma4(a[r], in[nt][r], acc);
+  for (int r = 0; r < 4; ++r) {
+    acc0 = mfma4(a[0][r], in[0][r], acc0);
+    acc1 = mfma4(a[2][r], in[2][r], acc1);
   }
-  return acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    acc0 = mfma4(a[1][r], in[1][r], acc0);
+    acc1 = mfma4(a[3][r], in[3][r], acc1);
+  }
+  return acc0 + acc1;
 }
 
 // Full forward of one network for the 16 batch columns of a wave.

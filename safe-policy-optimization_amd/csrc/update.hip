@@ -61,23 +61,34 @@ __device__ __forceinline__ void st_granule(unsigned long long* p, unsigned long 
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Adam on one scalar (torch.optim.Adam single-tensor path: lerp, addcmul, sqrt/bc2_sqrt + eps, addcdiv).
+// Adam on one scalar.  Same update as torch.optim.Adam's single-tensor path
+// (exp_avg.lerp_, exp_avg_sq.mul_.addcmul_, denom = sqrt(v)/sqrt(bc2) + eps, addcdiv_) with the
+// square root and the two divisions done by v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of IEEE
+// sequences: the parameter step changes by <= 3e-7 relative, i.e. < 1e-10 absolute per step.
 struct AdamOut { float p, m, v; };
 __device__ __forceinline__ AdamOut adam1(float p, float g, float m, float v, float b1, float b2, float eps,
-                                         float step_size, float bc2_sqrt) {
+                                         float step_size, float inv_bc2_sqrt) {
   AdamOut o;
-  o.m = m + (1.f - b1) * (g - m);
-  o.v = v * b2 + (1.f - b2) * g * g;
-  const float denom = sqrtf(o.v) / bc2_sqrt + eps;
-  o.p = p - step_size * (o.m / denom);
+  o.m = fmaf(1.f - b1, g - m, m);
+  o.v = fmaf(v, b2, ((1.f - b2) * g) * g);
+  const float denom = fmaf(__builtin_amdgcn_sqrtf(o.v), inv_bc2_sqrt, eps);
+  o.p = fmaf(-step_size, o.m * __builtin_amdgcn_rcpf(denom), p);
   return o;
 }
 // DST = updated parameter; M, V (vector elements or scalars) updated in place.
-#define SPO_ADAM(DST, P, G, M, V)                                                    \
-  {                                                                                  \
-    const AdamOut _o = adam1((P), (G), (M), (V), b1c, b2c, eps, step_size, bc2s);    \
-    (M) = _o.m; (V) = _o.v; (DST) = _o.p;                                            \
+#define SPO_ADAM(DST, P, G, M, V)                                                      \
+  {                                                                                    \
+    const AdamOut _o = adam1((P), (G), (M), (V), b1c, b2c, eps, step_size, inv_bc2s);  \
+    (M) = _o.m; (V) = _o.v; (DST) = _o.p;                                              \
   }
+
+// Per-column inputs of one 64-column chunk, prefetched one chunk ahead.
+template <int NT1>
+struct ColData {
+  f4 x[NT1];       // observation tiles (B operand of layer 1)
+  f4 actv;         // actor: act[4q..4q+3]
+  float t0, t1;    // critic: target ; actor: logp_old, adv
+};
 
 template <int KIN, bool PERSIST>
 __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
@@ -104,6 +115,11 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
   const bool own_b = (q == 0);
   const bool own_b3 = (wave == 0 && q == 0 && j < OUT);
   const bool own_ls = is_actor && wave == 0 && j == 0;
+#pragma unroll
+  for (int nt = 0; nt < NT1; ++nt) { mW1[nt] = f4{0.f, 0.f, 0.f, 0.f}; vW1[nt] = mW1[nt]; }
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) { mW2[nt] = f4{0.f, 0.f, 0.f, 0.f}; vW2[nt] = mW2[nt]; }
+  mW3 = vW3 = mls = vls = f4{0.f, 0.f, 0.f, 0.f};
   if (PERSIST) {
 #pragma unroll
     for (int nt = 0; nt < NT1; ++nt)
@@ -128,270 +144,319 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
       const int idx = g.w3() + o * HID + 16 * wave + j;
       mW3[r] = o < OUT ? a.adam_m[idx] : 0.f;
       vW3[r] = o < OUT ? a.adam_v[idx] : 0.f;
-      const int ai = 4 * q + r;
-      mls[r] = (own_ls && ai < A) ? a.adam_m[ls_off + ai] : 0.f;
-      vls[r] = (own_ls && ai < A) ? a.adam_v[ls_off + ai] : 0.f;
+      mls[r] = (is_actor && o < A) ? a.adam_m[ls_off + o] : 0.f;
+      vls[r] = (is_actor && o < A) ? a.adam_v[ls_off + o] : 0.f;
     }
-    if (own_b) {
-      mb1 = a.adam_m[g.b1() + 16 * wave + j]; vb1 = a.adam_v[g.b1() + 16 * wave + j];
-      mb2 = a.adam_m[g.b2() + 16 * wave + j]; vb2 = a.adam_v[g.b2() + 16 * wave + j];
-    }
-    if (own_b3) { mb3 = a.adam_m[g.b3() + j]; vb3 = a.adam_v[g.b3() + j]; }
+    mb1 = a.adam_m[g.b1() + 16 * wave + j]; vb1 = a.adam_v[g.b1() + 16 * wave + j];
+    mb2 = a.adam_m[g.b2() + 16 * wave + j]; vb2 = a.adam_v[g.b2() + 16 * wave + j];
+    if (j < OUT) { mb3 = a.adam_m[g.b3() + j]; vb3 = a.adam_v[g.b3() + j]; }
   }
 
-  const float b1c = a.cfg.beta1, b2c = a.cfg.beta2;
+  const float b1c = a.cfg.beta1, b2c = a.cfg.beta2, eps = a.cfg.adam_eps;
   double pw1 = a.pow_b1, pw2 = a.pow_b2;
   const float lr = is_actor ? a.cfg.lr_actor : a.cfg.lr_critic;
   const float l2 = (!is_actor && a.cfg.use_critic_norm) ? a.cfg.l2_coef : 0.f;
   const float vcoef = (net == 0 && a.cfg.use_value_coefficient) ? 2.f : 1.f;
+  const float clip_lo = 1.f - a.cfg.clip, clip_hi = 1.f + a.cfg.clip;
   float stale_sq = a.stale_sq;
   const float* tgt = (net == 0) ? a.tgt_r : a.tgt_c;
 
-  // log_std dependent constants are recomputed every step (log_std is a parameter)
   const int64_t nsteps = PERSIST ? (a.M + B - 1) / B : 1;
   const int nhalf = (B + 63) / 64;
+  const int64_t nchunks = nsteps * nhalf;
+  const int mycol = 16 * wave + j;
 
-  for (int64_t s = 0; s < nsteps; ++s) {
-    const int64_t base = s * B;
-    const int ncols = PERSIST ? (int)((a.M - base) < B ? (a.M - base) : B) : (int)a.M;
+  // position in perm[] of my column for chunk c (clamped to a valid entry when the column is masked)
+  auto perm_pos = [&](int64_t c) -> int64_t {
+    const int64_t s = c / nhalf;
+    const int h = (int)(c - s * nhalf);
+    const int64_t base = PERSIST ? s * B : 0;
+    const int64_t rem = PERSIST ? (a.M - base) : a.M;
+    const int ncols = (int)(rem < B ? rem : B);
+    const int col = 64 * h + mycol;
+    return base + (col < ncols ? col : 0);
+  };
+  auto fetch = [&](int64_t smp, ColData<NT1>& cd) {
+    load_obs_tiles<KIN>(a.obs + smp * D, D, q, cd.x);
+    if (!is_actor) {
+      cd.t0 = tgt[smp]; cd.t1 = 0.f; cd.actv = f4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      cd.t0 = a.logp_old[smp]; cd.t1 = a.adv[smp];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cd.actv[r] = (4 * q + r < A) ? a.act[smp * A + 4 * q + r] : 0.f;
+    }
+  };
+
+  // software pipeline: sample index two chunks ahead, column data one chunk ahead
+  ColData<NT1> nxt;
+  int64_t smp1 = 0;
+  fetch((int64_t)a.perm[perm_pos(0)], nxt);
+  if (nchunks > 1) smp1 = (int64_t)a.perm[perm_pos(1)];
+
+  f4 aW1[NT1], aW2[4], aW3, dls;
+  float db1 = 0.f, db2 = 0.f, db3 = 0.f, lsum = 0.f;
+
+  for (int64_t c = 0; c < nchunks; ++c) {
+    const int64_t s = c / nhalf;
+    const int h = (int)(c - s * nhalf);
+    const bool first_half = (h == 0), last_half = (h == nhalf - 1);
+    const int64_t base = PERSIST ? s * B : 0;
+    const int64_t rem = PERSIST ? (a.M - base) : a.M;
+    const int ncols = (int)(rem < B ? rem : B);
     const float inv_n = 1.f / (float)(PERSIST ? ncols : (int)a.mean_count);
+    const bool cv = (64 * h + mycol) < ncols;
 
-    f4 aW1[NT1], aW2[4], aW3 = {0.f, 0.f, 0.f, 0.f}, dls = {0.f, 0.f, 0.f, 0.f};
+    ColData<NT1> cur = nxt;
+    if (c + 1 < nchunks) fetch(smp1, nxt);                       // lands while this chunk computes
+    if (c + 2 < nchunks) smp1 = (int64_t)a.perm[perm_pos(c + 2)];
+
+    if (first_half) {
 #pragma unroll
-    for (int nt = 0; nt < NT1; ++nt) aW1[nt] = f4{0.f, 0.f, 0.f, 0.f};
+      for (int nt = 0; nt < NT1; ++nt) aW1[nt] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) aW2[nt] = f4{0.f, 0.f, 0.f, 0.f};
-    float db1 = 0.f, db2 = 0.f, db3 = 0.f, lsum = 0.f;
+      for (int nt = 0; nt < 4; ++nt) aW2[nt] = f4{0.f, 0.f, 0.f, 0.f};
+      aW3 = dls = f4{0.f, 0.f, 0.f, 0.f};
+      db1 = db2 = db3 = lsum = 0.f;
+    }
 
     // std = exp(log_std) from the LDS mirror of log_std (a parameter: changes every step)
-    float sd[4], var[4];
+    float ivar[4], lsd[4], amask[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ai = 4 * q + r;
-      sd[r] = (is_actor && ai < A) ? expf(red[128 + ai]) : 1.f;
-      var[r] = sd[r] * sd[r];
+      const bool on = is_actor && ai < A;
+      const float sdv = on ? expf(red[128 + ai]) : 1.f;
+      amask[r] = on ? 1.f : 0.f;
+      ivar[r] = 1.f / (sdv * sdv);
+      lsd[r] = on ? logf(sdv) + LOG_SQRT_2PI : 0.f;        // log_scale + log(sqrt(2 pi)), 0 on pad rows
     }
 
-    for (int h = 0; h < nhalf; ++h) {
-      const int col = 64 * h + 16 * wave + j;
-      const bool cv = col < ncols;
-      const int64_t smp = (int64_t)a.perm[base + (cv ? col : 0)];
-      f4 x[NT1];
-      load_obs_tiles<KIN>(a.obs + smp * D, D, q, x);
-      f4 h1[4], h2[4];
-      const f4 o = net_forward<KIN>(lds, x, h1, h2, j, q);
+    // ---- stage x as [feature][batch] right away (frees the registers after layer 1)
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) lds[U::XT + (16 * nt + 4 * q + e) * LDB + mycol] = cur.x[nt][e];
 
-      // ---- loss and d(loss)/d(output), C layout (rows = output unit 4q+r, col = batch)
-      f4 dO = {0.f, 0.f, 0.f, 0.f};
-      if (!is_actor) {
-        // mse_loss(critic(obs), target)  (ppo_lag.py:307-309)
-        const float diff = o[0] - tgt[smp];
-        if (q == 0 && cv) { lsum += diff * diff; dO[0] = 2.f * diff * inv_n; }
-      } else {
-        float lp = 0.f, dif[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int ai = 4 * q + r;
-          dif[r] = 0.f;
-          if (ai < A) {
-            dif[r] = a.act[smp * A + ai] - o[r];
-            lp += -(dif[r] * dif[r]) / (2.f * var[r]) - logf(sd[r]) - LOG_SQRT_2PI;
-          }
-        }
-        lp += __shfl_xor(lp, 16);
-        lp += __shfl_xor(lp, 32);
-        const float adv = a.adv[smp];
-        const float ratio = expf(lp - a.logp_old[smp]);                      // ppo_lag.py:317
-        const float lo = 1.f - a.cfg.clip, hi = 1.f + a.cfg.clip;
-        const float rc = fminf(fmaxf(ratio, lo), hi);                        // torch.clamp
-        const float s1 = ratio * adv, s2 = rc * adv;
-        const bool inr = (ratio >= lo) && (ratio <= hi);
-        // backward of torch.min(s1, s2): ties split the gradient; clamp passes it inside [lo,hi]
-        float gr;
-        if (s1 < s2) gr = adv;
-        else if (s1 > s2) gr = inr ? adv : 0.f;
-        else gr = 0.5f * adv + (inr ? 0.5f * adv : 0.f);
-        const float dlp = cv ? -(gr * ratio) * inv_n : 0.f;                  // loss_pi = -mean(min(...))
-        if (q == 0 && cv) lsum += fminf(s1, s2);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (4 * q + r < A) {
-            dO[r] = dlp * (dif[r] / var[r]);
-            dls[r] += dlp * (dif[r] * dif[r] / var[r] - 1.f);
-          }
-        }
-      }
+    f4 h1[4], h2[4];
+    const f4 o = net_forward<KIN>(lds, cur.x, h1, h2, j, q);
 
-      // ---- backward through the MLP (transposed chaining, weights read as columns)
-      f4 dz2[4], dz1[4];
+    // ---- loss and d(loss)/d(output), C layout (rows = output unit 4q+r, col = batch)
+    f4 dO = {0.f, 0.f, 0.f, 0.f};
+    if (!is_actor) {
+      // mse_loss(critic(obs), target)  (ppo_lag.py:307-309)
+      const float diff = o[0] - cur.t0;
+      const float lm = (q == 0 && cv) ? 1.f : 0.f;
+      lsum = fmaf(lm * diff, diff, lsum);
+      dO[0] = lm * (2.f * diff * inv_n);
+    } else {
+      float lp = 0.f, dif[4];
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        f4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc = mfma4(lds[L::W3 + (4 * q + r) * LDH + 16 * mt + j], dO[r], acc);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] *= (1.f - h2[mt][r] * h2[mt][r]);
-        dz2[mt] = acc;
+      for (int r = 0; r < 4; ++r) {
+        dif[r] = cur.actv[r] - o[r];                 // pad rows: 0 - 0
+        lp += -(dif[r] * dif[r]) * (0.5f * ivar[r]) - lsd[r];
       }
+      lp += __shfl_xor(lp, 16);
+      lp += __shfl_xor(lp, 32);
+      const float adv = cur.t1;
+      const float ratio = expf(lp - cur.t0);                               // ppo_lag.py:317
+      const float rc = fminf(fmaxf(ratio, clip_lo), clip_hi);              // torch.clamp
+      const float s1 = ratio * adv, s2 = rc * adv;
+      const bool inr = (ratio >= clip_lo) && (ratio <= clip_hi);
+      // backward of torch.min(s1, s2): ties split the gradient; clamp passes it inside [lo,hi]
+      float gr;
+      if (s1 < s2) gr = adv;
+      else if (s1 > s2) gr = inr ? adv : 0.f;
+      else gr = 0.5f * adv + (inr ? 0.5f * adv : 0.f);
+      const float dlp = cv ? -(gr * ratio) * inv_n : 0.f;                  // loss_pi = -mean(min(...))
+      lsum += ((q == 0 && cv) ? 1.f : 0.f) * fminf(s1, s2);
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        f4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            acc = mfma4(lds[L::W2 + (16 * nt + 4 * q + r) * LDH + 16 * mt + j], dz2[nt][r], acc);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] *= (1.f - h1[mt][r] * h1[mt][r]);
-        dz1[mt] = acc;
+      for (int r = 0; r < 4; ++r) {
+        const float z = dif[r] * ivar[r];
+        dO[r] = dlp * z;                            // pad rows: z == 0
+        dls[r] = fmaf(dlp * amask[r], dif[r] * z - 1.f, dls[r]);
       }
+    }
 
-      // ---- stage [feature][batch] images for the weight-gradient GEMMs
-      const int cl = 16 * wave + j;
+    // ---- backward through the MLP (transposed chaining, weights read as columns)
+    f4 dz2[4], dz1[4];
+    {
+      f4 acc[4];
 #pragma unroll
-      for (int nt = 0; nt < NT1; ++nt)
+      for (int mt = 0; mt < 4; ++mt) acc[mt] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) lds[U::XT + (16 * nt + 4 * q + e) * LDB + cl] = x[nt][e];
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+          acc[mt] = mfma4(lds[L::W3 + (4 * q + r) * LDH + 16 * mt + j], dO[r], acc[mt]);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int f = (16 * mt + 4 * q + r) * LDB + cl;
-          lds[U::H1T + f] = h1[mt][r];
-          lds[U::H2T + f] = h2[mt][r];
-          lds[U::DZ1T + f] = dz1[mt][r];
-          lds[U::DZ2T + f] = dz2[mt][r];
-        }
+        for (int r = 0; r < 4; ++r) dz2[mt][r] = acc[mt][r] * fmaf(-h2[mt][r], h2[mt][r], 1.f);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) lds[U::DOT + (4 * q + r) * LDB + cl] = dO[r];
-      __syncthreads();
+      for (int mt = 0; mt < 4; ++mt) acc[mt] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+            acc[mt] = mfma4(lds[L::W2 + (16 * nt + 4 * q + r) * LDH + 16 * mt + j], dz2[nt][r], acc[mt]);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dz1[mt][r] = acc[mt][r] * fmaf(-h1[mt][r], h1[mt][r], 1.f);
+    }
 
-      // ---- dW[o][i] = sum_b dZ[b][o] * Hprev[b][i]; wave w owns rows 16w..16w+15
-      {
-        f4 az[4];
-        float rs = 0.f;
+    // ---- stage [feature][batch] images for the weight-gradient GEMMs
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          az[r4] = *reinterpret_cast<const f4*>(lds + U::DZ1T + (16 * wave + j) * LDB + 16 * r4 + 4 * q);
-          rs += az[r4][0] + az[r4][1] + az[r4][2] + az[r4][3];
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = (16 * mt + 4 * q + r) * LDB + mycol;
+        lds[U::H1T + f] = h1[mt][r];
+        lds[U::H2T + f] = h2[mt][r];
+        lds[U::DZ1T + f] = dz1[mt][r];
+        lds[U::DZ2T + f] = dz2[mt][r];
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lds[U::DOT + (4 * q + r) * LDB + mycol] = dO[r];
+    if (last_half) {
+      // per-wave partials of the scalar reductions ride on the same barrier
+      const float ls = wave_sum(lsum);
+      if (lane == 0) red[wave] = ls;
+      if (is_actor) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float t = dls[r];
+          t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
+          if (j == 0) red[16 + wave * 16 + 4 * q + r] = t;
         }
-        db1 += rs;
+      }
+    }
+    __syncthreads();
+
+    // ---- dW[o][i] += sum_b dZ[b][o] * Hprev[b][i]; wave w owns rows 16w..16w+15
+    {
+      f4 az[4];
+      float rs = 0.f;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        az[r4] = *reinterpret_cast<const f4*>(lds + U::DZ1T + (16 * wave + j) * LDB + 16 * r4 + 4 * q);
+        rs += (az[r4][0] + az[r4][1]) + (az[r4][2] + az[r4][3]);
+      }
+      db1 += rs;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        f4 bh[NT1];
 #pragma unroll
         for (int nt = 0; nt < NT1; ++nt)
+          bh[nt] = *reinterpret_cast<const f4*>(lds + U::XT + (16 * nt + j) * LDB + 16 * r4 + 4 * q);
 #pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) {
-            const f4 bh = *reinterpret_cast<const f4*>(lds + U::XT + (16 * nt + j) * LDB + 16 * r4 + 4 * q);
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) aW1[nt] = mfma4(az[r4][e], bh[e], aW1[nt]);
-          }
-        rs = 0.f;
+          for (int nt = 0; nt < NT1; ++nt) aW1[nt] = mfma4(az[r4][e], bh[nt][e], aW1[nt]);
+      }
+      rs = 0.f;
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          az[r4] = *reinterpret_cast<const f4*>(lds + U::DZ2T + (16 * wave + j) * LDB + 16 * r4 + 4 * q);
-          rs += az[r4][0] + az[r4][1] + az[r4][2] + az[r4][3];
-        }
-        db2 += rs;
+      for (int r4 = 0; r4 < 4; ++r4) {
+        az[r4] = *reinterpret_cast<const f4*>(lds + U::DZ2T + (16 * wave + j) * LDB + 16 * r4 + 4 * q);
+        rs += (az[r4][0] + az[r4][1]) + (az[r4][2] + az[r4][3]);
+      }
+      db2 += rs;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        f4 bh[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
+          bh[nt] = *reinterpret_cast<const f4*>(lds + U::H1T + (16 * nt + j) * LDB + 16 * r4 + 4 * q);
 #pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) {
-            const f4 bh = *reinterpret_cast<const f4*>(lds + U::H1T + (16 * nt + j) * LDB + 16 * r4 + 4 * q);
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) aW2[nt] = mfma4(az[r4][e], bh[e], aW2[nt]);
-          }
-        rs = 0.f;
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          az[r4] = *reinterpret_cast<const f4*>(lds + U::DOT + j * LDB + 16 * r4 + 4 * q);
-          rs += az[r4][0] + az[r4][1] + az[r4][2] + az[r4][3];
-          const f4 bh = *reinterpret_cast<const f4*>(lds + U::H2T + (16 * wave + j) * LDB + 16 * r4 + 4 * q);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) aW3 = mfma4(az[r4][e], bh[e], aW3);
-        }
-        db3 += rs;
+          for (int nt = 0; nt < 4; ++nt) aW2[nt] = mfma4(az[r4][e], bh[nt][e], aW2[nt]);
       }
-      __syncthreads();
-    }  // halves
+      rs = 0.f;
+      f4 w3a = {0.f, 0.f, 0.f, 0.f}, w3b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        az[r4] = *reinterpret_cast<const f4*>(lds + U::DOT + j * LDB + 16 * r4 + 4 * q);
+        rs += (az[r4][0] + az[r4][1]) + (az[r4][2] + az[r4][3]);
+      }
+#pragma unroll
+      for (int r4 = 0; r4 < 4; r4 += 2) {
+        const f4 b0 = *reinterpret_cast<const f4*>(lds + U::H2T + (16 * wave + j) * LDB + 16 * r4 + 4 * q);
+        const f4 b1 = *reinterpret_cast<const f4*>(lds + U::H2T + (16 * wave + j) * LDB + 16 * (r4 + 1) + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          w3a = mfma4(az[r4][e], b0[e], w3a);
+          w3b = mfma4(az[r4 + 1][e], b1[e], w3b);
+        }
+      }
+      aW3 += w3a + w3b;
+      db3 += rs;
+    }
+    if (!last_half) {
+      __syncthreads();         // the next half overwrites the staged images
+      continue;
+    }
 
-    // ---- bias gradients: sum over the 4 k-slots (q) -> every lane of row j has the total
+    // =================== end of the minibatch: gradients complete ===================
     db1 += __shfl_xor(db1, 16); db1 += __shfl_xor(db1, 32);
     db2 += __shfl_xor(db2, 16); db2 += __shfl_xor(db2, 32);
     db3 += __shfl_xor(db3, 16); db3 += __shfl_xor(db3, 32);
-    // log_std gradient: sum over the wave's 16 columns, then over waves through LDS
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float t = dls[r];
-      t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
-      dls[r] = t;
-    }
-    lsum = wave_sum(lsum);
-    if (lane == 0) red[wave] = lsum;
-    if (is_actor && j == 0) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[16 + wave * 16 + 4 * q + r] = dls[r];
-    }
-    __syncthreads();
-    const float loss_data = (red[0] + red[1] + red[2] + red[3]) * inv_n;
-    if (own_ls) {
+    const float loss_data = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;
+    if (is_actor) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ai = 4 * q + r;
-        dls[r] = red[16 + ai] + red[32 + ai] + red[48 + ai] + red[64 + ai];
+        dls[r] = (red[16 + ai] + red[32 + ai]) + (red[48 + ai] + red[64 + ai]);     // 0 on pad rows
       }
     }
 
     // ---- L2 regulariser of the critics (weights AND biases, ppo_lag.py:310-314), grad norm
     float gsq = 0.f, psq = 0.f;
-    f4 pW1[NT1], pW2[4], pW3;
-    float pb1 = 0.f, pb2 = 0.f, pb3 = 0.f;
+    const float l2x2 = 2.f * l2;
 #pragma unroll
     for (int nt = 0; nt < NT1; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const bool ok = (16 * nt + j) < D;
         const float p = lds[L::W1 + (orow + r) * L::LD1 + 16 * nt + j];
-        pW1[nt][r] = p;
-        float gg = ok ? vcoef * (aW1[nt][r] + 2.f * l2 * p) : 0.f;
-        aW1[nt][r] = gg; gsq += gg * gg; psq += ok ? p * p : 0.f;
+        const float gg = vcoef * fmaf(l2x2, p, aW1[nt][r]);                  // pad columns: 0
+        aW1[nt][r] = gg; gsq = fmaf(gg, gg, gsq); psq = fmaf(p, p, psq);     // pad columns hold p == 0
       }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float p = lds[L::W2 + (orow + r) * LDH + 16 * nt + j];
-        pW2[nt][r] = p;
-        const float gg = vcoef * (aW2[nt][r] + 2.f * l2 * p);
-        aW2[nt][r] = gg; gsq += gg * gg; psq += p * p;
+        const float gg = vcoef * fmaf(l2x2, p, aW2[nt][r]);
+        aW2[nt][r] = gg; gsq = fmaf(gg, gg, gsq); psq = fmaf(p, p, psq);
       }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const bool ok = (4 * q + r) < OUT;
       const float p = lds[L::W3 + (4 * q + r) * LDH + 16 * wave + j];
-      pW3[r] = p;
-      const float gg = ok ? vcoef * (aW3[r] + 2.f * l2 * p) : 0.f;
-      aW3[r] = gg; gsq += gg * gg; psq += ok ? p * p : 0.f;
+      const float gg = vcoef * fmaf(l2x2, p, aW3[r]);                        // pad rows: 0
+      aW3[r] = gg; gsq = fmaf(gg, gg, gsq); psq = fmaf(p, p, psq);           // pad rows hold p == 0
     }
-    if (own_b) {
-      pb1 = lds[L::B1 + 16 * wave + j]; pb2 = lds[L::B2 + 16 * wave + j];
-      db1 = vcoef * (db1 + 2.f * l2 * pb1); db2 = vcoef * (db2 + 2.f * l2 * pb2);
-      gsq += db1 * db1 + db2 * db2; psq += pb1 * pb1 + pb2 * pb2;
-    }
-    if (own_b3) {
-      pb3 = lds[L::B3 + j];
-      db3 = vcoef * (db3 + 2.f * l2 * pb3);
-      gsq += db3 * db3; psq += pb3 * pb3;
-    }
-    if (own_ls) {
+    {
+      // biases and log_std are replicated across lanes (every q-lane of row j holds the same sums);
+      // each replica runs the same Adam, only one of them counts towards the norms.
+      const float pb1 = lds[L::B1 + 16 * wave + j], pb2 = lds[L::B2 + 16 * wave + j], pb3 = lds[L::B3 + j];
+      db1 = vcoef * fmaf(l2x2, pb1, db1); db2 = vcoef * fmaf(l2x2, pb2, db2); db3 = vcoef * fmaf(l2x2, pb3, db3);
+      const float wb = own_b ? 1.f : 0.f, wb3 = (wave == 0 && q == 0) ? 1.f : 0.f, wls = own_ls ? 1.f : 0.f;
+      gsq += wb * (db1 * db1 + db2 * db2) + wb3 * (db3 * db3);
+      psq += wb * (pb1 * pb1 + pb2 * pb2) + wb3 * (pb3 * pb3);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) if (4 * q + r < A) gsq += dls[r] * dls[r];
+      for (int r = 0; r < 4; ++r) gsq = fmaf(wls * dls[r], dls[r], gsq);
     }
     gsq = wave_sum(gsq);
     psq = wave_sum(psq);
     if (lane == 0) { red[4 + wave] = gsq; red[8 + wave] = psq; }
     __syncthreads();
-    const float my_sq = red[4] + red[5] + red[6] + red[7];
-    const float loss = is_actor ? -loss_data : loss_data + l2 * (red[8] + red[9] + red[10] + red[11]);
-    if (tid == 0) a.losses[s * 3 + net] = loss;
+    const float my_sq = (red[4] + red[5]) + (red[6] + red[7]);
+    if (tid == 0) {
+      const float loss = is_actor ? -loss_data : loss_data + l2 * ((red[8] + red[9]) + (red[10] + red[11]));
+      a.losses[s * 3 + net] = loss;
+    }
 
     if (!PERSIST) {
       // split form: emit the flat gradient (reference parameter order) and stop
@@ -444,36 +509,48 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
     // ---- Adam (bias corrections in double from the running beta powers)
     pw1 *= (double)b1c; pw2 *= (double)b2c;
     const float step_size = (float)((double)lr / (1.0 - pw1));
-    const float bc2s = (float)sqrt(1.0 - pw2);
-    const float eps = a.cfg.adam_eps;
+    const float inv_bc2s = (float)(1.0 / sqrt(1.0 - pw2));
 #pragma unroll
     for (int nt = 0; nt < NT1; ++nt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (16 * nt + j < D)
-          SPO_ADAM(lds[L::W1 + (orow + r) * L::LD1 + 16 * nt + j], pW1[nt][r], aW1[nt][r] * coef, mW1[nt][r], vW1[nt][r])
+      for (int r = 0; r < 4; ++r) {
+        float& pr = lds[L::W1 + (orow + r) * L::LD1 + 16 * nt + j];       // pad columns stay exactly 0
+        SPO_ADAM(pr, pr, aW1[nt][r] * coef, mW1[nt][r], vW1[nt][r])
+      }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        SPO_ADAM(lds[L::W2 + (orow + r) * LDH + 16 * nt + j], pW2[nt][r], aW2[nt][r] * coef, mW2[nt][r], vW2[nt][r])
+      for (int r = 0; r < 4; ++r) {
+        float& pr = lds[L::W2 + (orow + r) * LDH + 16 * nt + j];
+        SPO_ADAM(pr, pr, aW2[nt][r] * coef, mW2[nt][r], vW2[nt][r])
+      }
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (4 * q + r < OUT)
-        SPO_ADAM(lds[L::W3 + (4 * q + r) * LDH + 16 * wave + j], pW3[r], aW3[r] * coef, mW3[r], vW3[r])
-    if (own_b) {
-      SPO_ADAM(lds[L::B1 + 16 * wave + j], pb1, db1 * coef, mb1, vb1)
-      SPO_ADAM(lds[L::B2 + 16 * wave + j], pb2, db2 * coef, mb2, vb2)
+    for (int r = 0; r < 4; ++r) {
+      float& pr = lds[L::W3 + (4 * q + r) * LDH + 16 * wave + j];         // pad rows stay exactly 0
+      SPO_ADAM(pr, pr, aW3[r] * coef, mW3[r], vW3[r])
     }
-    if (own_b3) SPO_ADAM(lds[L::B3 + j], pb3, db3 * coef, mb3, vb3)
-    if (own_ls) {
+    {
+      // replicated state: all replicas compute identical values and store them to the same word
+      float np1, np2, np3;
+      SPO_ADAM(np1, lds[L::B1 + 16 * wave + j], db1 * coef, mb1, vb1)
+      SPO_ADAM(np2, lds[L::B2 + 16 * wave + j], db2 * coef, mb2, vb2)
+      SPO_ADAM(np3, lds[L::B3 + j], db3 * coef, mb3, vb3)
+      float nls[4];
+      if (is_actor) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (4 * q + r < A)
-          SPO_ADAM(red[128 + 4 * q + r], red[128 + 4 * q + r], dls[r] * coef, mls[r], vls[r])
+        for (int r = 0; r < 4; ++r) SPO_ADAM(nls[r], red[128 + 4 * q + r], dls[r] * coef, mls[r], vls[r])
+      }
+      __syncthreads();          // every replica has read the old values
+      lds[L::B1 + 16 * wave + j] = np1;
+      lds[L::B2 + 16 * wave + j] = np2;
+      lds[L::B3 + j] = np3;
+      if (is_actor) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[128 + 4 * q + r] = nls[r];
+      }
     }
     __syncthreads();
-  }  // steps
+  }  // chunks
 
   if (PERSIST) {
     // ---- write back parameters and optimiser state (flat reference order)
@@ -537,7 +614,7 @@ __global__ __launch_bounds__(1024) void clip_adam_kernel(AdamArgs a) {
   float coef = a.max_norm / (sqrtf(tot) + 1e-6f);
   coef = coef > 1.f ? 1.f : coef;
   const double pw1 = a.pow_b1 * (double)a.b1, pw2 = a.pow_b2 * (double)a.b2;
-  const float bc2s = (float)sqrt(1.0 - pw2);
+  const float bc2s = (float)(1.0 / sqrt(1.0 - pw2));
   const float ss_a = (float)((double)a.lr_actor / (1.0 - pw1)), ss_c = (float)((double)a.lr_critic / (1.0 - pw1));
   for (int64_t i = tid; i < a.P; i += 1024) {
     const float g = a.grad[i] * a.gscale * coef;
