@@ -120,6 +120,10 @@ int spo_ppo_lag_update_iter(float* theta, float* adam_m, float* adam_v, int64_t 
                             const int32_t* perm, int64_t M, const spo_ppo_cfg* cfg_host,
                             float* losses_out, void* sync_ws, void* stream);
 
+/* Debug aid (not a reference function): pass a device buffer of 30 u64 to make the next
+ * spo_ppo_lag_update_iter launches accumulate shader cycles per phase of the step; NULL disables. */
+int spo_debug_set_update_profile(void* dev_u64_30);
+
 /* Split form of the same step for data-parallel training: gradient of ONE
  * minibatch into flat_grad[P] (+ losses[3]); the caller all-reduces flat_grad and then
  * applies clip + Adam.  `grad_scale` multiplies the gradient (1/world_size for averaging). */

@@ -86,17 +86,33 @@ __device__ inline void stage_net(const float* __restrict__ theta, const NetGeom 
 }
 
 // B-operand tiles of one observation row: x[nt][reg] = obs[16*nt + 4*q + reg] (0 beyond D).
+// Loads are UNCONDITIONAL (clamped address, select afterwards): a predicated load compiles to a
+// branch plus `s_waitcnt vmcnt(0)` before the next one, which serialises the HBM latencies.
 template <int KIN>
 __device__ __forceinline__ void load_obs_tiles(const float* __restrict__ row, int D, int q, f4 (&x)[KIN / 16]) {
+  if ((D & 3) == 0) {
+    f4 v[KIN / 16];
 #pragma unroll
-  for (int nt = 0; nt < KIN / 16; ++nt) {
-    const int c = 16 * nt + 4 * q;
-    if ((D & 3) == 0) {
-      x[nt] = (c < D) ? *reinterpret_cast<const f4*>(row + c) : f4{0.f, 0.f, 0.f, 0.f};
-    } else {
+    for (int nt = 0; nt < KIN / 16; ++nt) {
+      const int c = 16 * nt + 4 * q;
+      v[nt] = *reinterpret_cast<const f4*>(row + (c < D ? c : 0));
+    }
+#pragma unroll
+    for (int nt = 0; nt < KIN / 16; ++nt) {
+      const bool ok = (16 * nt + 4 * q) < D;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[nt][e] = ok ? v[nt][e] : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int nt = 0; nt < KIN / 16; ++nt) {
       f4 v;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (c + e < D) ? row[c + e] : 0.f;
+      for (int e = 0; e < 4; ++e) {
+        const int c = 16 * nt + 4 * q + e;
+        const float t = row[c < D ? c : 0];
+        v[e] = c < D ? t : 0.f;
+      }
       x[nt] = v;
     }
   }

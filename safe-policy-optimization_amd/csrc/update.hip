@@ -52,7 +52,9 @@ struct UpdArgs {
   float* stale_sq_out;
   // split (data-parallel) form
   float* flat_grad; int64_t mean_count;
+  unsigned long long* prof;      // optional [3][NPHASE] cycle accumulators (debug builds of the launch)
 };
+constexpr int NPHASE = 10;
 
 __device__ __forceinline__ unsigned long long ld_granule(unsigned long long* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -90,8 +92,15 @@ struct ColData {
   float t0, t1;    // critic: target ; actor: logp_old, adv
 };
 
-template <int KIN, bool PERSIST>
+template <int KIN, bool PERSIST, bool PROF = false>
 __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
+  unsigned long long pacc[NPHASE] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = 0;
+#define SPO_STAMP(i)                                           \
+  if (PROF) {                                                  \
+    const unsigned long long _t = __builtin_readcyclecounter(); \
+    pacc[i] += _t - tprev; tprev = _t;                         \
+  }
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using U = UpdLds<KIN>;
   using L = NetLds<KIN>;
@@ -166,10 +175,8 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
   const int64_t nchunks = nsteps * nhalf;
   const int mycol = 16 * wave + j;
 
-  // position in perm[] of my column for chunk c (clamped to a valid entry when the column is masked)
-  auto perm_pos = [&](int64_t c) -> int64_t {
-    const int64_t s = c / nhalf;
-    const int h = (int)(c - s * nhalf);
+  // position in perm[] of my column for (step s, half h) (clamped to a valid entry when masked)
+  auto perm_pos = [&](int64_t s, int h) -> int64_t {
     const int64_t base = PERSIST ? s * B : 0;
     const int64_t rem = PERSIST ? (a.M - base) : a.M;
     const int ncols = (int)(rem < B ? rem : B);
@@ -183,22 +190,31 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
     } else {
       cd.t0 = a.logp_old[smp]; cd.t1 = a.adv[smp];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) cd.actv[r] = (4 * q + r < A) ? a.act[smp * A + 4 * q + r] : 0.f;
+      for (int r = 0; r < 4; ++r) {
+        const int ai = 4 * q + r;
+        const float t = a.act[smp * A + (ai < A ? ai : 0)];       // unconditional load, select after
+        cd.actv[r] = ai < A ? t : 0.f;
+      }
     }
   };
 
   // software pipeline: sample index two chunks ahead, column data one chunk ahead
   ColData<NT1> nxt;
   int64_t smp1 = 0;
-  fetch((int64_t)a.perm[perm_pos(0)], nxt);
-  if (nchunks > 1) smp1 = (int64_t)a.perm[perm_pos(1)];
+  fetch((int64_t)a.perm[perm_pos(0, 0)], nxt);
+  // (s1,h1) / (s2,h2): step and half of chunk c+1 / c+2, advanced without divisions
+  int64_t s_cur = 0, s1 = (nhalf > 1) ? 0 : 1, s2;
+  int h_cur = 0, h1n = (nhalf > 1) ? 1 : 0, h2n;
+  h2n = h1n + 1; s2 = s1;
+  if (h2n == nhalf) { h2n = 0; s2 = s1 + 1; }
+  if (nchunks > 1) smp1 = (int64_t)a.perm[perm_pos(s1, h1n)];
 
   f4 aW1[NT1], aW2[4], aW3, dls;
   float db1 = 0.f, db2 = 0.f, db3 = 0.f, lsum = 0.f;
 
   for (int64_t c = 0; c < nchunks; ++c) {
-    const int64_t s = c / nhalf;
-    const int h = (int)(c - s * nhalf);
+    const int64_t s = s_cur;
+    const int h = h_cur;
     const bool first_half = (h == 0), last_half = (h == nhalf - 1);
     const int64_t base = PERSIST ? s * B : 0;
     const int64_t rem = PERSIST ? (a.M - base) : a.M;
@@ -206,9 +222,13 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
     const float inv_n = 1.f / (float)(PERSIST ? ncols : (int)a.mean_count);
     const bool cv = (64 * h + mycol) < ncols;
 
+    if (PROF) tprev = __builtin_readcyclecounter();
     ColData<NT1> cur = nxt;
-    if (c + 1 < nchunks) fetch(smp1, nxt);                       // lands while this chunk computes
-    if (c + 2 < nchunks) smp1 = (int64_t)a.perm[perm_pos(c + 2)];
+    const int64_t smp_next = smp1;
+    const int64_t pos2 = perm_pos(s2, h2n);
+    s_cur = s1; h_cur = h1n; s1 = s2; h1n = h2n;
+    h2n += 1;
+    if (h2n == nhalf) { h2n = 0; s2 += 1; }
 
     if (first_half) {
 #pragma unroll
@@ -225,10 +245,11 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
     for (int r = 0; r < 4; ++r) {
       const int ai = 4 * q + r;
       const bool on = is_actor && ai < A;
-      const float sdv = on ? expf(red[128 + ai]) : 1.f;
+      const float lsv = on ? red[128 + ai] : 0.f;
+      const float sdv = __expf(lsv);                        // std = exp(log_std)
       amask[r] = on ? 1.f : 0.f;
-      ivar[r] = 1.f / (sdv * sdv);
-      lsd[r] = on ? logf(sdv) + LOG_SQRT_2PI : 0.f;        // log_scale + log(sqrt(2 pi)), 0 on pad rows
+      ivar[r] = __builtin_amdgcn_rcpf(sdv * sdv);
+      lsd[r] = on ? lsv + LOG_SQRT_2PI : 0.f;               // log(scale) = log_std (to 1 ulp) + log(sqrt(2 pi))
     }
 
     // ---- stage x as [feature][batch] right away (frees the registers after layer 1)
@@ -237,8 +258,15 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) lds[U::XT + (16 * nt + 4 * q + e) * LDB + mycol] = cur.x[nt][e];
 
+    SPO_STAMP(0)
     f4 h1[4], h2[4];
     const f4 o = net_forward<KIN>(lds, cur.x, h1, h2, j, q);
+    // Prefetch: column data of chunk c+1 (its sample index was loaded one chunk ago), THEN the sample
+    // index of chunk c+2 -- in this order, so the in-order vmcnt wait on the old index never covers
+    // a load issued in this iteration.
+    if (c + 1 < nchunks) fetch(smp_next, nxt);
+    if (c + 2 < nchunks) smp1 = (int64_t)a.perm[pos2];
+    SPO_STAMP(1)
 
     // ---- loss and d(loss)/d(output), C layout (rows = output unit 4q+r, col = batch)
     f4 dO = {0.f, 0.f, 0.f, 0.f};
@@ -258,7 +286,7 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
       lp += __shfl_xor(lp, 16);
       lp += __shfl_xor(lp, 32);
       const float adv = cur.t1;
-      const float ratio = expf(lp - cur.t0);                               // ppo_lag.py:317
+      const float ratio = __expf(lp - cur.t0);                             // ppo_lag.py:317 (argument ~0: 1e-7 rel)
       const float rc = fminf(fmaxf(ratio, clip_lo), clip_hi);              // torch.clamp
       const float s1 = ratio * adv, s2 = rc * adv;
       const bool inr = (ratio >= clip_lo) && (ratio <= clip_hi);
@@ -307,6 +335,7 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
         for (int r = 0; r < 4; ++r) dz1[mt][r] = acc[mt][r] * fmaf(-h1[mt][r], h1[mt][r], 1.f);
     }
 
+    SPO_STAMP(2)
     // ---- stage [feature][batch] images for the weight-gradient GEMMs
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -333,7 +362,9 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
         }
       }
     }
+    SPO_STAMP(3)
     __syncthreads();
+    SPO_STAMP(4)
 
     // ---- dW[o][i] += sum_b dZ[b][o] * Hprev[b][i]; wave w owns rows 16w..16w+15
     {
@@ -399,6 +430,7 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
       continue;
     }
 
+    SPO_STAMP(5)
     // =================== end of the minibatch: gradients complete ===================
     db1 += __shfl_xor(db1, 16); db1 += __shfl_xor(db1, 32);
     db2 += __shfl_xor(db2, 16); db2 += __shfl_xor(db2, 32);
@@ -415,11 +447,28 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
     // ---- L2 regulariser of the critics (weights AND biases, ppo_lag.py:310-314), grad norm
     float gsq = 0.f, psq = 0.f;
     const float l2x2 = 2.f * l2;
+    f4 pW1[NT1], pW2[4], pW3;
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pW1[nt][r] = lds[L::W1 + (orow + r) * L::LD1 + 16 * nt + j];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pW2[nt][r] = lds[L::W2 + (orow + r) * LDH + 16 * nt + j];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pW3[r] = lds[L::W3 + (4 * q + r) * LDH + 16 * wave + j];
+    const float pb1 = lds[L::B1 + 16 * wave + j], pb2 = lds[L::B2 + 16 * wave + j], pb3 = lds[L::B3 + j];
+    f4 pls = {0.f, 0.f, 0.f, 0.f};
+    if (is_actor) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pls[r] = red[128 + 4 * q + r];
+    }
 #pragma unroll
     for (int nt = 0; nt < NT1; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = lds[L::W1 + (orow + r) * L::LD1 + 16 * nt + j];
+        const float p = pW1[nt][r];
         const float gg = vcoef * fmaf(l2x2, p, aW1[nt][r]);                  // pad columns: 0
         aW1[nt][r] = gg; gsq = fmaf(gg, gg, gsq); psq = fmaf(p, p, psq);     // pad columns hold p == 0
       }
@@ -427,20 +476,19 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = lds[L::W2 + (orow + r) * LDH + 16 * nt + j];
+        const float p = pW2[nt][r];
         const float gg = vcoef * fmaf(l2x2, p, aW2[nt][r]);
         aW2[nt][r] = gg; gsq = fmaf(gg, gg, gsq); psq = fmaf(p, p, psq);
       }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float p = lds[L::W3 + (4 * q + r) * LDH + 16 * wave + j];
+      const float p = pW3[r];
       const float gg = vcoef * fmaf(l2x2, p, aW3[r]);                        // pad rows: 0
       aW3[r] = gg; gsq = fmaf(gg, gg, gsq); psq = fmaf(p, p, psq);           // pad rows hold p == 0
     }
     {
       // biases and log_std are replicated across lanes (every q-lane of row j holds the same sums);
       // each replica runs the same Adam, only one of them counts towards the norms.
-      const float pb1 = lds[L::B1 + 16 * wave + j], pb2 = lds[L::B2 + 16 * wave + j], pb3 = lds[L::B3 + j];
       db1 = vcoef * fmaf(l2x2, pb1, db1); db2 = vcoef * fmaf(l2x2, pb2, db2); db3 = vcoef * fmaf(l2x2, pb3, db3);
       const float wb = own_b ? 1.f : 0.f, wb3 = (wave == 0 && q == 0) ? 1.f : 0.f, wls = own_ls ? 1.f : 0.f;
       gsq += wb * (db1 * db1 + db2 * db2) + wb3 * (db3 * db3);
@@ -451,6 +499,7 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
     gsq = wave_sum(gsq);
     psq = wave_sum(psq);
     if (lane == 0) { red[4 + wave] = gsq; red[8 + wave] = psq; }
+    SPO_STAMP(6)
     __syncthreads();
     const float my_sq = (red[4] + red[5]) + (red[6] + red[7]);
     if (tid == 0) {
@@ -499,6 +548,7 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
       }
       __syncthreads();
     }
+    SPO_STAMP(7)
     float total_sq = stale_sq;
     for (int k = 0; k < a.n_nets; ++k) total_sq += red[96 + k];
     const float norm = sqrtf(total_sq);
@@ -513,34 +563,28 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT1; ++nt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float& pr = lds[L::W1 + (orow + r) * L::LD1 + 16 * nt + j];       // pad columns stay exactly 0
-        SPO_ADAM(pr, pr, aW1[nt][r] * coef, mW1[nt][r], vW1[nt][r])
-      }
+      for (int r = 0; r < 4; ++r)                                         // pad columns stay exactly 0
+        SPO_ADAM(lds[L::W1 + (orow + r) * L::LD1 + 16 * nt + j], pW1[nt][r], aW1[nt][r] * coef, mW1[nt][r], vW1[nt][r])
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float& pr = lds[L::W2 + (orow + r) * LDH + 16 * nt + j];
-        SPO_ADAM(pr, pr, aW2[nt][r] * coef, mW2[nt][r], vW2[nt][r])
-      }
+      for (int r = 0; r < 4; ++r)
+        SPO_ADAM(lds[L::W2 + (orow + r) * LDH + 16 * nt + j], pW2[nt][r], aW2[nt][r] * coef, mW2[nt][r], vW2[nt][r])
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float& pr = lds[L::W3 + (4 * q + r) * LDH + 16 * wave + j];         // pad rows stay exactly 0
-      SPO_ADAM(pr, pr, aW3[r] * coef, mW3[r], vW3[r])
-    }
+    for (int r = 0; r < 4; ++r)                                           // pad rows stay exactly 0
+      SPO_ADAM(lds[L::W3 + (4 * q + r) * LDH + 16 * wave + j], pW3[r], aW3[r] * coef, mW3[r], vW3[r])
     {
       // replicated state: all replicas compute identical values and store them to the same word
       float np1, np2, np3;
-      SPO_ADAM(np1, lds[L::B1 + 16 * wave + j], db1 * coef, mb1, vb1)
-      SPO_ADAM(np2, lds[L::B2 + 16 * wave + j], db2 * coef, mb2, vb2)
-      SPO_ADAM(np3, lds[L::B3 + j], db3 * coef, mb3, vb3)
+      SPO_ADAM(np1, pb1, db1 * coef, mb1, vb1)
+      SPO_ADAM(np2, pb2, db2 * coef, mb2, vb2)
+      SPO_ADAM(np3, pb3, db3 * coef, mb3, vb3)
       float nls[4];
       if (is_actor) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) SPO_ADAM(nls[r], red[128 + 4 * q + r], dls[r] * coef, mls[r], vls[r])
+        for (int r = 0; r < 4; ++r) SPO_ADAM(nls[r], pls[r], dls[r] * coef, mls[r], vls[r])
       }
-      __syncthreads();          // every replica has read the old values
+      // (old values were read before the norm barrier: replicas may store right away)
       lds[L::B1 + 16 * wave + j] = np1;
       lds[L::B2 + 16 * wave + j] = np2;
       lds[L::B3 + j] = np3;
@@ -549,8 +593,13 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
         for (int r = 0; r < 4; ++r) red[128 + 4 * q + r] = nls[r];
       }
     }
+    SPO_STAMP(8)
     __syncthreads();
+    SPO_STAMP(9)
   }  // chunks
+  if (PROF && a.prof && tid == 0)
+    for (int i = 0; i < NPHASE; ++i) a.prof[blockIdx.x * NPHASE + i] = pacc[i];
+#undef SPO_STAMP
 
   if (PERSIST) {
     // ---- write back parameters and optimiser state (flat reference order)
@@ -625,9 +674,19 @@ __global__ __launch_bounds__(1024) void clip_adam_kernel(AdamArgs a) {
 
 int pick_kin(int D) { return D <= 16 ? 16 : D <= 32 ? 32 : 64; }
 
+unsigned long long* g_prof_buf = nullptr;
+
 template <bool PERSIST>
 int launch_update(const UpdArgs& a, int blocks, hipStream_t st) {
   const int kin = pick_kin(a.cfg.obs_dim);
+  if (PERSIST && a.prof && kin == 64) {
+    const size_t sh = UpdLds<64>::SIZE * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_update_kernel<64, true, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (e != hipSuccess) return spo::hip_check(e, "hipFuncSetAttribute(update prof)");
+    hipLaunchKernelGGL((ppo_update_kernel<64, true, true>), dim3(blocks), dim3(256), sh, st, a);
+    return 0;
+  }
 #define SPO_LAUNCH(K)                                                                                   \
   {                                                                                                     \
     const size_t sh = UpdLds<K>::SIZE * sizeof(float);                                                  \
@@ -677,9 +736,16 @@ extern "C" int spo_ppo_lag_update_iter(float* theta, float* adam_m, float* adam_
   a.pow_b1 = pow((double)cfg_host->beta1, (double)adam_step_host);
   a.pow_b2 = pow((double)cfg_host->beta2, (double)adam_step_host);
   a.first_net = 0; a.n_nets = 3; a.stale_sq = 0.f; a.stale_sq_out = nullptr;
-  a.flat_grad = nullptr; a.mean_count = 0;
+  a.flat_grad = nullptr; a.mean_count = 0; a.prof = g_prof_buf;
   if (int rc = launch_update<true>(a, 3, st)) return rc;
   SPO_LAUNCH_CHECK("spo_ppo_lag_update_iter");
+  return 0;
+}
+
+// Debug: when set (device pointer to 3*10 u64), spo_ppo_lag_update_iter runs an instrumented build of
+// the kernel that accumulates shader-clock cycles per phase of the step (wave 0 lane 0 per block).
+extern "C" int spo_debug_set_update_profile(void* dev_u64_30) {
+  g_prof_buf = reinterpret_cast<unsigned long long*>(dev_u64_30);
   return 0;
 }
 
