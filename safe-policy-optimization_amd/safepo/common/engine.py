@@ -21,7 +21,7 @@ import torch
 from safepo import _abi
 from safepo.common.buffer import VectorizedOnPolicyBuffer
 from safepo.common.model import ActorVCritic
-from safepo.parallel import Comm
+from safepo.parallel import Comm, dp_reduce_gradient_
 
 
 class _Space:
@@ -185,7 +185,6 @@ class PPOLagEngine:
             self.adam_step += n_mb
         else:
             # data-parallel: local minibatch gradient -> all-reduce (RCCL) -> identical clip+Adam on every rank
-            scale = 1.0 / self.comm.world_size
             for k in range(n_mb):
                 lo = k * cfg.batch
                 n_idx = min(cfg.batch, M - lo)
@@ -194,13 +193,13 @@ class PPOLagEngine:
                     _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]), _abi.ptr(b.adv_mix),
                     perm.data_ptr() + 4 * lo, n_idx, n_idx, cfg, _abi.ptr(self.flat_grad), _abi.ptr(losses[k]), st),
                     "spo_ppo_lag_grad")
-                self.comm.all_reduce_sum_(self.flat_grad)
+                scale = dp_reduce_gradient_(self.comm, self.flat_grad)
                 _abi.check(self.lib.spo_clip_adam(_abi.ptr(th), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v),
                                                   _abi.ptr(self.flat_grad), self.adam_step, scale, cfg, st),
                            "spo_clip_adam")
                 self.adam_step += 1
             self.comm.all_reduce_sum_(losses)
-            losses *= scale
+            losses *= 1.0 / self.comm.world_size
         return losses
 
     def check_sync_error(self):

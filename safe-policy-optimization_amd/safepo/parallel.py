@@ -63,3 +63,30 @@ def shard_envs(num_envs_global: int, comm: Comm) -> tuple[int, int]:
     count = base + (1 if r < rem else 0)
     start = r * base + min(r, rem)
     return start, count
+
+
+def dp_reduce_gradient_(comm: Comm, flat_grad: torch.Tensor) -> float:
+    """All-reduce(sum) the flat minibatch gradient of all three networks in place and return the
+    scale (1/world_size) that turns the sum of per-rank MEAN-loss gradients into the gradient of the
+    mean over the global minibatch (the L2 terms are identical on every rank, so they average to
+    themselves).  The joint clip_grad_norm_ and Adam then run identically on every rank."""
+    comm.all_reduce_sum_(flat_grad)
+    return 1.0 / comm.world_size
+
+
+def dp_mean_scalar(comm: Comm, value: float, device=None) -> float:
+    """Mean over ranks of a host scalar (EpCost for the Lagrange update, ppo_lag.py:272)."""
+    if comm.world_size == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    comm.all_reduce_sum_(t)
+    return float(t.item()) / comm.world_size
+
+
+def adv_stats_from_sums(sums: torch.Tensor):
+    """(mean_r, unbiased std_r, mean_c) from all-reduced [sum r, sum r^2, sum c, n] (buffer.py:154-160)."""
+    s = sums.double().cpu()
+    n = float(s[3])
+    mean_r = float(s[0]) / n
+    var = max((float(s[1]) - float(s[0]) ** 2 / n) / (n - 1.0), 0.0)
+    return mean_r, var ** 0.5, float(s[2]) / n

@@ -24,7 +24,7 @@ from safepo.common.env import make_sa_mujoco_env
 from safepo.common.lagrange import Lagrange
 from safepo.common.logger import EpochLogger
 from safepo.common.model import ActorVCritic
-from safepo.parallel import Comm, init_from_env, shard_envs
+from safepo.parallel import Comm, dp_mean_scalar, init_from_env, shard_envs
 from safepo.utils.config import isaac_gym_map, single_agent_args
 
 default_cfg = {
@@ -111,9 +111,7 @@ def main(args, cfg_env=None):
 
         # ---- Lagrange multiplier (ppo_lag.py:271-273); EpCost mean is all-reduced over shards
         ep_costs = logger.get_stats("Metrics/EpCost")
-        if comm.world_size > 1:
-            t = torch.tensor([float(ep_costs)], dtype=torch.float64, device=device)
-            ep_costs = float(comm.all_reduce_sum_(t).item()) / comm.world_size
+        ep_costs = dp_mean_scalar(comm, ep_costs, device)
         lagrange.update_lagrange_multiplier(ep_costs)
 
         # ---- policy update (ppo_lag.py:275-350)

@@ -1,0 +1,165 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every symbol include/safepo_hip.h declares;
+host-side logic (CLI surface, logger formats, Lagrange, env sharding) matches the reference's contract."""
+import csv
+import json
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.build()
+    return g.LIB
+
+
+def test_every_declared_symbol_is_exported_and_bound(built_lib):
+    from safepo import _abi
+    header = open(os.path.join(ROOT, "include", "safepo_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(spo_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_abi.PROTOTYPES), (declared ^ set(_abi.PROTOTYPES))
+    lib = _abi.load(built_lib)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.spo_abi_version() == 1
+    # geometry helpers are host functions: 2*8129 + 8592 = 24850
+    assert lib.spo_param_count(60, 8) == 24850
+    assert [lib.spo_param_offset(60, 8, k) for k in range(3)] == [0, 8129, 16258]
+    assert lib.spo_gae_num_blocks(4096, 128) == 512
+
+
+def test_argument_errors_without_gpu(built_lib):
+    from safepo import _abi
+    lib = _abi.load(built_lib)
+    assert lib.spo_gae_fused(None, None, None, None, None, None, None, None, None, None, None, None, 4, 8, 0.99, 0.95, 0.95, None) < 0
+    assert b"null" in lib.spo_last_error()
+    assert lib.spo_policy_step(None, None, None, None, None, None, None, None, None, None, None, None, 4, 1, 0, 500, 8, None) < 0
+    assert b"obs_dim" in lib.spo_last_error()
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from safepo import _abi
+    with pytest.raises(_abi.SpoError, match="no CPU fallback"):
+        _abi.load(str(tmp_path / "nope.so"))
+
+
+def test_cpu_tensors_are_rejected(built_lib):
+    from safepo import _abi
+    from safepo.common.buffer import VectorizedOnPolicyBuffer
+    from safepo.common.model import ActorVCritic
+    pol = ActorVCritic(60, 8)
+    with pytest.raises(_abi.SpoError, match="GPU tensor"):
+        pol.step(torch.zeros(4, 60))
+    class S:  # noqa
+        shape = (60,)
+    with pytest.raises(_abi.SpoError, match="no CPU fallback"):
+        VectorizedOnPolicyBuffer(S(), S(), size=8, num_envs=2, device="cpu")
+
+
+def test_policy_parameter_layout_matches_reference_order():
+    from safepo.common.model import ActorVCritic
+    torch.manual_seed(0)
+    pol = ActorVCritic(60, 8)
+    names = [n for n, _ in pol.named_parameters()]
+    assert names[:2] == ["reward_critic.critic.0.weight", "reward_critic.critic.0.bias"]
+    assert names[6] == "cost_critic.critic.0.weight" and names[12] == "actor.log_std"
+    assert names[13:] == [f"actor.mean.{i}.{k}" for i in (0, 2, 4) for k in ("weight", "bias")]
+    assert set(pol.actor.state_dict()) == {"log_std", "mean.0.weight", "mean.0.bias", "mean.2.weight",
+                                           "mean.2.bias", "mean.4.weight", "mean.4.bias"}
+    # parameters are views into ONE flat vector, in policy.parameters() order
+    flat = torch.cat([p.detach().reshape(-1) for p in pol.parameters()])
+    assert torch.equal(flat, pol.theta) and pol.theta.numel() == 24850
+    # same RNG consumption as the reference constructor => same init for the same seed
+    from oracle import restatement as R
+    torch.manual_seed(0)
+    ref = R.OraclePolicy(60, 8)
+    assert torch.equal(R.flat_params(ref), pol.theta)
+    pol.actor.mean[0].weight.data[3, 5] = 42.0
+    assert pol.theta[2 * 8129 + 8 + 3 * 60 + 5] == 42.0
+    with pytest.raises(NotImplementedError):
+        ActorVCritic(60, 8, hidden_sizes=[1024, 1024, 512])._require_kernels()
+
+
+def test_cli_flags_match_reference_table():
+    from safepo.utils.config import build_parser, single_agent_args
+    flags = {a.option_strings[0]: a.default for a in build_parser()._actions if a.option_strings and a.dest != "help"}
+    expected = {"--seed": 0, "--use-eval": False, "--task": "SafetyPointGoal1-v0", "--num-envs": 10,
+                "--experiment": "single_agent_exp", "--log-dir": "../runs", "--device-id": 0,
+                "--write-terminal": True, "--headless": False, "--total-steps": 10000000,
+                "--steps-per-epoch": 20000, "--randomize": False, "--cost-limit": 25.0,
+                "--lagrangian-multiplier-init": 0.001, "--lagrangian-multiplier-lr": 0.035}
+    for k, v in expected.items():
+        assert flags[k] == v, k
+    assert set(flags) == set(expected) | {"--device"}
+    args, cfg_env = single_agent_args(["--task", "SynthSafe-v0", "--num-envs", "4", "--use-eval", "False",
+                                       "--write-terminal", "no", "--seed", "3"])
+    assert (args.num_envs, args.use_eval, args.write_terminal, args.seed, cfg_env) == (4, False, False, 3, {})
+
+
+def test_logger_files_and_get_stats_protocol(tmp_path):
+    from safepo.common.logger import EpochLogger
+    from safepo.common.model import ActorVCritic
+    d = str(tmp_path / "exp" / "task" / "run")
+    lg = EpochLogger(log_dir=d, seed="7", verbose=False)
+    assert lg.exp_name == "exp-task-seed-7"
+    lg.save_config({"seed": 7, "hidden_sizes": [64, 64], "fn": print})
+    cfg = json.load(open(os.path.join(d, "config.json")))
+    assert cfg["exp_name"] == "exp-task-seed-7" and cfg["fn"] == "print"
+    assert lg.get_stats("Metrics/EpCost") == 0.0                     # unknown key before the first dump
+    lg.store(**{"Metrics/EpCost": 2.0}); lg.store(**{"Metrics/EpCost": 4.0})
+    assert lg.get_stats("Metrics/EpCost") == 0.0                     # still not in a dumped header
+    lg.log_tabular("Metrics/EpCost"); lg.log_tabular("Train/Epoch", 1)
+    lg.dump_tabular()
+    lg.store(**{"Metrics/EpCost": 10.0})
+    assert lg.get_stats("Metrics/EpCost") == 10.0
+    lg.log_tabular("Metrics/EpCost"); lg.log_tabular("Train/Epoch", 2)
+    with pytest.raises(AssertionError):
+        lg.log_tabular("New/Key", 1)
+    lg.dump_tabular()
+    rows = list(csv.reader(open(os.path.join(d, "progress.csv"))))
+    assert rows == [["Metrics/EpCost", "Train/Epoch"], ["3.0", "1"], ["10.0", "2"]]
+    pol = ActorVCritic(6, 2)
+    lg.setup_torch_saver(pol.actor)
+    lg.save_state({"Normalizer": {"mean": np.zeros(6)}}, itr=0)
+    sd = torch.load(os.path.join(d, "torch_save", "model0.pt"))
+    assert set(sd) == set(pol.actor.state_dict()) and sd["mean.0.weight"].shape == (64, 6)
+    import joblib
+    assert "Normalizer" in joblib.load(os.path.join(d, "state0.pkl"))
+    lg.close()
+
+
+def test_lagrange_matches_oracle():
+    from oracle import restatement as R
+    from safepo.common.lagrange import Lagrange
+    a, b = Lagrange(25.0, 0.001, 0.035), R.OracleLagrange(25.0, 0.001, 0.035)
+    for jc in (0.0, 30.0, 41.5, 12.0, 60.0, float(np.mean([26.0, 27.0]))):
+        a.update_lagrange_multiplier(jc); b.update_lagrange_multiplier(jc)
+        assert a.lagrangian_multiplier == b.lagrangian_multiplier
+    assert a.lagrangian_multiplier >= 0.0
+    c = Lagrange(1.0, 5.0, 0.5, lagrangian_upper_bound=5.2)
+    for _ in range(5):
+        c.update_lagrange_multiplier(100.0)
+    assert c.lagrangian_multiplier == pytest.approx(5.2)
+
+
+def test_shard_envs_partitions_all_envs():
+    from safepo.parallel import shard_envs
+    class C:  # noqa
+        def __init__(self, w, r): self.world_size, self.rank = w, r
+    for n, w in ((32768, 8), (10, 4), (7, 8), (4096, 1)):
+        spans = [shard_envs(n, C(w, r)) for r in range(w)]
+        assert sum(c for _, c in spans) == n
+        pos = 0
+        for s, c in spans:
+            assert s == pos
+            pos += c
