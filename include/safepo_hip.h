@@ -144,6 +144,34 @@ int spo_actor_kl(const float* theta, const float* obs, const float* mean_old, co
                  double* kl_partials, int kl_partials_capacity, double* kl_sum, int64_t rows,
                  int obs_dim, int act_dim, void* stream);
 
+/* ---- CPO (safepo/single_agent/cpo.py).  Actor-only flat vectors use the actor's own layout
+ * [log_std, W1, b1, W2, b2, W3, b3] = actor.named_parameters() order (cpo.py:70-78), length
+ * Pa = spo_param_count - 2*critic.  Workspaces: partial_ws float[spo_cpo_num_partials(rows)*Pa],
+ * loss_ws double[spo_cpo_num_partials(rows)].
+ * a-16 spo_cpo_surrogate_grad: grad_out = d/dtheta [ sign * mean(ratio * adv) ], ratio = exp(logp - logp_old)
+ *      (cpo.py:356-365 with sign=-1/adv_r, :372-381 with sign=+1/adv_c); loss_sum_out[0] = sum(ratio*adv).
+ * a-14 spo_cpo_fvp: out = J^T diag(1/sigma^2) J vec / (rows*act_dim) on the mean-network entries, 0 on the
+ *      log_std entries; the caller adds (2/act_dim)*vec[log_std] and the 0.1*vec damping (cpo.py:132-157).
+ * a-17 spo_cpo_linesearch_eval: sums3_out = {sum ratio*adv_r, sum ratio*adv_c, sum_{rows,dims} KL(old||new)}
+ *      for the parameters currently in theta (cpo.py:473-491).
+ * a-18 spo_critic_fit_iter: one pass of the critic fit (cpo.py:541-571) on the persistent kernel with two
+ *      networks; *stale_sq_io carries ||actor.grad||^2 (the stale cost gradient that clip_grad_norm_ over ALL
+ *      policy parameters still sees, and rescales in place whenever it clips). */
+int spo_cpo_num_partials(int64_t rows);
+int spo_cpo_surrogate_grad(const float* theta, const float* obs, const float* act, const float* logp_old,
+                           const float* adv, float sign, int64_t rows, int obs_dim, int act_dim,
+                           float* partial_ws, double* loss_ws, float* grad_out, double* loss_sum_out, void* stream);
+int spo_cpo_fvp(const float* theta, const float* obs, const float* vec, int64_t rows, int obs_dim, int act_dim,
+                float* partial_ws, double* loss_ws, float* out, void* stream);
+int spo_cpo_linesearch_eval(const float* theta, const float* obs, const float* act, const float* logp_old,
+                            const float* adv_r, const float* adv_c, const float* mean_old, const float* log_std_old,
+                            int64_t rows, int obs_dim, int act_dim, double* partial_ws, int partial_capacity,
+                            double* sums3_out, void* stream);
+int spo_critic_fit_iter(float* theta, float* adam_m, float* adam_v, int64_t adam_step_host,
+                        const float* obs, const float* target_r, const float* target_c, const int32_t* perm,
+                        int64_t M, const spo_ppo_cfg* cfg_host, float* stale_sq_io, float* losses_out,
+                        void* sync_ws, void* stream);
+
 /* parameter-vector geometry helpers (host) */
 int64_t spo_param_count(int obs_dim, int act_dim);
 int64_t spo_param_offset(int obs_dim, int act_dim, int net /*0 r-critic,1 c-critic,2 actor*/);

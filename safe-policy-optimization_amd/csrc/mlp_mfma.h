@@ -163,6 +163,33 @@ __device__ __forceinline__ void layer_hidden(const float* Wl, int ld, const floa
   }
 }
 
+// acc[mt] += W[16mt.., k] * in  (no bias, no activation): building block for tangent products.
+template <int NT_IN>
+__device__ __forceinline__ void layer_accum(const float* Wl, int ld, const f4 (&in)[NT_IN], f4 (&acc)[HID / 16],
+                                            int j, int q) {
+#pragma unroll
+  for (int nt = 0; nt < NT_IN; ++nt) {
+    f4 a[HID / 16];
+#pragma unroll
+    for (int mt = 0; mt < HID / 16; ++mt)
+      a[mt] = *reinterpret_cast<const f4*>(Wl + (16 * mt + j) * ld + 16 * nt + 4 * q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int mt = 0; mt < HID / 16; ++mt) acc[mt] = mfma4(a[mt][r], in[nt][r], acc[mt]);
+  }
+}
+// acc += W3[0..15, k] * in   (output tile, no bias)
+__device__ __forceinline__ f4 out_accum(const float* Wl, const f4 (&in)[HID / 16], f4 acc, int j, int q) {
+#pragma unroll
+  for (int nt = 0; nt < HID / 16; ++nt) {
+    const f4 a = *reinterpret_cast<const f4*>(Wl + j * LDH + 16 * nt + 4 * q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = mfma4(a[r], in[nt][r], acc);
+  }
+  return acc;
+}
+
 // Output layer (one padded 16-row tile): rows 4q+reg = output unit.  Two accumulators (k halves)
 // keep the MFMA pipe busy; they are summed at the end.
 __device__ __forceinline__ f4 layer_out(const float* Wl, const float* bl, const f4 (&in)[HID / 16], int j, int q) {

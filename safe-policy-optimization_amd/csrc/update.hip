@@ -49,7 +49,7 @@ struct UpdArgs {
   double pow_b1, pow_b2;         // beta^adam_step at launch
   int first_net, n_nets;         // PPO-Lag: 0,3   CPO critic fit: 0,2
   float stale_sq;                // CPO: ||stale actor grad||^2 taking part in the joint clip
-  float* stale_sq_out;
+  float* stale_io;               // CPO: device scalar carrying stale_sq across launches (read at start, written at end)
   // split (data-parallel) form
   float* flat_grad; int64_t mean_count;
   unsigned long long* prof;      // optional [3][NPHASE] cycle accumulators (debug builds of the launch)
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
   const float l2 = (!is_actor && a.cfg.use_critic_norm) ? a.cfg.l2_coef : 0.f;
   const float vcoef = (net == 0 && a.cfg.use_value_coefficient) ? 2.f : 1.f;
   const float clip_lo = 1.f - a.cfg.clip, clip_hi = 1.f + a.cfg.clip;
-  float stale_sq = a.stale_sq;
+  float stale_sq = a.stale_io ? *a.stale_io : a.stale_sq;
   const float* tgt = (net == 0) ? a.tgt_r : a.tgt_c;
 
   const int64_t nsteps = PERSIST ? (a.M + B - 1) / B : 1;
@@ -641,7 +641,10 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
       a.theta[g.b2() + o] = lds[L::B2 + o]; a.adam_m[g.b2() + o] = mb2; a.adam_v[g.b2() + o] = vb2;
     }
     if (own_b3) { a.theta[g.b3() + j] = lds[L::B3 + j]; a.adam_m[g.b3() + j] = mb3; a.adam_v[g.b3() + j] = vb3; }
-    if (tid == 0 && blockIdx.x == 0 && a.stale_sq_out) *a.stale_sq_out = stale_sq;
+    if (tid == 0 && blockIdx.x == 0 && a.stale_io) {
+      // every workgroup read the old value before its first step; they all finish after the last exchange
+      *a.stale_io = stale_sq;
+    }
   }
 }
 
@@ -735,10 +738,34 @@ extern "C" int spo_ppo_lag_update_iter(float* theta, float* adam_m, float* adam_
   a.err = reinterpret_cast<int*>(reinterpret_cast<char*>(sync_ws) + 64);
   a.pow_b1 = pow((double)cfg_host->beta1, (double)adam_step_host);
   a.pow_b2 = pow((double)cfg_host->beta2, (double)adam_step_host);
-  a.first_net = 0; a.n_nets = 3; a.stale_sq = 0.f; a.stale_sq_out = nullptr;
+  a.first_net = 0; a.n_nets = 3; a.stale_sq = 0.f; a.stale_io = nullptr;
   a.flat_grad = nullptr; a.mean_count = 0; a.prof = g_prof_buf;
   if (int rc = launch_update<true>(a, 3, st)) return rc;
   SPO_LAUNCH_CHECK("spo_ppo_lag_update_iter");
+  return 0;
+}
+
+extern "C" int spo_critic_fit_iter(float* theta, float* adam_m, float* adam_v, int64_t adam_step_host,
+                                   const float* obs, const float* target_r, const float* target_c,
+                                   const int32_t* perm, int64_t M, const spo_ppo_cfg* cfg_host, float* stale_sq_io,
+                                   float* losses_out, void* sync_ws, void* stream) {
+  if (int rc = check_cfg(cfg_host)) return rc;
+  SPO_REQUIRE(theta && adam_m && adam_v && obs && target_r && target_c && perm && losses_out && sync_ws,
+              "critic_fit_iter: null pointer");
+  SPO_REQUIRE(M > 0 && adam_step_host >= 0, "critic_fit_iter: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = spo::hip_check(hipMemsetAsync(sync_ws, 0, 72, st), "hipMemsetAsync(sync_ws)")) return rc;
+  UpdArgs a{};
+  a.theta = theta; a.adam_m = adam_m; a.adam_v = adam_v;
+  a.obs = obs; a.tgt_r = target_r; a.tgt_c = target_c; a.perm = perm; a.M = M; a.cfg = *cfg_host;
+  a.losses = losses_out;
+  a.slots = reinterpret_cast<unsigned long long*>(sync_ws);
+  a.err = reinterpret_cast<int*>(reinterpret_cast<char*>(sync_ws) + 64);
+  a.pow_b1 = pow((double)cfg_host->beta1, (double)adam_step_host);
+  a.pow_b2 = pow((double)cfg_host->beta2, (double)adam_step_host);
+  a.first_net = 0; a.n_nets = 2; a.stale_sq = 0.f; a.stale_io = stale_sq_io;
+  if (int rc = launch_update<true>(a, 2, st)) return rc;
+  SPO_LAUNCH_CHECK("spo_critic_fit_iter");
   return 0;
 }
 

@@ -43,6 +43,11 @@ PROTOTYPES = {
     "spo_clip_adam": (c_int, [P, P, P, P, c_int64, c_float, POINTER(PpoCfg), P]),
     "spo_actor_mean": (c_int, [P, P, P, c_int64, c_int, c_int, P]),
     "spo_actor_kl": (c_int, [P, P, P, P, P, c_int, P, c_int64, c_int, c_int, P]),
+    "spo_cpo_num_partials": (c_int, [c_int64]),
+    "spo_cpo_surrogate_grad": (c_int, [P] * 5 + [c_float, c_int64, c_int, c_int, P, P, P, P, P]),
+    "spo_cpo_fvp": (c_int, [P, P, P, c_int64, c_int, c_int, P, P, P, P]),
+    "spo_cpo_linesearch_eval": (c_int, [P] * 8 + [c_int64, c_int, c_int, P, c_int, P, P]),
+    "spo_critic_fit_iter": (c_int, [P, P, P, c_int64, P, P, P, P, c_int64, POINTER(PpoCfg), P, P, P, P]),
     "spo_param_count": (c_int64, [c_int, c_int]),
     "spo_param_offset": (c_int64, [c_int, c_int, c_int]),
     "spo_synth_env_step": (c_int, [P] * 7 + [c_int64, c_int, c_uint64, c_uint64, c_float, c_float, c_int, P]),

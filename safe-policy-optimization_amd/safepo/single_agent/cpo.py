@@ -1,0 +1,373 @@
+"""CPO (Constrained Policy Optimization), MI355X-native hot path behind the reference entry point.
+
+`main(args, cfg_env=None)` / `default_cfg` / CLI as in the reference script
+(safepo/single_agent/cpo.py:47-54,160,604-651).  Collect and GAE are shared with PPO-Lag
+(safepo.common.engine); the update (cpo.py:350-571) runs on HIP kernels:
+  policy-gradient pair g, b          -> spo_cpo_surrogate_grad (full batch, MFMA fwd+bwd, fixed-order reduction)
+  fvp (33 per epoch)                 -> spo_cpo_fvp (analytic Gauss-Newton product: forward tangent + backward)
+  conjugate gradients (cpo.py:81-106)-> device vector ops around spo_cpo_fvp
+  case analysis (cpo.py:384-463)     -> host scalars, exactly the reference's closed forms and comparisons
+  line search (cpo.py:465-519)       -> spo_cpo_linesearch_eval per candidate
+  critic fit (cpo.py:534-571)        -> spo_critic_fit_iter (persistent kernel, two critics, batch 128)
+"""
+from __future__ import annotations
+
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+from safepo import _abi
+from safepo.common.engine import PPOLagEngine
+from safepo.common.env import make_sa_mujoco_env
+from safepo.common.logger import EpochLogger
+from safepo.common.model import ActorVCritic
+from safepo.parallel import init_from_env, shard_envs
+from safepo.utils.config import isaac_gym_map, single_agent_args
+
+STEP_FRACTION = 0.8
+CPO_SEARCHING_STEPS = 15
+CONJUGATE_GRADIENT_ITERS = 15
+
+default_cfg = {
+    'hidden_sizes': [64, 64],
+    'gamma': 0.99,
+    'target_kl': 0.01,
+    'batch_size': 128,
+    'learning_iters': 10,
+    'max_grad_norm': 40.0,
+}
+
+
+class CPOEngine(PPOLagEngine):
+    """Adds the CPO actor update and critic fit on top of the shared collect/GAE engine."""
+
+    def __init__(self, policy: ActorVCritic, num_envs: int, steps: int, config: dict, device, comm=None):
+        super().__init__(policy, num_envs, steps, config, device, comm=comm, lr=1e-3, critic_lr=1e-3)
+        if self.comm.world_size > 1:
+            raise NotImplementedError("CPO runs single-GPU in this build (BASELINE config 3)")
+        self.ls_off = policy.log_std_offset
+        self.Pa = policy.theta.numel() - self.ls_off
+        nparts = self.lib.spo_cpo_num_partials(self.M)
+        self.partial_ws = torch.empty(nparts * self.Pa, dtype=torch.float32, device=self.dev)
+        self.loss_ws = torch.empty(nparts, dtype=torch.float64, device=self.dev)
+        self.loss_sum = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        self.ls_partials = torch.empty(3 * 1024, dtype=torch.float64, device=self.dev)
+        self.ls_sums = torch.zeros(3, dtype=torch.float64, device=self.dev)
+        self.stale_sq = torch.zeros(1, dtype=torch.float32, device=self.dev)
+
+    # ---------------------------------------------------------------- actor flat views (cpo.py:70-78,109-121)
+    @property
+    def theta_actor(self) -> torch.Tensor:
+        return self.policy.theta[self.ls_off:]
+
+    def surrogate_grad(self, adv: torch.Tensor, sign: float):
+        """grad of sign*mean(ratio*adv) wrt the actor parameters, and mean(ratio*adv)."""
+        d = self.buffer.data
+        g = torch.empty(self.Pa, dtype=torch.float32, device=self.dev)
+        _abi.check(self.lib.spo_cpo_surrogate_grad(
+            _abi.ptr(self.policy.theta), _abi.ptr(d["obs"]), _abi.ptr(d["act"]), _abi.ptr(d["log_prob"]),
+            _abi.ptr(adv), float(sign), self.M, self.D, self.A, _abi.ptr(self.partial_ws), _abi.ptr(self.loss_ws),
+            _abi.ptr(g), _abi.ptr(self.loss_sum), _abi.stream_ptr()), "spo_cpo_surrogate_grad")
+        return g, float(self.loss_sum.item()) / self.M
+
+    def fvp(self, v: torch.Tensor) -> torch.Tensor:
+        """cpo.py:132-157: H v + 0.1 v with H the Hessian of mean(KL(old||cur)) at cur == old."""
+        out = torch.empty(self.Pa, dtype=torch.float32, device=self.dev)
+        v = v.contiguous()
+        _abi.check(self.lib.spo_cpo_fvp(_abi.ptr(self.policy.theta), _abi.ptr(self.buffer.data["obs"]), _abi.ptr(v),
+                                        self.M, self.D, self.A, _abi.ptr(self.partial_ws), _abi.ptr(self.loss_ws),
+                                        _abi.ptr(out), _abi.stream_ptr()), "spo_cpo_fvp")
+        out[:self.A] += (2.0 / self.A) * v[:self.A]          # log_std block of the Hessian
+        return out + v * 0.1
+
+    def conjugate_gradients(self, b: torch.Tensor, num_steps: int = CONJUGATE_GRADIENT_ITERS,
+                            residual_tol: float = 1e-10, eps: float = 1e-6) -> torch.Tensor:
+        """cpo.py:81-106 on device vectors."""
+        x = torch.zeros_like(b)
+        r = b - self.fvp(x)
+        p = r.clone()
+        rdotr = torch.dot(r, r)
+        for _ in range(num_steps):
+            z = self.fvp(p)
+            alpha = rdotr / (torch.dot(p, z) + eps)
+            x += alpha * p
+            r -= alpha * z
+            new_rdotr = torch.dot(r, r)
+            if torch.sqrt(new_rdotr) < residual_tol:
+                break
+            mu = new_rdotr / (rdotr + eps)
+            p = r + mu * p
+            rdotr = new_rdotr
+        return x
+
+    def linesearch_eval(self):
+        """(loss_reward, loss_cost, kl) for the parameters currently in theta (cpo.py:473-491)."""
+        d = self.buffer.data
+        _abi.check(self.lib.spo_cpo_linesearch_eval(
+            _abi.ptr(self.policy.theta), _abi.ptr(d["obs"]), _abi.ptr(d["act"]), _abi.ptr(d["log_prob"]),
+            _abi.ptr(d["adv_r"]), _abi.ptr(d["adv_c"]), _abi.ptr(self.mean_old), _abi.ptr(self.logstd_old),
+            self.M, self.D, self.A, _abi.ptr(self.ls_partials), self.ls_partials.numel(), _abi.ptr(self.ls_sums),
+            _abi.stream_ptr()), "spo_cpo_linesearch_eval")
+        s = self.ls_sums.cpu()
+        return -float(s[0]) / self.M, float(s[1]) / self.M, float(s[2]) / (self.M * self.A)
+
+    def policy_update(self, ep_costs: float, logger=None) -> dict:
+        """cpo.py:350-532.  `ep_costs` = Jc - cost_limit.  Requires compute_gae() to have run."""
+        target_kl = self.cfg["target_kl"]
+        d = self.buffer.data
+        theta_old = self.theta_actor.clone()
+        self.snapshot_old_distribution()
+        g_loss, mean_r = self.surrogate_grad(d["adv_r"], -1.0)          # grad of loss_pi_r = -mean(ratio*adv_r)
+        loss_reward_before = -mean_r
+        grads = -g_loss
+        x = self.conjugate_gradients(grads)
+        assert torch.isfinite(x).all(), "x is not finite"
+        xHx = torch.dot(x, self.fvp(x))
+        assert xHx.item() >= 0, "xHx is negative"
+        alpha = torch.sqrt(2 * target_kl / (xHx + 1e-8))
+        b_grads, mean_c = self.surrogate_grad(d["adv_c"], 1.0)
+        loss_cost_before = mean_c
+        p = self.conjugate_gradients(b_grads)
+        # host scalars for the case analysis (the reference mixes CPU tensors in here, cpo.py:390-391,413)
+        q = xHx.detach().cpu()
+        r = grads.dot(p).cpu()
+        s = b_grads.dot(p).cpu()
+        bb = b_grads.dot(b_grads).cpu()
+        if bb <= 1e-6 and ep_costs < 0:
+            A = torch.zeros(1)
+            B = torch.zeros(1)
+            optim_case = 4
+        else:
+            assert torch.isfinite(r).all(), "r is not finite"
+            assert torch.isfinite(s).all(), "s is not finite"
+            A = q - r ** 2 / (s + 1e-8)
+            B = 2 * target_kl - ep_costs ** 2 / (s + 1e-8)
+            if ep_costs < 0 and B < 0:
+                optim_case = 3
+            elif ep_costs < 0 <= B:
+                optim_case = 2
+            elif ep_costs >= 0 and B >= 0:
+                optim_case = 1
+                if logger:
+                    logger.log("Alert! Attempting feasible recovery!", "yellow")
+            else:
+                optim_case = 0
+                if logger:
+                    logger.log("Alert! Attempting infeasible recovery!", "red")
+        if optim_case in (3, 4):
+            alpha = torch.sqrt(2 * target_kl / (xHx + 1e-8))
+            nu_star = torch.zeros(1)
+            lambda_star = 1 / (alpha.cpu() + 1e-8)
+            step_direction = alpha * x
+        elif optim_case in (1, 2):
+            lambda_a = torch.sqrt(A / B)
+            lambda_b = torch.sqrt(q / (2 * target_kl))
+            r_num = r.item()
+            eps_cost = ep_costs + 1e-8
+            if ep_costs < 0:
+                lambda_a_star = torch.clamp(lambda_a, torch.as_tensor(0.0), r_num / eps_cost)
+                lambda_b_star = torch.clamp(lambda_b, r_num / eps_cost, torch.as_tensor(torch.inf))
+            else:
+                lambda_a_star = torch.clamp(lambda_a, r_num / eps_cost, torch.as_tensor(torch.inf))
+                lambda_b_star = torch.clamp(lambda_b, torch.as_tensor(0.0), r_num / eps_cost)
+            f_a = -0.5 * (A / (lambda_a_star + 1e-8) + B * lambda_a_star) - r * ep_costs / (s + 1e-8)
+            f_b = -0.5 * (q / (lambda_b_star + 1e-8) + 2 * target_kl * lambda_b_star)
+            lambda_star = lambda_a_star if f_a >= f_b else lambda_b_star
+            nu_star = torch.clamp(lambda_star * ep_costs - r, min=0) / (s + 1e-8)
+            step_direction = (1.0 / (lambda_star + 1e-8)).to(self.dev) * (x - nu_star.to(self.dev) * p)
+        else:
+            lambda_star = torch.zeros(1)
+            nu_star = torch.sqrt(2 * target_kl / (s + 1e-8))
+            step_direction = -nu_star.to(self.dev) * p
+
+        # ---- line search (cpo.py:465-519)
+        step_frac = 1.0
+        expected_reward_improve = grads.dot(step_direction)
+        kl = 0.0
+        acceptance_step = 0
+        for step in range(CPO_SEARCHING_STEPS):
+            self.theta_actor.copy_(theta_old + step_frac * step_direction)
+            acceptance_step = step + 1
+            loss_reward, loss_cost, kl = self.linesearch_eval()
+            loss_reward_improve = loss_reward_before - loss_reward
+            loss_cost_diff = loss_cost - loss_cost_before
+            if logger:
+                logger.log(f"Expected Improvement: {expected_reward_improve} Actual: {loss_reward_improve}")
+            if not np.isfinite(kl):
+                if logger:
+                    logger.log("WARNING: KL not finite")
+                continue
+            if (loss_reward_improve < 0) if optim_case > 1 else False:
+                if logger:
+                    logger.log("INFO: did not improve improve <0")
+            elif loss_cost_diff > max(-ep_costs, 0):
+                if logger:
+                    logger.log(f"INFO: no improve {loss_cost_diff} > {max(-ep_costs, 0)}")
+            elif kl > target_kl:
+                if logger:
+                    logger.log(f"INFO: violated KL constraint {kl} at step {step + 1}.")
+            else:
+                if logger:
+                    logger.log(f"Accept step at i={step + 1}")
+                break
+            step_frac *= STEP_FRACTION
+        else:
+            if logger:
+                logger.log("INFO: no suitable step found...")
+            step_direction = torch.zeros_like(step_direction)
+            acceptance_step = 0
+        self.theta_actor.copy_(theta_old + step_frac * step_direction)
+        # the actor's .grad keeps the cost gradient b: it takes part in the critic fit's joint clip (cpo.py:557)
+        self.stale_sq.copy_(b_grads.dot(b_grads).reshape(1))
+        return {"alpha": float(alpha), "final_step_norm": float(torch.norm(step_direction)), "xHx": float(xHx),
+                "gradient_norm": float(torch.norm(grads)), "H_inv_g": float(x.norm()),
+                "acceptance_step": acceptance_step, "loss_actor": loss_reward_before + loss_cost_before, "kl": kl,
+                "case": optim_case, "g": grads, "b": b_grads, "x": x, "p": p, "step_direction": step_direction}
+
+    def critic_fit(self, perm_fn=None):
+        """cpo.py:534-571: learning_iters passes of minibatches (batch_size rows) over both critics."""
+        c = self.cfg
+        cfg = self._cfg_struct()
+        d = self.buffer.data
+        if perm_fn is None:
+            perm_fn = lambda it: torch.randperm(self.M, device=self.dev).to(torch.int32)
+        n_mb = (self.M + cfg.batch - 1) // cfg.batch
+        all_losses = []
+        for it in range(c["learning_iters"]):
+            perm = _abi.require_gpu_tensor(perm_fn(it), "perm", torch.int32)
+            losses = torch.empty((n_mb, 3), dtype=torch.float32, device=self.dev)
+            _abi.check(self.lib.spo_critic_fit_iter(
+                _abi.ptr(self.policy.theta), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), self.adam_step,
+                _abi.ptr(d["obs"]), _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]), _abi.ptr(perm),
+                self.M, cfg, _abi.ptr(self.stale_sq), _abi.ptr(losses), _abi.ptr(self.sync_ws), _abi.stream_ptr()),
+                "spo_critic_fit_iter")
+            self.adam_step += n_mb
+            all_losses.append(losses[:, :2])
+        self.check_sync_error()
+        means = torch.cat(all_losses, 0).mean(0).tolist() if all_losses else [float("nan")] * 2
+        return {"loss_r": means[0], "loss_c": means[1], "losses": all_losses}
+
+
+def _to_dev(x, dev):
+    return torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x, dtype=torch.float32, device=dev).contiguous()
+
+
+def main(args, cfg_env=None):
+    random.seed(args.seed)
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)
+    if args.device == "cpu":
+        raise RuntimeError("this build runs the CPO hot path on a ROCm GPU only (--device cuda); no CPU fallback")
+    comm = init_from_env()
+    device = torch.device(f"cuda:{args.device_id}")
+    torch.cuda.set_device(device)
+    if args.task in isaac_gym_map:
+        raise NotImplementedError("Isaac Gym tasks (isaac_gym_specific_cfg) are not part of this build")
+    config = dict(default_cfg)
+    config.update(getattr(args, "cfg_override", None) or {})
+    env, obs_space, act_space = make_sa_mujoco_env(num_envs=args.num_envs, env_id=args.task, seed=args.seed,
+                                                   device=device, **(getattr(args, "env_kwargs", None) or {}))
+    device_env = getattr(env, "is_device_env", False)
+    steps_per_epoch = config.get("steps_per_epoch", args.steps_per_epoch)
+    total_steps = config.get("total_steps", args.total_steps)
+    local_steps_per_epoch = steps_per_epoch // args.num_envs
+    epochs = total_steps // steps_per_epoch
+    policy = ActorVCritic(obs_dim=obs_space.shape[0], act_dim=act_space.shape[0],
+                          hidden_sizes=config["hidden_sizes"]).to(device)
+    engine = CPOEngine(policy, args.num_envs, local_steps_per_epoch, config, device, comm=comm)
+    dict_args = dict(vars(args))
+    dict_args.update(config)
+    logger = EpochLogger(log_dir=args.log_dir, seed=str(args.seed))
+    logger.save_config(dict_args)
+    logger.setup_torch_saver(policy.actor)
+    logger.log("Start with training.")
+    obs, _ = env.reset()
+    obs = _to_dev(obs, device)
+    timings = []
+    for epoch in range(epochs):
+        rollout_start_time = time.time()
+        for steps in range(local_steps_per_epoch):
+            act = engine.collect_step(steps, obs)
+            action = act if device_env else act.detach().squeeze().cpu().numpy()
+            next_obs, reward, cost, terminated, truncated, info = env.step(action)
+            final_obs = None
+            if "final_observation" in info:
+                fo = info["final_observation"]
+                if not torch.is_tensor(fo):
+                    fo = np.array([a if a is not None else np.zeros(obs.shape[-1]) for a in fo])
+                final_obs = _to_dev(fo, device)
+            next_obs = _to_dev(next_obs, device)
+            engine.post_step(steps, next_obs, _to_dev(reward, device), _to_dev(cost, device),
+                             _to_dev(terminated, device), _to_dev(truncated, device), final_obs)
+            obs = next_obs
+        engine.drain_episode_events(logger)
+        torch.cuda.synchronize(device)
+        rollout_end_time = time.time()
+        eval_end_time = rollout_end_time
+
+        # ---- update policy (cpo.py:350-532) and critics (:534-571)
+        engine.buffer.compute_gae(None, comm)
+        ep_costs = logger.get_stats("Metrics/EpCost") - args.cost_limit
+        out = engine.policy_update(ep_costs, logger)
+        logger.store(**{"Misc/Alpha": out["alpha"], "Misc/FinalStepNorm": out["final_step_norm"], "Misc/xHx": out["xHx"],
+                        "Misc/gradient_norm": out["gradient_norm"], "Misc/H_inv_g": out["H_inv_g"],
+                        "Misc/AcceptanceStep": out["acceptance_step"], "Loss/Loss_actor": out["loss_actor"],
+                        "Train/KL": out["kl"]})
+        fit = engine.critic_fit()
+        engine.buffer.reset()
+        logger.store(**{"Loss/Loss_reward_critic": fit["loss_r"], "Loss/Loss_cost_critic": fit["loss_c"]})
+        torch.cuda.synchronize(device)
+        update_end_time = time.time()
+        timings.append((rollout_end_time - rollout_start_time, update_end_time - eval_end_time))
+        if not logger.logged:
+            logger.log_tabular("Metrics/EpRet")
+            logger.log_tabular("Metrics/EpCost")
+            logger.log_tabular("Metrics/EpLen")
+            logger.log_tabular("Train/Epoch", epoch + 1)
+            logger.log_tabular("Train/TotalSteps", (epoch + 1) * args.steps_per_epoch)
+            logger.log_tabular("Train/KL")
+            logger.log_tabular("Loss/Loss_reward_critic")
+            logger.log_tabular("Loss/Loss_cost_critic")
+            logger.log_tabular("Loss/Loss_actor")
+            logger.log_tabular("Time/Rollout", rollout_end_time - rollout_start_time)
+            logger.log_tabular("Time/Update", update_end_time - eval_end_time)
+            logger.log_tabular("Time/Total", update_end_time - rollout_start_time)
+            d = engine.buffer.data
+            logger.log_tabular("Value/RewardAdv", d["adv_r"].mean().item())
+            logger.log_tabular("Value/CostAdv", d["adv_c"].mean().item())
+            logger.log_tabular("Misc/Alpha")
+            logger.log_tabular("Misc/FinalStepNorm")
+            logger.log_tabular("Misc/xHx")
+            logger.log_tabular("Misc/gradient_norm")
+            logger.log_tabular("Misc/H_inv_g")
+            logger.log_tabular("Misc/AcceptanceStep")
+            logger.dump_tabular()
+            if (epoch + 1) % 100 == 0 or epoch == 0:
+                logger.torch_save(itr=epoch)
+                logger.save_state(state_dict={"Normalizer": getattr(env, "obs_rms", None)}, itr=epoch)
+        else:
+            for k in list(logger.epoch_dict):
+                logger.epoch_dict[k] = []
+    logger.close()
+    return {"timings": timings, "policy": policy, "engine": engine}
+
+
+if __name__ == "__main__":
+    args, cfg_env = single_agent_args()
+    relpath = time.strftime("%Y-%m-%d-%H-%M-%S")
+    subfolder = "-".join(["seed", str(args.seed).zfill(3)])
+    relpath = "-".join([subfolder, relpath])
+    algo = os.path.basename(__file__).split(".")[0]
+    args.log_dir = os.path.join(args.log_dir, args.experiment, args.task, algo, relpath)
+    if not args.write_terminal:
+        os.makedirs(args.log_dir, exist_ok=True)
+        with open(os.path.join(args.log_dir, f"seed{args.seed}_terminal.log"), "w", encoding="utf-8") as f_out, \
+                open(os.path.join(args.log_dir, f"seed{args.seed}_error.log"), "w", encoding="utf-8") as f_err:
+            sys.stdout, sys.stderr = f_out, f_err
+            main(args, cfg_env)
+    else:
+        main(args, cfg_env)

@@ -420,3 +420,120 @@ def test_library_is_loaded_from_tree(dev):
     _abi.load()
     maps = open("/proc/self/maps").read()
     assert "libsafepo_hip.so" in maps
+
+
+# ---------------------------------------------------------------------------------------- CPO (config 3)
+def _cpo_engine(z, prefix, dev, N, T, cfg_over=None):
+    from safepo.single_agent.cpo import CPOEngine, default_cfg
+    pol = _policy_from_npz(z, prefix, dev)
+    cfg = dict(default_cfg)
+    cfg.update(cfg_over or {})
+    return pol, CPOEngine(pol, N, T, cfg, dev)
+
+
+def test_cpo_fvp_known_answers_from_reference(dev, golden_dir):
+    """FVP vectors recorded from the reference's double-backward fvp() (cpo.py:132-157)."""
+    z = np.load(os.path.join(golden_dir, "cpo_trace.npz"))
+    N, T = int(z["meta_num_envs"]), int(z["meta_T"])
+    pol, eng = _cpo_engine(z, "init_sd_", dev, N, T)
+    eng.buffer.data["obs"].copy_(torch.from_numpy(z["e0_raw_obs"]))
+    for i in range(3):
+        sd = {"actor." + k[len(f"fvp_sd{i}_"):]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith(f"fvp_sd{i}_")}
+        pol.load_state_dict(sd, strict=False)
+        got = eng.fvp(torch.from_numpy(z[f"fvp_in{i}"]).to(dev)).cpu().numpy()
+        ref = z[f"fvp_out{i}"]
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
+
+
+def test_cpo_surrogate_gradients_vs_oracle(dev):
+    from safepo.single_agent.cpo import CPOEngine, default_cfg
+    from safepo.common.model import ActorVCritic
+    torch.manual_seed(4)
+    M, D, A = 1000, 60, 8
+    pol = ActorVCritic(D, A).to(dev)
+    with torch.no_grad():
+        pol.actor.log_std.copy_(torch.randn(A) * 0.2)
+    eng = CPOEngine(pol, 1, M, dict(default_cfg), dev)
+    obs, act, logp, _, _, adv = _synthetic_update_problem(M, D, A, seed=9)
+    b = eng.buffer
+    b.data["obs"].copy_(obs.view(1, M, D)); b.data["act"].copy_(act.view(1, M, A)); b.data["log_prob"].copy_(logp.view(1, M))
+    b.data["adv_r"].copy_(adv.view(1, M)); b.data["adv_c"].copy_((adv * 0.5 + 0.1).view(1, M))
+    ref = R.OraclePolicy(D, A)
+    ref.load_state_dict({k: v.cpu().clone() for k, v in pol.state_dict().items()})
+    data = {"obs": obs, "act": act, "log_prob": logp, "adv_r": adv, "adv_c": adv * 0.5 + 0.1}
+    for which, key, sign in (("r", "adv_r", -1.0), ("c", "adv_c", 1.0)):
+        ref.actor.zero_grad()
+        loss = R.cpo_surrogate(ref, data, which)
+        loss.backward()
+        g_ref = R.actor_flat_grads(ref.actor).numpy()
+        g, mean = eng.surrogate_grad(b.data[key], sign)
+        np.testing.assert_allclose(g.cpu().numpy(), g_ref, rtol=1e-4, atol=1e-5 * np.abs(g_ref).max())
+        assert sign * mean == pytest.approx(float(loss), rel=1e-5)
+    # FVP against the oracle's double backward, random direction
+    v = torch.randn(eng.Pa)
+    hv_ref = R.cpo_fvp(v, ref, obs).numpy()
+    np.testing.assert_allclose(eng.fvp(v.to(dev)).cpu().numpy(), hv_ref, rtol=1e-4, atol=1e-5 * np.abs(hv_ref).max())
+    # line-search evaluation at the unchanged parameters: KL == 0, losses == the surrogates
+    eng.snapshot_old_distribution()
+    lr_, lc_, kl = eng.linesearch_eval()
+    assert kl == pytest.approx(0.0, abs=1e-9)
+    assert lr_ == pytest.approx(float(R.cpo_surrogate(ref, data, "r")), rel=1e-5)
+    assert lc_ == pytest.approx(float(R.cpo_surrogate(ref, data, "c")), rel=1e-5)
+
+
+def test_cpo_update_vs_reference_main_trace(dev, golden_dir):
+    """Replays the reference cpo.main(): CG, case analysis (incl. an infeasible-recovery epoch), line search,
+    actor parameters after the step, critic fit with the recorded shuffles."""
+    z = np.load(os.path.join(golden_dir, "cpo_trace.npz"))
+    N, T, epochs = int(z["meta_num_envs"]), int(z["meta_T"]), int(z["meta_epochs"])
+    pol, eng = _cpo_engine(z, "init_sd_", dev, N, T, {"learning_iters": int(z["meta_cfg_learning_iters"]),
+                                                       "batch_size": int(z["e0_batch_size"]),
+                                                       "target_kl": float(z["meta_cfg_target_kl"])})
+    cases = []
+    for e in range(epochs):
+        ref_before = np.concatenate([z[f"e{e}_sd_before_{k}"].reshape(-1) for k in pol.state_dict()])
+        _assert_params_close(pol.theta.cpu().numpy(), ref_before, 1e-3, 8, rtol=2e-3, atol=2e-5, what=f"theta before epoch {e}")
+        _load_epoch_into_engine(z, e, eng, dev)
+        eng.buffer.compute_gae(None)
+        assert np.array_equal(eng.buffer.data["target_value_c"].cpu().numpy(), z[f"e{e}_raw_target_value_c"])
+        ep_costs = float(z[f"e{e}_get_stats_Metrics_EpCost"]) - float(z["meta_arg_cost_limit"])
+        out = eng.policy_update(ep_costs)
+        cases.append(out["case"])
+        assert out["acceptance_step"] == int(z[f"e{e}_Misc_AcceptanceStep"])
+        assert out["xHx"] == pytest.approx(float(z[f"e{e}_Misc_xHx"]), rel=5e-3)
+        assert out["H_inv_g"] == pytest.approx(float(z[f"e{e}_Misc_H_inv_g"]), rel=5e-3)
+        assert out["gradient_norm"] == pytest.approx(float(z[f"e{e}_Misc_gradient_norm"]), rel=1e-4)
+        assert out["final_step_norm"] == pytest.approx(float(z[f"e{e}_Misc_FinalStepNorm"]), rel=5e-3)
+        assert out["alpha"] == pytest.approx(float(z[f"e{e}_Misc_Alpha"]), rel=5e-3)
+        assert out["kl"] == pytest.approx(float(z[f"e{e}_Train_KL"]), rel=2e-2)
+        assert out["loss_actor"] == pytest.approx(float(z[f"e{e}_Loss_Loss_actor"]), rel=1e-3, abs=1e-6)
+        act_ref = np.concatenate([z[f"e{e}_actor_after_{k}"].reshape(-1) for k in pol.actor.state_dict()])
+        np.testing.assert_allclose(eng.theta_actor.cpu().numpy(), act_ref, rtol=5e-3, atol=2e-5)
+        iters = int(z["meta_cfg_learning_iters"])
+        perms = [torch.from_numpy(z[f"e{e}_perm{i}"].astype(np.int32)).to(dev) for i in range(iters)]
+        fit = eng.critic_fit(perm_fn=lambda it: perms[it])
+        eng.buffer.reset()
+        got = torch.cat(fit["losses"], 0).cpu().numpy()
+        np.testing.assert_allclose(got, z[f"e{e}_mb_losses"][:, :2], rtol=2e-3, atol=1e-5)
+    assert cases[1] in (0, 1)
+    ref_final = np.concatenate([z[f"final_sd_{k}"].reshape(-1) for k in pol.state_dict()])
+    _assert_params_close(pol.theta.cpu().numpy(), ref_final, 1e-3, 12, rtol=5e-3, atol=5e-5, what="final theta")
+
+
+def test_cpo_main_entrypoint_synthetic(dev, tmp_path):
+    import argparse
+    import csv
+    from safepo.single_agent import cpo
+    args = argparse.Namespace(seed=0, use_eval=False, task="SynthSafe-v0", num_envs=16, experiment="t",
+                              log_dir=str(tmp_path / "exp" / "task" / "run"), device="cuda", device_id=0,
+                              write_terminal=True, headless=False, total_steps=2 * 16 * 64, steps_per_epoch=16 * 64,
+                              randomize=False, cost_limit=25.0, lagrangian_multiplier_init=0.001,
+                              lagrangian_multiplier_lr=0.035, cfg_override={"learning_iters": 2},
+                              env_kwargs={"trunc_len": 16})
+    cpo.main(args, {})
+    rows = list(csv.DictReader(open(tmp_path / "exp" / "task" / "run" / "progress.csv")))
+    assert len(rows) == 2
+    for col in ("Metrics/EpRet", "Train/KL", "Loss/Loss_actor", "Misc/Alpha", "Misc/FinalStepNorm", "Misc/xHx",
+                "Misc/gradient_norm", "Misc/H_inv_g", "Misc/AcceptanceStep", "Time/Update"):
+        assert col in rows[0], col
+    assert float(rows[0]["Misc/xHx"]) >= 0
