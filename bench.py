@@ -31,6 +31,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 GAE_BYTES_PER_ELEM = 33.0       # 4 f32 in + 1 u8 mask + 4 f32 out
+GAE_REPS = 20                   # back-to-back launches per timed epoch (event timing cannot resolve one ~10 us launch)
 
 
 def cpu_baseline(sample_envs: int, T: int, threads: int = 4):
@@ -74,6 +75,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-envs", type=int, default=32)
     ap.add_argument("--stream-envs", type=int, default=262144, help="extra GAE roofline point that streams from HBM")
+    ap.add_argument("--algo", choices=["ppo_lag", "cpo"], default="ppo_lag",
+                    help="cpo = BASELINE config 3 (not the headline metric; single GPU)")
     a = ap.parse_args()
 
     from safepo import _abi
@@ -94,7 +97,12 @@ def main():
            "learning_iters": a.learning_iters, "max_grad_norm": 40.0}
     policy = ActorVCritic(D, A).to(dev)
     comm.broadcast_(policy.theta, 0)
-    eng = PPOLagEngine(policy, N, T, cfg, dev, comm=comm)
+    if a.algo == "cpo":
+        from safepo.single_agent.cpo import CPOEngine, default_cfg as cpo_cfg
+        cfg = dict(cpo_cfg)
+        eng = CPOEngine(policy, N, T, cfg, dev, comm=comm)
+    else:
+        eng = PPOLagEngine(policy, N, T, cfg, dev, comm=comm)
     env = SynthDeviceEnv(N, D, A, seed=1234 + comm.rank, p_term=0.0, p_cost=0.1, trunc_len=64, device=dev)
     obs, _ = env.reset()
     lam = 0.001
@@ -111,12 +119,16 @@ def main():
         n_ep = eng.drain_episode_events(None)
         torch.cuda.synchronize(dev)
         t1 = time.time()
-        if timed:   # HIP events around the GAE scan kernel of this epoch (same stream)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            eng.buffer._gae_events = (e0, e1)
-            gae_events.append((e0, e1))
-        out = eng.update(lam)
-        eng.buffer._gae_events = None
+        if a.algo == "cpo":
+            eng.buffer.compute_gae(None, comm)
+            pu = eng.policy_update(-1.0)
+            fit = eng.critic_fit()
+            eng.buffer.reset()
+            out = {"stop_iter": pu["acceptance_step"], "kl": pu["kl"]}
+        else:
+            out = eng.update(lam)
+        if timed:   # GAE scan of THIS epoch's buffer: graph of GAE_REPS launches between HIP events (~0.1 ms)
+            gae_events.append(eng.buffer.time_scan(GAE_REPS))
         torch.cuda.synchronize(dev)
         t2 = time.time()
         return t1 - t0, t2 - t1, out, n_ep
@@ -144,8 +156,10 @@ def main():
     total_env_steps = world * N * T * a.steps
     value = total_env_steps / elapsed
     n_mb = (N * T + 63) // 64
-    gae_ms = [e0.elapsed_time(e1) for e0, e1 in gae_events]
-    gae_avg_s = (sum(gae_ms) / len(gae_ms)) * 1e-3 if gae_ms else float("nan")
+    if a.algo == "cpo":
+        n_mb = (N * T + 127) // 128
+    gae_ms = gae_events
+    gae_avg_s = (sum(gae_ms) / len(gae_ms)) if gae_ms else float("nan")
     seg_ends = int(eng.buffer.seg_end.sum().item())
     gae_bytes = GAE_BYTES_PER_ELEM * N * T + 8.0 * seg_ends
     achieved = gae_bytes / gae_avg_s / 1e9
@@ -158,7 +172,9 @@ def main():
             traffic = None
     roofline = {"kernel": "gae_kernel<4,32> (spo_gae_fused)", "bound": "hbm", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "bytes_per_launch": gae_bytes, "avg_launch_us": round(gae_avg_s * 1e6, 2), "launches_timed": len(gae_ms)}
+                "bytes_per_launch": gae_bytes, "avg_launch_us": round(gae_avg_s * 1e6, 2), "launches_timed": len(gae_ms) * GAE_REPS,
+                "note": "HIP events around a hipGraph of 20 back-to-back launches, once per timed epoch, inside the timed region "
+                        "(includes the ~1.5 us kernel boundary of each launch)"}
 
     # extra roofline point on a buffer that cannot sit in the 256 MiB Infinity Cache (untimed, after the run)
     stream = None
@@ -172,20 +188,7 @@ def main():
         big.seg_end[:, T - 1] = 1
         big.seg_end[:, T // 2 - 1] = 1
         big.compute_gae(None)
-        torch.cuda.synchronize(dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 10
-        d = big.data
-        e0.record()
-        for _ in range(reps):
-            _abi.check(big._lib.spo_gae_fused(
-                _abi.ptr(d["reward"]), _abi.ptr(d["cost"]), _abi.ptr(d["value_r"]), _abi.ptr(d["value_c"]),
-                _abi.ptr(big.seg_end), _abi.ptr(big.boot_r), _abi.ptr(big.boot_c), _abi.ptr(d["adv_r"]),
-                _abi.ptr(d["adv_c"]), _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]),
-                _abi.ptr(big._partials), Ns, T, 0.99, 0.95, 0.95, _abi.stream_ptr()), "gae")
-        e1.record()
-        torch.cuda.synchronize(dev)
-        t_s = e0.elapsed_time(e1) * 1e-3 / reps
+        t_s = big.time_scan(10)
         b = GAE_BYTES_PER_ELEM * Ns * T + 8.0 * 2 * Ns
         stream = {"num_envs": Ns, "bytes_per_launch": b, "avg_launch_us": round(t_s * 1e6, 1),
                   "achieved": round(b / t_s / 1e9, 1), "unit": "GB/s", "frac": round(b / t_s / 1e9 / HBM_PEAK_GBS, 4)}
@@ -194,7 +197,7 @@ def main():
         stream = {"error": str(e)[:200]}
 
     cpu = None
-    if world == 1 and not a.no_cpu_baseline:
+    if world == 1 and not a.no_cpu_baseline and a.algo == "ppo_lag":
         cpu = cpu_baseline(a.cpu_sample_envs, T)
 
     line = {
@@ -202,16 +205,19 @@ def main():
         "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"ppo_lag synthetic env (obs=60, act=8), num_envs={N} per GPU, num_steps={T}, "
-                               f"default_cfg batch 64 x {a.learning_iters} learning iters (target_kl=inf: all iters run), "
-                               f"device-resident env", "global_envs": world * N,
+        "config": {"workload": (f"ppo_lag synthetic env (obs=60, act=8), num_envs={N} per GPU, num_steps={T}, "
+                                f"default_cfg batch 64 x {a.learning_iters} learning iters (target_kl=inf: all iters run), "
+                                f"device-resident env") if a.algo == "ppo_lag" else
+                               (f"cpo synthetic env (obs=60, act=8), num_envs={N}, num_steps={T}, default_cfg "
+                                f"(15 CG iters, 33 FVPs, line search, critic fit batch 128 x 10 iters), device-resident env"),
+                   "global_envs": world * N,
                    "parallelism": f"dp{world} over num_envs, per-minibatch flat-grad all-reduce" if world > 1 else "single GPU",
                    "minibatch_steps_per_epoch": n_mb * a.learning_iters},
         "roofline": roofline,
         "roofline_hbm_streaming": stream,
         "cpu_baseline": cpu,
         "phases": {"rollout_s_per_epoch": round(roll / a.steps, 4), "update_s_per_epoch": round(upd / a.steps, 4),
-                   "update_us_per_minibatch_step": round(upd / a.steps / (n_mb * a.learning_iters) * 1e6, 3),
+                   "update_us_per_minibatch_step": round(upd / a.steps / (n_mb * (a.learning_iters if a.algo == "ppo_lag" else 10)) * 1e6, 3),
                    "stop_iter": last["stop_iter"], "kl": last["kl"], "episodes_per_epoch": n_ep},
     }
     if cpu:

@@ -56,6 +56,10 @@ int spo_gae_fused(const float* reward, const float* cost, const float* value_r, 
                   double* partials, int64_t num_envs, int64_t T,
                   double gamma, double lam, double lam_c, void* stream);
 
+/* Debug/bench knob: 0 = automatic, 1 = eager bootstrap loads (latency-optimised, cache-resident
+ * buffers), 2 = predicated bootstrap loads (fewest bytes, HBM-streaming buffers). */
+int spo_debug_gae_variant(int v);
+
 /* ---- a-6: statistics of VectorizedOnPolicyBuffer.get() (buffer.py:154-160).
  * spo_adv_reduce: partials -> sums[4] = {sum adv_r, sum adv_r^2, sum adv_c, count} (fixed order,
  * deterministic).  Multi-GPU: all-reduce(sum) sums[] between the two calls.

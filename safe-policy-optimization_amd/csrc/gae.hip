@@ -23,6 +23,26 @@ __device__ __forceinline__ double shfl_down_d(double x, int off) {
   return __shfl_down(x, off, LPR);
 }
 
+// v + (v moved by the DPP control, +0.0 where the source lane is out of range / the row is masked)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_d(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int slo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+  const int shi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  return v + __hiloint2double(shi, slo);
+}
+// Wave-wide fp64 sum without LDS traffic: row_shr 1,2,4,8 (prefix sums inside each 16-lane row), then
+// row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3.  The total ends up in lane 63.
+__device__ __forceinline__ double wave_sum_to_lane63(double v) {
+  v = dpp_add_d<0x111, 0xf>(v);
+  v = dpp_add_d<0x112, 0xf>(v);
+  v = dpp_add_d<0x114, 0xf>(v);
+  v = dpp_add_d<0x118, 0xf>(v);
+  v = dpp_add_d<0x142, 0xa>(v);
+  v = dpp_add_d<0x143, 0xc>(v);
+  return v;
+}
+
 struct GaeArgs {
   const float* reward; const float* cost; const float* value_r; const float* value_c;
   const uint8_t* seg_end; const float* boot_r; const float* boot_c;
@@ -30,6 +50,7 @@ struct GaeArgs {
   double* partials;
   int64_t N; int64_t T;
   float gamma32; double disc_r; double disc_c;
+  int ablate;     // debug timing knob: 1 skip stats reduction, 2 skip cross-lane scan, 4 skip stores
 };
 
 template <int VEC> struct VecT;
@@ -53,7 +74,11 @@ __device__ __forceinline__ void store_vec(float* p, bool ok, const float (&o)[VE
 }
 
 // One affine map c_out = A*c_in + B, composed right-to-left.
-template <int VEC, int LPR>
+// EAGER_BOOT: load the bootstrap arrays unconditionally (8 extra B/element) instead of only at
+// path ends.  Removes a dependent memory round trip (seg_end -> boot) -- used when the buffer is
+// cache-resident and the launch is latency-bound; the predicated form moves fewer bytes and is
+// used for buffers that stream from HBM.
+template <int VEC, int LPR, bool EAGER_BOOT>
 __global__ __launch_bounds__(256) void gae_kernel(GaeArgs a) {
   constexpr int ROWS_PER_WAVE = 64 / LPR;
   constexpr int CHUNK = LPR * VEC;
@@ -69,7 +94,7 @@ __global__ __launch_bounds__(256) void gae_kernel(GaeArgs a) {
   double carry_c[2] = {0.0, 0.0};       // c at the first element of the chunk to the right
   float carry_v[2] = {0.f, 0.f};        // value at that element (v_{t+1} across the chunk edge)
   bool carry_any = false;               // a seg_end exists to the right of this chunk
-  double s_r = 0.0, s_r2 = 0.0, s_c = 0.0, s_n = 0.0;
+  double s_r = 0.0, s_r2 = 0.0, s_c = 0.0;
   const double disc[2] = {a.disc_r, a.disc_c};
 
   const int nchunks = (int)((T + CHUNK - 1) / CHUNK);
@@ -92,6 +117,11 @@ __global__ __launch_bounds__(256) void gae_kernel(GaeArgs a) {
     bool lane_seg = false;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) lane_seg |= seg[e];
+    float bt[2][VEC];
+    if (EAGER_BOOT) {
+      load_vec<VEC>(a.boot_r + rbase + t0, ok, bt[0]);
+      load_vec<VEC>(a.boot_c + rbase + t0, ok, bt[1]);
+    }
 
     // which lanes of my row hold a segment end (wave-wide ballot, then my row's slice)
     const unsigned long long ball = __ballot(lane_seg);
@@ -113,7 +143,8 @@ __global__ __launch_bounds__(256) void gae_kernel(GaeArgs a) {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         float vn = (e == VEC - 1) ? vnext_edge[k] : vv[k][e + 1];
-        if (seg[e]) vn = boot[rbase + t0 + e];                 // predicated: only at path ends
+        if (EAGER_BOOT) vn = seg[e] ? bt[k][e] : vn;
+        else if (seg[e]) vn = boot[rbase + t0 + e];            // predicated: only at path ends
         // deltas = rewards[:-1] + gamma * values[1:] - values[:-1]   (fp32, buffer.py:198)
         float d = __fsub_rn(__fadd_rn(rw[k][e], __fmul_rn(a.gamma32, vn)), vv[k][e]);
         delta[k][e] = (double)d;
@@ -134,6 +165,7 @@ __global__ __launch_bounds__(256) void gae_kernel(GaeArgs a) {
       }
     }
     // inclusive suffix scan over the row's lanes
+    if (!(a.ablate & 2))
 #pragma unroll
     for (int off = 1; off < LPR; off <<= 1) {
 #pragma unroll
@@ -171,15 +203,16 @@ __global__ __launch_bounds__(256) void gae_kernel(GaeArgs a) {
         oadv[k][e] = adv; otgt[k][e] = tgt;
       }
     }
-    store_vec<VEC>(a.adv_r + rbase + t0, ok, oadv[0]);
-    store_vec<VEC>(a.adv_c + rbase + t0, ok, oadv[1]);
-    store_vec<VEC>(a.target_r + rbase + t0, ok, otgt[0]);
-    store_vec<VEC>(a.target_c + rbase + t0, ok, otgt[1]);
+    const bool st_ok = ok && !(a.ablate & 4);
+    store_vec<VEC>(a.adv_r + rbase + t0, st_ok, oadv[0]);
+    store_vec<VEC>(a.adv_c + rbase + t0, st_ok, oadv[1]);
+    store_vec<VEC>(a.target_r + rbase + t0, st_ok, otgt[0]);
+    store_vec<VEC>(a.target_c + rbase + t0, st_ok, otgt[1]);
     if (ok) {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         double x = (double)oadv[0][e];
-        s_r += x; s_r2 += x * x; s_c += (double)oadv[1][e]; s_n += 1.0;
+        s_r += x; s_r2 += x * x; s_c += (double)oadv[1][e];
       }
     }
     // carries for the chunk to the left: values at the first lane of my row group
@@ -192,18 +225,23 @@ __global__ __launch_bounds__(256) void gae_kernel(GaeArgs a) {
     carry_any = carry_any || (grp != 0ull);
   }
 
-  // block reduction in a fixed order -> partials[block][4]
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    s_r += __shfl_xor(s_r, off); s_r2 += __shfl_xor(s_r2, off);
-    s_c += __shfl_xor(s_c, off); s_n += __shfl_xor(s_n, off);
-  }
-  __shared__ double red[4][4];
-  if (lane == 0) { red[wave][0] = s_r; red[wave][1] = s_r2; red[wave][2] = s_c; red[wave][3] = s_n; }
+  // block reduction in a fixed order -> partials[block][4] = {sum adv_r, sum adv_r^2, sum adv_c, count}
+  if (a.ablate & 1) return;
+  s_r = wave_sum_to_lane63(s_r);
+  s_r2 = wave_sum_to_lane63(s_r2);
+  s_c = wave_sum_to_lane63(s_c);
+  __shared__ double red[4][3];
+  if (lane == 63) { red[wave][0] = s_r; red[wave][1] = s_r2; red[wave][2] = s_c; }
   __syncthreads();
-  if (threadIdx.x < 4) {
-    double t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (threadIdx.x < 3) {
+    const double t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
     a.partials[(int64_t)blockIdx.x * SPO_GAE_PARTIAL_STRIDE + threadIdx.x] = t;
+  } else if (threadIdx.x == 3) {
+    // number of elements this block covered (every element of a valid row is counted)
+    constexpr int ROWS_PER_BLOCK = 4 * ROWS_PER_WAVE;
+    int64_t rows = a.N - (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+    rows = rows < 0 ? 0 : (rows > ROWS_PER_BLOCK ? ROWS_PER_BLOCK : rows);
+    a.partials[(int64_t)blockIdx.x * SPO_GAE_PARTIAL_STRIDE + 3] = (double)(rows * T);
   }
 }
 
@@ -262,6 +300,7 @@ __global__ __launch_bounds__(256) void adv_apply_kernel(float* adv_r, float* adv
   }
 }
 
+int g_gae_force_variant = 0;    // 0 auto, 1 eager bootstrap loads, 2 predicated (debug/bench knob)
 struct GaeGeom { int vec; int lpr; int rows_per_block; };
 inline GaeGeom gae_geom(int64_t T) {
   GaeGeom g;
@@ -274,10 +313,10 @@ inline GaeGeom gae_geom(int64_t T) {
   return g;
 }
 
-template <int VEC>
+template <int VEC, bool EAGER>
 int launch_gae(const GaeGeom& g, const GaeArgs& a, int blocks, hipStream_t st) {
   switch (g.lpr) {
-#define SPO_CASE(L) case L: hipLaunchKernelGGL((gae_kernel<VEC, L>), dim3(blocks), dim3(256), 0, st, a); break;
+#define SPO_CASE(L) case L: hipLaunchKernelGGL((gae_kernel<VEC, L, EAGER>), dim3(blocks), dim3(256), 0, st, a); break;
     SPO_CASE(1) SPO_CASE(2) SPO_CASE(4) SPO_CASE(8) SPO_CASE(16) SPO_CASE(32) SPO_CASE(64)
 #undef SPO_CASE
     default: return spo::fail(-1, "gae: bad lanes-per-row %d", g.lpr);
@@ -303,14 +342,21 @@ extern "C" int spo_gae_fused(const float* reward, const float* cost, const float
                   target_c && partials, "gae: null pointer");
   GaeGeom g = gae_geom(T);
   GaeArgs a{reward, cost, value_r, value_c, seg_end, boot_r, boot_c, adv_r, adv_c, target_r, target_c, partials,
-            num_envs, T, (float)gamma, gamma * lam, gamma * lam_c};
+            num_envs, T, (float)gamma, gamma * lam, gamma * lam_c, g_gae_force_variant >> 4};
   const int blocks = spo_gae_num_blocks(num_envs, T);
   hipStream_t st = (hipStream_t)stream;
-  int rc = g.vec == 4 ? launch_gae<4>(g, a, blocks, st) : launch_gae<1>(g, a, blocks, st);
+  // predicated bootstrap loads by default (fewest bytes; measured equal or faster at every size)
+  const int fv = g_gae_force_variant & 15;
+  const bool eager = fv == 1;
+  int rc;
+  if (g.vec == 4) rc = eager ? launch_gae<4, true>(g, a, blocks, st) : launch_gae<4, false>(g, a, blocks, st);
+  else rc = eager ? launch_gae<1, true>(g, a, blocks, st) : launch_gae<1, false>(g, a, blocks, st);
   if (rc) return rc;
   SPO_LAUNCH_CHECK("spo_gae_fused");
   return 0;
 }
+
+extern "C" int spo_debug_gae_variant(int v) { g_gae_force_variant = v; return 0; }
 
 extern "C" int spo_adv_reduce(const double* partials, int num_blocks, double* sums, void* stream) {
   SPO_REQUIRE(partials && sums && num_blocks > 0, "adv_reduce: bad args");

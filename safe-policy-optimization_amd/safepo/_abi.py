@@ -32,6 +32,7 @@ PROTOTYPES = {
     "spo_last_error": (c_char_p, []),
     "spo_gae_num_blocks": (c_int, [c_int64, c_int64]),
     "spo_gae_fused": (c_int, [P] * 12 + [c_int64, c_int64, c_double, c_double, c_double, P]),
+    "spo_debug_gae_variant": (c_int, [c_int]),
     "spo_adv_reduce": (c_int, [P, c_int, P, P]),
     "spo_adv_apply": (c_int, [P, P, P, P, c_int64, c_double, c_int, c_int, P, P]),
     "spo_policy_step": (c_int, [P] * 12 + [c_int64, c_int64, c_int64, c_int, c_int, P]),

@@ -82,16 +82,14 @@ class VectorizedOnPolicyBuffer:
         `comm`: optional safepo.parallel.Comm -- statistics are all-reduced over the env shards."""
         d, lib, st = self.data, self._lib, _abi.stream_ptr()
         N, T = self.num_envs, self.size
-        ev = getattr(self, "_gae_events", None)      # optional (start, end) HIP events around the scan (bench.py)
-        if ev:
-            ev[0].record()
-        _abi.check(lib.spo_gae_fused(
-            _abi.ptr(d["reward"]), _abi.ptr(d["cost"]), _abi.ptr(d["value_r"]), _abi.ptr(d["value_c"]),
-            _abi.ptr(self.seg_end), _abi.ptr(self.boot_r), _abi.ptr(self.boot_c), _abi.ptr(d["adv_r"]),
-            _abi.ptr(d["adv_c"]), _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]),
-            _abi.ptr(self._partials), N, T, self._gamma, self._lam, self._lam_c, st), "spo_gae_fused")
-        if ev:
-            ev[1].record()
+        def launch_scan():
+            return lib.spo_gae_fused(
+                _abi.ptr(d["reward"]), _abi.ptr(d["cost"]), _abi.ptr(d["value_r"]), _abi.ptr(d["value_c"]),
+                _abi.ptr(self.seg_end), _abi.ptr(self.boot_r), _abi.ptr(self.boot_c), _abi.ptr(d["adv_r"]),
+                _abi.ptr(d["adv_c"]), _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]),
+                _abi.ptr(self._partials), N, T, self._gamma, self._lam, self._lam_c, _abi.stream_ptr())
+        self._launch_scan = launch_scan
+        _abi.check(launch_scan(), "spo_gae_fused")
         _abi.check(lib.spo_adv_reduce(_abi.ptr(self._partials), self._partials.shape[0], _abi.ptr(self.sums), st),
                    "spo_adv_reduce")
         if comm is not None and comm.world_size > 1:
@@ -124,3 +122,35 @@ class VectorizedOnPolicyBuffer:
         self.seg_end.zero_()
         self.boot_r.zero_()
         self.boot_c.zero_()
+
+    def time_scan(self, reps: int = 20) -> float:
+        """Average GPU time (seconds) of one spo_gae_fused launch on the current buffer contents:
+        `reps` launches captured in a HIP graph and replayed between two HIP events, so neither host
+        launch cost nor event resolution pollutes a ~5 us kernel.  The scan is idempotent.
+        Falls back to an eager loop if graph capture is unavailable."""
+        launch = self._launch_scan
+        torch.cuda.synchronize(self._device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        try:
+            side = torch.cuda.Stream(device=self._device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                _abi.check(launch(), "spo_gae_fused")
+                torch.cuda.synchronize(self._device)
+                with torch.cuda.graph(graph, stream=side):
+                    for _ in range(reps):
+                        launch()
+                graph.replay()
+                torch.cuda.synchronize(self._device)
+                e0.record()
+                graph.replay()
+                e1.record()
+                torch.cuda.synchronize(self._device)
+        except Exception:
+            torch.cuda.synchronize(self._device)
+            e0.record()
+            for _ in range(reps):
+                launch()
+            e1.record()
+            torch.cuda.synchronize(self._device)
+        return e0.elapsed_time(e1) * 1e-3 / reps

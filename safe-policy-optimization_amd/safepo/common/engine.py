@@ -176,7 +176,8 @@ class PPOLagEngine:
         losses = torch.empty((n_mb, 3), dtype=torch.float32, device=self.dev)
         st = _abi.stream_ptr()
         th = self.policy.theta
-        if self.comm.world_size == 1:
+        import os
+        if self.comm.world_size == 1 and os.environ.get("SPO_FORCE_DP", "0") != "1":
             _abi.check(self.lib.spo_ppo_lag_update_iter(
                 _abi.ptr(th), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), self.adam_step, _abi.ptr(d["obs"]),
                 _abi.ptr(d["act"]), _abi.ptr(d["log_prob"]), _abi.ptr(d["target_value_r"]),
