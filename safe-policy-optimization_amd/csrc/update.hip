@@ -78,11 +78,24 @@ __device__ __forceinline__ AdamOut adam1(float p, float g, float m, float v, flo
   return o;
 }
 // DST = updated parameter; M, V (vector elements or scalars) updated in place.
+#ifdef SPO_ABLATE_ADAM_STATE
+#define SPO_ST_MV(IDX, M, V)
+#else
+#define SPO_ST_MV(IDX, M, V) { a.adam_m[IDX] = (M); a.adam_v[IDX] = (V); }
+#endif
+#ifdef SPO_ABLATE_ADAM_STATE
+#define SPO_ADAM(DST, P, G, M, V)                                                      \
+  {                                                                                    \
+    const AdamOut _o = adam1((P), (G), 0.f, 0.f, b1c, b2c, eps, step_size, inv_bc2s);  \
+    (DST) = _o.p;                                                                      \
+  }
+#else
 #define SPO_ADAM(DST, P, G, M, V)                                                      \
   {                                                                                    \
     const AdamOut _o = adam1((P), (G), (M), (V), b1c, b2c, eps, step_size, inv_bc2s);  \
     (M) = _o.m; (V) = _o.v; (DST) = _o.p;                                              \
   }
+#endif
 
 // Per-column inputs of one 64-column chunk, prefetched one chunk ahead.
 template <int NT1>
@@ -611,7 +624,7 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
         if (i < D) {
           const int idx = g.w1() + (orow + r) * D + i;
           a.theta[idx] = lds[L::W1 + (orow + r) * L::LD1 + i];
-          a.adam_m[idx] = mW1[nt][r]; a.adam_v[idx] = vW1[nt][r];
+          SPO_ST_MV(idx, mW1[nt][r], vW1[nt][r])
         }
       }
 #pragma unroll
@@ -620,7 +633,7 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int idx = g.w2() + (orow + r) * HID + 16 * nt + j;
         a.theta[idx] = lds[L::W2 + (orow + r) * LDH + 16 * nt + j];
-        a.adam_m[idx] = mW2[nt][r]; a.adam_v[idx] = vW2[nt][r];
+        SPO_ST_MV(idx, mW2[nt][r], vW2[nt][r])
       }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -628,19 +641,19 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
       if (o < OUT) {
         const int idx = g.w3() + o * HID + 16 * wave + j;
         a.theta[idx] = lds[L::W3 + o * LDH + 16 * wave + j];
-        a.adam_m[idx] = mW3[r]; a.adam_v[idx] = vW3[r];
+        SPO_ST_MV(idx, mW3[r], vW3[r])
       }
       if (own_ls && o < A) {
         a.theta[ls_off + o] = red[128 + o];
-        a.adam_m[ls_off + o] = mls[r]; a.adam_v[ls_off + o] = vls[r];
+        SPO_ST_MV(ls_off + o, mls[r], vls[r])
       }
     }
     if (own_b) {
       const int o = 16 * wave + j;
-      a.theta[g.b1() + o] = lds[L::B1 + o]; a.adam_m[g.b1() + o] = mb1; a.adam_v[g.b1() + o] = vb1;
-      a.theta[g.b2() + o] = lds[L::B2 + o]; a.adam_m[g.b2() + o] = mb2; a.adam_v[g.b2() + o] = vb2;
+      a.theta[g.b1() + o] = lds[L::B1 + o]; SPO_ST_MV(g.b1() + o, mb1, vb1)
+      a.theta[g.b2() + o] = lds[L::B2 + o]; SPO_ST_MV(g.b2() + o, mb2, vb2)
     }
-    if (own_b3) { a.theta[g.b3() + j] = lds[L::B3 + j]; a.adam_m[g.b3() + j] = mb3; a.adam_v[g.b3() + j] = vb3; }
+    if (own_b3) { a.theta[g.b3() + j] = lds[L::B3 + j]; SPO_ST_MV(g.b3() + j, mb3, vb3) }
     if (tid == 0 && blockIdx.x == 0 && a.stale_io) {
       // every workgroup read the old value before its first step; they all finish after the last exchange
       *a.stale_io = stale_sq;

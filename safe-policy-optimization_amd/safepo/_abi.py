@@ -10,7 +10,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libsafepo_hip.so")
+LIB_PATH = os.environ.get("SPO_LIB") or os.path.join(_HERE, "_lib", "libsafepo_hip.so")   # SPO_LIB: debug override
 
 
 class SpoError(RuntimeError):
