@@ -124,6 +124,9 @@ int spo_ppo_lag_update_iter(float* theta, float* adam_m, float* adam_v, int64_t 
                             const int32_t* perm, int64_t M, const spo_ppo_cfg* cfg_host,
                             float* losses_out, void* sync_ws, void* stream);
 
+/* Debug self-test of the cross-lane helpers (DPP row sums, gfx950 permlane swaps): in[64] -> out[192]. */
+int spo_debug_crosslane_selftest(const float* in64, float* out192, void* stream);
+
 /* Debug aid (not a reference function): pass a device buffer of 30 u64 to make the next
  * spo_ppo_lag_update_iter launches accumulate shader cycles per phase of the step; NULL disables. */
 int spo_debug_set_update_profile(void* dev_u64_30);

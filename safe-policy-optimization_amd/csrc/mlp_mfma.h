@@ -118,19 +118,13 @@ __device__ __forceinline__ void load_obs_tiles(const float* __restrict__ row, in
   }
 }
 
-// tanh with ~1e-7 relative error in a dozen VALU ops (ocml tanhf costs ~40): odd Taylor series below
-// 0.25, 1 - 2/(exp(2|x|)+1) above (v_exp_f32 / v_rcp_f32).
+// tanh(x) = 1 - 2 / (exp(2x) + 1): five VALU ops (v_exp_f32, v_rcp_f32 are 1-ulp), valid for every x
+// (exp -> 0 gives -1, exp -> inf gives +1).  ABSOLUTE error <= ~1.2e-7, i.e. the rounding noise of an
+// O(1) fp32 value -- the same class as the re-associated fp32 dot products that feed it; ocml's tanhf
+// costs ~40 VALU ops per value and there are 32 values per lane per minibatch step.
 __device__ __forceinline__ float fast_tanh(float x) {
-  const float ax = fabsf(x);
-  const float x2 = x * x;
-  float p = fmaf(x2, 62.f / 2835.f, -17.f / 315.f);
-  p = fmaf(x2, p, 2.f / 15.f);
-  p = fmaf(x2, p, -1.f / 3.f);
-  p = fmaf(x2 * x, p, x);
-  const float e = __expf(2.f * ax);
-  float r = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
-  r = copysignf(r, x);
-  return ax < 0.25f ? p : r;
+  const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);      // exp(2x) = 2^(2x*log2(e))
+  return fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
 }
 
 // Hidden layer: out[mt] (rows 16mt+4q+reg, col batch) = tanh?(W in + b).  The four output tiles
@@ -140,18 +134,22 @@ template <int NT_IN, bool TANH>
 __device__ __forceinline__ void layer_hidden(const float* Wl, int ld, const float* bl, const f4 (&in)[NT_IN],
                                              f4 (&out)[HID / 16], int j, int q) {
   f4 acc[HID / 16];
+  f4 a[2][HID / 16];                       // A tiles of group nt and nt+1: the LDS reads of the next group are
+#pragma unroll                             // in flight while the 16 MFMAs of the current group occupy the pipe
+  for (int mt = 0; mt < HID / 16; ++mt) a[0][mt] = *reinterpret_cast<const f4*>(Wl + (16 * mt + j) * ld + 4 * q);
 #pragma unroll
   for (int mt = 0; mt < HID / 16; ++mt) acc[mt] = *reinterpret_cast<const f4*>(bl + 16 * mt + 4 * q);
 #pragma unroll
   for (int nt = 0; nt < NT_IN; ++nt) {
-    f4 a[HID / 16];
+    if (nt + 1 < NT_IN) {
 #pragma unroll
-    for (int mt = 0; mt < HID / 16; ++mt)
-      a[mt] = *reinterpret_cast<const f4*>(Wl + (16 * mt + j) * ld + 16 * nt + 4 * q);
+      for (int mt = 0; mt < HID / 16; ++mt)
+        a[(nt + 1) & 1][mt] = *reinterpret_cast<const f4*>(Wl + (16 * mt + j) * ld + 16 * (nt + 1) + 4 * q);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int mt = 0; mt < HID / 16; ++mt) acc[mt] = mfma4(a[mt][r], in[nt][r], acc[mt]);
+      for (int mt = 0; mt < HID / 16; ++mt) acc[mt] = mfma4(a[nt & 1][mt][r], in[nt][r], acc[mt]);
   }
 #pragma unroll
   for (int mt = 0; mt < HID / 16; ++mt) {
@@ -230,6 +228,41 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
   return v;
+}
+
+// ---- cross-lane sums without LDS traffic (ds_bpermute costs ~100+ cycles of exposed latency each
+//      when one wave owns a SIMD).  The MFMA layouts put batch column j on lanes (l & 15) = one DPP row
+//      and the k-slot q on the row index, so "sum over j" is a row reduction and "sum over q" a
+//      reduction across the 4 rows.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add_f(float v) {
+  const int s = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+  return v + __int_as_float(s);
+}
+// sum over the 16 lanes of each DPP row; valid in lane 15 of the row (row_shr 1,2,4,8 prefix sums)
+__device__ __forceinline__ float row_sum_lane15(float v) {
+  v = dpp_add_f<0x111, 0xf>(v);
+  v = dpp_add_f<0x112, 0xf>(v);
+  v = dpp_add_f<0x114, 0xf>(v);
+  v = dpp_add_f<0x118, 0xf>(v);
+  return v;
+}
+// sum over the whole wave; valid in lane 63 (row_bcast:15 into rows 1,3, row_bcast:31 into rows 2,3)
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+  v = row_sum_lane15(v);
+  v = dpp_add_f<0x142, 0xa>(v);
+  v = dpp_add_f<0x143, 0xc>(v);
+  return v;
+}
+// sum over the 4 rows (lanes l, l^16, l^32, l^48), result in every lane: gfx950 v_permlane16_swap /
+// v_permlane32_swap exchange odd/even rows and upper/lower halves in one VALU op each.
+__device__ __forceinline__ float quad_row_sum(float v) {
+  const unsigned x = __float_as_uint(v);
+  const auto r16 = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+  const float s1 = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+  const unsigned y = __float_as_uint(s1);
+  const auto r32 = __builtin_amdgcn_permlane32_swap(y, y, false, false);
+  return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
 }
 
 constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;   // math.log(math.sqrt(2*math.pi))

@@ -296,8 +296,7 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
         dif[r] = cur.actv[r] - o[r];                 // pad rows: 0 - 0
         lp += -(dif[r] * dif[r]) * (0.5f * ivar[r]) - lsd[r];
       }
-      lp += __shfl_xor(lp, 16);
-      lp += __shfl_xor(lp, 32);
+      lp = quad_row_sum(lp);                                               // .sum(dim=-1) over the 4 k-slot rows
       const float adv = cur.t1;
       const float ratio = __expf(lp - cur.t0);                             // ppo_lag.py:317 (argument ~0: 1e-7 rel)
       const float rc = fminf(fmaxf(ratio, clip_lo), clip_hi);              // torch.clamp
@@ -318,17 +317,27 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
       }
     }
 
-    // ---- backward through the MLP (transposed chaining, weights read as columns)
+    // ---- backward through the MLP (transposed chaining, weights read as columns).  The A operands
+    //      (one LDS word per MFMA) are fetched a whole k-group ahead of the MFMAs that consume them.
     f4 dz2[4], dz1[4];
     {
       f4 acc[4];
+      float w3c[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) w3c[r][mt] = lds[L::W3 + (4 * q + r) * LDH + 16 * mt + j];
+      float w2c[2][4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) w2c[0][r][mt] = lds[L::W2 + (4 * q + r) * LDH + 16 * mt + j];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) acc[mt] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-          acc[mt] = mfma4(lds[L::W3 + (4 * q + r) * LDH + 16 * mt + j], dO[r], acc[mt]);
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma4(w3c[r][mt], dO[r], acc[mt]);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -336,12 +345,19 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) acc[mt] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+      for (int nt = 0; nt < 4; ++nt) {
+        if (nt + 1 < 4) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+              w2c[(nt + 1) & 1][r][mt] = lds[L::W2 + (16 * (nt + 1) + 4 * q + r) * LDH + 16 * mt + j];
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt)
-            acc[mt] = mfma4(lds[L::W2 + (16 * nt + 4 * q + r) * LDH + 16 * mt + j], dz2[nt][r], acc[mt]);
+          for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma4(w2c[nt & 1][r][mt], dz2[nt][r], acc[mt]);
+      }
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -364,14 +380,13 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
     for (int r = 0; r < 4; ++r) lds[U::DOT + (4 * q + r) * LDB + mycol] = dO[r];
     if (last_half) {
       // per-wave partials of the scalar reductions ride on the same barrier
-      const float ls = wave_sum(lsum);
-      if (lane == 0) red[wave] = ls;
+      const float ls = wave_sum_lane63(lsum);
+      if (lane == 63) red[wave] = ls;
       if (is_actor) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float t = dls[r];
-          t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
-          if (j == 0) red[16 + wave * 16 + 4 * q + r] = t;
+          const float t = row_sum_lane15(dls[r]);           // over the wave's 16 columns
+          if (j == 15) red[16 + wave * 16 + 4 * q + r] = t;
         }
       }
     }
@@ -379,64 +394,70 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
     __syncthreads();
     SPO_STAMP(4)
 
-    // ---- dW[o][i] += sum_b dZ[b][o] * Hprev[b][i]; wave w owns rows 16w..16w+15
+    // ---- dW[o][i] += sum_b dZ[b][o] * Hprev[b][i]; wave w owns rows 16w..16w+15.
+    //      A tiles (dZ^T rows) of all three layers are read first; B tiles are read one k-group ahead.
     {
-      f4 az[4];
-      float rs = 0.f;
+      f4 az1[4], az2[4], az3[4];
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        az[r4] = *reinterpret_cast<const f4*>(lds + U::DZ1T + (16 * wave + j) * LDB + 16 * r4 + 4 * q);
-        rs += (az[r4][0] + az[r4][1]) + (az[r4][2] + az[r4][3]);
+        az2[r4] = *reinterpret_cast<const f4*>(lds + U::DZ2T + (16 * wave + j) * LDB + 16 * r4 + 4 * q);
+        az3[r4] = *reinterpret_cast<const f4*>(lds + U::DOT + j * LDB + 16 * r4 + 4 * q);
+        az1[r4] = *reinterpret_cast<const f4*>(lds + U::DZ1T + (16 * wave + j) * LDB + 16 * r4 + 4 * q);
       }
-      db1 += rs;
+      // layer 2 then layer 3 then layer 1
+      f4 bh[2][4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        bh[0][nt] = *reinterpret_cast<const f4*>(lds + U::H1T + (16 * nt + j) * LDB + 4 * q);
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        f4 bh[NT1];
+        if (r4 + 1 < 4) {
 #pragma unroll
-        for (int nt = 0; nt < NT1; ++nt)
-          bh[nt] = *reinterpret_cast<const f4*>(lds + U::XT + (16 * nt + j) * LDB + 16 * r4 + 4 * q);
+          for (int nt = 0; nt < 4; ++nt)
+            bh[(r4 + 1) & 1][nt] = *reinterpret_cast<const f4*>(lds + U::H1T + (16 * nt + j) * LDB + 16 * (r4 + 1) + 4 * q);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int nt = 0; nt < NT1; ++nt) aW1[nt] = mfma4(az[r4][e], bh[nt][e], aW1[nt]);
+          for (int nt = 0; nt < 4; ++nt) aW2[nt] = mfma4(az2[r4][e], bh[r4 & 1][nt][e], aW2[nt]);
       }
-      rs = 0.f;
+      f4 b3[4];
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        az[r4] = *reinterpret_cast<const f4*>(lds + U::DZ2T + (16 * wave + j) * LDB + 16 * r4 + 4 * q);
-        rs += (az[r4][0] + az[r4][1]) + (az[r4][2] + az[r4][3]);
-      }
-      db2 += rs;
+      for (int r4 = 0; r4 < 4; ++r4)
+        b3[r4] = *reinterpret_cast<const f4*>(lds + U::H2T + (16 * wave + j) * LDB + 16 * r4 + 4 * q);
+      f4 bx[2][NT1];
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        f4 bh[4];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-          bh[nt] = *reinterpret_cast<const f4*>(lds + U::H1T + (16 * nt + j) * LDB + 16 * r4 + 4 * q);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) aW2[nt] = mfma4(az[r4][e], bh[nt][e], aW2[nt]);
-      }
-      rs = 0.f;
+      for (int nt = 0; nt < NT1; ++nt)
+        bx[0][nt] = *reinterpret_cast<const f4*>(lds + U::XT + (16 * nt + j) * LDB + 4 * q);
       f4 w3a = {0.f, 0.f, 0.f, 0.f}, w3b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        az[r4] = *reinterpret_cast<const f4*>(lds + U::DOT + j * LDB + 16 * r4 + 4 * q);
-        rs += (az[r4][0] + az[r4][1]) + (az[r4][2] + az[r4][3]);
-      }
-#pragma unroll
-      for (int r4 = 0; r4 < 4; r4 += 2) {
-        const f4 b0 = *reinterpret_cast<const f4*>(lds + U::H2T + (16 * wave + j) * LDB + 16 * r4 + 4 * q);
-        const f4 b1 = *reinterpret_cast<const f4*>(lds + U::H2T + (16 * wave + j) * LDB + 16 * (r4 + 1) + 4 * q);
+      for (int r4 = 0; r4 < 4; r4 += 2)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          w3a = mfma4(az[r4][e], b0[e], w3a);
-          w3b = mfma4(az[r4 + 1][e], b1[e], w3b);
+          w3a = mfma4(az3[r4][e], b3[r4][e], w3a);
+          w3b = mfma4(az3[r4 + 1][e], b3[r4 + 1][e], w3b);
         }
-      }
       aW3 += w3a + w3b;
-      db3 += rs;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        if (r4 + 1 < 4) {
+#pragma unroll
+          for (int nt = 0; nt < NT1; ++nt)
+            bx[(r4 + 1) & 1][nt] = *reinterpret_cast<const f4*>(lds + U::XT + (16 * nt + j) * LDB + 16 * (r4 + 1) + 4 * q);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int nt = 0; nt < NT1; ++nt) aW1[nt] = mfma4(az1[r4][e], bx[r4 & 1][nt][e], aW1[nt]);
+      }
+      float rs1 = 0.f, rs2 = 0.f, rs3 = 0.f;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        rs1 += (az1[r4][0] + az1[r4][1]) + (az1[r4][2] + az1[r4][3]);
+        rs2 += (az2[r4][0] + az2[r4][1]) + (az2[r4][2] + az2[r4][3]);
+        rs3 += (az3[r4][0] + az3[r4][1]) + (az3[r4][2] + az3[r4][3]);
+      }
+      db1 += rs1; db2 += rs2; db3 += rs3;
     }
     if (!last_half) {
       __syncthreads();         // the next half overwrites the staged images
@@ -445,9 +466,9 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
 
     SPO_STAMP(5)
     // =================== end of the minibatch: gradients complete ===================
-    db1 += __shfl_xor(db1, 16); db1 += __shfl_xor(db1, 32);
-    db2 += __shfl_xor(db2, 16); db2 += __shfl_xor(db2, 32);
-    db3 += __shfl_xor(db3, 16); db3 += __shfl_xor(db3, 32);
+    db1 = quad_row_sum(db1);
+    db2 = quad_row_sum(db2);
+    db3 = quad_row_sum(db3);
     const float loss_data = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;
     if (is_actor) {
 #pragma unroll
@@ -509,9 +530,9 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) gsq = fmaf(wls * dls[r], dls[r], gsq);
     }
-    gsq = wave_sum(gsq);
-    psq = wave_sum(psq);
-    if (lane == 0) { red[4 + wave] = gsq; red[8 + wave] = psq; }
+    gsq = wave_sum_lane63(gsq);
+    psq = wave_sum_lane63(psq);
+    if (lane == 63) { red[4 + wave] = gsq; red[8 + wave] = psq; }
     SPO_STAMP(6)
     __syncthreads();
     const float my_sq = (red[4] + red[5]) + (red[6] + red[7]);

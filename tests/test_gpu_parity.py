@@ -537,3 +537,17 @@ def test_cpo_main_entrypoint_synthetic(dev, tmp_path):
                 "Misc/gradient_norm", "Misc/H_inv_g", "Misc/AcceptanceStep", "Time/Update"):
         assert col in rows[0], col
     assert float(rows[0]["Misc/xHx"]) >= 0
+
+
+def test_crosslane_helpers_selftest(dev):
+    """DPP row sums and gfx950 permlane-swap reductions used inside the MFMA kernels."""
+    from safepo import _abi
+    x = torch.randn(64)
+    out = torch.zeros(192, device=dev)
+    xin = x.to(dev)
+    _abi.check(_abi.load().spo_debug_crosslane_selftest(_abi.ptr(xin), _abi.ptr(out), _abi.stream_ptr()), "selftest")
+    o = out.cpu().numpy()
+    xn = x.numpy().reshape(4, 16)
+    np.testing.assert_allclose(o[:64].reshape(4, 16), np.broadcast_to(xn.sum(0), (4, 16)), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(o[64:128].reshape(4, 16)[:, 15], xn.sum(1), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(o[128 + 63], xn.sum(), rtol=1e-6, atol=1e-6)
