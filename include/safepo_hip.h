@@ -141,6 +141,14 @@ int spo_ppo_lag_grad(const float* theta, const float* obs, const float* act, con
 int spo_clip_adam(float* theta, float* adam_m, float* adam_v, const float* flat_grad, int64_t adam_step_host,
                   float grad_scale, const spo_ppo_cfg* cfg_host, void* stream);
 
+/* one host call per data-parallel step: spo_clip_adam(step k) followed by spo_ppo_lag_grad(step k+1)
+ * into the same flat_grad buffer (next_idx == NULL: only the optimiser step). */
+int spo_clip_adam_then_grad(float* theta, float* adam_m, float* adam_v, float* flat_grad, int64_t adam_step_host,
+                            float grad_scale, const float* obs, const float* act, const float* logp_old,
+                            const float* target_r, const float* target_c, const float* adv,
+                            const int32_t* next_idx, int next_n_idx, const spo_ppo_cfg* cfg_host,
+                            float* next_losses3, void* stream);
+
 /* ---- a-11: full-batch actor forward + KL early-stop statistic (ppo_lag.py:277,338-345).
  * spo_actor_mean: mean_out[M,act_dim] = actor.mean(obs).  spo_actor_kl: partial sums of
  * KL(N(mu_old, exp(log_std_old)) || N(mu_new, exp(log_std_new))).sum(-1) over rows into

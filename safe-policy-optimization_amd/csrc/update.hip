@@ -828,6 +828,19 @@ extern "C" int spo_ppo_lag_grad(const float* theta, const float* obs, const floa
   return 0;
 }
 
+// Data-parallel inner loop helper: apply the (all-reduced) gradient of step k, then immediately
+// enqueue the local gradient of step k+1 -- one host call per optimiser step instead of two.
+extern "C" int spo_clip_adam_then_grad(float* theta, float* adam_m, float* adam_v, float* flat_grad,
+                                       int64_t adam_step_host, float grad_scale, const float* obs, const float* act,
+                                       const float* logp_old, const float* target_r, const float* target_c,
+                                       const float* adv, const int32_t* next_idx, int next_n_idx,
+                                       const spo_ppo_cfg* cfg_host, float* next_losses3, void* stream) {
+  if (int rc = spo_clip_adam(theta, adam_m, adam_v, flat_grad, adam_step_host, grad_scale, cfg_host, stream)) return rc;
+  if (next_idx == nullptr || next_n_idx <= 0) return 0;
+  return spo_ppo_lag_grad(theta, obs, act, logp_old, target_r, target_c, adv, next_idx, next_n_idx, next_n_idx,
+                          cfg_host, flat_grad, next_losses3, stream);
+}
+
 extern "C" int spo_clip_adam(float* theta, float* adam_m, float* adam_v, const float* flat_grad,
                              int64_t adam_step_host, float grad_scale, const spo_ppo_cfg* cfg_host, void* stream) {
   if (int rc = check_cfg(cfg_host)) return rc;

@@ -43,6 +43,7 @@ PROTOTYPES = {
     "spo_debug_set_update_profile": (c_int, [P]),
     "spo_ppo_lag_grad": (c_int, [P] * 8 + [c_int, c_int64, POINTER(PpoCfg), P, P, P]),
     "spo_clip_adam": (c_int, [P, P, P, P, c_int64, c_float, POINTER(PpoCfg), P]),
+    "spo_clip_adam_then_grad": (c_int, [P, P, P, P, c_int64, c_float] + [P] * 7 + [c_int, POINTER(PpoCfg), P, P]),
     "spo_actor_mean": (c_int, [P, P, P, c_int64, c_int, c_int, P]),
     "spo_actor_kl": (c_int, [P, P, P, P, P, c_int, P, c_int64, c_int, c_int, P]),
     "spo_cpo_num_partials": (c_int, [c_int64]),

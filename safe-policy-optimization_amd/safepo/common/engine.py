@@ -185,19 +185,31 @@ class PPOLagEngine:
                 _abi.ptr(self.sync_ws), st), "spo_ppo_lag_update_iter")
             self.adam_step += n_mb
         else:
-            # data-parallel: local minibatch gradient -> all-reduce (RCCL) -> identical clip+Adam on every rank
+            # data-parallel: local minibatch gradient -> all-reduce (RCCL) -> identical clip+Adam on every rank.
+            # One C call per step: it applies step k and enqueues the gradient kernel of step k+1.
+            lib, fg = self.lib, self.flat_grad
+            p_th, p_m, p_v, p_fg = _abi.ptr(th), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), _abi.ptr(fg)
+            p_obs, p_act, p_lp = _abi.ptr(d["obs"]), _abi.ptr(d["act"]), _abi.ptr(d["log_prob"])
+            p_tr, p_tc, p_adv = _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]), _abi.ptr(b.adv_mix)
+            p_perm, p_loss = perm.data_ptr(), losses.data_ptr()
+            scale = 1.0 / self.comm.world_size
+            n0 = min(cfg.batch, M)
+            _abi.check(lib.spo_ppo_lag_grad(p_th, p_obs, p_act, p_lp, p_tr, p_tc, p_adv, p_perm, n0, n0, cfg, p_fg,
+                                            p_loss, st), "spo_ppo_lag_grad")
+            reduce_ = self.comm.all_reduce_sum_
             for k in range(n_mb):
-                lo = k * cfg.batch
-                n_idx = min(cfg.batch, M - lo)
-                _abi.check(self.lib.spo_ppo_lag_grad(
-                    _abi.ptr(th), _abi.ptr(d["obs"]), _abi.ptr(d["act"]), _abi.ptr(d["log_prob"]),
-                    _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]), _abi.ptr(b.adv_mix),
-                    perm.data_ptr() + 4 * lo, n_idx, n_idx, cfg, _abi.ptr(self.flat_grad), _abi.ptr(losses[k]), st),
-                    "spo_ppo_lag_grad")
-                scale = dp_reduce_gradient_(self.comm, self.flat_grad)
-                _abi.check(self.lib.spo_clip_adam(_abi.ptr(th), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v),
-                                                  _abi.ptr(self.flat_grad), self.adam_step, scale, cfg, st),
-                           "spo_clip_adam")
+                reduce_(fg)
+                nxt = k + 1
+                if nxt < n_mb:
+                    lo = nxt * cfg.batch
+                    rc = lib.spo_clip_adam_then_grad(p_th, p_m, p_v, p_fg, self.adam_step, scale, p_obs, p_act, p_lp,
+                                                     p_tr, p_tc, p_adv, p_perm + 4 * lo, min(cfg.batch, M - lo), cfg,
+                                                     p_loss + 12 * nxt, st)
+                else:
+                    rc = lib.spo_clip_adam_then_grad(p_th, p_m, p_v, p_fg, self.adam_step, scale, p_obs, p_act, p_lp,
+                                                     p_tr, p_tc, p_adv, None, 0, cfg, None, st)
+                if rc:
+                    _abi.check(rc, "spo_clip_adam_then_grad")
                 self.adam_step += 1
             self.comm.all_reduce_sum_(losses)
             losses *= 1.0 / self.comm.world_size

@@ -73,8 +73,52 @@ class SynthDeviceEnv:
         return self.obs, self.reward, self.cost, self.terminated, self.truncated, info
 
 
+class SynthHostEnv:
+    """Host (numpy) counterpart with the gymnasium vector-env return contract the reference loop consumes
+    (numpy arrays, bool terminated/truncated, `final_observation` object array with None holes,
+    ppo_lag.py:166-186).  Exercises the host-env path of main(): observations cross PCIe every step."""
+
+    is_device_env = False
+
+    def __init__(self, num_envs: int, obs_dim: int = 60, act_dim: int = 8, seed: int = 0, p_term: float = 0.0,
+                 p_cost: float = 0.1, trunc_len: int = 64, **_):
+        self.num_envs, self.obs_dim, self.act_dim = int(num_envs), int(obs_dim), int(act_dim)
+        self.p_term, self.p_cost, self.trunc_len = float(p_term), float(p_cost), int(trunc_len)
+        self.rng = np.random.default_rng(seed or 0)
+        self.t_env = np.zeros(self.num_envs, dtype=np.int64)
+        self.obs_rms = {"mean": np.zeros(obs_dim), "var": np.ones(obs_dim), "count": 1e-4}
+        self.single_observation_space, self.single_action_space = Box(obs_dim), Box(act_dim, -1.0, 1.0)
+
+    def reset(self, seed=None):
+        self.t_env[:] = 0
+        return self.rng.standard_normal((self.num_envs, self.obs_dim)).astype(np.float32), {}
+
+    def step(self, action):
+        n = self.num_envs
+        assert np.asarray(action).shape == (n, self.act_dim)
+        self.t_env += 1
+        obs = self.rng.standard_normal((n, self.obs_dim)).astype(np.float32)
+        reward = self.rng.standard_normal(n).astype(np.float32)
+        cost = (self.rng.random(n) < self.p_cost).astype(np.float32)
+        terminated = self.rng.random(n) < self.p_term
+        truncated = (self.t_env >= self.trunc_len) & ~terminated
+        done = terminated | truncated
+        info = {}
+        if done.any():
+            final = np.empty(n, dtype=object)
+            for i in range(n):
+                final[i] = obs[i].copy() if done[i] else None
+            obs[done] = self.rng.standard_normal((int(done.sum()), self.obs_dim)).astype(np.float32)
+            info["final_observation"] = final
+            self.t_env[done] = 0
+        return obs, reward, cost, terminated, truncated, info
+
+
 def make_sa_mujoco_env(num_envs: int, env_id: str, seed: int | None = None, device="cuda:0", **synth_kw):
     """(env, obs_space, act_space) -- reference signature plus `device` for synthetic tasks."""
+    if env_id.startswith("SynthHost"):
+        env = SynthHostEnv(num_envs, seed=seed or 0, **synth_kw)
+        return env, env.single_observation_space, env.single_action_space
     if env_id.startswith("Synth"):
         env = SynthDeviceEnv(num_envs, seed=seed or 0, device=device, **synth_kw)
         return env, env.single_observation_space, env.single_action_space

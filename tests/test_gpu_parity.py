@@ -551,3 +551,81 @@ def test_crosslane_helpers_selftest(dev):
     np.testing.assert_allclose(o[:64].reshape(4, 16), np.broadcast_to(xn.sum(0), (4, 16)), rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(o[64:128].reshape(4, 16)[:, 15], xn.sum(1), rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(o[128 + 63], xn.sum(), rtol=1e-6, atol=1e-6)
+
+
+def test_host_env_path_through_main(dev, tmp_path):
+    """Host (numpy) vector env with object-array final_observation, as gymnasium provides it."""
+    import argparse
+    import csv
+    from safepo.single_agent import ppo_lag
+    args = argparse.Namespace(seed=1, use_eval=False, task="SynthHost-v0", num_envs=6, experiment="t",
+                              log_dir=str(tmp_path / "exp" / "task" / "run"), device="cuda", device_id=0,
+                              write_terminal=True, headless=False, total_steps=6 * 40, steps_per_epoch=6 * 40,
+                              randomize=False, cost_limit=25.0, lagrangian_multiplier_init=0.001,
+                              lagrangian_multiplier_lr=0.035, cfg_override={"learning_iters": 2},
+                              env_kwargs={"trunc_len": 9, "p_term": 0.05, "obs_dim": 17, "act_dim": 3})
+    out = ppo_lag.main(args, {})
+    rows = list(csv.DictReader(open(tmp_path / "exp" / "task" / "run" / "progress.csv")))
+    assert len(rows) == 1 and float(rows[0]["Metrics/EpLen"]) <= 9.0
+    b = out["engine"].buffer
+    assert b.seg_end[:, -1].all()
+    assert torch.isfinite(out["policy"].theta).all()
+
+
+def test_forced_data_parallel_path_equals_persistent(dev, monkeypatch):
+    """engine.learning_iter through the split grad / all-reduce / clip+Adam loop (world size 1) gives
+    the same parameters and per-minibatch losses as the persistent kernel."""
+    from safepo.common.engine import PPOLagEngine
+    from safepo.common.model import ActorVCritic
+    M, D, A = 200, 60, 8
+    obs, act, logp, tgt_r, tgt_c, adv = _synthetic_update_problem(M, D, A, seed=2)
+    cfg = {"hidden_sizes": [64, 64], "gamma": 0.99, "target_kl": 1e9, "batch_size": 64, "learning_iters": 1, "max_grad_norm": 40.0}
+    res = []
+    for forced in ("0", "1"):
+        monkeypatch.setenv("SPO_FORCE_DP", forced)
+        torch.manual_seed(5)
+        pol = ActorVCritic(D, A).to(dev)
+        eng = PPOLagEngine(pol, 1, M, cfg, dev)
+        b = eng.buffer
+        b.data["obs"].copy_(obs.view(1, M, D)); b.data["act"].copy_(act.view(1, M, A))
+        b.data["log_prob"].copy_(logp.view(1, M)); b.data["target_value_r"].copy_(tgt_r.view(1, M))
+        b.data["target_value_c"].copy_(tgt_c.view(1, M)); b.adv_mix.copy_(adv.view(1, M))
+        perm = torch.randperm(M, generator=torch.Generator().manual_seed(1)).to(torch.int32).to(dev)
+        losses = eng.learning_iter(perm)
+        res.append((pol.theta.cpu().numpy(), losses.cpu().numpy(), eng.adam_step))
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-7)
+    assert res[0][2] == res[1][2] == 4
+
+
+def test_limits_and_edge_shapes(dev):
+    """Largest supported dims (obs 64 in the update kernels, act 16), single env / single step, and the
+    loud failures outside the envelope."""
+    from safepo import _abi
+    from safepo.common.engine import PPOLagEngine, smoke_check
+    from safepo.common.model import ActorVCritic
+    pol = ActorVCritic(64, 16).to(dev)
+    M = 96
+    cfg = {"hidden_sizes": [64, 64], "gamma": 0.99, "target_kl": 1e9, "batch_size": 64, "learning_iters": 1, "max_grad_norm": 40.0}
+    eng = PPOLagEngine(pol, 1, M, cfg, dev)
+    obs, act, logp, tgt_r, tgt_c, adv = _synthetic_update_problem(M, 64, 16, seed=3)
+    b = eng.buffer
+    b.data["obs"].copy_(obs.view(1, M, 64)); b.data["act"].copy_(act.view(1, M, 16)); b.data["log_prob"].copy_(logp.view(1, M) - 10)
+    b.data["target_value_r"].copy_(tgt_r.view(1, M)); b.data["target_value_c"].copy_(tgt_c.view(1, M)); b.adv_mix.copy_(adv.view(1, M))
+    ref = R.OraclePolicy(64, 16)
+    ref.load_state_dict({k: v.cpu().clone() for k, v in pol.state_dict().items()})
+    upd = R.PPOLagUpdater(ref, epochs=1)
+    perm = torch.arange(M)
+    lr = [upd.minibatch_step(obs[s:s + 64], act[s:s + 64], logp[s:s + 64] - 10, tgt_r[s:s + 64], tgt_c[s:s + 64], adv[s:s + 64])
+          for s in range(0, M, 64)]
+    losses = eng.learning_iter(perm.to(torch.int32).to(dev))
+    np.testing.assert_allclose(losses.cpu().numpy(), np.asarray(lr), rtol=1e-4, atol=2e-6)
+    _assert_params_close(pol.theta.cpu().numpy(), R.flat_params(ref).numpy(), 3e-4, 2, what="64x16")
+    # update kernels reject obs_dim > 64 loudly (collect supports up to 128)
+    big = ActorVCritic(100, 4).to(dev)
+    e2 = PPOLagEngine(big, 2, 8, cfg, dev)
+    with pytest.raises(_abi.SpoError, match="obs_dim"):
+        e2.learning_iter(torch.arange(16, dtype=torch.int32, device=dev))
+    with pytest.raises(_abi.SpoError, match="act_dim"):
+        ActorVCritic(10, 17).to(dev).step(torch.zeros(2, 10, device=dev))
+    smoke_check(num_envs=1, steps=3, seed=3)     # (M=1 gives std()=NaN in the reference too)
