@@ -81,6 +81,13 @@ int spo_policy_step(const float* theta, const float* obs, const float* eps,
                     float* buf_obs, float* buf_act, float* buf_logp, float* buf_v_r, float* buf_v_c,
                     int64_t num_envs, int64_t T, int64_t t, int obs_dim, int act_dim, void* stream);
 
+/* ---- a-2: observation normalisation of SafeNormalizeObservation (safepo/common/wrappers.py:42-49 ->
+ * gymnasium NormalizeObservation / RunningMeanStd, third-party, restated from its documented algorithm:
+ * PARITY UNPINNED).  rms_state = double[2*obs_dim+1] = mean[D], var[D], count (init 0, 1, 1e-4).
+ * update != 0: merge this batch (mean, biased var over num_envs) into the running statistics first;
+ * then obs <- (obs - mean) / sqrt(var + 1e-8), in place. */
+int spo_obs_normalize(float* obs, double* rms_state, int64_t num_envs, int obs_dim, int update, void* stream);
+
 /* critics only (bootstrap values of ppo_lag.py:201-215): v_r, v_c for `rows` observations. */
 int spo_values(const float* theta, const float* obs, float* v_r, float* v_c,
                int64_t rows, int obs_dim, int act_dim, void* stream);

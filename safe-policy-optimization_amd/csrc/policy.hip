@@ -289,6 +289,47 @@ __global__ void synth_obs_kernel(float* next_obs, float* final_obs, const float*
   }
 }
 
+// ---------------------------------------------------------------- a-2: running observation normaliser
+// gymnasium.wrappers.normalize.RunningMeanStd.update + NormalizeObservation.normalize (the wrapper
+// SafeNormalizeObservation applies inside the env, reference safepo/common/wrappers.py:42-49):
+// batch mean / biased variance over the N envs per feature, parallel-variance merge into the running
+// (mean, var, count) in fp64, then obs <- (obs - mean) / sqrt(var + 1e-8) in the input precision (fp32 out).
+// One workgroup per feature column block; fp64 throughout like the numpy original.
+__global__ __launch_bounds__(256) void obs_normalize_kernel(float* obs, double* rms /*[2*D+1]: mean[D], var[D], count*/,
+                                                            int64_t N, int D, int update, double eps) {
+  __shared__ double sh_s[256], sh_q[256];
+  const int f = blockIdx.x;                     // feature
+  const int tid = threadIdx.x;
+  double* mean = rms; double* var = rms + D; double* count = rms + 2 * D;
+  if (update) {
+    // pass 1: batch mean ; pass 2: batch variance around it (numpy's x.mean(0), x.var(0))
+    double s = 0.0;
+    for (int64_t i = tid; i < N; i += 256) s += (double)obs[i * D + f];
+    sh_s[tid] = s;
+    __syncthreads();
+    for (int k = 128; k >= 1; k >>= 1) { if (tid < k) sh_s[tid] += sh_s[tid + k]; __syncthreads(); }
+    const double bmean = sh_s[0] / (double)N;
+    __syncthreads();
+    double qv = 0.0;
+    for (int64_t i = tid; i < N; i += 256) { const double d = (double)obs[i * D + f] - bmean; qv += d * d; }
+    sh_q[tid] = qv;
+    __syncthreads();
+    for (int k = 128; k >= 1; k >>= 1) { if (tid < k) sh_q[tid] += sh_q[tid + k]; __syncthreads(); }
+    if (tid == 0) {
+      const double bvar = sh_q[0] / (double)N, bn = (double)N, c = *count;   // every block reads the OLD count
+      const double delta = bmean - mean[f], tot = c + bn;
+      const double m2 = var[f] * c + bvar * bn + delta * delta * c * bn / tot;
+      mean[f] = mean[f] + delta * bn / tot;
+      var[f] = m2 / tot;
+    }
+    __syncthreads();
+  }
+  const double mu = mean[f];
+  const double inv = 1.0 / sqrt(var[f] + eps);
+  for (int64_t i = tid; i < N; i += 256) obs[i * D + f] = (float)(((double)obs[i * D + f] - mu) * inv);
+}
+__global__ void obs_normalize_count_kernel(double* rms, int D, int64_t N) { rms[2 * D] += (double)N; }
+
 int pick_kin(int D) { return D <= 16 ? 16 : D <= 32 ? 32 : D <= 64 ? 64 : 128; }
 
 template <bool WITH_ACTOR>
@@ -419,5 +460,14 @@ extern "C" int spo_synth_env_step(float* next_obs, float* final_obs, float* rewa
   hipLaunchKernelGGL(synth_obs_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, next_obs, final_obs,
                      terminated, truncated, num_envs, obs_dim, seed, step);
   SPO_LAUNCH_CHECK("spo_synth_env_step");
+  return 0;
+}
+
+extern "C" int spo_obs_normalize(float* obs, double* rms_state, int64_t num_envs, int obs_dim, int update, void* stream) {
+  SPO_REQUIRE(obs && rms_state && num_envs > 0 && obs_dim > 0, "obs_normalize: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(obs_normalize_kernel, dim3(obs_dim), dim3(256), 0, st, obs, rms_state, num_envs, obs_dim, update, 1e-8);
+  if (update) hipLaunchKernelGGL(obs_normalize_count_kernel, dim3(1), dim3(1), 0, st, rms_state, obs_dim, num_envs);
+  SPO_LAUNCH_CHECK("spo_obs_normalize");
   return 0;
 }

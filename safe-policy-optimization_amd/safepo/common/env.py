@@ -25,6 +25,35 @@ class Box:
         self.low, self.high = low, high
 
 
+class DeviceObsNormalizer:
+    """Device-side SafeNormalizeObservation (reference safepo/common/wrappers.py:42-49): running mean/var/count
+    in fp64 (gymnasium RunningMeanStd: mean 0, var 1, count 1e-4), updated with every batch of observations and
+    applied in place by spo_obs_normalize.  `.obs_rms` gives the host object that the training loop checkpoints
+    into state{itr}.pkl (ppo_lag.py:383)."""
+
+    class _Rms:
+        def __init__(self, mean, var, count):
+            self.mean, self.var, self.count = mean, var, count
+
+    def __init__(self, obs_dim: int, device):
+        self.D = int(obs_dim)
+        self.state = torch.zeros(2 * self.D + 1, dtype=torch.float64, device=device)
+        self.state[self.D:2 * self.D] = 1.0
+        self.state[2 * self.D] = 1e-4
+        self.lib = _abi.load()
+
+    def normalize_(self, obs: torch.Tensor, update: bool = True) -> torch.Tensor:
+        obs = _abi.require_gpu_tensor(obs, "obs", torch.float32)
+        _abi.check(self.lib.spo_obs_normalize(_abi.ptr(obs), _abi.ptr(self.state), obs.shape[0], self.D, int(update),
+                                              _abi.stream_ptr()), "spo_obs_normalize")
+        return obs
+
+    @property
+    def obs_rms(self):
+        s = self.state.cpu().numpy()
+        return self._Rms(s[:self.D].copy(), s[self.D:2 * self.D].copy(), float(s[2 * self.D]))
+
+
 class SynthDeviceEnv:
     """obs' ~ N(0,1), reward ~ N(0,1), cost ~ Bernoulli(p_cost), terminated ~ Bernoulli(p_term),
     truncated = (episode length >= trunc_len); counter-based RNG on the GPU (spo_synth_env_step).
@@ -33,8 +62,11 @@ class SynthDeviceEnv:
     is_device_env = True
 
     def __init__(self, num_envs: int, obs_dim: int = 60, act_dim: int = 8, seed: int = 0, p_term: float = 0.0,
-                 p_cost: float = 0.1, trunc_len: int = 64, device="cuda:0"):
+                 p_cost: float = 0.1, trunc_len: int = 64, device="cuda:0", normalize_obs: bool = False,
+                 obs_scale: float = 1.0, obs_shift: float = 0.0):
         self.num_envs, self.obs_dim, self.act_dim = int(num_envs), int(obs_dim), int(act_dim)
+        self.obs_scale, self.obs_shift = float(obs_scale), float(obs_shift)
+        self.normalizer = DeviceObsNormalizer(obs_dim, device) if normalize_obs else None
         self.seed, self.p_term, self.p_cost, self.trunc_len = int(seed or 0), float(p_term), float(p_cost), int(trunc_len)
         self.dev = torch.device(device)
         self.lib = _abi.load()
@@ -56,6 +88,11 @@ class SynthDeviceEnv:
             _abi.ptr(self.terminated), _abi.ptr(self.truncated), _abi.ptr(self.t_env), self.num_envs, self.obs_dim,
             self.seed, self.step_count, self.p_term, self.p_cost, self.trunc_len, _abi.stream_ptr()),
             "spo_synth_env_step")
+        if self.normalizer is not None:
+            # raw observations x*scale + shift, then the running normaliser (as the wrapper does in step())
+            self.obs.mul_(self.obs_scale).add_(self.obs_shift)
+            self.normalizer.normalize_(self.obs, update=True)
+            self.obs_rms = self.normalizer.obs_rms if self.step_count % 1024 == 0 else self.obs_rms
 
     def reset(self, seed=None):
         if seed is not None:

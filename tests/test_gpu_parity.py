@@ -629,3 +629,25 @@ def test_limits_and_edge_shapes(dev):
     with pytest.raises(_abi.SpoError, match="act_dim"):
         ActorVCritic(10, 17).to(dev).step(torch.zeros(2, 10, device=dev))
     smoke_check(num_envs=1, steps=3, seed=3)     # (M=1 gives std()=NaN in the reference too)
+
+
+def test_obs_normalizer_vs_oracle_running_mean_std(dev):
+    """a-2: device RunningMeanStd update + normalise against the numpy restatement of gymnasium's algorithm."""
+    from safepo.common.env import DeviceObsNormalizer
+    rng = np.random.default_rng(0)
+    D = 60
+    norm = DeviceObsNormalizer(D, dev)
+    ref = R.RunningMeanStd((D,))
+    for step, n in enumerate((4096, 4096, 7, 300)):
+        x = (rng.standard_normal((n, D)) * (1 + np.arange(D)) + 3.0 * np.arange(D)).astype(np.float32)
+        want = ref.normalize(x.astype(np.float64)).astype(np.float32)
+        got = norm.normalize_(torch.from_numpy(x.copy()).to(dev)).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+    rms = norm.obs_rms
+    np.testing.assert_allclose(rms.mean, ref.mean, rtol=1e-10)
+    np.testing.assert_allclose(rms.var, ref.var, rtol=1e-10)
+    assert rms.count == pytest.approx(ref.count)
+    # frozen statistics (evaluation mode): no update
+    x = rng.standard_normal((5, D)).astype(np.float32)
+    got = norm.normalize_(torch.from_numpy(x.copy()).to(dev), update=False).cpu().numpy()
+    np.testing.assert_allclose(got, ((x - ref.mean) / np.sqrt(ref.var + 1e-8)).astype(np.float32), rtol=1e-5, atol=1e-5)
