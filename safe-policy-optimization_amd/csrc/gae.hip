@@ -216,13 +216,15 @@ __global__ __launch_bounds__(256) void gae_kernel(GaeArgs a) {
       }
     }
     // carries for the chunk to the left: values at the first lane of my row group
-    const int src = sub * LPR;
+    if (ch > 0) {                              // uniform: single-chunk rows (T <= LPR*VEC) never need the carries
+      const int src = sub * LPR;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      carry_c[k] = __shfl(cfirst[k], src);
-      carry_v[k] = __shfl(vv[k][0], src);
+      for (int k = 0; k < 2; ++k) {
+        carry_c[k] = __shfl(cfirst[k], src);
+        carry_v[k] = __shfl(vv[k][0], src);
+      }
+      carry_any = carry_any || (grp != 0ull);
     }
-    carry_any = carry_any || (grp != 0ull);
   }
 
   // block reduction in a fixed order -> partials[block][4] = {sum adv_r, sum adv_r^2, sum adv_c, count}
