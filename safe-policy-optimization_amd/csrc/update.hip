@@ -119,7 +119,12 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
   using L = NetLds<KIN>;
   constexpr int NT1 = KIN / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
-  const int net = a.first_net + blockIdx.x;
+  // Placement hint (speed only, never correctness): workgroup b is observed to land on XCD b % 8, so the
+  // persistent form launches 8*(n-1)+1 blocks and only blocks 0, 8, 16 work -- the networks then share one
+  // XCD's L2 and the per-step granule exchange is ~0.1-0.3 us faster.  Any other placement is just slower.
+  const int wg = PERSIST ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  if (PERSIST && (blockIdx.x & 7)) return;
+  const int net = a.first_net + wg;
   const int D = a.cfg.obs_dim, A = a.cfg.act_dim, B = a.cfg.batch;
   const NetGeom g = net_geom(D, A, net);
   const bool is_actor = (net == 2);
@@ -564,75 +569,95 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
       return;
     }
 
-    // ---- joint clip_grad_norm_ over all networks: exchange ||g||^2 (one granule per workgroup)
-    {
-      unsigned long long* row = a.slots + (s & 1) * 4;
-      const unsigned tag = (unsigned)(s + 1);
-      if (tid == 0) st_granule(row + blockIdx.x, ((unsigned long long)tag << 32) | __float_as_uint(my_sq));
-      if (tid < a.n_nets) {
-        unsigned long long v = 0;
-        unsigned spins = 0;
-        for (;;) {
-          v = ld_granule(row + tid);
-          if ((unsigned)(v >> 32) == tag) break;
-          if (++spins > (1u << 24)) { *a.err = 1; break; }          // bounded: never hang the GPU
-          __builtin_amdgcn_s_sleep(1);
+    // ---- joint clip_grad_norm_ over all networks: publish ||g||^2 (one granule per workgroup) ...
+    unsigned long long* const grow = a.slots + (s & 1) * 4;
+    const unsigned tag = (unsigned)(s + 1);
+    if (tid == 0) st_granule(grow + wg, ((unsigned long long)tag << 32) | __float_as_uint(my_sq));
+    // first look at the peers' granules now: the load's fabric latency (~0.6 us) hides under the speculative Adam
+    unsigned long long peek = 0;
+    if (tid < a.n_nets) peek = ld_granule(grow + tid);
+
+    // ---- ... and run Adam SPECULATIVELY with clip coefficient 1 while the granules are in flight
+    //      (max_grad_norm = 40 almost never clips).  The moments are backed up so that a clipped step is
+    //      redone exactly from the old state; parameters are only read by other waves after the final barrier.
+    pw1 *= (double)b1c; pw2 *= (double)b2c;
+    const float step_size = (float)((double)lr / (1.0 - pw1));
+    const float inv_bc2s = (float)(1.0 / sqrt(1.0 - pw2));
+    f4 omW1[NT1], ovW1[NT1], omW2[4], ovW2[4];
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt) { omW1[nt] = mW1[nt]; ovW1[nt] = vW1[nt]; }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) { omW2[nt] = mW2[nt]; ovW2[nt] = vW2[nt]; }
+    const f4 omW3 = mW3, ovW3 = vW3, omls = mls, ovls = vls;
+    const float omb1 = mb1, ovb1 = vb1, omb2 = mb2, ovb2 = vb2, omb3 = mb3, ovb3 = vb3;
+    auto run_adam = [&](const float coef) {
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)                                         // pad columns stay exactly 0
+          SPO_ADAM(lds[L::W1 + (orow + r) * L::LD1 + 16 * nt + j], pW1[nt][r], aW1[nt][r] * coef, mW1[nt][r], vW1[nt][r])
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          SPO_ADAM(lds[L::W2 + (orow + r) * LDH + 16 * nt + j], pW2[nt][r], aW2[nt][r] * coef, mW2[nt][r], vW2[nt][r])
+#pragma unroll
+      for (int r = 0; r < 4; ++r)                                           // pad rows stay exactly 0
+        SPO_ADAM(lds[L::W3 + (4 * q + r) * LDH + 16 * wave + j], pW3[r], aW3[r] * coef, mW3[r], vW3[r])
+      // replicated state (biases, log_std): all replicas compute identical values and store them to the same word
+      float np1, np2, np3;
+      SPO_ADAM(np1, pb1, db1 * coef, mb1, vb1)
+      SPO_ADAM(np2, pb2, db2 * coef, mb2, vb2)
+      SPO_ADAM(np3, pb3, db3 * coef, mb3, vb3)
+      lds[L::B1 + 16 * wave + j] = np1;
+      lds[L::B2 + 16 * wave + j] = np2;
+      lds[L::B3 + j] = np3;
+      if (is_actor) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float nl;
+          SPO_ADAM(nl, pls[r], dls[r] * coef, mls[r], vls[r])
+          red[128 + 4 * q + r] = nl;
         }
-        red[96 + tid] = __uint_as_float((unsigned)v);
       }
-      __syncthreads();
-    }
+    };
+    run_adam(1.f);
     SPO_STAMP(7)
+
+    // ---- collect the other workgroups' ||g||^2 (already there in the common case)
+    if (tid < a.n_nets) {
+      unsigned long long v = peek;
+      unsigned spins = 0;
+      while ((unsigned)(v >> 32) != tag) {
+        if (++spins > (1u << 24)) { *a.err = 1; break; }          // bounded: never hang the GPU
+        __builtin_amdgcn_s_sleep(1);
+        v = ld_granule(grow + tid);
+      }
+      red[96 + tid] = __uint_as_float((unsigned)v);
+    }
+    __syncthreads();
     float total_sq = stale_sq;
     for (int k = 0; k < a.n_nets; ++k) total_sq += red[96 + k];
     const float norm = sqrtf(total_sq);
     float coef = a.cfg.max_grad_norm / (norm + 1e-6f);                // clip_grad_norm_ (torch): eps 1e-6
     coef = coef > 1.f ? 1.f : coef;
     stale_sq *= coef * coef;                                         // stale actor grads are scaled in place too
-
-    // ---- Adam (bias corrections in double from the running beta powers)
-    pw1 *= (double)b1c; pw2 *= (double)b2c;
-    const float step_size = (float)((double)lr / (1.0 - pw1));
-    const float inv_bc2s = (float)(1.0 / sqrt(1.0 - pw2));
+    if (coef != 1.f) {
+      // clipped step (uniform across the grid: every workgroup sees the same total): redo from the old state
 #pragma unroll
-    for (int nt = 0; nt < NT1; ++nt)
+      for (int nt = 0; nt < NT1; ++nt) { mW1[nt] = omW1[nt]; vW1[nt] = ovW1[nt]; }
 #pragma unroll
-      for (int r = 0; r < 4; ++r)                                         // pad columns stay exactly 0
-        SPO_ADAM(lds[L::W1 + (orow + r) * L::LD1 + 16 * nt + j], pW1[nt][r], aW1[nt][r] * coef, mW1[nt][r], vW1[nt][r])
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        SPO_ADAM(lds[L::W2 + (orow + r) * LDH + 16 * nt + j], pW2[nt][r], aW2[nt][r] * coef, mW2[nt][r], vW2[nt][r])
-#pragma unroll
-    for (int r = 0; r < 4; ++r)                                           // pad rows stay exactly 0
-      SPO_ADAM(lds[L::W3 + (4 * q + r) * LDH + 16 * wave + j], pW3[r], aW3[r] * coef, mW3[r], vW3[r])
-    {
-      // replicated state: all replicas compute identical values and store them to the same word
-      float np1, np2, np3;
-      SPO_ADAM(np1, pb1, db1 * coef, mb1, vb1)
-      SPO_ADAM(np2, pb2, db2 * coef, mb2, vb2)
-      SPO_ADAM(np3, pb3, db3 * coef, mb3, vb3)
-      float nls[4];
-      if (is_actor) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) SPO_ADAM(nls[r], pls[r], dls[r] * coef, mls[r], vls[r])
-      }
-      // (old values were read before the norm barrier: replicas may store right away)
-      lds[L::B1 + 16 * wave + j] = np1;
-      lds[L::B2 + 16 * wave + j] = np2;
-      lds[L::B3 + j] = np3;
-      if (is_actor) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[128 + 4 * q + r] = nls[r];
-      }
+      for (int nt = 0; nt < 4; ++nt) { mW2[nt] = omW2[nt]; vW2[nt] = ovW2[nt]; }
+      mW3 = omW3; vW3 = ovW3; mls = omls; vls = ovls;
+      mb1 = omb1; vb1 = ovb1; mb2 = omb2; vb2 = ovb2; mb3 = omb3; vb3 = ovb3;
+      run_adam(coef);
     }
     SPO_STAMP(8)
     __syncthreads();
     SPO_STAMP(9)
   }  // chunks
   if (PROF && a.prof && tid == 0)
-    for (int i = 0; i < NPHASE; ++i) a.prof[blockIdx.x * NPHASE + i] = pacc[i];
+    for (int i = 0; i < NPHASE; ++i) a.prof[wg * NPHASE + i] = pacc[i];
 #undef SPO_STAMP
 
   if (PERSIST) {
@@ -675,7 +700,7 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
       a.theta[g.b2() + o] = lds[L::B2 + o]; SPO_ST_MV(g.b2() + o, mb2, vb2)
     }
     if (own_b3) { a.theta[g.b3() + j] = lds[L::B3 + j]; SPO_ST_MV(g.b3() + j, mb3, vb3) }
-    if (tid == 0 && blockIdx.x == 0 && a.stale_io) {
+    if (tid == 0 && wg == 0 && a.stale_io) {
       // every workgroup read the old value before its first step; they all finish after the last exchange
       *a.stale_io = stale_sq;
     }
@@ -721,7 +746,7 @@ int launch_update(const UpdArgs& a, int blocks, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_update_kernel<64, true, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return spo::hip_check(e, "hipFuncSetAttribute(update prof)");
-    hipLaunchKernelGGL((ppo_update_kernel<64, true, true>), dim3(blocks), dim3(256), sh, st, a);
+    hipLaunchKernelGGL((ppo_update_kernel<64, true, true>), dim3(8 * (blocks - 1) + 1), dim3(256), sh, st, a);
     return 0;
   }
 #define SPO_LAUNCH(K)                                                                                   \
@@ -734,7 +759,8 @@ int launch_update(const UpdArgs& a, int blocks, hipStream_t st) {
       if (e != hipSuccess) return spo::hip_check(e, "hipFuncSetAttribute(update)");                     \
       attr_done = true;                                                                                 \
     }                                                                                                   \
-    hipLaunchKernelGGL((ppo_update_kernel<K, PERSIST>), dim3(blocks), dim3(256), sh, st, a);            \
+    hipLaunchKernelGGL((ppo_update_kernel<K, PERSIST>), dim3(PERSIST ? 8 * (blocks - 1) + 1 : blocks),   \
+                       dim3(256), sh, st, a);                                                          \
   }
   if (kin == 16) SPO_LAUNCH(16) else if (kin == 32) SPO_LAUNCH(32) else SPO_LAUNCH(64)
 #undef SPO_LAUNCH
