@@ -31,9 +31,10 @@ struct UpdLds {
   static constexpr int XT = L::SIZE;
   static constexpr int H1T = XT + KIN * LDB;
   static constexpr int H2T = H1T + HID * LDB;
-  static constexpr int DZ1T = H2T + HID * LDB;
-  static constexpr int DZ2T = DZ1T + HID * LDB;
-  static constexpr int DOT = DZ2T + HID * LDB;
+  static constexpr bool SPLIT = (KIN > 64);        // obs_dim > 64: dZ1^T reuses the dZ2^T buffer (two sub-phases)
+  static constexpr int DZ2T = H2T + HID * LDB;
+  static constexpr int DZ1T = SPLIT ? DZ2T : DZ2T + HID * LDB;
+  static constexpr int DOT = DZ1T + HID * LDB;
   static constexpr int RED = DOT + OUTP * LDB;
   static constexpr int SIZE = RED + RED_FLOATS;
 };
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
         const int f = (16 * mt + 4 * q + r) * LDB + mycol;
         lds[U::H1T + f] = h1[mt][r];
         lds[U::H2T + f] = h2[mt][r];
-        lds[U::DZ1T + f] = dz1[mt][r];
+        if (!U::SPLIT) lds[U::DZ1T + f] = dz1[mt][r];
         lds[U::DZ2T + f] = dz2[mt][r];
       }
 #pragma unroll
@@ -400,16 +401,21 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
     SPO_STAMP(4)
 
     // ---- dW[o][i] += sum_b dZ[b][o] * Hprev[b][i]; wave w owns rows 16w..16w+15.
-    //      A tiles (dZ^T rows) of all three layers are read first; B tiles are read one k-group ahead.
+    //      A tiles (dZ^T rows) are read first; B tiles are read one k-group ahead of their MFMAs.
     {
-      f4 az1[4], az2[4], az3[4];
+      f4 az2[4], az3[4];
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
         az2[r4] = *reinterpret_cast<const f4*>(lds + U::DZ2T + (16 * wave + j) * LDB + 16 * r4 + 4 * q);
         az3[r4] = *reinterpret_cast<const f4*>(lds + U::DOT + j * LDB + 16 * r4 + 4 * q);
-        az1[r4] = *reinterpret_cast<const f4*>(lds + U::DZ1T + (16 * wave + j) * LDB + 16 * r4 + 4 * q);
       }
-      // layer 2 then layer 3 then layer 1
+      f4 az1[4];
+      if (!U::SPLIT) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+          az1[r4] = *reinterpret_cast<const f4*>(lds + U::DZ1T + (16 * wave + j) * LDB + 16 * r4 + 4 * q);
+      }
+      // layer 2 then layer 3
       f4 bh[2][4];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
@@ -430,10 +436,6 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4)
         b3[r4] = *reinterpret_cast<const f4*>(lds + U::H2T + (16 * wave + j) * LDB + 16 * r4 + 4 * q);
-      f4 bx[2][NT1];
-#pragma unroll
-      for (int nt = 0; nt < NT1; ++nt)
-        bx[0][nt] = *reinterpret_cast<const f4*>(lds + U::XT + (16 * nt + j) * LDB + 4 * q);
       f4 w3a = {0.f, 0.f, 0.f, 0.f}, w3b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int r4 = 0; r4 < 4; r4 += 2)
@@ -443,6 +445,30 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
           w3b = mfma4(az3[r4 + 1][e], b3[r4 + 1][e], w3b);
         }
       aW3 += w3a + w3b;
+      float rs2 = 0.f, rs3 = 0.f;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        rs2 += (az2[r4][0] + az2[r4][1]) + (az2[r4][2] + az2[r4][3]);
+        rs3 += (az3[r4][0] + az3[r4][1]) + (az3[r4][2] + az3[r4][3]);
+      }
+      db2 += rs2; db3 += rs3;
+      if (U::SPLIT) {
+        // second sub-phase: dZ1^T goes into the buffer dZ2^T just vacated
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lds[U::DZ1T + (16 * mt + 4 * q + r) * LDB + mycol] = dz1[mt][r];
+        __syncthreads();
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+          az1[r4] = *reinterpret_cast<const f4*>(lds + U::DZ1T + (16 * wave + j) * LDB + 16 * r4 + 4 * q);
+      }
+      // layer 1
+      f4 bx[2][NT1];
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt)
+        bx[0][nt] = *reinterpret_cast<const f4*>(lds + U::XT + (16 * nt + j) * LDB + 4 * q);
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
         if (r4 + 1 < 4) {
@@ -455,14 +481,10 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
 #pragma unroll
           for (int nt = 0; nt < NT1; ++nt) aW1[nt] = mfma4(az1[r4][e], bx[r4 & 1][nt][e], aW1[nt]);
       }
-      float rs1 = 0.f, rs2 = 0.f, rs3 = 0.f;
+      float rs1 = 0.f;
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        rs1 += (az1[r4][0] + az1[r4][1]) + (az1[r4][2] + az1[r4][3]);
-        rs2 += (az2[r4][0] + az2[r4][1]) + (az2[r4][2] + az2[r4][3]);
-        rs3 += (az3[r4][0] + az3[r4][1]) + (az3[r4][2] + az3[r4][3]);
-      }
-      db1 += rs1; db2 += rs2; db3 += rs3;
+      for (int r4 = 0; r4 < 4; ++r4) rs1 += (az1[r4][0] + az1[r4][1]) + (az1[r4][2] + az1[r4][3]);
+      db1 += rs1;
     }
     if (!last_half) {
       __syncthreads();         // the next half overwrites the staged images
@@ -583,13 +605,16 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
     pw1 *= (double)b1c; pw2 *= (double)b2c;
     const float step_size = (float)((double)lr / (1.0 - pw1));
     const float inv_bc2s = (float)(1.0 / sqrt(1.0 - pw2));
+    constexpr bool SPEC = (KIN <= 64);          // the 128-wide variant has no registers to spare for the backups
     f4 omW1[NT1], ovW1[NT1], omW2[4], ovW2[4];
+    f4 omW3 = mW3, ovW3 = vW3, omls = mls, ovls = vls;
+    float omb1 = mb1, ovb1 = vb1, omb2 = mb2, ovb2 = vb2, omb3 = mb3, ovb3 = vb3;
+    if (SPEC) {
 #pragma unroll
-    for (int nt = 0; nt < NT1; ++nt) { omW1[nt] = mW1[nt]; ovW1[nt] = vW1[nt]; }
+      for (int nt = 0; nt < NT1; ++nt) { omW1[nt] = mW1[nt]; ovW1[nt] = vW1[nt]; }
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) { omW2[nt] = mW2[nt]; ovW2[nt] = vW2[nt]; }
-    const f4 omW3 = mW3, ovW3 = vW3, omls = mls, ovls = vls;
-    const float omb1 = mb1, ovb1 = vb1, omb2 = mb2, ovb2 = vb2, omb3 = mb3, ovb3 = vb3;
+      for (int nt = 0; nt < 4; ++nt) { omW2[nt] = mW2[nt]; ovW2[nt] = vW2[nt]; }
+    }
     auto run_adam = [&](const float coef) {
 #pragma unroll
       for (int nt = 0; nt < NT1; ++nt)
@@ -621,7 +646,7 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
         }
       }
     };
-    run_adam(1.f);
+    if (SPEC) run_adam(1.f);
     SPO_STAMP(7)
 
     // ---- collect the other workgroups' ||g||^2 (already there in the common case)
@@ -642,7 +667,9 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
     float coef = a.cfg.max_grad_norm / (norm + 1e-6f);                // clip_grad_norm_ (torch): eps 1e-6
     coef = coef > 1.f ? 1.f : coef;
     stale_sq *= coef * coef;                                         // stale actor grads are scaled in place too
-    if (coef != 1.f) {
+    if (!SPEC) {
+      run_adam(coef);
+    } else if (coef != 1.f) {
       // clipped step (uniform across the grid: every workgroup sees the same total): redo from the old state
 #pragma unroll
       for (int nt = 0; nt < NT1; ++nt) { mW1[nt] = omW1[nt]; vW1[nt] = ovW1[nt]; }
@@ -734,7 +761,7 @@ __global__ __launch_bounds__(1024) void clip_adam_kernel(AdamArgs a) {
   }
 }
 
-int pick_kin(int D) { return D <= 16 ? 16 : D <= 32 ? 32 : 64; }
+int pick_kin(int D) { return D <= 16 ? 16 : D <= 32 ? 32 : D <= 64 ? 64 : 128; }
 
 unsigned long long* g_prof_buf = nullptr;
 
@@ -762,16 +789,15 @@ int launch_update(const UpdArgs& a, int blocks, hipStream_t st) {
     hipLaunchKernelGGL((ppo_update_kernel<K, PERSIST>), dim3(PERSIST ? 8 * (blocks - 1) + 1 : blocks),   \
                        dim3(256), sh, st, a);                                                          \
   }
-  if (kin == 16) SPO_LAUNCH(16) else if (kin == 32) SPO_LAUNCH(32) else SPO_LAUNCH(64)
+  if (kin == 16) SPO_LAUNCH(16) else if (kin == 32) SPO_LAUNCH(32) else if (kin == 64) SPO_LAUNCH(64) else SPO_LAUNCH(128)
 #undef SPO_LAUNCH
   return 0;
 }
 
 int check_cfg(const spo_ppo_cfg* c) {
   if (!c) return spo::fail(-1, "update: cfg is NULL");
-  if (c->obs_dim < 1 || c->obs_dim > 64)
-    return spo::fail(-2, "update: obs_dim %d outside [1,64] (update kernels; collect supports up to %d)", c->obs_dim,
-                     SPO_MAX_OBS);
+  if (c->obs_dim < 1 || c->obs_dim > SPO_MAX_OBS)
+    return spo::fail(-2, "update: obs_dim %d outside [1,%d]", c->obs_dim, SPO_MAX_OBS);
   if (c->act_dim < 1 || c->act_dim > SPO_MAX_ACT) return spo::fail(-2, "update: act_dim %d outside [1,16]", c->act_dim);
   if (c->batch < 1) return spo::fail(-2, "update: batch must be >= 1");
   return 0;

@@ -268,7 +268,7 @@ def _synthetic_update_problem(M, D, A, seed):
 
 
 @pytest.mark.parametrize("M,D,A,batch", [(256, 60, 8, 64), (150, 60, 8, 64), (200, 12, 2, 64), (64, 33, 5, 64),
-                                         (300, 60, 8, 128), (40, 20, 3, 64)])
+                                         (300, 60, 8, 128), (40, 20, 3, 64), (150, 100, 4, 64), (130, 128, 16, 64)])
 def test_minibatch_grad_and_step_vs_oracle(dev, M, D, A, batch):
     """First-minibatch gradient (pre-clip), losses, and parameters after one full pass
     (partial last batch included) against torch autograd + Adam on the CPU oracle."""
@@ -621,11 +621,13 @@ def test_limits_and_edge_shapes(dev):
     losses = eng.learning_iter(perm.to(torch.int32).to(dev))
     np.testing.assert_allclose(losses.cpu().numpy(), np.asarray(lr), rtol=1e-4, atol=2e-6)
     _assert_params_close(pol.theta.cpu().numpy(), R.flat_params(ref).numpy(), 3e-4, 2, what="64x16")
-    # update kernels reject obs_dim > 64 loudly (collect supports up to 128)
-    big = ActorVCritic(100, 4).to(dev)
-    e2 = PPOLagEngine(big, 2, 8, cfg, dev)
+    # outside the envelope: loud failures
     with pytest.raises(_abi.SpoError, match="obs_dim"):
-        e2.learning_iter(torch.arange(16, dtype=torch.int32, device=dev))
+        ActorVCritic(129, 4).to(dev).step(torch.zeros(2, 129, device=dev))
+    from safepo.single_agent.cpo import CPOEngine, default_cfg as cpo_cfg
+    with pytest.raises(_abi.SpoError, match="obs_dim"):
+        e3 = CPOEngine(ActorVCritic(100, 4).to(dev), 2, 8, dict(cpo_cfg), dev)
+        e3.fvp(torch.zeros(e3.Pa, device=dev))
     with pytest.raises(_abi.SpoError, match="act_dim"):
         ActorVCritic(10, 17).to(dev).step(torch.zeros(2, 10, device=dev))
     smoke_check(num_envs=1, steps=3, seed=3)     # (M=1 gives std()=NaN in the reference too)
