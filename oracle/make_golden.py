@@ -300,3 +300,28 @@ if __name__ == "__main__":
     golden_trace("cpo", "cpo_trace.npz", num_envs=4, T=48, epochs=2, env_kw=env_kw,
                  cfg_over={"learning_iters": 2, "batch_size": 64}, fvp_calls=3,
                  args_over={"cost_limit": 3.0})
+
+
+def golden_pid():
+    """PIDLagrangian multipliers for a fixed episode-cost sequence (reference safepo/common/lagrange.py:108-200,
+    loaded straight from its file: the module has no third-party imports)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_lagrange", os.path.join(ref_shim.REF_ROOT, "safepo/common/lagrange.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    rng = np.random.default_rng(0)
+    costs = np.concatenate([[0.0], rng.uniform(0, 60, 40), np.full(8, 25.0), rng.uniform(20, 30, 16)])
+    out = {}
+    for tag, kw in {"default": {}, "diffnorm": {"diff_norm": True}, "nosum": {"sum_norm": False, "penalty_max": 0.5}}.items():
+        pid = m.PIDLagrangian(cost_limit=25.0, lagrangian_multiplier_init=0.001, **kw)
+        vals = []
+        for c in costs:
+            pid.update_lagrange_multiplier(float(c))
+            vals.append(pid.lagrangian_multiplier)
+        out[tag] = np.asarray(vals)
+    np.savez_compressed(os.path.join(OUT, "pid.npz"), costs=costs, **out)
+    print("pid.npz")
+
+
+if __name__ == "__main__":
+    golden_pid()

@@ -1,0 +1,157 @@
+"""Shared driver of the first-order single-agent scripts (ppo_lag, ppo, pg, cppo_pid).
+
+The reference keeps one near-identical copy of this loop per script (SURVEY.md section 2 rows 6 and 8:
+ppo.py drops the Lagrange multiplier, `advantage = data["adv_r"]` (ppo.py:272); pg.py additionally drops
+the ratio clip (pg.py:309); cppo_pid.py swaps Lagrange for PIDLagrangian (cppo_pid.py:39)).  Here the
+variants are parameters of one loop over the same HIP kernels:
+    multiplier = "adam" | "pid" | None       clip = 0.2 | None (no clipping)
+The epoch structure follows safepo/single_agent/ppo_lag.py:159-386.
+"""
+from __future__ import annotations
+
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+from safepo.common.engine import PPOLagEngine
+from safepo.common.env import make_sa_mujoco_env
+from safepo.common.lagrange import Lagrange, PIDLagrangian
+from safepo.common.logger import EpochLogger
+from safepo.common.model import ActorVCritic
+from safepo.parallel import dp_mean_scalar, init_from_env, shard_envs
+from safepo.utils.config import isaac_gym_map
+
+NO_CLIP = 1e30      # clamp(ratio, 1-1e30, 1+1e30) is the identity: pg's unclipped surrogate on the same kernel
+
+
+def _to_dev(x, dev):
+    return torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x, dtype=torch.float32, device=dev).contiguous()
+
+
+def run(args, cfg_env, default_cfg: dict, multiplier: str | None = "adam", clip: float | None = 0.2):
+    random.seed(args.seed)
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)
+    if args.device == "cpu":
+        raise RuntimeError("this build runs the PPO-Lagrangian hot path on a ROCm GPU only (--device cuda); "
+                           "there is no CPU fallback")
+    comm = init_from_env()
+    local_rank = int(os.environ.get("LOCAL_RANK", args.device_id))
+    device = torch.device(f"cuda:{local_rank if comm.world_size > 1 else args.device_id}")
+    torch.cuda.set_device(device)
+    if args.task in isaac_gym_map:
+        raise NotImplementedError("Isaac Gym tasks (isaac_gym_specific_cfg) are not part of this build")
+    config = dict(default_cfg)
+    config.update(getattr(args, "cfg_override", None) or {})
+    config["clip"] = NO_CLIP if clip is None else clip
+
+    _, n_local = shard_envs(args.num_envs, comm)
+    env, obs_space, act_space = make_sa_mujoco_env(num_envs=n_local, env_id=args.task,
+                                                   seed=args.seed + 1000 * comm.rank, device=device,
+                                                   **(getattr(args, "env_kwargs", None) or {}))
+    device_env = getattr(env, "is_device_env", False)
+
+    steps_per_epoch = config.get("steps_per_epoch", args.steps_per_epoch)
+    total_steps = config.get("total_steps", args.total_steps)
+    local_steps_per_epoch = steps_per_epoch // args.num_envs
+    epochs = total_steps // steps_per_epoch
+
+    policy = ActorVCritic(obs_dim=obs_space.shape[0], act_dim=act_space.shape[0],
+                          hidden_sizes=config["hidden_sizes"]).to(device)
+    comm.broadcast_(policy.theta, 0)            # identical replicas
+    engine = PPOLagEngine(policy, n_local, local_steps_per_epoch, config, device, comm=comm, lr=3e-4)
+    if multiplier == "adam":
+        lagrange = Lagrange(cost_limit=args.cost_limit, lagrangian_multiplier_init=args.lagrangian_multiplier_init,
+                            lagrangian_multiplier_lr=args.lagrangian_multiplier_lr)
+    elif multiplier == "pid":
+        lagrange = PIDLagrangian(cost_limit=args.cost_limit, lagrangian_multiplier_init=args.lagrangian_multiplier_init)
+    else:
+        lagrange = None
+
+    dict_args = dict(vars(args))
+    dict_args.update(config)
+    is_root = comm.rank == 0
+    log_dir = args.log_dir if is_root else os.path.join(args.log_dir, f"rank{comm.rank}")
+    logger = EpochLogger(log_dir=log_dir, seed=str(args.seed), verbose=is_root)
+    logger.save_config(dict_args)
+    logger.setup_torch_saver(policy.actor)
+    logger.log("Start with training.")
+
+    obs, _ = env.reset()
+    obs = _to_dev(obs, device)
+    timings = []
+    for epoch in range(epochs):
+        rollout_start_time = time.time()
+        # ---- collect (ppo_lag.py:162-234): no host sync inside the loop for device envs
+        for steps in range(local_steps_per_epoch):
+            act = engine.collect_step(steps, obs)
+            action = act if device_env else act.detach().squeeze().cpu().numpy()
+            next_obs, reward, cost, terminated, truncated, info = env.step(action)
+            final_obs = None
+            if "final_observation" in info:
+                fo = info["final_observation"]
+                if not torch.is_tensor(fo):
+                    fo = np.array([a if a is not None else np.zeros(obs.shape[-1]) for a in fo])
+                final_obs = _to_dev(fo, device)
+            next_obs = _to_dev(next_obs, device)
+            engine.post_step(steps, next_obs, _to_dev(reward, device), _to_dev(cost, device),
+                             _to_dev(terminated, device), _to_dev(truncated, device), final_obs)
+            obs = next_obs
+        engine.drain_episode_events(logger)
+        torch.cuda.synchronize(device)
+        rollout_end_time = time.time()
+        eval_end_time = rollout_end_time        # --use-eval is handled by safepo/evaluate.py (out of scope here)
+
+        # ---- Lagrange multiplier (ppo_lag.py:271-273); EpCost mean is all-reduced over shards
+        ep_costs = logger.get_stats("Metrics/EpCost")
+        ep_costs = dp_mean_scalar(comm, ep_costs, device)
+        if lagrange is not None:
+            lagrange.update_lagrange_multiplier(ep_costs)
+        # lambda == 0 makes (adv_r - 0*adv_c)/(0+1) == adv_r exactly: ppo / pg (ppo.py:272)
+        lam = lagrange.lagrangian_multiplier if lagrange is not None else 0.0
+
+        # ---- policy update (ppo_lag.py:275-350)
+        engine.lr_factor = 1.0 - epoch / epochs if epochs > 0 else 1.0      # LinearLR(1 -> 0, total_iters=epochs)
+        out = engine.update(lam)
+        torch.cuda.synchronize(device)
+        update_end_time = time.time()
+        next_lr = 3e-4 * (1.0 - min(epoch + 1, epochs) / epochs)
+        logger.store(**{"Loss/Loss_reward_critic": out["loss_r"], "Loss/Loss_cost_critic": out["loss_c"],
+                        "Loss/Loss_actor": out["loss_pi"]})
+        timings.append((rollout_end_time - rollout_start_time, update_end_time - eval_end_time))
+        if not logger.logged:
+            logger.log_tabular("Metrics/EpRet")
+            logger.log_tabular("Metrics/EpCost")
+            logger.log_tabular("Metrics/EpLen")
+            logger.log_tabular("Train/Epoch", epoch + 1)
+            logger.log_tabular("Train/TotalSteps", (epoch + 1) * args.steps_per_epoch)
+            logger.log_tabular("Train/StopIter", out["stop_iter"])
+            logger.log_tabular("Train/KL", out["kl"])
+            if lagrange is not None:
+                logger.log_tabular("Train/LagragianMultiplier", lagrange.lagrangian_multiplier)
+            logger.log_tabular("Train/LR", next_lr)
+            logger.log_tabular("Loss/Loss_reward_critic")
+            logger.log_tabular("Loss/Loss_cost_critic")
+            logger.log_tabular("Loss/Loss_actor")
+            logger.log_tabular("Time/Rollout", rollout_end_time - rollout_start_time)
+            logger.log_tabular("Time/Update", update_end_time - eval_end_time)
+            logger.log_tabular("Time/Total", update_end_time - rollout_start_time)
+            stats = engine.buffer.stats.cpu()
+            d = engine.buffer.data
+            logger.log_tabular("Value/RewardAdv", d["adv_r"].mean().item())
+            logger.log_tabular("Value/CostAdv", d["adv_c"].mean().item())
+            logger.dump_tabular()
+            if is_root and ((epoch + 1) % 100 == 0 or epoch == 0):
+                logger.torch_save(itr=epoch)
+                logger.save_state(state_dict={"Normalizer": getattr(env, "obs_rms", None)}, itr=epoch)
+        else:
+            logger.epoch_dict["Loss/Loss_reward_critic"] = []
+            logger.epoch_dict["Loss/Loss_cost_critic"] = []
+            logger.epoch_dict["Loss/Loss_actor"] = []
+    logger.close()
+    return {"timings": timings, "policy": policy, "engine": engine}
+
+

@@ -1,13 +1,5 @@
-"""PPO-Lagrangian, MI355X-native hot path behind the reference entry point.
-
-`main(args, cfg_env=None)`, `default_cfg` and the `python ppo_lag.py --task ... --num-envs ...` command line are
-those of the reference script (safepo/single_agent/ppo_lag.py:45-52,67,390-426).  The loop itself lives in
-safepo.single_agent._first_order (shared with ppo / pg / cppo_pid); every hot loop is a HIP kernel driven by
-safepo.common.engine.PPOLagEngine.
-
-Sharding: under torchrun (WORLD_SIZE > 1) `--num-envs` is the GLOBAL env count, split over ranks; each rank samples
-minibatches of `batch_size` rows from its own shard and the flat gradient is all-reduced (RCCL) at every minibatch
-step, so all replicas stay bit-identical.
+"""CPPO-PID: reference safepo/single_agent/cppo_pid.py = ppo_lag with PIDLagrangian in place of Lagrange
+(cppo_pid.py:39).  Same kernels; the multiplier is host-side scalar arithmetic.
 """
 from __future__ import annotations
 
@@ -29,7 +21,7 @@ default_cfg = {
 
 
 def main(args, cfg_env=None):
-    return _first_order.run(args, cfg_env, default_cfg, multiplier="adam", clip=0.2)
+    return _first_order.run(args, cfg_env, default_cfg, multiplier="pid", clip=0.2)
 
 
 if __name__ == "__main__":

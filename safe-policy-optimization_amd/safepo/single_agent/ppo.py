@@ -1,13 +1,5 @@
-"""PPO-Lagrangian, MI355X-native hot path behind the reference entry point.
-
-`main(args, cfg_env=None)`, `default_cfg` and the `python ppo_lag.py --task ... --num-envs ...` command line are
-those of the reference script (safepo/single_agent/ppo_lag.py:45-52,67,390-426).  The loop itself lives in
-safepo.single_agent._first_order (shared with ppo / pg / cppo_pid); every hot loop is a HIP kernel driven by
-safepo.common.engine.PPOLagEngine.
-
-Sharding: under torchrun (WORLD_SIZE > 1) `--num-envs` is the GLOBAL env count, split over ranks; each rank samples
-minibatches of `batch_size` rows from its own shard and the flat gradient is all-reduced (RCCL) at every minibatch
-step, so all replicas stay bit-identical.
+"""PPO (no constraint handling): reference safepo/single_agent/ppo.py = ppo_lag without the Lagrange multiplier,
+`advantage = data["adv_r"]` (ppo.py:272); the cost critic is still fitted.  Same kernels, lambda == 0.
 """
 from __future__ import annotations
 
@@ -29,7 +21,7 @@ default_cfg = {
 
 
 def main(args, cfg_env=None):
-    return _first_order.run(args, cfg_env, default_cfg, multiplier="adam", clip=0.2)
+    return _first_order.run(args, cfg_env, default_cfg, multiplier=None, clip=0.2)
 
 
 if __name__ == "__main__":

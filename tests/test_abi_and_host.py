@@ -163,3 +163,26 @@ def test_shard_envs_partitions_all_envs():
         for s, c in spans:
             assert s == pos
             pos += c
+
+
+def test_pid_lagrangian_matches_reference_golden(golden_dir):
+    from safepo.common.lagrange import PIDLagrangian
+    z = np.load(os.path.join(golden_dir, "pid.npz"))
+    for tag, kw in {"default": {}, "diffnorm": {"diff_norm": True}, "nosum": {"sum_norm": False, "penalty_max": 0.5}}.items():
+        pid = PIDLagrangian(cost_limit=25.0, lagrangian_multiplier_init=0.001, **kw)
+        got = []
+        for c in z["costs"]:
+            pid.update_lagrange_multiplier(float(c))
+            got.append(pid.lagrangian_multiplier)
+        np.testing.assert_allclose(np.asarray(got), z[tag], rtol=1e-12, atol=0)
+
+
+def test_sibling_scripts_share_the_reference_surface():
+    import importlib
+    for algo in ("ppo_lag", "ppo", "pg", "cppo_pid", "cpo"):
+        m = importlib.import_module(f"safepo.single_agent.{algo}")
+        assert callable(m.main) and m.default_cfg["hidden_sizes"] == [64, 64]
+    from safepo.single_agent import ppo_lag, cpo
+    assert ppo_lag.default_cfg == {'hidden_sizes': [64, 64], 'gamma': 0.99, 'target_kl': 0.02, 'batch_size': 64,
+                                   'learning_iters': 40, 'max_grad_norm': 40.0}
+    assert cpo.default_cfg["batch_size"] == 128 and cpo.default_cfg["target_kl"] == 0.01

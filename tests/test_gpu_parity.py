@@ -653,3 +653,66 @@ def test_obs_normalizer_vs_oracle_running_mean_std(dev):
     x = rng.standard_normal((5, D)).astype(np.float32)
     got = norm.normalize_(torch.from_numpy(x.copy()).to(dev), update=False).cpu().numpy()
     np.testing.assert_allclose(got, ((x - ref.mean) / np.sqrt(ref.var + 1e-8)).astype(np.float32), rtol=1e-5, atol=1e-5)
+
+
+def test_pg_unclipped_surrogate_and_ppo_lambda_zero(dev):
+    """f2 siblings on the same kernels: pg = no ratio clip (pg.py:309), ppo = lambda 0 (ppo.py:272)."""
+    from safepo import _abi
+    from safepo.common.engine import PPOLagEngine
+    from safepo.common.model import ActorVCritic
+    from safepo.single_agent._first_order import NO_CLIP
+    M, D, A = 64, 60, 8
+    torch.manual_seed(8)
+    pol = ActorVCritic(D, A).to(dev)
+    obs, act, logp, tgt_r, tgt_c, adv = _synthetic_update_problem(M, D, A, seed=21)
+    logp = logp + 0.5 * torch.randn(M)                       # push many ratios outside [0.8, 1.2]
+    cfg = {"hidden_sizes": [64, 64], "gamma": 0.99, "target_kl": 1e9, "batch_size": 64, "learning_iters": 1,
+           "max_grad_norm": 40.0, "clip": NO_CLIP}
+    eng = PPOLagEngine(pol, 1, M, cfg, dev)
+    b = eng.buffer
+    b.data["obs"].copy_(obs.view(1, M, D)); b.data["act"].copy_(act.view(1, M, A)); b.data["log_prob"].copy_(logp.view(1, M))
+    b.data["target_value_r"].copy_(tgt_r.view(1, M)); b.data["target_value_c"].copy_(tgt_c.view(1, M)); b.adv_mix.copy_(adv.view(1, M))
+    ref = R.OraclePolicy(D, A)
+    ref.load_state_dict({k: v.cpu().clone() for k, v in pol.state_dict().items()})
+    dist = ref.actor(obs)
+    ratio = torch.exp(dist.log_prob(act).sum(-1) - logp)
+    assert ((ratio < 0.8) | (ratio > 1.2)).float().mean() > 0.3
+    loss_pg = -(ratio * adv).mean()
+    ref.actor.zero_grad()
+    loss_pg.backward()
+    g_ref = torch.cat([p.grad.reshape(-1) for p in ref.actor.parameters()]).numpy()
+    idx = torch.arange(M, dtype=torch.int32, device=dev)
+    d = b.data
+    _abi.check(eng.lib.spo_ppo_lag_grad(_abi.ptr(pol.theta), _abi.ptr(d["obs"]), _abi.ptr(d["act"]), _abi.ptr(d["log_prob"]),
+                                        _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]), _abi.ptr(b.adv_mix),
+                                        _abi.ptr(idx), M, M, eng._cfg_struct(), _abi.ptr(eng.flat_grad), _abi.ptr(eng.losses3),
+                                        _abi.stream_ptr()), "grad")
+    got = eng.flat_grad[pol.log_std_offset:].cpu().numpy()
+    np.testing.assert_allclose(got, g_ref, rtol=1e-4, atol=1e-5 * np.abs(g_ref).max())
+    assert float(eng.losses3[2]) == pytest.approx(float(loss_pg), rel=1e-5)
+    # lambda == 0 leaves adv_r untouched by the mix kernel (bit pattern)
+    b.data["adv_r"].copy_(adv.view(1, M)); b.data["adv_c"].copy_(tgt_c.view(1, M))
+    b.sums.copy_(torch.tensor([0.0, float(M - 1), 0.0, float(M)], dtype=torch.float64))     # mean 0, std 1
+    _abi.check(eng.lib.spo_adv_apply(_abi.ptr(d["adv_r"]), _abi.ptr(d["adv_c"]), _abi.ptr(b.adv_mix), _abi.ptr(b.sums), M,
+                                     0.0, 0, 0, None, _abi.stream_ptr()), "apply")
+    assert torch.equal(b.adv_mix.view(-1).cpu(), adv)
+
+
+@pytest.mark.parametrize("algo", ["ppo", "pg", "cppo_pid"])
+def test_sibling_entrypoints_synthetic(dev, tmp_path, algo):
+    import argparse
+    import csv
+    import importlib
+    mod = importlib.import_module(f"safepo.single_agent.{algo}")
+    args = argparse.Namespace(seed=0, use_eval=False, task="SynthSafe-v0", num_envs=8, experiment="t",
+                              log_dir=str(tmp_path / "exp" / "task" / "run"), device="cuda", device_id=0,
+                              write_terminal=True, headless=False, total_steps=2 * 8 * 32, steps_per_epoch=8 * 32,
+                              randomize=False, cost_limit=0.5, lagrangian_multiplier_init=0.001,
+                              lagrangian_multiplier_lr=0.035, cfg_override={"learning_iters": 2},
+                              env_kwargs={"trunc_len": 8, "p_cost": 0.5})
+    mod.main(args, {})
+    rows = list(csv.DictReader(open(tmp_path / "exp" / "task" / "run" / "progress.csv")))
+    assert len(rows) == 2
+    assert ("Train/LagragianMultiplier" in rows[0]) == (algo == "cppo_pid")
+    if algo == "cppo_pid":
+        assert float(rows[1]["Train/LagragianMultiplier"]) > 0.0          # cost 4/episode > limit 0.5

@@ -1,6 +1,6 @@
 """Micro-benchmark of the GAE scan kernel: variants x sizes, HIP-event timing over R launches."""
 import os, sys, torch
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "safe-policy-optimization_amd"))
 from safepo import _abi
 from safepo.common.buffer import VectorizedOnPolicyBuffer

@@ -1,7 +1,7 @@
 """Debug tool: per-phase shader-cycle breakdown of the persistent PPO-Lag update kernel.
-Usage (GPU box): python tools_phase_profile.py"""
+Usage (GPU box): python tools/phase_profile.py"""
 import os, sys, torch
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "safe-policy-optimization_amd"))
 from safepo import _abi
 from safepo.common.engine import PPOLagEngine
