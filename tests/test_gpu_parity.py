@@ -716,3 +716,96 @@ def test_sibling_entrypoints_synthetic(dev, tmp_path, algo):
     assert ("Train/LagragianMultiplier" in rows[0]) == (algo == "cppo_pid")
     if algo == "cppo_pid":
         assert float(rows[1]["Train/LagragianMultiplier"]) > 0.0          # cost 4/episode > limit 0.5
+
+
+class _TargetEnv:
+    """Tiny device env with an action-dependent reward (test utility): reward = -mean((a - tanh(W obs))^2),
+    cost = 1 if |a_0| > 0.5; truncation every 16 steps.  A working collect->GAE->update loop must raise the return."""
+    is_device_env = True
+
+    def __init__(self, n, D, A, dev, seed=0):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        self.W = (torch.randn(D, A, generator=g) / D ** 0.5).to(dev)
+        self.n, self.D, self.A, self.dev, self.t = n, D, A, dev, 0
+        self.obs = torch.randn(n, D, device=dev)
+        self.obs_rms = None
+
+    def reset(self):
+        return self.obs, {}
+
+    def step(self, act):
+        tgt = torch.tanh(self.obs @ self.W)
+        reward = -((act - tgt) ** 2).mean(-1)
+        cost = (act[:, 0].abs() > 0.5).float()
+        self.t += 1
+        trunc = torch.full((self.n,), float(self.t % 16 == 0), device=self.dev)
+        nxt = torch.randn(self.n, self.D, device=self.dev)
+        info = {"final_observation": nxt.clone()}
+        self.obs = nxt
+        return nxt, reward.contiguous(), cost, torch.zeros(self.n, device=self.dev), trunc, info
+
+
+def test_end_to_end_learning_on_action_dependent_env(dev):
+    from safepo.common.engine import PPOLagEngine
+    from safepo.common.lagrange import Lagrange
+    from safepo.common.model import ActorVCritic
+    torch.manual_seed(0)
+    N, T, D, A = 256, 64, 12, 3
+    cfg = {"hidden_sizes": [64, 64], "gamma": 0.99, "target_kl": 0.02, "batch_size": 64, "learning_iters": 10, "max_grad_norm": 40.0}
+    pol = ActorVCritic(D, A).to(dev)
+    eng = PPOLagEngine(pol, N, T, cfg, dev)
+    env = _TargetEnv(N, D, A, dev)
+    lag = Lagrange(cost_limit=4.0, lagrangian_multiplier_init=0.001, lagrangian_multiplier_lr=0.035)
+    obs, _ = env.reset()
+    returns, costs = [], []
+    for epoch in range(25):
+        ep_r = 0.0
+        for t in range(T):
+            act = eng.collect_step(t, obs)
+            nobs, rew, cost, term, trunc, info = env.step(act.clone())
+            ep_r += float(rew.mean())
+            eng.post_step(t, nobs, rew, cost, term, trunc, info["final_observation"])
+            obs = nobs
+        eng.drain_episode_events(None)
+        returns.append(ep_r / T)
+        costs.append(float(np.mean(eng.cost_deque)))
+        lag.update_lagrange_multiplier(costs[-1])
+        out = eng.update(lag.lagrangian_multiplier)
+        assert np.isfinite(out["kl"]) and torch.isfinite(pol.theta).all()
+    first, last = np.mean(returns[:3]), np.mean(returns[-3:])
+    assert last > first + 0.25 * abs(first), (first, last)          # mean squared error to the target drops clearly
+    assert costs[-1] < costs[0]                                    # and the cost (|a_0| > 0.5 rate) comes down
+
+
+def test_long_trajectory_parity_1024_steps(dev):
+    """1 024 consecutive optimiser steps (one pass over 65 536 samples) against the CPU oracle: per-minibatch losses
+    along the whole trajectory and the final parameters (k = 1, 8, 8192 steps)."""
+    from safepo.common.engine import PPOLagEngine
+    from safepo.common.model import ActorVCritic
+    M, D, A = 65536, 60, 8
+    torch.manual_seed(3)
+    pol = ActorVCritic(D, A).to(dev)
+    obs, act, logp, tgt_r, tgt_c, adv = _synthetic_update_problem(M, D, A, seed=77)
+    cfg = {"hidden_sizes": [64, 64], "gamma": 0.99, "target_kl": 1e9, "batch_size": 64, "learning_iters": 1, "max_grad_norm": 40.0}
+    eng = PPOLagEngine(pol, 1, M, cfg, dev)
+    b = eng.buffer
+    b.data["obs"].copy_(obs.view(1, M, D)); b.data["act"].copy_(act.view(1, M, A)); b.data["log_prob"].copy_(logp.view(1, M))
+    b.data["target_value_r"].copy_(tgt_r.view(1, M)); b.data["target_value_c"].copy_(tgt_c.view(1, M)); b.adv_mix.copy_(adv.view(1, M))
+    ref = R.OraclePolicy(D, A)
+    ref.load_state_dict({k: v.cpu().clone() for k, v in pol.state_dict().items()})
+    upd = R.PPOLagUpdater(ref, epochs=1)
+    perm = torch.randperm(M, generator=torch.Generator().manual_seed(5))
+    torch.set_num_threads(4)
+    ref_losses = [upd.minibatch_step(obs[perm[s:s + 64]], act[perm[s:s + 64]], logp[perm[s:s + 64]], tgt_r[perm[s:s + 64]],
+                                     tgt_c[perm[s:s + 64]], adv[perm[s:s + 64]]) for s in range(0, M, 64)]
+    losses = eng.learning_iter(perm.to(torch.int32).to(dev)).cpu().numpy()
+    eng.check_sync_error()
+    ref_losses = np.asarray(ref_losses)
+    # early steps agree tightly; rounding differences grow slowly along the trajectory (Adam is not contractive)
+    np.testing.assert_allclose(losses[:8], ref_losses[:8], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(losses, ref_losses, rtol=5e-3, atol=5e-5)
+    rel = np.abs(losses - ref_losses) / (np.abs(ref_losses) + 1e-3)
+    assert np.median(rel) < 2e-4
+    th, tr = pol.theta.cpu().numpy(), R.flat_params(ref).numpy()
+    err = np.abs(th - tr)
+    assert np.median(err) < 2e-5 and err.max() < 5e-3, (np.median(err), err.max())
