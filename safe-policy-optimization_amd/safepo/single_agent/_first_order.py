@@ -53,6 +53,10 @@ def run(args, cfg_env, default_cfg: dict, multiplier: str | None = "adam", clip:
                                                    seed=args.seed + 1000 * comm.rank, device=device,
                                                    **(getattr(args, "env_kwargs", None) or {}))
     device_env = getattr(env, "is_device_env", False)
+    eval_env = None
+    if args.use_eval:
+        eval_env, _, _ = make_sa_mujoco_env(num_envs=1, env_id=args.task, seed=None, device=device,
+                                            **(getattr(args, "env_kwargs", None) or {}))
 
     steps_per_epoch = config.get("steps_per_epoch", args.steps_per_epoch)
     total_steps = config.get("total_steps", args.total_steps)
@@ -103,7 +107,32 @@ def run(args, cfg_env, default_cfg: dict, multiplier: str | None = "adam", clip:
         engine.drain_episode_events(logger)
         torch.cuda.synchronize(device)
         rollout_end_time = time.time()
-        eval_end_time = rollout_end_time        # --use-eval is handled by safepo/evaluate.py (out of scope here)
+
+        # ---- evaluation episodes (ppo_lag.py:237-269): deterministic policy on the single eval env.
+        # (The reference steps `env` instead of `eval_env` inside this loop, which only works for
+        #  --num-envs 1; the eval env is stepped here.)
+        if args.use_eval:
+            eval_rews, eval_costs, eval_lens = [], [], []
+            for _ in range(1 if epoch < epochs - 1 else 10):
+                eval_obs, _ = eval_env.reset()
+                eval_obs = _to_dev(eval_obs, device).reshape(1, -1)
+                eval_rew, eval_cost, eval_len, eval_done = 0.0, 0.0, 0.0, False
+                while not eval_done:
+                    act, _, _, _ = policy.step(eval_obs, deterministic=True)
+                    a_in = act if getattr(eval_env, "is_device_env", False) else act.detach().cpu().numpy()
+                    nobs, rew, cst, term, trunc, _ = eval_env.step(a_in)
+                    eval_rew += float(np.asarray(rew.cpu() if torch.is_tensor(rew) else rew).reshape(-1)[0])
+                    eval_cost += float(np.asarray(cst.cpu() if torch.is_tensor(cst) else cst).reshape(-1)[0])
+                    eval_len += 1
+                    t0 = np.asarray(term.cpu() if torch.is_tensor(term) else term).reshape(-1)[0]
+                    t1 = np.asarray(trunc.cpu() if torch.is_tensor(trunc) else trunc).reshape(-1)[0]
+                    eval_done = bool(t0) or bool(t1)
+                    eval_obs = _to_dev(nobs, device).reshape(1, -1)
+                eval_rews.append(eval_rew); eval_costs.append(eval_cost); eval_lens.append(eval_len)
+            logger.store(**{"Metrics/EvalEpRet": np.mean(eval_rews), "Metrics/EvalEpCost": np.mean(eval_costs),
+                            "Metrics/EvalEpLen": np.mean(eval_lens)})
+        torch.cuda.synchronize(device)
+        eval_end_time = time.time()
 
         # ---- Lagrange multiplier (ppo_lag.py:271-273); EpCost mean is all-reduced over shards
         ep_costs = logger.get_stats("Metrics/EpCost")
@@ -126,6 +155,10 @@ def run(args, cfg_env, default_cfg: dict, multiplier: str | None = "adam", clip:
             logger.log_tabular("Metrics/EpRet")
             logger.log_tabular("Metrics/EpCost")
             logger.log_tabular("Metrics/EpLen")
+            if args.use_eval:
+                logger.log_tabular("Metrics/EvalEpRet")
+                logger.log_tabular("Metrics/EvalEpCost")
+                logger.log_tabular("Metrics/EvalEpLen")
             logger.log_tabular("Train/Epoch", epoch + 1)
             logger.log_tabular("Train/TotalSteps", (epoch + 1) * args.steps_per_epoch)
             logger.log_tabular("Train/StopIter", out["stop_iter"])
@@ -137,6 +170,8 @@ def run(args, cfg_env, default_cfg: dict, multiplier: str | None = "adam", clip:
             logger.log_tabular("Loss/Loss_cost_critic")
             logger.log_tabular("Loss/Loss_actor")
             logger.log_tabular("Time/Rollout", rollout_end_time - rollout_start_time)
+            if args.use_eval:
+                logger.log_tabular("Time/Eval", eval_end_time - rollout_end_time)
             logger.log_tabular("Time/Update", update_end_time - eval_end_time)
             logger.log_tabular("Time/Total", update_end_time - rollout_start_time)
             stats = engine.buffer.stats.cpu()
@@ -151,6 +186,9 @@ def run(args, cfg_env, default_cfg: dict, multiplier: str | None = "adam", clip:
             logger.epoch_dict["Loss/Loss_reward_critic"] = []
             logger.epoch_dict["Loss/Loss_cost_critic"] = []
             logger.epoch_dict["Loss/Loss_actor"] = []
+            for k in ("Metrics/EvalEpRet", "Metrics/EvalEpCost", "Metrics/EvalEpLen"):
+                if k in logger.epoch_dict:
+                    logger.epoch_dict[k] = []
     logger.close()
     return {"timings": timings, "policy": policy, "engine": engine}
 

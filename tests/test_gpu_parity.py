@@ -809,3 +809,50 @@ def test_long_trajectory_parity_1024_steps(dev):
     th, tr = pol.theta.cpu().numpy(), R.flat_params(ref).numpy()
     err = np.abs(th - tr)
     assert np.median(err) < 2e-5 and err.max() < 5e-3, (np.median(err), err.max())
+
+
+@pytest.mark.parametrize("tag", ["a", "c"])
+def test_buffer_reference_api_store_finish_path_get(dev, golden_dir, tag):
+    """The reference's own call sequence -- store() per step, finish_path() per ended path, get() --
+    on the dense device buffer, against the outputs of the reference VectorizedOnPolicyBuffer."""
+    from safepo.common.buffer import VectorizedOnPolicyBuffer
+    from safepo.common.engine import _Space
+    z = np.load(os.path.join(golden_dir, "gae.npz"))
+    i = lambda k: z[f"{tag}_in_{k}"]
+    N, T = i("reward").shape
+    buf = VectorizedOnPolicyBuffer(obs_space=_Space(6), act_space=_Space(2), size=T, num_envs=N, gamma=0.99, device=dev)
+    for t in range(T):
+        buf.store(obs=torch.from_numpy(i("obs")[:, t]).to(dev), act=torch.from_numpy(i("act")[:, t]).to(dev),
+                  reward=torch.from_numpy(i("reward")[:, t]), cost=torch.from_numpy(i("cost")[:, t]),
+                  value_r=torch.from_numpy(i("value_r")[:, t]), value_c=torch.from_numpy(i("value_c")[:, t]),
+                  log_prob=torch.from_numpy(i("log_prob")[:, t]))
+        for n in range(N):
+            if i("seg_end")[n, t]:
+                buf.finish_path(last_value_r=torch.tensor([i("boot_r")[n, t]]), last_value_c=torch.tensor([i("boot_c")[n, t]]), idx=n)
+    with pytest.raises(AssertionError, match="Buffer overflow"):
+        buf.store(reward=torch.zeros(N))
+    data = buf.get()
+    assert set(data) >= {"obs", "act", "reward", "cost", "done", "value_r", "value_c", "adv_r", "adv_c",
+                         "target_value_r", "target_value_c", "log_prob"}
+    for k in ("obs", "act", "reward", "cost", "value_r", "value_c", "log_prob"):
+        assert np.array_equal(data[k].cpu().numpy(), z[f"{tag}_get_{k}"]), k
+    for k in ("target_value_r", "target_value_c"):
+        assert _ulp_diff(data[k].cpu().numpy(), z[f"{tag}_get_{k}"]).max() <= 1, k
+    np.testing.assert_allclose(data["adv_r"].cpu().numpy(), z[f"{tag}_get_adv_r"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(data["adv_c"].cpu().numpy(), z[f"{tag}_get_adv_c"], rtol=1e-5, atol=2e-6)
+    assert buf.ptr == 0 and buf.ptr_list == [0] * N
+
+
+def test_use_eval_branch(dev, tmp_path):
+    import argparse
+    import csv
+    from safepo.single_agent import ppo_lag
+    args = argparse.Namespace(seed=0, use_eval=True, task="SynthSafe-v0", num_envs=4, experiment="t",
+                              log_dir=str(tmp_path / "exp" / "task" / "run"), device="cuda", device_id=0,
+                              write_terminal=True, headless=False, total_steps=2 * 4 * 32, steps_per_epoch=4 * 32,
+                              randomize=False, cost_limit=25.0, lagrangian_multiplier_init=0.001,
+                              lagrangian_multiplier_lr=0.035, cfg_override={"learning_iters": 1},
+                              env_kwargs={"trunc_len": 8})
+    ppo_lag.main(args, {})
+    rows = list(csv.DictReader(open(tmp_path / "exp" / "task" / "run" / "progress.csv")))
+    assert len(rows) == 2 and float(rows[0]["Metrics/EvalEpLen"]) == 8.0 and "Time/Eval" in rows[0]
