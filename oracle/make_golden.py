@@ -325,3 +325,7 @@ def golden_pid():
 
 if __name__ == "__main__":
     golden_pid()
+    _env_kw = dict(obs_dim=60, act_dim=8, p_term=0.03, p_cost=0.3, trunc_len=20)
+    for _algo in ("natural_pg", "trpo"):
+        golden_trace(_algo, f"{_algo}_trace.npz", num_envs=4, T=48, epochs=2, env_kw=_env_kw,
+                     cfg_over={"learning_iters": 2, "batch_size": 64})

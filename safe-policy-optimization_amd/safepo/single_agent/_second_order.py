@@ -1,0 +1,134 @@
+"""Shared driver of the trust-region single-agent scripts natural_pg, trpo, rcpo, trpo_lag.
+
+In the reference each is a ~520-line copy of the same file that differs in two places:
+    natural_pg.py:356-381   step = x * sqrt(2*delta/xHx), applied directly
+    trpo.py:384-428         the same direction + backtracking line search (surrogate improves, KL <= delta)
+    rcpo.py:325-326         natural_pg on advantage = (adv_r - lambda*adv_c)/(lambda+1), Lagrange updated per epoch
+    trpo_lag.py:326-327     trpo on the same mixed advantage
+All of them reuse the CPO kernels (spo_cpo_surrogate_grad / spo_cpo_fvp / spo_cpo_linesearch_eval /
+spo_critic_fit_iter) through safepo.single_agent.cpo.CPOEngine.
+"""
+from __future__ import annotations
+
+import random
+import time
+
+import numpy as np
+import torch
+
+from safepo.common.env import make_sa_mujoco_env
+from safepo.common.lagrange import Lagrange
+from safepo.common.logger import EpochLogger
+from safepo.common.model import ActorVCritic
+from safepo.parallel import init_from_env
+from safepo.single_agent.cpo import CPOEngine, _to_dev
+from safepo.utils.config import isaac_gym_map
+
+
+def run(args, cfg_env, default_cfg: dict, line_search: bool, use_lagrange: bool):
+    random.seed(args.seed)
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)
+    if args.device == "cpu":
+        raise RuntimeError("this build runs the trust-region hot path on a ROCm GPU only (--device cuda); no CPU fallback")
+    comm = init_from_env()
+    device = torch.device(f"cuda:{args.device_id}")
+    torch.cuda.set_device(device)
+    if args.task in isaac_gym_map:
+        raise NotImplementedError("Isaac Gym tasks (isaac_gym_specific_cfg) are not part of this build")
+    config = dict(default_cfg)
+    config.update(getattr(args, "cfg_override", None) or {})
+    env, obs_space, act_space = make_sa_mujoco_env(num_envs=args.num_envs, env_id=args.task, seed=args.seed,
+                                                   device=device, **(getattr(args, "env_kwargs", None) or {}))
+    device_env = getattr(env, "is_device_env", False)
+    steps_per_epoch = config.get("steps_per_epoch", args.steps_per_epoch)
+    total_steps = config.get("total_steps", args.total_steps)
+    local_steps_per_epoch = steps_per_epoch // args.num_envs
+    epochs = total_steps // steps_per_epoch
+    policy = ActorVCritic(obs_dim=obs_space.shape[0], act_dim=act_space.shape[0],
+                          hidden_sizes=config["hidden_sizes"]).to(device)
+    engine = CPOEngine(policy, args.num_envs, local_steps_per_epoch, config, device, comm=comm)
+    lagrange = Lagrange(cost_limit=args.cost_limit, lagrangian_multiplier_init=args.lagrangian_multiplier_init,
+                        lagrangian_multiplier_lr=args.lagrangian_multiplier_lr) if use_lagrange else None
+    dict_args = dict(vars(args))
+    dict_args.update(config)
+    logger = EpochLogger(log_dir=args.log_dir, seed=str(args.seed))
+    logger.save_config(dict_args)
+    logger.setup_torch_saver(policy.actor)
+    logger.log("Start with training.")
+    obs, _ = env.reset()
+    obs = _to_dev(obs, device)
+    outs = []
+    for epoch in range(epochs):
+        rollout_start_time = time.time()
+        for steps in range(local_steps_per_epoch):
+            act = engine.collect_step(steps, obs)
+            action = act if device_env else act.detach().squeeze().cpu().numpy()
+            next_obs, reward, cost, terminated, truncated, info = env.step(action)
+            final_obs = None
+            if "final_observation" in info:
+                fo = info["final_observation"]
+                if not torch.is_tensor(fo):
+                    fo = np.array([a if a is not None else np.zeros(obs.shape[-1]) for a in fo])
+                final_obs = _to_dev(fo, device)
+            next_obs = _to_dev(next_obs, device)
+            engine.post_step(steps, next_obs, _to_dev(reward, device), _to_dev(cost, device),
+                             _to_dev(terminated, device), _to_dev(truncated, device), final_obs)
+            obs = next_obs
+        engine.drain_episode_events(logger)
+        torch.cuda.synchronize(device)
+        rollout_end_time = time.time()
+        eval_end_time = rollout_end_time
+
+        ep_costs = logger.get_stats("Metrics/EpCost")
+        lam = None
+        if lagrange is not None:
+            lagrange.update_lagrange_multiplier(ep_costs)
+            lam = lagrange.lagrangian_multiplier
+        engine.buffer.compute_gae(lam, comm)
+        M = engine.M
+        advantage = engine.buffer.adv_mix.reshape(M) if lam is not None else engine.buffer.data["adv_r"].reshape(M)
+        out = engine.trust_region_update(advantage, line_search, logger)
+        misc = {"Misc/Alpha": out["alpha"], "Misc/FinalStepNorm": out["final_step_norm"], "Misc/xHx": out["xHx"],
+                "Misc/gradient_norm": out["gradient_norm"], "Misc/H_inv_g": out["H_inv_g"],
+                "Loss/Loss_actor": out["loss_actor"], "Train/KL": out["kl"]}
+        if line_search:
+            misc["Misc/AcceptanceStep"] = out["acceptance_step"]
+        logger.store(**misc)
+        fit = engine.critic_fit()
+        engine.buffer.reset()
+        logger.store(**{"Loss/Loss_reward_critic": fit["loss_r"], "Loss/Loss_cost_critic": fit["loss_c"]})
+        torch.cuda.synchronize(device)
+        update_end_time = time.time()
+        outs.append(out)
+        if not logger.logged:
+            logger.log_tabular("Metrics/EpRet")
+            logger.log_tabular("Metrics/EpCost")
+            logger.log_tabular("Metrics/EpLen")
+            logger.log_tabular("Train/Epoch", epoch + 1)
+            logger.log_tabular("Train/TotalSteps", (epoch + 1) * args.steps_per_epoch)
+            logger.log_tabular("Train/KL")
+            if lagrange is not None:
+                logger.log_tabular("Train/LagragianMultiplier", lagrange.lagrangian_multiplier)
+            logger.log_tabular("Loss/Loss_reward_critic")
+            logger.log_tabular("Loss/Loss_cost_critic")
+            logger.log_tabular("Loss/Loss_actor")
+            logger.log_tabular("Time/Rollout", rollout_end_time - rollout_start_time)
+            logger.log_tabular("Time/Update", update_end_time - eval_end_time)
+            logger.log_tabular("Time/Total", update_end_time - rollout_start_time)
+            d = engine.buffer.data
+            logger.log_tabular("Value/RewardAdv", d["adv_r"].mean().item())
+            logger.log_tabular("Value/CostAdv", d["adv_c"].mean().item())
+            for k in ("Misc/Alpha", "Misc/FinalStepNorm", "Misc/xHx", "Misc/gradient_norm", "Misc/H_inv_g"):
+                logger.log_tabular(k)
+            if line_search:
+                logger.log_tabular("Misc/AcceptanceStep")
+            logger.dump_tabular()
+            if (epoch + 1) % 100 == 0 or epoch == 0:
+                logger.torch_save(itr=epoch)
+                logger.save_state(state_dict={"Normalizer": getattr(env, "obs_rms", None)}, itr=epoch)
+        else:
+            for k in list(logger.epoch_dict):
+                logger.epoch_dict[k] = []
+    logger.close()
+    return {"policy": policy, "engine": engine, "outs": outs}

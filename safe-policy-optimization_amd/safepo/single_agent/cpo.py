@@ -104,12 +104,15 @@ class CPOEngine(PPOLagEngine):
             rdotr = new_rdotr
         return x
 
-    def linesearch_eval(self):
-        """(loss_reward, loss_cost, kl) for the parameters currently in theta (cpo.py:473-491)."""
+    def linesearch_eval(self, adv_a=None, adv_b=None):
+        """(-mean(ratio*adv_a), mean(ratio*adv_b), kl) for the parameters currently in theta
+        (cpo.py:473-491; adv_a/adv_b default to the buffer's adv_r/adv_c)."""
         d = self.buffer.data
+        adv_a = d["adv_r"] if adv_a is None else adv_a
+        adv_b = d["adv_c"] if adv_b is None else adv_b
         _abi.check(self.lib.spo_cpo_linesearch_eval(
             _abi.ptr(self.policy.theta), _abi.ptr(d["obs"]), _abi.ptr(d["act"]), _abi.ptr(d["log_prob"]),
-            _abi.ptr(d["adv_r"]), _abi.ptr(d["adv_c"]), _abi.ptr(self.mean_old), _abi.ptr(self.logstd_old),
+            _abi.ptr(adv_a), _abi.ptr(adv_b), _abi.ptr(self.mean_old), _abi.ptr(self.logstd_old),
             self.M, self.D, self.A, _abi.ptr(self.ls_partials), self.ls_partials.numel(), _abi.ptr(self.ls_sums),
             _abi.stream_ptr()), "spo_cpo_linesearch_eval")
         s = self.ls_sums.cpu()
@@ -227,6 +230,68 @@ class CPOEngine(PPOLagEngine):
                 "gradient_norm": float(torch.norm(grads)), "H_inv_g": float(x.norm()),
                 "acceptance_step": acceptance_step, "loss_actor": loss_reward_before + loss_cost_before, "kl": kl,
                 "case": optim_case, "g": grads, "b": b_grads, "x": x, "p": p, "step_direction": step_direction}
+
+    def trust_region_update(self, advantage: torch.Tensor, line_search: bool, logger=None) -> dict:
+        """Natural-gradient step x*alpha with alpha = sqrt(2*delta / xHx) (natural_pg.py:350-381), optionally
+        followed by TRPO's backtracking line search on surrogate improvement and KL (trpo.py:384-428).
+        `advantage`: flat device tensor (adv_r, or the Lagrangian mix for rcpo / trpo_lag)."""
+        target_kl = self.cfg["target_kl"]
+        theta_old = self.theta_actor.clone()
+        self.snapshot_old_distribution()
+        g_loss, mean_ra = self.surrogate_grad(advantage, -1.0)          # loss_pi = -mean(ratio*advantage)
+        loss_before = -mean_ra
+        grads = -g_loss
+        x = self.conjugate_gradients(grads)
+        assert torch.isfinite(x).all(), "x is not finite"
+        xHx = torch.dot(x, self.fvp(x))
+        assert xHx.item() >= 0, "xHx is negative"
+        alpha = torch.sqrt(2 * target_kl / (xHx + 1e-8))
+        step_direction = x * alpha
+        assert torch.isfinite(step_direction).all(), "step_direction is not finite"
+        acceptance_step = None
+        if not line_search:
+            self.theta_actor.copy_(theta_old + step_direction)
+            _, _, final_kl = self.linesearch_eval(advantage, advantage)
+        else:
+            step_frac, final_kl, acceptance_step = 1.0, 0.0, 0
+            loss_pi = loss_before
+            expected_improve = grads.dot(step_direction)
+            for step in range(CPO_SEARCHING_STEPS):
+                self.theta_actor.copy_(theta_old + step_frac * step_direction)
+                loss_pi, _, kl = self.linesearch_eval(advantage, advantage)
+                loss_improve = loss_before - loss_pi
+                if logger:
+                    logger.log(f"Expected Improvement: {expected_improve} Actual: {loss_improve}")
+                if not np.isfinite(loss_pi):
+                    if logger:
+                        logger.log("WARNING: loss_pi not finite")
+                elif loss_improve < 0:
+                    if logger:
+                        logger.log("INFO: did not improve improve <0")
+                elif kl > target_kl:
+                    if logger:
+                        logger.log("INFO: violated KL constraint.")
+                else:
+                    acceptance_step = step + 1
+                    if logger:
+                        logger.log(f"Accept step at i={acceptance_step}")
+                    final_kl = kl
+                    break
+                step_frac *= STEP_FRACTION
+            else:
+                if logger:
+                    logger.log("INFO: no suitable step found...")
+                step_direction = torch.zeros_like(step_direction)
+                acceptance_step = 0
+            self.theta_actor.copy_(theta_old + step_frac * step_direction)
+        # actor.grad keeps d(loss_pi)/d(theta) = -grads: part of the critic fit's joint clip_grad_norm_
+        self.stale_sq.copy_(grads.dot(grads).reshape(1))
+        # Loss/Loss_actor: natural_pg logs the surrogate before the step (natural_pg.py:390), trpo the one of the
+        # last line-search candidate (trpo.py:438)
+        return {"alpha": float(alpha), "final_step_norm": float(torch.norm(step_direction)), "xHx": float(xHx),
+                "gradient_norm": float(torch.norm(grads)), "H_inv_g": float(x.norm()),
+                "acceptance_step": acceptance_step, "loss_actor": (loss_pi if line_search else loss_before),
+                "kl": final_kl, "g": grads, "x": x}
 
     def critic_fit(self, perm_fn=None):
         """cpo.py:534-571: learning_iters passes of minibatches (batch_size rows) over both critics."""

@@ -179,7 +179,7 @@ def test_pid_lagrangian_matches_reference_golden(golden_dir):
 
 def test_sibling_scripts_share_the_reference_surface():
     import importlib
-    for algo in ("ppo_lag", "ppo", "pg", "cppo_pid", "cpo"):
+    for algo in ("ppo_lag", "ppo", "pg", "cppo_pid", "cpo", "natural_pg", "trpo", "rcpo", "trpo_lag"):
         m = importlib.import_module(f"safepo.single_agent.{algo}")
         assert callable(m.main) and m.default_cfg["hidden_sizes"] == [64, 64]
     from safepo.single_agent import ppo_lag, cpo

@@ -856,3 +856,55 @@ def test_use_eval_branch(dev, tmp_path):
     ppo_lag.main(args, {})
     rows = list(csv.DictReader(open(tmp_path / "exp" / "task" / "run" / "progress.csv")))
     assert len(rows) == 2 and float(rows[0]["Metrics/EvalEpLen"]) == 8.0 and "Time/Eval" in rows[0]
+
+
+@pytest.mark.parametrize("algo,line_search", [("natural_pg", False), ("trpo", True)])
+def test_trust_region_family_vs_reference_main_trace(dev, golden_dir, algo, line_search):
+    """f4: natural_pg / trpo on the CPO kernels against traces of the reference mains (rcpo / trpo_lag only add the
+    Lagrangian advantage mix, covered by the PPO-Lag tests)."""
+    z = np.load(os.path.join(golden_dir, f"{algo}_trace.npz"))
+    N, T, epochs = int(z["meta_num_envs"]), int(z["meta_T"]), int(z["meta_epochs"])
+    pol, eng = _cpo_engine(z, "init_sd_", dev, N, T, {"learning_iters": int(z["meta_cfg_learning_iters"]),
+                                                       "batch_size": int(z["e0_batch_size"]),
+                                                       "target_kl": float(z["meta_cfg_target_kl"])})
+    for e in range(epochs):
+        _load_epoch_into_engine(z, e, eng, dev)
+        eng.buffer.compute_gae(None)
+        out = eng.trust_region_update(eng.buffer.data["adv_r"].reshape(-1), line_search)
+        assert out["xHx"] == pytest.approx(float(z[f"e{e}_Misc_xHx"]), rel=5e-3)
+        assert out["H_inv_g"] == pytest.approx(float(z[f"e{e}_Misc_H_inv_g"]), rel=5e-3)
+        assert out["gradient_norm"] == pytest.approx(float(z[f"e{e}_Misc_gradient_norm"]), rel=1e-4)
+        assert out["final_step_norm"] == pytest.approx(float(z[f"e{e}_Misc_FinalStepNorm"]), rel=5e-3)
+        assert out["alpha"] == pytest.approx(float(z[f"e{e}_Misc_Alpha"]), rel=5e-3)
+        assert out["kl"] == pytest.approx(float(z[f"e{e}_Train_KL"]), rel=2e-2)
+        assert out["loss_actor"] == pytest.approx(float(z[f"e{e}_Loss_Loss_actor"]), rel=2e-3, abs=1e-6)
+        if line_search:
+            assert out["acceptance_step"] == int(z[f"e{e}_Misc_AcceptanceStep"])
+        act_ref = np.concatenate([z[f"e{e}_actor_after_{k}"].reshape(-1) for k in pol.actor.state_dict()])
+        np.testing.assert_allclose(eng.theta_actor.cpu().numpy(), act_ref, rtol=5e-3, atol=2e-5)
+        iters = int(z["meta_cfg_learning_iters"])
+        perms = [torch.from_numpy(z[f"e{e}_perm{i}"].astype(np.int32)).to(dev) for i in range(iters)]
+        fit = eng.critic_fit(perm_fn=lambda it: perms[it])
+        eng.buffer.reset()
+        np.testing.assert_allclose(torch.cat(fit["losses"], 0).cpu().numpy(), z[f"e{e}_mb_losses"][:, :2], rtol=2e-3, atol=1e-5)
+    ref_final = np.concatenate([z[f"final_sd_{k}"].reshape(-1) for k in pol.state_dict()])
+    _assert_params_close(pol.theta.cpu().numpy(), ref_final, 1e-3, 12, rtol=5e-3, atol=5e-5, what="final theta")
+
+
+@pytest.mark.parametrize("algo", ["natural_pg", "trpo", "rcpo", "trpo_lag"])
+def test_trust_region_entrypoints_synthetic(dev, tmp_path, algo):
+    import argparse
+    import csv
+    import importlib
+    mod = importlib.import_module(f"safepo.single_agent.{algo}")
+    args = argparse.Namespace(seed=0, use_eval=False, task="SynthSafe-v0", num_envs=8, experiment="t",
+                              log_dir=str(tmp_path / "exp" / "task" / "run"), device="cuda", device_id=0,
+                              write_terminal=True, headless=False, total_steps=2 * 8 * 32, steps_per_epoch=8 * 32,
+                              randomize=False, cost_limit=0.5, lagrangian_multiplier_init=0.001,
+                              lagrangian_multiplier_lr=0.035, cfg_override={"learning_iters": 2},
+                              env_kwargs={"trunc_len": 8, "p_cost": 0.5})
+    mod.main(args, {})
+    rows = list(csv.DictReader(open(tmp_path / "exp" / "task" / "run" / "progress.csv")))
+    assert len(rows) == 2 and float(rows[0]["Misc/xHx"]) >= 0
+    assert ("Train/LagragianMultiplier" in rows[0]) == (algo in ("rcpo", "trpo_lag"))
+    assert ("Misc/AcceptanceStep" in rows[0]) == (algo in ("trpo", "trpo_lag"))
