@@ -307,8 +307,8 @@ def test_minibatch_grad_and_step_vs_oracle(dev, M, D, A, batch):
     g_ref = rec["grad_preclip"].numpy()
     g_got = eng.flat_grad.cpu().numpy()
     scale = np.abs(g_ref).max()
-    np.testing.assert_allclose(g_got, g_ref, rtol=1e-4, atol=1e-5 * scale)
-    np.testing.assert_allclose(eng.losses3.cpu().numpy(), np.asarray(l3), rtol=1e-5, atol=1e-6)
+    assert np.abs(g_got - g_ref).max() <= 1e-5 * scale                 # north_star: grads within 1e-5 (of the scale)
+    np.testing.assert_allclose(eng.losses3.cpu().numpy(), np.asarray(l3), rtol=1e-5, atol=0)
     # --- persistent kernel: one full pass, compare with the oracle restarted from the same weights
     ref.load_state_dict(ref0)
     upd = R.PPOLagUpdater(ref, epochs=1, max_grad_norm=cfg["max_grad_norm"])
@@ -468,7 +468,7 @@ def test_cpo_surrogate_gradients_vs_oracle(dev):
         g_ref = R.actor_flat_grads(ref.actor).numpy()
         g, mean = eng.surrogate_grad(b.data[key], sign)
         np.testing.assert_allclose(g.cpu().numpy(), g_ref, rtol=1e-4, atol=1e-5 * np.abs(g_ref).max())
-        assert sign * mean == pytest.approx(float(loss), rel=1e-5)
+        assert sign * mean == pytest.approx(float(loss.detach()), rel=1e-5)
     # FVP against the oracle's double backward, random direction
     v = torch.randn(eng.Pa)
     hv_ref = R.cpo_fvp(v, ref, obs).numpy()
