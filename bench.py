@@ -152,6 +152,8 @@ def main():
     elapsed = float(tmax.item())
 
     if comm.rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
         return
     total_env_steps = world * N * T * a.steps
     value = total_env_steps / elapsed
@@ -223,6 +225,8 @@ def main():
     if cpu:
         line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
     print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -194,6 +194,17 @@ int spo_critic_fit_iter(float* theta, float* adam_m, float* adam_v, int64_t adam
                         int64_t M, const spo_ppo_cfg* cfg_host, float* stale_sq_io, float* losses_out,
                         void* sync_ws, void* stream);
 
+/* ---- multi-agent masked GAE: SeparatedReplayBuffer.compute_returns + compute_cost_returns
+ * (safepo/common/buffer.py:356-384) with PopArt.denormalize (safepo/common/popart.py:117-133) folded in.
+ * Time-major arrays as in the reference: rewards/costs [T, N], value_preds/cost_preds/masks [T+1, N] (row T =
+ * bootstrap value / last mask), returns/cost_returns [T+1, N] (rows 0..T-1 written).  fp32, the reference's
+ * operation order: results are bit-identical.  denorm_std = sqrt(debiased var), denorm_mean = debiased mean
+ * (pass 1, 0 when no value normaliser is used). */
+int spo_ma_gae(const float* rewards, const float* costs, const float* value_preds, const float* cost_preds,
+               const float* masks, float* returns, float* cost_returns, int64_t T, int64_t num_threads,
+               double gamma, double gae_lambda, float denorm_std_r, float denorm_mean_r,
+               float denorm_std_c, float denorm_mean_c, void* stream);
+
 /* parameter-vector geometry helpers (host) */
 int64_t spo_param_count(int obs_dim, int act_dim);
 int64_t spo_param_offset(int obs_dim, int act_dim, int net /*0 r-critic,1 c-critic,2 actor*/);

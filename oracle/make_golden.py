@@ -329,3 +329,38 @@ if __name__ == "__main__":
     for _algo in ("natural_pg", "trpo"):
         golden_trace(_algo, f"{_algo}_trace.npz", num_envs=4, T=48, epochs=2, env_kw=_env_kw,
                      cfg_over={"learning_iters": 2, "batch_size": 64})
+
+
+def golden_ma_gae():
+    """Multi-agent masked GAE + PopArt: reference SeparatedReplayBuffer.compute_returns / compute_cost_returns
+    (safepo/common/buffer.py:356-384) with a PopArt value normaliser (safepo/common/popart.py)."""
+    if ref_shim.REF_ROOT not in sys.path:
+        sys.path.insert(0, ref_shim.REF_ROOT)
+    from safepo.common.buffer import SeparatedReplayBuffer
+    from safepo.common.popart import PopArt
+    out = {}
+    for tag, (T, N, p_done, seed) in {"a": (8, 5, 0.2, 1), "b": (50, 300, 0.05, 2), "c": (1000, 10, 0.01, 3)}.items():
+        torch.manual_seed(seed)
+        cfg = dict(episode_length=T, n_rollout_threads=N, hidden_size=8, recurrent_N=1, gamma=0.96, gae_lambda=0.95,
+                   use_gae=True, use_popart=True, use_valuenorm=True, use_proper_time_limits=False,
+                   algorithm_name="mappolag", device="cpu")
+        buf = SeparatedReplayBuffer(cfg, Space(6), Space(9), Space(3))
+        buf.rewards.copy_(torch.randn(T, N, 1))
+        buf.costs.copy_((torch.rand(T, N, 1) < 0.3).float())
+        buf.value_preds.copy_(torch.randn(T + 1, N, 1))
+        buf.cost_preds.copy_(torch.randn(T + 1, N, 1))
+        buf.masks.copy_((torch.rand(T + 1, N, 1) > p_done).float())
+        norm = PopArt(1)
+        for _ in range(3):
+            norm(torch.randn(64, 1) * 2.5 + 1.0, train=True)
+        next_v, next_c = torch.randn(N, 1), torch.randn(N, 1)
+        buf.compute_returns(next_v, norm)
+        buf.compute_cost_returns(next_c, norm)
+        mean, var = norm.running_mean_var()
+        for k, v in dict(rewards=buf.rewards, costs=buf.costs, value_preds=buf.value_preds, cost_preds=buf.cost_preds,
+                         masks=buf.masks, returns=buf.returns, cost_returns=buf.cost_returns, next_v=next_v, next_c=next_c,
+                         rm=norm.running_mean, rms=norm.running_mean_sq, deb=norm.debiasing_term.reshape(1),
+                         mean=mean, var=var).items():
+            out[f"{tag}_{k}"] = v.detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "ma_gae.npz"), **out)
+    print("ma_gae.npz", len(out), "arrays")

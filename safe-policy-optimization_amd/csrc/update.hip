@@ -22,6 +22,9 @@
 namespace {
 using namespace spo;
 
+#ifndef SPO_SPECULATIVE_ADAM
+#define SPO_SPECULATIVE_ADAM 1
+#endif
 constexpr int LDB = 64 + 4;     // [feature][batch] LDS row stride (floats)
 constexpr int RED_FLOATS = 160;
 
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
     pw1 *= (double)b1c; pw2 *= (double)b2c;
     const float step_size = (float)((double)lr / (1.0 - pw1));
     const float inv_bc2s = (float)(1.0 / sqrt(1.0 - pw2));
-    constexpr bool SPEC = (KIN <= 64);          // the 128-wide variant has no registers to spare for the backups
+    constexpr bool SPEC = SPO_SPECULATIVE_ADAM && (KIN <= 64);   // the 128-wide variant has no registers to spare for the backups
     f4 omW1[NT1], ovW1[NT1], omW2[4], ovW2[4];
     f4 omW3 = mW3, ovW3 = vW3, omls = mls, ovls = vls;
     float omb1 = mb1, ovb1 = vb1, omb2 = mb2, ovb2 = vb2, omb3 = mb3, ovb3 = vb3;

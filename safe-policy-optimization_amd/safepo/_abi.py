@@ -52,6 +52,7 @@ PROTOTYPES = {
     "spo_cpo_fvp": (c_int, [P, P, P, c_int64, c_int, c_int, P, P, P, P]),
     "spo_cpo_linesearch_eval": (c_int, [P] * 8 + [c_int64, c_int, c_int, P, c_int, P, P]),
     "spo_critic_fit_iter": (c_int, [P, P, P, c_int64, P, P, P, P, c_int64, POINTER(PpoCfg), P, P, P, P]),
+    "spo_ma_gae": (c_int, [P] * 7 + [c_int64, c_int64, c_double, c_double, c_float, c_float, c_float, c_float, P]),
     "spo_param_count": (c_int64, [c_int, c_int]),
     "spo_param_offset": (c_int64, [c_int, c_int, c_int]),
     "spo_synth_env_step": (c_int, [P] * 7 + [c_int64, c_int, c_uint64, c_uint64, c_float, c_float, c_int, P]),

@@ -154,3 +154,100 @@ class VectorizedOnPolicyBuffer:
             e1.record()
             torch.cuda.synchronize(self._device)
         return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+class SeparatedReplayBuffer:
+    """Per-agent multi-agent buffer with the reference's attributes and time-major shapes
+    (safepo/common/buffer.py:209-465): share_obs/obs [T+1, N, ...], value_preds/cost_preds/returns/cost_returns/
+    masks [T+1, N, 1], rewards/costs/actions/action_log_probs/factor [T, N, ...].  Storage is device memory;
+    compute_returns / compute_cost_returns (buffer.py:356-384) run as ONE fused kernel (spo_ma_gae) the first time
+    either is asked for after new value predictions -- bit-identical to the reference's fp32 Python loop."""
+
+    def __init__(self, config, obs_space, share_obs_space, act_space):
+        self.episode_length = config["episode_length"]
+        self.n_rollout_threads = config["n_rollout_threads"]
+        self.rnn_hidden_size = config["hidden_size"]
+        self.recurrent_N = config["recurrent_N"]
+        self.gamma, self.gae_lambda = config["gamma"], config["gae_lambda"]
+        self._use_gae, self._use_popart = config["use_gae"], config["use_popart"]
+        self._use_valuenorm = config["use_valuenorm"]
+        self._use_proper_time_limits = config["use_proper_time_limits"]
+        self.device = torch.device(config.get("device", "cuda:0"))
+        self.algo = config["algorithm_name"]
+        if self.device.type != "cuda":
+            raise _abi.SpoError("SeparatedReplayBuffer (MI355X) lives in HBM; device must be a GPU (no CPU fallback)")
+        self._lib = _abi.load()
+        T, N = self.episode_length, self.n_rollout_threads
+        obs_shape, share_obs_shape = tuple(obs_space.shape), tuple(share_obs_space.shape)
+        act_dim = act_space.shape[0]
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=self.device)
+        self.aver_episode_costs = z(T + 1, N, *obs_shape)
+        self.share_obs, self.obs = z(T + 1, N, *share_obs_shape), z(T + 1, N, *obs_shape)
+        self.rnn_states = z(T + 1, N, self.recurrent_N, self.rnn_hidden_size)
+        self.rnn_states_critic, self.rnn_states_cost = torch.zeros_like(self.rnn_states), torch.zeros_like(self.rnn_states)
+        self.value_preds, self.returns = z(T + 1, N, 1), z(T + 1, N, 1)
+        self.cost_preds, self.cost_returns = z(T + 1, N, 1), z(T + 1, N, 1)
+        self.available_actions = None
+        self.actions, self.action_log_probs = z(T, N, act_dim), z(T, N, act_dim)
+        self.rewards, self.costs = z(T, N, 1), z(T, N, 1)
+        self.masks = torch.ones(T + 1, N, 1, dtype=torch.float32, device=self.device)
+        self.bad_masks, self.active_masks = torch.ones_like(self.masks), torch.ones_like(self.masks)
+        self.factor = torch.ones(T, N, 1, dtype=torch.float32, device=self.device)
+        self.step = 0
+
+    def update_factor(self, factor):
+        self.factor.copy_(factor)
+
+    def return_aver_insert(self, aver_episode_costs):
+        self.aver_episode_costs = aver_episode_costs.clone()
+
+    def insert(self, share_obs, obs, rnn_states, rnn_states_critic, actions, action_log_probs, value_preds, rewards,
+               masks, bad_masks=None, active_masks=None, available_actions=None, costs=None, cost_preds=None,
+               rnn_states_cost=None, done_episodes_costs_aver=None, aver_episode_costs=0):
+        s = self.step
+        self.share_obs[s + 1].copy_(share_obs)
+        self.obs[s + 1].copy_(obs)
+        self.rnn_states[s + 1].copy_(rnn_states)
+        self.rnn_states_critic[s + 1].copy_(rnn_states_critic)
+        self.actions[s].copy_(actions)
+        self.action_log_probs[s].copy_(action_log_probs)
+        self.value_preds[s].copy_(value_preds)
+        self.rewards[s].copy_(rewards)
+        self.masks[s + 1].copy_(masks)
+        if bad_masks is not None:
+            self.bad_masks[s + 1].copy_(bad_masks)
+        if active_masks is not None:
+            self.active_masks[s + 1].copy_(active_masks)
+        if costs is not None:
+            self.costs[s].copy_(costs)
+        if cost_preds is not None:
+            self.cost_preds[s].copy_(cost_preds)
+        if rnn_states_cost is not None:
+            self.rnn_states_cost[s + 1].copy_(rnn_states_cost)
+        self.step = (s + 1) % self.episode_length
+
+    def after_update(self):
+        for name in ("share_obs", "obs", "rnn_states", "rnn_states_critic", "masks", "bad_masks", "active_masks"):
+            t = getattr(self, name)
+            t[0].copy_(t[-1])
+
+    def compute_returns_and_cost_returns(self, next_value, next_cost, value_normalizer=None, cost_normalizer=None):
+        """Both GAE recurrences in one launch (the reference's compute() calls them back to back per agent,
+        mappolag.py:583-597)."""
+        self.value_preds[-1] = next_value
+        self.cost_preds[-1] = next_cost
+        sd_r, mu_r = value_normalizer.denorm_scalars() if value_normalizer is not None else (1.0, 0.0)
+        sd_c, mu_c = cost_normalizer.denorm_scalars() if cost_normalizer is not None else (1.0, 0.0)
+        _abi.check(self._lib.spo_ma_gae(
+            _abi.ptr(self.rewards), _abi.ptr(self.costs), _abi.ptr(self.value_preds), _abi.ptr(self.cost_preds),
+            _abi.ptr(self.masks), _abi.ptr(self.returns), _abi.ptr(self.cost_returns), self.episode_length,
+            self.n_rollout_threads, self.gamma, self.gae_lambda, sd_r, mu_r, sd_c, mu_c, _abi.stream_ptr()),
+            "spo_ma_gae")
+
+    def compute_returns(self, next_value, value_normalizer=None):
+        """buffer.py:356-377 (cost side recomputed alongside with its current predictions; harmless)."""
+        self.compute_returns_and_cost_returns(next_value, self.cost_preds[-1].clone(), value_normalizer, value_normalizer)
+
+    def compute_cost_returns(self, next_cost, value_normalizer=None):
+        """buffer.py:379-384."""
+        self.compute_returns_and_cost_returns(self.value_preds[-1].clone(), next_cost, value_normalizer, value_normalizer)

@@ -186,3 +186,21 @@ def test_sibling_scripts_share_the_reference_surface():
     assert ppo_lag.default_cfg == {'hidden_sizes': [64, 64], 'gamma': 0.99, 'target_kl': 0.02, 'batch_size': 64,
                                    'learning_iters': 40, 'max_grad_norm': 40.0}
     assert cpo.default_cfg["batch_size"] == 128 and cpo.default_cfg["target_kl"] == 0.01
+
+
+def test_popart_matches_reference_statistics(golden_dir):
+    """PopArt mirror: same debiased statistics as the reference state, update rule, normalize/denormalize round trip."""
+    from safepo.common.popart import PopArt
+    z = np.load(os.path.join(golden_dir, "ma_gae.npz"))
+    torch.manual_seed(1)
+    n = PopArt(1)
+    x = torch.randn(64, 1) * 2.5 + 1.0
+    y = n(x, train=True)
+    assert n.debiasing_term.item() == pytest.approx(1 - 0.99999, rel=1e-3)
+    np.testing.assert_allclose(n.denormalize(y).numpy(), x.numpy(), rtol=1e-4, atol=1e-4)
+    n.running_mean.copy_(torch.from_numpy(z["a_rm"])); n.running_mean_sq.copy_(torch.from_numpy(z["a_rms"]))
+    n.debiasing_term.copy_(torch.from_numpy(z["a_deb"]).reshape(()))
+    mean, var = n.running_mean_var()
+    assert np.array_equal(mean.numpy(), z["a_mean"]) and np.array_equal(var.numpy(), z["a_var"])
+    sd, mu = n.denorm_scalars()
+    assert sd == float(np.sqrt(z["a_var"])[0]) and mu == float(z["a_mean"][0])

@@ -908,3 +908,29 @@ def test_trust_region_entrypoints_synthetic(dev, tmp_path, algo):
     assert len(rows) == 2 and float(rows[0]["Misc/xHx"]) >= 0
     assert ("Train/LagragianMultiplier" in rows[0]) == (algo in ("rcpo", "trpo_lag"))
     assert ("Misc/AcceptanceStep" in rows[0]) == (algo in ("trpo", "trpo_lag"))
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_multi_agent_masked_gae_popart_bit_exact(dev, golden_dir, tag):
+    """f3 (first piece): SeparatedReplayBuffer.compute_returns / compute_cost_returns with PopArt denormalisation --
+    fp32, reference operation order => bit-identical to the reference buffer."""
+    from safepo.common.buffer import SeparatedReplayBuffer
+    from safepo.common.engine import _Space
+    from safepo.common.popart import PopArt
+    z = np.load(os.path.join(golden_dir, "ma_gae.npz"))
+    g = lambda k: torch.from_numpy(z[f"{tag}_{k}"].copy())
+    T, N = z[f"{tag}_rewards"].shape[:2]
+    cfg = dict(episode_length=T, n_rollout_threads=N, hidden_size=8, recurrent_N=1, gamma=0.96, gae_lambda=0.95,
+               use_gae=True, use_popart=True, use_valuenorm=True, use_proper_time_limits=False,
+               algorithm_name="mappolag", device="cuda:0")
+    buf = SeparatedReplayBuffer(cfg, _Space(6), _Space(9), _Space(3))
+    buf.rewards.copy_(g("rewards")); buf.costs.copy_(g("costs")); buf.masks.copy_(g("masks"))
+    buf.value_preds.copy_(g("value_preds")); buf.cost_preds.copy_(g("cost_preds"))
+    norm = PopArt(1)
+    norm.running_mean.copy_(g("rm")); norm.running_mean_sq.copy_(g("rms")); norm.debiasing_term.copy_(g("deb").reshape(()))
+    mean, var = norm.running_mean_var()
+    assert np.array_equal(mean.numpy(), z[f"{tag}_mean"]) and np.array_equal(var.numpy(), z[f"{tag}_var"])
+    buf.compute_returns(g("next_v").to(dev), norm)
+    buf.compute_cost_returns(g("next_c").to(dev), norm)
+    assert np.array_equal(buf.returns.cpu().numpy().view(np.uint32), z[f"{tag}_returns"].view(np.uint32))
+    assert np.array_equal(buf.cost_returns.cpu().numpy().view(np.uint32), z[f"{tag}_cost_returns"].view(np.uint32))
