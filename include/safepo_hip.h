@@ -194,6 +194,25 @@ int spo_critic_fit_iter(float* theta, float* adam_m, float* adam_v, int64_t adam
                         int64_t M, const spo_ppo_cfg* cfg_host, float* stale_sq_io, float* losses_out,
                         void* sync_ws, void* stream);
 
+/* ---- f2: FOCOPS (safepo/single_agent/focops.py:300-350) and CUP (safepo/single_agent/cup.py:300-400) on the
+ * persistent update kernel.  spo_update_iter_ex is spo_ppo_lag_update_iter with
+ *  - separate Adam step counts for the critics' and the actor's optimisers (CUP's second stage steps the actor alone),
+ *  - actor_only != 0: only the actor network is trained and clip_grad_norm_ spans the actor's parameters (cup.py:385),
+ *  - actor_loss = SPO_ACTOR_LOSS_CLIP: the PPO clipped surrogate (old_mean/old_std unused, may be NULL), or
+ *    SPO_ACTOR_LOSS_KL_PENALTY: loss = mean_i(ind_i*KL_i) - pg_coef*mean_i(ind_i)*mean_j(ratio_j*adv_j) with
+ *    KL_i = KL(N(mu_i,sigma) || N(old_mean_i, old_std)).sum(-1), ind_i = [KL_i <= kl_bound]
+ *    (focops.py:326-337: kl_bound = target_kl, pg_coef = 1/FOCOPS_LAM; cup.py:372-383: kl_bound = +inf,
+ *    pg_coef = -lagrangian_multiplier*(1-gamma*CUP_LAMBDA)/(1-gamma)).  old_mean float[M*act_dim], old_std
+ *    float[act_dim].  Needs cfg.batch <= 64.
+ * losses_out float[ceil(M/batch)*3]; with actor_only only column 2 is written. */
+#define SPO_ACTOR_LOSS_CLIP 0
+#define SPO_ACTOR_LOSS_KL_PENALTY 1
+int spo_update_iter_ex(float* theta, float* adam_m, float* adam_v, int64_t adam_step_critics_host,
+                       int64_t adam_step_actor_host, const float* obs, const float* act, const float* logp_old,
+                       const float* target_r, const float* target_c, const float* adv, const int32_t* perm, int64_t M,
+                       const spo_ppo_cfg* cfg_host, int actor_loss, const float* old_mean, const float* old_std,
+                       float kl_bound, float pg_coef, int actor_only, float* losses_out, void* sync_ws, void* stream);
+
 /* ---- multi-agent masked GAE: SeparatedReplayBuffer.compute_returns + compute_cost_returns
  * (safepo/common/buffer.py:356-384) with PopArt.denormalize (safepo/common/popart.py:117-133) folded in.
  * Time-major arrays as in the reference: rewards/costs [T, N], value_preds/cost_preds/masks [T+1, N] (row T =

@@ -192,16 +192,23 @@ def _instrument(P, rec: Recorder, env_kw: dict, algo: str):
     class DL:
         def __init__(self, dataset, batch_size, shuffle):
             self.inner = RealDL(dataset=dataset, batch_size=batch_size, shuffle=shuffle)
-            rec.put(f"e{state['epoch']}_batch_size", np.int64(batch_size))
-            self.passes = 0
+            e = state["epoch"]
+            rec.put(f"e{e}_batch_size", np.int64(batch_size))
+            n_loaders = state.setdefault("loaders", {})
+            if n_loaders.get(e, 0) > 0:                # CUP builds a second loader per epoch (cup.py:362)
+                for kk, v in state["policy"].state_dict().items():
+                    rec.put(f"e{e}_sd_stage{n_loaders[e]}_{kk}", v)
+            n_loaders[e] = n_loaders.get(e, 0) + 1
 
         def __iter__(self):
             idxs = []
             for batch in self.inner:
                 idxs.append(batch[-1])
                 yield batch[:-1]
-            rec.put(f"e{state['epoch']}_perm{self.passes}", torch.cat(idxs))
-            self.passes += 1
+            e = state["epoch"]
+            passes = state.setdefault("passes", {})    # numbered per epoch across all loaders
+            rec.put(f"e{e}_perm{passes.get(e, 0)}", torch.cat(idxs))
+            passes[e] = passes.get(e, 0) + 1
 
     P.ActorVCritic = policy_factory
     P.VectorizedOnPolicyBuffer = Buf
@@ -288,20 +295,6 @@ def golden_trace(algo: str, fname: str, num_envs: int, T: int, epochs: int, env_
     print(fname, len(rec.a), "arrays")
 
 
-if __name__ == "__main__":
-    os.makedirs(OUT, exist_ok=True)
-    torch.set_num_threads(1)
-    golden_gae()
-    golden_model()
-    env_kw = dict(obs_dim=60, act_dim=8, p_term=0.03, p_cost=0.3, trunc_len=20)
-    golden_trace("ppo_lag", "ppo_lag_trace.npz", num_envs=4, T=48, epochs=3, env_kw=env_kw,
-                 cfg_over={"learning_iters": 6, "target_kl": 0.004},
-                 args_over={"cost_limit": 1.0, "lagrangian_multiplier_init": 0.5})
-    golden_trace("cpo", "cpo_trace.npz", num_envs=4, T=48, epochs=2, env_kw=env_kw,
-                 cfg_over={"learning_iters": 2, "batch_size": 64}, fvp_calls=3,
-                 args_over={"cost_limit": 3.0})
-
-
 def golden_pid():
     """PIDLagrangian multipliers for a fixed episode-cost sequence (reference safepo/common/lagrange.py:108-200,
     loaded straight from its file: the module has no third-party imports)."""
@@ -321,14 +314,6 @@ def golden_pid():
         out[tag] = np.asarray(vals)
     np.savez_compressed(os.path.join(OUT, "pid.npz"), costs=costs, **out)
     print("pid.npz")
-
-
-if __name__ == "__main__":
-    golden_pid()
-    _env_kw = dict(obs_dim=60, act_dim=8, p_term=0.03, p_cost=0.3, trunc_len=20)
-    for _algo in ("natural_pg", "trpo"):
-        golden_trace(_algo, f"{_algo}_trace.npz", num_envs=4, T=48, epochs=2, env_kw=_env_kw,
-                     cfg_over={"learning_iters": 2, "batch_size": 64})
 
 
 def golden_ma_gae():
@@ -364,3 +349,30 @@ def golden_ma_gae():
             out[f"{tag}_{k}"] = v.detach().numpy().copy()
     np.savez_compressed(os.path.join(OUT, "ma_gae.npz"), **out)
     print("ma_gae.npz", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(1)
+    golden_gae()
+    golden_model()
+    golden_pid()
+    golden_ma_gae()
+    env_kw = dict(obs_dim=60, act_dim=8, p_term=0.03, p_cost=0.3, trunc_len=20)
+    golden_trace("ppo_lag", "ppo_lag_trace.npz", num_envs=4, T=48, epochs=3, env_kw=env_kw,
+                 cfg_over={"learning_iters": 6, "target_kl": 0.004},
+                 args_over={"cost_limit": 1.0, "lagrangian_multiplier_init": 0.5})
+    golden_trace("cpo", "cpo_trace.npz", num_envs=4, T=48, epochs=2, env_kw=env_kw,
+                 cfg_over={"learning_iters": 2, "batch_size": 64}, fvp_calls=3,
+                 args_over={"cost_limit": 3.0})
+    golden_trace("pcpo", "pcpo_trace.npz", num_envs=4, T=48, epochs=2, env_kw=env_kw,
+                 cfg_over={"learning_iters": 2, "batch_size": 64}, args_over={"cost_limit": 3.0})
+    golden_trace("focops", "focops_trace.npz", num_envs=4, T=48, epochs=3, env_kw=env_kw,
+                 cfg_over={"learning_iters": 8, "target_kl": 0.0006},
+                 args_over={"cost_limit": 1.0, "lagrangian_multiplier_init": 0.5})
+    golden_trace("cup", "cup_trace.npz", num_envs=4, T=48, epochs=3, env_kw=env_kw,
+                 cfg_over={"learning_iters": 6, "target_kl": 0.002},
+                 args_over={"cost_limit": 1.0, "lagrangian_multiplier_init": 0.5})
+    for _algo in ("natural_pg", "trpo"):
+        golden_trace(_algo, f"{_algo}_trace.npz", num_envs=4, T=48, epochs=2, env_kw=env_kw,
+                     cfg_over={"learning_iters": 2, "batch_size": 64})

@@ -292,12 +292,14 @@ def ppo_lag_update(policy, updater: PPOLagUpdater, data: dict, lam: float, perms
 # --------------------------------------------------------------------------
 # a-7  Lagrange multiplier
 # --------------------------------------------------------------------------
+
 class OracleLagrange:
     """safepo/common/lagrange.py:24-105: scalar Parameter, Adam(lr), loss -lambda*(Jc-limit),
     clamp >= 0; read-out = relu(lambda).item()."""
 
-    def __init__(self, cost_limit, lagrangian_multiplier_init, lagrangian_multiplier_lr):
+    def __init__(self, cost_limit, lagrangian_multiplier_init, lagrangian_multiplier_lr, lagrangian_upper_bound=None):
         self.cost_limit = cost_limit
+        self.upper = lagrangian_upper_bound
         self._lam = torch.nn.Parameter(torch.as_tensor(max(lagrangian_multiplier_init, 0.0)))
         self._opt = torch.optim.Adam([self._lam], lr=lagrangian_multiplier_lr)
 
@@ -310,7 +312,142 @@ class OracleLagrange:
         loss = -self._lam * (Jc - self.cost_limit)
         loss.backward()
         self._opt.step()
-        self._lam.data.clamp_(0.0, None)
+        self._lam.data.clamp_(0.0, self.upper)              # lagrange.py:103-105
+
+
+# ------------------------------------------------------------------ FOCOPS / CUP
+FOCOPS_LAM = 1.50          # focops.py:44
+CUP_LAMBDA = 0.95          # cup.py:44
+
+
+def focops_actor_loss(policy: OraclePolicy, obs_b, act_b, logp_b, adv_b, old_mean_b, old_std_b, target_kl: float):
+    """safepo/single_agent/focops.py:326-337, shapes as there: ratio and adv_b are [B], temp_kl is [B, 1], so the
+    product broadcasts to a [B, B] matrix before .mean()."""
+    old = torch.distributions.Normal(old_mean_b, old_std_b)
+    dist = policy.actor(obs_b)
+    logp = dist.log_prob(act_b).sum(dim=-1)
+    ratio = torch.exp(logp - logp_b)
+    temp_kl = torch.distributions.kl_divergence(dist, old).sum(-1, keepdim=True)
+    loss_pi = (temp_kl - (1 / FOCOPS_LAM) * ratio * adv_b) * (temp_kl.detach() <= target_kl).type(torch.float32)
+    return loss_pi.mean()
+
+
+def cup_second_stage_loss(policy: OraclePolicy, obs_b, act_b, logp_b, adv_c_b, old_mean_b, old_std_b,
+                          lagrangian_multiplier: float, gamma: float):
+    """safepo/single_agent/cup.py:372-383 (same [B] vs [B, 1] broadcast)."""
+    old = torch.distributions.Normal(old_mean_b, old_std_b)
+    dist = policy.actor(obs_b)
+    logp = dist.log_prob(act_b).sum(dim=-1)
+    ratio = torch.exp(logp - logp_b)
+    temp_kl = torch.distributions.kl_divergence(dist, old).sum(-1, keepdim=True)
+    coef = (1 - gamma * CUP_LAMBDA) / (1 - gamma)
+    return (lagrangian_multiplier * coef * ratio * adv_c_b + temp_kl).mean()
+
+
+class KLPenaltyUpdater(PPOLagUpdater):
+    """The optimisers of PPOLagUpdater driving the FOCOPS minibatch step (focops.py:312-347) and CUP's actor-only
+    second stage (cup.py:370-386)."""
+
+    def focops_step(self, obs_b, act_b, logp_b, tgt_r_b, tgt_c_b, adv_b, old_mean_b, old_std_b, target_kl, record=None):
+        self.opt_r.zero_grad()
+        self.opt_c.zero_grad()
+        self.opt_a.zero_grad()
+        pol = self.policy
+        loss_r = torch.nn.functional.mse_loss(pol.reward_critic(obs_b), tgt_r_b)
+        loss_c = torch.nn.functional.mse_loss(pol.cost_critic(obs_b), tgt_c_b)
+        if self.loss_kw.get("use_critic_norm", True):
+            for prm in pol.reward_critic.parameters():
+                loss_r = loss_r + prm.pow(2).sum() * 0.001
+            for prm in pol.cost_critic.parameters():
+                loss_c = loss_c + prm.pow(2).sum() * 0.001
+        loss_pi = focops_actor_loss(pol, obs_b, act_b, logp_b, adv_b, old_mean_b, old_std_b, target_kl)
+        total = loss_pi + 2 * loss_r + loss_c if self.loss_kw.get("use_value_coefficient", False) \
+            else loss_pi + loss_r + loss_c
+        total.backward()
+        if record is not None:
+            record["grad_preclip"] = flat_grads(pol).clone()
+        torch.nn.utils.clip_grad_norm_(pol.parameters(), self.max_grad_norm)
+        self.opt_r.step()
+        self.opt_c.step()
+        self.opt_a.step()
+        return loss_r.item(), loss_c.item(), loss_pi.item()
+
+    def cup_second_stage_step(self, obs_b, act_b, logp_b, adv_c_b, old_mean_b, old_std_b, lagrangian_multiplier,
+                              gamma, record=None):
+        self.opt_a.zero_grad()
+        loss = cup_second_stage_loss(self.policy, obs_b, act_b, logp_b, adv_c_b, old_mean_b, old_std_b,
+                                     lagrangian_multiplier, gamma)
+        loss.backward()
+        if record is not None:
+            record["grad_preclip"] = actor_flat_grads(self.policy.actor).clone()
+        torch.nn.utils.clip_grad_norm_(self.policy.actor.parameters(), self.max_grad_norm)
+        self.opt_a.step()
+        return loss.item()
+
+def _kl_stopped_passes(policy, data, perms, perm0, learning_iters, batch_size, target_kl, old_mean, old_std, step_fn):
+    M = data["obs"].shape[0]
+    losses, stop_iter, final_kl = [], 0, 1.0
+    for it in range(learning_iters):
+        perm = torch.as_tensor(perms[perm0 + it], dtype=torch.long)
+        for s in range(0, M, batch_size):
+            losses.append(step_fn(perm[s:s + batch_size]))
+        final_kl = actor_kl(policy, data["obs"], old_mean, old_std)
+        stop_iter += 1
+        if final_kl > target_kl:
+            break
+    return losses, stop_iter, final_kl
+
+
+def focops_update(policy, updater: KLPenaltyUpdater, data: dict, lam: float, perms, learning_iters: int = 40,
+                  batch_size: int = 64, target_kl: float = 0.02, trace=None):
+    """focops.py:279-367 with the shuffles supplied."""
+    with torch.no_grad():
+        old = policy.actor(data["obs"])
+        old_mean, old_std = old.mean.clone(), old.stddev.clone()
+    advantage = adv_mix(data["adv_r"], data["adv_c"], lam)            # focops.py:286-287
+
+    def step(idx):
+        rec = {} if trace is not None else None
+        l = updater.focops_step(data["obs"][idx], data["act"][idx], data["log_prob"][idx], data["target_value_r"][idx],
+                                data["target_value_c"][idx], advantage[idx], old_mean[idx], old_std[idx], target_kl,
+                                record=rec)
+        if trace is not None:
+            trace.append(rec)
+        return l
+    losses, stop_iter, kl = _kl_stopped_passes(policy, data, perms, 0, learning_iters, batch_size, target_kl,
+                                               old_mean, old_std, step)
+    updater.sched.step()
+    return {"losses": np.asarray(losses, np.float64), "stop_iter": stop_iter, "kl": kl}
+
+
+def cup_update(policy, updater: KLPenaltyUpdater, data: dict, lam: float, perms, gamma: float,
+               learning_iters: int = 40, batch_size: int = 64, target_kl: float = 0.02, trace=None):
+    """cup.py:279-405 with the shuffles supplied (first-stage passes first, then the second stage's)."""
+    with torch.no_grad():
+        old = policy.actor(data["obs"])
+        old_mean, old_std = old.mean.clone(), old.stddev.clone()
+
+    def step1(idx):
+        return updater.minibatch_step(data["obs"][idx], data["act"][idx], data["log_prob"][idx],
+                                      data["target_value_r"][idx], data["target_value_c"][idx], data["adv_r"][idx])
+    losses, stop_iter, kl1 = _kl_stopped_passes(policy, data, perms, 0, learning_iters, batch_size, target_kl,
+                                                old_mean, old_std, step1)
+    with torch.no_grad():
+        old = policy.actor(data["obs"])
+        old_mean, old_std = old.mean.clone(), old.stddev.clone()
+
+    def step2(idx):
+        rec = {} if trace is not None else None
+        l = updater.cup_second_stage_step(data["obs"][idx], data["act"][idx], data["log_prob"][idx],
+                                          data["adv_c"][idx], old_mean[idx], old_std[idx], lam, gamma, record=rec)
+        if trace is not None:
+            trace.append(rec)
+        return l
+    losses2, stop_iter2, kl2 = _kl_stopped_passes(policy, data, perms, stop_iter, learning_iters, batch_size, target_kl,
+                                                  old_mean, old_std, step2)
+    updater.sched.step()
+    return {"losses": np.asarray(losses, np.float64), "stop_iter": stop_iter, "second_stage_losses": losses2,
+            "second_stage_stop_iter": stop_iter2, "kl": kl2, "kl_first_stage": kl1}
 
 
 # --------------------------------------------------------------------------

@@ -57,6 +57,11 @@ struct UpdArgs {
   // split (data-parallel) form
   float* flat_grad; int64_t mean_count;
   unsigned long long* prof;      // optional [3][NPHASE] cycle accumulators (debug builds of the launch)
+  // KL-penalty actor loss (FOCOPS, CUP second stage): AMODE == 1 instantiations only
+  const float* old_mean;         // [M][A] mean of the distribution the KL is taken to
+  const float* old_std;          // [A]    its std (state independent)
+  float kl_bound, pg_coef;
+  double pow_b1_actor, pow_b2_actor;   // the actor's optimiser may be ahead of the critics' (CUP steps it alone)
 };
 constexpr int NPHASE = 10;
 
@@ -106,10 +111,17 @@ template <int NT1>
 struct ColData {
   f4 x[NT1];       // observation tiles (B operand of layer 1)
   f4 actv;         // actor: act[4q..4q+3]
+  f4 omv;          // actor, KL-penalty loss: old_mean[4q..4q+3]
   float t0, t1;    // critic: target ; actor: logp_old, adv
 };
 
-template <int KIN, bool PERSIST, bool PROF = false>
+// AMODE: actor loss.  0 = PPO clipped surrogate (ppo_lag.py:316-319; clip = 1e30 gives the plain policy gradient);
+//        1 = KL-penalty form shared by FOCOPS (focops.py:326-337) and CUP's second stage (cup.py:372-383):
+//            loss = mean_i(ind_i * KL_i) - pg_coef * mean_i(ind_i) * mean_j(ratio_j * adv_j),
+//            KL_i = KL(N(mu_i, sigma) || N(mu_old_i, sigma_old)).sum(-1),  ind_i = [KL_i <= kl_bound].
+//        (The reference subtracts a [B] tensor from a [B,1] tensor, so its loss is the mean of a BxB matrix: that is
+//        exactly the product of means above.  CUP has no indicator: kl_bound = +inf, pg_coef = -lambda * coef.)
+template <int KIN, bool PERSIST, bool PROF = false, int AMODE = 0>
 __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
   unsigned long long pacc[NPHASE] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = 0;
@@ -184,7 +196,7 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
   }
 
   const float b1c = a.cfg.beta1, b2c = a.cfg.beta2, eps = a.cfg.adam_eps;
-  double pw1 = a.pow_b1, pw2 = a.pow_b2;
+  double pw1 = is_actor ? a.pow_b1_actor : a.pow_b1, pw2 = is_actor ? a.pow_b2_actor : a.pow_b2;
   const float lr = is_actor ? a.cfg.lr_actor : a.cfg.lr_critic;
   const float l2 = (!is_actor && a.cfg.use_critic_norm) ? a.cfg.l2_coef : 0.f;
   const float vcoef = (net == 0 && a.cfg.use_value_coefficient) ? 2.f : 1.f;
@@ -216,6 +228,10 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
         const int ai = 4 * q + r;
         const float t = a.act[smp * A + (ai < A ? ai : 0)];       // unconditional load, select after
         cd.actv[r] = ai < A ? t : 0.f;
+        if (AMODE == 1) {
+          const float u = a.old_mean[smp * A + (ai < A ? ai : 0)];
+          cd.omv[r] = ai < A ? u : 0.f;
+        }
       }
     }
   };
@@ -233,6 +249,14 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
 
   f4 aW1[NT1], aW2[4], aW3, dls;
   float db1 = 0.f, db2 = 0.f, db3 = 0.f, lsum = 0.f;
+  float iso[4] = {1.f, 1.f, 1.f, 1.f};      // 1 / sigma_old for my 4 action rows (KL-penalty loss)
+  if (AMODE == 1 && is_actor) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ai = 4 * q + r;
+      iso[r] = ai < A ? 1.f / a.old_std[ai] : 1.f;
+    }
+  }
 
   for (int64_t c = 0; c < nchunks; ++c) {
     const int64_t s = s_cur;
@@ -262,7 +286,7 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
     }
 
     // std = exp(log_std) from the LDS mirror of log_std (a parameter: changes every step)
-    float ivar[4], lsd[4], amask[4];
+    float ivar[4], lsd[4], amask[4], vrat[4], lvrat[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ai = 4 * q + r;
@@ -270,6 +294,11 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
       const float lsv = on ? red[128 + ai] : 0.f;
       const float sdv = __expf(lsv);                        // std = exp(log_std)
       amask[r] = on ? 1.f : 0.f;
+      if (AMODE == 1) {
+        const float sr = sdv * iso[r];                      // kl_normal_normal: var_ratio = (p.scale / q.scale)^2
+        vrat[r] = sr * sr;
+        lvrat[r] = logf(vrat[r]);
+      }
       ivar[r] = __builtin_amdgcn_rcpf(sdv * sdv);
       lsd[r] = on ? lsv + LOG_SQRT_2PI : 0.f;               // log(scale) = log_std (to 1 ulp) + log(sqrt(2 pi))
     }
@@ -298,6 +327,34 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
       const float lm = (q == 0 && cv) ? 1.f : 0.f;
       lsum = fmaf(lm * diff, diff, lsum);
       dO[0] = lm * (2.f * diff * inv_n);
+    } else if (AMODE == 1) {
+      float lp = 0.f, klp = 0.f, dif[4], dm[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dif[r] = cur.actv[r] - o[r];
+        lp += -(dif[r] * dif[r]) * (0.5f * ivar[r]) - lsd[r];
+        dm[r] = (o[r] - cur.omv[r]) * iso[r];        // (loc_p - loc_q) / scale_q ; pad rows: 0
+        klp += amask[r] * (0.5f * (vrat[r] + dm[r] * dm[r] - 1.f - lvrat[r]));
+      }
+      lp = quad_row_sum(lp);
+      const float kl = quad_row_sum(klp);            // .sum(-1, keepdim=True)
+      const float ind = (kl <= a.kl_bound) ? 1.f : 0.f;
+      const float cnt = wave_sum_lane63((q == 0 && cv) ? ind : 0.f);
+      if (lane == 63) red[104 + wave] = cnt;
+      __syncthreads();                               // actor workgroup only (block-uniform branch)
+      const float frac = ((red[104] + red[105]) + (red[106] + red[107])) * inv_n;
+      const float adv = cur.t1;
+      const float ratio = __expf(lp - cur.t0);
+      const float pg = a.pg_coef * frac;
+      const float dlp = cv ? -(pg * adv * ratio) * inv_n : 0.f;
+      const float wk = cv ? ind * inv_n : 0.f;
+      lsum += ((q == 0 && cv) ? 1.f : 0.f) * (pg * ratio * adv - ind * kl);     // loss = -mean(this)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float z = dif[r] * ivar[r];
+        dO[r] = fmaf(dlp, z, wk * dm[r] * iso[r]);
+        dls[r] += amask[r] * fmaf(dlp, dif[r] * z - 1.f, wk * (vrat[r] - 1.f));
+      }
     } else {
       float lp = 0.f, dif[4];
 #pragma unroll
@@ -768,10 +825,10 @@ int pick_kin(int D) { return D <= 16 ? 16 : D <= 32 ? 32 : D <= 64 ? 64 : 128; }
 
 unsigned long long* g_prof_buf = nullptr;
 
-template <bool PERSIST>
+template <bool PERSIST, int AMODE = 0>
 int launch_update(const UpdArgs& a, int blocks, hipStream_t st) {
   const int kin = pick_kin(a.cfg.obs_dim);
-  if (PERSIST && a.prof && kin == 64) {
+  if (PERSIST && AMODE == 0 && a.prof && kin == 64) {
     const size_t sh = UpdLds<64>::SIZE * sizeof(float);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_update_kernel<64, true, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
@@ -784,12 +841,12 @@ int launch_update(const UpdArgs& a, int blocks, hipStream_t st) {
     const size_t sh = UpdLds<K>::SIZE * sizeof(float);                                                  \
     static bool attr_done = false;                                                                      \
     if (!attr_done) {                                                                                   \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_update_kernel<K, PERSIST>), \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_update_kernel<K, PERSIST, false, AMODE>), \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);          \
       if (e != hipSuccess) return spo::hip_check(e, "hipFuncSetAttribute(update)");                     \
       attr_done = true;                                                                                 \
     }                                                                                                   \
-    hipLaunchKernelGGL((ppo_update_kernel<K, PERSIST>), dim3(PERSIST ? 8 * (blocks - 1) + 1 : blocks),   \
+    hipLaunchKernelGGL((ppo_update_kernel<K, PERSIST, false, AMODE>), dim3(PERSIST ? 8 * (blocks - 1) + 1 : blocks), \
                        dim3(256), sh, st, a);                                                          \
   }
   if (kin == 16) SPO_LAUNCH(16) else if (kin == 32) SPO_LAUNCH(32) else if (kin == 64) SPO_LAUNCH(64) else SPO_LAUNCH(128)
@@ -827,6 +884,7 @@ extern "C" int spo_ppo_lag_update_iter(float* theta, float* adam_m, float* adam_
   a.err = reinterpret_cast<int*>(reinterpret_cast<char*>(sync_ws) + 64);
   a.pow_b1 = pow((double)cfg_host->beta1, (double)adam_step_host);
   a.pow_b2 = pow((double)cfg_host->beta2, (double)adam_step_host);
+  a.pow_b1_actor = a.pow_b1; a.pow_b2_actor = a.pow_b2;
   a.first_net = 0; a.n_nets = 3; a.stale_sq = 0.f; a.stale_io = nullptr;
   a.flat_grad = nullptr; a.mean_count = 0; a.prof = g_prof_buf;
   if (int rc = launch_update<true>(a, 3, st)) return rc;
@@ -852,9 +910,50 @@ extern "C" int spo_critic_fit_iter(float* theta, float* adam_m, float* adam_v, i
   a.err = reinterpret_cast<int*>(reinterpret_cast<char*>(sync_ws) + 64);
   a.pow_b1 = pow((double)cfg_host->beta1, (double)adam_step_host);
   a.pow_b2 = pow((double)cfg_host->beta2, (double)adam_step_host);
+  a.pow_b1_actor = a.pow_b1; a.pow_b2_actor = a.pow_b2;
   a.first_net = 0; a.n_nets = 2; a.stale_sq = 0.f; a.stale_io = stale_sq_io;
   if (int rc = launch_update<true>(a, 2, st)) return rc;
   SPO_LAUNCH_CHECK("spo_critic_fit_iter");
+  return 0;
+}
+
+extern "C" int spo_update_iter_ex(float* theta, float* adam_m, float* adam_v, int64_t adam_step_critics_host,
+                                  int64_t adam_step_actor_host, const float* obs, const float* act,
+                                  const float* logp_old, const float* target_r, const float* target_c,
+                                  const float* adv, const int32_t* perm, int64_t M, const spo_ppo_cfg* cfg_host,
+                                  int actor_loss, const float* old_mean, const float* old_std, float kl_bound,
+                                  float pg_coef, int actor_only, float* losses_out, void* sync_ws, void* stream) {
+  if (int rc = check_cfg(cfg_host)) return rc;
+  SPO_REQUIRE(theta && adam_m && adam_v && obs && act && logp_old && adv && perm && losses_out && sync_ws,
+              "update_iter_ex: null pointer");
+  SPO_REQUIRE(actor_loss == SPO_ACTOR_LOSS_CLIP || actor_loss == SPO_ACTOR_LOSS_KL_PENALTY,
+              "update_iter_ex: unknown actor_loss %d", actor_loss);
+  SPO_REQUIRE(actor_loss == SPO_ACTOR_LOSS_CLIP || (old_mean && old_std), "update_iter_ex: old distribution is NULL");
+  SPO_REQUIRE(actor_only || (target_r && target_c), "update_iter_ex: critic targets are NULL");
+  SPO_REQUIRE(M > 0 && adam_step_critics_host >= 0 && adam_step_actor_host >= 0, "update_iter_ex: bad sizes");
+  // the indicator fraction couples every sample of a minibatch: one 64-column pass must hold the whole minibatch
+  SPO_REQUIRE(actor_loss == SPO_ACTOR_LOSS_CLIP || cfg_host->batch <= 64,
+              "update_iter_ex: KL-penalty loss with batch_size %d > 64 is not supported", cfg_host->batch);
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = spo::hip_check(hipMemsetAsync(sync_ws, 0, 72, st), "hipMemsetAsync(sync_ws)")) return rc;
+  UpdArgs a{};
+  a.theta = theta; a.adam_m = adam_m; a.adam_v = adam_v;
+  a.obs = obs; a.act = act; a.logp_old = logp_old; a.tgt_r = target_r; a.tgt_c = target_c; a.adv = adv;
+  a.perm = perm; a.M = M; a.cfg = *cfg_host; a.losses = losses_out;
+  a.slots = reinterpret_cast<unsigned long long*>(sync_ws);
+  a.err = reinterpret_cast<int*>(reinterpret_cast<char*>(sync_ws) + 64);
+  a.pow_b1 = pow((double)cfg_host->beta1, (double)adam_step_critics_host);
+  a.pow_b2 = pow((double)cfg_host->beta2, (double)adam_step_critics_host);
+  a.pow_b1_actor = pow((double)cfg_host->beta1, (double)adam_step_actor_host);
+  a.pow_b2_actor = pow((double)cfg_host->beta2, (double)adam_step_actor_host);
+  a.first_net = actor_only ? 2 : 0; a.n_nets = actor_only ? 1 : 3; a.stale_sq = 0.f; a.stale_io = nullptr;
+  a.old_mean = old_mean; a.old_std = old_std; a.kl_bound = kl_bound; a.pg_coef = pg_coef;
+  if (actor_loss == SPO_ACTOR_LOSS_KL_PENALTY) {
+    if (int rc = launch_update<true, 1>(a, a.n_nets, st)) return rc;
+  } else {
+    if (int rc = launch_update<true, 0>(a, a.n_nets, st)) return rc;
+  }
+  SPO_LAUNCH_CHECK("spo_update_iter_ex");
   return 0;
 }
 

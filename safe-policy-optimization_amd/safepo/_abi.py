@@ -27,6 +27,8 @@ class PpoCfg(Structure):
 
 P = c_void_p
 # name -> (restype, argtypes); must list every symbol declared in include/safepo_hip.h
+ACTOR_LOSS_CLIP, ACTOR_LOSS_KL_PENALTY = 0, 1      # include/safepo_hip.h SPO_ACTOR_LOSS_*
+
 PROTOTYPES = {
     "spo_abi_version": (c_int, []),
     "spo_last_error": (c_char_p, []),
@@ -52,6 +54,8 @@ PROTOTYPES = {
     "spo_cpo_fvp": (c_int, [P, P, P, c_int64, c_int, c_int, P, P, P, P]),
     "spo_cpo_linesearch_eval": (c_int, [P] * 8 + [c_int64, c_int, c_int, P, c_int, P, P]),
     "spo_critic_fit_iter": (c_int, [P, P, P, c_int64, P, P, P, P, c_int64, POINTER(PpoCfg), P, P, P, P]),
+    "spo_update_iter_ex": (c_int, [P, P, P, c_int64, c_int64, P, P, P, P, P, P, P, c_int64, POINTER(PpoCfg), c_int, P, P,
+                                   c_float, c_float, c_int, P, P, P]),
     "spo_ma_gae": (c_int, [P] * 7 + [c_int64, c_int64, c_double, c_double, c_float, c_float, c_float, c_float, P]),
     "spo_param_count": (c_int64, [c_int, c_int]),
     "spo_param_offset": (c_int64, [c_int, c_int, c_int]),

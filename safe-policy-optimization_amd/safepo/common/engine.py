@@ -60,6 +60,8 @@ class PPOLagEngine:
         P = policy.theta.numel()
         self.adam_m, self.adam_v = torch.zeros(P, **f32), torch.zeros(P, **f32)
         self.adam_step = 0
+        self.adam_step_actor_extra = 0        # actor-only optimiser steps (CUP's second stage)
+        self.std_old = torch.empty(A, **f32)
         self.lr_actor0, self.lr_critic = lr, (lr if critic_lr is None else critic_lr)
         self.lr_factor = 1.0
         self.M = N * T
@@ -154,6 +156,7 @@ class PPOLagEngine:
                                            self.M, self.D, self.A, _abi.stream_ptr()), "spo_actor_mean")
         off = self.policy.log_std_offset
         self.logstd_old.copy_(self.policy.theta[off:off + self.A])
+        torch.exp(self.logstd_old, out=self.std_old)      # Normal.stddev of the snapshot (focops.py:283, cup.py:358)
 
     def kl_to_old(self) -> float:
         """KL(old || new).sum(-1).mean() over the (global) batch (ppo_lag.py:338-345)."""
@@ -214,6 +217,84 @@ class PPOLagEngine:
             self.comm.all_reduce_sum_(losses)
             losses *= 1.0 / self.comm.world_size
         return losses
+
+    def learning_iter_ex(self, perm: torch.Tensor, adv: torch.Tensor, actor_loss: int = 0,
+                         kl_bound: float = float("inf"), pg_coef: float = 0.0, actor_only: bool = False) -> torch.Tensor:
+        """One pass over the data on the persistent kernel with the FOCOPS / CUP options of spo_update_iter_ex
+        (include/safepo_hip.h): KL-penalty actor loss against the last snapshot_old_distribution(), actor-only
+        optimisation, separate optimiser step counts.  Single GPU only."""
+        if self.comm.world_size != 1:
+            raise NotImplementedError("focops / cup run on one GPU in this build (no data-parallel form of the "
+                                      "KL-penalty minibatch step)")
+        cfg = self._cfg_struct()
+        perm = _abi.require_gpu_tensor(perm, "perm", torch.int32)
+        adv = _abi.require_gpu_tensor(adv, "adv", torch.float32)
+        d = self.buffer.data
+        M = self.M
+        n_mb = (M + cfg.batch - 1) // cfg.batch
+        losses = torch.full((n_mb, 3), float("nan"), dtype=torch.float32, device=self.dev)
+        _abi.check(self.lib.spo_update_iter_ex(
+            _abi.ptr(self.policy.theta), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), self.adam_step,
+            self.adam_step + self.adam_step_actor_extra, _abi.ptr(d["obs"]), _abi.ptr(d["act"]),
+            _abi.ptr(d["log_prob"]), _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]), _abi.ptr(adv),
+            _abi.ptr(perm), M, cfg, int(actor_loss), _abi.ptr(self.mean_old), _abi.ptr(self.std_old),
+            float(kl_bound), float(pg_coef), int(actor_only), _abi.ptr(losses), _abi.ptr(self.sync_ws),
+            _abi.stream_ptr()), "spo_update_iter_ex")
+        if actor_only:
+            self.adam_step_actor_extra += n_mb
+        else:
+            self.adam_step += n_mb
+        return losses
+
+    def _kl_stopped_loop(self, perm_fn, it0: int, run_iter):
+        c = self.cfg
+        all_losses, stop_iter, kl = [], 0, 1.0
+        for it in range(c["learning_iters"]):
+            all_losses.append(run_iter(perm_fn(it0 + it)))
+            kl = self.kl_to_old()
+            stop_iter += 1
+            if kl > c["target_kl"]:
+                break
+        return all_losses, stop_iter, kl
+
+    def update_focops(self, lagrangian_multiplier: float, perm_fn=None, focops_lam: float = 1.5):
+        """FOCOPS epoch update (safepo/single_agent/focops.py:280-366): advantage (adv_r - nu*adv_c)/(nu+1), per-sample
+        KL to the pre-update policy as a penalty, masked where it exceeds target_kl."""
+        self.buffer.compute_gae(lagrangian_multiplier, self.comm)
+        self.snapshot_old_distribution()
+        if perm_fn is None:
+            perm_fn = lambda it: torch.randperm(self.M, device=self.dev).to(torch.int32)
+        adv = self.buffer.adv_mix
+        losses, stop_iter, kl = self._kl_stopped_loop(perm_fn, 0, lambda perm: self.learning_iter_ex(
+            perm, adv, _abi.ACTOR_LOSS_KL_PENALTY, self.cfg["target_kl"], 1.0 / focops_lam))
+        self.check_sync_error()
+        self.buffer.reset()
+        means = torch.cat(losses, 0).mean(0).tolist()
+        return {"stop_iter": stop_iter, "kl": kl, "loss_r": means[0], "loss_c": means[1], "loss_pi": means[2],
+                "losses": losses}
+
+    def update_cup(self, lagrangian_multiplier: float, perm_fn=None, cup_lambda: float = 0.95):
+        """CUP epoch update (safepo/single_agent/cup.py:280-400): a PPO stage on adv_r, then an actor-only stage
+        minimising  nu*coef*ratio*adv_c + KL(new || policy after stage one)."""
+        self.buffer.compute_gae(0.0, self.comm)            # lambda 0: adv_mix == adv_r exactly (cup.py:285)
+        self.snapshot_old_distribution()
+        if perm_fn is None:
+            perm_fn = lambda it: torch.randperm(self.M, device=self.dev).to(torch.int32)
+        adv_r = self.buffer.adv_mix
+        losses, stop_iter, kl = self._kl_stopped_loop(perm_fn, 0, lambda perm: self.learning_iter_ex(
+            perm, adv_r, _abi.ACTOR_LOSS_CLIP))
+        self.snapshot_old_distribution()                   # cup.py:355-358
+        gamma = self.cfg["gamma"]
+        coef = (1 - gamma * cup_lambda) / (1 - gamma)
+        adv_c = self.buffer.data["adv_c"]
+        losses2, stop_iter2, kl2 = self._kl_stopped_loop(perm_fn, stop_iter, lambda perm: self.learning_iter_ex(
+            perm, adv_c, _abi.ACTOR_LOSS_KL_PENALTY, float("inf"), -float(lagrangian_multiplier) * coef, True))
+        self.check_sync_error()
+        self.buffer.reset()
+        means = torch.cat(losses, 0).mean(0).tolist()
+        return {"stop_iter": stop_iter, "second_stage_stop_iter": stop_iter2, "kl": kl2, "kl_first_stage": kl,
+                "loss_r": means[0], "loss_c": means[1], "loss_pi": means[2], "losses": losses,
+                "second_stage_losses": losses2}
 
     def check_sync_error(self):
         if int(self.sync_ws[8].item()) & 0xFFFFFFFF:

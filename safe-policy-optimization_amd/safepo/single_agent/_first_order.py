@@ -31,7 +31,13 @@ def _to_dev(x, dev):
     return torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x, dtype=torch.float32, device=dev).contiguous()
 
 
-def run(args, cfg_env, default_cfg: dict, multiplier: str | None = "adam", clip: float | None = 0.2):
+FOCOPS_LAM, FOCOPS_NU = 1.50, 2.00     # focops.py:44-45
+CUP_LAMBDA, CUP_NU = 0.95, 0.20        # cup.py:44-45
+
+
+def run(args, cfg_env, default_cfg: dict, multiplier: str | None = "adam", clip: float | None = 0.2,
+        variant: str = "ppo"):
+    """variant: "ppo" (clipped surrogate family), "focops" (focops.py:279-367) or "cup" (cup.py:279-405)."""
     random.seed(args.seed)
     np.random.seed(args.seed)
     torch.manual_seed(args.seed)
@@ -68,8 +74,9 @@ def run(args, cfg_env, default_cfg: dict, multiplier: str | None = "adam", clip:
     comm.broadcast_(policy.theta, 0)            # identical replicas
     engine = PPOLagEngine(policy, n_local, local_steps_per_epoch, config, device, comm=comm, lr=3e-4)
     if multiplier == "adam":
+        upper = {"focops": FOCOPS_NU, "cup": CUP_NU}.get(variant)          # focops.py:136, cup.py:136
         lagrange = Lagrange(cost_limit=args.cost_limit, lagrangian_multiplier_init=args.lagrangian_multiplier_init,
-                            lagrangian_multiplier_lr=args.lagrangian_multiplier_lr)
+                            lagrangian_multiplier_lr=args.lagrangian_multiplier_lr, lagrangian_upper_bound=upper)
     elif multiplier == "pid":
         lagrange = PIDLagrangian(cost_limit=args.cost_limit, lagrangian_multiplier_init=args.lagrangian_multiplier_init)
     else:
@@ -144,7 +151,12 @@ def run(args, cfg_env, default_cfg: dict, multiplier: str | None = "adam", clip:
 
         # ---- policy update (ppo_lag.py:275-350)
         engine.lr_factor = 1.0 - epoch / epochs if epochs > 0 else 1.0      # LinearLR(1 -> 0, total_iters=epochs)
-        out = engine.update(lam)
+        if variant == "focops":
+            out = engine.update_focops(lam, focops_lam=FOCOPS_LAM)
+        elif variant == "cup":
+            out = engine.update_cup(lam, cup_lambda=CUP_LAMBDA)
+        else:
+            out = engine.update(lam)
         torch.cuda.synchronize(device)
         update_end_time = time.time()
         next_lr = 3e-4 * (1.0 - min(epoch + 1, epochs) / epochs)
@@ -162,6 +174,8 @@ def run(args, cfg_env, default_cfg: dict, multiplier: str | None = "adam", clip:
             logger.log_tabular("Train/Epoch", epoch + 1)
             logger.log_tabular("Train/TotalSteps", (epoch + 1) * args.steps_per_epoch)
             logger.log_tabular("Train/StopIter", out["stop_iter"])
+            if variant == "cup":
+                logger.log_tabular("Train/SeconStageStopIter", out["second_stage_stop_iter"])   # (sic) cup.py:419
             logger.log_tabular("Train/KL", out["kl"])
             if lagrange is not None:
                 logger.log_tabular("Train/LagragianMultiplier", lagrange.lagrangian_multiplier)

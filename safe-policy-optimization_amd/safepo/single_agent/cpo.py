@@ -187,42 +187,8 @@ class CPOEngine(PPOLagEngine):
             nu_star = torch.sqrt(2 * target_kl / (s + 1e-8))
             step_direction = -nu_star.to(self.dev) * p
 
-        # ---- line search (cpo.py:465-519)
-        step_frac = 1.0
-        expected_reward_improve = grads.dot(step_direction)
-        kl = 0.0
-        acceptance_step = 0
-        for step in range(CPO_SEARCHING_STEPS):
-            self.theta_actor.copy_(theta_old + step_frac * step_direction)
-            acceptance_step = step + 1
-            loss_reward, loss_cost, kl = self.linesearch_eval()
-            loss_reward_improve = loss_reward_before - loss_reward
-            loss_cost_diff = loss_cost - loss_cost_before
-            if logger:
-                logger.log(f"Expected Improvement: {expected_reward_improve} Actual: {loss_reward_improve}")
-            if not np.isfinite(kl):
-                if logger:
-                    logger.log("WARNING: KL not finite")
-                continue
-            if (loss_reward_improve < 0) if optim_case > 1 else False:
-                if logger:
-                    logger.log("INFO: did not improve improve <0")
-            elif loss_cost_diff > max(-ep_costs, 0):
-                if logger:
-                    logger.log(f"INFO: no improve {loss_cost_diff} > {max(-ep_costs, 0)}")
-            elif kl > target_kl:
-                if logger:
-                    logger.log(f"INFO: violated KL constraint {kl} at step {step + 1}.")
-            else:
-                if logger:
-                    logger.log(f"Accept step at i={step + 1}")
-                break
-            step_frac *= STEP_FRACTION
-        else:
-            if logger:
-                logger.log("INFO: no suitable step found...")
-            step_direction = torch.zeros_like(step_direction)
-            acceptance_step = 0
+        step_frac, step_direction, acceptance_step, kl = self._constrained_line_search(
+            theta_old, step_direction, grads, optim_case, ep_costs, loss_reward_before, loss_cost_before, logger)
         self.theta_actor.copy_(theta_old + step_frac * step_direction)
         # the actor's .grad keeps the cost gradient b: it takes part in the critic fit's joint clip (cpo.py:557)
         self.stale_sq.copy_(b_grads.dot(b_grads).reshape(1))
@@ -293,6 +259,82 @@ class CPOEngine(PPOLagEngine):
                 "acceptance_step": acceptance_step, "loss_actor": (loss_pi if line_search else loss_before),
                 "kl": final_kl, "g": grads, "x": x}
 
+    def _constrained_line_search(self, theta_old, step_direction, grads, optim_case, ep_costs, loss_reward_before,
+                                 loss_cost_before, logger=None):
+        """Backtracking search shared by CPO (cpo.py:465-519) and PCPO (pcpo.py:404-458)."""
+        target_kl = self.cfg["target_kl"]
+        step_frac = 1.0
+        expected_reward_improve = grads.dot(step_direction)
+        kl = 0.0
+        acceptance_step = 0
+        for step in range(CPO_SEARCHING_STEPS):
+            self.theta_actor.copy_(theta_old + step_frac * step_direction)
+            acceptance_step = step + 1
+            loss_reward, loss_cost, kl = self.linesearch_eval()
+            loss_reward_improve = loss_reward_before - loss_reward
+            loss_cost_diff = loss_cost - loss_cost_before
+            if logger:
+                logger.log(f"Expected Improvement: {expected_reward_improve} Actual: {loss_reward_improve}")
+            if not np.isfinite(kl):
+                if logger:
+                    logger.log("WARNING: KL not finite")
+                continue
+            if (loss_reward_improve < 0) if optim_case > 1 else False:
+                if logger:
+                    logger.log("INFO: did not improve improve <0")
+            elif loss_cost_diff > max(-ep_costs, 0):
+                if logger:
+                    logger.log(f"INFO: no improve {loss_cost_diff} > {max(-ep_costs, 0)}")
+            elif kl > target_kl:
+                if logger:
+                    logger.log(f"INFO: violated KL constraint {kl} at step {step + 1}.")
+            else:
+                if logger:
+                    logger.log(f"Accept step at i={step + 1}")
+                break
+            step_frac *= STEP_FRACTION
+        else:
+            if logger:
+                logger.log("INFO: no suitable step found...")
+            step_direction = torch.zeros_like(step_direction)
+            acceptance_step = 0
+        return step_frac, step_direction, acceptance_step, kl
+
+    def pcpo_update(self, ep_costs: float, logger=None) -> dict:
+        """PCPO (reference safepo/single_agent/pcpo.py:352-470): reward step sqrt(2*delta/q) * H x projected onto
+        the cost constraint, step = sqrt(2d/(q+1e-8)) * Hx - max(0, (sqrt(2d/q) r + c) / s) * p, then CPO's line
+        search with optim_case fixed to 0."""
+        target_kl = self.cfg["target_kl"]
+        d = self.buffer.data
+        theta_old = self.theta_actor.clone()
+        self.snapshot_old_distribution()
+        g_loss, mean_r = self.surrogate_grad(d["adv_r"], -1.0)
+        loss_reward_before = -mean_r
+        grads = -g_loss
+        x = self.conjugate_gradients(grads)
+        assert torch.isfinite(x).all(), "x is not finite"
+        Hx = self.fvp(x)                               # the reference names this H_inv_g (pcpo.py:372)
+        xHx = torch.dot(x, Hx)
+        assert xHx.item() >= 0, "xHx is negative"
+        alpha = torch.sqrt(2 * target_kl / (xHx + 1e-8))
+        b_grads, mean_c = self.surrogate_grad(d["adv_c"], 1.0)
+        loss_cost_before = mean_c
+        p = self.conjugate_gradients(b_grads)
+        q = xHx
+        r = grads.dot(p)
+        s_ = b_grads.dot(p)
+        step_direction = (torch.sqrt(2 * target_kl / (q + 1e-8)) * Hx
+                          - torch.clamp_min((torch.sqrt(2 * target_kl / q) * r + ep_costs) / s_,
+                                            torch.tensor(0.0, device=self.dev)) * p)
+        step_frac, step_direction, acceptance_step, kl = self._constrained_line_search(
+            theta_old, step_direction, grads, 0, ep_costs, loss_reward_before, loss_cost_before, logger)
+        self.theta_actor.copy_(theta_old + step_frac * step_direction)
+        self.stale_sq.copy_(b_grads.dot(b_grads).reshape(1))
+        return {"alpha": float(alpha), "final_step_norm": float(torch.norm(step_direction)), "xHx": float(xHx),
+                "gradient_norm": float(torch.norm(grads)), "H_inv_g": float(x.norm()),
+                "acceptance_step": acceptance_step, "loss_actor": loss_reward_before + loss_cost_before, "kl": kl,
+                "case": 0, "g": grads, "b": b_grads, "x": x, "p": p, "step_direction": step_direction}
+
     def critic_fit(self, perm_fn=None):
         """cpo.py:534-571: learning_iters passes of minibatches (batch_size rows) over both critics."""
         c = self.cfg
@@ -321,7 +363,7 @@ def _to_dev(x, dev):
     return torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x, dtype=torch.float32, device=dev).contiguous()
 
 
-def main(args, cfg_env=None):
+def main(args, cfg_env=None, _update="cpo"):
     random.seed(args.seed)
     np.random.seed(args.seed)
     torch.manual_seed(args.seed)
@@ -377,7 +419,7 @@ def main(args, cfg_env=None):
         # ---- update policy (cpo.py:350-532) and critics (:534-571)
         engine.buffer.compute_gae(None, comm)
         ep_costs = logger.get_stats("Metrics/EpCost") - args.cost_limit
-        out = engine.policy_update(ep_costs, logger)
+        out = engine.policy_update(ep_costs, logger) if _update == "cpo" else engine.pcpo_update(ep_costs, logger)
         logger.store(**{"Misc/Alpha": out["alpha"], "Misc/FinalStepNorm": out["final_step_norm"], "Misc/xHx": out["xHx"],
                         "Misc/gradient_norm": out["gradient_norm"], "Misc/H_inv_g": out["H_inv_g"],
                         "Misc/AcceptanceStep": out["acceptance_step"], "Loss/Loss_actor": out["loss_actor"],

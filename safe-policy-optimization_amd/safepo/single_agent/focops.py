@@ -1,0 +1,43 @@
+"""FOCOPS (First Order Constrained Optimization in Policy Space): reference safepo/single_agent/focops.py.
+The ppo_lag epoch loop with (a) the multiplier bounded by FOCOPS_NU, (b) the actor loss
+    ((KL(pi || pi_old) - (1/FOCOPS_LAM) * ratio * adv) * [KL <= target_kl]).mean()          (focops.py:326-337)
+evaluated in the persistent update kernel (spo_update_iter_ex, SPO_ACTOR_LOSS_KL_PENALTY).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+from safepo.single_agent import _first_order
+from safepo.utils.config import single_agent_args
+
+default_cfg = {
+    'hidden_sizes': [64, 64],
+    'gamma': 0.99,
+    'target_kl': 0.02,
+    'batch_size': 64,
+    'learning_iters': 40,
+    'max_grad_norm': 40.0,
+}
+
+
+def main(args, cfg_env=None):
+    return _first_order.run(args, cfg_env, default_cfg, multiplier="adam", clip=0.2, variant="focops")
+
+
+if __name__ == "__main__":
+    args, cfg_env = single_agent_args()
+    relpath = time.strftime("%Y-%m-%d-%H-%M-%S")
+    subfolder = "-".join(["seed", str(args.seed).zfill(3)])
+    relpath = "-".join([subfolder, relpath])
+    algo = os.path.basename(__file__).split(".")[0]
+    args.log_dir = os.path.join(args.log_dir, args.experiment, args.task, algo, relpath)
+    if not args.write_terminal:
+        os.makedirs(args.log_dir, exist_ok=True)
+        with open(os.path.join(args.log_dir, f"seed{args.seed}_terminal.log"), "w", encoding="utf-8") as f_out, \
+                open(os.path.join(args.log_dir, f"seed{args.seed}_error.log"), "w", encoding="utf-8") as f_err:
+            sys.stdout, sys.stderr = f_out, f_err
+            main(args, cfg_env)
+    else:
+        main(args, cfg_env)

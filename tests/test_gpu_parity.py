@@ -520,6 +520,41 @@ def test_cpo_update_vs_reference_main_trace(dev, golden_dir):
     _assert_params_close(pol.theta.cpu().numpy(), ref_final, 1e-3, 12, rtol=5e-3, atol=5e-5, what="final theta")
 
 
+def test_pcpo_update_vs_reference_main_trace(dev, golden_dir):
+    """Replays the reference pcpo.main(): two CG solves, the projection step, line search (incl. an epoch that
+    backtracks six times), actor parameters after the step, critic fit with the recorded shuffles."""
+    z = np.load(os.path.join(golden_dir, "pcpo_trace.npz"))
+    N, T, epochs = int(z["meta_num_envs"]), int(z["meta_T"]), int(z["meta_epochs"])
+    pol, eng = _cpo_engine(z, "init_sd_", dev, N, T, {"learning_iters": int(z["meta_cfg_learning_iters"]),
+                                                       "batch_size": int(z["e0_batch_size"]),
+                                                       "target_kl": float(z["meta_cfg_target_kl"])})
+    steps = []
+    for e in range(epochs):
+        _load_epoch_into_engine(z, e, eng, dev)
+        eng.buffer.compute_gae(None)
+        ep_costs = float(z[f"e{e}_get_stats_Metrics_EpCost"]) - float(z["meta_arg_cost_limit"])
+        out = eng.pcpo_update(ep_costs)
+        steps.append(out["acceptance_step"])
+        assert out["acceptance_step"] == int(z[f"e{e}_Misc_AcceptanceStep"])
+        assert out["xHx"] == pytest.approx(float(z[f"e{e}_Misc_xHx"]), rel=5e-3)
+        assert out["H_inv_g"] == pytest.approx(float(z[f"e{e}_Misc_H_inv_g"]), rel=5e-3)
+        assert out["gradient_norm"] == pytest.approx(float(z[f"e{e}_Misc_gradient_norm"]), rel=1e-4)
+        assert out["final_step_norm"] == pytest.approx(float(z[f"e{e}_Misc_FinalStepNorm"]), rel=5e-3)
+        assert out["alpha"] == pytest.approx(float(z[f"e{e}_Misc_Alpha"]), rel=5e-3)
+        assert out["kl"] == pytest.approx(float(z[f"e{e}_Train_KL"]), rel=2e-2)
+        act_ref = np.concatenate([z[f"e{e}_actor_after_{k}"].reshape(-1) for k in pol.actor.state_dict()])
+        np.testing.assert_allclose(eng.theta_actor.cpu().numpy(), act_ref, rtol=5e-3, atol=3e-5)
+        iters = int(z["meta_cfg_learning_iters"])
+        perms = [torch.from_numpy(z[f"e{e}_perm{i}"].astype(np.int32)).to(dev) for i in range(iters)]
+        fit = eng.critic_fit(perm_fn=lambda it: perms[it])
+        eng.buffer.reset()
+        got = torch.cat(fit["losses"], 0).cpu().numpy()
+        np.testing.assert_allclose(got, z[f"e{e}_mb_losses"][:, :2], rtol=2e-3, atol=1e-5)
+    assert max(steps) > 1
+    ref_final = np.concatenate([z[f"final_sd_{k}"].reshape(-1) for k in pol.state_dict()])
+    _assert_params_close(pol.theta.cpu().numpy(), ref_final, 1e-3, 12, rtol=5e-3, atol=5e-5, what="final theta")
+
+
 def test_cpo_main_entrypoint_synthetic(dev, tmp_path):
     import argparse
     import csv
@@ -698,7 +733,7 @@ def test_pg_unclipped_surrogate_and_ppo_lambda_zero(dev):
     assert torch.equal(b.adv_mix.view(-1).cpu(), adv)
 
 
-@pytest.mark.parametrize("algo", ["ppo", "pg", "cppo_pid"])
+@pytest.mark.parametrize("algo", ["ppo", "pg", "cppo_pid", "focops", "cup"])
 def test_sibling_entrypoints_synthetic(dev, tmp_path, algo):
     import argparse
     import csv
@@ -713,9 +748,132 @@ def test_sibling_entrypoints_synthetic(dev, tmp_path, algo):
     mod.main(args, {})
     rows = list(csv.DictReader(open(tmp_path / "exp" / "task" / "run" / "progress.csv")))
     assert len(rows) == 2
-    assert ("Train/LagragianMultiplier" in rows[0]) == (algo == "cppo_pid")
+    assert ("Train/LagragianMultiplier" in rows[0]) == (algo in ("cppo_pid", "focops", "cup"))
+    assert ("Train/SeconStageStopIter" in rows[0]) == (algo == "cup")
     if algo == "cppo_pid":
         assert float(rows[1]["Train/LagragianMultiplier"]) > 0.0          # cost 4/episode > limit 0.5
+
+@pytest.mark.parametrize("algo", ["focops", "cup"])
+def test_kl_penalty_family_vs_reference_main_trace(dev, golden_dir, algo):
+    """3 epochs of the reference focops.main() / cup.main(): same buffers, shuffles and initial weights ->
+    per-minibatch losses (critics + the KL-penalty actor loss with its indicator), early-stop iterations of both
+    stages, KL and parameters after every epoch."""
+    from safepo.common.engine import PPOLagEngine
+    z = np.load(os.path.join(golden_dir, f"{algo}_trace.npz"))
+    N, T, epochs = int(z["meta_num_envs"]), int(z["meta_T"]), int(z["meta_epochs"])
+    pol = _policy_from_npz(z, "init_sd_", dev)
+    cfg = {"hidden_sizes": [64, 64], "gamma": float(z["meta_cfg_gamma"]), "target_kl": float(z["meta_cfg_target_kl"]),
+           "batch_size": int(z["e0_batch_size"]), "learning_iters": int(z["meta_cfg_learning_iters"]),
+           "max_grad_norm": float(z["meta_cfg_max_grad_norm"])}
+    eng = PPOLagEngine(pol, N, T, cfg, dev)
+    for e in range(epochs):
+        ref_before = np.concatenate([z[f"e{e}_sd_before_{k}"].reshape(-1) for k in pol.state_dict()])
+        _assert_params_close(pol.theta.cpu().numpy(), ref_before, 3e-4, 40 * max(e, 1), rtol=5e-4, atol=5e-6,
+                             what=f"theta before epoch {e}")
+        _load_epoch_into_engine(z, e, eng, dev)
+        lam = float(z[f"e{e}_row_Train_LagragianMultiplier"])
+        n_perm = len([k for k in z.files if k.startswith(f"e{e}_perm")])
+        perms = [torch.from_numpy(z[f"e{e}_perm{i}"].astype(np.int32)).to(dev) for i in range(n_perm)]
+        eng.lr_factor = 1.0 - e / epochs
+        perm_fn = lambda it: perms[min(it, n_perm - 1)]
+        if algo == "focops":
+            out = eng.update_focops(lam, perm_fn=perm_fn)
+        else:
+            out = eng.update_cup(lam, perm_fn=perm_fn)
+            assert out["second_stage_stop_iter"] == int(z[f"e{e}_row_Train_SeconStageStopIter"])
+            # parameters between the stages (recorded when the reference builds its second DataLoader)
+            assert torch.isnan(torch.cat(out["second_stage_losses"], 0)[:, :2]).all()      # critics untouched
+        assert out["stop_iter"] == int(z[f"e{e}_row_Train_StopIter"]), (out["stop_iter"], out["kl"])
+        got = torch.cat(out["losses"], 0).cpu().numpy()
+        np.testing.assert_allclose(got, z[f"e{e}_mb_losses"], rtol=2e-4, atol=3e-6)
+        assert out["kl"] == pytest.approx(float(z[f"e{e}_row_Train_KL"]), rel=3e-3, abs=1e-7)
+    ref_final = np.concatenate([z[f"final_sd_{k}"].reshape(-1) for k in pol.state_dict()])
+    _assert_params_close(pol.theta.cpu().numpy(), ref_final, 3e-4, 120, rtol=5e-4, atol=5e-6, what="final theta")
+
+
+@pytest.mark.parametrize("M,D,A,actor_only", [(192, 60, 8, False), (150, 17, 6, True), (100, 100, 3, True),
+                                               (64, 128, 16, False)])
+def test_kl_penalty_minibatch_steps_vs_oracle(dev, M, D, A, actor_only):
+    """One pass of KL-penalty minibatch steps (partial last batch included, indicator active on part of the batch)
+    against torch autograd + Adam in the oracle; the actor's optimiser clock is ahead of the critics'."""
+    from safepo import _abi
+    from safepo.common.engine import PPOLagEngine
+    from safepo.common.model import ActorVCritic
+    torch.manual_seed(M + D)
+    pol = ActorVCritic(D, A).to(dev)
+    with torch.no_grad():
+        pol.actor.log_std.copy_(torch.randn(A) * 0.2)
+    ref = R.OraclePolicy(D, A)
+    ref.load_state_dict({k: v.cpu().clone() for k, v in pol.state_dict().items()})
+    obs, act, logp, tgt_r, tgt_c, adv = _synthetic_update_problem(M, D, A, seed=M)
+    with torch.no_grad():
+        dist = ref.actor(obs)
+        old_mean = dist.mean + 0.05 * torch.randn(M, A)          # a nearby "old" policy: KL straddles the bound
+        old_std = dist.stddev * torch.exp(0.05 * torch.randn(A))
+    with torch.no_grad():
+        kl0 = torch.distributions.kl_divergence(dist, torch.distributions.Normal(old_mean, old_std)).sum(-1)
+    kl_bound = float(kl0.quantile(0.55)) if not actor_only else float("inf")       # between two samples, not on one
+    pg_coef = 1 / 1.5 if not actor_only else -0.37
+    cfg = {"hidden_sizes": [64, 64], "gamma": 0.99, "target_kl": 1e9, "batch_size": 64, "learning_iters": 1,
+           "max_grad_norm": 40.0}
+    eng = PPOLagEngine(pol, 1, M, cfg, dev)
+    b = eng.buffer
+    b.data["obs"].copy_(obs.view(1, M, D)); b.data["act"].copy_(act.view(1, M, A))
+    b.data["log_prob"].copy_(logp.view(1, M)); b.data["target_value_r"].copy_(tgt_r.view(1, M))
+    b.data["target_value_c"].copy_(tgt_c.view(1, M))
+    eng.mean_old.copy_(old_mean); eng.std_old.copy_(old_std[0] if old_std.dim() > 1 else old_std)
+    perm = torch.randperm(M, generator=torch.Generator().manual_seed(3))
+    # oracle: 5 earlier actor-only steps move the actor's Adam clock ahead (zero gradients leave the moments at 0)
+    upd = R.KLPenaltyUpdater(ref)
+    for _ in range(5):
+        upd.opt_a.zero_grad()
+        for prm in ref.actor.parameters():
+            prm.grad = torch.zeros_like(prm)
+        upd.opt_a.step()
+    eng.adam_step_actor_extra = 5
+    theta0 = pol.theta.clone()
+    ref_losses, n_masked = [], 0
+    os_full = old_std.expand(M, A) if old_std.dim() == 1 else old_std
+    for s0 in range(0, M, 64):
+        idx = perm[s0:s0 + 64]
+        with torch.no_grad():
+            kl_i = torch.distributions.kl_divergence(ref.actor(obs[idx]), torch.distributions.Normal(old_mean[idx], os_full[idx])).sum(-1)
+            n_masked += int((kl_i > kl_bound).sum())
+        if actor_only:
+            l = upd.cup_second_stage_step(obs[idx], act[idx], logp[idx], adv[idx], old_mean[idx], os_full[idx],
+                                          0.37 / ((1 - 0.99 * 0.95) / (1 - 0.99)), 0.99)
+            ref_losses.append([np.nan, np.nan, l])
+        else:
+            ref_losses.append(list(upd.focops_step(obs[idx], act[idx], logp[idx], tgt_r[idx], tgt_c[idx], adv[idx],
+                                                   old_mean[idx], os_full[idx], kl_bound)))
+    if not actor_only:
+        assert 0 < n_masked < M, n_masked             # the indicator is exercised on both sides
+    losses = eng.learning_iter_ex(perm.to(torch.int32).to(dev), torch.as_tensor(adv).to(dev).contiguous(),
+                                  _abi.ACTOR_LOSS_KL_PENALTY, kl_bound, pg_coef, actor_only)
+    eng.check_sync_error()
+    got = losses.cpu().numpy()
+    np.testing.assert_allclose(got, np.asarray(ref_losses), rtol=2e-4, atol=3e-6, equal_nan=True)
+    n_steps = (M + 63) // 64
+    _assert_params_close(pol.theta.cpu().numpy(), R.flat_params(ref).numpy(), 3e-4, n_steps, rtol=5e-4, atol=5e-6,
+                         what="theta after one pass")
+    if actor_only:
+        off = int(_abi.load().spo_param_offset(D, A, 2))
+        assert torch.equal(pol.theta[:off], theta0[:off])        # critics untouched
+        assert eng.adam_step == 0 and eng.adam_step_actor_extra == 5 + n_steps
+
+
+def test_kl_penalty_refuses_wide_minibatch(dev):
+    from safepo import _abi
+    from safepo.common.engine import PPOLagEngine
+    from safepo.common.model import ActorVCritic
+    pol = ActorVCritic(12, 2).to(dev)
+    eng = PPOLagEngine(pol, 1, 256, {"hidden_sizes": [64, 64], "gamma": 0.99, "target_kl": 0.02, "batch_size": 128,
+                                     "learning_iters": 1, "max_grad_norm": 40.0}, dev)
+    eng.snapshot_old_distribution()
+    with pytest.raises(_abi.SpoError, match="batch_size 128 > 64"):
+        eng.learning_iter_ex(torch.arange(256, dtype=torch.int32, device=dev), eng.buffer.adv_mix,
+                             _abi.ACTOR_LOSS_KL_PENALTY, 0.02, 1.0)
+
 
 
 class _TargetEnv:

@@ -180,6 +180,50 @@ def test_cpo_main_trace(golden_dir):
         np.testing.assert_allclose(v.numpy(), z[f"final_sd_{k}"], rtol=1e-3, atol=5e-6, err_msg=k)
 
 
+def _trace_epoch_inputs(z, e):
+    N, T, adv_r, adv_c, tgt_r, tgt_c = _epoch_data(z, e)
+    sr, sc = R.adv_standardize(torch.from_numpy(adv_r.reshape(-1)), torch.from_numpy(adv_c.reshape(-1)))
+    flat = lambda k: torch.from_numpy(z[f"e{e}_raw_{k}"].reshape(N * T, *z[f"e{e}_raw_{k}"].shape[2:]))
+    data = {"obs": flat("obs"), "act": flat("act"), "log_prob": flat("log_prob"),
+            "target_value_r": torch.from_numpy(tgt_r.reshape(-1)), "target_value_c": torch.from_numpy(tgt_c.reshape(-1)),
+            "adv_r": sr, "adv_c": sc}
+    n_perm = len([k for k in z.files if k.startswith(f"e{e}_perm")])
+    return data, [z[f"e{e}_perm{i}"] for i in range(n_perm)]
+
+
+@pytest.mark.parametrize("algo,upper", [("focops", 2.0), ("cup", 0.2)])
+def test_kl_penalty_family_main_trace(golden_dir, algo, upper):
+    """Replays the reference focops.main() / cup.main() through the restatement: the [B,1] x [B] broadcast of the
+    KL-penalty losses, the per-sample indicator, CUP's actor-only second stage with its own optimiser clock."""
+    z = _load(golden_dir, f"{algo}_trace.npz")
+    epochs, iters = int(z["meta_epochs"]), int(z["meta_cfg_learning_iters"])
+    pol = _policy_from(z, "init_sd_")
+    upd = R.KLPenaltyUpdater(pol, epochs=epochs)
+    lag = R.OracleLagrange(float(z["meta_arg_cost_limit"]), float(z["meta_arg_lagrangian_multiplier_init"]),
+                           float(z["meta_arg_lagrangian_multiplier_lr"]), lagrangian_upper_bound=upper)
+    masked = 0
+    for e in range(epochs):
+        for k, v in pol.state_dict().items():
+            np.testing.assert_allclose(v.numpy(), z[f"e{e}_sd_before_{k}"], rtol=2e-6, atol=1e-7, err_msg=k)
+        data, perms = _trace_epoch_inputs(z, e)
+        lag.update_lagrange_multiplier(float(z[f"e{e}_get_stats_Metrics_EpCost"]))
+        assert lag.lagrangian_multiplier == pytest.approx(float(z[f"e{e}_row_Train_LagragianMultiplier"]), rel=1e-6)
+        kw = dict(learning_iters=iters, batch_size=int(z[f"e{e}_batch_size"]), target_kl=float(z["meta_cfg_target_kl"]))
+        perms = perms + [perms[-1]] * (2 * iters)
+        if algo == "focops":
+            out = R.focops_update(pol, upd, data, lag.lagrangian_multiplier, perms, **kw)
+        else:
+            out = R.cup_update(pol, upd, data, lag.lagrangian_multiplier, perms, float(z["meta_cfg_gamma"]), **kw)
+            assert out["second_stage_stop_iter"] == int(z[f"e{e}_row_Train_SeconStageStopIter"])
+            if e > 0:
+                pass
+        assert out["stop_iter"] == int(z[f"e{e}_row_Train_StopIter"])
+        assert out["kl"] == pytest.approx(float(z[f"e{e}_row_Train_KL"]), rel=1e-4)
+        np.testing.assert_allclose(out["losses"], z[f"e{e}_mb_losses"], rtol=2e-5, atol=1e-7)
+    for k, v in pol.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), z[f"final_sd_{k}"], rtol=2e-5, atol=2e-7, err_msg=k)
+
+
 def test_boundary_logic_matches_trace(golden_dir):
     """a-4: done -> bootstrap 0; epoch end and time-out both end a path (ppo_lag.py:198-234)."""
     z = _load(golden_dir, "ppo_lag_trace.npz")
