@@ -213,6 +213,35 @@ int spo_update_iter_ex(float* theta, float* adam_m, float* adam_v, int64_t adam_
                        const spo_ppo_cfg* cfg_host, int actor_loss, const float* old_mean, const float* old_std,
                        float kl_bound, float pg_coef, int actor_only, float* losses_out, void* sync_ws, void* stream);
 
+/* ---- (e) multi-GPU, in-kernel form (SURVEY.md 8(e) "direct all-reduce over the xGMI mesh, fused as the epilogue of
+ * the backward kernel").  Each rank owns one exchange region (uncached device memory, spo_p2p_alloc) and maps its
+ * peers' regions through the 64-byte IPC handle (spo_p2p_open; exchange the handles with any host collective).
+ * regions[r] = rank r's region as seen from this process (own pointer at index rank), world <= 8.
+ * spo_ppo_lag_update_iter_dp is spo_ppo_lag_update_iter for one rank of a data-parallel job: every rank launches it on
+ * its own shard (same M, same batch, same step counts) and the per-step mean of the ranks' minibatch gradients is formed
+ * inside the step, so all replicas apply bit-identical updates.  Every float travels as an 8-byte {tag, value} word
+ * written with one system-scope write-through store and polled by the lane that needs it (no flags, no barriers):
+ * 2 ranks push whole gradients to each other (one hand-off per step); more ranks reduce-scatter then all-gather
+ * (two hand-offs, 2 x 88 KB per network per step at any world size).  Environment: SPO_P2P_ALGO=twophase forces the
+ * second form at 2 ranks.  step0 = optimiser steps already taken through these regions (monotonic tag base, identical
+ * on every rank; advance it by the number of minibatches).  A peer that never answers costs ONE bounded wait and is
+ * reported through sync_ws (int at byte 64 = 2), never a hang.
+ * spo_p2p_selftest runs `iters` exchange rounds of known patterns on the same grid and protocol:
+ * result2_dev[0] = wrong values, result2_dev[1] = 2 after a timeout; it consumes `iters` tags. */
+int64_t spo_p2p_region_bytes(void);
+int spo_debug_xr_profile(unsigned long long* out8_host, int reset);   /* self-test kernel phase cycles (debug) */
+int spo_p2p_alloc(void** region_out, void* ipc_handle64_out);
+int spo_p2p_open(const void* ipc_handle64, void** region_out);
+int spo_p2p_close(void* peer_region);
+int spo_p2p_free(void* own_region);
+int spo_p2p_selftest(int rank, int world, void* const* regions, uint32_t step0, int iters, int32_t* result2_dev,
+                     void* stream);
+int spo_ppo_lag_update_iter_dp(float* theta, float* adam_m, float* adam_v, int64_t adam_step_host, const float* obs,
+                               const float* act, const float* logp_old, const float* target_r, const float* target_c,
+                               const float* adv, const int32_t* perm, int64_t M, const spo_ppo_cfg* cfg_host,
+                               float* losses_out, void* sync_ws, int rank, int world, void* const* regions,
+                               uint32_t step0, void* stream);
+
 /* ---- multi-agent masked GAE: SeparatedReplayBuffer.compute_returns + compute_cost_returns
  * (safepo/common/buffer.py:356-384) with PopArt.denormalize (safepo/common/popart.py:117-133) folded in.
  * Time-major arrays as in the reference: rewards/costs [T, N], value_preds/cost_preds/masks [T+1, N] (row T =

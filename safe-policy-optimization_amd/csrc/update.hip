@@ -15,6 +15,8 @@
 // Wave w owns batch columns [16w,16w+16) in forward/backward (transposed chaining, mlp_mfma.h) and
 // rows [16w,16w+16) of every weight-gradient tile (reduction over the 64 batch columns staged
 // through LDS as [feature][batch]).
+#include <cstdlib>
+#include <cstring>
 #include "common.h"
 #include "mlp_mfma.h"
 #include "../../include/safepo_hip.h"
@@ -42,6 +44,29 @@ struct UpdLds {
   static constexpr int SIZE = RED + RED_FLOATS;
 };
 
+// ---- cross-rank exchange regions (direct all-reduce over the xGMI mesh, fused into the step).
+// One region per rank, allocated uncached/fine-grained so that stores arriving from peer GPUs are visible to a running
+// kernel, shared by IPC handle.  A network's gradient is NV*256 float4 (NV per lane, accumulator layout).  Per step:
+//   phase 1 (reduce-scatter): the vector is cut into `world` contiguous slices; every rank PUSHES slice c of its gradient
+//           into slot1[parity][me][net] of rank c's region; rank c sums its slice over the sources in rank order and
+//           scales by 1/world;
+//   phase 2 (all-gather): rank c PUSHES the reduced slice into red2[parity][net] of every region and every rank reads
+//           the full reduced vector back from its own region.
+// Every element is reduced by exactly one rank, so all replicas see identical bits.
+// There are no flags and no barriers: every float travels as an 8-byte {tag, value} word written by ONE system-scope
+// write-through store (untorn), and a consumer lane polls exactly the words it needs until their tags equal the
+// step's tag -- the latency of a hand-off is one store plus one load instead of store, drain, flag, poll, load.
+// Words are laid out in 4 planes (component k of element e at plane k, index e) so a wave's store covers 512
+// contiguous bytes.  Tags are the global step count (monotonic, never reset).  Buffers are double-buffered by step
+// parity: a word used at step g is rewritten at step g+2, which a peer can only reach after it has consumed every
+// phase-2 word of step g+1 from us, all of them written after our reads of step g.
+constexpr int XR_MAX_WORLD = 8;
+constexpr int XR_SLOT_F4 = (8 + 7) * 256;                               // elements per slot, sized for obs_dim <= 128
+constexpr size_t XR_SLOT_WORDS = (size_t)4 * XR_SLOT_F4;                // 4 planes of u64
+constexpr size_t XR_SLOT1_WORDS = (size_t)2 * XR_MAX_WORLD * 3 * XR_SLOT_WORDS;     // [parity][source rank][network]
+constexpr size_t XR_RED2_WORDS = (size_t)2 * 3 * XR_SLOT_WORDS;                     // [parity][network]
+constexpr size_t XR_REGION_BYTES = (XR_SLOT1_WORDS + XR_RED2_WORDS) * 8;
+
 struct UpdArgs {
   float* theta; float* adam_m; float* adam_v;
   const float* obs; const float* act; const float* logp_old; const float* tgt_r; const float* tgt_c;
@@ -62,6 +87,11 @@ struct UpdArgs {
   const float* old_std;          // [A]    its std (state independent)
   float kl_bound, pg_coef;
   double pow_b1_actor, pow_b2_actor;   // the actor's optimiser may be ahead of the critics' (CUP steps it alone)
+  // cross-rank (data-parallel) gradient exchange inside the persistent kernel: XR instantiations only
+  int xr_rank, xr_world;
+  int xr_algo;                         // 1: one-shot push at 2 ranks; 0: reduce-scatter + all-gather everywhere
+  unsigned xr_step0;                   // global optimiser-step count before this launch (same on every rank)
+  void* xr_region[XR_MAX_WORLD];       // every rank's exchange region (own + IPC-mapped peers), indexed by rank
 };
 constexpr int NPHASE = 10;
 
@@ -115,13 +145,175 @@ struct ColData {
   float t0, t1;    // critic: target ; actor: logp_old, adv
 };
 
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) unsigned long long gu64;    // global address space: global_* not flat_*
+// Word layout inside a slot: element e (a float4) lives in row e >> 8; a row is 4 planes of 256 words, so component k of
+// element e is word (e >> 8) * 1024 + k * 256 + (e & 255).  A wave's store covers 512 contiguous bytes, and the four
+// components of one element sit at -4096 / -2048 / 0 / +2048 bytes around one address (13-bit immediates: ONE address
+// register pair per element instead of four).
+__device__ __forceinline__ gu64* xr_elem(gu64* slot, int e) { return slot + ((size_t)(e >> 8) * 1024 + (e & 255) + 512); }
+__device__ __forceinline__ void st_ll(gu64* elem, const f4 v, unsigned tag) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    __hip_atomic_store(elem + (k - 2) * 256, ((u64)tag << 32) | __float_as_uint(v[k]), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);                          // global_store_dwordx2 sc0 sc1
+}
+__device__ __forceinline__ bool ld_ll(gu64* elem, unsigned tag, f4& v) {
+  u64 w[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    w[k] = __hip_atomic_load(elem + (k - 2) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    ok = ok && ((unsigned)(w[k] >> 32) == tag);
+    v[k] = __uint_as_float((unsigned)w[k]);
+  }
+  return ok;
+}
+__device__ __forceinline__ gu64* xr_words(u64 region) { return (gu64*)region; }
+
+constexpr unsigned XR_SPIN_LIMIT = 1u << 21;
+constexpr int XR_BATCH = 8;      // (element, source) pairs polled together (16 spills the 64-wide kernel)
+// debug profile of the exchange (self-test kernel only): cycles in {push1, reduce polls, push2, final polls} and the
+// number of poll rounds {reduce, final}, summed over iterations by thread 0 of every workgroup
+__device__ unsigned long long g_xr_prof[8];
+
+// All-reduce(mean) of NV float4 per lane across the ranks for network `net` at global step tag `gtag`.
+// Every lane of the workgroup calls it (no barrier inside).  `regions`: LDS table of the ranks' region base
+// addresses.  `dead_word` (LDS) goes non-zero after a timed-out poll; from then on this rank keeps publishing
+// (peers must not hang on us) but no longer waits, so a broken fabric costs one bounded wait, not one per step.
+template <int NV, bool XPROF = false>
+__device__ __forceinline__ void xr_allreduce(const u64* regions, int me, int R, int net, int tid, unsigned gtag,
+                                             f4 (&pk)[NV], volatile float* dead_word, int* err) {
+  unsigned long long tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0, rounds_a = 0, rounds_b = 0;
+  if (XPROF) tp0 = __builtin_readcyclecounter();
+  constexpr int TOTAL = NV * 256;
+  const int par = (int)(gtag & 1u);
+  const int chunk = (TOTAL + R - 1) / R;
+  // ---- phase 1 push: element i = v*256 + tid goes to rank i / chunk
+  const size_t slot1_me = ((size_t)(par * XR_MAX_WORLD + me) * 3 + net) * XR_SLOT_WORDS;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int i = v * 256 + tid;
+    int dst = 0;
+    for (int c = 1; c < R; ++c) dst += (i >= c * chunk) ? 1 : 0;
+    st_ll(xr_elem(xr_words(regions[dst]) + slot1_me, i - dst * chunk), pk[v], gtag);
+  }
+  if (XPROF) tp1 = __builtin_readcyclecounter();
+  // ---- reduce my slice over the sources in rank order, push the result to every rank (phase 2)
+  const int my_lo = me * chunk;
+  const int my_n = (TOTAL - my_lo) < chunk ? (TOTAL - my_lo) : chunk;
+  const int lg = R <= 2 ? 1 : R <= 4 ? 2 : 3;                  // sources padded to 2 / 4 / 8 per element
+  const int G = XR_BATCH >> lg;                                // elements per batch of XR_BATCH loads
+  const int E = (my_n + 255) >> 8;
+  const float inv_world = 1.f / (float)R;
+  gu64* const src0 = xr_words(regions[me]) + ((size_t)(par * XR_MAX_WORLD) * 3 + net) * XR_SLOT_WORDS;
+  const size_t red2_off = XR_SLOT1_WORDS + ((size_t)par * 3 + net) * XR_SLOT_WORDS;
+  for (int b = 0; b * G < E; ++b) {
+    f4 x[XR_BATCH];
+    unsigned spins = 0;
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int jj = 0; jj < XR_BATCH; ++jj) {
+        const int g = jj >> lg, r = jj & ((1 << lg) - 1);
+        const int e = (b * G + g) * 256 + tid;
+        x[jj] = f4{0.f, 0.f, 0.f, 0.f};
+        if (r < R && e < my_n) ok = ld_ll(xr_elem(src0 + (size_t)r * 3 * XR_SLOT_WORDS, e), gtag, x[jj]) && ok;
+      }
+      if (XPROF) rounds_a += 1;
+      if (ok || *dead_word != 0.f) break;
+      if (++spins > XR_SPIN_LIMIT) { *err = 2; *dead_word = 1.f; break; }        // bounded: never hang the GPU
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (XPROF) { tp2 += __builtin_readcyclecounter() - tp1; tp1 = __builtin_readcyclecounter(); }
+    f4 run = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jj = 0; jj < XR_BATCH; ++jj) {
+      const int g = jj >> lg, r = jj & ((1 << lg) - 1);
+      if (r < R) {
+        run = (r == 0) ? x[jj] : run + x[jj];
+        const int e = (b * G + g) * 256 + tid;
+        if (r == R - 1 && e < my_n) {
+          const f4 val = run * inv_world;
+          for (int dst = 0; dst < R; ++dst) st_ll(xr_elem(xr_words(regions[dst]) + red2_off, my_lo + e), val, gtag);
+        }
+      }
+    }
+  }
+  // ---- the reduced vector
+  gu64* const fin = xr_words(regions[me]) + red2_off;
+  unsigned spins = 0;
+  if (XPROF) tp3 = __builtin_readcyclecounter();
+  for (;;) {
+    bool ok = true;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) ok = ld_ll(xr_elem(fin, v * 256 + tid), gtag, pk[v]) && ok;
+    if (XPROF) rounds_b += 1;
+    if (ok || *dead_word != 0.f) break;
+    if (++spins > XR_SPIN_LIMIT) { *err = 2; *dead_word = 1.f; break; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  if (XPROF && tid == 0) {
+    const unsigned long long tend = __builtin_readcyclecounter();
+    atomicAdd(&g_xr_prof[0], tp1 - tp0 - tp2);      // pushes (phase 1 + phase 2 stores), roughly
+    atomicAdd(&g_xr_prof[1], tp2);                  // reduce polls
+    atomicAdd(&g_xr_prof[2], tp3 - tp0);            // everything before the final poll
+    atomicAdd(&g_xr_prof[3], tend - tp3);           // final polls
+    atomicAdd(&g_xr_prof[4], rounds_a);
+    atomicAdd(&g_xr_prof[5], rounds_b);
+    atomicAdd(&g_xr_prof[6], 1ull);
+  }
+}
+
+// One-shot form for TWO ranks: each rank pushes its whole gradient to the peer and adds the two copies itself, in rank
+// order (own contribution from registers) -- one hand-off per step instead of two.  Identical bits on both ranks because
+// both add the same two values in the same order.  (A 4-rank one-shot was tried: it needs the own gradient and three
+// peer copies live at once, spills 250-500 B per lane next to the optimiser state and loses to the two-phase form.)
+template <int NV>
+__device__ __forceinline__ void xr_allreduce_pair(const u64* regions, int me, int net, int tid, unsigned gtag,
+                                                  f4 (&pk)[NV], volatile float* dead_word, int* err) {
+  constexpr int VB = 6;                                         // gradient rows polled together
+  const int par = (int)(gtag & 1u);
+  const int peer = 1 - me;
+  gu64* const p = xr_words(regions[peer]) + ((size_t)(par * XR_MAX_WORLD + me) * 3 + net) * XR_SLOT_WORDS;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) st_ll(xr_elem(p, v * 256 + tid), pk[v], gtag);
+  gu64* const src = xr_words(regions[me]) + ((size_t)(par * XR_MAX_WORLD + peer) * 3 + net) * XR_SLOT_WORDS;
+#pragma unroll
+  for (int v0 = 0; v0 < NV; v0 += VB) {
+    f4 x[VB];
+    unsigned spins = 0;
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int vv = 0; vv < VB; ++vv)
+        if (v0 + vv < NV) ok = ld_ll(xr_elem(src, (v0 + vv) * 256 + tid), gtag, x[vv]) && ok;
+      if (ok || *dead_word != 0.f) break;
+      if (++spins > XR_SPIN_LIMIT) { *err = 2; *dead_word = 1.f; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int vv = 0; vv < VB; ++vv)
+      if (v0 + vv < NV) {
+        const f4 lo = me == 0 ? pk[v0 + vv] : x[vv], hi = me == 0 ? x[vv] : pk[v0 + vv];   // rank 0 first
+        pk[v0 + vv] = (lo + hi) * 0.5f;
+      }
+  }
+}
+
 // AMODE: actor loss.  0 = PPO clipped surrogate (ppo_lag.py:316-319; clip = 1e30 gives the plain policy gradient);
 //        1 = KL-penalty form shared by FOCOPS (focops.py:326-337) and CUP's second stage (cup.py:372-383):
 //            loss = mean_i(ind_i * KL_i) - pg_coef * mean_i(ind_i) * mean_j(ratio_j * adv_j),
 //            KL_i = KL(N(mu_i, sigma) || N(mu_old_i, sigma_old)).sum(-1),  ind_i = [KL_i <= kl_bound].
 //        (The reference subtracts a [B] tensor from a [B,1] tensor, so its loss is the mean of a BxB matrix: that is
 //        exactly the product of means above.  CUP has no indicator: kl_bound = +inf, pg_coef = -lambda * coef.)
-template <int KIN, bool PERSIST, bool PROF = false, int AMODE = 0>
+// XR: data-parallel form of the persistent kernel -- every rank runs it on its own env shard and the per-step
+//     gradient all-reduce happens inside the step (xr_allreduce above) instead of kernel / RCCL / kernel.
+// XR = 1: reduce-scatter + all-gather (any world); 2: one-shot push for exactly 2 ranks (separate instantiations:
+//     both exchange bodies together do not fit the register file next to the optimiser state).
+template <int KIN, bool PERSIST, bool PROF = false, int AMODE = 0, int XR = 0>
 __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
   unsigned long long pacc[NPHASE] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = 0;
@@ -149,6 +341,12 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
   float* const red = lds + U::RED;
   stage_net<KIN>(a.theta, g, lds, tid, 256);
   if (is_actor && tid < A) red[128 + tid] = a.theta[ls_off + tid];     // log_std mirror
+  if (XR) {
+    static_assert(U::RED % 2 == 0 && RED_FLOATS >= 160, "8-byte aligned pointer table in red[144..159]");
+    if (tid == 0) red[112] = 0.f;                                      // cross-rank "stop waiting" word
+    if (tid < XR_MAX_WORLD)
+      reinterpret_cast<unsigned long long*>(red + 144)[tid] = reinterpret_cast<unsigned long long>(a.xr_region[tid]);
+  }
   __syncthreads();
 
   // ---- ownership (C layout of the weight-gradient tiles) and optimiser state in registers
@@ -565,6 +763,28 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
       }
     }
 
+    if (XR) {
+      // ---- gradient of the global minibatch = mean over ranks of the local-minibatch gradients
+      constexpr int NV = NT1 + 7;
+      f4 pk[NV];
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt) pk[nt] = aW1[nt];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) pk[NT1 + nt] = aW2[nt];
+      pk[NT1 + 4] = aW3; pk[NT1 + 5] = f4{db1, db2, db3, 0.f}; pk[NT1 + 6] = dls;
+      const u64* const xr_tab = reinterpret_cast<const u64*>(red + 144);
+      const unsigned gtag = a.xr_step0 + (unsigned)s + 1u;
+      if (XR == 2)
+        xr_allreduce_pair<NV>(xr_tab, a.xr_rank, net, tid, gtag, pk, red + 112, a.err);
+      else
+        xr_allreduce<NV>(xr_tab, a.xr_rank, a.xr_world, net, tid, gtag, pk, red + 112, a.err);
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt) aW1[nt] = pk[nt];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) aW2[nt] = pk[NT1 + nt];
+      aW3 = pk[NT1 + 4]; db1 = pk[NT1 + 5][0]; db2 = pk[NT1 + 5][1]; db3 = pk[NT1 + 5][2]; dls = pk[NT1 + 6];
+    }
+
     // ---- L2 regulariser of the critics (weights AND biases, ppo_lag.py:310-314), grad norm
     float gsq = 0.f, psq = 0.f;
     const float l2x2 = 2.f * l2;
@@ -821,11 +1041,45 @@ __global__ __launch_bounds__(1024) void clip_adam_kernel(AdamArgs a) {
   }
 }
 
+// Self-test of the exchange protocol on the same grid shape as the real kernel: every (rank, network) workgroup
+// pushes small-integer patterns and checks the reduced values; result[0] = mismatches, result[1] = timeout flag.
+__global__ __launch_bounds__(256, 1) void xr_selftest_kernel(int rank, int world, unsigned step0, int iters, int* result,
+                                                             UpdArgs a) {
+  __shared__ float dead;
+  __shared__ unsigned long long regions[XR_MAX_WORLD];
+  if (blockIdx.x & 7) return;
+  const int net = blockIdx.x >> 3, tid = threadIdx.x;
+  if (tid == 0) dead = 0.f;
+  if (tid < XR_MAX_WORLD) regions[tid] = reinterpret_cast<unsigned long long>(a.xr_region[tid]);
+  __syncthreads();
+  int bad = 0;
+  for (int it = 0; it < iters; ++it) {
+    const unsigned gtag = step0 + (unsigned)it + 1u;
+    f4 pk[11];
+#pragma unroll
+    for (int v = 0; v < 11; ++v) {
+      const float c = (float)((gtag + 3u * v + tid + 5u * net) & 15u);
+      pk[v] = f4{(float)(rank + 1) + c, (float)(rank + 1) - c, c, (float)(rank + 1) * 2.f};
+    }
+    if (a.xr_algo == 1 && world == 2) xr_allreduce_pair<11>(regions, rank, net, tid, gtag, pk, &dead, result + 1);
+    else xr_allreduce<11, true>(regions, rank, world, net, tid, gtag, pk, &dead, result + 1);
+    const float tri = 0.5f * (float)(world + 1);
+#pragma unroll
+    for (int v = 0; v < 11; ++v) {
+      const float c = (float)((gtag + 3u * v + tid + 5u * net) & 15u);
+      const f4 want = {tri + c, tri - c, c, 2.f * tri};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bad += fabsf(pk[v][e] - want[e]) > 1e-4f ? 1 : 0;
+    }
+  }
+  if (bad) atomicAdd(result, bad);
+}
+
 int pick_kin(int D) { return D <= 16 ? 16 : D <= 32 ? 32 : D <= 64 ? 64 : 128; }
 
 unsigned long long* g_prof_buf = nullptr;
 
-template <bool PERSIST, int AMODE = 0>
+template <bool PERSIST, int AMODE = 0, int XR = 0>
 int launch_update(const UpdArgs& a, int blocks, hipStream_t st) {
   const int kin = pick_kin(a.cfg.obs_dim);
   if (PERSIST && AMODE == 0 && a.prof && kin == 64) {
@@ -841,12 +1095,12 @@ int launch_update(const UpdArgs& a, int blocks, hipStream_t st) {
     const size_t sh = UpdLds<K>::SIZE * sizeof(float);                                                  \
     static bool attr_done = false;                                                                      \
     if (!attr_done) {                                                                                   \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_update_kernel<K, PERSIST, false, AMODE>), \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_update_kernel<K, PERSIST, false, AMODE, XR>), \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);          \
       if (e != hipSuccess) return spo::hip_check(e, "hipFuncSetAttribute(update)");                     \
       attr_done = true;                                                                                 \
     }                                                                                                   \
-    hipLaunchKernelGGL((ppo_update_kernel<K, PERSIST, false, AMODE>), dim3(PERSIST ? 8 * (blocks - 1) + 1 : blocks), \
+    hipLaunchKernelGGL((ppo_update_kernel<K, PERSIST, false, AMODE, XR>), dim3(PERSIST ? 8 * (blocks - 1) + 1 : blocks), \
                        dim3(256), sh, st, a);                                                          \
   }
   if (kin == 16) SPO_LAUNCH(16) else if (kin == 32) SPO_LAUNCH(32) else if (kin == 64) SPO_LAUNCH(64) else SPO_LAUNCH(128)
@@ -954,6 +1208,119 @@ extern "C" int spo_update_iter_ex(float* theta, float* adam_m, float* adam_v, in
     if (int rc = launch_update<true, 0>(a, a.n_nets, st)) return rc;
   }
   SPO_LAUNCH_CHECK("spo_update_iter_ex");
+  return 0;
+}
+
+// ---- data-parallel persistent form: cross-rank exchange regions and the per-iteration launch
+static int fill_xr(UpdArgs& a, int rank, int world, void* const* regions, unsigned step0) {
+  SPO_REQUIRE(world >= 2 && world <= XR_MAX_WORLD && rank >= 0 && rank < world, "p2p: bad rank/world %d/%d", rank, world);
+  SPO_REQUIRE(regions != nullptr, "p2p: regions is NULL");
+  for (int r = 0; r < world; ++r) SPO_REQUIRE(regions[r] != nullptr, "p2p: region of rank %d is NULL", r);
+  a.xr_rank = rank; a.xr_world = world; a.xr_step0 = step0;
+  const char* algo = getenv("SPO_P2P_ALGO");                 // "twophase" forces the reduce-scatter form everywhere
+  a.xr_algo = (algo && !strcmp(algo, "twophase")) ? 0 : 1;
+  for (int r = 0; r < XR_MAX_WORLD; ++r) a.xr_region[r] = r < world ? regions[r] : nullptr;
+  return 0;
+}
+
+extern "C" int spo_debug_xr_profile(unsigned long long* out8_host, int reset) {
+  SPO_REQUIRE(out8_host, "xr_profile: null pointer");
+  if (int rc = spo::hip_check(hipMemcpyFromSymbol(out8_host, HIP_SYMBOL(g_xr_prof), 64), "hipMemcpyFromSymbol")) return rc;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    return spo::hip_check(hipMemcpyToSymbol(HIP_SYMBOL(g_xr_prof), z, 64), "hipMemcpyToSymbol");
+  }
+  return 0;
+}
+
+extern "C" int64_t spo_p2p_region_bytes(void) { return (int64_t)XR_REGION_BYTES; }
+
+extern "C" int spo_p2p_alloc(void** region_out, void* ipc_handle64_out) {
+  SPO_REQUIRE(region_out && ipc_handle64_out, "p2p_alloc: null pointer");
+  void* p = nullptr;
+  // SPO_P2P_MEM = uncached (default) | finegrained | coarse (single-GPU experiments only: not coherent across GPUs)
+  const char* kind = getenv("SPO_P2P_MEM");
+  hipError_t e = hipErrorUnknown;
+  if (kind && !strcmp(kind, "coarse")) {
+    e = hipMalloc(&p, XR_REGION_BYTES);
+  } else {
+    if (!(kind && !strcmp(kind, "finegrained"))) e = hipExtMallocWithFlags(&p, XR_REGION_BYTES, hipDeviceMallocUncached);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      e = hipExtMallocWithFlags(&p, XR_REGION_BYTES, hipDeviceMallocFinegrained);
+    }
+  }
+  if (e != hipSuccess) return spo::hip_check(e, "hipExtMallocWithFlags(p2p region)");
+  if (int rc = spo::hip_check(hipMemset(p, 0, XR_REGION_BYTES), "hipMemset(p2p region)")) { (void)hipFree(p); return rc; }
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+  hipIpcMemHandle_t h;
+  e = hipIpcGetMemHandle(&h, p);
+  if (e != hipSuccess) { (void)hipFree(p); return spo::hip_check(e, "hipIpcGetMemHandle"); }
+  std::memcpy(ipc_handle64_out, &h, 64);
+  *region_out = p;
+  return 0;
+}
+
+extern "C" int spo_p2p_open(const void* ipc_handle64, void** region_out) {
+  SPO_REQUIRE(ipc_handle64 && region_out, "p2p_open: null pointer");
+  hipIpcMemHandle_t h;
+  std::memcpy(&h, ipc_handle64, 64);
+  void* p = nullptr;
+  if (int rc = spo::hip_check(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle")) return rc;
+  *region_out = p;
+  return 0;
+}
+
+extern "C" int spo_p2p_close(void* peer_region) {
+  if (!peer_region) return 0;
+  return spo::hip_check(hipIpcCloseMemHandle(peer_region), "hipIpcCloseMemHandle");
+}
+
+extern "C" int spo_p2p_free(void* own_region) {
+  if (!own_region) return 0;
+  return spo::hip_check(hipFree(own_region), "hipFree(p2p region)");
+}
+
+extern "C" int spo_p2p_selftest(int rank, int world, void* const* regions, uint32_t step0, int iters,
+                                int32_t* result2_dev, void* stream) {
+  SPO_REQUIRE(result2_dev && iters > 0, "p2p_selftest: bad args");
+  UpdArgs a{};
+  if (int rc = fill_xr(a, rank, world, regions, step0)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = spo::hip_check(hipMemsetAsync(result2_dev, 0, 8, st), "hipMemsetAsync(selftest)")) return rc;
+  hipLaunchKernelGGL(xr_selftest_kernel, dim3(17), dim3(256), 0, st, rank, world, step0, iters, result2_dev, a);
+  SPO_LAUNCH_CHECK("spo_p2p_selftest");
+  return 0;
+}
+
+extern "C" int spo_ppo_lag_update_iter_dp(float* theta, float* adam_m, float* adam_v, int64_t adam_step_host,
+                                          const float* obs, const float* act, const float* logp_old,
+                                          const float* target_r, const float* target_c, const float* adv,
+                                          const int32_t* perm, int64_t M, const spo_ppo_cfg* cfg_host, float* losses_out,
+                                          void* sync_ws, int rank, int world, void* const* regions, uint32_t step0,
+                                          void* stream) {
+  if (int rc = check_cfg(cfg_host)) return rc;
+  SPO_REQUIRE(theta && adam_m && adam_v && obs && act && logp_old && target_r && target_c && adv && perm &&
+                  losses_out && sync_ws, "update_iter_dp: null pointer");
+  SPO_REQUIRE(M > 0 && adam_step_host >= 0, "update_iter_dp: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = spo::hip_check(hipMemsetAsync(sync_ws, 0, 72, st), "hipMemsetAsync(sync_ws)")) return rc;
+  UpdArgs a{};
+  if (int rc = fill_xr(a, rank, world, regions, step0)) return rc;
+  a.theta = theta; a.adam_m = adam_m; a.adam_v = adam_v;
+  a.obs = obs; a.act = act; a.logp_old = logp_old; a.tgt_r = target_r; a.tgt_c = target_c; a.adv = adv;
+  a.perm = perm; a.M = M; a.cfg = *cfg_host; a.losses = losses_out;
+  a.slots = reinterpret_cast<unsigned long long*>(sync_ws);
+  a.err = reinterpret_cast<int*>(reinterpret_cast<char*>(sync_ws) + 64);
+  a.pow_b1 = pow((double)cfg_host->beta1, (double)adam_step_host);
+  a.pow_b2 = pow((double)cfg_host->beta2, (double)adam_step_host);
+  a.pow_b1_actor = a.pow_b1; a.pow_b2_actor = a.pow_b2;
+  a.first_net = 0; a.n_nets = 3; a.stale_sq = 0.f; a.stale_io = nullptr;
+  int rc = 0;
+  if (a.xr_algo == 1 && world == 2) rc = launch_update<true, 0, 2>(a, 3, st);
+  else rc = launch_update<true, 0, 1>(a, 3, st);
+  if (rc) return rc;
+  SPO_LAUNCH_CHECK("spo_ppo_lag_update_iter_dp");
   return 0;
 }
 

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPO_LIB") or os.path.join(_HERE, "_lib", "libsafepo_hip.so")   # SPO_LIB: debug override
@@ -56,6 +56,15 @@ PROTOTYPES = {
     "spo_critic_fit_iter": (c_int, [P, P, P, c_int64, P, P, P, P, c_int64, POINTER(PpoCfg), P, P, P, P]),
     "spo_update_iter_ex": (c_int, [P, P, P, c_int64, c_int64, P, P, P, P, P, P, P, c_int64, POINTER(PpoCfg), c_int, P, P,
                                    c_float, c_float, c_int, P, P, P]),
+    "spo_p2p_region_bytes": (c_int64, []),
+    "spo_debug_xr_profile": (c_int, [P, c_int]),
+    "spo_p2p_alloc": (c_int, [POINTER(c_void_p), P]),
+    "spo_p2p_open": (c_int, [P, POINTER(c_void_p)]),
+    "spo_p2p_close": (c_int, [P]),
+    "spo_p2p_free": (c_int, [P]),
+    "spo_p2p_selftest": (c_int, [c_int, c_int, POINTER(c_void_p), c_uint32, c_int, P, P]),
+    "spo_ppo_lag_update_iter_dp": (c_int, [P, P, P, c_int64, P, P, P, P, P, P, P, c_int64, POINTER(PpoCfg), P, P,
+                                           c_int, c_int, POINTER(c_void_p), c_uint32, P]),
     "spo_ma_gae": (c_int, [P] * 7 + [c_int64, c_int64, c_double, c_double, c_float, c_float, c_float, c_float, P]),
     "spo_param_count": (c_int64, [c_int, c_int]),
     "spo_param_offset": (c_int64, [c_int, c_int, c_int]),

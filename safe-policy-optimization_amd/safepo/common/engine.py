@@ -73,6 +73,15 @@ class PPOLagEngine:
         self.flat_grad = torch.zeros(P, **f32)
         self.losses3 = torch.zeros(3, **f32)
         self._losses = None
+        # data-parallel: in-kernel exchange over peer-mapped regions when available (every rank must hold the same
+        # number of rows), else the RCCL form
+        self.p2p = None
+        if self.comm.world_size > 1:
+            from safepo.parallel import PeerExchange
+            rows = torch.tensor([float(self.M), -float(self.M)], device=self.dev)
+            self.comm.all_reduce_max_(rows)
+            if rows[0].item() == -rows[1].item():
+                self.p2p = PeerExchange.try_create(self.comm, self.dev)
         self.rew_deque, self.cost_deque, self.len_deque = deque(maxlen=50), deque(maxlen=50), deque(maxlen=50)
 
     # ------------------------------------------------------------------ collect
@@ -180,7 +189,19 @@ class PPOLagEngine:
         st = _abi.stream_ptr()
         th = self.policy.theta
         import os
-        if self.comm.world_size == 1 and os.environ.get("SPO_FORCE_DP", "0") != "1":
+        if self.comm.world_size > 1 and self.p2p is not None:
+            px = self.p2p
+            _abi.check(self.lib.spo_ppo_lag_update_iter_dp(
+                _abi.ptr(th), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), self.adam_step, _abi.ptr(d["obs"]),
+                _abi.ptr(d["act"]), _abi.ptr(d["log_prob"]), _abi.ptr(d["target_value_r"]),
+                _abi.ptr(d["target_value_c"]), _abi.ptr(b.adv_mix), _abi.ptr(perm), M, cfg, _abi.ptr(losses),
+                _abi.ptr(self.sync_ws), px.rank, px.world, px.regions, px.step & 0xFFFFFFFF, st),
+                "spo_ppo_lag_update_iter_dp")
+            px.step += n_mb
+            self.adam_step += n_mb
+            self.comm.all_reduce_sum_(losses)
+            losses *= 1.0 / self.comm.world_size
+        elif self.comm.world_size == 1 and os.environ.get("SPO_FORCE_DP", "0") != "1":
             _abi.check(self.lib.spo_ppo_lag_update_iter(
                 _abi.ptr(th), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), self.adam_step, _abi.ptr(d["obs"]),
                 _abi.ptr(d["act"]), _abi.ptr(d["log_prob"]), _abi.ptr(d["target_value_r"]),
@@ -297,7 +318,11 @@ class PPOLagEngine:
                 "second_stage_losses": losses2}
 
     def check_sync_error(self):
-        if int(self.sync_ws[8].item()) & 0xFFFFFFFF:
+        code = int(self.sync_ws[8].item()) & 0xFFFFFFFF
+        if code == 2:
+            raise _abi.SpoError("update kernel: a peer rank never answered the in-kernel gradient exchange "
+                                "(set SPO_P2P=0 to use the RCCL form)")
+        if code:
             raise _abi.SpoError("update kernel: inter-workgroup exchange timed out")
 
     def update(self, lagrangian_multiplier: float, perm_fn=None):

@@ -90,3 +90,100 @@ def adv_stats_from_sums(sums: torch.Tensor):
     mean_r = float(s[0]) / n
     var = max((float(s[1]) - float(s[0]) ** 2 / n) / (n - 1.0), 0.0)
     return mean_r, var ** 0.5, float(s[2]) / n
+
+
+class PeerExchange:
+    """Exchange regions of the in-kernel data-parallel update (include/safepo_hip.h section (e), csrc/update.hip
+    xr_allreduce): one uncached device region per rank, mapped into every peer through an IPC handle, so the
+    persistent update kernel can push / reduce the per-minibatch gradient over xGMI inside the step instead of
+    leaving the kernel for an RCCL call 327 680 times per epoch.  `step` is the tag base (optimiser steps taken
+    through the regions), advanced by the caller identically on every rank."""
+
+    MAX_WORLD = 8
+
+    def __init__(self, comm: Comm, device: torch.device):
+        import ctypes
+        from safepo import _abi
+        self._abi, self._ct = _abi, ctypes
+        self.lib = _abi.load()
+        self.comm, self.device = comm, device
+        self.world, self.rank = comm.world_size, comm.rank
+        if not (2 <= self.world <= self.MAX_WORLD):
+            raise _abi.SpoError(f"PeerExchange: world size {self.world} outside [2, {self.MAX_WORLD}]")
+        self.step = 0
+        self.own = ctypes.c_void_p()
+        self.regions = (ctypes.c_void_p * self.MAX_WORLD)()
+        self._opened = []
+        handle = (ctypes.c_ubyte * 64)()
+        ok = 1
+        try:
+            _abi.check(self.lib.spo_p2p_alloc(ctypes.byref(self.own), handle), "spo_p2p_alloc")
+        except _abi.SpoError as e:
+            ok, self._why = 0, str(e)
+        # handles travel through the job's own process group (GPU tensors for nccl, CPU tensors for gloo)
+        coll_dev = device if dist.get_backend(comm.group) == "nccl" else torch.device("cpu")
+        mine = torch.tensor(list(bytes(handle)) + [ok], dtype=torch.uint8, device=coll_dev)
+        gathered = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(gathered, mine, group=comm.group)
+        gathered = [g.cpu() for g in gathered]
+        if all(int(g[64]) == 1 for g in gathered):
+            for r in range(self.world):
+                if r == self.rank:
+                    self.regions[r] = self.own
+                    continue
+                buf = (ctypes.c_ubyte * 64)(*gathered[r][:64].tolist())
+                ptr = ctypes.c_void_p()
+                try:
+                    _abi.check(self.lib.spo_p2p_open(buf, ctypes.byref(ptr)), "spo_p2p_open")
+                    self.regions[r] = ptr
+                    self._opened.append(ptr)
+                except _abi.SpoError as e:
+                    ok, self._why = 0, str(e)
+                    break
+        else:
+            ok = 0
+        flag = torch.tensor([float(ok)], device=coll_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=comm.group)
+        self.ok = bool(flag.item() == 1.0)
+        self._result = torch.zeros(2, dtype=torch.int32, device=device)
+
+    def selftest(self, iters: int = 200) -> bool:
+        """Run the exchange protocol on known patterns on every rank; True only if every rank saw every value right."""
+        if not self.ok:
+            return False
+        _abi = self._abi
+        _abi.check(self.lib.spo_p2p_selftest(self.rank, self.world, self.regions, self.step & 0xFFFFFFFF, iters,
+                                             _abi.ptr(self._result), _abi.stream_ptr()), "spo_p2p_selftest")
+        self.step += iters
+        bad, timeout = self._result.tolist()
+        coll_dev = self.device if dist.get_backend(self.comm.group) == "nccl" else torch.device("cpu")
+        flag = torch.tensor([1.0 if (bad == 0 and timeout == 0) else 0.0], device=coll_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.comm.group)
+        self.ok = bool(flag.item() == 1.0)
+        self.last_selftest = (bad, timeout)
+        return self.ok
+
+    def close(self) -> None:
+        for ptr in self._opened:
+            self.lib.spo_p2p_close(ptr)
+        self._opened = []
+        if self.own:
+            self.lib.spo_p2p_free(self.own)
+            self.own = self._ct.c_void_p()
+        self.ok = False
+
+    @classmethod
+    def try_create(cls, comm: Comm, device, verbose: bool = True):
+        """Regions + self-test, or None (with a note on stderr) when peer mapping is not available: the caller then
+        uses the kernel / RCCL all-reduce / kernel form of the step."""
+        import sys
+        if comm.world_size < 2 or comm.world_size > cls.MAX_WORLD or os.environ.get("SPO_P2P", "1") == "0":
+            return None
+        px = cls(comm, torch.device(device))
+        if px.ok and px.selftest():
+            return px
+        if verbose and comm.rank == 0:
+            print(f"[safepo] in-kernel gradient exchange unavailable ({getattr(px, '_why', getattr(px, 'last_selftest', ''))}); "
+                  "using the RCCL all-reduce form of the minibatch step", file=sys.stderr)
+        px.close()
+        return None

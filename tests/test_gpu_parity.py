@@ -1092,3 +1092,29 @@ def test_multi_agent_masked_gae_popart_bit_exact(dev, golden_dir, tag):
     buf.compute_cost_returns(g("next_c").to(dev), norm)
     assert np.array_equal(buf.returns.cpu().numpy().view(np.uint32), z[f"{tag}_returns"].view(np.uint32))
     assert np.array_equal(buf.cost_returns.cpu().numpy().view(np.uint32), z[f"{tag}_cost_returns"].view(np.uint32))
+
+
+@pytest.mark.parametrize("algo", ["pair", "twophase"])
+def test_in_kernel_gradient_exchange_two_ranks_one_gpu(dev, tmp_path, algo):
+    """SURVEY.md 8(e) in-kernel form: two ranks (two processes, this one GPU, regions mapped through IPC handles) run
+    the data-parallel persistent kernel.  Replicas must stay bit-identical and match the kernel / all-reduce / kernel
+    form of the same steps."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    out = tmp_path / "p2p.json"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SPO_P2P_ALGO=algo)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "p2p_worker.py"), str(out), "1000", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = json.load(open(out))
+    assert res["p2p_created"], res
+    assert res["selftest"] == [0, 0], res
+    assert res["replicas_identical"] and res["finite"], res
+    assert res["frac_outside_1e-5"] <= 1e-3 and res["max_abs_diff_vs_allreduce_form"] < 2e-3, res
+    assert res["loss_max_abs_diff"] < 1e-4, res
+    print("p2p", res)
