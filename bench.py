@@ -8,7 +8,8 @@ One "step" = one epoch of BASELINE.json config[1] per GPU: 4096 synthetic envs x
 (obs 60, act 8), device-resident env, collect -> fused reward/cost GAE -> 40 learning iterations
 of 8192 minibatches of 64 (default_cfg of the reference, ppo_lag.py:45-52; KL early stopping
 disabled so the work per step is fixed).  N > 1: one process per GPU, 4096 envs per
-rank (weak scaling), flat-gradient all-reduce (RCCL) at every minibatch step.
+rank (weak scaling); the per-minibatch gradient all-reduce runs inside the persistent update kernel over
+IPC-mapped peer regions (xGMI), or through RCCL between kernels when peer mapping is unavailable.
 Prints ONE JSON line (rank 0) with the driver's fields plus `roofline` (GAE scan kernel, HBM
 bound, 33 algorithmic bytes per (env, step)) and `cpu_baseline` (oracle port of the reference
 loop timed on host cores, rank 0 at N=1 only).
@@ -85,10 +86,13 @@ def main():
     from safepo.common.model import ActorVCritic
     from safepo.parallel import init_from_env
 
-    comm = init_from_env()
+    # SPO_BENCH_ONE_GPU=1 (development aid): all ranks share cuda:0 with gloo for the host collectives, to exercise the
+    # N > 1 code path -- including the in-kernel exchange through IPC-mapped regions -- on a single-GPU box.
+    one_gpu = os.environ.get("SPO_BENCH_ONE_GPU", "0") == "1"
+    comm = init_from_env(backend="gloo" if one_gpu else None)
     world = comm.world_size
     assert world == max(a.gpus, 1) or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     torch.manual_seed(0)
@@ -169,7 +173,8 @@ def main():
     pmc_path = os.path.join(ROOT, "profiles", "r01_gae_pmc.json")
     if os.path.exists(pmc_path):
         try:
-            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch_n4096")
+            # PMC counters were collected (separate rocprofv3 passes) for the 4096 x 128 launch only
+            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch_n4096") if (N, T) == (4096, 128) else None
         except Exception:
             traffic = None
     roofline = {"kernel": "gae_kernel<4,32> (spo_gae_fused)", "bound": "hbm", "achieved": round(achieved, 1),
@@ -213,7 +218,10 @@ def main():
                                (f"cpo synthetic env (obs=60, act=8), num_envs={N}, num_steps={T}, default_cfg "
                                 f"(15 CG iters, 33 FVPs, line search, critic fit batch 128 x 10 iters), device-resident env"),
                    "global_envs": world * N,
-                   "parallelism": f"dp{world} over num_envs, per-minibatch flat-grad all-reduce" if world > 1 else "single GPU",
+                   "parallelism": (f"dp{world} over num_envs, per-minibatch gradient all-reduce "
+                                   + ("inside the persistent update kernel over IPC-mapped peer regions (xGMI)"
+                                      if getattr(eng, "p2p", None) is not None else "via RCCL between kernels"))
+                   if world > 1 else "single GPU",
                    "minibatch_steps_per_epoch": n_mb * a.learning_iters},
         "roofline": roofline,
         "roofline_hbm_streaming": stream,
