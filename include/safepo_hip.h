@@ -264,6 +264,55 @@ int spo_synth_env_step(float* next_obs, float* final_obs, float* reward, float* 
                        float* truncated, int* t_env, int64_t num_envs, int obs_dim, uint64_t seed,
                        uint64_t step, float p_term, float p_cost, int trunc_len, void* stream);
 
+/* ---- f3: multi-agent MAPPO-L networks and update (csrc/ma_net.hip).
+ * Networks: safepo/common/model.py:172-363 + safepo/utils/{mlp,act,distributions}.py -- LayerNorm(obs), then n_blocks x
+ * [Linear -> ELU -> LayerNorm], then a Linear head (actor: action mean, with a state-independent
+ * std = sigmoid(log_std / std_x_coef) * std_y_coef; critics: one value).  One flat fp32 parameter vector per network in the
+ * reference's state_dict order (spo_ma_param_offset: which = 0 feature_norm.weight, 1 feature_norm.bias, 2 W_k, 3 b_k,
+ * 4 ln_k.weight, 5 ln_k.bias, 6 log_std, 7 head W, 8 head b).  GEMMs run on rocBLAS (dlopen'ed on first use).
+ * spo_ma_forward keeps the activations of `rows` rows in ws (spo_ma_workspace_floats) for spo_ma_backward, which turns
+ * d(loss)/d(head output) into the flat gradient (log_std's entry is owned by spo_ma_actor_loss).
+ * Trainer pieces (safepo/multi_agent/mappolag.py:126-199): spo_ma_actor_loss = clipped surrogate on
+ * imp = prod_a exp(logp_a - old_a) with the hybrid advantage adv - lamda*cost_adv, HAPPO factor, active masks and entropy
+ * bonus; scalars5_out = {policy_loss, dist_entropy, mean(imp), mean(imp*cost_adv), sum(active)};
+ * spo_ma_lamda_update = the in-loop multiplier step; spo_ma_popart_forward = PopArt.forward (popart.py:86-112) on a
+ * [rows] vector, state3 = {running_mean, running_mean_sq, debiasing_term}; spo_ma_value_loss = max of the clipped /
+ * unclipped Huber losses (util.huber_loss, including its zero branch for e < -delta) with separately normalised targets;
+ * spo_ma_clip_adam = clip_grad_norm_ + torch.optim.Adam(lr, eps, weight_decay) on one network. */
+typedef struct spo_ma_net {
+  int32_t in_dim, hidden, n_blocks, out_dim, is_actor;
+} spo_ma_net;
+typedef struct spo_ma_loss_cfg {
+  float clip_param, entropy_coef, std_x_coef, std_y_coef;
+  int32_t use_policy_active_masks;
+} spo_ma_loss_cfg;
+int64_t spo_ma_param_count(const spo_ma_net* net);
+int64_t spo_ma_param_offset(const spo_ma_net* net, int which, int block);
+int64_t spo_ma_workspace_floats(const spo_ma_net* net, int64_t rows);
+int64_t spo_ma_backward_scratch_floats(const spo_ma_net* net, int64_t rows);
+int spo_ma_forward(const float* theta, const spo_ma_net* net, const float* x, int64_t rows, float* ws, float* out,
+                   void* stream);
+int spo_ma_backward(const float* theta, const spo_ma_net* net, const float* x, int64_t rows, const float* ws,
+                    const float* dout, float* grad, float* scratch, void* stream);
+int spo_ma_sample(const float* mean, const float* log_std, const float* eps, float std_x_coef, float std_y_coef,
+                  int deterministic, float* act_out, float* logp_out, int64_t rows, int act_dim, void* stream);
+int spo_ma_log_probs(const float* mean, const float* log_std, const float* act, float std_x_coef, float std_y_coef,
+                     float* logp_out, int64_t rows, int act_dim, void* stream);
+int spo_ma_actor_loss(const float* mean, const float* log_std, const float* act, const float* old_logp, const float* adv,
+                      const float* cost_adv, const float* factor, const float* active, const float* lamda_dev,
+                      const spo_ma_loss_cfg* cfg, int64_t rows, int act_dim, float active_sum_host, float* dmean_out,
+                      float* dlogstd_out, float* scalars5_out, double* partial_ws, void* stream);
+int spo_ma_lamda_update(float* lamda_dev, const float* scalars5, float aver_episode_cost, float cost_limit, float gamma,
+                        float lagrangian_coef_rate, void* stream);
+int spo_ma_popart_forward(const float* x, int64_t rows, float* state3, float beta, float epsilon, int train, float* out,
+                          double* partial_ws, void* stream);
+int spo_ma_value_loss(const float* values, const float* value_preds, const float* returns_norm_clipped,
+                      const float* returns_norm_original, float clip_param, float huber_delta, float value_loss_coef,
+                      int64_t rows, float* dvalues_out, float* loss_out, double* partial_ws, void* stream);
+int spo_ma_clip_adam(float* theta, const float* grad, float* adam_m, float* adam_v, int64_t n, int64_t adam_step_host,
+                     float lr, float adam_eps, float weight_decay, float max_grad_norm, int use_max_grad_norm,
+                     float* grad_norm_out, double* partial_ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

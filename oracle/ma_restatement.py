@@ -1,0 +1,196 @@
+"""TEST INFRASTRUCTURE -- CPU restatement of the multi-agent MAPPO-L networks and trainer step.
+
+Only tests/ may import this file (checker, never the product).  Pinned by tests/test_oracle_golden.py against
+tests/golden/ma_mappolag.npz, which oracle/make_golden.py::golden_ma_mappolag produced by running the reference's own
+MAPPO_L_Policy / MAPPO_L_Trainer here.  Each function cites the reference lines it restates.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+
+class MANet(nn.Module):
+    """MLPBase + head (safepo/utils/mlp.py:1-71; safepo/common/model.py:218-224, 322-331):
+    LayerNorm(in) -> n_blocks x [Linear, ELU, LayerNorm(hidden)] -> Linear(hidden, out).  Actor nets own `log_std`
+    (safepo/utils/distributions.py:36-37); std = sigmoid(log_std / x_coef) * y_coef (distributions.py:41).
+    Parameter registration order equals the reference's state_dict order."""
+
+    def __init__(self, in_dim, hidden, n_blocks, out_dim, is_actor, std_x_coef=1.0, std_y_coef=0.5):
+        super().__init__()
+        self.feature_norm = nn.LayerNorm(in_dim)
+        self.linears = nn.ModuleList()
+        self.norms = nn.ModuleList()
+        # interleave registration: W_k, b_k, ln_k.weight, ln_k.bias
+        self.blocks = nn.ModuleList()
+        d = in_dim
+        for _ in range(n_blocks):
+            self.blocks.append(nn.ModuleList([nn.Linear(d, hidden), nn.LayerNorm(hidden)]))
+            d = hidden
+        self.is_actor = bool(is_actor)
+        if self.is_actor:
+            self.log_std = nn.Parameter(torch.ones(out_dim) * std_x_coef)
+        self.head = nn.Linear(hidden, out_dim)
+        self.xc, self.yc = std_x_coef, std_y_coef
+
+    def ordered_parameters(self):
+        ps = [self.feature_norm.weight, self.feature_norm.bias]
+        for lin, ln in self.blocks:
+            ps += [lin.weight, lin.bias, ln.weight, ln.bias]
+        if self.is_actor:
+            ps.append(self.log_std)
+        ps += [self.head.weight, self.head.bias]
+        return ps
+
+    def load_reference_state_dict(self, sd: dict):
+        """`sd`: state_dict of the reference MultiAgentActor / MultiAgentCritic (same order as ordered_parameters)."""
+        vals = list(sd.values())
+        ps = self.ordered_parameters()
+        assert len(vals) == len(ps), (len(vals), len(ps))
+        with torch.no_grad():
+            for p, v in zip(ps, vals):
+                p.copy_(torch.as_tensor(v).reshape(p.shape))
+
+    def flat(self) -> torch.Tensor:
+        return torch.cat([p.detach().reshape(-1) for p in self.ordered_parameters()])
+
+    def flat_grad(self) -> torch.Tensor:
+        return torch.cat([p.grad.reshape(-1) for p in self.ordered_parameters()])
+
+    def forward(self, x):
+        h = self.feature_norm(x)
+        for lin, ln in self.blocks:
+            h = ln(nn.functional.elu(lin(h)))
+        return self.head(h)
+
+    def std(self):
+        return torch.sigmoid(self.log_std / self.xc) * self.yc
+
+
+def log_probs(mean, std, act):
+    """FixedNormal.log_probs: per-dimension Normal.log_prob (distributions.py:9-11)."""
+    return torch.distributions.Normal(mean, std).log_prob(act)
+
+
+def huber_loss(e, d):
+    """safepo/utils/util.py huber_loss (the branch for e < -d contributes nothing)."""
+    a = (e.abs() <= d).float()
+    b = (e > d).float()
+    return a * e ** 2 / 2 + b * d * (e.abs() - d / 2)
+
+
+class OraclePopArt:
+    """safepo/common/popart.py:45-133 with input_shape 1."""
+
+    def __init__(self, beta=0.99999, epsilon=1e-5):
+        self.beta, self.epsilon = beta, epsilon
+        self.running_mean = torch.zeros(1)
+        self.running_mean_sq = torch.zeros(1)
+        self.debiasing_term = torch.tensor(0.0)
+
+    def mean_var(self):
+        dm = self.running_mean / self.debiasing_term.clamp(min=self.epsilon)
+        dsq = self.running_mean_sq / self.debiasing_term.clamp(min=self.epsilon)
+        return dm, (dsq - dm ** 2).clamp(min=1e-2)
+
+    def __call__(self, x, train=True):
+        if train:
+            d = x.detach()
+            self.running_mean.mul_(self.beta).add_(d.mean(dim=0) * (1.0 - self.beta))
+            self.running_mean_sq.mul_(self.beta).add_((d ** 2).mean(dim=0) * (1.0 - self.beta))
+            self.debiasing_term.mul_(self.beta).add_(1.0 * (1.0 - self.beta))
+        m, v = self.mean_var()
+        return (x - m[None]) / torch.sqrt(v)[None]
+
+    def denormalize(self, x):
+        m, v = self.mean_var()
+        return (x * torch.sqrt(v)[None] + m[None]).detach()
+
+
+class OracleMATrainer:
+    """MAPPO_L_Policy optimisers (mappolag.py:57-66) + MAPPO_L_Trainer.ppo_update (mappolag.py:140-199)."""
+
+    def __init__(self, cfg: dict, actor: MANet, critic: MANet, cost_critic: MANet):
+        self.cfg, self.actor, self.critic, self.cost_critic = cfg, actor, critic, cost_critic
+        mk = lambda net, lr: torch.optim.Adam(net.ordered_parameters(), lr=lr, eps=cfg["opti_eps"], weight_decay=cfg["weight_decay"])
+        self.opt_a, self.opt_r, self.opt_c = mk(actor, cfg["actor_lr"]), mk(critic, cfg["critic_lr"]), mk(cost_critic, cfg["critic_lr"])
+        self.popart = OraclePopArt()
+        self.lamda = torch.tensor(float(cfg["lamda_lagr"]))
+
+    def value_loss(self, values, value_preds, returns):
+        c = self.cfg
+        vpc = value_preds + (values - value_preds).clamp(-c["clip_param"], c["clip_param"])
+        e_c = self.popart(returns) - vpc              # each call updates the statistics (mappolag.py:129-130)
+        e_o = self.popart(returns) - values
+        return torch.max(huber_loss(e_o, c["huber_delta"]), huber_loss(e_c, c["huber_delta"])).mean()
+
+    def ppo_update(self, s: dict):
+        c = self.cfg
+        mean = self.actor(s["obs"])
+        std = self.actor.std()
+        logp = log_probs(mean, std, s["actions"])
+        ent = torch.distributions.Normal(mean, std.expand_as(mean)).entropy()
+        if c["use_policy_active_masks"]:
+            dist_entropy = (ent * s["active_masks"]).sum() / s["active_masks"].sum()
+        else:
+            dist_entropy = ent.mean()
+        values, cost_values = self.critic(s["share_obs"]), self.cost_critic(s["share_obs"])
+        adv_h = s["adv"] - self.lamda * s["cost_adv"]
+        imp = torch.prod(torch.exp(logp - s["old_logp"]), dim=-1, keepdim=True)
+        surr1 = imp * adv_h
+        surr2 = torch.clamp(imp, 1.0 - c["clip_param"], 1.0 + c["clip_param"]) * adv_h
+        m = torch.sum(s["factor"] * torch.min(surr1, surr2), dim=-1, keepdim=True)
+        if c["use_policy_active_masks"]:
+            policy_loss = (-m * s["active_masks"]).sum() / s["active_masks"].sum()
+        else:
+            policy_loss = -m.mean()
+        self.opt_a.zero_grad()
+        (policy_loss - dist_entropy * c["entropy_coef"]).backward()
+        rec = {"actor_grad": self.actor.flat_grad().clone()}
+        a_norm = nn.utils.clip_grad_norm_(self.actor.ordered_parameters(), c["max_grad_norm"])
+        self.opt_a.step()
+        delta = -((s["aver_episode_costs"].mean() - c["cost_limit"]) * (1 - c["gamma"]) + (imp * s["cost_adv"])).mean().detach()
+        self.lamda = torch.relu(self.lamda - delta * c["lagrangian_coef_rate"])
+        vl = self.value_loss(values, s["value_preds"], s["returns"])
+        self.opt_r.zero_grad()
+        (vl * c["value_loss_coef"]).backward()
+        rec["critic_grad"] = self.critic.flat_grad().clone()
+        r_norm = nn.utils.clip_grad_norm_(self.critic.ordered_parameters(), c["max_grad_norm"])
+        self.opt_r.step()
+        cl = self.value_loss(cost_values, s["cost_preds"], s["cost_returns"])
+        self.opt_c.zero_grad()
+        (cl * c["value_loss_coef"]).backward()
+        rec["cost_grad"] = self.cost_critic.flat_grad().clone()
+        c_norm = nn.utils.clip_grad_norm_(self.cost_critic.ordered_parameters(), c["max_grad_norm"])
+        self.opt_c.step()
+        rec["row"] = [float(vl), float(r_norm), float(policy_loss), float(dist_entropy), float(a_norm), float(imp.mean()),
+                      float(cl), float(c_norm), float(self.lamda), float(self.popart.running_mean),
+                      float(self.popart.running_mean_sq), float(self.popart.debiasing_term)]
+        return rec
+
+
+def nets_from_golden(z, tag: str, which: str = "init"):
+    """Build the three oracle nets of golden case `tag` from tests/golden/ma_mappolag.npz."""
+    H, nb = int(z[f"{tag}_cfg_hidden_size"]), 1 + int(z[f"{tag}_cfg_layer_N"])
+    xc, yc = float(z[f"{tag}_cfg_std_x_coef"]), float(z[f"{tag}_cfg_std_y_coef"])
+    D, S, A = z[f"{tag}_obs"].shape[1], z[f"{tag}_share_obs"].shape[1], z[f"{tag}_actions"].shape[1]
+    nets = {"actor": MANet(D, H, nb, A, True, xc, yc), "critic": MANet(S, H, nb, 1, False), "cost_critic": MANet(S, H, nb, 1, False)}
+    for nm, net in nets.items():
+        pre = f"{tag}_{which}_{nm}_"
+        net.load_reference_state_dict({k[len(pre):]: z[k] for k in z.files if k.startswith(pre)})
+    return nets
+
+
+def cfg_from_golden(z, tag: str) -> dict:
+    pre = f"{tag}_cfg_"
+    cfg = {k[len(pre):]: float(z[k]) for k in z.files if k.startswith(pre)}
+    cfg["use_policy_active_masks"] = bool(cfg["use_policy_active_masks"])
+    return cfg
+
+
+def sample_from_golden(z, tag: str) -> dict:
+    keys = ["share_obs", "obs", "actions", "value_preds", "returns", "active_masks", "old_logp", "adv", "factor", "cost_preds",
+            "cost_returns", "cost_adv", "aver_episode_costs"]
+    return {k: torch.from_numpy(z[f"{tag}_{k}"].copy()) for k in keys}

@@ -351,6 +351,70 @@ def golden_ma_gae():
     print("ma_gae.npz", len(out), "arrays")
 
 
+def golden_ma_mappolag():
+    """MAPPO-L networks and trainer step: the reference MAPPO_L_Policy / MAPPO_L_Trainer.ppo_update
+    (safepo/multi_agent/mappolag.py:45-199) run on fixed samples, for the default config (no active masks, entropy 0)
+    and the mamujoco overrides (active masks, entropy 0.01)."""
+    import importlib
+    import yaml
+    if ref_shim.REF_ROOT not in sys.path:
+        sys.path.insert(0, ref_shim.REF_ROOT)
+    ref_shim._install_stubs()
+    M = importlib.import_module("safepo.multi_agent.mappolag")
+    base = yaml.safe_load(open(os.path.join(ref_shim.REF_ROOT, "safepo/multi_agent/marl_cfg/mappolag/config.yaml")))
+    out = {}
+    for tag, over in {"default": {}, "mamujoco": dict(base["mamujoco"])}.items():
+        cfg = dict(base)
+        cfg.update(over)
+        cfg.update(device="cpu", hidden_size=64, cost_limit=0.5, lagrangian_coef_rate=0.05, actor_lr=3e-3, critic_lr=3e-3)
+        torch.manual_seed(11)
+        D, S, A, B = 20, 33, 5, 96
+        pol = M.MAPPO_L_Policy(cfg, Space(D), Space(S), Space(A))
+        with torch.no_grad():                      # default init has v_out == 0 and a tiny actor head: perturb so every path is live
+            for net in (pol.actor, pol.critic, pol.cost_critic):
+                for prm in net.parameters():
+                    prm.add_(0.05 * torch.randn_like(prm))
+        tr = M.MAPPO_L_Trainer(cfg, pol)
+        for nm, net in (("actor", pol.actor), ("critic", pol.critic), ("cost_critic", pol.cost_critic)):
+            for k, v in net.state_dict().items():
+                out[f"{tag}_init_{nm}_{k}"] = v.detach().numpy().copy()
+        share_obs, obs = torch.randn(B, S), torch.randn(B, D)
+        with torch.no_grad():
+            values, actions, logp, _, _, cost_preds, _ = pol.get_actions(share_obs, obs, torch.zeros(B, 1, 64), torch.zeros(B, 1, 64),
+                                                                         torch.ones(B, 1), rnn_states_cost=torch.zeros(B, 1, 64))
+            mean = pol.actor.act.action_out(pol.actor.base(obs)).mean
+        out[f"{tag}_fwd_mean"], out[f"{tag}_fwd_values"], out[f"{tag}_fwd_cost_preds"] = mean.numpy(), values.numpy(), cost_preds.numpy()
+        out[f"{tag}_fwd_logp"] = logp.numpy()
+        old_logp = logp + 0.05 * torch.randn(B, A)
+        active = (torch.rand(B, 1) > 0.2).float()
+        sample = (share_obs, obs, torch.zeros(B, 1, 64), torch.zeros(B, 1, 64), actions, values + 0.3 * torch.randn(B, 1),
+                  torch.randn(B, 1) * 2 + 0.5, torch.ones(B, 1), active, old_logp, torch.randn(B, 1), None,
+                  torch.rand(B, 1) + 0.5, cost_preds + 0.3 * torch.randn(B, 1), torch.rand(B, 1) * 3, torch.zeros(B, 1, 64),
+                  torch.randn(B, 1), torch.tensor(0.9))
+        names = ["share_obs", "obs", None, None, "actions", "value_preds", "returns", None, "active_masks", "old_logp", "adv",
+                 None, "factor", "cost_preds", "cost_returns", None, "cost_adv", "aver_episode_costs"]
+        for nme, t in zip(names, sample):
+            if nme:
+                out[f"{tag}_{nme}"] = t.numpy().copy()
+        steps = []
+        for _ in range(3):
+            vl, cgn, plo, ent, agn, imp, cl, cogn = tr.ppo_update(sample)
+            steps.append([float(vl), float(cgn), float(plo), float(ent), float(agn), float(imp.mean()), float(cl), float(cogn),
+                          float(tr.lamda_lagr), float(tr.value_normalizer.running_mean), float(tr.value_normalizer.running_mean_sq),
+                          float(tr.value_normalizer.debiasing_term)])
+        out[f"{tag}_steps"] = np.asarray(steps, np.float64)
+        for nm, net in (("actor", pol.actor), ("critic", pol.critic), ("cost_critic", pol.cost_critic)):
+            for k, v in net.state_dict().items():
+                out[f"{tag}_final_{nm}_{k}"] = v.detach().numpy().copy()
+        for k in ("clip_param", "entropy_coef", "huber_delta", "value_loss_coef", "max_grad_norm", "actor_lr", "critic_lr",
+                  "opti_eps", "weight_decay", "lamda_lagr", "cost_limit", "gamma", "lagrangian_coef_rate", "std_x_coef",
+                  "std_y_coef", "layer_N", "hidden_size"):
+            out[f"{tag}_cfg_{k}"] = np.float64(cfg[k])
+        out[f"{tag}_cfg_use_policy_active_masks"] = np.float64(cfg["use_policy_active_masks"])
+    np.savez_compressed(os.path.join(OUT, "ma_mappolag.npz"), **out)
+    print("ma_mappolag.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
@@ -358,6 +422,7 @@ if __name__ == "__main__":
     golden_model()
     golden_pid()
     golden_ma_gae()
+    golden_ma_mappolag()
     env_kw = dict(obs_dim=60, act_dim=8, p_term=0.03, p_cost=0.3, trunc_len=20)
     golden_trace("ppo_lag", "ppo_lag_trace.npz", num_envs=4, T=48, epochs=3, env_kw=env_kw,
                  cfg_over={"learning_iters": 6, "target_kl": 0.004},

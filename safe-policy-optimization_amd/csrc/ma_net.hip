@@ -1,0 +1,701 @@
+// Multi-agent (MAPPO-L) networks and update -- SURVEY.md 8 f3.
+// Reference: safepo/common/model.py:172-363 (MultiAgentActor / MultiAgentCritic), safepo/utils/mlp.py (MLPBase:
+// LayerNorm(obs) -> [Linear -> ELU -> LayerNorm] x (1 + layer_N)), safepo/utils/distributions.py (DiagGaussian with
+// std = sigmoid(log_std / x_coef) * y_coef), safepo/multi_agent/mappolag.py:115-234 (MAPPO_L_Trainer), popart.py.
+//
+// Regime: unlike the single-agent path (327 680 tiny sequential steps), MAPPO-L makes `learning_iters` (5) FULL-BATCH
+// steps per agent per epoch over episode_length x n_rollout_threads rows with hidden 128..512: plain large GEMMs.
+// The GEMMs go to rocBLAS (loaded lazily with dlopen, so the single-agent library has no rocBLAS load cost); everything
+// around them is fused here: bias + ELU + LayerNorm forward, its backward with the three column reductions, the
+// Gaussian head / clipped HAPPO surrogate / entropy / lambda-delta epilogue, the clipped Huber value loss on
+// PopArt-normalised targets, PopArt statistics, per-network clip_grad_norm_ + Adam.
+//
+// One flat fp32 parameter vector per network in the reference's state_dict order:
+//   feature_norm.{weight,bias}[in], then per block k: W_k[H, in_k], b_k[H], ln_k.weight[H], ln_k.bias[H],
+//   then (actor only) log_std[out], then head W[out, H], head b[out].
+#include <cstdlib>
+#include <cstring>
+#include <dlfcn.h>
+#include "common.h"
+#include "../../include/safepo_hip.h"
+
+namespace {
+
+using spo::fail;
+
+// ---------------------------------------------------------------- rocBLAS through dlopen
+typedef void* rb_handle;
+typedef int (*rb_create_t)(rb_handle*);
+typedef int (*rb_set_stream_t)(rb_handle, hipStream_t);
+typedef int (*rb_sgemm_t)(rb_handle, int, int, int, int, int, const float*, const float*, int, const float*, int,
+                          const float*, float*, int);
+constexpr int RB_N = 111, RB_T = 112;       // rocblas_operation_none / rocblas_operation_transpose
+struct RocBlas {
+  void* lib = nullptr; rb_handle h = nullptr; rb_create_t create = nullptr; rb_set_stream_t set_stream = nullptr;
+  rb_sgemm_t sgemm = nullptr; bool tried = false;
+} g_rb;
+
+int rb_init() {
+  if (g_rb.h) return 0;
+  if (g_rb.tried) return fail(-20, "rocBLAS unavailable (earlier dlopen failed)");
+  g_rb.tried = true;
+  const char* names[] = {"librocblas.so", "librocblas.so.5", "librocblas.so.4", "/opt/rocm/lib/librocblas.so"};
+  for (const char* n : names) {
+    g_rb.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (g_rb.lib) break;
+  }
+  if (!g_rb.lib) return fail(-20, "dlopen(librocblas.so) failed: %s", dlerror());
+  g_rb.create = (rb_create_t)dlsym(g_rb.lib, "rocblas_create_handle");
+  g_rb.set_stream = (rb_set_stream_t)dlsym(g_rb.lib, "rocblas_set_stream");
+  g_rb.sgemm = (rb_sgemm_t)dlsym(g_rb.lib, "rocblas_sgemm");
+  if (!g_rb.create || !g_rb.set_stream || !g_rb.sgemm) return fail(-20, "rocBLAS symbols missing");
+  if (int rc = g_rb.create(&g_rb.h)) return fail(-21, "rocblas_create_handle failed (%d)", rc);
+  return 0;
+}
+
+// Row-major helpers.  Y[B,N] (+)= X[B,K] * W[N,K]^T
+int gemm_xwT(hipStream_t st, const float* X, const float* W, float* Y, int64_t B, int K, int N, float beta = 0.f) {
+  const float alpha = 1.f;
+  if (int rc = g_rb.set_stream(g_rb.h, st)) return fail(-22, "rocblas_set_stream (%d)", rc);
+  if (int rc = g_rb.sgemm(g_rb.h, RB_T, RB_N, N, (int)B, K, &alpha, W, K, X, K, &beta, Y, N)) return fail(-22, "sgemm xwT (%d)", rc);
+  return 0;
+}
+// dX[B,K] = dY[B,N] * W[N,K]
+int gemm_dyw(hipStream_t st, const float* dY, const float* W, float* dX, int64_t B, int K, int N) {
+  const float alpha = 1.f, beta = 0.f;
+  if (int rc = g_rb.set_stream(g_rb.h, st)) return fail(-22, "rocblas_set_stream (%d)", rc);
+  if (int rc = g_rb.sgemm(g_rb.h, RB_N, RB_N, K, (int)B, N, &alpha, W, K, dY, N, &beta, dX, K)) return fail(-22, "sgemm dyw (%d)", rc);
+  return 0;
+}
+// dW[N,K] = dY[B,N]^T * X[B,K]
+int gemm_dyTx(hipStream_t st, const float* dY, const float* X, float* dW, int64_t B, int K, int N) {
+  const float alpha = 1.f, beta = 0.f;
+  if (int rc = g_rb.set_stream(g_rb.h, st)) return fail(-22, "rocblas_set_stream (%d)", rc);
+  if (int rc = g_rb.sgemm(g_rb.h, RB_N, RB_T, K, N, (int)B, &alpha, X, K, dY, N, &beta, dW, K)) return fail(-22, "sgemm dyTx (%d)", rc);
+  return 0;
+}
+
+// ---------------------------------------------------------------- layout
+struct Lay {
+  int D, H, NB, O, actor;
+  int64_t fn_g() const { return 0; }
+  int64_t fn_b() const { return D; }
+  int in_k(int k) const { return k == 0 ? D : H; }
+  int64_t blk(int k) const {          // start of block k
+    int64_t o = 2 * (int64_t)D;
+    for (int i = 0; i < k; ++i) o += (int64_t)H * in_k(i) + 3 * (int64_t)H;
+    return o;
+  }
+  int64_t W(int k) const { return blk(k); }
+  int64_t b(int k) const { return blk(k) + (int64_t)H * in_k(k); }
+  int64_t g(int k) const { return b(k) + H; }
+  int64_t be(int k) const { return g(k) + H; }
+  int64_t logstd() const { return blk(NB); }
+  int64_t hW() const { return blk(NB) + (actor ? O : 0); }
+  int64_t hb() const { return hW() + (int64_t)O * H; }
+  int64_t count() const { return hb() + O; }
+  // workspace (floats) for B rows: xhat[B,D], st0[B,2], per block: a[B,H], st[B,2], y[B,H]
+  int64_t ws_xhat() const { return 0; }
+  int64_t ws_st0(int64_t B) const { return B * D; }
+  int64_t ws_blk(int64_t B, int k) const { return B * D + 2 * B + (int64_t)k * (2 * B * H + 2 * B); }
+  int64_t ws_a(int64_t B, int k) const { return ws_blk(B, k); }
+  int64_t ws_st(int64_t B, int k) const { return ws_blk(B, k) + B * H; }
+  int64_t ws_y(int64_t B, int k) const { return ws_blk(B, k) + B * H + 2 * B; }
+  int64_t ws_count(int64_t B) const { return ws_blk(B, NB); }
+};
+
+int lay_of(const spo_ma_net* n, Lay* L) {
+  if (!n) return fail(-1, "ma: net is NULL");
+  if (n->in_dim < 1 || n->in_dim > 512 || n->hidden < 1 || n->hidden > 512 || n->n_blocks < 1 || n->n_blocks > 8 ||
+      n->out_dim < 1 || n->out_dim > 64)
+    return fail(-2, "ma: net dims out of range (in %d, hidden %d, blocks %d, out %d; limits 512/512/8/64)", n->in_dim,
+                n->hidden, n->n_blocks, n->out_dim);
+  *L = Lay{n->in_dim, n->hidden, n->n_blocks, n->out_dim, n->is_actor ? 1 : 0};
+  return 0;
+}
+
+constexpr float LN_EPS = 1e-5f;
+constexpr int MAXE = 8;       // elements per lane in a row (dims <= 512)
+
+__device__ __forceinline__ float wave_sum_all(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// One wave per row.  MODE 0: y = LN(x)*g + b                      (feature_norm)
+//                    MODE 1: a = ELU(z + bias); y = LN(a)*g + b    (block epilogue; a and the row statistics are kept)
+template <int MODE>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                      const float* __restrict__ g, const float* __restrict__ b,
+                                                      float* __restrict__ a_out, float* __restrict__ y,
+                                                      float* __restrict__ stats, int64_t B, int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < B; row += (int64_t)gridDim.x * 4) {
+    float v[MAXE];
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      const int j = lane + 64 * e;
+      float t = 0.f;
+      if (j < D) {
+        t = x[row * D + j];
+        if (MODE == 1) {
+          t += bias[j];
+          t = t > 0.f ? t : expm1f(t);          // nn.ELU(alpha=1)
+          a_out[row * D + j] = t;
+        }
+      }
+      v[e] = t; s += t;
+    }
+    const float mean = wave_sum_all(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      const int j = lane + 64 * e;
+      const float d = j < D ? v[e] - mean : 0.f;
+      q += d * d;
+    }
+    const float var = wave_sum_all(q) / (float)D;          // biased, as nn.LayerNorm
+    const float rstd = 1.f / sqrtf(var + LN_EPS);
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      const int j = lane + 64 * e;
+      if (j < D) y[row * D + j] = (v[e] - mean) * rstd * g[j] + b[j];
+    }
+    if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+  }
+}
+
+// Backward of y = LN(a)*g + b with a = ELU(z): dz (in place over dy is allowed) and per-block partial column sums
+// of d(ln weight) = sum dy*xhat, d(ln bias) = sum dy, d(linear bias) = sum dz.   MODE 0: feature_norm (no dz: the input
+// needs no gradient), `a` is the raw input x.
+template <int MODE>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ a,
+                                                      const float* __restrict__ stats, const float* __restrict__ g,
+                                                      float* __restrict__ dz, float* __restrict__ partial, int64_t B,
+                                                      int D) {
+  __shared__ float sh[3][4][64 * MAXE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float cg[MAXE], cb[MAXE], cz[MAXE];
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) cg[e] = cb[e] = cz[e] = 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < B; row += (int64_t)gridDim.x * 4) {
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    float xh[MAXE], dxh[MAXE], av[MAXE];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      const int j = lane + 64 * e;
+      float d = 0.f, t = 0.f, gg = 0.f;
+      if (j < D) { d = dy[row * D + j]; t = a[row * D + j]; gg = g[j]; }
+      av[e] = t;
+      xh[e] = j < D ? (t - mean) * rstd : 0.f;
+      dxh[e] = d * gg;
+      cg[e] += d * xh[e]; cb[e] += d;
+      s1 += dxh[e]; s2 += dxh[e] * xh[e];
+    }
+    if (MODE == 1) {
+      const float m1 = wave_sum_all(s1) / (float)D, m2 = wave_sum_all(s2) / (float)D;
+#pragma unroll
+      for (int e = 0; e < MAXE; ++e) {
+        const int j = lane + 64 * e;
+        if (j < D) {
+          const float da = rstd * (dxh[e] - m1 - xh[e] * m2);
+          const float dzv = da * (av[e] > 0.f ? 1.f : av[e] + 1.f);      // ELU' = exp(z) = a + 1 for z <= 0
+          dz[row * D + j] = dzv;
+          cz[e] += dzv;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) { sh[0][wave][lane + 64 * e] = cg[e]; sh[1][wave][lane + 64 * e] = cb[e]; sh[2][wave][lane + 64 * e] = cz[e]; }
+  __syncthreads();
+  for (int j = threadIdx.x; j < D; j += 256)
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+      partial[((int64_t)blockIdx.x * 3 + w) * D + j] = (sh[w][0][j] + sh[w][1][j]) + (sh[w][2][j] + sh[w][3][j]);
+}
+
+// out[w][j] = sum over blocks (fixed order) of partial[block][w][j]
+__global__ void colsum_finish_kernel(const float* __restrict__ partial, int nblocks, int D, float* o0, float* o1, float* o2) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= D) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int b = 0; b < nblocks; ++b) {
+    s0 += partial[((int64_t)b * 3 + 0) * D + j];
+    s1 += partial[((int64_t)b * 3 + 1) * D + j];
+    s2 += partial[((int64_t)b * 3 + 2) * D + j];
+  }
+  if (o0) o0[j] = s0;
+  if (o1) o1[j] = s1;
+  if (o2) o2[j] = s2;
+}
+
+// head: out[B,O] += bias ; db[O] = column sums of dout (second form)
+__global__ void add_bias_kernel(float* __restrict__ out, const float* __restrict__ b, int64_t n, int O) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] += b[i % O];
+}
+__global__ __launch_bounds__(256) void colsum_small_kernel(const float* __restrict__ d, int64_t B, int O, float* __restrict__ out) {
+  // one block per output column (O <= 64), fixed-order tree
+  __shared__ float sh[256];
+  const int o = blockIdx.x;
+  float s = 0.f;
+  for (int64_t r = threadIdx.x; r < B; r += 256) s += d[r * O + o];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[o] = sh[0];
+}
+
+int grid_rows(int64_t B) {
+  int64_t g = (B + 3) / 4;
+  return (int)(g < 1 ? 1 : g > 1024 ? 1024 : g);
+}
+
+constexpr float LOG_SQRT_2PI_F = 0.91893853320467274178f;
+
+// ---------------------------------------------------------------- Gaussian head: sample / evaluate
+// std = sigmoid(log_std / xc) * yc (distributions.py:41); log_probs are PER DIMENSION (FixedNormal.log_probs)
+__global__ void ma_sample_kernel(const float* __restrict__ mean, const float* __restrict__ log_std, const float* __restrict__ eps,
+                                 float xc, float yc, int deterministic, float* __restrict__ act, float* __restrict__ logp,
+                                 int64_t n, int A) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int a = (int)(i % A);
+  const float sd = yc / (1.f + expf(-log_std[a] / xc));
+  const float mu = mean[i];
+  const float x = deterministic ? mu : mu + sd * eps[i];
+  act[i] = x;
+  const float d = x - mu;
+  logp[i] = -(d * d) / (2.f * sd * sd) - logf(sd) - LOG_SQRT_2PI_F;
+}
+__global__ void ma_logp_kernel(const float* __restrict__ mean, const float* __restrict__ log_std, const float* __restrict__ act,
+                               float xc, float yc, float* __restrict__ logp, int64_t n, int A) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int a = (int)(i % A);
+  const float sd = yc / (1.f + expf(-log_std[a] / xc));
+  const float d = act[i] - mean[i];
+  logp[i] = -(d * d) / (2.f * sd * sd) - logf(sd) - LOG_SQRT_2PI_F;
+}
+
+// ---------------------------------------------------------------- actor loss epilogue (mappolag.py:150-176)
+// per row: imp = prod_a exp(logp_a - old_a); hybrid advantage adv - lambda*cost_adv; clipped surrogate times the HAPPO
+// factor; entropy bonus; the lambda-delta term mean(imp * cost_adv).  Writes d(loss)/d(mean) and per-block partials
+// {sum factor*min*w, sum imp, sum imp*cost_adv, sum active, d(log_std)[A]}.
+constexpr int AL_NS = 4;       // scalar partials
+__global__ __launch_bounds__(256) void ma_actor_loss_kernel(
+    const float* __restrict__ mean, const float* __restrict__ log_std, const float* __restrict__ act,
+    const float* __restrict__ old_logp, const float* __restrict__ adv, const float* __restrict__ cost_adv,
+    const float* __restrict__ factor, const float* __restrict__ active, const float* __restrict__ lamda_dev,
+    spo_ma_loss_cfg c, float inv_denom, float ent_w, float* __restrict__ dmean, double* __restrict__ partial,
+    int64_t B, int A) {
+  __shared__ double sh[AL_NS + 64][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float sd[SPO_MAX_ACT], dsd_dls[SPO_MAX_ACT];
+  for (int a = 0; a < A; ++a) {
+    const float s = 1.f / (1.f + expf(-log_std[a] / c.std_x_coef));
+    sd[a] = s * c.std_y_coef;
+    dsd_dls[a] = c.std_y_coef * s * (1.f - s) / c.std_x_coef;
+  }
+  const float lamda = *lamda_dev;
+  double acc[AL_NS] = {0, 0, 0, 0};
+  double dls[SPO_MAX_ACT];
+  for (int a = 0; a < A; ++a) dls[a] = 0.0;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < B; r += (int64_t)gridDim.x * 256) {
+    float imp = 1.f;
+    float dif[SPO_MAX_ACT];
+    for (int a = 0; a < A; ++a) {
+      dif[a] = act[r * A + a] - mean[r * A + a];
+      const float lp = -(dif[a] * dif[a]) / (2.f * sd[a] * sd[a]) - logf(sd[a]) - LOG_SQRT_2PI_F;
+      imp *= expf(lp - old_logp[r * A + a]);                 // torch.exp per dim, then torch.prod
+    }
+    const float advh = adv[r] - lamda * cost_adv[r];
+    const float lo = 1.f - c.clip_param, hi = 1.f + c.clip_param;
+    const float rc = fminf(fmaxf(imp, lo), hi);
+    const float s1 = imp * advh, s2 = rc * advh;
+    const bool inr = imp >= lo && imp <= hi;
+    float gr;                                                 // d min(s1, s2) / d imp
+    if (s1 < s2) gr = advh;
+    else if (s1 > s2) gr = inr ? advh : 0.f;
+    else gr = 0.5f * advh + (inr ? 0.5f * advh : 0.f);
+    const float w = (c.use_policy_active_masks ? active[r] : 1.f) * inv_denom;
+    const float f = factor[r];
+    acc[0] += (double)(f * fminf(s1, s2) * w);
+    acc[1] += (double)imp;
+    acc[2] += (double)(imp * cost_adv[r]);
+    acc[3] += (double)active[r];
+    const float dimp = -f * w * gr;                           // d(policy_action_loss) / d imp
+    const float dlp = dimp * imp;                             // every dimension's log-prob enters imp the same way
+    const float ew = c.use_policy_active_masks ? active[r] * inv_denom : ent_w;      // entropy weight of this row
+    for (int a = 0; a < A; ++a) {
+      const float iv = 1.f / (sd[a] * sd[a]);
+      dmean[r * A + a] = dlp * dif[a] * iv;
+      // d logp / d sigma = dif^2 / sigma^3 - 1 / sigma ; entropy_a = 0.5 + log(sqrt(2 pi)) + log sigma
+      const float dsig = dlp * (dif[a] * dif[a] * iv / sd[a] - 1.f / sd[a]) - c.entropy_coef * ew / sd[a];
+      dls[a] += (double)(dsig * dsd_dls[a]);
+    }
+  }
+  for (int k = 0; k < AL_NS + A; ++k) {
+    double v = k < AL_NS ? acc[k] : dls[k - AL_NS];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) sh[k][wave] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < AL_NS + A)
+    partial[(int64_t)blockIdx.x * (AL_NS + SPO_MAX_ACT) + threadIdx.x] =
+        (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+}
+
+// scalars_out: {policy_loss, dist_entropy, mean(imp), mean(imp*cost_adv), sum(active)}; dlogstd_out[A]
+__global__ void ma_actor_loss_finish_kernel(const double* __restrict__ partial, int nblocks, const float* __restrict__ log_std,
+                                            spo_ma_loss_cfg c, int64_t B, int A, float* __restrict__ scalars_out,
+                                            float* __restrict__ dlogstd_out) {
+  const int k = threadIdx.x;
+  if (k >= AL_NS + A) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * (AL_NS + SPO_MAX_ACT) + k];
+  if (k == 0) {
+    scalars_out[0] = (float)(-s);
+    // entropy of a state-independent sigma is the same in every row
+    double ent = 0.0;
+    for (int a = 0; a < A; ++a) {
+      const float sg = c.std_y_coef / (1.f + expf(-log_std[a] / c.std_x_coef));
+      ent += 0.5 + (double)LOG_SQRT_2PI_F + (double)logf(sg);
+    }
+    scalars_out[1] = (float)(c.use_policy_active_masks ? ent : ent / (double)A);   // (ent*mask).sum()/mask.sum() vs .mean()
+  } else if (k == 1) scalars_out[2] = (float)(s / (double)B);
+  else if (k == 2) scalars_out[3] = (float)(s / (double)B);
+  else if (k == 3) scalars_out[4] = (float)s;
+  else dlogstd_out[k - AL_NS] = (float)s;
+}
+
+// lamda <- relu(lamda - delta*rate), delta = -((aver_cost - limit)*(1-gamma) + mean(imp*cost_adv))  (mappolag.py:178-182)
+__global__ void ma_lamda_update_kernel(float* lamda, const float* scalars, float aver_episode_cost, float cost_limit,
+                                       float gamma, float rate) {
+  const float delta = -((aver_episode_cost - cost_limit) * (1.f - gamma) + scalars[3]);
+  const float nl = *lamda - delta * rate;
+  *lamda = nl > 0.f ? nl : 0.f;
+}
+
+// ---------------------------------------------------------------- PopArt (popart.py:86-112) on a [B] vector
+// state = {running_mean, running_mean_sq, debiasing_term}
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, int64_t B, double* __restrict__ partial) {
+  __shared__ double sh[2][4];
+  double s = 0, q = 0;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < B; r += (int64_t)gridDim.x * 256) {
+    const double v = x[r];
+    s += v; q += v * v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+    partial[2 * blockIdx.x + 1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+  }
+}
+__global__ void popart_update_kernel(const double* __restrict__ partial, int nblocks, int64_t B, float beta, float* state) {
+  double s = 0, q = 0;
+  for (int b = 0; b < nblocks; ++b) { s += partial[2 * b]; q += partial[2 * b + 1]; }
+  const float bm = (float)(s / (double)B), bq = (float)(q / (double)B);
+  state[0] = state[0] * beta + bm * (1.f - beta);
+  state[1] = state[1] * beta + bq * (1.f - beta);
+  state[2] = state[2] * beta + 1.f * (1.f - beta);
+}
+__global__ void popart_normalize_kernel(const float* __restrict__ x, const float* __restrict__ state, float eps,
+                                        float* __restrict__ out, int64_t B) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const float deb = fmaxf(state[2], eps);
+  const float m = state[0] / deb, msq = state[1] / deb;
+  const float var = fmaxf(msq - m * m, 1e-2f);
+  out[i] = (x[i] - m) / sqrtf(var);
+}
+
+// ---------------------------------------------------------------- value loss (mappolag.py:126-138, util.huber_loss)
+__device__ __forceinline__ float huber(float e, float d) {
+  const float a = fabsf(e) <= d ? 1.f : 0.f, b = e > d ? 1.f : 0.f;            // (sic) nothing for e < -d
+  return a * e * e / 2.f + b * d * (fabsf(e) - d / 2.f);
+}
+__device__ __forceinline__ float huber_grad(float e, float d) {
+  return fabsf(e) <= d ? e : (e > d ? d : 0.f);
+}
+__global__ __launch_bounds__(256) void ma_value_loss_kernel(const float* __restrict__ values, const float* __restrict__ value_preds,
+                                                            const float* __restrict__ ret_n1, const float* __restrict__ ret_n2,
+                                                            float clip, float delta, float coef_over_B,
+                                                            float* __restrict__ dvalues, double* __restrict__ partial, int64_t B) {
+  __shared__ double sh[4];
+  double s = 0;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < B; r += (int64_t)gridDim.x * 256) {
+    const float v = values[r], vp = value_preds[r];
+    const float dv = v - vp;
+    const float vc = vp + fminf(fmaxf(dv, -clip), clip);
+    const float ec = ret_n1[r] - vc, eo = ret_n2[r] - v;
+    const float hc = huber(ec, delta), ho = huber(eo, delta);
+    s += (double)fmaxf(ho, hc);
+    const float go = -huber_grad(eo, delta);
+    const float gc = (dv >= -clip && dv <= clip) ? -huber_grad(ec, delta) : 0.f;
+    float g;
+    if (ho > hc) g = go;
+    else if (ho < hc) g = gc;
+    else g = 0.5f * (go + gc);                               // torch.max splits ties
+    dvalues[r] = g * coef_over_B;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ void sum_finish_kernel(const double* partial, int n, double scale, float* out) {
+  double s = 0;
+  for (int b = 0; b < n; ++b) s += partial[b];
+  *out = (float)(s * scale);
+}
+
+// ---------------------------------------------------------------- clip_grad_norm_ + Adam on one flat vector
+__global__ __launch_bounds__(256) void sq_partial_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ partial) {
+  __shared__ double sh[4];
+  double s = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += (double)g[i] * g[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ void norm_finish_kernel(const double* partial, int n, float* norm_out) {
+  double s = 0;
+  for (int b = 0; b < n; ++b) s += partial[b];
+  *norm_out = (float)sqrt(s);
+}
+__global__ void ma_adam_kernel(float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m,
+                               float* __restrict__ v, int64_t n, const float* __restrict__ norm, float max_norm, int use_clip,
+                               float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float coef = 1.f;
+  if (use_clip) {
+    coef = max_norm / (*norm + 1e-6f);
+    coef = coef > 1.f ? 1.f : coef;
+  }
+  float g = grad[i] * coef;
+  const float p = theta[i];
+  if (wd != 0.f) g += wd * p;
+  const float mm = m[i] + (1.f - b1) * (g - m[i]);                       // exp_avg.lerp_
+  const float vv = v[i] * b2 + (1.f - b2) * g * g;
+  m[i] = mm; v[i] = vv;
+  const float denom = sqrtf(vv) / bc2_sqrt + eps;
+  theta[i] = p - (lr / bc1) * (mm / denom);
+}
+
+}  // namespace
+
+// ================================================================= C ABI
+extern "C" int64_t spo_ma_param_count(const spo_ma_net* net) {
+  Lay L;
+  if (lay_of(net, &L)) return -1;
+  return L.count();
+}
+extern "C" int64_t spo_ma_workspace_floats(const spo_ma_net* net, int64_t rows) {
+  Lay L;
+  if (lay_of(net, &L) || rows < 1) return -1;
+  return L.ws_count(rows);
+}
+extern "C" int64_t spo_ma_param_offset(const spo_ma_net* net, int which, int block) {
+  Lay L;
+  if (lay_of(net, &L)) return -1;
+  switch (which) {
+    case 0: return L.fn_g();
+    case 1: return L.fn_b();
+    case 2: return block >= 0 && block < L.NB ? L.W(block) : -1;
+    case 3: return block >= 0 && block < L.NB ? L.b(block) : -1;
+    case 4: return block >= 0 && block < L.NB ? L.g(block) : -1;
+    case 5: return block >= 0 && block < L.NB ? L.be(block) : -1;
+    case 6: return L.actor ? L.logstd() : -1;
+    case 7: return L.hW();
+    case 8: return L.hb();
+    default: return -1;
+  }
+}
+
+extern "C" int spo_ma_forward(const float* theta, const spo_ma_net* net, const float* x, int64_t rows, float* ws,
+                              float* out, void* stream) {
+  Lay L;
+  if (int rc = lay_of(net, &L)) return rc;
+  SPO_REQUIRE(theta && x && ws && out && rows > 0, "ma_forward: bad args");
+  if (int rc = rb_init()) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t B = rows;
+  const int gr = grid_rows(B);
+  hipLaunchKernelGGL(ln_fwd_kernel<0>, dim3(gr), dim3(256), 0, st, x, nullptr, theta + L.fn_g(), theta + L.fn_b(), nullptr,
+                     ws + L.ws_xhat(), ws + L.ws_st0(B), B, L.D);
+  const float* in = ws + L.ws_xhat();
+  for (int k = 0; k < L.NB; ++k) {
+    float* a = ws + L.ws_a(B, k);
+    if (int rc = gemm_xwT(st, in, theta + L.W(k), a, B, L.in_k(k), L.H)) return rc;
+    hipLaunchKernelGGL(ln_fwd_kernel<1>, dim3(gr), dim3(256), 0, st, a, theta + L.b(k), theta + L.g(k), theta + L.be(k), a,
+                       ws + L.ws_y(B, k), ws + L.ws_st(B, k), B, L.H);
+    in = ws + L.ws_y(B, k);
+  }
+  if (int rc = gemm_xwT(st, in, theta + L.hW(), out, B, L.H, L.O)) return rc;
+  const int64_t n = B * L.O;
+  hipLaunchKernelGGL(add_bias_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, theta + L.hb(), n, L.O);
+  SPO_LAUNCH_CHECK("spo_ma_forward");
+  return 0;
+}
+
+// grad: flat, same layout as theta (every entry written, log_std left untouched: the loss kernel owns it).
+// scratch: float[2 * rows * max(hidden, in_dim)] + partial column sums float[1024 * 3 * max(hidden, in_dim)]
+extern "C" int64_t spo_ma_backward_scratch_floats(const spo_ma_net* net, int64_t rows) {
+  Lay L;
+  if (lay_of(net, &L) || rows < 1) return -1;
+  const int64_t W = L.H > L.D ? L.H : L.D;
+  return 2 * rows * W + 1024 * 3 * W;
+}
+extern "C" int spo_ma_backward(const float* theta, const spo_ma_net* net, const float* x, int64_t rows, const float* ws,
+                               const float* dout, float* grad, float* scratch, void* stream) {
+  Lay L;
+  if (int rc = lay_of(net, &L)) return rc;
+  SPO_REQUIRE(theta && x && ws && dout && grad && scratch && rows > 0, "ma_backward: bad args");
+  if (int rc = rb_init()) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t B = rows;
+  const int64_t Wd = L.H > L.D ? L.H : L.D;
+  float* d0 = scratch;                 // [B, Wd] gradient wrt the current block's output
+  float* d1 = scratch + B * Wd;        // [B, Wd] dz of the current block
+  float* partial = scratch + 2 * B * Wd;
+  const int gr = grid_rows(B);
+  // head
+  const float* y_last = ws + L.ws_y(B, L.NB - 1);
+  if (int rc = gemm_dyTx(st, dout, y_last, grad + L.hW(), B, L.H, L.O)) return rc;
+  hipLaunchKernelGGL(colsum_small_kernel, dim3(L.O), dim3(256), 0, st, dout, B, L.O, grad + L.hb());
+  if (int rc = gemm_dyw(st, dout, theta + L.hW(), d0, B, L.H, L.O)) return rc;
+  for (int k = L.NB - 1; k >= 0; --k) {
+    hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(gr), dim3(256), 0, st, d0, ws + L.ws_a(B, k), ws + L.ws_st(B, k), theta + L.g(k),
+                       d1, partial, B, L.H);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((L.H + 63) / 64), dim3(64), 0, st, partial, gr, L.H, grad + L.g(k),
+                       grad + L.be(k), grad + L.b(k));
+    const float* in = k == 0 ? ws + L.ws_xhat() : ws + L.ws_y(B, k - 1);
+    if (int rc = gemm_dyTx(st, d1, in, grad + L.W(k), B, L.in_k(k), L.H)) return rc;
+    if (int rc = gemm_dyw(st, d1, theta + L.W(k), d0, B, L.in_k(k), L.H)) return rc;
+  }
+  // feature_norm parameters (the observation itself needs no gradient)
+  hipLaunchKernelGGL(ln_bwd_kernel<0>, dim3(gr), dim3(256), 0, st, d0, x, ws + L.ws_st0(B), theta + L.fn_g(), nullptr, partial, B, L.D);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((L.D + 63) / 64), dim3(64), 0, st, partial, gr, L.D, grad + L.fn_g(),
+                     grad + L.fn_b(), nullptr);
+  SPO_LAUNCH_CHECK("spo_ma_backward");
+  return 0;
+}
+
+extern "C" int spo_ma_sample(const float* mean, const float* log_std, const float* eps, float std_x_coef, float std_y_coef,
+                             int deterministic, float* act_out, float* logp_out, int64_t rows, int act_dim, void* stream) {
+  SPO_REQUIRE(mean && log_std && act_out && logp_out && rows > 0 && act_dim > 0 && act_dim <= SPO_MAX_ACT && (deterministic || eps),
+              "ma_sample: bad args");
+  const int64_t n = rows * act_dim;
+  hipLaunchKernelGGL(ma_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mean, log_std, eps,
+                     std_x_coef, std_y_coef, deterministic, act_out, logp_out, n, act_dim);
+  SPO_LAUNCH_CHECK("spo_ma_sample");
+  return 0;
+}
+extern "C" int spo_ma_log_probs(const float* mean, const float* log_std, const float* act, float std_x_coef, float std_y_coef,
+                                float* logp_out, int64_t rows, int act_dim, void* stream) {
+  SPO_REQUIRE(mean && log_std && act && logp_out && rows > 0 && act_dim > 0 && act_dim <= SPO_MAX_ACT, "ma_log_probs: bad args");
+  const int64_t n = rows * act_dim;
+  hipLaunchKernelGGL(ma_logp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mean, log_std, act,
+                     std_x_coef, std_y_coef, logp_out, n, act_dim);
+  SPO_LAUNCH_CHECK("spo_ma_log_probs");
+  return 0;
+}
+
+// partial_ws: double[1024 * (4 + SPO_MAX_ACT)]
+extern "C" int spo_ma_actor_loss(const float* mean, const float* log_std, const float* act, const float* old_logp,
+                                 const float* adv, const float* cost_adv, const float* factor, const float* active,
+                                 const float* lamda_dev, const spo_ma_loss_cfg* cfg, int64_t rows, int act_dim,
+                                 float active_sum_host, float* dmean_out, float* dlogstd_out, float* scalars5_out,
+                                 double* partial_ws, void* stream) {
+  SPO_REQUIRE(mean && log_std && act && old_logp && adv && cost_adv && factor && active && lamda_dev && cfg && dmean_out &&
+                  dlogstd_out && scalars5_out && partial_ws, "ma_actor_loss: null pointer");
+  SPO_REQUIRE(rows > 0 && act_dim > 0 && act_dim <= SPO_MAX_ACT, "ma_actor_loss: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t g = (rows + 255) / 256;
+  const int gr = (int)(g > 1024 ? 1024 : g);
+  const float inv_denom = cfg->use_policy_active_masks ? 1.f / active_sum_host : 1.f / (float)rows;
+  const float ent_w = 1.f / ((float)rows * (float)act_dim);
+  hipLaunchKernelGGL(ma_actor_loss_kernel, dim3(gr), dim3(256), 0, st, mean, log_std, act, old_logp, adv, cost_adv, factor,
+                     active, lamda_dev, *cfg, inv_denom, ent_w, dmean_out, partial_ws, rows, act_dim);
+  hipLaunchKernelGGL(ma_actor_loss_finish_kernel, dim3(1), dim3(64), 0, st, partial_ws, gr, log_std, *cfg, rows, act_dim,
+                     scalars5_out, dlogstd_out);
+  SPO_LAUNCH_CHECK("spo_ma_actor_loss");
+  return 0;
+}
+
+extern "C" int spo_ma_lamda_update(float* lamda_dev, const float* scalars5, float aver_episode_cost, float cost_limit,
+                                   float gamma, float lagrangian_coef_rate, void* stream) {
+  SPO_REQUIRE(lamda_dev && scalars5, "ma_lamda_update: null pointer");
+  hipLaunchKernelGGL(ma_lamda_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, lamda_dev, scalars5, aver_episode_cost,
+                     cost_limit, gamma, lagrangian_coef_rate);
+  SPO_LAUNCH_CHECK("spo_ma_lamda_update");
+  return 0;
+}
+
+// PopArt.forward(x, train): optional statistics update, then normalisation.  partial_ws: double[2 * 1024]
+extern "C" int spo_ma_popart_forward(const float* x, int64_t rows, float* state3, float beta, float epsilon, int train,
+                                     float* out, double* partial_ws, void* stream) {
+  SPO_REQUIRE(x && state3 && out && partial_ws && rows > 0, "ma_popart_forward: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  if (train) {
+    int64_t g = (rows + 255) / 256;
+    const int gr = (int)(g > 1024 ? 1024 : g);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(gr), dim3(256), 0, st, x, rows, partial_ws);
+    hipLaunchKernelGGL(popart_update_kernel, dim3(1), dim3(1), 0, st, partial_ws, gr, rows, beta, state3);
+  }
+  hipLaunchKernelGGL(popart_normalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, x, state3, epsilon, out, rows);
+  SPO_LAUNCH_CHECK("spo_ma_popart_forward");
+  return 0;
+}
+
+extern "C" int spo_ma_value_loss(const float* values, const float* value_preds, const float* returns_norm_clipped,
+                                 const float* returns_norm_original, float clip_param, float huber_delta,
+                                 float value_loss_coef, int64_t rows, float* dvalues_out, float* loss_out, double* partial_ws,
+                                 void* stream) {
+  SPO_REQUIRE(values && value_preds && returns_norm_clipped && returns_norm_original && dvalues_out && loss_out && partial_ws &&
+                  rows > 0, "ma_value_loss: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t g = (rows + 255) / 256;
+  const int gr = (int)(g > 1024 ? 1024 : g);
+  hipLaunchKernelGGL(ma_value_loss_kernel, dim3(gr), dim3(256), 0, st, values, value_preds, returns_norm_clipped,
+                     returns_norm_original, clip_param, huber_delta, value_loss_coef / (float)rows, dvalues_out, partial_ws, rows);
+  hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(1), 0, st, partial_ws, gr, 1.0 / (double)rows, loss_out);
+  SPO_LAUNCH_CHECK("spo_ma_value_loss");
+  return 0;
+}
+
+// clip_grad_norm_(max_norm) over one network's flat gradient, then torch.optim.Adam(lr, eps, weight_decay) step number
+// adam_step_host + 1.  grad_norm_out (device float) receives the pre-clip norm.  partial_ws: double[1024]
+extern "C" int spo_ma_clip_adam(float* theta, const float* grad, float* adam_m, float* adam_v, int64_t n, int64_t adam_step_host,
+                                float lr, float adam_eps, float weight_decay, float max_grad_norm, int use_max_grad_norm,
+                                float* grad_norm_out, double* partial_ws, void* stream) {
+  SPO_REQUIRE(theta && grad && adam_m && adam_v && grad_norm_out && partial_ws && n > 0 && adam_step_host >= 0, "ma_clip_adam: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t g = (n + 255) / 256;
+  const int gr = (int)(g > 1024 ? 1024 : g);
+  hipLaunchKernelGGL(sq_partial_kernel, dim3(gr), dim3(256), 0, st, grad, n, partial_ws);
+  hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(1), 0, st, partial_ws, gr, grad_norm_out);
+  const double b1 = 0.9, b2 = 0.999;
+  const double t = (double)(adam_step_host + 1);
+  const float bc1 = (float)(1.0 - pow(b1, t)), bc2s = (float)sqrt(1.0 - pow(b2, t));
+  hipLaunchKernelGGL(ma_adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, theta, grad, adam_m, adam_v, n,
+                     grad_norm_out, max_grad_norm, use_max_grad_norm, lr, (float)b1, (float)b2, adam_eps, weight_decay, bc1, bc2s);
+  SPO_LAUNCH_CHECK("spo_ma_clip_adam");
+  return 0;
+}

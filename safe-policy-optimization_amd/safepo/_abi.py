@@ -25,6 +25,18 @@ class PpoCfg(Structure):
                 ("adam_eps", c_float), ("l2_coef", c_float)]
 
 
+class MaNet(Structure):
+    """spo_ma_net (include/safepo_hip.h)."""
+    _fields_ = [("in_dim", c_int32), ("hidden", c_int32), ("n_blocks", c_int32), ("out_dim", c_int32),
+                ("is_actor", c_int32)]
+
+
+class MaLossCfg(Structure):
+    """spo_ma_loss_cfg (include/safepo_hip.h)."""
+    _fields_ = [("clip_param", c_float), ("entropy_coef", c_float), ("std_x_coef", c_float), ("std_y_coef", c_float),
+                ("use_policy_active_masks", c_int32)]
+
+
 P = c_void_p
 # name -> (restype, argtypes); must list every symbol declared in include/safepo_hip.h
 ACTOR_LOSS_CLIP, ACTOR_LOSS_KL_PENALTY = 0, 1      # include/safepo_hip.h SPO_ACTOR_LOSS_*
@@ -65,6 +77,19 @@ PROTOTYPES = {
     "spo_p2p_selftest": (c_int, [c_int, c_int, POINTER(c_void_p), c_uint32, c_int, P, P]),
     "spo_ppo_lag_update_iter_dp": (c_int, [P, P, P, c_int64, P, P, P, P, P, P, P, c_int64, POINTER(PpoCfg), P, P,
                                            c_int, c_int, POINTER(c_void_p), c_uint32, P]),
+    "spo_ma_param_count": (c_int64, [POINTER(MaNet)]),
+    "spo_ma_param_offset": (c_int64, [POINTER(MaNet), c_int, c_int]),
+    "spo_ma_workspace_floats": (c_int64, [POINTER(MaNet), c_int64]),
+    "spo_ma_backward_scratch_floats": (c_int64, [POINTER(MaNet), c_int64]),
+    "spo_ma_forward": (c_int, [P, POINTER(MaNet), P, c_int64, P, P, P]),
+    "spo_ma_backward": (c_int, [P, POINTER(MaNet), P, c_int64, P, P, P, P, P]),
+    "spo_ma_sample": (c_int, [P, P, P, c_float, c_float, c_int, P, P, c_int64, c_int, P]),
+    "spo_ma_log_probs": (c_int, [P, P, P, c_float, c_float, P, c_int64, c_int, P]),
+    "spo_ma_actor_loss": (c_int, [P] * 9 + [POINTER(MaLossCfg), c_int64, c_int, c_float, P, P, P, P, P]),
+    "spo_ma_lamda_update": (c_int, [P, P, c_float, c_float, c_float, c_float, P]),
+    "spo_ma_popart_forward": (c_int, [P, c_int64, P, c_float, c_float, c_int, P, P, P]),
+    "spo_ma_value_loss": (c_int, [P, P, P, P, c_float, c_float, c_float, c_int64, P, P, P, P]),
+    "spo_ma_clip_adam": (c_int, [P, P, P, P, c_int64, c_int64, c_float, c_float, c_float, c_float, c_int, P, P, P]),
     "spo_ma_gae": (c_int, [P] * 7 + [c_int64, c_int64, c_double, c_double, c_float, c_float, c_float, c_float, P]),
     "spo_param_count": (c_int64, [c_int, c_int]),
     "spo_param_offset": (c_int64, [c_int, c_int, c_int]),

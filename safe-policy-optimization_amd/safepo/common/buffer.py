@@ -166,7 +166,9 @@ class SeparatedReplayBuffer:
     def __init__(self, config, obs_space, share_obs_space, act_space):
         self.episode_length = config["episode_length"]
         self.n_rollout_threads = config["n_rollout_threads"]
-        self.rnn_hidden_size = config["hidden_size"]
+        # recurrent policies are not built: the rnn_states* tensors keep their place in the API with a hidden dim of 1
+        # (the reference allocates [T+1, N, recurrent_N, hidden_size] zeros for each of the three, buffer.py:239-244)
+        self.rnn_hidden_size = 1
         self.recurrent_N = config["recurrent_N"]
         self.gamma, self.gae_lambda = config["gamma"], config["gae_lambda"]
         self._use_gae, self._use_popart = config["use_gae"], config["use_popart"]
@@ -197,6 +199,32 @@ class SeparatedReplayBuffer:
 
     def update_factor(self, factor):
         self.factor.copy_(factor)
+
+    def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None, cost_adv=None, perm=None):
+        """buffer.py:386-465: `num_mini_batch` index sets of a random permutation of the T*N rows; yields the reference's
+        18-tuple (mappolag / macpo form).  Row gathers are device index_selects; `perm` may carry the permutation."""
+        T, N = self.rewards.shape[0:2]
+        batch_size = N * T
+        if mini_batch_size is None:
+            assert batch_size >= num_mini_batch, (N, T, num_mini_batch)
+            mini_batch_size = batch_size // num_mini_batch
+        rand = (torch.randperm(batch_size) if perm is None else torch.as_tensor(perm)).to(self.device)
+        flat = lambda t: t.reshape(-1, *t.shape[2:])
+        share_obs, obs = flat(self.share_obs[:-1]), flat(self.obs[:-1])
+        rnn, rnn_c, rnn_k = flat(self.rnn_states[:-1]), flat(self.rnn_states_critic[:-1]), flat(self.rnn_states_cost[:-1])
+        actions, logp = flat(self.actions), flat(self.action_log_probs)
+        value_preds, returns = self.value_preds[:-1].reshape(-1, 1), self.returns[:-1].reshape(-1, 1)
+        cost_preds, cost_returns = self.cost_preds[:-1].reshape(-1, 1), self.cost_returns[:-1].reshape(-1, 1)
+        masks, active = self.masks[:-1].reshape(-1, 1), self.active_masks[:-1].reshape(-1, 1)
+        factor = self.factor.reshape(-1, self.factor.shape[-1])
+        advantages = advantages.reshape(-1, 1)
+        cost_adv = cost_adv.reshape(-1, 1) if cost_adv is not None else None
+        for i in range(num_mini_batch if num_mini_batch is not None else batch_size // mini_batch_size):
+            idx = rand[i * mini_batch_size:(i + 1) * mini_batch_size]
+            g = lambda t: t.index_select(0, idx)
+            yield (g(share_obs), g(obs), g(rnn), g(rnn_c), g(actions), g(value_preds), g(returns), g(masks), g(active),
+                   g(logp), g(advantages), None, g(factor), g(cost_preds), g(cost_returns), g(rnn_k),
+                   g(cost_adv) if cost_adv is not None else None, self.aver_episode_costs)
 
     def return_aver_insert(self, aver_episode_costs):
         self.aver_episode_costs = aver_episode_costs.clone()

@@ -186,3 +186,58 @@ def make_sa_mujoco_env(num_envs: int, env_id: str, seed: int | None = None, devi
     obs_space, act_space = env.observation_space, env.action_space
     env = SafeUnsqueeze(SafeNormalizeObservation(SafeRescaleAction(SafeAutoResetWrapper(env), -1.0, 1.0)))
     return env, obs_space, act_space
+
+
+class SynthMultiAgentEnv:
+    """Device-resident synthetic multi-agent vector env with the interface the MAPPO-L Runner consumes
+    (reference safepo/common/env.py make_ma_mujoco_env -> ShareVecEnv: reset() -> (obs, share_obs, available_actions),
+    step(list of per-agent actions) -> (obs, share_obs, rewards, costs, dones, infos, available_actions) with
+    obs [N, agents, obs_dim], share_obs [N, agents, share_dim], rewards / costs [N, agents, 1], dones [N, agents] bool).
+    Dynamics (BASELINE config 5 shape: SafetyMujocoMulti-style, 4 agents, obs 48): observations are i.i.d. normals, the
+    team reward prefers actions near a fixed linear map of each agent's observation, cost is Bernoulli; all agents of a
+    thread finish together every `trunc_len` steps (auto-reset)."""
+    is_device_env = True
+
+    def __init__(self, num_envs: int, num_agents: int = 4, obs_dim: int = 48, act_dim: int = 6, share_dim: int | None = None,
+                 seed: int = 0, p_cost: float = 0.2, trunc_len: int = 64, device="cuda:0"):
+        self.num_envs, self.num_agents, self.obs_dim, self.act_dim = num_envs, num_agents, obs_dim, act_dim
+        self.share_dim = share_dim if share_dim is not None else obs_dim * num_agents // 2
+        self.dev = torch.device(device)
+        self.p_cost, self.trunc_len, self.t = p_cost, trunc_len, 0
+        self.gen = torch.Generator(device=self.dev).manual_seed(int(seed))
+        g = torch.Generator().manual_seed(12345)
+        self.W = (torch.randn(num_agents, obs_dim, act_dim, generator=g) / obs_dim ** 0.5).to(self.dev)
+        self.observation_space = [Box(obs_dim) for _ in range(num_agents)]
+        self.share_observation_space = [Box(self.share_dim) for _ in range(num_agents)]
+        self.action_space = [Box(act_dim, -1.0, 1.0) for _ in range(num_agents)]
+        self._obs = None
+
+    def _draw(self):
+        obs = torch.randn(self.num_envs, self.num_agents, self.obs_dim, device=self.dev, generator=self.gen)
+        flat = obs.reshape(self.num_envs, -1)
+        share = flat[:, :self.share_dim].unsqueeze(1).expand(-1, self.num_agents, -1).contiguous()
+        return obs, share
+
+    def reset(self):
+        self.t = 0
+        self._obs, share = self._draw()
+        return self._obs, share, None
+
+    def step(self, actions):
+        act = torch.stack([a.reshape(self.num_envs, self.act_dim) for a in actions], dim=1)        # [N, agents, A]
+        target = torch.tanh(torch.einsum("nad,adk->nak", self._obs, self.W))
+        team = -((act - target) ** 2).mean(dim=(1, 2))                                            # shared team reward
+        rewards = team.view(-1, 1, 1).expand(-1, self.num_agents, 1).contiguous()
+        costs = (torch.rand(self.num_envs, 1, 1, device=self.dev, generator=self.gen) < self.p_cost).float() \
+            .expand(-1, self.num_agents, 1).contiguous()
+        self.t += 1
+        done = self.t % self.trunc_len == 0
+        dones = torch.full((self.num_envs, self.num_agents), bool(done), device=self.dev)
+        self._obs, share = self._draw()
+        return self._obs, share, rewards, costs, dones, [{} for _ in range(self.num_envs)], None
+
+
+def make_ma_synth_env(cfg_train: dict, seed: int = 0, **kw):
+    """Multi-agent counterpart of make_sa_mujoco_env for Synth* tasks (BASELINE config 5 shape by default)."""
+    return SynthMultiAgentEnv(cfg_train["n_rollout_threads"], seed=seed, device=cfg_train["device"],
+                              **{**(cfg_train.get("env_kwargs") or {}), **kw})

@@ -140,3 +140,156 @@ class ActorVCritic(nn.Module):
         _abi.check(_abi.load().spo_values(_abi.ptr(self.theta), _abi.ptr(obs2), _abi.ptr(v_r), _abi.ptr(v_c), n,
                                           self.obs_dim, self.act_dim, _abi.stream_ptr()), "spo_values")
         return v_r, v_c
+
+
+# ====================================================================== multi-agent networks
+def _ma_init(module, gain, orthogonal=True):
+    """safepo/utils/util.py init(): weight by orthogonal_/xavier_uniform_ with `gain`, bias 0."""
+    (nn.init.orthogonal_ if orthogonal else nn.init.xavier_uniform_)(module.weight.data, gain=gain)
+    nn.init.constant_(module.bias.data, 0)
+    return module
+
+
+class _MATrunk(nn.Module):
+    """Parameters of MLPBase (safepo/utils/mlp.py) under the reference's state_dict names:
+    base.feature_norm.{weight,bias}, base.mlp.fc1.{0,2}.*, base.mlp.fc2.<i>.{0,2}.* -- Linear at index 0, LayerNorm at
+    index 2 of each Sequential (index 1 is the ELU)."""
+
+    def __init__(self, config, in_dim):
+        super().__init__()
+        H, layer_N = config["hidden_size"], config["layer_N"]
+        gain = nn.init.calculate_gain(["tanh", "relu"][config["use_ReLU"]])
+        orth = config["use_orthogonal"]
+        if not config["use_feature_normalization"]:
+            raise NotImplementedError("use_feature_normalization=False is not built (the kernels fuse the input LayerNorm)")
+        self.feature_norm = nn.LayerNorm(in_dim)
+
+        def block(d):
+            return nn.Sequential(_ma_init(nn.Linear(d, H), gain, orth), nn.ELU(), nn.LayerNorm(H))
+        mlp = nn.Module()
+        mlp.fc1 = block(in_dim)
+        mlp.fc2 = nn.ModuleList([block(H) for _ in range(layer_N)])
+        self.mlp = mlp
+
+
+class _MAFlatNet(nn.Module):
+    """One MAPPO network over a flat fp32 parameter vector (layout: include/safepo_hip.h, section f3).  forward /
+    backward run through spo_ma_forward / spo_ma_backward (rocBLAS GEMMs + fused LayerNorm/ELU kernels); the
+    nn.Parameters are views into `theta` so state_dict() keeps the reference's keys and shapes."""
+
+    def _finish(self, in_dim, out_dim, is_actor):
+        self._net = _abi.MaNet(in_dim=in_dim, hidden=self.hidden_size, n_blocks=1 + self.config["layer_N"], out_dim=out_dim,
+                               is_actor=int(is_actor))
+        self.theta = None
+        self._flatten()
+
+    def _flatten(self):
+        params = list(self.parameters())
+        flat = torch.cat([p.detach().reshape(-1) for p in params]).to(torch.float32).contiguous()
+        off = 0
+        for p in params:
+            n = p.numel()
+            p.data = flat[off:off + n].view(p.shape)
+            off += n
+        self.theta = flat
+        if flat.is_cuda:
+            n = _abi.load().spo_ma_param_count(self._net)
+            assert n == flat.numel(), (n, flat.numel())
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._flatten()
+        return out
+
+    def offset(self, which: int, block: int = 0) -> int:
+        return int(_abi.load().spo_ma_param_offset(self._net, which, block))
+
+    def net_forward(self, x: torch.Tensor, keep: bool = False):
+        """Head output [rows, out] for x [rows, in]; with keep=True also the activation workspace for net_backward."""
+        x = _abi.require_gpu_tensor(x.reshape(-1, self._net.in_dim).contiguous(), "x", torch.float32)
+        lib = _abi.load()
+        rows = x.shape[0]
+        ws = torch.empty(int(lib.spo_ma_workspace_floats(self._net, rows)), dtype=torch.float32, device=x.device)
+        out = torch.empty((rows, self._net.out_dim), dtype=torch.float32, device=x.device)
+        _abi.check(lib.spo_ma_forward(_abi.ptr(self.theta), self._net, _abi.ptr(x), rows, _abi.ptr(ws), _abi.ptr(out),
+                                      _abi.stream_ptr()), "spo_ma_forward")
+        return (out, (x, ws)) if keep else out
+
+    def net_backward(self, saved, dout: torch.Tensor, grad: torch.Tensor) -> None:
+        x, ws = saved
+        lib = _abi.load()
+        rows = x.shape[0]
+        scratch = torch.empty(int(lib.spo_ma_backward_scratch_floats(self._net, rows)), dtype=torch.float32, device=x.device)
+        _abi.check(lib.spo_ma_backward(_abi.ptr(self.theta), self._net, _abi.ptr(x), rows, _abi.ptr(ws), _abi.ptr(dout.contiguous()),
+                                       _abi.ptr(grad), _abi.ptr(scratch), _abi.stream_ptr()), "spo_ma_backward")
+
+
+class MultiAgentActor(_MAFlatNet):
+    """safepo/common/model.py:172-301: MLPBase + ACTLayer(DiagGaussian).  forward(obs, rnn_states, masks) ->
+    (actions, per-dimension action_log_probs, rnn_states); evaluate_actions(...) -> (action_log_probs, dist_entropy)."""
+
+    def __init__(self, config, obs_space, action_space, device=torch.device("cuda")):
+        super().__init__()
+        self.config, self.hidden_size = config, config["hidden_size"]
+        self.tpdv = dict(dtype=torch.float32, device=device)
+        obs_dim, act_dim = obs_space.shape[0], action_space.shape[0]
+        self.base = _MATrunk(config, obs_dim)
+        act = nn.Module()
+        out = nn.Module()
+        out.log_std = nn.Parameter(torch.ones(act_dim) * config["std_x_coef"])          # distributions.py:36-37
+        out.fc_mean = _ma_init(nn.Linear(self.hidden_size, act_dim), config["actor_gain"], config["use_orthogonal"])
+        act.action_out = out
+        self.act = act
+        self.act_dim = act_dim
+        self.std_x_coef, self.std_y_coef = float(config["std_x_coef"]), float(config["std_y_coef"])
+        self._finish(obs_dim, act_dim, True)
+        self.to(device)
+
+    @property
+    def log_std(self) -> torch.Tensor:
+        o = self.offset(6)
+        return self.theta[o:o + self.act_dim]
+
+    def forward(self, obs, rnn_states, masks, available_actions=None, deterministic=False, eps=None):
+        mean = self.net_forward(torch.as_tensor(obs, **self.tpdv))
+        rows = mean.shape[0]
+        if not deterministic and eps is None:
+            eps = torch.randn((rows, self.act_dim), **self.tpdv)
+        act, logp = torch.empty_like(mean), torch.empty_like(mean)
+        _abi.check(_abi.load().spo_ma_sample(_abi.ptr(mean), _abi.ptr(self.log_std), _abi.ptr(eps) if eps is not None else None,
+                                             self.std_x_coef, self.std_y_coef, int(bool(deterministic)), _abi.ptr(act),
+                                             _abi.ptr(logp), rows, self.act_dim, _abi.stream_ptr()), "spo_ma_sample")
+        return act, logp, rnn_states
+
+    def evaluate_actions(self, obs, rnn_states, action, masks, available_actions=None, active_masks=None):
+        mean = self.net_forward(torch.as_tensor(obs, **self.tpdv))
+        action = _abi.require_gpu_tensor(torch.as_tensor(action, **self.tpdv).reshape(mean.shape).contiguous(), "action", torch.float32)
+        logp = torch.empty_like(mean)
+        _abi.check(_abi.load().spo_ma_log_probs(_abi.ptr(mean), _abi.ptr(self.log_std), _abi.ptr(action), self.std_x_coef,
+                                                self.std_y_coef, _abi.ptr(logp), mean.shape[0], self.act_dim,
+                                                _abi.stream_ptr()), "spo_ma_log_probs")
+        std = torch.sigmoid(self.log_std / self.std_x_coef) * self.std_y_coef
+        ent = 0.5 + 0.5 * np.log(2 * np.pi) + torch.log(std)                        # Normal.entropy, same in every row
+        if active_masks is not None and self.config["use_policy_active_masks"]:
+            dist_entropy = ent.sum()                                                 # (ent * mask).sum() / mask.sum()
+        else:
+            dist_entropy = ent.mean()
+        return logp, dist_entropy
+
+
+class MultiAgentCritic(_MAFlatNet):
+    """safepo/common/model.py:304-363: MLPBase + v_out (initialised with gain 0).  forward(cent_obs, rnn_states, masks)
+    -> (values [rows, 1], rnn_states)."""
+
+    def __init__(self, config, cent_obs_space, device=torch.device("cuda")):
+        super().__init__()
+        self.config, self.hidden_size = config, config["hidden_size"]
+        self.tpdv = dict(dtype=torch.float32, device=device)
+        in_dim = cent_obs_space.shape[0]
+        self.base = _MATrunk(config, in_dim)
+        self.v_out = _ma_init(nn.Linear(self.hidden_size, 1), 0, config["use_orthogonal"])
+        self._finish(in_dim, 1, False)
+        self.to(device)
+
+    def forward(self, cent_obs, rnn_states, masks):
+        return self.net_forward(torch.as_tensor(cent_obs, **self.tpdv)), rnn_states

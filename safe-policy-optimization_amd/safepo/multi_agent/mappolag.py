@@ -1,0 +1,448 @@
+"""MAPPO-Lagrangian (multi-agent): reference safepo/multi_agent/mappolag.py, SURVEY.md 8 f3.
+
+Same surface -- MAPPO_L_Policy, MAPPO_L_Trainer, Runner, train(args, cfg_train) -- on the MI355X kernels of
+csrc/ma_net.hip and csrc/multi_agent.hip: per-agent actor / critic / cost-critic networks are flat device vectors whose
+forward and backward run as rocBLAS GEMMs with fused LayerNorm/ELU kernels; the clipped HAPPO surrogate, entropy bonus,
+in-loop multiplier step, PopArt statistics, clipped Huber value losses and clip_grad_norm_ + Adam are single kernels;
+GAE + PopArt de-normalisation for rewards and costs is one kernel per agent (spo_ma_gae).  Everything between the
+environment and the logger stays in HBM; there is no CPU fallback.
+
+Regime note: num_mini_batch = 1 and learning_iters = 5, so one epoch is 5 full-batch steps per network per agent over
+episode_length x n_rollout_threads rows -- large GEMMs, the opposite of the single-agent path's 327 680 tiny steps.
+"""
+from __future__ import annotations
+
+import copy
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from safepo import _abi
+from safepo.common.buffer import SeparatedReplayBuffer
+from safepo.common.logger import EpochLogger
+from safepo.common.model import MultiAgentActor as Actor, MultiAgentCritic as Critic
+from safepo.common.popart import PopArt
+
+# Defaults of the reference's marl_cfg/mappolag/config.yaml, and its `mamujoco` overrides (applied for the MuJoCo
+# velocity / multi-goal tasks, safepo/utils/config.py:236-241).
+default_cfg = dict(
+    env_name="mappolag", algorithm_name="mappolag", experiment_name="check", seed=0, run_dir="./runs/",
+    num_env_steps=100000000, episode_length=8, n_rollout_threads=1, n_eval_rollout_threads=1, hidden_size=512,
+    use_render=False, recurrent_N=1, use_single_network=False, save_interval=1, use_eval=False, eval_interval=25,
+    log_interval=25, eval_episodes=10000, cost_limit=25, lagrangian_coef_rate=1.0e-5, lamda_lagr=0.78, gamma=0.96,
+    gae_lambda=0.95, use_gae=True, use_popart=True, use_valuenorm=True, use_proper_time_limits=False, target_kl=0.016,
+    searching_steps=10, accept_ratio=0.5, clip_param=0.2, learning_iters=5, num_mini_batch=1, data_chunk_length=None,
+    value_loss_coef=1, entropy_coef=0.0, max_grad_norm=10, huber_delta=10.0, use_recurrent_policy=False,
+    use_naive_recurrent_policy=False, use_max_grad_norm=True, use_clipped_value_loss=True, use_huber_loss=True,
+    use_value_active_masks=False, use_policy_active_masks=False, actor_lr=9.0e-5, critic_lr=5.0e-3, opti_eps=1.0e-5,
+    weight_decay=0.0, gain=0.01, actor_gain=0.01, use_orthogonal=True, use_feature_normalization=True, use_ReLU=True,
+    stacked_frames=1, layer_N=2, std_x_coef=1, std_y_coef=0.5)
+mamujoco_cfg = dict(
+    num_env_steps=10000000, episode_length=1000, n_rollout_threads=10, n_eval_rollout_threads=10, hidden_size=128,
+    gamma=0.99, entropy_coef=0.01, actor_lr=5.0e-4, critic_lr=5.0e-4, max_grad_norm=10.0, use_value_active_masks=True,
+    use_policy_active_masks=True, data_chunk_length=10)
+
+
+def check(x):
+    return torch.from_numpy(x) if type(x) == np.ndarray else x
+
+
+class _Adam:
+    """Flat optimiser state of one network; `step` = clip_grad_norm_ + torch.optim.Adam through spo_ma_clip_adam."""
+
+    def __init__(self, net, lr, eps, weight_decay):
+        self.net, self.lr, self.eps, self.wd = net, float(lr), float(eps), float(weight_decay)
+        self.m, self.v = torch.zeros_like(net.theta), torch.zeros_like(net.theta)
+        self.grad = torch.zeros_like(net.theta)
+        self.t = 0
+        self.norm = torch.zeros(1, dtype=torch.float32, device=net.theta.device)
+        self.partial = torch.zeros(1024, dtype=torch.float64, device=net.theta.device)
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def step(self, max_grad_norm, use_max_grad_norm=True):
+        th = self.net.theta
+        _abi.check(_abi.load().spo_ma_clip_adam(_abi.ptr(th), _abi.ptr(self.grad), _abi.ptr(self.m), _abi.ptr(self.v),
+                                                th.numel(), self.t, self.lr, self.eps, self.wd, float(max_grad_norm),
+                                                int(bool(use_max_grad_norm)), _abi.ptr(self.norm), _abi.ptr(self.partial),
+                                                _abi.stream_ptr()), "spo_ma_clip_adam")
+        self.t += 1
+        return self.norm.clone().reshape(())
+
+
+class MAPPO_L_Policy:
+    """mappolag.py:45-113: actor on the agent's observation, critic and cost critic on the shared observation."""
+
+    def __init__(self, config, obs_space, cent_obs_space, act_space):
+        self.config, self.obs_space, self.act_space, self.share_obs_space = config, obs_space, act_space, cent_obs_space
+        dev = torch.device(config["device"])
+        if dev.type != "cuda":
+            raise _abi.SpoError("MAPPO-L (MI355X) runs on a ROCm GPU only (--device cuda); there is no CPU fallback")
+        self.actor = Actor(config, obs_space, act_space, dev)
+        self.critic = Critic(config, cent_obs_space, dev)
+        self.cost_critic = Critic(config, cent_obs_space, dev)
+        self.actor_optimizer = _Adam(self.actor, config["actor_lr"], config["opti_eps"], config["weight_decay"])
+        self.critic_optimizer = _Adam(self.critic, config["critic_lr"], config["opti_eps"], config["weight_decay"])
+        self.cost_optimizer = _Adam(self.cost_critic, config["critic_lr"], config["opti_eps"], config["weight_decay"])
+
+    def get_actions(self, cent_obs, obs, rnn_states_actor, rnn_states_critic, masks, available_actions=None,
+                    deterministic=False, rnn_states_cost=None):
+        actions, action_log_probs, rnn_states_actor = self.actor(obs, rnn_states_actor, masks, available_actions, deterministic)
+        values, rnn_states_critic = self.critic(cent_obs, rnn_states_critic, masks)
+        if rnn_states_cost is None:
+            return values, actions, action_log_probs, rnn_states_actor, rnn_states_critic
+        cost_preds, rnn_states_cost = self.cost_critic(cent_obs, rnn_states_cost, masks)
+        return values, actions, action_log_probs, rnn_states_actor, rnn_states_critic, cost_preds, rnn_states_cost
+
+    def get_values(self, cent_obs, rnn_states_critic, masks):
+        return self.critic(cent_obs, rnn_states_critic, masks)[0]
+
+    def get_cost_values(self, cent_obs, rnn_states_cost, masks):
+        return self.cost_critic(cent_obs, rnn_states_cost, masks)[0]
+
+    def evaluate_actions(self, cent_obs, obs, rnn_states_actor, rnn_states_critic, action, masks, available_actions=None,
+                         active_masks=None, rnn_states_cost=None):
+        action_log_probs, dist_entropy = self.actor.evaluate_actions(obs, rnn_states_actor, action, masks, available_actions,
+                                                                     active_masks)
+        values, _ = self.critic(cent_obs, rnn_states_critic, masks)
+        if rnn_states_cost is None:
+            return values, action_log_probs, dist_entropy
+        cost_values, _ = self.cost_critic(cent_obs, rnn_states_cost, masks)
+        return values, action_log_probs, dist_entropy, cost_values
+
+    def act(self, obs, rnn_states_actor, masks, available_actions=None, deterministic=False):
+        actions, _, rnn_states_actor = self.actor(obs, rnn_states_actor, masks, available_actions, deterministic)
+        return actions, rnn_states_actor
+
+
+class MAPPO_L_Trainer:
+    """mappolag.py:115-249.  `lamda_lagr` is a device scalar updated inside every minibatch step (mappolag.py:178-182)."""
+
+    def __init__(self, config, policy):
+        self.config, self.policy = config, policy
+        self.dev = torch.device(config["device"])
+        self.tpdv = dict(dtype=torch.float32, device=self.dev)
+        self.value_normalizer = PopArt(1, device=self.dev)
+        self._popart_state = torch.zeros(3, **self.tpdv)         # {running_mean, running_mean_sq, debiasing_term}
+        self._lamda = torch.tensor([float(config["lamda_lagr"])], **self.tpdv)
+        self._partial = torch.zeros(1024 * (4 + 16), dtype=torch.float64, device=self.dev)
+        self._scalars = torch.zeros(5, **self.tpdv)
+        self._loss_cfg = _abi.MaLossCfg(clip_param=float(config["clip_param"]), entropy_coef=float(config["entropy_coef"]),
+                                        std_x_coef=float(config["std_x_coef"]), std_y_coef=float(config["std_y_coef"]),
+                                        use_policy_active_masks=int(bool(config["use_policy_active_masks"])))
+
+    @property
+    def lamda_lagr(self):
+        return self._lamda[0]
+
+    # PopArt statistics live in one device vector for the kernels; the nn.Module view is refreshed from it
+    def _sync_normalizer(self):
+        vn, s = self.value_normalizer, self._popart_state
+        vn.running_mean.copy_(s[0:1]); vn.running_mean_sq.copy_(s[1:2]); vn.debiasing_term.copy_(s[2])
+
+    def _normalize_returns(self, returns, out):
+        vn = self.value_normalizer
+        _abi.check(_abi.load().spo_ma_popart_forward(_abi.ptr(returns), returns.numel(), _abi.ptr(self._popart_state), float(vn.beta),
+                                                     float(vn.epsilon), 1, _abi.ptr(out), _abi.ptr(self._partial),
+                                                     _abi.stream_ptr()), "spo_ma_popart_forward")
+
+    def _value_step(self, net, opt, inputs, value_preds, returns):
+        """cal_value_loss (mappolag.py:126-138) + backward + clip + Adam for one critic."""
+        c, lib = self.config, _abi.load()
+        values, saved = net.net_forward(inputs, keep=True)
+        rows = values.shape[0]
+        returns = returns.reshape(-1).contiguous()
+        n1, n2 = torch.empty_like(returns), torch.empty_like(returns)
+        self._normalize_returns(returns, n1)                    # value_normalizer(return_batch) for error_clipped ...
+        self._normalize_returns(returns, n2)                    # ... and again for error_original: two statistics updates
+        dvalues, loss = torch.empty_like(values), torch.empty(1, **self.tpdv)
+        _abi.check(lib.spo_ma_value_loss(_abi.ptr(values), _abi.ptr(value_preds.reshape(-1).contiguous()), _abi.ptr(n1), _abi.ptr(n2),
+                                         float(c["clip_param"]), float(c["huber_delta"]), float(c["value_loss_coef"]), rows,
+                                         _abi.ptr(dvalues), _abi.ptr(loss), _abi.ptr(self._partial), _abi.stream_ptr()),
+                   "spo_ma_value_loss")
+        net.net_backward(saved, dvalues, opt.grad)
+        norm = opt.step(c["max_grad_norm"], c["use_max_grad_norm"])
+        return loss.reshape(()), norm
+
+    def ppo_update(self, sample):
+        (share_obs_batch, obs_batch, _rnn, _rnn_c, actions_batch, value_preds_batch, return_batch, _masks, active_masks_batch,
+         old_action_log_probs_batch, adv_targ, _avail, factor_batch, cost_preds_batch, cost_returns_batch, _rnn_k, cost_adv_targ,
+         aver_episode_costs) = sample
+        c, lib, pol = self.config, _abi.load(), self.policy
+        f = lambda t: _abi.require_gpu_tensor(check(t).to(**self.tpdv).contiguous(), "sample", torch.float32)
+        obs_batch, share_obs_batch, actions_batch = f(obs_batch), f(share_obs_batch), f(actions_batch)
+        old_lp, adv, cadv, factor, active = (f(old_action_log_probs_batch), f(adv_targ).reshape(-1), f(cost_adv_targ).reshape(-1),
+                                             f(factor_batch).reshape(-1), f(active_masks_batch).reshape(-1))
+        rows, A = obs_batch.shape[0], pol.actor.act_dim
+        # ---- actor: clipped HAPPO surrogate on the hybrid advantage, entropy bonus (mappolag.py:150-176)
+        mean, saved = pol.actor.net_forward(obs_batch, keep=True)
+        dmean = torch.empty_like(mean)
+        opt = pol.actor_optimizer
+        ls_off = pol.actor.offset(6)
+        active_sum = float(active.sum().item()) if c["use_policy_active_masks"] else float(rows)
+        _abi.check(lib.spo_ma_actor_loss(_abi.ptr(mean), _abi.ptr(pol.actor.log_std), _abi.ptr(actions_batch), _abi.ptr(old_lp),
+                                         _abi.ptr(adv), _abi.ptr(cadv), _abi.ptr(factor), _abi.ptr(active), _abi.ptr(self._lamda),
+                                         self._loss_cfg, rows, A, active_sum, _abi.ptr(dmean), _abi.ptr(opt.grad[ls_off:ls_off + A]),
+                                         _abi.ptr(self._scalars), _abi.ptr(self._partial), _abi.stream_ptr()), "spo_ma_actor_loss")
+        pol.actor.net_backward(saved, dmean, opt.grad)
+        actor_grad_norm = opt.step(c["max_grad_norm"], c["use_max_grad_norm"])
+        scal = self._scalars.clone()
+        # ---- multiplier (mappolag.py:178-182); aver_episode_costs.mean() is a host scalar of the buffer
+        aver = float(check(aver_episode_costs).float().mean().item())
+        _abi.check(lib.spo_ma_lamda_update(_abi.ptr(self._lamda), _abi.ptr(self._scalars), aver, float(c["cost_limit"]), float(c["gamma"]),
+                                           float(c["lagrangian_coef_rate"]), _abi.stream_ptr()), "spo_ma_lamda_update")
+        # ---- critics (mappolag.py:183-197); both share the one PopArt normaliser
+        value_loss, critic_grad_norm = self._value_step(pol.critic, pol.critic_optimizer, share_obs_batch, f(value_preds_batch), f(return_batch))
+        cost_loss, cost_grad_norm = self._value_step(pol.cost_critic, pol.cost_optimizer, share_obs_batch, f(cost_preds_batch), f(cost_returns_batch))
+        self._sync_normalizer()
+        policy_loss, dist_entropy, imp_mean = scal[0], scal[1], scal[2]
+        return value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_mean, cost_loss, cost_grad_norm
+
+    def train(self, buffer, logger, perm_fn=None):
+        """mappolag.py:201-236 (advantage standardisation with torch.mean / torch.std over the NaN-masked copy, as written)."""
+        c = self.config
+        self._sync_normalizer()
+
+        def standardised(returns, preds):
+            adv = returns[:-1] - self.value_normalizer.denormalize(preds[:-1])
+            cp = adv.clone()
+            cp[buffer.active_masks[:-1] == 0.0] = float("nan")
+            return (adv - torch.mean(cp)) / (torch.std(cp) + 1e-8)
+        advantages = standardised(buffer.returns, buffer.value_preds)
+        cost_adv = standardised(buffer.cost_returns, buffer.cost_preds)
+        out = None
+        for it in range(c["learning_iters"]):
+            perm = perm_fn(it) if perm_fn is not None else None
+            for sample in buffer.feed_forward_generator(advantages, c["num_mini_batch"], cost_adv=cost_adv, perm=perm):
+                out = self.ppo_update(sample)
+            value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights, cost_loss, cost_grad_norm = out
+            if logger is not None:
+                logger.store(**{"Loss/Loss_reward_critic": value_loss.item(), "Loss/Loss_cost_critic": cost_loss.item(),
+                                "Loss/Loss_actor": policy_loss.item(), "Misc/Reward_critic_norm": critic_grad_norm.item(),
+                                "Misc/Cost_critic_norm": cost_grad_norm.item(), "Misc/Entropy": dist_entropy.item(),
+                                "Misc/Ratio": imp_weights.detach().mean().item()})
+        return out
+
+    def prep_training(self):
+        pass        # no dropout / batch-norm in these networks: train() / eval() modes are identical
+
+    def prep_rollout(self):
+        pass
+
+
+class Runner:
+    """mappolag.py:252-604: collect -> insert -> compute -> train with sequential (HAPPO) agent updates."""
+
+    def __init__(self, vec_env, vec_eval_env, config, model_dir=""):
+        self.envs, self.eval_envs, self.config, self.model_dir = vec_env, vec_eval_env, config, model_dir
+        self.num_agents = self.envs.num_agents
+        self.dev = torch.device(config["device"])
+        self.logger = EpochLogger(log_dir=config["log_dir"], seed=str(config["seed"]))
+        self.save_dir = str(config["log_dir"] + "/models_seed{}".format(config["seed"]))
+        os.makedirs(self.save_dir, exist_ok=True)
+        self.logger.save_config(config)
+        self.policy = [MAPPO_L_Policy(config, self.envs.observation_space[a], self.envs.share_observation_space[a],
+                                      self.envs.action_space[a]) for a in range(self.num_agents)]
+        if self.model_dir != "":
+            self.restore()
+        self.trainer = [MAPPO_L_Trainer(config, self.policy[a]) for a in range(self.num_agents)]
+        self.buffer = [SeparatedReplayBuffer(config, self.envs.observation_space[a], self.envs.share_observation_space[a],
+                                             self.envs.action_space[a]) for a in range(self.num_agents)]
+
+    def run(self):
+        c = self.config
+        self.warmup()
+        start = time.time()
+        episodes = int(c["num_env_steps"]) // c["episode_length"] // c["n_rollout_threads"]
+        train_episode_rewards = torch.zeros(1, c["n_rollout_threads"], device=self.dev)
+        train_episode_costs = torch.zeros(1, c["n_rollout_threads"], device=self.dev)
+        eval_rewards, eval_costs = 0.0, 0.0
+        for episode in range(episodes):
+            done_rewards, done_costs = [], []
+            for step in range(c["episode_length"]):
+                values, actions, action_log_probs, rnn_states, rnn_states_critic, cost_preds, rnn_states_cost = self.collect(step)
+                obs, share_obs, rewards, costs, dones, infos, _ = self.envs.step(actions)
+                dones_env = torch.all(dones, dim=1)
+                train_episode_rewards += torch.mean(rewards, dim=1).flatten()
+                train_episode_costs += torch.mean(costs, dim=1).flatten()
+                if bool(dones_env.any()):                     # one host sync per step instead of one per rollout thread
+                    idx = torch.nonzero(dones_env).flatten().tolist()
+                    for t in idx:
+                        done_rewards.append(train_episode_rewards[:, t].clone())
+                        done_costs.append(train_episode_costs[:, t].clone())
+                    train_episode_rewards[:, idx] = 0
+                    train_episode_costs[:, idx] = 0
+                done_episodes_costs_aver = train_episode_costs.mean()
+                self.insert((obs, share_obs, rewards, costs, dones, infos, values, actions, action_log_probs, rnn_states,
+                             rnn_states_critic, cost_preds, rnn_states_cost, done_episodes_costs_aver))
+            self.compute()
+            self.train()
+            total_num_steps = (episode + 1) * c["episode_length"] * c["n_rollout_threads"]
+            if episode % c["save_interval"] == 0 or episode == episodes - 1:
+                self.save()
+            end = time.time()
+            if episode % c["eval_interval"] == 0 and c["use_eval"]:
+                eval_rewards, eval_costs = self.eval()
+            if len(done_rewards) != 0:
+                aver_episode_rewards = torch.stack(done_rewards).mean()
+                aver_episode_costs = torch.stack(done_costs).mean()
+                self.return_aver_cost(aver_episode_costs)
+                self.logger.store(**{"Metrics/EpRet": aver_episode_rewards.item(), "Metrics/EpCost": aver_episode_costs.item(),
+                                     "Eval/EpRet": eval_rewards, "Eval/EpCost": eval_costs})
+                self.logger.log_tabular("Metrics/EpRet", min_and_max=True, std=True)
+                self.logger.log_tabular("Metrics/EpCost", min_and_max=True, std=True)
+                self.logger.log_tabular("Eval/EpRet")
+                self.logger.log_tabular("Eval/EpCost")
+                self.logger.log_tabular("Train/Epoch", episode)
+                self.logger.log_tabular("Train/TotalSteps", total_num_steps)
+                for k in ("Loss/Loss_reward_critic", "Loss/Loss_cost_critic", "Loss/Loss_actor", "Misc/Reward_critic_norm",
+                          "Misc/Cost_critic_norm", "Misc/Entropy", "Misc/Ratio"):
+                    self.logger.log_tabular(k)
+                self.logger.log_tabular("Time/Total", end - start)
+                self.logger.log_tabular("Time/FPS", int(total_num_steps / (end - start)))
+                self.logger.dump_tabular()
+
+    def return_aver_cost(self, aver_episode_costs):
+        for b in self.buffer:
+            b.return_aver_insert(aver_episode_costs)
+
+    def warmup(self):
+        obs, share_obs, _ = self.envs.reset()
+        for a in range(self.num_agents):
+            self.buffer[a].share_obs[0].copy_(share_obs[:, a])
+            self.buffer[a].obs[0].copy_(obs[:, a])
+
+    @torch.no_grad()
+    def collect(self, step):
+        vals, acts, lps, rnn, rnn_c, cps, rnn_k = [], [], [], [], [], [], []
+        for a in range(self.num_agents):
+            b = self.buffer[a]
+            v, act, lp, r, rc, cp, rk = self.trainer[a].policy.get_actions(
+                b.share_obs[step], b.obs[step], b.rnn_states[step], b.rnn_states_critic[step], b.masks[step],
+                rnn_states_cost=b.rnn_states_cost[step])
+            vals.append(v); acts.append(act); lps.append(lp); rnn.append(r); rnn_c.append(rc); cps.append(cp); rnn_k.append(rk)
+        tr = lambda xs: torch.transpose(torch.stack(xs), 1, 0)
+        return tr(vals), acts, lps, tr(rnn), tr(rnn_c), tr(cps), tr(rnn_k)
+
+    def insert(self, data, aver_episode_costs=0):
+        (obs, share_obs, rewards, costs, dones, infos, values, actions, action_log_probs, rnn_states, rnn_states_critic,
+         cost_preds, rnn_states_cost, done_episodes_costs_aver) = data
+        dones_env = torch.all(dones, axis=1)
+        keep = (~dones_env).float()
+        # mappolag.py:458-472, as mask arithmetic on the device instead of boolean-index assignment
+        masks = keep.view(-1, 1, 1).expand(-1, self.num_agents, 1).contiguous()
+        active_masks = torch.ones(dones.shape[0], self.num_agents, 1, device=self.dev)
+        active_masks[dones == True] = 0.0
+        active_masks[dones_env == True] = 1.0
+        rnn_states = rnn_states * keep.view(-1, 1, 1, 1)
+        rnn_states_critic = rnn_states_critic * keep.view(-1, 1, 1, 1)
+        rnn_states_cost = rnn_states_cost * keep.view(-1, 1, 1, 1)
+        for a in range(self.num_agents):
+            self.buffer[a].insert(share_obs[:, a], obs[:, a], rnn_states[:, a], rnn_states_critic[:, a], actions[a],
+                                  action_log_probs[a], values[:, a], rewards[:, a], masks[:, a], None, active_masks[:, a], None,
+                                  costs=costs[:, a], cost_preds=cost_preds[:, a], rnn_states_cost=rnn_states_cost[:, a],
+                                  done_episodes_costs_aver=done_episodes_costs_aver, aver_episode_costs=aver_episode_costs)
+
+    def train(self, order=None, perm_fn=None):
+        c = self.config
+        factor = torch.ones(c["episode_length"], c["n_rollout_threads"], 1, device=self.dev)
+        order = torch.randperm(self.num_agents) if order is None else order
+        for agent_id in order:
+            a = int(agent_id)
+            b = self.buffer[a]
+            action_dim = b.actions.shape[-1]
+            b.update_factor(factor)
+            flat = lambda t: t.reshape(-1, *t.shape[2:])
+            args = (flat(b.obs[:-1]), flat(b.rnn_states[0:1]), flat(b.actions), flat(b.masks[:-1]), None, flat(b.active_masks[:-1]))
+            old_logp, _ = self.trainer[a].policy.actor.evaluate_actions(*args)
+            self.trainer[a].train(b, logger=self.logger, perm_fn=(lambda it, a=a: perm_fn(a, it)) if perm_fn else None)
+            new_logp, _ = self.trainer[a].policy.actor.evaluate_actions(*args)
+            action_prod = torch.prod(torch.exp(new_logp - old_logp).reshape(c["episode_length"], c["n_rollout_threads"], action_dim),
+                                     dim=-1, keepdim=True)
+            factor = factor * action_prod
+            b.after_update()
+
+    def save(self):
+        for a in range(self.num_agents):
+            torch.save(self.trainer[a].policy.actor.state_dict(), str(self.save_dir) + "/actor_agent" + str(a) + ".pt")
+            torch.save(self.trainer[a].policy.critic.state_dict(), str(self.save_dir) + "/critic_agent" + str(a) + ".pt")
+
+    def restore(self):
+        for a in range(self.num_agents):
+            self.policy[a].actor.load_state_dict(torch.load(str(self.model_dir) + "/actor_agent" + str(a) + ".pt"))
+            self.policy[a].critic.load_state_dict(torch.load(str(self.model_dir) + "/critic_agent" + str(a) + ".pt"))
+
+    @torch.no_grad()
+    def eval(self, eval_episodes=1):
+        c = self.config
+        n = c["n_eval_rollout_threads"]
+        done, rets, csts = 0, [], []
+        one_r, one_c = torch.zeros(1, n, device=self.dev), torch.zeros(1, n, device=self.dev)
+        eval_obs, _, _ = self.eval_envs.reset()
+        rnn = torch.zeros(n, self.num_agents, c["recurrent_N"], 1, device=self.dev)
+        masks = torch.ones(n, self.num_agents, 1, device=self.dev)
+        while True:
+            acts = []
+            for a in range(self.num_agents):
+                act, r = self.trainer[a].policy.act(eval_obs[:, a], rnn[:, a], masks[:, a], deterministic=True)
+                rnn[:, a] = r
+                acts.append(act)
+            eval_obs, _, rewards, costs, dones, _, _ = self.eval_envs.step(acts)
+            one_r += torch.mean(rewards, dim=1).flatten()
+            one_c += torch.mean(costs, dim=1).flatten()
+            dones_env = torch.all(dones, dim=1)
+            masks = (~dones_env).float().view(-1, 1, 1).expand(-1, self.num_agents, 1).contiguous()
+            rnn = rnn * masks.unsqueeze(-1)
+            for i in torch.nonzero(dones_env).flatten().tolist():
+                done += 1
+                rets.append(one_r[:, i].mean().item()); one_r[:, i] = 0
+                csts.append(one_c[:, i].mean().item()); one_c[:, i] = 0
+            if done >= eval_episodes:
+                return np.mean(rets), np.mean(csts)
+
+    @torch.no_grad()
+    def compute(self):
+        """mappolag.py:587-603: both recurrences of an agent in ONE kernel (spo_ma_gae) with PopArt de-normalisation."""
+        for a in range(self.num_agents):
+            b, tr = self.buffer[a], self.trainer[a]
+            tr._sync_normalizer()
+            next_value = tr.policy.get_values(b.share_obs[-1], b.rnn_states_critic[-1], b.masks[-1])
+            next_cost = tr.policy.get_cost_values(b.share_obs[-1], b.rnn_states_cost[-1], b.masks[-1])
+            b.compute_returns_and_cost_returns(next_value, next_cost, tr.value_normalizer, tr.value_normalizer)
+
+
+def train(args, cfg_train):
+    from safepo.common.env import make_ma_synth_env
+    if not str(args.task).startswith("Synth"):
+        raise NotImplementedError("this build has no simulator (safety_gymnasium / Isaac Gym are not installed here); "
+                                  "use a Synth* multi-agent task, or pass your own vector env to Runner(...)")
+    env = make_ma_synth_env(cfg_train, seed=args.seed)
+    cfg_eval = copy.deepcopy(cfg_train)
+    cfg_eval["seed"] = args.seed + 10000
+    cfg_eval["n_rollout_threads"] = cfg_eval["n_eval_rollout_threads"]
+    eval_env = make_ma_synth_env(cfg_eval, seed=args.seed + 10000)
+    runner = Runner(env, eval_env, cfg_train, args.model_dir)
+    if args.model_dir != "":
+        runner.eval(100000)
+    else:
+        runner.run()
+    return runner
+
+
+if __name__ == "__main__":
+    from safepo.utils.config import multi_agent_args
+    args, cfg_env, cfg_train = multi_agent_args(algo="mappolag")
+    torch.manual_seed(cfg_train.get("seed", 0))
+    np.random.seed(cfg_train.get("seed", 0))
+    if args.write_terminal:
+        train(args=args, cfg_train=cfg_train)
+    else:
+        os.makedirs(cfg_train["log_dir"], exist_ok=True)
+        with open(os.path.join(cfg_train["log_dir"], f"seed{args.seed}_terminal.log"), "w", encoding="utf-8") as f_out, \
+                open(os.path.join(cfg_train["log_dir"], f"seed{args.seed}_error.log"), "w", encoding="utf-8") as f_err:
+            sys.stdout, sys.stderr = f_out, f_err
+            train(args=args, cfg_train=cfg_train)

@@ -62,3 +62,63 @@ def single_agent_args(argv=None):
     if args.task in isaac_gym_map:
         raise Exception("Please install isaacgym to run Isaac Gym tasks!")
     return args, {}
+
+
+multi_agent_velocity_map = {
+    "Safety2x4AntVelocity-v0": {"agent_conf": "2x4", "scenario": "Ant"},
+    "Safety4x2AntVelocity-v0": {"agent_conf": "4x2", "scenario": "Ant"},
+    "Safety2x3HalfCheetahVelocity-v0": {"agent_conf": "2x3", "scenario": "HalfCheetah"},
+    "Safety6x1HalfCheetahVelocity-v0": {"agent_conf": "6x1", "scenario": "HalfCheetah"},
+    "Safety3x1HopperVelocity-v0": {"agent_conf": "3x1", "scenario": "Hopper"},
+    "Safety2x3Walker2dVelocity-v0": {"agent_conf": "2x3", "scenario": "Walker2d"},
+    "Safety2x1SwimmerVelocity-v0": {"agent_conf": "2x1", "scenario": "Swimmer"},
+    "Safety9|8HumanoidVelocity-v0": {"agent_conf": "9|8", "scenario": "Humanoid"},
+}
+
+
+def multi_agent_args(algo: str, argv=None):
+    """CLI of the multi-agent scripts (reference safepo/utils/config.py:194-278): same flags; the training config
+    starts from the algorithm's defaults (the reference's marl_cfg/<algo>/config.yaml, here a dict in the algorithm
+    module), with the `mamujoco` overrides for MuJoCo-style tasks -- the Synth* tasks count as such."""
+    import importlib
+    import time
+    p = argparse.ArgumentParser(description="RL Policy")
+    p.add_argument("--use-eval", type=_bool, default=False)
+    p.add_argument("--task", type=str, default="SynthMultiAgent-v0")
+    p.add_argument("--agent-conf", type=str, default="2x4")
+    p.add_argument("--scenario", type=str, default="Ant")
+    p.add_argument("--experiment", type=str, default="Base")
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--model-dir", type=str, default="")
+    p.add_argument("--cost-limit", type=float, default=25.0)
+    p.add_argument("--device", type=str, default="cuda")
+    p.add_argument("--device-id", type=int, default=0)
+    p.add_argument("--write-terminal", type=_bool, default=True)
+    p.add_argument("--headless", type=_bool, default=False)
+    p.add_argument("--total-steps", type=int, default=None)
+    p.add_argument("--num-envs", type=int, default=None)
+    p.add_argument("--randomize", type=bool, default=False)
+    args = p.parse_args(argv)
+    if args.task in isaac_gym_map:
+        raise NotImplementedError("Isaac Gym tasks need the isaacgym package (not part of this build)")
+    mod = importlib.import_module(f"safepo.multi_agent.{algo}")
+    cfg_train = dict(mod.default_cfg)
+    if args.task in multi_agent_velocity_map or args.task.startswith("Synth"):
+        cfg_train.update(mod.mamujoco_cfg)
+        if args.task in multi_agent_velocity_map:
+            args.agent_conf = multi_agent_velocity_map[args.task]["agent_conf"]
+            args.scenario = multi_agent_velocity_map[args.task]["scenario"]
+    cfg_train["use_eval"] = args.use_eval
+    cfg_train["cost_limit"] = args.cost_limit
+    cfg_train["algorithm_name"] = algo
+    cfg_train["device"] = args.device + ":" + str(args.device_id)
+    cfg_train["env_name"] = args.task
+    cfg_train["seed"] = args.seed
+    if args.total_steps:
+        cfg_train["num_env_steps"] = args.total_steps
+    if args.num_envs:
+        cfg_train["n_rollout_threads"] = args.num_envs
+        cfg_train["n_eval_rollout_threads"] = args.num_envs
+    relpath = "-".join(["-".join(["seed", str(args.seed).zfill(3)]), time.strftime("%Y-%m-%d-%H-%M-%S")])
+    cfg_train["log_dir"] = "../runs/" + args.experiment + "/" + args.task + "/" + algo + "/" + relpath
+    return args, {}, cfg_train

@@ -1118,3 +1118,117 @@ def test_in_kernel_gradient_exchange_two_ranks_one_gpu(dev, tmp_path, algo):
     assert res["frac_outside_1e-5"] <= 1e-3 and res["max_abs_diff_vs_allreduce_form"] < 2e-3, res
     assert res["loss_max_abs_diff"] < 1e-4, res
     print("p2p", res)
+
+
+# ====================================================================== f3: multi-agent MAPPO-L
+def _ma_cfg(dev, **over):
+    from safepo.multi_agent.mappolag import default_cfg
+    cfg = dict(default_cfg)
+    cfg.update(device=str(dev), **over)
+    return cfg
+
+
+class _Sp:
+    def __init__(self, n):
+        self.shape = (n,)
+
+
+@pytest.mark.parametrize("D,H,nb,O,actor,B", [(20, 64, 3, 5, True, 97), (33, 64, 3, 1, False, 97), (48, 128, 3, 6, True, 1030),
+                                               (100, 512, 2, 1, False, 259), (7, 33, 1, 2, True, 5)])
+def test_ma_network_forward_backward_vs_oracle(dev, D, H, nb, O, actor, B):
+    """LayerNorm -> [Linear, ELU, LayerNorm] x nb -> head: outputs and the full flat gradient (rocBLAS GEMMs + fused
+    LayerNorm/ELU kernels) against torch autograd on the CPU restatement."""
+    from oracle import ma_restatement as MR
+    from safepo.common.model import MultiAgentActor, MultiAgentCritic
+    torch.manual_seed(D + H)
+    cfg = _ma_cfg(dev, hidden_size=H, layer_N=nb - 1)
+    net = MultiAgentActor(cfg, _Sp(D), _Sp(O), dev) if actor else MultiAgentCritic(cfg, _Sp(D), dev)
+    with torch.no_grad():
+        net.theta.add_(0.1 * torch.randn_like(net.theta))            # LayerNorm weights/biases and heads off their defaults
+    ref = MR.MANet(D, H, nb, O, actor)
+    ref.load_reference_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    assert torch.equal(ref.flat(), net.theta.cpu())
+    x = torch.randn(B, D) * 1.5 + 0.3
+    out, saved = net.net_forward(x.to(dev), keep=True)
+    ref_out = ref(x)
+    np.testing.assert_allclose(out.cpu().numpy(), ref_out.detach().numpy(), rtol=2e-4, atol=2e-5)
+    dout = torch.randn(B, O)
+    ref_out.backward(dout)
+    grad = torch.full_like(net.theta, float("nan"))
+    net.net_backward(saved, dout.to(dev), grad)
+    got, want = grad.cpu(), ref.flat_grad() if not actor else None
+    if actor:                                  # log_std has no gradient through the mean head; its slot is left alone
+        ps = ref.ordered_parameters()
+        want = torch.cat([(p.grad if p.grad is not None else torch.full_like(p, float("nan"))).reshape(-1) for p in ps])
+        o = net.offset(6)
+        assert torch.isnan(got[o:o + O]).all()
+    m = ~torch.isnan(want)
+    scale = float(want[m].abs().max())
+    np.testing.assert_allclose(got[m].numpy(), want[m].numpy(), rtol=2e-3, atol=2e-5 * max(scale, 1.0))
+
+
+@pytest.mark.parametrize("tag", ["default", "mamujoco"])
+def test_ma_trainer_ppo_update_vs_reference_golden(dev, golden_dir, tag):
+    """Three MAPPO_L_Trainer.ppo_update steps against the reference's own trainer (tests/golden/ma_mappolag.npz): value /
+    cost / policy losses, the three gradient norms, entropy, ratio, the in-loop multiplier, PopArt statistics, and the
+    parameters of all three networks afterwards."""
+    from oracle import ma_restatement as MR
+    from safepo.multi_agent.mappolag import MAPPO_L_Policy, MAPPO_L_Trainer
+    z = np.load(os.path.join(golden_dir, "ma_mappolag.npz"))
+    gc = MR.cfg_from_golden(z, tag)
+    cfg = _ma_cfg(dev, **{k: gc[k] for k in gc})
+    cfg["hidden_size"], cfg["layer_N"] = int(gc["hidden_size"]), int(gc["layer_N"])
+    s = MR.sample_from_golden(z, tag)
+    D, S, A = s["obs"].shape[1], s["share_obs"].shape[1], s["actions"].shape[1]
+    pol = MAPPO_L_Policy(cfg, _Sp(D), _Sp(S), _Sp(A))
+    for nm, net in (("actor", pol.actor), ("critic", pol.critic), ("cost_critic", pol.cost_critic)):
+        pre = f"{tag}_init_{nm}_"
+        net.load_state_dict({k[len(pre):]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith(pre)})
+    # forward parity on the reference's own numbers
+    np.testing.assert_allclose(pol.actor.net_forward(s["obs"].to(dev)).cpu().numpy(), z[f"{tag}_fwd_mean"], rtol=2e-4, atol=2e-5)
+    lp, _ = pol.actor.evaluate_actions(s["obs"].to(dev), None, s["actions"].to(dev), None)
+    np.testing.assert_allclose(lp.cpu().numpy(), z[f"{tag}_fwd_logp"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(pol.get_values(s["share_obs"].to(dev), None, None).cpu().numpy(), z[f"{tag}_fwd_values"], rtol=2e-4, atol=2e-5)
+    tr = MAPPO_L_Trainer(cfg, pol)
+    sample = (s["share_obs"], s["obs"], None, None, s["actions"], s["value_preds"], s["returns"], None, s["active_masks"],
+              s["old_logp"], s["adv"], None, s["factor"], s["cost_preds"], s["cost_returns"], None, s["cost_adv"],
+              s["aver_episode_costs"])
+    sample = tuple(t.to(dev) if torch.is_tensor(t) else t for t in sample)
+    rows = []
+    for _ in range(3):
+        vl, cgn, plo, ent, agn, imp, cl, cogn = tr.ppo_update(sample)
+        vn = tr.value_normalizer
+        rows.append([vl.item(), cgn.item(), plo.item(), ent.item(), agn.item(), imp.detach().mean().item(), cl.item(), cogn.item(),
+                     float(tr.lamda_lagr), float(vn.running_mean), float(vn.running_mean_sq), float(vn.debiasing_term)])
+    np.testing.assert_allclose(np.asarray(rows), z[f"{tag}_steps"], rtol=2e-3, atol=2e-6)
+    lr = max(float(gc["actor_lr"]), float(gc["critic_lr"]))
+    for nm, net in (("actor", pol.actor), ("critic", pol.critic), ("cost_critic", pol.cost_critic)):
+        pre = f"{tag}_final_{nm}_"
+        want = np.concatenate([z[k].reshape(-1) for k in z.files if k.startswith(pre)])
+        _assert_params_close(net.theta.cpu().numpy(), want, lr, 3, rtol=2e-3, atol=2e-5, what=f"{tag} {nm}")
+
+
+def test_ma_mappolag_runner_end_to_end_synthetic(dev, tmp_path):
+    """safepo.multi_agent.mappolag.train() on the synthetic 4-agent env: collect -> insert -> fused GAE/PopArt -> HAPPO
+    sequential updates, logger rows and per-agent checkpoints in the reference's formats; the team reward improves."""
+    import argparse
+    import csv
+    from safepo.multi_agent import mappolag
+    cfg = _ma_cfg(dev, **mappolag.mamujoco_cfg)
+    cfg.update(n_rollout_threads=64, n_eval_rollout_threads=4, episode_length=16, num_env_steps=64 * 16 * 12, hidden_size=64,
+               log_dir=str(tmp_path / "run"), seed=0, actor_lr=3e-3, critic_lr=3e-3, env_name="SynthMultiAgent-v0",
+               env_kwargs={"trunc_len": 16, "num_agents": 3, "obs_dim": 12, "act_dim": 2}, cost_limit=1.0)
+    args = argparse.Namespace(task="SynthMultiAgent-v0", seed=0, model_dir="")
+    torch.manual_seed(0)
+    runner = mappolag.train(args, cfg)
+    rows = list(csv.DictReader(open(tmp_path / "run" / "progress.csv")))
+    assert len(rows) == 12
+    for col in ("Metrics/EpRet", "Metrics/EpCost", "Loss/Loss_reward_critic", "Loss/Loss_cost_critic", "Loss/Loss_actor",
+                "Misc/Reward_critic_norm", "Misc/Cost_critic_norm", "Misc/Entropy", "Misc/Ratio", "Time/FPS"):
+        assert col in rows[0], col
+    rets = [float(r["Metrics/EpRet"]) for r in rows]
+    assert np.isfinite(rets).all() and np.mean(rets[-3:]) > np.mean(rets[:3]), rets
+    for a in range(3):
+        sd = torch.load(tmp_path / "run" / "models_seed0" / f"actor_agent{a}.pt")
+        assert "act.action_out.log_std" in sd and sd["base.mlp.fc1.0.weight"].shape == (64, 12)
+    assert float(runner.trainer[0].lamda_lagr) >= 0.0

@@ -224,6 +224,27 @@ def test_kl_penalty_family_main_trace(golden_dir, algo, upper):
         np.testing.assert_allclose(v.numpy(), z[f"final_sd_{k}"], rtol=2e-5, atol=2e-7, err_msg=k)
 
 
+@pytest.mark.parametrize("tag", ["default", "mamujoco"])
+def test_ma_mappolag_restatement_vs_reference(golden_dir, tag):
+    """Networks (forward, per-dimension log-probs) and three MAPPO_L_Trainer.ppo_update steps of the reference:
+    losses, gradient norms, entropy, ratio, in-loop lambda, PopArt statistics, parameters after."""
+    from oracle import ma_restatement as MR
+    z = _load(golden_dir, "ma_mappolag.npz")
+    nets, cfg, s = MR.nets_from_golden(z, tag), MR.cfg_from_golden(z, tag), MR.sample_from_golden(z, tag)
+    with torch.no_grad():
+        mean = nets["actor"](s["obs"])
+        np.testing.assert_allclose(mean.numpy(), z[f"{tag}_fwd_mean"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(MR.log_probs(mean, nets["actor"].std(), s["actions"]).numpy(), z[f"{tag}_fwd_logp"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(nets["critic"](s["share_obs"]).numpy(), z[f"{tag}_fwd_values"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(nets["cost_critic"](s["share_obs"]).numpy(), z[f"{tag}_fwd_cost_preds"], rtol=1e-5, atol=1e-6)
+    tr = MR.OracleMATrainer(cfg, nets["actor"], nets["critic"], nets["cost_critic"])
+    rows = [tr.ppo_update(s)["row"] for _ in range(3)]
+    np.testing.assert_allclose(np.asarray(rows), z[f"{tag}_steps"], rtol=2e-5, atol=1e-7)
+    fin = MR.nets_from_golden(z, tag, "final")
+    for nm in nets:
+        np.testing.assert_allclose(nets[nm].flat().numpy(), fin[nm].flat().numpy(), rtol=2e-5, atol=2e-7, err_msg=nm)
+
+
 def test_boundary_logic_matches_trace(golden_dir):
     """a-4: done -> bootstrap 0; epoch end and time-out both end a path (ppo_lag.py:198-234)."""
     z = _load(golden_dir, "ppo_lag_trace.npz")
