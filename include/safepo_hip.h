@@ -304,7 +304,7 @@ int spo_ma_actor_loss(const float* mean, const float* log_std, const float* act,
                       float* dlogstd_out, float* scalars5_out, double* partial_ws, void* stream);
 int spo_ma_lamda_update(float* lamda_dev, const float* scalars5, float aver_episode_cost, float cost_limit, float gamma,
                         float lagrangian_coef_rate, void* stream);
-int spo_ma_popart_forward(const float* x, int64_t rows, float* state3, float beta, float epsilon, int train, float* out,
+int spo_ma_popart_forward(const float* x, int64_t rows, float* state3, double beta, float epsilon, int train, float* out,
                           double* partial_ws, void* stream);
 int spo_ma_value_loss(const float* values, const float* value_preds, const float* returns_norm_clipped,
                       const float* returns_norm_original, float clip_param, float huber_delta, float value_loss_coef,

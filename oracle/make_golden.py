@@ -415,6 +415,95 @@ def golden_ma_mappolag():
     print("ma_mappolag.npz", len(out), "arrays")
 
 
+def golden_ma_runner_trace():
+    """Three episodes of the reference mappolag Runner.run() (safepo/multi_agent/mappolag.py:252-604) on SynthMAEnv:
+    buffers before compute(), returns after it, the agent order and minibatch permutations (recorded from torch.randperm),
+    logger rows, multipliers, PopArt statistics and all networks after every episode."""
+    import importlib
+    import shutil
+    import yaml
+    from oracle.synth_env import SynthMAEnv
+    if ref_shim.REF_ROOT not in sys.path:
+        sys.path.insert(0, ref_shim.REF_ROOT)
+    ref_shim._install_stubs()
+    M = importlib.import_module("safepo.multi_agent.mappolag")
+    cfg = yaml.safe_load(open(os.path.join(ref_shim.REF_ROOT, "safepo/multi_agent/marl_cfg/mappolag/config.yaml")))
+    cfg.update(cfg["mamujoco"])
+    N, T, EP = 6, 12, 3
+    log_dir = "/tmp/oracle_runs/ma_runner"
+    shutil.rmtree(log_dir, ignore_errors=True)
+    cfg.update(device="cpu", hidden_size=32, n_rollout_threads=N, n_eval_rollout_threads=2, episode_length=T,
+               num_env_steps=N * T * EP, learning_iters=3, num_mini_batch=2, use_eval=False, cost_limit=0.3,
+               lagrangian_coef_rate=0.05, actor_lr=2e-3, critic_lr=2e-3, log_dir=log_dir, seed=0, algorithm_name="mappolag",
+               env_name="SynthMA")
+    torch.manual_seed(5)
+    env = SynthMAEnv(N, seed=3, trunc_len=6)
+    rec = Recorder()
+    runner = M.Runner(env, None, cfg)
+    runner.logger.use_tensorboard = False if hasattr(runner.logger, "use_tensorboard") else None
+    A = runner.num_agents
+    for a in range(A):
+        pol = runner.policy[a]
+        for nm, net in (("actor", pol.actor), ("critic", pol.critic), ("cost_critic", pol.cost_critic)):
+            for k, v in net.state_dict().items():
+                rec.put(f"init_a{a}_{nm}_{k}", v)
+    state = {"ep": 0, "perms": []}
+    real_randperm = torch.randperm
+
+    def randperm(n, *a, **k):
+        out = real_randperm(n, *a, **k)
+        state["perms"].append(out.clone())
+        return out
+    real_compute, real_train, real_dump = runner.compute, runner.train, runner.logger.dump_tabular
+    BUF = ("share_obs", "obs", "actions", "action_log_probs", "value_preds", "cost_preds", "rewards", "costs", "masks", "active_masks")
+
+    def compute():
+        e = state["ep"]
+        for a in range(A):
+            for k in BUF:
+                rec.put(f"e{e}_a{a}_{k}", getattr(runner.buffer[a], k))
+            rec.put(f"e{e}_a{a}_aver_episode_costs", runner.buffer[a].aver_episode_costs)
+        real_compute()
+        for a in range(A):
+            rec.put(f"e{e}_a{a}_returns", runner.buffer[a].returns)
+            rec.put(f"e{e}_a{a}_cost_returns", runner.buffer[a].cost_returns)
+
+    def train():
+        e = state["ep"]
+        state["perms"] = []
+        torch.randperm = randperm
+        try:
+            real_train()
+        finally:
+            torch.randperm = real_randperm
+        rec.put(f"e{e}_agent_order", state["perms"][0])
+        for i, pm in enumerate(state["perms"][1:]):
+            rec.put(f"e{e}_perm{i}", pm)
+        for k, v in runner.logger.epoch_dict.items():
+            if k.startswith(("Loss/", "Misc/")):
+                rec.put(f"e{e}_stored_{k.replace('/', '_')}", np.asarray(v, np.float64))
+        for a in range(A):
+            tr = runner.trainer[a]
+            rec.put(f"e{e}_a{a}_lamda", np.float64(float(tr.lamda_lagr)))
+            vn = tr.value_normalizer
+            rec.put(f"e{e}_a{a}_popart", np.asarray([float(vn.running_mean), float(vn.running_mean_sq), float(vn.debiasing_term)]))
+            for nm, net in (("actor", tr.policy.actor), ("critic", tr.policy.critic), ("cost_critic", tr.policy.cost_critic)):
+                for k, v in net.state_dict().items():
+                    rec.put(f"e{e}_a{a}_after_{nm}_{k}", v)
+        state["ep"] += 1
+    runner.compute, runner.train = compute, train
+    runner.run()
+    for k in ("clip_param", "entropy_coef", "huber_delta", "value_loss_coef", "max_grad_norm", "actor_lr", "critic_lr", "opti_eps",
+              "weight_decay", "lamda_lagr", "cost_limit", "gamma", "gae_lambda", "lagrangian_coef_rate", "std_x_coef", "std_y_coef",
+              "layer_N", "hidden_size", "learning_iters", "num_mini_batch", "use_policy_active_masks", "episode_length",
+              "n_rollout_threads"):
+        rec.put(f"cfg_{k}", np.float64(cfg[k]))
+    rec.put("meta_agents", np.int64(A))
+    rec.put("meta_episodes", np.int64(EP))
+    np.savez_compressed(os.path.join(OUT, "ma_runner_trace.npz"), **rec.a)
+    print("ma_runner_trace.npz", len(rec.a), "arrays")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
@@ -423,6 +512,7 @@ if __name__ == "__main__":
     golden_pid()
     golden_ma_gae()
     golden_ma_mappolag()
+    golden_ma_runner_trace()
     env_kw = dict(obs_dim=60, act_dim=8, p_term=0.03, p_cost=0.3, trunc_len=20)
     golden_trace("ppo_lag", "ppo_lag_trace.npz", num_envs=4, T=48, epochs=3, env_kw=env_kw,
                  cfg_over={"learning_iters": 6, "target_kl": 0.004},

@@ -81,3 +81,43 @@ class SynthEnv:
             info["final_observation"] = final
             self.t_env[finished] = 0
         return obs, reward, cost, terminated, truncated, info
+
+
+class SynthMAEnv:
+    """CPU multi-agent vector env with the interface the reference MAPPO-L Runner consumes (TEST INFRASTRUCTURE:
+    drives the unmodified reference Runner for tests/golden/ma_runner_trace.npz).  All agents of a thread finish
+    together every `trunc_len` steps."""
+
+    def __init__(self, num_envs, num_agents=3, obs_dim=10, act_dim=2, share_dim=14, seed=0, p_cost=0.3, trunc_len=6):
+        import torch
+        self.torch = torch
+        self.num_envs, self.num_agents, self.obs_dim, self.act_dim, self.share_dim = num_envs, num_agents, obs_dim, act_dim, share_dim
+        self.p_cost, self.trunc_len, self.t = p_cost, trunc_len, 0
+        self.gen = torch.Generator().manual_seed(seed)
+        self.W = torch.randn(num_agents, obs_dim, act_dim, generator=torch.Generator().manual_seed(99)) / obs_dim ** 0.5
+        self.observation_space = [Space(obs_dim) for _ in range(num_agents)]
+        self.share_observation_space = [Space(share_dim) for _ in range(num_agents)]
+        self.action_space = [Space(act_dim) for _ in range(num_agents)]
+
+    def _draw(self):
+        t = self.torch
+        obs = t.randn(self.num_envs, self.num_agents, self.obs_dim, generator=self.gen)
+        share = obs.reshape(self.num_envs, -1)[:, :self.share_dim].unsqueeze(1).expand(-1, self.num_agents, -1).contiguous()
+        return obs, share
+
+    def reset(self):
+        self.t = 0
+        self._obs, share = self._draw()
+        return self._obs, share, None
+
+    def step(self, actions):
+        t = self.torch
+        act = t.stack([a.reshape(self.num_envs, self.act_dim) for a in actions], dim=1)
+        target = t.tanh(t.einsum("nad,adk->nak", self._obs, self.W))
+        team = -((act - target) ** 2).mean(dim=(1, 2))
+        rewards = team.view(-1, 1, 1).expand(-1, self.num_agents, 1).contiguous()
+        costs = (t.rand(self.num_envs, 1, 1, generator=self.gen) < self.p_cost).float().expand(-1, self.num_agents, 1).contiguous()
+        self.t += 1
+        dones = t.full((self.num_envs, self.num_agents), self.t % self.trunc_len == 0)
+        self._obs, share = self._draw()
+        return self._obs, share, rewards, costs, dones, [{} for _ in range(self.num_envs)], None

@@ -403,13 +403,15 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
     partial[2 * blockIdx.x + 1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
   }
 }
-__global__ void popart_update_kernel(const double* __restrict__ partial, int nblocks, int64_t B, float beta, float* state) {
+__global__ void popart_update_kernel(const double* __restrict__ partial, int nblocks, int64_t B, float beta, float omb, float* state) {
   double s = 0, q = 0;
   for (int b = 0; b < nblocks; ++b) { s += partial[2 * b]; q += partial[2 * b + 1]; }
   const float bm = (float)(s / (double)B), bq = (float)(q / (double)B);
-  state[0] = state[0] * beta + bm * (1.f - beta);
-  state[1] = state[1] * beta + bq * (1.f - beta);
-  state[2] = state[2] * beta + 1.f * (1.f - beta);
+  // omb = (1.0 - beta) formed in double on the host, as the reference's python float arithmetic does (popart.py:104-106):
+  // 1.f - 0.99999f would be 1.00136e-5
+  state[0] = state[0] * beta + bm * omb;
+  state[1] = state[1] * beta + bq * omb;
+  state[2] = state[2] * beta + 1.f * omb;
 }
 __global__ void popart_normalize_kernel(const float* __restrict__ x, const float* __restrict__ state, float eps,
                                         float* __restrict__ out, int64_t B) {
@@ -649,15 +651,16 @@ extern "C" int spo_ma_lamda_update(float* lamda_dev, const float* scalars5, floa
 }
 
 // PopArt.forward(x, train): optional statistics update, then normalisation.  partial_ws: double[2 * 1024]
-extern "C" int spo_ma_popart_forward(const float* x, int64_t rows, float* state3, float beta, float epsilon, int train,
+extern "C" int spo_ma_popart_forward(const float* x, int64_t rows, float* state3, double beta_d, float epsilon, int train,
                                      float* out, double* partial_ws, void* stream) {
+  const float beta = (float)beta_d;
   SPO_REQUIRE(x && state3 && out && partial_ws && rows > 0, "ma_popart_forward: bad args");
   hipStream_t st = (hipStream_t)stream;
   if (train) {
     int64_t g = (rows + 255) / 256;
     const int gr = (int)(g > 1024 ? 1024 : g);
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(gr), dim3(256), 0, st, x, rows, partial_ws);
-    hipLaunchKernelGGL(popart_update_kernel, dim3(1), dim3(1), 0, st, partial_ws, gr, rows, beta, state3);
+    hipLaunchKernelGGL(popart_update_kernel, dim3(1), dim3(1), 0, st, partial_ws, gr, rows, beta, (float)(1.0 - beta_d), state3);
   }
   hipLaunchKernelGGL(popart_normalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, x, state3, epsilon, out, rows);
   SPO_LAUNCH_CHECK("spo_ma_popart_forward");

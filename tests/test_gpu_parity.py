@@ -1232,3 +1232,64 @@ def test_ma_mappolag_runner_end_to_end_synthetic(dev, tmp_path):
         sd = torch.load(tmp_path / "run" / "models_seed0" / f"actor_agent{a}.pt")
         assert "act.action_out.log_std" in sd and sd["base.mlp.fc1.0.weight"].shape == (64, 12)
     assert float(runner.trainer[0].lamda_lagr) >= 0.0
+
+
+def test_ma_runner_compute_and_train_vs_reference_runner_trace(dev, golden_dir, tmp_path):
+    """Replays three episodes of the reference mappolag Runner (tests/golden/ma_runner_trace.npz): same buffers, agent
+    order and minibatch permutations -> returns / cost returns after compute() (fused GAE + PopArt kernel, next values
+    from the HIP networks), every stored loss / norm / entropy / ratio, multipliers, PopArt statistics and all three
+    networks of every agent after each episode's HAPPO-sequential training."""
+    from safepo.multi_agent import mappolag
+    z = np.load(os.path.join(golden_dir, "ma_runner_trace.npz"))
+    A, EP = int(z["meta_agents"]), int(z["meta_episodes"])
+    T, N = int(z["cfg_episode_length"]), int(z["cfg_n_rollout_threads"])
+    over = {k[4:]: float(z[k]) for k in z.files if k.startswith("cfg_")}
+    cfg = _ma_cfg(dev, **mappolag.mamujoco_cfg)
+    cfg.update(over)
+    for k in ("hidden_size", "layer_N", "learning_iters", "num_mini_batch", "episode_length", "n_rollout_threads"):
+        cfg[k] = int(cfg[k])
+    cfg["use_policy_active_masks"] = bool(cfg["use_policy_active_masks"])
+    cfg.update(log_dir=str(tmp_path / "run"), seed=0, env_name="trace")
+    D, S, Adim = z["e0_a0_obs"].shape[-1], z["e0_a0_share_obs"].shape[-1], z["e0_a0_actions"].shape[-1]
+
+    class _Spaces:
+        num_agents = A
+        observation_space = [_Sp(D)] * A
+        share_observation_space = [_Sp(S)] * A
+        action_space = [_Sp(Adim)] * A
+    runner = mappolag.Runner(_Spaces(), None, cfg)
+    for a in range(A):
+        pol = runner.policy[a]
+        for nm, net in (("actor", pol.actor), ("critic", pol.critic), ("cost_critic", pol.cost_critic)):
+            pre = f"init_a{a}_{nm}_"
+            net.load_state_dict({k[len(pre):]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith(pre)})
+    n_steps = 0
+    for e in range(EP):
+        for a in range(A):
+            b = runner.buffer[a]
+            for k in ("share_obs", "obs", "actions", "action_log_probs", "value_preds", "cost_preds", "rewards", "costs", "masks",
+                      "active_masks"):
+                getattr(b, k).copy_(torch.from_numpy(z[f"e{e}_a{a}_{k}"]))
+            b.aver_episode_costs = torch.from_numpy(z[f"e{e}_a{a}_aver_episode_costs"].copy()).to(dev)
+        runner.compute()
+        for a in range(A):
+            np.testing.assert_allclose(runner.buffer[a].returns.cpu().numpy(), z[f"e{e}_a{a}_returns"], rtol=2e-4, atol=2e-5)
+            np.testing.assert_allclose(runner.buffer[a].cost_returns.cpu().numpy(), z[f"e{e}_a{a}_cost_returns"], rtol=2e-4, atol=2e-5)
+        order = [int(i) for i in z[f"e{e}_agent_order"]]
+        iters = cfg["learning_iters"]
+        perm_of = {a: [z[f"e{e}_perm{pos * iters + it}"] for it in range(iters)] for pos, a in enumerate(order)}
+        runner.logger.epoch_dict.clear()
+        runner.train(order=order, perm_fn=lambda a, it: perm_of[a][it])
+        n_steps += iters * cfg["num_mini_batch"]
+        for key in ("Loss/Loss_reward_critic", "Loss/Loss_cost_critic", "Loss/Loss_actor", "Misc/Reward_critic_norm",
+                    "Misc/Cost_critic_norm", "Misc/Entropy", "Misc/Ratio"):
+            got = np.asarray(runner.logger.epoch_dict[key], np.float64)
+            np.testing.assert_allclose(got, z[f"e{e}_stored_{key.replace('/', '_')}"], rtol=5e-3, atol=5e-5, err_msg=f"episode {e} {key}")
+        for a in range(A):
+            tr = runner.trainer[a]
+            assert float(tr.lamda_lagr) == pytest.approx(float(z[f"e{e}_a{a}_lamda"]), rel=1e-4)
+            np.testing.assert_allclose(tr._popart_state.cpu().numpy(), z[f"e{e}_a{a}_popart"], rtol=1e-3, atol=1e-8)
+            for nm, net in (("actor", tr.policy.actor), ("critic", tr.policy.critic), ("cost_critic", tr.policy.cost_critic)):
+                pre = f"e{e}_a{a}_after_{nm}_"
+                want = np.concatenate([z[k].reshape(-1) for k in z.files if k.startswith(pre)])
+                _assert_params_close(net.theta.cpu().numpy(), want, 2e-3, n_steps, rtol=5e-3, atol=5e-5, what=f"episode {e} agent {a} {nm}")
