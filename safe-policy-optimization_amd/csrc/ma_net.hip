@@ -67,11 +67,109 @@ int gemm_dyw(hipStream_t st, const float* dY, const float* W, float* dX, int64_t
   if (int rc = g_rb.sgemm(g_rb.h, RB_N, RB_N, K, (int)B, N, &alpha, W, K, dY, N, &beta, dX, K)) return fail(-22, "sgemm dyw (%d)", rc);
   return 0;
 }
-// dW[N,K] = dY[B,N]^T * X[B,K]
-int gemm_dyTx(hipStream_t st, const float* dY, const float* X, float* dW, int64_t B, int K, int N) {
-  const float alpha = 1.f, beta = 0.f;
-  if (int rc = g_rb.set_stream(g_rb.h, st)) return fail(-22, "rocblas_set_stream (%d)", rc);
-  if (int rc = g_rb.sgemm(g_rb.h, RB_N, RB_T, K, N, (int)B, &alpha, X, K, dY, N, &beta, dW, K)) return fail(-22, "sgemm dyTx (%d)", rc);
+// dW[N,K] = dY[B,N]^T * X[B,K]: a tiny output reduced over a huge row count.  rocBLAS runs this shape at 5 TFLOP/s
+// (one 256x64 macro-tile marching over 524 288 rows: 3.15 ms at N = K = 128, 59 % of a MAPPO-L epoch); the shape is
+// HBM-bound (both operands are read once: 537 MB -> ~0.15 ms), so it is done here: the rows are split over up to 256
+// workgroups per 128x128 output tile, each accumulating its slice with fp32 MFMA from LDS-staged 32-row chunks, and a
+// second kernel adds the slices in a fixed order.
+typedef float f4v __attribute__((ext_vector_type(4)));
+constexpr int DW_T = 128, DW_R = 32, DW_LD = DW_T + 16;      // row stride 144: the two row-groups of a half-wave land 16 banks apart
+
+int dw_splits(int64_t B, int N, int K) {
+  const int64_t tiles = (int64_t)((N + DW_T - 1) / DW_T) * ((K + DW_T - 1) / DW_T);
+  int64_t s = (B + 255) / 256;                       // at least 256 rows per slice
+  const int64_t cap_mem = (int64_t)(1 << 24) / ((int64_t)N * K) > 0 ? (int64_t)(1 << 24) / ((int64_t)N * K) : 1;   // <= 64 MB of slices
+  const int64_t cap_grid = 2048 / tiles > 0 ? 2048 / tiles : 1;
+  if (s > 256) s = 256;
+  if (s > cap_mem) s = cap_mem;
+  if (s > cap_grid) s = cap_grid;
+  return (int)(s < 1 ? 1 : s);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256, 2) void dw_partial_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+                                                            float* __restrict__ partial, int64_t B, int N, int K, int S) {
+  __shared__ __attribute__((aligned(16))) float Ys[DW_R * DW_LD];
+  __shared__ __attribute__((aligned(16))) float Xs[DW_R * DW_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kk = lane >> 4;
+  const int tiles_k = (K + DW_T - 1) / DW_T;
+  const int tile = blockIdx.x / S, slice = blockIdx.x % S;
+  const int n0 = (tile / tiles_k) * DW_T, k0 = (tile % tiles_k) * DW_T;
+  const int64_t rows_per = ((B + S - 1) / S + DW_R - 1) / DW_R * DW_R;
+  const int64_t r_begin = (int64_t)slice * rows_per;
+  const int64_t r_end = r_begin + rows_per < B ? r_begin + rows_per : B;
+  f4v acc[2][8];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[m][t] = f4v{0.f, 0.f, 0.f, 0.f};
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += DW_R) {
+    // stage 32 rows x 128 columns of both operands (zero beyond the matrix edges)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = q * 256 + tid, row = idx >> 5, c4 = (idx & 31) * 4;
+      const int64_t r = r0 + row;
+      f4v y = {0.f, 0.f, 0.f, 0.f}, x = {0.f, 0.f, 0.f, 0.f};
+      if (r < r_end) {
+        if (VEC) {
+          if (n0 + c4 < N) y = *reinterpret_cast<const f4v*>(dY + r * N + n0 + c4);
+          if (k0 + c4 < K) x = *reinterpret_cast<const f4v*>(X + r * K + k0 + c4);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (n0 + c4 + e < N) y[e] = dY[r * N + n0 + c4 + e];
+            if (k0 + c4 + e < K) x[e] = X[r * K + k0 + c4 + e];
+          }
+        }
+      }
+      *reinterpret_cast<f4v*>(Ys + row * DW_LD + c4) = y;
+      *reinterpret_cast<f4v*>(Xs + row * DW_LD + c4) = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < DW_R / 4; ++st) {
+      const float* yr = Ys + (4 * st + kk) * DW_LD + 32 * wave + i;
+      const float* xr = Xs + (4 * st + kk) * DW_LD + i;
+      const float a0 = yr[0], a1 = yr[16];
+      float b[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) b[t] = xr[16 * t];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[t], acc[0][t], 0, 0, 0);
+        acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[t], acc[1][t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // C layout: lane holds C[row = 4*(lane>>4) + e][col = lane & 15] of each 16x16 tile
+  float* out = partial + (int64_t)slice * N * K;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = n0 + 32 * wave + 16 * m + 4 * kk + e, k = k0 + 16 * t + i;
+        if (n < N && k < K) out[(int64_t)n * K + k] = acc[m][t][e];
+      }
+}
+__global__ void dw_reduce_kernel(const float* __restrict__ partial, int S, int64_t NK, float* __restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= NK) return;
+  float s = 0.f;
+  for (int b = 0; b < S; ++b) s += partial[(int64_t)b * NK + j];
+  out[j] = s;
+}
+// `slices`: float[dw_splits(B, N, K) * N * K]
+int gemm_dyTx(hipStream_t st, const float* dY, const float* X, float* dW, int64_t B, int K, int N, float* slices) {
+  const int S = dw_splits(B, N, K);
+  const int tiles = ((N + DW_T - 1) / DW_T) * ((K + DW_T - 1) / DW_T);
+  const bool vec = (N % 4 == 0) && (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X)) % 16 == 0);
+  if (vec) hipLaunchKernelGGL(dw_partial_kernel<true>, dim3(tiles * S), dim3(256), 0, st, dY, X, slices, B, N, K, S);
+  else hipLaunchKernelGGL(dw_partial_kernel<false>, dim3(tiles * S), dim3(256), 0, st, dY, X, slices, B, N, K, S);
+  const int64_t NK = (int64_t)N * K;
+  hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)((NK + 255) / 256)), dim3(256), 0, st, slices, S, NK, dW);
   return 0;
 }
 
@@ -219,18 +317,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 }
 
 // out[w][j] = sum over blocks (fixed order) of partial[block][w][j]
-__global__ void colsum_finish_kernel(const float* __restrict__ partial, int nblocks, int D, float* o0, float* o1, float* o2) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= D) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  for (int b = 0; b < nblocks; ++b) {
-    s0 += partial[((int64_t)b * 3 + 0) * D + j];
-    s1 += partial[((int64_t)b * 3 + 1) * D + j];
-    s2 += partial[((int64_t)b * 3 + 2) * D + j];
-  }
-  if (o0) o0[j] = s0;
-  if (o1) o1[j] = s1;
-  if (o2) o2[j] = s2;
+// grid (ceil(D/64), 3), 256 threads = 64 columns x 4 strided slices of the block list, combined in a fixed order
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, int nblocks, int D, float* o0,
+                                                            float* o1, float* o2) {
+  __shared__ float sh[4][64];
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6, w = blockIdx.y;
+  const int j = blockIdx.x * 64 + c;
+  float s = 0.f;
+  if (j < D)
+    for (int b = q; b < nblocks; b += 4) s += partial[((int64_t)b * 3 + w) * D + j];
+  sh[q][c] = s;
+  __syncthreads();
+  float* o = w == 0 ? o0 : w == 1 ? o1 : o2;
+  if (q == 0 && j < D && o) o[j] = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
 }
 
 // head: out[B,O] += bias ; db[O] = column sums of dout (second form)
@@ -238,19 +337,29 @@ __global__ void add_bias_kernel(float* __restrict__ out, const float* __restrict
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] += b[i % O];
 }
-__global__ __launch_bounds__(256) void colsum_small_kernel(const float* __restrict__ d, int64_t B, int O, float* __restrict__ out) {
-  // one block per output column (O <= 64), fixed-order tree
+// column sums of d[B, O] (O <= 64): grid (O, nslices) -> partial[slice][O], then a fixed-order finish
+__global__ __launch_bounds__(256) void colsum_small_kernel(const float* __restrict__ d, int64_t B, int O, int nslices,
+                                                           float* __restrict__ partial) {
   __shared__ float sh[256];
-  const int o = blockIdx.x;
+  const int o = blockIdx.x, sl = blockIdx.y;
+  const int64_t per = (B + nslices - 1) / nslices;
+  const int64_t lo = sl * per, hi = lo + per < B ? lo + per : B;
   float s = 0.f;
-  for (int64_t r = threadIdx.x; r < B; r += 256) s += d[r * O + o];
+  for (int64_t r = lo + threadIdx.x; r < hi; r += 256) s += d[r * O + o];
   sh[threadIdx.x] = s;
   __syncthreads();
   for (int k = 128; k > 0; k >>= 1) {
     if (threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[o] = sh[0];
+  if (threadIdx.x == 0) partial[sl * O + o] = sh[0];
+}
+__global__ void colsum_small_finish_kernel(const float* __restrict__ partial, int O, int nslices, float* __restrict__ out) {
+  const int o = threadIdx.x;
+  if (o >= O) return;
+  float s = 0.f;
+  for (int b = 0; b < nslices; ++b) s += partial[b * O + o];
+  out[o] = s;
 }
 
 int grid_rows(int64_t B) {
@@ -562,7 +671,11 @@ extern "C" int64_t spo_ma_backward_scratch_floats(const spo_ma_net* net, int64_t
   Lay L;
   if (lay_of(net, &L) || rows < 1) return -1;
   const int64_t W = L.H > L.D ? L.H : L.D;
-  return 2 * rows * W + 1024 * 3 * W;
+  int64_t slices = (int64_t)dw_splits(rows, L.H, L.H) * L.H * L.H;
+  const int64_t s0 = (int64_t)dw_splits(rows, L.H, L.D) * L.H * L.D, s1 = (int64_t)dw_splits(rows, L.O, L.H) * L.O * L.H;
+  if (s0 > slices) slices = s0;
+  if (s1 > slices) slices = s1;
+  return 2 * rows * W + 1024 * 3 * W + slices;
 }
 extern "C" int spo_ma_backward(const float* theta, const spo_ma_net* net, const float* x, int64_t rows, const float* ws,
                                const float* dout, float* grad, float* scratch, void* stream) {
@@ -576,24 +689,29 @@ extern "C" int spo_ma_backward(const float* theta, const spo_ma_net* net, const 
   float* d0 = scratch;                 // [B, Wd] gradient wrt the current block's output
   float* d1 = scratch + B * Wd;        // [B, Wd] dz of the current block
   float* partial = scratch + 2 * B * Wd;
+  float* slices = partial + 1024 * 3 * Wd;
   const int gr = grid_rows(B);
   // head
   const float* y_last = ws + L.ws_y(B, L.NB - 1);
-  if (int rc = gemm_dyTx(st, dout, y_last, grad + L.hW(), B, L.H, L.O)) return rc;
-  hipLaunchKernelGGL(colsum_small_kernel, dim3(L.O), dim3(256), 0, st, dout, B, L.O, grad + L.hb());
+  if (int rc = gemm_dyTx(st, dout, y_last, grad + L.hW(), B, L.H, L.O, slices)) return rc;
+  {
+    const int ns = (int)(B / 4096 < 1 ? 1 : B / 4096 > 256 ? 256 : B / 4096);
+    hipLaunchKernelGGL(colsum_small_kernel, dim3(L.O, ns), dim3(256), 0, st, dout, B, L.O, ns, partial);
+    hipLaunchKernelGGL(colsum_small_finish_kernel, dim3(1), dim3(64), 0, st, partial, L.O, ns, grad + L.hb());
+  }
   if (int rc = gemm_dyw(st, dout, theta + L.hW(), d0, B, L.H, L.O)) return rc;
   for (int k = L.NB - 1; k >= 0; --k) {
     hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(gr), dim3(256), 0, st, d0, ws + L.ws_a(B, k), ws + L.ws_st(B, k), theta + L.g(k),
                        d1, partial, B, L.H);
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((L.H + 63) / 64), dim3(64), 0, st, partial, gr, L.H, grad + L.g(k),
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((L.H + 63) / 64, 3), dim3(256), 0, st, partial, gr, L.H, grad + L.g(k),
                        grad + L.be(k), grad + L.b(k));
     const float* in = k == 0 ? ws + L.ws_xhat() : ws + L.ws_y(B, k - 1);
-    if (int rc = gemm_dyTx(st, d1, in, grad + L.W(k), B, L.in_k(k), L.H)) return rc;
+    if (int rc = gemm_dyTx(st, d1, in, grad + L.W(k), B, L.in_k(k), L.H, slices)) return rc;
     if (int rc = gemm_dyw(st, d1, theta + L.W(k), d0, B, L.in_k(k), L.H)) return rc;
   }
   // feature_norm parameters (the observation itself needs no gradient)
   hipLaunchKernelGGL(ln_bwd_kernel<0>, dim3(gr), dim3(256), 0, st, d0, x, ws + L.ws_st0(B), theta + L.fn_g(), nullptr, partial, B, L.D);
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((L.D + 63) / 64), dim3(64), 0, st, partial, gr, L.D, grad + L.fn_g(),
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((L.D + 63) / 64, 3), dim3(256), 0, st, partial, gr, L.D, grad + L.fn_g(),
                      grad + L.fn_b(), nullptr);
   SPO_LAUNCH_CHECK("spo_ma_backward");
   return 0;
