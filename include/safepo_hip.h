@@ -278,7 +278,11 @@ int spo_synth_env_step(float* next_obs, float* final_obs, float* reward, float* 
  * spo_ma_lamda_update = the in-loop multiplier step; spo_ma_popart_forward = PopArt.forward (popart.py:86-112) on a
  * [rows] vector, state3 = {running_mean, running_mean_sq, debiasing_term}; spo_ma_value_loss = max of the clipped /
  * unclipped Huber losses (util.huber_loss, including its zero branch for e < -delta) with separately normalised targets;
- * spo_ma_clip_adam = clip_grad_norm_ + torch.optim.Adam(lr, eps, weight_decay) on one network. */
+ * spo_ma_clip_adam = clip_grad_norm_ + torch.optim.Adam(lr, eps, weight_decay) on one network.
+ * Data parallel over rollout threads: every mean is taken over the GLOBAL batch -- denom_host (global row count, or the
+ * global sum of active masks) and rows_global are passed in, scalars / losses come back as this rank's share of the
+ * global mean, and the caller all-reduces (sum) the scalars, the PopArt sums and the flat gradients before
+ * spo_ma_lamda_update / spo_ma_popart_forward / spo_ma_clip_adam.  Single rank: rows_global = rows. */
 typedef struct spo_ma_net {
   int32_t in_dim, hidden, n_blocks, out_dim, is_actor;
 } spo_ma_net;
@@ -300,15 +304,17 @@ int spo_ma_log_probs(const float* mean, const float* log_std, const float* act, 
                      float* logp_out, int64_t rows, int act_dim, void* stream);
 int spo_ma_actor_loss(const float* mean, const float* log_std, const float* act, const float* old_logp, const float* adv,
                       const float* cost_adv, const float* factor, const float* active, const float* lamda_dev,
-                      const spo_ma_loss_cfg* cfg, int64_t rows, int act_dim, float active_sum_host, float* dmean_out,
-                      float* dlogstd_out, float* scalars5_out, double* partial_ws, void* stream);
+                      const spo_ma_loss_cfg* cfg, int64_t rows, int act_dim, float denom_host, int64_t rows_global,
+                      float* dmean_out, float* dlogstd_out, float* scalars5_out, double* partial_ws, void* stream);
 int spo_ma_lamda_update(float* lamda_dev, const float* scalars5, float aver_episode_cost, float cost_limit, float gamma,
                         float lagrangian_coef_rate, void* stream);
-int spo_ma_popart_forward(const float* x, int64_t rows, float* state3, double beta, float epsilon, int train, float* out,
-                          double* partial_ws, void* stream);
+int spo_ma_popart_stats(const float* x, int64_t rows, double* sums2_dev, double* partial_ws, void* stream);
+int spo_ma_popart_forward(const float* x, int64_t rows, float* state3, double beta, float epsilon, int train,
+                          const double* sums2_dev, int64_t rows_global, float* out, void* stream);
 int spo_ma_value_loss(const float* values, const float* value_preds, const float* returns_norm_clipped,
                       const float* returns_norm_original, float clip_param, float huber_delta, float value_loss_coef,
-                      int64_t rows, float* dvalues_out, float* loss_out, double* partial_ws, void* stream);
+                      int64_t rows, int64_t rows_global, float* dvalues_out, float* loss_out, double* partial_ws,
+                      void* stream);
 int spo_ma_clip_adam(float* theta, const float* grad, float* adam_m, float* adam_v, int64_t n, int64_t adam_step_host,
                      float lr, float adam_eps, float weight_decay, float max_grad_norm, int use_max_grad_norm,
                      float* grad_norm_out, double* partial_ws, void* stream);

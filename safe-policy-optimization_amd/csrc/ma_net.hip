@@ -465,8 +465,8 @@ __global__ __launch_bounds__(256) void ma_actor_loss_kernel(
 
 // scalars_out: {policy_loss, dist_entropy, mean(imp), mean(imp*cost_adv), sum(active)}; dlogstd_out[A]
 __global__ void ma_actor_loss_finish_kernel(const double* __restrict__ partial, int nblocks, const float* __restrict__ log_std,
-                                            spo_ma_loss_cfg c, int64_t B, int A, float* __restrict__ scalars_out,
-                                            float* __restrict__ dlogstd_out) {
+                                            spo_ma_loss_cfg c, int64_t B /* rows of the GLOBAL batch */, int A,
+                                            float* __restrict__ scalars_out, float* __restrict__ dlogstd_out) {
   const int k = threadIdx.x;
   if (k >= AL_NS + A) return;
   double s = 0.0;
@@ -512,9 +512,13 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
     partial[2 * blockIdx.x + 1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
   }
 }
-__global__ void popart_update_kernel(const double* __restrict__ partial, int nblocks, int64_t B, float beta, float omb, float* state) {
+__global__ void sumsq_finish_kernel(const double* __restrict__ partial, int nblocks, double* __restrict__ sums2) {
   double s = 0, q = 0;
   for (int b = 0; b < nblocks; ++b) { s += partial[2 * b]; q += partial[2 * b + 1]; }
+  sums2[0] = s; sums2[1] = q;
+}
+__global__ void popart_update_kernel(const double* __restrict__ sums2, int64_t B, float beta, float omb, float* state) {
+  const double s = sums2[0], q = sums2[1];
   const float bm = (float)(s / (double)B), bq = (float)(q / (double)B);
   // omb = (1.0 - beta) formed in double on the host, as the reference's python float arithmetic does (popart.py:104-106):
   // 1.f - 0.99999f would be 1.00136e-5
@@ -741,19 +745,19 @@ extern "C" int spo_ma_log_probs(const float* mean, const float* log_std, const f
 extern "C" int spo_ma_actor_loss(const float* mean, const float* log_std, const float* act, const float* old_logp,
                                  const float* adv, const float* cost_adv, const float* factor, const float* active,
                                  const float* lamda_dev, const spo_ma_loss_cfg* cfg, int64_t rows, int act_dim,
-                                 float active_sum_host, float* dmean_out, float* dlogstd_out, float* scalars5_out,
-                                 double* partial_ws, void* stream) {
+                                 float denom_host, int64_t rows_global, float* dmean_out, float* dlogstd_out,
+                                 float* scalars5_out, double* partial_ws, void* stream) {
   SPO_REQUIRE(mean && log_std && act && old_logp && adv && cost_adv && factor && active && lamda_dev && cfg && dmean_out &&
                   dlogstd_out && scalars5_out && partial_ws, "ma_actor_loss: null pointer");
-  SPO_REQUIRE(rows > 0 && act_dim > 0 && act_dim <= SPO_MAX_ACT, "ma_actor_loss: bad sizes");
+  SPO_REQUIRE(rows > 0 && act_dim > 0 && act_dim <= SPO_MAX_ACT && rows_global >= rows && denom_host > 0.f, "ma_actor_loss: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   int64_t g = (rows + 255) / 256;
   const int gr = (int)(g > 1024 ? 1024 : g);
-  const float inv_denom = cfg->use_policy_active_masks ? 1.f / active_sum_host : 1.f / (float)rows;
-  const float ent_w = 1.f / ((float)rows * (float)act_dim);
+  const float inv_denom = 1.f / denom_host;
+  const float ent_w = 1.f / ((float)rows_global * (float)act_dim);
   hipLaunchKernelGGL(ma_actor_loss_kernel, dim3(gr), dim3(256), 0, st, mean, log_std, act, old_logp, adv, cost_adv, factor,
                      active, lamda_dev, *cfg, inv_denom, ent_w, dmean_out, partial_ws, rows, act_dim);
-  hipLaunchKernelGGL(ma_actor_loss_finish_kernel, dim3(1), dim3(64), 0, st, partial_ws, gr, log_std, *cfg, rows, act_dim,
+  hipLaunchKernelGGL(ma_actor_loss_finish_kernel, dim3(1), dim3(64), 0, st, partial_ws, gr, log_std, *cfg, rows_global, act_dim,
                      scalars5_out, dlogstd_out);
   SPO_LAUNCH_CHECK("spo_ma_actor_loss");
   return 0;
@@ -768,18 +772,26 @@ extern "C" int spo_ma_lamda_update(float* lamda_dev, const float* scalars5, floa
   return 0;
 }
 
-// PopArt.forward(x, train): optional statistics update, then normalisation.  partial_ws: double[2 * 1024]
-extern "C" int spo_ma_popart_forward(const float* x, int64_t rows, float* state3, double beta_d, float epsilon, int train,
-                                     float* out, double* partial_ws, void* stream) {
-  const float beta = (float)beta_d;
-  SPO_REQUIRE(x && state3 && out && partial_ws && rows > 0, "ma_popart_forward: bad args");
+// PopArt.forward(x, train) in two calls so that a data-parallel job can all-reduce the batch sums in between:
+// spo_ma_popart_stats -> sums2_dev = {sum x, sum x^2} of the local rows; spo_ma_popart_forward(train) folds the (global)
+// sums over rows_global rows into the statistics, then normalises the local rows.  partial_ws: double[2 * 1024]
+extern "C" int spo_ma_popart_stats(const float* x, int64_t rows, double* sums2_dev, double* partial_ws, void* stream) {
+  SPO_REQUIRE(x && sums2_dev && partial_ws && rows > 0, "ma_popart_stats: bad args");
   hipStream_t st = (hipStream_t)stream;
-  if (train) {
-    int64_t g = (rows + 255) / 256;
-    const int gr = (int)(g > 1024 ? 1024 : g);
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(gr), dim3(256), 0, st, x, rows, partial_ws);
-    hipLaunchKernelGGL(popart_update_kernel, dim3(1), dim3(1), 0, st, partial_ws, gr, rows, beta, (float)(1.0 - beta_d), state3);
-  }
+  int64_t g = (rows + 255) / 256;
+  const int gr = (int)(g > 1024 ? 1024 : g);
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(gr), dim3(256), 0, st, x, rows, partial_ws);
+  hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(1), 0, st, partial_ws, gr, sums2_dev);
+  SPO_LAUNCH_CHECK("spo_ma_popart_stats");
+  return 0;
+}
+extern "C" int spo_ma_popart_forward(const float* x, int64_t rows, float* state3, double beta_d, float epsilon, int train,
+                                     const double* sums2_dev, int64_t rows_global, float* out, void* stream) {
+  SPO_REQUIRE(x && state3 && out && rows > 0 && (!train || (sums2_dev && rows_global >= rows)), "ma_popart_forward: bad args");
+  const float beta = (float)beta_d;
+  hipStream_t st = (hipStream_t)stream;
+  if (train)
+    hipLaunchKernelGGL(popart_update_kernel, dim3(1), dim3(1), 0, st, sums2_dev, rows_global, beta, (float)(1.0 - beta_d), state3);
   hipLaunchKernelGGL(popart_normalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, x, state3, epsilon, out, rows);
   SPO_LAUNCH_CHECK("spo_ma_popart_forward");
   return 0;
@@ -787,16 +799,16 @@ extern "C" int spo_ma_popart_forward(const float* x, int64_t rows, float* state3
 
 extern "C" int spo_ma_value_loss(const float* values, const float* value_preds, const float* returns_norm_clipped,
                                  const float* returns_norm_original, float clip_param, float huber_delta,
-                                 float value_loss_coef, int64_t rows, float* dvalues_out, float* loss_out, double* partial_ws,
-                                 void* stream) {
+                                 float value_loss_coef, int64_t rows, int64_t rows_global, float* dvalues_out, float* loss_out,
+                                 double* partial_ws, void* stream) {
   SPO_REQUIRE(values && value_preds && returns_norm_clipped && returns_norm_original && dvalues_out && loss_out && partial_ws &&
-                  rows > 0, "ma_value_loss: bad args");
+                  rows > 0 && rows_global >= rows, "ma_value_loss: bad args");
   hipStream_t st = (hipStream_t)stream;
   int64_t g = (rows + 255) / 256;
   const int gr = (int)(g > 1024 ? 1024 : g);
   hipLaunchKernelGGL(ma_value_loss_kernel, dim3(gr), dim3(256), 0, st, values, value_preds, returns_norm_clipped,
-                     returns_norm_original, clip_param, huber_delta, value_loss_coef / (float)rows, dvalues_out, partial_ws, rows);
-  hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(1), 0, st, partial_ws, gr, 1.0 / (double)rows, loss_out);
+                     returns_norm_original, clip_param, huber_delta, value_loss_coef / (float)rows_global, dvalues_out, partial_ws, rows);
+  hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(1), 0, st, partial_ws, gr, 1.0 / (double)rows_global, loss_out);
   SPO_LAUNCH_CHECK("spo_ma_value_loss");
   return 0;
 }

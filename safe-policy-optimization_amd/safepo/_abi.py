@@ -85,10 +85,11 @@ PROTOTYPES = {
     "spo_ma_backward": (c_int, [P, POINTER(MaNet), P, c_int64, P, P, P, P, P]),
     "spo_ma_sample": (c_int, [P, P, P, c_float, c_float, c_int, P, P, c_int64, c_int, P]),
     "spo_ma_log_probs": (c_int, [P, P, P, c_float, c_float, P, c_int64, c_int, P]),
-    "spo_ma_actor_loss": (c_int, [P] * 9 + [POINTER(MaLossCfg), c_int64, c_int, c_float, P, P, P, P, P]),
+    "spo_ma_actor_loss": (c_int, [P] * 9 + [POINTER(MaLossCfg), c_int64, c_int, c_float, c_int64, P, P, P, P, P]),
     "spo_ma_lamda_update": (c_int, [P, P, c_float, c_float, c_float, c_float, P]),
-    "spo_ma_popart_forward": (c_int, [P, c_int64, P, c_double, c_float, c_int, P, P, P]),
-    "spo_ma_value_loss": (c_int, [P, P, P, P, c_float, c_float, c_float, c_int64, P, P, P, P]),
+    "spo_ma_popart_stats": (c_int, [P, c_int64, P, P, P]),
+    "spo_ma_popart_forward": (c_int, [P, c_int64, P, c_double, c_float, c_int, P, c_int64, P, P]),
+    "spo_ma_value_loss": (c_int, [P, P, P, P, c_float, c_float, c_float, c_int64, c_int64, P, P, P, P]),
     "spo_ma_clip_adam": (c_int, [P, P, P, P, c_int64, c_int64, c_float, c_float, c_float, c_float, c_int, P, P, P]),
     "spo_ma_gae": (c_int, [P] * 7 + [c_int64, c_int64, c_double, c_double, c_float, c_float, c_float, c_float, P]),
     "spo_param_count": (c_int64, [c_int, c_int]),

@@ -25,6 +25,7 @@ from safepo.common.buffer import SeparatedReplayBuffer
 from safepo.common.logger import EpochLogger
 from safepo.common.model import MultiAgentActor as Actor, MultiAgentCritic as Critic
 from safepo.common.popart import PopArt
+from safepo.parallel import Comm, init_from_env
 
 # Defaults of the reference's marl_cfg/mappolag/config.yaml, and its `mamujoco` overrides (applied for the MuJoCo
 # velocity / multi-goal tasks, safepo/utils/config.py:236-241).
@@ -64,8 +65,10 @@ class _Adam:
     def zero_grad(self):
         self.grad.zero_()
 
-    def step(self, max_grad_norm, use_max_grad_norm=True):
+    def step(self, max_grad_norm, use_max_grad_norm=True, comm=None):
         th = self.net.theta
+        if comm is not None and comm.world_size > 1:
+            comm.all_reduce_sum_(self.grad)        # every rank holds its share of the global-batch gradient
         _abi.check(_abi.load().spo_ma_clip_adam(_abi.ptr(th), _abi.ptr(self.grad), _abi.ptr(self.m), _abi.ptr(self.v),
                                                 th.numel(), self.t, self.lr, self.eps, self.wd, float(max_grad_norm),
                                                 int(bool(use_max_grad_norm)), _abi.ptr(self.norm), _abi.ptr(self.partial),
@@ -122,8 +125,9 @@ class MAPPO_L_Policy:
 class MAPPO_L_Trainer:
     """mappolag.py:115-249.  `lamda_lagr` is a device scalar updated inside every minibatch step (mappolag.py:178-182)."""
 
-    def __init__(self, config, policy):
+    def __init__(self, config, policy, comm: Comm | None = None):
         self.config, self.policy = config, policy
+        self.comm = comm or Comm()
         self.dev = torch.device(config["device"])
         self.tpdv = dict(dtype=torch.float32, device=self.dev)
         self.value_normalizer = PopArt(1, device=self.dev)
@@ -131,6 +135,7 @@ class MAPPO_L_Trainer:
         self._lamda = torch.tensor([float(config["lamda_lagr"])], **self.tpdv)
         self._partial = torch.zeros(1024 * (4 + 16), dtype=torch.float64, device=self.dev)
         self._scalars = torch.zeros(5, **self.tpdv)
+        self._sums2 = torch.zeros(2, dtype=torch.float64, device=self.dev)
         self._loss_cfg = _abi.MaLossCfg(clip_param=float(config["clip_param"]), entropy_coef=float(config["entropy_coef"]),
                                         std_x_coef=float(config["std_x_coef"]), std_y_coef=float(config["std_y_coef"]),
                                         use_policy_active_masks=int(bool(config["use_policy_active_masks"])))
@@ -145,10 +150,14 @@ class MAPPO_L_Trainer:
         vn.running_mean.copy_(s[0:1]); vn.running_mean_sq.copy_(s[1:2]); vn.debiasing_term.copy_(s[2])
 
     def _normalize_returns(self, returns, out):
-        vn = self.value_normalizer
-        _abi.check(_abi.load().spo_ma_popart_forward(_abi.ptr(returns), returns.numel(), _abi.ptr(self._popart_state), float(vn.beta),
-                                                     float(vn.epsilon), 1, _abi.ptr(out), _abi.ptr(self._partial),
-                                                     _abi.stream_ptr()), "spo_ma_popart_forward")
+        vn, lib, st = self.value_normalizer, _abi.load(), _abi.stream_ptr()
+        rows = returns.numel()
+        _abi.check(lib.spo_ma_popart_stats(_abi.ptr(returns), rows, _abi.ptr(self._sums2), _abi.ptr(self._partial), st),
+                   "spo_ma_popart_stats")
+        self.comm.all_reduce_sum_(self._sums2)                  # batch mean / mean of squares of the GLOBAL batch
+        _abi.check(lib.spo_ma_popart_forward(_abi.ptr(returns), rows, _abi.ptr(self._popart_state), float(vn.beta), float(vn.epsilon),
+                                             1, _abi.ptr(self._sums2), rows * self.comm.world_size, _abi.ptr(out), st),
+                   "spo_ma_popart_forward")
 
     def _value_step(self, net, opt, inputs, value_preds, returns):
         """cal_value_loss (mappolag.py:126-138) + backward + clip + Adam for one critic."""
@@ -162,10 +171,11 @@ class MAPPO_L_Trainer:
         dvalues, loss = torch.empty_like(values), torch.empty(1, **self.tpdv)
         _abi.check(lib.spo_ma_value_loss(_abi.ptr(values), _abi.ptr(value_preds.reshape(-1).contiguous()), _abi.ptr(n1), _abi.ptr(n2),
                                          float(c["clip_param"]), float(c["huber_delta"]), float(c["value_loss_coef"]), rows,
-                                         _abi.ptr(dvalues), _abi.ptr(loss), _abi.ptr(self._partial), _abi.stream_ptr()),
-                   "spo_ma_value_loss")
+                                         rows * self.comm.world_size, _abi.ptr(dvalues), _abi.ptr(loss), _abi.ptr(self._partial),
+                                         _abi.stream_ptr()), "spo_ma_value_loss")
+        self.comm.all_reduce_sum_(loss)
         net.net_backward(saved, dvalues, opt.grad)
-        norm = opt.step(c["max_grad_norm"], c["use_max_grad_norm"])
+        norm = opt.step(c["max_grad_norm"], c["use_max_grad_norm"], self.comm)
         return loss.reshape(()), norm
 
     def ppo_update(self, sample):
@@ -183,13 +193,23 @@ class MAPPO_L_Trainer:
         dmean = torch.empty_like(mean)
         opt = pol.actor_optimizer
         ls_off = pol.actor.offset(6)
-        active_sum = float(active.sum().item()) if c["use_policy_active_masks"] else float(rows)
+        rows_g = rows * self.comm.world_size                 # data parallel over rollout threads: equal shards
+        if c["use_policy_active_masks"]:
+            asum = active.sum().reshape(1).double()
+            self.comm.all_reduce_sum_(asum)
+            denom = float(asum.item())
+        else:
+            denom = float(rows_g)
         _abi.check(lib.spo_ma_actor_loss(_abi.ptr(mean), _abi.ptr(pol.actor.log_std), _abi.ptr(actions_batch), _abi.ptr(old_lp),
                                          _abi.ptr(adv), _abi.ptr(cadv), _abi.ptr(factor), _abi.ptr(active), _abi.ptr(self._lamda),
-                                         self._loss_cfg, rows, A, active_sum, _abi.ptr(dmean), _abi.ptr(opt.grad[ls_off:ls_off + A]),
+                                         self._loss_cfg, rows, A, denom, rows_g, _abi.ptr(dmean), _abi.ptr(opt.grad[ls_off:ls_off + A]),
                                          _abi.ptr(self._scalars), _abi.ptr(self._partial), _abi.stream_ptr()), "spo_ma_actor_loss")
+        if self.comm.world_size > 1:
+            ent = self._scalars[1].clone()                   # the entropy of a state-independent sigma is not a sum over rows
+            self.comm.all_reduce_sum_(self._scalars)
+            self._scalars[1] = ent
         pol.actor.net_backward(saved, dmean, opt.grad)
-        actor_grad_norm = opt.step(c["max_grad_norm"], c["use_max_grad_norm"])
+        actor_grad_norm = opt.step(c["max_grad_norm"], c["use_max_grad_norm"], self.comm)
         scal = self._scalars.clone()
         # ---- multiplier (mappolag.py:178-182); aver_episode_costs.mean() is a host scalar of the buffer
         aver = float(check(aver_episode_costs).float().mean().item())
@@ -211,7 +231,15 @@ class MAPPO_L_Trainer:
             adv = returns[:-1] - self.value_normalizer.denormalize(preds[:-1])
             cp = adv.clone()
             cp[buffer.active_masks[:-1] == 0.0] = float("nan")
-            return (adv - torch.mean(cp)) / (torch.std(cp) + 1e-8)
+            if self.comm.world_size == 1:
+                return (adv - torch.mean(cp)) / (torch.std(cp) + 1e-8)
+            # torch.mean / torch.std (unbiased) of the rows of ALL ranks, NaN-propagating like the single-rank form
+            d = cp.double()
+            sums = torch.stack([d.sum(), (d * d).sum(), torch.tensor(float(d.numel()), dtype=torch.float64, device=d.device)])
+            self.comm.all_reduce_sum_(sums)
+            mean = sums[0] / sums[2]
+            var = (sums[1] - sums[2] * mean * mean) / (sums[2] - 1.0)
+            return (adv - mean.float()) / (torch.sqrt(var.clamp(min=0.0)).float() + 1e-8)
         advantages = standardised(buffer.returns, buffer.value_preds)
         cost_adv = standardised(buffer.cost_returns, buffer.cost_preds)
         out = None
@@ -237,11 +265,17 @@ class MAPPO_L_Trainer:
 class Runner:
     """mappolag.py:252-604: collect -> insert -> compute -> train with sequential (HAPPO) agent updates."""
 
-    def __init__(self, vec_env, vec_eval_env, config, model_dir=""):
+    def __init__(self, vec_env, vec_eval_env, config, model_dir="", comm: Comm | None = None):
+        """Data parallel: one process per GPU, each with its own shard of rollout threads (config["n_rollout_threads"] is
+        the PER-RANK count here); replicas start identical (broadcast) and stay identical (all-reduced gradients,
+        statistics and agent order); rank 0 logs and saves."""
         self.envs, self.eval_envs, self.config, self.model_dir = vec_env, vec_eval_env, config, model_dir
+        self.comm = comm or Comm()
+        self.is_root = self.comm.rank == 0
         self.num_agents = self.envs.num_agents
         self.dev = torch.device(config["device"])
-        self.logger = EpochLogger(log_dir=config["log_dir"], seed=str(config["seed"]))
+        log_dir = config["log_dir"] if self.is_root else os.path.join(config["log_dir"], f"rank{self.comm.rank}")
+        self.logger = EpochLogger(log_dir=log_dir, seed=str(config["seed"]), verbose=self.is_root)
         self.save_dir = str(config["log_dir"] + "/models_seed{}".format(config["seed"]))
         os.makedirs(self.save_dir, exist_ok=True)
         self.logger.save_config(config)
@@ -249,7 +283,10 @@ class Runner:
                                       self.envs.action_space[a]) for a in range(self.num_agents)]
         if self.model_dir != "":
             self.restore()
-        self.trainer = [MAPPO_L_Trainer(config, self.policy[a]) for a in range(self.num_agents)]
+        for pol in self.policy:
+            for net in (pol.actor, pol.critic, pol.cost_critic):
+                self.comm.broadcast_(net.theta, 0)
+        self.trainer = [MAPPO_L_Trainer(config, self.policy[a], self.comm) for a in range(self.num_agents)]
         self.buffer = [SeparatedReplayBuffer(config, self.envs.observation_space[a], self.envs.share_observation_space[a],
                                              self.envs.action_space[a]) for a in range(self.num_agents)]
 
@@ -257,7 +294,7 @@ class Runner:
         c = self.config
         self.warmup()
         start = time.time()
-        episodes = int(c["num_env_steps"]) // c["episode_length"] // c["n_rollout_threads"]
+        episodes = int(c["num_env_steps"]) // c["episode_length"] // (c["n_rollout_threads"] * self.comm.world_size)
         train_episode_rewards = torch.zeros(1, c["n_rollout_threads"], device=self.dev)
         train_episode_costs = torch.zeros(1, c["n_rollout_threads"], device=self.dev)
         eval_rewards, eval_costs = 0.0, 0.0
@@ -281,15 +318,18 @@ class Runner:
                              rnn_states_critic, cost_preds, rnn_states_cost, done_episodes_costs_aver))
             self.compute()
             self.train()
-            total_num_steps = (episode + 1) * c["episode_length"] * c["n_rollout_threads"]
-            if episode % c["save_interval"] == 0 or episode == episodes - 1:
+            total_num_steps = (episode + 1) * c["episode_length"] * c["n_rollout_threads"] * self.comm.world_size
+            if self.is_root and (episode % c["save_interval"] == 0 or episode == episodes - 1):
                 self.save()
             end = time.time()
             if episode % c["eval_interval"] == 0 and c["use_eval"]:
                 eval_rewards, eval_costs = self.eval()
-            if len(done_rewards) != 0:
-                aver_episode_rewards = torch.stack(done_rewards).mean()
-                aver_episode_costs = torch.stack(done_costs).mean()
+            n_done = torch.tensor([float(len(done_rewards)), float(torch.stack(done_rewards).sum()) if done_rewards else 0.0,
+                                   float(torch.stack(done_costs).sum()) if done_costs else 0.0], dtype=torch.float64, device=self.dev)
+            self.comm.all_reduce_sum_(n_done)               # finished episodes of every shard
+            if n_done[0].item() != 0:
+                aver_episode_rewards = (n_done[1] / n_done[0]).float()
+                aver_episode_costs = (n_done[2] / n_done[0]).float()
                 self.return_aver_cost(aver_episode_costs)
                 self.logger.store(**{"Metrics/EpRet": aver_episode_rewards.item(), "Metrics/EpCost": aver_episode_costs.item(),
                                      "Eval/EpRet": eval_rewards, "Eval/EpCost": eval_costs})
@@ -350,7 +390,10 @@ class Runner:
     def train(self, order=None, perm_fn=None):
         c = self.config
         factor = torch.ones(c["episode_length"], c["n_rollout_threads"], 1, device=self.dev)
-        order = torch.randperm(self.num_agents) if order is None else order
+        if order is None:
+            order = torch.randperm(self.num_agents).to(self.dev)
+            self.comm.broadcast_(order, 0)                   # the same HAPPO update order on every rank
+            order = order.tolist()
         for agent_id in order:
             a = int(agent_id)
             b = self.buffer[a]
@@ -420,12 +463,21 @@ def train(args, cfg_train):
     if not str(args.task).startswith("Synth"):
         raise NotImplementedError("this build has no simulator (safety_gymnasium / Isaac Gym are not installed here); "
                                   "use a Synth* multi-agent task, or pass your own vector env to Runner(...)")
-    env = make_ma_synth_env(cfg_train, seed=args.seed)
+    comm = init_from_env()
+    if comm.world_size > 1:
+        # one process per GPU (torchrun): shard the rollout threads, one device per rank
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        cfg_train = dict(cfg_train)
+        cfg_train["device"] = f"cuda:{local_rank}"
+        torch.cuda.set_device(local_rank)
+        assert cfg_train["n_rollout_threads"] % comm.world_size == 0, "n_rollout_threads must divide over the ranks"
+        cfg_train["n_rollout_threads"] //= comm.world_size
+    env = make_ma_synth_env(cfg_train, seed=args.seed + 1000 * comm.rank)
     cfg_eval = copy.deepcopy(cfg_train)
     cfg_eval["seed"] = args.seed + 10000
     cfg_eval["n_rollout_threads"] = cfg_eval["n_eval_rollout_threads"]
     eval_env = make_ma_synth_env(cfg_eval, seed=args.seed + 10000)
-    runner = Runner(env, eval_env, cfg_train, args.model_dir)
+    runner = Runner(env, eval_env, cfg_train, args.model_dir, comm=comm)
     if args.model_dir != "":
         runner.eval(100000)
     else:

@@ -22,6 +22,13 @@ class Comm:
         self.world_size = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
 
+    @classmethod
+    def single(cls) -> "Comm":
+        """A communicator of one rank, whatever process group exists (reference runs inside a distributed test)."""
+        c = cls.__new__(cls)
+        c.enabled, c.group, c.world_size, c.rank = False, None, 1, 0
+        return c
+
     def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
         if self.world_size > 1:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)

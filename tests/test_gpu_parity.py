@@ -1293,3 +1293,27 @@ def test_ma_runner_compute_and_train_vs_reference_runner_trace(dev, golden_dir, 
                 pre = f"e{e}_a{a}_after_{nm}_"
                 want = np.concatenate([z[k].reshape(-1) for k in z.files if k.startswith(pre)])
                 _assert_params_close(net.theta.cpu().numpy(), want, 2e-3, n_steps, rtol=5e-3, atol=5e-5, what=f"episode {e} agent {a} {nm}")
+
+
+def test_ma_mappolag_data_parallel_two_ranks_one_gpu(dev, tmp_path):
+    """MAPPO-L sharded over rollout threads: two ranks (two processes on this GPU, gloo) x half the threads must equal one
+    rank x all threads -- every mean (surrogate, entropy weights, value losses, PopArt batch statistics, advantage
+    standardisation, lambda delta) is taken over the global batch and the flat gradients are all-reduced."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    out = tmp_path / "ma_dp.json"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "ma_dp_worker.py"), str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = json.load(open(out))
+    assert res["replicas_identical"], res
+    assert res["frac_outside"] <= 1e-3 and res["max_abs_diff_vs_single_rank"] < 5e-4, res
+    assert res["lamda"][0] == pytest.approx(res["lamda"][1], rel=1e-5), res
+    np.testing.assert_allclose(res["popart"][0], res["popart"][1], rtol=1e-5)
+    np.testing.assert_allclose(res["losses"][0], res["losses"][1], rtol=2e-4, atol=2e-6)
+    assert res["moved"] > 1e-4
