@@ -221,9 +221,9 @@ int spo_update_iter_ex(float* theta, float* adam_m, float* adam_v, int64_t adam_
  * its own shard (same M, same batch, same step counts) and the per-step mean of the ranks' minibatch gradients is formed
  * inside the step, so all replicas apply bit-identical updates.  Every float travels as an 8-byte {tag, value} word
  * written with one system-scope write-through store and polled by the lane that needs it (no flags, no barriers):
- * 2 ranks push whole gradients to each other (one hand-off per step); more ranks reduce-scatter then all-gather
- * (two hand-offs, 2 x 88 KB per network per step at any world size).  Environment: SPO_P2P_ALGO=twophase forces the
- * second form at 2 ranks.  step0 = optimiser steps already taken through these regions (monotonic tag base, identical
+ * power-of-two worlds use recursive doubling (round k: swap the running sum with rank me ^ 2^k; log2(world) hand-offs);
+ * other worlds reduce-scatter then all-gather (two hand-offs, 2 x 88 KB per network per step).  Environment:
+ * SPO_P2P_ALGO=twophase forces the second form everywhere.  step0 = optimiser steps already taken through these regions (monotonic tag base, identical
  * on every rank; advance it by the number of minibatches).  A peer that never answers costs ONE bounded wait and is
  * reported through sync_ws (int at byte 64 = 2), never a hang.
  * spo_p2p_selftest runs `iters` exchange rounds of known patterns on the same grid and protocol:

@@ -89,7 +89,7 @@ struct UpdArgs {
   double pow_b1_actor, pow_b2_actor;   // the actor's optimiser may be ahead of the critics' (CUP steps it alone)
   // cross-rank (data-parallel) gradient exchange inside the persistent kernel: XR instantiations only
   int xr_rank, xr_world;
-  int xr_algo;                         // 1: one-shot push at 2 ranks; 0: reduce-scatter + all-gather everywhere
+  int xr_algo;                         // 1: recursive doubling at power-of-two worlds; 0: reduce-scatter + all-gather everywhere
   unsigned xr_step0;                   // global optimiser-step count before this launch (same on every rank)
   void* xr_region[XR_MAX_WORLD];       // every rank's exchange region (own + IPC-mapped peers), indexed by rank
 };
@@ -267,40 +267,47 @@ __device__ __forceinline__ void xr_allreduce(const u64* regions, int me, int R, 
   }
 }
 
-// One-shot form for TWO ranks: each rank pushes its whole gradient to the peer and adds the two copies itself, in rank
-// order (own contribution from registers) -- one hand-off per step instead of two.  Identical bits on both ranks because
-// both add the same two values in the same order.  (A 4-rank one-shot was tried: it needs the own gradient and three
-// peer copies live at once, spills 250-500 B per lane next to the optimiser state and loses to the two-phase form.)
+// Recursive doubling for a power-of-two number of ranks: in round k every rank swaps its running sum with rank
+// me ^ (1 << k) (a whole-vector push into slot [parity][k][net] of the partner's region) and adds what it receives;
+// after log2(world) hand-offs everybody holds the total.  Partners add the same two values (a + b == b + a exactly in
+// IEEE arithmetic), so by induction all replicas hold identical bits.  One hand-off at 2 ranks, two at 4, three at 8 --
+// against two for the reduce-scatter form at any size, but each of these is a single push/poll with no slice
+// bookkeeping, and the gradient registers plus six polled rows fit the register file (the 4-rank one-shot -- own gradient
+// plus three peer copies live at once -- spilled 250-500 B per lane next to the optimiser state and lost).
 template <int NV>
-__device__ __forceinline__ void xr_allreduce_pair(const u64* regions, int me, int net, int tid, unsigned gtag,
-                                                  f4 (&pk)[NV], volatile float* dead_word, int* err) {
+__device__ __forceinline__ void xr_allreduce_rd(const u64* regions, int me, int R, int net, int tid, unsigned gtag,
+                                                f4 (&pk)[NV], volatile float* dead_word, int* err) {
   constexpr int VB = 6;                                         // gradient rows polled together
   const int par = (int)(gtag & 1u);
-  const int peer = 1 - me;
-  gu64* const p = xr_words(regions[peer]) + ((size_t)(par * XR_MAX_WORLD + me) * 3 + net) * XR_SLOT_WORDS;
+#pragma unroll 1
+  for (int k = 0; (1 << k) < R; ++k) {
+    const int peer = me ^ (1 << k);
+    const size_t slot = ((size_t)(par * XR_MAX_WORLD + k) * 3 + net) * XR_SLOT_WORDS;
+    gu64* const p = xr_words(regions[peer]) + slot;
 #pragma unroll
-  for (int v = 0; v < NV; ++v) st_ll(xr_elem(p, v * 256 + tid), pk[v], gtag);
-  gu64* const src = xr_words(regions[me]) + ((size_t)(par * XR_MAX_WORLD + peer) * 3 + net) * XR_SLOT_WORDS;
+    for (int v = 0; v < NV; ++v) st_ll(xr_elem(p, v * 256 + tid), pk[v], gtag);
+    gu64* const src = xr_words(regions[me]) + slot;
 #pragma unroll
-  for (int v0 = 0; v0 < NV; v0 += VB) {
-    f4 x[VB];
-    unsigned spins = 0;
-    for (;;) {
-      bool ok = true;
+    for (int v0 = 0; v0 < NV; v0 += VB) {
+      f4 x[VB];
+      unsigned spins = 0;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int vv = 0; vv < VB; ++vv)
+          if (v0 + vv < NV) ok = ld_ll(xr_elem(src, (v0 + vv) * 256 + tid), gtag, x[vv]) && ok;
+        if (ok || *dead_word != 0.f) break;
+        if (++spins > XR_SPIN_LIMIT) { *err = 2; *dead_word = 1.f; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
 #pragma unroll
       for (int vv = 0; vv < VB; ++vv)
-        if (v0 + vv < NV) ok = ld_ll(xr_elem(src, (v0 + vv) * 256 + tid), gtag, x[vv]) && ok;
-      if (ok || *dead_word != 0.f) break;
-      if (++spins > XR_SPIN_LIMIT) { *err = 2; *dead_word = 1.f; break; }
-      __builtin_amdgcn_s_sleep(1);
+        if (v0 + vv < NV) pk[v0 + vv] += x[vv];
     }
-#pragma unroll
-    for (int vv = 0; vv < VB; ++vv)
-      if (v0 + vv < NV) {
-        const f4 lo = me == 0 ? pk[v0 + vv] : x[vv], hi = me == 0 ? x[vv] : pk[v0 + vv];   // rank 0 first
-        pk[v0 + vv] = (lo + hi) * 0.5f;
-      }
   }
+  const float inv_world = 1.f / (float)R;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) pk[v] *= inv_world;
 }
 
 // AMODE: actor loss.  0 = PPO clipped surrogate (ppo_lag.py:316-319; clip = 1e30 gives the plain policy gradient);
@@ -311,8 +318,8 @@ __device__ __forceinline__ void xr_allreduce_pair(const u64* regions, int me, in
 //        exactly the product of means above.  CUP has no indicator: kl_bound = +inf, pg_coef = -lambda * coef.)
 // XR: data-parallel form of the persistent kernel -- every rank runs it on its own env shard and the per-step
 //     gradient all-reduce happens inside the step (xr_allreduce above) instead of kernel / RCCL / kernel.
-// XR = 1: reduce-scatter + all-gather (any world); 2: one-shot push for exactly 2 ranks (separate instantiations:
-//     both exchange bodies together do not fit the register file next to the optimiser state).
+// XR = 1: reduce-scatter + all-gather (any world); 2: recursive doubling (power-of-two worlds).  Separate instantiations:
+//     both exchange bodies together do not fit the register file next to the optimiser state.
 template <int KIN, bool PERSIST, bool PROF = false, int AMODE = 0, int XR = 0>
 __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
   unsigned long long pacc[NPHASE] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -775,7 +782,7 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
       const u64* const xr_tab = reinterpret_cast<const u64*>(red + 144);
       const unsigned gtag = a.xr_step0 + (unsigned)s + 1u;
       if (XR == 2)
-        xr_allreduce_pair<NV>(xr_tab, a.xr_rank, net, tid, gtag, pk, red + 112, a.err);
+        xr_allreduce_rd<NV>(xr_tab, a.xr_rank, a.xr_world, net, tid, gtag, pk, red + 112, a.err);
       else
         xr_allreduce<NV>(xr_tab, a.xr_rank, a.xr_world, net, tid, gtag, pk, red + 112, a.err);
 #pragma unroll
@@ -1061,7 +1068,7 @@ __global__ __launch_bounds__(256, 1) void xr_selftest_kernel(int rank, int world
       const float c = (float)((gtag + 3u * v + tid + 5u * net) & 15u);
       pk[v] = f4{(float)(rank + 1) + c, (float)(rank + 1) - c, c, (float)(rank + 1) * 2.f};
     }
-    if (a.xr_algo == 1 && world == 2) xr_allreduce_pair<11>(regions, rank, net, tid, gtag, pk, &dead, result + 1);
+    if (a.xr_algo == 1 && (world & (world - 1)) == 0) xr_allreduce_rd<11>(regions, rank, world, net, tid, gtag, pk, &dead, result + 1);
     else xr_allreduce<11, true>(regions, rank, world, net, tid, gtag, pk, &dead, result + 1);
     const float tri = 0.5f * (float)(world + 1);
 #pragma unroll
@@ -1317,7 +1324,7 @@ extern "C" int spo_ppo_lag_update_iter_dp(float* theta, float* adam_m, float* ad
   a.pow_b1_actor = a.pow_b1; a.pow_b2_actor = a.pow_b2;
   a.first_net = 0; a.n_nets = 3; a.stale_sq = 0.f; a.stale_io = nullptr;
   int rc = 0;
-  if (a.xr_algo == 1 && world == 2) rc = launch_update<true, 0, 2>(a, 3, st);
+  if (a.xr_algo == 1 && (world & (world - 1)) == 0) rc = launch_update<true, 0, 2>(a, 3, st);
   else rc = launch_update<true, 0, 1>(a, 3, st);
   if (rc) return rc;
   SPO_LAUNCH_CHECK("spo_ppo_lag_update_iter_dp");
