@@ -236,6 +236,10 @@ int spo_p2p_close(void* peer_region);
 int spo_p2p_free(void* own_region);
 int spo_p2p_selftest(int rank, int world, void* const* regions, uint32_t step0, int iters, int32_t* result2_dev,
                      void* stream);
+int spo_critic_fit_iter_dp(float* theta, float* adam_m, float* adam_v, int64_t adam_step_host, const float* obs,
+                           const float* target_r, const float* target_c, const int32_t* perm, int64_t M,
+                           const spo_ppo_cfg* cfg_host, float* stale_sq_io, float* losses_out, void* sync_ws, int rank,
+                           int world, void* const* regions, uint32_t step0, void* stream);
 int spo_ppo_lag_update_iter_dp(float* theta, float* adam_m, float* adam_v, int64_t adam_step_host, const float* obs,
                                const float* act, const float* logp_old, const float* target_r, const float* target_c,
                                const float* adv, const int32_t* perm, int64_t M, const spo_ppo_cfg* cfg_host,

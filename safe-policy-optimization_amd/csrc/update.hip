@@ -1331,6 +1331,37 @@ extern "C" int spo_ppo_lag_update_iter_dp(float* theta, float* adam_m, float* ad
   return 0;
 }
 
+// CPO critic fit for one rank of a data-parallel job: spo_critic_fit_iter with the in-kernel gradient exchange
+// (cpo.py:541-571 over env shards; the stale actor-gradient norm is identical on every rank).
+extern "C" int spo_critic_fit_iter_dp(float* theta, float* adam_m, float* adam_v, int64_t adam_step_host, const float* obs,
+                                      const float* target_r, const float* target_c, const int32_t* perm, int64_t M,
+                                      const spo_ppo_cfg* cfg_host, float* stale_sq_io, float* losses_out, void* sync_ws,
+                                      int rank, int world, void* const* regions, uint32_t step0, void* stream) {
+  if (int rc = check_cfg(cfg_host)) return rc;
+  SPO_REQUIRE(theta && adam_m && adam_v && obs && target_r && target_c && perm && losses_out && sync_ws,
+              "critic_fit_iter_dp: null pointer");
+  SPO_REQUIRE(M > 0 && adam_step_host >= 0, "critic_fit_iter_dp: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = spo::hip_check(hipMemsetAsync(sync_ws, 0, 72, st), "hipMemsetAsync(sync_ws)")) return rc;
+  UpdArgs a{};
+  if (int rc = fill_xr(a, rank, world, regions, step0)) return rc;
+  a.theta = theta; a.adam_m = adam_m; a.adam_v = adam_v;
+  a.obs = obs; a.tgt_r = target_r; a.tgt_c = target_c; a.perm = perm; a.M = M; a.cfg = *cfg_host;
+  a.losses = losses_out;
+  a.slots = reinterpret_cast<unsigned long long*>(sync_ws);
+  a.err = reinterpret_cast<int*>(reinterpret_cast<char*>(sync_ws) + 64);
+  a.pow_b1 = pow((double)cfg_host->beta1, (double)adam_step_host);
+  a.pow_b2 = pow((double)cfg_host->beta2, (double)adam_step_host);
+  a.pow_b1_actor = a.pow_b1; a.pow_b2_actor = a.pow_b2;
+  a.first_net = 0; a.n_nets = 2; a.stale_sq = 0.f; a.stale_io = stale_sq_io;
+  int rc = 0;
+  if (a.xr_algo == 1 && (world & (world - 1)) == 0) rc = launch_update<true, 0, 2>(a, 2, st);
+  else rc = launch_update<true, 0, 1>(a, 2, st);
+  if (rc) return rc;
+  SPO_LAUNCH_CHECK("spo_critic_fit_iter_dp");
+  return 0;
+}
+
 // Debug: when set (device pointer to 3*10 u64), spo_ppo_lag_update_iter runs an instrumented build of
 // the kernel that accumulates shader-clock cycles per phase of the step (wave 0 lane 0 per block).
 extern "C" int spo_debug_set_update_profile(void* dev_u64_30) {

@@ -75,6 +75,8 @@ PROTOTYPES = {
     "spo_p2p_close": (c_int, [P]),
     "spo_p2p_free": (c_int, [P]),
     "spo_p2p_selftest": (c_int, [c_int, c_int, POINTER(c_void_p), c_uint32, c_int, P, P]),
+    "spo_critic_fit_iter_dp": (c_int, [P, P, P, c_int64, P, P, P, P, c_int64, POINTER(PpoCfg), P, P, P, c_int, c_int,
+                                       POINTER(c_void_p), c_uint32, P]),
     "spo_ppo_lag_update_iter_dp": (c_int, [P, P, P, c_int64, P, P, P, P, P, P, P, c_int64, POINTER(PpoCfg), P, P,
                                            c_int, c_int, POINTER(c_void_p), c_uint32, P]),
     "spo_ma_param_count": (c_int64, [POINTER(MaNet)]),

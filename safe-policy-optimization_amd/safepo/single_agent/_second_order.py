@@ -10,6 +10,7 @@ spo_critic_fit_iter) through safepo.single_agent.cpo.CPOEngine.
 """
 from __future__ import annotations
 
+import os
 import random
 import time
 
@@ -20,7 +21,7 @@ from safepo.common.env import make_sa_mujoco_env
 from safepo.common.lagrange import Lagrange
 from safepo.common.logger import EpochLogger
 from safepo.common.model import ActorVCritic
-from safepo.parallel import init_from_env
+from safepo.parallel import dp_mean_scalar, init_from_env, shard_envs
 from safepo.single_agent.cpo import CPOEngine, _to_dev
 from safepo.utils.config import isaac_gym_map
 
@@ -32,13 +33,15 @@ def run(args, cfg_env, default_cfg: dict, line_search: bool, use_lagrange: bool)
     if args.device == "cpu":
         raise RuntimeError("this build runs the trust-region hot path on a ROCm GPU only (--device cuda); no CPU fallback")
     comm = init_from_env()
-    device = torch.device(f"cuda:{args.device_id}")
+    local_rank = int(os.environ.get("LOCAL_RANK", args.device_id))
+    device = torch.device(f"cuda:{local_rank if comm.world_size > 1 else args.device_id}")
     torch.cuda.set_device(device)
     if args.task in isaac_gym_map:
         raise NotImplementedError("Isaac Gym tasks (isaac_gym_specific_cfg) are not part of this build")
     config = dict(default_cfg)
     config.update(getattr(args, "cfg_override", None) or {})
-    env, obs_space, act_space = make_sa_mujoco_env(num_envs=args.num_envs, env_id=args.task, seed=args.seed,
+    _, n_local = shard_envs(args.num_envs, comm)          # one process per GPU: a contiguous shard of the envs each
+    env, obs_space, act_space = make_sa_mujoco_env(num_envs=n_local, env_id=args.task, seed=args.seed + 1000 * comm.rank,
                                                    device=device, **(getattr(args, "env_kwargs", None) or {}))
     device_env = getattr(env, "is_device_env", False)
     steps_per_epoch = config.get("steps_per_epoch", args.steps_per_epoch)
@@ -47,12 +50,15 @@ def run(args, cfg_env, default_cfg: dict, line_search: bool, use_lagrange: bool)
     epochs = total_steps // steps_per_epoch
     policy = ActorVCritic(obs_dim=obs_space.shape[0], act_dim=act_space.shape[0],
                           hidden_sizes=config["hidden_sizes"]).to(device)
-    engine = CPOEngine(policy, args.num_envs, local_steps_per_epoch, config, device, comm=comm)
+    comm.broadcast_(policy.theta, 0)                       # identical replicas
+    engine = CPOEngine(policy, n_local, local_steps_per_epoch, config, device, comm=comm)
     lagrange = Lagrange(cost_limit=args.cost_limit, lagrangian_multiplier_init=args.lagrangian_multiplier_init,
                         lagrangian_multiplier_lr=args.lagrangian_multiplier_lr) if use_lagrange else None
     dict_args = dict(vars(args))
     dict_args.update(config)
-    logger = EpochLogger(log_dir=args.log_dir, seed=str(args.seed))
+    is_root = comm.rank == 0
+    logger = EpochLogger(log_dir=args.log_dir if is_root else os.path.join(args.log_dir, f"rank{comm.rank}"),
+                         seed=str(args.seed), verbose=is_root)
     logger.save_config(dict_args)
     logger.setup_torch_saver(policy.actor)
     logger.log("Start with training.")
@@ -80,7 +86,7 @@ def run(args, cfg_env, default_cfg: dict, line_search: bool, use_lagrange: bool)
         rollout_end_time = time.time()
         eval_end_time = rollout_end_time
 
-        ep_costs = logger.get_stats("Metrics/EpCost")
+        ep_costs = dp_mean_scalar(comm, logger.get_stats("Metrics/EpCost"), device)
         lam = None
         if lagrange is not None:
             lagrange.update_lagrange_multiplier(ep_costs)

@@ -25,7 +25,7 @@ from safepo.common.engine import PPOLagEngine
 from safepo.common.env import make_sa_mujoco_env
 from safepo.common.logger import EpochLogger
 from safepo.common.model import ActorVCritic
-from safepo.parallel import init_from_env, shard_envs
+from safepo.parallel import dp_mean_scalar, init_from_env, shard_envs
 from safepo.utils.config import isaac_gym_map, single_agent_args
 
 STEP_FRACTION = 0.8
@@ -47,8 +47,10 @@ class CPOEngine(PPOLagEngine):
 
     def __init__(self, policy: ActorVCritic, num_envs: int, steps: int, config: dict, device, comm=None):
         super().__init__(policy, num_envs, steps, config, device, comm=comm, lr=1e-3, critic_lr=1e-3)
-        if self.comm.world_size > 1:
-            raise NotImplementedError("CPO runs single-GPU in this build (BASELINE config 3)")
+        # data parallel over env shards: the actor update is full-batch, so it is EXACT -- the two
+        # surrogate gradients, every Fisher-vector product and the line-search sums are all-reduced means; the critic fit
+        # runs the persistent kernel with the in-kernel gradient exchange (needs peer-mapped regions).
+        self._inv_world = 1.0 / self.comm.world_size
         self.ls_off = policy.log_std_offset
         self.Pa = policy.theta.numel() - self.ls_off
         nparts = self.lib.spo_cpo_num_partials(self.M)
@@ -72,7 +74,11 @@ class CPOEngine(PPOLagEngine):
             _abi.ptr(self.policy.theta), _abi.ptr(d["obs"]), _abi.ptr(d["act"]), _abi.ptr(d["log_prob"]),
             _abi.ptr(adv), float(sign), self.M, self.D, self.A, _abi.ptr(self.partial_ws), _abi.ptr(self.loss_ws),
             _abi.ptr(g), _abi.ptr(self.loss_sum), _abi.stream_ptr()), "spo_cpo_surrogate_grad")
-        return g, float(self.loss_sum.item()) / self.M
+        if self.comm.world_size > 1:
+            self.comm.all_reduce_sum_(g)
+            g *= self._inv_world
+            self.comm.all_reduce_sum_(self.loss_sum)
+        return g, float(self.loss_sum.item()) / (self.M * self.comm.world_size)
 
     def fvp(self, v: torch.Tensor) -> torch.Tensor:
         """cpo.py:132-157: H v + 0.1 v with H the Hessian of mean(KL(old||cur)) at cur == old."""
@@ -81,6 +87,9 @@ class CPOEngine(PPOLagEngine):
         _abi.check(self.lib.spo_cpo_fvp(_abi.ptr(self.policy.theta), _abi.ptr(self.buffer.data["obs"]), _abi.ptr(v),
                                         self.M, self.D, self.A, _abi.ptr(self.partial_ws), _abi.ptr(self.loss_ws),
                                         _abi.ptr(out), _abi.stream_ptr()), "spo_cpo_fvp")
+        if self.comm.world_size > 1:
+            self.comm.all_reduce_sum_(out)
+            out *= self._inv_world
         out[:self.A] += (2.0 / self.A) * v[:self.A]          # log_std block of the Hessian
         return out + v * 0.1
 
@@ -115,8 +124,10 @@ class CPOEngine(PPOLagEngine):
             _abi.ptr(adv_a), _abi.ptr(adv_b), _abi.ptr(self.mean_old), _abi.ptr(self.logstd_old),
             self.M, self.D, self.A, _abi.ptr(self.ls_partials), self.ls_partials.numel(), _abi.ptr(self.ls_sums),
             _abi.stream_ptr()), "spo_cpo_linesearch_eval")
+        self.comm.all_reduce_sum_(self.ls_sums)
         s = self.ls_sums.cpu()
-        return -float(s[0]) / self.M, float(s[1]) / self.M, float(s[2]) / (self.M * self.A)
+        Mg = self.M * self.comm.world_size
+        return -float(s[0]) / Mg, float(s[1]) / Mg, float(s[2]) / (Mg * self.A)
 
     def policy_update(self, ep_costs: float, logger=None) -> dict:
         """cpo.py:350-532.  `ep_costs` = Jc - cost_limit.  Requires compute_gae() to have run."""
@@ -347,11 +358,25 @@ class CPOEngine(PPOLagEngine):
         for it in range(c["learning_iters"]):
             perm = _abi.require_gpu_tensor(perm_fn(it), "perm", torch.int32)
             losses = torch.empty((n_mb, 3), dtype=torch.float32, device=self.dev)
-            _abi.check(self.lib.spo_critic_fit_iter(
-                _abi.ptr(self.policy.theta), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), self.adam_step,
-                _abi.ptr(d["obs"]), _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]), _abi.ptr(perm),
-                self.M, cfg, _abi.ptr(self.stale_sq), _abi.ptr(losses), _abi.ptr(self.sync_ws), _abi.stream_ptr()),
-                "spo_critic_fit_iter")
+            if self.comm.world_size > 1:
+                px = self.p2p
+                if px is None:
+                    raise NotImplementedError("data-parallel CPO needs the in-kernel gradient exchange (peer-mapped "
+                                              "regions) for the critic fit; it is unavailable on this node")
+                _abi.check(self.lib.spo_critic_fit_iter_dp(
+                    _abi.ptr(self.policy.theta), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), self.adam_step,
+                    _abi.ptr(d["obs"]), _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]), _abi.ptr(perm),
+                    self.M, cfg, _abi.ptr(self.stale_sq), _abi.ptr(losses), _abi.ptr(self.sync_ws), px.rank, px.world,
+                    px.regions, px.step & 0xFFFFFFFF, _abi.stream_ptr()), "spo_critic_fit_iter_dp")
+                px.step += n_mb
+                self.comm.all_reduce_sum_(losses)
+                losses *= self._inv_world
+            else:
+                _abi.check(self.lib.spo_critic_fit_iter(
+                    _abi.ptr(self.policy.theta), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), self.adam_step,
+                    _abi.ptr(d["obs"]), _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]), _abi.ptr(perm),
+                    self.M, cfg, _abi.ptr(self.stale_sq), _abi.ptr(losses), _abi.ptr(self.sync_ws), _abi.stream_ptr()),
+                    "spo_critic_fit_iter")
             self.adam_step += n_mb
             all_losses.append(losses[:, :2])
         self.check_sync_error()
@@ -370,13 +395,15 @@ def main(args, cfg_env=None, _update="cpo"):
     if args.device == "cpu":
         raise RuntimeError("this build runs the CPO hot path on a ROCm GPU only (--device cuda); no CPU fallback")
     comm = init_from_env()
-    device = torch.device(f"cuda:{args.device_id}")
+    local_rank = int(os.environ.get("LOCAL_RANK", args.device_id))
+    device = torch.device(f"cuda:{local_rank if comm.world_size > 1 else args.device_id}")
     torch.cuda.set_device(device)
     if args.task in isaac_gym_map:
         raise NotImplementedError("Isaac Gym tasks (isaac_gym_specific_cfg) are not part of this build")
     config = dict(default_cfg)
     config.update(getattr(args, "cfg_override", None) or {})
-    env, obs_space, act_space = make_sa_mujoco_env(num_envs=args.num_envs, env_id=args.task, seed=args.seed,
+    _, n_local = shard_envs(args.num_envs, comm)          # one process per GPU: a contiguous shard of the envs each
+    env, obs_space, act_space = make_sa_mujoco_env(num_envs=n_local, env_id=args.task, seed=args.seed + 1000 * comm.rank,
                                                    device=device, **(getattr(args, "env_kwargs", None) or {}))
     device_env = getattr(env, "is_device_env", False)
     steps_per_epoch = config.get("steps_per_epoch", args.steps_per_epoch)
@@ -385,10 +412,13 @@ def main(args, cfg_env=None, _update="cpo"):
     epochs = total_steps // steps_per_epoch
     policy = ActorVCritic(obs_dim=obs_space.shape[0], act_dim=act_space.shape[0],
                           hidden_sizes=config["hidden_sizes"]).to(device)
-    engine = CPOEngine(policy, args.num_envs, local_steps_per_epoch, config, device, comm=comm)
+    comm.broadcast_(policy.theta, 0)                       # identical replicas
+    engine = CPOEngine(policy, n_local, local_steps_per_epoch, config, device, comm=comm)
     dict_args = dict(vars(args))
     dict_args.update(config)
-    logger = EpochLogger(log_dir=args.log_dir, seed=str(args.seed))
+    is_root = comm.rank == 0
+    logger = EpochLogger(log_dir=args.log_dir if is_root else os.path.join(args.log_dir, f"rank{comm.rank}"),
+                         seed=str(args.seed), verbose=is_root)
     logger.save_config(dict_args)
     logger.setup_torch_saver(policy.actor)
     logger.log("Start with training.")
@@ -418,7 +448,7 @@ def main(args, cfg_env=None, _update="cpo"):
 
         # ---- update policy (cpo.py:350-532) and critics (:534-571)
         engine.buffer.compute_gae(None, comm)
-        ep_costs = logger.get_stats("Metrics/EpCost") - args.cost_limit
+        ep_costs = dp_mean_scalar(comm, logger.get_stats("Metrics/EpCost"), device) - args.cost_limit
         out = engine.policy_update(ep_costs, logger) if _update == "cpo" else engine.pcpo_update(ep_costs, logger)
         logger.store(**{"Misc/Alpha": out["alpha"], "Misc/FinalStepNorm": out["final_step_norm"], "Misc/xHx": out["xHx"],
                         "Misc/gradient_norm": out["gradient_norm"], "Misc/H_inv_g": out["H_inv_g"],

@@ -1,0 +1,78 @@
+"""Worker of tests/test_gpu_parity.py::test_cpo_data_parallel_two_ranks_one_gpu (not a test module).
+
+Two ranks on ONE GPU (gloo host collectives, exchange regions mapped through IPC) each hold half of the envs of a CPO
+buffer.  The actor update is full-batch, so two ranks x half the rows must reproduce one rank x all rows; the critic fit
+(minibatches of each shard, gradients averaged in-kernel) must keep the replicas bit-identical."""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "safe-policy-optimization_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def main(out_path):
+    from safepo import parallel as P
+    from safepo.common.model import ActorVCritic
+    from safepo.single_agent.cpo import CPOEngine, default_cfg
+    comm = P.init_from_env(backend="gloo")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    rank, world = comm.rank, comm.world_size
+    N, T, D, A = 8, 40, 60, 8
+    cfg = dict(default_cfg, learning_iters=2, batch_size=64)
+    g = torch.Generator().manual_seed(77)
+    full = {"obs": torch.randn(N, T, D, generator=g), "act": torch.randn(N, T, A, generator=g),
+            "reward": torch.randn(N, T, generator=g), "cost": (torch.rand(N, T, generator=g) < 0.3).float(),
+            "value_r": torch.randn(N, T, generator=g) * 0.3, "value_c": torch.rand(N, T, generator=g)}
+    full["log_prob"] = -A * 0.92 - 0.5 * (full["act"] ** 2).sum(-1) + 0.05 * torch.randn(N, T, generator=g)
+
+    def build(n, lo, comm_):
+        torch.manual_seed(21)
+        pol = ActorVCritic(D, A).to(dev)
+        eng = CPOEngine(pol, n, T, cfg, dev, comm=comm_)
+        b = eng.buffer
+        for k, v in full.items():
+            b.data[k].copy_(v[lo:lo + n])
+        b.seg_end.zero_(); b.seg_end[:, T // 2 - 1] = 1; b.seg_end[:, T - 1] = 1
+        b.boot_r.zero_(); b.boot_c.zero_()
+        b.ptr = T
+        return pol, eng
+    shard = N // world
+    pol, eng = build(shard, rank * shard, comm)
+    res = {"world": world, "p2p": eng.p2p is not None}
+    eng.buffer.compute_gae(None, comm)
+    out = eng.policy_update(0.4)
+    actor_dp = eng.theta_actor.detach().cpu().clone()
+    fit = eng.critic_fit(perm_fn=lambda it: torch.randperm(eng.M, generator=torch.Generator().manual_seed(5 + it + 10 * rank)).to(torch.int32).to(dev))
+    eng.check_sync_error()
+    theta = pol.theta.detach().cpu()
+    gathered = [torch.empty_like(theta) for _ in range(world)]
+    dist.all_gather(gathered, theta)
+    res["replicas_identical"] = all(torch.equal(gathered[0], x) for x in gathered[1:])
+    res["finite"] = bool(torch.isfinite(theta).all())
+    if rank == 0:
+        pol1, eng1 = build(N, 0, P.Comm.single())
+        eng1.buffer.compute_gae(None, None)
+        out1 = eng1.policy_update(0.4)
+        ref = eng1.theta_actor.detach().cpu()
+        d = (actor_dp - ref).abs()
+        res["actor_max_abs_diff"] = float(d.max())
+        res["actor_frac_outside"] = float((d > 1e-6 + 1e-3 * ref.abs()).float().mean())
+        for k in ("xHx", "gradient_norm", "H_inv_g", "alpha", "final_step_norm", "kl", "loss_actor"):
+            res[k] = [float(out[k]), float(out1[k])]
+        res["case"] = [int(out["case"]), int(out1["case"])]
+        res["acceptance_step"] = [int(out["acceptance_step"]), int(out1["acceptance_step"])]
+        with open(out_path, "w") as f:
+            json.dump(res, f)
+    comm.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -1317,3 +1317,27 @@ def test_ma_mappolag_data_parallel_two_ranks_one_gpu(dev, tmp_path):
     np.testing.assert_allclose(res["popart"][0], res["popart"][1], rtol=1e-5)
     np.testing.assert_allclose(res["losses"][0], res["losses"][1], rtol=2e-4, atol=2e-6)
     assert res["moved"] > 1e-4
+
+
+def test_cpo_data_parallel_two_ranks_one_gpu(dev, tmp_path):
+    """CPO sharded over envs.  Gradients g and b, every Fisher-vector product and the line-search
+    sums are all-reduced means, so two ranks x half the envs reproduce one rank x all envs; the critic fit runs the
+    persistent kernel with the in-kernel exchange and keeps the replicas bit-identical."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    out = tmp_path / "cpo_dp.json"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "cpo_dp_worker.py"), str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = json.load(open(out))
+    assert res["p2p"] and res["replicas_identical"] and res["finite"], res
+    assert res["case"][0] == res["case"][1] and res["acceptance_step"][0] == res["acceptance_step"][1], res
+    for k in ("xHx", "gradient_norm", "H_inv_g", "alpha", "final_step_norm", "kl"):
+        assert res[k][0] == pytest.approx(res[k][1], rel=2e-3), (k, res)
+    assert res["actor_frac_outside"] <= 2e-3 and res["actor_max_abs_diff"] < 1e-3, res
