@@ -357,16 +357,47 @@ class Runner:
             self.buffer[a].obs[0].copy_(obs[:, a])
 
     @torch.no_grad()
-    def collect(self, step):
-        vals, acts, lps, rnn, rnn_c, cps, rnn_k = [], [], [], [], [], [], []
+    def _collect_eager(self, share_obs, obs, rnn, rnn_c, rnn_k, masks):
+        vals, acts, lps, o_rnn, o_rnn_c, cps, o_rnn_k = [], [], [], [], [], [], []
         for a in range(self.num_agents):
-            b = self.buffer[a]
-            v, act, lp, r, rc, cp, rk = self.trainer[a].policy.get_actions(
-                b.share_obs[step], b.obs[step], b.rnn_states[step], b.rnn_states_critic[step], b.masks[step],
-                rnn_states_cost=b.rnn_states_cost[step])
-            vals.append(v); acts.append(act); lps.append(lp); rnn.append(r); rnn_c.append(rc); cps.append(cp); rnn_k.append(rk)
+            v, act, lp, r, rc, cp, rk = self.trainer[a].policy.get_actions(share_obs[a], obs[a], rnn[a], rnn_c[a], masks[a],
+                                                                         rnn_states_cost=rnn_k[a])
+            vals.append(v); acts.append(act); lps.append(lp); o_rnn.append(r); o_rnn_c.append(rc); cps.append(cp); o_rnn_k.append(rk)
         tr = lambda xs: torch.transpose(torch.stack(xs), 1, 0)
-        return tr(vals), acts, lps, tr(rnn), tr(rnn_c), tr(cps), tr(rnn_k)
+        return tr(vals), acts, lps, tr(o_rnn), tr(o_rnn_c), tr(cps), tr(o_rnn_k)
+
+    @torch.no_grad()
+    def collect(self, step):
+        """mappolag.py:411-447.  The 12 network forwards + sampling of one step are ~110 small launches (8 k per epoch,
+        launch-bound); with config["collect_graph"] (default on) they are captured once into a HIP graph over static
+        input buffers and replayed every step.  Any capture failure falls back to eager launches for good."""
+        bufs = self.buffer
+        ins = ([b.share_obs[step] for b in bufs], [b.obs[step] for b in bufs], [b.rnn_states[step] for b in bufs],
+               [b.rnn_states_critic[step] for b in bufs], [b.rnn_states_cost[step] for b in bufs], [b.masks[step] for b in bufs])
+        if not self.config.get("collect_graph", True) or getattr(self, "_graph_failed", False):
+            return self._collect_eager(*ins)
+        if getattr(self, "_graph", None) is None:
+            try:
+                self._static_in = tuple([t.clone() for t in group] for group in ins)
+                self._collect_eager(*self._static_in)            # warm-up: rocBLAS handle / workspaces, allocator pools
+                torch.cuda.synchronize(self.dev)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._static_out = self._collect_eager(*self._static_in)
+                self._graph = g
+            except Exception as e:                                   # noqa: BLE001 -- eager launches are always valid
+                self._graph_failed = True
+                self._graph = None
+                torch.cuda.synchronize(self.dev)
+                if self.is_root:
+                    print(f"[safepo] collect graph capture failed ({type(e).__name__}: {e}); using eager launches", file=sys.stderr)
+                return self._collect_eager(*ins)
+        for dst_group, src_group in zip(self._static_in, ins):
+            for dst, src in zip(dst_group, src_group):
+                dst.copy_(src)
+        self._graph.replay()
+        v, acts, lps, r, rc, cp, rk = self._static_out
+        return v.clone(), [x.clone() for x in acts], [x.clone() for x in lps], r.clone(), rc.clone(), cp.clone(), rk.clone()
 
     def insert(self, data, aver_episode_costs=0):
         (obs, share_obs, rewards, costs, dones, infos, values, actions, action_log_probs, rnn_states, rnn_states_critic,
