@@ -154,12 +154,22 @@ __global__ __launch_bounds__(256, 2) void dw_partial_kernel(const float* __restr
         if (n < N && k < K) out[(int64_t)n * K + k] = acc[m][t][e];
       }
 }
-__global__ void dw_reduce_kernel(const float* __restrict__ partial, int S, int64_t NK, float* __restrict__ out) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= NK) return;
+// 64 outputs x 16 strided groups of slices per workgroup (1024 threads), combined in a fixed order
+__global__ __launch_bounds__(1024) void dw_reduce_kernel(const float* __restrict__ partial, int S, int64_t NK, float* __restrict__ out) {
+  __shared__ float sh[16][64];
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int64_t j = (int64_t)blockIdx.x * 64 + c;
   float s = 0.f;
-  for (int b = 0; b < S; ++b) s += partial[(int64_t)b * NK + j];
-  out[j] = s;
+  if (j < NK)
+    for (int b = q; b < S; b += 16) s += partial[(int64_t)b * NK + j];
+  sh[q][c] = s;
+  __syncthreads();
+  if (q == 0 && j < NK) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[k][c];
+    out[j] = t;
+  }
 }
 // `slices`: float[dw_splits(B, N, K) * N * K]
 int gemm_dyTx(hipStream_t st, const float* dY, const float* X, float* dW, int64_t B, int K, int N, float* slices) {
@@ -169,7 +179,7 @@ int gemm_dyTx(hipStream_t st, const float* dY, const float* X, float* dW, int64_
   if (vec) hipLaunchKernelGGL(dw_partial_kernel<true>, dim3(tiles * S), dim3(256), 0, st, dY, X, slices, B, N, K, S);
   else hipLaunchKernelGGL(dw_partial_kernel<false>, dim3(tiles * S), dim3(256), 0, st, dY, X, slices, B, N, K, S);
   const int64_t NK = (int64_t)N * K;
-  hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)((NK + 255) / 256)), dim3(256), 0, st, slices, S, NK, dW);
+  hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)((NK + 63) / 64)), dim3(1024), 0, st, slices, S, NK, dW);
   return 0;
 }
 
@@ -192,13 +202,15 @@ struct Lay {
   int64_t hW() const { return blk(NB) + (actor ? O : 0); }
   int64_t hb() const { return hW() + (int64_t)O * H; }
   int64_t count() const { return hb() + O; }
-  // workspace (floats) for B rows: xhat[B,D], st0[B,2], per block: a[B,H], st[B,2], y[B,H]
+  // workspace (floats) for B rows: xhat[B,D], st0[B,2], per block: a[B,H], st[B,2], y[B,H]; every region starts on a
+  // 16-byte boundary (row statistics padded to a multiple of 4 floats) so the 128-wide kernels can use float4 accesses
+  static int64_t al4(int64_t n) { return (n + 3) & ~(int64_t)3; }
   int64_t ws_xhat() const { return 0; }
-  int64_t ws_st0(int64_t B) const { return B * D; }
-  int64_t ws_blk(int64_t B, int k) const { return B * D + 2 * B + (int64_t)k * (2 * B * H + 2 * B); }
+  int64_t ws_st0(int64_t B) const { return al4(B * D); }
+  int64_t ws_blk(int64_t B, int k) const { return al4(B * D) + al4(2 * B) + (int64_t)k * (2 * al4(B * H) + al4(2 * B)); }
   int64_t ws_a(int64_t B, int k) const { return ws_blk(B, k); }
-  int64_t ws_st(int64_t B, int k) const { return ws_blk(B, k) + B * H; }
-  int64_t ws_y(int64_t B, int k) const { return ws_blk(B, k) + B * H + 2 * B; }
+  int64_t ws_st(int64_t B, int k) const { return ws_blk(B, k) + al4(B * H); }
+  int64_t ws_y(int64_t B, int k) const { return ws_blk(B, k) + al4(B * H) + al4(2 * B); }
   int64_t ws_count(int64_t B) const { return ws_blk(B, NB); }
 };
 
@@ -317,19 +329,107 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 }
 
 // out[w][j] = sum over blocks (fixed order) of partial[block][w][j]
-// grid (ceil(D/64), 3), 256 threads = 64 columns x 4 strided slices of the block list, combined in a fixed order
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, int nblocks, int D, float* o0,
-                                                            float* o1, float* o2) {
-  __shared__ float sh[4][64];
+// ---- 128-wide rows (hidden_size 128: the MuJoCo configs): float4 per lane, TWO rows per wave (lanes 0-31 / 32-63), so a
+// wave moves 1 KB per instruction instead of 256 B and reduces over 32 lanes.  Same arithmetic as the generic kernels.
+typedef float f4w __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float half_wave_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void ln_fwd128_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                         const float* __restrict__ g, const float* __restrict__ b,
+                                                         float* __restrict__ a_out, float* __restrict__ y,
+                                                         float* __restrict__ stats, int64_t B) {
+  constexpr int D = 128;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = (lane & 31) * 4, sub = lane >> 5;
+  const f4w gg = *reinterpret_cast<const f4w*>(g + c), bb = *reinterpret_cast<const f4w*>(b + c);
+  f4w bi = {0.f, 0.f, 0.f, 0.f};
+  if (MODE == 1) bi = *reinterpret_cast<const f4w*>(bias + c);
+  for (int64_t row = ((int64_t)blockIdx.x * 4 + wave) * 2 + sub; row < B + sub; row += (int64_t)gridDim.x * 8) {
+    const bool ok = row < B;                                   // the two halves of a wave stay in the loop together
+    f4w v = {0.f, 0.f, 0.f, 0.f};
+    if (ok) v = *reinterpret_cast<const f4w*>(x + row * D + c);
+    if (MODE == 1) {
+      v += bi;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : expm1f(v[e]);
+      if (ok) *reinterpret_cast<f4w*>(a_out + row * D + c) = v;
+    }
+    const float mean = half_wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.f / D);
+    const f4w d = v - mean;
+    const float var = half_wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.f / D);
+    const float rstd = 1.f / sqrtf(var + LN_EPS);
+    if (ok) {
+      *reinterpret_cast<f4w*>(y + row * D + c) = d * rstd * gg + bb;
+      if ((lane & 31) == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+    }
+  }
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void ln_bwd128_kernel(const float* __restrict__ dy, const float* __restrict__ a,
+                                                         const float* __restrict__ stats, const float* __restrict__ g,
+                                                         float* __restrict__ dz, float* __restrict__ partial, int64_t B) {
+  constexpr int D = 128;
+  __shared__ float sh[3][8][D];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = (lane & 31) * 4, sub = lane >> 5;
+  const f4w gg = *reinterpret_cast<const f4w*>(g + c);
+  f4w cg = {0.f, 0.f, 0.f, 0.f}, cb = cg, cz = cg;
+  for (int64_t row = ((int64_t)blockIdx.x * 4 + wave) * 2 + sub; row < B + sub; row += (int64_t)gridDim.x * 8) {
+    const bool ok = row < B;
+    f4w d = {0.f, 0.f, 0.f, 0.f}, av = d;
+    float mean = 0.f, rstd = 0.f;
+    if (ok) {
+      d = *reinterpret_cast<const f4w*>(dy + row * D + c);
+      av = *reinterpret_cast<const f4w*>(a + row * D + c);
+      mean = stats[2 * row]; rstd = stats[2 * row + 1];
+    }
+    const f4w xh = (av - mean) * rstd;
+    const f4w dxh = d * gg;
+    cg += d * xh; cb += d;
+    if (MODE == 1) {
+      const float m1 = half_wave_sum((dxh[0] + dxh[1]) + (dxh[2] + dxh[3])) * (1.f / D);
+      const f4w t = dxh * xh;
+      const float m2 = half_wave_sum((t[0] + t[1]) + (t[2] + t[3])) * (1.f / D);
+      f4w dzv = (dxh - m1 - xh * m2) * rstd;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dzv[e] *= av[e] > 0.f ? 1.f : av[e] + 1.f;
+      if (ok) *reinterpret_cast<f4w*>(dz + row * D + c) = dzv;
+      cz += ok ? dzv : f4w{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  *reinterpret_cast<f4w*>(&sh[0][2 * wave + sub][c]) = cg;
+  *reinterpret_cast<f4w*>(&sh[1][2 * wave + sub][c]) = cb;
+  *reinterpret_cast<f4w*>(&sh[2][2 * wave + sub][c]) = cz;
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 3 * D; idx += 256) {
+    const int w = idx / D, jcol = idx % D;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += sh[w][k][jcol];
+    partial[((int64_t)blockIdx.x * 3 + w) * D + jcol] = s;
+  }
+}
+
+// grid (ceil(D/64), 3), 1024 threads = 64 columns x 16 strided slices of the block list, combined in a fixed order
+__global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ partial, int nblocks, int D, float* o0,
+                                                             float* o1, float* o2) {
+  __shared__ float sh[16][64];
   const int c = threadIdx.x & 63, q = threadIdx.x >> 6, w = blockIdx.y;
   const int j = blockIdx.x * 64 + c;
   float s = 0.f;
   if (j < D)
-    for (int b = q; b < nblocks; b += 4) s += partial[((int64_t)b * 3 + w) * D + j];
+    for (int b = q; b < nblocks; b += 16) s += partial[((int64_t)b * 3 + w) * D + j];
   sh[q][c] = s;
   __syncthreads();
   float* o = w == 0 ? o0 : w == 1 ? o1 : o2;
-  if (q == 0 && j < D && o) o[j] = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
+  if (q == 0 && j < D && o) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[k][c];
+    o[j] = t;
+  }
 }
 
 // head: out[B,O] += bias ; db[O] = column sums of dout (second form)
@@ -658,8 +758,12 @@ extern "C" int spo_ma_forward(const float* theta, const spo_ma_net* net, const f
   for (int k = 0; k < L.NB; ++k) {
     float* a = ws + L.ws_a(B, k);
     if (int rc = gemm_xwT(st, in, theta + L.W(k), a, B, L.in_k(k), L.H)) return rc;
-    hipLaunchKernelGGL(ln_fwd_kernel<1>, dim3(gr), dim3(256), 0, st, a, theta + L.b(k), theta + L.g(k), theta + L.be(k), a,
-                       ws + L.ws_y(B, k), ws + L.ws_st(B, k), B, L.H);
+    if (L.H == 128)
+      hipLaunchKernelGGL(ln_fwd128_kernel<1>, dim3(gr), dim3(256), 0, st, a, theta + L.b(k), theta + L.g(k), theta + L.be(k), a,
+                         ws + L.ws_y(B, k), ws + L.ws_st(B, k), B);
+    else
+      hipLaunchKernelGGL(ln_fwd_kernel<1>, dim3(gr), dim3(256), 0, st, a, theta + L.b(k), theta + L.g(k), theta + L.be(k), a,
+                         ws + L.ws_y(B, k), ws + L.ws_st(B, k), B, L.H);
     in = ws + L.ws_y(B, k);
   }
   if (int rc = gemm_xwT(st, in, theta + L.hW(), out, B, L.H, L.O)) return rc;
@@ -705,9 +809,13 @@ extern "C" int spo_ma_backward(const float* theta, const spo_ma_net* net, const 
   }
   if (int rc = gemm_dyw(st, dout, theta + L.hW(), d0, B, L.H, L.O)) return rc;
   for (int k = L.NB - 1; k >= 0; --k) {
-    hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(gr), dim3(256), 0, st, d0, ws + L.ws_a(B, k), ws + L.ws_st(B, k), theta + L.g(k),
-                       d1, partial, B, L.H);
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((L.H + 63) / 64, 3), dim3(256), 0, st, partial, gr, L.H, grad + L.g(k),
+    if (L.H == 128)
+      hipLaunchKernelGGL(ln_bwd128_kernel<1>, dim3(gr), dim3(256), 0, st, d0, ws + L.ws_a(B, k), ws + L.ws_st(B, k), theta + L.g(k),
+                         d1, partial, B);
+    else
+      hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(gr), dim3(256), 0, st, d0, ws + L.ws_a(B, k), ws + L.ws_st(B, k), theta + L.g(k),
+                         d1, partial, B, L.H);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((L.H + 63) / 64, 3), dim3(1024), 0, st, partial, gr, L.H, grad + L.g(k),
                        grad + L.be(k), grad + L.b(k));
     const float* in = k == 0 ? ws + L.ws_xhat() : ws + L.ws_y(B, k - 1);
     if (int rc = gemm_dyTx(st, d1, in, grad + L.W(k), B, L.in_k(k), L.H, slices)) return rc;
@@ -715,7 +823,7 @@ extern "C" int spo_ma_backward(const float* theta, const spo_ma_net* net, const 
   }
   // feature_norm parameters (the observation itself needs no gradient)
   hipLaunchKernelGGL(ln_bwd_kernel<0>, dim3(gr), dim3(256), 0, st, d0, x, ws + L.ws_st0(B), theta + L.fn_g(), nullptr, partial, B, L.D);
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((L.D + 63) / 64, 3), dim3(256), 0, st, partial, gr, L.D, grad + L.fn_g(),
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((L.D + 63) / 64, 3), dim3(1024), 0, st, partial, gr, L.D, grad + L.fn_g(),
                      grad + L.fn_b(), nullptr);
   SPO_LAUNCH_CHECK("spo_ma_backward");
   return 0;
