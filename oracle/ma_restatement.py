@@ -21,10 +21,7 @@ class MANet(nn.Module):
     def __init__(self, in_dim, hidden, n_blocks, out_dim, is_actor, std_x_coef=1.0, std_y_coef=0.5):
         super().__init__()
         self.feature_norm = nn.LayerNorm(in_dim)
-        self.linears = nn.ModuleList()
-        self.norms = nn.ModuleList()
-        # interleave registration: W_k, b_k, ln_k.weight, ln_k.bias
-        self.blocks = nn.ModuleList()
+        self.blocks = nn.ModuleList()                      # per block: [Linear, LayerNorm] -> W_k, b_k, ln_k.weight, ln_k.bias
         d = in_dim
         for _ in range(n_blocks):
             self.blocks.append(nn.ModuleList([nn.Linear(d, hidden), nn.LayerNorm(hidden)]))

@@ -204,3 +204,59 @@ def test_popart_matches_reference_statistics(golden_dir):
     assert np.array_equal(mean.numpy(), z["a_mean"]) and np.array_equal(var.numpy(), z["a_var"])
     sd, mu = n.denorm_scalars()
     assert sd == float(np.sqrt(z["a_var"])[0]) and mu == float(z["a_mean"][0])
+
+
+def test_multi_agent_network_layout_matches_reference_state_dict(golden_dir):
+    """f3: the flat parameter layout of the HIP multi-agent networks IS the reference's state_dict order -- names, shapes
+    and offsets (spo_ma_param_offset is host-only arithmetic) -- so checkpoints load both ways."""
+    import numpy as np
+    from safepo import _abi
+    from safepo.common.model import MultiAgentActor, MultiAgentCritic
+    from safepo.multi_agent.mappolag import default_cfg
+    z = np.load(os.path.join(golden_dir, "ma_mappolag.npz"))
+    cfg = dict(default_cfg, hidden_size=int(z["default_cfg_hidden_size"]), layer_N=int(z["default_cfg_layer_N"]))
+
+    class Sp:
+        def __init__(self, n):
+            self.shape = (n,)
+    D, S, A = z["default_obs"].shape[1], z["default_share_obs"].shape[1], z["default_actions"].shape[1]
+    lib = _abi.load()
+    for nm, net in (("actor", MultiAgentActor(cfg, Sp(D), Sp(A), torch.device("cpu"))),
+                    ("critic", MultiAgentCritic(cfg, Sp(S), torch.device("cpu")))):
+        pre = f"default_init_{nm}_"
+        ref = {k[len(pre):]: z[k].shape for k in z.files if k.startswith(pre)}
+        mine = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        assert list(mine) == list(ref) and mine == ref
+        assert lib.spo_ma_param_count(net._net) == net.theta.numel()
+        # every parameter is a view at the offset the C side computes
+        base = net.theta.data_ptr()
+        sd = net.state_dict()
+        nb = 1 + cfg["layer_N"]
+        names = ["base.feature_norm.weight", "base.feature_norm.bias"]
+        which = [(0, 0), (1, 0)]
+        for k in range(nb):
+            blk = "base.mlp.fc1" if k == 0 else f"base.mlp.fc2.{k - 1}"
+            names += [f"{blk}.0.weight", f"{blk}.0.bias", f"{blk}.2.weight", f"{blk}.2.bias"]
+            which += [(2, k), (3, k), (4, k), (5, k)]
+        if nm == "actor":
+            names += ["act.action_out.log_std", "act.action_out.fc_mean.weight", "act.action_out.fc_mean.bias"]
+            which += [(6, 0), (7, 0), (8, 0)]
+        else:
+            names += ["v_out.weight", "v_out.bias"]
+            which += [(7, 0), (8, 0)]
+        assert names == list(sd)
+        for n_, (w, k) in zip(names, which):
+            assert (sd[n_].data_ptr() - base) // 4 == lib.spo_ma_param_offset(net._net, w, k), n_
+        # loading the reference's weights is a plain load_state_dict
+        net.load_state_dict({k[len(pre):]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith(pre)})
+        assert np.array_equal(net.theta.numpy(), np.concatenate([z[k].reshape(-1) for k in z.files if k.startswith(pre)]))
+
+
+def test_multi_agent_args_defaults_and_overrides():
+    from safepo.multi_agent.mappolag import default_cfg, mamujoco_cfg
+    from safepo.utils.config import multi_agent_args
+    args, cfg_env, cfg = multi_agent_args("mappolag", ["--num-envs", "16", "--cost-limit", "3.5", "--seed", "7", "--total-steps", "4096"])
+    assert cfg["n_rollout_threads"] == 16 and cfg["n_eval_rollout_threads"] == 16 and cfg["cost_limit"] == 3.5
+    assert cfg["hidden_size"] == mamujoco_cfg["hidden_size"] and cfg["learning_iters"] == default_cfg["learning_iters"]
+    assert cfg["num_env_steps"] == 4096 and cfg["algorithm_name"] == "mappolag" and cfg["device"] == "cuda:0"
+    assert "seed-007" in cfg["log_dir"] and args.task.startswith("Synth")
