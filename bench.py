@@ -225,6 +225,14 @@ def main():
                    "minibatch_steps_per_epoch": n_mb * a.learning_iters},
         "roofline": roofline,
         "roofline_hbm_streaming": stream,
+        # the kernel that owns 99 % of the GPU time is not HBM- but latency/matrix-bound: 327 680 strictly sequential
+        # optimiser steps, each at least 368 v_mfma_f32_16x16x4_f32 (32 cycles each) per wave on one CU per network
+        "update_kernel": ({"kernel": "ppo_update_kernel<64, persistent>", "bound": "fp32 MFMA issue of one CU per network + per-step latency chain",
+                           "us_per_minibatch_step": round(upd / a.steps / (n_mb * a.learning_iters) * 1e6, 3),
+                           "mfma_floor_us": round(368 * 32 / 2.4e9 * 1e6, 3),
+                           "frac": round((368 * 32 / 2.4e9) / (upd / a.steps / (n_mb * a.learning_iters)), 4),
+                           "note": "floor = MFMA issue cycles at 2.4 GHz; DESIGN.md 3.3 has the instruction mix"}
+                          if a.algo == "ppo_lag" else None),
         "cpu_baseline": cpu,
         "phases": {"rollout_s_per_epoch": round(roll / a.steps, 4), "update_s_per_epoch": round(upd / a.steps, 4),
                    "update_us_per_minibatch_step": round(upd / a.steps / (n_mb * (a.learning_iters if a.algo == "ppo_lag" else 10)) * 1e6, 3),
