@@ -412,6 +412,136 @@ __global__ __launch_bounds__(256) void ln_bwd128_kernel(const float* __restrict_
   }
 }
 
+// ---- fused block forward for hidden 128:  y = LayerNorm(ELU(X W^T + b))  in ONE kernel (GEMM on fp32 MFMA, epilogue in
+// registers) instead of rocBLAS sgemm + the bias/ELU/LayerNorm kernel: the GEMM output never goes to HBM and back.
+// Workgroup = 128 rows x all 128 output columns (a LayerNorm row stays inside one workgroup), W (128 x K) staged once per
+// workgroup and reused over its grid-stride row tiles.  MFMA 16x16x4 with the k index permuted inside each 16-wide k block
+// (lane group kk supplies k = 16*kb + 4*kk + reg) so that ONE ds_read_b128 per operand row feeds four MFMAs.
+constexpr int FB_N = 128, FB_ROWS = 128, FB_SLD = FB_N + 4;
+__device__ __forceinline__ float row16_allsum(float v) {          // sum over the 16 lanes of a DPP row, in every lane
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));   // row_ror:2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
+  return v;
+}
+__global__ __launch_bounds__(256, 1) void fused_block_fwd128_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                                    const float* __restrict__ bias, const float* __restrict__ g,
+                                                                    const float* __restrict__ be, float* __restrict__ a_out,
+                                                                    float* __restrict__ y, float* __restrict__ stats,
+                                                                    int64_t B, int K) {
+  extern __shared__ __attribute__((aligned(16))) float fb_lds[];
+  const int KP = (K + 15) & ~15;                 // k padded to whole 16-blocks (zero filled)
+  const int LD = KP + 4;                         // row stride: 16-byte aligned, bank-rotated
+  float* Ws = fb_lds;                            // [128][LD]
+  float* Xs = fb_lds + FB_N * LD;                // [128][LD]
+  float* Stg = Xs;                               // [128][FB_SLD]  ELU outputs, row-major for coalesced stores: ALIASES the X tile
+  float* Sst = Xs + FB_ROWS * FB_SLD;            // [128][2]       row mean / rstd
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kk = lane >> 4;
+  // staging map: thread -> (row tid/32 + 8*pass, columns 4*(tid%32)..+3): no divisions, 16 independent loads in flight
+  const int lc4 = (tid & 31) * 4, lrow = tid >> 5;
+  const bool lcol_ok = lc4 < K, lcol_in = lc4 < KP;      // K % 4 == 0; columns K..KP-1 are zero padding
+  {
+    f4w wv[16];
+#pragma unroll
+    for (int ps = 0; ps < 16; ++ps) {
+      wv[ps] = f4w{0.f, 0.f, 0.f, 0.f};
+      if (lcol_ok) wv[ps] = *reinterpret_cast<const f4w*>(W + (int64_t)(lrow + 8 * ps) * K + lc4);
+    }
+#pragma unroll
+    for (int ps = 0; ps < 16; ++ps)
+      if (lcol_in) *reinterpret_cast<f4w*>(Ws + (lrow + 8 * ps) * LD + lc4) = wv[ps];
+  }
+  float bcol[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) bcol[t] = bias[16 * t + i];
+  const int64_t ntiles = (B + FB_ROWS - 1) / FB_ROWS;
+  // The kernel is HBM-bound (read X once, write a and y once: 192 KB per 128-row tile), so the next tile's rows are
+  // fetched into registers while this tile is multiplied and normalised.
+  f4w xv[16];
+  auto fetch_tile = [&](int64_t t) {
+    const int64_t rb = t * FB_ROWS;
+#pragma unroll
+    for (int ps = 0; ps < 16; ++ps) {
+      const int rr = lrow + 8 * ps;
+      xv[ps] = f4w{0.f, 0.f, 0.f, 0.f};
+      if (lcol_ok && t < ntiles && rb + rr < B) xv[ps] = *reinterpret_cast<const f4w*>(X + (rb + rr) * K + lc4);
+    }
+  };
+  fetch_tile(blockIdx.x);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t r0 = tile * FB_ROWS;
+    __syncthreads();                             // previous tile's output image has been read out (and Ws is staged)
+#pragma unroll
+    for (int ps = 0; ps < 16; ++ps)
+      if (lcol_in) *reinterpret_cast<f4w*>(Xs + (lrow + 8 * ps) * LD + lc4) = xv[ps];
+    __syncthreads();
+    fetch_tile(tile + gridDim.x);                // in flight during the MFMA loop and the epilogue
+    f4w acc[2][8];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[m][t] = f4w{0.f, 0.f, 0.f, 0.f};
+    const float* xa = Xs + (32 * wave + i) * LD + 4 * kk;
+    const float* wb = Ws + i * LD + 4 * kk;
+    for (int kb = 0; kb < KP / 16; ++kb) {
+      const f4w a0 = *reinterpret_cast<const f4w*>(xa + 16 * kb);
+      const f4w a1 = *reinterpret_cast<const f4w*>(xa + 16 * LD + 16 * kb);
+      f4w bt[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) bt[t] = *reinterpret_cast<const f4w*>(wb + 16 * t * LD + 16 * kb);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], bt[t][r], acc[0][t], 0, 0, 0);
+          acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[r], bt[t][r], acc[1][t], 0, 0, 0);
+        }
+    }
+    __syncthreads();                             // every wave is done with the X tile: its LDS becomes the output image
+    // epilogue: lane holds rows 4*kk + e (e = 0..3) of each 16-row tile m, columns 16*t + i.  The ELU outputs go through
+    // an LDS image of this wave's 32 rows so that HBM sees whole 512-byte rows (a and y), not 64-byte column slivers.
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int rl = 32 * wave + 16 * m + 4 * kk + e;
+        float v[8], sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          float z = acc[m][t][e] + bcol[t];
+          z = z > 0.f ? z : __expf(z) - 1.f;            // nn.ELU: exp(x) - 1 (abs error < 1e-7)
+          v[t] = z; sum += z;
+        }
+        const float mean = row16_allsum(sum) * (1.f / FB_N);
+        float q = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { const float d = v[t] - mean; q += d * d; }
+        const float rstd = 1.f / sqrtf(row16_allsum(q) * (1.f / FB_N) + LN_EPS);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) Stg[rl * FB_SLD + 16 * t + i] = v[t];
+        if (i == 0) { Sst[2 * rl] = mean; Sst[2 * rl + 1] = rstd; }
+      }
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS writes have landed (rows are wave-private)
+    {
+      const int c4 = (lane & 31) * 4;
+      const f4w g4 = *reinterpret_cast<const f4w*>(g + c4), be4 = *reinterpret_cast<const f4w*>(be + c4);
+#pragma unroll 4
+      for (int jj = 0; jj < 16; ++jj) {
+        const int rl = 32 * wave + 2 * jj + (lane >> 5);
+        const int64_t row = r0 + rl;
+        const f4w a4 = *reinterpret_cast<const f4w*>(Stg + rl * FB_SLD + c4);
+        const float mean = Sst[2 * rl], rstd = Sst[2 * rl + 1];
+        if (row < B) {
+          *reinterpret_cast<f4w*>(a_out + row * FB_N + c4) = a4;
+          *reinterpret_cast<f4w*>(y + row * FB_N + c4) = (a4 - mean) * rstd * g4 + be4;
+          if ((lane & 31) == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+        }
+      }
+    }
+  }
+}
+
 // grid (ceil(D/64), 3), 1024 threads = 64 columns x 16 strided slices of the block list, combined in a fixed order
 __global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ partial, int nblocks, int D, float* o0,
                                                              float* o1, float* o2) {
@@ -757,6 +887,23 @@ extern "C" int spo_ma_forward(const float* theta, const spo_ma_net* net, const f
   const float* in = ws + L.ws_xhat();
   for (int k = 0; k < L.NB; ++k) {
     float* a = ws + L.ws_a(B, k);
+    if (L.H == 128 && L.in_k(k) % 4 == 0 && L.in_k(k) <= 128 && B >= 32768) {
+      // one fused MFMA kernel (large batches: the training / evaluation passes; small collect batches keep rocBLAS)
+      const int K = L.in_k(k), KP = (K + 15) & ~15;
+      const size_t sh = ((size_t)128 * (KP + 4) + 128 * 132 + 256) * sizeof(float);       // W image + max(X tile, output image)
+      static bool attr_done = false;
+      if (!attr_done) {
+        if (int rc = spo::hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_block_fwd128_kernel),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (2 * 128 * 132 + 256) * 4),
+                                    "hipFuncSetAttribute(fused_block_fwd128)")) return rc;
+        attr_done = true;
+      }
+      const int64_t nt = (B + 127) / 128;
+      hipLaunchKernelGGL(fused_block_fwd128_kernel, dim3((unsigned)(nt < 256 ? nt : 256)), dim3(256), sh, st, in, theta + L.W(k),
+                         theta + L.b(k), theta + L.g(k), theta + L.be(k), a, ws + L.ws_y(B, k), ws + L.ws_st(B, k), B, K);
+      in = ws + L.ws_y(B, k);
+      continue;
+    }
     if (int rc = gemm_xwT(st, in, theta + L.W(k), a, B, L.in_k(k), L.H)) return rc;
     if (L.H == 128)
       hipLaunchKernelGGL(ln_fwd128_kernel<1>, dim3(gr), dim3(256), 0, st, a, theta + L.b(k), theta + L.g(k), theta + L.be(k), a,
