@@ -32,7 +32,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 GAE_BYTES_PER_ELEM = 33.0       # 4 f32 in + 1 u8 mask + 4 f32 out
-GAE_REPS = 20                   # back-to-back launches per timed epoch (event timing cannot resolve one ~10 us launch)
+GAE_REPS = 100                   # back-to-back launches per timed epoch (event timing cannot resolve one ~10 us launch)
 
 
 def cpu_baseline(sample_envs: int, T: int, threads: int = 4):
@@ -131,7 +131,7 @@ def main():
             out = {"stop_iter": pu["acceptance_step"], "kl": pu["kl"]}
         else:
             out = eng.update(lam)
-        if timed:   # GAE scan of THIS epoch's buffer: graph of GAE_REPS launches between HIP events (~0.1 ms)
+        if timed:   # GAE scan of THIS epoch's buffer: graph of GAE_REPS launches between HIP events (~0.5 ms)
             gae_events.append(eng.buffer.time_scan(GAE_REPS))
         torch.cuda.synchronize(dev)
         t2 = time.time()
@@ -180,7 +180,7 @@ def main():
     roofline = {"kernel": "gae_kernel<4,32> (spo_gae_fused)", "bound": "hbm", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "bytes_per_launch": gae_bytes, "avg_launch_us": round(gae_avg_s * 1e6, 2), "launches_timed": len(gae_ms) * GAE_REPS,
-                "note": "HIP events around a hipGraph of 20 back-to-back launches, once per timed epoch, inside the timed region "
+                "note": "HIP events around a hipGraph of 100 back-to-back launches, once per timed epoch, inside the timed region "
                         "(includes the ~1.5 us kernel boundary of each launch)"}
 
     # extra roofline point on a buffer that cannot sit in the 256 MiB Infinity Cache (untimed, after the run)

@@ -13,6 +13,7 @@
 // incoming carry so every element's final value is produced by the reference's own
 // `delta + disc*c` step.  delta is formed in fp32 with three separately rounded ops and gamma
 // rounded to fp32 (buffer.py:198); fp contraction is disabled for this file.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/safepo_hip.h"
 
@@ -78,35 +79,56 @@ __device__ __forceinline__ void store_vec(float* p, bool ok, const float (&o)[VE
 // path ends.  Removes a dependent memory round trip (seg_end -> boot) -- used when the buffer is
 // cache-resident and the launch is latency-bound; the predicated form moves fewer bytes and is
 // used for buffers that stream from HBM.
-template <int VEC, int LPR, bool EAGER_BOOT>
+// RC: the reward scan and the cost scan of a row run in DIFFERENT lane groups (group g of a wave: row g/2, quantity g%2)
+// instead of both in every lane.  Same instructions in total, but each wave's dependent chain (deltas, affine
+// composition, replay) is half as long and twice as many waves are in flight -- the 4096x128 launch is latency-bound.
+template <int VEC, int LPR, bool EAGER_BOOT, bool RC>
 __global__ __launch_bounds__(256) void gae_kernel(GaeArgs a) {
-  constexpr int ROWS_PER_WAVE = 64 / LPR;
+  static_assert(!RC || LPR <= 32, "RC needs two lane groups per wave");
+  constexpr int NK = RC ? 1 : 2;
+  constexpr int ROWS_PER_WAVE = RC ? 64 / LPR / 2 : 64 / LPR;
   constexpr int CHUNK = LPR * VEC;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int sub = lane / LPR;
+  const int grp_id = lane / LPR;
+  const int sub = RC ? grp_id / 2 : grp_id;                   // row within the wave
+  const int ksel = RC ? (grp_id & 1) : 0;                     // RC: 0 = reward scan, 1 = cost scan
   const int sl = lane % LPR;
   const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * ROWS_PER_WAVE + sub;
   const bool row_ok = row < a.N;
   const int64_t T = a.T;
   const int64_t rbase = row * T;
 
-  double carry_c[2] = {0.0, 0.0};       // c at the first element of the chunk to the right
-  float carry_v[2] = {0.f, 0.f};        // value at that element (v_{t+1} across the chunk edge)
+  double carry_c[NK];                   // c at the first element of the chunk to the right
+  float carry_v[NK];                    // value at that element (v_{t+1} across the chunk edge)
+#pragma unroll
+  for (int k = 0; k < NK; ++k) { carry_c[k] = 0.0; carry_v[k] = 0.f; }
   bool carry_any = false;               // a seg_end exists to the right of this chunk
   double s_r = 0.0, s_r2 = 0.0, s_c = 0.0;
-  const double disc[2] = {a.disc_r, a.disc_c};
+  double disc[NK];
+  const float* in_rw[NK]; const float* in_v[NK]; const float* in_boot[NK]; float* out_adv[NK]; float* out_tgt[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const bool cost_side = RC ? (ksel == 1) : (k == 1);
+    disc[k] = cost_side ? a.disc_c : a.disc_r;
+    in_rw[k] = cost_side ? a.cost : a.reward;
+    in_v[k] = cost_side ? a.value_c : a.value_r;
+    in_boot[k] = cost_side ? a.boot_c : a.boot_r;
+    out_adv[k] = cost_side ? a.adv_c : a.adv_r;
+    out_tgt[k] = cost_side ? a.target_c : a.target_r;
+  }
 
   const int nchunks = (int)((T + CHUNK - 1) / CHUNK);
   for (int ch = nchunks - 1; ch >= 0; --ch) {
     const int64_t t0 = (int64_t)ch * CHUNK + (int64_t)sl * VEC;
     // VEC==4 requires T%4==0, so a lane's elements are all valid or all invalid.
     const bool ok = row_ok && (t0 < T);
-    float rw[2][VEC], vv[2][VEC];
-    load_vec<VEC>(a.reward + rbase + t0, ok, rw[0]);
-    load_vec<VEC>(a.cost + rbase + t0, ok, rw[1]);
-    load_vec<VEC>(a.value_r + rbase + t0, ok, vv[0]);
-    load_vec<VEC>(a.value_c + rbase + t0, ok, vv[1]);
+    float rw[NK][VEC], vv[NK][VEC];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      load_vec<VEC>(in_rw[k] + rbase + t0, ok, rw[k]);
+      load_vec<VEC>(in_v[k] + rbase + t0, ok, vv[k]);
+    }
     bool seg[VEC];
     if constexpr (VEC == 4) {
       uchar4 s4 = ok ? *reinterpret_cast<const uchar4*>(a.seg_end + rbase + t0) : make_uchar4(0, 0, 0, 0);
@@ -117,29 +139,29 @@ __global__ __launch_bounds__(256) void gae_kernel(GaeArgs a) {
     bool lane_seg = false;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) lane_seg |= seg[e];
-    float bt[2][VEC];
+    float bt[NK][VEC];
     if (EAGER_BOOT) {
-      load_vec<VEC>(a.boot_r + rbase + t0, ok, bt[0]);
-      load_vec<VEC>(a.boot_c + rbase + t0, ok, bt[1]);
+#pragma unroll
+      for (int k = 0; k < NK; ++k) load_vec<VEC>(in_boot[k] + rbase + t0, ok, bt[k]);
     }
 
     // which lanes of my row hold a segment end (wave-wide ballot, then my row's slice)
     const unsigned long long ball = __ballot(lane_seg);
-    unsigned long long grp = (LPR == 64) ? ball : ((ball >> (sub * LPR)) & ((1ull << LPR) - 1ull));
+    unsigned long long grp = (LPR == 64) ? ball : ((ball >> (grp_id * LPR)) & ((1ull << LPR) - 1ull));
     const bool any_right_lane = (sl + 1 < LPR) ? ((grp >> (sl + 1)) != 0ull) : false;
 
     // v_{t+1} of my last element comes from the lane to the right (or the chunk carry)
-    float vnext_edge[2];
+    float vnext_edge[NK];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NK; ++k) {
       float nb = __shfl_down(vv[k][0], 1, LPR);
       vnext_edge[k] = (sl == LPR - 1) ? carry_v[k] : nb;
     }
 
-    double delta[2][VEC];
+    double delta[NK][VEC];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const float* boot = k == 0 ? a.boot_r : a.boot_c;
+    for (int k = 0; k < NK; ++k) {
+      const float* boot = in_boot[k];
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         float vn = (e == VEC - 1) ? vnext_edge[k] : vv[k][e + 1];
@@ -152,9 +174,9 @@ __global__ __launch_bounds__(256) void gae_kernel(GaeArgs a) {
     }
 
     // lane composite (A,B): c_first_of_lane = A*c_in + B
-    double A[2], B[2];
+    double A[NK], B[NK];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NK; ++k) {
       A[k] = 1.0; B[k] = 0.0;
       if (ok) {
 #pragma unroll
@@ -169,7 +191,7 @@ __global__ __launch_bounds__(256) void gae_kernel(GaeArgs a) {
 #pragma unroll
     for (int off = 1; off < LPR; off <<= 1) {
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
+      for (int k = 0; k < NK; ++k) {
         double An = shfl_down_d<LPR>(A[k], off);
         double Bn = shfl_down_d<LPR>(B[k], off);
         if (sl + off < LPR) {
@@ -179,19 +201,19 @@ __global__ __launch_bounds__(256) void gae_kernel(GaeArgs a) {
       }
     }
     // c entering my lane from the right = c_first(sl+1) evaluated with the chunk carry
-    double cin[2], cfirst[2];
+    double cin[NK], cfirst[NK];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NK; ++k) {
       cfirst[k] = __dadd_rn(__dmul_rn(A[k], carry_c[k]), B[k]);
       double nb = shfl_down_d<LPR>(cfirst[k], 1);
       cin[k] = (sl == LPR - 1) ? carry_c[k] : nb;
     }
 
     // replay in reference order and emit
-    float oadv[2][VEC], otgt[2][VEC];
+    float oadv[NK][VEC], otgt[NK][VEC];
     bool fin_right = any_right_lane || carry_any;            // a path end exists right of my lane
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NK; ++k) {
       double c = cin[k];
       bool fin = fin_right;
 #pragma unroll
@@ -204,22 +226,28 @@ __global__ __launch_bounds__(256) void gae_kernel(GaeArgs a) {
       }
     }
     const bool st_ok = ok && !(a.ablate & 4);
-    store_vec<VEC>(a.adv_r + rbase + t0, st_ok, oadv[0]);
-    store_vec<VEC>(a.adv_c + rbase + t0, st_ok, oadv[1]);
-    store_vec<VEC>(a.target_r + rbase + t0, st_ok, otgt[0]);
-    store_vec<VEC>(a.target_c + rbase + t0, st_ok, otgt[1]);
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      store_vec<VEC>(out_adv[k] + rbase + t0, st_ok, oadv[k]);
+      store_vec<VEC>(out_tgt[k] + rbase + t0, st_ok, otgt[k]);
+    }
     if (ok) {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        double x = (double)oadv[0][e];
-        s_r += x; s_r2 += x * x; s_c += (double)oadv[1][e];
+        if (RC) {
+          const double x = (double)oadv[0][e];
+          if (ksel == 0) { s_r += x; s_r2 += x * x; } else { s_c += x; }
+        } else {
+          const double x = (double)oadv[0][e];
+          s_r += x; s_r2 += x * x; s_c += (double)oadv[NK - 1][e];
+        }
       }
     }
     // carries for the chunk to the left: values at the first lane of my row group
     if (ch > 0) {                              // uniform: single-chunk rows (T <= LPR*VEC) never need the carries
-      const int src = sub * LPR;
+      const int src = grp_id * LPR;
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
+      for (int k = 0; k < NK; ++k) {
         carry_c[k] = __shfl(cfirst[k], src);
         carry_v[k] = __shfl(vv[k][0], src);
       }
@@ -303,22 +331,33 @@ __global__ __launch_bounds__(256) void adv_apply_kernel(float* adv_r, float* adv
 }
 
 int g_gae_force_variant = 0;    // 0 auto, 1 eager bootstrap loads, 2 predicated (debug/bench knob)
-struct GaeGeom { int vec; int lpr; int rows_per_block; };
-inline GaeGeom gae_geom(int64_t T) {
+struct GaeGeom { int vec; int lpr; int rows_per_block; bool rc; };
+inline bool gae_rc_enabled() {
+  static const int v = [] { const char* e = getenv("SPO_GAE_RC_SPLIT"); return e ? atoi(e) : 1; }();
+  return v != 0;
+}
+inline GaeGeom gae_geom(int64_t T, int64_t N) {
   GaeGeom g;
   g.vec = (T % 4 == 0) ? 4 : 1;
   int64_t need = (T + g.vec - 1) / g.vec;
   int lpr = 1;
   while (lpr < need && lpr < 64) lpr <<= 1;
   g.lpr = lpr;
-  g.rows_per_block = 4 * (64 / lpr);
+  // 128-step rows while the buffer is cache-resident and the launch latency-bound (measured on MI355X at 4096 x 128:
+  // 5.0-5.25 us against 5.2-5.65 us per launch); buffers that stream from HBM keep both scans in every lane
+  // (262 144 x 128: 235 us against 270 us).
+  g.rc = gae_rc_enabled() && g.vec == 4 && lpr == 32 && N * T <= ((int64_t)4 << 20);
+  g.rows_per_block = g.rc ? 4 : 4 * (64 / lpr);
   return g;
 }
 
 template <int VEC, bool EAGER>
 int launch_gae(const GaeGeom& g, const GaeArgs& a, int blocks, hipStream_t st) {
+  if (g.rc) {
+    if constexpr (VEC == 4) { hipLaunchKernelGGL((gae_kernel<4, 32, EAGER, true>), dim3(blocks), dim3(256), 0, st, a); return 0; }
+  }
   switch (g.lpr) {
-#define SPO_CASE(L) case L: hipLaunchKernelGGL((gae_kernel<VEC, L, EAGER>), dim3(blocks), dim3(256), 0, st, a); break;
+#define SPO_CASE(L) case L: hipLaunchKernelGGL((gae_kernel<VEC, L, EAGER, false>), dim3(blocks), dim3(256), 0, st, a); break;
     SPO_CASE(1) SPO_CASE(2) SPO_CASE(4) SPO_CASE(8) SPO_CASE(16) SPO_CASE(32) SPO_CASE(64)
 #undef SPO_CASE
     default: return spo::fail(-1, "gae: bad lanes-per-row %d", g.lpr);
@@ -330,7 +369,7 @@ int launch_gae(const GaeGeom& g, const GaeArgs& a, int blocks, hipStream_t st) {
 
 extern "C" int spo_gae_num_blocks(int64_t num_envs, int64_t T) {
   if (num_envs <= 0 || T <= 0) return 0;
-  GaeGeom g = gae_geom(T);
+  GaeGeom g = gae_geom(T, num_envs);
   return (int)((num_envs + g.rows_per_block - 1) / g.rows_per_block);
 }
 
@@ -342,7 +381,7 @@ extern "C" int spo_gae_fused(const float* reward, const float* cost, const float
   if (num_envs == 0 || T == 0) return 0;
   SPO_REQUIRE(reward && cost && value_r && value_c && seg_end && boot_r && boot_c && adv_r && adv_c && target_r &&
                   target_c && partials, "gae: null pointer");
-  GaeGeom g = gae_geom(T);
+  GaeGeom g = gae_geom(T, num_envs);
   GaeArgs a{reward, cost, value_r, value_c, seg_end, boot_r, boot_c, adv_r, adv_c, target_r, target_c, partials,
             num_envs, T, (float)gamma, gamma * lam, gamma * lam_c, g_gae_force_variant >> 4};
   const int blocks = spo_gae_num_blocks(num_envs, T);
