@@ -35,7 +35,9 @@ def test_every_declared_symbol_is_exported_and_bound(built_lib):
     # geometry helpers are host functions: 2*8129 + 8592 = 24850
     assert lib.spo_param_count(60, 8) == 24850
     assert [lib.spo_param_offset(60, 8, k) for k in range(3)] == [0, 8129, 16258]
-    assert lib.spo_gae_num_blocks(4096, 128) == 512
+    # 4 rows per block while the buffer is cache-resident (reward / cost scans in separate lane groups), 8 when it streams
+    assert lib.spo_gae_num_blocks(4096, 128) == 1024
+    assert lib.spo_gae_num_blocks(262144, 128) == 32768
 
 
 def test_argument_errors_without_gpu(built_lib):

@@ -386,7 +386,7 @@ def test_actor_kl_vs_oracle(dev):
 
 @pytest.mark.parametrize("n,steps", [(8, 32), (70, 20), (3, 130)])
 def test_collect_boundary_update_end_to_end(dev, n, steps):
-    from safepo.common.engine import smoke_check
+    from smoke_check import smoke_check
     smoke_check(num_envs=n, steps=steps, seed=n)
 
 
@@ -637,7 +637,8 @@ def test_limits_and_edge_shapes(dev):
     """Largest supported dims (obs 64 in the update kernels, act 16), single env / single step, and the
     loud failures outside the envelope."""
     from safepo import _abi
-    from safepo.common.engine import PPOLagEngine, smoke_check
+    from safepo.common.engine import PPOLagEngine
+    from smoke_check import smoke_check
     from safepo.common.model import ActorVCritic
     pol = ActorVCritic(64, 16).to(dev)
     M = 96
