@@ -26,7 +26,7 @@ import time
 t0 = time.time(); eng.learning_iter(perm); torch.cuda.synchronize(); dt = time.time() - t0
 lib.spo_debug_set_update_profile(None)
 names = ["fetch-issue+XT stage", "forward", "loss+backward dH", "stage writes+partials", "barrier1", "dW GEMMs",
-         "grads/L2/norm", "barrier+exchange", "Adam", "final barrier"]
+         "grads/L2/norm", "barrier + publish + speculative Adam", "granule wait + clip decision (+ redo)", "final barrier"]
 steps = N * T // 64
 p = prof.cpu().view(3, 10).numpy()
 print(f"instrumented launch: {dt*1e6/steps:.2f} us/step")
