@@ -183,25 +183,37 @@ def main():
                 "note": "HIP events around a hipGraph of 100 back-to-back launches, once per timed epoch, inside the timed region "
                         "(includes the ~1.5 us kernel boundary of each launch)"}
 
-    # extra roofline point on a buffer that cannot sit in the 256 MiB Infinity Cache (untimed, after the run)
-    stream = None
-    try:
+    # extra roofline points (untimed, after the run): 32 768 envs (138 MB) and a buffer that cannot sit in
+    # the 256 MiB Infinity Cache
+    def scan_point(Ns, reps):
         from safepo.common.buffer import VectorizedOnPolicyBuffer
         from safepo.common.engine import _Space
-        Ns = a.stream_envs
         big = VectorizedOnPolicyBuffer(_Space(1), _Space(1), size=T, num_envs=Ns, device=dev)
         for k in ("reward", "cost", "value_r", "value_c"):
             big.data[k].normal_()
         big.seg_end[:, T - 1] = 1
         big.seg_end[:, T // 2 - 1] = 1
         big.compute_gae(None)
-        t_s = big.time_scan(10)
+        t_s = big.time_scan(reps)
         b = GAE_BYTES_PER_ELEM * Ns * T + 8.0 * 2 * Ns
-        stream = {"num_envs": Ns, "bytes_per_launch": b, "avg_launch_us": round(t_s * 1e6, 1),
-                  "achieved": round(b / t_s / 1e9, 1), "unit": "GB/s", "frac": round(b / t_s / 1e9 / HBM_PEAK_GBS, 4)}
         del big
+        return {"num_envs": Ns, "bytes_per_launch": b, "avg_launch_us": round(t_s * 1e6, 1),
+                "achieved": round(b / t_s / 1e9, 1), "unit": "GB/s", "frac": round(b / t_s / 1e9 / HBM_PEAK_GBS, 4)}
+    stream, mid = None, None
+    try:
+        mid = scan_point(32768, 20)
+        stream = scan_point(a.stream_envs, 10)
     except Exception as e:  # pragma: no cover
         stream = {"error": str(e)[:200]}
+
+    # the reference-faithful epoch (KL early stopping at default_cfg's target_kl = 0.02), untimed extra
+    faithful = None
+    if world == 1 and a.algo == "ppo_lag":
+        cfg["target_kl"] = 0.02
+        r_f, u_f, out_f, _ = epoch(False)
+        cfg["target_kl"] = float("inf")
+        faithful = {"target_kl": 0.02, "stop_iter": out_f["stop_iter"], "kl": out_f["kl"], "s_per_epoch": round(r_f + u_f, 4),
+                    "env_steps_per_s": round(N * T / (r_f + u_f), 1)}
 
     cpu = None
     if world == 1 and not a.no_cpu_baseline and a.algo == "ppo_lag":
@@ -224,7 +236,9 @@ def main():
                    if world > 1 else "single GPU",
                    "minibatch_steps_per_epoch": n_mb * a.learning_iters},
         "roofline": roofline,
+        "roofline_32768_envs": mid,
         "roofline_hbm_streaming": stream,
+        "early_stopping_epoch": faithful,
         # the kernel that owns 99 % of the GPU time is not HBM- but latency/matrix-bound: 327 680 strictly sequential
         # optimiser steps, each at least 368 v_mfma_f32_16x16x4_f32 (32 cycles each) per wave on one CU per network
         "update_kernel": ({"kernel": "ppo_update_kernel<64, persistent>", "bound": "fp32 MFMA issue of one CU per network + per-step latency chain",
