@@ -162,8 +162,9 @@ class OracleMATrainer:
         rec["cost_grad"] = self.cost_critic.flat_grad().clone()
         c_norm = nn.utils.clip_grad_norm_(self.cost_critic.ordered_parameters(), c["max_grad_norm"])
         self.opt_c.step()
-        rec["row"] = [float(vl), float(r_norm), float(policy_loss), float(dist_entropy), float(a_norm), float(imp.mean()),
-                      float(cl), float(c_norm), float(self.lamda), float(self.popart.running_mean),
+        f = lambda t: float(t.detach()) if torch.is_tensor(t) else float(t)
+        rec["row"] = [f(vl), f(r_norm), f(policy_loss), f(dist_entropy), f(a_norm), f(imp.mean()),
+                      f(cl), f(c_norm), f(self.lamda), float(self.popart.running_mean),
                       float(self.popart.running_mean_sq), float(self.popart.debiasing_term)]
         return rec
 
@@ -191,3 +192,75 @@ def sample_from_golden(z, tag: str) -> dict:
     keys = ["share_obs", "obs", "actions", "value_preds", "returns", "active_masks", "old_logp", "adv", "factor", "cost_preds",
             "cost_returns", "cost_adv", "aver_episode_costs"]
     return {k: torch.from_numpy(z[f"{tag}_{k}"].copy()) for k in keys}
+
+
+# ---------------------------------------------------------------------- Runner level (mappolag.py:475-504, 587-603)
+def masked_gae(rewards, value_preds, masks, popart: OraclePopArt, gamma: float, lam: float):
+    """SeparatedReplayBuffer.compute_returns with use_gae and PopArt (safepo/common/buffer.py:356-377): value_preds[-1]
+    is the bootstrap value, fp32 tensor arithmetic in the reference's order."""
+    T = rewards.shape[0]
+    returns = torch.zeros_like(value_preds)
+    gae = 0
+    for step in reversed(range(T)):
+        v_next, v_cur = popart.denormalize(value_preds[step + 1]), popart.denormalize(value_preds[step])
+        delta = rewards[step] + gamma * v_next * masks[step + 1] - v_cur
+        gae = delta + gamma * lam * masks[step + 1] * gae
+        returns[step] = gae + v_cur
+    return returns
+
+
+def feed_forward_samples(buf: dict, advantages, cost_adv, perm, num_mini_batch: int):
+    """feed_forward_generator (buffer.py:386-465) with the permutation supplied."""
+    T, N = buf["rewards"].shape[0:2]
+    mb = (T * N) // num_mini_batch
+    flat = lambda t: t.reshape(-1, *t.shape[2:])
+    cols = {"share_obs": flat(buf["share_obs"][:-1]), "obs": flat(buf["obs"][:-1]), "actions": flat(buf["actions"]),
+            "value_preds": buf["value_preds"][:-1].reshape(-1, 1), "returns": buf["returns"][:-1].reshape(-1, 1),
+            "active_masks": buf["active_masks"][:-1].reshape(-1, 1), "old_logp": flat(buf["action_log_probs"]),
+            "adv": advantages.reshape(-1, 1), "factor": buf["factor"].reshape(-1, 1),
+            "cost_preds": buf["cost_preds"][:-1].reshape(-1, 1), "cost_returns": buf["cost_returns"][:-1].reshape(-1, 1),
+            "cost_adv": cost_adv.reshape(-1, 1)}
+    perm = torch.as_tensor(perm, dtype=torch.long)
+    for i in range(num_mini_batch):
+        idx = perm[i * mb:(i + 1) * mb]
+        s = {k: v[idx] for k, v in cols.items()}
+        s["aver_episode_costs"] = buf["aver_episode_costs"]
+        yield s
+
+
+def train_agent(tr: OracleMATrainer, buf: dict, perms, cfg: dict):
+    """MAPPO_L_Trainer.train (mappolag.py:201-236): NaN-masked torch.mean / torch.std standardisation of both advantages,
+    then learning_iters passes of num_mini_batch ppo_update steps.  Returns the rows the reference stores per pass."""
+    def standardised(returns, preds):
+        adv = returns[:-1] - tr.popart.denormalize(preds[:-1])
+        cp = adv.clone()
+        cp[buf["active_masks"][:-1] == 0.0] = float("nan")
+        return (adv - torch.mean(cp)) / (torch.std(cp) + 1e-8)
+    advantages = standardised(buf["returns"], buf["value_preds"])
+    cost_adv = standardised(buf["cost_returns"], buf["cost_preds"])
+    rows = []
+    for it in range(int(cfg["learning_iters"])):
+        rec = None
+        for s in feed_forward_samples(buf, advantages, cost_adv, perms[it], int(cfg["num_mini_batch"])):
+            rec = tr.ppo_update(s)
+        rows.append(rec["row"])
+    return rows
+
+
+def runner_train(trainers, bufs, order, perms_of, cfg: dict):
+    """Runner.train (mappolag.py:475-504): agents in `order`, each with the running product of the previous agents'
+    probability ratios as its factor."""
+    T, N = bufs[0]["rewards"].shape[0:2]
+    factor = torch.ones(T, N, 1)
+    stored = []
+    for a in order:
+        b, tr = bufs[a], trainers[a]
+        b["factor"] = factor.clone()
+        obs, act = b["obs"][:-1].reshape(T * N, -1), b["actions"].reshape(T * N, -1)
+        with torch.no_grad():
+            old = log_probs(tr.actor(obs), tr.actor.std(), act)
+        stored += train_agent(tr, b, perms_of[a], cfg)
+        with torch.no_grad():
+            new = log_probs(tr.actor(obs), tr.actor.std(), act)
+        factor = factor * torch.prod(torch.exp(new - old).reshape(T, N, -1), dim=-1, keepdim=True)
+    return stored
