@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--num-steps", type=int, default=128)
     ap.add_argument("--learning-iters", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-envs", type=int, default=32)
+    ap.add_argument("--cpu-sample-envs", type=int, default=96)   # ~15 s of CPU work on the GPU box host
     ap.add_argument("--stream-envs", type=int, default=262144, help="extra GAE roofline point that streams from HBM")
     ap.add_argument("--algo", choices=["ppo_lag", "cpo"], default="ppo_lag",
                     help="cpo = BASELINE config 3 (not the headline metric; single GPU)")
