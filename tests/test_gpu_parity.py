@@ -1342,3 +1342,42 @@ def test_cpo_data_parallel_two_ranks_one_gpu(dev, tmp_path):
     for k in ("xHx", "gradient_norm", "H_inv_g", "alpha", "final_step_norm", "kl"):
         assert res[k][0] == pytest.approx(res[k][1], rel=2e-3), (k, res)
     assert res["actor_frac_outside"] <= 2e-3 and res["actor_max_abs_diff"] < 1e-3, res
+
+
+def test_full_size_learning_iteration_is_deterministic(dev):
+    """BASELINE config 2 size (4096 envs x 128 steps = 524 288 rows, 8192 minibatch steps in ONE persistent launch):
+    size-independent properties -- two runs from the same state with the same shuffle are bit-identical (fixed-order
+    reductions, tagged granule exchange, no atomics on data), every parameter stays finite and moves, the per-step losses
+    are finite, and the optimiser step count advances by the number of minibatches."""
+    from safepo.common.engine import PPOLagEngine
+    from safepo.common.model import ActorVCritic
+    N, T, D, A = 4096, 128, 60, 8
+    M = N * T
+    cfg = {"hidden_sizes": [64, 64], "gamma": 0.99, "target_kl": 1e9, "batch_size": 64, "learning_iters": 1, "max_grad_norm": 40.0}
+    g = torch.Generator(device=dev).manual_seed(123)
+    obs = torch.randn(N, T, D, device=dev, generator=g)
+    act = torch.randn(N, T, A, device=dev, generator=g)
+    logp = -A * 0.92 - 0.5 * (act ** 2).sum(-1) + 0.05 * torch.randn(N, T, device=dev, generator=g)
+    tgt_r, tgt_c = torch.randn(N, T, device=dev, generator=g), torch.rand(N, T, device=dev, generator=g)
+    adv = torch.randn(N, T, device=dev, generator=g)
+    perm = torch.randperm(M, device=dev, generator=g).to(torch.int32)
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(9)
+        pol = ActorVCritic(D, A).to(dev)
+        theta0 = pol.theta.clone()
+        eng = PPOLagEngine(pol, N, T, cfg, dev)
+        b = eng.buffer
+        b.data["obs"].copy_(obs); b.data["act"].copy_(act); b.data["log_prob"].copy_(logp)
+        b.data["target_value_r"].copy_(tgt_r); b.data["target_value_c"].copy_(tgt_c); b.adv_mix.copy_(adv)
+        losses = eng.learning_iter(perm)
+        eng.check_sync_error()
+        outs.append((pol.theta.clone(), losses.clone(), eng.adam_step, eng.adam_m.clone(), eng.adam_v.clone()))
+    assert outs[0][2] == outs[1][2] == M // 64
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][3], outs[1][3]) and torch.equal(outs[0][4], outs[1][4])
+    assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
+    assert outs[0][1].shape == (M // 64, 3)
+    moved = (outs[0][0] - theta0).abs()
+    assert float(moved.max()) > 1e-3 and float((moved > 0).float().mean()) > 0.99
+    assert float(outs[0][4].min()) >= 0.0                      # second moments
