@@ -349,6 +349,13 @@ __device__ __forceinline__ float half_wave_sum(float v) {
   for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+__device__ __forceinline__ float row16_allsum_fwd(float v) {      // sum over the 16 lanes of a DPP row, in every lane
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));   // row_ror:2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
+  return v;
+}
 template <int MODE>
 __global__ __launch_bounds__(256) void ln_fwd128_kernel(const float* __restrict__ x, const float* __restrict__ bias,
                                                          const float* __restrict__ g, const float* __restrict__ b,
@@ -421,6 +428,38 @@ __global__ __launch_bounds__(256) void ln_bwd128_kernel(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < 8; ++k) s += sh[w][k][jcol];
     partial[((int64_t)blockIdx.x * 3 + w) * D + jcol] = s;
+  }
+}
+
+// ---- input LayerNorm (feature_norm) for narrow observations (dim <= 128, multiple of 4): float4 per lane, LPR lanes per
+// row (16 for dim <= 64, 32 for dim <= 128), 64/LPR rows per wave; the generic kernel spends one wave on a 48-wide row.
+template <int LPR>
+__device__ __forceinline__ float group_allsum(float v) {
+  if (LPR == 32) v += __shfl_xor(v, 16, 64);
+  return row16_allsum_fwd(v);
+}
+template <int LPR>
+__global__ __launch_bounds__(256) void ln_fwd_narrow_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                            const float* __restrict__ b, float* __restrict__ y,
+                                                            float* __restrict__ stats, int64_t B, int D) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / LPR, c = (lane % LPR) * 4;
+  const bool col_ok = c < D;
+  f4w gg = {0.f, 0.f, 0.f, 0.f}, bb = gg;
+  if (col_ok) { gg = *reinterpret_cast<const f4w*>(g + c); bb = *reinterpret_cast<const f4w*>(b + c); }
+  const float inv_d = 1.f / (float)D;
+  for (int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * RPW; r0 < B; r0 += (int64_t)gridDim.x * 4 * RPW) {
+    const int64_t row = r0 + sub;
+    const bool ok = row < B && col_ok;
+    f4w v = {0.f, 0.f, 0.f, 0.f};
+    if (ok) v = *reinterpret_cast<const f4w*>(x + row * D + c);
+    const float mean = group_allsum<LPR>((v[0] + v[1]) + (v[2] + v[3])) * inv_d;
+    f4w d = v - mean;
+    if (!col_ok) d = f4w{0.f, 0.f, 0.f, 0.f};
+    const float var = group_allsum<LPR>((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * inv_d;
+    const float rstd = 1.f / sqrtf(var + LN_EPS);
+    if (ok) *reinterpret_cast<f4w*>(y + row * D + c) = d * rstd * gg + bb;
+    if (row < B && (lane % LPR) == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
   }
 }
 
@@ -907,8 +946,16 @@ extern "C" int spo_ma_forward(const float* theta, const spo_ma_net* net, const f
   hipStream_t st = (hipStream_t)stream;
   const int64_t B = rows;
   const int gr = grid_rows(B);
-  hipLaunchKernelGGL(ln_fwd_kernel<0>, dim3(gr), dim3(256), 0, st, x, nullptr, theta + L.fn_g(), theta + L.fn_b(), nullptr,
-                     ws + L.ws_xhat(), ws + L.ws_st0(B), B, L.D);
+  const bool x_vec = (L.D % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+  if (x_vec && L.D <= 64)
+    hipLaunchKernelGGL(ln_fwd_narrow_kernel<16>, dim3(gr), dim3(256), 0, st, x, theta + L.fn_g(), theta + L.fn_b(),
+                       ws + L.ws_xhat(), ws + L.ws_st0(B), B, L.D);
+  else if (x_vec && L.D <= 128)
+    hipLaunchKernelGGL(ln_fwd_narrow_kernel<32>, dim3(gr), dim3(256), 0, st, x, theta + L.fn_g(), theta + L.fn_b(),
+                       ws + L.ws_xhat(), ws + L.ws_st0(B), B, L.D);
+  else
+    hipLaunchKernelGGL(ln_fwd_kernel<0>, dim3(gr), dim3(256), 0, st, x, nullptr, theta + L.fn_g(), theta + L.fn_b(), nullptr,
+                       ws + L.ws_xhat(), ws + L.ws_st0(B), B, L.D);
   const float* in = ws + L.ws_xhat();
   for (int k = 0; k < L.NB; ++k) {
     float* a = ws + L.ws_a(B, k);
