@@ -593,6 +593,144 @@ __global__ __launch_bounds__(256, 1) void fused_block_fwd128_kernel(const float*
   }
 }
 
+// ---- fused block backward for hidden 128: from dz_k (gradient at block k's pre-activation) straight to dz_{k-1}:
+//   dY = dz_k * W_k                              (the dX GEMM, fp32 MFMA)
+//   dz_{k-1} = LayerNorm'(dY; a_{k-1}, stats_{k-1}, gamma_{k-1}) * ELU'(a_{k-1})          (epilogue in registers)
+// plus the per-workgroup column partials of block k-1's {ln weight, ln bias, linear bias} gradients, in the layout
+// colsum_finish_kernel reads.  Replaces rocBLAS sgemm (285 us) + ln_bwd128_kernel (142 us): dY never goes to HBM.
+// 64-row tiles; W_k is staged TRANSPOSED once per workgroup so the B operand reads 4 consecutive k per lane (b128).
+constexpr int FBW_ROWS = 64;
+__global__ __launch_bounds__(256, 1) void fused_dx_lnbwd128_kernel(const float* __restrict__ dz, const float* __restrict__ W,
+                                                                   const float* __restrict__ a_prev, const float* __restrict__ stats_prev,
+                                                                   const float* __restrict__ g_prev, float* __restrict__ dz_out,
+                                                                   float* __restrict__ partial, int64_t B) {
+  extern __shared__ __attribute__((aligned(16))) float fb_lds[];
+  constexpr int LD = FB_N + 4;
+  float* WsT = fb_lds;                           // [128 c][LD]  W^T: WsT[c][n] = W[n][c]
+  float* Ds = WsT + FB_N * LD;                   // [64][LD]     dz tile
+  float* As = Ds + FBW_ROWS * LD;                // [64][LD]     a_{k-1} tile, overwritten in place by dz_{k-1}
+  float* Sst = As + FBW_ROWS * LD;               // [64][2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kk = lane >> 4;
+  const int lc4 = (tid & 31) * 4, lrow = tid >> 5;
+  {
+    f4w wv[16];
+#pragma unroll
+    for (int ps = 0; ps < 16; ++ps) wv[ps] = *reinterpret_cast<const f4w*>(W + (int64_t)(lrow + 8 * ps) * FB_N + lc4);
+#pragma unroll
+    for (int ps = 0; ps < 16; ++ps)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) WsT[(lc4 + e) * LD + lrow + 8 * ps] = wv[ps][e];
+  }
+  float gcol[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) gcol[t] = g_prev[16 * t + i];
+  float cg[8], cb[8], cz[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) cg[t] = cb[t] = cz[t] = 0.f;
+  const int64_t ntiles = (B + FBW_ROWS - 1) / FBW_ROWS;
+  f4w pd[8], pa[8];
+  auto fetch_tile = [&](int64_t t) {
+    const int64_t rb = t * FBW_ROWS;
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+      const int64_t r = rb + lrow + 8 * ps;
+      pd[ps] = pa[ps] = f4w{0.f, 0.f, 0.f, 0.f};
+      if (t < ntiles && r < B) {
+        pd[ps] = *reinterpret_cast<const f4w*>(dz + r * FB_N + lc4);
+        pa[ps] = *reinterpret_cast<const f4w*>(a_prev + r * FB_N + lc4);
+      }
+    }
+  };
+  fetch_tile(blockIdx.x);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t r0 = tile * FBW_ROWS;
+    __syncthreads();                             // the previous tile's output image has been read out (and WsT is staged)
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+      *reinterpret_cast<f4w*>(Ds + (lrow + 8 * ps) * LD + lc4) = pd[ps];
+      *reinterpret_cast<f4w*>(As + (lrow + 8 * ps) * LD + lc4) = pa[ps];
+    }
+    if (tid < FBW_ROWS) {
+      const int64_t r = r0 + tid;
+      Sst[2 * tid] = r < B ? stats_prev[2 * r] : 0.f;
+      Sst[2 * tid + 1] = r < B ? stats_prev[2 * r + 1] : 0.f;
+    }
+    __syncthreads();
+    fetch_tile(tile + gridDim.x);                // in flight during the MFMA loop and the epilogue
+    f4w acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = f4w{0.f, 0.f, 0.f, 0.f};
+    const float* da = Ds + (16 * wave + i) * LD + 4 * kk;
+    const float* wb = WsT + i * LD + 4 * kk;
+#pragma unroll 2
+    for (int kb = 0; kb < FB_N / 16; ++kb) {
+      const f4w a0 = *reinterpret_cast<const f4w*>(da + 16 * kb);
+      f4w bt[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) bt[t] = *reinterpret_cast<const f4w*>(wb + 16 * t * LD + 16 * kb);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], bt[t][r], acc[t], 0, 0, 0);
+    }
+    // epilogue: lane holds dY rows 16*wave + 4*kk + e, columns 16*t + i; rows are wave-private in As
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int rl = 16 * wave + 4 * kk + e;
+      const bool rok = r0 + rl < B;
+      const float mean = Sst[2 * rl], rstd = Sst[2 * rl + 1];
+      float av[8], xh[8], dxh[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        av[t] = As[rl * LD + 16 * t + i];
+        xh[t] = (av[t] - mean) * rstd;
+        const float d = rok ? acc[t][e] : 0.f;
+        dxh[t] = d * gcol[t];
+        cg[t] += d * xh[t]; cb[t] += d;
+        s1 += dxh[t]; s2 += dxh[t] * xh[t];
+      }
+      const float m1 = row16_allsum(s1) * (1.f / FB_N), m2 = row16_allsum(s2) * (1.f / FB_N);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        float v = (dxh[t] - m1 - xh[t] * m2) * rstd;
+        v *= av[t] > 0.f ? 1.f : av[t] + 1.f;
+        v = rok ? v : 0.f;
+        cz[t] += v;
+        As[rl * LD + 16 * t + i] = v;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's rows of the output image are in LDS
+    {
+      const int c4 = (lane & 31) * 4;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int rl = 16 * wave + 2 * jj + (lane >> 5);
+        const int64_t row = r0 + rl;
+        const f4w v4 = *reinterpret_cast<const f4w*>(As + rl * LD + c4);
+        if (row < B) *reinterpret_cast<f4w*>(dz_out + row * FB_N + c4) = v4;
+      }
+    }
+  }
+  // column partials: 16 (wave, kk) slots per column, summed in a fixed order
+  __syncthreads();
+  float* sh = Ds;                                 // [3][16][128] floats = 24.6 KB, the dz tile is dead
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int slot = 4 * wave + kk, col = 16 * t + i;
+    sh[(0 * 16 + slot) * FB_N + col] = cg[t];
+    sh[(1 * 16 + slot) * FB_N + col] = cb[t];
+    sh[(2 * 16 + slot) * FB_N + col] = cz[t];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 3 * FB_N; idx += 256) {
+    const int w = idx / FB_N, col = idx % FB_N;
+    float sacc = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) sacc += sh[(w * 16 + sl) * FB_N + col];
+    partial[((int64_t)blockIdx.x * 3 + w) * FB_N + col] = sacc;
+  }
+}
+
 // grid (ceil(D/64), 3), 1024 threads = 64 columns x 16 strided slices of the block list, combined in a fixed order
 __global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ partial, int nblocks, int D, float* o0,
                                                              float* o1, float* o2) {
@@ -1027,19 +1165,54 @@ extern "C" int spo_ma_backward(const float* theta, const spo_ma_net* net, const 
     hipLaunchKernelGGL(colsum_small_finish_kernel, dim3(1), dim3(64), 0, st, partial, L.O, ns, grad + L.hb());
   }
   if (int rc = gemm_dyw(st, dout, theta + L.hW(), d0, B, L.H, L.O)) return rc;
-  for (int k = L.NB - 1; k >= 0; --k) {
+  // dz of the top block from the head's dX; below it, for hidden 128 at large batch, one fused kernel per block turns
+  // dz_k into dz_{k-1} (dX GEMM + LayerNorm/ELU backward + column partials), otherwise rocBLAS + the LayerNorm kernel.
+  const bool fuse_bwd = (L.H == 128) && (B >= 32768);
+  float* dzc = d1;                     // dz of the current block
+  float* other = d0;                   // free buffer (holds dY of the current block until its LayerNorm backward ran)
+  int nparts = gr;
+  {
+    const int k = L.NB - 1;
     if (L.H == 128)
       hipLaunchKernelGGL(ln_bwd128_kernel<1>, dim3(gr), dim3(256), 0, st, d0, ws + L.ws_a(B, k), ws + L.ws_st(B, k), theta + L.g(k),
                          d1, partial, B);
     else
       hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(gr), dim3(256), 0, st, d0, ws + L.ws_a(B, k), ws + L.ws_st(B, k), theta + L.g(k),
                          d1, partial, B, L.H);
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((L.H + 63) / 64, 3), dim3(1024), 0, st, partial, gr, L.H, grad + L.g(k),
+  }
+  for (int k = L.NB - 1; k >= 0; --k) {
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((L.H + 63) / 64, 3), dim3(1024), 0, st, partial, nparts, L.H, grad + L.g(k),
                        grad + L.be(k), grad + L.b(k));
     const float* in = k == 0 ? ws + L.ws_xhat() : ws + L.ws_y(B, k - 1);
-    if (int rc = gemm_dyTx(st, d1, in, grad + L.W(k), B, L.in_k(k), L.H, slices)) return rc;
-    if (int rc = gemm_dyw(st, d1, theta + L.W(k), d0, B, L.in_k(k), L.H)) return rc;
+    if (int rc = gemm_dyTx(st, dzc, in, grad + L.W(k), B, L.in_k(k), L.H, slices)) return rc;
+    if (k >= 1 && fuse_bwd) {
+      const size_t sh = ((size_t)128 * 132 + 2 * 64 * 132 + 128) * sizeof(float);
+      static bool attr_done = false;
+      if (!attr_done) {
+        if (int rc = spo::hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dx_lnbwd128_kernel),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh),
+                                    "hipFuncSetAttribute(fused_dx_lnbwd128)")) return rc;
+        attr_done = true;
+      }
+      const int64_t nt = (B + FBW_ROWS - 1) / FBW_ROWS;
+      nparts = (int)(nt < 256 ? nt : 256);
+      hipLaunchKernelGGL(fused_dx_lnbwd128_kernel, dim3(nparts), dim3(256), sh, st, dzc, theta + L.W(k), ws + L.ws_a(B, k - 1),
+                         ws + L.ws_st(B, k - 1), theta + L.g(k - 1), other, partial, B);
+      float* t = dzc; dzc = other; other = t;
+    } else {
+      if (int rc = gemm_dyw(st, dzc, theta + L.W(k), other, B, L.in_k(k), L.H)) return rc;      // dY of block k-1 (or d xhat)
+      if (k >= 1) {
+        nparts = gr;
+        if (L.H == 128)
+          hipLaunchKernelGGL(ln_bwd128_kernel<1>, dim3(gr), dim3(256), 0, st, other, ws + L.ws_a(B, k - 1), ws + L.ws_st(B, k - 1),
+                             theta + L.g(k - 1), dzc, partial, B);
+        else
+          hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(gr), dim3(256), 0, st, other, ws + L.ws_a(B, k - 1), ws + L.ws_st(B, k - 1),
+                             theta + L.g(k - 1), dzc, partial, B, L.H);
+      }
+    }
   }
+  d0 = other;                          // d xhat: gradient at the normalised observation
   // feature_norm parameters (the observation itself needs no gradient)
   hipLaunchKernelGGL(ln_bwd_kernel<0>, dim3(gr), dim3(256), 0, st, d0, x, ws + L.ws_st0(B), theta + L.fn_g(), nullptr, partial, B, L.D);
   hipLaunchKernelGGL(colsum_finish_kernel, dim3((L.D + 63) / 64, 3), dim3(1024), 0, st, partial, gr, L.D, grad + L.fn_g(),
