@@ -209,7 +209,9 @@ class SeparatedReplayBuffer:
             assert batch_size >= num_mini_batch, (N, T, num_mini_batch)
             mini_batch_size = batch_size // num_mini_batch
         # the shuffle is drawn on the device (a 524 288-element CPU randperm costs ~10 ms per learning iteration)
-        rand = torch.randperm(batch_size, device=self.device) if perm is None else torch.as_tensor(perm).to(self.device)
+        one_batch = perm is None and (mini_batch_size == batch_size)
+        rand = (torch.arange(1, device=self.device) if one_batch else torch.randperm(batch_size, device=self.device)) \
+            if perm is None else torch.as_tensor(perm).to(self.device)
         flat = lambda t: t.reshape(-1, *t.shape[2:])
         share_obs, obs = flat(self.share_obs[:-1]), flat(self.obs[:-1])
         rnn, rnn_c, rnn_k = flat(self.rnn_states[:-1]), flat(self.rnn_states_critic[:-1]), flat(self.rnn_states_cost[:-1])
@@ -220,9 +222,13 @@ class SeparatedReplayBuffer:
         factor = self.factor.reshape(-1, self.factor.shape[-1])
         advantages = advantages.reshape(-1, 1)
         cost_adv = cost_adv.reshape(-1, 1) if cost_adv is not None else None
+        # One minibatch = the whole buffer (the reference default): every loss is a mean over all rows, so the shuffle only
+        # changes the summation order.  Without a caller-supplied permutation the rows are handed over in place -- no
+        # 0.5 GB gather per learning iteration.
+        whole = perm is None and mini_batch_size == batch_size
         for i in range(num_mini_batch if num_mini_batch is not None else batch_size // mini_batch_size):
             idx = rand[i * mini_batch_size:(i + 1) * mini_batch_size]
-            g = lambda t: t.index_select(0, idx)
+            g = (lambda t: t) if whole else (lambda t: t.index_select(0, idx))
             yield (g(share_obs), g(obs), g(rnn), g(rnn_c), g(actions), g(value_preds), g(returns), g(masks), g(active),
                    g(logp), g(advantages), None, g(factor), g(cost_preds), g(cost_returns), g(rnn_k),
                    g(cost_adv) if cost_adv is not None else None, self.aver_episode_costs)
