@@ -223,7 +223,10 @@ struct Lay {
   int64_t ws_a(int64_t B, int k) const { return ws_blk(B, k); }
   int64_t ws_st(int64_t B, int k) const { return ws_blk(B, k) + al4(B * H); }
   int64_t ws_y(int64_t B, int k) const { return ws_blk(B, k) + al4(B * H) + al4(2 * B); }
-  int64_t ws_count(int64_t B) const { return ws_blk(B, NB); }
+  // block 0's weights with the input LayerNorm's affine folded in: W'[n][c] = W_0[n][c] * gamma[c], b'[n] = b_0[n] + W_0[n] . beta
+  int64_t ws_w0f(int64_t B) const { return ws_blk(B, NB); }
+  int64_t ws_b0f(int64_t B) const { return ws_w0f(B) + al4((int64_t)H * D); }
+  int64_t ws_count(int64_t B) const { return ws_b0f(B) + al4(H); }
 };
 
 int lay_of(const spo_ma_net* n, Lay* L) {
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) {
       const int j = lane + 64 * e;
-      if (j < D) y[row * D + j] = (v[e] - mean) * rstd * g[j] + b[j];
+      if (j < D) y[row * D + j] = (MODE == 0) ? (v[e] - mean) * rstd : (v[e] - mean) * rstd * g[j] + b[j];   // MODE 0: xn, affine folded into W_0
     }
     if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
   }
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(256) void ln_fwd_narrow_kernel(const float* __restr
     if (!col_ok) d = f4w{0.f, 0.f, 0.f, 0.f};
     const float var = group_allsum<LPR>((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * inv_d;
     const float rstd = 1.f / sqrtf(var + LN_EPS);
-    if (ok) *reinterpret_cast<f4w*>(y + row * D + c) = d * rstd * gg + bb;
+    if (ok) *reinterpret_cast<f4w*>(y + row * D + c) = d * rstd;          // pre-affine: gamma / beta are folded into W_0
     if (row < B && (lane % LPR) == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
   }
 }
@@ -729,6 +732,40 @@ __global__ __launch_bounds__(256, 1) void fused_dx_lnbwd128_kernel(const float* 
     for (int sl = 0; sl < 16; ++sl) sacc += sh[(w * 16 + sl) * FB_N + col];
     partial[((int64_t)blockIdx.x * 3 + w) * FB_N + col] = sacc;
   }
+}
+
+// The input LayerNorm's affine is folded into block 0:  (gamma o xn + beta) W_0^T + b_0 = xn (W_0 diag(gamma))^T + (b_0 + W_0 beta),
+// so the network runs on xn (pre-affine) with W' = W_0 diag(gamma), b' = b_0 + W_0 beta (one tiny kernel per forward), and the
+// backward never forms d(xn) = dz_0 W' over all rows (a B x H x D GEMM plus a B x D pass, whose only use was two D-vectors):
+//   with dW' = dz_0^T xn (the weight-gradient GEMM that runs anyway) and db_0 = column sums of dz_0,
+//   d(gamma)[c] = sum_n W_0[n][c] dW'[n][c],   d(beta)[c] = sum_n db_0[n] W_0[n][c],
+//   dW_0[n][c]  = gamma[c] dW'[n][c] + beta[c] db_0[n].
+__global__ void fn_fold_kernel(const float* __restrict__ W0, const float* __restrict__ b0, const float* __restrict__ gam,
+                               const float* __restrict__ bet, int H, int D, float* __restrict__ Wf, float* __restrict__ bf) {
+  const int n = blockIdx.x;                      // one workgroup (64 lanes) per output row
+  float dot = 0.f;
+  for (int c = threadIdx.x; c < D; c += 64) {
+    const float w = W0[(int64_t)n * D + c];
+    Wf[(int64_t)n * D + c] = w * gam[c];
+    dot = fmaf(w, bet[c], dot);
+  }
+  dot = wave_sum_all(dot);
+  if (threadIdx.x == 0) bf[n] = b0[n] + dot;
+}
+__global__ void fn_unfold_grad_kernel(const float* __restrict__ W0, const float* __restrict__ gam, const float* __restrict__ bet,
+                                      float* __restrict__ dW, const float* __restrict__ db0, int H, int D, float* __restrict__ dg,
+                                      float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  const float gc = gam[c], bc = bet[c];
+  float sg = 0.f, sb = 0.f;
+  for (int n = 0; n < H; ++n) {
+    const float w = W0[(int64_t)n * D + c], dwp = dW[(int64_t)n * D + c], dbn = db0[n];
+    sg = fmaf(w, dwp, sg);
+    sb = fmaf(dbn, w, sb);
+    dW[(int64_t)n * D + c] = fmaf(gc, dwp, bc * dbn);
+  }
+  dg[c] = sg; dbeta[c] = sb;
 }
 
 // grid (ceil(D/64), 3), 1024 threads = 64 columns x 16 strided slices of the block list, combined in a fixed order
@@ -1094,9 +1131,13 @@ extern "C" int spo_ma_forward(const float* theta, const spo_ma_net* net, const f
   else
     hipLaunchKernelGGL(ln_fwd_kernel<0>, dim3(gr), dim3(256), 0, st, x, nullptr, theta + L.fn_g(), theta + L.fn_b(), nullptr,
                        ws + L.ws_xhat(), ws + L.ws_st0(B), B, L.D);
+  hipLaunchKernelGGL(fn_fold_kernel, dim3(L.H), dim3(64), 0, st, theta + L.W(0), theta + L.b(0), theta + L.fn_g(), theta + L.fn_b(),
+                     L.H, L.D, ws + L.ws_w0f(B), ws + L.ws_b0f(B));
   const float* in = ws + L.ws_xhat();
   for (int k = 0; k < L.NB; ++k) {
     float* a = ws + L.ws_a(B, k);
+    const float* Wk = k == 0 ? ws + L.ws_w0f(B) : theta + L.W(k);
+    const float* bk = k == 0 ? ws + L.ws_b0f(B) : theta + L.b(k);
     if (L.H == 128 && L.in_k(k) % 4 == 0 && L.in_k(k) <= 128 && B >= 32768) {
       // one fused MFMA kernel (large batches: the training / evaluation passes; small collect batches keep rocBLAS)
       const int K = L.in_k(k), KP = (K + 15) & ~15;
@@ -1109,17 +1150,17 @@ extern "C" int spo_ma_forward(const float* theta, const spo_ma_net* net, const f
         attr_done = true;
       }
       const int64_t nt = (B + 127) / 128;
-      hipLaunchKernelGGL(fused_block_fwd128_kernel, dim3((unsigned)(nt < 256 ? nt : 256)), dim3(256), sh, st, in, theta + L.W(k),
-                         theta + L.b(k), theta + L.g(k), theta + L.be(k), a, ws + L.ws_y(B, k), ws + L.ws_st(B, k), B, K);
+      hipLaunchKernelGGL(fused_block_fwd128_kernel, dim3((unsigned)(nt < 256 ? nt : 256)), dim3(256), sh, st, in, Wk,
+                         bk, theta + L.g(k), theta + L.be(k), a, ws + L.ws_y(B, k), ws + L.ws_st(B, k), B, K);
       in = ws + L.ws_y(B, k);
       continue;
     }
-    if (int rc = gemm_xwT(st, in, theta + L.W(k), a, B, L.in_k(k), L.H)) return rc;
+    if (int rc = gemm_xwT(st, in, Wk, a, B, L.in_k(k), L.H)) return rc;
     if (L.H == 128)
-      hipLaunchKernelGGL(ln_fwd128_kernel<1>, dim3(gr), dim3(256), 0, st, a, theta + L.b(k), theta + L.g(k), theta + L.be(k), a,
+      hipLaunchKernelGGL(ln_fwd128_kernel<1>, dim3(gr), dim3(256), 0, st, a, bk, theta + L.g(k), theta + L.be(k), a,
                          ws + L.ws_y(B, k), ws + L.ws_st(B, k), B);
     else
-      hipLaunchKernelGGL(ln_fwd_kernel<1>, dim3(gr), dim3(256), 0, st, a, theta + L.b(k), theta + L.g(k), theta + L.be(k), a,
+      hipLaunchKernelGGL(ln_fwd_kernel<1>, dim3(gr), dim3(256), 0, st, a, bk, theta + L.g(k), theta + L.be(k), a,
                          ws + L.ws_y(B, k), ws + L.ws_st(B, k), B, L.H);
     in = ws + L.ws_y(B, k);
   }
@@ -1199,9 +1240,9 @@ extern "C" int spo_ma_backward(const float* theta, const spo_ma_net* net, const 
       hipLaunchKernelGGL(fused_dx_lnbwd128_kernel, dim3(nparts), dim3(256), sh, st, dzc, theta + L.W(k), ws + L.ws_a(B, k - 1),
                          ws + L.ws_st(B, k - 1), theta + L.g(k - 1), other, partial, B);
       float* t = dzc; dzc = other; other = t;
-    } else {
-      if (int rc = gemm_dyw(st, dzc, theta + L.W(k), other, B, L.in_k(k), L.H)) return rc;      // dY of block k-1 (or d xhat)
-      if (k >= 1) {
+    } else if (k >= 1) {
+      if (int rc = gemm_dyw(st, dzc, theta + L.W(k), other, B, L.in_k(k), L.H)) return rc;      // dY of block k-1
+      {
         nparts = gr;
         if (L.H == 128)
           hipLaunchKernelGGL(ln_bwd128_kernel<1>, dim3(gr), dim3(256), 0, st, other, ws + L.ws_a(B, k - 1), ws + L.ws_st(B, k - 1),
@@ -1212,11 +1253,9 @@ extern "C" int spo_ma_backward(const float* theta, const spo_ma_net* net, const 
       }
     }
   }
-  d0 = other;                          // d xhat: gradient at the normalised observation
-  // feature_norm parameters (the observation itself needs no gradient)
-  hipLaunchKernelGGL(ln_bwd_kernel<0>, dim3(gr), dim3(256), 0, st, d0, x, ws + L.ws_st0(B), theta + L.fn_g(), nullptr, partial, B, L.D);
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((L.D + 63) / 64, 3), dim3(1024), 0, st, partial, gr, L.D, grad + L.fn_g(),
-                     grad + L.fn_b(), nullptr);
+  // grad + W(0) holds dW' = dz_0^T xn: turn it into dW_0 and read the input LayerNorm's two gradients off it
+  hipLaunchKernelGGL(fn_unfold_grad_kernel, dim3((L.D + 63) / 64), dim3(64), 0, st, theta + L.W(0), theta + L.fn_g(), theta + L.fn_b(),
+                     grad + L.W(0), grad + L.b(0), L.H, L.D, grad + L.fn_g(), grad + L.fn_b());
   SPO_LAUNCH_CHECK("spo_ma_backward");
   return 0;
 }
