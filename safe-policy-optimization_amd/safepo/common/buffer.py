@@ -242,8 +242,7 @@ class SeparatedReplayBuffer:
         s = self.step
         self.share_obs[s + 1].copy_(share_obs)
         self.obs[s + 1].copy_(obs)
-        self.rnn_states[s + 1].copy_(rnn_states)
-        self.rnn_states_critic[s + 1].copy_(rnn_states_critic)
+        # recurrent policies are not built: the three rnn_states tensors are, and stay, zeros (no per-step copies)
         self.actions[s].copy_(actions)
         self.action_log_probs[s].copy_(action_log_probs)
         self.value_preds[s].copy_(value_preds)
@@ -257,12 +256,10 @@ class SeparatedReplayBuffer:
             self.costs[s].copy_(costs)
         if cost_preds is not None:
             self.cost_preds[s].copy_(cost_preds)
-        if rnn_states_cost is not None:
-            self.rnn_states_cost[s + 1].copy_(rnn_states_cost)
         self.step = (s + 1) % self.episode_length
 
     def after_update(self):
-        for name in ("share_obs", "obs", "rnn_states", "rnn_states_critic", "masks", "bad_masks", "active_masks"):
+        for name in ("share_obs", "obs", "masks", "bad_masks", "active_masks"):
             t = getattr(self, name)
             t[0].copy_(t[-1])
 

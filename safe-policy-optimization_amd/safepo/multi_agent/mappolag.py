@@ -392,12 +392,14 @@ class Runner:
                 if self.is_root:
                     print(f"[safepo] collect graph capture failed ({type(e).__name__}: {e}); using eager launches", file=sys.stderr)
                 return self._collect_eager(*ins)
-        for dst_group, src_group in zip(self._static_in, ins):
+        for gi, (dst_group, src_group) in enumerate(zip(self._static_in, ins)):
+            if gi in (2, 3, 4):
+                continue                                          # rnn states: zeros on both sides, nothing to copy
             for dst, src in zip(dst_group, src_group):
                 dst.copy_(src)
         self._graph.replay()
         v, acts, lps, r, rc, cp, rk = self._static_out
-        return v.clone(), [x.clone() for x in acts], [x.clone() for x in lps], r.clone(), rc.clone(), cp.clone(), rk.clone()
+        return v.clone(), [x.clone() for x in acts], [x.clone() for x in lps], r, rc, cp.clone(), rk
 
     def insert(self, data, aver_episode_costs=0):
         (obs, share_obs, rewards, costs, dones, infos, values, actions, action_log_probs, rnn_states, rnn_states_critic,
@@ -409,9 +411,7 @@ class Runner:
         active_masks = torch.ones(dones.shape[0], self.num_agents, 1, device=self.dev)
         active_masks[dones == True] = 0.0
         active_masks[dones_env == True] = 1.0
-        rnn_states = rnn_states * keep.view(-1, 1, 1, 1)
-        rnn_states_critic = rnn_states_critic * keep.view(-1, 1, 1, 1)
-        rnn_states_cost = rnn_states_cost * keep.view(-1, 1, 1, 1)
+        # (rnn states are zeros throughout: recurrent policies are not built, so there is nothing to reset at episode ends)
         for a in range(self.num_agents):
             self.buffer[a].insert(share_obs[:, a], obs[:, a], rnn_states[:, a], rnn_states_critic[:, a], actions[a],
                                   action_log_probs[a], values[:, a], rewards[:, a], masks[:, a], None, active_masks[:, a], None,
