@@ -289,6 +289,26 @@ class Runner:
         self.trainer = [MAPPO_L_Trainer(config, self.policy[a], self.comm) for a in range(self.num_agents)]
         self.buffer = [SeparatedReplayBuffer(config, self.envs.observation_space[a], self.envs.share_observation_space[a],
                                              self.envs.action_space[a]) for a in range(self.num_agents)]
+        self._stack_buffers()
+
+    _STACKED = ("share_obs", "obs", "actions", "action_log_probs", "value_preds", "cost_preds", "rewards", "costs", "masks",
+                "active_masks")
+
+    def _stack_buffers(self):
+        """Homogeneous agents: the per-agent buffers become views of ONE [agents, T(+1), N, ...] tensor per field, so a step
+        is inserted with one strided copy per field instead of one per field per agent (the per-step work of collect /
+        insert is pure launch overhead: ~85 tiny copies)."""
+        b0 = self.buffer[0]
+        same = all(getattr(b, f).shape == getattr(b0, f).shape for b in self.buffer for f in self._STACKED)
+        self._stack = None
+        if not same:
+            return
+        self._stack = {}
+        for f in self._STACKED:
+            st = torch.stack([getattr(b, f) for b in self.buffer])
+            self._stack[f] = st
+            for a, b in enumerate(self.buffer):
+                setattr(b, f, st[a])
 
     def run(self):
         c = self.config
@@ -374,11 +394,19 @@ class Runner:
         bufs = self.buffer
         ins = ([b.share_obs[step] for b in bufs], [b.obs[step] for b in bufs], [b.rnn_states[step] for b in bufs],
                [b.rnn_states_critic[step] for b in bufs], [b.rnn_states_cost[step] for b in bufs], [b.masks[step] for b in bufs])
+        stacked = getattr(self, "_stack", None) is not None
         if not self.config.get("collect_graph", True) or getattr(self, "_graph_failed", False):
             return self._collect_eager(*ins)
         if getattr(self, "_graph", None) is None:
             try:
-                self._static_in = tuple([t.clone() for t in group] for group in ins)
+                if stacked:      # one static [agents, N, ...] tensor per input; the per-agent graph inputs are its views
+                    self._static_stk = {f: self._stack[f][:, step].clone() for f in ("share_obs", "obs", "masks")}
+                    self._static_in = ([self._static_stk["share_obs"][a] for a in range(self.num_agents)],
+                                       [self._static_stk["obs"][a] for a in range(self.num_agents)],
+                                       [t.clone() for t in ins[2]], [t.clone() for t in ins[3]], [t.clone() for t in ins[4]],
+                                       [self._static_stk["masks"][a] for a in range(self.num_agents)])
+                else:
+                    self._static_in = tuple([t.clone() for t in group] for group in ins)
                 self._collect_eager(*self._static_in)            # warm-up: rocBLAS handle / workspaces, allocator pools
                 torch.cuda.synchronize(self.dev)
                 g = torch.cuda.CUDAGraph()
@@ -392,11 +420,15 @@ class Runner:
                 if self.is_root:
                     print(f"[safepo] collect graph capture failed ({type(e).__name__}: {e}); using eager launches", file=sys.stderr)
                 return self._collect_eager(*ins)
-        for gi, (dst_group, src_group) in enumerate(zip(self._static_in, ins)):
-            if gi in (2, 3, 4):
-                continue                                          # rnn states: zeros on both sides, nothing to copy
-            for dst, src in zip(dst_group, src_group):
-                dst.copy_(src)
+        if stacked:
+            for f in ("share_obs", "obs", "masks"):
+                self._static_stk[f].copy_(self._stack[f][:, step])
+        else:
+            for gi, (dst_group, src_group) in enumerate(zip(self._static_in, ins)):
+                if gi in (2, 3, 4):
+                    continue                                      # rnn states: zeros on both sides, nothing to copy
+                for dst, src in zip(dst_group, src_group):
+                    dst.copy_(src)
         self._graph.replay()
         v, acts, lps, r, rc, cp, rk = self._static_out
         return v.clone(), [x.clone() for x in acts], [x.clone() for x in lps], r, rc, cp.clone(), rk
@@ -412,6 +444,17 @@ class Runner:
         active_masks[dones == True] = 0.0
         active_masks[dones_env == True] = 1.0
         # (rnn states are zeros throughout: recurrent policies are not built, so there is nothing to reset at episode ends)
+        if self._stack is not None:
+            st, s0 = self._stack, self.buffer[0].step
+            tr = lambda t: t.transpose(0, 1)                                  # [N, agents, ...] -> [agents, N, ...]
+            st["share_obs"][:, s0 + 1].copy_(tr(share_obs)); st["obs"][:, s0 + 1].copy_(tr(obs))
+            st["actions"][:, s0].copy_(torch.stack(actions)); st["action_log_probs"][:, s0].copy_(torch.stack(action_log_probs))
+            st["value_preds"][:, s0].copy_(tr(values)); st["cost_preds"][:, s0].copy_(tr(cost_preds))
+            st["rewards"][:, s0].copy_(tr(rewards)); st["costs"][:, s0].copy_(tr(costs))
+            st["masks"][:, s0 + 1].copy_(tr(masks)); st["active_masks"][:, s0 + 1].copy_(tr(active_masks))
+            for b in self.buffer:
+                b.step = (s0 + 1) % b.episode_length
+            return
         for a in range(self.num_agents):
             self.buffer[a].insert(share_obs[:, a], obs[:, a], rnn_states[:, a], rnn_states_critic[:, a], actions[a],
                                   action_log_probs[a], values[:, a], rewards[:, a], masks[:, a], None, active_masks[:, a], None,
