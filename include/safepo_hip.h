@@ -283,6 +283,9 @@ int spo_synth_env_step(float* next_obs, float* final_obs, float* reward, float* 
  * [rows] vector, state3 = {running_mean, running_mean_sq, debiasing_term}; spo_ma_value_loss = max of the clipped /
  * unclipped Huber losses (util.huber_loss, including its zero branch for e < -delta) with separately normalised targets;
  * spo_ma_clip_adam = clip_grad_norm_ + torch.optim.Adam(lr, eps, weight_decay) on one network.
+ * HAPPO / MAPPO (safepo/multi_agent/{happo,mappo}.py) run on the same entry points: no cost critic / multiplier (pass
+ * lamda = 0), spo_ma_value_loss with active_or_null != NULL and denom_host = the global sum of active masks for
+ * use_value_active_masks (else NULL and the global row count), and per_dim_ratio = 1 for MAPPO's per-dimension ratios.
  * Data parallel over rollout threads: every mean is taken over the GLOBAL batch -- denom_host (global row count, or the
  * global sum of active masks) and rows_global are passed in, scalars / losses come back as this rank's share of the
  * global mean, and the caller all-reduces (sum) the scalars, the PopArt sums and the flat gradients before
@@ -293,6 +296,7 @@ typedef struct spo_ma_net {
 typedef struct spo_ma_loss_cfg {
   float clip_param, entropy_coef, std_x_coef, std_y_coef;
   int32_t use_policy_active_masks;
+  int32_t per_dim_ratio;      /* MAPPO (mappo.py:150-160): per-dimension ratios, min(surr1, surr2) summed over dimensions */
 } spo_ma_loss_cfg;
 int64_t spo_ma_param_count(const spo_ma_net* net);
 int64_t spo_ma_param_offset(const spo_ma_net* net, int which, int block);
@@ -316,9 +320,9 @@ int spo_ma_popart_stats(const float* x, int64_t rows, double* sums2_dev, double*
 int spo_ma_popart_forward(const float* x, int64_t rows, float* state3, double beta, float epsilon, int train,
                           const double* sums2_dev, int64_t rows_global, float* out, void* stream);
 int spo_ma_value_loss(const float* values, const float* value_preds, const float* returns_norm_clipped,
-                      const float* returns_norm_original, float clip_param, float huber_delta, float value_loss_coef,
-                      int64_t rows, int64_t rows_global, float* dvalues_out, float* loss_out, double* partial_ws,
-                      void* stream);
+                      const float* returns_norm_original, const float* active_or_null, float denom_host, float clip_param,
+                      float huber_delta, float value_loss_coef, int64_t rows, int64_t rows_global, float* dvalues_out,
+                      float* loss_out, double* partial_ws, void* stream);
 int spo_ma_clip_adam(float* theta, const float* grad, float* adam_m, float* adam_v, int64_t n, int64_t adam_step_host,
                      float lr, float adam_eps, float weight_decay, float max_grad_norm, int use_max_grad_norm,
                      float* grad_norm_out, double* partial_ws, void* stream);

@@ -107,23 +107,72 @@ class OraclePopArt:
 
 
 class OracleMATrainer:
-    """MAPPO_L_Policy optimisers (mappolag.py:57-66) + MAPPO_L_Trainer.ppo_update (mappolag.py:140-199)."""
+    """MAPPO_L_Policy optimisers (mappolag.py:57-66) + MAPPO_L_Trainer.ppo_update (mappolag.py:140-199); with
+    algo = "happo" / "mappo" the HAPPO_Trainer (happo.py:96-169) and MAPPO_Trainer (mappo.py:96-161) steps."""
 
-    def __init__(self, cfg: dict, actor: MANet, critic: MANet, cost_critic: MANet):
-        self.cfg, self.actor, self.critic, self.cost_critic = cfg, actor, critic, cost_critic
+    def __init__(self, cfg: dict, actor: MANet, critic: MANet, cost_critic: MANet | None = None, algo: str = "mappolag"):
+        self.cfg, self.actor, self.critic, self.cost_critic, self.algo = cfg, actor, critic, cost_critic, algo
         mk = lambda net, lr: torch.optim.Adam(net.ordered_parameters(), lr=lr, eps=cfg["opti_eps"], weight_decay=cfg["weight_decay"])
-        self.opt_a, self.opt_r, self.opt_c = mk(actor, cfg["actor_lr"]), mk(critic, cfg["critic_lr"]), mk(cost_critic, cfg["critic_lr"])
+        self.opt_a, self.opt_r = mk(actor, cfg["actor_lr"]), mk(critic, cfg["critic_lr"])
+        self.opt_c = mk(cost_critic, cfg["critic_lr"]) if cost_critic is not None else None
         self.popart = OraclePopArt()
-        self.lamda = torch.tensor(float(cfg["lamda_lagr"]))
+        self.lamda = torch.tensor(float(cfg.get("lamda_lagr", 0.0)))
 
-    def value_loss(self, values, value_preds, returns):
+    def value_loss(self, values, value_preds, returns, active=None):
         c = self.cfg
         vpc = value_preds + (values - value_preds).clamp(-c["clip_param"], c["clip_param"])
         e_c = self.popart(returns) - vpc              # each call updates the statistics (mappolag.py:129-130)
         e_o = self.popart(returns) - values
-        return torch.max(huber_loss(e_o, c["huber_delta"]), huber_loss(e_c, c["huber_delta"])).mean()
+        vl = torch.max(huber_loss(e_o, c["huber_delta"]), huber_loss(e_c, c["huber_delta"]))
+        if active is not None:                        # happo.py:117-120
+            return (vl * active).sum() / active.sum()
+        return vl.mean()
+
+    def _ppo_update_unconstrained(self, s: dict):
+        """happo.py:124-169 (joint ratio x factor) and mappo.py:119-161 (per-dimension ratios, no factor)."""
+        c = self.cfg
+        mean = self.actor(s["obs"])
+        std = self.actor.std()
+        logp = log_probs(mean, std, s["actions"])
+        ent = torch.distributions.Normal(mean, std.expand_as(mean)).entropy()
+        if c["use_policy_active_masks"]:
+            dist_entropy = (ent * s["active_masks"]).sum() / s["active_masks"].sum()
+        else:
+            dist_entropy = ent.mean()
+        values = self.critic(s["share_obs"])
+        imp = torch.exp(logp - s["old_logp"])
+        if self.algo == "happo":
+            imp = torch.prod(imp, dim=-1, keepdim=True)
+        surr1 = imp * s["adv"]
+        surr2 = torch.clamp(imp, 1.0 - c["clip_param"], 1.0 + c["clip_param"]) * s["adv"]
+        inner = torch.min(surr1, surr2)
+        if self.algo == "happo":
+            inner = s["factor"] * inner
+        m = torch.sum(inner, dim=-1, keepdim=True)
+        if c["use_policy_active_masks"]:
+            policy_loss = (-m * s["active_masks"]).sum() / s["active_masks"].sum()
+        else:
+            policy_loss = -m.mean()
+        self.opt_a.zero_grad()
+        (policy_loss - dist_entropy * c["entropy_coef"]).backward()
+        rec = {"actor_grad": self.actor.flat_grad().clone()}
+        a_norm = nn.utils.clip_grad_norm_(self.actor.ordered_parameters(), c["max_grad_norm"])
+        self.opt_a.step()
+        masked = self.algo == "happo" and c.get("use_value_active_masks", False)
+        vl = self.value_loss(values, s["value_preds"], s["returns"], s["active_masks"] if masked else None)
+        self.opt_r.zero_grad()
+        (vl * c["value_loss_coef"]).backward()
+        rec["critic_grad"] = self.critic.flat_grad().clone()
+        r_norm = nn.utils.clip_grad_norm_(self.critic.ordered_parameters(), c["max_grad_norm"])
+        self.opt_r.step()
+        f = lambda t: float(t.detach()) if torch.is_tensor(t) else float(t)
+        rec["row"] = [f(vl), f(r_norm), f(policy_loss), f(dist_entropy), f(a_norm), f(imp.mean()),
+                      float(self.popart.running_mean), float(self.popart.running_mean_sq), float(self.popart.debiasing_term)]
+        return rec
 
     def ppo_update(self, s: dict):
+        if self.algo != "mappolag":
+            return self._ppo_update_unconstrained(s)
         c = self.cfg
         mean = self.actor(s["obs"])
         std = self.actor.std()
@@ -174,7 +223,9 @@ def nets_from_golden(z, tag: str, which: str = "init"):
     H, nb = int(z[f"{tag}_cfg_hidden_size"]), 1 + int(z[f"{tag}_cfg_layer_N"])
     xc, yc = float(z[f"{tag}_cfg_std_x_coef"]), float(z[f"{tag}_cfg_std_y_coef"])
     D, S, A = z[f"{tag}_obs"].shape[1], z[f"{tag}_share_obs"].shape[1], z[f"{tag}_actions"].shape[1]
-    nets = {"actor": MANet(D, H, nb, A, True, xc, yc), "critic": MANet(S, H, nb, 1, False), "cost_critic": MANet(S, H, nb, 1, False)}
+    nets = {"actor": MANet(D, H, nb, A, True, xc, yc), "critic": MANet(S, H, nb, 1, False)}
+    if any(k.startswith(f"{tag}_{which}_cost_critic_") for k in z.files):
+        nets["cost_critic"] = MANet(S, H, nb, 1, False)
     for nm, net in nets.items():
         pre = f"{tag}_{which}_{nm}_"
         net.load_reference_state_dict({k[len(pre):]: z[k] for k in z.files if k.startswith(pre)})
@@ -185,13 +236,15 @@ def cfg_from_golden(z, tag: str) -> dict:
     pre = f"{tag}_cfg_"
     cfg = {k[len(pre):]: float(z[k]) for k in z.files if k.startswith(pre)}
     cfg["use_policy_active_masks"] = bool(cfg["use_policy_active_masks"])
+    if "use_value_active_masks" in cfg:
+        cfg["use_value_active_masks"] = bool(cfg["use_value_active_masks"])
     return cfg
 
 
 def sample_from_golden(z, tag: str) -> dict:
     keys = ["share_obs", "obs", "actions", "value_preds", "returns", "active_masks", "old_logp", "adv", "factor", "cost_preds",
             "cost_returns", "cost_adv", "aver_episode_costs"]
-    return {k: torch.from_numpy(z[f"{tag}_{k}"].copy()) for k in keys}
+    return {k: torch.from_numpy(z[f"{tag}_{k}"].copy()) for k in keys if f"{tag}_{k}" in z.files}
 
 
 # ---------------------------------------------------------------------- Runner level (mappolag.py:475-504, 587-603)
@@ -217,27 +270,33 @@ def feed_forward_samples(buf: dict, advantages, cost_adv, perm, num_mini_batch: 
     cols = {"share_obs": flat(buf["share_obs"][:-1]), "obs": flat(buf["obs"][:-1]), "actions": flat(buf["actions"]),
             "value_preds": buf["value_preds"][:-1].reshape(-1, 1), "returns": buf["returns"][:-1].reshape(-1, 1),
             "active_masks": buf["active_masks"][:-1].reshape(-1, 1), "old_logp": flat(buf["action_log_probs"]),
-            "adv": advantages.reshape(-1, 1), "factor": buf["factor"].reshape(-1, 1),
-            "cost_preds": buf["cost_preds"][:-1].reshape(-1, 1), "cost_returns": buf["cost_returns"][:-1].reshape(-1, 1),
-            "cost_adv": cost_adv.reshape(-1, 1)}
+            "adv": advantages.reshape(-1, 1), "factor": buf["factor"].reshape(-1, 1)}
+    if cost_adv is not None:
+        cols.update({"cost_preds": buf["cost_preds"][:-1].reshape(-1, 1), "cost_returns": buf["cost_returns"][:-1].reshape(-1, 1),
+                     "cost_adv": cost_adv.reshape(-1, 1)})
     perm = torch.as_tensor(perm, dtype=torch.long)
     for i in range(num_mini_batch):
         idx = perm[i * mb:(i + 1) * mb]
         s = {k: v[idx] for k, v in cols.items()}
-        s["aver_episode_costs"] = buf["aver_episode_costs"]
+        if cost_adv is not None:
+            s["aver_episode_costs"] = buf["aver_episode_costs"]
         yield s
 
 
 def train_agent(tr: OracleMATrainer, buf: dict, perms, cfg: dict):
     """MAPPO_L_Trainer.train (mappolag.py:201-236): NaN-masked torch.mean / torch.std standardisation of both advantages,
     then learning_iters passes of num_mini_batch ppo_update steps.  Returns the rows the reference stores per pass."""
+    constrained = tr.algo == "mappolag"
+
     def standardised(returns, preds):
         adv = returns[:-1] - tr.popart.denormalize(preds[:-1])
+        if not constrained:                            # happo.py:171-175 / mappo.py:163-167: plain statistics, + 1e-5
+            return (adv - torch.mean(adv)) / (torch.std(adv) + 1e-5)
         cp = adv.clone()
         cp[buf["active_masks"][:-1] == 0.0] = float("nan")
         return (adv - torch.mean(cp)) / (torch.std(cp) + 1e-8)
     advantages = standardised(buf["returns"], buf["value_preds"])
-    cost_adv = standardised(buf["cost_returns"], buf["cost_preds"])
+    cost_adv = standardised(buf["cost_returns"], buf["cost_preds"]) if constrained else None
     rows = []
     for it in range(int(cfg["learning_iters"])):
         rec = None

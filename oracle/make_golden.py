@@ -415,6 +415,105 @@ def golden_ma_mappolag():
     print("ma_mappolag.npz", len(out), "arrays")
 
 
+def golden_ma_happo_mappo():
+    """HAPPO / MAPPO trainers: the reference {HAPPO,MAPPO}_Trainer.ppo_update (happo.py:124-169, mappo.py:119-161) for three
+    steps on a fixed sample, and one {HAPPO,MAPPO}_Trainer.train (happo.py:171-191, mappo.py:163-183) over a filled
+    reference SeparatedReplayBuffer (advantage standardisation + learning_iters whole-buffer steps)."""
+    import importlib
+    import yaml
+    if ref_shim.REF_ROOT not in sys.path:
+        sys.path.insert(0, ref_shim.REF_ROOT)
+    ref_shim._install_stubs()
+    RB = importlib.import_module("safepo.common.buffer")
+    out = {}
+    cases = {"happo_default": ("happo", {}), "happo_masked": ("happo", {"use_value_active_masks": True, "use_policy_active_masks": True,
+                                                                       "entropy_coef": 0.01}),
+             "mappo_default": ("mappo", {}), "mappo_mamujoco": ("mappo", "mamujoco")}
+    for tag, (algo, over) in cases.items():
+        M = importlib.import_module(f"safepo.multi_agent.{algo}")
+        base = yaml.safe_load(open(os.path.join(ref_shim.REF_ROOT, f"safepo/multi_agent/marl_cfg/{algo}/config.yaml")))
+        cfg = dict(base)
+        cfg.update(base["mamujoco"] if over == "mamujoco" else over)
+        D, S, A, B, T, N = 20, 33, 5, 96, 6, 8
+        cfg.update(device="cpu", hidden_size=32, actor_lr=3e-3, critic_lr=3e-3, episode_length=T, n_rollout_threads=N,
+                   learning_iters=3, num_mini_batch=1)
+        Pol, Tr = (M.HAPPO_Policy, M.HAPPO_Trainer) if algo == "happo" else (M.MAPPO_Policy, M.MAPPO_Trainer)
+        torch.manual_seed(17)
+
+        def fresh(prefix):
+            pol = Pol(cfg, Space(D), Space(S), Space(A))
+            with torch.no_grad():
+                for net in (pol.actor, pol.critic):
+                    for prm in net.parameters():
+                        prm.add_(0.05 * torch.randn_like(prm))
+            for nm, net in (("actor", pol.actor), ("critic", pol.critic)):
+                for k, v in net.state_dict().items():
+                    out[f"{tag}_{prefix}_{nm}_{k}"] = v.detach().numpy().copy()
+            return pol, Tr(cfg, pol)
+
+        def final(prefix, pol):
+            for nm, net in (("actor", pol.actor), ("critic", pol.critic)):
+                for k, v in net.state_dict().items():
+                    out[f"{tag}_{prefix}_{nm}_{k}"] = v.detach().numpy().copy()
+        # ---- three ppo_update steps on one sample
+        pol, tr = fresh("init")
+        share_obs, obs = torch.randn(B, S), torch.randn(B, D)
+        H = cfg["hidden_size"]
+        with torch.no_grad():
+            values, actions, logp, _, _ = pol.get_actions(share_obs, obs, torch.zeros(B, 1, H), torch.zeros(B, 1, H), torch.ones(B, 1))
+        old_logp = logp + 0.05 * torch.randn(B, A)
+        active = (torch.rand(B, 1) > 0.2).float()
+        sample = (share_obs, obs, torch.zeros(B, 1, H), torch.zeros(B, 1, H), actions, values + 0.3 * torch.randn(B, 1),
+                  torch.randn(B, 1) * 2 + 0.5, torch.ones(B, 1), active, old_logp, torch.randn(B, 1), None, torch.rand(B, 1) + 0.5)
+        names = ["share_obs", "obs", None, None, "actions", "value_preds", "returns", None, "active_masks", "old_logp", "adv", None,
+                 "factor"]
+        for nme, t in zip(names, sample):
+            if nme:
+                out[f"{tag}_{nme}"] = t.numpy().copy()
+        steps = []
+        for _ in range(3):
+            vl, cgn, plo, ent, agn, imp = tr.ppo_update(sample)
+            vn = tr.value_normalizer
+            steps.append([float(vl), float(cgn), float(plo), float(ent), float(agn), float(imp.mean()), float(vn.running_mean),
+                          float(vn.running_mean_sq), float(vn.debiasing_term)])
+        out[f"{tag}_steps"] = np.asarray(steps, np.float64)
+        final("final", pol)
+        # ---- one Trainer.train over a filled buffer
+        pol, tr = fresh("tinit")
+        buf = RB.SeparatedReplayBuffer(cfg, Space(D), Space(S), Space(A))
+        with torch.no_grad():
+            buf.share_obs.copy_(torch.randn_like(buf.share_obs)); buf.obs.copy_(torch.randn_like(buf.obs))
+            flat_o, flat_s = buf.obs[:-1].reshape(T * N, D), buf.share_obs[:-1].reshape(T * N, S)
+            v, a, lp, _, _ = pol.get_actions(flat_s, flat_o, torch.zeros(T * N, 1, H), torch.zeros(T * N, 1, H), torch.ones(T * N, 1))
+            buf.actions.copy_(a.reshape(T, N, A)); buf.action_log_probs.copy_((lp + 0.03 * torch.randn_like(lp)).reshape(T, N, A))
+            buf.value_preds.copy_(torch.randn_like(buf.value_preds) * 0.5)
+            buf.returns.copy_(torch.randn_like(buf.returns) * 2 + 0.3)
+            buf.active_masks.copy_((torch.rand_like(buf.active_masks) > 0.15).float())
+            buf.update_factor(torch.rand(T, N, 1) + 0.5)
+        for k in ("share_obs", "obs", "actions", "action_log_probs", "value_preds", "returns", "active_masks", "factor"):
+            out[f"{tag}_buf_{k}"] = getattr(buf, k).numpy().copy()
+
+        class _Log:
+            rows = []
+
+            def store(self, **kw):
+                self.rows.append([kw["Loss/Loss_reward_critic"], kw["Misc/Reward_critic_norm"], kw["Loss/Loss_actor"],
+                                  kw["Misc/Entropy"], kw["Misc/Ratio"]])
+        lg = _Log()
+        lg.rows = []
+        tr.train(buf, lg)
+        out[f"{tag}_train_rows"] = np.asarray(lg.rows, np.float64)
+        vn = tr.value_normalizer
+        out[f"{tag}_train_popart"] = np.asarray([float(vn.running_mean), float(vn.running_mean_sq), float(vn.debiasing_term)])
+        final("tfinal", pol)
+        for k in ("clip_param", "entropy_coef", "huber_delta", "value_loss_coef", "max_grad_norm", "actor_lr", "critic_lr",
+                  "opti_eps", "weight_decay", "gamma", "std_x_coef", "std_y_coef", "layer_N", "hidden_size", "learning_iters",
+                  "num_mini_batch", "use_policy_active_masks", "use_value_active_masks"):
+            out[f"{tag}_cfg_{k}"] = np.float64(cfg[k])
+    np.savez_compressed(os.path.join(OUT, "ma_happo_mappo.npz"), **out)
+    print("ma_happo_mappo.npz", len(out), "arrays")
+
+
 def golden_ma_runner_trace():
     """Three episodes of the reference mappolag Runner.run() (safepo/multi_agent/mappolag.py:252-604) on SynthMAEnv:
     buffers before compute(), returns after it, the agent order and minibatch permutations (recorded from torch.randperm),
@@ -512,6 +611,7 @@ if __name__ == "__main__":
     golden_pid()
     golden_ma_gae()
     golden_ma_mappolag()
+    golden_ma_happo_mappo()
     golden_ma_runner_trace()
     env_kw = dict(obs_dim=60, act_dim=8, p_term=0.03, p_cost=0.3, trunc_len=20)
     golden_trace("ppo_lag", "ppo_lag_trace.npz", num_envs=4, T=48, epochs=3, env_kw=env_kw,

@@ -875,14 +875,41 @@ __global__ __launch_bounds__(256) void ma_actor_loss_kernel(
   for (int a = 0; a < A; ++a) dls[a] = 0.0;
   for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < B; r += (int64_t)gridDim.x * 256) {
     float imp = 1.f;
-    float dif[SPO_MAX_ACT];
+    float dif[SPO_MAX_ACT], impd[SPO_MAX_ACT];
     for (int a = 0; a < A; ++a) {
       dif[a] = act[r * A + a] - mean[r * A + a];
       const float lp = -(dif[a] * dif[a]) / (2.f * sd[a] * sd[a]) - logf(sd[a]) - LOG_SQRT_2PI_F;
-      imp *= expf(lp - old_logp[r * A + a]);                 // torch.exp per dim, then torch.prod
+      impd[a] = expf(lp - old_logp[r * A + a]);
+      imp *= impd[a];                                        // torch.exp per dim, then torch.prod
     }
     const float advh = adv[r] - lamda * cost_adv[r];
     const float lo = 1.f - c.clip_param, hi = 1.f + c.clip_param;
+    if (c.per_dim_ratio) {
+      // MAPPO (mappo.py:150-160): the ratio stays per action dimension; min(surr1, surr2) is summed over the dimensions
+      const float w = (c.use_policy_active_masks ? active[r] : 1.f) * inv_denom;
+      const float ew = c.use_policy_active_masks ? active[r] * inv_denom : ent_w;
+      float msum = 0.f;
+      for (int a = 0; a < A; ++a) {
+        const float ia = impd[a];
+        const float rca = fminf(fmaxf(ia, lo), hi);
+        const float s1 = ia * advh, s2 = rca * advh;
+        const bool inr = ia >= lo && ia <= hi;
+        float gr;
+        if (s1 < s2) gr = advh;
+        else if (s1 > s2) gr = inr ? advh : 0.f;
+        else gr = 0.5f * advh + (inr ? 0.5f * advh : 0.f);
+        msum += fminf(s1, s2);
+        acc[1] += (double)ia;
+        const float dlp = -w * gr * ia;
+        const float iv = 1.f / (sd[a] * sd[a]);
+        dmean[r * A + a] = dlp * dif[a] * iv;
+        const float dsig = dlp * (dif[a] * dif[a] * iv / sd[a] - 1.f / sd[a]) - c.entropy_coef * ew / sd[a];
+        dls[a] += (double)(dsig * dsd_dls[a]);
+      }
+      acc[0] += (double)(msum * w);
+      acc[3] += (double)active[r];
+      continue;
+    }
     const float rc = fminf(fmaxf(imp, lo), hi);
     const float s1 = imp * advh, s2 = rc * advh;
     const bool inr = imp >= lo && imp <= hi;
@@ -952,7 +979,7 @@ __global__ void ma_actor_loss_finish_kernel(const double* __restrict__ partial, 
       ent += 0.5 + (double)LOG_SQRT_2PI_F + (double)logf(sg);
     }
     scalars_out[1] = (float)(c.use_policy_active_masks ? ent : ent / (double)A);   // (ent*mask).sum()/mask.sum() vs .mean()
-  } else if (k == 1) scalars_out[2] = (float)(s / (double)B);
+  } else if (k == 1) scalars_out[2] = (float)(s / ((double)B * (c.per_dim_ratio ? (double)A : 1.0)));
   else if (k == 2) scalars_out[3] = (float)(s / (double)B);
   else if (k == 3) scalars_out[4] = (float)s;
   else dlogstd_out[k - AL_NS] = (float)s;
@@ -1017,7 +1044,7 @@ __device__ __forceinline__ float huber_grad(float e, float d) {
 }
 __global__ __launch_bounds__(256) void ma_value_loss_kernel(const float* __restrict__ values, const float* __restrict__ value_preds,
                                                             const float* __restrict__ ret_n1, const float* __restrict__ ret_n2,
-                                                            float clip, float delta, float coef_over_B,
+                                                            const float* __restrict__ active, float clip, float delta, float coef_over_B,
                                                             float* __restrict__ dvalues, double* __restrict__ partial, int64_t B) {
   __shared__ double sh[4];
   double s = 0;
@@ -1027,14 +1054,15 @@ __global__ __launch_bounds__(256) void ma_value_loss_kernel(const float* __restr
     const float vc = vp + fminf(fmaxf(dv, -clip), clip);
     const float ec = ret_n1[r] - vc, eo = ret_n2[r] - v;
     const float hc = huber(ec, delta), ho = huber(eo, delta);
-    s += (double)fmaxf(ho, hc);
+    const float aw = active ? active[r] : 1.f;                // happo.py:117-120: (loss * active).sum() / active.sum()
+    s += (double)(fmaxf(ho, hc) * aw);
     const float go = -huber_grad(eo, delta);
     const float gc = (dv >= -clip && dv <= clip) ? -huber_grad(ec, delta) : 0.f;
     float g;
     if (ho > hc) g = go;
     else if (ho < hc) g = gc;
     else g = 0.5f * (go + gc);                               // torch.max splits ties
-    dvalues[r] = g * coef_over_B;
+    dvalues[r] = g * coef_over_B * aw;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -1337,17 +1365,18 @@ extern "C" int spo_ma_popart_forward(const float* x, int64_t rows, float* state3
 }
 
 extern "C" int spo_ma_value_loss(const float* values, const float* value_preds, const float* returns_norm_clipped,
-                                 const float* returns_norm_original, float clip_param, float huber_delta,
-                                 float value_loss_coef, int64_t rows, int64_t rows_global, float* dvalues_out, float* loss_out,
-                                 double* partial_ws, void* stream) {
+                                 const float* returns_norm_original, const float* active_or_null, float denom_host,
+                                 float clip_param, float huber_delta, float value_loss_coef, int64_t rows, int64_t rows_global,
+                                 float* dvalues_out, float* loss_out, double* partial_ws, void* stream) {
   SPO_REQUIRE(values && value_preds && returns_norm_clipped && returns_norm_original && dvalues_out && loss_out && partial_ws &&
-                  rows > 0 && rows_global >= rows, "ma_value_loss: bad args");
+                  rows > 0 && rows_global >= rows && denom_host > 0.f, "ma_value_loss: bad args");
   hipStream_t st = (hipStream_t)stream;
   int64_t g = (rows + 255) / 256;
   const int gr = (int)(g > 1024 ? 1024 : g);
   hipLaunchKernelGGL(ma_value_loss_kernel, dim3(gr), dim3(256), 0, st, values, value_preds, returns_norm_clipped,
-                     returns_norm_original, clip_param, huber_delta, value_loss_coef / (float)rows_global, dvalues_out, partial_ws, rows);
-  hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(256), 0, st, partial_ws, gr, 1.0 / (double)rows_global, loss_out);
+                     returns_norm_original, active_or_null, clip_param, huber_delta, value_loss_coef / denom_host, dvalues_out,
+                     partial_ws, rows);
+  hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(256), 0, st, partial_ws, gr, 1.0 / (double)denom_host, loss_out);
   SPO_LAUNCH_CHECK("spo_ma_value_loss");
   return 0;
 }

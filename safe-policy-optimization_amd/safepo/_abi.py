@@ -34,7 +34,7 @@ class MaNet(Structure):
 class MaLossCfg(Structure):
     """spo_ma_loss_cfg (include/safepo_hip.h)."""
     _fields_ = [("clip_param", c_float), ("entropy_coef", c_float), ("std_x_coef", c_float), ("std_y_coef", c_float),
-                ("use_policy_active_masks", c_int32)]
+                ("use_policy_active_masks", c_int32), ("per_dim_ratio", c_int32)]
 
 
 P = c_void_p
@@ -91,7 +91,7 @@ PROTOTYPES = {
     "spo_ma_lamda_update": (c_int, [P, P, c_float, c_float, c_float, c_float, P]),
     "spo_ma_popart_stats": (c_int, [P, c_int64, P, P, P]),
     "spo_ma_popart_forward": (c_int, [P, c_int64, P, c_double, c_float, c_int, P, c_int64, P, P]),
-    "spo_ma_value_loss": (c_int, [P, P, P, P, c_float, c_float, c_float, c_int64, c_int64, P, P, P, P]),
+    "spo_ma_value_loss": (c_int, [P, P, P, P, P, c_float, c_float, c_float, c_float, c_int64, c_int64, P, P, P, P]),
     "spo_ma_clip_adam": (c_int, [P, P, P, P, c_int64, c_int64, c_float, c_float, c_float, c_float, c_int, P, P, P]),
     "spo_ma_gae": (c_int, [P] * 7 + [c_int64, c_int64, c_double, c_double, c_float, c_float, c_float, c_float, P]),
     "spo_param_count": (c_int64, [c_int, c_int]),

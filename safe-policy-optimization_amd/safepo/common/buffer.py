@@ -229,9 +229,13 @@ class SeparatedReplayBuffer:
         for i in range(num_mini_batch if num_mini_batch is not None else batch_size // mini_batch_size):
             idx = rand[i * mini_batch_size:(i + 1) * mini_batch_size]
             g = (lambda t: t) if whole else (lambda t: t.index_select(0, idx))
-            yield (g(share_obs), g(obs), g(rnn), g(rnn_c), g(actions), g(value_preds), g(returns), g(masks), g(active),
-                   g(logp), g(advantages), None, g(factor), g(cost_preds), g(cost_returns), g(rnn_k),
-                   g(cost_adv) if cost_adv is not None else None, self.aver_episode_costs)
+            head = (g(share_obs), g(obs), g(rnn), g(rnn_c), g(actions), g(value_preds), g(returns), g(masks), g(active),
+                    g(logp), g(advantages), None, g(factor))
+            if self.algo not in ("mappolag", "macpo"):           # buffer.py:462-464: the 13-tuple of happo / mappo
+                yield head
+                continue
+            yield head + (g(cost_preds), g(cost_returns), g(rnn_k), g(cost_adv) if cost_adv is not None else None,
+                          self.aver_episode_costs)
 
     def return_aver_insert(self, aver_episode_costs):
         self.aver_episode_costs = aver_episode_costs.clone()

@@ -78,7 +78,9 @@ class _Adam:
 
 
 class MAPPO_L_Policy:
-    """mappolag.py:45-113: actor on the agent's observation, critic and cost critic on the shared observation."""
+    """mappolag.py:45-113: actor on the agent's observation, critic and cost critic on the shared observation.
+    `use_cost = False` (HAPPO_Policy / MAPPO_Policy, happo.py:46-93, mappo.py:46-93) drops the cost critic."""
+    use_cost = True
 
     def __init__(self, config, obs_space, cent_obs_space, act_space):
         self.config, self.obs_space, self.act_space, self.share_obs_space = config, obs_space, act_space, cent_obs_space
@@ -87,10 +89,14 @@ class MAPPO_L_Policy:
             raise _abi.SpoError("MAPPO-L (MI355X) runs on a ROCm GPU only (--device cuda); there is no CPU fallback")
         self.actor = Actor(config, obs_space, act_space, dev)
         self.critic = Critic(config, cent_obs_space, dev)
-        self.cost_critic = Critic(config, cent_obs_space, dev)
+        self.cost_critic = Critic(config, cent_obs_space, dev) if self.use_cost else None
         self.actor_optimizer = _Adam(self.actor, config["actor_lr"], config["opti_eps"], config["weight_decay"])
         self.critic_optimizer = _Adam(self.critic, config["critic_lr"], config["opti_eps"], config["weight_decay"])
-        self.cost_optimizer = _Adam(self.cost_critic, config["critic_lr"], config["opti_eps"], config["weight_decay"])
+        self.cost_optimizer = (_Adam(self.cost_critic, config["critic_lr"], config["opti_eps"], config["weight_decay"])
+                               if self.use_cost else None)
+
+    def networks(self):
+        return [n for n in (self.actor, self.critic, self.cost_critic) if n is not None]
 
     def get_actions(self, cent_obs, obs, rnn_states_actor, rnn_states_critic, masks, available_actions=None,
                     deterministic=False, rnn_states_cost=None):
@@ -123,7 +129,10 @@ class MAPPO_L_Policy:
 
 
 class MAPPO_L_Trainer:
-    """mappolag.py:115-249.  `lamda_lagr` is a device scalar updated inside every minibatch step (mappolag.py:178-182)."""
+    """mappolag.py:115-249.  `lamda_lagr` is a device scalar updated inside every minibatch step (mappolag.py:178-182).
+    `algo` selects the sibling trainers built on the same kernels: "happo" (happo.py:96-205: no cost side, value loss with
+    use_value_active_masks) and "mappo" (mappo.py:96-189: additionally per-dimension ratios and no sequential factor)."""
+    algo = "mappolag"
 
     def __init__(self, config, policy, comm: Comm | None = None):
         self.config, self.policy = config, policy
@@ -132,13 +141,16 @@ class MAPPO_L_Trainer:
         self.tpdv = dict(dtype=torch.float32, device=self.dev)
         self.value_normalizer = PopArt(1, device=self.dev)
         self._popart_state = torch.zeros(3, **self.tpdv)         # {running_mean, running_mean_sq, debiasing_term}
-        self._lamda = torch.tensor([float(config["lamda_lagr"])], **self.tpdv)
+        self.use_cost = self.algo == "mappolag"
+        self._lamda = torch.tensor([float(config["lamda_lagr"]) if self.use_cost else 0.0], **self.tpdv)
         self._partial = torch.zeros(1024 * (4 + 16), dtype=torch.float64, device=self.dev)
         self._scalars = torch.zeros(5, **self.tpdv)
         self._sums2 = torch.zeros(2, dtype=torch.float64, device=self.dev)
         self._loss_cfg = _abi.MaLossCfg(clip_param=float(config["clip_param"]), entropy_coef=float(config["entropy_coef"]),
                                         std_x_coef=float(config["std_x_coef"]), std_y_coef=float(config["std_y_coef"]),
-                                        use_policy_active_masks=int(bool(config["use_policy_active_masks"])))
+                                        use_policy_active_masks=int(bool(config["use_policy_active_masks"])),
+                                        per_dim_ratio=int(self.algo == "mappo"))
+        self._zeros = self._ones = None
 
     @property
     def lamda_lagr(self):
@@ -159,8 +171,8 @@ class MAPPO_L_Trainer:
                                              1, _abi.ptr(self._sums2), rows * self.comm.world_size, _abi.ptr(out), st),
                    "spo_ma_popart_forward")
 
-    def _value_step(self, net, opt, inputs, value_preds, returns):
-        """cal_value_loss (mappolag.py:126-138) + backward + clip + Adam for one critic."""
+    def _value_step(self, net, opt, inputs, value_preds, returns, active=None, active_sum=None):
+        """cal_value_loss (mappolag.py:126-138; happo.py:106-122 with `active`) + backward + clip + Adam for one critic."""
         c, lib = self.config, _abi.load()
         values, saved = net.net_forward(inputs, keep=True)
         rows = values.shape[0]
@@ -169,7 +181,9 @@ class MAPPO_L_Trainer:
         self._normalize_returns(returns, n1)                    # value_normalizer(return_batch) for error_clipped ...
         self._normalize_returns(returns, n2)                    # ... and again for error_original: two statistics updates
         dvalues, loss = torch.empty_like(values), torch.empty(1, **self.tpdv)
+        denom = float(active_sum) if active is not None else float(rows * self.comm.world_size)
         _abi.check(lib.spo_ma_value_loss(_abi.ptr(values), _abi.ptr(value_preds.reshape(-1).contiguous()), _abi.ptr(n1), _abi.ptr(n2),
+                                         _abi.ptr(active) if active is not None else None, denom,
                                          float(c["clip_param"]), float(c["huber_delta"]), float(c["value_loss_coef"]), rows,
                                          rows * self.comm.world_size, _abi.ptr(dvalues), _abi.ptr(loss), _abi.ptr(self._partial),
                                          _abi.stream_ptr()), "spo_ma_value_loss")
@@ -179,14 +193,21 @@ class MAPPO_L_Trainer:
         return loss.reshape(()), norm
 
     def ppo_update(self, sample):
-        (share_obs_batch, obs_batch, _rnn, _rnn_c, actions_batch, value_preds_batch, return_batch, _masks, active_masks_batch,
-         old_action_log_probs_batch, adv_targ, _avail, factor_batch, cost_preds_batch, cost_returns_batch, _rnn_k, cost_adv_targ,
-         aver_episode_costs) = sample
+        if self.use_cost:
+            (share_obs_batch, obs_batch, _rnn, _rnn_c, actions_batch, value_preds_batch, return_batch, _masks, active_masks_batch,
+             old_action_log_probs_batch, adv_targ, _avail, factor_batch, cost_preds_batch, cost_returns_batch, _rnn_k,
+             cost_adv_targ, aver_episode_costs) = sample
+        else:       # happo.py:124-127 / mappo.py:119-121: the 13-tuple
+            (share_obs_batch, obs_batch, _rnn, _rnn_c, actions_batch, value_preds_batch, return_batch, _masks, active_masks_batch,
+             old_action_log_probs_batch, adv_targ, _avail, factor_batch) = sample[:13]
         c, lib, pol = self.config, _abi.load(), self.policy
         f = lambda t: _abi.require_gpu_tensor(check(t).to(**self.tpdv).contiguous(), "sample", torch.float32)
         obs_batch, share_obs_batch, actions_batch = f(obs_batch), f(share_obs_batch), f(actions_batch)
-        old_lp, adv, cadv, factor, active = (f(old_action_log_probs_batch), f(adv_targ).reshape(-1), f(cost_adv_targ).reshape(-1),
-                                             f(factor_batch).reshape(-1), f(active_masks_batch).reshape(-1))
+        old_lp, adv, active = f(old_action_log_probs_batch), f(adv_targ).reshape(-1), f(active_masks_batch).reshape(-1)
+        if self._zeros is None or self._zeros.numel() != adv.numel():
+            self._zeros, self._ones = torch.zeros_like(adv), torch.ones_like(adv)
+        cadv = f(cost_adv_targ).reshape(-1) if self.use_cost else self._zeros       # lamda is 0 as well: A - 0 * 0
+        factor = self._ones if self.algo == "mappo" else f(factor_batch).reshape(-1)
         rows, A = obs_batch.shape[0], pol.actor.act_dim
         # ---- actor: clipped HAPPO surrogate on the hybrid advantage, entropy bonus (mappolag.py:150-176)
         mean, saved = pol.actor.net_forward(obs_batch, keep=True)
@@ -211,6 +232,17 @@ class MAPPO_L_Trainer:
         pol.actor.net_backward(saved, dmean, opt.grad)
         actor_grad_norm = opt.step(c["max_grad_norm"], c["use_max_grad_norm"], self.comm)
         scal = self._scalars.clone()
+        policy_loss, dist_entropy, imp_mean = scal[0], scal[1], scal[2]
+        if not self.use_cost:
+            masked = self.algo == "happo" and c["use_value_active_masks"]
+            if masked and not c["use_policy_active_masks"]:
+                asum = active.sum().reshape(1).double()
+                self.comm.all_reduce_sum_(asum)
+                denom = float(asum.item())
+            value_loss, critic_grad_norm = self._value_step(pol.critic, pol.critic_optimizer, share_obs_batch, f(value_preds_batch),
+                                                            f(return_batch), active if masked else None, denom if masked else None)
+            self._sync_normalizer()
+            return value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_mean
         # ---- multiplier (mappolag.py:178-182); aver_episode_costs.mean() is a host scalar of the buffer
         aver = float(check(aver_episode_costs).float().mean().item())
         _abi.check(lib.spo_ma_lamda_update(_abi.ptr(self._lamda), _abi.ptr(self._scalars), aver, float(c["cost_limit"]), float(c["gamma"]),
@@ -219,34 +251,42 @@ class MAPPO_L_Trainer:
         value_loss, critic_grad_norm = self._value_step(pol.critic, pol.critic_optimizer, share_obs_batch, f(value_preds_batch), f(return_batch))
         cost_loss, cost_grad_norm = self._value_step(pol.cost_critic, pol.cost_optimizer, share_obs_batch, f(cost_preds_batch), f(cost_returns_batch))
         self._sync_normalizer()
-        policy_loss, dist_entropy, imp_mean = scal[0], scal[1], scal[2]
         return value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_mean, cost_loss, cost_grad_norm
 
     def train(self, buffer, logger, perm_fn=None):
         """mappolag.py:201-236 (advantage standardisation with torch.mean / torch.std over the NaN-masked copy, as written)."""
         c = self.config
         self._sync_normalizer()
+        eps = 1e-8 if self.use_cost else 1e-5            # happo.py:171-175 / mappo.py:163-167: no NaN masking, + 1e-5
 
         def standardised(returns, preds):
             adv = returns[:-1] - self.value_normalizer.denormalize(preds[:-1])
             cp = adv.clone()
-            cp[buffer.active_masks[:-1] == 0.0] = float("nan")
+            if self.use_cost:
+                cp[buffer.active_masks[:-1] == 0.0] = float("nan")
             if self.comm.world_size == 1:
-                return (adv - torch.mean(cp)) / (torch.std(cp) + 1e-8)
+                return (adv - torch.mean(cp)) / (torch.std(cp) + eps)
             # torch.mean / torch.std (unbiased) of the rows of ALL ranks, NaN-propagating like the single-rank form
             d = cp.double()
             sums = torch.stack([d.sum(), (d * d).sum(), torch.tensor(float(d.numel()), dtype=torch.float64, device=d.device)])
             self.comm.all_reduce_sum_(sums)
             mean = sums[0] / sums[2]
             var = (sums[1] - sums[2] * mean * mean) / (sums[2] - 1.0)
-            return (adv - mean.float()) / (torch.sqrt(var.clamp(min=0.0)).float() + 1e-8)
+            return (adv - mean.float()) / (torch.sqrt(var.clamp(min=0.0)).float() + eps)
         advantages = standardised(buffer.returns, buffer.value_preds)
-        cost_adv = standardised(buffer.cost_returns, buffer.cost_preds)
+        cost_adv = standardised(buffer.cost_returns, buffer.cost_preds) if self.use_cost else None
         out = None
         for it in range(c["learning_iters"]):
             perm = perm_fn(it) if perm_fn is not None else None
             for sample in buffer.feed_forward_generator(advantages, c["num_mini_batch"], cost_adv=cost_adv, perm=perm):
                 out = self.ppo_update(sample)
+            if not self.use_cost:
+                value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights = out
+                if logger is not None:
+                    logger.store(**{"Loss/Loss_reward_critic": value_loss.item(), "Loss/Loss_actor": policy_loss.item(),
+                                    "Misc/Reward_critic_norm": critic_grad_norm.item(), "Misc/Entropy": dist_entropy.item(),
+                                    "Misc/Ratio": imp_weights.detach().mean().item()})
+                continue
             value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights, cost_loss, cost_grad_norm = out
             if logger is not None:
                 logger.store(**{"Loss/Loss_reward_critic": value_loss.item(), "Loss/Loss_cost_critic": cost_loss.item(),
@@ -263,7 +303,11 @@ class MAPPO_L_Trainer:
 
 
 class Runner:
-    """mappolag.py:252-604: collect -> insert -> compute -> train with sequential (HAPPO) agent updates."""
+    """mappolag.py:252-604: collect -> insert -> compute -> train with sequential (HAPPO) agent updates.  The happo / mappo
+    runners (happo.py:208-540, mappo.py:192-532) are this class with `policy_cls` / `trainer_cls` swapped: no cost
+    predictions in collect / insert / compute, the shorter log table."""
+    policy_cls = MAPPO_L_Policy
+    trainer_cls = MAPPO_L_Trainer
 
     def __init__(self, vec_env, vec_eval_env, config, model_dir="", comm: Comm | None = None):
         """Data parallel: one process per GPU, each with its own shard of rollout threads (config["n_rollout_threads"] is
@@ -279,14 +323,15 @@ class Runner:
         self.save_dir = str(config["log_dir"] + "/models_seed{}".format(config["seed"]))
         os.makedirs(self.save_dir, exist_ok=True)
         self.logger.save_config(config)
-        self.policy = [MAPPO_L_Policy(config, self.envs.observation_space[a], self.envs.share_observation_space[a],
-                                      self.envs.action_space[a]) for a in range(self.num_agents)]
+        self.use_cost = self.policy_cls.use_cost
+        self.policy = [self.policy_cls(config, self.envs.observation_space[a], self.envs.share_observation_space[a],
+                                       self.envs.action_space[a]) for a in range(self.num_agents)]
         if self.model_dir != "":
             self.restore()
         for pol in self.policy:
-            for net in (pol.actor, pol.critic, pol.cost_critic):
+            for net in pol.networks():
                 self.comm.broadcast_(net.theta, 0)
-        self.trainer = [MAPPO_L_Trainer(config, self.policy[a], self.comm) for a in range(self.num_agents)]
+        self.trainer = [self.trainer_cls(config, self.policy[a], self.comm) for a in range(self.num_agents)]
         self.buffer = [SeparatedReplayBuffer(config, self.envs.observation_space[a], self.envs.share_observation_space[a],
                                              self.envs.action_space[a]) for a in range(self.num_agents)]
         self._stack_buffers()
@@ -321,7 +366,9 @@ class Runner:
         for episode in range(episodes):
             done_rewards, done_costs = [], []
             for step in range(c["episode_length"]):
-                values, actions, action_log_probs, rnn_states, rnn_states_critic, cost_preds, rnn_states_cost = self.collect(step)
+                out = self.collect(step)
+                values, actions, action_log_probs, rnn_states, rnn_states_critic = out[:5]
+                cost_preds, rnn_states_cost = (out[5], out[6]) if self.use_cost else (None, None)
                 obs, share_obs, rewards, costs, dones, infos, _ = self.envs.step(actions)
                 dones_env = torch.all(dones, dim=1)
                 train_episode_rewards += torch.mean(rewards, dim=1).flatten()
@@ -359,9 +406,11 @@ class Runner:
                 self.logger.log_tabular("Eval/EpCost")
                 self.logger.log_tabular("Train/Epoch", episode)
                 self.logger.log_tabular("Train/TotalSteps", total_num_steps)
-                for k in ("Loss/Loss_reward_critic", "Loss/Loss_cost_critic", "Loss/Loss_actor", "Misc/Reward_critic_norm",
-                          "Misc/Cost_critic_norm", "Misc/Entropy", "Misc/Ratio"):
-                    self.logger.log_tabular(k)
+                keys = ("Loss/Loss_reward_critic", "Loss/Loss_cost_critic", "Loss/Loss_actor", "Misc/Reward_critic_norm",
+                        "Misc/Cost_critic_norm", "Misc/Entropy", "Misc/Ratio")
+                for k in keys:
+                    if self.use_cost or "ost_critic" not in k:
+                        self.logger.log_tabular(k)
                 self.logger.log_tabular("Time/Total", end - start)
                 self.logger.log_tabular("Time/FPS", int(total_num_steps / (end - start)))
                 self.logger.dump_tabular()
@@ -379,11 +428,16 @@ class Runner:
     @torch.no_grad()
     def _collect_eager(self, share_obs, obs, rnn, rnn_c, rnn_k, masks):
         vals, acts, lps, o_rnn, o_rnn_c, cps, o_rnn_k = [], [], [], [], [], [], []
+        tr = lambda xs: torch.transpose(torch.stack(xs), 1, 0)
+        if not self.use_cost:
+            for a in range(self.num_agents):
+                v, act, lp, r, rc = self.trainer[a].policy.get_actions(share_obs[a], obs[a], rnn[a], rnn_c[a], masks[a])
+                vals.append(v); acts.append(act); lps.append(lp); o_rnn.append(r); o_rnn_c.append(rc)
+            return tr(vals), acts, lps, tr(o_rnn), tr(o_rnn_c)
         for a in range(self.num_agents):
             v, act, lp, r, rc, cp, rk = self.trainer[a].policy.get_actions(share_obs[a], obs[a], rnn[a], rnn_c[a], masks[a],
                                                                          rnn_states_cost=rnn_k[a])
             vals.append(v); acts.append(act); lps.append(lp); o_rnn.append(r); o_rnn_c.append(rc); cps.append(cp); o_rnn_k.append(rk)
-        tr = lambda xs: torch.transpose(torch.stack(xs), 1, 0)
         return tr(vals), acts, lps, tr(o_rnn), tr(o_rnn_c), tr(cps), tr(o_rnn_k)
 
     @torch.no_grad()
@@ -430,6 +484,9 @@ class Runner:
                 for dst, src in zip(dst_group, src_group):
                     dst.copy_(src)
         self._graph.replay()
+        if not self.use_cost:
+            v, acts, lps, r, rc = self._static_out
+            return v.clone(), [x.clone() for x in acts], [x.clone() for x in lps], r, rc
         v, acts, lps, r, rc, cp, rk = self._static_out
         return v.clone(), [x.clone() for x in acts], [x.clone() for x in lps], r, rc, cp.clone(), rk
 
@@ -449,13 +506,18 @@ class Runner:
             tr = lambda t: t.transpose(0, 1)                                  # [N, agents, ...] -> [agents, N, ...]
             st["share_obs"][:, s0 + 1].copy_(tr(share_obs)); st["obs"][:, s0 + 1].copy_(tr(obs))
             st["actions"][:, s0].copy_(torch.stack(actions)); st["action_log_probs"][:, s0].copy_(torch.stack(action_log_probs))
-            st["value_preds"][:, s0].copy_(tr(values)); st["cost_preds"][:, s0].copy_(tr(cost_preds))
-            st["rewards"][:, s0].copy_(tr(rewards)); st["costs"][:, s0].copy_(tr(costs))
+            st["value_preds"][:, s0].copy_(tr(values)); st["rewards"][:, s0].copy_(tr(rewards))
+            if self.use_cost:       # happo.py:403-414 / mappo.py:395-406 keep costs out of the buffer
+                st["cost_preds"][:, s0].copy_(tr(cost_preds)); st["costs"][:, s0].copy_(tr(costs))
             st["masks"][:, s0 + 1].copy_(tr(masks)); st["active_masks"][:, s0 + 1].copy_(tr(active_masks))
             for b in self.buffer:
                 b.step = (s0 + 1) % b.episode_length
             return
         for a in range(self.num_agents):
+            if not self.use_cost:
+                self.buffer[a].insert(share_obs[:, a], obs[:, a], rnn_states[:, a], rnn_states_critic[:, a], actions[a],
+                                      action_log_probs[a], values[:, a], rewards[:, a], masks[:, a], None, active_masks[:, a], None)
+                continue
             self.buffer[a].insert(share_obs[:, a], obs[:, a], rnn_states[:, a], rnn_states_critic[:, a], actions[a],
                                   action_log_probs[a], values[:, a], rewards[:, a], masks[:, a], None, active_masks[:, a], None,
                                   costs=costs[:, a], cost_preds=cost_preds[:, a], rnn_states_cost=rnn_states_cost[:, a],
@@ -528,12 +590,16 @@ class Runner:
             b, tr = self.buffer[a], self.trainer[a]
             tr._sync_normalizer()
             next_value = tr.policy.get_values(b.share_obs[-1], b.rnn_states_critic[-1], b.masks[-1])
+            if not self.use_cost:
+                b.compute_returns(next_value, tr.value_normalizer)
+                continue
             next_cost = tr.policy.get_cost_values(b.share_obs[-1], b.rnn_states_cost[-1], b.masks[-1])
             b.compute_returns_and_cost_returns(next_value, next_cost, tr.value_normalizer, tr.value_normalizer)
 
 
-def train(args, cfg_train):
+def train(args, cfg_train, runner_cls=None):
     from safepo.common.env import make_ma_synth_env
+    runner_cls = runner_cls or Runner
     if not str(args.task).startswith("Synth"):
         raise NotImplementedError("this build has no simulator (safety_gymnasium / Isaac Gym are not installed here); "
                                   "use a Synth* multi-agent task, or pass your own vector env to Runner(...)")
@@ -551,7 +617,7 @@ def train(args, cfg_train):
     cfg_eval["seed"] = args.seed + 10000
     cfg_eval["n_rollout_threads"] = cfg_eval["n_eval_rollout_threads"]
     eval_env = make_ma_synth_env(cfg_eval, seed=args.seed + 10000)
-    runner = Runner(env, eval_env, cfg_train, args.model_dir, comm=comm)
+    runner = runner_cls(env, eval_env, cfg_train, args.model_dir, comm=comm)
     if args.model_dir != "":
         runner.eval(100000)
     else:
@@ -559,16 +625,21 @@ def train(args, cfg_train):
     return runner
 
 
-if __name__ == "__main__":
+def cli(algo, train_fn):
+    """The `if __name__ == "__main__"` block shared by the multi-agent scripts (mappolag.py:606-637)."""
     from safepo.utils.config import multi_agent_args
-    args, cfg_env, cfg_train = multi_agent_args(algo="mappolag")
+    args, cfg_env, cfg_train = multi_agent_args(algo=algo)
     torch.manual_seed(cfg_train.get("seed", 0))
     np.random.seed(cfg_train.get("seed", 0))
     if args.write_terminal:
-        train(args=args, cfg_train=cfg_train)
+        train_fn(args=args, cfg_train=cfg_train)
     else:
         os.makedirs(cfg_train["log_dir"], exist_ok=True)
         with open(os.path.join(cfg_train["log_dir"], f"seed{args.seed}_terminal.log"), "w", encoding="utf-8") as f_out, \
                 open(os.path.join(cfg_train["log_dir"], f"seed{args.seed}_error.log"), "w", encoding="utf-8") as f_err:
             sys.stdout, sys.stderr = f_out, f_err
-            train(args=args, cfg_train=cfg_train)
+            train_fn(args=args, cfg_train=cfg_train)
+
+
+if __name__ == "__main__":
+    cli("mappolag", train)

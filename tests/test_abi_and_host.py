@@ -262,3 +262,24 @@ def test_multi_agent_args_defaults_and_overrides():
     assert cfg["hidden_size"] == mamujoco_cfg["hidden_size"] and cfg["learning_iters"] == default_cfg["learning_iters"]
     assert cfg["num_env_steps"] == 4096 and cfg["algorithm_name"] == "mappolag" and cfg["device"] == "cuda:0"
     assert "seed-007" in cfg["log_dir"] and args.task.startswith("Synth")
+
+
+@pytest.mark.parametrize("algo", ["happo", "mappo"])
+def test_multi_agent_sibling_modules_surface_and_defaults(algo):
+    """safepo/multi_agent/{happo,mappo}.py keep the reference's names and config.yaml defaults (incl. the mamujoco block)."""
+    import importlib
+    from safepo.utils.config import multi_agent_args
+    M = importlib.import_module(f"safepo.multi_agent.{algo}")
+    for name in (f"{algo.upper()}_Policy", f"{algo.upper()}_Trainer", "Runner", "train", "default_cfg", "mamujoco_cfg"):
+        assert hasattr(M, name), name
+    assert getattr(M, f"{algo.upper()}_Trainer").algo == algo and not getattr(M, f"{algo.upper()}_Policy").use_cost
+    assert "lamda_lagr" not in M.default_cfg and M.default_cfg["algorithm_name"] == algo
+    if algo == "happo":
+        assert M.default_cfg["episode_length"] == 75 and M.default_cfg["actor_lr"] == 5e-4 and M.default_cfg["use_valuenorm"]
+        assert "use_value_active_masks" not in M.mamujoco_cfg
+    else:
+        assert M.default_cfg["n_rollout_threads"] == 80 and M.default_cfg["actor_lr"] == 9e-5 and not M.default_cfg["use_valuenorm"]
+        assert M.mamujoco_cfg["use_policy_active_masks"] and M.mamujoco_cfg["use_value_active_masks"]
+    args, _, cfg = multi_agent_args(algo, ["--num-envs", "32", "--seed", "3"])
+    assert cfg["algorithm_name"] == algo and cfg["n_rollout_threads"] == 32 and cfg["hidden_size"] == 128
+

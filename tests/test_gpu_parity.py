@@ -1209,6 +1209,109 @@ def test_ma_trainer_ppo_update_vs_reference_golden(dev, golden_dir, tag):
         _assert_params_close(net.theta.cpu().numpy(), want, lr, 3, rtol=2e-3, atol=2e-5, what=f"{tag} {nm}")
 
 
+def _ma_sibling(algo):
+    import importlib
+    M = importlib.import_module(f"safepo.multi_agent.{algo}")
+    return M, getattr(M, f"{algo.upper()}_Policy"), getattr(M, f"{algo.upper()}_Trainer")
+
+
+@pytest.mark.parametrize("tag", ["happo_default", "happo_masked", "mappo_default", "mappo_mamujoco"])
+def test_ma_happo_mappo_trainer_vs_reference_golden(dev, golden_dir, tag):
+    """HAPPO / MAPPO on the MAPPO-L kernels (joint ratio x factor vs per-dimension ratios; value loss over active rows):
+    three reference Trainer.ppo_update steps on a fixed sample, then one reference Trainer.train over a filled buffer
+    (tests/golden/ma_happo_mappo.npz) -- logged scalars, PopArt statistics and both networks afterwards."""
+    from oracle import ma_restatement as MR
+    from safepo.common.buffer import SeparatedReplayBuffer
+    algo = tag.split("_")[0]
+    M, Pol, Tr = _ma_sibling(algo)
+    z = np.load(os.path.join(golden_dir, "ma_happo_mappo.npz"))
+    gc = MR.cfg_from_golden(z, tag)
+    cfg = dict(M.default_cfg)
+    cfg.update(device=str(dev), **gc)
+    for k in ("hidden_size", "layer_N", "learning_iters", "num_mini_batch"):
+        cfg[k] = int(gc[k])
+    s = MR.sample_from_golden(z, tag)
+    D, S, A = s["obs"].shape[1], s["share_obs"].shape[1], s["actions"].shape[1]
+
+    def load(pol, which):
+        for nm, net in (("actor", pol.actor), ("critic", pol.critic)):
+            pre = f"{tag}_{which}_{nm}_"
+            net.load_state_dict({k[len(pre):]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith(pre)})
+
+    def check_final(pol, which, steps):
+        lr = max(float(gc["actor_lr"]), float(gc["critic_lr"]))
+        for nm, net in (("actor", pol.actor), ("critic", pol.critic)):
+            pre = f"{tag}_{which}_{nm}_"
+            want = np.concatenate([z[k].reshape(-1) for k in z.files if k.startswith(pre)])
+            _assert_params_close(net.theta.cpu().numpy(), want, lr, steps, rtol=2e-3, atol=2e-5, what=f"{tag} {which} {nm}")
+    pol = Pol(cfg, _Sp(D), _Sp(S), _Sp(A))
+    assert pol.cost_critic is None
+    load(pol, "init")
+    tr = Tr(cfg, pol)
+    sample = (s["share_obs"], s["obs"], None, None, s["actions"], s["value_preds"], s["returns"], None, s["active_masks"],
+              s["old_logp"], s["adv"], None, s["factor"])
+    sample = tuple(t.to(dev) if torch.is_tensor(t) else t for t in sample)
+    rows = []
+    for _ in range(3):
+        vl, cgn, plo, ent, agn, imp = tr.ppo_update(sample)
+        vn = tr.value_normalizer
+        rows.append([vl.item(), cgn.item(), plo.item(), ent.item(), agn.item(), imp.item(), float(vn.running_mean),
+                     float(vn.running_mean_sq), float(vn.debiasing_term)])
+    np.testing.assert_allclose(np.asarray(rows), z[f"{tag}_steps"], rtol=2e-3, atol=2e-6)
+    check_final(pol, "final", 3)
+    # ---- Trainer.train over the reference's filled buffer
+    T, N = z[f"{tag}_buf_factor"].shape[0:2]
+    cfg.update(episode_length=int(T), n_rollout_threads=int(N))
+    pol = Pol(cfg, _Sp(D), _Sp(S), _Sp(A))
+    load(pol, "tinit")
+    tr = Tr(cfg, pol)
+    buf = SeparatedReplayBuffer(cfg, _Sp(D), _Sp(S), _Sp(A))
+    for k in ("share_obs", "obs", "actions", "action_log_probs", "value_preds", "returns", "active_masks", "factor"):
+        getattr(buf, k).copy_(torch.from_numpy(z[f"{tag}_buf_{k}"].copy()))
+
+    class _Log:
+        def __init__(self):
+            self.rows = []
+
+        def store(self, **kw):
+            self.rows.append([kw["Loss/Loss_reward_critic"], kw["Misc/Reward_critic_norm"], kw["Loss/Loss_actor"],
+                              kw["Misc/Entropy"], kw["Misc/Ratio"]])
+    lg = _Log()
+    tr.train(buf, lg)
+    np.testing.assert_allclose(np.asarray(lg.rows), z[f"{tag}_train_rows"], rtol=2e-3, atol=2e-6)
+    vn = tr.value_normalizer
+    np.testing.assert_allclose([float(vn.running_mean), float(vn.running_mean_sq), float(vn.debiasing_term)],
+                               z[f"{tag}_train_popart"], rtol=1e-4)
+    check_final(pol, "tfinal", int(gc["learning_iters"]))
+
+
+@pytest.mark.parametrize("algo", ["happo", "mappo"])
+def test_ma_happo_mappo_runner_end_to_end_synthetic(dev, tmp_path, algo):
+    """safepo.multi_agent.{happo,mappo}.train() on the synthetic env: the shorter collect / insert / compute path (no
+    cost critic), the reference's log columns and checkpoints; the team reward improves."""
+    import argparse
+    import csv
+    M, _, _ = _ma_sibling(algo)
+    cfg = dict(M.default_cfg)
+    cfg.update(M.mamujoco_cfg)
+    cfg.update(device=str(dev), n_rollout_threads=64, n_eval_rollout_threads=4, episode_length=16, num_env_steps=64 * 16 * 12,
+               hidden_size=64, log_dir=str(tmp_path / "run"), seed=0, actor_lr=3e-3, critic_lr=3e-3,
+               env_name="SynthMultiAgent-v0", env_kwargs={"trunc_len": 16, "num_agents": 3, "obs_dim": 12, "act_dim": 2})
+    args = argparse.Namespace(task="SynthMultiAgent-v0", seed=0, model_dir="")
+    torch.manual_seed(0)
+    runner = M.train(args, cfg)
+    rows = list(csv.DictReader(open(tmp_path / "run" / "progress.csv")))
+    assert len(rows) == 12
+    for col in ("Metrics/EpRet", "Metrics/EpCost", "Loss/Loss_reward_critic", "Loss/Loss_actor", "Misc/Reward_critic_norm",
+                "Misc/Entropy", "Misc/Ratio", "Time/FPS"):
+        assert col in rows[0], col
+    assert "Loss/Loss_cost_critic" not in rows[0]
+    rets = [float(r["Metrics/EpRet"]) for r in rows]
+    assert np.isfinite(rets).all() and np.mean(rets[-3:]) > np.mean(rets[:3]), rets
+    assert runner.policy[0].cost_critic is None
+    assert os.path.exists(tmp_path / "run" / "models_seed0" / "critic_agent2.pt")
+
+
 def test_ma_mappolag_runner_end_to_end_synthetic(dev, tmp_path):
     """safepo.multi_agent.mappolag.train() on the synthetic 4-agent env: collect -> insert -> fused GAE/PopArt -> HAPPO
     sequential updates, logger rows and per-agent checkpoints in the reference's formats; the team reward improves."""

@@ -245,6 +245,38 @@ def test_ma_mappolag_restatement_vs_reference(golden_dir, tag):
         np.testing.assert_allclose(nets[nm].flat().numpy(), fin[nm].flat().numpy(), rtol=2e-5, atol=2e-7, err_msg=nm)
 
 
+@pytest.mark.parametrize("tag", ["happo_default", "happo_masked", "mappo_default", "mappo_mamujoco"])
+def test_ma_happo_mappo_restatement_vs_reference(golden_dir, tag):
+    """HAPPO / MAPPO: three reference Trainer.ppo_update steps on a fixed sample, and one Trainer.train over a filled
+    reference buffer (plain mean/std standardisation + learning_iters whole-buffer steps)."""
+    from oracle import ma_restatement as MR
+    z = _load(golden_dir, "ma_happo_mappo.npz")
+    algo = tag.split("_")[0]
+    nets, cfg, s = MR.nets_from_golden(z, tag), MR.cfg_from_golden(z, tag), MR.sample_from_golden(z, tag)
+    assert set(nets) == {"actor", "critic"}
+    tr = MR.OracleMATrainer(cfg, nets["actor"], nets["critic"], None, algo=algo)
+    rows = [tr.ppo_update(s)["row"] for _ in range(3)]
+    np.testing.assert_allclose(np.asarray(rows), z[f"{tag}_steps"], rtol=2e-5, atol=1e-7)
+    fin = MR.nets_from_golden(z, tag, "final")
+    for nm in nets:
+        np.testing.assert_allclose(nets[nm].flat().numpy(), fin[nm].flat().numpy(), rtol=2e-5, atol=2e-7, err_msg=nm)
+    # Trainer.train: the reference shuffles the single whole-buffer minibatch, which only reorders the sums
+    nets = MR.nets_from_golden(z, tag, "tinit")
+    tr = MR.OracleMATrainer(cfg, nets["actor"], nets["critic"], None, algo=algo)
+    buf = {k: torch.from_numpy(z[f"{tag}_buf_{k}"].copy()) for k in ("share_obs", "obs", "actions", "action_log_probs",
+                                                                     "value_preds", "returns", "active_masks", "factor")}
+    buf["rewards"] = torch.zeros_like(buf["factor"])
+    iters = int(cfg["learning_iters"])
+    n = buf["factor"].numel()
+    got = MR.train_agent(tr, buf, [torch.arange(n)] * iters, cfg)
+    want = z[f"{tag}_train_rows"]                 # value loss, critic norm, policy loss, entropy, ratio
+    np.testing.assert_allclose(np.asarray(got)[:, [0, 1, 2, 3, 5]], want, rtol=5e-5, atol=2e-7)
+    np.testing.assert_allclose(np.asarray(got)[-1, 6:9], z[f"{tag}_train_popart"], rtol=1e-5)
+    fin = MR.nets_from_golden(z, tag, "tfinal")
+    for nm in nets:
+        np.testing.assert_allclose(nets[nm].flat().numpy(), fin[nm].flat().numpy(), rtol=5e-5, atol=5e-7, err_msg=nm)
+
+
 def test_ma_runner_restatement_vs_reference_runner_trace(golden_dir):
     """Three episodes of the reference mappolag Runner (compute() with PopArt-denormalised masked GAE, then
     HAPPO-sequential train()) replayed through the restatement with the recorded buffers, agent order and shuffles."""
