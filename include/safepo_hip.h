@@ -113,7 +113,9 @@ int spo_boundary_step(const float* reward, const float* cost, const float* termi
  * Adam moments in registers for the launch (loaded from / stored to adam_m, adam_v).
  * adam_step_host: number of optimiser steps already taken (bias correction continues from it).
  * losses_out: [num_minibatches][3] = loss_r, loss_c, loss_pi per minibatch (ppo_lag.py:330-336).
- * sync_ws: >= 64 bytes of device scratch, zeroed by this call.                                */
+ * sync_ws: >= 72 bytes of device scratch, zero before first use.  Bytes 0..63 are exchange slots, zeroed by every
+ * call; the int at byte 64 is a STICKY error word the kernels only ever set (1 = inter-workgroup exchange timed out,
+ * 2 = a peer rank never answered the in-kernel gradient exchange) -- the caller reads and clears it.                */
 typedef struct {
   int obs_dim, act_dim, batch;
   int use_critic_norm;          /* config.get("use_critic_norm", True)                        */

@@ -1136,7 +1136,7 @@ extern "C" int spo_ppo_lag_update_iter(float* theta, float* adam_m, float* adam_
                   losses_out && sync_ws, "update_iter: null pointer");
   SPO_REQUIRE(M > 0 && adam_step_host >= 0, "update_iter: bad sizes");
   hipStream_t st = (hipStream_t)stream;
-  if (int rc = spo::hip_check(hipMemsetAsync(sync_ws, 0, 72, st), "hipMemsetAsync(sync_ws)")) return rc;
+  if (int rc = spo::hip_check(hipMemsetAsync(sync_ws, 0, 64, st), "hipMemsetAsync(sync_ws)")) return rc;
   UpdArgs a{};
   a.theta = theta; a.adam_m = adam_m; a.adam_v = adam_v;
   a.obs = obs; a.act = act; a.logp_old = logp_old; a.tgt_r = target_r; a.tgt_c = target_c; a.adv = adv;
@@ -1162,7 +1162,7 @@ extern "C" int spo_critic_fit_iter(float* theta, float* adam_m, float* adam_v, i
               "critic_fit_iter: null pointer");
   SPO_REQUIRE(M > 0 && adam_step_host >= 0, "critic_fit_iter: bad sizes");
   hipStream_t st = (hipStream_t)stream;
-  if (int rc = spo::hip_check(hipMemsetAsync(sync_ws, 0, 72, st), "hipMemsetAsync(sync_ws)")) return rc;
+  if (int rc = spo::hip_check(hipMemsetAsync(sync_ws, 0, 64, st), "hipMemsetAsync(sync_ws)")) return rc;
   UpdArgs a{};
   a.theta = theta; a.adam_m = adam_m; a.adam_v = adam_v;
   a.obs = obs; a.tgt_r = target_r; a.tgt_c = target_c; a.perm = perm; a.M = M; a.cfg = *cfg_host;
@@ -1196,7 +1196,7 @@ extern "C" int spo_update_iter_ex(float* theta, float* adam_m, float* adam_v, in
   SPO_REQUIRE(actor_loss == SPO_ACTOR_LOSS_CLIP || cfg_host->batch <= 64,
               "update_iter_ex: KL-penalty loss with batch_size %d > 64 is not supported", cfg_host->batch);
   hipStream_t st = (hipStream_t)stream;
-  if (int rc = spo::hip_check(hipMemsetAsync(sync_ws, 0, 72, st), "hipMemsetAsync(sync_ws)")) return rc;
+  if (int rc = spo::hip_check(hipMemsetAsync(sync_ws, 0, 64, st), "hipMemsetAsync(sync_ws)")) return rc;
   UpdArgs a{};
   a.theta = theta; a.adam_m = adam_m; a.adam_v = adam_v;
   a.obs = obs; a.act = act; a.logp_old = logp_old; a.tgt_r = target_r; a.tgt_c = target_c; a.adv = adv;
@@ -1311,7 +1311,7 @@ extern "C" int spo_ppo_lag_update_iter_dp(float* theta, float* adam_m, float* ad
                   losses_out && sync_ws, "update_iter_dp: null pointer");
   SPO_REQUIRE(M > 0 && adam_step_host >= 0, "update_iter_dp: bad sizes");
   hipStream_t st = (hipStream_t)stream;
-  if (int rc = spo::hip_check(hipMemsetAsync(sync_ws, 0, 72, st), "hipMemsetAsync(sync_ws)")) return rc;
+  if (int rc = spo::hip_check(hipMemsetAsync(sync_ws, 0, 64, st), "hipMemsetAsync(sync_ws)")) return rc;
   UpdArgs a{};
   if (int rc = fill_xr(a, rank, world, regions, step0)) return rc;
   a.theta = theta; a.adam_m = adam_m; a.adam_v = adam_v;
@@ -1342,7 +1342,7 @@ extern "C" int spo_critic_fit_iter_dp(float* theta, float* adam_m, float* adam_v
               "critic_fit_iter_dp: null pointer");
   SPO_REQUIRE(M > 0 && adam_step_host >= 0, "critic_fit_iter_dp: bad sizes");
   hipStream_t st = (hipStream_t)stream;
-  if (int rc = spo::hip_check(hipMemsetAsync(sync_ws, 0, 72, st), "hipMemsetAsync(sync_ws)")) return rc;
+  if (int rc = spo::hip_check(hipMemsetAsync(sync_ws, 0, 64, st), "hipMemsetAsync(sync_ws)")) return rc;
   UpdArgs a{};
   if (int rc = fill_xr(a, rank, world, regions, step0)) return rc;
   a.theta = theta; a.adam_m = adam_m; a.adam_v = adam_v;

@@ -318,12 +318,32 @@ class PPOLagEngine:
                 "second_stage_losses": losses2}
 
     def check_sync_error(self):
-        code = int(self.sync_ws[8].item()) & 0xFFFFFFFF
+        """Raise if an update kernel gave up on an exchange.  With the in-kernel data-parallel exchange the code is
+        max-reduced over the ranks first, so every rank raises together (a rank that alone went on to the next
+        collective would hang the job) and a caller can fall back to the RCCL form on all ranks at once."""
+        if self.comm.world_size > 1 and self.p2p is not None:
+            code_t = self.sync_ws[8:9].clone()
+            self.comm.all_reduce_max_(code_t)
+            code = int(code_t.item()) & 0xFFFFFFFF
+        else:
+            code = int(self.sync_ws[8].item()) & 0xFFFFFFFF
+        if code:
+            self.sync_ws[8] = 0           # sticky on the device (set by any launch since the last check): cleared here
         if code == 2:
             raise _abi.SpoError("update kernel: a peer rank never answered the in-kernel gradient exchange "
                                 "(set SPO_P2P=0 to use the RCCL form)")
         if code:
             raise _abi.SpoError("update kernel: inter-workgroup exchange timed out")
+
+    def drop_peer_exchange(self):
+        """Leave the in-kernel gradient exchange for the RCCL form of the minibatch step (after a peer timeout): close the
+        regions, clear the error word and make the replicas identical again from rank 0 (parameters, Adam moments)."""
+        if self.p2p is not None:
+            self.p2p.close()
+            self.p2p = None
+        self.sync_ws.zero_()
+        for t in (self.policy.theta, self.adam_m, self.adam_v):
+            self.comm.broadcast_(t, 0)
 
     def update(self, lagrangian_multiplier: float, perm_fn=None):
         """GAE + statistics + mix, then the PPO-Lag update with KL early stopping

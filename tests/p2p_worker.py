@@ -71,7 +71,27 @@ def main(out_path: str, M: int, iters: int):
         res["replicas_identical"] = all(torch.equal(gathered[0], x) for x in gathered[1:])
         res["finite"] = bool(torch.isfinite(theta_p2p).all())
         res["moved"] = float((theta_p2p - theta0).abs().max())
-        eng.p2p.close()
+        # a peer timeout seen by ONE rank must raise on EVERY rank (max-reduced error word), after which the engine drops
+        # to the RCCL form with the replicas made identical again
+        from safepo._abi import SpoError
+        if rank == world - 1:
+            eng.sync_ws[8] = 2
+        try:
+            eng.check_sync_error()
+            raised = 0.0
+        except SpoError:
+            raised = 1.0
+        flag = torch.tensor([raised])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        res["timeout_raises_on_every_rank"] = bool(flag.item() == 1.0)
+        eng.drop_peer_exchange()
+        assert eng.p2p is None
+        eng.learning_iter(perms[0])
+        eng.check_sync_error()
+        th_fb = pol.theta.detach().cpu()
+        gathered = [torch.empty_like(th_fb) for _ in range(world)]
+        dist.all_gather(gathered, th_fb)
+        res["fallback_replicas_identical"] = all(torch.equal(gathered[0], x) for x in gathered[1:]) and bool(torch.isfinite(th_fb).all())
         # the same steps through kernel / all-reduce / kernel
         pol2, eng2 = fresh_engine(False)
         assert eng2.p2p is None

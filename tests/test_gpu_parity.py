@@ -1118,6 +1118,7 @@ def test_in_kernel_gradient_exchange_two_ranks_one_gpu(dev, tmp_path, algo):
     assert res["replicas_identical"] and res["finite"], res
     assert res["frac_outside_1e-5"] <= 1e-3 and res["max_abs_diff_vs_allreduce_form"] < 2e-3, res
     assert res["loss_max_abs_diff"] < 1e-4, res
+    assert res["timeout_raises_on_every_rank"] and res["fallback_replicas_identical"], res
     print("p2p", res)
 
 
