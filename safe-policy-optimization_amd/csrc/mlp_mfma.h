@@ -118,6 +118,35 @@ __device__ __forceinline__ void load_obs_tiles(const float* __restrict__ row, in
   }
 }
 
+// Prefetch form of load_obs_tiles: the loads only (clamped addresses, NO select).  A select right behind a load makes
+// the wave wait for that load on the spot -- which turns a prefetch issued a whole minibatch step ahead into an exposed
+// HBM round trip.  The consumer calls mask_obs_tiles when it picks the tiles up, one step later.
+template <int KIN>
+__device__ __forceinline__ void load_obs_tiles_raw(const float* __restrict__ row, int D, int q, f4 (&x)[KIN / 16]) {
+  if ((D & 3) == 0) {
+#pragma unroll
+    for (int nt = 0; nt < KIN / 16; ++nt) {
+      const int c = 16 * nt + 4 * q;
+      x[nt] = *reinterpret_cast<const f4*>(row + (c < D ? c : 0));
+    }
+  } else {
+#pragma unroll
+    for (int nt = 0; nt < KIN / 16; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = 16 * nt + 4 * q + e;
+        x[nt][e] = row[c < D ? c : 0];
+      }
+  }
+}
+template <int KIN>
+__device__ __forceinline__ void mask_obs_tiles(int D, int q, f4 (&x)[KIN / 16]) {
+#pragma unroll
+  for (int nt = 0; nt < KIN / 16; ++nt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[nt][e] = (16 * nt + 4 * q + e) < D ? x[nt][e] : 0.f;
+}
+
 // tanh(x) = 1 - 2 / (exp(2x) + 1): five VALU ops (v_exp_f32, v_rcp_f32 are 1-ulp), valid for every x
 // (exp -> 0 gives -1, exp -> inf gives +1).  ABSOLUTE error <= ~1.2e-7, i.e. the rounding noise of an
 // O(1) fp32 value -- the same class as the re-associated fp32 dot products that feed it; ocml's tanhf

@@ -136,7 +136,9 @@ __device__ __forceinline__ AdamOut adam1(float p, float g, float m, float v, flo
   }
 #endif
 
-// Per-column inputs of one 64-column chunk, prefetched one chunk ahead.
+// Per-column inputs of one 64-column chunk, prefetched one chunk ahead.  The prefetch stores what the loads returned
+// (pad lanes read a clamped, valid address); the pad selects run when the chunk is picked up (settle_prefetch), never
+// behind the loads -- see load_obs_tiles_raw.
 template <int NT1>
 struct ColData {
   f4 x[NT1];       // observation tiles (B operand of layer 1)
@@ -144,6 +146,10 @@ struct ColData {
   f4 omv;          // actor, KL-penalty loss: old_mean[4q..4q+3]
   float t0, t1;    // critic: target ; actor: logp_old, adv
 };
+// Pins the point where a prefetched register is first touched: everything that consumes it (selects, sign extension)
+// is data-dependent on this and cannot be scheduled back up to the load.
+__device__ __forceinline__ float pinned(float v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ int pinned(int v) { asm volatile("" : "+v"(v)); return v; }
 
 typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) unsigned long long gu64;    // global address space: global_* not flat_*
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
     return base + (col < ncols ? col : 0);
   };
   auto fetch = [&](int64_t smp, ColData<NT1>& cd) {
-    load_obs_tiles<KIN>(a.obs + smp * D, D, q, cd.x);
+    load_obs_tiles_raw<KIN>(a.obs + smp * D, D, q, cd.x);
     if (!is_actor) {
       cd.t0 = tgt[smp]; cd.t1 = 0.f; cd.actv = f4{0.f, 0.f, 0.f, 0.f};
     } else {
@@ -431,11 +437,28 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ai = 4 * q + r;
-        const float t = a.act[smp * A + (ai < A ? ai : 0)];       // unconditional load, select after
-        cd.actv[r] = ai < A ? t : 0.f;
+        cd.actv[r] = a.act[smp * A + (ai < A ? ai : 0)];          // unconditional loads; pads selected at pick-up
+        if (AMODE == 1) cd.omv[r] = a.old_mean[smp * A + (ai < A ? ai : 0)];
+      }
+    }
+  };
+  auto settle_prefetch = [&](ColData<NT1>& cd) {
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cd.x[nt][e] = pinned(cd.x[nt][e]);
+    mask_obs_tiles<KIN>(D, q, cd.x);
+    cd.t0 = pinned(cd.t0);
+    if (is_actor) {
+      cd.t1 = pinned(cd.t1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ai = 4 * q + r;
+        const float av = pinned(cd.actv[r]);
+        cd.actv[r] = ai < A ? av : 0.f;
         if (AMODE == 1) {
-          const float u = a.old_mean[smp * A + (ai < A ? ai : 0)];
-          cd.omv[r] = ai < A ? u : 0.f;
+          const float ov = pinned(cd.omv[r]);
+          cd.omv[r] = ai < A ? ov : 0.f;
         }
       }
     }
@@ -443,14 +466,14 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
 
   // software pipeline: sample index two chunks ahead, column data one chunk ahead
   ColData<NT1> nxt;
-  int64_t smp1 = 0;
+  int smp1 = 0;                // sample index of chunk c+1 as loaded (widened where it is used, one step later)
   fetch((int64_t)a.perm[perm_pos(0, 0)], nxt);
   // (s1,h1) / (s2,h2): step and half of chunk c+1 / c+2, advanced without divisions
   int64_t s_cur = 0, s1 = (nhalf > 1) ? 0 : 1, s2;
   int h_cur = 0, h1n = (nhalf > 1) ? 1 : 0, h2n;
   h2n = h1n + 1; s2 = s1;
   if (h2n == nhalf) { h2n = 0; s2 = s1 + 1; }
-  if (nchunks > 1) smp1 = (int64_t)a.perm[perm_pos(s1, h1n)];
+  if (nchunks > 1) smp1 = a.perm[perm_pos(s1, h1n)];
 
   f4 aW1[NT1], aW2[4], aW3, dls;
   float db1 = 0.f, db2 = 0.f, db3 = 0.f, lsum = 0.f;
@@ -475,7 +498,8 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
 
     if (PROF) tprev = __builtin_readcyclecounter();
     ColData<NT1> cur = nxt;
-    const int64_t smp_next = smp1;
+    settle_prefetch(cur);
+    const int smp_next = pinned(smp1);
     const int64_t pos2 = perm_pos(s2, h2n);
     s_cur = s1; h_cur = h1n; s1 = s2; h1n = h2n;
     h2n += 1;
@@ -520,8 +544,8 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
     // Prefetch: column data of chunk c+1 (its sample index was loaded one chunk ago), THEN the sample
     // index of chunk c+2 -- in this order, so the in-order vmcnt wait on the old index never covers
     // a load issued in this iteration.
-    if (c + 1 < nchunks) fetch(smp_next, nxt);
-    if (c + 2 < nchunks) smp1 = (int64_t)a.perm[pos2];
+    if (c + 1 < nchunks) fetch((int64_t)smp_next, nxt);
+    if (c + 2 < nchunks) smp1 = a.perm[pos2];
     SPO_STAMP(1)
 
     // ---- loss and d(loss)/d(output), C layout (rows = output unit 4q+r, col = batch)
