@@ -308,6 +308,14 @@ int spo_ma_forward(const float* theta, const spo_ma_net* net, const float* x, in
                    void* stream);
 int spo_ma_backward(const float* theta, const spo_ma_net* net, const float* x, int64_t rows, const float* ws,
                     const float* dout, float* grad, float* scratch, void* stream);
+/* Tangent (forward-mode) pass of the same network: dout[rows, out_dim] = d(out)/d(theta) . tangent at the point whose
+ * activations spo_ma_forward left in ws (tangent: flat, laid out like theta; a log_std slot is ignored).  With
+ * spo_ma_backward this gives MACPO's Fisher-vector product J^T M J v without a second-order autograd pass
+ * (replaces the double torch.autograd.grad of safepo/multi_agent/macpo.py:187-199).
+ * scratch: float[spo_ma_jvp_scratch_floats(net, rows)]. */
+int64_t spo_ma_jvp_scratch_floats(const spo_ma_net* net, int64_t rows);
+int spo_ma_jvp(const float* theta, const spo_ma_net* net, const float* tangent, int64_t rows, const float* ws, float* dout,
+               float* scratch, void* stream);
 int spo_ma_sample(const float* mean, const float* log_std, const float* eps, float std_x_coef, float std_y_coef,
                   int deterministic, float* act_out, float* logp_out, int64_t rows, int act_dim, void* stream);
 int spo_ma_log_probs(const float* mean, const float* log_std, const float* act, float std_x_coef, float std_y_coef,

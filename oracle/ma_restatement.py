@@ -170,7 +170,142 @@ class OracleMATrainer:
                       float(self.popart.running_mean), float(self.popart.running_mean_sq), float(self.popart.debiasing_term)]
         return rec
 
+    # ------------------------------------------------------------------ MACPO (macpo.py:153-371)
+    def _actor_out(self, actor, s):
+        mean = actor(s["obs"])
+        std = actor.std().expand_as(mean)
+        return mean, std, log_probs(mean, actor.std(), s["actions"])
+
+    def _kl(self, s, new_actor, old_actor):
+        mu, std, _ = self._actor_out(new_actor, s)
+        mu_old, std_old, _ = self._actor_out(old_actor, s)
+        mu_old, std_old = mu_old.detach(), std_old.detach()
+        kl = torch.log(std_old) - torch.log(std) + (std_old.pow(2) + (mu_old - mu).pow(2)) / (1e-8 + 2.0 * std.pow(2)) - 0.5
+        return kl.sum(1, keepdim=True)
+
+    def _fvp(self, s, p):
+        ps = self.actor.ordered_parameters()
+        kl = self._kl(s, self.actor, self.actor).mean()
+        g = torch.autograd.grad(kl, ps, create_graph=True, allow_unused=True)
+        flat = torch.cat([x.reshape(-1) for x in g if x is not None])
+        h = torch.autograd.grad((flat * p).sum(), ps, allow_unused=True)
+        return torch.cat([x.contiguous().reshape(-1) for x in h if x is not None]).data + 0.1 * p
+
+    def _cg(self, s, b, nsteps, residual_tol=1e-10):
+        x = torch.zeros_like(b)
+        r, p = b.clone(), b.clone()
+        rdotr = torch.dot(r, r)
+        for _ in range(nsteps):
+            avp = self._fvp(s, p)
+            alpha = rdotr / (torch.dot(p, avp) + 1e-8)
+            x += alpha * p
+            r -= alpha * avp
+            new_rdotr = torch.dot(r, r)
+            p = r + (new_rdotr / rdotr) * p
+            rdotr = new_rdotr
+            if rdotr < residual_tol:
+                break
+        return x
+
+    def trpo_update(self, s: dict):
+        import copy
+        import numpy as np
+        c = self.cfg
+        values, cost_values = self.critic(s["share_obs"]), self.cost_critic(s["share_obs"])
+        vl = self.value_loss(values, s["value_preds"], s["returns"])
+        self.opt_r.zero_grad()
+        (vl * c["value_loss_coef"]).backward()
+        r_norm = nn.utils.clip_grad_norm_(self.critic.ordered_parameters(), c["max_grad_norm"])
+        self.opt_r.step()
+        cl = self.value_loss(cost_values, s["cost_preds"], s["cost_returns"])
+        self.opt_c.zero_grad()
+        (cl * c["value_loss_coef"]).backward()
+        c_norm = nn.utils.clip_grad_norm_(self.cost_critic.ordered_parameters(), c["max_grad_norm"])
+        self.opt_c.step()
+        rescale = float((s["aver_episode_costs"].mean() - c["cost_limit"]) * (1 - c["gamma"]))
+        if rescale == 0:
+            rescale = 1e-8
+        ps = self.actor.ordered_parameters()
+        fl = lambda gs: torch.cat([g.reshape(-1) for g in gs if g is not None])
+        _, _, logp = self._actor_out(self.actor, s)
+        ratio = torch.prod(torch.exp(logp - s["old_logp"]), dim=-1, keepdim=True)
+        reward_loss = -torch.sum(ratio * s["factor"] * s["adv"], dim=-1, keepdim=True).mean()
+        g = fl(torch.autograd.grad(reward_loss, ps, retain_graph=True, allow_unused=True))
+        cost_loss = torch.sum(ratio * s["factor"] * s["cost_adv"], dim=-1, keepdim=True).mean()
+        b = fl(torch.autograd.grad(cost_loss, ps, retain_graph=True, allow_unused=True))
+        iters = int(c["conjugate_gradient_iters"])
+        g_dir, b_dir = self._cg(s, g.data.clone(), iters), self._cg(s, b.data.clone(), iters)
+        q = float(torch.dot(g, g_dir))
+        tkl = float(c["target_kl"])
+        bb = float(torch.dot(b, b))
+        if bb <= 1e-8 and rescale < 0:
+            b_dir = torch.zeros_like(g_dir)
+            r_c = s_c = pcv = wrp = 0.0
+            case = 4
+        else:
+            r_c, s_c = float(torch.dot(g, b_dir)), float(torch.dot(b, b_dir))
+            r_c = 1e-8 if r_c == 0 else r_c
+            s_c = 1e-8 if s_c == 0 else s_c
+            pcv = q - r_c ** 2 / (1e-8 + s_c)
+            wrp = 2 * tkl - rescale ** 2 / (1e-8 + s_c)
+            case = 3 if (rescale < 0 and wrp < 0) else 2 if (rescale < 0) else 1 if wrp >= 0 else 0
+        if wrp == 0:
+            wrp = 1e-8
+        sqrt = lambda v: float(torch.sqrt(torch.tensor(float(v))))
+        if case in (3, 4):
+            lam, nu = sqrt(q / (2 * tkl)), 0.0
+        elif case in (1, 2):
+            LA, LB = [0, r_c / rescale], [r_c / rescale, np.inf]
+            LA, LB = (LA, LB) if rescale < 0 else (LB, LA)
+            proj = lambda x, L: max(L[0], min(L[1], x))
+            lam_a, lam_b = proj(sqrt(pcv / wrp), LA), proj(sqrt(q / (2 * tkl)), LB)
+            f_a = lambda l: -0.5 * (pcv / (1e-8 + l) + wrp * l) - r_c * rescale / (1e-8 + s_c)
+            f_b = lambda l: -0.5 * (q / (1e-8 + l) + 2 * tkl * l)
+            lam = lam_a if f_a(lam_a) >= f_b(lam_b) else lam_b
+            nu = max(0, lam * rescale - r_c) / (1e-8 + s_c)
+        else:
+            lam, nu = 0.0, sqrt(2 * tkl / (1e-8 + s_c))
+        x = (1.0 / (lam + 1e-8)) * (g_dir + nu * b_dir) if case > 0 else nu * b_dir
+        reward_loss, cost_loss = reward_loss.detach(), cost_loss.detach()
+        params = self.actor.flat().clone()
+        old_actor = copy.deepcopy(self.actor)
+        expected = -torch.dot(x, g).detach()
+        flag, kl, improve = False, torch.tensor(0.0), torch.tensor(0.0)
+
+        def set_params(vec):
+            off = 0
+            with torch.no_grad():
+                for prm in self.actor.ordered_parameters():
+                    n = prm.numel()
+                    prm.copy_(vec[off:off + n].view_as(prm))
+                    off += n
+        for i in range(int(c["searching_steps"])):
+            xn = torch.norm(x)
+            if xn > 0.5:
+                x = x * 0.5 / xn
+            set_params(params - c["fraction_coef"] * (c["step_fraction"] ** i) * x)
+            with torch.no_grad():
+                _, _, lp = self._actor_out(self.actor, s)
+                ratio = torch.prod(torch.exp(lp - s["old_logp"]), dim=-1, keepdim=True)
+                new_r = -torch.sum(ratio * s["factor"] * s["adv"], dim=-1, keepdim=True).mean()
+                new_c = torch.sum(ratio * s["factor"] * s["cost_adv"], dim=-1, keepdim=True).mean()
+                improve = new_r - reward_loss
+                kl = self._kl(s, self.actor, old_actor).mean()
+            if (kl < tkl) and (improve < 0 if case > 1 else True) and (new_c - cost_loss <= max(-rescale, 0)):
+                flag = True
+                break
+            expected = expected * c["step_fraction"]
+        if not flag:
+            set_params(params)
+        f = lambda t: float(t.detach()) if torch.is_tensor(t) else float(t)
+        return {"row": [f(vl), f(r_norm), f(kl), f(improve), f(expected), f(cost_loss), f(c_norm), f(wrp), f(lam), f(nu), bb,
+                        float(self.popart.running_mean), float(self.popart.running_mean_sq), float(self.popart.debiasing_term)],
+                "case": case, "accepted": flag,
+                "g": g.detach().clone(), "b": b.detach().clone(), "g_dir": g_dir.clone(), "b_dir": b_dir.clone(), "x": x.clone()}
+
     def ppo_update(self, s: dict):
+        if self.algo == "macpo":
+            return self.trpo_update(s)
         if self.algo != "mappolag":
             return self._ppo_update_unconstrained(s)
         c = self.cfg

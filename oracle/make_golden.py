@@ -514,6 +514,79 @@ def golden_ma_happo_mappo():
     print("ma_happo_mappo.npz", len(out), "arrays")
 
 
+def golden_ma_macpo():
+    """MACPO trainer: the reference MACPO_Trainer.trpo_update (safepo/multi_agent/macpo.py:201-371) for two consecutive
+    steps on fixed samples, in three settings that reach different branches of its case analysis (average episode cost
+    below / above the limit; the mamujoco block)."""
+    import importlib
+    import yaml
+    if ref_shim.REF_ROOT not in sys.path:
+        sys.path.insert(0, ref_shim.REF_ROOT)
+    ref_shim._install_stubs()
+    M = importlib.import_module("safepo.multi_agent.macpo")
+    base = yaml.safe_load(open(os.path.join(ref_shim.REF_ROOT, "safepo/multi_agent/marl_cfg/macpo/config.yaml")))
+    out = {}
+    cases = {"safe": ({}, 0.2, 0.5), "unsafe": ({}, 0.9, 0.5), "mamujoco": (dict(base["mamujoco"]), 0.7, 0.5),
+             "recover": ({}, 30.0, 0.5), "deep_safe": ({}, 0.1, 30.0)}
+    for tag, (over, aver_cost, limit) in cases.items():
+        cfg = dict(base)
+        cfg.update(over)
+        cfg.update(device="cpu", hidden_size=32, cost_limit=limit, actor_lr=3e-3, critic_lr=3e-3, algorithm_name="macpo")
+        torch.manual_seed(23)
+        D, S, A, B, H = 20, 33, 5, 96, 32
+        pol = M.MACPO_Policy(cfg, Space(D), Space(S), Space(A))
+        with torch.no_grad():
+            for net in (pol.actor, pol.critic, pol.cost_critic):
+                for prm in net.parameters():
+                    prm.add_(0.05 * torch.randn_like(prm))
+        tr = M.MACPO_Trainer(cfg, pol)
+        for nm, net in (("actor", pol.actor), ("critic", pol.critic), ("cost_critic", pol.cost_critic)):
+            for k, v in net.state_dict().items():
+                out[f"{tag}_init_{nm}_{k}"] = v.detach().numpy().copy()
+        share_obs, obs = torch.randn(B, S), torch.randn(B, D)
+        with torch.no_grad():
+            values, actions, logp, _, _, cost_preds, _ = pol.get_actions(share_obs, obs, torch.zeros(B, 1, H), torch.zeros(B, 1, H),
+                                                                         torch.ones(B, 1), rnn_states_cost=torch.zeros(B, 1, H))
+        old_logp = logp + 0.02 * torch.randn(B, A)
+        active = (torch.rand(B, 1) > 0.2).float()
+        sample = (share_obs, obs, torch.zeros(B, 1, H), torch.zeros(B, 1, H), actions, values + 0.3 * torch.randn(B, 1),
+                  torch.randn(B, 1) * 2 + 0.5, torch.ones(B, 1), active, old_logp, torch.randn(B, 1), None,
+                  torch.rand(B, 1) + 0.5, cost_preds + 0.3 * torch.randn(B, 1), torch.rand(B, 1) * 3, torch.zeros(B, 1, H),
+                  torch.randn(B, 1), torch.tensor(aver_cost))
+        names = ["share_obs", "obs", None, None, "actions", "value_preds", "returns", None, "active_masks", "old_logp", "adv",
+                 None, "factor", "cost_preds", "cost_returns", None, "cost_adv", "aver_episode_costs"]
+        for nme, t in zip(names, sample):
+            if nme:
+                out[f"{tag}_{nme}"] = t.numpy().copy()
+        rows = []
+        for it in range(2):
+            r = tr.trpo_update(sample)
+            (vl, cgn, kl, improve, expected, _ent, _ratio, cost_loss, cost_gn, wrp, _cp, _cr, bgrad, lam, nu, g_dir, b_dir, x, _mu,
+             _std, bb) = r
+            vn = tr.value_normalizer
+            rows.append([float(vl), float(cgn), float(kl), float(improve), float(expected), float(cost_loss), float(cost_gn),
+                         float(wrp), float(lam), float(nu), float(bb), float(vn.running_mean), float(vn.running_mean_sq),
+                         float(vn.debiasing_term)])
+            out[f"{tag}_s{it}_g_step_dir"] = g_dir.detach().numpy().copy()
+            out[f"{tag}_s{it}_b_step_dir"] = (b_dir.detach().numpy().copy() if b_dir.dim() else np.zeros_like(g_dir.numpy()))
+            out[f"{tag}_s{it}_x"] = x.detach().numpy().copy()
+            out[f"{tag}_s{it}_cost_grad"] = bgrad.detach().numpy().copy()
+            out[f"{tag}_s{it}_actor_after"] = torch.cat([p.detach().reshape(-1) for p in pol.actor.parameters()]).numpy().copy()
+        out[f"{tag}_steps"] = np.asarray(rows, np.float64)
+        for nm, net in (("actor", pol.actor), ("critic", pol.critic), ("cost_critic", pol.cost_critic)):
+            for k, v in net.state_dict().items():
+                out[f"{tag}_final_{nm}_{k}"] = v.detach().numpy().copy()
+        for k in ("clip_param", "entropy_coef", "huber_delta", "value_loss_coef", "max_grad_norm", "actor_lr", "critic_lr",
+                  "opti_eps", "weight_decay", "cost_limit", "gamma", "std_x_coef", "std_y_coef", "layer_N", "hidden_size",
+                  "target_kl", "searching_steps", "conjugate_gradient_iters", "step_fraction", "fraction_coef",
+                  "use_policy_active_masks"):
+            out[f"{tag}_cfg_{k}"] = np.float64(cfg[k])
+    np.savez_compressed(os.path.join(OUT, "ma_macpo.npz"), **out)
+    print("ma_macpo.npz", len(out), "arrays")
+    for tag in cases:
+        print(tag, out[f"{tag}_steps"][:, [2, 3, 7, 8, 9]])
+
+
 def golden_ma_runner_trace():
     """Three episodes of the reference mappolag Runner.run() (safepo/multi_agent/mappolag.py:252-604) on SynthMAEnv:
     buffers before compute(), returns after it, the agent order and minibatch permutations (recorded from torch.randperm),
@@ -612,6 +685,7 @@ if __name__ == "__main__":
     golden_ma_gae()
     golden_ma_mappolag()
     golden_ma_happo_mappo()
+    golden_ma_macpo()
     golden_ma_runner_trace()
     env_kw = dict(obs_dim=60, act_dim=8, p_term=0.03, p_cost=0.3, trunc_len=20)
     golden_trace("ppo_lag", "ppo_lag_trace.npz", num_envs=4, T=48, epochs=3, env_kw=env_kw,

@@ -1288,6 +1288,91 @@ extern "C" int spo_ma_backward(const float* theta, const spo_ma_net* net, const 
   return 0;
 }
 
+// ---------------------------------------------------------------- tangent (forward-mode) pass
+// d(out)/d(theta) . t at the point kept in ws by spo_ma_forward: the J v of MACPO's Fisher-vector product
+// (macpo.py:187-199 differentiates the KL twice; at theta = theta_old that Hessian is J^T M J, see safepo/multi_agent/macpo.py).
+// Per block: dz = y_{k-1} tW^T + dy_{k-1} W^T + tb;  da = ELU'(a) dz;  xhat = (a - mean) rstd;
+//            dxhat = rstd (da - mean(da) - xhat mean(xhat da));  dy = tg xhat + g dxhat + tbe.
+__global__ void fn_fold_tangent_kernel(const float* __restrict__ W0, const float* __restrict__ gam, const float* __restrict__ bet,
+                                       const float* __restrict__ tW0, const float* __restrict__ tb0, const float* __restrict__ tgam,
+                                       const float* __restrict__ tbet, int H, int D, float* __restrict__ tWf, float* __restrict__ tbf) {
+  const int n = blockIdx.x;                      // W' = W_0 diag(gamma), b' = b_0 + W_0 beta  ->  their tangents
+  float dot = 0.f;
+  for (int c = threadIdx.x; c < D; c += 64) {
+    const float w = W0[(int64_t)n * D + c], tw = tW0[(int64_t)n * D + c];
+    tWf[(int64_t)n * D + c] = tw * gam[c] + w * tgam[c];
+    dot += tw * bet[c] + w * tbet[c];
+  }
+  dot = wave_sum_all(dot);
+  if (threadIdx.x == 0) tbf[n] = tb0[n] + dot;
+}
+// one wave per row; dz is overwritten with dy
+__global__ __launch_bounds__(256) void ln_jvp_kernel(float* __restrict__ dz, const float* __restrict__ tb, const float* __restrict__ a,
+                                                      const float* __restrict__ stats, const float* __restrict__ g,
+                                                      const float* __restrict__ tg, const float* __restrict__ tbe, int64_t B, int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < B; row += (int64_t)gridDim.x * 4) {
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    float da[MAXE], xh[MAXE];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      const int j = lane + 64 * e;
+      da[e] = xh[e] = 0.f;
+      if (j < D) {
+        const float av = a[row * D + j];
+        da[e] = (dz[row * D + j] + tb[j]) * (av > 0.f ? 1.f : av + 1.f);
+        xh[e] = (av - mean) * rstd;
+      }
+      s1 += da[e]; s2 += da[e] * xh[e];
+    }
+    const float m1 = wave_sum_all(s1) / (float)D, m2 = wave_sum_all(s2) / (float)D;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      const int j = lane + 64 * e;
+      if (j < D) dz[row * D + j] = tg[j] * xh[e] + g[j] * (rstd * (da[e] - m1 - xh[e] * m2)) + tbe[j];
+    }
+  }
+}
+
+extern "C" int64_t spo_ma_jvp_scratch_floats(const spo_ma_net* net, int64_t rows) {
+  Lay L;
+  if (lay_of(net, &L) || rows < 1) return -1;
+  return 2 * Lay::al4(rows * L.H) + Lay::al4((int64_t)L.H * L.D) + Lay::al4(L.H);
+}
+extern "C" int spo_ma_jvp(const float* theta, const spo_ma_net* net, const float* tangent, int64_t rows, const float* ws,
+                          float* dout, float* scratch, void* stream) {
+  Lay L;
+  if (int rc = lay_of(net, &L)) return rc;
+  SPO_REQUIRE(theta && tangent && ws && dout && scratch && rows > 0, "ma_jvp: bad args");
+  if (int rc = rb_init()) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t B = rows;
+  const int gr = grid_rows(B);
+  float* bufs[2] = {scratch, scratch + Lay::al4(B * L.H)};
+  float* tWf = scratch + 2 * Lay::al4(B * L.H);
+  float* tbf = tWf + Lay::al4((int64_t)L.H * L.D);
+  hipLaunchKernelGGL(fn_fold_tangent_kernel, dim3(L.H), dim3(64), 0, st, theta + L.W(0), theta + L.fn_g(), theta + L.fn_b(),
+                     tangent + L.W(0), tangent + L.b(0), tangent + L.fn_g(), tangent + L.fn_b(), L.H, L.D, tWf, tbf);
+  const float* dy_prev = nullptr;
+  for (int k = 0; k < L.NB; ++k) {
+    float* dz = bufs[k & 1];
+    const float* y_prev = k == 0 ? ws + L.ws_xhat() : ws + L.ws_y(B, k - 1);
+    if (int rc = gemm_xwT(st, y_prev, k == 0 ? tWf : tangent + L.W(k), dz, B, L.in_k(k), L.H)) return rc;
+    if (k > 0)
+      if (int rc = gemm_xwT(st, dy_prev, theta + L.W(k), dz, B, L.H, L.H, 1.f)) return rc;
+    hipLaunchKernelGGL(ln_jvp_kernel, dim3(gr), dim3(256), 0, st, dz, k == 0 ? tbf : tangent + L.b(k), ws + L.ws_a(B, k),
+                       ws + L.ws_st(B, k), theta + L.g(k), tangent + L.g(k), tangent + L.be(k), B, L.H);
+    dy_prev = dz;
+  }
+  if (int rc = gemm_xwT(st, ws + L.ws_y(B, L.NB - 1), tangent + L.hW(), dout, B, L.H, L.O)) return rc;
+  if (int rc = gemm_xwT(st, dy_prev, theta + L.hW(), dout, B, L.H, L.O, 1.f)) return rc;
+  const int64_t n = B * L.O;
+  hipLaunchKernelGGL(add_bias_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dout, tangent + L.hb(), n, L.O);
+  SPO_LAUNCH_CHECK("spo_ma_jvp");
+  return 0;
+}
+
 extern "C" int spo_ma_sample(const float* mean, const float* log_std, const float* eps, float std_x_coef, float std_y_coef,
                              int deterministic, float* act_out, float* logp_out, int64_t rows, int act_dim, void* stream) {
   SPO_REQUIRE(mean && log_std && act_out && logp_out && rows > 0 && act_dim > 0 && act_dim <= SPO_MAX_ACT && (deterministic || eps),

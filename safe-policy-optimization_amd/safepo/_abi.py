@@ -91,6 +91,8 @@ PROTOTYPES = {
     "spo_ma_lamda_update": (c_int, [P, P, c_float, c_float, c_float, c_float, P]),
     "spo_ma_popart_stats": (c_int, [P, c_int64, P, P, P]),
     "spo_ma_popart_forward": (c_int, [P, c_int64, P, c_double, c_float, c_int, P, c_int64, P, P]),
+    "spo_ma_jvp_scratch_floats": (c_int64, [POINTER(MaNet), c_int64]),
+    "spo_ma_jvp": (c_int, [P, POINTER(MaNet), P, c_int64, P, P, P, P]),
     "spo_ma_value_loss": (c_int, [P, P, P, P, P, c_float, c_float, c_float, c_float, c_int64, c_int64, P, P, P, P]),
     "spo_ma_clip_adam": (c_int, [P, P, P, P, c_int64, c_int64, c_float, c_float, c_float, c_float, c_int, P, P, P]),
     "spo_ma_gae": (c_int, [P] * 7 + [c_int64, c_int64, c_double, c_double, c_float, c_float, c_float, c_float, P]),

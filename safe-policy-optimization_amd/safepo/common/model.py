@@ -215,6 +215,19 @@ class _MAFlatNet(nn.Module):
                                       _abi.stream_ptr()), "spo_ma_forward")
         return (out, (x, ws)) if keep else out
 
+    def net_jvp(self, saved, tangent: torch.Tensor) -> torch.Tensor:
+        """d(out)/d(theta) . tangent [rows, out] at the point of `saved` (forward-mode pass, spo_ma_jvp)."""
+        x, ws = saved
+        lib = _abi.load()
+        rows = x.shape[0]
+        tangent = _abi.require_gpu_tensor(tangent.contiguous(), "tangent", torch.float32)
+        assert tangent.numel() == self.theta.numel()
+        scratch = torch.empty(int(lib.spo_ma_jvp_scratch_floats(self._net, rows)), dtype=torch.float32, device=x.device)
+        dout = torch.empty((rows, self._net.out_dim), dtype=torch.float32, device=x.device)
+        _abi.check(lib.spo_ma_jvp(_abi.ptr(self.theta), self._net, _abi.ptr(tangent), rows, _abi.ptr(ws), _abi.ptr(dout),
+                                  _abi.ptr(scratch), _abi.stream_ptr()), "spo_ma_jvp")
+        return dout
+
     def net_backward(self, saved, dout: torch.Tensor, grad: torch.Tensor) -> None:
         x, ws = saved
         lib = _abi.load()
@@ -274,6 +287,8 @@ class MultiAgentActor(_MAFlatNet):
             dist_entropy = ent.sum()                                                 # (ent * mask).sum() / mask.sum()
         else:
             dist_entropy = ent.mean()
+        if self.config.get("algorithm_name") == "macpo":       # model.py:282-290 (evaluate_actions_trpo): + mean and stddev
+            return logp, dist_entropy, mean, std.expand_as(mean)
         return logp, dist_entropy
 
 

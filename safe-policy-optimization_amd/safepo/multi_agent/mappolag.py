@@ -308,6 +308,8 @@ class Runner:
     predictions in collect / insert / compute, the shorter log table."""
     policy_cls = MAPPO_L_Policy
     trainer_cls = MAPPO_L_Trainer
+    log_keys = ("Loss/Loss_reward_critic", "Loss/Loss_cost_critic", "Loss/Loss_actor", "Misc/Reward_critic_norm",
+                "Misc/Cost_critic_norm", "Misc/Entropy", "Misc/Ratio")
 
     def __init__(self, vec_env, vec_eval_env, config, model_dir="", comm: Comm | None = None):
         """Data parallel: one process per GPU, each with its own shard of rollout threads (config["n_rollout_threads"] is
@@ -406,8 +408,7 @@ class Runner:
                 self.logger.log_tabular("Eval/EpCost")
                 self.logger.log_tabular("Train/Epoch", episode)
                 self.logger.log_tabular("Train/TotalSteps", total_num_steps)
-                keys = ("Loss/Loss_reward_critic", "Loss/Loss_cost_critic", "Loss/Loss_actor", "Misc/Reward_critic_norm",
-                        "Misc/Cost_critic_norm", "Misc/Entropy", "Misc/Ratio")
+                keys = self.log_keys
                 for k in keys:
                     if self.use_cost or "ost_critic" not in k:
                         self.logger.log_tabular(k)
@@ -537,9 +538,9 @@ class Runner:
             b.update_factor(factor)
             flat = lambda t: t.reshape(-1, *t.shape[2:])
             args = (flat(b.obs[:-1]), flat(b.rnn_states[0:1]), flat(b.actions), flat(b.masks[:-1]), None, flat(b.active_masks[:-1]))
-            old_logp, _ = self.trainer[a].policy.actor.evaluate_actions(*args)
+            old_logp = self.trainer[a].policy.actor.evaluate_actions(*args)[0]
             self.trainer[a].train(b, logger=self.logger, perm_fn=(lambda it, a=a: perm_fn(a, it)) if perm_fn else None)
-            new_logp, _ = self.trainer[a].policy.actor.evaluate_actions(*args)
+            new_logp = self.trainer[a].policy.actor.evaluate_actions(*args)[0]
             action_prod = torch.prod(torch.exp(new_logp - old_logp).reshape(c["episode_length"], c["n_rollout_threads"], action_dim),
                                      dim=-1, keepdim=True)
             factor = factor * action_prod

@@ -283,3 +283,16 @@ def test_multi_agent_sibling_modules_surface_and_defaults(algo):
     args, _, cfg = multi_agent_args(algo, ["--num-envs", "32", "--seed", "3"])
     assert cfg["algorithm_name"] == algo and cfg["n_rollout_threads"] == 32 and cfg["hidden_size"] == 128
 
+
+def test_macpo_module_surface_and_defaults():
+    from safepo.multi_agent import macpo
+    from safepo.utils.config import multi_agent_args
+    for name in ("MACPO_Policy", "MACPO_Trainer", "Runner", "train", "default_cfg", "mamujoco_cfg"):
+        assert hasattr(macpo, name), name
+    d = macpo.default_cfg
+    assert d["algorithm_name"] == "macpo" and d["conjugate_gradient_iters"] == 10 and d["fraction_coef"] == 0.1 and d["step_fraction"] == 0.5
+    assert "lamda_lagr" not in d and macpo.mamujoco_cfg["layer_N"] == 1 and macpo.mamujoco_cfg["target_kl"] == 0.01
+    args, _, cfg = multi_agent_args("macpo", ["--num-envs", "32", "--cost-limit", "2.0"])
+    assert cfg["algorithm_name"] == "macpo" and cfg["layer_N"] == 1 and cfg["cost_limit"] == 2.0 and cfg["hidden_size"] == 128
+    assert macpo.Runner.log_keys[2] == "Loss/Loss_actor_improve" and "Misc/KL" in macpo.Runner.log_keys
+

@@ -1313,6 +1313,125 @@ def test_ma_happo_mappo_runner_end_to_end_synthetic(dev, tmp_path, algo):
     assert os.path.exists(tmp_path / "run" / "models_seed0" / "critic_agent2.pt")
 
 
+@pytest.mark.parametrize("D,H,nb,O,B", [(20, 32, 3, 5, 97), (48, 128, 2, 6, 1030), (33, 64, 1, 3, 260)])
+def test_ma_network_tangent_pass_vs_autograd(dev, D, H, nb, O, B):
+    """spo_ma_jvp (forward-mode pass: rocBLAS GEMMs + LayerNorm/ELU tangent kernel) against torch.func.jvp on the CPU
+    restatement, and the Fisher-vector product built from it against the reference's double-backward form."""
+    from torch.func import functional_call, jvp
+    from oracle import ma_restatement as MR
+    from safepo.common.model import MultiAgentActor
+    torch.manual_seed(D + H + nb)
+    cfg = _ma_cfg(dev, hidden_size=H, layer_N=nb - 1)
+    net = MultiAgentActor(cfg, _Sp(D), _Sp(O), dev)
+    with torch.no_grad():
+        net.theta.add_(0.1 * torch.randn_like(net.theta))
+    ref = MR.MANet(D, H, nb, O, True)
+    ref.load_reference_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    x = torch.randn(B, D) * 1.5 + 0.3
+    t = torch.randn(net.theta.numel())
+    names = [n for n, _ in ref.named_parameters()]
+    by_id = {id(p): n for n, p in ref.named_parameters()}
+    order = [by_id[id(p)] for p in ref.ordered_parameters()]
+    prm = {n: p.detach() for n, p in ref.named_parameters()}
+    tan, off = {}, 0
+    for n in order:
+        k = prm[n].numel()
+        tan[n] = t[off:off + k].view_as(prm[n])
+        off += k
+    assert off == t.numel() and set(names) == set(order)
+    tan = {n: tan[n] for n in prm}                      # same pytree structure (key order) as the primals
+    _, want = jvp(lambda pp: functional_call(ref, pp, (x,)), (prm,), (tan,))
+    out, saved = net.net_forward(x.to(dev), keep=True)
+    got = net.net_jvp(saved, t.to(dev))
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=2e-3, atol=2e-4 * float(want.abs().max()))
+    # Fisher-vector product of MACPO: J^T M J p + log_std block + 0.1 p  ==  double backward of the reference's KL expression
+    from safepo.multi_agent.macpo import MACPO_Policy, MACPO_Trainer, default_cfg
+    c2 = dict(default_cfg)
+    c2.update(device=str(dev), hidden_size=H, layer_N=nb - 1)
+    pol = MACPO_Policy(c2, _Sp(D), _Sp(D), _Sp(O))
+    pol.actor.theta.copy_(net.theta)
+    tr = MACPO_Trainer(c2, pol)
+    _, saved = pol.actor.net_forward(x.to(dev), keep=True)
+    std = tr._std()
+    m_diag = (2.0 / (1e-8 + 2.0 * std * std)).reshape(1, -1)
+    got_f = tr.fisher_vector_product(saved, t.to(dev), m_diag, tr._kl_hessian_logstd()).cpu()
+    orc = MR.OracleMATrainer({"actor_lr": 1e-3, "critic_lr": 1e-3, "opti_eps": 1e-5, "weight_decay": 0.0}, ref, MR.MANet(D, H, nb, 1, False),
+                             MR.MANet(D, H, nb, 1, False), algo="macpo")
+    want_f = orc._fvp({"obs": x, "actions": torch.zeros(B, O)}, t)
+    np.testing.assert_allclose(got_f.numpy(), want_f.numpy(), rtol=5e-3, atol=5e-4 * float(want_f.abs().max()))
+
+
+@pytest.mark.parametrize("tag", ["safe", "unsafe", "mamujoco", "recover", "deep_safe"])
+def test_ma_macpo_trainer_vs_reference_golden(dev, golden_dir, tag):
+    """Two MACPO_Trainer.trpo_update steps against the reference's own trainer (tests/golden/ma_macpo.npz), five settings
+    covering optim cases 0-3: critic losses / norms, KL, improvement, expected improvement, the cost surrogate,
+    (lam, nu), both conjugate-gradient solutions, the step, and the actor after the line search."""
+    from oracle import ma_restatement as MR
+    from safepo.multi_agent.macpo import MACPO_Policy, MACPO_Trainer, default_cfg
+    z = np.load(os.path.join(golden_dir, "ma_macpo.npz"))
+    gc = MR.cfg_from_golden(z, tag)
+    cfg = dict(default_cfg)
+    cfg.update(device=str(dev), **gc)
+    for k in ("hidden_size", "layer_N", "searching_steps", "conjugate_gradient_iters"):
+        cfg[k] = int(gc[k])
+    s = MR.sample_from_golden(z, tag)
+    D, S, A = s["obs"].shape[1], s["share_obs"].shape[1], s["actions"].shape[1]
+    pol = MACPO_Policy(cfg, _Sp(D), _Sp(S), _Sp(A))
+    for nm, net in (("actor", pol.actor), ("critic", pol.critic), ("cost_critic", pol.cost_critic)):
+        pre = f"{tag}_init_{nm}_"
+        net.load_state_dict({k[len(pre):]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith(pre)})
+    tr = MACPO_Trainer(cfg, pol)
+    sample = (s["share_obs"], s["obs"], None, None, s["actions"], s["value_preds"], s["returns"], None, s["active_masks"],
+              s["old_logp"], s["adv"], None, s["factor"], s["cost_preds"], s["cost_returns"], None, s["cost_adv"],
+              s["aver_episode_costs"])
+    sample = tuple(t.to(dev) if torch.is_tensor(t) else t for t in sample)
+    for it in range(2):
+        r = tr.trpo_update(sample)
+        (vl, cgn, kl, improve, expected, _ent, _ratio, cost_loss, cost_gn, wrp, _cp, _cr, bgrad, lam, nu, g_dir, b_dir, x, _mu,
+         _std, bb) = r
+        vn = tr.value_normalizer
+        row = [float(vl), float(cgn), float(kl), float(improve), float(expected), float(cost_loss), float(cost_gn), float(wrp),
+               float(lam), float(nu), float(bb), float(vn.running_mean), float(vn.running_mean_sq), float(vn.debiasing_term)]
+        np.testing.assert_allclose(row, z[f"{tag}_steps"][it], rtol=5e-3, atol=5e-6, err_msg=f"step {it}")
+        for got, key in ((bgrad, "cost_grad"), (g_dir, "g_step_dir"), (b_dir, "b_step_dir"), (x, "x")):
+            want = z[f"{tag}_s{it}_{key}"]
+            np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-2, atol=1e-3 * max(float(np.abs(want).max()), 1e-6),
+                                       err_msg=f"step {it} {key}")
+        np.testing.assert_allclose(pol.actor.theta.cpu().numpy(), z[f"{tag}_s{it}_actor_after"], rtol=2e-3, atol=5e-5)
+    lr = float(gc["critic_lr"])
+    for nm, net in (("critic", pol.critic), ("cost_critic", pol.cost_critic)):
+        pre = f"{tag}_final_{nm}_"
+        want = np.concatenate([z[k].reshape(-1) for k in z.files if k.startswith(pre)])
+        _assert_params_close(net.theta.cpu().numpy(), want, lr, 2, rtol=2e-3, atol=2e-5, what=f"{tag} {nm}")
+
+
+def test_ma_macpo_runner_end_to_end_synthetic(dev, tmp_path):
+    """safepo.multi_agent.macpo.train() on the synthetic env: trust-region actor steps per agent in HAPPO order, the
+    reference's MACPO log columns; KL stays inside the trust region and the run is finite."""
+    import argparse
+    import csv
+    from safepo.multi_agent import macpo
+    cfg = dict(macpo.default_cfg)
+    cfg.update(macpo.mamujoco_cfg)
+    cfg.update(device=str(dev), n_rollout_threads=64, n_eval_rollout_threads=4, episode_length=16, num_env_steps=64 * 16 * 8,
+               hidden_size=64, log_dir=str(tmp_path / "run"), seed=0, critic_lr=3e-3, env_name="SynthMultiAgent-v0",
+               env_kwargs={"trunc_len": 16, "num_agents": 3, "obs_dim": 12, "act_dim": 2}, cost_limit=1.0)
+    args = argparse.Namespace(task="SynthMultiAgent-v0", seed=0, model_dir="")
+    torch.manual_seed(0)
+    runner = macpo.train(args, cfg)
+    rows = list(csv.DictReader(open(tmp_path / "run" / "progress.csv")))
+    assert len(rows) == 8
+    for col in ("Metrics/EpRet", "Metrics/EpCost", "Loss/Loss_reward_critic", "Loss/Loss_cost_critic", "Loss/Loss_actor_improve",
+                "Loss/Loss_actor_expected_improve", "Misc/Reward_critic_norm", "Misc/Cost_critic_norm", "Misc/Entropy", "Misc/Ratio",
+                "Misc/KL", "Time/FPS"):
+        assert col in rows[0], col
+    assert "Loss/Loss_actor" not in rows[0]
+    kls = [float(r["Misc/KL"]) for r in rows]
+    assert np.isfinite(kls).all() and max(kls) < cfg["target_kl"] + 1e-6, kls
+    assert all(np.isfinite(float(r["Metrics/EpRet"])) for r in rows)
+    assert torch.isfinite(runner.policy[0].actor.theta).all()
+
+
 def test_ma_mappolag_runner_end_to_end_synthetic(dev, tmp_path):
     """safepo.multi_agent.mappolag.train() on the synthetic 4-agent env: collect -> insert -> fused GAE/PopArt -> HAPPO
     sequential updates, logger rows and per-agent checkpoints in the reference's formats; the team reward improves."""

@@ -277,6 +277,27 @@ def test_ma_happo_mappo_restatement_vs_reference(golden_dir, tag):
         np.testing.assert_allclose(nets[nm].flat().numpy(), fin[nm].flat().numpy(), rtol=5e-5, atol=5e-7, err_msg=nm)
 
 
+@pytest.mark.parametrize("tag,case", [("safe", 2), ("unsafe", 1), ("mamujoco", 1), ("recover", 0), ("deep_safe", 3)])
+def test_ma_macpo_restatement_vs_reference(golden_dir, tag, case):
+    """MACPO: two reference MACPO_Trainer.trpo_update steps (critic steps, surrogate gradients, two conjugate-gradient solves
+    with the double-backward Fisher product, case analysis, line search) in five settings covering optim cases 0-3."""
+    from oracle import ma_restatement as MR
+    z = _load(golden_dir, "ma_macpo.npz")
+    nets, cfg, s = MR.nets_from_golden(z, tag), MR.cfg_from_golden(z, tag), MR.sample_from_golden(z, tag)
+    tr = MR.OracleMATrainer(cfg, nets["actor"], nets["critic"], nets["cost_critic"], algo="macpo")
+    for it in range(2):
+        rec = tr.ppo_update(s)
+        assert rec["case"] == case
+        np.testing.assert_allclose(rec["row"], z[f"{tag}_steps"][it], rtol=2e-3, atol=2e-6)
+        for k in ("g_dir", "b_dir", "x"):
+            want = z[f"{tag}_s{it}_{'g_step_dir' if k == 'g_dir' else 'b_step_dir' if k == 'b_dir' else 'x'}"]
+            np.testing.assert_allclose(rec[k].numpy(), want, rtol=5e-3, atol=2e-4 * max(np.abs(want).max(), 1e-6), err_msg=k)
+        np.testing.assert_allclose(nets["actor"].flat().numpy(), z[f"{tag}_s{it}_actor_after"], rtol=1e-3, atol=2e-5)
+    fin = MR.nets_from_golden(z, tag, "final")
+    for nm in ("critic", "cost_critic"):
+        np.testing.assert_allclose(nets[nm].flat().numpy(), fin[nm].flat().numpy(), rtol=2e-5, atol=2e-7, err_msg=nm)
+
+
 def test_ma_runner_restatement_vs_reference_runner_trace(golden_dir):
     """Three episodes of the reference mappolag Runner (compute() with PopArt-denormalised masked GAE, then
     HAPPO-sequential train()) replayed through the restatement with the recorded buffers, agent order and shuffles."""
