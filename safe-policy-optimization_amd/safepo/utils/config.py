@@ -76,6 +76,9 @@ multi_agent_velocity_map = {
 }
 
 
+multi_agent_goal_tasks = [f"Safety{robot}MultiGoal{level}-v0" for robot in ("Point", "Ant") for level in (0, 1, 2)]
+
+
 def multi_agent_args(algo: str, argv=None):
     """CLI of the multi-agent scripts (reference safepo/utils/config.py:194-278): same flags; the training config
     starts from the algorithm's defaults (the reference's marl_cfg/<algo>/config.yaml, here a dict in the algorithm
@@ -103,7 +106,7 @@ def multi_agent_args(algo: str, argv=None):
         raise NotImplementedError("Isaac Gym tasks need the isaacgym package (not part of this build)")
     mod = importlib.import_module(f"safepo.multi_agent.{algo}")
     cfg_train = dict(mod.default_cfg)
-    if args.task in multi_agent_velocity_map or args.task.startswith("Synth"):
+    if args.task in multi_agent_velocity_map or args.task in multi_agent_goal_tasks or args.task.startswith("Synth"):
         cfg_train.update(mod.mamujoco_cfg)
         if args.task in multi_agent_velocity_map:
             args.agent_conf = multi_agent_velocity_map[args.task]["agent_conf"]

@@ -296,3 +296,26 @@ def test_macpo_module_surface_and_defaults():
     assert cfg["algorithm_name"] == "macpo" and cfg["layer_N"] == 1 and cfg["cost_limit"] == 2.0 and cfg["hidden_size"] == 128
     assert macpo.Runner.log_keys[2] == "Loss/Loss_actor_improve" and "Misc/KL" in macpo.Runner.log_keys
 
+
+def test_benchmark_launchers_build_the_reference_command_lines():
+    """single_agent/benchmark.py and multi_agent/benchmark.py: one command per (seed, task, algo) with the reference's
+    flags, seeds start + 1000 * k, runs dealt round-robin over the GPUs."""
+    from safepo.multi_agent import benchmark as mb
+    from safepo.single_agent import benchmark as sb
+    a = sb.parse_args(["--tasks", "SynthSafe-v0", "SafetyDoggoGoal1-v0", "--algo", "ppo_lag", "cpo", "--num-seeds", "2", "--start-seed", "5",
+                       "--total-steps", "4096", "--num-envs", "16", "--steps-per-epoch", "2048", "--workers", "0"])
+    cmds = sb.build_commands(a, n_gpus=4)
+    assert len(cmds) == 2 * 2 * 2
+    assert cmds[0].split()[1].endswith("single_agent/ppo_lag.py") and "--seed 5 " in cmds[0] and "--write-terminal False" in cmds[0]
+    assert "--total-steps 4096 --num-envs 16 --steps-per-epoch 2048 --device-id 0" in cmds[0]
+    assert "--seed 1005 " in cmds[-1] and cmds[-1].split()[1].endswith("cpo.py")
+    doggo = [c for c in cmds if "Doggo" in c]
+    assert all("--total-steps 100000000 --num-envs 20 --steps-per-epoch 200000" in c for c in doggo)
+    assert [c.rsplit(" ", 1)[1] for c in cmds] == ["0", "1", "2", "3", "0", "1", "2", "3"]
+    assert sb.main(["--tasks", "SynthSafe-v0", "--algo", "pg", "--num-seeds", "1", "--workers", "0"])[0].count("pg.py") == 1
+    m = mb.parse_args(["--tasks", "SynthMultiAgent-v0", "--num-seeds", "1", "--total-steps", "1024", "--num-envs", "8"])
+    mc = mb.build_commands(m, n_gpus=2)
+    assert [c.split()[1].rsplit("/", 1)[1] for c in mc] == ["macpo.py", "mappo.py", "mappolag.py", "happo.py"]
+    assert all("--headless True --total-steps 1024 --num-envs 8" in c for c in mc)
+    assert len(sb.NAVI_TASKS) == 40 and sb.NAVI_TASKS[0] == "SafetyAntButton1-v0" and len(sb.VEL_TASKS) == 6
+

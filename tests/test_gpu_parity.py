@@ -1432,6 +1432,36 @@ def test_ma_macpo_runner_end_to_end_synthetic(dev, tmp_path):
     assert torch.isfinite(runner.policy[0].actor.theta).all()
 
 
+def test_benchmark_launcher_then_evaluate_round_trip(dev, tmp_path, monkeypatch):
+    """The callers either side of the path (reference safepo/single_agent/benchmark.py, multi_agent/benchmark.py,
+    evaluate.py): launch one single-agent and one multi-agent run as subprocesses through the sweep launchers, then
+    evaluate the saved checkpoints through benchmark_eval / single_runs_eval."""
+    import glob
+    from safepo import evaluate
+    from safepo.multi_agent import benchmark as mb
+    from safepo.single_agent import benchmark as sb
+    work = tmp_path / "w"
+    work.mkdir()
+    monkeypatch.chdir(work)                      # the scripts log under ../runs relative to where they are started
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.setenv("PYTHONPATH", os.pathsep.join([os.path.join(root, "safe-policy-optimization_amd"), os.environ.get("PYTHONPATH", "")]))
+    sb.main(["--tasks", "SynthSafe-v0", "--algo", "ppo_lag", "--num-seeds", "1", "--workers", "1", "--experiment", "bench",
+             "--total-steps", "2048", "--num-envs", "16", "--steps-per-epoch", "1024"])
+    runs = glob.glob(str(tmp_path / "runs" / "bench" / "SynthSafe-v0" / "ppo_lag" / "seed-000-*"))
+    assert len(runs) == 1 and os.path.exists(os.path.join(runs[0], "torch_save")) and os.path.exists(os.path.join(runs[0], "progress.csv"))
+    res = evaluate.benchmark_eval(["--benchmark-dir", str(tmp_path / "runs" / "bench"), "--eval-episodes", "2",
+                                   "--save-dir", str(tmp_path / "results")])
+    (rm, rs, cm, cs) = res[("SynthSafe-v0", "ppo_lag")]
+    assert np.isfinite([rm, rs, cm, cs]).all() and cm >= 0
+    assert "ppo_lag in SynthSafe-v0 evaluation reward" in open(tmp_path / "results" / "eval_result.txt").read()
+    mb.main(["--tasks", "SynthMultiAgent-v0", "--algo", "mappolag", "--num-seeds", "1", "--workers", "1", "--experiment", "mabench",
+             "--total-steps", "8000", "--num-envs", "8"])
+    mruns = glob.glob(str(tmp_path / "runs" / "mabench" / "SynthMultiAgent-v0" / "mappolag" / "seed-000-*"))
+    assert len(mruns) == 1
+    r, c = evaluate.single_runs_eval(mruns[0], 2)
+    assert np.isfinite([r, c]).all()
+
+
 def test_ma_mappolag_runner_end_to_end_synthetic(dev, tmp_path):
     """safepo.multi_agent.mappolag.train() on the synthetic 4-agent env: collect -> insert -> fused GAE/PopArt -> HAPPO
     sequential updates, logger rows and per-agent checkpoints in the reference's formats; the team reward improves."""
