@@ -37,7 +37,7 @@ extern "C" {
 #define SPO_HIDDEN 64          /* hidden width the MLP kernels are specialised for          */
 #define SPO_MAX_ACT 16         /* act_dim <= 16 (one MFMA output tile)                       */
 #define SPO_MAX_OBS 128        /* obs_dim <= 128                                             */
-#define SPO_GAE_PARTIAL_STRIDE 4 /* doubles per block written by spo_gae_fused               */
+#define SPO_GAE_PARTIAL_STRIDE 16 /* doubles per block written by spo_gae_fused: 4 waves x 4 */
 
 int spo_abi_version(void);
 const char* spo_last_error(void);
@@ -48,7 +48,8 @@ const char* spo_last_error(void);
  * delta in fp32 (three separately rounded ops, gamma rounded to fp32), segmented backward
  * scan in fp64 with discount gamma*lam formed in double, results rounded to fp32.
  * Steps after the last seg_end of a row (unfinished path) get adv = target = 0.
- * partials: [spo_gae_num_blocks(N,T)][4] doubles {sum adv_r, sum adv_r^2, sum adv_c, count}. */
+ * partials: [spo_gae_num_blocks(N,T)][SPO_GAE_PARTIAL_STRIDE] doubles: one row {sum adv_r, sum adv_r^2, sum adv_c,
+ * count} per wave of each workgroup (no block-level combine inside the scan; spo_adv_reduce adds the rows). */
 int spo_gae_num_blocks(int64_t num_envs, int64_t T);
 int spo_gae_fused(const float* reward, const float* cost, const float* value_r, const float* value_c,
                   const uint8_t* seg_end, const float* boot_r, const float* boot_c,

@@ -267,32 +267,39 @@ __global__ __launch_bounds__(256) void gae_kernel(GaeArgs a) {
     }
   }
 
-  // block reduction in a fixed order -> partials[block][4] = {sum adv_r, sum adv_r^2, sum adv_c, count}
+  // per-WAVE partial sums in a fixed order -> partials[block][wave][4] = {sum adv_r, sum adv_r^2, sum adv_c, count}.
+  // No LDS stage and no barrier: the tail of the launch is a handful of DPP adds and one 32-byte row per wave
+  // (the block-level combine cost 0.6 us of the 4.5 us launch at 4096 x 128; spo_adv_reduce adds the rows in a fixed order).
   if (a.ablate & 1) return;
-  s_r = wave_sum_to_lane63(s_r);
-  s_r2 = wave_sum_to_lane63(s_r2);
-  s_c = wave_sum_to_lane63(s_c);
-  __shared__ double red[4][3];
-  if (lane == 63) { red[wave][0] = s_r; red[wave][1] = s_r2; red[wave][2] = s_c; }
-  __syncthreads();
-  if (threadIdx.x < 3) {
-    const double t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    a.partials[(int64_t)blockIdx.x * SPO_GAE_PARTIAL_STRIDE + threadIdx.x] = t;
-  } else if (threadIdx.x == 3) {
-    // number of elements this block covered (every element of a valid row is counted)
-    constexpr int ROWS_PER_BLOCK = 4 * ROWS_PER_WAVE;
-    int64_t rows = a.N - (int64_t)blockIdx.x * ROWS_PER_BLOCK;
-    rows = rows < 0 ? 0 : (rows > ROWS_PER_BLOCK ? ROWS_PER_BLOCK : rows);
-    a.partials[(int64_t)blockIdx.x * SPO_GAE_PARTIAL_STRIDE + 3] = (double)(rows * T);
+  double* const prow = a.partials + ((int64_t)blockIdx.x * 4 + wave) * 4;
+  int64_t wrows = a.N - ((int64_t)blockIdx.x * 4 + wave) * ROWS_PER_WAVE;
+  wrows = wrows < 0 ? 0 : (wrows > ROWS_PER_WAVE ? ROWS_PER_WAVE : wrows);
+  if constexpr (RC) {
+    static_assert(!RC || LPR == 32, "RC layout: lanes 0-31 scan the reward, lanes 32-63 the cost of the wave's row");
+    // after row_shr 1,2,4,8 and row_bcast:15 lane 31 holds the sum of lanes 0-31 and lane 63 that of lanes 32-63
+    double x = (ksel == 0) ? s_r : s_c, y = s_r2;
+    x = dpp_add_d<0x111, 0xf>(x); y = dpp_add_d<0x111, 0xf>(y);
+    x = dpp_add_d<0x112, 0xf>(x); y = dpp_add_d<0x112, 0xf>(y);
+    x = dpp_add_d<0x114, 0xf>(x); y = dpp_add_d<0x114, 0xf>(y);
+    x = dpp_add_d<0x118, 0xf>(x); y = dpp_add_d<0x118, 0xf>(y);
+    x = dpp_add_d<0x142, 0xa>(x); y = dpp_add_d<0x142, 0xa>(y);
+    if (lane == 31) { prow[0] = x; prow[1] = y; }
+    if (lane == 63) { prow[2] = x; prow[3] = (double)(wrows * T); }
+  } else {
+    s_r = wave_sum_to_lane63(s_r);
+    s_r2 = wave_sum_to_lane63(s_r2);
+    s_c = wave_sum_to_lane63(s_c);
+    if (lane == 63) { prow[0] = s_r; prow[1] = s_r2; prow[2] = s_c; prow[3] = (double)(wrows * T); }
   }
 }
 
 __global__ __launch_bounds__(256) void adv_reduce_kernel(const double* partials, int nb, double* sums) {
-  // fixed-order tree: thread i sums partials i, i+256, ...; then a shared-memory tree.
+  // fixed-order tree over the nb * 4 per-wave rows: thread i sums rows i, i+256, ...; then a shared-memory tree.
   __shared__ double sh[4][256];
   double acc[4] = {0, 0, 0, 0};
-  for (int b = threadIdx.x; b < nb; b += 256)
-    for (int k = 0; k < 4; ++k) acc[k] += partials[(int64_t)b * SPO_GAE_PARTIAL_STRIDE + k];
+  const int nrows = nb * (SPO_GAE_PARTIAL_STRIDE / 4);
+  for (int b = threadIdx.x; b < nrows; b += 256)
+    for (int k = 0; k < 4; ++k) acc[k] += partials[(int64_t)b * 4 + k];
   for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] = acc[k];
   __syncthreads();
   for (int s = 128; s >= 1; s >>= 1) {

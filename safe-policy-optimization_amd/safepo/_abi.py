@@ -40,6 +40,7 @@ class MaLossCfg(Structure):
 P = c_void_p
 # name -> (restype, argtypes); must list every symbol declared in include/safepo_hip.h
 ACTOR_LOSS_CLIP, ACTOR_LOSS_KL_PENALTY = 0, 1      # include/safepo_hip.h SPO_ACTOR_LOSS_*
+GAE_PARTIAL_STRIDE = 16                            # include/safepo_hip.h SPO_GAE_PARTIAL_STRIDE (doubles per workgroup)
 
 PROTOTYPES = {
     "spo_abi_version": (c_int, []),

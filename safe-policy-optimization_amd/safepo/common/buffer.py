@@ -41,7 +41,8 @@ class VectorizedOnPolicyBuffer:
         self.boot_r = torch.zeros((N, T), **f32)
         self.boot_c = torch.zeros((N, T), **f32)
         self.adv_mix = torch.zeros((N, T), **f32)
-        self._partials = torch.zeros((max(self._lib.spo_gae_num_blocks(N, T), 1), 4), dtype=torch.float64, device=dev)
+        self._partials = torch.zeros((max(self._lib.spo_gae_num_blocks(N, T), 1), _abi.GAE_PARTIAL_STRIDE), dtype=torch.float64,
+                                     device=dev)
         self.sums = torch.zeros(4, dtype=torch.float64, device=dev)
         self.stats = torch.zeros(3, **f32)
         self._gamma, self._lam, self._lam_c = gamma, lam, lam_c

@@ -36,6 +36,8 @@ def test_every_declared_symbol_is_exported_and_bound(built_lib):
     assert lib.spo_param_count(60, 8) == 24850
     assert [lib.spo_param_offset(60, 8, k) for k in range(3)] == [0, 8129, 16258]
     # 4 rows per block while the buffer is cache-resident (reward / cost scans in separate lane groups), 8 when it streams
+    raw = open(os.path.join(ROOT, "include", "safepo_hip.h")).read()
+    assert int(re.search(r"#define SPO_GAE_PARTIAL_STRIDE (\d+)", raw).group(1)) == _abi.GAE_PARTIAL_STRIDE == 16
     assert lib.spo_gae_num_blocks(4096, 128) == 1024
     assert lib.spo_gae_num_blocks(262144, 128) == 32768
 
