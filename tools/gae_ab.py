@@ -10,8 +10,9 @@ for k in ("reward", "cost", "value_r", "value_c"):
     b.data[k].normal_()
 b.seg_end.zero_(); b.seg_end[:, 63] = 1; b.seg_end[:, 127] = 1
 from safepo import _abi
-if os.environ.get("SPO_GAE_ABLATE"):
-    _abi.load().spo_debug_gae_variant(16 * int(os.environ["SPO_GAE_ABLATE"]))      # 1 no stats, 2 no lane scan, 4 no stores
+if os.environ.get("SPO_GAE_ABLATE") or os.environ.get("SPO_GAE_VARIANT"):
+    # ablate: 1 no stats, 2 no lane scan, 4 no stores; variant: 1 eager bootstrap loads, 2 predicated
+    _abi.load().spo_debug_gae_variant(16 * int(os.environ.get("SPO_GAE_ABLATE", "0")) + int(os.environ.get("SPO_GAE_VARIANT", "0")))
 b.compute_gae(None)
 reps = 200 if N <= 8192 else 20
 ts = sorted(b.time_scan(reps) * 1e6 for _ in range(7))

@@ -7,6 +7,7 @@ import csv
 import glob
 import json
 import os
+import re
 import statistics
 import sys
 
@@ -34,7 +35,8 @@ def main():
             if "gae_kernel" not in name:
                 continue
             grid = int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1)
-            per.setdefault((name.split("(")[0].split("::")[-1], grid), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+            m = re.search(r"gae_kernel<[^>]*>", name)
+            per.setdefault((m.group(0) if m else "gae_kernel", grid), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     out = {"command": command, "per_kernel_and_grid_size": {}}
     for (name, grid), v in sorted(per.items()):
         out["per_kernel_and_grid_size"][f"{name} grid={grid}"] = {

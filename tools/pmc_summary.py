@@ -17,7 +17,7 @@ res = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate pass
 for g in sorted(f):
     # 256 threads per block; 4 rows per block for the cache-resident variant (reward / cost scans in separate lane groups:
     # bench.py's 4096-env launch), 8 rows per block otherwise (the 262 144-env streaming launch)
-    n_envs = g // 256 * 4 if g <= 262144 * 2 else g // 256 * 8
+    n_envs = g // 64 if (g // 64) * 128 <= (4 << 20) else g // 32
     algo = 33.0 * n_envs * 128
     fb, wb = f[g] * 1024 * 2, w.get(g, 0.0) * 1024
     res["launches"][str(n_envs)] = {"grid": g, "fetch_bytes_corrected": fb, "write_bytes": wb, "hbm_bytes": fb + wb,
