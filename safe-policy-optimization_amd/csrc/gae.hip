@@ -51,7 +51,7 @@ struct GaeArgs {
   double* partials;
   int64_t N; int64_t T;
   float gamma32; double disc_r; double disc_c;
-  int ablate;     // debug timing knob: 1 skip stats reduction, 2 skip cross-lane scan, 4 skip stores
+  int ablate;     // debug timing knob: 1 skip stats reduction, 2 skip cross-lane scan, 4 skip stores, 8 no loads/stores
   int plain_stores;   // A/B knob (env SPO_GAE_PLAIN_STORES=1): ordinary stores instead of the write-through ones
 };
 
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void gae_kernel(GaeArgs a) {
   const int ksel = RC ? (grp_id & 1) : 0;                     // RC: 0 = reward scan, 1 = cost scan
   const int sl = lane % LPR;
   const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * ROWS_PER_WAVE + sub;
-  const bool row_ok = row < a.N;
+  const bool row_ok = row < a.N && !(a.ablate & 8);           // ablate 8: no loads, no stores (launch floor)
   const int64_t T = a.T;
   const int64_t rbase = row * T;
 
