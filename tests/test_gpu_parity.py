@@ -555,6 +555,54 @@ def test_pcpo_update_vs_reference_main_trace(dev, golden_dir):
     _assert_params_close(pol.theta.cpu().numpy(), ref_final, 1e-3, 12, rtol=5e-3, atol=5e-5, what="final theta")
 
 
+def test_cpo_critic_fit_two_launch_form_vs_oracle_and_one_launch_form(dev, monkeypatch):
+    """Critic fit at the reference batch of 128 on one GPU: two co-resident persistent launches, each with 64 of every 128
+    rows, exchanging the gradient inside the step (CPOEngine._split_setup).  Against the CPU restatement of
+    cpo.py:534-571 (incl. the stale actor gradient in the joint clip) and against the one-launch form of the same steps."""
+    from safepo.single_agent.cpo import CPOEngine, default_cfg
+    from safepo.common.model import ActorVCritic
+    M, D, A, iters = 2048, 60, 8, 3
+    obs, _act, _lp, tgt_r, tgt_c, _adv = _synthetic_update_problem(M, D, A, seed=21)
+    g = torch.Generator().manual_seed(5)
+    perms = [torch.randperm(M, generator=g).to(torch.int32) for _ in range(iters)]
+    cfg = dict(default_cfg)
+    cfg.update(learning_iters=iters, batch_size=128)
+
+    def run(split: bool):
+        monkeypatch.setenv("SPO_CPO_SPLIT", "1" if split else "0")
+        torch.manual_seed(11)
+        pol = ActorVCritic(D, A).to(dev)
+        eng = CPOEngine(pol, 1, M, cfg, dev)
+        b = eng.buffer
+        b.data["obs"].copy_(obs.view(1, M, D)); b.data["target_value_r"].copy_(tgt_r.view(1, M)); b.data["target_value_c"].copy_(tgt_c.view(1, M))
+        eng.stale_sq.fill_(2500.0)                     # a stale actor gradient of norm 50: the joint clip (40) is active
+        init = {k: v.cpu().clone() for k, v in pol.state_dict().items()}
+        fit = eng.critic_fit(perm_fn=lambda it: perms[it].to(dev))
+        assert (eng._split is not False and eng._split is not None) == split
+        return init, pol.theta.cpu().clone(), torch.cat(fit["losses"], 0).cpu()
+    init, th_split, loss_split = run(True)
+    _, th_one, loss_one = run(False)
+    np.testing.assert_allclose(loss_split.numpy(), loss_one.numpy(), rtol=2e-4, atol=2e-6)
+    _assert_params_close(th_split.numpy(), th_one.numpy(), 1e-3, iters * (M // 128), rtol=2e-4, atol=2e-6, what="split vs one launch")
+    ref = R.OraclePolicy(D, A)
+    ref.load_state_dict(init)
+    # the stale actor gradient: any vector of norm 50 on the actor's .grad (only its norm enters the critics' clip)
+    n_act = sum(p.numel() for p in ref.actor.parameters())
+    for p in ref.actor.parameters():
+        p.grad = torch.full_like(p, 50.0 / np.sqrt(n_act))
+    fitter = R.CriticFitter(ref)
+    want_losses = []
+    for it in range(iters):
+        pm = perms[it].long()
+        for k in range(M // 128):
+            idx = pm[k * 128:(k + 1) * 128]
+            want_losses.append(fitter.minibatch_step(obs[idx], tgt_r[idx], tgt_c[idx]))
+    np.testing.assert_allclose(loss_split.numpy(), np.asarray(want_losses), rtol=2e-3, atol=1e-5)
+    want = torch.cat([p.detach().reshape(-1) for p in ref.parameters()]).numpy()
+    n_crit = th_split.numel() - (n_act)
+    _assert_params_close(th_split.numpy()[:n_crit], want[:n_crit], 1e-3, iters * (M // 128), rtol=2e-3, atol=2e-5, what="split vs oracle")
+
+
 def test_cpo_main_entrypoint_synthetic(dev, tmp_path):
     import argparse
     import csv
