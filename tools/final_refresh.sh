@@ -2,6 +2,10 @@ set -x
 cd $GRAFT_REPO_ROOT
 timeout 300 python bench.py --steps 2 --warmup 1 > gpurun_out/g_bench.json 2> gpurun_out/g_bench.err
 tail -c 300 gpurun_out/g_bench.json
+timeout 200 python bench.py --algo cpo --no-cpu-baseline --steps 3 --warmup 1 > gpurun_out/g_bench_cpo.json 2>/dev/null
+tail -c 400 gpurun_out/g_bench_cpo.json
+timeout 150 python tools/ma_bench.py --episodes 3 2>/dev/null | tail -1 > gpurun_out/g_ma_bench.json
+cat gpurun_out/g_ma_bench.json
 export TMPDIR=/tmp
 cd /tmp && rm -rf /tmp/prof /tmp/pmcf /tmp/pmcw
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /tmp/prof.log 2>&1
