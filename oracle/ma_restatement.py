@@ -421,6 +421,13 @@ def feed_forward_samples(buf: dict, advantages, cost_adv, perm, num_mini_batch: 
 def train_agent(tr: OracleMATrainer, buf: dict, perms, cfg: dict):
     """MAPPO_L_Trainer.train (mappolag.py:201-236): NaN-masked torch.mean / torch.std standardisation of both advantages,
     then learning_iters passes of num_mini_batch ppo_update steps.  Returns the rows the reference stores per pass."""
+    if tr.algo == "macpo":
+        # macpo.py:373-412: plain statistics (+ 1e-5) for both advantages, ONE pass over the minibatches
+        def std_(returns, preds):
+            adv = returns[:-1] - tr.popart.denormalize(preds[:-1])
+            return (adv - torch.mean(adv)) / (torch.std(adv) + 1e-5)
+        advantages, cost_adv = std_(buf["returns"], buf["value_preds"]), std_(buf["cost_returns"], buf["cost_preds"])
+        return [tr.ppo_update(s_)["row"] for s_ in feed_forward_samples(buf, advantages, cost_adv, perms[0], int(cfg["num_mini_batch"]))]
     constrained = tr.algo == "mappolag"
 
     def standardised(returns, preds):

@@ -587,8 +587,8 @@ def golden_ma_macpo():
         print(tag, out[f"{tag}_steps"][:, [2, 3, 7, 8, 9]])
 
 
-def golden_ma_runner_trace():
-    """Three episodes of the reference mappolag Runner.run() (safepo/multi_agent/mappolag.py:252-604) on SynthMAEnv:
+def golden_ma_runner_trace(algo: str = "mappolag", fname: str = "ma_runner_trace.npz", N: int = 6, T: int = 12, EP: int = 3):
+    """Episodes of the reference multi-agent Runner.run() (safepo/multi_agent/{mappolag,happo,macpo}.py) on SynthMAEnv:
     buffers before compute(), returns after it, the agent order and minibatch permutations (recorded from torch.randperm),
     logger rows, multipliers, PopArt statistics and all networks after every episode."""
     import importlib
@@ -598,25 +598,30 @@ def golden_ma_runner_trace():
     if ref_shim.REF_ROOT not in sys.path:
         sys.path.insert(0, ref_shim.REF_ROOT)
     ref_shim._install_stubs()
-    M = importlib.import_module("safepo.multi_agent.mappolag")
-    cfg = yaml.safe_load(open(os.path.join(ref_shim.REF_ROOT, "safepo/multi_agent/marl_cfg/mappolag/config.yaml")))
+    M = importlib.import_module(f"safepo.multi_agent.{algo}")
+    cfg = yaml.safe_load(open(os.path.join(ref_shim.REF_ROOT, f"safepo/multi_agent/marl_cfg/{algo}/config.yaml")))
     cfg.update(cfg["mamujoco"])
-    N, T, EP = 6, 12, 3
-    log_dir = "/tmp/oracle_runs/ma_runner"
+    use_cost = algo in ("mappolag", "macpo")
+    log_dir = f"/tmp/oracle_runs/ma_runner_{algo}"
     shutil.rmtree(log_dir, ignore_errors=True)
     cfg.update(device="cpu", hidden_size=32, n_rollout_threads=N, n_eval_rollout_threads=2, episode_length=T,
                num_env_steps=N * T * EP, learning_iters=3, num_mini_batch=2, use_eval=False, cost_limit=0.3,
-               lagrangian_coef_rate=0.05, actor_lr=2e-3, critic_lr=2e-3, log_dir=log_dir, seed=0, algorithm_name="mappolag",
-               env_name="SynthMA")
+               actor_lr=2e-3, critic_lr=2e-3, log_dir=log_dir, seed=0, algorithm_name=algo, env_name="SynthMA")
+    if algo == "mappolag":
+        cfg.update(lagrangian_coef_rate=0.05)
     torch.manual_seed(5)
     env = SynthMAEnv(N, seed=3, trunc_len=6)
     rec = Recorder()
     runner = M.Runner(env, None, cfg)
-    runner.logger.use_tensorboard = False if hasattr(runner.logger, "use_tensorboard") else None
     A = runner.num_agents
+
+    def nets_of(pol):
+        out = [("actor", pol.actor), ("critic", pol.critic)]
+        if use_cost:
+            out.append(("cost_critic", pol.cost_critic))
+        return out
     for a in range(A):
-        pol = runner.policy[a]
-        for nm, net in (("actor", pol.actor), ("critic", pol.critic), ("cost_critic", pol.cost_critic)):
+        for nm, net in nets_of(runner.policy[a]):
             for k, v in net.state_dict().items():
                 rec.put(f"init_a{a}_{nm}_{k}", v)
     state = {"ep": 0, "perms": []}
@@ -626,19 +631,23 @@ def golden_ma_runner_trace():
         out = real_randperm(n, *a, **k)
         state["perms"].append(out.clone())
         return out
-    real_compute, real_train, real_dump = runner.compute, runner.train, runner.logger.dump_tabular
-    BUF = ("share_obs", "obs", "actions", "action_log_probs", "value_preds", "cost_preds", "rewards", "costs", "masks", "active_masks")
+    real_compute, real_train = runner.compute, runner.train
+    BUF = ["share_obs", "obs", "actions", "action_log_probs", "value_preds", "rewards", "masks", "active_masks"]
+    if use_cost:
+        BUF += ["cost_preds", "costs"]
 
     def compute():
         e = state["ep"]
         for a in range(A):
             for k in BUF:
                 rec.put(f"e{e}_a{a}_{k}", getattr(runner.buffer[a], k))
-            rec.put(f"e{e}_a{a}_aver_episode_costs", runner.buffer[a].aver_episode_costs)
+            if use_cost:
+                rec.put(f"e{e}_a{a}_aver_episode_costs", runner.buffer[a].aver_episode_costs)
         real_compute()
         for a in range(A):
             rec.put(f"e{e}_a{a}_returns", runner.buffer[a].returns)
-            rec.put(f"e{e}_a{a}_cost_returns", runner.buffer[a].cost_returns)
+            if use_cost:
+                rec.put(f"e{e}_a{a}_cost_returns", runner.buffer[a].cost_returns)
 
     def train():
         e = state["ep"]
@@ -656,24 +665,30 @@ def golden_ma_runner_trace():
                 rec.put(f"e{e}_stored_{k.replace('/', '_')}", np.asarray(v, np.float64))
         for a in range(A):
             tr = runner.trainer[a]
-            rec.put(f"e{e}_a{a}_lamda", np.float64(float(tr.lamda_lagr)))
+            if algo == "mappolag":
+                rec.put(f"e{e}_a{a}_lamda", np.float64(float(tr.lamda_lagr)))
             vn = tr.value_normalizer
             rec.put(f"e{e}_a{a}_popart", np.asarray([float(vn.running_mean), float(vn.running_mean_sq), float(vn.debiasing_term)]))
-            for nm, net in (("actor", tr.policy.actor), ("critic", tr.policy.critic), ("cost_critic", tr.policy.cost_critic)):
+            for nm, net in nets_of(tr.policy):
                 for k, v in net.state_dict().items():
                     rec.put(f"e{e}_a{a}_after_{nm}_{k}", v)
         state["ep"] += 1
     runner.compute, runner.train = compute, train
     runner.run()
-    for k in ("clip_param", "entropy_coef", "huber_delta", "value_loss_coef", "max_grad_norm", "actor_lr", "critic_lr", "opti_eps",
-              "weight_decay", "lamda_lagr", "cost_limit", "gamma", "gae_lambda", "lagrangian_coef_rate", "std_x_coef", "std_y_coef",
-              "layer_N", "hidden_size", "learning_iters", "num_mini_batch", "use_policy_active_masks", "episode_length",
-              "n_rollout_threads"):
+    keys = ["clip_param", "entropy_coef", "huber_delta", "value_loss_coef", "max_grad_norm", "actor_lr", "critic_lr", "opti_eps",
+            "weight_decay", "cost_limit", "gamma", "gae_lambda", "std_x_coef", "std_y_coef", "layer_N", "hidden_size",
+            "learning_iters", "num_mini_batch", "use_policy_active_masks", "use_value_active_masks", "episode_length",
+            "n_rollout_threads"]
+    if algo == "mappolag":
+        keys += ["lamda_lagr", "lagrangian_coef_rate"]
+    if algo == "macpo":
+        keys += ["target_kl", "searching_steps", "conjugate_gradient_iters", "step_fraction", "fraction_coef"]
+    for k in keys:
         rec.put(f"cfg_{k}", np.float64(cfg[k]))
     rec.put("meta_agents", np.int64(A))
     rec.put("meta_episodes", np.int64(EP))
-    np.savez_compressed(os.path.join(OUT, "ma_runner_trace.npz"), **rec.a)
-    print("ma_runner_trace.npz", len(rec.a), "arrays")
+    np.savez_compressed(os.path.join(OUT, fname), **rec.a)
+    print(fname, len(rec.a), "arrays", "perms per episode:", len(state["perms"]))
 
 
 if __name__ == "__main__":
@@ -687,6 +702,8 @@ if __name__ == "__main__":
     golden_ma_happo_mappo()
     golden_ma_macpo()
     golden_ma_runner_trace()
+    golden_ma_runner_trace("happo", "ma_runner_trace_happo.npz", N=4, T=8, EP=2)
+    golden_ma_runner_trace("macpo", "ma_runner_trace_macpo.npz", N=4, T=8, EP=2)
     env_kw = dict(obs_dim=60, act_dim=8, p_term=0.03, p_cost=0.3, trunc_len=20)
     golden_trace("ppo_lag", "ppo_lag_trace.npz", num_envs=4, T=48, epochs=3, env_kw=env_kw,
                  cfg_over={"learning_iters": 6, "target_kl": 0.004},

@@ -1536,22 +1536,30 @@ def test_ma_mappolag_runner_end_to_end_synthetic(dev, tmp_path):
     assert float(runner.trainer[0].lamda_lagr) >= 0.0
 
 
-def test_ma_runner_compute_and_train_vs_reference_runner_trace(dev, golden_dir, tmp_path):
-    """Replays three episodes of the reference mappolag Runner (tests/golden/ma_runner_trace.npz): same buffers, agent
-    order and minibatch permutations -> returns / cost returns after compute() (fused GAE + PopArt kernel, next values
-    from the HIP networks), every stored loss / norm / entropy / ratio, multipliers, PopArt statistics and all three
+@pytest.mark.parametrize("algo,fname", [("mappolag", "ma_runner_trace.npz"), ("happo", "ma_runner_trace_happo.npz"),
+                                        ("macpo", "ma_runner_trace_macpo.npz")])
+def test_ma_runner_compute_and_train_vs_reference_runner_trace(dev, golden_dir, tmp_path, algo, fname):
+    """Replays episodes of the reference multi-agent Runner (mappolag / happo / macpo traces): same buffers, agent order and
+    minibatch permutations -> returns (/ cost returns) after compute() (fused GAE + PopArt kernel, next values from the HIP
+    networks), every stored loss / norm / entropy / ratio (/ KL, improvement), multipliers, PopArt statistics and all
     networks of every agent after each episode's HAPPO-sequential training."""
-    from safepo.multi_agent import mappolag
-    z = np.load(os.path.join(golden_dir, "ma_runner_trace.npz"))
+    import importlib
+    M = importlib.import_module(f"safepo.multi_agent.{algo}")
+    z = np.load(os.path.join(golden_dir, fname))
+    use_cost = algo in ("mappolag", "macpo")
     A, EP = int(z["meta_agents"]), int(z["meta_episodes"])
     T, N = int(z["cfg_episode_length"]), int(z["cfg_n_rollout_threads"])
     over = {k[4:]: float(z[k]) for k in z.files if k.startswith("cfg_")}
-    cfg = _ma_cfg(dev, **mappolag.mamujoco_cfg)
-    cfg.update(over)
-    for k in ("hidden_size", "layer_N", "learning_iters", "num_mini_batch", "episode_length", "n_rollout_threads"):
-        cfg[k] = int(cfg[k])
+    cfg = dict(M.default_cfg)
+    cfg.update(M.mamujoco_cfg)
+    cfg.update(device=str(dev), **over)
+    for k in ("hidden_size", "layer_N", "learning_iters", "num_mini_batch", "episode_length", "n_rollout_threads", "searching_steps",
+              "conjugate_gradient_iters"):
+        if k in cfg:
+            cfg[k] = int(cfg[k])
     cfg["use_policy_active_masks"] = bool(cfg["use_policy_active_masks"])
-    cfg.update(log_dir=str(tmp_path / "run"), seed=0, env_name="trace")
+    cfg["use_value_active_masks"] = bool(cfg.get("use_value_active_masks", False))
+    cfg.update(log_dir=str(tmp_path / "run"), seed=0, env_name="trace", algorithm_name=algo)
     D, S, Adim = z["e0_a0_obs"].shape[-1], z["e0_a0_share_obs"].shape[-1], z["e0_a0_actions"].shape[-1]
 
     class _Spaces:
@@ -1559,42 +1567,60 @@ def test_ma_runner_compute_and_train_vs_reference_runner_trace(dev, golden_dir, 
         observation_space = [_Sp(D)] * A
         share_observation_space = [_Sp(S)] * A
         action_space = [_Sp(Adim)] * A
-    runner = mappolag.Runner(_Spaces(), None, cfg)
+    runner = M.Runner(_Spaces(), None, cfg)
+
+    def nets_of(pol):
+        return [("actor", pol.actor), ("critic", pol.critic)] + ([("cost_critic", pol.cost_critic)] if use_cost else [])
     for a in range(A):
-        pol = runner.policy[a]
-        for nm, net in (("actor", pol.actor), ("critic", pol.critic), ("cost_critic", pol.cost_critic)):
+        for nm, net in nets_of(runner.policy[a]):
             pre = f"init_a{a}_{nm}_"
             net.load_state_dict({k[len(pre):]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith(pre)})
+    buf_keys = ["share_obs", "obs", "actions", "action_log_probs", "value_preds", "rewards", "masks", "active_masks"]
+    buf_keys += ["cost_preds", "costs"] if use_cost else []
+    iters = 1 if algo == "macpo" else cfg["learning_iters"]
+    if algo == "mappolag":
+        keys = ("Loss/Loss_reward_critic", "Loss/Loss_cost_critic", "Loss/Loss_actor", "Misc/Reward_critic_norm",
+                "Misc/Cost_critic_norm", "Misc/Entropy", "Misc/Ratio")
+    elif algo == "happo":
+        keys = ("Loss/Loss_reward_critic", "Loss/Loss_actor", "Misc/Reward_critic_norm", "Misc/Entropy", "Misc/Ratio")
+    else:
+        keys = ("Loss/Loss_reward_critic", "Loss/Loss_cost_critic", "Loss/Loss_actor_improve", "Loss/Loss_actor_expected_improve",
+                "Misc/Reward_critic_norm", "Misc/Cost_critic_norm", "Misc/Entropy", "Misc/Ratio", "Misc/KL")
+    loose = algo == "macpo"          # ten CG iterations amplify fp32 reduction-order noise in the step direction
     n_steps = 0
     for e in range(EP):
         for a in range(A):
             b = runner.buffer[a]
-            for k in ("share_obs", "obs", "actions", "action_log_probs", "value_preds", "cost_preds", "rewards", "costs", "masks",
-                      "active_masks"):
+            for k in buf_keys:
                 getattr(b, k).copy_(torch.from_numpy(z[f"e{e}_a{a}_{k}"]))
-            b.aver_episode_costs = torch.from_numpy(z[f"e{e}_a{a}_aver_episode_costs"].copy()).to(dev)
+            if use_cost:
+                b.aver_episode_costs = torch.from_numpy(z[f"e{e}_a{a}_aver_episode_costs"].copy()).to(dev)
         runner.compute()
         for a in range(A):
             np.testing.assert_allclose(runner.buffer[a].returns.cpu().numpy(), z[f"e{e}_a{a}_returns"], rtol=2e-4, atol=2e-5)
-            np.testing.assert_allclose(runner.buffer[a].cost_returns.cpu().numpy(), z[f"e{e}_a{a}_cost_returns"], rtol=2e-4, atol=2e-5)
+            if use_cost:
+                np.testing.assert_allclose(runner.buffer[a].cost_returns.cpu().numpy(), z[f"e{e}_a{a}_cost_returns"], rtol=2e-4, atol=2e-5)
         order = [int(i) for i in z[f"e{e}_agent_order"]]
-        iters = cfg["learning_iters"]
         perm_of = {a: [z[f"e{e}_perm{pos * iters + it}"] for it in range(iters)] for pos, a in enumerate(order)}
         runner.logger.epoch_dict.clear()
         runner.train(order=order, perm_fn=lambda a, it: perm_of[a][it])
         n_steps += iters * cfg["num_mini_batch"]
-        for key in ("Loss/Loss_reward_critic", "Loss/Loss_cost_critic", "Loss/Loss_actor", "Misc/Reward_critic_norm",
-                    "Misc/Cost_critic_norm", "Misc/Entropy", "Misc/Ratio"):
+        for key in keys:
             got = np.asarray(runner.logger.epoch_dict[key], np.float64)
-            np.testing.assert_allclose(got, z[f"e{e}_stored_{key.replace('/', '_')}"], rtol=5e-3, atol=5e-5, err_msg=f"episode {e} {key}")
+            np.testing.assert_allclose(got, z[f"e{e}_stored_{key.replace('/', '_')}"], rtol=2e-2 if loose else 5e-3,
+                                       atol=2e-4 if loose else 5e-5, err_msg=f"episode {e} {key}")
         for a in range(A):
             tr = runner.trainer[a]
-            assert float(tr.lamda_lagr) == pytest.approx(float(z[f"e{e}_a{a}_lamda"]), rel=1e-4)
+            if algo == "mappolag":
+                assert float(tr.lamda_lagr) == pytest.approx(float(z[f"e{e}_a{a}_lamda"]), rel=1e-4)
             np.testing.assert_allclose(tr._popart_state.cpu().numpy(), z[f"e{e}_a{a}_popart"], rtol=1e-3, atol=1e-8)
-            for nm, net in (("actor", tr.policy.actor), ("critic", tr.policy.critic), ("cost_critic", tr.policy.cost_critic)):
+            for nm, net in nets_of(tr.policy):
                 pre = f"e{e}_a{a}_after_{nm}_"
                 want = np.concatenate([z[k].reshape(-1) for k in z.files if k.startswith(pre)])
-                _assert_params_close(net.theta.cpu().numpy(), want, 2e-3, n_steps, rtol=5e-3, atol=5e-5, what=f"episode {e} agent {a} {nm}")
+                if loose and nm == "actor":
+                    np.testing.assert_allclose(net.theta.cpu().numpy(), want, rtol=5e-3, atol=2e-4, err_msg=f"episode {e} agent {a} actor")
+                else:
+                    _assert_params_close(net.theta.cpu().numpy(), want, 2e-3, n_steps, rtol=5e-3, atol=5e-5, what=f"episode {e} agent {a} {nm}")
 
 
 def test_ma_mappolag_data_parallel_two_ranks_one_gpu(dev, tmp_path):
