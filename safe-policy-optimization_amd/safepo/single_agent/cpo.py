@@ -395,6 +395,17 @@ class CPOEngine(PPOLagEngine):
         self._split = st
         return st
 
+    def __del__(self):
+        st = getattr(self, "_split", None)
+        if st:                       # release the two exchange regions of the two-launch critic fit
+            try:
+                torch.cuda.synchronize(self.dev)
+                for own in st["owns"]:
+                    self.lib.spo_p2p_free(own)
+            except Exception:        # noqa: BLE001 -- interpreter shutdown
+                pass
+            self._split = False
+
     def _critic_fit_split(self, st, perm_fn, cfg64, n_mb):
         """learning_iters passes with the two-launch form; None if an exchange timed out (state restored)."""
         c, d, lib = self.cfg, self.buffer.data, self.lib
