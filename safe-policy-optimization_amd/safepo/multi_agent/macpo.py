@@ -150,8 +150,11 @@ class MACPO_Trainer(_base.MAPPO_L_Trainer):
         # ---- surrogate gradients at the old parameters
         mean, saved = actor.net_forward(obs_batch, keep=True)
         std_vec = self._std()
-        ent = 0.5 + 0.5 * np.log(2 * np.pi) + torch.log(std_vec)
-        dist_entropy = ent.sum() if c["use_policy_active_masks"] else ent.mean()      # as MultiAgentActor.evaluate_actions
+
+        def entropy_of(std):                          # Normal.entropy of the state-independent sigma, as MultiAgentActor.evaluate_actions
+            ent = 0.5 + 0.5 * np.log(2 * np.pi) + torch.log(std)
+            return ent.sum() if c["use_policy_active_masks"] else ent.mean()
+        dist_entropy = entropy_of(std_vec)
         reward_loss, reward_loss_grad = self._surrogate_grad(saved, mean, actions_batch, old_lp, adv, factor, active)
         neg_cost_loss, neg_cost_grad = self._surrogate_grad(saved, mean, actions_batch, old_lp, cadv, factor, active)
         cost_loss, cost_loss_grad = -neg_cost_loss, -neg_cost_grad
@@ -233,7 +236,9 @@ class MACPO_Trainer(_base.MAPPO_L_Trainer):
             new_reward_loss = -(w * adv).mean()
             new_cost_loss = (w * cadv).mean()
             loss_improve = new_reward_loss - reward_loss
-            kl = self.kl_divergence(mu, self._std().reshape(1, -1), mu_old, std_old).mean()
+            std_new = self._std()
+            dist_entropy = entropy_of(std_new)         # the reference returns the entropy of the last parameters it tried
+            kl = self.kl_divergence(mu, std_new.reshape(1, -1), mu_old, std_old).mean()
             if (float(kl) < tkl and (float(loss_improve) < 0 if optim_case > 1 else True)
                     and float(new_cost_loss - cost_loss) <= max(-rescale_constraint_val, 0)):
                 flag = True
