@@ -159,12 +159,20 @@ class PeerExchange:
         if not self.ok:
             return False
         _abi = self._abi
+        import time
+        torch.cuda.synchronize(self.device)
+        self.comm.barrier()                      # the ranks enter together, so the wall time below is the exchange itself
+        t0 = time.perf_counter()
         _abi.check(self.lib.spo_p2p_selftest(self.rank, self.world, self.regions, self.step & 0xFFFFFFFF, iters,
                                              _abi.ptr(self._result), _abi.stream_ptr()), "spo_p2p_selftest")
         self.step += iters
         bad, timeout = self._result.tolist()
+        self.last_selftest_s = time.perf_counter() - t0
+        # an exchange that works but crawls (peers time-sliced on a shared GPU: one scheduler quantum per hand-off) is as
+        # useless as one that fails: `iters` rounds take a few milliseconds when every rank's kernel is resident
+        crawling = self.last_selftest_s > max(2.0, 0.01 * iters)
         coll_dev = self.device if dist.get_backend(self.comm.group) == "nccl" else torch.device("cpu")
-        flag = torch.tensor([1.0 if (bad == 0 and timeout == 0) else 0.0], device=coll_dev)
+        flag = torch.tensor([1.0 if (bad == 0 and timeout == 0 and not crawling) else 0.0], device=coll_dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.comm.group)
         self.ok = bool(flag.item() == 1.0)
         self.last_selftest = (bad, timeout)
