@@ -321,3 +321,15 @@ def test_benchmark_launchers_build_the_reference_command_lines():
     assert all("--headless True --total-steps 1024 --num-envs 8" in c for c in mc)
     assert len(sb.NAVI_TASKS) == 40 and sb.NAVI_TASKS[0] == "SafetyAntButton1-v0" and len(sb.VEL_TASKS) == 6
 
+
+def test_evaluate_picks_the_newest_checkpoint_numerically(tmp_path):
+    """evaluate.py:40-47 sorts checkpoint names as strings (model9.pt after model10.pt); the epoch number decides here."""
+    from safepo import evaluate
+    d = tmp_path / "torch_save"
+    d.mkdir()
+    for n in ("model2.pt", "model10.pt", "model9.pt", "notes.txt"):
+        (d / n).write_bytes(b"")
+    assert os.path.basename(evaluate._latest(str(d), ".pt")) == "model10.pt"
+    assert evaluate._latest(str(d), ".pkl") is None
+    assert evaluate.MULTI_AGENT_ALGOS == ("macpo", "mappo", "mappolag", "happo")
+
