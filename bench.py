@@ -10,9 +10,14 @@ of 8192 minibatches of 64 (default_cfg of the reference, ppo_lag.py:45-52; KL ea
 disabled so the work per step is fixed).  N > 1: one process per GPU, 4096 envs per
 rank (weak scaling); the per-minibatch gradient all-reduce runs inside the persistent update kernel over
 IPC-mapped peer regions (xGMI), or through RCCL between kernels when peer mapping is unavailable.
-Prints ONE JSON line (rank 0) with the driver's fields plus `roofline` (GAE scan kernel, HBM
-bound, 33 algorithmic bytes per (env, step)) and `cpu_baseline` (oracle port of the reference
-loop timed on host cores, rank 0 at N=1 only).
+Prints ONE JSON line (rank 0) with the driver's fields plus
+  `roofline`      GAE scan kernel at the headline size (HBM bound by its algorithmic bytes, 33 B per (env, step) + 8 B per
+                  path end); the 17 MB buffer is Infinity-Cache resident, which the entry says; `achieved` = bytes / mean
+                  per-dispatch duration (HIP events around every launch: the figure rocprofv3 --kernel-trace reports);
+  `roofline_hbm_streaming`  the same kernel on a 1.1 GB buffer that cannot sit in the 256 MiB Infinity Cache: the HBM claim;
+  `cpu_baseline`  oracle port of the reference loop timed on this box's host cores (rank 0, N=1 only) + the unmodified
+                  reference's own figures recorded in the build container (profiles/r02/cpu_reference_timing.json);
+  `config3_cpo`   BASELINE config 3 (CPO, same sizes) with its own CPU baseline, N=1 only.
 """
 from __future__ import annotations
 
@@ -32,85 +37,85 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 GAE_BYTES_PER_ELEM = 33.0       # 4 f32 in + 1 u8 mask + 4 f32 out
-GAE_REPS = 100                   # back-to-back launches per timed epoch (event timing cannot resolve one ~10 us launch)
+GAE_REPS = 100                   # back-to-back launches per hipGraph replay
+GAE_DISPATCHES = 50              # individually event-bracketed launches per timed epoch
+PEER_EXCHANGE_USED = [False]     # set by run_epochs on rank 0 (N > 1): which form of the minibatch exchange ran
 
 
-def cpu_baseline(sample_envs: int, T: int, threads: int = 4):
-    """Oracle port of the reference epoch (oracle/restatement.ppo_lag_epoch_port: per-env Python
-    store loop, per-path Python GAE, DataLoader minibatches, torch CPU) on a bounded sample of the
-    same workload: `sample_envs` envs x T steps, full default_cfg (batch 64, 40 iterations)."""
+def recorded_reference(algo: str):
+    """Figures of the UNMODIFIED reference main() recorded in the build container by oracle/time_reference.py (the
+    reference tree cannot travel to the GPU box).  Provenance (box, torch, command) is carried along."""
+    path = os.path.join(ROOT, "profiles", "r02", "cpu_reference_timing.json")
+    try:
+        recs = [r for r in json.load(open(path)) if r.get("algo") == algo]
+    except Exception:
+        return None
+    return [{k: r.get(k) for k in ("num_envs", "num_steps", "env_steps_per_s", "time_rollout_s", "time_update_s", "threads",
+                                   "port_env_steps_per_s", "port_over_reference", "box", "date", "what")} for r in recs] or None
+
+
+def cpu_baseline(sample_envs: int, T: int, threads: int = 4, algo: str = "ppo_lag"):
+    """Oracle port of the reference epoch (oracle/restatement.{ppo_lag,cpo}_epoch_port: per-env Python store loop, per-path
+    Python GAE, DataLoader minibatches, torch CPU) on a bounded sample of the same workload: `sample_envs` envs x T steps,
+    full default_cfg (ppo_lag: batch 64, 40 iterations; cpo: 33 FVPs, line search, critic fit batch 128 x 10)."""
     from collections import deque
     from oracle import restatement as R
     from oracle.synth_env import SynthEnv
     torch.set_num_threads(threads)
     torch.manual_seed(0)
-    cfg = {"gamma": 0.99, "target_kl": float("inf"), "batch_size": 64, "learning_iters": 40}
     env = SynthEnv(sample_envs, 60, 8, seed=0, p_term=0.0, trunc_len=64)
     pol = R.OraclePolicy(60, 8)
-    upd = R.PPOLagUpdater(pol, epochs=1)
-    lag = R.OracleLagrange(25.0, 0.001, 0.035)
     stats = R.StatsLog()
     obs, _ = env.reset()
     obs = torch.as_tensor(obs)
     timers = {}
+    dq = (deque(maxlen=50), deque(maxlen=50), deque(maxlen=50))
+    acc = (np.zeros(sample_envs), np.zeros(sample_envs), np.zeros(sample_envs))
     t0 = time.time()
-    R.ppo_lag_epoch_port(env, pol, upd, lag, obs, sample_envs, T, stats,
-                         (deque(maxlen=50), deque(maxlen=50), deque(maxlen=50)),
-                         (np.zeros(sample_envs), np.zeros(sample_envs), np.zeros(sample_envs)), cfg, timers)
+    if algo == "ppo_lag":
+        cfg = {"gamma": 0.99, "target_kl": float("inf"), "batch_size": 64, "learning_iters": 40}
+        R.ppo_lag_epoch_port(env, pol, R.PPOLagUpdater(pol, epochs=1), R.OracleLagrange(25.0, 0.001, 0.035), obs,
+                             sample_envs, T, stats, dq, acc, cfg, timers)
+        what = "batch 64, 40 learning iters"
+    else:
+        cfg = {"gamma": 0.99, "target_kl": 0.01, "batch_size": 128, "learning_iters": 10, "cg_iters": 15}
+        R.cpo_epoch_port(env, pol, R.CriticFitter(pol), obs, sample_envs, T, stats, dq, acc, cfg, timers=timers)
+        what = "15 CG iters (33 FVPs by double backward), line search, critic fit batch 128 x 10 iters"
     wall = time.time() - t0
     steps = sample_envs * T
-    return {"value": steps / (timers["rollout"] + timers["update"]), "unit": "env-steps/s", "cores": threads,
+    host = next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "?")
+    return {"value": round(steps / (timers["rollout"] + timers["update"]), 1), "unit": "env-steps/s", "cores": threads,
             "kind": "port",
-            "sample": f"1 epoch of {sample_envs} envs x {T} steps (={steps} env-steps), batch 64, 40 learning iters, "
-                      f"torch CPU {threads} threads; rollout {timers['rollout']:.2f}s update {timers['update']:.2f}s wall {wall:.2f}s"}
+            "sample": f"1 epoch of {sample_envs} envs x {T} steps (={steps} env-steps), {what}, "
+                      f"torch CPU {threads} threads on {host} ({os.cpu_count()} logical cores); "
+                      f"rollout {timers['rollout']:.2f}s update {timers['update']:.2f}s wall {wall:.2f}s",
+            "reference_recorded": recorded_reference(algo)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--num-envs", type=int, default=4096, help="envs PER GPU")
-    ap.add_argument("--num-steps", type=int, default=128)
-    ap.add_argument("--learning-iters", type=int, default=40)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-envs", type=int, default=96)   # ~15 s of CPU work on the GPU box host
-    ap.add_argument("--stream-envs", type=int, default=262144, help="extra GAE roofline point that streams from HBM")
-    ap.add_argument("--algo", choices=["ppo_lag", "cpo"], default="ppo_lag",
-                    help="cpo = BASELINE config 3 (not the headline metric; single GPU)")
-    a = ap.parse_args()
-
+def run_epochs(algo, a, comm, dev, N, T, D, A, steps, warmup, time_gae):
+    """Builds the engine + device env for `algo` and runs `warmup` untimed and `steps` timed epochs bracketed by a
+    barrier + device synchronisation on both sides.  Returns a dict with the MAX-over-ranks elapsed time and the pieces
+    the JSON line needs."""
     from safepo import _abi
     from safepo.common.engine import PPOLagEngine
     from safepo.common.env import SynthDeviceEnv
     from safepo.common.model import ActorVCritic
-    from safepo.parallel import init_from_env
-
-    # SPO_BENCH_ONE_GPU=1 (development aid): all ranks share cuda:0 with gloo for the host collectives, to exercise the
-    # N > 1 code path -- including the in-kernel exchange through IPC-mapped regions -- on a single-GPU box.
-    one_gpu = os.environ.get("SPO_BENCH_ONE_GPU", "0") == "1"
-    comm = init_from_env(backend="gloo" if one_gpu else None)
     world = comm.world_size
-    assert world == max(a.gpus, 1) or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    local_rank = 0 if one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
-    dev = torch.device(f"cuda:{local_rank}")
-    torch.cuda.set_device(dev)
     torch.manual_seed(0)
-    N, T, D, A = a.num_envs, a.num_steps, 60, 8
-    cfg = {"hidden_sizes": [64, 64], "gamma": 0.99, "target_kl": float("inf"), "batch_size": 64,
-           "learning_iters": a.learning_iters, "max_grad_norm": 40.0}
     policy = ActorVCritic(D, A).to(dev)
     comm.broadcast_(policy.theta, 0)
-    if a.algo == "cpo":
+    if algo == "cpo":
         from safepo.single_agent.cpo import CPOEngine, default_cfg as cpo_cfg
         cfg = dict(cpo_cfg)
         eng = CPOEngine(policy, N, T, cfg, dev, comm=comm)
     else:
+        cfg = {"hidden_sizes": [64, 64], "gamma": 0.99, "target_kl": float("inf"), "batch_size": 64,
+               "learning_iters": a.learning_iters, "max_grad_norm": 40.0}
         eng = PPOLagEngine(policy, N, T, cfg, dev, comm=comm)
     env = SynthDeviceEnv(N, D, A, seed=1234 + comm.rank, p_term=0.0, p_cost=0.1, trunc_len=64, device=dev)
     obs, _ = env.reset()
     lam = 0.001
-    gae_events = []
+    gae_graph, gae_disp = [], []
 
     def epoch(timed: bool):
         nonlocal obs
@@ -123,16 +128,20 @@ def main():
         n_ep = eng.drain_episode_events(None)
         torch.cuda.synchronize(dev)
         t1 = time.time()
-        if a.algo == "cpo":
+        if algo == "cpo":
             eng.buffer.compute_gae(None, comm)
             pu = eng.policy_update(-1.0)
-            fit = eng.critic_fit()
+            eng.critic_fit()
             eng.buffer.reset()
             out = {"stop_iter": pu["acceptance_step"], "kl": pu["kl"]}
         else:
             out = eng.update(lam)
-        if timed:   # GAE scan of THIS epoch's buffer: graph of GAE_REPS launches between HIP events (~0.5 ms)
-            gae_events.append(eng.buffer.time_scan(GAE_REPS))
+        if timed and time_gae:
+            # GAE scan of THIS epoch's buffer, inside the timed region: (1) every launch between its own pair of HIP events
+            # (per-dispatch duration, what rocprofv3 --kernel-trace reports), (2) a hipGraph of GAE_REPS launches
+            # between two events (back-to-back throughput; the command processor overlaps dispatch set-up).  ~1 ms.
+            gae_disp.extend(eng.buffer.time_scan_dispatches(GAE_DISPATCHES))
+            gae_graph.append(eng.buffer.time_scan(GAE_REPS))
         torch.cuda.synchronize(dev)
         t2 = time.time()
         return t1 - t0, t2 - t1, out, n_ep
@@ -140,7 +149,7 @@ def main():
     # N > 1: the in-kernel gradient exchange has a self-test at start-up; should a peer still time out in a full epoch
     # (bounded spins, the error is max-reduced so every rank sees it), all ranks drop to the RCCL form together and the
     # warm-up starts over.  One guard epoch runs even with --warmup 0 so the timed region never hits this first.
-    guard = max(a.warmup, 1) if (world > 1 and getattr(eng, "p2p", None) is not None) else a.warmup
+    guard = max(warmup, 1) if (world > 1 and getattr(eng, "p2p", None) is not None) else warmup
     done_w = 0
     while done_w < guard:
         try:
@@ -161,8 +170,8 @@ def main():
     torch.cuda.synchronize(dev)
     t_start = time.time()
     roll = upd = 0.0
-    last = None
-    for _ in range(a.steps):
+    last, n_ep = None, 0
+    for _ in range(steps):
         r, u, last, n_ep = epoch(True)
         roll += r
         upd += u
@@ -171,7 +180,44 @@ def main():
     elapsed = time.time() - t_start
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     comm.all_reduce_max_(tmax)
-    elapsed = float(tmax.item())
+    PEER_EXCHANGE_USED[0] = getattr(eng, "p2p", None) is not None
+    return {"elapsed": float(tmax.item()), "roll": roll, "upd": upd, "last": last, "n_ep": n_ep, "eng": eng, "cfg": cfg,
+            "epoch": epoch, "gae_graph": gae_graph, "gae_disp": gae_disp}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--num-envs", type=int, default=4096, help="envs PER GPU")
+    ap.add_argument("--num-steps", type=int, default=128)
+    ap.add_argument("--learning-iters", type=int, default=40)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-envs", type=int, default=512)   # ~80 s of CPU work on the GPU box host (12.5 % of the workload)
+    ap.add_argument("--cpo-cpu-sample-envs", type=int, default=256)
+    ap.add_argument("--no-config3", action="store_true", help="skip the CPO (BASELINE config 3) section")
+    ap.add_argument("--cpo-steps", type=int, default=3)
+    ap.add_argument("--stream-envs", type=int, default=262144, help="extra GAE roofline point that streams from HBM")
+    ap.add_argument("--algo", choices=["ppo_lag", "cpo"], default="ppo_lag",
+                    help="cpo = time BASELINE config 3 as the main workload (not the headline metric; single GPU)")
+    a = ap.parse_args()
+
+    from safepo.parallel import init_from_env
+
+    # SPO_BENCH_ONE_GPU=1 (development aid): all ranks share cuda:0 with gloo for the host collectives, to exercise the
+    # N > 1 code path -- including the in-kernel exchange through IPC-mapped regions -- on a single-GPU box.
+    one_gpu = os.environ.get("SPO_BENCH_ONE_GPU", "0") == "1"
+    comm = init_from_env(backend="gloo" if one_gpu else None)
+    world = comm.world_size
+    assert world == max(a.gpus, 1) or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    local_rank = 0 if one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    N, T, D, A = a.num_envs, a.num_steps, 60, 8
+
+    res = run_epochs(a.algo, a, comm, dev, N, T, D, A, a.steps, a.warmup, time_gae=True)
+    elapsed, roll, upd, last, n_ep, eng, cfg = (res[k] for k in ("elapsed", "roll", "upd", "last", "n_ep", "eng", "cfg"))
 
     if comm.rank != 0:
         if world > 1:
@@ -179,27 +225,37 @@ def main():
         return
     total_env_steps = world * N * T * a.steps
     value = total_env_steps / elapsed
-    n_mb = (N * T + 63) // 64
-    if a.algo == "cpo":
-        n_mb = (N * T + 127) // 128
-    gae_ms = gae_events
-    gae_avg_s = (sum(gae_ms) / len(gae_ms)) if gae_ms else float("nan")
+    batch = 128 if a.algo == "cpo" else 64
+    iters = 10 if a.algo == "cpo" else a.learning_iters
+    n_mb = (N * T + batch - 1) // batch
     seg_ends = int(eng.buffer.seg_end.sum().item())
     gae_bytes = GAE_BYTES_PER_ELEM * N * T + 8.0 * seg_ends
-    achieved = gae_bytes / gae_avg_s / 1e9
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_gae_pmc.json")
-    if os.path.exists(pmc_path):
-        try:
-            # PMC counters were collected (separate rocprofv3 passes) for the 4096 x 128 launch only
-            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch_n4096") if (N, T) == (4096, 128) else None
-        except Exception:
-            traffic = None
-    roofline = {"kernel": "gae_kernel<4,32> (spo_gae_fused)", "bound": "hbm", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "bytes_per_launch": gae_bytes, "avg_launch_us": round(gae_avg_s * 1e6, 2), "launches_timed": len(gae_ms) * GAE_REPS,
-                "note": "HIP events around a hipGraph of 100 back-to-back launches, once per timed epoch, inside the timed region "
-                        "(includes the ~1.5 us kernel boundary of each launch)"}
+    disp = np.asarray(res["gae_disp"], np.float64)
+    graph = np.asarray(res["gae_graph"], np.float64)
+    disp_avg = float(disp.mean()) if disp.size else float("nan")
+    achieved = gae_bytes / disp_avg / 1e9
+    pmc = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02", "gae_pmc.json")))
+    except Exception:
+        pass
+    roofline = {"kernel": "gae_kernel (spo_gae_fused)", "bound": "hbm", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "traffic_profiled": pmc,
+                "bytes_per_launch": gae_bytes, "avg_launch_us": round(disp_avg * 1e6, 3),
+                "median_launch_us": round(float(np.median(disp)) * 1e6, 3) if disp.size else None,
+                "launches_timed": int(disp.size),
+                "graph_avg_launch_us": round(float(graph.mean()) * 1e6, 3) if graph.size else None,
+                "graph_frac": round(gae_bytes / float(graph.mean()) / 1e9 / HBM_PEAK_GBS, 4) if graph.size else None,
+                "residency": f"{gae_bytes / 1e6:.1f} MB per launch: Infinity-Cache resident (256 MiB), re-read by every timed "
+                             "launch -- NOT an HBM-streaming figure; see roofline_hbm_streaming for the HBM claim",
+                "note": "achieved = algorithmic bytes / MEAN per-dispatch duration: each launch between its own pair of HIP "
+                        "events on the launch stream, inside the timed region (the per-dispatch figure rocprofv3 "
+                        "--kernel-trace reports; profiles/r02 holds the trace of this command). graph_* = hipGraph of "
+                        f"{GAE_REPS} back-to-back launches between two events (dispatch set-up overlapped). traffic: PMC "
+                        "counters cannot be read inside this run -> null; traffic_profiled is the committed rocprofv3 "
+                        "--pmc measurement (FETCH_SIZE x2 + WRITE_SIZE, separate passes) with its source"}
 
     # extra roofline points (untimed, after the run): 32 768 envs (138 MB) and a buffer that cannot sit in
     # the 256 MiB Infinity Cache
@@ -212,15 +268,18 @@ def main():
         big.seg_end[:, T - 1] = 1
         big.seg_end[:, T // 2 - 1] = 1
         big.compute_gae(None)
-        t_s = big.time_scan(reps)
+        d_s = float(np.mean(big.time_scan_dispatches(reps)))
+        g_s = big.time_scan(reps)
         b = GAE_BYTES_PER_ELEM * Ns * T + 8.0 * 2 * Ns
         del big
-        return {"num_envs": Ns, "bytes_per_launch": b, "avg_launch_us": round(t_s * 1e6, 1),
-                "achieved": round(b / t_s / 1e9, 1), "unit": "GB/s", "frac": round(b / t_s / 1e9 / HBM_PEAK_GBS, 4)}
+        return {"num_envs": Ns, "bytes_per_launch": b, "avg_launch_us": round(d_s * 1e6, 1),
+                "achieved": round(b / d_s / 1e9, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": round(b / d_s / 1e9 / HBM_PEAK_GBS, 4),
+                "graph_avg_launch_us": round(g_s * 1e6, 1), "graph_frac": round(b / g_s / 1e9 / HBM_PEAK_GBS, 4)}
     stream, mid = None, None
     try:
         mid = scan_point(32768, 20)
         stream = scan_point(a.stream_envs, 10)
+        stream["residency"] = "1.1 GB per launch > 256 MiB Infinity Cache: streams from HBM3E -- the HBM-roofline claim of this kernel"
     except Exception as e:  # pragma: no cover
         stream = {"error": str(e)[:200]}
 
@@ -228,15 +287,42 @@ def main():
     faithful = None
     if world == 1 and a.algo == "ppo_lag":
         cfg["target_kl"] = 0.02
-        r_f, u_f, out_f, _ = epoch(False)
+        r_f, u_f, out_f, _ = res["epoch"](False)
         cfg["target_kl"] = float("inf")
         faithful = {"target_kl": 0.02, "stop_iter": out_f["stop_iter"], "kl": out_f["kl"], "s_per_epoch": round(r_f + u_f, 4),
                     "env_steps_per_s": round(N * T / (r_f + u_f), 1)}
 
     cpu = None
-    if world == 1 and not a.no_cpu_baseline and a.algo == "ppo_lag":
-        cpu = cpu_baseline(a.cpu_sample_envs, T)
+    if world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.cpu_sample_envs if a.algo == "ppo_lag" else a.cpo_cpu_sample_envs, T, algo=a.algo)
 
+    # BASELINE config 3 (CPO) in the same line: its own engine, env, timed epochs and CPU baseline (N = 1 only)
+    config3 = None
+    if world == 1 and a.algo == "ppo_lag" and not a.no_config3:
+        del res, eng
+        torch.cuda.empty_cache()
+        try:
+            r3 = run_epochs("cpo", a, comm, dev, N, T, D, A, a.cpo_steps, 1, time_gae=False)
+            v3 = N * T * a.cpo_steps / r3["elapsed"]
+            n_mb3 = (N * T + 127) // 128
+            config3 = {"workload": (f"cpo synthetic env (obs=60, act=8), num_envs={N}, num_steps={T}, default_cfg (2 surrogate "
+                                    "gradients, 2 x 15 CG iters = 33 Fisher-vector products, line search, critic fit batch 128 x 10 "
+                                    "iters), device-resident env"),
+                       "value": round(v3, 1), "unit": "env-steps/s", "steps": a.cpo_steps, "warmup": 1,
+                       "ms_per_step": round(r3["elapsed"] / a.cpo_steps * 1e3, 2),
+                       "rollout_s_per_epoch": round(r3["roll"] / a.cpo_steps, 4),
+                       "update_s_per_epoch": round(r3["upd"] / a.cpo_steps, 4),
+                       "critic_minibatch_steps_per_epoch": n_mb3 * 10,
+                       "acceptance_step": r3["last"]["stop_iter"], "kl": r3["last"]["kl"],
+                       "critic_fit_form": ("two co-resident persistent launches (64 of every 128 rows each)"
+                                           if getattr(r3["eng"], "_split", None) else "one persistent launch")}
+            if not a.no_cpu_baseline:
+                config3["cpu_baseline"] = cpu_baseline(a.cpo_cpu_sample_envs, T, algo="cpo")
+                config3["speedup_vs_cpu_baseline"] = round(v3 / config3["cpu_baseline"]["value"], 1)
+        except Exception as e:  # pragma: no cover
+            config3 = {"error": str(e)[:300]}
+
+    us_step = upd / a.steps / (n_mb * iters) * 1e6
     line = {
         "metric": "env-steps/sec (collect+GAE+update) at num_envs=4096, 1/2/4/8 GPU",
         "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -250,9 +336,9 @@ def main():
                    "global_envs": world * N,
                    "parallelism": (f"dp{world} over num_envs, per-minibatch gradient all-reduce "
                                    + ("inside the persistent update kernel over IPC-mapped peer regions (xGMI)"
-                                      if getattr(eng, "p2p", None) is not None else "via RCCL between kernels"))
+                                      if PEER_EXCHANGE_USED[0] else "via RCCL between kernels"))
                    if world > 1 else "single GPU",
-                   "minibatch_steps_per_epoch": n_mb * a.learning_iters},
+                   "minibatch_steps_per_epoch": n_mb * iters},
         "roofline": roofline,
         "roofline_32768_envs": mid,
         "roofline_hbm_streaming": stream,
@@ -260,14 +346,15 @@ def main():
         # the kernel that owns 99 % of the GPU time is not HBM- but latency/matrix-bound: 327 680 strictly sequential
         # optimiser steps, each at least 368 v_mfma_f32_16x16x4_f32 (32 cycles each) per wave on one CU per network
         "update_kernel": ({"kernel": "ppo_update_kernel<64, persistent>", "bound": "fp32 MFMA issue of one CU per network + per-step latency chain",
-                           "us_per_minibatch_step": round(upd / a.steps / (n_mb * a.learning_iters) * 1e6, 3),
+                           "us_per_minibatch_step": round(us_step, 3),
                            "mfma_floor_us": round(368 * 32 / 2.4e9 * 1e6, 3),
-                           "frac": round((368 * 32 / 2.4e9) / (upd / a.steps / (n_mb * a.learning_iters)), 4),
+                           "frac": round((368 * 32 / 2.4e9) / (us_step * 1e-6), 4),
                            "note": "floor = MFMA issue cycles at 2.4 GHz; DESIGN.md 3.3 has the instruction mix"}
                           if a.algo == "ppo_lag" else None),
         "cpu_baseline": cpu,
+        "config3_cpo": config3,
         "phases": {"rollout_s_per_epoch": round(roll / a.steps, 4), "update_s_per_epoch": round(upd / a.steps, 4),
-                   "update_us_per_minibatch_step": round(upd / a.steps / (n_mb * (a.learning_iters if a.algo == "ppo_lag" else 10)) * 1e6, 3),
+                   "update_us_per_minibatch_step": round(us_step, 3),
                    "stop_iter": last["stop_iter"], "kl": last["kl"], "episodes_per_epoch": n_ep},
     }
     if cpu:

@@ -774,18 +774,15 @@ class StatsLog:
         return row
 
 
-def ppo_lag_epoch_port(env, policy: OraclePolicy, updater: PPOLagUpdater, lagrange: OracleLagrange,
-                       obs, num_envs: int, local_steps: int, stats: StatsLog, deques, ep_acc,
-                       cfg: dict, timers: dict | None = None):
-    """One epoch of safepo/single_agent/ppo_lag.py:159-350 (eval off), torch CPU.
-    Returns (next obs, per-epoch info)."""
-    import time
-    from torch.utils.data import DataLoader, TensorDataset
+def collect_epoch_port(env, policy: OraclePolicy, obs, num_envs: int, local_steps: int, stats: StatsLog, deques, ep_acc,
+                       gamma: float):
+    """The rollout half of one epoch, identical in safepo/single_agent/ppo_lag.py:159-234 and cpo.py:240-313: batched
+    policy step, per-env Python store loop, per-env boundary scan with single-row bootstrap forwards and per-path GAE.
+    Returns (next obs, filled PerEnvBuffer)."""
     obs_dim, act_dim = obs.shape[-1], policy.actor.log_std.shape[0]
-    buf = PerEnvBuffer(obs_dim, act_dim, local_steps, num_envs, gamma=cfg["gamma"])
+    buf = PerEnvBuffer(obs_dim, act_dim, local_steps, num_envs, gamma=gamma)
     rew_dq, cost_dq, len_dq = deques
     ep_ret, ep_cost, ep_len = ep_acc
-    t0 = time.time()
     for step in range(local_steps):
         with torch.no_grad():
             dist = policy.actor(obs)
@@ -825,6 +822,18 @@ def ppo_lag_epoch_port(env, policy: OraclePolicy, updater: PPOLagUpdater, lagran
                                    "Metrics/EpLen": np.mean(len_dq)})
                     ep_ret[idx] = ep_cost[idx] = ep_len[idx] = 0.0
                 buf.finish_path(last_r, last_c, idx)
+    return obs, buf
+
+
+def ppo_lag_epoch_port(env, policy: OraclePolicy, updater: PPOLagUpdater, lagrange: OracleLagrange,
+                       obs, num_envs: int, local_steps: int, stats: StatsLog, deques, ep_acc,
+                       cfg: dict, timers: dict | None = None):
+    """One epoch of safepo/single_agent/ppo_lag.py:159-350 (eval off), torch CPU.
+    Returns (next obs, per-epoch info)."""
+    import time
+    from torch.utils.data import DataLoader, TensorDataset
+    t0 = time.time()
+    obs, buf = collect_epoch_port(env, policy, obs, num_envs, local_steps, stats, deques, ep_acc, cfg["gamma"])
     t1 = time.time()
     lagrange.update_lagrange_multiplier(stats.get_stats("Metrics/EpCost"))
     data = buf.get()
@@ -852,3 +861,29 @@ def ppo_lag_epoch_port(env, policy: OraclePolicy, updater: PPOLagUpdater, lagran
         timers["rollout"] = t1 - t0
         timers["update"] = t2 - t1
     return obs, {"stop_iter": stop_iter, "kl": kl, "lambda": lam, "data": data}
+
+
+def cpo_epoch_port(env, policy: OraclePolicy, fitter: CriticFitter, obs, num_envs: int, local_steps: int,
+                   stats: StatsLog, deques, ep_acc, cfg: dict, cost_limit: float = 25.0, timers: dict | None = None):
+    """One epoch of safepo/single_agent/cpo.py:240-571 (eval off), torch CPU: the shared rollout, then the trust-region
+    actor update (two surrogate gradients, two 15-step CG solves = 33 Fisher-vector products by double backward, case
+    analysis, line search) and the critic fit through a shuffling DataLoader (batch 128 x 10 iterations)."""
+    import time
+    from torch.utils.data import DataLoader, TensorDataset
+    t0 = time.time()
+    obs, buf = collect_epoch_port(env, policy, obs, num_envs, local_steps, stats, deques, ep_acc, cfg["gamma"])
+    t1 = time.time()
+    data = buf.get()
+    ep_costs = stats.get_stats("Metrics/EpCost") - cost_limit
+    out = cpo_policy_update(policy, data, ep_costs, target_kl=cfg.get("target_kl", 0.01), cg_iters=cfg.get("cg_iters", 15))
+    loader = DataLoader(TensorDataset(data["obs"], data["target_value_r"], data["target_value_c"]),
+                        batch_size=cfg["batch_size"], shuffle=True)
+    for _ in range(cfg["learning_iters"]):
+        for ob, trb, tcb in loader:
+            lr_, lc_ = fitter.minibatch_step(ob, trb, tcb)
+            stats.store(**{"Loss/Loss_reward_critic": lr_, "Loss/Loss_cost_critic": lc_})
+    t2 = time.time()
+    if timers is not None:
+        timers["rollout"] = t1 - t0
+        timers["update"] = t2 - t1
+    return obs, {"case": out["case"], "accept_step": out.get("accept"), "data": data}

@@ -57,6 +57,10 @@ class VectorizedOnPolicyBuffer:
         """Write one vector step (buffer.py:84-95).  The fused collect kernel writes the same slots
         directly (safepo.common.engine); this method is the API-compatible path."""
         assert self.ptr < self.size, "Buffer overflow"
+        if self.ptr == 0:
+            # first store of an epoch: the path marks of the previous epoch must not cut this epoch's paths (the
+            # engine path never gets here -- spo_boundary_step rewrites every slot of a column)
+            self.clear_boundaries()
         for key, value in data.items():
             self.data[key][:, self.ptr] = torch.as_tensor(value, dtype=torch.float32, device=self._device)
         self.advance()
@@ -155,6 +159,23 @@ class VectorizedOnPolicyBuffer:
             e1.record()
             torch.cuda.synchronize(self._device)
         return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+    def time_scan_dispatches(self, reps: int = 50):
+        """Per-dispatch GPU time (seconds, one entry per launch) of spo_gae_fused: every launch sits between its own pair
+        of HIP events on the launch stream, so each figure covers one dispatch from the moment the queue reaches it to
+        its completion -- the quantity rocprofv3 --kernel-trace reports per dispatch (unlike the graph average of
+        time_scan, which lets the command processor overlap the next dispatch's set-up with the running kernel)."""
+        launch = self._launch_scan
+        torch.cuda.synchronize(self._device)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        _abi.check(launch(), "spo_gae_fused")
+        for e0, e1 in ev:
+            e0.record()
+            launch()
+            e1.record()
+        torch.cuda.synchronize(self._device)
+        return [e0.elapsed_time(e1) * 1e-3 for e0, e1 in ev]
 
 
 class SeparatedReplayBuffer:

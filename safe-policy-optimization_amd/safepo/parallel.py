@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import os
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -72,6 +73,15 @@ def shard_envs(num_envs_global: int, comm: Comm) -> tuple[int, int]:
     return start, count
 
 
+def require_equal_shards(num_envs_global: int, comm: Comm) -> None:
+    """The data-parallel update assumes every rank holds the same number of rows: the per-minibatch exchange runs
+    ceil(M_local / batch) rounds per rank (unequal counts would leave collectives unmatched and hang the job) and the
+    global means (KL, CPO surrogates, gradient scale 1/world) weight every rank equally."""
+    if comm.world_size > 1 and num_envs_global % comm.world_size != 0:
+        raise ValueError(f"--num-envs {num_envs_global} is not divisible by the number of ranks ({comm.world_size}): "
+                         "data-parallel runs need equal env shards")
+
+
 def dp_reduce_gradient_(comm: Comm, flat_grad: torch.Tensor) -> float:
     """All-reduce(sum) the flat minibatch gradient of all three networks in place and return the
     scale (1/world_size) that turns the sum of per-rank MEAN-loss gradients into the gradient of the
@@ -88,6 +98,23 @@ def dp_mean_scalar(comm: Comm, value: float, device=None) -> float:
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     comm.all_reduce_sum_(t)
     return float(t.item()) / comm.world_size
+
+
+def dp_epoch_stat(comm: Comm, logger, key: str, device=None) -> float:
+    """logger.get_stats(key) for a data-parallel job (ppo_lag.py:272, logger.py:369-373): the mean over ALL values stored
+    this epoch on ANY rank -- (sum, count) are all-reduced, so a rank that finished no episode contributes nothing instead
+    of a NaN / 0.0 placeholder.  Keeps the reference's two quirks job-wide: 0.0 until the key has been in a dumped header
+    on some rank, NaN when it has been but no rank stored a value this epoch."""
+    if comm.world_size == 1:
+        return float(logger.get_stats(key))
+    vals = logger.epoch_dict.get(key, []) if key in logger.log_headers else []
+    t = torch.tensor([float(np.sum(vals)) if len(vals) else 0.0, float(len(vals)), 1.0 if key in logger.log_headers else 0.0],
+                     dtype=torch.float64, device=device)
+    comm.all_reduce_sum_(t)
+    s, n, seen = (float(x) for x in t.tolist())
+    if seen == 0.0:
+        return 0.0
+    return s / n if n > 0 else float("nan")
 
 
 def adv_stats_from_sums(sums: torch.Tensor):

@@ -21,7 +21,7 @@ from safepo.common.env import make_sa_mujoco_env
 from safepo.common.lagrange import Lagrange, PIDLagrangian
 from safepo.common.logger import EpochLogger
 from safepo.common.model import ActorVCritic
-from safepo.parallel import dp_mean_scalar, init_from_env, shard_envs
+from safepo.parallel import dp_epoch_stat, init_from_env, require_equal_shards, shard_envs
 from safepo.utils.config import isaac_gym_map
 
 NO_CLIP = 1e30      # clamp(ratio, 1-1e30, 1+1e30) is the identity: pg's unclipped surrogate on the same kernel
@@ -54,6 +54,7 @@ def run(args, cfg_env, default_cfg: dict, multiplier: str | None = "adam", clip:
     config.update(getattr(args, "cfg_override", None) or {})
     config["clip"] = NO_CLIP if clip is None else clip
 
+    require_equal_shards(args.num_envs, comm)
     _, n_local = shard_envs(args.num_envs, comm)
     env, obs_space, act_space = make_sa_mujoco_env(num_envs=n_local, env_id=args.task,
                                                    seed=args.seed + 1000 * comm.rank, device=device,
@@ -142,8 +143,7 @@ def run(args, cfg_env, default_cfg: dict, multiplier: str | None = "adam", clip:
         eval_end_time = time.time()
 
         # ---- Lagrange multiplier (ppo_lag.py:271-273); EpCost mean is all-reduced over shards
-        ep_costs = logger.get_stats("Metrics/EpCost")
-        ep_costs = dp_mean_scalar(comm, ep_costs, device)
+        ep_costs = dp_epoch_stat(comm, logger, "Metrics/EpCost", device)
         if lagrange is not None:
             lagrange.update_lagrange_multiplier(ep_costs)
         # lambda == 0 makes (adv_r - 0*adv_c)/(0+1) == adv_r exactly: ppo / pg (ppo.py:272)

@@ -21,7 +21,7 @@ from safepo.common.env import make_sa_mujoco_env
 from safepo.common.lagrange import Lagrange
 from safepo.common.logger import EpochLogger
 from safepo.common.model import ActorVCritic
-from safepo.parallel import dp_mean_scalar, init_from_env, shard_envs
+from safepo.parallel import dp_epoch_stat, init_from_env, require_equal_shards, shard_envs
 from safepo.single_agent.cpo import CPOEngine, _to_dev
 from safepo.utils.config import isaac_gym_map
 
@@ -40,6 +40,7 @@ def run(args, cfg_env, default_cfg: dict, line_search: bool, use_lagrange: bool)
         raise NotImplementedError("Isaac Gym tasks (isaac_gym_specific_cfg) are not part of this build")
     config = dict(default_cfg)
     config.update(getattr(args, "cfg_override", None) or {})
+    require_equal_shards(args.num_envs, comm)
     _, n_local = shard_envs(args.num_envs, comm)          # one process per GPU: a contiguous shard of the envs each
     env, obs_space, act_space = make_sa_mujoco_env(num_envs=n_local, env_id=args.task, seed=args.seed + 1000 * comm.rank,
                                                    device=device, **(getattr(args, "env_kwargs", None) or {}))
@@ -86,7 +87,7 @@ def run(args, cfg_env, default_cfg: dict, line_search: bool, use_lagrange: bool)
         rollout_end_time = time.time()
         eval_end_time = rollout_end_time
 
-        ep_costs = dp_mean_scalar(comm, logger.get_stats("Metrics/EpCost"), device)
+        ep_costs = dp_epoch_stat(comm, logger, "Metrics/EpCost", device)
         lam = None
         if lagrange is not None:
             lagrange.update_lagrange_multiplier(ep_costs)

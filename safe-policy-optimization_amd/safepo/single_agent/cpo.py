@@ -25,7 +25,7 @@ from safepo.common.engine import PPOLagEngine
 from safepo.common.env import make_sa_mujoco_env
 from safepo.common.logger import EpochLogger
 from safepo.common.model import ActorVCritic
-from safepo.parallel import dp_mean_scalar, init_from_env, shard_envs
+from safepo.parallel import dp_epoch_stat, init_from_env, require_equal_shards, shard_envs
 from safepo.utils.config import isaac_gym_map, single_agent_args
 
 STEP_FRACTION = 0.8
@@ -524,6 +524,7 @@ def main(args, cfg_env=None, _update="cpo"):
         raise NotImplementedError("Isaac Gym tasks (isaac_gym_specific_cfg) are not part of this build")
     config = dict(default_cfg)
     config.update(getattr(args, "cfg_override", None) or {})
+    require_equal_shards(args.num_envs, comm)
     _, n_local = shard_envs(args.num_envs, comm)          # one process per GPU: a contiguous shard of the envs each
     env, obs_space, act_space = make_sa_mujoco_env(num_envs=n_local, env_id=args.task, seed=args.seed + 1000 * comm.rank,
                                                    device=device, **(getattr(args, "env_kwargs", None) or {}))
@@ -570,7 +571,7 @@ def main(args, cfg_env=None, _update="cpo"):
 
         # ---- update policy (cpo.py:350-532) and critics (:534-571)
         engine.buffer.compute_gae(None, comm)
-        ep_costs = dp_mean_scalar(comm, logger.get_stats("Metrics/EpCost"), device) - args.cost_limit
+        ep_costs = dp_epoch_stat(comm, logger, "Metrics/EpCost", device) - args.cost_limit
         out = engine.policy_update(ep_costs, logger) if _update == "cpo" else engine.pcpo_update(ep_costs, logger)
         logger.store(**{"Misc/Alpha": out["alpha"], "Misc/FinalStepNorm": out["final_step_norm"], "Misc/xHx": out["xHx"],
                         "Misc/gradient_norm": out["gradient_norm"], "Misc/H_inv_g": out["H_inv_g"],
