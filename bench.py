@@ -229,7 +229,10 @@ def main():
     iters = 10 if a.algo == "cpo" else a.learning_iters
     n_mb = (N * T + batch - 1) // batch
     seg_ends = int(eng.buffer.seg_end.sum().item())
-    gae_bytes = GAE_BYTES_PER_ELEM * N * T + 8.0 * seg_ends
+    folded = bool(getattr(eng.buffer, "last_scan_folded", False))
+    # folded form (the engine's): gamma * bootstrap already sits in the reward / cost arrays the scan reads -> exactly
+    # 33 B per element; with separate bootstrap arrays 8 more bytes are algorithmic per path end
+    gae_bytes = GAE_BYTES_PER_ELEM * N * T + (0.0 if folded else 8.0 * seg_ends)
     disp = np.asarray(res["gae_disp"], np.float64)
     graph = np.asarray(res["gae_graph"], np.float64)
     disp_avg = float(disp.mean()) if disp.size else float("nan")
@@ -239,7 +242,7 @@ def main():
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r02", "gae_pmc.json")))
     except Exception:
         pass
-    roofline = {"kernel": "gae_kernel (spo_gae_fused)", "bound": "hbm", "achieved": round(achieved, 1),
+    roofline = {"kernel": "gae_kernel (spo_gae_fused" + (", folded bootstrap form)" if folded else ")"), "bound": "hbm", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None,
                 "traffic_profiled": pmc,
@@ -250,9 +253,11 @@ def main():
                 "graph_frac": round(gae_bytes / float(graph.mean()) / 1e9 / HBM_PEAK_GBS, 4) if graph.size else None,
                 "residency": f"{gae_bytes / 1e6:.1f} MB per launch: Infinity-Cache resident (256 MiB), re-read by every timed "
                              "launch -- NOT an HBM-streaming figure; see roofline_hbm_streaming for the HBM claim",
-                "note": "achieved = algorithmic bytes / MEAN per-dispatch duration: each launch between its own pair of HIP "
-                        "events on the launch stream, inside the timed region (the per-dispatch figure rocprofv3 "
-                        "--kernel-trace reports; profiles/r02 holds the trace of this command). graph_* = hipGraph of "
+                "note": "achieved = algorithmic bytes / MEAN per-dispatch duration: every dispatch carries its own start/stop HIP "
+                        "events on the launch stream (hipExtLaunchKernelGGL: the dispatch packet's own timestamps, the "
+                        "figure rocprofv3 --kernel-trace reports), inside the timed region. Under rocprofv3 itself dispatches "
+                        "run ~8 % slower (the profiler serialises the queue): profiles/r02 holds the trace of this command "
+                        "TOGETHER with the line printed by that profiled run, whose frac matches the trace. graph_* = hipGraph of "
                         f"{GAE_REPS} back-to-back launches between two events (dispatch set-up overlapped). traffic: PMC "
                         "counters cannot be read inside this run -> null; traffic_profiled is the committed rocprofv3 "
                         "--pmc measurement (FETCH_SIZE x2 + WRITE_SIZE, separate passes) with its source"}
@@ -267,10 +272,14 @@ def main():
             big.data[k].normal_()
         big.seg_end[:, T - 1] = 1
         big.seg_end[:, T // 2 - 1] = 1
+        # the engine's layout: bootstrap folded into the arrays the scan reads (boot arrays are zero here: fold == raw)
+        big.reward_fold.copy_(big.data["reward"]); big.cost_fold.copy_(big.data["cost"])
+        big.ptr, big._fold_cols = T, T
         big.compute_gae(None)
+        assert big.last_scan_folded
         d_s = float(np.mean(big.time_scan_dispatches(reps)))
         g_s = big.time_scan(reps)
-        b = GAE_BYTES_PER_ELEM * Ns * T + 8.0 * 2 * Ns
+        b = GAE_BYTES_PER_ELEM * Ns * T
         del big
         return {"num_envs": Ns, "bytes_per_launch": b, "avg_launch_us": round(d_s * 1e6, 1),
                 "achieved": round(b / d_s / 1e9, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": round(b / d_s / 1e9 / HBM_PEAK_GBS, 4),

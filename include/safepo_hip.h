@@ -48,6 +48,8 @@ const char* spo_last_error(void);
  * delta in fp32 (three separately rounded ops, gamma rounded to fp32), segmented backward
  * scan in fp64 with discount gamma*lam formed in double, results rounded to fp32.
  * Steps after the last seg_end of a row (unfinished path) get adv = target = 0.
+ * boot_r == boot_c == NULL selects the FOLDED form: `reward` / `cost` are then the arrays written by
+ * spo_boundary_step_fold (gamma * bootstrap already added at path ends); same results, no bootstrap loads.
  * partials: [spo_gae_num_blocks(N,T)][SPO_GAE_PARTIAL_STRIDE] doubles: one row {sum adv_r, sum adv_r^2, sum adv_c,
  * count} per wave of each workgroup (no block-level combine inside the scan; spo_adv_reduce adds the rows). */
 int spo_gae_num_blocks(int64_t num_envs, int64_t T);
@@ -60,6 +62,14 @@ int spo_gae_fused(const float* reward, const float* cost, const float* value_r, 
 /* Debug/bench knob: 0 = automatic, 1 = eager bootstrap loads (latency-optimised, cache-resident
  * buffers), 2 = predicated bootstrap loads (fewest bytes, HBM-streaming buffers). */
 int spo_debug_gae_variant(int v);
+/* Measurement aid (bench.py `roofline`): spo_gae_fused `reps` times on `stream`, every dispatch carrying its own start /
+ * stop events, so durations_us_host[i] (host array of `reps` floats) is the execution time of dispatch i as the dispatch
+ * packet's own timestamps record it -- the per-dispatch figure rocprofv3 --kernel-trace reports.  Synchronises `stream`. */
+int spo_gae_fused_timed(const float* reward, const float* cost, const float* value_r, const float* value_c,
+                        const uint8_t* seg_end, const float* boot_r, const float* boot_c,
+                        float* adv_r, float* adv_c, float* target_r, float* target_c,
+                        double* partials, int64_t num_envs, int64_t T,
+                        double gamma, double lam, double lam_c, int reps, float* durations_us_host, void* stream);
 
 /* ---- a-6: statistics of VectorizedOnPolicyBuffer.get() (buffer.py:154-160).
  * spo_adv_reduce: partials -> sums[4] = {sum adv_r, sum adv_r^2, sum adv_c, count} (fixed order,
@@ -105,6 +115,18 @@ int spo_boundary_step(const float* reward, const float* cost, const float* termi
                       float* buf_reward, float* buf_cost, uint8_t* seg_end, float* boot_r, float* boot_c,
                       double* ep_ret, double* ep_cost, double* ep_len, double* events, int* events_count,
                       int events_capacity, int64_t num_envs, int64_t T, int64_t t, int epoch_end, void* stream);
+
+/* The same step, additionally writing the two arrays spo_gae_fused reads in its FOLDED form (boot_r == boot_c == NULL
+ * there): fold_reward[env,t] = fl(reward + fl((float)gamma * boot_r)) at a path end and the plain reward elsewhere (same
+ * for cost) -- the first two of the three fp32 operations of delta_t = r_t + gamma*v_{t+1} - v_t (buffer.py:198) applied
+ * to the value finish_path would append (buffer.py:118-125).  The scan then needs no bootstrap loads: exactly the 33
+ * algorithmic bytes per (env, step), no second memory round trip, results bit-identical to the unfolded form. */
+int spo_boundary_step_fold(const float* reward, const float* cost, const float* terminated, const float* truncated,
+                           const float* v_next_r, const float* v_next_c, const float* v_final_r, const float* v_final_c,
+                           float* buf_reward, float* buf_cost, uint8_t* seg_end, float* boot_r, float* boot_c,
+                           double* ep_ret, double* ep_cost, double* ep_len, double* events, int* events_count,
+                           int events_capacity, int64_t num_envs, int64_t T, int64_t t, int epoch_end,
+                           float* fold_reward, float* fold_cost, double gamma, void* stream);
 
 /* ---- a-9/a-10: one learning iteration of the PPO-Lagrangian update (ppo_lag.py:297-336):
  * for each consecutive chunk of `batch` indices of perm[M] (last partial chunk kept): gather,

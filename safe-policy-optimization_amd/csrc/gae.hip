@@ -14,6 +14,8 @@
 // `delta + disc*c` step.  delta is formed in fp32 with three separately rounded ops and gamma
 // rounded to fp32 (buffer.py:198); fp contraction is disabled for this file.
 #include <cstdlib>
+#include <vector>
+#include <hip/hip_ext.h>
 #include "common.h"
 #include "../../include/safepo_hip.h"
 
@@ -87,15 +89,21 @@ __device__ __forceinline__ void store_vec(float* p, bool ok, const float (&o)[VE
 }
 
 // One affine map c_out = A*c_in + B, composed right-to-left.
-// EAGER_BOOT: load the bootstrap arrays unconditionally (8 extra B/element) instead of only at
-// path ends.  Removes a dependent memory round trip (seg_end -> boot) -- used when the buffer is
-// cache-resident and the launch is latency-bound; the predicated form moves fewer bytes and is
-// used for buffers that stream from HBM.
+// BOOT: where the bootstrap value of a path end comes from.
+//   BOOT_PRED   load boot_r / boot_c only at path ends (a dependent round trip seg_end -> boot, and a whole 128-byte
+//               line fetched for 4 useful bytes: 1.13 x the algorithmic bytes at one path end per 64 steps);
+//   BOOT_EAGER  load them unconditionally (8 extra B/element; debug / A-B knob);
+//   BOOT_FOLDED no bootstrap arrays at all: `reward` / `cost` are the arrays spo_boundary_step_fold wrote, which hold
+//               fl(r + fl(gamma32 * boot)) at path ends -- exactly the first two of the three fp32 operations of
+//               delta = r + gamma*v_next - v (buffer.py:198), so delta = fl(folded - v) is bit-identical, the traffic is
+//               the 33 algorithmic bytes per element and nothing waits for a second round trip.
 // RC: the reward scan and the cost scan of a row run in DIFFERENT lane groups (group g of a wave: row g/2, quantity g%2)
 // instead of both in every lane.  Same instructions in total, but each wave's dependent chain (deltas, affine
 // composition, replay) is half as long and twice as many waves are in flight -- the 4096x128 launch is latency-bound.
-template <int VEC, int LPR, bool EAGER_BOOT, bool RC>
+constexpr int BOOT_PRED = 0, BOOT_EAGER = 1, BOOT_FOLDED = 2;
+template <int VEC, int LPR, int BOOT, bool RC>
 __global__ __launch_bounds__(256) void gae_kernel(GaeArgs a) {
+  constexpr bool EAGER_BOOT = (BOOT == BOOT_EAGER);
   static_assert(!RC || LPR <= 32, "RC needs two lane groups per wave");
   constexpr int NK = RC ? 1 : 2;
   constexpr int ROWS_PER_WAVE = RC ? 64 / LPR / 2 : 64 / LPR;
@@ -178,9 +186,11 @@ __global__ __launch_bounds__(256) void gae_kernel(GaeArgs a) {
       for (int e = 0; e < VEC; ++e) {
         float vn = (e == VEC - 1) ? vnext_edge[k] : vv[k][e + 1];
         if (EAGER_BOOT) vn = seg[e] ? bt[k][e] : vn;
-        else if (seg[e]) vn = boot[rbase + t0 + e];            // predicated: only at path ends
+        else if (BOOT == BOOT_PRED && seg[e]) vn = boot[rbase + t0 + e];            // predicated: only at path ends
         // deltas = rewards[:-1] + gamma * values[1:] - values[:-1]   (fp32, buffer.py:198)
-        float d = __fsub_rn(__fadd_rn(rw[k][e], __fmul_rn(a.gamma32, vn)), vv[k][e]);
+        float rg = __fadd_rn(rw[k][e], __fmul_rn(a.gamma32, vn));
+        if (BOOT == BOOT_FOLDED) rg = seg[e] ? rw[k][e] : rg;   // the boundary step already added gamma * bootstrap
+        float d = __fsub_rn(rg, vv[k][e]);
         delta[k][e] = (double)d;
       }
     }
@@ -370,17 +380,27 @@ inline GaeGeom gae_geom(int64_t T, int64_t N) {
   return g;
 }
 
-template <int VEC, bool EAGER>
+// Optional timing of the next launches: when set, the dispatch carries its own start / stop events
+// (hipExtLaunchKernelGGL), i.e. the timestamps of the dispatch packet itself -- what rocprofv3 --kernel-trace reports.
+hipEvent_t g_gae_ev_start = nullptr, g_gae_ev_stop = nullptr;
+
+template <int VEC, int BOOT>
 int launch_gae(const GaeGeom& g, const GaeArgs& a, int blocks, hipStream_t st) {
+#define SPO_GAE_LAUNCH(...)                                                                                       \
+  {                                                                                                               \
+    if (g_gae_ev_start) hipExtLaunchKernelGGL((gae_kernel<__VA_ARGS__>), dim3(blocks), dim3(256), 0, st, g_gae_ev_start, g_gae_ev_stop, 0, a); \
+    else hipLaunchKernelGGL((gae_kernel<__VA_ARGS__>), dim3(blocks), dim3(256), 0, st, a);                         \
+  }
   if (g.rc) {
-    if constexpr (VEC == 4) { hipLaunchKernelGGL((gae_kernel<4, 32, EAGER, true>), dim3(blocks), dim3(256), 0, st, a); return 0; }
+    if constexpr (VEC == 4) { SPO_GAE_LAUNCH(4, 32, BOOT, true) return 0; }
   }
   switch (g.lpr) {
-#define SPO_CASE(L) case L: hipLaunchKernelGGL((gae_kernel<VEC, L, EAGER, false>), dim3(blocks), dim3(256), 0, st, a); break;
+#define SPO_CASE(L) case L: SPO_GAE_LAUNCH(VEC, L, BOOT, false) break;
     SPO_CASE(1) SPO_CASE(2) SPO_CASE(4) SPO_CASE(8) SPO_CASE(16) SPO_CASE(32) SPO_CASE(64)
 #undef SPO_CASE
     default: return spo::fail(-1, "gae: bad lanes-per-row %d", g.lpr);
   }
+#undef SPO_GAE_LAUNCH
   return 0;
 }
 
@@ -404,25 +424,61 @@ extern "C" int spo_gae_fused(const float* reward, const float* cost, const float
                              int64_t T, double gamma, double lam, double lam_c, void* stream) {
   SPO_REQUIRE(num_envs >= 0 && T >= 0, "gae: negative size");
   if (num_envs == 0 || T == 0) return 0;
-  SPO_REQUIRE(reward && cost && value_r && value_c && seg_end && boot_r && boot_c && adv_r && adv_c && target_r &&
-                  target_c && partials, "gae: null pointer");
+  SPO_REQUIRE(reward && cost && value_r && value_c && seg_end && adv_r && adv_c && target_r && target_c && partials,
+              "gae: null pointer");
+  SPO_REQUIRE((boot_r == nullptr) == (boot_c == nullptr), "gae: boot_r and boot_c must both be given or both be NULL (folded)");
+  const bool folded = boot_r == nullptr;
   GaeGeom g = gae_geom(T, num_envs);
   GaeArgs a{reward, cost, value_r, value_c, seg_end, boot_r, boot_c, adv_r, adv_c, target_r, target_c, partials,
             num_envs, T, (float)gamma, gamma * lam, gamma * lam_c, g_gae_force_variant >> 4, gae_plain_stores()};
   const int blocks = spo_gae_num_blocks(num_envs, T);
   hipStream_t st = (hipStream_t)stream;
-  // predicated bootstrap loads by default (fewest bytes; measured equal or faster at every size)
+  // predicated bootstrap loads by default when bootstrap arrays are given (fewest bytes; measured equal or faster than
+  // the eager form at every size); no bootstrap loads at all in the folded form
   const int fv = g_gae_force_variant & 15;
-  const bool eager = fv == 1;
+  const bool eager = fv == 1 && !folded;
   int rc;
-  if (g.vec == 4) rc = eager ? launch_gae<4, true>(g, a, blocks, st) : launch_gae<4, false>(g, a, blocks, st);
-  else rc = eager ? launch_gae<1, true>(g, a, blocks, st) : launch_gae<1, false>(g, a, blocks, st);
+#define SPO_GAE_GO(V)                                                                     \
+  rc = folded ? launch_gae<V, BOOT_FOLDED>(g, a, blocks, st)                              \
+              : eager ? launch_gae<V, BOOT_EAGER>(g, a, blocks, st) : launch_gae<V, BOOT_PRED>(g, a, blocks, st);
+  if (g.vec == 4) { SPO_GAE_GO(4) } else { SPO_GAE_GO(1) }
+#undef SPO_GAE_GO
   if (rc) return rc;
   SPO_LAUNCH_CHECK("spo_gae_fused");
   return 0;
 }
 
 extern "C" int spo_debug_gae_variant(int v) { g_gae_force_variant = v; return 0; }
+
+// The scan `reps` times, every dispatch carrying its own start / stop events: durations_us_host[i] = execution time of
+// dispatch i as the dispatch packet's timestamps record it.  Synchronises the stream.  (bench.py's roofline figure.)
+extern "C" int spo_gae_fused_timed(const float* reward, const float* cost, const float* value_r, const float* value_c,
+                                   const uint8_t* seg_end, const float* boot_r, const float* boot_c, float* adv_r,
+                                   float* adv_c, float* target_r, float* target_c, double* partials, int64_t num_envs,
+                                   int64_t T, double gamma, double lam, double lam_c, int reps, float* durations_us_host,
+                                   void* stream) {
+  SPO_REQUIRE(reps > 0 && reps <= 4096 && durations_us_host, "gae_timed: bad reps / output");
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<hipEvent_t> ev(2 * (size_t)reps, nullptr);
+  int rc = 0;
+  for (auto& e : ev)
+    if (!rc) rc = spo::hip_check(hipEventCreate(&e), "hipEventCreate");
+  for (int i = 0; i < reps && !rc; ++i) {
+    g_gae_ev_start = ev[2 * i]; g_gae_ev_stop = ev[2 * i + 1];
+    rc = spo_gae_fused(reward, cost, value_r, value_c, seg_end, boot_r, boot_c, adv_r, adv_c, target_r, target_c, partials,
+                       num_envs, T, gamma, lam, lam_c, stream);
+  }
+  g_gae_ev_start = g_gae_ev_stop = nullptr;
+  if (!rc) rc = spo::hip_check(hipStreamSynchronize(st), "hipStreamSynchronize(gae_timed)");
+  for (int i = 0; i < reps && !rc; ++i) {
+    float ms = 0.f;
+    rc = spo::hip_check(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]), "hipEventElapsedTime");
+    durations_us_host[i] = ms * 1000.f;
+  }
+  for (auto& e : ev)
+    if (e) (void)hipEventDestroy(e);
+  return rc;
+}
 
 extern "C" int spo_adv_reduce(const double* partials, int num_blocks, double* sums, void* stream) {
   SPO_REQUIRE(partials && sums && num_blocks > 0, "adv_reduce: bad args");

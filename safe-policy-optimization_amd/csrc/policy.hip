@@ -175,6 +175,7 @@ struct BoundaryArgs {
   float* buf_reward; float* buf_cost; uint8_t* seg_end; float* boot_r; float* boot_c;
   double* ep_ret; double* ep_cost; double* ep_len; double* events; int* events_count; int events_capacity;
   int64_t N; int64_t T; int64_t t; int epoch_end;
+  float* fold_reward; float* fold_cost; float gamma32;     // optional: reward / cost with gamma * bootstrap folded in at path ends
 };
 
 // ONE block: finished episodes are appended in env order, the order of the reference's Python
@@ -208,6 +209,12 @@ __global__ __launch_bounds__(256) void boundary_kernel(BoundaryArgs a) {
       a.seg_end[slot] = boundary ? 1 : 0;
       a.boot_r[slot] = br;
       a.boot_c[slot] = bc;
+      if (a.fold_reward) {
+        // what spo_gae_fused reads in its folded form: fl(r + fl(gamma32 * bootstrap)) at a path end, r elsewhere --
+        // the first two of the three fp32 operations of delta_t (buffer.py:198) for the appended bootstrap value
+        a.fold_reward[slot] = boundary ? __fadd_rn(rw, __fmul_rn(a.gamma32, br)) : rw;
+        a.fold_cost[slot] = boundary ? __fadd_rn(cs, __fmul_rn(a.gamma32, bc)) : cs;
+      }
       fin = done || tout;
       a.ep_ret[i] = fin ? 0.0 : ret;
       a.ep_cost[i] = fin ? 0.0 : cst;
@@ -402,22 +409,48 @@ extern "C" int spo_values(const float* theta, const float* obs, float* v_r, floa
   return 0;
 }
 
+static int boundary_step_impl(const float* reward, const float* cost, const float* terminated,
+                              const float* truncated, const float* v_next_r, const float* v_next_c,
+                              const float* v_final_r, const float* v_final_c, float* buf_reward, float* buf_cost,
+                              uint8_t* seg_end, float* boot_r, float* boot_c, double* ep_ret, double* ep_cost,
+                              double* ep_len, double* events, int* events_count, int events_capacity,
+                              int64_t num_envs, int64_t T, int64_t t, int epoch_end, float* fold_reward, float* fold_cost,
+                              double gamma, void* stream) {
+  SPO_REQUIRE(reward && cost && terminated && truncated && buf_reward && buf_cost && seg_end && boot_r && boot_c &&
+                  ep_ret && ep_cost && ep_len && events && events_count, "boundary: null pointer");
+  SPO_REQUIRE(v_next_r && v_next_c && v_final_r && v_final_c, "boundary: null value pointer");
+  SPO_REQUIRE((fold_reward == nullptr) == (fold_cost == nullptr), "boundary: fold_reward and fold_cost go together");
+  SPO_REQUIRE(t >= 0 && t < T, "Buffer overflow");
+  BoundaryArgs a{reward, cost, terminated, truncated, v_next_r, v_next_c, v_final_r, v_final_c, buf_reward, buf_cost,
+                 seg_end, boot_r, boot_c, ep_ret, ep_cost, ep_len, events, events_count,
+                 events_capacity, num_envs, T, t, epoch_end, fold_reward, fold_cost, (float)gamma};
+  hipLaunchKernelGGL(boundary_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+  SPO_LAUNCH_CHECK("spo_boundary_step");
+  return 0;
+}
+
 extern "C" int spo_boundary_step(const float* reward, const float* cost, const float* terminated,
                                  const float* truncated, const float* v_next_r, const float* v_next_c,
                                  const float* v_final_r, const float* v_final_c, float* buf_reward, float* buf_cost,
                                  uint8_t* seg_end, float* boot_r, float* boot_c, double* ep_ret, double* ep_cost,
                                  double* ep_len, double* events, int* events_count, int events_capacity,
                                  int64_t num_envs, int64_t T, int64_t t, int epoch_end, void* stream) {
-  SPO_REQUIRE(reward && cost && terminated && truncated && buf_reward && buf_cost && seg_end && boot_r && boot_c &&
-                  ep_ret && ep_cost && ep_len && events && events_count, "boundary: null pointer");
-  SPO_REQUIRE(v_next_r && v_next_c && v_final_r && v_final_c, "boundary: null value pointer");
-  SPO_REQUIRE(t >= 0 && t < T, "Buffer overflow");
-  BoundaryArgs a{reward, cost, terminated, truncated, v_next_r, v_next_c, v_final_r, v_final_c, buf_reward, buf_cost,
-                 seg_end, boot_r, boot_c, ep_ret, ep_cost, ep_len, events, events_count,
-                 events_capacity, num_envs, T, t, epoch_end};
-  hipLaunchKernelGGL(boundary_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
-  SPO_LAUNCH_CHECK("spo_boundary_step");
-  return 0;
+  return boundary_step_impl(reward, cost, terminated, truncated, v_next_r, v_next_c, v_final_r, v_final_c, buf_reward,
+                            buf_cost, seg_end, boot_r, boot_c, ep_ret, ep_cost, ep_len, events, events_count,
+                            events_capacity, num_envs, T, t, epoch_end, nullptr, nullptr, 0.0, stream);
+}
+
+extern "C" int spo_boundary_step_fold(const float* reward, const float* cost, const float* terminated,
+                                      const float* truncated, const float* v_next_r, const float* v_next_c,
+                                      const float* v_final_r, const float* v_final_c, float* buf_reward, float* buf_cost,
+                                      uint8_t* seg_end, float* boot_r, float* boot_c, double* ep_ret, double* ep_cost,
+                                      double* ep_len, double* events, int* events_count, int events_capacity,
+                                      int64_t num_envs, int64_t T, int64_t t, int epoch_end, float* fold_reward,
+                                      float* fold_cost, double gamma, void* stream) {
+  SPO_REQUIRE(fold_reward && fold_cost, "boundary_fold: null fold pointer");
+  return boundary_step_impl(reward, cost, terminated, truncated, v_next_r, v_next_c, v_final_r, v_final_c, buf_reward,
+                            buf_cost, seg_end, boot_r, boot_c, ep_ret, ep_cost, ep_len, events, events_count,
+                            events_capacity, num_envs, T, t, epoch_end, fold_reward, fold_cost, gamma, stream);
 }
 
 extern "C" int spo_actor_mean(const float* theta, const float* obs, float* mean_out, int64_t rows, int obs_dim,

@@ -48,12 +48,14 @@ PROTOTYPES = {
     "spo_gae_num_blocks": (c_int, [c_int64, c_int64]),
     "spo_gae_fused": (c_int, [P] * 12 + [c_int64, c_int64, c_double, c_double, c_double, P]),
     "spo_debug_gae_variant": (c_int, [c_int]),
+    "spo_gae_fused_timed": (c_int, [P] * 12 + [c_int64, c_int64, c_double, c_double, c_double, c_int, P, P]),
     "spo_adv_reduce": (c_int, [P, c_int, P, P]),
     "spo_adv_apply": (c_int, [P, P, P, P, c_int64, c_double, c_int, c_int, P, P]),
     "spo_policy_step": (c_int, [P] * 12 + [c_int64, c_int64, c_int64, c_int, c_int, P]),
     "spo_obs_normalize": (c_int, [P, P, c_int64, c_int, c_int, P]),
     "spo_values": (c_int, [P, P, P, P, c_int64, c_int, c_int, P]),
     "spo_boundary_step": (c_int, [P] * 18 + [c_int, c_int64, c_int64, c_int64, c_int, P]),
+    "spo_boundary_step_fold": (c_int, [P] * 18 + [c_int, c_int64, c_int64, c_int64, c_int, P, P, c_double, P]),
     "spo_ppo_lag_update_iter": (c_int, [P, P, P, c_int64] + [P] * 7 + [c_int64, POINTER(PpoCfg), P, P, P]),
     "spo_debug_crosslane_selftest": (c_int, [P, P, P]),
     "spo_debug_set_update_profile": (c_int, [P]),
@@ -110,7 +112,7 @@ def load(path: str | None = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("SPO_LIB_PATH") or LIB_PATH      # SPO_LIB_PATH: development aid (A/B of kernel builds)
     if not os.path.exists(p):
         raise SpoError(
             f"{p} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "

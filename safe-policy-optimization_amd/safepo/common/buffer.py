@@ -41,6 +41,12 @@ class VectorizedOnPolicyBuffer:
         self.boot_r = torch.zeros((N, T), **f32)
         self.boot_c = torch.zeros((N, T), **f32)
         self.adv_mix = torch.zeros((N, T), **f32)
+        # reward / cost with gamma * bootstrap folded in at path ends (written by spo_boundary_step_fold, one column per
+        # collect step); the scan reads these instead of reward/cost + boot_r/boot_c when every column of the epoch
+        # came from that kernel (self._fold_cols == size)
+        self.reward_fold = torch.zeros((N, T), **f32)
+        self.cost_fold = torch.zeros((N, T), **f32)
+        self._fold_cols = 0
         self._partials = torch.zeros((max(self._lib.spo_gae_num_blocks(N, T), 1), _abi.GAE_PARTIAL_STRIDE), dtype=torch.float64,
                                      device=dev)
         self.sums = torch.zeros(4, dtype=torch.float64, device=dev)
@@ -87,12 +93,16 @@ class VectorizedOnPolicyBuffer:
         `comm`: optional safepo.parallel.Comm -- statistics are all-reduced over the env shards."""
         d, lib, st = self.data, self._lib, _abi.stream_ptr()
         N, T = self.num_envs, self.size
+        folded = self._fold_cols == T and self.ptr == T
+        rew, cst = (self.reward_fold, self.cost_fold) if folded else (d["reward"], d["cost"])
+        boot_r, boot_c = (None, None) if folded else (self.boot_r, self.boot_c)
+        self.last_scan_folded = folded
+        self._scan_args = (_abi.ptr(rew), _abi.ptr(cst), _abi.ptr(d["value_r"]), _abi.ptr(d["value_c"]),
+                           _abi.ptr(self.seg_end), _abi.ptr(boot_r), _abi.ptr(boot_c), _abi.ptr(d["adv_r"]),
+                           _abi.ptr(d["adv_c"]), _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]),
+                           _abi.ptr(self._partials), N, T, self._gamma, self._lam, self._lam_c)
         def launch_scan():
-            return lib.spo_gae_fused(
-                _abi.ptr(d["reward"]), _abi.ptr(d["cost"]), _abi.ptr(d["value_r"]), _abi.ptr(d["value_c"]),
-                _abi.ptr(self.seg_end), _abi.ptr(self.boot_r), _abi.ptr(self.boot_c), _abi.ptr(d["adv_r"]),
-                _abi.ptr(d["adv_c"]), _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]),
-                _abi.ptr(self._partials), N, T, self._gamma, self._lam, self._lam_c, _abi.stream_ptr())
+            return lib.spo_gae_fused(*self._scan_args, _abi.stream_ptr())
         self._launch_scan = launch_scan
         _abi.check(launch_scan(), "spo_gae_fused")
         _abi.check(lib.spo_adv_reduce(_abi.ptr(self._partials), self._partials.shape[0], _abi.ptr(self.sums), st),
@@ -120,6 +130,7 @@ class VectorizedOnPolicyBuffer:
 
     def reset(self) -> None:
         self.ptr = 0
+        self._fold_cols = 0
         self.ptr_list = [0] * self.num_envs
         self.path_start_idx_list = [0] * self.num_envs
 
@@ -162,20 +173,16 @@ class VectorizedOnPolicyBuffer:
 
 
     def time_scan_dispatches(self, reps: int = 50):
-        """Per-dispatch GPU time (seconds, one entry per launch) of spo_gae_fused: every launch sits between its own pair
-        of HIP events on the launch stream, so each figure covers one dispatch from the moment the queue reaches it to
-        its completion -- the quantity rocprofv3 --kernel-trace reports per dispatch (unlike the graph average of
-        time_scan, which lets the command processor overlap the next dispatch's set-up with the running kernel)."""
-        launch = self._launch_scan
+        """Per-dispatch GPU time (seconds, one entry per launch) of spo_gae_fused on the current buffer contents: every
+        dispatch carries its own start / stop events (spo_gae_fused_timed), i.e. the timestamps of the dispatch packet
+        itself -- the per-dispatch duration rocprofv3 --kernel-trace reports, unlike the graph average of time_scan,
+        in which the command processor overlaps one dispatch's end-of-kernel tail with the next one's start."""
+        import ctypes
+        args = self._scan_args
+        out = (ctypes.c_float * reps)()
         torch.cuda.synchronize(self._device)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        _abi.check(launch(), "spo_gae_fused")
-        for e0, e1 in ev:
-            e0.record()
-            launch()
-            e1.record()
-        torch.cuda.synchronize(self._device)
-        return [e0.elapsed_time(e1) * 1e-3 for e0, e1 in ev]
+        _abi.check(self._lib.spo_gae_fused_timed(*args, reps, out, _abi.stream_ptr()), "spo_gae_fused_timed")
+        return [float(x) * 1e-6 for x in out]
 
 
 class SeparatedReplayBuffer:

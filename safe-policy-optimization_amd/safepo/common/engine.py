@@ -118,12 +118,15 @@ class PPOLagEngine:
             _abi.check(self.lib.spo_values(_abi.ptr(self.policy.theta), _abi.ptr(final_obs), _abi.ptr(self.vfinal_r),
                                            _abi.ptr(self.vfinal_c), self.N, self.D, self.A, st), "spo_values")
         d = b.data
-        _abi.check(self.lib.spo_boundary_step(
+        _abi.check(self.lib.spo_boundary_step_fold(
             _abi.ptr(tens[0]), _abi.ptr(tens[1]), _abi.ptr(tens[2]), _abi.ptr(tens[3]),
             _abi.ptr(self.vnext_r), _abi.ptr(self.vnext_c), _abi.ptr(self.vfinal_r), _abi.ptr(self.vfinal_c),
             _abi.ptr(d["reward"]), _abi.ptr(d["cost"]), _abi.ptr(b.seg_end), _abi.ptr(b.boot_r), _abi.ptr(b.boot_c),
             _abi.ptr(self.ep_ret), _abi.ptr(self.ep_cost), _abi.ptr(self.ep_len), _abi.ptr(self.events),
-            _abi.ptr(self.events_count), self.events_cap, self.N, self.T, t, int(epoch_end), st), "spo_boundary_step")
+            _abi.ptr(self.events_count), self.events_cap, self.N, self.T, t, int(epoch_end),
+            _abi.ptr(b.reward_fold), _abi.ptr(b.cost_fold), float(b._gamma), st), "spo_boundary_step_fold")
+        if b._fold_cols == t:
+            b._fold_cols = t + 1          # column t of this epoch carries its folded bootstrap
         b.advance()
 
     def drain_episode_events(self, logger=None):

@@ -80,6 +80,7 @@ def smoke_check(verbose: bool = False, num_envs: int = 8, steps: int = 32, seed:
     sr, sc = R.adv_standardize(torch.from_numpy(o[0].reshape(-1)), torch.from_numpy(o[1].reshape(-1)))
     np.testing.assert_allclose(b.data["adv_r"].cpu().numpy().reshape(-1), sr.numpy(), rtol=2e-5, atol=2e-6)
     np.testing.assert_array_equal(b.data["target_value_r"].cpu().numpy(), o[2])
+    assert b.last_scan_folded, "the engine path must run the folded form of the scan (spo_boundary_step_fold)"
     # oracle update on the same data / same shuffles
     M = eng.M
     data = {"obs": torch.from_numpy(st["obs"].reshape(M, D)), "act": b.data["act"].cpu().reshape(M, A),

@@ -159,6 +159,45 @@ def test_gae_vs_oracle_random(dev, N, T, p):
     _assert_gae_close(got, ref, f"N={N},T={T}")
 
 
+def _raw_gae_folded(buf, gamma=0.99):
+    """The folded form of the scan: reward / cost carry fl(r + fl(gamma32 * bootstrap)) at path ends (what
+    spo_boundary_step_fold writes), no bootstrap arrays."""
+    from safepo import _abi
+    d = buf.data
+    g32 = np.float32(gamma)
+    seg = buf.seg_end.cpu().numpy().astype(bool)
+    fold = {}
+    for k, bk in (("reward", buf.boot_r), ("cost", buf.boot_c)):
+        r, bt = d[k].cpu().numpy(), bk.cpu().numpy()
+        fold[k] = torch.from_numpy(np.where(seg, (r + (g32 * bt).astype(np.float32)).astype(np.float32), r)).to(d[k].device)
+    _abi.check(buf._lib.spo_gae_fused(
+        _abi.ptr(fold["reward"]), _abi.ptr(fold["cost"]), _abi.ptr(d["value_r"]), _abi.ptr(d["value_c"]),
+        _abi.ptr(buf.seg_end), None, None, _abi.ptr(d["adv_r"]), _abi.ptr(d["adv_c"]),
+        _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]), _abi.ptr(buf._partials), buf.num_envs, buf.size,
+        buf._gamma, buf._lam, buf._lam_c, _abi.stream_ptr()), "gae folded")
+    torch.cuda.synchronize()
+    return tuple(d[k].cpu().numpy() for k in ("adv_r", "adv_c", "target_value_r", "target_value_c"))
+
+
+@pytest.mark.parametrize("N,T,p", [(257, 128, 1 / 64), (33, 1000, 1 / 100), (65, 77, 0.05), (1, 4, 0.5), (130, 16, 0.2),
+                                   (4096, 128, 1 / 64), (40000, 128, 1 / 64)])
+def test_gae_folded_form_is_bit_identical(dev, N, T, p):
+    """The layout the engine / bench use -- gamma * bootstrap folded into the reward at the boundary step, no bootstrap
+    arrays -- against the plain form on the same inputs: every output bit; and the timed entry point runs the same scan."""
+    case = _random_case(N, T, p, seed=N + 7 * T)
+    buf = _run_gae(dev, *case)
+    base = _raw_gae(buf)
+    folded = _raw_gae_folded(buf)
+    for b, f in zip(base, folded):
+        assert np.array_equal(b.view(np.uint32), f.view(np.uint32))
+    if N * T <= 600000:
+        _assert_gae_close(base, R.gae_dense(*case, 0.99, 0.95, 0.95), f"N={N},T={T}")
+    buf.ptr = T
+    buf.compute_gae(None)
+    durs = buf.time_scan_dispatches(5)
+    assert len(durs) == 5 and all(0.0 < d < 1e-2 for d in durs), durs
+
+
 def test_gae_segment_mask_edge_cases(dev):
     # every step ends a path / single long path / all-terminated bootstraps / -0.0 deltas
     N, T = 9, 64
