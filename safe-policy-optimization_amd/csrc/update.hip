@@ -95,10 +95,10 @@ struct UpdArgs {
   int xr_algo;                         // 1: recursive doubling at power-of-two worlds; 0: reduce-scatter + all-gather everywhere
   unsigned xr_step0;                   // global optimiser-step count before this launch (same on every rank)
   void* xr_region[XR_MAX_WORLD];       // every rank's exchange region (own + IPC-mapped peers), indexed by rank
-  float* backup;                       // eight-wave form: [UPD8_BACKUP_ROWS][3 workgroups][512 lanes] float4 rows of moment backups
+  float* backup;                       // main + helper form: [UPD_BACKUP_ROWS][3 workgroups][512 lanes] float4 backup rows
 };
 constexpr int NPHASE = 10;
-constexpr int UPD8_BACKUP_ROWS = 32;      // float4 rows per lane of the 512-thread kernels' backup scratch (main+helper form: 3*NT1 + 12 + 8)
+constexpr int UPD_BACKUP_ROWS = 32;      // float4 rows per lane of the 512-thread kernels' backup scratch (main+helper form: 3*NT1 + 12 + 8)
 
 __device__ __forceinline__ unsigned long long ld_granule(unsigned long long* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1051,744 +1051,6 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
 }
 
 // =====================================================================================================================
-// Eight-wave form of the persistent step (two waves per SIMD): ppo_update8_kernel.
-//
-// The four-wave kernel above gives every SIMD ONE wave, so nothing overlaps unless the compiler interleaves it: the step
-// is a chain of MFMA phases (11.8 k cycles of matrix pipe) and VALU / LDS phases (tanh, staging, norms, Adam: ~14 k issue
-// cycles) that mostly run one after the other (PMC: matrix pipe busy 40 % of the time).  Here a workgroup has 512 threads:
-// the two waves of a SIMD take the SAME 16 batch columns and DIFFERENT halves of the 64 hidden features, so each wave
-// carries half the MFMAs, half the activations and half the optimiser state, and the hardware overlaps one wave's VALU /
-// LDS / barrier time with its partner's MFMAs.
-//
-//   wave = 4*fh + cg :  cg = column group (batch columns 16cg .. 16cg+15),  fh = feature half (m-tiles 2fh, 2fh+1).
-//   forward   layer n: the wave computes ITS two 16-row output tiles over the whole reduction; the two tiles its partner
-//             produced arrive through the [feature][batch] LDS image that the weight-gradient GEMMs need anyway.  The
-//             reduction runs over the wave's own tiles first (registers, transposed chaining as before), so 16 MFMAs sit
-//             between publishing its tiles and needing the partner's: the barrier is covered.
-//   output    tile (16 padded rows): computed by both waves of a pair (16 MFMAs, redundant) so both know dO.
-//   backward  same split: own dz tiles, partner's through the dZ^T images.
-//   dW        16 + 4*NT1 + 4 output tiles of 16 x 16 over 8 waves: wave (cg, fh) owns row tile cg and column tiles
-//             2fh, 2fh+1 of W2 (and the matching half of W1), the fh = 0 waves the W3 tile of their column group, the
-//             fh = 1 waves the bias sums.  Optimiser state follows the ownership (<= 24 elements per lane).
-// Semantics are those of ppo_update_kernel<KIN, true, *, 0, 0> (same loss, same joint clip, same Adam, same granule
-// exchange between the networks' workgroups); only the association order of the fp32 dot products over the hidden
-// features differs between the two feature halves (own tiles first).  Used for batch <= 64, obs_dim <= 64.
-template <int N_OWN>
-__device__ __forceinline__ void half_layer(const float* Wl, int ld, const f4 bias0, const f4 bias1,
-                                           const f4 (&in_own)[N_OWN], int nt_own0, f4 (&acc)[2], int mt0, int j, int q) {
-  acc[0] = bias0; acc[1] = bias1;
-#pragma unroll
-  for (int t = 0; t < N_OWN; ++t) {
-    const int nt = nt_own0 + t;
-    const f4 a0 = *reinterpret_cast<const f4*>(Wl + (16 * mt0 + j) * ld + 16 * nt + 4 * q);
-    const f4 a1 = *reinterpret_cast<const f4*>(Wl + (16 * (mt0 + 1) + j) * ld + 16 * nt + 4 * q);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      acc[0] = mfma4(a0[r], in_own[t][r], acc[0]);
-      acc[1] = mfma4(a1[r], in_own[t][r], acc[1]);
-    }
-  }
-}
-
-// acc[t] += W[16(mt0+t) + .., 16nt + ..] * in   for one k-tile nt (A tiles read here)
-__device__ __forceinline__ void half_tile(const float* Wl, int ld, const f4 in, int nt, f4 (&acc)[2], int mt0, int j, int q) {
-  const f4 a0 = *reinterpret_cast<const f4*>(Wl + (16 * mt0 + j) * ld + 16 * nt + 4 * q);
-  const f4 a1 = *reinterpret_cast<const f4*>(Wl + (16 * (mt0 + 1) + j) * ld + 16 * nt + 4 * q);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    acc[0] = mfma4(a0[r], in[r], acc[0]);
-    acc[1] = mfma4(a1[r], in[r], acc[1]);
-  }
-}
-
-template <int KIN, bool PROF = false>
-__global__ __launch_bounds__(512) void ppo_update8_kernel(UpdArgs a) {
-  unsigned long long pacc[NPHASE] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long tprev = 0;
-#define SPO_STAMP(i)                                           \
-  if (PROF) {                                                  \
-    const unsigned long long _t = __builtin_readcyclecounter(); \
-    pacc[i] += _t - tprev; tprev = _t;                         \
-  }
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  using U = UpdLds<KIN>;
-  using L = NetLds<KIN>;
-  static_assert(!U::SPLIT, "eight-wave form: obs_dim <= 64");
-  constexpr int NT1 = KIN / 16;
-  constexpr int NT1H = NT1 >= 2 ? NT1 / 2 : 1;       // layer-1 k-tiles staged / W1 column tiles owned per feature half
-  const int tid = threadIdx.x, lane = tid & 63, j_ = lane & 15, q_ = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // wave-uniform: keeps cg / fh / mt0 in SGPRs
-  const int cg = wave & 3, fh = wave >> 2;
-  // Register budget: two waves per SIMD leave 256 VGPRs per wave.  Every phase of the step re-derives its lane indices
-  // from an opaque copy (SPO_REIDX), so LDS addresses are recomputed where they are used (a few VALU ops) instead of being
-  // hoisted out of the loop and held -- or spilled -- across all of it.
-  int j = j_, q = q_, mycol = 16 * cg + j_, orow = 16 * cg + 4 * q_;
-#define SPO_REIDX { j = pinned(j_); q = pinned(q_); mycol = 16 * cg + j; orow = 16 * cg + 4 * q; }
-  const int wg = (int)(blockIdx.x >> 3);
-  if (blockIdx.x & 7) return;                        // placement hint, see ppo_update_kernel
-  const int net = a.first_net + wg;
-  const int D = a.cfg.obs_dim, A = a.cfg.act_dim, B = a.cfg.batch;
-  const NetGeom g = net_geom(D, A, net);
-  const bool is_actor = (net == 2);
-  const int OUT = g.OUT;
-  const int ls_off = g.off - A;
-  float* const red = lds + U::RED;
-  stage_net<KIN>(a.theta, g, lds, tid, 512);
-  if (is_actor && tid < A) red[128 + tid] = a.theta[ls_off + tid];
-  __syncthreads();
-
-  // ---- ownership of weight-gradient tiles and optimiser state
-  const int mt0 = 2 * fh;                            // my output m-tiles in forward / backward: mt0, mt0 + 1
-  const int nt1_0 = (NT1 >= 2) ? fh * NT1H : 0;      // first W1 column tile I own
-  const bool own_w1 = (NT1 >= 2) || fh == 0;
-  const bool own_w3 = (fh == 0);
-  const bool own_b = (fh == 1 && q == 0);            // b1, b2 rows 16cg + j
-  const bool own_b3 = (wave == 0 && q == 0 && j < OUT);
-  const bool own_ls = is_actor && wave == 0 && j == 0;
-  f4 mW1[NT1H], vW1[NT1H], mW2[2], vW2[2], mW3, vW3, mls, vls;
-  float mb1 = 0, vb1 = 0, mb2 = 0, vb2 = 0, mb3 = 0, vb3 = 0;
-#pragma unroll
-  for (int t = 0; t < NT1H; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = 16 * (nt1_0 + t) + j;
-      const int idx = g.w1() + (orow + r) * D + i;
-      const bool ok = own_w1 && i < D;
-      mW1[t][r] = ok ? a.adam_m[idx] : 0.f;
-      vW1[t][r] = ok ? a.adam_v[idx] : 0.f;
-    }
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int idx = g.w2() + (orow + r) * HID + 16 * (mt0 + t) + j;
-      mW2[t][r] = a.adam_m[idx];
-      vW2[t][r] = a.adam_v[idx];
-    }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int o = 4 * q + r;
-    const int idx = g.w3() + o * HID + 16 * cg + j;
-    const bool ok = own_w3 && o < OUT;
-    mW3[r] = ok ? a.adam_m[idx] : 0.f;
-    vW3[r] = ok ? a.adam_v[idx] : 0.f;
-    mls[r] = (is_actor && o < A) ? a.adam_m[ls_off + o] : 0.f;
-    vls[r] = (is_actor && o < A) ? a.adam_v[ls_off + o] : 0.f;
-  }
-  mb1 = a.adam_m[g.b1() + 16 * cg + j]; vb1 = a.adam_v[g.b1() + 16 * cg + j];
-  mb2 = a.adam_m[g.b2() + 16 * cg + j]; vb2 = a.adam_v[g.b2() + 16 * cg + j];
-  if (j < OUT) { mb3 = a.adam_m[g.b3() + j]; vb3 = a.adam_v[g.b3() + j]; }
-
-  const float b1c = a.cfg.beta1, b2c = a.cfg.beta2, eps = a.cfg.adam_eps;
-  double pw1 = is_actor ? a.pow_b1_actor : a.pow_b1, pw2 = is_actor ? a.pow_b2_actor : a.pow_b2;
-  const float lr = is_actor ? a.cfg.lr_actor : a.cfg.lr_critic;
-  const float l2 = (!is_actor && a.cfg.use_critic_norm) ? a.cfg.l2_coef : 0.f;
-  const float vcoef = (net == 0 && a.cfg.use_value_coefficient) ? 2.f : 1.f;
-  const float clip_lo = 1.f - a.cfg.clip, clip_hi = 1.f + a.cfg.clip;
-  float stale_sq = a.stale_io ? *a.stale_io : a.stale_sq;
-  const float* tgt = (net == 0) ? a.tgt_r : a.tgt_c;
-
-  const int64_t nsteps = (a.M + B - 1) / B;
-
-  auto perm_pos = [&](int64_t s) -> int64_t {
-    const int64_t base = s * B;
-    const int64_t rem = a.M - base;
-    const int ncols = (int)(rem < B ? rem : B);
-    return base + (mycol < ncols ? mycol : 0);
-  };
-  auto fetch = [&](int64_t smp, ColData<NT1>& cd) {
-    load_obs_tiles_raw<KIN>(a.obs + smp * D, D, q, cd.x);
-    if (!is_actor) {
-      cd.t0 = tgt[smp]; cd.t1 = 0.f; cd.actv = f4{0.f, 0.f, 0.f, 0.f};
-    } else {
-      cd.t0 = a.logp_old[smp]; cd.t1 = a.adv[smp];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ai = 4 * q + r;
-        cd.actv[r] = a.act[smp * A + (ai < A ? ai : 0)];
-      }
-    }
-  };
-  auto settle_prefetch = [&](ColData<NT1>& cd) {
-#pragma unroll
-    for (int nt = 0; nt < NT1; ++nt)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) cd.x[nt][e] = pinned(cd.x[nt][e]);
-    mask_obs_tiles<KIN>(D, q, cd.x);
-    cd.t0 = pinned(cd.t0);
-    if (is_actor) {
-      cd.t1 = pinned(cd.t1);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ai = 4 * q + r;
-        const float av = pinned(cd.actv[r]);
-        cd.actv[r] = ai < A ? av : 0.f;
-      }
-    }
-  };
-
-  ColData<NT1> nxt;
-  int smp1 = 0;
-  fetch((int64_t)a.perm[perm_pos(0)], nxt);
-  if (nsteps > 1) smp1 = a.perm[perm_pos(1)];
-
-  for (int64_t s = 0; s < nsteps; ++s) {
-    const int64_t base = s * B;
-    const int64_t rem = a.M - base;
-    const int ncols = (int)(rem < B ? rem : B);
-    const float inv_n = 1.f / (float)ncols;
-
-    SPO_REIDX
-    if (PROF) tprev = __builtin_readcyclecounter();
-    ColData<NT1> cur = nxt;
-    settle_prefetch(cur);
-    const int smp_next = pinned(smp1);
-    const int64_t pos2 = (s + 2 < nsteps) ? perm_pos(s + 2) : 0;
-
-    // ---- x^T image for dW1: each feature half stages its share of the k-tiles
-    if (own_w1) {
-#pragma unroll
-      for (int t = 0; t < NT1H; ++t)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          // (a register array must not be indexed by the runtime tile number: select between the two candidates)
-          const float xv = (NT1 >= 2 && fh == 1) ? cur.x[(NT1 >= 2 ? NT1H : 0) + t][e] : cur.x[t][e];
-          lds[U::XT + (16 * (nt1_0 + t) + 4 * q + e) * LDB + mycol] = xv;
-        }
-    }
-    SPO_STAMP(0)
-
-    SPO_REIDX
-    // ---- forward, layer 1: my two output tiles over all of x
-    f4 h1o[2], h1p[2], h2o[2], h2p[2];
-    {
-      f4 acc[2];
-      const f4 bb0 = *reinterpret_cast<const f4*>(lds + L::B1 + 16 * mt0 + 4 * q);
-      const f4 bb1 = *reinterpret_cast<const f4*>(lds + L::B1 + 16 * (mt0 + 1) + 4 * q);
-      half_layer<NT1>(lds + L::W1, L::LD1, bb0, bb1, cur.x, 0, acc, mt0, j, q);
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          h1o[t][r] = fast_tanh(acc[t][r]);
-          lds[U::H1T + (16 * (mt0 + t) + 4 * q + r) * LDB + mycol] = h1o[t][r];
-        }
-    }
-    // prefetch for the next step rides here (its latency hides under the rest of the step)
-    if (s + 1 < nsteps) fetch((int64_t)smp_next, nxt);
-    if (s + 2 < nsteps) smp1 = a.perm[pos2];
-    SPO_REIDX
-    // ---- layer 2: own k-tiles first (registers), then the partner's (LDS, after the barrier)
-    {
-      f4 acc[2];
-      const f4 bb0 = *reinterpret_cast<const f4*>(lds + L::B2 + 16 * mt0 + 4 * q);
-      const f4 bb1 = *reinterpret_cast<const f4*>(lds + L::B2 + 16 * (mt0 + 1) + 4 * q);
-      half_layer<2>(lds + L::W2, LDH, bb0, bb1, h1o, mt0, acc, mt0, j, q);
-      __syncthreads();                                                    // B1: H1^T (and x^T) complete
-      const int pt0 = 2 - mt0;                                            // partner's tiles: pt0, pt0 + 1
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h1p[t][r] = lds[U::H1T + (16 * (pt0 + t) + 4 * q + r) * LDB + mycol];
-      half_tile(lds + L::W2, LDH, h1p[0], pt0, acc, mt0, j, q);
-      half_tile(lds + L::W2, LDH, h1p[1], pt0 + 1, acc, mt0, j, q);
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          h2o[t][r] = fast_tanh(acc[t][r]);
-          lds[U::H2T + (16 * (mt0 + t) + 4 * q + r) * LDB + mycol] = h2o[t][r];
-        }
-    }
-    SPO_REIDX
-    // ---- output tile (both waves of a pair): own k-tiles, barrier, partner's.  One accumulator per k-tile pair half; the
-    //      bias rides on k-tile 0 and the halves are added as (tiles 0,1) + (tiles 2,3) by BOTH waves, so they hold
-    //      bit-identical outputs (and therefore the same dO).
-    f4 o;
-    {
-      const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
-      const f4 bias3 = *reinterpret_cast<const f4*>(lds + L::B3 + 4 * q);
-      f4 own0 = (fh == 0) ? bias3 : zero4, own1 = zero4;
-      const f4 a0 = *reinterpret_cast<const f4*>(lds + L::W3 + j * LDH + 16 * mt0 + 4 * q);
-      const f4 a1 = *reinterpret_cast<const f4*>(lds + L::W3 + j * LDH + 16 * (mt0 + 1) + 4 * q);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        own0 = mfma4(a0[r], h2o[0][r], own0);
-        own1 = mfma4(a1[r], h2o[1][r], own1);
-      }
-      __syncthreads();                                                    // B2: H2^T complete
-      const int pt0 = 2 - mt0;
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h2p[t][r] = lds[U::H2T + (16 * (pt0 + t) + 4 * q + r) * LDB + mycol];
-      f4 par0 = (fh == 0) ? zero4 : bias3, par1 = zero4;
-      const f4 a2 = *reinterpret_cast<const f4*>(lds + L::W3 + j * LDH + 16 * pt0 + 4 * q);
-      const f4 a3 = *reinterpret_cast<const f4*>(lds + L::W3 + j * LDH + 16 * (pt0 + 1) + 4 * q);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        par0 = mfma4(a2[r], h2p[0][r], par0);
-        par1 = mfma4(a3[r], h2p[1][r], par1);
-      }
-      const f4 so = own0 + own1, sp = par0 + par1;
-      o = (fh == 0) ? (so + sp) : (sp + so);                              // (tiles 0,1) + (tiles 2,3) either way
-    }
-    SPO_STAMP(1)
-
-    SPO_REIDX
-    // ---- loss and d(loss)/d(output) (both waves of a pair compute it; only fh == 0 contributes to the sums)
-    float ivar[4], lsd[4], amask[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ai = 4 * q + r;
-      const bool on = is_actor && ai < A;
-      const float lsv = on ? red[128 + ai] : 0.f;
-      const float sdv = __expf(lsv);
-      amask[r] = on ? 1.f : 0.f;
-      ivar[r] = __builtin_amdgcn_rcpf(sdv * sdv);
-      lsd[r] = on ? lsv + LOG_SQRT_2PI : 0.f;
-    }
-
-    f4 dO = {0.f, 0.f, 0.f, 0.f};
-    float lsum = 0.f;
-    f4 dls = {0.f, 0.f, 0.f, 0.f};
-    const bool cv = mycol < ncols;
-    const float cnt_me = (fh == 0 && q == 0 && cv) ? 1.f : 0.f;
-    if (!is_actor) {
-      const float diff = o[0] - cur.t0;
-      const float lm = (q == 0 && cv) ? 1.f : 0.f;
-      lsum = cnt_me * diff * diff;
-      dO[0] = lm * (2.f * diff * inv_n);
-    } else {
-      float lp = 0.f, dif[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        dif[r] = cur.actv[r] - o[r];
-        lp += -(dif[r] * dif[r]) * (0.5f * ivar[r]) - lsd[r];
-      }
-      lp = quad_row_sum(lp);
-      const float adv = cur.t1;
-      const float ratio = __expf(lp - cur.t0);
-      const float rc = fminf(fmaxf(ratio, clip_lo), clip_hi);
-      const float s1 = ratio * adv, s2 = rc * adv;
-      const bool inr = (ratio >= clip_lo) && (ratio <= clip_hi);
-      float gr;
-      if (s1 < s2) gr = adv;
-      else if (s1 > s2) gr = inr ? adv : 0.f;
-      else gr = 0.5f * adv + (inr ? 0.5f * adv : 0.f);
-      const float dlp = cv ? -(gr * ratio) * inv_n : 0.f;
-      lsum = cnt_me * fminf(s1, s2);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float z = dif[r] * ivar[r];
-        dO[r] = dlp * z;
-        dls[r] = (fh == 0 ? dlp * amask[r] : 0.f) * (dif[r] * z - 1.f);
-      }
-    }
-
-    SPO_REIDX
-    // ---- backward: my dz2 tiles, then my dz1 tiles (own dz2 k-tiles, barrier, partner's)
-    f4 dz2o[2], dz2p[2], dz1o[2];
-    {
-      f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float w0 = lds[L::W3 + (4 * q + r) * LDH + 16 * mt0 + j];
-        const float w1 = lds[L::W3 + (4 * q + r) * LDH + 16 * (mt0 + 1) + j];
-        acc[0] = mfma4(w0, dO[r], acc[0]);
-        acc[1] = mfma4(w1, dO[r], acc[1]);
-      }
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          dz2o[t][r] = acc[t][r] * fmaf(-h2o[t][r], h2o[t][r], 1.f);
-          lds[U::DZ2T + (16 * (mt0 + t) + 4 * q + r) * LDB + mycol] = dz2o[t][r];
-        }
-      if (fh == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) lds[U::DOT + (4 * q + r) * LDB + mycol] = dO[r];
-      }
-      acc[0] = acc[1] = f4{0.f, 0.f, 0.f, 0.f};
-      // dz1[mt] += W2[16nt + k][16mt + ..]^T dz2[nt]
-      auto bwd_tile = [&](const f4 dz, int nt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float w0 = lds[L::W2 + (16 * nt + 4 * q + r) * LDH + 16 * mt0 + j];
-          const float w1 = lds[L::W2 + (16 * nt + 4 * q + r) * LDH + 16 * (mt0 + 1) + j];
-          acc[0] = mfma4(w0, dz[r], acc[0]);
-          acc[1] = mfma4(w1, dz[r], acc[1]);
-        }
-      };
-      bwd_tile(dz2o[0], mt0);
-      bwd_tile(dz2o[1], mt0 + 1);
-      __syncthreads();                                                    // B3: dZ2^T complete
-      const int pt0 = 2 - mt0;
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dz2p[t][r] = lds[U::DZ2T + (16 * (pt0 + t) + 4 * q + r) * LDB + mycol];
-      bwd_tile(dz2p[0], pt0);
-      bwd_tile(dz2p[1], pt0 + 1);
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          dz1o[t][r] = acc[t][r] * fmaf(-h1o[t][r], h1o[t][r], 1.f);
-          lds[U::DZ1T + (16 * (mt0 + t) + 4 * q + r) * LDB + mycol] = dz1o[t][r];
-        }
-    }
-    SPO_STAMP(2)
-    SPO_REIDX
-    // per-wave partials of the scalar reductions ride on the barrier below
-    {
-      const float ls = wave_sum_lane63(lsum);
-      if (fh == 0 && lane == 63) red[cg] = ls;
-      if (is_actor && fh == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float t = row_sum_lane15(dls[r]);
-          if (j == 15) red[16 + cg * 16 + 4 * q + r] = t;
-        }
-      }
-    }
-    SPO_STAMP(3)
-    __syncthreads();                                                      // B4: all [feature][batch] images complete
-    SPO_STAMP(4)
-
-    SPO_REIDX
-    // ---- weight gradients: row tile cg; W2 column tiles mt0, mt0+1; my half of W1's column tiles; W3 tile (fh == 0);
-    //      bias sums (fh == 1)
-    f4 aW1[NT1H], aW2[2], aW3 = {0.f, 0.f, 0.f, 0.f};
-    float db1 = 0.f, db2 = 0.f, db3 = 0.f;
-    {
-      f4 az2[4], az1[4];
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        az2[r4] = *reinterpret_cast<const f4*>(lds + U::DZ2T + (16 * cg + j) * LDB + 16 * r4 + 4 * q);
-        az1[r4] = *reinterpret_cast<const f4*>(lds + U::DZ1T + (16 * cg + j) * LDB + 16 * r4 + 4 * q);
-      }
-      aW2[0] = aW2[1] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const f4 b0 = *reinterpret_cast<const f4*>(lds + U::H1T + (16 * mt0 + j) * LDB + 16 * r4 + 4 * q);
-        const f4 b1 = *reinterpret_cast<const f4*>(lds + U::H1T + (16 * (mt0 + 1) + j) * LDB + 16 * r4 + 4 * q);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          aW2[0] = mfma4(az2[r4][e], b0[e], aW2[0]);
-          aW2[1] = mfma4(az2[r4][e], b1[e], aW2[1]);
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < NT1H; ++t) aW1[t] = f4{0.f, 0.f, 0.f, 0.f};
-      if (own_w1) {
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          f4 bx[NT1H];
-#pragma unroll
-          for (int t = 0; t < NT1H; ++t)
-            bx[t] = *reinterpret_cast<const f4*>(lds + U::XT + (16 * (nt1_0 + t) + j) * LDB + 16 * r4 + 4 * q);
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int t = 0; t < NT1H; ++t) aW1[t] = mfma4(az1[r4][e], bx[t][e], aW1[t]);
-        }
-      }
-      if (fh == 0) {
-        f4 w3a = {0.f, 0.f, 0.f, 0.f}, w3b = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r4 = 0; r4 < 4; r4 += 2) {
-          const f4 z0 = *reinterpret_cast<const f4*>(lds + U::DOT + j * LDB + 16 * r4 + 4 * q);
-          const f4 z1 = *reinterpret_cast<const f4*>(lds + U::DOT + j * LDB + 16 * (r4 + 1) + 4 * q);
-          const f4 c0 = *reinterpret_cast<const f4*>(lds + U::H2T + (16 * cg + j) * LDB + 16 * r4 + 4 * q);
-          const f4 c1 = *reinterpret_cast<const f4*>(lds + U::H2T + (16 * cg + j) * LDB + 16 * (r4 + 1) + 4 * q);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            w3a = mfma4(z0[e], c0[e], w3a);
-            w3b = mfma4(z1[e], c1[e], w3b);
-          }
-        }
-        aW3 = w3a + w3b;
-        if (cg == 0) {
-          float rs3 = 0.f;
-#pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) {
-            const f4 z = *reinterpret_cast<const f4*>(lds + U::DOT + j * LDB + 16 * r4 + 4 * q);
-            rs3 += (z[0] + z[1]) + (z[2] + z[3]);
-          }
-          db3 = quad_row_sum(rs3);
-        }
-      } else {
-        float rs1 = 0.f, rs2 = 0.f;
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          rs1 += (az1[r4][0] + az1[r4][1]) + (az1[r4][2] + az1[r4][3]);
-          rs2 += (az2[r4][0] + az2[r4][1]) + (az2[r4][2] + az2[r4][3]);
-        }
-        db1 = quad_row_sum(rs1);
-        db2 = quad_row_sum(rs2);
-      }
-    }
-    SPO_STAMP(5)
-
-    SPO_REIDX
-    // =================== gradients complete: L2 term, norms ===================
-    const float loss_data = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;
-    if (is_actor) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ai = 4 * q + r;
-        dls[r] = (red[16 + ai] + red[32 + ai]) + (red[48 + ai] + red[64 + ai]);
-      }
-    }
-    float gsq = 0.f, psq = 0.f;
-    const float l2x2 = 2.f * l2;
-    f4 pW1[NT1H], pW2[2], pW3;
-#pragma unroll
-    for (int t = 0; t < NT1H; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) pW1[t][r] = own_w1 ? lds[L::W1 + (orow + r) * L::LD1 + 16 * (nt1_0 + t) + j] : 0.f;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) pW2[t][r] = lds[L::W2 + (orow + r) * LDH + 16 * (mt0 + t) + j];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) pW3[r] = own_w3 ? lds[L::W3 + (4 * q + r) * LDH + 16 * cg + j] : 0.f;
-    const float pb1 = lds[L::B1 + 16 * cg + j], pb2 = lds[L::B2 + 16 * cg + j], pb3 = lds[L::B3 + j];
-    f4 pls = {0.f, 0.f, 0.f, 0.f};
-    if (is_actor) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) pls[r] = red[128 + 4 * q + r];
-    }
-#pragma unroll
-    for (int t = 0; t < NT1H; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = pW1[t][r];
-        const float gg = vcoef * fmaf(l2x2, p, aW1[t][r]);
-        aW1[t][r] = gg; gsq = fmaf(gg, gg, gsq); psq = fmaf(p, p, psq);
-      }
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = pW2[t][r];
-        const float gg = vcoef * fmaf(l2x2, p, aW2[t][r]);
-        aW2[t][r] = gg; gsq = fmaf(gg, gg, gsq); psq = fmaf(p, p, psq);
-      }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float p = pW3[r];
-      const float gg = vcoef * fmaf(l2x2, p, aW3[r]);
-      aW3[r] = gg; gsq = fmaf(gg, gg, gsq); psq = fmaf(p, p, psq);
-    }
-    {
-      db1 = vcoef * fmaf(l2x2, pb1, db1); db2 = vcoef * fmaf(l2x2, pb2, db2); db3 = vcoef * fmaf(l2x2, pb3, db3);
-      const float wb = own_b ? 1.f : 0.f, wb3 = (wave == 0 && q == 0) ? 1.f : 0.f, wls = own_ls ? 1.f : 0.f;
-      gsq += wb * (db1 * db1 + db2 * db2) + wb3 * (db3 * db3);
-      psq += wb * (pb1 * pb1 + pb2 * pb2) + wb3 * (pb3 * pb3);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) gsq = fmaf(wls * dls[r], dls[r], gsq);
-    }
-    gsq = wave_sum_lane63(gsq);
-    psq = wave_sum_lane63(psq);
-    if (lane == 63) { red[80 + wave] = gsq; red[88 + wave] = psq; }
-    SPO_STAMP(6)
-    __syncthreads();
-    const float my_sq = ((red[80] + red[81]) + (red[82] + red[83])) + ((red[84] + red[85]) + (red[86] + red[87]));
-    if (tid == 0) {
-      const float pp = ((red[88] + red[89]) + (red[90] + red[91])) + ((red[92] + red[93]) + (red[94] + red[95]));
-      a.losses[s * 3 + net] = is_actor ? -loss_data : loss_data + l2 * pp;
-    }
-
-    unsigned long long* const grow = a.slots + (s & 1) * 4;
-    const unsigned tag = (unsigned)(s + 1);
-    if (tid == 0) st_granule(grow + wg, ((unsigned long long)tag << 32) | __float_as_uint(my_sq));
-    unsigned long long peek = 0;
-    if (tid < a.n_nets) peek = ld_granule(grow + tid);
-
-    SPO_REIDX
-    // ---- speculative Adam (clip coefficient 1) while the granules are in flight; exact redo when the clip is active
-    pw1 *= (double)b1c; pw2 *= (double)b2c;
-    const float step_size = (float)((double)lr / (1.0 - pw1));
-    const float inv_bc2s = (float)(1.0 / sqrt(1.0 - pw2));
-    // Backups of the moments for the (rare) clipped step go to a per-lane row of global scratch (a.backup: fire-and-forget
-    // 16-byte stores that stay in L2; read back only when the clip is active) instead of 54 more registers per lane.
-    f4* const bk = reinterpret_cast<f4*>(a.backup) + ((size_t)wg * 512 + tid);      // element e at bk[e * 3 * 512]
-    constexpr size_t BKS = (size_t)3 * 512;
-    {
-      int e = 0;
-#pragma unroll
-      for (int t = 0; t < NT1H; ++t) { bk[BKS * e++] = mW1[t]; bk[BKS * e++] = vW1[t]; }
-#pragma unroll
-      for (int t = 0; t < 2; ++t) { bk[BKS * e++] = mW2[t]; bk[BKS * e++] = vW2[t]; }
-      bk[BKS * e++] = mW3; bk[BKS * e++] = vW3; bk[BKS * e++] = mls; bk[BKS * e++] = vls;
-      bk[BKS * e++] = f4{mb1, vb1, mb2, vb2}; bk[BKS * e++] = f4{mb3, vb3, pb1, pb2};
-      // ... and of the parameters (the speculative step overwrites the LDS master copy)
-#pragma unroll
-      for (int t = 0; t < NT1H; ++t) bk[BKS * e++] = pW1[t];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) bk[BKS * e++] = pW2[t];
-      bk[BKS * e++] = pW3; bk[BKS * e++] = pls; bk[BKS * e++] = f4{pb3, 0.f, 0.f, 0.f};
-    }
-    auto run_adam = [&](const float coef) {
-      if (own_w1) {
-#pragma unroll
-        for (int t = 0; t < NT1H; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            SPO_ADAM(lds[L::W1 + (orow + r) * L::LD1 + 16 * (nt1_0 + t) + j], lds[L::W1 + (orow + r) * L::LD1 + 16 * (nt1_0 + t) + j], aW1[t][r] * coef, mW1[t][r], vW1[t][r])
-      }
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          SPO_ADAM(lds[L::W2 + (orow + r) * LDH + 16 * (mt0 + t) + j], lds[L::W2 + (orow + r) * LDH + 16 * (mt0 + t) + j], aW2[t][r] * coef, mW2[t][r], vW2[t][r])
-      if (own_w3) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          SPO_ADAM(lds[L::W3 + (4 * q + r) * LDH + 16 * cg + j], lds[L::W3 + (4 * q + r) * LDH + 16 * cg + j], aW3[r] * coef, mW3[r], vW3[r])
-      }
-      if (fh == 1) {
-        float np1, np2;
-        SPO_ADAM(np1, pb1, db1 * coef, mb1, vb1)
-        SPO_ADAM(np2, pb2, db2 * coef, mb2, vb2)
-        lds[L::B1 + 16 * cg + j] = np1;
-        lds[L::B2 + 16 * cg + j] = np2;
-      }
-      if (wave == 0) {
-        float np3;
-        SPO_ADAM(np3, pb3, db3 * coef, mb3, vb3)
-        lds[L::B3 + j] = np3;
-        if (is_actor) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float nl;
-            SPO_ADAM(nl, pls[r], dls[r] * coef, mls[r], vls[r])
-            red[128 + 4 * q + r] = nl;
-          }
-        }
-      }
-    };
-    run_adam(1.f);
-    SPO_STAMP(7)
-
-    if (tid < a.n_nets) {
-      unsigned long long v = peek;
-      unsigned spins = 0;
-      while ((unsigned)(v >> 32) != tag) {
-        if (++spins > (1u << 24)) { *a.err = 1; break; }
-        __builtin_amdgcn_s_sleep(1);
-        v = ld_granule(grow + tid);
-      }
-      red[96 + tid] = __uint_as_float((unsigned)v);
-    }
-    __syncthreads();
-    float total_sq = stale_sq;
-    for (int k = 0; k < a.n_nets; ++k) total_sq += red[96 + k];
-    const float norm = sqrtf(total_sq);
-    float coef = a.cfg.max_grad_norm / (norm + 1e-6f);
-    coef = coef > 1.f ? 1.f : coef;
-    stale_sq *= coef * coef;
-    if (coef != 1.f) {
-      // clipped step (uniform across the grid): restore the moments from the backup rows and redo exactly
-      __builtin_amdgcn_s_waitcnt(0);
-      int e = 0;
-#pragma unroll
-      for (int t = 0; t < NT1H; ++t) { mW1[t] = bk[BKS * e++]; vW1[t] = bk[BKS * e++]; }
-#pragma unroll
-      for (int t = 0; t < 2; ++t) { mW2[t] = bk[BKS * e++]; vW2[t] = bk[BKS * e++]; }
-      mW3 = bk[BKS * e++]; vW3 = bk[BKS * e++]; mls = bk[BKS * e++]; vls = bk[BKS * e++];
-      const f4 s0 = bk[BKS * e++], s1 = bk[BKS * e++];
-      mb1 = s0[0]; vb1 = s0[1]; mb2 = s0[2]; vb2 = s0[3]; mb3 = s1[0]; vb3 = s1[1];
-      // parameters back into the LDS master copy (every element by the lane that owns it; replicas write equal values)
-      if (own_w1) {
-#pragma unroll
-        for (int t = 0; t < NT1H; ++t) {
-          const f4 pv = bk[BKS * (e + t)];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) lds[L::W1 + (orow + r) * L::LD1 + 16 * (nt1_0 + t) + j] = pv[r];
-        }
-      }
-      e += NT1H;
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const f4 pv = bk[BKS * e++];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) lds[L::W2 + (orow + r) * LDH + 16 * (mt0 + t) + j] = pv[r];
-      }
-      {
-        const f4 pv = bk[BKS * e++], lv = bk[BKS * e++], bv = bk[BKS * e++];
-        if (own_w3) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) lds[L::W3 + (4 * q + r) * LDH + 16 * cg + j] = pv[r];
-        }
-        if (fh == 1) { lds[L::B1 + 16 * cg + j] = s1[2]; lds[L::B2 + 16 * cg + j] = s1[3]; }
-        if (wave == 0) {
-          lds[L::B3 + j] = bv[0];
-          if (is_actor) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[128 + 4 * q + r] = lv[r];
-          }
-        }
-      }
-      run_adam(coef);
-    }
-    SPO_STAMP(8)
-    __syncthreads();
-    SPO_STAMP(9)
-  }
-  if (PROF && a.prof && tid == 0)
-    for (int i = 0; i < NPHASE; ++i) a.prof[wg * NPHASE + i] = pacc[i];
-#undef SPO_STAMP
-
-    SPO_REIDX
-  // ---- write back parameters and optimiser state (flat reference order)
-  if (own_w1) {
-#pragma unroll
-    for (int t = 0; t < NT1H; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 16 * (nt1_0 + t) + j;
-        if (i < D) {
-          const int idx = g.w1() + (orow + r) * D + i;
-          a.theta[idx] = lds[L::W1 + (orow + r) * L::LD1 + i];
-          SPO_ST_MV(idx, mW1[t][r], vW1[t][r])
-        }
-      }
-  }
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int idx = g.w2() + (orow + r) * HID + 16 * (mt0 + t) + j;
-      a.theta[idx] = lds[L::W2 + (orow + r) * LDH + 16 * (mt0 + t) + j];
-      SPO_ST_MV(idx, mW2[t][r], vW2[t][r])
-    }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int o = 4 * q + r;
-    if (own_w3 && o < OUT) {
-      const int idx = g.w3() + o * HID + 16 * cg + j;
-      a.theta[idx] = lds[L::W3 + o * LDH + 16 * cg + j];
-      SPO_ST_MV(idx, mW3[r], vW3[r])
-    }
-    if (own_ls && o < A) {
-      a.theta[ls_off + o] = red[128 + o];
-      SPO_ST_MV(ls_off + o, mls[r], vls[r])
-    }
-  }
-  if (own_b) {
-    const int o = 16 * cg + j;
-    a.theta[g.b1() + o] = lds[L::B1 + o]; SPO_ST_MV(g.b1() + o, mb1, vb1)
-    a.theta[g.b2() + o] = lds[L::B2 + o]; SPO_ST_MV(g.b2() + o, mb2, vb2)
-  }
-  if (own_b3) { a.theta[g.b3() + j] = lds[L::B3 + j]; SPO_ST_MV(g.b3() + j, mb3, vb3) }
-  if (tid == 0 && wg == 0 && a.stale_io) *a.stale_io = stale_sq;
-#undef SPO_REIDX
-}
-
-// =====================================================================================================================
 // Main + helper waves: ppo_update_h_kernel (512 threads per network).
 //
 // In ppo_update_kernel a fifth of every step is optimiser work that uses no matrix pipe at all (L2 terms and norms, Adam,
@@ -1922,7 +1184,7 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
   f4* const bk = reinterpret_cast<f4*>(a.backup) + ((size_t)wg * 512 + tid);
   constexpr size_t BKS = (size_t)3 * 512;
   constexpr int BK_W1 = 0, BK_W2 = 3 * NT1, BK_END = BK_W2 + 12;
-  static_assert(BK_END <= UPD8_BACKUP_ROWS, "backup rows");
+  static_assert(BK_END <= UPD_BACKUP_ROWS, "backup rows");
 
   // One layer of the helper's work: L2 term + norms, backups, speculative Adam.  G = LDS gradient tiles written by main lane
   // (wave, lane); WOFF/LD = LDS weight image; the macro body is instantiated per layer to keep every index a constant.
@@ -2603,12 +1865,11 @@ int pick_kin(int D) { return D <= 16 ? 16 : D <= 32 ? 32 : D <= 64 ? 64 : 128; }
 
 unsigned long long* g_prof_buf = nullptr;
 
-// moment backups of the eight-wave kernel (one launch of it at a time per process; 393 KB, L2-resident)
-__device__ float4 g_upd8_backup[UPD8_BACKUP_ROWS * 3 * 512];
+// backup rows of the main + helper kernel (one launch of it at a time per process and device; L2-resident)
+__device__ float4 g_upd_backup[UPD_BACKUP_ROWS * 3 * 512];
 __device__ unsigned long long g_h_slots[32];
 
-// SPO_UPDATE_FORM: 0 = four-wave kernel everywhere, 1 = symmetric eight-wave form, 2 = main + helper waves (default)
-// where they apply (persistent PPO step, clipped-surrogate loss, no in-kernel cross-rank exchange, batch <= 64, obs <= 64).
+// SPO_UPDATE_FORM: 0 = four-wave kernel everywhere, 2 = main + helper waves (default) where that form applies (persistent PPO step, clipped-surrogate loss, no in-kernel cross-rank exchange, batch <= 64, obs <= 64).
 inline int update_form() {
   static const int v = [] { const char* e = getenv("SPO_UPDATE_FORM"); return e ? atoi(e) : 2; }();
   return v;
@@ -2617,8 +1878,8 @@ inline int update_form() {
 template <int K, bool PROF = false>
 int launch_update_h(const UpdArgs& a_in, int blocks, hipStream_t st) {
   UpdArgs a = a_in;
-  if (int rc = spo::hip_check(hipGetSymbolAddress(reinterpret_cast<void**>(&a.backup), HIP_SYMBOL(g_upd8_backup)),
-                              "hipGetSymbolAddress(g_upd8_backup)")) return rc;
+  if (int rc = spo::hip_check(hipGetSymbolAddress(reinterpret_cast<void**>(&a.backup), HIP_SYMBOL(g_upd_backup)),
+                              "hipGetSymbolAddress(g_upd_backup)")) return rc;
   // [parity][network][helper wave] norm granules of this form (tags restart at 1 with every launch)
   if (int rc = spo::hip_check(hipGetSymbolAddress(reinterpret_cast<void**>(&a.slots), HIP_SYMBOL(g_h_slots)),
                               "hipGetSymbolAddress(g_h_slots)")) return rc;
@@ -2635,23 +1896,6 @@ int launch_update_h(const UpdArgs& a_in, int blocks, hipStream_t st) {
   return 0;
 }
 
-template <int K, bool PROF>
-int launch_update8(const UpdArgs& a_in, int blocks, hipStream_t st) {
-  UpdArgs a = a_in;
-  if (int rc = spo::hip_check(hipGetSymbolAddress(reinterpret_cast<void**>(&a.backup), HIP_SYMBOL(g_upd8_backup)),
-                              "hipGetSymbolAddress(g_upd8_backup)")) return rc;
-  const size_t sh = UpdLds<K>::SIZE * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_update8_kernel<K, PROF>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    if (e != hipSuccess) return spo::hip_check(e, "hipFuncSetAttribute(update8)");
-    attr_done = true;
-  }
-  hipLaunchKernelGGL((ppo_update8_kernel<K, PROF>), dim3(8 * (blocks - 1) + 1), dim3(512), sh, st, a);
-  return 0;
-}
-
 template <bool PERSIST, int AMODE = 0, int XR = 0>
 int launch_update(const UpdArgs& a, int blocks, hipStream_t st) {
   const int kin = pick_kin(a.cfg.obs_dim);
@@ -2660,12 +1904,6 @@ int launch_update(const UpdArgs& a, int blocks, hipStream_t st) {
     if (kin == 16) return launch_update_h<16>(a, blocks, st);
     if (kin == 32) return launch_update_h<32>(a, blocks, st);
     return launch_update_h<64>(a, blocks, st);
-  }
-  if (PERSIST && AMODE == 0 && XR == 0 && kin <= 64 && a.cfg.batch <= 64 && update_form() == 1) {
-    if (a.prof && kin == 64) return launch_update8<64, true>(a, blocks, st);
-    if (kin == 16) return launch_update8<16, false>(a, blocks, st);
-    if (kin == 32) return launch_update8<32, false>(a, blocks, st);
-    return launch_update8<64, false>(a, blocks, st);
   }
   if (PERSIST && AMODE == 0 && a.prof && kin == 64) {
     const size_t sh = UpdLds<64>::SIZE * sizeof(float);
