@@ -239,7 +239,11 @@ def main():
     achieved = gae_bytes / disp_avg / 1e9
     pmc = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02", "gae_pmc.json")))
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r02", "gae_pmc.json")))
+        hit = [l for l in pj["launches"] if l["num_envs"] == N and l["folded"] == folded and T == 128]
+        if hit:
+            pmc = {"hbm_bytes_per_launch": round(hit[0]["hbm_bytes"]), "traffic_over_algorithmic": hit[0]["traffic_over_algorithmic"],
+                   "source": "profiles/r02/gae_pmc.json: " + pj["source"] + "; " + pj["corrections"]}
     except Exception:
         pass
     roofline = {"kernel": "gae_kernel (spo_gae_fused" + (", folded bootstrap form)" if folded else ")"), "bound": "hbm", "achieved": round(achieved, 1),

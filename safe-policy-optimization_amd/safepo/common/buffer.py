@@ -172,17 +172,19 @@ class VectorizedOnPolicyBuffer:
         return e0.elapsed_time(e1) * 1e-3 / reps
 
 
-    def time_scan_dispatches(self, reps: int = 50):
+    def time_scan_dispatches(self, reps: int = 50, warm: int = 10):
         """Per-dispatch GPU time (seconds, one entry per launch) of spo_gae_fused on the current buffer contents: every
         dispatch carries its own start / stop events (spo_gae_fused_timed), i.e. the timestamps of the dispatch packet
         itself -- the per-dispatch duration rocprofv3 --kernel-trace reports, unlike the graph average of time_scan,
         in which the command processor overlaps one dispatch's end-of-kernel tail with the next one's start."""
         import ctypes
         args = self._scan_args
-        out = (ctypes.c_float * reps)()
+        out = (ctypes.c_float * (warm + reps))()
         torch.cuda.synchronize(self._device)
-        _abi.check(self._lib.spo_gae_fused_timed(*args, reps, out, _abi.stream_ptr()), "spo_gae_fused_timed")
-        return [float(x) * 1e-6 for x in out]
+        # `warm` untimed-in-effect dispatches first: the launches that directly follow a long persistent kernel (3 busy CUs
+        # for seconds) run at ramping clocks with a cold cache -- 2-3x the steady duration -- and would dominate a mean
+        _abi.check(self._lib.spo_gae_fused_timed(*args, warm + reps, out, _abi.stream_ptr()), "spo_gae_fused_timed")
+        return [float(x) * 1e-6 for x in out][warm:]
 
 
 class SeparatedReplayBuffer:
