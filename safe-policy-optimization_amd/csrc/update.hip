@@ -68,7 +68,15 @@ constexpr int XR_SLOT_F4 = (8 + 7) * 256;                               // eleme
 constexpr size_t XR_SLOT_WORDS = (size_t)4 * XR_SLOT_F4;                // 4 planes of u64
 constexpr size_t XR_SLOT1_WORDS = (size_t)2 * XR_MAX_WORLD * 3 * XR_SLOT_WORDS;     // [parity][source rank][network]
 constexpr size_t XR_RED2_WORDS = (size_t)2 * 3 * XR_SLOT_WORDS;                     // [parity][network]
-constexpr size_t XR_REGION_BYTES = (XR_SLOT1_WORDS + XR_RED2_WORDS) * 8;
+constexpr size_t XR_V1_BYTES = (XR_SLOT1_WORDS + XR_RED2_WORDS) * 8;                // tagged-word protocols (above)
+// All-to-all form used by the helper waves of ppo_update_h_kernel (xr_a2a_* below): plain float4 rows plus one flag per
+// (source rank, network, stage, helper wave), in their own part of the region so the two protocols never see each other's words.
+constexpr int A2A_ROWS = 13;                                                        // slot rows 0 .. NT1 + 8
+constexpr size_t A2A_DATA_F4 = (size_t)2 * XR_MAX_WORLD * 3 * A2A_ROWS * 256;       // [parity][source][network][row][lane]
+constexpr size_t A2A_FLAG_WORDS = (size_t)2 * XR_MAX_WORLD * 3 * 2 * 4;             // [parity][source][network][stage][wave]
+constexpr size_t A2A_DATA_OFF = XR_V1_BYTES;
+constexpr size_t A2A_FLAG_OFF = A2A_DATA_OFF + A2A_DATA_F4 * 16;
+constexpr size_t XR_REGION_BYTES = A2A_FLAG_OFF + A2A_FLAG_WORDS * 8;
 
 struct UpdArgs {
   float* theta; float* adam_m; float* adam_v;
@@ -93,6 +101,7 @@ struct UpdArgs {
   // cross-rank (data-parallel) gradient exchange inside the persistent kernel: XR instantiations only
   int xr_rank, xr_world;
   int xr_algo;                         // 1: recursive doubling at power-of-two worlds; 0: reduce-scatter + all-gather everywhere
+  int xr_debug;                        // SPO_A2A_DEBUG bits (development): 1 no row stores, 2 no flag stores/waits, 4 no row loads
   unsigned xr_step0;                   // global optimiser-step count before this launch (same on every rank)
   void* xr_region[XR_MAX_WORLD];       // every rank's exchange region (own + IPC-mapped peers), indexed by rank
   float* backup;                       // main + helper form: [UPD_BACKUP_ROWS][3 workgroups][512 lanes] float4 backup rows
@@ -155,6 +164,12 @@ struct ColData {
 // is data-dependent on this and cannot be scheduled back up to the load.
 __device__ __forceinline__ float pinned(float v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ int pinned(int v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ f4 pinned4(f4 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(v));
+#endif
+  return v;
+}
 
 typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) unsigned long long gu64;    // global address space: global_* not flat_*
@@ -1081,13 +1096,135 @@ struct UpdHLds {
   static constexpr int G3 = G1 + 4 * NT1 * 64 * 4;          // [4][2][64] float4: W3 tile, (unused)
   static constexpr int GB = G3 + 4 * 2 * 64 * 4;            // [3][256] floats: db1, db2, db3 as the main lanes hold them
   static constexpr int XW = GB + 3 * 256;                   // 32 floats of helper-to-helper / helper-to-main words
-  static constexpr int SIZE = XW + 32;
+  static constexpr int SIZE = XW + 32 + 2 * XR_MAX_WORLD;   // + the ranks' exchange-region pointers (8-byte aligned: XW is even)
+  static_assert(XW % 2 == 0, "pointer table alignment");
   static_assert(4 * 4 * 64 * 4 <= HID * LDB, "G2 must fit the dZ1^T image");
 };
 // words in XW (as 32-bit): [0..7] {tag, ||g||^2 partial} per helper wave, [8..15] {tag, sum p^2 partial},
 //                          [16,17] {tag, clip coefficient}, [18] redo tag (step whose forward must be repeated)
 
-template <int KIN, bool PROF = false>
+// All-to-all form of the cross-rank gradient mean for the helper waves of ppo_update_h_kernel: ONE exchange round at any
+// world size.  The tagged-word protocols above make the CONSUMER poll every float (8 bytes each): at 8 ranks that is
+// 7 x 43 words per lane, far more than fits in registers, i.e. many dependent round trips to local memory.  Here a helper
+// wave writes its float4 rows plainly (write-through, system scope) into slot [parity][source = me][network][row] of every
+// peer, waits until its stores are acknowledged (s_waitcnt vmcnt(0)), and then raises ONE flag per peer (the global step
+// count).  The consumer wave polls world - 1 flags, after which the rows are ordinary 16-byte loads that can be issued back
+// to back: G rows x (world - 1) sources in flight at once, summed IN RANK ORDER (own contribution at position `me`), so all
+// replicas add the same values in the same order and hold identical bits.  Cost of the round: one store acknowledgement
+// plus one flag flight plus the streamed loads, at any world size.  Buffers are double-buffered by step parity as above.
+// (the row base is wave-uniform; readfirstlane pins it to SGPRs, which the "s" operands of the accesses below require)
+__device__ __forceinline__ f4* a2a_row(void* region, int par, int src, int net, int row) {
+  const unsigned long long p = reinterpret_cast<unsigned long long>(reinterpret_cast<char*>(region) + A2A_DATA_OFF) +
+                               ((((size_t)par * XR_MAX_WORLD + src) * 3 + net) * A2A_ROWS + row) * 256 * sizeof(f4);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+  return reinterpret_cast<f4*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ unsigned long long* a2a_flag(void* region, int par, int src, int net, int stage, int wave) {
+  return reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(region) + A2A_FLAG_OFF) +
+         ((((size_t)par * XR_MAX_WORLD + src) * 3 + net) * 2 + stage) * 4 + wave;
+}
+// (uniform row base in SGPRs + one 32-bit lane offset: no per-access 64-bit address registers)
+__device__ __forceinline__ void a2a_store(const f4* row_base, unsigned lane_byte_off, const f4 v) {
+#if defined(__HIP_DEVICE_COMPILE__)          // (the host pass would reject the register constraints)
+  // s_nop 4: the base may have just been written by a VALU instruction (v_readfirstlane / v_readlane of a spilled SGPR);
+  // gfx9 needs 5 wait states between that and a VMEM instruction reading the SGPR, and the hazard recogniser does not
+  // look inside inline assembly
+  asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(lane_byte_off), "v"(v), "s"(row_base) : "memory");
+#endif
+}
+// region pointer of rank `idx` from the LDS copy of the kernel-argument table (the table in SGPRs costs 16 of them for the
+// whole kernel, and indexing it dynamically is not possible)
+__device__ __forceinline__ void* a2a_region(const unsigned long long* tab, int idx) {
+  return reinterpret_cast<void*>(tab[idx]);
+}
+// The world size R is a template parameter and a rank treats ITSELF like any other peer (it also writes its rows and its
+// flag into its own region), so every loop below is a plain constant-trip loop: no rank-dependent control flow.
+template <int R>
+__device__ __forceinline__ void a2a_push_row(const UpdArgs& a, const unsigned long long* tab, int net, int hl, int par, int row,
+                                             const f4 g) {
+  const int me = a.xr_rank;
+  if (a.xr_debug & 1) return;
+#pragma unroll
+  for (int r = 0; r < R; ++r) a2a_store(a2a_row(a2a_region(tab, r), par, me, net, row), (unsigned)hl * 16u, g);
+}
+// after the pushes of a stage: stores acknowledged, then the flag (lanes 0 .. R-1 of the wave: one destination each)
+template <int R>
+__device__ __forceinline__ void a2a_signal(const UpdArgs& a, const unsigned long long* tab, int net, int lane, int wave, int par,
+                                           int stage, unsigned gtag) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  const int me = a.xr_rank;
+  if (lane < R && !(a.xr_debug & 2))
+    __hip_atomic_store(a2a_flag(a2a_region(tab, lane), par, me, net, stage, wave), (unsigned long long)gtag, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// lane r of the wave waits for rank r's flag of this (stage, wave); bounded, wave-uniform outcome
+template <int R>
+__device__ __forceinline__ void a2a_wait(const UpdArgs& a, const unsigned long long* tab, int net, int lane, int wave, int par,
+                                         int stage, unsigned gtag, volatile int* dead, int* err) {
+  if (lane < R && *dead == 0 && !(a.xr_debug & 2)) {
+    unsigned long long* const f = a2a_flag(a2a_region(tab, a.xr_rank), par, lane, net, stage, wave);
+    unsigned spins = 0;
+    while ((unsigned)__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != gtag) {
+      if (++spins > XR_SPIN_LIMIT) { *err = 2; *dead = 1; break; }             // bounded: never hang the GPU
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  // (the branch re-converges here: every lane continues only after the polling lanes have seen their flags)
+}
+// G rows at once: R x G loads in flight, one wait, sums in rank order; returns the MEAN over the ranks
+template <int R, int G>
+__device__ __forceinline__ void a2a_pull(const UpdArgs& a, const unsigned long long* tab, int net, int hl, int par,
+                                         const int (&rows)[G], f4 (&g)[G]) {
+  if (a.xr_debug & 4) return;
+  void* const mine = a2a_region(tab, a.xr_rank);
+  f4 x[G][R];
+#pragma unroll
+  for (int v = 0; v < G; ++v)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const f4* const base = a2a_row(mine, par, r, net, rows[v]);
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc0 sc1" : "=v"(x[v][r]) : "v"((unsigned)hl * 16u), "s"(base) : "memory");
+#else
+      x[v][r] = base[hl];
+#endif
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  const float inv_world = 1.f / (float)R;
+#pragma unroll
+  for (int v = 0; v < G; ++v) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) x[v][r] = pinned4(x[v][r]);              // the asm outputs are valid only after the wait
+    f4 run = x[v][0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) run += x[v][r];
+    g[v] = run * inv_world;
+  }
+}
+
+// N rows in groups of GS (fewer rows in flight at 8 ranks: G x R float4 must fit beside the optimiser state)
+template <int R, int N, int C0 = 0>
+__device__ __forceinline__ void a2a_pull_all(const UpdArgs& a, const unsigned long long* tab, int net, int hl, int par,
+                                             const int (&rows)[N], f4 (&g)[N]) {
+  constexpr int GS = (R >= 8) ? 2 : 3;
+  if constexpr (C0 < N) {
+    constexpr int G = (N - C0) < GS ? (N - C0) : GS;
+    int rr[G];
+    f4 gg[G];
+#pragma unroll
+    for (int v = 0; v < G; ++v) { rr[v] = rows[C0 + v]; gg[v] = g[C0 + v]; }
+    a2a_pull<R, G>(a, tab, net, hl, par, rr, gg);
+#pragma unroll
+    for (int v = 0; v < G; ++v) g[C0 + v] = gg[v];
+    a2a_pull_all<R, N, C0 + G>(a, tab, net, hl, par, rows, g);
+  }
+}
+
+template <int KIN, bool PROF = false, int XR = 0>        // XR: world size of the in-kernel data-parallel exchange (0 = none)
 __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
   // PROF: wave 0 of each role of the LAST workgroup accumulates shader cycles per interval (a.prof rows 0 = main, 1 = helper)
   unsigned long long pacc[NPHASE] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1121,6 +1258,9 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
   stage_net<KIN>(a.theta, g, lds, tid, 512);
   if (is_actor && tid < A) red[128 + tid] = a.theta[ls_off + tid];
   if (tid < 32) xw[tid] = 0;
+  const unsigned long long* const xtab = reinterpret_cast<const unsigned long long*>(lds + H::XW + 32);
+  if (XR > 0 && tid < XR_MAX_WORLD)
+    reinterpret_cast<unsigned long long*>(lds + H::XW + 32)[tid] = reinterpret_cast<unsigned long long>(a.xr_region[tid]);
   __syncthreads();
 
   const int64_t nsteps = (a.M + B - 1) / B;
@@ -1539,6 +1679,29 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
     {
       // ---- layer 1 (W1, b1): L2 term, norm share, SPECULATIVE Adam (clip coefficient 1)
       SPO_REIDX
+      if constexpr (XR > 0) {
+        // data-parallel: the gradient of the GLOBAL minibatch = mean over the ranks, exchanged layer by layer; layer 1 goes
+        // out while the main waves still compute dW2 / dW3.  The reduced values replace the local ones in G1 / GB[0].
+        const unsigned gtag = a.xr_step0 + (unsigned)s + 1u;
+        const int par = (int)(gtag & 1u), hl = wave * 64 + lane;
+        f4 gx[NT1 + 1];
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt) gx[nt] = *reinterpret_cast<const f4*>(lds + H::G1 + ((wave * NT1 + nt) * 64 + lane) * 4);
+        gx[NT1] = f4{lds[H::GB + 0 * 256 + hl], 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int v = 0; v <= NT1; ++v) a2a_push_row<XR>(a, xtab, net, hl, par, v < NT1 ? v : NT1 + 5, gx[v]);
+        a2a_signal<XR>(a, xtab, net, lane, wave, par, 0, gtag);
+        a2a_wait<XR>(a, xtab, net, lane, wave, par, 0, gtag, xw + 19, a.err);
+        {
+          int rows[NT1 + 1];
+#pragma unroll
+          for (int v = 0; v <= NT1; ++v) rows[v] = v < NT1 ? v : NT1 + 5;
+          a2a_pull_all<XR, NT1 + 1>(a, xtab, net, hl, par, rows, gx);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt) *reinterpret_cast<f4*>(lds + H::G1 + ((wave * NT1 + nt) * 64 + lane) * 4) = gx[nt];
+        lds[H::GB + 0 * 256 + hl] = gx[NT1][0];
+      }
       pw1 *= (double)b1c; pw2 *= (double)b2c;
       step_size = (float)((double)lr / (1.0 - pw1));
       inv_bc2s = (float)(1.0 / sqrt(1.0 - pw2));
@@ -1571,6 +1734,59 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
     f4 pW2[4];
     float ggb2, ggb3 = 0.f, bmb2, bvb2, bpb2;
     unsigned long long* const grow = a.slots + (s & 1) * 16;            // [parity][network][helper wave]
+    if constexpr (XR > 0) {
+      // data-parallel: layers 2 and 3 (and the log_std row) in one exchange; the reduced values replace the local ones in
+      // G2 / G3 / GB[1..2] and in the log_std partials (first partial = reduced sum, the other three = 0)
+      const unsigned gtag = a.xr_step0 + (unsigned)s + 1u;
+      const int par = (int)(gtag & 1u), hl = wave * 64 + lane;
+      const bool with_ls = is_actor && wave == 0;                        // wave-uniform
+      f4 gx[7];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) gx[nt] = *reinterpret_cast<const f4*>(lds + H::G2 + ((wave * 4 + nt) * 64 + lane) * 4);
+      gx[4] = *reinterpret_cast<const f4*>(lds + H::G3 + ((wave * 2 + 0) * 64 + lane) * 4);
+      gx[5] = f4{lds[H::GB + 1 * 256 + hl], lds[H::GB + 2 * 256 + hl], 0.f, 0.f};
+      gx[6] = f4{0.f, 0.f, 0.f, 0.f};
+      if (with_ls) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ai = 4 * q_ + r;
+          gx[6][r] = (red[16 + ai] + red[32 + ai]) + (red[48 + ai] + red[64 + ai]);
+        }
+      }
+      const int rows7[7] = {NT1 + 0, NT1 + 1, NT1 + 2, NT1 + 3, NT1 + 4, NT1 + 7, NT1 + 6};
+#pragma unroll
+      for (int v = 0; v < 6; ++v) a2a_push_row<XR>(a, xtab, net, hl, par, rows7[v], gx[v]);
+      if (with_ls) a2a_push_row<XR>(a, xtab, net, hl, par, rows7[6], gx[6]);
+      a2a_signal<XR>(a, xtab, net, lane, wave, par, 1, gtag);
+      a2a_wait<XR>(a, xtab, net, lane, wave, par, 1, gtag, xw + 19, a.err);
+      {
+        int r6[6];
+        f4 g6[6];
+#pragma unroll
+        for (int v = 0; v < 6; ++v) { r6[v] = rows7[v]; g6[v] = gx[v]; }
+        a2a_pull_all<XR, 6>(a, xtab, net, hl, par, r6, g6);
+#pragma unroll
+        for (int v = 0; v < 6; ++v) gx[v] = g6[v];
+        if (with_ls) {
+          const int rc[1] = {rows7[6]};
+          f4 gc[1] = {gx[6]};
+          a2a_pull<XR, 1>(a, xtab, net, hl, par, rc, gc);
+          gx[6] = gc[0];
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f4*>(lds + H::G2 + ((wave * 4 + nt) * 64 + lane) * 4) = gx[nt];
+      *reinterpret_cast<f4*>(lds + H::G3 + ((wave * 2 + 0) * 64 + lane) * 4) = gx[4];
+      lds[H::GB + 1 * 256 + hl] = gx[5][0];
+      lds[H::GB + 2 * 256 + hl] = gx[5][1];
+      if (with_ls) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ai = 4 * q_ + r;
+          red[16 + ai] = gx[6][r]; red[32 + ai] = 0.f; red[48 + ai] = 0.f; red[64 + ai] = 0.f;
+        }
+      }
+    }
     {
       SPO_REIDX
 #pragma unroll
@@ -1866,8 +2082,9 @@ int pick_kin(int D) { return D <= 16 ? 16 : D <= 32 ? 32 : D <= 64 ? 64 : 128; }
 unsigned long long* g_prof_buf = nullptr;
 
 // backup rows of the main + helper kernel (one launch of it at a time per process and device; L2-resident)
-__device__ float4 g_upd_backup[UPD_BACKUP_ROWS * 3 * 512];
-__device__ unsigned long long g_h_slots[32];
+// one set per rank slot: a process may drive several ranks of one device at once (tools/p2p_loopback_bench.py)
+__device__ float4 g_upd_backup[XR_MAX_WORLD][UPD_BACKUP_ROWS * 3 * 512];
+__device__ unsigned long long g_h_slots[XR_MAX_WORLD][32];
 
 // SPO_UPDATE_FORM: 0 = four-wave kernel everywhere, 2 = main + helper waves (default) where that form applies (persistent PPO step, clipped-surrogate loss, no in-kernel cross-rank exchange, batch <= 64, obs <= 64).
 inline int update_form() {
@@ -1875,24 +2092,29 @@ inline int update_form() {
   return v;
 }
 
-template <int K, bool PROF = false>
+template <int K, bool PROF = false, int XR = 0>
 int launch_update_h(const UpdArgs& a_in, int blocks, hipStream_t st) {
   UpdArgs a = a_in;
-  if (int rc = spo::hip_check(hipGetSymbolAddress(reinterpret_cast<void**>(&a.backup), HIP_SYMBOL(g_upd_backup)),
+  const int rslot = XR ? a.xr_rank : 0;
+  float4* bkbase = nullptr;
+  unsigned long long* slbase = nullptr;
+  if (int rc = spo::hip_check(hipGetSymbolAddress(reinterpret_cast<void**>(&bkbase), HIP_SYMBOL(g_upd_backup)),
                               "hipGetSymbolAddress(g_upd_backup)")) return rc;
   // [parity][network][helper wave] norm granules of this form (tags restart at 1 with every launch)
-  if (int rc = spo::hip_check(hipGetSymbolAddress(reinterpret_cast<void**>(&a.slots), HIP_SYMBOL(g_h_slots)),
+  if (int rc = spo::hip_check(hipGetSymbolAddress(reinterpret_cast<void**>(&slbase), HIP_SYMBOL(g_h_slots)),
                               "hipGetSymbolAddress(g_h_slots)")) return rc;
+  a.backup = reinterpret_cast<float*>(bkbase + (size_t)rslot * UPD_BACKUP_ROWS * 3 * 512);
+  a.slots = slbase + (size_t)rslot * 32;
   if (int rc = spo::hip_check(hipMemsetAsync(a.slots, 0, sizeof(unsigned long long) * 32, st), "hipMemsetAsync(g_h_slots)")) return rc;
   const size_t sh = UpdHLds<K>::SIZE * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_update_h_kernel<K, PROF>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_update_h_kernel<K, PROF, XR>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return spo::hip_check(e, "hipFuncSetAttribute(update_h)");
     attr_done = true;
   }
-  hipLaunchKernelGGL((ppo_update_h_kernel<K, PROF>), dim3(8 * (blocks - 1) + 1), dim3(512), sh, st, a);
+  hipLaunchKernelGGL((ppo_update_h_kernel<K, PROF, XR>), dim3(8 * (blocks - 1) + 1), dim3(512), sh, st, a);
   return 0;
 }
 
@@ -2042,6 +2264,7 @@ static int fill_xr(UpdArgs& a, int rank, int world, void* const* regions, unsign
   a.xr_rank = rank; a.xr_world = world; a.xr_step0 = step0;
   const char* algo = getenv("SPO_P2P_ALGO");                 // "twophase" forces the reduce-scatter form everywhere
   a.xr_algo = (algo && !strcmp(algo, "twophase")) ? 0 : 1;
+  { const char* dbg = getenv("SPO_A2A_DEBUG"); a.xr_debug = dbg ? atoi(dbg) : 0; }
   for (int r = 0; r < XR_MAX_WORLD; ++r) a.xr_region[r] = r < world ? regions[r] : nullptr;
   return 0;
 }
@@ -2140,7 +2363,22 @@ extern "C" int spo_ppo_lag_update_iter_dp(float* theta, float* adam_m, float* ad
   a.pow_b1_actor = a.pow_b1; a.pow_b2_actor = a.pow_b2;
   a.first_net = 0; a.n_nets = 3; a.stale_sq = 0.f; a.stale_io = nullptr;
   int rc = 0;
-  if (a.xr_algo == 1 && (world & (world - 1)) == 0) rc = launch_update<true, 0, 2>(a, 3, st);
+  const int kin = pick_kin(cfg_host->obs_dim);
+  // SPO_P2P_A2A=1 (opt-in): main + helper kernel with the flag-based all-to-all exchange on the helper waves.  One exchange
+  // round at any world size, layer by layer beside the main waves' MFMAs -- but in single-GPU loopback (all ranks sharing
+  // one memory system) it measured SLOWER than recursive doubling on the four-wave kernel (18.6 / 23.9 / 33.5 against
+  // 15.9 / 18.8 / 24.0 us per step at 2 / 4 / 8 ranks): a store acknowledgement plus a flag flight plus the row loads per
+  // stage cost more than three tagged-word hand-offs there.  Kept for measurement on a real xGMI node.
+  static const bool a2a = [] { const char* e = getenv("SPO_P2P_A2A"); return e && e[0] == '1'; }();
+  if (a2a && kin <= 64 && cfg_host->batch <= 64 && update_form() == 2 && a.xr_algo == 1 && (world == 2 || world == 4 || world == 8)) {
+    // main + helper form with the all-to-all exchange on the helper waves (one hand-off at any world size)
+#define SPO_H_XR(K) (world == 2 ? launch_update_h<K, false, 2>(a, 3, st) : world == 4 ? launch_update_h<K, false, 4>(a, 3, st) \
+                                                                                         : launch_update_h<K, false, 8>(a, 3, st))
+    if (kin == 16) rc = SPO_H_XR(16);
+    else if (kin == 32) rc = SPO_H_XR(32);
+    else rc = SPO_H_XR(64);
+#undef SPO_H_XR
+  } else if (a.xr_algo == 1 && (world & (world - 1)) == 0) rc = launch_update<true, 0, 2>(a, 3, st);
   else rc = launch_update<true, 0, 1>(a, 3, st);
   if (rc) return rc;
   SPO_LAUNCH_CHECK("spo_ppo_lag_update_iter_dp");
