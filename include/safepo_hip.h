@@ -99,6 +99,16 @@ int spo_policy_step(const float* theta, const float* obs, const float* eps,
  * then obs <- (obs - mean) / sqrt(var + 1e-8), in place. */
 int spo_obs_normalize(float* obs, double* rms_state, int64_t num_envs, int obs_dim, int update, void* stream);
 
+/* a-1 + a-2 fused (north_star: "fused obs-normalise + MLP forward"): spo_policy_step on RAW observations with the
+ * SafeNormalizeObservation wrapper's arithmetic (wrappers.py:42-49 -> gymnasium NormalizeObservation / RunningMeanStd) folded
+ * in.  update != 0: the batch is first merged into rms_state (mean[D], var[D], count; fp64; parallel-variance merge).  Then
+ * every row is read ONCE, normalised in registers as (float)(((double)x - mean) / sqrt(var + 1e-8)), fed to the three
+ * networks, stored to the buffer slot and written back to obs_inout (the wrapper hands the normalised observation on). */
+int spo_policy_step_norm(const float* theta, float* obs_inout, double* rms_state, int update, const float* eps,
+                         float* act, float* logp, float* v_r, float* v_c,
+                         float* buf_obs, float* buf_act, float* buf_logp, float* buf_v_r, float* buf_v_c,
+                         int64_t num_envs, int64_t T, int64_t t, int obs_dim, int act_dim, void* stream);
+
 /* critics only (bootstrap values of ppo_lag.py:201-215): v_r, v_c for `rows` observations. */
 int spo_values(const float* theta, const float* obs, float* v_r, float* v_c,
                int64_t rows, int obs_dim, int act_dim, void* stream);

@@ -722,3 +722,9 @@ if __name__ == "__main__":
     for _algo in ("natural_pg", "trpo"):
         golden_trace(_algo, f"{_algo}_trace.npz", num_envs=4, T=48, epochs=2, env_kw=env_kw,
                      cfg_over={"learning_iters": 2, "batch_size": 64})
+    # the Lagrangian trust-region siblings: a multiplier that starts away from zero and a binding cost limit, so the
+    # advantage mix (rcpo.py:325-326, trpo_lag.py:326-327) and the multiplier update both matter in every epoch
+    for _algo in ("rcpo", "trpo_lag"):
+        golden_trace(_algo, f"{_algo}_trace.npz", num_envs=4, T=48, epochs=3, env_kw=env_kw,
+                     cfg_over={"learning_iters": 2, "batch_size": 64},
+                     args_over={"cost_limit": 1.0, "lagrangian_multiplier_init": 0.5})

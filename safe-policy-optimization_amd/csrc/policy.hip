@@ -18,6 +18,9 @@ struct StepArgs {
   float* act; float* logp; float* v_r; float* v_c;
   float* buf_obs; float* buf_act; float* buf_logp; float* buf_v_r; float* buf_v_c;
   int64_t N; int64_t T; int64_t t; int D; int A;
+  const double* rms;     // optional running (mean[D], var[D], count): normalise the observation row on load (a-2 fused)
+  float* obs_io;         // with rms: the normalised row is also written back here (the wrapper returns normalised obs)
+  double rms_eps;
 };
 
 // 256 threads = 4 waves; wave w owns rows [64*block + 16w, +16).  Networks are staged through one
@@ -32,6 +35,22 @@ __global__ __launch_bounds__(256) void policy_step_kernel(StepArgs a) {
   const int64_t rrow = valid ? row : a.N - 1;
   f4 x[KIN / 16];
   load_obs_tiles<KIN>(a.obs + rrow * D, D, q, x);
+  if (a.rms) {
+    // NormalizeObservation.normalize (reference wrappers.py:42-49 -> gymnasium): (obs - mean) / sqrt(var + 1e-8) in float64
+    // with the statistics spo_obs_stats_update has just merged this batch into, rounded to fp32 once -- in registers, so the
+    // raw row is read once and the network, the buffer slot and the caller all get the normalised values
+#pragma unroll
+    for (int nt = 0; nt < KIN / 16; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = 16 * nt + 4 * q + e;
+        if (c < D) {
+          const double v = ((double)x[nt][e] - a.rms[c]) / sqrt(a.rms[D + c] + a.rms_eps);
+          x[nt][e] = (float)v;
+          if (valid) a.obs_io[row * D + c] = x[nt][e];
+        }
+      }
+  }
   float vout[2] = {0.f, 0.f};
   f4 mu = {0.f, 0.f, 0.f, 0.f};
   constexpr int NNET = WITH_ACTOR ? 3 : 2;
@@ -303,7 +322,7 @@ __global__ void synth_obs_kernel(float* next_obs, float* final_obs, const float*
 // (mean, var, count) in fp64, then obs <- (obs - mean) / sqrt(var + 1e-8) in the input precision (fp32 out).
 // One workgroup per feature column block; fp64 throughout like the numpy original.
 __global__ __launch_bounds__(256) void obs_normalize_kernel(float* obs, double* rms /*[2*D+1]: mean[D], var[D], count*/,
-                                                            int64_t N, int D, int update, double eps) {
+                                                            int64_t N, int D, int update, double eps, int normalize) {
   __shared__ double sh_s[256], sh_q[256];
   const int f = blockIdx.x;                     // feature
   const int tid = threadIdx.x;
@@ -331,9 +350,10 @@ __global__ __launch_bounds__(256) void obs_normalize_kernel(float* obs, double* 
     }
     __syncthreads();
   }
+  if (!normalize) return;                        // statistics only: spo_policy_step_norm normalises on load
   const double mu = mean[f];
-  const double inv = 1.0 / sqrt(var[f] + eps);
-  for (int64_t i = tid; i < N; i += 256) obs[i * D + f] = (float)(((double)obs[i * D + f] - mu) * inv);
+  const double sd = sqrt(var[f] + eps);
+  for (int64_t i = tid; i < N; i += 256) obs[i * D + f] = (float)(((double)obs[i * D + f] - mu) / sd);
 }
 __global__ void obs_normalize_count_kernel(double* rms, int D, int64_t N) { rms[2 * D] += (double)N; }
 
@@ -392,9 +412,34 @@ extern "C" int spo_policy_step(const float* theta, const float* obs, const float
     SPO_REQUIRE(t >= 0 && t < T, "Buffer overflow");          /* reference assert, buffer.py:92 */
   }
   StepArgs a{theta, obs, eps, act, logp, v_r, v_c, buf_obs, buf_act, buf_logp, buf_v_r, buf_v_c,
-             num_envs, T > 0 ? T : 1, buf ? t : 0, obs_dim, act_dim};
+             num_envs, T > 0 ? T : 1, buf ? t : 0, obs_dim, act_dim, nullptr, nullptr, 0.0};
   launch_step<true>(a, (hipStream_t)stream);
   SPO_LAUNCH_CHECK("spo_policy_step");
+  return 0;
+}
+
+extern "C" int spo_policy_step_norm(const float* theta, float* obs_inout, double* rms_state, int update, const float* eps,
+                                    float* act, float* logp, float* v_r, float* v_c, float* buf_obs, float* buf_act,
+                                    float* buf_logp, float* buf_v_r, float* buf_v_c, int64_t num_envs, int64_t T,
+                                    int64_t t, int obs_dim, int act_dim, void* stream) {
+  if (int rc = check_dims(obs_dim, act_dim)) return rc;
+  SPO_REQUIRE(theta && obs_inout && rms_state && act && logp && v_r && v_c, "policy_step_norm: null pointer");
+  SPO_REQUIRE(num_envs > 0, "policy_step_norm: num_envs must be > 0");
+  const bool buf = buf_obs || buf_act || buf_logp || buf_v_r || buf_v_c;
+  if (buf) {
+    SPO_REQUIRE(buf_obs && buf_act && buf_logp && buf_v_r && buf_v_c, "policy_step_norm: all buffer slots or none");
+    SPO_REQUIRE(t >= 0 && t < T, "Buffer overflow");          /* reference assert, buffer.py:92 */
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (update) {
+    // RunningMeanStd.update(batch): the merge needs the whole batch before any row can be normalised with the NEW statistics
+    hipLaunchKernelGGL(obs_normalize_kernel, dim3(obs_dim), dim3(256), 0, st, obs_inout, rms_state, num_envs, obs_dim, 1, 1e-8, 0);
+    hipLaunchKernelGGL(obs_normalize_count_kernel, dim3(1), dim3(1), 0, st, rms_state, obs_dim, num_envs);
+  }
+  StepArgs a{theta, obs_inout, eps, act, logp, v_r, v_c, buf_obs, buf_act, buf_logp, buf_v_r, buf_v_c,
+             num_envs, T > 0 ? T : 1, buf ? t : 0, obs_dim, act_dim, rms_state, obs_inout, 1e-8};
+  launch_step<true>(a, st);
+  SPO_LAUNCH_CHECK("spo_policy_step_norm");
   return 0;
 }
 
@@ -403,7 +448,7 @@ extern "C" int spo_values(const float* theta, const float* obs, float* v_r, floa
   if (int rc = check_dims(obs_dim, act_dim)) return rc;
   SPO_REQUIRE(theta && obs && v_r && v_c && rows > 0, "values: bad args");
   StepArgs a{theta, obs, nullptr, nullptr, nullptr, v_r, v_c, nullptr, nullptr, nullptr, nullptr, nullptr,
-             rows, 1, 0, obs_dim, act_dim};
+             rows, 1, 0, obs_dim, act_dim, nullptr, nullptr, 0.0};
   launch_step<false>(a, (hipStream_t)stream);
   SPO_LAUNCH_CHECK("spo_values");
   return 0;
@@ -499,7 +544,7 @@ extern "C" int spo_synth_env_step(float* next_obs, float* final_obs, float* rewa
 extern "C" int spo_obs_normalize(float* obs, double* rms_state, int64_t num_envs, int obs_dim, int update, void* stream) {
   SPO_REQUIRE(obs && rms_state && num_envs > 0 && obs_dim > 0, "obs_normalize: bad args");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(obs_normalize_kernel, dim3(obs_dim), dim3(256), 0, st, obs, rms_state, num_envs, obs_dim, update, 1e-8);
+  hipLaunchKernelGGL(obs_normalize_kernel, dim3(obs_dim), dim3(256), 0, st, obs, rms_state, num_envs, obs_dim, update, 1e-8, 1);
   if (update) hipLaunchKernelGGL(obs_normalize_count_kernel, dim3(1), dim3(1), 0, st, rms_state, obs_dim, num_envs);
   SPO_LAUNCH_CHECK("spo_obs_normalize");
   return 0;

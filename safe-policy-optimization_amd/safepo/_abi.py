@@ -53,6 +53,7 @@ PROTOTYPES = {
     "spo_adv_apply": (c_int, [P, P, P, P, c_int64, c_double, c_int, c_int, P, P]),
     "spo_policy_step": (c_int, [P] * 12 + [c_int64, c_int64, c_int64, c_int, c_int, P]),
     "spo_obs_normalize": (c_int, [P, P, c_int64, c_int, c_int, P]),
+    "spo_policy_step_norm": (c_int, [P, P, P, c_int] + [P] * 10 + [c_int64, c_int64, c_int64, c_int, c_int, P]),
     "spo_values": (c_int, [P, P, P, P, c_int64, c_int, c_int, P]),
     "spo_boundary_step": (c_int, [P] * 18 + [c_int, c_int64, c_int64, c_int64, c_int, P]),
     "spo_boundary_step_fold": (c_int, [P] * 18 + [c_int, c_int64, c_int64, c_int64, c_int, P, P, c_double, P]),

@@ -86,15 +86,26 @@ class PPOLagEngine:
 
     # ------------------------------------------------------------------ collect
     def collect_step(self, t: int, obs: torch.Tensor, eps: torch.Tensor | None = None,
-                     deterministic: bool = False) -> torch.Tensor:
+                     deterministic: bool = False, rms=None) -> torch.Tensor:
         """policy.step(obs) + buffer.store(obs, act, value_r, value_c, log_prob) for step t
-        (ppo_lag.py:163-164,187-195) in one kernel.  Returns the sampled action [N, A] (device)."""
+        (ppo_lag.py:163-164,187-195) in one kernel.  Returns the sampled action [N, A] (device).
+        `rms`: a DeviceObsNormalizer in fused mode (env.fuse_normalize()): when its `pending` flag says `obs` is still raw,
+        the statistics merge and the normalisation (wrappers.py:42-49) run inside this step (spo_policy_step_norm) and
+        `obs` is normalised in place."""
         b = self.buffer
         assert t == b.ptr and t < self.T, "Buffer overflow"
         obs = _abi.require_gpu_tensor(obs, "obs", torch.float32)
         if not deterministic and eps is None:
             eps = torch.randn((self.N, self.A), device=self.dev, dtype=torch.float32)
         d = b.data
+        if rms is not None and rms.pending:
+            rms.pending = False
+            _abi.check(self.lib.spo_policy_step_norm(
+                _abi.ptr(self.policy.theta), _abi.ptr(obs), _abi.ptr(rms.state), int(rms.update_enabled), _abi.ptr(eps),
+                _abi.ptr(self.act_out), _abi.ptr(self.logp), _abi.ptr(self.v_r), _abi.ptr(self.v_c), _abi.ptr(d["obs"]),
+                _abi.ptr(d["act"]), _abi.ptr(d["log_prob"]), _abi.ptr(d["value_r"]), _abi.ptr(d["value_c"]), self.N, self.T,
+                t, self.D, self.A, _abi.stream_ptr()), "spo_policy_step_norm")
+            return self.act_out
         _abi.check(self.lib.spo_policy_step(
             _abi.ptr(self.policy.theta), _abi.ptr(obs), _abi.ptr(eps), _abi.ptr(self.act_out), _abi.ptr(self.logp),
             _abi.ptr(self.v_r), _abi.ptr(self.v_c), _abi.ptr(d["obs"]), _abi.ptr(d["act"]), _abi.ptr(d["log_prob"]),
@@ -102,11 +113,16 @@ class PPOLagEngine:
             "spo_policy_step")
         return self.act_out
 
-    def post_step(self, t: int, next_obs, reward, cost, terminated, truncated, final_obs=None) -> None:
+    def post_step(self, t: int, next_obs, reward, cost, terminated, truncated, final_obs=None, rms=None) -> None:
         """Everything after env.step for step t (ppo_lag.py:168-234): reward/cost store, episode
-        accumulators, boundary flags, bootstrap values, finish_path marks."""
+        accumulators, boundary flags, bootstrap values, finish_path marks.
+        `rms` (fused normaliser, see collect_step): at the epoch end the bootstrap values are taken from `next_obs`, which the
+        reference's wrapper has already normalised -- a still-raw `next_obs` is merged and normalised here, once."""
         b, st = self.buffer, _abi.stream_ptr()
         epoch_end = t >= self.T - 1
+        if epoch_end and rms is not None and rms.pending:
+            rms.pending = False
+            rms.normalize_(_abi.require_gpu_tensor(next_obs, "next_obs", torch.float32), update=True)
         tens = [_abi.require_gpu_tensor(x, n, torch.float32) for x, n in
                 ((reward, "reward"), (cost, "cost"), (terminated, "terminated"), (truncated, "truncated"))]
         if epoch_end:

@@ -41,11 +41,23 @@ class DeviceObsNormalizer:
         self.state[self.D:2 * self.D] = 1.0
         self.state[2 * self.D] = 1e-4
         self.lib = _abi.load()
+        self.update_enabled = True       # False: frozen statistics (evaluation with checkpointed statistics)
+        self.pending = False             # fused mode: the env's current observation is still raw (see SynthDeviceEnv)
+
+    def load(self, rms, freeze: bool = True) -> None:
+        """Restore checkpointed statistics (state{itr}.pkl "Normalizer": an object or dict with mean / var / count) and,
+        by default, stop updating them -- what evaluate.py needs (reference evaluate.py:53-57 assigns eval_env.obs_rms)."""
+        get = (lambda k: rms[k]) if isinstance(rms, dict) else (lambda k: getattr(rms, k))
+        D = self.D
+        self.state[:D] = torch.as_tensor(np.asarray(get("mean"), np.float64).reshape(-1), device=self.state.device)
+        self.state[D:2 * D] = torch.as_tensor(np.asarray(get("var"), np.float64).reshape(-1), device=self.state.device)
+        self.state[2 * D] = float(get("count"))
+        self.update_enabled = not freeze
 
     def normalize_(self, obs: torch.Tensor, update: bool = True) -> torch.Tensor:
         obs = _abi.require_gpu_tensor(obs, "obs", torch.float32)
-        _abi.check(self.lib.spo_obs_normalize(_abi.ptr(obs), _abi.ptr(self.state), obs.shape[0], self.D, int(update),
-                                              _abi.stream_ptr()), "spo_obs_normalize")
+        _abi.check(self.lib.spo_obs_normalize(_abi.ptr(obs), _abi.ptr(self.state), obs.shape[0], self.D,
+                                              int(update and self.update_enabled), _abi.stream_ptr()), "spo_obs_normalize")
         return obs
 
     @property
@@ -78,7 +90,8 @@ class SynthDeviceEnv:
         self.terminated, self.truncated = torch.zeros(N, **f32), torch.zeros(N, **f32)
         self.t_env = torch.zeros(N, dtype=torch.int32, device=self.dev)
         self.step_count = 0
-        self.obs_rms = {"mean": np.zeros(D), "var": np.ones(D), "count": 1e-4}   # identity normaliser
+        self.fused_normalizer = None
+        self._identity_rms = {"mean": np.zeros(D), "var": np.ones(D), "count": 1e-4}
         self.single_observation_space, self.single_action_space = Box(D), Box(act_dim, -1.0, 1.0)
 
     def _advance(self):
@@ -91,8 +104,34 @@ class SynthDeviceEnv:
         if self.normalizer is not None:
             # raw observations x*scale + shift, then the running normaliser (as the wrapper does in step())
             self.obs.mul_(self.obs_scale).add_(self.obs_shift)
-            self.normalizer.normalize_(self.obs, update=True)
-            self.obs_rms = self.normalizer.obs_rms if self.step_count % 1024 == 0 else self.obs_rms
+            if self.fused_normalizer is not None:
+                # fused mode: the observation stays RAW here; the training loop hands `fused_normalizer` to
+                # engine.collect_step / post_step, whose kernels merge the statistics and normalise on load
+                # (spo_policy_step_norm) -- once per observation, tracked by `pending`
+                self.normalizer.pending = True
+            else:
+                self.normalizer.normalize_(self.obs, update=True)
+
+    @property
+    def obs_rms(self):
+        """What the training loop checkpoints into state{itr}.pkl (ppo_lag.py:383): the live statistics."""
+        return self.normalizer.obs_rms if self.normalizer is not None else self._identity_rms
+
+    @obs_rms.setter
+    def obs_rms(self, rms):
+        self.load_obs_rms(rms)
+
+    def load_obs_rms(self, rms, freeze: bool = True) -> None:
+        """Checkpointed statistics for evaluation (reference evaluate.py:53-57): restored into the device normaliser and
+        frozen.  Without a normaliser (normalize_obs=False) the statistics are ignored, as an identity wrapper would."""
+        if self.normalizer is not None and rms is not None:
+            self.normalizer.load(rms, freeze=freeze)
+
+    def fuse_normalize(self, on: bool = True):
+        """Leave observations raw and let the engine's fused kernel normalise them (returns the normaliser to pass as
+        `rms=` to collect_step / post_step, or None when this env does not normalise)."""
+        self.fused_normalizer = self.normalizer if (on and self.normalizer is not None) else None
+        return self.fused_normalizer
 
     def reset(self, seed=None):
         if seed is not None:

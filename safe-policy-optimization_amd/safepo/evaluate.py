@@ -46,7 +46,10 @@ def eval_single_agent(eval_dir: str, eval_episodes: int, device: str = "cuda:0")
     if norm_path is not None:
         norm = joblib.load(open(norm_path, "rb")).get("Normalizer")
         if norm is not None:
-            eval_env.obs_rms = norm
+            if hasattr(eval_env, "load_obs_rms"):
+                eval_env.load_obs_rms(norm, freeze=True)      # device normaliser: restore the statistics and stop updating them
+            else:
+                eval_env.obs_rms = norm
     rews, costs, lens = deque(maxlen=50), deque(maxlen=50), deque(maxlen=50)
     host_env = not getattr(eval_env, "is_device_env", False)          # host envs take numpy actions
     first = lambda v: float(v[0]) if not torch.is_tensor(v) else float(v[0].item())

@@ -63,13 +63,16 @@ def run(args, cfg_env, default_cfg: dict, line_search: bool, use_lagrange: bool)
     logger.save_config(dict_args)
     logger.setup_torch_saver(policy.actor)
     logger.log("Start with training.")
+    # device envs that normalise observations hand the normaliser over: statistics merge + normalisation then run inside
+    # the collect kernel (spo_policy_step_norm), one pass over the raw observations
+    rms = env.fuse_normalize(True) if hasattr(env, "fuse_normalize") else None
     obs, _ = env.reset()
     obs = _to_dev(obs, device)
     outs = []
     for epoch in range(epochs):
         rollout_start_time = time.time()
         for steps in range(local_steps_per_epoch):
-            act = engine.collect_step(steps, obs)
+            act = engine.collect_step(steps, obs, rms=rms)
             action = act if device_env else act.detach().squeeze().cpu().numpy()
             next_obs, reward, cost, terminated, truncated, info = env.step(action)
             final_obs = None
@@ -80,7 +83,7 @@ def run(args, cfg_env, default_cfg: dict, line_search: bool, use_lagrange: bool)
                 final_obs = _to_dev(fo, device)
             next_obs = _to_dev(next_obs, device)
             engine.post_step(steps, next_obs, _to_dev(reward, device), _to_dev(cost, device),
-                             _to_dev(terminated, device), _to_dev(truncated, device), final_obs)
+                             _to_dev(terminated, device), _to_dev(truncated, device), final_obs, rms=rms)
             obs = next_obs
         engine.drain_episode_events(logger)
         torch.cuda.synchronize(device)

@@ -828,6 +828,68 @@ def test_obs_normalizer_vs_oracle_running_mean_std(dev):
     np.testing.assert_allclose(got, ((x - ref.mean) / np.sqrt(ref.var + 1e-8)).astype(np.float32), rtol=1e-5, atol=1e-5)
 
 
+def test_fused_normalise_policy_step_vs_oracle(dev, tmp_path):
+    """a-1 + a-2 fused (spo_policy_step_norm): RAW observations in; statistics merged, rows normalised on load, networks
+    evaluated, buffer slot and the caller's tensor filled with the normalised rows -- against the restated
+    RunningMeanStd / normalize (float64, rounded to fp32 once) followed by the oracle policy step on the normalised rows."""
+    import argparse
+    from safepo.common.engine import PPOLagEngine
+    from safepo.common.env import DeviceObsNormalizer
+    from safepo.common.model import ActorVCritic
+    rng = np.random.default_rng(1)
+    N, T, D, A = 300, 3, 60, 8
+    torch.manual_seed(5)
+    pol = ActorVCritic(D, A).to(dev)
+    ref = R.OraclePolicy(D, A)
+    ref.load_state_dict({k: v.cpu().clone() for k, v in pol.state_dict().items()})
+    cfg = {"hidden_sizes": [64, 64], "gamma": 0.99, "target_kl": 0.02, "batch_size": 64, "learning_iters": 1, "max_grad_norm": 40.0}
+    eng = PPOLagEngine(pol, N, T, cfg, dev)
+    norm = DeviceObsNormalizer(D, dev)
+    rms = R.RunningMeanStd((D,))
+    for t in range(T):
+        x = (rng.standard_normal((N, D)) * (1 + 0.2 * np.arange(D)) + 0.5 * np.arange(D)).astype(np.float32)
+        eps = rng.standard_normal((N, A)).astype(np.float32)
+        want = rms.normalize(x.astype(np.float64)).astype(np.float32)          # update, then normalise
+        obs = torch.from_numpy(x.copy()).to(dev)
+        norm.pending = True
+        act = eng.collect_step(t, obs, torch.from_numpy(eps).to(dev), rms=norm)
+        assert not norm.pending
+        got = obs.cpu().numpy()
+        assert _ulp_diff(got, want).max() <= 1, "normalised rows (in place)"
+        assert np.array_equal(eng.buffer.data["obs"][:, t].cpu().numpy(), got), "buffer slot holds the normalised rows"
+        with torch.no_grad():
+            a_ref, lp_ref, vr_ref, vc_ref = ref.step_with_eps(torch.from_numpy(got), torch.from_numpy(eps))
+        np.testing.assert_allclose(act.cpu().numpy(), a_ref.numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(eng.logp.cpu().numpy(), lp_ref.numpy(), rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(eng.v_r.cpu().numpy(), vr_ref.numpy(), rtol=1e-5, atol=1e-5)
+        eng.buffer.advance()
+    st = norm.obs_rms
+    np.testing.assert_allclose(st.mean, rms.mean, rtol=1e-12)
+    np.testing.assert_allclose(st.var, rms.var, rtol=1e-12)
+    assert st.count == pytest.approx(rms.count)
+    # second call on the same tensor: nothing pending -> the plain step, no second normalisation
+    eng.buffer.reset()
+    obs2 = obs.clone()
+    eng.collect_step(0, obs2, torch.zeros((N, A), device=dev), rms=norm)
+    assert torch.equal(obs2, obs)
+    # the training loop end to end with a normalising device env (fused path) + evaluation with frozen restored statistics
+    from safepo.single_agent import ppo_lag
+    from safepo.evaluate import eval_single_agent
+    args = argparse.Namespace(seed=0, use_eval=False, task="SynthSafe-v0", num_envs=16, experiment="t",
+                              log_dir=str(tmp_path / "exp" / "task" / "run"), device="cuda", device_id=0,
+                              write_terminal=False, headless=False, total_steps=16 * 32 * 2, steps_per_epoch=16 * 32,
+                              randomize=False, cost_limit=25.0, lagrangian_multiplier_init=0.001,
+                              lagrangian_multiplier_lr=0.035,
+                              env_kwargs={"normalize_obs": True, "obs_scale": 3.0, "obs_shift": 1.5, "trunc_len": 16})
+    out = ppo_lag.main(args, {})
+    env_rms = out["engine"] and out["policy"] is not None
+    assert env_rms
+    import joblib
+    state = joblib.load(open(tmp_path / "exp" / "task" / "run" / "state0.pkl", "rb"))["Normalizer"]
+    mean = np.asarray(state.mean if hasattr(state, "mean") else state["mean"])
+    assert abs(float(mean.mean()) - 1.5) < 0.3, "running mean tracks the shifted observations (the fused path updated it)"
+
+
 def test_pg_unclipped_surrogate_and_ppo_lambda_zero(dev):
     """f2 siblings on the same kernels: pg = no ratio clip (pg.py:309), ppo = lambda 0 (ppo.py:272)."""
     from safepo import _abi
@@ -1142,19 +1204,33 @@ def test_use_eval_branch(dev, tmp_path):
     assert len(rows) == 2 and float(rows[0]["Metrics/EvalEpLen"]) == 8.0 and "Time/Eval" in rows[0]
 
 
-@pytest.mark.parametrize("algo,line_search", [("natural_pg", False), ("trpo", True)])
+@pytest.mark.parametrize("algo,line_search", [("natural_pg", False), ("trpo", True), ("rcpo", False), ("trpo_lag", True)])
 def test_trust_region_family_vs_reference_main_trace(dev, golden_dir, algo, line_search):
-    """f4: natural_pg / trpo on the CPO kernels against traces of the reference mains (rcpo / trpo_lag only add the
-    Lagrangian advantage mix, covered by the PPO-Lag tests)."""
+    """f4: natural_pg / trpo / rcpo / trpo_lag on the CPO kernels against traces of the reference mains.  The two
+    Lagrangian siblings (rcpo.py:325-326, trpo_lag.py:326-327) take the multiplier from the host Lagrange object fed with
+    the recorded EpCost statistics and run the update on the mixed advantage."""
+    from safepo.common.lagrange import Lagrange
     z = np.load(os.path.join(golden_dir, f"{algo}_trace.npz"))
+    lagrangian = algo in ("rcpo", "trpo_lag")
+    lagrange = Lagrange(cost_limit=float(z["meta_arg_cost_limit"]),
+                        lagrangian_multiplier_init=float(z["meta_arg_lagrangian_multiplier_init"]),
+                        lagrangian_multiplier_lr=float(z["meta_arg_lagrangian_multiplier_lr"])) if lagrangian else None
     N, T, epochs = int(z["meta_num_envs"]), int(z["meta_T"]), int(z["meta_epochs"])
     pol, eng = _cpo_engine(z, "init_sd_", dev, N, T, {"learning_iters": int(z["meta_cfg_learning_iters"]),
                                                        "batch_size": int(z["e0_batch_size"]),
                                                        "target_kl": float(z["meta_cfg_target_kl"])})
     for e in range(epochs):
         _load_epoch_into_engine(z, e, eng, dev)
-        eng.buffer.compute_gae(None)
-        out = eng.trust_region_update(eng.buffer.data["adv_r"].reshape(-1), line_search)
+        if lagrangian:
+            lagrange.update_lagrange_multiplier(float(z[f"e{e}_get_stats_Metrics_EpCost"]))
+            lam = lagrange.lagrangian_multiplier
+            assert lam == pytest.approx(float(z[f"e{e}_row_Train_LagragianMultiplier"]), rel=1e-6)
+            eng.buffer.compute_gae(lam)
+            adv = eng.buffer.adv_mix.reshape(-1)
+        else:
+            eng.buffer.compute_gae(None)
+            adv = eng.buffer.data["adv_r"].reshape(-1)
+        out = eng.trust_region_update(adv, line_search)
         assert out["xHx"] == pytest.approx(float(z[f"e{e}_Misc_xHx"]), rel=5e-3)
         assert out["H_inv_g"] == pytest.approx(float(z[f"e{e}_Misc_H_inv_g"]), rel=5e-3)
         assert out["gradient_norm"] == pytest.approx(float(z[f"e{e}_Misc_gradient_norm"]), rel=1e-4)

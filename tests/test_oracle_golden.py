@@ -391,3 +391,49 @@ def test_boundary_logic_matches_trace(golden_dir):
             # recorded bootstrap is zero exactly where the episode terminated
             assert np.all(z[f"e{e}_boot_r"][:, t][term] == 0)
             assert np.all(br[trunc] == 8.0) and np.all(br[seg & ~term & ~trunc] == 7.0)
+
+
+@pytest.mark.parametrize("algo", ["rcpo", "trpo_lag"])
+def test_lagrangian_trust_region_traces_multiplier_and_mix(golden_dir, algo):
+    """The Lagrangian trust-region siblings (rcpo.py:320-327, trpo_lag.py:320-327): the multiplier the reference logged in
+    every epoch follows from the recorded EpCost statistics through the oracle's Lagrange restatement, and it moves."""
+    z = _load(golden_dir, f"{algo}_trace.npz")
+    lag = R.OracleLagrange(float(z["meta_arg_cost_limit"]), float(z["meta_arg_lagrangian_multiplier_init"]),
+                           float(z["meta_arg_lagrangian_multiplier_lr"]))
+    lams = []
+    for e in range(int(z["meta_epochs"])):
+        lag.update_lagrange_multiplier(float(z[f"e{e}_get_stats_Metrics_EpCost"]))
+        assert lag.lagrangian_multiplier == pytest.approx(float(z[f"e{e}_row_Train_LagragianMultiplier"]), rel=1e-6)
+        lams.append(lag.lagrangian_multiplier)
+    assert len(set(round(l, 6) for l in lams)) == len(lams) and all(l > 0 for l in lams)
+
+
+def test_running_mean_std_restatement_vs_independent_two_pass():
+    """a-2 (parity unpinned by the reference: gymnasium is not vendored / installed).  The restated RunningMeanStd -- the
+    incremental parallel-variance merge, mean 0 / var 1 / count 1e-4 prior -- is pinned here against an
+    INDEPENDENT float64 evaluation written from the definition: the prior is a pseudo-batch of weight 1e-4 with mean 0 and
+    variance 1; merging batches must equal the weighted two-pass mean / variance of everything seen so far."""
+    rng = np.random.default_rng(3)
+    D = 7
+    rms = R.RunningMeanStd((D,))
+    seen = []
+    for n in (5, 1, 1000, 64, 3):
+        x = rng.standard_normal((n, D)) * (1.0 + np.arange(D)) + 10.0 * np.arange(D)
+        rms.update(x)
+        seen.append(x)
+        allx = np.concatenate(seen, 0)
+        w0 = 1e-4
+        tot = w0 + allx.shape[0]
+        mean = allx.sum(0) / tot                                   # prior mean 0 contributes nothing to the sum
+        var = (w0 * (1.0 + mean ** 2) + ((allx - mean) ** 2).sum(0)) / tot
+        np.testing.assert_allclose(rms.mean, mean, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(rms.var, var, rtol=1e-10)
+        assert rms.count == pytest.approx(tot, rel=1e-15)
+    # normalize() = update with the batch, then (x - mean) / sqrt(var + 1e-8) with the UPDATED statistics
+    y = rng.standard_normal((4, D))
+    out = rms.normalize(y.copy())
+    allx = np.concatenate(seen + [y], 0)
+    tot = 1e-4 + allx.shape[0]
+    mean = allx.sum(0) / tot
+    var = (1e-4 * (1.0 + mean ** 2) + ((allx - mean) ** 2).sum(0)) / tot
+    np.testing.assert_allclose(out, (y - mean) / np.sqrt(var + 1e-8), rtol=1e-9, atol=1e-12)
