@@ -370,6 +370,11 @@ int spo_ma_clip_adam(float* theta, const float* grad, float* adam_m, float* adam
                      float lr, float adam_eps, float weight_decay, float max_grad_norm, int use_max_grad_norm,
                      float* grad_norm_out, double* partial_ws, void* stream);
 
+/* Test comparator for the multi-agent networks' plain products: y[B,N] = x[B,K] w[N,K]^T (mode 0) or y[B,K] = x[B,N] w[N,K]
+ * (mode 1) through the hand-written fp32 MFMA kernel (use_rocblas = 0, what spo_ma_forward / backward / jvp run) or through
+ * rocBLAS (use_rocblas = 1; dlopen'ed on demand, not used by any product path). */
+int spo_debug_ma_gemm(int use_rocblas, int mode, const float* x, const float* w, float* y, int64_t B, int K, int N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,16 +53,139 @@ int rb_init() {
   return 0;
 }
 
+#ifndef SPO_MA_FUSE_MIN_ROWS_DEFAULT
+#define SPO_MA_FUSE_MIN_ROWS_DEFAULT 2048
+#endif
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------- hand-written fp32 MFMA GEMM (all plain products)
+// Y[B, N] (+)= X[B, R] * Wop[R, N], where the weight operand is addressed as Wop[r][j] = W[j * w_sj + r * w_sr]:
+//   Y = X W^T  (forward blocks at small batch / hidden != 128, heads, tangent passes):  w_sj = R, w_sr = 1
+//   dX = dY W  (head and non-fused block input gradients):                              w_sj = 1, w_sr = N_w (= K of W)
+// 64 rows x 64 columns per workgroup, 4 waves x (16 rows x 64 columns), reduction in chunks of 32 staged through LDS
+// (row stride 33: the 16 x 4 operand pattern of v_mfma_f32_16x16x4_f32 touches 32 different banks twice).  These shapes
+// are launch-bound (8192 x 48..128 x 128 at collect time, heads with 1-16 columns), so the kernel is kept simple; the
+// large-batch training products run in the fused block kernels below.  rocBLAS stays only as a test comparator
+// (spo_debug_ma_gemm).
+constexpr int GM_T = 64, GM_KC = 32, GM_LD = GM_KC + 1;
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ Y,
+                                                        int64_t B, int R, int N, int64_t w_sj, int64_t w_sr, float beta) {
+  __shared__ float Xs[GM_T * GM_LD];
+  __shared__ float Ws[GM_T * GM_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.y * GM_T;
+  const int col0 = blockIdx.x * GM_T;
+  f4v acc[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) acc[nt] = f4v{0.f, 0.f, 0.f, 0.f};
+  const int lr = tid >> 2, ls = (tid & 3) * 8;                  // staging: row / column lr, 8 reduction indices from ls
+  for (int r0 = 0; r0 < R; r0 += GM_KC) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int r = r0 + ls + e;
+      const int64_t xr = row0 + lr;
+      Xs[lr * GM_LD + ls + e] = (xr < B && r < R) ? X[xr * R + r] : 0.f;
+      const int wc = col0 + lr;
+      Ws[lr * GM_LD + ls + e] = (wc < N && r < R) ? W[(int64_t)wc * w_sj + (int64_t)r * w_sr] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GM_KC; kk += 4) {
+      const float av = Xs[(16 * wave + i) * GM_LD + kk + kq];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Ws[(16 * nt + i) * GM_LD + kk + kq], acc[nt], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int64_t row = row0 + 16 * wave + 4 * kq + reg;
+      const int col = col0 + 16 * nt + i;
+      if (row < B && col < N) {
+        float* const y = Y + row * N + col;
+        *y = beta != 0.f ? fmaf(beta, *y, acc[nt][reg]) : acc[nt][reg];
+      }
+    }
+}
+int gemm_mfma(hipStream_t st, const float* X, const float* W, float* Y, int64_t B, int R, int N, int64_t w_sj, int64_t w_sr,
+              float beta) {
+  const dim3 grid((unsigned)((N + GM_T - 1) / GM_T), (unsigned)((B + GM_T - 1) / GM_T));
+  hipLaunchKernelGGL(gemm_mfma_kernel, grid, dim3(256), 0, st, X, W, Y, B, R, N, w_sj, w_sr, beta);
+  return 0;
+}
+// Heads: N <= 16 output columns (act_dim or 1) over K <= 512 features.  A 64 x 64 MFMA tile would be mostly padding; here a
+// workgroup takes 64 rows, keeps W (+ bias) in LDS, and four lanes share a row: each forms the partial dot products of its
+// quarter of the features for all N outputs, two shuffles add the quarters.  Bias fused (saves the add_bias launch).
+constexpr int HS_MAXN = 16, HS_MAXK = 512;
+__global__ __launch_bounds__(256) void head_small_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, float* __restrict__ Y, int64_t B, int K, int N) {
+  __shared__ float Ws[HS_MAXN * (HS_MAXK + 4)];
+  const int tid = threadIdx.x;
+  const int ld = K + 4;
+  for (int idx = tid; idx < N * K; idx += 256) Ws[(idx / K) * ld + (idx % K)] = W[idx];
+  __syncthreads();
+  const int64_t row = (int64_t)blockIdx.x * 64 + (tid >> 2);
+  const int part = tid & 3;
+  float acc[HS_MAXN];
+#pragma unroll
+  for (int n = 0; n < HS_MAXN; ++n) acc[n] = 0.f;
+  if (row < B) {
+    const float* xr = X + row * K;
+    if ((K & 15) == 0) {
+      // the four lanes of a row read consecutive float4s (64 contiguous bytes per row and step)
+      for (int k0 = 4 * part; k0 < K; k0 += 16) {
+        const f4v xv = *reinterpret_cast<const f4v*>(xr + k0);
+#pragma unroll
+        for (int n = 0; n < HS_MAXN; ++n)
+          if (n < N) {
+            const float* wr = Ws + n * ld + k0;
+            acc[n] = fmaf(xv[0], wr[0], fmaf(xv[1], wr[1], fmaf(xv[2], wr[2], fmaf(xv[3], wr[3], acc[n]))));
+          }
+      }
+    } else {
+      for (int k = part; k < K; k += 4) {
+        const float xv = xr[k];
+#pragma unroll
+        for (int n = 0; n < HS_MAXN; ++n)
+          if (n < N) acc[n] = fmaf(xv, Ws[n * ld + k], acc[n]);
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < HS_MAXN; ++n) {
+    acc[n] += __shfl_xor(acc[n], 1);
+    acc[n] += __shfl_xor(acc[n], 2);
+  }
+  if (row < B && part == 0) {
+#pragma unroll
+    for (int n = 0; n < HS_MAXN; ++n)
+      if (n < N) Y[row * N + n] = acc[n] + (bias ? bias[n] : 0.f);
+  }
+}
+// rows from which the fused block kernels (128 rows per workgroup) replace GEMM + LayerNorm kernels (SPO_MA_FUSE_MIN_ROWS: A/B knob)
+inline int64_t ma_fuse_min_rows() {
+  static const int64_t v = [] { const char* e = getenv("SPO_MA_FUSE_MIN_ROWS"); return e ? (int64_t)atoll(e) : (int64_t)SPO_MA_FUSE_MIN_ROWS_DEFAULT; }();
+  return v;
+}
+int g_ma_gemm_rocblas = 0;      // spo_debug_ma_gemm only: 1 routes the two helpers below through rocBLAS (comparator)
+
 // Row-major helpers.  Y[B,N] (+)= X[B,K] * W[N,K]^T
 int gemm_xwT(hipStream_t st, const float* X, const float* W, float* Y, int64_t B, int K, int N, float beta = 0.f) {
+  if (!g_ma_gemm_rocblas) return gemm_mfma(st, X, W, Y, B, K, N, K, 1, beta);
   const float alpha = 1.f;
+  if (int rc = rb_init()) return rc;
   if (int rc = g_rb.set_stream(g_rb.h, st)) return fail(-22, "rocblas_set_stream (%d)", rc);
   if (int rc = g_rb.sgemm(g_rb.h, RB_T, RB_N, N, (int)B, K, &alpha, W, K, X, K, &beta, Y, N)) return fail(-22, "sgemm xwT (%d)", rc);
   return 0;
 }
 // dX[B,K] = dY[B,N] * W[N,K]
 int gemm_dyw(hipStream_t st, const float* dY, const float* W, float* dX, int64_t B, int K, int N) {
+  if (!g_ma_gemm_rocblas) return gemm_mfma(st, dY, W, dX, B, N, K, 1, K, 0.f);
   const float alpha = 1.f, beta = 0.f;
+  if (int rc = rb_init()) return rc;
   if (int rc = g_rb.set_stream(g_rb.h, st)) return fail(-22, "rocblas_set_stream (%d)", rc);
   if (int rc = g_rb.sgemm(g_rb.h, RB_N, RB_N, K, (int)B, N, &alpha, W, K, dY, N, &beta, dX, K)) return fail(-22, "sgemm dyw (%d)", rc);
   return 0;
@@ -72,7 +195,6 @@ int gemm_dyw(hipStream_t st, const float* dY, const float* W, float* dX, int64_t
 // HBM-bound (both operands are read once: 537 MB -> ~0.15 ms), so it is done here: the rows are split over up to 256
 // workgroups per 128x128 output tile, each accumulating its slice with fp32 MFMA from LDS-staged 32-row chunks, and a
 // second kernel adds the slices in a fixed order.
-typedef float f4v __attribute__((ext_vector_type(4)));
 constexpr int DW_T = 128, DW_R = 32, DW_LD = DW_T + 16;      // row stride 144: the two row-groups of a half-wave land 16 banks apart
 
 int dw_splits(int64_t B, int N, int K) {
@@ -479,6 +601,9 @@ __device__ __forceinline__ float row16_allsum(float v) {          // sum over th
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
   return v;
 }
+// MT = 16-row MFMA tiles per wave: 2 (128-row workgroup tiles) for training batches, 1 (64-row tiles, twice the
+// workgroups) for collect-size batches that would otherwise leave most CUs idle.
+template <int MT>
 __global__ __launch_bounds__(256, 1) void fused_block_fwd128_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                                     const float* __restrict__ bias, const float* __restrict__ g,
                                                                     const float* __restrict__ be, float* __restrict__ a_out,
@@ -488,9 +613,10 @@ __global__ __launch_bounds__(256, 1) void fused_block_fwd128_kernel(const float*
   const int KP = (K + 15) & ~15;                 // k padded to whole 16-blocks (zero filled)
   const int LD = KP + 4;                         // row stride: 16-byte aligned, bank-rotated
   float* Ws = fb_lds;                            // [128][LD]
-  float* Xs = fb_lds + FB_N * LD;                // [128][LD]
+  float* Xs = fb_lds + FB_N * LD;                // [ROWS][LD]
   float* Stg = Xs;                               // [128][FB_SLD]  ELU outputs, row-major for coalesced stores: ALIASES the X tile
-  float* Sst = Xs + FB_ROWS * FB_SLD;            // [128][2]       row mean / rstd
+  float* Sst = Xs + 64 * MT * FB_SLD;            // [128][2]       row mean / rstd
+  constexpr int ROWS = 64 * MT, XP = 8 * MT;     // rows per workgroup tile, staging passes of 8 rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kk = lane >> 4;
   // staging map: thread -> (row tid/32 + 8*pass, columns 4*(tid%32)..+3): no divisions, 16 independent loads in flight
   const int lc4 = (tid & 31) * 4, lrow = tid >> 5;
@@ -509,14 +635,14 @@ __global__ __launch_bounds__(256, 1) void fused_block_fwd128_kernel(const float*
   float bcol[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) bcol[t] = bias[16 * t + i];
-  const int64_t ntiles = (B + FB_ROWS - 1) / FB_ROWS;
+  const int64_t ntiles = (B + ROWS - 1) / ROWS;
   // The kernel is HBM-bound (read X once, write a and y once: 192 KB per 128-row tile), so the next tile's rows are
   // fetched into registers while this tile is multiplied and normalised.
-  f4w xv[16];
+  f4w xv[XP];
   auto fetch_tile = [&](int64_t t) {
-    const int64_t rb = t * FB_ROWS;
+    const int64_t rb = t * ROWS;
 #pragma unroll
-    for (int ps = 0; ps < 16; ++ps) {
+    for (int ps = 0; ps < XP; ++ps) {
       const int rr = lrow + 8 * ps;
       xv[ps] = f4w{0.f, 0.f, 0.f, 0.f};
       if (lcol_ok && t < ntiles && rb + rr < B) xv[ps] = *reinterpret_cast<const f4w*>(X + (rb + rr) * K + lc4);
@@ -524,23 +650,24 @@ __global__ __launch_bounds__(256, 1) void fused_block_fwd128_kernel(const float*
   };
   fetch_tile(blockIdx.x);
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t r0 = tile * FB_ROWS;
+    const int64_t r0 = tile * ROWS;
     __syncthreads();                             // previous tile's output image has been read out (and Ws is staged)
 #pragma unroll
-    for (int ps = 0; ps < 16; ++ps)
+    for (int ps = 0; ps < XP; ++ps)
       if (lcol_in) *reinterpret_cast<f4w*>(Xs + (lrow + 8 * ps) * LD + lc4) = xv[ps];
     __syncthreads();
     fetch_tile(tile + gridDim.x);                // in flight during the MFMA loop and the epilogue
-    f4w acc[2][8];
+    f4w acc[MT][8];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int t = 0; t < 8; ++t) acc[m][t] = f4w{0.f, 0.f, 0.f, 0.f};
-    const float* xa = Xs + (32 * wave + i) * LD + 4 * kk;
+    const float* xa = Xs + (16 * MT * wave + i) * LD + 4 * kk;
     const float* wb = Ws + i * LD + 4 * kk;
     for (int kb = 0; kb < KP / 16; ++kb) {
-      const f4w a0 = *reinterpret_cast<const f4w*>(xa + 16 * kb);
-      const f4w a1 = *reinterpret_cast<const f4w*>(xa + 16 * LD + 16 * kb);
+      f4w am[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) am[m] = *reinterpret_cast<const f4w*>(xa + 16 * m * LD + 16 * kb);
       f4w bt[8];
 #pragma unroll
       for (int t = 0; t < 8; ++t) bt[t] = *reinterpret_cast<const f4w*>(wb + 16 * t * LD + 16 * kb);
@@ -548,18 +675,19 @@ __global__ __launch_bounds__(256, 1) void fused_block_fwd128_kernel(const float*
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], bt[t][r], acc[0][t], 0, 0, 0);
-          acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[r], bt[t][r], acc[1][t], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[m][r], bt[t][r], acc[m][t], 0, 0, 0);
         }
     }
     __syncthreads();                             // every wave is done with the X tile: its LDS becomes the output image
     // epilogue: lane holds rows 4*kk + e (e = 0..3) of each 16-row tile m, columns 16*t + i.  The ELU outputs go through
     // an LDS image of this wave's 32 rows so that HBM sees whole 512-byte rows (a and y), not 64-byte column slivers.
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int rl = 32 * wave + 16 * m + 4 * kk + e;
+        const int rl = 16 * MT * wave + 16 * m + 4 * kk + e;
         float v[8], sum = 0.f;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -581,8 +709,8 @@ __global__ __launch_bounds__(256, 1) void fused_block_fwd128_kernel(const float*
       const int c4 = (lane & 31) * 4;
       const f4w g4 = *reinterpret_cast<const f4w*>(g + c4), be4 = *reinterpret_cast<const f4w*>(be + c4);
 #pragma unroll 4
-      for (int jj = 0; jj < 16; ++jj) {
-        const int rl = 32 * wave + 2 * jj + (lane >> 5);
+      for (int jj = 0; jj < 8 * MT; ++jj) {
+        const int rl = 16 * MT * wave + 2 * jj + (lane >> 5);
         const int64_t row = r0 + rl;
         const f4w a4 = *reinterpret_cast<const f4w*>(Stg + rl * FB_SLD + c4);
         const float mean = Sst[2 * rl], rstd = Sst[2 * rl + 1];
@@ -1145,7 +1273,6 @@ extern "C" int spo_ma_forward(const float* theta, const spo_ma_net* net, const f
   Lay L;
   if (int rc = lay_of(net, &L)) return rc;
   SPO_REQUIRE(theta && x && ws && out && rows > 0, "ma_forward: bad args");
-  if (int rc = rb_init()) return rc;
   hipStream_t st = (hipStream_t)stream;
   const int64_t B = rows;
   const int gr = grid_rows(B);
@@ -1166,20 +1293,29 @@ extern "C" int spo_ma_forward(const float* theta, const spo_ma_net* net, const f
     float* a = ws + L.ws_a(B, k);
     const float* Wk = k == 0 ? ws + L.ws_w0f(B) : theta + L.W(k);
     const float* bk = k == 0 ? ws + L.ws_b0f(B) : theta + L.b(k);
-    if (L.H == 128 && L.in_k(k) % 4 == 0 && L.in_k(k) <= 128 && B >= 32768) {
-      // one fused MFMA kernel (large batches: the training / evaluation passes; small collect batches keep rocBLAS)
+    if (L.H == 128 && L.in_k(k) % 4 == 0 && L.in_k(k) <= 128 && B >= ma_fuse_min_rows()) {
+      // one fused MFMA kernel (collect-size batches upwards; below that the plain MFMA GEMM + LayerNorm kernel)
       const int K = L.in_k(k), KP = (K + 15) & ~15;
       const size_t sh = ((size_t)128 * (KP + 4) + 128 * 132 + 256) * sizeof(float);       // W image + max(X tile, output image)
       static bool attr_done = false;
       if (!attr_done) {
-        if (int rc = spo::hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_block_fwd128_kernel),
+        if (int rc = spo::hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_block_fwd128_kernel<2>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (2 * 128 * 132 + 256) * 4),
+                                    "hipFuncSetAttribute(fused_block_fwd128)")) return rc;
+        if (int rc = spo::hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_block_fwd128_kernel<1>),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (2 * 128 * 132 + 256) * 4),
                                     "hipFuncSetAttribute(fused_block_fwd128)")) return rc;
         attr_done = true;
       }
-      const int64_t nt = (B + 127) / 128;
-      hipLaunchKernelGGL(fused_block_fwd128_kernel, dim3((unsigned)(nt < 256 ? nt : 256)), dim3(256), sh, st, in, Wk,
-                         bk, theta + L.g(k), theta + L.be(k), a, ws + L.ws_y(B, k), ws + L.ws_st(B, k), B, K);
+      if (B >= 256 * 128) {
+        const int64_t nt = (B + 127) / 128;
+        hipLaunchKernelGGL(fused_block_fwd128_kernel<2>, dim3((unsigned)(nt < 256 ? nt : 256)), dim3(256), sh, st, in, Wk,
+                           bk, theta + L.g(k), theta + L.be(k), a, ws + L.ws_y(B, k), ws + L.ws_st(B, k), B, K);
+      } else {
+        const int64_t nt = (B + 63) / 64;
+        hipLaunchKernelGGL(fused_block_fwd128_kernel<1>, dim3((unsigned)(nt < 256 ? nt : 256)), dim3(256), sh, st, in, Wk,
+                           bk, theta + L.g(k), theta + L.be(k), a, ws + L.ws_y(B, k), ws + L.ws_st(B, k), B, K);
+      }
       in = ws + L.ws_y(B, k);
       continue;
     }
@@ -1192,9 +1328,14 @@ extern "C" int spo_ma_forward(const float* theta, const spo_ma_net* net, const f
                          ws + L.ws_y(B, k), ws + L.ws_st(B, k), B, L.H);
     in = ws + L.ws_y(B, k);
   }
-  if (int rc = gemm_xwT(st, in, theta + L.hW(), out, B, L.H, L.O)) return rc;
-  const int64_t n = B * L.O;
-  hipLaunchKernelGGL(add_bias_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, theta + L.hb(), n, L.O);
+  if (L.O <= HS_MAXN && L.H <= HS_MAXK && !g_ma_gemm_rocblas) {
+    hipLaunchKernelGGL(head_small_kernel, dim3((unsigned)((B + 63) / 64)), dim3(256), 0, st, in, theta + L.hW(), theta + L.hb(), out,
+                       B, L.H, L.O);
+  } else {
+    if (int rc = gemm_xwT(st, in, theta + L.hW(), out, B, L.H, L.O)) return rc;
+    const int64_t n = B * L.O;
+    hipLaunchKernelGGL(add_bias_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, theta + L.hb(), n, L.O);
+  }
   SPO_LAUNCH_CHECK("spo_ma_forward");
   return 0;
 }
@@ -1216,7 +1357,6 @@ extern "C" int spo_ma_backward(const float* theta, const spo_ma_net* net, const 
   Lay L;
   if (int rc = lay_of(net, &L)) return rc;
   SPO_REQUIRE(theta && x && ws && dout && grad && scratch && rows > 0, "ma_backward: bad args");
-  if (int rc = rb_init()) return rc;
   hipStream_t st = (hipStream_t)stream;
   const int64_t B = rows;
   const int64_t Wd = L.H > L.D ? L.H : L.D;
@@ -1236,7 +1376,7 @@ extern "C" int spo_ma_backward(const float* theta, const spo_ma_net* net, const 
   if (int rc = gemm_dyw(st, dout, theta + L.hW(), d0, B, L.H, L.O)) return rc;
   // dz of the top block from the head's dX; below it, for hidden 128 at large batch, one fused kernel per block turns
   // dz_k into dz_{k-1} (dX GEMM + LayerNorm/ELU backward + column partials), otherwise rocBLAS + the LayerNorm kernel.
-  const bool fuse_bwd = (L.H == 128) && (B >= 32768);
+  const bool fuse_bwd = (L.H == 128) && (B >= ma_fuse_min_rows());
   float* dzc = d1;                     // dz of the current block
   float* other = d0;                   // free buffer (holds dY of the current block until its LayerNorm backward ran)
   int nparts = gr;
@@ -1345,7 +1485,6 @@ extern "C" int spo_ma_jvp(const float* theta, const spo_ma_net* net, const float
   Lay L;
   if (int rc = lay_of(net, &L)) return rc;
   SPO_REQUIRE(theta && tangent && ws && dout && scratch && rows > 0, "ma_jvp: bad args");
-  if (int rc = rb_init()) return rc;
   hipStream_t st = (hipStream_t)stream;
   const int64_t B = rows;
   const int gr = grid_rows(B);
@@ -1483,5 +1622,18 @@ extern "C" int spo_ma_clip_adam(float* theta, const float* grad, float* adam_m, 
   hipLaunchKernelGGL(ma_adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, theta, grad, adam_m, adam_v, n,
                      grad_norm_out, max_grad_norm, use_max_grad_norm, lr, (float)b1, (float)b2, adam_eps, weight_decay, bc1, bc2s);
   SPO_LAUNCH_CHECK("spo_ma_clip_adam");
+  return 0;
+}
+
+// Test comparator: Y[B,N] = X[B,K] W[N,K]^T (mode 0) or dX[B,K] = dY[B,N] W[N,K] (mode 1) through the hand-written MFMA
+// kernel (use_rocblas = 0) or through rocBLAS (use_rocblas = 1: dlopen'ed, never used by the product path).
+extern "C" int spo_debug_ma_gemm(int use_rocblas, int mode, const float* x, const float* w, float* y, int64_t B, int K, int N,
+                                 void* stream) {
+  SPO_REQUIRE(x && w && y && B > 0 && K > 0 && N > 0 && (mode == 0 || mode == 1), "debug_ma_gemm: bad args");
+  g_ma_gemm_rocblas = use_rocblas ? 1 : 0;
+  const int rc = mode == 0 ? gemm_xwT((hipStream_t)stream, x, w, y, B, K, N) : gemm_dyw((hipStream_t)stream, x, w, y, B, K, N);
+  g_ma_gemm_rocblas = 0;
+  if (rc) return rc;
+  SPO_LAUNCH_CHECK("spo_debug_ma_gemm");
   return 0;
 }

@@ -1325,6 +1325,30 @@ def test_in_kernel_gradient_exchange_two_ranks_one_gpu(dev, tmp_path, algo):
     print("p2p", res)
 
 
+@pytest.mark.parametrize("B,K,N", [(8192, 48, 128), (8192, 128, 128), (8192, 128, 6), (100, 7, 1), (65, 130, 70), (1, 1, 1)])
+def test_ma_plain_products_run_on_the_mfma_kernel_vs_rocblas_and_torch(dev, B, K, N):
+    """f3: every plain product of the multi-agent networks -- collect-size blocks, heads, input gradients,
+    tangent passes -- runs on the hand-written fp32 MFMA kernel; rocBLAS is only this test's comparator."""
+    from safepo import _abi
+    lib = _abi.load()
+    g = torch.Generator(device=dev).manual_seed(B + K + N)
+    x = torch.randn(B, K, device=dev, generator=g)
+    w = torch.randn(N, K, device=dev, generator=g)
+    dy = torch.randn(B, N, device=dev, generator=g)
+    ref_fwd = (x.double() @ w.double().T)
+    ref_bwd = (dy.double() @ w.double())
+    for mode, a, ref, shape in ((0, x, ref_fwd, (B, N)), (1, dy, ref_bwd, (B, K))):
+        outs = []
+        for use_rb in (0, 1):
+            y = torch.full(shape, float("nan"), device=dev)
+            _abi.check(lib.spo_debug_ma_gemm(use_rb, mode, _abi.ptr(a), _abi.ptr(w), _abi.ptr(y), B, K, N, _abi.stream_ptr()), "gemm")
+            outs.append(y)
+        scale = float(ref.abs().max()) + 1e-6
+        for y in outs:                                   # both within fp32 rounding of the float64 product
+            assert float((y.double() - ref).abs().max()) <= 2e-6 * scale * max(1.0, (K if mode == 0 else N) ** 0.5)
+        assert torch.isfinite(outs[0]).all()
+
+
 # ====================================================================== f3: multi-agent MAPPO-L
 def _ma_cfg(dev, **over):
     from safepo.multi_agent.mappolag import default_cfg
