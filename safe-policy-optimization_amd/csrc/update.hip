@@ -105,6 +105,8 @@ struct UpdArgs {
   unsigned xr_step0;                   // global optimiser-step count before this launch (same on every rank)
   void* xr_region[XR_MAX_WORLD];       // every rank's exchange region (own + IPC-mapped peers), indexed by rank
   float* backup;                       // main + helper form: [UPD_BACKUP_ROWS][3 workgroups][512 lanes] float4 backup rows
+  int spec_mode;                       // main + helper form: 1 = the clip verdict is validated AFTER the next step's forward
+                                       // while the previous step was not clipped (SPO_UPDATE_SPEC, default), 0 = never
 };
 constexpr int NPHASE = 10;
 constexpr int UPD_BACKUP_ROWS = 32;      // float4 rows per lane of the 512-thread kernels' backup scratch (main+helper form: 3*NT1 + 12 + 8)
@@ -1229,6 +1231,15 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
   // PROF: wave 0 of each role of the LAST workgroup accumulates shader cycles per interval (a.prof rows 0 = main, 1 = helper)
   unsigned long long pacc[NPHASE] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = 0;
+  // finer intervals inside the main waves' longest phase (row 2 of a.prof)
+  unsigned long long pacc2[NPHASE] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev2 = 0;
+#define SPO_SUB(i)                                             \
+  if (PROF) {                                                  \
+    const unsigned long long _t = __builtin_readcyclecounter(); \
+    if ((i) >= 0) pacc2[(i) < 0 ? 0 : (i)] += _t - tprev2;     \
+    tprev2 = _t;                                               \
+  }
 #define SPO_STAMP(i)                                           \
   if (PROF) {                                                  \
     const unsigned long long _t = __builtin_readcyclecounter(); \
@@ -1413,7 +1424,7 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
         for (int e = 0; e < 4; ++e) lds[U::XT + (16 * nt + 4 * q + e) * LDB + mycol] = cur.x[nt][e];
         }
     SPO_STAMP(0)
-    bool redone = false;
+    bool redone = false, late_redone = false;
     for (;;) {
       {
         SPO_REIDX
@@ -1431,14 +1442,14 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
       SPO_STAMP(4)
       const int redo_tag = xw[18];
       if (redo_tag == (int)(s & 0x3fffffff) + 1 && !redone) { redone = true; continue; }   // clipped: W1, W2 were redone
-      break;
-    }
     {
       // ---- rest of the step of the main waves: prefetch, L3, loss, backward, staging
       SPO_REIDX
+      SPO_SUB(-1)
       if (s + 1 < nsteps) fetch((int64_t)smp_next, nxt);
       if (s + 2 < nsteps) smp1 = a.perm[pos2];
       const f4 o = layer_out(lds + L::W3, lds + L::B3, h2, j, q);
+      SPO_SUB(0)
       const bool cv = mycol < ncols;
       float ivar[4], lsd[4], amask[4];
 #pragma unroll
@@ -1484,6 +1495,7 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
           dls[r] = (dlp * amask[r]) * (dif[r] * z - 1.f);
         }
       }
+      SPO_SUB(1)
       // backward through the MLP (as in ppo_update_kernel)
       f4 dz2[4], dz1[4];
       {
@@ -1503,6 +1515,7 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) dz2[mt][r] = acc[mt][r] * fmaf(-h2[mt][r], h2[mt][r], 1.f);
+        SPO_SUB(2)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[mt] = f4{0.f, 0.f, 0.f, 0.f};
         float w2c[2][4][4];
@@ -1529,6 +1542,7 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) dz1[mt][r] = acc[mt][r] * fmaf(-h1[mt][r], h1[mt][r], 1.f);
       }
+      SPO_SUB(3)
       SPO_REIDX
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
@@ -1542,6 +1556,7 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
         }
 #pragma unroll
       for (int r = 0; r < 4; ++r) lds[U::DOT + (4 * q + r) * LDB + mycol] = dO[r];
+      SPO_SUB(4)
       {
         const float ls = wave_sum_lane63(lsum);
         if (lane == 63) red[wave] = ls;
@@ -1553,10 +1568,25 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
           }
         }
       }
+      SPO_SUB(5)
         }
     SPO_STAMP(5)
     __syncthreads();                                                      // B_stage: all [feature][batch] images complete
     SPO_STAMP(6)
+      // Deferred validation: the helpers updated ALL layers with clip coefficient 1 and found, while this forward /
+      // backward ran, that the previous step's joint norm exceeds the bound.  They have restored and redone the update
+      // exactly before this barrier; the step is repeated from layer 1 on the exact weights (x from its LDS image).
+      if (xw[20] == (int)(s & 0x3fffffff) + 1 && !late_redone) {
+        late_redone = true;
+        SPO_REIDX
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) cur.x[nt][e] = lds[U::XT + (16 * nt + 4 * q + e) * LDB + mycol];
+        continue;
+      }
+      break;
+    }
     {
       // ---- dW1 (rows 16 wave .., all NT1 column tiles) -> G1, db1 -> GB[0]
       SPO_REIDX
@@ -1653,7 +1683,7 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
     if (PROF) tprev = __builtin_readcyclecounter();
   }
   if (PROF && a.prof && tid == 0 && wg == a.n_nets - 1)
-    for (int i = 0; i < NPHASE; ++i) a.prof[i] = pacc[i];
+    for (int i = 0; i < NPHASE; ++i) { a.prof[i] = pacc[i]; a.prof[2 * NPHASE + i] = pacc2[i]; }
   __syncthreads();                                                        // after the loop (helpers: last verdict done)
   } else {
   // The helpers are the younger waves of their SIMDs and would get only the issue slots the main waves leave; their
@@ -1665,6 +1695,7 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
   __syncthreads();                                                        // Xd of step 0
   __syncthreads();                                                        // B_stage of step 0
   if (PROF) tprev = __builtin_readcyclecounter();
+  bool spec = a.spec_mode != 0;                      // deferred validation of the clip (see below); off after a clipped step
   for (int64_t s = 0; s < nsteps; ++s) {
     const int64_t base = s * B;
     const int64_t rem = a.M - base;
@@ -1787,109 +1818,8 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
         }
       }
     }
-    {
-      SPO_REIDX
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const f4 gv = *reinterpret_cast<const f4*>(lds + H::G2 + ((wave * 4 + nt) * 64 + lane) * 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p_ = lds[L::W2 + (orow + r) * LDH + 16 * nt + j];
-          const float g_ = vcoef * fmaf(l2x2, p_, gv[r]);
-          gg2[nt][r] = g_; pW2[nt][r] = p_; gsq = fmaf(g_, g_, gsq); psq = fmaf(p_, p_, psq);
-        }
-      }
-      {
-        const f4 gv = *reinterpret_cast<const f4*>(lds + H::G3 + ((wave * 2 + 0) * 64 + lane) * 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {                                       // pad rows hold p == 0, g == 0
-          const float p_ = lds[L::W3 + (4 * q + r) * LDH + 16 * wave + j];
-          const float g_ = vcoef * fmaf(l2x2, p_, gv[r]);
-          gg3[r] = g_; gsq = fmaf(g_, g_, gsq); psq = fmaf(p_, p_, psq);
-        }
-      }
-      {
-        bpb2 = lds[L::B2 + 16 * wave + j];
-        ggb2 = vcoef * fmaf(l2x2, bpb2, lds[H::GB + 1 * 256 + wave * 64 + lane]);
-        if (own_b) { gsq = fmaf(ggb2, ggb2, gsq); psq = fmaf(bpb2, bpb2, psq); }
-      }
-      if (wave == 0) {
-        const float p_ = lds[L::B3 + j];
-        ggb3 = vcoef * fmaf(l2x2, p_, lds[H::GB + 2 * 256 + lane]);
-        if (q == 0) { gsq = fmaf(ggb3, ggb3, gsq); psq = fmaf(p_, p_, psq); }
-        if (is_actor) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int ai = 4 * q + r;
-            dls[r] = (red[16 + ai] + red[32 + ai]) + (red[48 + ai] + red[64 + ai]);     // 0 on pad rows
-            if (own_ls) gsq = fmaf(dls[r], dls[r], gsq);
-          }
-        }
-      }
-      // every helper wave publishes ITS share of ||g||^2 as a tagged granule of its own (12 granules per step); every
-      // helper wave later adds all of them in the same fixed order -- no gather and no spinning inside the workgroup
-      const float wg_sq = wave_sum_lane63(gsq), wp_sq = wave_sum_lane63(psq);
-      if (lane == 63) {
-        st_granule(grow + 4 * wg + wave, ((unsigned long long)tag << 32) | __float_as_uint(wg_sq));
-        red[88 + wave] = wp_sq;                                            // sum p^2 shares: read after the next barrier
-      }
-      SPO_STAMP(3)
-    }
-    {
-      // ---- layer 2 (W2, b2): SPECULATIVE Adam like layer 1 (the other networks' norms are still in flight)
-      SPO_REIDX
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        bk[BKS * (BK_W2 + 3 * nt + 0)] = mW2[nt];
-        bk[BKS * (BK_W2 + 3 * nt + 1)] = vW2[nt];
-        bk[BKS * (BK_W2 + 3 * nt + 2)] = pW2[nt];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const AdamOut o_ = adam1(pW2[nt][r], gg2[nt][r], mW2[nt][r], vW2[nt][r], b1c, b2c, eps, step_size, inv_bc2s);
-          mW2[nt][r] = o_.m; vW2[nt][r] = o_.v; lds[L::W2 + (orow + r) * LDH + 16 * nt + j] = o_.p;
-        }
-      }
-      bmb2 = mb2; bvb2 = vb2;
-      const AdamOut o_ = adam1(bpb2, ggb2, mb2, vb2, b1c, b2c, eps, step_size, inv_bc2s);
-      mb2 = o_.m; vb2 = o_.v; lds[L::B2 + 16 * wave + j] = o_.p;
-    }
-    SPO_STAMP(9)
-    if (s + 1 < nsteps) __syncthreads();                                  // Q2 of step s + 1: (speculative) W2 / b2 in place
-    SPO_STAMP(4)
-    // ---- the joint norm and the clip coefficient (the granules have had a forward layer's time to arrive)
-    float coef = 1.f;
-    {
-      if (wave == 0 && lane == 0 && s + 1 < nsteps) {                       // the loss value of this step (logging); the
-        // last step has no Q2 barrier before this point: its value is written after the barrier that follows the loop
-        const float loss_data = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;
-        const float pp = (red[88] + red[89]) + (red[90] + red[91]);
-        a.losses[s * 3 + net] = is_actor ? -loss_data : loss_data + l2 * pp;
-      }
-      float mine = 0.f;
-      const int ngr = 4 * a.n_nets;
-      if (lane < ngr) {                                                     // lane k polls granule k (network k / 4, wave k % 4)
-        __builtin_amdgcn_s_setprio(0);
-        unsigned long long v = ld_granule(grow + lane);
-        unsigned sp2 = 0;
-        while ((unsigned)(v >> 32) != tag) {
-          if (++sp2 > (1u << 22)) { *a.err = 1; break; }
-          __builtin_amdgcn_s_sleep(4);
-          v = ld_granule(grow + lane);
-        }
-        mine = __uint_as_float((unsigned)v);
-        __builtin_amdgcn_s_setprio(SPO_HELPER_PRIO);
-      }
-      float total_sq = stale_sq;
-      for (int kk = 0; kk < ngr; ++kk) total_sq += __shfl(mine, kk);        // fixed order: identical in every wave and workgroup
-      const float norm = sqrtf(total_sq);
-      coef = a.cfg.max_grad_norm / (norm + 1e-6f);                        // clip_grad_norm_ (torch): eps 1e-6
-      coef = coef > 1.f ? 1.f : coef;
-      stale_sq *= coef * coef;
-    }
-    SPO_STAMP(8)
-    if (coef != 1.f) {
-      // ---- the clip is active (rare): layers 1 and 2 were updated with coefficient 1 -- restore them, redo them exactly,
-      //      and make the main waves repeat L1 / L2 of the step they have started
+    // exact redo of the two hidden layers from their backups (clip coefficient known)
+    auto redo_layers12 = [&](float coef) {
       SPO_REIDX
       __builtin_amdgcn_s_waitcnt(0);
       __builtin_amdgcn_sched_barrier(0);
@@ -1918,39 +1848,288 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
       mb2 = bmb2; vb2 = bvb2;
       const AdamOut o2 = adam1(bpb2, ggb2 * coef, mb2, vb2, b1c, b2c, eps, step_size, inv_bc2s);
       mb2 = o2.m; vb2 = o2.v; lds[L::B2 + 16 * wave + j] = o2.p;
-      if (wave == 0 && lane == 0) xw[18] = (int)((s + 1) & 0x3fffffff) + 1;
-      redo_next = true;
-    }
-    {
-      // ---- output layer (W3, b3, log_std) with the exact coefficient
-      SPO_REIDX
+    };
+    float coef = 1.f;
+    if (spec) {
+      // ======== deferred validation (the previous step was not clipped): EVERY layer is updated with coefficient 1 as
+      // soon as its gradient is there, so the main waves never wait for the joint norm; the norm is checked while they
+      // run the next forward / backward, and a clipped step is restored, redone exactly and its successor repeated.
+      {
+        // ---- layer 2 (W2, b2): L2 term, norm share, backups, speculative Adam
+        SPO_REIDX
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int addr = L::W3 + (4 * q + r) * LDH + 16 * wave + j;
-        const AdamOut o_ = adam1(lds[addr], gg3[r] * coef, mW3[r], vW3[r], b1c, b2c, eps, step_size, inv_bc2s);
-        mW3[r] = o_.m; vW3[r] = o_.v; lds[addr] = o_.p;
-      }
-      if (wave == 0) {
-        const AdamOut o_ = adam1(lds[L::B3 + j], ggb3 * coef, mb3, vb3, b1c, b2c, eps, step_size, inv_bc2s);
-        mb3 = o_.m; vb3 = o_.v; lds[L::B3 + j] = o_.p;
-        if (is_actor) {
+        for (int nt = 0; nt < 4; ++nt) {
+          const f4 gv = *reinterpret_cast<const f4*>(lds + H::G2 + ((wave * 4 + nt) * 64 + lane) * 4);
+          bk[BKS * (BK_W2 + 3 * nt + 0)] = mW2[nt];
+          bk[BKS * (BK_W2 + 3 * nt + 1)] = vW2[nt];
+          f4 pv;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int ai = 4 * q + r;
-            const AdamOut ol = adam1(red[128 + ai], dls[r] * coef, mls[r], vls[r], b1c, b2c, eps, step_size, inv_bc2s);
-            mls[r] = ol.m; vls[r] = ol.v; red[128 + ai] = ol.p;
+            const int addr = L::W2 + (orow + r) * LDH + 16 * nt + j;
+            const float p_ = lds[addr];
+            const float g_ = vcoef * fmaf(l2x2, p_, gv[r]);
+            gg2[nt][r] = g_; pv[r] = p_; gsq = fmaf(g_, g_, gsq); psq = fmaf(p_, p_, psq);
+            const AdamOut o_ = adam1(p_, g_, mW2[nt][r], vW2[nt][r], b1c, b2c, eps, step_size, inv_bc2s);
+            mW2[nt][r] = o_.m; vW2[nt][r] = o_.v; lds[addr] = o_.p;
+          }
+          bk[BKS * (BK_W2 + 3 * nt + 2)] = pv;
+        }
+        bpb2 = lds[L::B2 + 16 * wave + j];
+        ggb2 = vcoef * fmaf(l2x2, bpb2, lds[H::GB + 1 * 256 + wave * 64 + lane]);
+        if (own_b) { gsq = fmaf(ggb2, ggb2, gsq); psq = fmaf(bpb2, bpb2, psq); }
+        bmb2 = mb2; bvb2 = vb2;
+        const AdamOut o_ = adam1(bpb2, ggb2, mb2, vb2, b1c, b2c, eps, step_size, inv_bc2s);
+        mb2 = o_.m; vb2 = o_.v; lds[L::B2 + 16 * wave + j] = o_.p;
+      }
+      SPO_STAMP(3)
+      if (s + 1 < nsteps) __syncthreads();                                // Q2 of step s + 1: (speculative) W2 / b2 in place
+      SPO_STAMP(4)
+      float loss_data = 0.f;
+      if (wave == 0 && lane == 0 && s + 1 < nsteps) loss_data = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;
+      f4 bW3p, bW3m = mW3, bW3v = vW3, blsp = {0.f, 0.f, 0.f, 0.f}, blsm = mls, blsv = vls;
+      float bb3p = 0.f, bb3m = mb3, bb3v = vb3;
+      {
+        // ---- output layer (W3, b3, log_std): the same, backups in registers; then the norm share goes out
+        SPO_REIDX
+        const f4 gv = *reinterpret_cast<const f4*>(lds + H::G3 + ((wave * 2 + 0) * 64 + lane) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                                       // pad rows hold p == 0, g == 0
+          const int addr = L::W3 + (4 * q + r) * LDH + 16 * wave + j;
+          const float p_ = lds[addr];
+          const float g_ = vcoef * fmaf(l2x2, p_, gv[r]);
+          gg3[r] = g_; bW3p[r] = p_; gsq = fmaf(g_, g_, gsq); psq = fmaf(p_, p_, psq);
+          const AdamOut o_ = adam1(p_, g_, mW3[r], vW3[r], b1c, b2c, eps, step_size, inv_bc2s);
+          mW3[r] = o_.m; vW3[r] = o_.v; lds[addr] = o_.p;
+        }
+        if (wave == 0) {
+          bb3p = lds[L::B3 + j];
+          ggb3 = vcoef * fmaf(l2x2, bb3p, lds[H::GB + 2 * 256 + lane]);
+          if (q == 0) { gsq = fmaf(ggb3, ggb3, gsq); psq = fmaf(bb3p, bb3p, psq); }
+          const AdamOut o_ = adam1(bb3p, ggb3, mb3, vb3, b1c, b2c, eps, step_size, inv_bc2s);
+          mb3 = o_.m; vb3 = o_.v; lds[L::B3 + j] = o_.p;
+          if (is_actor) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int ai = 4 * q + r;
+              dls[r] = (red[16 + ai] + red[32 + ai]) + (red[48 + ai] + red[64 + ai]);     // 0 on pad rows
+              if (own_ls) gsq = fmaf(dls[r], dls[r], gsq);
+              blsp[r] = red[128 + ai];
+              const AdamOut ol = adam1(blsp[r], dls[r], mls[r], vls[r], b1c, b2c, eps, step_size, inv_bc2s);
+              mls[r] = ol.m; vls[r] = ol.v; red[128 + ai] = ol.p;
+            }
+          }
+        }
+        const float wg_sq = wave_sum_lane63(gsq), wp_sq = wave_sum_lane63(psq);
+        if (lane == 63) {
+          st_granule(grow + 4 * wg + wave, ((unsigned long long)tag << 32) | __float_as_uint(wg_sq));
+          red[88 + wave] = wp_sq;                                          // sum p^2 shares: read after the next barrier
+        }
+      }
+      SPO_STAMP(5)
+      if (s + 1 < nsteps) __syncthreads();                                // Xd of step s + 1: W3 / b3 / log_std in place
+      SPO_STAMP(9)
+      {
+        if (wave == 0 && lane == 0 && s + 1 < nsteps) {
+          const float pp = (red[88] + red[89]) + (red[90] + red[91]);
+          a.losses[s * 3 + net] = is_actor ? -loss_data : loss_data + l2 * pp;
+        }
+        float mine = 0.f;
+        const int ngr = 4 * a.n_nets;
+        if (lane < ngr) {
+          __builtin_amdgcn_s_setprio(0);
+          unsigned long long v = ld_granule(grow + lane);
+          unsigned sp2 = 0;
+          while ((unsigned)(v >> 32) != tag) {
+            if (++sp2 > (1u << 22)) { *a.err = 1; break; }
+            __builtin_amdgcn_s_sleep(4);
+            v = ld_granule(grow + lane);
+          }
+          mine = __uint_as_float((unsigned)v);
+          __builtin_amdgcn_s_setprio(SPO_HELPER_PRIO);
+        }
+        float total_sq = stale_sq;
+        for (int kk = 0; kk < ngr; ++kk) total_sq += __shfl(mine, kk);
+        const float norm = sqrtf(total_sq);
+        coef = a.cfg.max_grad_norm / (norm + 1e-6f);
+        coef = coef > 1.f ? 1.f : coef;
+        stale_sq *= coef * coef;
+      }
+      bool late = false;
+      if (coef != 1.f) {
+        // ---- clipped after all: restore every layer, redo it exactly, make the main waves repeat the step they are in
+        redo_layers12(coef);
+        SPO_REIDX
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int addr = L::W3 + (4 * q + r) * LDH + 16 * wave + j;
+          const AdamOut o_ = adam1(bW3p[r], gg3[r] * coef, bW3m[r], bW3v[r], b1c, b2c, eps, step_size, inv_bc2s);
+          mW3[r] = o_.m; vW3[r] = o_.v; lds[addr] = o_.p;
+        }
+        if (wave == 0) {
+          const AdamOut o_ = adam1(bb3p, ggb3 * coef, bb3m, bb3v, b1c, b2c, eps, step_size, inv_bc2s);
+          mb3 = o_.m; vb3 = o_.v; lds[L::B3 + j] = o_.p;
+          if (is_actor) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int ai = 4 * q + r;
+              const AdamOut ol = adam1(blsp[r], dls[r] * coef, blsm[r], blsv[r], b1c, b2c, eps, step_size, inv_bc2s);
+              mls[r] = ol.m; vls[r] = ol.v; red[128 + ai] = ol.p;
+            }
+          }
+        }
+        if (wave == 0 && lane == 0) xw[20] = (int)((s + 1) & 0x3fffffff) + 1;
+        late = true;
+      }
+      SPO_STAMP(8)
+      if (s + 1 < nsteps) {
+        __syncthreads();                                                  // B_stage of step s + 1: the verdict is out
+        if (late) {                                                       // the main waves repeat L1, Q2, L2, Xd, ..., B_stage
+          __syncthreads();
+          __syncthreads();
+          __syncthreads();
+        }
+      }
+      spec = (coef == 1.f);
+    } else {
+      // ======== the previous step was clipped (or SPO_UPDATE_SPEC=0): the output layer waits for the joint norm
+      {
+        SPO_REIDX
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const f4 gv = *reinterpret_cast<const f4*>(lds + H::G2 + ((wave * 4 + nt) * 64 + lane) * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p_ = lds[L::W2 + (orow + r) * LDH + 16 * nt + j];
+            const float g_ = vcoef * fmaf(l2x2, p_, gv[r]);
+            gg2[nt][r] = g_; pW2[nt][r] = p_; gsq = fmaf(g_, g_, gsq); psq = fmaf(p_, p_, psq);
+          }
+        }
+        {
+          const f4 gv = *reinterpret_cast<const f4*>(lds + H::G3 + ((wave * 2 + 0) * 64 + lane) * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {                                       // pad rows hold p == 0, g == 0
+            const float p_ = lds[L::W3 + (4 * q + r) * LDH + 16 * wave + j];
+            const float g_ = vcoef * fmaf(l2x2, p_, gv[r]);
+            gg3[r] = g_; gsq = fmaf(g_, g_, gsq); psq = fmaf(p_, p_, psq);
+          }
+        }
+        {
+          bpb2 = lds[L::B2 + 16 * wave + j];
+          ggb2 = vcoef * fmaf(l2x2, bpb2, lds[H::GB + 1 * 256 + wave * 64 + lane]);
+          if (own_b) { gsq = fmaf(ggb2, ggb2, gsq); psq = fmaf(bpb2, bpb2, psq); }
+        }
+        if (wave == 0) {
+          const float p_ = lds[L::B3 + j];
+          ggb3 = vcoef * fmaf(l2x2, p_, lds[H::GB + 2 * 256 + lane]);
+          if (q == 0) { gsq = fmaf(ggb3, ggb3, gsq); psq = fmaf(p_, p_, psq); }
+          if (is_actor) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int ai = 4 * q + r;
+              dls[r] = (red[16 + ai] + red[32 + ai]) + (red[48 + ai] + red[64 + ai]);     // 0 on pad rows
+              if (own_ls) gsq = fmaf(dls[r], dls[r], gsq);
+            }
+          }
+        }
+        // every helper wave publishes ITS share of ||g||^2 as a tagged granule of its own (12 granules per step); every
+        // helper wave later adds all of them in the same fixed order -- no gather and no spinning inside the workgroup
+        const float wg_sq = wave_sum_lane63(gsq), wp_sq = wave_sum_lane63(psq);
+        if (lane == 63) {
+          st_granule(grow + 4 * wg + wave, ((unsigned long long)tag << 32) | __float_as_uint(wg_sq));
+          red[88 + wave] = wp_sq;                                            // sum p^2 shares: read after the next barrier
+        }
+        SPO_STAMP(3)
+      }
+      {
+        // ---- layer 2 (W2, b2): SPECULATIVE Adam like layer 1 (the other networks' norms are still in flight)
+        SPO_REIDX
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          bk[BKS * (BK_W2 + 3 * nt + 0)] = mW2[nt];
+          bk[BKS * (BK_W2 + 3 * nt + 1)] = vW2[nt];
+          bk[BKS * (BK_W2 + 3 * nt + 2)] = pW2[nt];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const AdamOut o_ = adam1(pW2[nt][r], gg2[nt][r], mW2[nt][r], vW2[nt][r], b1c, b2c, eps, step_size, inv_bc2s);
+            mW2[nt][r] = o_.m; vW2[nt][r] = o_.v; lds[L::W2 + (orow + r) * LDH + 16 * nt + j] = o_.p;
+          }
+        }
+        bmb2 = mb2; bvb2 = vb2;
+        const AdamOut o_ = adam1(bpb2, ggb2, mb2, vb2, b1c, b2c, eps, step_size, inv_bc2s);
+        mb2 = o_.m; vb2 = o_.v; lds[L::B2 + 16 * wave + j] = o_.p;
+      }
+      SPO_STAMP(9)
+      if (s + 1 < nsteps) __syncthreads();                                  // Q2 of step s + 1: (speculative) W2 / b2 in place
+      SPO_STAMP(4)
+      // ---- the joint norm and the clip coefficient (the granules have had a forward layer's time to arrive)
+      {
+        if (wave == 0 && lane == 0 && s + 1 < nsteps) {                       // the loss value of this step (logging); the
+          // last step has no Q2 barrier before this point: its value is written after the barrier that follows the loop
+          const float loss_data = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;
+          const float pp = (red[88] + red[89]) + (red[90] + red[91]);
+          a.losses[s * 3 + net] = is_actor ? -loss_data : loss_data + l2 * pp;
+        }
+        float mine = 0.f;
+        const int ngr = 4 * a.n_nets;
+        if (lane < ngr) {                                                     // lane k polls granule k (network k / 4, wave k % 4)
+          __builtin_amdgcn_s_setprio(0);
+          unsigned long long v = ld_granule(grow + lane);
+          unsigned sp2 = 0;
+          while ((unsigned)(v >> 32) != tag) {
+            if (++sp2 > (1u << 22)) { *a.err = 1; break; }
+            __builtin_amdgcn_s_sleep(4);
+            v = ld_granule(grow + lane);
+          }
+          mine = __uint_as_float((unsigned)v);
+          __builtin_amdgcn_s_setprio(SPO_HELPER_PRIO);
+        }
+        float total_sq = stale_sq;
+        for (int kk = 0; kk < ngr; ++kk) total_sq += __shfl(mine, kk);        // fixed order: identical in every wave and workgroup
+        const float norm = sqrtf(total_sq);
+        coef = a.cfg.max_grad_norm / (norm + 1e-6f);                        // clip_grad_norm_ (torch): eps 1e-6
+        coef = coef > 1.f ? 1.f : coef;
+        stale_sq *= coef * coef;
+      }
+      SPO_STAMP(8)
+      if (coef != 1.f) {
+        // ---- the clip is active (rare): layers 1 and 2 were updated with coefficient 1 -- restore them, redo them exactly,
+        //      and make the main waves repeat L1 / L2 of the step they have started
+        redo_layers12(coef);
+        if (wave == 0 && lane == 0) xw[18] = (int)((s + 1) & 0x3fffffff) + 1;
+        redo_next = true;
+      }
+      {
+        // ---- output layer (W3, b3, log_std) with the exact coefficient
+        SPO_REIDX
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int addr = L::W3 + (4 * q + r) * LDH + 16 * wave + j;
+          const AdamOut o_ = adam1(lds[addr], gg3[r] * coef, mW3[r], vW3[r], b1c, b2c, eps, step_size, inv_bc2s);
+          mW3[r] = o_.m; vW3[r] = o_.v; lds[addr] = o_.p;
+        }
+        if (wave == 0) {
+          const AdamOut o_ = adam1(lds[L::B3 + j], ggb3 * coef, mb3, vb3, b1c, b2c, eps, step_size, inv_bc2s);
+          mb3 = o_.m; vb3 = o_.v; lds[L::B3 + j] = o_.p;
+          if (is_actor) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int ai = 4 * q + r;
+              const AdamOut ol = adam1(red[128 + ai], dls[r] * coef, mls[r], vls[r], b1c, b2c, eps, step_size, inv_bc2s);
+              mls[r] = ol.m; vls[r] = ol.v; red[128 + ai] = ol.p;
+            }
           }
         }
       }
-    }
-    SPO_STAMP(5)
-    if (s + 1 < nsteps) {
-      __syncthreads();                                                    // Xd of step s + 1: W3 / b3 / log_std updated, verdict out
-      if (redo_next) {                                                    // the main waves repeat L1, Q2, L2, Xd
-        __syncthreads();
-        __syncthreads();
+      SPO_STAMP(5)
+      if (s + 1 < nsteps) {
+        __syncthreads();                                                    // Xd of step s + 1: W3 / b3 / log_std updated, verdict out
+        if (redo_next) {                                                    // the main waves repeat L1, Q2, L2, Xd
+          __syncthreads();
+          __syncthreads();
+        }
+        __syncthreads();                                                    // B_stage of step s + 1
       }
-      __syncthreads();                                                    // B_stage of step s + 1
+      spec = a.spec_mode != 0 && coef == 1.f;
     }
     SPO_STAMP(6)
   }
@@ -2014,6 +2193,7 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
   }   // helper role
 #undef SPO_REIDX
 #undef SPO_STAMP
+#undef SPO_SUB
 }
 
 // Split form, second half: joint clip + Adam over the flat vector (one workgroup; P ~ 25k).
@@ -2104,6 +2284,10 @@ int launch_update_h(const UpdArgs& a_in, int blocks, hipStream_t st) {
   if (int rc = spo::hip_check(hipGetSymbolAddress(reinterpret_cast<void**>(&slbase), HIP_SYMBOL(g_h_slots)),
                               "hipGetSymbolAddress(g_h_slots)")) return rc;
   a.backup = reinterpret_cast<float*>(bkbase + (size_t)rslot * UPD_BACKUP_ROWS * 3 * 512);
+  {
+    static const int spec_env = [] { const char* e = getenv("SPO_UPDATE_SPEC"); return e ? atoi(e) : 1; }();
+    a.spec_mode = spec_env;
+  }
   a.slots = slbase + (size_t)rslot * 32;
   if (int rc = spo::hip_check(hipMemsetAsync(a.slots, 0, sizeof(unsigned long long) * 32, st), "hipMemsetAsync(g_h_slots)")) return rc;
   const size_t sh = UpdHLds<K>::SIZE * sizeof(float);

@@ -414,6 +414,62 @@ def test_minibatch_grad_and_step_vs_oracle(dev, M, D, A, batch):
     np.testing.assert_allclose(eng.adam_m[:m_ref.numel()].cpu().numpy(), m_ref.numpy(), rtol=1e-3, atol=1e-7)
 
 
+@pytest.mark.parametrize("spec", ["1", "0"])
+def test_intermittent_clip_vs_oracle(dev, spec, monkeypatch):
+    """clip_grad_norm_ active on SOME steps (bound = median of the unclipped run's joint norms): the persistent launch
+    validates the clip after the next step's forward while steps are unclipped and falls back to waiting for the norm
+    after a clipped one, so runs of clipped / unclipped steps in both orders must all match the oracle
+    (ppo_lag.py:325 clip_grad_norm_ over actor + both critics)."""
+    import subprocess, sys
+    if spec == "0":
+        # the switch is read once per process: the non-speculative form is checked in a child process
+        env = dict(os.environ, SPO_UPDATE_SPEC="0")
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__, "-k",
+                            "test_intermittent_clip_vs_oracle and 1"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return
+    from safepo.common.engine import PPOLagEngine
+    from safepo.common.model import ActorVCritic
+    M, D, A, batch = 1536, 60, 8, 64
+    torch.manual_seed(11)
+    pol = ActorVCritic(D, A).to(dev)
+    ref = R.OraclePolicy(D, A)
+    ref.load_state_dict({k: v.cpu().clone() for k, v in pol.state_dict().items()})
+    ref0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    obs, act, logp, tgt_r, tgt_c, adv = _synthetic_update_problem(M, D, A, seed=5)
+    perm = torch.randperm(M, generator=torch.Generator().manual_seed(3))
+
+    def oracle_run(bound):
+        ref.load_state_dict(ref0)
+        upd = R.PPOLagUpdater(ref, epochs=1, max_grad_norm=bound)
+        out, norms = [], []
+        for s in range(0, M, batch):
+            ii = perm[s:s + batch]
+            rec = {}
+            out.append(upd.minibatch_step(obs[ii], act[ii], logp[ii], tgt_r[ii], tgt_c[ii], adv[ii], record=rec))
+            norms.append(float(rec["grad_preclip"].double().norm()))
+        return np.asarray(out), np.asarray(norms)
+
+    _, free_norms = oracle_run(1e9)
+    bound = float(np.median(free_norms))
+    losses_ref, norms = oracle_run(bound)
+    clipped = norms > bound
+    flips = int(np.sum(clipped[1:] != clipped[:-1]))
+    assert clipped.any() and (~clipped).any() and flips >= 4, (clipped, bound)
+    assert np.abs(norms / bound - 1).min() > 1e-4           # no step sits on the bound (the decision is not a rounding matter)
+    cfg = {"hidden_sizes": [64, 64], "gamma": 0.99, "target_kl": 1e9, "batch_size": batch, "learning_iters": 1,
+           "max_grad_norm": bound}
+    eng = PPOLagEngine(pol, 1, M, cfg, dev)
+    b = eng.buffer
+    b.data["obs"].copy_(obs.view(1, M, D)); b.data["act"].copy_(act.view(1, M, A))
+    b.data["log_prob"].copy_(logp.view(1, M)); b.data["target_value_r"].copy_(tgt_r.view(1, M))
+    b.data["target_value_c"].copy_(tgt_c.view(1, M)); b.adv_mix.copy_(adv.view(1, M))
+    losses = eng.learning_iter(perm.to(torch.int32).to(dev))
+    eng.check_sync_error()
+    np.testing.assert_allclose(losses.cpu().numpy(), losses_ref, rtol=1e-4, atol=2e-6)
+    _assert_params_close(pol.theta.cpu().numpy(), R.flat_params(ref).numpy(), 3e-4, len(losses_ref), what="theta")
+
+
 def test_split_path_equals_persistent(dev):
     """spo_ppo_lag_grad + spo_clip_adam (data-parallel form, world size 1) == persistent kernel."""
     from safepo import _abi

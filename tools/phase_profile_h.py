@@ -29,9 +29,14 @@ p = prof.cpu().view(3, 10).numpy()
 print(f"instrumented launch: {dt*1e6/steps:.2f} us/step")
 main = ["settle + x^T", "L1", "wait Q2", "L2", "wait Xd", "L3 loss bwd stage", "wait B_stage", "dW1 -> G1", "wait P1", "dW2 dW3 -> G"]
 helper = ["wait P1", "Adam W1 (speculative)", "wait P3", "norms of W2 W3 + tags", "wait Q2", "Adam W3 b3 log_std", "wait Xd + B_stage", "", "poll norms, coefficient", "Adam W2 (speculative)"]
-for row, names in ((0, main), (1, helper)):
+spec = os.environ.get("SPO_UPDATE_SPEC", "1") != "0"
+if spec:
+    helper = ["wait P1", "W1: L2 norm Adam (spec)", "wait P3", "W2: L2 norm Adam (spec)", "wait Q2", "W3 b3 log_std (spec), norm out", "wait B_stage", "",
+              "poll norms, verdict", "wait Xd"]
+sub = ["prefetch issue + L3", "loss", "dO -> dZ2", "dZ2 -> dZ1", "stage 4 images + dO", "loss / dls sums"]
+for row, names in ((0, main), (2, sub), (1, helper)):
     tot = p[row].sum()
-    print(("main" if row == 0 else "helper") + f" wave 0 of the actor: total {tot/steps:.0f} cycles/step")
+    print({0: "main", 1: "helper", 2: "main, inside 'L3 loss bwd stage':"}[row] + f" wave 0 of the actor: total {tot/steps:.0f} cycles/step")
     for i, n in enumerate(names):
         if n:
             print(f"   {n:22s} {p[row][i]/steps:8.0f} cyc  {100*p[row][i]/max(tot,1):5.1f}%")
