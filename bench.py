@@ -128,6 +128,9 @@ def run_epochs(algo, a, comm, dev, N, T, D, A, steps, warmup, time_gae):
         n_ep = eng.drain_episode_events(None)
         torch.cuda.synchronize(dev)
         t1 = time.time()
+        if os.environ.get("SPO_BENCH_DUMP_DISPATCHES") == "2" and timed and time_gae and getattr(eng.buffer, "_scan_args", None):
+            pre = np.asarray(eng.buffer.time_scan_dispatches(GAE_DISPATCHES)) * 1e6     # development aid: before the update
+            print(f"[bench] before update: mean {pre.mean():.2f} median {np.median(pre):.2f} max {pre.max():.2f}", file=sys.stderr)
         if algo == "cpo":
             eng.buffer.compute_gae(None, comm)
             pu = eng.policy_update(-1.0)
@@ -141,6 +144,10 @@ def run_epochs(algo, a, comm, dev, N, T, D, A, steps, warmup, time_gae):
             # (per-dispatch duration, what rocprofv3 --kernel-trace reports), (2) a hipGraph of GAE_REPS launches
             # between two events (back-to-back throughput; the command processor overlaps dispatch set-up).  ~1 ms.
             gae_disp.extend(eng.buffer.time_scan_dispatches(GAE_DISPATCHES))
+            if os.environ.get("SPO_BENCH_DUMP_DISPATCHES") == "2":
+                for _ in range(3):
+                    again = np.asarray(eng.buffer.time_scan_dispatches(GAE_DISPATCHES)) * 1e6
+                    print(f"[bench] after update, again: mean {again.mean():.2f} median {np.median(again):.2f} max {again.max():.2f}", file=sys.stderr)
             gae_graph.append(eng.buffer.time_scan(GAE_REPS))
         torch.cuda.synchronize(dev)
         t2 = time.time()
@@ -236,6 +243,8 @@ def main():
     disp = np.asarray(res["gae_disp"], np.float64)
     graph = np.asarray(res["gae_graph"], np.float64)
     disp_avg = float(disp.mean()) if disp.size else float("nan")
+    if os.environ.get("SPO_BENCH_DUMP_DISPATCHES"):          # development aid: the raw per-dispatch series
+        print("[bench] per-dispatch us:", np.round(disp * 1e6, 2).tolist(), file=sys.stderr)
     achieved = gae_bytes / disp_avg / 1e9
     pmc = None
     try:
@@ -358,7 +367,8 @@ def main():
         "early_stopping_epoch": faithful,
         # the kernel that owns 99 % of the GPU time is not HBM- but latency/matrix-bound: 327 680 strictly sequential
         # optimiser steps, each at least 368 v_mfma_f32_16x16x4_f32 (32 cycles each) per wave on one CU per network
-        "update_kernel": ({"kernel": "ppo_update_kernel<64, persistent>", "bound": "fp32 MFMA issue of one CU per network + per-step latency chain",
+        "update_kernel": ({"kernel": "ppo_update_h_kernel<64> (persistent; 4 main + 4 helper waves per network)",
+                           "bound": "fp32 MFMA issue of one CU per network + per-step latency chain",
                            "us_per_minibatch_step": round(us_step, 3),
                            "mfma_floor_us": round(368 * 32 / 2.4e9 * 1e6, 3),
                            "frac": round((368 * 32 / 2.4e9) / (us_step * 1e-6), 4),

@@ -172,7 +172,7 @@ class VectorizedOnPolicyBuffer:
         return e0.elapsed_time(e1) * 1e-3 / reps
 
 
-    def time_scan_dispatches(self, reps: int = 50, warm: int = 10):
+    def time_scan_dispatches(self, reps: int = 50, warm: int = 200):
         """Per-dispatch GPU time (seconds, one entry per launch) of spo_gae_fused on the current buffer contents: every
         dispatch carries its own start / stop events (spo_gae_fused_timed), i.e. the timestamps of the dispatch packet
         itself -- the per-dispatch duration rocprofv3 --kernel-trace reports, unlike the graph average of time_scan,
@@ -181,8 +181,11 @@ class VectorizedOnPolicyBuffer:
         args = self._scan_args
         out = (ctypes.c_float * (warm + reps))()
         torch.cuda.synchronize(self._device)
-        # `warm` untimed-in-effect dispatches first: the launches that directly follow a long persistent kernel (3 busy CUs
-        # for seconds) run at ramping clocks with a cold cache -- 2-3x the steady duration -- and would dominate a mean
+        # `warm` untimed-in-effect dispatches first (~0.9 ms): for the first few hundred microseconds after the GPU switches
+        # from a light load (the persistent update kernel keeps 3 CUs busy for seconds; the rollout is tiny kernels) to
+        # full-chip launches, scattered dispatches take 2-6x the steady 4.3 us (power-management transient: the series is
+        # in tools/gae_after_update.py / SPO_BENCH_DUMP_DISPATCHES); a second batch right after is flat.  The steady state
+        # is the kernel's figure; the one scan of a real epoch costs 4-30 us of a 3.6 s epoch either way
         _abi.check(self._lib.spo_gae_fused_timed(*args, warm + reps, out, _abi.stream_ptr()), "spo_gae_fused_timed")
         return [float(x) * 1e-6 for x in out][warm:]
 
