@@ -55,6 +55,7 @@ struct GaeArgs {
   float gamma32; double disc_r; double disc_c;
   int ablate;     // debug timing knob: 1 skip stats reduction, 2 skip cross-lane scan, 4 skip stores, 8 no loads/stores
   int plain_stores;   // A/B knob (env SPO_GAE_PLAIN_STORES=1): ordinary stores instead of the write-through ones
+  int64_t nblocks;    // logical 4-wave blocks (= partial rows / 4)
 };
 
 template <int VEC> struct VecT;
@@ -101,20 +102,23 @@ __device__ __forceinline__ void store_vec(float* p, bool ok, const float (&o)[VE
 // instead of both in every lane.  Same instructions in total, but each wave's dependent chain (deltas, affine
 // composition, replay) is half as long and twice as many waves are in flight -- the 4096x128 launch is latency-bound.
 constexpr int BOOT_PRED = 0, BOOT_EAGER = 1, BOOT_FOLDED = 2;
-template <int VEC, int LPR, int BOOT, bool RC>
-__global__ __launch_bounds__(256) void gae_kernel(GaeArgs a) {
+template <int VEC, int LPR, int BOOT, bool RC, int F = 1>
+__global__ __launch_bounds__(256 * F) void gae_kernel(GaeArgs a) {
   constexpr bool EAGER_BOOT = (BOOT == BOOT_EAGER);
   static_assert(!RC || LPR <= 32, "RC needs two lane groups per wave");
   constexpr int NK = RC ? 1 : 2;
   constexpr int ROWS_PER_WAVE = RC ? 64 / LPR / 2 : 64 / LPR;
   constexpr int CHUNK = LPR * VEC;
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = (threadIdx.x >> 6) & 3;
+  // F logical 4-wave blocks per workgroup (fewer, fatter workgroups; the numbering of rows and partial rows is unchanged)
+  const int64_t lblock = (int64_t)blockIdx.x * F + (F > 1 ? (int)(threadIdx.x >> 8) : 0);
+  if (F > 1 && lblock >= a.nblocks) return;
   const int grp_id = lane / LPR;
   const int sub = RC ? grp_id / 2 : grp_id;                   // row within the wave
   const int ksel = RC ? (grp_id & 1) : 0;                     // RC: 0 = reward scan, 1 = cost scan
   const int sl = lane % LPR;
-  const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * ROWS_PER_WAVE + sub;
+  const int64_t row = (lblock * 4 + wave) * ROWS_PER_WAVE + sub;
   const bool row_ok = row < a.N && !(a.ablate & 8);           // ablate 8: no loads, no stores (launch floor)
   const int64_t T = a.T;
   const int64_t rbase = row * T;
@@ -281,8 +285,8 @@ __global__ __launch_bounds__(256) void gae_kernel(GaeArgs a) {
   // No LDS stage and no barrier: the tail of the launch is a handful of DPP adds and one 32-byte row per wave
   // (the block-level combine cost 0.6 us of the 4.5 us launch at 4096 x 128; spo_adv_reduce adds the rows in a fixed order).
   if (a.ablate & 1) return;
-  double* const prow = a.partials + ((int64_t)blockIdx.x * 4 + wave) * 4;
-  int64_t wrows = a.N - ((int64_t)blockIdx.x * 4 + wave) * ROWS_PER_WAVE;
+  double* const prow = a.partials + (lblock * 4 + wave) * 4;
+  int64_t wrows = a.N - (lblock * 4 + wave) * ROWS_PER_WAVE;
   wrows = wrows < 0 ? 0 : (wrows > ROWS_PER_WAVE ? ROWS_PER_WAVE : wrows);
   if constexpr (RC) {
     static_assert(!RC || LPR == 32, "RC layout: lanes 0-31 scan the reward, lanes 32-63 the cost of the wave's row");
@@ -392,7 +396,21 @@ int launch_gae(const GaeGeom& g, const GaeArgs& a, int blocks, hipStream_t st) {
     else hipLaunchKernelGGL((gae_kernel<__VA_ARGS__>), dim3(blocks), dim3(256), 0, st, a);                         \
   }
   if (g.rc) {
-    if constexpr (VEC == 4) { SPO_GAE_LAUNCH(4, 32, BOOT, true) return 0; }
+    if constexpr (VEC == 4) {
+      static const int fat = [] { const char* e = getenv("SPO_GAE_FAT"); return e ? atoi(e) : 1; }();
+      if (fat == 2 || fat == 4) {
+        const int pb = (blocks + fat - 1) / fat;
+#define SPO_GAE_FAT_LAUNCH(FF)                                                                                    \
+        {                                                                                                         \
+          if (g_gae_ev_start) hipExtLaunchKernelGGL((gae_kernel<4, 32, BOOT, true, FF>), dim3(pb), dim3(256 * FF), 0, st, g_gae_ev_start, g_gae_ev_stop, 0, a); \
+          else hipLaunchKernelGGL((gae_kernel<4, 32, BOOT, true, FF>), dim3(pb), dim3(256 * FF), 0, st, a);         \
+        }
+        if (fat == 2) SPO_GAE_FAT_LAUNCH(2) else SPO_GAE_FAT_LAUNCH(4)
+#undef SPO_GAE_FAT_LAUNCH
+        return 0;
+      }
+      SPO_GAE_LAUNCH(4, 32, BOOT, true) return 0;
+    }
   }
   switch (g.lpr) {
 #define SPO_CASE(L) case L: SPO_GAE_LAUNCH(VEC, L, BOOT, false) break;
@@ -430,8 +448,9 @@ extern "C" int spo_gae_fused(const float* reward, const float* cost, const float
   const bool folded = boot_r == nullptr;
   GaeGeom g = gae_geom(T, num_envs);
   GaeArgs a{reward, cost, value_r, value_c, seg_end, boot_r, boot_c, adv_r, adv_c, target_r, target_c, partials,
-            num_envs, T, (float)gamma, gamma * lam, gamma * lam_c, g_gae_force_variant >> 4, gae_plain_stores()};
+            num_envs, T, (float)gamma, gamma * lam, gamma * lam_c, g_gae_force_variant >> 4, gae_plain_stores(), 0};
   const int blocks = spo_gae_num_blocks(num_envs, T);
+  a.nblocks = blocks;
   hipStream_t st = (hipStream_t)stream;
   // predicated bootstrap loads by default when bootstrap arrays are given (fewest bytes; measured equal or faster than
   // the eager form at every size); no bootstrap loads at all in the folded form
