@@ -5,8 +5,10 @@
 //
 // Regime: unlike the single-agent path (327 680 tiny sequential steps), MAPPO-L makes `learning_iters` (5) FULL-BATCH
 // steps per agent per epoch over episode_length x n_rollout_threads rows with hidden 128..512: plain large GEMMs.
-// The GEMMs go to rocBLAS (loaded lazily with dlopen, so the single-agent library has no rocBLAS load cost); everything
-// around them is fused here: bias + ELU + LayerNorm forward, its backward with the three column reductions, the
+// Every product runs on in-tree fp32 MFMA kernels (fused block forward / backward, the split-row weight gradient,
+// gemm_mfma_kernel for the plain X*W^T and dY*W products, head_small_kernel for narrow heads); rocBLAS is only a test
+// comparator behind spo_debug_ma_gemm (dlopen'ed on that call, never by the product path).  Fused around the products:
+// bias + ELU + LayerNorm forward, its backward with the three column reductions, the
 // Gaussian head / clipped HAPPO surrogate / entropy / lambda-delta epilogue, the clipped Huber value loss on
 // PopArt-normalised targets, PopArt statistics, per-network clip_grad_norm_ + Adam.
 //
@@ -23,7 +25,7 @@ namespace {
 
 using spo::fail;
 
-// ---------------------------------------------------------------- rocBLAS through dlopen
+// ---------------------------------------------------------------- rocBLAS through dlopen (test comparator only)
 typedef void* rb_handle;
 typedef int (*rb_create_t)(rb_handle*);
 typedef int (*rb_set_stream_t)(rb_handle, hipStream_t);

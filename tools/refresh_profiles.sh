@@ -18,3 +18,8 @@ echo "F=$F W=$W"
 if [ -n "$F" ] && [ -n "$W" ]; then python tools/gae_pmc_summary.py "$F" "$W" $O/gae_pmc.json | tail -40; else tail -5 /tmp/pmcf.log /tmp/pmcw.log; fi
 python tools/gae_modes.py > $O/gae_modes.log 2>&1; tail -6 $O/gae_modes.log
 python tools/phase_profile_h.py > $O/update_phase_cycles_h.txt 2>&1; tail -22 $O/update_phase_cycles_h.txt
+timeout 200 python tools/update_ab.py > $O/update_ab.txt 2>&1; tail -1 $O/update_ab.txt
+timeout 200 python tools/ma_bench.py --episodes 3 2>/dev/null | tail -1 > $O/ma_bench_mappolag_config5.json; cut -c1-300 $O/ma_bench_mappolag_config5.json
+cd /tmp && rm -rf /tmp/matrace && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/matrace -- python $GRAFT_REPO_ROOT/tools/ma_bench.py --episodes 2 > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+( echo "# rocprofv3 --kernel-trace --output-format csv -- python tools/ma_bench.py --episodes 2, grouped by kernel and grid size (tools/kernel_trace_by_grid.py)"; python tools/kernel_trace_by_grid.py /tmp/matrace ) > $O/ma_kernel_trace_by_grid.txt; head -8 $O/ma_kernel_trace_by_grid.txt
