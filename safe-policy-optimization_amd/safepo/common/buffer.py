@@ -194,8 +194,9 @@ class SeparatedReplayBuffer:
     """Per-agent multi-agent buffer with the reference's attributes and time-major shapes
     (safepo/common/buffer.py:209-465): share_obs/obs [T+1, N, ...], value_preds/cost_preds/returns/cost_returns/
     masks [T+1, N, 1], rewards/costs/actions/action_log_probs/factor [T, N, ...].  Storage is device memory;
-    compute_returns / compute_cost_returns (buffer.py:356-384) run as ONE fused kernel (spo_ma_gae) the first time
-    either is asked for after new value predictions -- bit-identical to the reference's fp32 Python loop."""
+    compute_returns / compute_cost_returns (buffer.py:356-384) run on the fused kernel spo_ma_gae (each writes only its own
+    output, like the reference; compute_returns_and_cost_returns does both in one launch) -- bit-identical to the
+    reference's fp32 Python loop."""
 
     def __init__(self, config, obs_space, share_obs_space, act_space):
         self.episode_length = config["episode_length"]
@@ -301,23 +302,35 @@ class SeparatedReplayBuffer:
             t = getattr(self, name)
             t[0].copy_(t[-1])
 
-    def compute_returns_and_cost_returns(self, next_value, next_cost, value_normalizer=None, cost_normalizer=None):
+    def compute_returns_and_cost_returns(self, next_value, next_cost, value_normalizer=None, cost_normalizer=None,
+                                         _returns_out=None, _cost_returns_out=None):
         """Both GAE recurrences in one launch (the reference's compute() calls them back to back per agent,
         mappolag.py:583-597)."""
         self.value_preds[-1] = next_value
         self.cost_preds[-1] = next_cost
         sd_r, mu_r = value_normalizer.denorm_scalars() if value_normalizer is not None else (1.0, 0.0)
         sd_c, mu_c = cost_normalizer.denorm_scalars() if cost_normalizer is not None else (1.0, 0.0)
+        ret = self.returns if _returns_out is None else _returns_out
+        cret = self.cost_returns if _cost_returns_out is None else _cost_returns_out
         _abi.check(self._lib.spo_ma_gae(
             _abi.ptr(self.rewards), _abi.ptr(self.costs), _abi.ptr(self.value_preds), _abi.ptr(self.cost_preds),
-            _abi.ptr(self.masks), _abi.ptr(self.returns), _abi.ptr(self.cost_returns), self.episode_length,
+            _abi.ptr(self.masks), _abi.ptr(ret), _abi.ptr(cret), self.episode_length,
             self.n_rollout_threads, self.gamma, self.gae_lambda, sd_r, mu_r, sd_c, mu_c, _abi.stream_ptr()),
             "spo_ma_gae")
 
+    def _other_side_scratch(self):
+        # the fused kernel always runs both recurrences; the side that was not asked for lands here, so that (like the
+        # reference, buffer.py:356-384) compute_returns touches only `returns` and compute_cost_returns only `cost_returns`
+        if getattr(self, "_gae_scratch", None) is None:
+            self._gae_scratch = torch.empty_like(self.returns)
+        return self._gae_scratch
+
     def compute_returns(self, next_value, value_normalizer=None):
-        """buffer.py:356-377 (cost side recomputed alongside with its current predictions; harmless)."""
-        self.compute_returns_and_cost_returns(next_value, self.cost_preds[-1].clone(), value_normalizer, value_normalizer)
+        """buffer.py:356-377."""
+        self.compute_returns_and_cost_returns(next_value, self.cost_preds[-1].clone(), value_normalizer, None,
+                                              _cost_returns_out=self._other_side_scratch())
 
     def compute_cost_returns(self, next_cost, value_normalizer=None):
         """buffer.py:379-384."""
-        self.compute_returns_and_cost_returns(self.value_preds[-1].clone(), next_cost, value_normalizer, value_normalizer)
+        self.compute_returns_and_cost_returns(self.value_preds[-1].clone(), next_cost, None, value_normalizer,
+                                              _returns_out=self._other_side_scratch())

@@ -1346,7 +1346,15 @@ def test_multi_agent_masked_gae_popart_bit_exact(dev, golden_dir, tag):
     norm.running_mean.copy_(g("rm")); norm.running_mean_sq.copy_(g("rms")); norm.debiasing_term.copy_(g("deb").reshape(()))
     mean, var = norm.running_mean_var()
     assert np.array_equal(mean.numpy(), z[f"{tag}_mean"]) and np.array_equal(var.numpy(), z[f"{tag}_var"])
+    buf.cost_returns[:-1].fill_(7.0)                        # (row T is never written by either recurrence)
     buf.compute_returns(g("next_v").to(dev), norm)
+    assert bool((buf.cost_returns[:-1] == 7.0).all())       # the reward side leaves cost_returns alone (buffer.py:356-377)
+    assert np.array_equal(buf.returns.cpu().numpy().view(np.uint32), z[f"{tag}_returns"].view(np.uint32))
+    # ... and the cost side leaves `returns` alone even when it is given a DIFFERENT normaliser (buffer.py:379-384)
+    other = PopArt(1)
+    other.running_mean.fill_(3.0); other.running_mean_sq.fill_(11.0); other.debiasing_term.fill_(0.5)
+    buf.compute_cost_returns(g("next_c").to(dev), other)
+    assert np.array_equal(buf.returns.cpu().numpy().view(np.uint32), z[f"{tag}_returns"].view(np.uint32))
     buf.compute_cost_returns(g("next_c").to(dev), norm)
     assert np.array_equal(buf.returns.cpu().numpy().view(np.uint32), z[f"{tag}_returns"].view(np.uint32))
     assert np.array_equal(buf.cost_returns.cpu().numpy().view(np.uint32), z[f"{tag}_cost_returns"].view(np.uint32))
