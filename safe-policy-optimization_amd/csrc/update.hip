@@ -1266,6 +1266,10 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
   const int ls_off = g.off - A;
   float* const red = lds + U::RED;
   volatile int* const xw = reinterpret_cast<volatile int*>(lds + H::XW);
+  // The main waves read the two redo words once per step right after a barrier: through a plain LDS pointer (ds_read_b32).
+  // Through the volatile pointer the read is a flat_load ... sc0 sc1 followed by s_waitcnt vmcnt(0): a round trip through
+  // the memory pipeline that also waits for every prefetch in flight, twice per step on the critical path.
+  const int* const xw_ro = reinterpret_cast<const int*>(lds + H::XW);
   stage_net<KIN>(a.theta, g, lds, tid, 512);
   if (is_actor && tid < A) red[128 + tid] = a.theta[ls_off + tid];
   if (tid < 32) xw[tid] = 0;
@@ -1440,7 +1444,7 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
       SPO_STAMP(3)
       __syncthreads();                                                    // Xd: W3 / b3 / log_std in place, clip verdict known
       SPO_STAMP(4)
-      const int redo_tag = xw[18];
+      const int redo_tag = xw_ro[18];
       if (redo_tag == (int)(s & 0x3fffffff) + 1 && !redone) { redone = true; continue; }   // clipped: W1, W2 were redone
     {
       // ---- rest of the step of the main waves: prefetch, L3, loss, backward, staging
@@ -1576,7 +1580,7 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
       // Deferred validation: the helpers updated ALL layers with clip coefficient 1 and found, while this forward /
       // backward ran, that the previous step's joint norm exceeds the bound.  They have restored and redone the update
       // exactly before this barrier; the step is repeated from layer 1 on the exact weights (x from its LDS image).
-      if (xw[20] == (int)(s & 0x3fffffff) + 1 && !late_redone) {
+      if (xw_ro[20] == (int)(s & 0x3fffffff) + 1 && !late_redone) {
         late_redone = true;
         SPO_REIDX
 #pragma unroll
