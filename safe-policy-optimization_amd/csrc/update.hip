@@ -28,6 +28,9 @@ using namespace spo;
 #define SPO_SPECULATIVE_ADAM 1
 #endif
 #ifndef SPO_HELPER_PRIO
+#ifndef SPO_H_RD_VB
+#define SPO_H_RD_VB 4          // rows polled together by the helper waves' recursive doubling (register budget: A/B knob)
+#endif
 #define SPO_HELPER_PRIO 2      // s_setprio of the helper waves of ppo_update_h_kernel (A/B knob)
 #endif
 constexpr int LDB = 64 + 4;     // [feature][batch] LDS row stride (floats)
@@ -105,6 +108,8 @@ struct UpdArgs {
   unsigned xr_step0;                   // global optimiser-step count before this launch (same on every rank)
   void* xr_region[XR_MAX_WORLD];       // every rank's exchange region (own + IPC-mapped peers), indexed by rank
   float* backup;                       // main + helper form: [UPD_BACKUP_ROWS][3 workgroups][512 lanes] float4 backup rows
+  int xr_helper_rd;                    // main + helper form, XR > 0: 1 = recursive doubling with tagged words on the helper
+                                       // waves (default), 0 = flag-based all-to-all (SPO_P2P_A2A=1)
   int spec_mode;                       // main + helper form: 1 = the clip verdict is validated AFTER the next step's forward
                                        // while the previous step was not clipped (SPO_UPDATE_SPEC, default), 0 = never
 };
@@ -302,10 +307,11 @@ __device__ __forceinline__ void xr_allreduce(const u64* regions, int me, int R, 
 // against two for the reduce-scatter form at any size, but each of these is a single push/poll with no slice
 // bookkeeping, and the gradient registers plus six polled rows fit the register file (the 4-rank one-shot -- own gradient
 // plus three peer copies live at once -- spilled 250-500 B per lane next to the optimiser state and lost).
-template <int NV>
+// ROW0: first slot row used (two calls per step with disjoint rows may share a tag).
+template <int NV, int ROW0 = 0, int VB = 6>                     // VB: gradient rows polled together
 __device__ __forceinline__ void xr_allreduce_rd(const u64* regions, int me, int R, int net, int tid, unsigned gtag,
                                                 f4 (&pk)[NV], volatile float* dead_word, int* err) {
-  constexpr int VB = 6;                                         // gradient rows polled together
+  static_assert((ROW0 + NV) * 256 <= XR_SLOT_F4, "slot rows");
   const int par = (int)(gtag & 1u);
 #pragma unroll 1
   for (int k = 0; (1 << k) < R; ++k) {
@@ -313,7 +319,7 @@ __device__ __forceinline__ void xr_allreduce_rd(const u64* regions, int me, int 
     const size_t slot = ((size_t)(par * XR_MAX_WORLD + k) * 3 + net) * XR_SLOT_WORDS;
     gu64* const p = xr_words(regions[peer]) + slot;
 #pragma unroll
-    for (int v = 0; v < NV; ++v) st_ll(xr_elem(p, v * 256 + tid), pk[v], gtag);
+    for (int v = 0; v < NV; ++v) st_ll(xr_elem(p, (ROW0 + v) * 256 + tid), pk[v], gtag);
     gu64* const src = xr_words(regions[me]) + slot;
 #pragma unroll
     for (int v0 = 0; v0 < NV; v0 += VB) {
@@ -323,7 +329,7 @@ __device__ __forceinline__ void xr_allreduce_rd(const u64* regions, int me, int 
         bool ok = true;
 #pragma unroll
         for (int vv = 0; vv < VB; ++vv)
-          if (v0 + vv < NV) ok = ld_ll(xr_elem(src, (v0 + vv) * 256 + tid), gtag, x[vv]) && ok;
+          if (v0 + vv < NV) ok = ld_ll(xr_elem(src, (ROW0 + v0 + vv) * 256 + tid), gtag, x[vv]) && ok;
         if (ok || *dead_word != 0.f) break;
         if (++spins > XR_SPIN_LIMIT) { *err = 2; *dead_word = 1.f; break; }
         __builtin_amdgcn_s_sleep(1);
@@ -1226,7 +1232,9 @@ __device__ __forceinline__ void a2a_pull_all(const UpdArgs& a, const unsigned lo
   }
 }
 
-template <int KIN, bool PROF = false, int XR = 0>        // XR: world size of the in-kernel data-parallel exchange (0 = none)
+// XR: world size of the in-kernel data-parallel exchange (0 = none); XRD: its form on the helper waves (true = recursive
+// doubling with tagged words, false = flag-based all-to-all) -- separate instantiations: both bodies together spill
+template <int KIN, bool PROF = false, int XR = 0, bool XRD = true>
 __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
   // PROF: wave 0 of each role of the LAST workgroup accumulates shader cycles per interval (a.prof rows 0 = main, 1 = helper)
   unsigned long long pacc[NPHASE] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1723,6 +1731,11 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT1; ++nt) gx[nt] = *reinterpret_cast<const f4*>(lds + H::G1 + ((wave * NT1 + nt) * 64 + lane) * 4);
         gx[NT1] = f4{lds[H::GB + 0 * 256 + hl], 0.f, 0.f, 0.f};
+        if constexpr (XRD) {
+          // recursive doubling with {tag, value} words (one flight per round, no acknowledgement wait), slot rows 0 .. NT1
+          xr_allreduce_rd<NT1 + 1, 0, SPO_H_RD_VB>(xtab, a.xr_rank, XR, net, hl, gtag, gx,
+                                      reinterpret_cast<volatile float*>(lds + H::XW + 21), a.err);
+        } else {
 #pragma unroll
         for (int v = 0; v <= NT1; ++v) a2a_push_row<XR>(a, xtab, net, hl, par, v < NT1 ? v : NT1 + 5, gx[v]);
         a2a_signal<XR>(a, xtab, net, lane, wave, par, 0, gtag);
@@ -1732,6 +1745,7 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
 #pragma unroll
           for (int v = 0; v <= NT1; ++v) rows[v] = v < NT1 ? v : NT1 + 5;
           a2a_pull_all<XR, NT1 + 1>(a, xtab, net, hl, par, rows, gx);
+        }
         }
 #pragma unroll
         for (int nt = 0; nt < NT1; ++nt) *reinterpret_cast<f4*>(lds + H::G1 + ((wave * NT1 + nt) * 64 + lane) * 4) = gx[nt];
@@ -1789,6 +1803,11 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
         }
       }
       const int rows7[7] = {NT1 + 0, NT1 + 1, NT1 + 2, NT1 + 3, NT1 + 4, NT1 + 7, NT1 + 6};
+      if constexpr (XRD) {
+        // slot rows NT1 + 1 .. NT1 + 7 (the log_std row travels from every wave: zeros except wave 0 of the actor)
+        xr_allreduce_rd<7, NT1 + 1, SPO_H_RD_VB>(xtab, a.xr_rank, XR, net, hl, gtag, gx,
+                                    reinterpret_cast<volatile float*>(lds + H::XW + 21), a.err);
+      } else {
 #pragma unroll
       for (int v = 0; v < 6; ++v) a2a_push_row<XR>(a, xtab, net, hl, par, rows7[v], gx[v]);
       if (with_ls) a2a_push_row<XR>(a, xtab, net, hl, par, rows7[6], gx[6]);
@@ -1808,6 +1827,7 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
           a2a_pull<XR, 1>(a, xtab, net, hl, par, rc, gc);
           gx[6] = gc[0];
         }
+      }
       }
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f4*>(lds + H::G2 + ((wave * 4 + nt) * 64 + lane) * 4) = gx[nt];
@@ -2276,7 +2296,7 @@ inline int update_form() {
   return v;
 }
 
-template <int K, bool PROF = false, int XR = 0>
+template <int K, bool PROF = false, int XR = 0, bool XRD = true>
 int launch_update_h(const UpdArgs& a_in, int blocks, hipStream_t st) {
   UpdArgs a = a_in;
   const int rslot = XR ? a.xr_rank : 0;
@@ -2297,12 +2317,12 @@ int launch_update_h(const UpdArgs& a_in, int blocks, hipStream_t st) {
   const size_t sh = UpdHLds<K>::SIZE * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_update_h_kernel<K, PROF, XR>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_update_h_kernel<K, PROF, XR, XRD>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return spo::hip_check(e, "hipFuncSetAttribute(update_h)");
     attr_done = true;
   }
-  hipLaunchKernelGGL((ppo_update_h_kernel<K, PROF, XR>), dim3(8 * (blocks - 1) + 1), dim3(512), sh, st, a);
+  hipLaunchKernelGGL((ppo_update_h_kernel<K, PROF, XR, XRD>), dim3(8 * (blocks - 1) + 1), dim3(512), sh, st, a);
   return 0;
 }
 
@@ -2558,13 +2578,19 @@ extern "C" int spo_ppo_lag_update_iter_dp(float* theta, float* adam_m, float* ad
   // 15.9 / 18.8 / 24.0 us per step at 2 / 4 / 8 ranks): a store acknowledgement plus a flag flight plus the row loads per
   // stage cost more than three tagged-word hand-offs there.  Kept for measurement on a real xGMI node.
   static const bool a2a = [] { const char* e = getenv("SPO_P2P_A2A"); return e && e[0] == '1'; }();
-  if (a2a && kin <= 64 && cfg_host->batch <= 64 && update_form() == 2 && a.xr_algo == 1 && (world == 2 || world == 4 || world == 8)) {
-    // main + helper form with the all-to-all exchange on the helper waves (one hand-off at any world size)
-#define SPO_H_XR(K) (world == 2 ? launch_update_h<K, false, 2>(a, 3, st) : world == 4 ? launch_update_h<K, false, 4>(a, 3, st) \
-                                                                                         : launch_update_h<K, false, 8>(a, 3, st))
-    if (kin == 16) rc = SPO_H_XR(16);
-    else if (kin == 32) rc = SPO_H_XR(32);
-    else rc = SPO_H_XR(64);
+  // SPO_P2P_HELPER=1 (opt-in): the main + helper kernel with recursive doubling ON THE HELPER WAVES -- layer 1 exchanged
+  // while the main waves still compute dW2 / dW3, layers 2 / 3 while they settle the next minibatch and run layer 1.
+  // Measured in loopback: 18.9 / 27.2 / 33.9 us per step at 2 / 4 / 8 ranks against 15.8 / 19.2 / 24.2 for the default
+  // below (four-wave kernel, ONE exchange of the whole gradient per step): two exchanges per step are twice the
+  // hand-off rounds, and the overlap does not pay for them.
+  static const bool helper_xr = [] { const char* e = getenv("SPO_P2P_HELPER"); return e && e[0] == '1'; }();
+  a.xr_helper_rd = a2a ? 0 : 1;
+  if ((a2a || helper_xr) && kin <= 64 && cfg_host->batch <= 64 && update_form() == 2 && a.xr_algo == 1 && (world == 2 || world == 4 || world == 8)) {
+    // main + helper form, exchange on the helper waves
+#define SPO_H_XR(K, D) (world == 2 ? launch_update_h<K, false, 2, D>(a, 3, st) : world == 4 ? launch_update_h<K, false, 4, D>(a, 3, st) \
+                                                                                               : launch_update_h<K, false, 8, D>(a, 3, st))
+    if (a2a) rc = kin == 16 ? SPO_H_XR(16, false) : kin == 32 ? SPO_H_XR(32, false) : SPO_H_XR(64, false);
+    else rc = kin == 16 ? SPO_H_XR(16, true) : kin == 32 ? SPO_H_XR(32, true) : SPO_H_XR(64, true);
 #undef SPO_H_XR
   } else if (a.xr_algo == 1 && (world & (world - 1)) == 0) rc = launch_update<true, 0, 2>(a, 3, st);
   else rc = launch_update<true, 0, 1>(a, 3, st);
@@ -2597,7 +2623,18 @@ extern "C" int spo_critic_fit_iter_dp(float* theta, float* adam_m, float* adam_v
   a.pow_b1_actor = a.pow_b1; a.pow_b2_actor = a.pow_b2;
   a.first_net = 0; a.n_nets = 2; a.stale_sq = 0.f; a.stale_io = stale_sq_io;
   int rc = 0;
-  if (a.xr_algo == 1 && (world & (world - 1)) == 0) rc = launch_update<true, 0, 2>(a, 2, st);
+  const int kin = pick_kin(cfg_host->obs_dim);
+  static const bool helper_xr = [] { const char* e = getenv("SPO_P2P_HELPER"); return e && e[0] == '1'; }();   // opt-in, see above
+  a.xr_helper_rd = 1;
+  if (helper_xr && kin <= 64 && cfg_host->batch <= 64 && update_form() == 2 && a.xr_algo == 1 && (world == 2 || world == 4 || world == 8)) {
+    // main + helper form with recursive doubling on the helper waves (see spo_ppo_lag_update_iter_dp)
+#define SPO_H_XR(K) (world == 2 ? launch_update_h<K, false, 2>(a, 2, st) : world == 4 ? launch_update_h<K, false, 4>(a, 2, st) \
+                                                                                         : launch_update_h<K, false, 8>(a, 2, st))
+    if (kin == 16) rc = SPO_H_XR(16);
+    else if (kin == 32) rc = SPO_H_XR(32);
+    else rc = SPO_H_XR(64);
+#undef SPO_H_XR
+  } else if (a.xr_algo == 1 && (world & (world - 1)) == 0) rc = launch_update<true, 0, 2>(a, 2, st);
   else rc = launch_update<true, 0, 1>(a, 2, st);
   if (rc) return rc;
   SPO_LAUNCH_CHECK("spo_critic_fit_iter_dp");
