@@ -1434,7 +1434,7 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
       for (int nt = 0; nt < NT1; ++nt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) lds[U::XT + (16 * nt + 4 * q + e) * LDB + mycol] = cur.x[nt][e];
-        }
+    }
     SPO_STAMP(0)
     bool redone = false, late_redone = false;
     for (;;) {
@@ -1454,137 +1454,137 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
       SPO_STAMP(4)
       const int redo_tag = xw_ro[18];
       if (redo_tag == (int)(s & 0x3fffffff) + 1 && !redone) { redone = true; continue; }   // clipped: W1, W2 were redone
-    {
-      // ---- rest of the step of the main waves: prefetch, L3, loss, backward, staging
-      SPO_REIDX
-      SPO_SUB(-1)
-      if (s + 1 < nsteps) fetch((int64_t)smp_next, nxt);
-      if (s + 2 < nsteps) smp1 = a.perm[pos2];
-      const f4 o = layer_out(lds + L::W3, lds + L::B3, h2, j, q);
-      SPO_SUB(0)
-      const bool cv = mycol < ncols;
-      float ivar[4], lsd[4], amask[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ai = 4 * q + r;
-        const bool on = is_actor && ai < A;
-        const float lsv = on ? red[128 + ai] : 0.f;
-        const float sdv = __expf(lsv);
-        amask[r] = on ? 1.f : 0.f;
-        ivar[r] = __builtin_amdgcn_rcpf(sdv * sdv);
-        lsd[r] = on ? lsv + LOG_SQRT_2PI : 0.f;
-      }
-      f4 dO = {0.f, 0.f, 0.f, 0.f}, dls = {0.f, 0.f, 0.f, 0.f};
-      float lsum = 0.f;
-      if (!is_actor) {
-        const float diff = o[0] - cur.t0;
-        const float lm = (q == 0 && cv) ? 1.f : 0.f;
-        lsum = lm * diff * diff;
-        dO[0] = lm * (2.f * diff * inv_n);
-      } else {
-        float lp = 0.f, dif[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          dif[r] = cur.actv[r] - o[r];
-          lp += -(dif[r] * dif[r]) * (0.5f * ivar[r]) - lsd[r];
-        }
-        lp = quad_row_sum(lp);
-        const float adv = cur.t1;
-        const float ratio = __expf(lp - cur.t0);
-        const float rc = fminf(fmaxf(ratio, clip_lo), clip_hi);
-        const float s1 = ratio * adv, s2 = rc * adv;
-        const bool inr = (ratio >= clip_lo) && (ratio <= clip_hi);
-        float gr;
-        if (s1 < s2) gr = adv;
-        else if (s1 > s2) gr = inr ? adv : 0.f;
-        else gr = 0.5f * adv + (inr ? 0.5f * adv : 0.f);
-        const float dlp = cv ? -(gr * ratio) * inv_n : 0.f;
-        lsum = ((q == 0 && cv) ? 1.f : 0.f) * fminf(s1, s2);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float z = dif[r] * ivar[r];
-          dO[r] = dlp * z;
-          dls[r] = (dlp * amask[r]) * (dif[r] * z - 1.f);
-        }
-      }
-      SPO_SUB(1)
-      // backward through the MLP (as in ppo_update_kernel)
-      f4 dz2[4], dz1[4];
       {
-        f4 acc[4];
-        float w3c[4][4];
+        // ---- rest of the step of the main waves: prefetch, L3, loss, backward, staging
+        SPO_REIDX
+        SPO_SUB(-1)
+        if (s + 1 < nsteps) fetch((int64_t)smp_next, nxt);
+        if (s + 2 < nsteps) smp1 = a.perm[pos2];
+        const f4 o = layer_out(lds + L::W3, lds + L::B3, h2, j, q);
+        SPO_SUB(0)
+        const bool cv = mycol < ncols;
+        float ivar[4], lsd[4], amask[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r) {
+          const int ai = 4 * q + r;
+          const bool on = is_actor && ai < A;
+          const float lsv = on ? red[128 + ai] : 0.f;
+          const float sdv = __expf(lsv);
+          amask[r] = on ? 1.f : 0.f;
+          ivar[r] = __builtin_amdgcn_rcpf(sdv * sdv);
+          lsd[r] = on ? lsv + LOG_SQRT_2PI : 0.f;
+        }
+        f4 dO = {0.f, 0.f, 0.f, 0.f}, dls = {0.f, 0.f, 0.f, 0.f};
+        float lsum = 0.f;
+        if (!is_actor) {
+          const float diff = o[0] - cur.t0;
+          const float lm = (q == 0 && cv) ? 1.f : 0.f;
+          lsum = lm * diff * diff;
+          dO[0] = lm * (2.f * diff * inv_n);
+        } else {
+          float lp = 0.f, dif[4];
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt) w3c[r][mt] = lds[L::W3 + (4 * q + r) * LDH + 16 * mt + j];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[mt] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma4(w3c[r][mt], dO[r], acc[mt]);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) dz2[mt][r] = acc[mt][r] * fmaf(-h2[mt][r], h2[mt][r], 1.f);
-        SPO_SUB(2)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[mt] = f4{0.f, 0.f, 0.f, 0.f};
-        float w2c[2][4][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt) w2c[0][r][mt] = lds[L::W2 + (4 * q + r) * LDH + 16 * mt + j];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          if (nt + 1 < 4) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-              for (int mt = 0; mt < 4; ++mt)
-                w2c[(nt + 1) & 1][r][mt] = lds[L::W2 + (16 * (nt + 1) + 4 * q + r) * LDH + 16 * mt + j];
+          for (int r = 0; r < 4; ++r) {
+            dif[r] = cur.actv[r] - o[r];
+            lp += -(dif[r] * dif[r]) * (0.5f * ivar[r]) - lsd[r];
           }
+          lp = quad_row_sum(lp);
+          const float adv = cur.t1;
+          const float ratio = __expf(lp - cur.t0);
+          const float rc = fminf(fmaxf(ratio, clip_lo), clip_hi);
+          const float s1 = ratio * adv, s2 = rc * adv;
+          const bool inr = (ratio >= clip_lo) && (ratio <= clip_hi);
+          float gr;
+          if (s1 < s2) gr = adv;
+          else if (s1 > s2) gr = inr ? adv : 0.f;
+          else gr = 0.5f * adv + (inr ? 0.5f * adv : 0.f);
+          const float dlp = cv ? -(gr * ratio) * inv_n : 0.f;
+          lsum = ((q == 0 && cv) ? 1.f : 0.f) * fminf(s1, s2);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float z = dif[r] * ivar[r];
+            dO[r] = dlp * z;
+            dls[r] = (dlp * amask[r]) * (dif[r] * z - 1.f);
+          }
+        }
+        SPO_SUB(1)
+        // backward through the MLP (as in ppo_update_kernel)
+        f4 dz2[4], dz1[4];
+        {
+          f4 acc[4];
+          float w3c[4][4];
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma4(w2c[nt & 1][r][mt], dz2[nt][r], acc[mt]);
+            for (int mt = 0; mt < 4; ++mt) w3c[r][mt] = lds[L::W3 + (4 * q + r) * LDH + 16 * mt + j];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) acc[mt] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma4(w3c[r][mt], dO[r], acc[mt]);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dz2[mt][r] = acc[mt][r] * fmaf(-h2[mt][r], h2[mt][r], 1.f);
+          SPO_SUB(2)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) acc[mt] = f4{0.f, 0.f, 0.f, 0.f};
+          float w2c[2][4][4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) w2c[0][r][mt] = lds[L::W2 + (4 * q + r) * LDH + 16 * mt + j];
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            if (nt + 1 < 4) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                  w2c[(nt + 1) & 1][r][mt] = lds[L::W2 + (16 * (nt + 1) + 4 * q + r) * LDH + 16 * mt + j];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma4(w2c[nt & 1][r][mt], dz2[nt][r], acc[mt]);
+          }
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dz1[mt][r] = acc[mt][r] * fmaf(-h1[mt][r], h1[mt][r], 1.f);
         }
+        SPO_SUB(3)
+        SPO_REIDX
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dz1[mt][r] = acc[mt][r] * fmaf(-h1[mt][r], h1[mt][r], 1.f);
-      }
-      SPO_SUB(3)
-      SPO_REIDX
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int f = (16 * mt + 4 * q + r) * LDB + mycol;
-          lds[U::H1T + f] = h1[mt][r];
-          lds[U::H2T + f] = h2[mt][r];
-          lds[U::DZ1T + f] = dz1[mt][r];
-          lds[U::DZ2T + f] = dz2[mt][r];
-        }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) lds[U::DOT + (4 * q + r) * LDB + mycol] = dO[r];
-      SPO_SUB(4)
-      {
-        const float ls = wave_sum_lane63(lsum);
-        if (lane == 63) red[wave] = ls;
-        if (is_actor) {
-#pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float t = row_sum_lane15(dls[r]);
-            if (j == 15) red[16 + wave * 16 + 4 * q + r] = t;
+            const int f = (16 * mt + 4 * q + r) * LDB + mycol;
+            lds[U::H1T + f] = h1[mt][r];
+            lds[U::H2T + f] = h2[mt][r];
+            lds[U::DZ1T + f] = dz1[mt][r];
+            lds[U::DZ2T + f] = dz2[mt][r];
+          }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds[U::DOT + (4 * q + r) * LDB + mycol] = dO[r];
+        SPO_SUB(4)
+        {
+          const float ls = wave_sum_lane63(lsum);
+          if (lane == 63) red[wave] = ls;
+          if (is_actor) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float t = row_sum_lane15(dls[r]);
+              if (j == 15) red[16 + wave * 16 + 4 * q + r] = t;
+            }
           }
         }
+        SPO_SUB(5)
       }
-      SPO_SUB(5)
-        }
-    SPO_STAMP(5)
-    __syncthreads();                                                      // B_stage: all [feature][batch] images complete
-    SPO_STAMP(6)
+      SPO_STAMP(5)
+      __syncthreads();                                                    // B_stage: all [feature][batch] images complete
+      SPO_STAMP(6)
       // Deferred validation: the helpers updated ALL layers with clip coefficient 1 and found, while this forward /
       // backward ran, that the previous step's joint norm exceeds the bound.  They have restored and redone the update
       // exactly before this barrier; the step is repeated from layer 1 on the exact weights (x from its LDS image).
@@ -1630,7 +1630,7 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
 #pragma unroll
       for (int nt = 0; nt < NT1; ++nt) *reinterpret_cast<f4*>(lds + H::G1 + ((wave * NT1 + nt) * 64 + lane) * 4) = aW1[nt];
       lds[H::GB + 0 * 256 + wave * 64 + lane] = quad_row_sum(rs1);
-        }
+    }
     SPO_STAMP(7)
     __syncthreads();                                                      // P1: G1 complete; x^T and dZ1^T are dead
     SPO_STAMP(8)
