@@ -1441,6 +1441,12 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
       {
         SPO_REIDX
         layer_hidden<NT1, true>(lds + L::W1, L::LD1, lds + L::B1, cur.x, h1, j, q);
+        // h1^T goes to its LDS image right away: the stores drain beside layer 2's MFMAs instead of queueing with the other
+        // three images at the end of the backward pass (the LDS store path moves 64 B/clk for the whole CU)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lds[U::H1T + (16 * mt + 4 * q + r) * LDB + mycol] = h1[mt][r];
       }
       SPO_STAMP(1)
       __syncthreads();                                                    // Q2: (speculative) W2 / b2 in place
@@ -1448,6 +1454,10 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
       {
         SPO_REIDX
         layer_hidden<4, true>(lds + L::W2, LDH, lds + L::B2, h1, h2, j, q);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lds[U::H2T + (16 * mt + 4 * q + r) * LDB + mycol] = h2[mt][r];
       }
       SPO_STAMP(3)
       __syncthreads();                                                    // Xd: W3 / b3 / log_std in place, clip verdict known
@@ -1527,6 +1537,13 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
           for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) dz2[mt][r] = acc[mt][r] * fmaf(-h2[mt][r], h2[mt][r], 1.f);
+          // dZ2^T and dO^T are staged now: their stores drain beside the 64 MFMAs of the next product
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lds[U::DZ2T + (16 * mt + 4 * q + r) * LDB + mycol] = dz2[mt][r];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lds[U::DOT + (4 * q + r) * LDB + mycol] = dO[r];
           SPO_SUB(2)
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) acc[mt] = f4{0.f, 0.f, 0.f, 0.f};
@@ -1559,15 +1576,7 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int f = (16 * mt + 4 * q + r) * LDB + mycol;
-            lds[U::H1T + f] = h1[mt][r];
-            lds[U::H2T + f] = h2[mt][r];
-            lds[U::DZ1T + f] = dz1[mt][r];
-            lds[U::DZ2T + f] = dz2[mt][r];
-          }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) lds[U::DOT + (4 * q + r) * LDB + mycol] = dO[r];
+          for (int r = 0; r < 4; ++r) lds[U::DZ1T + (16 * mt + 4 * q + r) * LDB + mycol] = dz1[mt][r];
         SPO_SUB(4)
         {
           const float ls = wave_sum_lane63(lsum);
