@@ -266,14 +266,26 @@ def main():
                 "graph_frac": round(gae_bytes / float(graph.mean()) / 1e9 / HBM_PEAK_GBS, 4) if graph.size else None,
                 "residency": f"{gae_bytes / 1e6:.1f} MB per launch: Infinity-Cache resident (256 MiB), re-read by every timed "
                              "launch -- NOT an HBM-streaming figure; see roofline_hbm_streaming for the HBM claim",
-                "note": "achieved = algorithmic bytes / MEAN per-dispatch duration: every dispatch carries its own start/stop HIP "
-                        "events on the launch stream (hipExtLaunchKernelGGL: the dispatch packet's own timestamps, the "
-                        "figure rocprofv3 --kernel-trace reports), inside the timed region. Under rocprofv3 itself dispatches "
-                        "run ~8 % slower (the profiler serialises the queue): profiles/r02 holds the trace of this command "
-                        "TOGETHER with the line printed by that profiled run, whose frac matches the trace. graph_* = hipGraph of "
+                "note": "achieved = algorithmic bytes / MEAN per-dispatch duration over the timed epochs (200 untimed dispatches first: "
+                        "power-management transient after a light-load phase, DESIGN.md 3.1): every dispatch carries its own "
+                        "start/stop HIP events on the launch stream (hipExtLaunchKernelGGL: the dispatch packet's timestamps). "
+                        "rocprof_* = the committed rocprofv3 --kernel-trace of this same command (profiles/r02/"
+                        "gae_dispatch_durations.json, same kernel and grid): the profiler's own per-dispatch average is ~8 % "
+                        "higher than the unprofiled event pairs, and under the profiler the event pairs themselves read ~2x "
+                        "(profiles/r02/bench_profiled_line.json), so the two figures cannot come from one run. graph_* = hipGraph of "
                         f"{GAE_REPS} back-to-back launches between two events (dispatch set-up overlapped). traffic: PMC "
                         "counters cannot be read inside this run -> null; traffic_profiled is the committed rocprofv3 "
                         "--pmc measurement (FETCH_SIZE x2 + WRITE_SIZE, separate passes) with its source"}
+    try:
+        dj = json.load(open(os.path.join(ROOT, "profiles", "r02", "gae_dispatch_durations.json")))
+        want = f"grid={2 * N * 32}"
+        hit = [v for k, v in dj["per_kernel_and_grid_size"].items() if k.endswith(want)] if (T == 128 and folded) else []
+        if hit:
+            roofline["rocprof_avg_launch_us"] = hit[0]["avg_us"]
+            roofline["rocprof_launches"] = hit[0]["launches"]
+            roofline["frac_at_rocprof_avg"] = round(gae_bytes / (hit[0]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+    except Exception:
+        pass
 
     # extra roofline points (untimed, after the run): 32 768 envs (138 MB) and a buffer that cannot sit in
     # the 256 MiB Infinity Cache
