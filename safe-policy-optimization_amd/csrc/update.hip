@@ -27,10 +27,10 @@ using namespace spo;
 #ifndef SPO_SPECULATIVE_ADAM
 #define SPO_SPECULATIVE_ADAM 1
 #endif
-#ifndef SPO_HELPER_PRIO
 #ifndef SPO_H_RD_VB
 #define SPO_H_RD_VB 4          // rows polled together by the helper waves' recursive doubling (register budget: A/B knob)
 #endif
+#ifndef SPO_HELPER_PRIO
 #define SPO_HELPER_PRIO 2      // s_setprio of the helper waves of ppo_update_h_kernel (A/B knob)
 #endif
 constexpr int LDB = 64 + 4;     // [feature][batch] LDS row stride (floats)
