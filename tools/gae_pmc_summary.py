@@ -23,11 +23,11 @@ def per_kernel(path, counter):
 f, w = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on tools/gae_modes.py",
        "corrections": "KiB -> bytes (x1024); FETCH_SIZE x2 (gfx950 wide-coalesced-read undercount); WRITE_SIZE x1",
-       "template_args": "gae_kernel<VEC, LPR, BOOT, RC>: BOOT 0 = bootstrap arrays (predicated loads), 2 = folded; RC = reward/cost in "
+       "template_args": "gae_kernel<VEC, LPR, BOOT, RC, F>: BOOT 0 = bootstrap arrays (predicated loads), 2 = folded; RC = reward/cost in "
                         "separate lane groups (cache-resident sizes)",
        "launches": []}
 for (targs, grid) in sorted(f):
-    rc = targs.replace(" ", "").endswith("true")
+    rc = targs.replace(" ", "").split(",")[3] == "true"       # <VEC, LPR, BOOT, RC[, F]>
     folded = targs.replace(" ", "").split(",")[2] == "2"
     n_envs = grid // 64 if rc else grid // 32          # 256 threads per block; 4 rows per block with RC, 8 without (T = 128)
     algo = 33.0 * n_envs * 128 + (0.0 if folded else 8.0 * 2 * n_envs)
