@@ -27,6 +27,9 @@ using namespace spo;
 #ifndef SPO_SPECULATIVE_ADAM
 #define SPO_SPECULATIVE_ADAM 1
 #endif
+#ifndef SPO_XR_SCOPE
+#define SPO_XR_SCOPE __HIP_MEMORY_SCOPE_SYSTEM     // scope of the tagged-word exchange accesses (A/B knob: ranks on ONE GPU)
+#endif
 #ifndef SPO_H_RD_VB
 #define SPO_H_RD_VB 4          // rows polled together by the helper waves' recursive doubling (register budget: A/B knob)
 #endif
@@ -189,13 +192,13 @@ __device__ __forceinline__ void st_ll(gu64* elem, const f4 v, unsigned tag) {
 #pragma unroll
   for (int k = 0; k < 4; ++k)
     __hip_atomic_store(elem + (k - 2) * 256, ((u64)tag << 32) | __float_as_uint(v[k]), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_SYSTEM);                          // global_store_dwordx2 sc0 sc1
+                       SPO_XR_SCOPE);                                       // global_store_dwordx2 sc0 sc1
 }
 __device__ __forceinline__ bool ld_ll(gu64* elem, unsigned tag, f4& v) {
   u64 w[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k)
-    w[k] = __hip_atomic_load(elem + (k - 2) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    w[k] = __hip_atomic_load(elem + (k - 2) * 256, __ATOMIC_RELAXED, SPO_XR_SCOPE);
   bool ok = true;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
