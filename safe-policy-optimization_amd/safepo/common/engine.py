@@ -13,6 +13,7 @@ event log and replayed on the host once per epoch, in the reference's (step, env
 """
 from __future__ import annotations
 
+import os
 from collections import deque
 
 import numpy as np
@@ -170,6 +171,15 @@ class PPOLagEngine:
         c = self.cfg
         M = self.M
         batch = c.get("batch_size", max(M // c.get("num_mini_batch", 1), 1))
+        # data-parallel batch semantics (SURVEY.md 8(e) "Partitioning"): "local" (default) = every rank takes batch_size rows
+        # of its shard per step (global batch = batch_size x world: weak scaling, a different optimisation trajectory);
+        # "global" = batch_size is the GLOBAL minibatch and every rank takes batch_size / world rows -- the reference's
+        # arithmetic up to the order of the sums (cfg key dp_batch or SPO_DP_BATCH)
+        if self.comm.world_size > 1 and str(c.get("dp_batch", os.environ.get("SPO_DP_BATCH", "local"))) == "global":
+            if batch % self.comm.world_size:
+                raise _abi.SpoError(f"dp_batch=global needs batch_size ({batch}) divisible by the world size "
+                                    f"({self.comm.world_size})")
+            batch //= self.comm.world_size
         return _abi.PpoCfg(obs_dim=self.D, act_dim=self.A, batch=int(batch),
                            use_critic_norm=int(c.get("use_critic_norm", True)),
                            use_value_coefficient=int(c.get("use_value_coefficient", False)),

@@ -1,0 +1,89 @@
+"""Worker of tests/test_gpu_parity.py::test_data_parallel_global_batch_equals_reference_minibatches (not a test module).
+
+Two ranks on ONE GPU (gloo for the host collectives), cfg dp_batch="global": every rank takes batch_size / world = 32 rows
+of its own shard per step, the gradient mean over the ranks is the gradient of the reference's 64-row minibatch
+(SURVEY.md 8(e) "Partitioning": exact reference semantics, reduction order aside).  Rank 0 replays the same global
+minibatches through the CPU oracle (oracle/restatement.PPOLagUpdater: torch autograd + clip_grad_norm_ + Adam as
+ppo_lag.py:297-336) and writes the comparison as JSON."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "safe-policy-optimization_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def shard(rank: int, M: int, D: int, A: int):
+    g = torch.Generator().manual_seed(4321 + rank)
+    obs, act = torch.randn(M, D, generator=g), torch.randn(M, A, generator=g)
+    logp = -A * 0.9 - 0.5 * (act ** 2).sum(-1) + 0.1 * torch.randn(M, generator=g)
+    tgt_r, tgt_c, adv = torch.randn(M, generator=g), torch.rand(M, generator=g), torch.randn(M, generator=g)
+    perm = torch.randperm(M, generator=g)
+    return obs, act, logp, tgt_r, tgt_c, adv, perm
+
+
+def main(out_path: str, use_p2p: str):
+    from safepo import parallel as P
+    from safepo.common.engine import PPOLagEngine
+    from safepo.common.model import ActorVCritic
+    comm = P.init_from_env(backend="gloo")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    rank, world = comm.rank, comm.world_size
+    M, D, A, GB = 512, 60, 8, 64                       # rows per rank; GLOBAL minibatch of 64 = 32 per rank
+    cfg = {"hidden_sizes": [64, 64], "gamma": 0.99, "target_kl": 1e9, "batch_size": GB, "learning_iters": 1,
+           "max_grad_norm": 40.0, "dp_batch": "global"}
+    os.environ["SPO_P2P"] = use_p2p
+    obs, act, logp, tgt_r, tgt_c, adv, perm = shard(rank, M, D, A)
+    torch.manual_seed(7)
+    pol = ActorVCritic(D, A).to(dev)
+    state0 = {k: v.detach().cpu().clone() for k, v in pol.state_dict().items()}
+    eng = PPOLagEngine(pol, 1, M, cfg, dev, comm=comm)
+    assert eng._cfg_struct().batch == GB // world
+    b = eng.buffer
+    b.data["obs"].copy_(obs.view(1, M, D)); b.data["act"].copy_(act.view(1, M, A))
+    b.data["log_prob"].copy_(logp.view(1, M)); b.data["target_value_r"].copy_(tgt_r.view(1, M))
+    b.data["target_value_c"].copy_(tgt_c.view(1, M)); b.adv_mix.copy_(adv.view(1, M))
+    losses = eng.learning_iter(perm.to(torch.int32).to(dev))
+    eng.check_sync_error()
+    theta = pol.theta.detach().cpu()
+    gathered = [torch.empty_like(theta) for _ in range(world)]
+    dist.all_gather(gathered, theta)
+    res = {"world": world, "in_kernel_exchange": eng.p2p is not None, "local_batch": GB // world,
+           "replicas_identical": all(torch.equal(gathered[0], x) for x in gathered[1:])}
+    if rank == 0:
+        from oracle import restatement as R          # checker only
+        ref = R.OraclePolicy(D, A)
+        ref.load_state_dict(state0)
+        th0 = R.flat_params(ref).numpy().copy()
+        upd = R.PPOLagUpdater(ref, epochs=1, max_grad_norm=cfg["max_grad_norm"])
+        shards = [shard(r, M, D, A) for r in range(world)]
+        lb = GB // world
+        ref_losses = []
+        for s in range(M // lb):
+            parts = [[t[sh[6][s * lb:(s + 1) * lb]] for t in sh[:6]] for sh in shards]
+            cat = [torch.cat([p[i] for p in parts], 0) for i in range(6)]
+            ref_losses.append(upd.minibatch_step(*cat))
+        th_ref = R.flat_params(ref).numpy()
+        got = theta.numpy()
+        res["steps"] = M // lb
+        res["loss_max_rel_diff"] = float(np.max(np.abs(losses.cpu().numpy() - np.asarray(ref_losses)) /
+                                                (np.abs(np.asarray(ref_losses)) + 1e-6)))
+        d = np.abs(got - th_ref)
+        res["theta_max_abs_diff"] = float(d.max())
+        res["theta_frac_outside"] = float(np.mean(d > 2e-6 + 3e-4 * np.abs(th_ref)))
+        res["theta_moved"] = float(np.abs(th_ref - th0).max())
+        with open(out_path, "w") as f:
+            json.dump(res, f)
+    comm.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "1")
