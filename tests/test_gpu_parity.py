@@ -647,6 +647,55 @@ def test_cpo_surrogate_gradients_vs_oracle(dev):
     assert lc_ == pytest.approx(float(R.cpo_surrogate(ref, data, "c")), rel=1e-5)
 
 
+@pytest.mark.parametrize("ep_costs", [-1.0, 0.3])
+def test_cpo_actor_step_drift_envelope(dev, ep_costs):
+    """The trust-region step (two surrogate gradients, 2 x 15 CG iterations on Fisher-vector products, case analysis, line
+    search: cpo.py:350-532) amplifies rounding through the CG recurrences, which is why the trace replays above compare at
+    5e-3.  Here the deviation is SHOWN to be rounding: the oracle takes the same step in float64 (yardstick) and in float32
+    (the reference's arithmetic), and the HIP step may be at most 3x as far from the float64 one as the float32 oracle is
+    (+ a floor of 1e-7 of the scale) -- for the curvature x^T H x, the step length alpha, the step norm and the actor
+    parameters after the step; the discrete decisions (case, accepted line-search step) must coincide."""
+    import copy
+    from safepo.single_agent.cpo import CPOEngine, default_cfg
+    from safepo.common.model import ActorVCritic
+    torch.manual_seed(14)
+    M, D, A = 4096, 60, 8
+    pol = ActorVCritic(D, A).to(dev)
+    with torch.no_grad():
+        pol.actor.log_std.copy_(torch.randn(A) * 0.2)
+    eng = CPOEngine(pol, 1, M, dict(default_cfg), dev)
+    obs, act, logp, _, _, adv = _synthetic_update_problem(M, D, A, seed=21)
+    adv_c = adv.flip(0) * 0.5 + 0.1
+    b = eng.buffer
+    b.data["obs"].copy_(obs.view(1, M, D)); b.data["act"].copy_(act.view(1, M, A)); b.data["log_prob"].copy_(logp.view(1, M))
+    b.data["adv_r"].copy_(adv.view(1, M)); b.data["adv_c"].copy_(adv_c.view(1, M))
+    ref32 = R.OraclePolicy(D, A)
+    ref32.load_state_dict({k: v.cpu().clone() for k, v in pol.state_dict().items()})
+    ref64 = copy.deepcopy(ref32).double()
+    data32 = {"obs": obs, "act": act, "log_prob": logp, "adv_r": adv, "adv_c": adv_c}
+    data64 = {k: v.double() for k, v in data32.items()}
+    o32 = R.cpo_policy_update(ref32, data32, ep_costs, target_kl=default_cfg["target_kl"])
+    o64 = R.cpo_policy_update(ref64, data64, ep_costs, target_kl=default_cfg["target_kl"])
+    th32 = R.actor_flat_params(ref32.actor).double().numpy()
+    th64 = R.actor_flat_params(ref64.actor).double().numpy()
+    out = eng.policy_update(ep_costs)
+    th_hip = eng.theta_actor.double().cpu().numpy()
+    assert out["case"] == o32["case"] == o64["case"]
+    assert out["acceptance_step"] == o32["accept"] == o64["accept"] and out["acceptance_step"] >= 1
+    for name, hip, v32, v64 in (("xHx", out["xHx"], float(o32["xHx"]), float(o64["xHx"])),
+                                ("alpha", out["alpha"], float(o32["alpha"]), float(o64["alpha"])),
+                                ("final_step_norm", out["final_step_norm"], float((o32["step_frac"] * o32["step_direction"]).norm()),
+                                 float((o64["step_frac"] * o64["step_direction"]).norm()))):
+        d_hip, d_32 = abs(hip - v64), abs(v32 - v64)
+        assert d_hip <= 3.0 * d_32 + 1e-6 * abs(v64), (name, hip, v32, v64)
+    d_hip, d_32 = np.abs(th_hip - th64), np.abs(th32 - th64)
+    scale = np.abs(th64).max()
+    assert np.linalg.norm(d_hip) <= 3.0 * np.linalg.norm(d_32) + 1e-7 * scale * np.sqrt(th64.size), (np.linalg.norm(d_hip), np.linalg.norm(d_32))
+    assert d_hip.max() <= 3.0 * d_32.max() + 1e-6 * scale, (d_hip.max(), d_32.max())
+    print(f"cpo step envelope (ep_costs {ep_costs}): case {out['case']}, |hip-f64| {np.linalg.norm(d_hip):.3e} vs |f32-f64| "
+          f"{np.linalg.norm(d_32):.3e}; xHx hip {out['xHx']:.9g} f32 {float(o32['xHx']):.9g} f64 {float(o64['xHx']):.9g}")
+
+
 def test_cpo_update_vs_reference_main_trace(dev, golden_dir):
     """Replays the reference cpo.main(): CG, case analysis (incl. an infeasible-recovery epoch), line search,
     actor parameters after the step, critic fit with the recorded shuffles."""
