@@ -1261,11 +1261,22 @@ def test_end_to_end_learning_on_action_dependent_env(dev):
     assert costs[-1] < costs[0]                                    # and the cost (|a_0| > 0.5 rate) comes down
 
 
-def test_long_trajectory_parity_1024_steps(dev):
+@pytest.mark.parametrize("form", ["main_plus_helper_waves", "four_wave_form"])
+def test_long_trajectory_parity_1024_steps(dev, form):
     """1 024 consecutive optimiser steps (one pass over 65 536 samples) against the CPU oracle with the drift envelope:
     per-minibatch losses along the whole trajectory and the parameters after 8 / 64 / 512 / 1 024 steps stay within
     3x the fp32 reference arithmetic's own distance from the float64 trajectory (SURVEY.md 8d: k = 1, 8, 8192 steps;
-    the 8 192-step case is test_full_size_update_parity_drift_envelope)."""
+    the 8 192-step case is test_full_size_update_parity_drift_envelope).  Both forms of the persistent kernel: the
+    four-wave form still serves the critic fit of the second-order scripts, the KL-penalty losses, obs_dim > 64 and the
+    data-parallel launches (SPO_UPDATE_FORM is read once per process, so that form runs in a child process)."""
+    if form == "four_wave_form":
+        import subprocess, sys
+        env = dict(os.environ, SPO_UPDATE_FORM="0")
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__, "-k",
+                            "test_long_trajectory_parity_1024_steps and main_plus_helper_waves"], env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return
     from safepo.common.engine import PPOLagEngine
     from safepo.common.model import ActorVCritic
     M, D, A = 65536, 60, 8
