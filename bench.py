@@ -112,7 +112,12 @@ def run_epochs(algo, a, comm, dev, N, T, D, A, steps, warmup, time_gae):
         cfg = {"hidden_sizes": [64, 64], "gamma": 0.99, "target_kl": float("inf"), "batch_size": 64,
                "learning_iters": a.learning_iters, "max_grad_norm": 40.0}
         eng = PPOLagEngine(policy, N, T, cfg, dev, comm=comm)
-    env = SynthDeviceEnv(N, D, A, seed=1234 + comm.rank, p_term=0.0, p_cost=0.1, trunc_len=64, device=dev)
+    # a-2 inside the timed region: the env hands out RAW observations and the collect step normalises them as it loads them
+    # (running mean / variance merged per step, spo_policy_step_norm) -- what SafeNormalizeObservation does in the
+    # reference's env stack (wrappers.py:42-49).  The CPU baselines run without the wrapper (gymnasium is not installed).
+    env = SynthDeviceEnv(N, D, A, seed=1234 + comm.rank, p_term=0.0, p_cost=0.1, trunc_len=64, device=dev,
+                         normalize_obs=not a.no_normalize_obs)
+    rms = env.fuse_normalize(True)
     obs, _ = env.reset()
     lam = 0.001
     gae_graph, gae_disp = [], []
@@ -121,9 +126,9 @@ def run_epochs(algo, a, comm, dev, N, T, D, A, steps, warmup, time_gae):
         nonlocal obs
         t0 = time.time()
         for t in range(T):
-            act = eng.collect_step(t, obs)
+            act = eng.collect_step(t, obs, rms=rms)
             nobs, rew, cost, term, trunc, info = env.step(act)
-            eng.post_step(t, nobs, rew, cost, term, trunc, info["final_observation"])
+            eng.post_step(t, nobs, rew, cost, term, trunc, info["final_observation"], rms=rms)
             obs = nobs
         n_ep = eng.drain_episode_events(None)
         torch.cuda.synchronize(dev)
@@ -204,6 +209,7 @@ def main():
     ap.add_argument("--cpu-sample-envs", type=int, default=512)   # ~80 s of CPU work on the GPU box host (12.5 % of the workload)
     ap.add_argument("--cpo-cpu-sample-envs", type=int, default=256)
     ap.add_argument("--no-config3", action="store_true", help="skip the CPO (BASELINE config 3) section")
+    ap.add_argument("--no-normalize-obs", action="store_true", help="rollout without the fused observation normaliser (a-2)")
     ap.add_argument("--cpo-steps", type=int, default=3)
     ap.add_argument("--stream-envs", type=int, default=262144, help="extra GAE roofline point that streams from HBM")
     ap.add_argument("--algo", choices=["ppo_lag", "cpo"], default="ppo_lag",
@@ -364,7 +370,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": (f"ppo_lag synthetic env (obs=60, act=8), num_envs={N} per GPU, num_steps={T}, "
                                 f"default_cfg batch 64 x {a.learning_iters} learning iters (target_kl=inf: all iters run), "
-                                f"device-resident env") if a.algo == "ppo_lag" else
+                                f"device-resident env, observation normalisation fused into the collect step") if a.algo == "ppo_lag" else
                                (f"cpo synthetic env (obs=60, act=8), num_envs={N}, num_steps={T}, default_cfg "
                                 f"(15 CG iters, 33 FVPs, line search, critic fit batch 128 x 10 iters), device-resident env"),
                    "global_envs": world * N,
