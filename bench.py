@@ -92,6 +92,37 @@ def cpu_baseline(sample_envs: int, T: int, threads: int = 4, algo: str = "ppo_la
             "reference_recorded": recorded_reference(algo)}
 
 
+def _lib_note():
+    """Which libsafepo_hip.so the run used: 'in-tree' or the absolute path of an SPO_LIB_PATH override."""
+    from safepo import _abi
+    p = _abi.loaded_library()
+    return "in-tree" if p == os.path.abspath(_abi.LIB_PATH) else f"OVERRIDE: {p}"
+
+
+def self_launch(n: int, one_gpu: bool) -> int:
+    """`python bench.py --gpus N` without a launcher: re-run this command as N ranks under torch.distributed.run (one process
+    per GPU, rendezvous on 127.0.0.1 at a free port) and pass the exit code on.  Refuses when the box has fewer than N GPUs
+    (unless SPO_BENCH_ONE_GPU=1 puts all ranks on cuda:0) -- a --gpus 8 line must never be a 1-GPU measurement."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    if ndev < n and not one_gpu:
+        print(f"bench.py: --gpus {n} but only {ndev} GPU(s) are visible (SPO_BENCH_ONE_GPU=1 runs all ranks on cuda:0 "
+              "as a development aid)", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {n} without WORLD_SIZE: spawning {n} ranks: {' '.join(cmd[1:9])} ...", file=sys.stderr)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def run_epochs(algo, a, comm, dev, N, T, D, A, steps, warmup, time_gae):
     """Builds the engine + device env for `algo` and runs `warmup` untimed and `steps` timed epochs bracketed by a
     barrier + device synchronisation on both sides.  Returns a dict with the MAX-over-ranks elapsed time and the pieces
@@ -110,7 +141,7 @@ def run_epochs(algo, a, comm, dev, N, T, D, A, steps, warmup, time_gae):
         eng = CPOEngine(policy, N, T, cfg, dev, comm=comm)
     else:
         cfg = {"hidden_sizes": [64, 64], "gamma": 0.99, "target_kl": float("inf"), "batch_size": 64,
-               "learning_iters": a.learning_iters, "max_grad_norm": 40.0}
+               "learning_iters": a.learning_iters, "max_grad_norm": 40.0, "dp_batch": a.dp_batch}
         eng = PPOLagEngine(policy, N, T, cfg, dev, comm=comm)
     # a-2 inside the timed region: the env hands out RAW observations and the collect step normalises them as it loads them
     # (running mean / variance merged per step, spo_policy_step_norm) -- what SafeNormalizeObservation does in the
@@ -192,9 +223,30 @@ def run_epochs(algo, a, comm, dev, N, T, D, A, steps, warmup, time_gae):
     elapsed = time.time() - t_start
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     comm.all_reduce_max_(tmax)
-    PEER_EXCHANGE_USED[0] = getattr(eng, "p2p", None) is not None
+    # per-rank figures for the line (N > 1): elapsed, rollout and update seconds of every rank
+    per_rank = [[elapsed, roll, upd]]
+    if world > 1:
+        mine = torch.tensor([elapsed, roll, upd], dtype=torch.float64, device=dev)
+        both = torch.zeros(world * 3, dtype=torch.float64, device=dev)
+        both[3 * comm.rank:3 * comm.rank + 3] = mine
+        comm.all_reduce_sum_(both)
+        per_rank = both.view(world, 3).tolist()
+    px = getattr(eng, "p2p", None)
+    PEER_EXCHANGE_USED[0] = px is not None
+    exchange = None
+    if world > 1:
+        import torch.distributed as dist
+        form = ("rccl all-reduce between kernels (spo_ppo_lag_grad -> all_reduce -> spo_clip_adam_then_grad)" if px is None else
+                "in-kernel, all-to-all on the helper waves" if os.environ.get("SPO_P2P_A2A", "0") == "1" else
+                "in-kernel, recursive doubling on the helper waves" if os.environ.get("SPO_P2P_HELPER", "0") == "1" else
+                "in-kernel, recursive doubling of tagged words over IPC-mapped peer regions"
+                if (world & (world - 1)) == 0 else "in-kernel, reduce-scatter + all-gather of tagged words over IPC-mapped peer regions")
+        exchange = {"form": form, "selftest_s": round(getattr(px, "last_selftest_s", float("nan")), 4) if px is not None else None,
+                    "selftest_result": list(getattr(px, "last_selftest", ())) if px is not None else None,
+                    "host_collectives_backend": dist.get_backend(), "host_collectives_world": dist.get_world_size(),
+                    "dp_batch": a.dp_batch, "all_ranks_on_one_gpu": os.environ.get("SPO_BENCH_ONE_GPU", "0") == "1"}
     return {"elapsed": float(tmax.item()), "roll": roll, "upd": upd, "last": last, "n_ep": n_ep, "eng": eng, "cfg": cfg,
-            "epoch": epoch, "gae_graph": gae_graph, "gae_disp": gae_disp}
+            "epoch": epoch, "gae_graph": gae_graph, "gae_disp": gae_disp, "per_rank": per_rank, "exchange": exchange}
 
 
 def main():
@@ -214,16 +266,26 @@ def main():
     ap.add_argument("--stream-envs", type=int, default=262144, help="extra GAE roofline point that streams from HBM")
     ap.add_argument("--algo", choices=["ppo_lag", "cpo"], default="ppo_lag",
                     help="cpo = time BASELINE config 3 as the main workload (not the headline metric; single GPU)")
+    ap.add_argument("--dp-batch", choices=["local", "global"], default="local",
+                    help="N > 1: 'local' = batch_size rows per RANK (global batch 64 x N, weak scaling, the headline); "
+                         "'global' = batch_size is the GLOBAL minibatch, every rank takes 64 / N rows per step -- the reference's "
+                         "arithmetic on the N x num_envs buffer (BASELINE config 4 with exact semantics, SURVEY.md 8(e))")
     a = ap.parse_args()
-
-    from safepo.parallel import init_from_env
 
     # SPO_BENCH_ONE_GPU=1 (development aid): all ranks share cuda:0 with gloo for the host collectives, to exercise the
     # N > 1 code path -- including the in-kernel exchange through IPC-mapped regions -- on a single-GPU box.
     one_gpu = os.environ.get("SPO_BENCH_ONE_GPU", "0") == "1"
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a.gpus, one_gpu))
+
+    from safepo.parallel import init_from_env
     comm = init_from_env(backend="gloo" if one_gpu else None)
     world = comm.world_size
-    assert world == max(a.gpus, 1) or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if world != max(a.gpus, 1):
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} "
+                         "(or run `python bench.py --gpus N` directly: it spawns its own ranks)")
+    if not one_gpu and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible")
     local_rank = 0 if one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
@@ -231,6 +293,7 @@ def main():
 
     res = run_epochs(a.algo, a, comm, dev, N, T, D, A, a.steps, a.warmup, time_gae=True)
     elapsed, roll, upd, last, n_ep, eng, cfg = (res[k] for k in ("elapsed", "roll", "upd", "last", "n_ep", "eng", "cfg"))
+    res_exchange, res_per_rank = res["exchange"], res["per_rank"]
 
     if comm.rank != 0:
         if world > 1:
@@ -238,7 +301,7 @@ def main():
         return
     total_env_steps = world * N * T * a.steps
     value = total_env_steps / elapsed
-    batch = 128 if a.algo == "cpo" else 64
+    batch = 128 if a.algo == "cpo" else (64 // world if (a.dp_batch == "global" and world > 1) else 64)
     iters = 10 if a.algo == "cpo" else a.learning_iters
     n_mb = (N * T + batch - 1) // batch
     seg_ends = int(eng.buffer.seg_end.sum().item())
@@ -354,7 +417,7 @@ def main():
                        "update_s_per_epoch": round(r3["upd"] / a.cpo_steps, 4),
                        "critic_minibatch_steps_per_epoch": n_mb3 * 10,
                        "acceptance_step": r3["last"]["stop_iter"], "kl": r3["last"]["kl"],
-                       "critic_fit_form": ("two co-resident persistent launches (64 of every 128 rows each)"
+                       "critic_fit_form": ("one persistent launch, two workgroup pairs (64 of every 128 rows each) exchanging in-kernel"
                                            if getattr(r3["eng"], "_split", None) else "one persistent launch")}
             if not a.no_cpu_baseline:
                 config3["cpu_baseline"] = cpu_baseline(a.cpo_cpu_sample_envs, T, algo="cpo")
@@ -369,7 +432,8 @@ def main():
         "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": (f"ppo_lag synthetic env (obs=60, act=8), num_envs={N} per GPU, num_steps={T}, "
-                                f"default_cfg batch 64 x {a.learning_iters} learning iters (target_kl=inf: all iters run), "
+                                f"default_cfg batch 64 {'per rank' if a.dp_batch == 'local' or world == 1 else 'GLOBAL (64/N rows per rank)'} "
+                                f"x {a.learning_iters} learning iters (target_kl=inf: all iters run), "
                                 f"device-resident env, observation normalisation fused into the collect step") if a.algo == "ppo_lag" else
                                (f"cpo synthetic env (obs=60, act=8), num_envs={N}, num_steps={T}, default_cfg "
                                 f"(15 CG iters, 33 FVPs, line search, critic fit batch 128 x 10 iters), device-resident env"),
@@ -394,6 +458,12 @@ def main():
                           if a.algo == "ppo_lag" else None),
         "cpu_baseline": cpu,
         "config3_cpo": config3,
+        "library": _lib_note(),
+        "exchange": res_exchange,
+        "per_rank": ([{"rank": r, "ms_per_step": round(e / a.steps * 1e3, 2), "rollout_s_per_epoch": round(ro / a.steps, 4),
+                       "update_s_per_epoch": round(u / a.steps, 4),
+                       "update_us_per_minibatch_step": round(u / a.steps / (n_mb * iters) * 1e6, 3)}
+                      for r, (e, ro, u) in enumerate(res_per_rank)] if world > 1 else None),
         "phases": {"rollout_s_per_epoch": round(roll / a.steps, 4), "update_s_per_epoch": round(upd / a.steps, 4),
                    "update_us_per_minibatch_step": round(us_step, 3),
                    "stop_iter": last["stop_iter"], "kl": last["kl"], "episodes_per_epoch": n_ep},

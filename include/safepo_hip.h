@@ -275,6 +275,18 @@ int spo_critic_fit_iter_dp(float* theta, float* adam_m, float* adam_v, int64_t a
                            const float* target_r, const float* target_c, const int32_t* perm, int64_t M,
                            const spo_ppo_cfg* cfg_host, float* stale_sq_io, float* losses_out, void* sync_ws, int rank,
                            int world, void* const* regions, uint32_t step0, void* stream);
+/* One-grid split critic fit (single GPU; cpo.py:534-571 at batch_size 128): the two 64-row halves of every minibatch run on
+ * two workgroup pairs of ONE launch, each with its own replica (theta0/1, adam_m0/1, adam_v0/1, stale_sq_io0/1, losses0/1,
+ * sync_ws0/1) and its own rows (perm0 / perm1: M_half entries each), exchanging the gradient inside the step through
+ * regions2[0..1] (spo_p2p_alloc; no IPC).  Co-resident by construction -- no second stream.  Consumes ceil(M_half / batch)
+ * tags from step0.  spo_p2p_selftest_one_grid: the exchange self-test in the same one-grid shape, result4_dev =
+ * {wrong values, timeout} per rank. */
+int spo_critic_fit_iter_split(float* theta0, float* adam_m0, float* adam_v0, float* theta1, float* adam_m1, float* adam_v1,
+                              int64_t adam_step_host, const float* obs, const float* target_r, const float* target_c,
+                              const int32_t* perm0, const int32_t* perm1, int64_t M_half, const spo_ppo_cfg* cfg_host,
+                              float* stale_sq_io0, float* stale_sq_io1, float* losses0, float* losses1, void* sync_ws0,
+                              void* sync_ws1, void* const* regions2, uint32_t step0, void* stream);
+int spo_p2p_selftest_one_grid(void* const* regions2, uint32_t step0, int iters, int32_t* result4_dev, void* stream);
 int spo_ppo_lag_update_iter_dp(float* theta, float* adam_m, float* adam_v, int64_t adam_step_host, const float* obs,
                                const float* act, const float* logp_old, const float* target_r, const float* target_c,
                                const float* adv, const int32_t* perm, int64_t M, const spo_ppo_cfg* cfg_host,

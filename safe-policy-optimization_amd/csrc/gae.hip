@@ -384,15 +384,15 @@ inline GaeGeom gae_geom(int64_t T, int64_t N) {
   return g;
 }
 
-// Optional timing of the next launches: when set, the dispatch carries its own start / stop events
-// (hipExtLaunchKernelGGL), i.e. the timestamps of the dispatch packet itself -- what rocprofv3 --kernel-trace reports.
-hipEvent_t g_gae_ev_start = nullptr, g_gae_ev_stop = nullptr;
-
+// Optional per-dispatch timing (spo_gae_fused_timed only): when the caller hands in an event pair, the dispatch carries its
+// own start / stop events (hipExtLaunchKernelGGL), i.e. the timestamps of the dispatch packet itself -- what rocprofv3
+// --kernel-trace reports.  The product entry point spo_gae_fused always passes nullptr: no mutable state on the launch path.
 template <int VEC, int BOOT>
-int launch_gae(const GaeGeom& g, const GaeArgs& a, int blocks, hipStream_t st) {
+int launch_gae(const GaeGeom& g, const GaeArgs& a, int blocks, hipStream_t st, hipEvent_t ev_start,
+               hipEvent_t ev_stop) {
 #define SPO_GAE_LAUNCH(...)                                                                                       \
   {                                                                                                               \
-    if (g_gae_ev_start) hipExtLaunchKernelGGL((gae_kernel<__VA_ARGS__>), dim3(blocks), dim3(256), 0, st, g_gae_ev_start, g_gae_ev_stop, 0, a); \
+    if (ev_start) hipExtLaunchKernelGGL((gae_kernel<__VA_ARGS__>), dim3(blocks), dim3(256), 0, st, ev_start, ev_stop, 0, a); \
     else hipLaunchKernelGGL((gae_kernel<__VA_ARGS__>), dim3(blocks), dim3(256), 0, st, a);                         \
   }
   if (g.rc) {
@@ -402,7 +402,7 @@ int launch_gae(const GaeGeom& g, const GaeArgs& a, int blocks, hipStream_t st) {
         const int pb = (blocks + fat - 1) / fat;
 #define SPO_GAE_FAT_LAUNCH(FF)                                                                                    \
         {                                                                                                         \
-          if (g_gae_ev_start) hipExtLaunchKernelGGL((gae_kernel<4, 32, BOOT, true, FF>), dim3(pb), dim3(256 * FF), 0, st, g_gae_ev_start, g_gae_ev_stop, 0, a); \
+          if (ev_start) hipExtLaunchKernelGGL((gae_kernel<4, 32, BOOT, true, FF>), dim3(pb), dim3(256 * FF), 0, st, ev_start, ev_stop, 0, a); \
           else hipLaunchKernelGGL((gae_kernel<4, 32, BOOT, true, FF>), dim3(pb), dim3(256 * FF), 0, st, a);         \
         }
         if (fat == 2) SPO_GAE_FAT_LAUNCH(2) else SPO_GAE_FAT_LAUNCH(4)
@@ -436,10 +436,11 @@ static int gae_plain_stores() {
   return mode;
 }
 
-extern "C" int spo_gae_fused(const float* reward, const float* cost, const float* value_r, const float* value_c,
-                             const uint8_t* seg_end, const float* boot_r, const float* boot_c, float* adv_r,
-                             float* adv_c, float* target_r, float* target_c, double* partials, int64_t num_envs,
-                             int64_t T, double gamma, double lam, double lam_c, void* stream) {
+static int gae_fused_impl(const float* reward, const float* cost, const float* value_r, const float* value_c,
+                          const uint8_t* seg_end, const float* boot_r, const float* boot_c, float* adv_r,
+                          float* adv_c, float* target_r, float* target_c, double* partials, int64_t num_envs,
+                          int64_t T, double gamma, double lam, double lam_c, void* stream, hipEvent_t ev_start,
+                          hipEvent_t ev_stop) {
   SPO_REQUIRE(num_envs >= 0 && T >= 0, "gae: negative size");
   if (num_envs == 0 || T == 0) return 0;
   SPO_REQUIRE(reward && cost && value_r && value_c && seg_end && adv_r && adv_c && target_r && target_c && partials,
@@ -458,13 +459,22 @@ extern "C" int spo_gae_fused(const float* reward, const float* cost, const float
   const bool eager = fv == 1 && !folded;
   int rc;
 #define SPO_GAE_GO(V)                                                                     \
-  rc = folded ? launch_gae<V, BOOT_FOLDED>(g, a, blocks, st)                              \
-              : eager ? launch_gae<V, BOOT_EAGER>(g, a, blocks, st) : launch_gae<V, BOOT_PRED>(g, a, blocks, st);
+  rc = folded ? launch_gae<V, BOOT_FOLDED>(g, a, blocks, st, ev_start, ev_stop)           \
+              : eager ? launch_gae<V, BOOT_EAGER>(g, a, blocks, st, ev_start, ev_stop)    \
+                      : launch_gae<V, BOOT_PRED>(g, a, blocks, st, ev_start, ev_stop);
   if (g.vec == 4) { SPO_GAE_GO(4) } else { SPO_GAE_GO(1) }
 #undef SPO_GAE_GO
   if (rc) return rc;
   SPO_LAUNCH_CHECK("spo_gae_fused");
   return 0;
+}
+
+extern "C" int spo_gae_fused(const float* reward, const float* cost, const float* value_r, const float* value_c,
+                             const uint8_t* seg_end, const float* boot_r, const float* boot_c, float* adv_r,
+                             float* adv_c, float* target_r, float* target_c, double* partials, int64_t num_envs,
+                             int64_t T, double gamma, double lam, double lam_c, void* stream) {
+  return gae_fused_impl(reward, cost, value_r, value_c, seg_end, boot_r, boot_c, adv_r, adv_c, target_r, target_c, partials,
+                        num_envs, T, gamma, lam, lam_c, stream, nullptr, nullptr);
 }
 
 extern "C" int spo_debug_gae_variant(int v) { g_gae_force_variant = v; return 0; }
@@ -482,12 +492,9 @@ extern "C" int spo_gae_fused_timed(const float* reward, const float* cost, const
   int rc = 0;
   for (auto& e : ev)
     if (!rc) rc = spo::hip_check(hipEventCreate(&e), "hipEventCreate");
-  for (int i = 0; i < reps && !rc; ++i) {
-    g_gae_ev_start = ev[2 * i]; g_gae_ev_stop = ev[2 * i + 1];
-    rc = spo_gae_fused(reward, cost, value_r, value_c, seg_end, boot_r, boot_c, adv_r, adv_c, target_r, target_c, partials,
-                       num_envs, T, gamma, lam, lam_c, stream);
-  }
-  g_gae_ev_start = g_gae_ev_stop = nullptr;
+  for (int i = 0; i < reps && !rc; ++i)
+    rc = gae_fused_impl(reward, cost, value_r, value_c, seg_end, boot_r, boot_c, adv_r, adv_c, target_r, target_c, partials,
+                        num_envs, T, gamma, lam, lam_c, stream, ev[2 * i], ev[2 * i + 1]);
   if (!rc) rc = spo::hip_check(hipStreamSynchronize(st), "hipStreamSynchronize(gae_timed)");
   for (int i = 0; i < reps && !rc; ++i) {
     float ms = 0.f;

@@ -75,8 +75,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const float* __restrict_
   __shared__ float Xs[GM_T * GM_LD];
   __shared__ float Ws[GM_T * GM_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
-  const int64_t row0 = (int64_t)blockIdx.y * GM_T;
-  const int col0 = blockIdx.x * GM_T;
+  const int64_t row0 = (int64_t)blockIdx.x * GM_T;          // rows on grid.x (2^31 - 1 tiles), the few column tiles on grid.y
+  const int col0 = blockIdx.y * GM_T;
   f4v acc[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) acc[nt] = f4v{0.f, 0.f, 0.f, 0.f};
@@ -114,7 +114,11 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const float* __restrict_
 }
 int gemm_mfma(hipStream_t st, const float* X, const float* W, float* Y, int64_t B, int R, int N, int64_t w_sj, int64_t w_sr,
               float beta) {
-  const dim3 grid((unsigned)((N + GM_T - 1) / GM_T), (unsigned)((B + GM_T - 1) / GM_T));
+  const int64_t row_tiles = (B + GM_T - 1) / GM_T, col_tiles = (N + GM_T - 1) / GM_T;
+  if (row_tiles > 0x7fffffffLL || col_tiles > 65535)
+    return spo::fail(-1, "ma gemm: %lld x %d exceeds the launch grid (row tiles %lld, column tiles %lld)", (long long)B, N,
+                     (long long)row_tiles, (long long)col_tiles);
+  const dim3 grid((unsigned)row_tiles, (unsigned)col_tiles);
   hipLaunchKernelGGL(gemm_mfma_kernel, grid, dim3(256), 0, st, X, W, Y, B, R, N, w_sj, w_sr, beta);
   return 0;
 }

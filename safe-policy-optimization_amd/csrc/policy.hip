@@ -34,7 +34,32 @@ __global__ __launch_bounds__(256) void policy_step_kernel(StepArgs a) {
   const bool valid = row < a.N;
   const int64_t rrow = valid ? row : a.N - 1;
   f4 x[KIN / 16];
-  load_obs_tiles<KIN>(a.obs + rrow * D, D, q, x);
+  if (a.rms) {
+    // in-place form: obs_io aliases obs, so the row is read through the pointer it is written through (no __restrict__
+    // promise), and lanes past the last row read nothing -- clamping them to row N-1 would race with that row's owner
+    // storing its normalised values
+    const float* row_io = a.obs_io + rrow * D;
+    if ((D & 3) == 0) {
+#pragma unroll
+      for (int nt = 0; nt < KIN / 16; ++nt) {
+        const int c = 16 * nt + 4 * q;
+        const f4 zero = {0.f, 0.f, 0.f, 0.f};
+        x[nt] = zero;
+        if (valid && c < D) x[nt] = *reinterpret_cast<const f4*>(row_io + c);
+      }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < KIN / 16; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = 16 * nt + 4 * q + e;
+          x[nt][e] = 0.f;
+          if (valid && c < D) x[nt][e] = row_io[c];
+        }
+    }
+  } else {
+    load_obs_tiles<KIN>(a.obs + rrow * D, D, q, x);
+  }
   if (a.rms) {
     // NormalizeObservation.normalize (reference wrappers.py:42-49 -> gymnasium): (obs - mean) / sqrt(var + 1e-8) in float64
     // with the statistics spo_obs_stats_update has just merged this batch into, rounded to fp32 once -- in registers, so the

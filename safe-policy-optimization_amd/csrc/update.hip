@@ -115,6 +115,7 @@ struct UpdArgs {
                                        // waves (default), 0 = flag-based all-to-all (SPO_P2P_A2A=1)
   int spec_mode;                       // main + helper form: 1 = the clip verdict is validated AFTER the next step's forward
                                        // while the previous step was not clipped (SPO_UPDATE_SPEC, default), 0 = never
+  int grid_ranks;                      // exchange self-test only: 2 = both ranks in one grid (spo_p2p_selftest_one_grid)
 };
 constexpr int NPHASE = 10;
 constexpr int UPD_BACKUP_ROWS = 32;      // float4 rows per lane of the 512-thread kernels' backup scratch (main+helper form: 3*NT1 + 12 + 8)
@@ -144,7 +145,7 @@ __device__ __forceinline__ AdamOut adam1(float p, float g, float m, float v, flo
 #ifdef SPO_ABLATE_ADAM_STATE
 #define SPO_ST_MV(IDX, M, V)
 #else
-#define SPO_ST_MV(IDX, M, V) { a.adam_m[IDX] = (M); a.adam_v[IDX] = (V); }
+#define SPO_ST_MV(IDX, M, V) { st_m[IDX] = (M); st_v[IDX] = (V); }   /* st_m / st_v: the kernel's moment outputs */
 #endif
 #ifdef SPO_ABLATE_ADAM_STATE
 #define SPO_ADAM(DST, P, G, M, V)                                                      \
@@ -357,8 +358,12 @@ __device__ __forceinline__ void xr_allreduce_rd(const u64* regions, int me, int 
 //     gradient all-reduce happens inside the step (xr_allreduce above) instead of kernel / RCCL / kernel.
 // XR = 1: reduce-scatter + all-gather (any world); 2: recursive doubling (power-of-two worlds).  Separate instantiations:
 //     both exchange bodies together do not fit the register file next to the optimiser state.
+// The body is a device function over a CONST reference to a kernel-argument struct so that the one-grid split form below
+// can run it on either of two argument structs (one per rank) under a block-uniform branch: every pointer stays a plain
+// kernel-argument load.  (Selecting per-rank pointers inside one body -- by offsets or by writing the by-value struct --
+// makes the gfx950 backend of ROCm 7.2 emit an illegal flat-aperture compare in the XR instantiations.)
 template <int KIN, bool PERSIST, bool PROF = false, int AMODE = 0, int XR = 0>
-__global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
+__device__ __forceinline__ void ppo_update_body(const UpdArgs& a, const int wg) {
   unsigned long long pacc[NPHASE] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = 0;
 #define SPO_STAMP(i)                                           \
@@ -374,8 +379,7 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
   // Placement hint (speed only, never correctness): workgroup b is observed to land on XCD b % 8, so the
   // persistent form launches 8*(n-1)+1 blocks and only blocks 0, 8, 16 work -- the networks then share one
   // XCD's L2 and the per-step granule exchange is ~0.1-0.3 us faster.  Any other placement is just slower.
-  const int wg = PERSIST ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-  if (PERSIST && (blockIdx.x & 7)) return;
+  float* const st_m = a.adam_m; float* const st_v = a.adam_v;
   const int net = a.first_net + wg;
   const int D = a.cfg.obs_dim, A = a.cfg.act_dim, B = a.cfg.batch;
   const NetGeom g = net_geom(D, A, net);
@@ -1076,6 +1080,24 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
   }
 }
 
+template <int KIN, bool PERSIST, bool PROF = false, int AMODE = 0, int XR = 0>
+__global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
+  if (PERSIST && (blockIdx.x & 7)) return;                     // placement hint, see ppo_update_body
+  ppo_update_body<KIN, PERSIST, PROF, AMODE, XR>(a, PERSIST ? (int)(blockIdx.x >> 3) : (int)blockIdx.x);
+}
+
+// One-grid split form (critic fit at batch 128 on one GPU): BOTH "ranks" of a two-way split of the minibatch live in ONE
+// launch -- workgroups [0, n_nets) run rank 0's arguments, [n_nets, 2 n_nets) rank 1's (own replica, rows, outputs, granules,
+// error word) -- so they are co-resident by construction (one grid of four workgroups) instead of by the luck of two
+// streams landing on two hardware queues.  Recursive doubling at world 2: one hand-off per step.
+template <int KIN>
+__global__ __launch_bounds__(256, 1) void ppo_update_split_kernel(UpdArgs a0, UpdArgs a1) {
+  if (blockIdx.x & 7) return;
+  const int wg = (int)(blockIdx.x >> 3);
+  if (wg < a0.n_nets) ppo_update_body<KIN, true, false, 0, 2>(a0, wg);
+  else ppo_update_body<KIN, true, false, 0, 2>(a1, wg - a0.n_nets);
+}
+
 // =====================================================================================================================
 // Main + helper waves: ppo_update_h_kernel (512 threads per network).
 //
@@ -1281,6 +1303,7 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
   // Through the volatile pointer the read is a flat_load ... sc0 sc1 followed by s_waitcnt vmcnt(0): a round trip through
   // the memory pipeline that also waits for every prefetch in flight, twice per step on the critical path.
   const int* const xw_ro = reinterpret_cast<const int*>(lds + H::XW);
+  float* const st_m = a.adam_m; float* const st_v = a.adam_v;
   stage_net<KIN>(a.theta, g, lds, tid, 512);
   if (is_actor && tid < A) red[128 + tid] = a.theta[ls_off + tid];
   if (tid < 32) xw[tid] = 0;
@@ -2266,7 +2289,12 @@ __global__ __launch_bounds__(256, 1) void xr_selftest_kernel(int rank, int world
   __shared__ float dead;
   __shared__ unsigned long long regions[XR_MAX_WORLD];
   if (blockIdx.x & 7) return;
-  const int net = blockIdx.x >> 3, tid = threadIdx.x;
+  int net = blockIdx.x >> 3;
+  const int tid = threadIdx.x;
+  if (a.grid_ranks == 2) {           // both ranks in one grid (41 blocks): workgroups 0..2 rank 0, 3..5 rank 1
+    rank = net / 3; net -= 3 * rank;
+    result += 2 * rank;
+  }
   if (tid == 0) dead = 0.f;
   if (tid < XR_MAX_WORLD) regions[tid] = reinterpret_cast<unsigned long long>(a.xr_region[tid]);
   __syncthreads();
@@ -2650,6 +2678,79 @@ extern "C" int spo_critic_fit_iter_dp(float* theta, float* adam_m, float* adam_v
   else rc = launch_update<true, 0, 1>(a, 2, st);
   if (rc) return rc;
   SPO_LAUNCH_CHECK("spo_critic_fit_iter_dp");
+  return 0;
+}
+
+// ---- one-grid split critic fit (single GPU): a 128-row minibatch as two 64-row halves on TWO workgroup pairs of ONE launch.
+// The data-parallel machinery above shards a step over ranks; here both "ranks" are workgroups of the same grid (rank 0:
+// workgroups 0, 1 = reward / cost critic on rows perm0; rank 1: workgroups 2, 3 on rows perm1), each with its own replica of
+// the parameters and moments, exchanging the gradient through the two exchange regions with the same tagged-word protocol.
+// One grid of four workgroups is co-resident by construction, so -- unlike two launches on two streams (round 1 / 2: the
+// second stream could land on the first one's hardware queue and never run beside it) -- the form never depends on HIP's
+// queue assignment.  cpo.py:534-571: identical arithmetic to the mean over the 128 rows up to the order of the sums.
+extern "C" int spo_critic_fit_iter_split(float* theta0, float* adam_m0, float* adam_v0, float* theta1, float* adam_m1,
+                                         float* adam_v1, int64_t adam_step_host, const float* obs, const float* target_r,
+                                         const float* target_c, const int32_t* perm0, const int32_t* perm1, int64_t M_half,
+                                         const spo_ppo_cfg* cfg_host, float* stale_sq_io0, float* stale_sq_io1,
+                                         float* losses0, float* losses1, void* sync_ws0, void* sync_ws1,
+                                         void* const* regions2, uint32_t step0, void* stream) {
+  if (int rc = check_cfg(cfg_host)) return rc;
+  SPO_REQUIRE(theta0 && adam_m0 && adam_v0 && theta1 && adam_m1 && adam_v1 && obs && target_r && target_c && perm0 && perm1 &&
+                  losses0 && losses1 && sync_ws0 && sync_ws1 && stale_sq_io0 && stale_sq_io1,
+              "critic_fit_iter_split: null pointer");
+  SPO_REQUIRE(theta0 != theta1 && adam_m0 != adam_m1 && adam_v0 != adam_v1 && sync_ws0 != sync_ws1 && losses0 != losses1 &&
+                  stale_sq_io0 != stale_sq_io1, "critic_fit_iter_split: the two halves need separate replicas and outputs");
+  SPO_REQUIRE(M_half > 0 && adam_step_host >= 0, "critic_fit_iter_split: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = spo::hip_check(hipMemsetAsync(sync_ws0, 0, 64, st), "hipMemsetAsync(sync_ws0)")) return rc;
+  if (int rc = spo::hip_check(hipMemsetAsync(sync_ws1, 0, 64, st), "hipMemsetAsync(sync_ws1)")) return rc;
+  UpdArgs a{};
+  if (int rc = fill_xr(a, 0, 2, regions2, step0)) return rc;
+  a.theta = theta0; a.adam_m = adam_m0; a.adam_v = adam_v0;
+  a.obs = obs; a.tgt_r = target_r; a.tgt_c = target_c; a.perm = perm0; a.M = M_half; a.cfg = *cfg_host;
+  a.losses = losses0;
+  a.slots = reinterpret_cast<unsigned long long*>(sync_ws0);
+  a.err = reinterpret_cast<int*>(reinterpret_cast<char*>(sync_ws0) + 64);
+  a.pow_b1 = pow((double)cfg_host->beta1, (double)adam_step_host);
+  a.pow_b2 = pow((double)cfg_host->beta2, (double)adam_step_host);
+  a.pow_b1_actor = a.pow_b1; a.pow_b2_actor = a.pow_b2;
+  a.first_net = 0; a.n_nets = 2; a.stale_sq = 0.f; a.stale_io = stale_sq_io0;
+  UpdArgs b = a;                       // rank 1: same data and configuration, its own replica / rows / outputs
+  b.xr_rank = 1;
+  b.theta = theta1; b.adam_m = adam_m1; b.adam_v = adam_v1; b.perm = perm1; b.losses = losses1;
+  b.slots = reinterpret_cast<unsigned long long*>(sync_ws1);
+  b.err = reinterpret_cast<int*>(reinterpret_cast<char*>(sync_ws1) + 64);
+  b.stale_io = stale_sq_io1;
+  const int kin = pick_kin(cfg_host->obs_dim);
+#define SPO_SPLIT(K)                                                                                              \
+  {                                                                                                               \
+    const size_t sh = UpdLds<K>::SIZE * sizeof(float);                                                            \
+    static bool attr_done = false;                                                                                \
+    if (!attr_done) {                                                                                             \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_update_split_kernel<K>),              \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);                    \
+      if (e != hipSuccess) return spo::hip_check(e, "hipFuncSetAttribute(update split)");                         \
+      attr_done = true;                                                                                           \
+    }                                                                                                             \
+    hipLaunchKernelGGL((ppo_update_split_kernel<K>), dim3(8 * (2 * a.n_nets - 1) + 1), dim3(256), sh, st, a, b);  \
+  }
+  if (kin == 16) SPO_SPLIT(16) else if (kin == 32) SPO_SPLIT(32) else if (kin == 64) SPO_SPLIT(64) else SPO_SPLIT(128)
+#undef SPO_SPLIT
+  SPO_LAUNCH_CHECK("spo_critic_fit_iter_split");
+  return 0;
+}
+
+// The exchange self-test with both ranks in one grid (the co-residency the split form relies on): result4_dev =
+// {mismatches, timeout} of rank 0 then of rank 1.
+extern "C" int spo_p2p_selftest_one_grid(void* const* regions2, uint32_t step0, int iters, int32_t* result4_dev, void* stream) {
+  SPO_REQUIRE(result4_dev && iters > 0, "p2p_selftest_one_grid: bad args");
+  UpdArgs a{};
+  if (int rc = fill_xr(a, 0, 2, regions2, step0)) return rc;
+  a.grid_ranks = 2;
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = spo::hip_check(hipMemsetAsync(result4_dev, 0, 16, st), "hipMemsetAsync(selftest)")) return rc;
+  hipLaunchKernelGGL(xr_selftest_kernel, dim3(41), dim3(256), 0, st, 0, 2, step0, iters, result4_dev, a);
+  SPO_LAUNCH_CHECK("spo_p2p_selftest_one_grid");
   return 0;
 }
 

@@ -80,6 +80,9 @@ PROTOTYPES = {
     "spo_p2p_close": (c_int, [P]),
     "spo_p2p_free": (c_int, [P]),
     "spo_p2p_selftest": (c_int, [c_int, c_int, POINTER(c_void_p), c_uint32, c_int, P, P]),
+    "spo_p2p_selftest_one_grid": (c_int, [POINTER(c_void_p), c_uint32, c_int, P, P]),
+    "spo_critic_fit_iter_split": (c_int, [P] * 6 + [c_int64, P, P, P, P, P, c_int64, POINTER(PpoCfg)] + [P] * 6
+                                  + [POINTER(c_void_p), c_uint32, P]),
     "spo_critic_fit_iter_dp": (c_int, [P, P, P, c_int64, P, P, P, P, c_int64, POINTER(PpoCfg), P, P, P, c_int, c_int,
                                        POINTER(c_void_p), c_uint32, P]),
     "spo_ppo_lag_update_iter_dp": (c_int, [P, P, P, c_int64, P, P, P, P, P, P, P, c_int64, POINTER(PpoCfg), P, P,
@@ -114,7 +117,17 @@ def load(path: str | None = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or os.environ.get("SPO_LIB_PATH") or LIB_PATH      # SPO_LIB_PATH: development aid (A/B of kernel builds)
+    # SPO_LIB_PATH (development aid: A/B of kernel builds) is honoured only together with SPO_LIB_OVERRIDE=1 and is
+    # announced on stderr, so a stale variable cannot silently swap the kernels under a training run or a parity test;
+    # loaded_library() reports what was loaded (bench.py puts it in its JSON line when it is not the in-tree build)
+    override = os.environ.get("SPO_LIB_PATH")
+    if override and path is None:
+        if os.environ.get("SPO_LIB_OVERRIDE", "0") != "1":
+            raise SpoError(f"SPO_LIB_PATH={override!r} is set without SPO_LIB_OVERRIDE=1: refusing to load kernels from "
+                           "outside the tree (unset it, or set SPO_LIB_OVERRIDE=1 for a deliberate A/B run)")
+        import sys
+        print(f"[safepo] WARNING: kernels loaded from SPO_LIB_PATH={override} instead of the in-tree {LIB_PATH}", file=sys.stderr)
+    p = path or override or LIB_PATH
     if not os.path.exists(p):
         raise SpoError(
             f"{p} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -128,7 +141,17 @@ def load(path: str | None = None):
         raise SpoError(f"ABI version mismatch: library {lib.spo_abi_version()} != binding 1")
     if path is None:
         _lib = lib
+        global _lib_loaded_from
+        _lib_loaded_from = os.path.abspath(p)
     return lib
+
+
+_lib_loaded_from = None
+
+
+def loaded_library() -> str | None:
+    """Absolute path of the shared object the process-wide binding was loaded from (None before load())."""
+    return _lib_loaded_from
 
 
 def check(rc: int, what: str = ""):

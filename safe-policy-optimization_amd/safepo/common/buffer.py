@@ -69,6 +69,7 @@ class VectorizedOnPolicyBuffer:
             self.clear_boundaries()
         for key, value in data.items():
             self.data[key][:, self.ptr] = torch.as_tensor(value, dtype=torch.float32, device=self._device)
+        self._fold_cols = -1          # a column written through the API has no folded bootstrap: scan the plain arrays
         self.advance()
 
     def advance(self) -> None:
@@ -82,18 +83,25 @@ class VectorizedOnPolicyBuffer:
         if self.ptr == 0 or self.path_start_idx_list[idx] >= self.ptr:
             return
         t = self.ptr - 1
+        # the marks below change seg_end / boot_* only: reward_fold / cost_fold of an engine-collected epoch would be stale
+        # (ADVICE r02), so the epoch falls back to the unfolded scan (reward/cost + boot_r/boot_c, bit-identical results)
+        self._fold_cols = -1
         self.seg_end[idx, t] = 1
         self.boot_r[idx, t] = 0.0 if last_value_r is None else torch.as_tensor(last_value_r).reshape(-1)[0]
         self.boot_c[idx, t] = 0.0 if last_value_c is None else torch.as_tensor(last_value_c).reshape(-1)[0]
         self.path_start_idx_list[idx] = self.ptr
 
-    def compute_gae(self, lagrangian_multiplier: float | None = None, comm=None) -> None:
+    def compute_gae(self, lagrangian_multiplier: float | None = None, comm=None, force_unfolded: bool = False) -> None:
         """All paths, reward + cost, one launch; then the get() statistics (buffer.py:154-160) and,
         if a multiplier is given, the PPO-Lag advantage mix (ppo_lag.py:280-281) into self.adv_mix.
-        `comm`: optional safepo.parallel.Comm -- statistics are all-reduced over the env shards."""
+        `comm`: optional safepo.parallel.Comm -- statistics are all-reduced over the env shards.
+        Folded form: when every column of the epoch was written by the engine's boundary kernel, the scan reads
+        reward_fold / cost_fold (reward + gamma * bootstrap at path ends) and no bootstrap arrays.  store() and
+        finish_path() invalidate it; a caller that edits data["reward"] / data["cost"] in place after an engine-collected
+        epoch (reward shaping) passes force_unfolded=True so the edit is what the scan sees."""
         d, lib, st = self.data, self._lib, _abi.stream_ptr()
         N, T = self.num_envs, self.size
-        folded = self._fold_cols == T and self.ptr == T
+        folded = self._fold_cols == T and self.ptr == T and not force_unfolded
         rew, cst = (self.reward_fold, self.cost_fold) if folded else (d["reward"], d["cost"])
         boot_r, boot_c = (None, None) if folded else (self.boot_r, self.boot_c)
         self.last_scan_folded = folded

@@ -350,13 +350,14 @@ class CPOEngine(PPOLagEngine):
     # ---------------------------------------------------------------- critic fit on two workgroup pairs (one GPU)
     def _split_setup(self):
         """The critic fit steps through minibatches of 128 rows, which one workgroup per critic takes as two 64-column
-        halves one after the other (the MFMA tile is 16 columns per wave, 4 waves).  On a single GPU the same
-        machinery that shards the step over ranks can shard it over CUs instead: TWO co-resident persistent launches
-        on two streams, each with its own replica of the critics and 64 of every 128 rows, exchanging the gradient
-        inside the step through a pair of exchange regions (spo_critic_fit_iter_dp with world = 2, no IPC -- both
-        "ranks" live in this process).  Same arithmetic as the mean over 128 rows, ~15 us instead of ~20 us per step.
-        Returns the state dict, or None when the form does not apply / the self-test failed (then the one-launch form
-        is used)."""
+        halves one after the other (the MFMA tile is 16 columns per wave, 4 waves).  On a single GPU the machinery that
+        shards the step over ranks shards it over CUs instead: ONE launch whose four workgroups are two "ranks" (each
+        with its own replica of the critics and 64 of every 128 rows), exchanging the gradient inside the step through a
+        pair of exchange regions (spo_critic_fit_iter_split; no IPC, no second stream).  Same arithmetic as the mean over
+        128 rows, ~15 us instead of ~20 us per step.  The four workgroups of one grid are co-resident by construction
+        (rounds 1-2 used two launches on two streams, whose co-residency depended on HIP's stream-to-queue assignment);
+        the exchange self-test in the same one-grid shape runs once as an assertion.
+        Returns the state dict, or None when the form does not apply (then the one-launch form is used)."""
         if self._split is not None:
             return self._split or None
         self._split = False
@@ -373,56 +374,30 @@ class CPOEngine(PPOLagEngine):
                 _abi.check(lib.spo_p2p_alloc(ctypes.byref(own), handle), "spo_p2p_alloc")
                 owns.append(own)
                 regions[r] = own
-        except _abi.SpoError:
+        except _abi.SpoError as e:
             for own in owns:
                 lib.spo_p2p_free(own)
+            print(f"[cpo] split critic fit unavailable ({e}); using the one-launch form", file=sys.stderr)
             return None
-        st = {"regions": regions, "owns": owns, "stream": None, "step": 0,
-              "sync_ws": torch.zeros(32, dtype=torch.int64, device=self.dev)}
-        # both launches of a pair must be resident at the same time: prove it with the exchange self-test, twice -- the
-        # second round is timed: when the GPU is shared with other processes the scheduler may time-slice the two
-        # launches, and then every hand-off costs a scheduler quantum instead of microseconds (a crawl, not a timeout).
-        # HIP deals streams onto a handful of hardware queues round-robin, so a fresh stream can land on the SAME queue as
-        # the current one (then its launch waits behind ours and the pair can never exchange): a failed attempt is
-        # repeated on another fresh stream before the one-launch form is chosen.
-        main = torch.cuda.current_stream(self.dev)
-        why = ""
-        keep = []                                          # rejected streams stay alive so the next one maps elsewhere
-        for attempt in range(4):
-            stream = torch.cuda.Stream(self.dev)
-            res = [torch.zeros(2, dtype=torch.int32, device=self.dev) for _ in range(2)]
-            elapsed, base = 0.0, 128 * attempt
-            for rnd in range(2):
-                stream.wait_stream(main)
-                torch.cuda.synchronize(self.dev)
-                t0 = time.perf_counter()
-                _abi.check(lib.spo_p2p_selftest(0, 2, regions, base + 64 * rnd, 64, _abi.ptr(res[0]), _abi.stream_ptr()), "spo_p2p_selftest")
-                with torch.cuda.stream(stream):
-                    _abi.check(lib.spo_p2p_selftest(1, 2, regions, base + 64 * rnd, 64, _abi.ptr(res[1]), _abi.stream_ptr()), "spo_p2p_selftest")
-                main.wait_stream(stream)
-                torch.cuda.synchronize(self.dev)
-                elapsed = time.perf_counter() - t0
-                if any(t.tolist() != [0, 0] for t in res):
-                    break
-            bad = any(t.tolist() != [0, 0] for t in res)
-            if not bad and elapsed <= 0.02:                # 64 exchanges take ~0.3 ms when co-resident
-                st["stream"], st["step"] = stream, base + 128
-                if attempt:
-                    print(f"[cpo] two-launch critic fit: stream {attempt + 1} accepted (before: {why})", file=sys.stderr)
-                break
-            why = (f"self-test {[t.tolist() for t in res]}" if bad else f"64 exchanges took {elapsed * 1e3:.1f} ms")
-            keep.append(stream)
-        if st["stream"] is None:
-            print(f"[cpo] two-launch critic fit unavailable ({why}); using the one-launch form", file=sys.stderr)
+        res = torch.zeros(4, dtype=torch.int32, device=self.dev)
+        _abi.check(lib.spo_p2p_selftest_one_grid(regions, 0, 64, _abi.ptr(res), _abi.stream_ptr()), "spo_p2p_selftest_one_grid")
+        got = res.tolist()
+        if got != [0, 0, 0, 0]:
             for own in owns:
                 lib.spo_p2p_free(own)
-            return None
+            raise _abi.SpoError(f"one-grid exchange self-test failed: {got} ({{wrong values, timeout}} per rank) -- the "
+                                "four workgroups of one grid must be co-resident; SPO_CPO_SPLIT=0 selects the one-launch form")
+        th = self.policy.theta
+        st = {"regions": regions, "owns": owns, "step": 64,
+              "sync_ws": torch.zeros(32, dtype=torch.int64, device=self.dev),
+              "theta1": torch.empty_like(th), "m1": torch.empty_like(th), "v1": torch.empty_like(th),
+              "stale1": torch.empty_like(self.stale_sq)}
         self._split = st
         return st
 
     def __del__(self):
         st = getattr(self, "_split", None)
-        if st:                       # release the two exchange regions of the two-launch critic fit
+        if st:                       # release the two exchange regions of the split critic fit
             try:
                 torch.cuda.synchronize(self.dev)
                 for own in st["owns"]:
@@ -432,12 +407,12 @@ class CPOEngine(PPOLagEngine):
             self._split = False
 
     def _critic_fit_split(self, st, perm_fn, cfg64, n_mb):
-        """learning_iters passes with the two-launch form; None if an exchange timed out (state restored)."""
+        """learning_iters passes with the one-grid split form; None if an exchange timed out (state restored)."""
         c, d, lib = self.cfg, self.buffer.data, self.lib
         th, m, v = self.policy.theta, self.adam_m, self.adam_v
         backup = (th.clone(), m.clone(), v.clone(), self.stale_sq.clone(), self.adam_step)
-        th1, m1, v1, stale1 = th.clone(), m.clone(), v.clone(), self.stale_sq.clone()
-        main, side = torch.cuda.current_stream(self.dev), st["stream"]
+        th1, m1, v1, stale1 = st["theta1"], st["m1"], st["v1"], st["stale1"]
+        th1.copy_(th); m1.copy_(m); v1.copy_(v); stale1.copy_(self.stale_sq)
         half = self.M // 2
         all_losses = []
         for it in range(c["learning_iters"]):
@@ -445,26 +420,18 @@ class CPOEngine(PPOLagEngine):
             p0, p1 = perm[:, :64].contiguous().view(-1), perm[:, 64:].contiguous().view(-1)
             l0 = torch.empty((n_mb, 3), dtype=torch.float32, device=self.dev)
             l1 = torch.empty_like(l0)
-            side.wait_stream(main)
-            step0 = st["step"] & 0xFFFFFFFF
-            _abi.check(lib.spo_critic_fit_iter_dp(
-                _abi.ptr(th), _abi.ptr(m), _abi.ptr(v), self.adam_step, _abi.ptr(d["obs"]), _abi.ptr(d["target_value_r"]),
-                _abi.ptr(d["target_value_c"]), _abi.ptr(p0), half, cfg64, _abi.ptr(self.stale_sq), _abi.ptr(l0),
-                _abi.ptr(self.sync_ws), 0, 2, st["regions"], step0, _abi.stream_ptr()), "spo_critic_fit_iter_dp")
-            with torch.cuda.stream(side):
-                _abi.check(lib.spo_critic_fit_iter_dp(
-                    _abi.ptr(th1), _abi.ptr(m1), _abi.ptr(v1), self.adam_step, _abi.ptr(d["obs"]), _abi.ptr(d["target_value_r"]),
-                    _abi.ptr(d["target_value_c"]), _abi.ptr(p1), half, cfg64, _abi.ptr(stale1), _abi.ptr(l1),
-                    _abi.ptr(st["sync_ws"]), 1, 2, st["regions"], step0, _abi.stream_ptr()), "spo_critic_fit_iter_dp")
-            main.wait_stream(side)
-            for t in (p1, l1, th1, m1, v1, stale1):
-                t.record_stream(side)
+            _abi.check(lib.spo_critic_fit_iter_split(
+                _abi.ptr(th), _abi.ptr(m), _abi.ptr(v), _abi.ptr(th1), _abi.ptr(m1), _abi.ptr(v1), self.adam_step,
+                _abi.ptr(d["obs"]), _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]), _abi.ptr(p0), _abi.ptr(p1), half,
+                cfg64, _abi.ptr(self.stale_sq), _abi.ptr(stale1), _abi.ptr(l0), _abi.ptr(l1), _abi.ptr(self.sync_ws),
+                _abi.ptr(st["sync_ws"]), st["regions"], st["step"] & 0xFFFFFFFF, _abi.stream_ptr()), "spo_critic_fit_iter_split")
             st["step"] += n_mb
             self.adam_step += n_mb
             all_losses.append(((l0 + l1) * 0.5)[:, :2])
         code = (int(self.sync_ws[8].item()) | int(st["sync_ws"][8].item())) & 0xFFFFFFFF
         if code:
-            # an exchange timed out (the two launches were not co-resident): back to the one-launch form for good
+            # an exchange timed out (cannot happen while the four workgroups are resident): restore, one-launch form for good
+            print(f"[cpo] split critic fit: exchange error {code}; falling back to the one-launch form", file=sys.stderr)
             self.sync_ws[8] = 0
             st["sync_ws"][8] = 0
             th.copy_(backup[0]); m.copy_(backup[1]); v.copy_(backup[2]); self.stale_sq.copy_(backup[3])

@@ -79,7 +79,11 @@ def smoke_check(verbose: bool = False, num_envs: int = 8, steps: int = 32, seed:
     # (update() ran the GAE kernel first; raw advantages were standardised in place -> recompute reference)
     sr, sc = R.adv_standardize(torch.from_numpy(o[0].reshape(-1)), torch.from_numpy(o[1].reshape(-1)))
     np.testing.assert_allclose(b.data["adv_r"].cpu().numpy().reshape(-1), sr.numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(b.data["adv_c"].cpu().numpy().reshape(-1), sc.numpy(), rtol=2e-5, atol=2e-6)
     np.testing.assert_array_equal(b.data["target_value_r"].cpu().numpy(), o[2])
+    np.testing.assert_array_equal(b.data["target_value_c"].cpu().numpy(), o[3])       # the cost side of the same scan
+    np.testing.assert_allclose(b.boot_c.cpu().numpy(), st["boot_c"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(b.data["value_c"].cpu().numpy(), st["v_c"], rtol=1e-4, atol=1e-5)
     assert b.last_scan_folded, "the engine path must run the folded form of the scan (spo_boundary_step_fold)"
     # oracle update on the same data / same shuffles
     M = eng.M

@@ -333,3 +333,21 @@ def test_evaluate_picks_the_newest_checkpoint_numerically(tmp_path):
     assert evaluate._latest(str(d), ".pkl") is None
     assert evaluate.MULTI_AGENT_ALGOS == ("macpo", "mappo", "mappolag", "happo")
 
+
+
+def test_bench_refuses_to_report_n_gpus_it_does_not_have():
+    """`python bench.py --gpus 8` without a launcher spawns its own ranks; on a box with fewer GPUs it must fail (exit
+    code 2, no JSON line) instead of benching one GPU under an `n_gpus: 1` label; a WORLD_SIZE that disagrees with
+    --gpus is refused too."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SPO_BENCH_ONE_GPU")}
+    env["HIP_VISIBLE_DEVICES"] = ""           # the check must not depend on what the test box has
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 2 and "only 0 GPU(s) are visible" in r.stderr and not r.stdout.strip()
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE=1" in r.stderr and not r.stdout.strip()

@@ -198,6 +198,88 @@ def test_gae_folded_form_is_bit_identical(dev, N, T, p):
     assert len(durs) == 5 and all(0.0 < d < 1e-2 for d in durs), durs
 
 
+def test_gae_fed_by_the_boundary_kernels_own_fold_full_size(dev):
+    """the scan fed with the fold arrays spo_boundary_step_fold ITSELF wrote (not a numpy-built fold) at
+    the headline size, random terminations / time-outs / final observations on every step: seg_end bit-equal to the
+    oracle's boundary logic, all four outputs bit-pattern-equal (<= 1 ulp on <= 1e-5 of the elements, the re-associated
+    fp64 carry) to the sequential reference scan on the device-held inputs, and the unfolded form on the same epoch
+    bit-identical to the folded one.  Then the API path on top of an engine-collected epoch: a
+    reference-style finish_path() and an in-place reward edit must both reach the scan."""
+    from safepo.common.engine import PPOLagEngine
+    from safepo.common.model import ActorVCritic
+    N, T, D, A = 4096, 128, 60, 8
+    torch.manual_seed(3)
+    pol = ActorVCritic(D, A).to(dev)
+    cfg = {"hidden_sizes": [64, 64], "gamma": 0.99, "target_kl": 0.02, "batch_size": 64, "learning_iters": 1, "max_grad_norm": 40.0}
+    eng = PPOLagEngine(pol, N, T, cfg, dev)
+    g = torch.Generator(device=dev).manual_seed(11)
+    rnd = lambda *sh: torch.randn(*sh, generator=g, device=dev)
+    uni = lambda *sh: torch.rand(*sh, generator=g, device=dev)
+    b = eng.buffer
+    b.data["value_r"].copy_(rnd(N, T)); b.data["value_c"].copy_(rnd(N, T))
+    segs, boots_r, boots_c = [], [], []
+    for t in range(T):
+        nobs, fobs = rnd(N, D), rnd(N, D)
+        rew, cost = rnd(N), (uni(N) < 0.1).float()
+        term, trunc = (uni(N) < 1 / 96).float(), (uni(N) < 1 / 64).float()
+        eng.post_step(t, nobs, rew, cost, term, trunc, fobs)
+        if t in (0, 63, T - 1):             # the oracle's boundary logic on the values the device used (spot-checked steps)
+            vn = (eng.vnext_r.cpu().numpy(), eng.vnext_c.cpu().numpy()) if t == T - 1 else (np.zeros(N, np.float32),) * 2
+            sg, br, bc = R.boundary_step(term.cpu().numpy(), trunc.cpu().numpy(), t == T - 1, vn[0], vn[1],
+                                         eng.vfinal_r.cpu().numpy(), eng.vfinal_c.cpu().numpy())
+            assert np.array_equal(b.seg_end[:, t].cpu().numpy(), np.asarray(sg).astype(np.uint8))
+            assert np.array_equal(b.boot_r[:, t].cpu().numpy(), np.asarray(br, np.float32))
+            assert np.array_equal(b.boot_c[:, t].cpu().numpy(), np.asarray(bc, np.float32))
+    assert b._fold_cols == T and b.ptr == T
+    host = lambda x: x.cpu().numpy()
+    inp = [host(b.data[k]) for k in ("reward", "cost", "value_r", "value_c")] + [host(b.seg_end).astype(bool), host(b.boot_r), host(b.boot_c)]
+    assert inp[4][:, -1].all() and 0.01 < inp[4].mean() < 0.05
+    # the fold the kernel wrote == the reference's first two roundings, bit for bit
+    g32 = np.float32(0.99)
+    for fold, r, bt in ((b.reward_fold, inp[0], inp[5]), (b.cost_fold, inp[1], inp[6])):
+        want = np.where(inp[4], (r + (g32 * bt).astype(np.float32)).astype(np.float32), r)
+        assert np.array_equal(host(fold).view(np.uint32), want.view(np.uint32))
+    ref = R.gae_dense(*inp, 0.99, 0.95, 0.95)
+    from safepo import _abi
+    d = b.data
+    outs = ("adv_r", "adv_c", "target_value_r", "target_value_c")
+    def scan(rew, cst, br, bc):
+        _abi.check(b._lib.spo_gae_fused(_abi.ptr(rew), _abi.ptr(cst), _abi.ptr(d["value_r"]), _abi.ptr(d["value_c"]), _abi.ptr(b.seg_end),
+                                        _abi.ptr(br), _abi.ptr(bc), *[_abi.ptr(d[k]) for k in outs], _abi.ptr(b._partials), N, T,
+                                        0.99, 0.95, 0.95, _abi.stream_ptr()), "gae")
+        torch.cuda.synchronize()
+        return tuple(host(d[k]).copy() for k in outs)
+    folded = scan(b.reward_fold, b.cost_fold, None, None)
+    _assert_gae_close(folded, ref, "boundary kernel's fold -> scan, 4096x128")
+    plain = scan(d["reward"], d["cost"], b.boot_r, b.boot_c)
+    for f, u in zip(folded, plain):
+        assert np.array_equal(f.view(np.uint32), u.view(np.uint32))
+    # engine entry: compute_gae picks the folded form; targets are untouched by the standardisation
+    b.compute_gae(None)
+    assert b.last_scan_folded
+    assert np.array_equal(host(d["target_value_c"]).view(np.uint32), folded[3].view(np.uint32))
+    # API calls on top of the engine-collected epoch: a new bootstrap value through finish_path ...
+    b.path_start_idx_list = [0] * N
+    b.finish_path(torch.tensor([1.5]), torch.tensor([-0.25]), idx=7)
+    b.compute_gae(None)
+    assert not b.last_scan_folded, "finish_path() must invalidate the folded arrays"
+    inp2 = [x.copy() for x in inp]
+    inp2[5][7, T - 1], inp2[6][7, T - 1] = 1.5, -0.25
+    ref2 = R.gae_dense(*[x[7:8] for x in inp2], 0.99, 0.95, 0.95)
+    assert np.array_equal(host(d["target_value_r"])[7:8].view(np.uint32), ref2[2].view(np.uint32)) or \
+        _ulp_diff(host(d["target_value_r"])[7:8], ref2[2]).max() <= 1
+    assert abs(host(d["target_value_r"])[7, T - 1] - folded[2][7, T - 1]) > 1e-3       # the new bootstrap really arrived
+    # ... and an in-place reward edit (reward shaping) with force_unfolded
+    eng2_fold = b._fold_cols
+    b._fold_cols = T                                # as if the epoch were still folded
+    d["reward"][5].add_(1.0)
+    b.compute_gae(None, force_unfolded=True)
+    inp3 = [x.copy() for x in inp2]
+    inp3[0][5] += np.float32(1.0)
+    ref3 = R.gae_dense(*[x[5:6] for x in inp3], 0.99, 0.95, 0.95)
+    assert _ulp_diff(host(d["target_value_r"])[5:6], ref3[2]).max() <= 1
+
+
 def test_gae_segment_mask_edge_cases(dev):
     # every step ends a path / single long path / all-terminated bootstraps / -0.0 deltas
     N, T = 9, 64
@@ -816,6 +898,144 @@ def test_cpo_critic_fit_two_launch_form_vs_oracle_and_one_launch_form(dev, monke
     want = torch.cat([p.detach().reshape(-1) for p in ref.parameters()]).numpy()
     n_crit = th_split.numel() - (n_act)
     _assert_params_close(th_split.numpy()[:n_crit], want[:n_crit], 1e-3, iters * (M // 128), rtol=2e-3, atol=2e-5, what="split vs oracle")
+
+
+def test_cpo_full_size_surrogate_gradients_and_fvp_fp64_yardstick(dev):
+    """BASELINE config 3 at ITS size: the two surrogate gradients and one Fisher-vector product over all
+    4096 x 128 = 524 288 rows -- the shape the 821 k env-steps/s line runs (256 workgroups x 2048 rows, per-workgroup
+    partial vectors, fixed-order reduction) -- against the oracle's autograd / double backward (cpo.py:132-157, 356-378) in
+    float64 (yardstick) and float32 (the reference's arithmetic): |HIP - f64| <= 3 |f32 - f64| + floor."""
+    import copy
+    from safepo.single_agent.cpo import CPOEngine, default_cfg
+    from safepo.common.model import ActorVCritic
+    torch.set_num_threads(8)
+    torch.manual_seed(31)
+    N, T, D, A = 4096, 128, 60, 8
+    M = N * T
+    pol = ActorVCritic(D, A).to(dev)
+    with torch.no_grad():
+        pol.actor.log_std.copy_(torch.randn(A) * 0.2)
+    eng = CPOEngine(pol, N, T, dict(default_cfg), dev)
+    obs, act, logp, _, _, adv = _synthetic_update_problem(M, D, A, seed=33)
+    adv_c = adv.flip(0) * 0.5 + 0.1
+    b = eng.buffer
+    b.data["obs"].copy_(obs.view(N, T, D)); b.data["act"].copy_(act.view(N, T, A)); b.data["log_prob"].copy_(logp.view(N, T))
+    b.data["adv_r"].copy_(adv.view(N, T)); b.data["adv_c"].copy_(adv_c.view(N, T))
+    ref32 = R.OraclePolicy(D, A)
+    ref32.load_state_dict({k: v.cpu().clone() for k, v in pol.state_dict().items()})
+    ref64 = copy.deepcopy(ref32).double()
+    data32 = {"obs": obs, "act": act, "log_prob": logp, "adv_r": adv, "adv_c": adv_c}
+    data64 = {k: v.double() for k, v in data32.items()}
+
+    def gate(name, hip, v32, v64, floor_rel=2e-7):
+        hip, v32, v64 = (np.asarray(x, np.float64).reshape(-1) for x in (hip, v32, v64))
+        d_hip, d_32 = np.linalg.norm(hip - v64), np.linalg.norm(v32 - v64)
+        floor = floor_rel * np.abs(v64).max() * np.sqrt(v64.size)
+        print(f"cpo full size {name}: |hip-f64| {d_hip:.3e}  |f32-f64| {d_32:.3e}  floor {floor:.3e}  |f64| {np.linalg.norm(v64):.3e}")
+        assert d_hip <= 3.0 * d_32 + floor, (name, d_hip, d_32, floor)
+        assert np.abs(hip - v64).max() <= 3.0 * np.abs(v32 - v64).max() + floor_rel * np.abs(v64).max() * 8, name
+
+    for which, key, sign in (("r", "adv_r", -1.0), ("c", "adv_c", 1.0)):
+        outs = []
+        for ref, data in ((ref32, data32), (ref64, data64)):
+            ref.actor.zero_grad()
+            loss = R.cpo_surrogate(ref, data, which)
+            loss.backward()
+            outs.append((R.actor_flat_grads(ref.actor).double().numpy().copy(), float(loss.detach())))
+        g, mean = eng.surrogate_grad(b.data[key], sign)
+        gate(f"surrogate gradient {which}", g.cpu().numpy(), outs[0][0], outs[1][0])
+        d_h, d_32 = abs(sign * mean - outs[1][1]), abs(outs[0][1] - outs[1][1])
+        assert d_h <= 3.0 * d_32 + 1e-7 * max(abs(outs[1][1]), 1e-3), (which, sign * mean, outs)
+    v = torch.randn(eng.Pa, generator=torch.Generator().manual_seed(5))
+    hv32 = R.cpo_fvp(v, ref32, obs).double().numpy()
+    hv64 = R.cpo_fvp(v.double(), ref64, obs.double()).numpy()
+    gate("Fisher-vector product", eng.fvp(v.to(dev)).cpu().numpy(), hv32, hv64)
+    # the same product again (workspace reuse) and linearity: H(2v) == 2 H(v) to rounding
+    h1 = eng.fvp(v.to(dev)); h2 = eng.fvp((2 * v).to(dev))
+    assert torch.equal(h1, eng.fvp(v.to(dev)))
+    np.testing.assert_allclose(h2.cpu().numpy(), 2 * h1.cpu().numpy(), rtol=1e-5, atol=1e-7 * float(h1.abs().max()))
+
+
+def _oracle_critic_trajectory(sd, obs, tgt_r, tgt_c, perm, batch, nsteps, dtype, checkpoints, stale_norm):
+    """`nsteps` consecutive critic-fit steps of the oracle (R.CriticFitter, cpo.py:541-571) in `dtype`; the actor's stale
+    gradient has norm `stale_norm`.  Returns (losses [nsteps, 2], {k: critic parameters after k steps}) as float64."""
+    D, A = obs.shape[1], sd["actor.log_std"].shape[0]
+    ref = R.OraclePolicy(D, A)
+    ref.load_state_dict({k: v.detach().cpu().clone() for k, v in sd.items()})
+    ref = ref.to(dtype)
+    n_act = sum(p.numel() for p in ref.actor.parameters())
+    for p_ in ref.actor.parameters():
+        p_.grad = torch.full_like(p_, stale_norm / np.sqrt(n_act))
+    fitter = R.CriticFitter(ref)
+    obs, tgt_r, tgt_c = obs.to(dtype), tgt_r.to(dtype), tgt_c.to(dtype)
+    perm = torch.as_tensor(perm, dtype=torch.long)
+    losses, thetas = np.zeros((nsteps, 2)), {}
+    crit = lambda: torch.cat([p_.detach().reshape(-1) for p_ in list(ref.reward_critic.parameters()) + list(ref.cost_critic.parameters())])
+    for s_ in range(nsteps):
+        ii = perm[s_ * batch:(s_ + 1) * batch]
+        losses[s_] = fitter.minibatch_step(obs[ii], tgt_r[ii], tgt_c[ii])
+        if (s_ + 1) in checkpoints:
+            thetas[s_ + 1] = crit().double().numpy().copy()
+    return losses, thetas
+
+
+_CRITIC_ENVELOPE_CACHE = {}
+
+
+@pytest.mark.parametrize("form", ["split_one_grid", "one_launch"])
+def test_cpo_full_size_critic_fit_drift_envelope(dev, form, monkeypatch):
+    """BASELINE config 3's critic fit at its size: ONE persistent launch of 4096 steps of 128 rows over
+    the 4096 x 128 buffer (cpo.py:534-571, stale actor gradient of norm 50 in the joint clip), in the split form (two
+    workgroup pairs of one grid, 64 of every 128 rows each) and in the one-launch form, under the same drift envelope as
+    the PPO-Lagrangian step: per-step losses and the critics' parameters after 8 / 64 / 512 / 4096 steps may be at most
+    3x as far from the oracle's float64 trajectory as the oracle's float32 trajectory is; first 8 steps at 1e-5."""
+    import envelope as E
+    from safepo.single_agent.cpo import CPOEngine, default_cfg
+    from safepo.common.model import ActorVCritic
+    monkeypatch.setenv("SPO_CPO_SPLIT", "1" if form == "split_one_grid" else "0")
+    torch.set_num_threads(8)
+    N, T, D, A, batch = 4096, 128, 60, 8, 128
+    M = N * T
+    ks = (8, 64, 512, 4096)
+    obs, _a, _l, tgt_r, tgt_c, _adv = _synthetic_update_problem(M, D, A, seed=41)
+    perm = torch.randperm(M, generator=torch.Generator().manual_seed(6)).to(torch.int32)
+    torch.manual_seed(17)
+    pol = ActorVCritic(D, A).to(dev)
+    cfg = dict(default_cfg)
+    cfg.update(learning_iters=1, batch_size=batch)
+    eng = CPOEngine(pol, N, T, cfg, dev)
+    bd = eng.buffer.data
+    bd["obs"].copy_(obs.view(N, T, D)); bd["target_value_r"].copy_(tgt_r.view(N, T)); bd["target_value_c"].copy_(tgt_c.view(N, T))
+    sd0 = {k: v.detach().cpu().clone() for k, v in pol.state_dict().items()}
+    theta0 = pol.theta.clone()
+    perm_dev = perm.to(dev)
+    n_crit = pol.log_std_offset                      # reward critic + cost critic come first in the flat vector
+    hip = {}
+    for k in ks:
+        pol.theta.copy_(theta0); eng.adam_m.zero_(); eng.adam_v.zero_(); eng.adam_step = 0
+        eng.stale_sq.fill_(2500.0)
+        eng.M = k * batch
+        fit = eng.critic_fit(perm_fn=lambda it: perm_dev[:k * batch].contiguous())
+        assert (eng._split is not False and eng._split is not None) == (form == "split_one_grid")
+        hip[k] = (pol.theta[:n_crit].double().cpu().numpy(), torch.cat(fit["losses"], 0).double().cpu().numpy())
+    eng.M = M
+    kmax = max(ks)
+    if "traj" not in _CRITIC_ENVELOPE_CACHE:             # same seeds in both parametrisations: the oracle runs once
+        _CRITIC_ENVELOPE_CACHE["traj"] = (
+            _oracle_critic_trajectory(sd0, obs, tgt_r, tgt_c, perm, batch, kmax, torch.float32, ks, 50.0),
+            _oracle_critic_trajectory(sd0, obs, tgt_r, tgt_c, perm, batch, kmax, torch.float64, ks, 50.0),
+            {k: v.clone() for k, v in sd0.items()})
+    (l32, t32), (l64, t64), sd_c = _CRITIC_ENVELOPE_CACHE["traj"]
+    assert all(torch.equal(sd_c[k], sd0[k]) for k in sd0)
+    lh = hip[kmax][1]
+    np.testing.assert_allclose(lh[:8], l32[:8], rtol=1e-5, atol=1e-6, err_msg=f"{form}: first 8 critic-fit steps")
+    r_loss = E.assert_loss_envelope(lh, l32, l64, f"critic fit ({form})")
+    rep = {}
+    for k in ks:
+        assert np.array_equal(hip[k][1], lh[:k]), f"{form}: the {k}-step launch is not a prefix of the {kmax}-step launch"
+        rep[k] = E.assert_theta_envelope(hip[k][0], t32[k], t64[k], f"critic fit ({form}): critics after {k} steps")
+    print(f"critic fit envelope ({form}): loss ratio {r_loss:.2f}; theta " +
+          "; ".join(f"k={k}: ratio {rep[k][0]:.2f} |hip-f64| {rep[k][1]['l2_hip']:.2e} |f32-f64| {rep[k][1]['l2_f32']:.2e}" for k in ks))
 
 
 def test_cpo_main_entrypoint_synthetic(dev, tmp_path):

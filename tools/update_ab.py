@@ -48,6 +48,7 @@ for lib in libs:
     env = dict(os.environ)
     if lib:
         env["SPO_LIB_PATH"] = os.path.abspath(lib)
+        env["SPO_LIB_OVERRIDE"] = "1"
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one"], env=env, capture_output=True, text=True)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if not line:
