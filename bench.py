@@ -92,6 +92,43 @@ def cpu_baseline(sample_envs: int, T: int, threads: int = 4, algo: str = "ppo_la
             "reference_recorded": recorded_reference(algo)}
 
 
+FP32_MATRIX_PEAK_TFLOPS = 157.3          # dense FP32 MFMA (= packed-FP32 VALU) peak of one MI355X (MI355X_MICROARCH.md)
+
+
+def time_fp32_kernel(fn, flops, reps, name, dev):
+    """Average device time of `fn` (one launch of an FP32-matrix-bound full-batch kernel + its tiny reduction) over `reps`
+    back-to-back calls between two HIP events on the launch stream; 3 warm-up calls first."""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    tf = flops / (us * 1e-6) / 1e12
+    return {"kernel": name, "bound": "mfma", "flops_per_launch": flops, "avg_us": round(us, 2), "achieved": round(tf, 2),
+            "unit": "TFLOP/s", "peak": FP32_MATRIX_PEAK_TFLOPS, "frac": round(tf / FP32_MATRIX_PEAK_TFLOPS, 4),
+            "note": f"{reps} back-to-back calls of the entry point between two HIP events on the launch stream (the full-batch kernel "
+                    "+ its small fixed-order reduction kernel; no host synchronisation inside)"}
+
+
+def fvp_entry(eng, N, T, D, A, dev):
+    """Roofline entry of the Fisher-vector product (cpo.py:132-157; 33 per epoch): algorithmic flops of the analytic J^T M J
+    form = actor forward + tangent forward + backward (input and weight gradients) = 4 x the forward's 2*(D*64+64*64+64*A) per row."""
+    from safepo import _abi
+    v = torch.randn(eng.Pa, device=dev)
+    out = torch.empty_like(v)
+
+    def fvp_launch():               # eng.fvp() without its three small torch vector ops
+        _abi.check(eng.lib.spo_cpo_fvp(_abi.ptr(eng.policy.theta), _abi.ptr(eng.buffer.data["obs"]), _abi.ptr(v), eng.M, D, A,
+                                       _abi.ptr(eng.partial_ws), _abi.ptr(eng.loss_ws), _abi.ptr(out), _abi.stream_ptr()), "spo_cpo_fvp")
+    return time_fp32_kernel(fvp_launch, 4 * 2.0 * (D * 64 + 64 * 64 + 64 * A) * N * T, 20,
+                            "cpo_actor_kernel<64,MODE_FVP> + fixed-order reduction (spo_cpo_fvp)", dev)
+
+
 def _lib_note():
     """Which libsafepo_hip.so the run used: 'in-tree' or the absolute path of an SPO_LIB_PATH override."""
     from safepo import _abi
@@ -395,6 +432,22 @@ def main():
         faithful = {"target_kl": 0.02, "stop_iter": out_f["stop_iter"], "kl": out_f["kl"], "s_per_epoch": round(r_f + u_f, 4),
                     "env_steps_per_s": round(N * T / (r_f + u_f), 1)}
 
+    # FP32-matrix-bound kernels of the path: the full-batch KL of the early-stop test.  Algorithmic flops =
+    # the actor forward, 2 * (D*64 + 64*64 + 64*A) per row; peak = the dense FP32 matrix rate (MI355X_MICROARCH.md)
+    kl_entry = None
+    if a.algo == "cpo" and world == 1:
+        kl_entry = fvp_entry(eng, N, T, D, A, dev)        # --algo cpo: the Fisher-vector product takes this slot
+    if a.algo == "ppo_lag" and world == 1:
+        from safepo import _abi
+
+        def kl_launch():            # the launches of eng.kl_to_old() without its host read-back of the sum
+            _abi.check(eng.lib.spo_actor_kl(_abi.ptr(eng.policy.theta), _abi.ptr(eng.buffer.data["obs"]), _abi.ptr(eng.mean_old),
+                                            _abi.ptr(eng.logstd_old), _abi.ptr(eng.kl_partials), eng.kl_partials.numel(),
+                                            _abi.ptr(eng.kl_sum), eng.M, D, A, _abi.stream_ptr()), "spo_actor_kl")
+        kl_entry = time_fp32_kernel(kl_launch, 2.0 * (D * 64 + 64 * 64 + 64 * A) * N * T, 20,
+                                    "actor_full_kernel<64,1> (spo_actor_kl: full-batch actor forward + KL(old || new), "
+                                    "ppo_lag.py:338-345)", dev)
+
     cpu = None
     if world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.cpu_sample_envs if a.algo == "ppo_lag" else a.cpo_cpu_sample_envs, T, algo=a.algo)
@@ -419,6 +472,7 @@ def main():
                        "acceptance_step": r3["last"]["stop_iter"], "kl": r3["last"]["kl"],
                        "critic_fit_form": ("one persistent launch, two workgroup pairs (64 of every 128 rows each) exchanging in-kernel"
                                            if getattr(r3["eng"], "_split", None) else "one persistent launch")}
+            config3["cpo_fvp"] = fvp_entry(r3["eng"], N, T, D, A, dev)
             if not a.no_cpu_baseline:
                 config3["cpu_baseline"] = cpu_baseline(a.cpo_cpu_sample_envs, T, algo="cpo")
                 config3["speedup_vs_cpu_baseline"] = round(v3 / config3["cpu_baseline"]["value"], 1)
@@ -456,6 +510,7 @@ def main():
                            "frac": round((368 * 32 / 2.4e9) / (us_step * 1e-6), 4),
                            "note": "floor = MFMA issue cycles at 2.4 GHz; DESIGN.md 3.3 has the instruction mix"}
                           if a.algo == "ppo_lag" else None),
+        ("kl_kernel" if a.algo == "ppo_lag" else "cpo_fvp"): kl_entry,
         "cpu_baseline": cpu,
         "config3_cpo": config3,
         "library": _lib_note(),

@@ -304,10 +304,21 @@ __global__ __launch_bounds__(256, 1) void cpo_actor_kernel(CpoArgs a) {
 // out[i] = post_scale * sum_k partial[k][i] (+ diag terms of the FVP on the host side); fixed order.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* partial, int nparts, int P, float* out,
                                                               const double* ploss, double* loss_out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < P) {
+    // sequential in k (the order every earlier round used: bit-identical sums), but sixteen loads are in flight before the
+    // first of them is added -- one exposed memory latency per sixteen partials instead of one per partial (61 -> ~8 us for
+    // 256 partial vectors of 8 592 floats)
     float acc = 0.f;
-    for (int k = 0; k < nparts; ++k) acc += partial[(int64_t)k * P + i];
+    int k = 0;
+    for (; k + 16 <= nparts; k += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = partial[(int64_t)(k + u) * P + i];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc += v[u];
+    }
+    for (; k < nparts; ++k) acc += partial[(int64_t)k * P + i];
     out[i] = acc;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && loss_out) {
@@ -433,7 +444,7 @@ extern "C" int spo_cpo_surrogate_grad(const float* theta, const float* obs, cons
   hipStream_t st = (hipStream_t)stream;
   if (int rc = launch_cpo<MODE_SURR>(a, blocks, st)) return rc;
   const int Pa = spo::actor_size(obs_dim, act_dim);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((Pa + 255) / 256), dim3(256), 0, st, partial_ws, blocks, Pa, grad_out,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((Pa + 63) / 64), dim3(64), 0, st, partial_ws, blocks, Pa, grad_out,
                      loss_ws, loss_sum_out);
   SPO_LAUNCH_CHECK("spo_cpo_surrogate_grad");
   return 0;
@@ -448,7 +459,7 @@ extern "C" int spo_cpo_fvp(const float* theta, const float* obs, const float* ve
   hipStream_t st = (hipStream_t)stream;
   if (int rc = launch_cpo<MODE_FVP>(a, blocks, st)) return rc;
   const int Pa = spo::actor_size(obs_dim, act_dim);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((Pa + 255) / 256), dim3(256), 0, st, partial_ws, blocks, Pa, out,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((Pa + 63) / 64), dim3(64), 0, st, partial_ws, blocks, Pa, out,
                      loss_ws, (double*)nullptr);
   SPO_LAUNCH_CHECK("spo_cpo_fvp");
   return 0;

@@ -168,6 +168,36 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // Hidden layer: out[mt] (rows 16mt+4q+reg, col batch) = tanh?(W in + b).  The four output tiles
 // are independent accumulators and are issued round-robin so back-to-back MFMAs never wait on the
 // 40-cycle dependent-accumulator latency of v_mfma_f32_16x16x4_f32.
+// Single-buffered form for throughput kernels that run two or more waves per SIMD (the partner wave covers the LDS latency;
+// 16 registers fewer than the double-buffered layer_hidden below): A tiles of one k-group at a time.
+template <int NT_IN, bool TANH>
+__device__ __forceinline__ void layer_hidden_lean(const float* Wl, int ld, const float* bl, const f4 (&in)[NT_IN],
+                                                  f4 (&out)[HID / 16], int j, int q) {
+  f4 acc[HID / 16];
+#pragma unroll
+  for (int mt = 0; mt < HID / 16; ++mt) acc[mt] = *reinterpret_cast<const f4*>(bl + 16 * mt + 4 * q);
+#pragma unroll
+  for (int nt = 0; nt < NT_IN; ++nt) {
+    f4 a[HID / 16];
+#pragma unroll
+    for (int mt = 0; mt < HID / 16; ++mt) a[mt] = *reinterpret_cast<const f4*>(Wl + (16 * mt + j) * ld + 16 * nt + 4 * q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int mt = 0; mt < HID / 16; ++mt) acc[mt] = mfma4(a[mt][r], in[nt][r], acc[mt]);
+    __builtin_amdgcn_sched_barrier(0);      // keep the next groups' operand reads out of this group's register budget
+  }
+#pragma unroll
+  for (int mt = 0; mt < HID / 16; ++mt) {
+    if (TANH) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[mt][r] = fast_tanh(acc[mt][r]);
+      __builtin_amdgcn_sched_barrier(0);    // four tanh chains in flight at a time, not sixteen
+    }
+    out[mt] = acc[mt];
+  }
+}
+
 template <int NT_IN, bool TANH>
 __device__ __forceinline__ void layer_hidden(const float* Wl, int ld, const float* bl, const f4 (&in)[NT_IN],
                                              f4 (&out)[HID / 16], int j, int q) {
@@ -254,6 +284,16 @@ __device__ __forceinline__ f4 net_forward(const float* lds_net, const f4 (&x)[KI
   using L = NetLds<KIN>;
   layer_hidden<KIN / 16, true>(lds_net + L::W1, L::LD1, lds_net + L::B1, x, h1, j, q);
   layer_hidden<4, true>(lds_net + L::W2, LDH, lds_net + L::B2, h1, h2, j, q);
+  return layer_out(lds_net + L::W3, lds_net + L::B3, h2, j, q);
+}
+
+// net_forward on the single-buffered layers (same arithmetic, same order: bit-identical results)
+template <int KIN>
+__device__ __forceinline__ f4 net_forward_lean(const float* lds_net, const f4 (&x)[KIN / 16], int j, int q) {
+  using L = NetLds<KIN>;
+  f4 h1[4], h2[4];
+  layer_hidden_lean<KIN / 16, true>(lds_net + L::W1, L::LD1, lds_net + L::B1, x, h1, j, q);
+  layer_hidden_lean<4, true>(lds_net + L::W2, LDH, lds_net + L::B2, h1, h2, j, q);
   return layer_out(lds_net + L::W3, lds_net + L::B3, h2, j, q);
 }
 

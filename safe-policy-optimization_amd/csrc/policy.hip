@@ -144,6 +144,12 @@ struct KlArgs {
 };
 
 // MODE 0: write means; MODE 1: accumulate KL(old || new).sum(-1) over rows.
+// Full-batch actor forward (ppo_lag.py:277,338-345): FP32-matrix bound (16.9 kFLOP per row against 240 B of observation).
+// A wave walks 16-row tiles; three waves share a SIMD (net_forward_lean keeps the kernel at 112-140 registers; rounds 1-2
+// used 293, i.e. ONE wave per SIMD, so a tile's load latency, its 144 MFMAs and its 32 tanh ran strictly one after the other:
+// 0.29 of the FP32 matrix peak), so one wave's tanh / KL arithmetic runs beside the others' MFMAs, and the next tile's
+// observation rows are requested before the current tile is computed (raw loads, masked at pick-up).  The grid is
+// persistent (three workgroups per CU: 3 x 39.7 KB of LDS): the network is staged once per workgroup.
 template <int KIN, int MODE>
 __global__ __launch_bounds__(256) void actor_full_kernel(KlArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[NetLds<KIN>::SIZE];
@@ -162,14 +168,34 @@ __global__ __launch_bounds__(256) void actor_full_kernel(KlArgs a) {
   }
   double acc = 0.0;
   const int64_t ntiles = (a.rows + 15) / 16;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  f4 xn[KIN / 16];
+  {
+    const int64_t r0 = tile * 16 + j;
+    load_obs_tiles_raw<KIN>(a.obs + (r0 < a.rows ? r0 : a.rows - 1) * D, D, q, xn);
+  }
+  for (; tile < ntiles; tile += stride) {
     const int64_t row = tile * 16 + j;
     const bool valid = row < a.rows;
     const int64_t rrow = valid ? row : a.rows - 1;
     f4 x[KIN / 16];
-    load_obs_tiles<KIN>(a.obs + rrow * D, D, q, x);
-    f4 h1[4], h2[4];
-    const f4 mu = net_forward<KIN>(lds, x, h1, h2, j, q);
+#pragma unroll
+    for (int nt = 0; nt < KIN / 16; ++nt) x[nt] = xn[nt];
+    mask_obs_tiles<KIN>(D, q, x);
+    float mo[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ai = 4 * q + r;
+        mo[r] = a.mean_old[rrow * A + (ai < A ? ai : 0)];          // unconditional (clamped) loads, used after the forward
+      }
+    }
+    {
+      const int64_t nrow = (tile + stride) * 16 + j;                // next tile of this wave (clamped: a harmless re-read at the end)
+      load_obs_tiles_raw<KIN>(a.obs + (nrow < a.rows ? nrow : a.rows - 1) * D, D, q, xn);
+    }
+    const f4 mu = net_forward_lean<KIN>(lds, x, j, q);
     if (MODE == 0) {
       if (valid) {
 #pragma unroll
@@ -184,7 +210,7 @@ __global__ __launch_bounds__(256) void actor_full_kernel(KlArgs a) {
           // torch.distributions.kl._kl_normal_normal(p=old, q=new)
           const float ratio = sd_old[r] / sd_new[r];
           const float var_ratio = ratio * ratio;
-          const float dm = (a.mean_old[rrow * A + ai] - mu[r]) / sd_new[r];
+          const float dm = (mo[r] - mu[r]) / sd_new[r];
           const float t1 = dm * dm;
           kl += 0.5f * (var_ratio + t1 - 1.f - logf(var_ratio));
         }
@@ -396,6 +422,7 @@ int launch_step(const StepArgs& a, hipStream_t st) {
   return 0;
 }
 
+constexpr int FULL_GRID = 768;          // actor_full_kernel: three resident workgroups on each of the 256 CUs
 template <int MODE>
 int launch_full(const KlArgs& a, unsigned blocks, hipStream_t st) {
   switch (pick_kin(a.D)) {
@@ -529,7 +556,7 @@ extern "C" int spo_actor_mean(const float* theta, const float* obs, float* mean_
   SPO_REQUIRE(theta && obs && mean_out && rows > 0, "actor_mean: bad args");
   KlArgs a{theta, obs, nullptr, nullptr, mean_out, nullptr, rows, obs_dim, act_dim};
   int64_t blocks = (rows + 63) / 64;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > FULL_GRID) blocks = FULL_GRID;
   launch_full<0>(a, (unsigned)blocks, (hipStream_t)stream);
   SPO_LAUNCH_CHECK("spo_actor_mean");
   return 0;
@@ -541,7 +568,7 @@ extern "C" int spo_actor_kl(const float* theta, const float* obs, const float* m
   if (int rc = check_dims(obs_dim, act_dim)) return rc;
   SPO_REQUIRE(theta && obs && mean_old && log_std_old && kl_partials && kl_sum && rows > 0, "actor_kl: bad args");
   int64_t blocks = (rows + 63) / 64;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > FULL_GRID) blocks = FULL_GRID;
   if (blocks > kl_partials_capacity) blocks = kl_partials_capacity;
   SPO_REQUIRE(blocks >= 1, "actor_kl: partials capacity must be >= 1");
   KlArgs a{theta, obs, mean_old, log_std_old, nullptr, kl_partials, rows, obs_dim, act_dim};

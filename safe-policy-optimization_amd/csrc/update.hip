@@ -348,6 +348,88 @@ __device__ __forceinline__ void xr_allreduce_rd(const u64* regions, int me, int 
   for (int v = 0; v < NV; ++v) pk[v] *= inv_world;
 }
 
+// The same recursive doubling with PACKED words (round 3): three gradient floats and the tag travel in one 16-byte
+// {f0, f1, f2, tag} word written by one system-scope write-through global_store_dwordx4 (a lane's aligned 16-byte store
+// lands in one memory line as a unit, like the 8-byte words above), so a lane moves ceil(4 NV / 3) words of 16 bytes per
+// round instead of 4 NV words of 8: 15 stores and 15 polling loads instead of 44 for the 60-wide network, 133 KB per rank and
+// step instead of 199 KB.  Word w of lane t sits at slot + (w * 256 + t) * 16 bytes: a wave's store covers 1 KB contiguous.
+#ifndef SPO_XR_PACK16
+#define SPO_XR_PACK16 1        // 0: the 8-byte {tag, value} words of rounds 1-2 (A/B knob; the self-test uses the same form)
+#endif
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st16_sys(char* p, const u4v v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#endif
+}
+__device__ __forceinline__ u4v ld16_sys(const char* p) {
+  u4v v = {0u, 0u, 0u, 0u};
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+#endif
+  return v;
+}
+template <int NV, int VB = 5>                                    // VB: packed words polled together
+__device__ __forceinline__ void xr_allreduce_rd16(const u64* regions, int me, int R, int net, int tid, unsigned gtag,
+                                                  f4 (&pk)[NV], volatile float* dead_word, int* err) {
+  constexpr int NF = 4 * NV, NW = (NF + 2) / 3;
+  static_assert((size_t)NW * 256 * 16 <= XR_SLOT_WORDS * 8, "packed rows must fit the slot");
+  const int par = (int)(gtag & 1u);
+#pragma unroll 1
+  for (int k = 0; (1 << k) < R; ++k) {
+    const int peer = me ^ (1 << k);
+    const size_t slot_b = (((size_t)(par * XR_MAX_WORLD + k) * 3 + net) * XR_SLOT_WORDS) * 8 + (size_t)tid * 16;
+    char* const p = reinterpret_cast<char*>(regions[peer]) + slot_b;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      u4v word;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int f = 3 * w + i;
+        word[i] = f < NF ? __float_as_uint(pk[(f < NF ? f : 0) >> 2][(f < NF ? f : 0) & 3]) : 0u;
+      }
+      word[3] = gtag;
+      st16_sys(p + (size_t)w * 4096, word);
+    }
+    const char* const src = reinterpret_cast<const char*>(regions[me]) + slot_b;
+#pragma unroll
+    for (int w0 = 0; w0 < NW; w0 += VB) {
+      u4v x[VB];
+      unsigned spins = 0;
+      for (;;) {
+#pragma unroll
+        for (int vv = 0; vv < VB; ++vv)
+          if (w0 + vv < NW) x[vv] = ld16_sys(src + (size_t)(w0 + vv) * 4096);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        bool ok = true;
+#pragma unroll
+        for (int vv = 0; vv < VB; ++vv)
+          if (w0 + vv < NW) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(x[vv]));                         // the asm outputs are valid only after the wait
+#endif
+            ok = ok && (x[vv][3] == gtag);
+          }
+        if (ok || *dead_word != 0.f) break;
+        if (++spins > XR_SPIN_LIMIT) { *err = 2; *dead_word = 1.f; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int vv = 0; vv < VB; ++vv)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int f = 3 * (w0 + vv) + i;
+          if (w0 + vv < NW && f < NF) pk[f >> 2][f & 3] += __uint_as_float(x[vv][i]);
+        }
+    }
+  }
+  const float inv_world = 1.f / (float)R;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) pk[v] *= inv_world;
+}
+
 // AMODE: actor loss.  0 = PPO clipped surrogate (ppo_lag.py:316-319; clip = 1e30 gives the plain policy gradient);
 //        1 = KL-penalty form shared by FOCOPS (focops.py:326-337) and CUP's second stage (cup.py:372-383):
 //            loss = mean_i(ind_i * KL_i) - pg_coef * mean_i(ind_i) * mean_j(ratio_j * adv_j),
@@ -840,7 +922,9 @@ __device__ __forceinline__ void ppo_update_body(const UpdArgs& a, const int wg) 
       pk[NT1 + 4] = aW3; pk[NT1 + 5] = f4{db1, db2, db3, 0.f}; pk[NT1 + 6] = dls;
       const u64* const xr_tab = reinterpret_cast<const u64*>(red + 144);
       const unsigned gtag = a.xr_step0 + (unsigned)s + 1u;
-      if (XR == 2)
+      if (XR == 2 && SPO_XR_PACK16)
+        xr_allreduce_rd16<NV>(xr_tab, a.xr_rank, a.xr_world, net, tid, gtag, pk, red + 112, a.err);
+      else if (XR == 2)
         xr_allreduce_rd<NV>(xr_tab, a.xr_rank, a.xr_world, net, tid, gtag, pk, red + 112, a.err);
       else
         xr_allreduce<NV>(xr_tab, a.xr_rank, a.xr_world, net, tid, gtag, pk, red + 112, a.err);
@@ -2307,7 +2391,10 @@ __global__ __launch_bounds__(256, 1) void xr_selftest_kernel(int rank, int world
       const float c = (float)((gtag + 3u * v + tid + 5u * net) & 15u);
       pk[v] = f4{(float)(rank + 1) + c, (float)(rank + 1) - c, c, (float)(rank + 1) * 2.f};
     }
-    if (a.xr_algo == 1 && (world & (world - 1)) == 0) xr_allreduce_rd<11>(regions, rank, world, net, tid, gtag, pk, &dead, result + 1);
+    if (a.xr_algo == 1 && (world & (world - 1)) == 0) {
+      if (SPO_XR_PACK16) xr_allreduce_rd16<11>(regions, rank, world, net, tid, gtag, pk, &dead, result + 1);
+      else xr_allreduce_rd<11>(regions, rank, world, net, tid, gtag, pk, &dead, result + 1);
+    }
     else xr_allreduce<11, true>(regions, rank, world, net, tid, gtag, pk, &dead, result + 1);
     const float tri = 0.5f * (float)(world + 1);
 #pragma unroll
