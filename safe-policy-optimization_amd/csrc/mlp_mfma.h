@@ -165,6 +165,43 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return copysignf(a < 0.125f ? small : big, x);
 }
 
+// Two values at a time on the packed-FP32 VALU (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two IEEE operations per
+// instruction at the scalar instruction's issue cost).  Element for element the same operations as fast_tanh -- the sign is
+// carried by x * poly instead of copysign(|x| * poly, x), which is the same product -- so the results are bit-identical;
+// 13 VALU + 4 transcendentals per PAIR instead of 22 + 4.  (On this part a wave's VALU work does not overlap anybody's MFMAs
+// on the same SIMD -- tools/mfma_valu_overlap.hip -- so every instruction saved is SIMD time saved.)
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 fast_tanh2(const f2 x) {
+  const f2 t = x * -2.885390081777927f;
+  f2 e;
+  e.x = __builtin_amdgcn_exp2f(-__builtin_fabsf(t.x));               // exp(-2|x|); the |.| and the sign are source modifiers
+  e.y = __builtin_amdgcn_exp2f(-__builtin_fabsf(t.y));
+  const f2 num = 1.f - e, den = 1.f + e;
+  f2 rc;
+  rc.x = __builtin_amdgcn_rcpf(den.x);
+  rc.y = __builtin_amdgcn_rcpf(den.y);
+  const f2 big = num * rc;
+  const f2 x2 = x * x;
+  const f2 c1 = {0.13333333333f, 0.13333333333f}, c2 = {-0.33333333333f, -0.33333333333f}, one = {1.f, 1.f};
+  const f2 poly = __builtin_elementwise_fma(x2, __builtin_elementwise_fma(x2, c1, c2), one);
+  const f2 small = x * poly;
+  f2 r;
+  r.x = __builtin_fabsf(x.x) < 0.125f ? small.x : copysignf(big.x, x.x);
+  r.y = __builtin_fabsf(x.y) < 0.125f ? small.y : copysignf(big.y, x.y);
+  return r;
+}
+#ifndef SPO_TANH_PACKED
+#define SPO_TANH_PACKED 1      // 0: four scalar fast_tanh (A/B knob; results must be bit-identical either way)
+#endif
+__device__ __forceinline__ f4 fast_tanh4(const f4 v) {
+#if SPO_TANH_PACKED
+  const f2 lo = fast_tanh2(f2{v[0], v[1]}), hi = fast_tanh2(f2{v[2], v[3]});
+  return f4{lo.x, lo.y, hi.x, hi.y};
+#else
+  return f4{fast_tanh(v[0]), fast_tanh(v[1]), fast_tanh(v[2]), fast_tanh(v[3])};
+#endif
+}
+
 // Hidden layer: out[mt] (rows 16mt+4q+reg, col batch) = tanh?(W in + b).  The four output tiles
 // are independent accumulators and are issued round-robin so back-to-back MFMAs never wait on the
 // 40-cycle dependent-accumulator latency of v_mfma_f32_16x16x4_f32.
@@ -190,8 +227,7 @@ __device__ __forceinline__ void layer_hidden_lean(const float* Wl, int ld, const
 #pragma unroll
   for (int mt = 0; mt < HID / 16; ++mt) {
     if (TANH) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[mt][r] = fast_tanh(acc[mt][r]);
+      acc[mt] = fast_tanh4(acc[mt]);
       __builtin_amdgcn_sched_barrier(0);    // four tanh chains in flight at a time, not sixteen
     }
     out[mt] = acc[mt];
@@ -221,10 +257,7 @@ __device__ __forceinline__ void layer_hidden(const float* Wl, int ld, const floa
   }
 #pragma unroll
   for (int mt = 0; mt < HID / 16; ++mt) {
-    if (TANH) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[mt][r] = fast_tanh(acc[mt][r]);
-    }
+    if (TANH) acc[mt] = fast_tanh4(acc[mt]);
     out[mt] = acc[mt];
   }
 }

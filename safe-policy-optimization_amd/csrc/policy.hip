@@ -150,8 +150,14 @@ struct KlArgs {
 // 0.29 of the FP32 matrix peak), so one wave's tanh / KL arithmetic runs beside the others' MFMAs, and the next tile's
 // observation rows are requested before the current tile is computed (raw loads, masked at pick-up).  The grid is
 // persistent (three workgroups per CU: 3 x 39.7 KB of LDS): the network is staged once per workgroup.
+#ifndef SPO_FULL_MINB
+#define SPO_FULL_MINB 1          // minimum resident workgroups per SIMD-set the register budget is shaped for (A/B knob)
+#endif
+#ifndef SPO_FULL_GRID
+#define SPO_FULL_GRID 768        // persistent grid: three resident workgroups on each of the 256 CUs (A/B knob)
+#endif
 template <int KIN, int MODE>
-__global__ __launch_bounds__(256) void actor_full_kernel(KlArgs a) {
+__global__ __launch_bounds__(256, SPO_FULL_MINB) void actor_full_kernel(KlArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[NetLds<KIN>::SIZE];
   __shared__ double red[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
@@ -422,7 +428,7 @@ int launch_step(const StepArgs& a, hipStream_t st) {
   return 0;
 }
 
-constexpr int FULL_GRID = 768;          // actor_full_kernel: three resident workgroups on each of the 256 CUs
+constexpr int FULL_GRID = SPO_FULL_GRID;
 template <int MODE>
 int launch_full(const KlArgs& a, unsigned blocks, hipStream_t st) {
   switch (pick_kin(a.D)) {

@@ -141,6 +141,32 @@ __device__ __forceinline__ AdamOut adam1(float p, float g, float m, float v, flo
   o.p = fmaf(-step_size, o.m * __builtin_amdgcn_rcpf(denom), p);
   return o;
 }
+// The two per-step scalars of Adam's bias correction: step_size = lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t).  The powers are
+// carried in double (one v_mul_f64 each per step); rounds 1-2 also formed the quotient and the square root in double -- ~40
+// double-precision VALU instructions per helper wave and step (IEEE division and sqrt sequences at half / quarter rate),
+// ~400 cycles of SIMD time that nothing overlaps (tools/mfma_valu_overlap.hip).  Now: 1 - beta^t is formed in double (exact
+// to 1e-16) and rounded to fp32 once, the reciprocal and the reciprocal square root come from v_rcp_f32 / v_rsq_f32 with
+// one Newton step and a residual correction: <= ~1.5e-7 relative on either scalar, half the error budget of the
+// v_sqrt_f32 / v_rcp_f32 inside adam1 itself (tests: drift envelopes at full size, first steps at 1e-5).
+#ifndef SPO_ADAM_SCALARS_F64
+#define SPO_ADAM_SCALARS_F64 0       // 1: the double-precision quotient / square root of rounds 1-2 (A/B knob)
+#endif
+__device__ __forceinline__ void adam_scalars(float lr, double pw1, double pw2, float& step_size, float& inv_bc2s) {
+#if SPO_ADAM_SCALARS_F64
+  step_size = (float)((double)lr / (1.0 - pw1));
+  inv_bc2s = (float)(1.0 / sqrt(1.0 - pw2));
+#else
+  const float bc1 = (float)(1.0 - pw1), bc2 = (float)(1.0 - pw2);
+  float r = __builtin_amdgcn_rcpf(bc1);
+  r = fmaf(fmaf(-bc1, r, 1.f), r, r);                 // Newton step on the reciprocal
+  float qv = lr * r;
+  qv = fmaf(fmaf(-bc1, qv, lr), r, qv);               // residual correction of the quotient
+  step_size = qv;
+  float y = __builtin_amdgcn_rsqf(bc2);
+  y = fmaf(y, fmaf(-(bc2 * y), 0.5f * y, 0.5f), y);   // y (1.5 - 0.5 x y^2)
+  inv_bc2s = y;
+#endif
+}
 // DST = updated parameter; M, V (vector elements or scalars) updated in place.
 #ifdef SPO_ABLATE_ADAM_STATE
 #define SPO_ST_MV(IDX, M, V)
@@ -359,7 +385,10 @@ __device__ __forceinline__ void xr_allreduce_rd(const u64* regions, int me, int 
 typedef unsigned int u4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st16_sys(char* p, const u4v v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  // s_nop 1: a VMEM store of more than 8 bytes reads its data registers up to two wait states after issue (gfx940+), and the
+  // compiler's hazard recogniser does not look inside inline assembly -- without it the VALU moves that assemble the NEXT word
+  // overwrite this word's registers under the store (seen on the GPU: lanes 12-15 of every 16 sent the next word's float)
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 #endif
 }
 __device__ __forceinline__ u4v ld16_sys(const char* p) {
@@ -369,7 +398,10 @@ __device__ __forceinline__ u4v ld16_sys(const char* p) {
 #endif
   return v;
 }
-template <int NV, int VB = 5>                                    // VB: packed words polled together
+#ifndef SPO_XR16_VB
+#define SPO_XR16_VB 5          // packed words polled together (A/B knob: register budget against poll round trips)
+#endif
+template <int NV, int VB = SPO_XR16_VB>                          // VB: packed words polled together
 __device__ __forceinline__ void xr_allreduce_rd16(const u64* regions, int me, int R, int net, int tid, unsigned gtag,
                                                   f4 (&pk)[NV], volatile float* dead_word, int* err) {
   constexpr int NF = 4 * NV, NW = (NF + 2) / 3;
@@ -1033,8 +1065,8 @@ __device__ __forceinline__ void ppo_update_body(const UpdArgs& a, const int wg) 
     //      (max_grad_norm = 40 almost never clips).  The moments are backed up so that a clipped step is
     //      redone exactly from the old state; parameters are only read by other waves after the final barrier.
     pw1 *= (double)b1c; pw2 *= (double)b2c;
-    const float step_size = (float)((double)lr / (1.0 - pw1));
-    const float inv_bc2s = (float)(1.0 / sqrt(1.0 - pw2));
+    float step_size, inv_bc2s;
+    adam_scalars(lr, pw1, pw2, step_size, inv_bc2s);
     constexpr bool SPEC = SPO_SPECULATIVE_ADAM && (KIN <= 64);   // the 128-wide variant has no registers to spare for the backups
     f4 omW1[NT1], ovW1[NT1], omW2[4], ovW2[4];
     f4 omW3 = mW3, ovW3 = vW3, omls = mls, ovls = vls;
@@ -1871,8 +1903,7 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
         lds[H::GB + 0 * 256 + hl] = gx[NT1][0];
       }
       pw1 *= (double)b1c; pw2 *= (double)b2c;
-      step_size = (float)((double)lr / (1.0 - pw1));
-      inv_bc2s = (float)(1.0 / sqrt(1.0 - pw2));
+      adam_scalars(lr, pw1, pw2, step_size, inv_bc2s);
       gsq = psq = 0.f;
 #pragma unroll
       for (int nt = 0; nt < NT1; ++nt) {
@@ -2357,8 +2388,9 @@ __global__ __launch_bounds__(1024) void clip_adam_kernel(AdamArgs a) {
   float coef = a.max_norm / (sqrtf(tot) + 1e-6f);
   coef = coef > 1.f ? 1.f : coef;
   const double pw1 = a.pow_b1 * (double)a.b1, pw2 = a.pow_b2 * (double)a.b2;
-  const float bc2s = (float)(1.0 / sqrt(1.0 - pw2));
-  const float ss_a = (float)((double)a.lr_actor / (1.0 - pw1)), ss_c = (float)((double)a.lr_critic / (1.0 - pw1));
+  float bc2s, ss_a, ss_c, bc2s_again;
+  adam_scalars(a.lr_actor, pw1, pw2, ss_a, bc2s);           // the same scalar forms as the persistent kernels
+  adam_scalars(a.lr_critic, pw1, pw2, ss_c, bc2s_again);
   for (int64_t i = tid; i < a.P; i += 1024) {
     const float g = a.grad[i] * a.gscale * coef;
     const AdamOut o = adam1(a.theta[i], g, a.m[i], a.v[i], a.b1, a.b2, a.eps, i >= a.actor_begin ? ss_a : ss_c, bc2s);
@@ -2402,7 +2434,17 @@ __global__ __launch_bounds__(256, 1) void xr_selftest_kernel(int rank, int world
       const float c = (float)((gtag + 3u * v + tid + 5u * net) & 15u);
       const f4 want = {tri + c, tri - c, c, 2.f * tri};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) bad += fabsf(pk[v][e] - want[e]) > 1e-4f ? 1 : 0;
+      for (int e = 0; e < 4; ++e) {
+        const bool b_ = fabsf(pk[v][e] - want[e]) > 1e-4f;
+        bad += b_ ? 1 : 0;
+#ifdef SPO_XR_DEBUG_MISMATCH
+        if (b_) {
+          const unsigned long long slot = atomicAdd(&g_xr_prof[7], 1ull);
+          if (slot < 7) g_xr_prof[slot] = ((unsigned long long)(rank * 3 + net) << 56) | ((unsigned long long)tid << 40) | ((unsigned long long)(v * 4 + e) << 32) |
+                                          (unsigned long long)__float_as_uint(pk[v][e]);
+        }
+#endif
+      }
     }
   }
   if (bad) atomicAdd(result, bad);

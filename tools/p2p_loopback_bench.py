@@ -44,6 +44,8 @@ def main(world=2, M=8192, iters=3, D=60, A=8):
         us_proto = 1e6 * (time.perf_counter() - t0) / xiters
         xstep += xiters
     proto_bad = [t.tolist() for t in res2]
+    if os.environ.get("SPO_LOOPBACK_DEBUG"):
+        print("selftest results {bad, timeout} per rank:", proto_bad, "us per exchange", round(us_proto, 2), flush=True)
     prof = (ctypes.c_ulonglong * 8)()
     _abi.check(lib.spo_debug_xr_profile(prof, 1), "prof")
     n = max(prof[6], 1)
@@ -85,6 +87,8 @@ def main(world=2, M=8192, iters=3, D=60, A=8):
         launch_all(step0); step0 += n_mb
     torch.cuda.synchronize()
     us_dp = 1e6 * (time.perf_counter() - t0) / (iters * n_mb)
+    if os.environ.get("SPO_LOOPBACK_DEBUG"):
+        print("us per step", round(us_dp, 2), "error words", [int(e.sync_ws[8].item()) & 0xFFFFFFFF for e in engines], flush=True)
     for eng in engines:
         eng.check_sync_error()
     same = all(torch.equal(engines[0].policy.theta, e.policy.theta) for e in engines[1:])
@@ -104,5 +108,14 @@ def main(world=2, M=8192, iters=3, D=60, A=8):
 
 
 if __name__ == "__main__":
-    for w in ([int(a) for a in sys.argv[1:]] or [2, 4, 8]):
-        main(world=w)
+    worlds = [int(a) for a in sys.argv[1:]] or [2, 4, 8]
+    if len(worlds) == 1:
+        main(world=worlds[0])
+    else:
+        # one process per world size: the W streams of a run must land on W different hardware queues, and streams left over
+        # from an earlier world size in the same process shift that assignment (GPU_MAX_HW_QUEUES=24 gives 8 ranks room)
+        import subprocess
+        env = dict(os.environ)
+        env.setdefault("GPU_MAX_HW_QUEUES", "24")
+        for w in worlds:
+            subprocess.run([sys.executable, os.path.abspath(__file__), str(w)], env=env)
