@@ -298,6 +298,7 @@ def main():
     ap.add_argument("--cpu-sample-envs", type=int, default=512)   # ~80 s of CPU work on the GPU box host (12.5 % of the workload)
     ap.add_argument("--cpo-cpu-sample-envs", type=int, default=256)
     ap.add_argument("--no-config3", action="store_true", help="skip the CPO (BASELINE config 3) section")
+    ap.add_argument("--no-config5", action="store_true", help="skip the MAPPO-L (BASELINE config 5 shape) section")
     ap.add_argument("--no-normalize-obs", action="store_true", help="rollout without the fused observation normaliser (a-2)")
     ap.add_argument("--cpo-steps", type=int, default=3)
     ap.add_argument("--stream-envs", type=int, default=262144, help="extra GAE roofline point that streams from HBM")
@@ -479,6 +480,19 @@ def main():
         except Exception as e:  # pragma: no cover
             config3 = {"error": str(e)[:300]}
 
+    # BASELINE config 5 (MAPPO-L shape: 4 agents, obs 48, 8 192 rollout threads x 64 steps; one GPU here, the row is
+    # "mappo_lag ... 8 x MI355X" in BASELINE.json): the multi-agent Runner of the f3 row, driver-visible (N = 1 only)
+    config5 = None
+    if world == 1 and a.algo == "ppo_lag" and not a.no_config5:
+        try:
+            torch.cuda.empty_cache()
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import ma_bench
+            config5 = ma_bench.run(argparse.Namespace(threads=8192, episode_length=64, hidden=128, episodes=2, agents=4))
+            config5["n_gpus"] = 1
+        except Exception as e:  # pragma: no cover
+            config5 = {"error": str(e)[:300]}
+
     us_step = upd / a.steps / (n_mb * iters) * 1e6
     line = {
         "metric": "env-steps/sec (collect+GAE+update) at num_envs=4096, 1/2/4/8 GPU",
@@ -513,6 +527,7 @@ def main():
         ("kl_kernel" if a.algo == "ppo_lag" else "cpo_fvp"): kl_entry,
         "cpu_baseline": cpu,
         "config3_cpo": config3,
+        "config5_mappolag": config5,
         "library": _lib_note(),
         "exchange": res_exchange,
         "per_rank": ([{"rank": r, "ms_per_step": round(e / a.steps * 1e3, 2), "rollout_s_per_epoch": round(ro / a.steps, 4),

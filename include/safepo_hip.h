@@ -387,6 +387,39 @@ int spo_ma_clip_adam(float* theta, const float* grad, float* adam_m, float* adam
  * rocBLAS (use_rocblas = 1; dlopen'ed on demand, not used by any product path). */
 int spo_debug_ma_gemm(int use_rocblas, int mode, const float* x, const float* w, float* y, int64_t B, int K, int N, void* stream);
 
+/* ---- wide single-agent networks: ActorVCritic(obs_dim, act_dim, hidden_sizes) for any hidden_sizes (reference
+ * safepo/common/model.py:30-48,131; isaac_gym_specific_cfg = [1024, 1024, 512], safepo/single_agent/ppo_lag.py:54-65).
+ * A network is n_layers Linear layers with tanh between them; dims[0] = input width, dims[n_layers] = output width.
+ * Flat layout of one network: for each layer W [out, in] row-major, then b [out] (nn.Sequential.parameters() order).
+ * spo_mlp_forward leaves every layer's activations in ws (float[spo_mlp_workspace_floats]); the output is the LAST
+ * rows * dims[n_layers] floats of ws.  spo_mlp_backward takes d(loss)/d(output) and writes the network's flat gradient;
+ * scratch: float[spo_mlp_backward_scratch_floats].
+ * spo_wide_ppo_loss (ppo_lag.py:306-323): MSE of both critics (WITHOUT their L2 terms), the clipped surrogate, their output
+ * gradients and d(loss)/d(log_std); partial_ws: double[>= 256 * (3 + SPO_MAX_ACT)].
+ * spo_wide_clip_adam (ppo_lag.py:310-329): adds the critics' L2 gradient 2 * l2_coef * p (cfg->use_critic_norm) and the value
+ * coefficient (cfg->use_value_coefficient) to `grad` in place, adds l2_coef * sum p^2 to losses3_inout[0..1], clips the joint
+ * norm over all n_params to cfg->max_grad_norm and takes one Adam step with cfg->lr_critic for [0, actor_begin) and
+ * cfg->lr_actor beyond.  scalars4_out = {clip coefficient, L2 term of the reward critic, of the cost critic, ||g||};
+ * partial_ws: double[>= 3 * 1024]. */
+#define SPO_MLP_MAX_LAYERS 5
+typedef struct spo_mlp_net {
+  int32_t n_layers;
+  int32_t dims[SPO_MLP_MAX_LAYERS + 1];
+} spo_mlp_net;
+int64_t spo_mlp_param_count(const spo_mlp_net* net);
+int64_t spo_mlp_workspace_floats(const spo_mlp_net* net, int64_t rows);
+int64_t spo_mlp_backward_scratch_floats(const spo_mlp_net* net, int64_t rows);
+int spo_mlp_forward(const float* theta, const spo_mlp_net* net, const float* x, int64_t rows, float* ws, void* stream);
+int spo_mlp_backward(const float* theta, const spo_mlp_net* net, const float* x, int64_t rows, const float* ws,
+                     const float* d_out, float* grad, float* scratch, void* stream);
+int spo_wide_ppo_loss(const float* v_r, const float* v_c, const float* mean, const float* log_std, const float* act,
+                      const float* logp_old, const float* adv, const float* tgt_r, const float* tgt_c, int64_t rows,
+                      int act_dim, float clip, float* d_vr, float* d_vc, float* d_mean, float* d_log_std, float* losses3,
+                      double* partial_ws, int partial_capacity, void* stream);
+int spo_wide_clip_adam(float* theta, float* grad, float* adam_m, float* adam_v, int64_t n_params, int64_t reward_critic_end,
+                       int64_t cost_critic_end, int64_t actor_begin, const spo_ppo_cfg* cfg, int64_t adam_step_host,
+                       float* losses3_inout, float* scalars4_out, double* partial_ws, int partial_capacity, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,8 @@
 #include <cstring>
 #include <dlfcn.h>
 #include "common.h"
+#include "adam.h"
+#include "mlp_mfma.h"
 #include "../../include/safepo_hip.h"
 
 namespace {
@@ -1641,5 +1643,296 @@ extern "C" int spo_debug_ma_gemm(int use_rocblas, int mode, const float* x, cons
   g_ma_gemm_rocblas = 0;
   if (rc) return rc;
   SPO_LAUNCH_CHECK("spo_debug_ma_gemm");
+  return 0;
+}
+
+// ====================================================================================================================
+// Wide single-agent networks: ActorVCritic(obs_dim, act_dim, hidden_sizes) for ANY hidden_sizes (reference
+// safepo/common/model.py:30-48,131; isaac_gym_specific_cfg uses [1024, 1024, 512] with minibatches of 8 192 rows,
+// safepo/single_agent/ppo_lag.py:54-65).  The persistent kernels of update.hip keep a 64-wide network in one CU's LDS for
+// thousands of dependent 64-row steps; a wide network at a wide batch is the opposite regime -- a handful of large steps
+// per epoch, each a chain of real GEMMs -- so it runs as a sequence of launches on the in-tree fp32 MFMA GEMM kernels
+// above (X W^T, dY W, dY^T X) with small elementwise kernels between them:
+//   forward   h_l = tanh(h_{l-1} W_l^T + b_l), last layer linear                      spo_mlp_forward
+//   backward  dZ_l = dH_l (1 - h_l^2); db_l = colsum dZ_l; dW_l = dZ_l^T h_{l-1}; dH_{l-1} = dZ_l W_l     spo_mlp_backward
+//   losses    MSE critics, clipped PPO surrogate + d(log_std) (ppo_lag.py:306-323)     spo_wide_ppo_loss
+//   step      critic L2 terms, joint clip_grad_norm_, Adam (ppo_lag.py:310-329)        spo_wide_clip_adam
+// Flat parameter layout of one network: for every Linear in order, W [out, in] row-major then b [out] -- the order of
+// nn.Sequential.parameters(), so the module's parameters stay views of one vector (log_std precedes the actor's layers).
+namespace {
+using namespace spo;
+
+struct MlpLay {
+  int n;                 // Linear layers
+  int d[SPO_MLP_MAX_LAYERS + 1];
+  int64_t w(int l) const { int64_t o = 0; for (int k = 0; k < l; ++k) o += (int64_t)d[k + 1] * d[k] + d[k + 1]; return o; }
+  int64_t b(int l) const { return w(l) + (int64_t)d[l + 1] * d[l]; }
+  int64_t count() const { return w(n); }
+  int64_t act_off(int l, int64_t rows) const { int64_t o = 0; for (int k = 0; k < l; ++k) o += rows * d[k + 1]; return o; }   // h_{l+1} inside ws
+  int maxdim() const { int m = 0; for (int k = 0; k <= n; ++k) m = d[k] > m ? d[k] : m; return m; }
+};
+int mlp_lay(const spo_mlp_net* net, MlpLay* L) {
+  if (!net) return fail(-1, "mlp: net is NULL");
+  if (net->n_layers < 1 || net->n_layers > SPO_MLP_MAX_LAYERS) return fail(-2, "mlp: n_layers %d outside [1,%d]", net->n_layers, SPO_MLP_MAX_LAYERS);
+  L->n = net->n_layers;
+  for (int k = 0; k <= L->n; ++k) {
+    if (net->dims[k] < 1 || net->dims[k] > 16384) return fail(-2, "mlp: dims[%d] = %d outside [1,16384]", k, net->dims[k]);
+    L->d[k] = net->dims[k];
+  }
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void mlp_bias_act_kernel(float* __restrict__ y, const float* __restrict__ b, int64_t n, int N, int tanh_on) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = y[i] + b[i % N];
+    y[i] = tanh_on ? fast_tanh(v) : v;
+  }
+}
+__global__ __launch_bounds__(256) void mlp_dtanh_kernel(float* __restrict__ dh, const float* __restrict__ h, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float hv = h[i];
+    dh[i] = dh[i] * fmaf(-hv, hv, 1.f);
+  }
+}
+// column sums in two fixed-order stages: partial[s][c] over row slice s, then over the slices
+constexpr int CS_SLICES = 64;
+__global__ __launch_bounds__(256) void mlp_colsum_partial_kernel(const float* __restrict__ d, int64_t B, int N, float* __restrict__ partial) {
+  const int c = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
+  if (c >= N) return;
+  const int64_t per = (B + CS_SLICES - 1) / CS_SLICES, r0 = s * per, r1 = r0 + per < B ? r0 + per : B;
+  float acc = 0.f;
+  for (int64_t r = r0; r < r1; ++r) acc += d[r * N + c];
+  partial[(int64_t)s * N + c] = acc;
+}
+__global__ __launch_bounds__(256) void mlp_colsum_finish_kernel(const float* __restrict__ partial, int N, float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  float acc = 0.f;
+  for (int s = 0; s < CS_SLICES; ++s) acc += partial[(int64_t)s * N + c];
+  out[c] = acc;
+}
+int ew_grid(int64_t n) { const int64_t g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
+
+// PPO-Lagrangian losses and output gradients of one minibatch (ppo_lag.py:306-323): one thread per row.
+constexpr int WL_NS = 3 + SPO_MAX_ACT;       // loss_r sum, loss_c sum, surrogate sum, d(log_std)[A]
+__global__ __launch_bounds__(256) void wide_ppo_loss_kernel(const float* __restrict__ v_r, const float* __restrict__ v_c, const float* __restrict__ mean,
+                                                            const float* __restrict__ log_std, const float* __restrict__ act,
+                                                            const float* __restrict__ logp_old, const float* __restrict__ adv,
+                                                            const float* __restrict__ tgt_r, const float* __restrict__ tgt_c, int64_t B, int A,
+                                                            float clip, float* __restrict__ d_vr, float* __restrict__ d_vc,
+                                                            float* __restrict__ d_mean, double* __restrict__ partial) {
+  __shared__ double red[4][WL_NS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float inv_n = 1.f / (float)B, clip_lo = 1.f - clip, clip_hi = 1.f + clip;
+  double acc[WL_NS];
+#pragma unroll
+  for (int k = 0; k < WL_NS; ++k) acc[k] = 0.0;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + tid; r < B; r += (int64_t)gridDim.x * 256) {
+    const float dr = v_r[r] - tgt_r[r], dc = v_c[r] - tgt_c[r];
+    acc[0] += (double)(dr * dr); acc[1] += (double)(dc * dc);
+    d_vr[r] = 2.f * dr * inv_n; d_vc[r] = 2.f * dc * inv_n;
+    float lp = 0.f, dif[SPO_MAX_ACT], ivar[SPO_MAX_ACT];
+    for (int k = 0; k < A; ++k) {
+      const float ls = log_std[k], sd = __expf(ls);
+      ivar[k] = 1.f / (sd * sd);
+      dif[k] = act[r * A + k] - mean[r * A + k];
+      lp += -(dif[k] * dif[k]) * (0.5f * ivar[k]) - ls - LOG_SQRT_2PI_F;
+    }
+    const float ad = adv[r];
+    const float ratio = __expf(lp - logp_old[r]);
+    const float rc = fminf(fmaxf(ratio, clip_lo), clip_hi);
+    const float s1 = ratio * ad, s2 = rc * ad;
+    const bool inr = (ratio >= clip_lo) && (ratio <= clip_hi);
+    float gr;                                          // backward of torch.min / torch.clamp (ties split the gradient)
+    if (s1 < s2) gr = ad;
+    else if (s1 > s2) gr = inr ? ad : 0.f;
+    else gr = 0.5f * ad + (inr ? 0.5f * ad : 0.f);
+    const float dlp = -(gr * ratio) * inv_n;
+    acc[2] += (double)fminf(s1, s2);
+    for (int k = 0; k < A; ++k) {
+      const float z = dif[k] * ivar[k];
+      d_mean[r * A + k] = dlp * z;
+      acc[3 + k] += (double)(dlp * (dif[k] * z - 1.f));
+    }
+  }
+  for (int k = 0; k < 3 + A; ++k) {
+    const double v = wave_sum_d(acc[k]);
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  if (tid < 3 + A) partial[(int64_t)blockIdx.x * WL_NS + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+__global__ void wide_ppo_loss_finish_kernel(const double* __restrict__ partial, int nblocks, int A, int64_t B, float* __restrict__ losses3,
+                                            float* __restrict__ d_log_std) {
+  const int k = threadIdx.x;
+  if (k >= 3 + A) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * WL_NS + k];
+  if (k < 2) losses3[k] = (float)(s / (double)B);
+  else if (k == 2) losses3[2] = (float)(-s / (double)B);
+  else d_log_std[k - 3] = (float)s;
+}
+
+// Joint clip + Adam over the flat vector of all three networks: stage 1 adds the critics' L2 gradient (2 l2 p) and the value
+// coefficient in place and reduces ||g||^2 and the critics' sum p^2; stage 2 forms the clip coefficient; stage 3 is Adam.
+struct WideAdamArgs {
+  float* theta; float* grad; float* m; float* v; int64_t P, r_end, c_end, actor_begin;
+  float l2, vcoef_r, max_norm, lr_actor, lr_critic, b1, b2, eps;
+  double pow_b1, pow_b2;
+  double* partial; float* scal;      // scal: {coef, l2 * sum p^2 (reward critic), l2 * sum p^2 (cost critic), ||g||}
+  float* losses3;
+};
+__global__ __launch_bounds__(256) void wide_prep_kernel(WideAdamArgs a) {
+  __shared__ double red[4][3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double gs = 0.0, pr = 0.0, pc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < a.P; i += (int64_t)gridDim.x * 256) {
+    float g = a.grad[i];
+    if (i < a.c_end) {
+      const float p = a.theta[i];
+      g = fmaf(2.f * a.l2, p, g);
+      if (i < a.r_end) { g *= a.vcoef_r; pr += (double)(p * p); } else pc += (double)(p * p);
+      a.grad[i] = g;
+    }
+    gs += (double)(g * g);
+  }
+  gs = wave_sum_d(gs); pr = wave_sum_d(pr); pc = wave_sum_d(pc);
+  if (lane == 0) { red[wave][0] = gs; red[wave][1] = pr; red[wave][2] = pc; }
+  __syncthreads();
+  if (tid < 3) a.partial[(int64_t)blockIdx.x * 3 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+__global__ void wide_coef_kernel(WideAdamArgs a, int nblocks) {
+  if (threadIdx.x != 0) return;
+  double gs = 0.0, pr = 0.0, pc = 0.0;
+  for (int b = 0; b < nblocks; ++b) { gs += a.partial[b * 3]; pr += a.partial[b * 3 + 1]; pc += a.partial[b * 3 + 2]; }
+  const float norm = sqrtf((float)gs);
+  float coef = a.max_norm / (norm + 1e-6f);                   // clip_grad_norm_ (torch): eps 1e-6
+  a.scal[0] = coef > 1.f ? 1.f : coef;
+  a.scal[1] = a.l2 * (float)pr; a.scal[2] = a.l2 * (float)pc; a.scal[3] = norm;
+  if (a.losses3) { a.losses3[0] += a.scal[1]; a.losses3[1] += a.scal[2]; }      // logged critic losses include their L2 terms
+}
+__global__ __launch_bounds__(256) void wide_adam_kernel(WideAdamArgs a) {
+  const float coef = a.scal[0];
+  const double pw1 = a.pow_b1 * (double)a.b1, pw2 = a.pow_b2 * (double)a.b2;
+  float ss_a, ss_c, bc2s, bc2s_again;
+  adam_scalars(a.lr_actor, pw1, pw2, ss_a, bc2s);
+  adam_scalars(a.lr_critic, pw1, pw2, ss_c, bc2s_again);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.P; i += (int64_t)gridDim.x * 256) {
+    const AdamOut o = adam1(a.theta[i], a.grad[i] * coef, a.m[i], a.v[i], a.b1, a.b2, a.eps, i >= a.actor_begin ? ss_a : ss_c, bc2s);
+    a.theta[i] = o.p; a.m[i] = o.m; a.v[i] = o.v;
+  }
+}
+}  // namespace
+
+extern "C" int64_t spo_mlp_param_count(const spo_mlp_net* net) {
+  MlpLay L;
+  if (mlp_lay(net, &L)) return -1;
+  return L.count();
+}
+extern "C" int64_t spo_mlp_workspace_floats(const spo_mlp_net* net, int64_t rows) {
+  MlpLay L;
+  if (mlp_lay(net, &L) || rows < 1) return -1;
+  return L.act_off(L.n, rows);
+}
+extern "C" int64_t spo_mlp_backward_scratch_floats(const spo_mlp_net* net, int64_t rows) {
+  MlpLay L;
+  if (mlp_lay(net, &L) || rows < 1) return -1;
+  int64_t slices = 0;
+  for (int l = 0; l < L.n; ++l) {
+    const int64_t s = (int64_t)dw_splits(rows, L.d[l + 1], L.d[l]) * L.d[l + 1] * L.d[l];
+    slices = s > slices ? s : slices;
+  }
+  return 2 * rows * (int64_t)L.maxdim() + slices + (int64_t)CS_SLICES * L.maxdim();
+}
+
+extern "C" int spo_mlp_forward(const float* theta, const spo_mlp_net* net, const float* x, int64_t rows, float* ws, void* stream) {
+  MlpLay L;
+  if (int rc = mlp_lay(net, &L)) return rc;
+  SPO_REQUIRE(theta && x && ws && rows > 0, "mlp_forward: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const float* in = x;
+  for (int l = 0; l < L.n; ++l) {
+    float* out = ws + L.act_off(l, rows);
+    if (int rc = gemm_xwT(st, in, theta + L.w(l), out, rows, L.d[l], L.d[l + 1])) return rc;
+    const int64_t n = rows * L.d[l + 1];
+    hipLaunchKernelGGL(mlp_bias_act_kernel, dim3(ew_grid(n)), dim3(256), 0, st, out, theta + L.b(l), n, L.d[l + 1], l + 1 < L.n ? 1 : 0);
+    in = out;
+  }
+  SPO_LAUNCH_CHECK("spo_mlp_forward");
+  return 0;
+}
+
+extern "C" int spo_mlp_backward(const float* theta, const spo_mlp_net* net, const float* x, int64_t rows, const float* ws,
+                                const float* d_out, float* grad, float* scratch, void* stream) {
+  MlpLay L;
+  if (int rc = mlp_lay(net, &L)) return rc;
+  SPO_REQUIRE(theta && x && ws && d_out && grad && scratch && rows > 0, "mlp_backward: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const int md = L.maxdim();
+  float* dA = scratch;                                   // ping-pong dZ buffers
+  float* dB = scratch + rows * (int64_t)md;
+  float* slices = scratch + 2 * rows * (int64_t)md;
+  int64_t smax = 0;
+  for (int l = 0; l < L.n; ++l) {
+    const int64_t s = (int64_t)dw_splits(rows, L.d[l + 1], L.d[l]) * L.d[l + 1] * L.d[l];
+    smax = s > smax ? s : smax;
+  }
+  float* cs = slices + smax;
+  const float* dz = d_out;                               // dZ of the last (linear) layer is d_out itself
+  for (int l = L.n - 1; l >= 0; --l) {
+    const int N = L.d[l + 1], K = L.d[l];
+    const float* hin = l == 0 ? x : ws + L.act_off(l - 1, rows);
+    hipLaunchKernelGGL(mlp_colsum_partial_kernel, dim3((N + 255) / 256, CS_SLICES), dim3(256), 0, st, dz, rows, N, cs);
+    hipLaunchKernelGGL(mlp_colsum_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, st, cs, N, grad + L.b(l));
+    if (int rc = gemm_dyTx(st, dz, hin, grad + L.w(l), rows, K, N, slices)) return rc;
+    if (l > 0) {
+      float* dh = (dz == dA) ? dB : dA;
+      if (int rc = gemm_dyw(st, dz, theta + L.w(l), dh, rows, K, N)) return rc;
+      const int64_t n = rows * (int64_t)K;
+      hipLaunchKernelGGL(mlp_dtanh_kernel, dim3(ew_grid(n)), dim3(256), 0, st, dh, hin, n);
+      dz = dh;
+    }
+  }
+  SPO_LAUNCH_CHECK("spo_mlp_backward");
+  return 0;
+}
+
+extern "C" int spo_wide_ppo_loss(const float* v_r, const float* v_c, const float* mean, const float* log_std, const float* act,
+                                 const float* logp_old, const float* adv, const float* tgt_r, const float* tgt_c, int64_t rows,
+                                 int act_dim, float clip, float* d_vr, float* d_vc, float* d_mean, float* d_log_std,
+                                 float* losses3, double* partial_ws, int partial_capacity, void* stream) {
+  SPO_REQUIRE(v_r && v_c && mean && log_std && act && logp_old && adv && tgt_r && tgt_c && d_vr && d_vc && d_mean && d_log_std &&
+                  losses3 && partial_ws && rows > 0, "wide_ppo_loss: bad args");
+  SPO_REQUIRE(act_dim >= 1 && act_dim <= SPO_MAX_ACT, "wide_ppo_loss: act_dim %d outside [1,%d]", act_dim, SPO_MAX_ACT);
+  int64_t blocks = (rows + 255) / 256;
+  if (blocks > 256) blocks = 256;
+  SPO_REQUIRE(partial_capacity >= blocks * WL_NS, "wide_ppo_loss: partial workspace too small (%d < %lld)", partial_capacity, (long long)(blocks * WL_NS));
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(wide_ppo_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, st, v_r, v_c, mean, log_std, act, logp_old, adv, tgt_r,
+                     tgt_c, rows, act_dim, clip, d_vr, d_vc, d_mean, partial_ws);
+  hipLaunchKernelGGL(wide_ppo_loss_finish_kernel, dim3(1), dim3(64), 0, st, partial_ws, (int)blocks, act_dim, rows, losses3, d_log_std);
+  SPO_LAUNCH_CHECK("spo_wide_ppo_loss");
+  return 0;
+}
+
+extern "C" int spo_wide_clip_adam(float* theta, float* grad, float* adam_m, float* adam_v, int64_t n_params, int64_t reward_critic_end,
+                                  int64_t cost_critic_end, int64_t actor_begin, const spo_ppo_cfg* cfg, int64_t adam_step_host,
+                                  float* losses3_inout, float* scalars4_out, double* partial_ws, int partial_capacity, void* stream) {
+  SPO_REQUIRE(theta && grad && adam_m && adam_v && cfg && scalars4_out && partial_ws && n_params > 0 && adam_step_host >= 0,
+              "wide_clip_adam: bad args");
+  SPO_REQUIRE(0 <= reward_critic_end && reward_critic_end <= cost_critic_end && cost_critic_end <= actor_begin && actor_begin <= n_params,
+              "wide_clip_adam: parameter ranges out of order");
+  int64_t blocks = (n_params + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  SPO_REQUIRE(partial_capacity >= blocks * 3, "wide_clip_adam: partial workspace too small");
+  WideAdamArgs a{theta, grad, adam_m, adam_v, n_params, reward_critic_end, cost_critic_end, actor_begin,
+                 cfg->use_critic_norm ? cfg->l2_coef : 0.f, cfg->use_value_coefficient ? 2.f : 1.f, cfg->max_grad_norm, cfg->lr_actor,
+                 cfg->lr_critic, cfg->beta1, cfg->beta2, cfg->adam_eps, pow((double)cfg->beta1, (double)adam_step_host),
+                 pow((double)cfg->beta2, (double)adam_step_host), partial_ws, scalars4_out, losses3_inout};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(wide_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(wide_coef_kernel, dim3(1), dim3(64), 0, st, a, (int)blocks);
+  hipLaunchKernelGGL(wide_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  SPO_LAUNCH_CHECK("spo_wide_clip_adam");
   return 0;
 }

@@ -31,6 +31,18 @@ class MaNet(Structure):
                 ("is_actor", c_int32)]
 
 
+class MlpNet(Structure):
+    """spo_mlp_net (include/safepo_hip.h): n_layers Linear layers, dims[0] = input ... dims[n_layers] = output."""
+    _fields_ = [("n_layers", c_int32), ("dims", c_int32 * 6)]
+
+    @classmethod
+    def of(cls, sizes):
+        sizes = [int(x) for x in sizes]
+        if not (2 <= len(sizes) <= 6):
+            raise SpoError(f"an MLP here has 1..5 Linear layers, got sizes {sizes}")
+        return cls(len(sizes) - 1, (c_int32 * 6)(*(sizes + [0] * (6 - len(sizes)))))
+
+
 class MaLossCfg(Structure):
     """spo_ma_loss_cfg (include/safepo_hip.h)."""
     _fields_ = [("clip_param", c_float), ("entropy_coef", c_float), ("std_x_coef", c_float), ("std_y_coef", c_float),
@@ -104,6 +116,13 @@ PROTOTYPES = {
     "spo_ma_value_loss": (c_int, [P, P, P, P, P, c_float, c_float, c_float, c_float, c_int64, c_int64, P, P, P, P]),
     "spo_ma_clip_adam": (c_int, [P, P, P, P, c_int64, c_int64, c_float, c_float, c_float, c_float, c_int, P, P, P]),
     "spo_ma_gae": (c_int, [P] * 7 + [c_int64, c_int64, c_double, c_double, c_float, c_float, c_float, c_float, P]),
+    "spo_mlp_param_count": (c_int64, [POINTER(MlpNet)]),
+    "spo_mlp_workspace_floats": (c_int64, [POINTER(MlpNet), c_int64]),
+    "spo_mlp_backward_scratch_floats": (c_int64, [POINTER(MlpNet), c_int64]),
+    "spo_mlp_forward": (c_int, [P, POINTER(MlpNet), P, c_int64, P, P]),
+    "spo_mlp_backward": (c_int, [P, POINTER(MlpNet), P, c_int64, P, P, P, P, P]),
+    "spo_wide_ppo_loss": (c_int, [P] * 9 + [c_int64, c_int, c_float] + [P] * 6 + [c_int, P]),
+    "spo_wide_clip_adam": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, POINTER(PpoCfg), c_int64, P, P, P, c_int, P]),
     "spo_param_count": (c_int64, [c_int, c_int]),
     "spo_param_offset": (c_int64, [c_int, c_int, c_int]),
     "spo_synth_env_step": (c_int, [P] * 7 + [c_int64, c_int, c_uint64, c_uint64, c_float, c_float, c_int, P]),

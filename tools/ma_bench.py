@@ -23,6 +23,12 @@ def main():
     ap.add_argument("--episodes", type=int, default=3)
     ap.add_argument("--agents", type=int, default=4)
     a = ap.parse_args()
+    print(json.dumps(run(a)))
+
+
+def run(a):
+    """One warm-up and a.episodes timed episodes of the MAPPO-L Runner on the config-5 shape; returns the result record
+    (bench.py puts it into its JSON line as `config5_mappolag`)."""
     from safepo.multi_agent import mappolag
     from safepo.common.env import SynthMultiAgentEnv
     dev = torch.device("cuda:0")
@@ -64,11 +70,11 @@ def main():
     per_row_actor = 2 * (D * H + 2 * H * H + H * A)
     per_row_critic = 2 * (S * H + 2 * H * H + H)
     train_flops = a.agents * cfg["learning_iters"] * rows * 3 * (per_row_actor + 2 * per_row_critic)
-    print(json.dumps({"workload": f"mappolag synthetic {a.agents} agents obs 48 act 6, {a.threads} rollout threads x {a.episode_length} steps, hidden {H}, "
-                                  f"learning_iters {cfg['learning_iters']}, num_mini_batch {cfg['num_mini_batch']}",
-                      "env_steps_per_s": round(steps / dt, 1), "s_per_epoch": round(dt / a.episodes, 4),
-                      "phases_s_per_epoch": {k: round(v / a.episodes, 4) for k, v in ph.items()},
-                      "train_gemm_tflops": round(train_flops / (ph["train"] / a.episodes) / 1e12, 2)}))
+    return {"workload": f"mappolag synthetic {a.agents} agents obs 48 act 6, {a.threads} rollout threads x {a.episode_length} steps, hidden {H}, "
+                        f"learning_iters {cfg['learning_iters']}, num_mini_batch {cfg['num_mini_batch']}",
+            "env_steps_per_s": round(steps / dt, 1), "episodes_timed": a.episodes, "s_per_epoch": round(dt / a.episodes, 4),
+            "phases_s_per_epoch": {k: round(v / a.episodes, 4) for k, v in ph.items()},
+            "train_gemm_tflops": round(train_flops / (ph["train"] / a.episodes) / 1e12, 2)}
 
 
 if __name__ == "__main__":
