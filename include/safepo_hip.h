@@ -412,6 +412,14 @@ int64_t spo_mlp_backward_scratch_floats(const spo_mlp_net* net, int64_t rows);
 int spo_mlp_forward(const float* theta, const spo_mlp_net* net, const float* x, int64_t rows, float* ws, void* stream);
 int spo_mlp_backward(const float* theta, const spo_mlp_net* net, const float* x, int64_t rows, const float* ws,
                      const float* d_out, float* grad, float* scratch, void* stream);
+/* rsample + log-prob of a diagonal Gaussian (model.py:149-170; eps == NULL: deterministic), and the row sum of
+ * KL(N(mean_old, exp(log_std_old)) || N(mean_new, exp(log_std_new))).sum(-1) (ppo_lag.py:338-345) added to (accumulate != 0) or
+ * stored into *sum_inout -- the full batch is evaluated in row chunks. */
+int spo_gauss_sample(const float* mean, const float* log_std, const float* eps, float* act_out, float* logp_out, int64_t rows,
+                     int act_dim, void* stream);
+int spo_gauss_kl_sum(const float* mean_old, const float* log_std_old, const float* mean_new, const float* log_std_new,
+                     int64_t rows, int act_dim, double* partial_ws, int partial_capacity, double* sum_inout, int accumulate,
+                     void* stream);
 int spo_wide_ppo_loss(const float* v_r, const float* v_c, const float* mean, const float* log_std, const float* act,
                       const float* logp_old, const float* adv, const float* tgt_r, const float* tgt_c, int64_t rows,
                       int act_dim, float clip, float* d_vr, float* d_vc, float* d_mean, float* d_log_std, float* losses3,

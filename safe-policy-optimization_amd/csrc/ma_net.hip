@@ -1824,6 +1824,77 @@ __global__ __launch_bounds__(256) void wide_adam_kernel(WideAdamArgs a) {
 }
 }  // namespace
 
+namespace {
+// a = mean + exp(log_std) * eps (rsample), logp = Normal(mean, exp(log_std)).log_prob(a).sum(-1)   (model.py:149-170)
+__global__ __launch_bounds__(256) void gauss_sample_kernel(const float* __restrict__ mean, const float* __restrict__ log_std,
+                                                           const float* __restrict__ eps, float* __restrict__ act, float* __restrict__ logp,
+                                                           int64_t B, int A) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= B) return;
+  float lp = 0.f;
+  for (int k = 0; k < A; ++k) {
+    const float sd = expf(log_std[k]), mu = mean[r * A + k];
+    const float ac = eps ? mu + eps[r * A + k] * sd : mu;
+    const float diff = ac - mu, var = sd * sd;
+    lp += -(diff * diff) / (2.f * var) - logf(sd) - LOG_SQRT_2PI_F;
+    act[r * A + k] = ac;
+  }
+  logp[r] = lp;
+}
+// sum over rows of KL(N(mean_old, std_old) || N(mean_new, std_new)).sum(-1)   (torch kl_normal_normal, ppo_lag.py:338-345)
+__global__ __launch_bounds__(256) void gauss_kl_kernel(const float* __restrict__ mean_old, const float* __restrict__ log_std_old,
+                                                       const float* __restrict__ mean_new, const float* __restrict__ log_std_new, int64_t B,
+                                                       int A, double* __restrict__ partial) {
+  __shared__ double red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double acc = 0.0;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + tid; r < B; r += (int64_t)gridDim.x * 256) {
+    float kl = 0.f;
+    for (int k = 0; k < A; ++k) {
+      const float so = expf(log_std_old[k]), sn = expf(log_std_new[k]);
+      const float ratio = so / sn, var_ratio = ratio * ratio;
+      const float dm = (mean_old[r * A + k] - mean_new[r * A + k]) / sn;
+      kl += 0.5f * (var_ratio + dm * dm - 1.f - logf(var_ratio));
+    }
+    acc += (double)kl;
+  }
+  acc = wave_sum_d(acc);
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (tid == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void gauss_kl_finish_kernel(const double* __restrict__ partial, int nblocks, double* __restrict__ sum_inout, int accumulate) {
+  if (threadIdx.x != 0) return;
+  double s = accumulate ? sum_inout[0] : 0.0;
+  for (int b = 0; b < nblocks; ++b) s += partial[b];
+  sum_inout[0] = s;
+}
+}  // namespace
+
+extern "C" int spo_gauss_sample(const float* mean, const float* log_std, const float* eps, float* act_out, float* logp_out,
+                                int64_t rows, int act_dim, void* stream) {
+  SPO_REQUIRE(mean && log_std && act_out && logp_out && rows > 0 && act_dim >= 1 && act_dim <= SPO_MAX_ACT, "gauss_sample: bad args");
+  hipLaunchKernelGGL(gauss_sample_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mean, log_std, eps,
+                     act_out, logp_out, rows, act_dim);
+  SPO_LAUNCH_CHECK("spo_gauss_sample");
+  return 0;
+}
+extern "C" int spo_gauss_kl_sum(const float* mean_old, const float* log_std_old, const float* mean_new, const float* log_std_new,
+                                int64_t rows, int act_dim, double* partial_ws, int partial_capacity, double* sum_inout, int accumulate,
+                                void* stream) {
+  SPO_REQUIRE(mean_old && log_std_old && mean_new && log_std_new && partial_ws && sum_inout && rows > 0 && act_dim >= 1 &&
+                  act_dim <= SPO_MAX_ACT && partial_capacity >= 1, "gauss_kl_sum: bad args");
+  int64_t blocks = (rows + 255) / 256;
+  if (blocks > 512) blocks = 512;
+  if (blocks > partial_capacity) blocks = partial_capacity;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gauss_kl_kernel, dim3((unsigned)blocks), dim3(256), 0, st, mean_old, log_std_old, mean_new, log_std_new, rows, act_dim,
+                     partial_ws);
+  hipLaunchKernelGGL(gauss_kl_finish_kernel, dim3(1), dim3(64), 0, st, partial_ws, (int)blocks, sum_inout, accumulate);
+  SPO_LAUNCH_CHECK("spo_gauss_kl_sum");
+  return 0;
+}
+
 extern "C" int64_t spo_mlp_param_count(const spo_mlp_net* net) {
   MlpLay L;
   if (mlp_lay(net, &L)) return -1;

@@ -121,6 +121,8 @@ PROTOTYPES = {
     "spo_mlp_backward_scratch_floats": (c_int64, [POINTER(MlpNet), c_int64]),
     "spo_mlp_forward": (c_int, [P, POINTER(MlpNet), P, c_int64, P, P]),
     "spo_mlp_backward": (c_int, [P, POINTER(MlpNet), P, c_int64, P, P, P, P, P]),
+    "spo_gauss_sample": (c_int, [P, P, P, P, P, c_int64, c_int, P]),
+    "spo_gauss_kl_sum": (c_int, [P, P, P, P, c_int64, c_int, P, c_int, P, c_int, P]),
     "spo_wide_ppo_loss": (c_int, [P] * 9 + [c_int64, c_int, c_float] + [P] * 6 + [c_int, P]),
     "spo_wide_clip_adam": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, POINTER(PpoCfg), c_int64, P, P, P, c_int, P]),
     "spo_param_count": (c_int64, [c_int, c_int]),

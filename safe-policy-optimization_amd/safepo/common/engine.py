@@ -35,7 +35,7 @@ class PPOLagEngine:
 
     def __init__(self, policy: ActorVCritic, num_envs: int, steps: int, config: dict, device,
                  comm: Comm | None = None, lr: float = 3e-4, critic_lr: float | None = None):
-        policy._require_kernels()
+        self._require_policy(policy)
         self.policy, self.N, self.T = policy, int(num_envs), int(steps)
         self.D, self.A = policy.obs_dim, policy.act_dim
         self.cfg = config
@@ -85,6 +85,14 @@ class PPOLagEngine:
                 self.p2p = PeerExchange.try_create(self.comm, self.dev)
         self.rew_deque, self.cost_deque, self.len_deque = deque(maxlen=50), deque(maxlen=50), deque(maxlen=50)
 
+    def _require_policy(self, policy) -> None:
+        policy._require_kernels()
+
+    def _values_into(self, obs: torch.Tensor, out_r: torch.Tensor, out_c: torch.Tensor) -> None:
+        """(v_r, v_c) of both critics for bootstrap values (ppo_lag.py:201-215)."""
+        _abi.check(self.lib.spo_values(_abi.ptr(self.policy.theta), _abi.ptr(obs), _abi.ptr(out_r), _abi.ptr(out_c), self.N,
+                                       self.D, self.A, _abi.stream_ptr()), "spo_values")
+
     # ------------------------------------------------------------------ collect
     def collect_step(self, t: int, obs: torch.Tensor, eps: torch.Tensor | None = None,
                      deterministic: bool = False, rms=None) -> torch.Tensor:
@@ -128,12 +136,10 @@ class PPOLagEngine:
                 ((reward, "reward"), (cost, "cost"), (terminated, "terminated"), (truncated, "truncated"))]
         if epoch_end:
             next_obs = _abi.require_gpu_tensor(next_obs, "next_obs", torch.float32)
-            _abi.check(self.lib.spo_values(_abi.ptr(self.policy.theta), _abi.ptr(next_obs), _abi.ptr(self.vnext_r),
-                                           _abi.ptr(self.vnext_c), self.N, self.D, self.A, st), "spo_values")
+            self._values_into(next_obs, self.vnext_r, self.vnext_c)
         if final_obs is not None:
             final_obs = _abi.require_gpu_tensor(final_obs, "final_observation", torch.float32)
-            _abi.check(self.lib.spo_values(_abi.ptr(self.policy.theta), _abi.ptr(final_obs), _abi.ptr(self.vfinal_r),
-                                           _abi.ptr(self.vfinal_c), self.N, self.D, self.A, st), "spo_values")
+            self._values_into(final_obs, self.vfinal_r, self.vfinal_c)
         d = b.data
         _abi.check(self.lib.spo_boundary_step_fold(
             _abi.ptr(tens[0]), _abi.ptr(tens[1]), _abi.ptr(tens[2]), _abi.ptr(tens[3]),
@@ -398,3 +404,111 @@ class PPOLagEngine:
             means = [float("nan")] * 3
         return {"stop_iter": stop_iter, "kl": kl, "loss_r": means[0], "loss_c": means[1], "loss_pi": means[2],
                 "losses": all_losses}
+
+
+class WidePPOLagEngine(PPOLagEngine):
+    """The same epoch for an ActorVCritic with hidden_sizes other than [64, 64] (reference model.py:131; the
+    isaac_gym_specific_cfg regime of ppo_lag.py:54-65): collect, boundary logic, GAE, statistics and the KL early stop are
+    shared with PPOLagEngine; the policy step, the bootstrap values, the full-batch actor evaluation and the minibatch step
+    run on the wide-network kernels (safepo.common.wide).  Single GPU."""
+
+    def _require_policy(self, policy) -> None:
+        if policy.kernels_supported():
+            raise ValueError("hidden_sizes [64, 64] runs on PPOLagEngine (persistent kernels)")
+        policy.wide          # builds the layout; raises on unsupported depths
+
+    def __init__(self, policy: ActorVCritic, num_envs: int, steps: int, config: dict, device,
+                 comm: Comm | None = None, lr: float = 3e-4, critic_lr: float | None = None):
+        super().__init__(policy, num_envs, steps, config, device, comm=comm, lr=lr, critic_lr=critic_lr)
+        if self.comm.world_size != 1:
+            raise NotImplementedError("the wide-network path runs on one GPU in this build")
+        self.wide = policy.wide
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        self.loss_partials = torch.zeros(4096, dtype=torch.float64, device=self.dev)
+        self.scal4 = torch.zeros(4, **f32)
+
+    def _values_into(self, obs, out_r, out_c) -> None:
+        v_r, v_c = self.wide.values(obs)
+        out_r.copy_(v_r); out_c.copy_(v_c)
+
+    def collect_step(self, t: int, obs: torch.Tensor, eps: torch.Tensor | None = None,
+                     deterministic: bool = False, rms=None) -> torch.Tensor:
+        b = self.buffer
+        assert t == b.ptr and t < self.T, "Buffer overflow"
+        obs = _abi.require_gpu_tensor(obs, "obs", torch.float32)
+        if rms is not None and rms.pending:
+            rms.pending = False
+            rms.normalize_(obs, update=True)
+        if not deterministic and eps is None:
+            eps = torch.randn((self.N, self.A), device=self.dev, dtype=torch.float32)
+        act, logp, v_r, v_c = self.wide.step(obs, None if deterministic else eps)
+        d = b.data
+        d["obs"][:, t].copy_(obs); d["act"][:, t].copy_(act); d["log_prob"][:, t].copy_(logp)
+        d["value_r"][:, t].copy_(v_r); d["value_c"][:, t].copy_(v_c)
+        self.act_out.copy_(act); self.logp.copy_(logp); self.v_r.copy_(v_r); self.v_c.copy_(v_c)
+        return self.act_out
+
+    def snapshot_old_distribution(self) -> None:
+        obs = self.buffer.data["obs"].view(self.M, self.D)
+        self.wide.actor_mean(obs, out=self.mean_old)
+        off = self.policy.log_std_offset
+        self.logstd_old.copy_(self.policy.theta[off:off + self.A])
+        torch.exp(self.logstd_old, out=self.std_old)
+
+    def kl_to_old(self) -> float:
+        obs = self.buffer.data["obs"].view(self.M, self.D)
+        off = self.policy.log_std_offset
+        ls_new = self.policy.theta[off:off + self.A]
+        from safepo.common.wide import KL_CHUNK
+        for k, lo in enumerate(range(0, self.M, KL_CHUNK)):
+            mu, _ = self.wide.forward("a", obs[lo:lo + KL_CHUNK])
+            _abi.check(self.lib.spo_gauss_kl_sum(_abi.ptr(self.mean_old[lo:lo + mu.shape[0]]), _abi.ptr(self.logstd_old), _abi.ptr(mu),
+                                                 _abi.ptr(ls_new), mu.shape[0], self.A, _abi.ptr(self.kl_partials),
+                                                 self.kl_partials.numel(), _abi.ptr(self.kl_sum), int(k > 0), _abi.stream_ptr()),
+                       "spo_gauss_kl_sum")
+        return float(self.kl_sum.item()) / float(self.M)
+
+    def minibatch_step(self, idx: torch.Tensor, losses_out: torch.Tensor) -> None:
+        """ppo_lag.py:306-329 on the rows `idx` (int64 device indices into the flat buffer)."""
+        w, lib, st = self.wide, self.lib, _abi.stream_ptr
+        d, b = self.buffer.data, self.buffer
+        cfg = self._cfg_struct()
+        obs = d["obs"].view(self.M, self.D).index_select(0, idx)
+        act = d["act"].view(self.M, self.A).index_select(0, idx)
+        logp_old, adv = d["log_prob"].view(-1).index_select(0, idx), b.adv_mix.view(-1).index_select(0, idx)
+        tgt_r, tgt_c = d["target_value_r"].view(-1).index_select(0, idx), d["target_value_c"].view(-1).index_select(0, idx)
+        n = obs.shape[0]
+        v_r, ws_r = w.forward("r", obs, slot=1)
+        v_c, ws_c = w.forward("c", obs, slot=1)
+        mu, ws_a = w.forward("a", obs, slot=1)
+        d_vr = torch.empty(n, dtype=torch.float32, device=self.dev)
+        d_vc, d_mu = torch.empty_like(d_vr), torch.empty((n, self.A), dtype=torch.float32, device=self.dev)
+        g = self.flat_grad
+        off_ls = w.off_ls
+        _abi.check(lib.spo_wide_ppo_loss(_abi.ptr(v_r), _abi.ptr(v_c), _abi.ptr(mu), _abi.ptr(self.policy.theta[off_ls:]), _abi.ptr(act),
+                                         _abi.ptr(logp_old), _abi.ptr(adv), _abi.ptr(tgt_r), _abi.ptr(tgt_c), n, self.A, float(cfg.clip),
+                                         _abi.ptr(d_vr), _abi.ptr(d_vc), _abi.ptr(d_mu), _abi.ptr(g[off_ls:]), _abi.ptr(losses_out),
+                                         _abi.ptr(self.loss_partials), self.loss_partials.numel(), st()), "spo_wide_ppo_loss")
+        w.backward("r", obs, ws_r, d_vr, g)
+        w.backward("c", obs, ws_c, d_vc, g)
+        w.backward("a", obs, ws_a, d_mu, g)
+        _abi.check(lib.spo_wide_clip_adam(_abi.ptr(self.policy.theta), _abi.ptr(g), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), w.P,
+                                          w.off_c, w.off_ls, w.off_ls, cfg, self.adam_step, _abi.ptr(losses_out), _abi.ptr(self.scal4),
+                                          _abi.ptr(self.loss_partials), self.loss_partials.numel(), st()), "spo_wide_clip_adam")
+        self.adam_step += 1
+
+    def learning_iter(self, perm: torch.Tensor) -> torch.Tensor:
+        cfg = self._cfg_struct()
+        perm = _abi.require_gpu_tensor(perm, "perm", torch.int32).long()
+        M = self.M
+        n_mb = (M + cfg.batch - 1) // cfg.batch
+        losses = torch.empty((n_mb, 3), dtype=torch.float32, device=self.dev)
+        for k in range(n_mb):
+            self.minibatch_step(perm[k * cfg.batch:(k + 1) * cfg.batch], losses[k])
+        return losses
+
+    def learning_iter_ex(self, *a, **k):
+        raise NotImplementedError("focops / cup run on hidden_sizes [64, 64] in this build")
+
+    def check_sync_error(self):
+        return None

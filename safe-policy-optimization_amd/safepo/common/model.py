@@ -88,25 +88,37 @@ class ActorVCritic(nn.Module):
         return out
 
     def kernels_supported(self) -> bool:
+        """True for the shape the persistent LDS-resident kernels are built for (hidden_sizes [64, 64], the default_cfg of
+        every reference script); every other hidden_sizes runs on the wide-network kernels (safepo.common.wide)."""
         return self.hidden_sizes == [HIDDEN, HIDDEN]
 
     def _require_kernels(self):
         if not self.kernels_supported():
             raise NotImplementedError(
-                f"HIP kernels are specialised for hidden_sizes=[64, 64] (got {self.hidden_sizes}); "
-                "isaac_gym_specific_cfg shapes are not built yet")
+                f"this entry point uses the kernels specialised for hidden_sizes=[64, 64] (got {self.hidden_sizes}); "
+                "other widths run through safepo.common.wide / WidePPOLagEngine (PPO-Lagrangian family)")
         n = _abi.load().spo_param_count(self.obs_dim, self.act_dim)
         assert n == self.theta.numel(), (n, self.theta.numel())
 
     @property
+    def wide(self):
+        """Host side of the wide-network kernels for this policy (created on first use; hidden_sizes != [64, 64])."""
+        w = self.__dict__.get("_wide")
+        if w is None or w.policy.theta is not self.theta:
+            from safepo.common.wide import WideNets
+            w = WideNets(self)
+            self.__dict__["_wide"] = w
+        return w
+
+    @property
     def log_std_offset(self) -> int:
-        return int(_abi.load().spo_param_offset(self.obs_dim, self.act_dim, 2))
+        n_critic = sum(p.numel() for p in self.reward_critic.parameters())
+        return 2 * n_critic             # policy.parameters() order: reward critic, cost critic, actor.log_std, actor.mean.*
 
     # ------------------------------------------------------------------ reference API
     def step(self, obs, deterministic: bool = False, eps: torch.Tensor | None = None):
         """ActorVCritic.step (model.py:149-170) through spo_policy_step.  `eps` may carry the
         rsample noise (parity tests); otherwise it is drawn from torch's device generator."""
-        self._require_kernels()
         single = obs.dim() == 1
         obs2 = obs.reshape(1, -1) if single else obs
         obs2 = _abi.require_gpu_tensor(obs2.contiguous(), "obs", torch.float32)
@@ -118,6 +130,9 @@ class ActorVCritic(nn.Module):
             eps = torch.randn((n, self.act_dim), device=dev, dtype=torch.float32)
         else:
             eps = _abi.require_gpu_tensor(eps.reshape(n, self.act_dim).contiguous(), "eps", torch.float32)
+        if not self.kernels_supported():
+            act, logp, v_r, v_c = self.wide.step(obs2, eps)
+            return (act[0], logp[0], v_r[0], v_c[0]) if single else (act, logp, v_r, v_c)
         act = torch.empty((n, self.act_dim), device=dev, dtype=torch.float32)
         logp = torch.empty(n, device=dev, dtype=torch.float32)
         v_r = torch.empty(n, device=dev, dtype=torch.float32)
@@ -132,8 +147,9 @@ class ActorVCritic(nn.Module):
 
     def values(self, obs):
         """(v_r, v_c) for a batch of observations (bootstrap calls, ppo_lag.py:201-215)."""
-        self._require_kernels()
         obs2 = _abi.require_gpu_tensor(obs.reshape(-1, self.obs_dim).contiguous(), "obs", torch.float32)
+        if not self.kernels_supported():
+            return self.wide.values(obs2)
         n = obs2.shape[0]
         v_r = torch.empty(n, device=obs2.device, dtype=torch.float32)
         v_c = torch.empty(n, device=obs2.device, dtype=torch.float32)

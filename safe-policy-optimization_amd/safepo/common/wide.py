@@ -1,0 +1,109 @@
+"""ActorVCritic with hidden_sizes other than [64, 64]: host side of the wide-network kernels.
+
+The reference builds its MLPs for any `hidden_sizes` (safepo/common/model.py:30-48,131) and selects
+`[1024, 1024, 512]` with minibatches of steps_per_epoch // 4 rows for Isaac Gym tasks
+(isaac_gym_specific_cfg, safepo/single_agent/ppo_lag.py:54-65).  The persistent kernels of csrc/update.hip are built
+around a 64-wide network living in one CU's LDS; every other shape runs here, as a sequence of launches on the in-tree
+fp32 MFMA GEMM kernels (csrc/ma_net.hip: spo_mlp_forward / spo_mlp_backward / spo_wide_ppo_loss / spo_wide_clip_adam).
+Same flat parameter vector, same state_dict keys, same optimiser semantics (critic L2 terms, joint clip_grad_norm_,
+three Adam optimisers with the actor's own learning rate, ppo_lag.py:306-329).
+"""
+from __future__ import annotations
+
+import torch
+
+from safepo import _abi
+
+KL_CHUNK = 65536        # rows per full-batch actor evaluation (activations of [1024, 1024, 512]: 0.7 GB per chunk)
+
+
+class WideNets:
+    """The three networks of an ActorVCritic as views of its flat parameter vector, with cached workspaces."""
+
+    def __init__(self, policy):
+        self.policy = policy
+        self.lib = _abi.load()
+        D, A, hs = policy.obs_dim, policy.act_dim, list(policy.hidden_sizes)
+        self.D, self.A = D, A
+        self.net_c = _abi.MlpNet.of([D] + hs + [1])
+        self.net_a = _abi.MlpNet.of([D] + hs + [A])
+        self.Pc = int(self.lib.spo_mlp_param_count(self.net_c))
+        self.Pa = int(self.lib.spo_mlp_param_count(self.net_a))
+        if self.Pc < 0 or self.Pa < 0:
+            _abi.check(-2, "spo_mlp_param_count")
+        # policy.parameters() order (model.py:131-135): reward critic, cost critic, actor.log_std, actor.mean.*
+        self.off_r, self.off_c, self.off_ls, self.off_a = 0, self.Pc, 2 * self.Pc, 2 * self.Pc + A
+        self.P = 2 * self.Pc + A + self.Pa
+        assert self.P == policy.theta.numel(), (self.P, policy.theta.numel())
+        self._ws, self._scratch = {}, {}
+
+    # ------------------------------------------------------------------ pieces
+    def theta_of(self, which):
+        th = self.policy.theta
+        return {"r": th[self.off_r:], "c": th[self.off_c:], "a": th[self.off_a:]}[which]
+
+    def net_of(self, which):
+        return self.net_a if which == "a" else self.net_c
+
+    def _workspace(self, which, rows, slot=0):
+        key = (which, rows, slot)
+        ws = self._ws.get(key)
+        if ws is None:
+            n = int(self.lib.spo_mlp_workspace_floats(self.net_of(which), rows))
+            ws = torch.empty(n, dtype=torch.float32, device=self.policy.theta.device)
+            if len(self._ws) > 24:
+                self._ws.clear()
+            self._ws[key] = ws
+        return ws
+
+    def forward(self, which, x, slot=0):
+        """Output [rows, out] (a view of the workspace, valid until the next forward with the same key) and the workspace."""
+        rows = x.shape[0]
+        ws = self._workspace(which, rows, slot)
+        _abi.check(self.lib.spo_mlp_forward(_abi.ptr(self.theta_of(which)), self.net_of(which), _abi.ptr(x), rows, _abi.ptr(ws),
+                                            _abi.stream_ptr()), "spo_mlp_forward")
+        out_dim = self.A if which == "a" else 1
+        return ws[ws.numel() - rows * out_dim:].view(rows, out_dim), ws
+
+    def backward(self, which, x, ws, d_out, grad_flat):
+        rows = x.shape[0]
+        net = self.net_of(which)
+        key = (which, rows)
+        sc = self._scratch.get(key)
+        if sc is None:
+            n = int(self.lib.spo_mlp_backward_scratch_floats(net, rows))
+            sc = torch.empty(n, dtype=torch.float32, device=x.device)
+            if len(self._scratch) > 12:
+                self._scratch.clear()
+            self._scratch[key] = sc
+        off = {"r": self.off_r, "c": self.off_c, "a": self.off_a}[which]
+        _abi.check(self.lib.spo_mlp_backward(_abi.ptr(self.theta_of(which)), net, _abi.ptr(x), rows, _abi.ptr(ws), _abi.ptr(d_out),
+                                             _abi.ptr(grad_flat[off:]), _abi.ptr(sc), _abi.stream_ptr()), "spo_mlp_backward")
+
+    # ------------------------------------------------------------------ reference API pieces
+    def values(self, obs):
+        v_r, _ = self.forward("r", obs)
+        v_r = v_r.reshape(-1).clone()
+        v_c, _ = self.forward("c", obs)
+        return v_r, v_c.reshape(-1).clone()
+
+    def actor_mean(self, obs, out=None):
+        """mean of policy.actor(obs) for any number of rows (chunked)."""
+        M = obs.shape[0]
+        out = torch.empty((M, self.A), dtype=torch.float32, device=obs.device) if out is None else out
+        for lo in range(0, M, KL_CHUNK):
+            mu, _ = self.forward("a", obs[lo:lo + KL_CHUNK])
+            out[lo:lo + mu.shape[0]].copy_(mu)
+        return out
+
+    def step(self, obs, eps):
+        """ActorVCritic.step (model.py:149-170): (act, logp, v_r, v_c); eps None = deterministic."""
+        n = obs.shape[0]
+        mu, _ = self.forward("a", obs)
+        act = torch.empty((n, self.A), dtype=torch.float32, device=obs.device)
+        logp = torch.empty(n, dtype=torch.float32, device=obs.device)
+        ls = self.policy.theta[self.off_ls:self.off_ls + self.A]
+        _abi.check(self.lib.spo_gauss_sample(_abi.ptr(mu), _abi.ptr(ls), _abi.ptr(eps), _abi.ptr(act), _abi.ptr(logp), n, self.A,
+                                             _abi.stream_ptr()), "spo_gauss_sample")
+        v_r, v_c = self.values(obs)
+        return act, logp, v_r, v_c

@@ -16,7 +16,7 @@ import time
 import numpy as np
 import torch
 
-from safepo.common.engine import PPOLagEngine
+from safepo.common.engine import PPOLagEngine, WidePPOLagEngine
 from safepo.common.env import make_sa_mujoco_env
 from safepo.common.lagrange import Lagrange, PIDLagrangian
 from safepo.common.logger import EpochLogger
@@ -52,7 +52,8 @@ def run(args, cfg_env, default_cfg: dict, multiplier: str | None = "adam", clip:
         raise NotImplementedError("Isaac Gym tasks (isaac_gym_specific_cfg) are not part of this build")
     config = dict(default_cfg)
     config.update(getattr(args, "cfg_override", None) or {})
-    config["clip"] = NO_CLIP if clip is None else clip
+    config = {k: v for k, v in config.items() if v is not None}      # an override of None drops the key (e.g. batch_size,
+    config["clip"] = NO_CLIP if clip is None else clip              # so that num_mini_batch decides as in isaac_gym_specific_cfg)
 
     require_equal_shards(args.num_envs, comm)
     _, n_local = shard_envs(args.num_envs, comm)
@@ -73,7 +74,13 @@ def run(args, cfg_env, default_cfg: dict, multiplier: str | None = "adam", clip:
     policy = ActorVCritic(obs_dim=obs_space.shape[0], act_dim=act_space.shape[0],
                           hidden_sizes=config["hidden_sizes"]).to(device)
     comm.broadcast_(policy.theta, 0)            # identical replicas
-    engine = PPOLagEngine(policy, n_local, local_steps_per_epoch, config, device, comm=comm, lr=3e-4)
+    # hidden_sizes [64, 64] (default_cfg): persistent LDS-resident kernels; any other width: the wide-network kernels
+    if policy.kernels_supported():
+        engine = PPOLagEngine(policy, n_local, local_steps_per_epoch, config, device, comm=comm, lr=3e-4)
+    else:
+        if variant != "ppo":
+            raise NotImplementedError(f"{variant} runs on hidden_sizes [64, 64] in this build (got {config['hidden_sizes']})")
+        engine = WidePPOLagEngine(policy, n_local, local_steps_per_epoch, config, device, comm=comm, lr=3e-4)
     if multiplier == "adam":
         upper = {"focops": FOCOPS_NU, "cup": CUP_NU}.get(variant)          # focops.py:136, cup.py:136
         lagrange = Lagrange(cost_limit=args.cost_limit, lagrangian_multiplier_init=args.lagrangian_multiplier_init,

@@ -28,6 +28,24 @@ default_cfg = {
 }
 
 
+# The reference's configuration for Isaac Gym tasks (ppo_lag.py:54-65).  The simulator itself is out of scope here, but its
+# network / batch regime is built: hidden_sizes other than [64, 64] run on the wide-network kernels (safepo.common.wide),
+# `num_mini_batch` without `batch_size` gives minibatches of steps_per_epoch // num_mini_batch rows; select it with
+# args.cfg_override = isaac_gym_specific_cfg on a synthetic or host env.
+isaac_gym_specific_cfg = {
+    'total_steps': 100000000,
+    'steps_per_epoch': 32768,
+    'hidden_sizes': [1024, 1024, 512],
+    'gamma': 0.96,
+    'target_kl': 0.016,
+    'num_mini_batch': 4,
+    'use_value_coefficient': True,
+    'learning_iters': 8,
+    'max_grad_norm': 1.0,
+    'use_critic_norm': False,
+}
+
+
 def main(args, cfg_env=None):
     return _first_order.run(args, cfg_env, default_cfg, multiplier="adam", clip=0.2)
 

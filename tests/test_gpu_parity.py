@@ -2310,3 +2310,113 @@ def test_full_size_update_parity_drift_envelope(dev):
     assert eng.adam_step == 8192
     rep = _assert_trajectory_in_envelope(runs, problem, sd0, perm, 64, ks, "full-size learning iteration")
     print("drift envelope (ratio <= 1 passes):", rep)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Wide networks: ActorVCritic(obs_dim, act_dim, hidden_sizes) beyond [64, 64] (reference model.py:131; the
+# isaac_gym_specific_cfg regime of ppo_lag.py:54-65) on the wide-network kernels.
+def _wide_pair(D, A, hidden, dev, seed):
+    from safepo.common.model import ActorVCritic
+    torch.manual_seed(seed)
+    pol = ActorVCritic(D, A, hidden_sizes=hidden).to(dev)
+    with torch.no_grad():
+        pol.actor.log_std.copy_(torch.randn(A) * 0.2)
+    ref = R.OraclePolicy(D, A, hidden_sizes=tuple(hidden))
+    ref.load_state_dict({k: v.detach().cpu().clone() for k, v in pol.state_dict().items()})
+    assert [k for k in pol.state_dict()] == [k for k in ref.state_dict()]
+    return pol, ref
+
+
+@pytest.mark.parametrize("D,A,hidden,n", [(60, 8, [128, 128], 257), (33, 3, [256, 96], 70), (60, 8, [1024, 1024, 512], 130),
+                                          (17, 2, [32], 5)])
+def test_wide_policy_step_vs_oracle(dev, D, A, hidden, n):
+    """ActorVCritic.step / values / actor forward for hidden_sizes other than [64, 64] (model.py:149-170) against the oracle
+    with the same state_dict: every Linear on the in-tree fp32 MFMA GEMM, tanh, rsample and log-prob kernels."""
+    pol, ref = _wide_pair(D, A, hidden, dev, seed=5 + n)
+    g = torch.Generator().manual_seed(n)
+    obs, eps = torch.randn(n, D, generator=g), torch.randn(n, A, generator=g)
+    act, logp, v_r, v_c = pol.step(obs.to(dev), eps=eps.to(dev))
+    with torch.no_grad():
+        a_ref, lp_ref, vr_ref, vc_ref = ref.step_with_eps(obs, eps)
+    tol = dict(rtol=2e-5, atol=5e-6)
+    np.testing.assert_allclose(act.cpu().numpy(), a_ref.numpy(), **tol)
+    np.testing.assert_allclose(logp.cpu().numpy(), lp_ref.numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(v_r.cpu().numpy(), vr_ref.numpy(), **tol)
+    np.testing.assert_allclose(v_c.cpu().numpy(), vc_ref.numpy(), **tol)
+    a_det, _, _, _ = pol.step(obs.to(dev), deterministic=True)
+    with torch.no_grad():
+        np.testing.assert_allclose(a_det.cpu().numpy(), ref.actor(obs).mean.numpy(), **tol)
+    vr2, vc2 = pol.values(obs.to(dev))
+    assert torch.equal(vr2, v_r) and torch.equal(vc2, v_c)
+    a1, lp1, _, _ = pol.step(obs[0].to(dev), eps=eps[0].to(dev))             # single-row form of the reference API
+    np.testing.assert_allclose(a1.cpu().numpy(), a_ref[0].numpy(), **tol)
+
+
+@pytest.mark.parametrize("D,A,hidden,batch,steps,cfg_kw", [
+    (60, 8, [128, 128], 64, 8, {}),
+    (60, 8, [256, 96], 100, 4, {"max_grad_norm": 0.5}),
+    (60, 8, [1024, 1024, 512], 8192, 2, {"use_critic_norm": False, "use_value_coefficient": True, "max_grad_norm": 1.0}),
+])
+def test_wide_minibatch_steps_vs_oracle(dev, D, A, hidden, batch, steps, cfg_kw):
+    """The PPO-Lagrangian minibatch step (ppo_lag.py:306-329: MSE + critic L2, clipped surrogate, value coefficient, joint
+    clip_grad_norm_, three Adam optimisers) for wide networks against the oracle: per-step losses at 1e-5, parameters after
+    the steps; [128, 128] at the default batch of 64 and [1024, 1024, 512] at 8 192 rows with isaac_gym_specific_cfg's options."""
+    from safepo.common.engine import WidePPOLagEngine
+    pol, ref = _wide_pair(D, A, hidden, dev, seed=3)
+    M = batch * steps
+    cfg = {"hidden_sizes": hidden, "gamma": 0.99, "target_kl": 0.02, "batch_size": batch, "learning_iters": 1, "max_grad_norm": 40.0}
+    cfg.update(cfg_kw)
+    eng = WidePPOLagEngine(pol, 1, M, cfg, dev)
+    problem = _synthetic_update_problem(M, D, A, seed=17)
+    _fill_update_problem(eng, problem)
+    perm = torch.randperm(M, generator=torch.Generator().manual_seed(2))
+    losses = eng.learning_iter(perm.to(torch.int32).to(dev)).cpu().numpy()
+    kw = {k: v for k, v in cfg_kw.items() if k in ("use_critic_norm", "use_value_coefficient")}
+    upd = R.PPOLagUpdater(ref, epochs=1, max_grad_norm=cfg["max_grad_norm"], **kw)
+    obs, act, logp, tgt_r, tgt_c, adv = problem
+    want = []
+    for k in range(steps):
+        ii = perm[k * batch:(k + 1) * batch]
+        want.append(upd.minibatch_step(obs[ii], act[ii], logp[ii], tgt_r[ii], tgt_c[ii], adv[ii]))
+    np.testing.assert_allclose(losses, np.asarray(want), rtol=1e-5, atol=2e-6)
+    _assert_params_close(pol.theta.cpu().numpy(), R.flat_params(ref).numpy(), 3e-4, steps, rtol=2e-4, atol=2e-6, what=f"wide {hidden}")
+    assert eng.adam_step == steps
+
+
+def test_wide_kl_and_entrypoint_synthetic(dev, tmp_path):
+    """Full-batch KL for a wide actor against the oracle, then ppo_lag.main() end to end with hidden_sizes [128, 128] on the
+    synthetic env (collect, boundary logic, GAE, update, logger) and with the shape options of isaac_gym_specific_cfg."""
+    import argparse
+    import csv
+    from safepo.common.engine import WidePPOLagEngine
+    from safepo.single_agent import ppo_lag
+    D, A, hidden, M = 60, 8, [128, 128], 3000
+    pol, ref = _wide_pair(D, A, hidden, dev, seed=9)
+    cfg = {"hidden_sizes": hidden, "gamma": 0.99, "target_kl": 0.02, "batch_size": 64, "learning_iters": 1, "max_grad_norm": 40.0}
+    eng = WidePPOLagEngine(pol, 1, M, cfg, dev)
+    obs = torch.randn(M, D, generator=torch.Generator().manual_seed(4))
+    eng.buffer.data["obs"].copy_(obs.view(1, M, D))
+    eng.snapshot_old_distribution()
+    with torch.no_grad():
+        old = ref.actor(obs)
+        old_mean, old_std = old.mean.clone(), old.stddev.clone()
+        delta = 0.01 * torch.randn(pol.theta.numel(), generator=torch.Generator().manual_seed(8))
+        pol.theta.add_(delta.to(dev))
+        ref.load_state_dict({k: v.detach().cpu().clone() for k, v in pol.state_dict().items()})
+    assert eng.kl_to_old() == pytest.approx(R.actor_kl(ref, obs, old_mean, old_std), rel=2e-5)
+    assert set(ppo_lag.isaac_gym_specific_cfg) >= {"hidden_sizes", "num_mini_batch", "use_value_coefficient", "use_critic_norm"}
+    for tag, override in (("w128", {"hidden_sizes": [128, 128], "learning_iters": 2, "batch_size": 256}),
+                          ("isaac_shape", {"hidden_sizes": [96, 64, 32], "num_mini_batch": 4, "batch_size": None, "learning_iters": 2,
+                                           "use_value_coefficient": True, "use_critic_norm": False, "max_grad_norm": 1.0})):
+        cfg_run = dict(override)                   # "batch_size": None removes default_cfg's key: minibatches of M // num_mini_batch rows
+        args = argparse.Namespace(seed=0, use_eval=False, task="SynthSafe-v0", num_envs=16, experiment="t",
+                                  log_dir=str(tmp_path / tag / "task" / "run"), device="cuda", device_id=0, write_terminal=True,
+                                  headless=False, total_steps=2 * 16 * 64, steps_per_epoch=16 * 64, randomize=False, cost_limit=25.0,
+                                  lagrangian_multiplier_init=0.001, lagrangian_multiplier_lr=0.035, cfg_override=cfg_run,
+                                  env_kwargs={"trunc_len": 16})
+        out = ppo_lag.main(args, {})
+        rows = list(csv.DictReader(open(tmp_path / tag / "task" / "run" / "progress.csv")))
+        assert len(rows) == 2 and np.isfinite(float(rows[-1]["Loss/Loss_actor"])) and np.isfinite(float(rows[-1]["Train/KL"]))
+        assert type(out["engine"]).__name__ == "WidePPOLagEngine"
+        if tag == "isaac_shape":
+            assert out["engine"]._cfg_struct().batch == 16 * 64 // 4 and out["engine"]._cfg_struct().use_value_coefficient == 1
