@@ -522,7 +522,13 @@ def main():
                            "us_per_minibatch_step": round(us_step, 3),
                            "mfma_floor_us": round(368 * 32 / 2.4e9 * 1e6, 3),
                            "frac": round((368 * 32 / 2.4e9) / (us_step * 1e-6), 4),
-                           "note": "floor = MFMA issue cycles at 2.4 GHz; DESIGN.md 3.3 has the instruction mix"}
+                           "simd_sum_floor_us": round((368 * 32 + 2400 * 4) / 2.4e9 * 1e6, 3),
+                           "frac_of_simd_sum_floor": round(((368 * 32 + 2400 * 4) / 2.4e9) / (us_step * 1e-6), 4),
+                           "note": "mfma_floor = the 368 MFMA issue slots of a main wave at 2.4 GHz; on this part a SIMD's vector "
+                                   "instructions do not overlap its matrix instructions (tools/probes/mfma_valu_overlap.hip, "
+                                   "profiles/r03/mfma_valu_overlap.txt: two waves together take exactly the sum of each alone), so the "
+                                   "floor of one step on one CU is MFMA cycles + ~2400 VALU instructions of the main and helper wave "
+                                   "x 4 cycles = simd_sum_floor; DESIGN.md 3.3"}
                           if a.algo == "ppo_lag" else None),
         ("kl_kernel" if a.algo == "ppo_lag" else "cpo_fvp"): kl_entry,
         "cpu_baseline": cpu,

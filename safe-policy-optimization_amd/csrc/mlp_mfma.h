@@ -72,15 +72,39 @@ struct NetLds {
 };
 
 // Cooperative copy of one network from the flat vector into its padded LDS image (pads zeroed).
+// Round 3: no integer division per element (the old form computed i / D and i % D for each of ~8 500 floats: ~40 VALU
+// instructions per element in front of every load, several microseconds per staged network in kernels that stage one per
+// launch): KIN / 4 lanes cover a row, each lane four consecutive columns, rows advance by nthr / (KIN / 4).
 template <int KIN>
 __device__ inline void stage_net(const float* __restrict__ theta, const NetGeom g, float* lds, int tid, int nthr) {
   using L = NetLds<KIN>;
-  for (int i = tid; i < L::SIZE; i += nthr) lds[i] = 0.f;
+  for (int i = tid; i < L::SIZE / 4; i += nthr) reinterpret_cast<f4*>(lds)[i] = f4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
   const int D = g.D;
-  for (int i = tid; i < HID * D; i += nthr) lds[L::W1 + (i / D) * L::LD1 + (i % D)] = theta[g.w1() + i];
-  for (int i = tid; i < HID * HID; i += nthr) lds[L::W2 + (i / HID) * LDH + (i % HID)] = theta[g.w2() + i];
-  for (int i = tid; i < g.OUT * HID; i += nthr) lds[L::W3 + (i / HID) * LDH + (i % HID)] = theta[g.w3() + i];
+  {
+    constexpr int TPR = KIN / 4;                       // lanes per row of W1 (a power of two: KIN is 16, 32, 64 or 128)
+    const int c0 = (tid % TPR) * 4, rstep = nthr / TPR;
+    for (int r = tid / TPR; r < HID; r += rstep) {
+      const float* src = theta + g.w1() + r * D + c0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c0 + e < D) lds[L::W1 + r * L::LD1 + c0 + e] = src[e];
+    }
+  }
+  {
+    constexpr int TPR = HID / 4;
+    const int c0 = (tid % TPR) * 4, rstep = nthr / TPR;
+    for (int r = tid / TPR; r < HID; r += rstep) {
+      const float* src = theta + g.w2() + r * HID + c0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) lds[L::W2 + r * LDH + c0 + e] = src[e];
+    }
+    for (int r = tid / TPR; r < g.OUT; r += rstep) {
+      const float* src = theta + g.w3() + r * HID + c0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) lds[L::W3 + r * LDH + c0 + e] = src[e];
+    }
+  }
   for (int i = tid; i < HID; i += nthr) { lds[L::B1 + i] = theta[g.b1() + i]; lds[L::B2 + i] = theta[g.b2() + i]; }
   for (int i = tid; i < g.OUT; i += nthr) lds[L::B3 + i] = theta[g.b3() + i];
 }

@@ -2420,3 +2420,32 @@ def test_wide_kl_and_entrypoint_synthetic(dev, tmp_path):
         assert type(out["engine"]).__name__ == "WidePPOLagEngine"
         if tag == "isaac_shape":
             assert out["engine"]._cfg_struct().batch == 16 * 64 // 4 and out["engine"]._cfg_struct().use_value_coefficient == 1
+
+
+@pytest.mark.parametrize("dp_batch", ["local", "global"])
+def test_bench_self_launches_two_ranks_on_one_gpu(dev, dp_batch):
+    """`python bench.py --gpus 2` WITHOUT a launcher (how the driver invokes it) spawns its own two ranks (here both on
+    cuda:0: SPO_BENCH_ONE_GPU=1), runs the data-parallel epoch with the in-kernel gradient exchange and prints ONE line with
+    n_gpus = 2, per-rank timings and the exchange form; `--dp-batch global` runs the exact-semantics partitioning (global
+    minibatch of 64 = 2 x 32 rows)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SPO_BENCH_ONE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--num-envs", "256",
+                        "--num-steps", "32", "--learning-iters", "2", "--no-cpu-baseline", "--no-config3", "--no-config5", "--stream-envs",
+                        "2048", "--dp-batch", dp_batch], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 512 and d["scaling"] == "weak"
+    assert len(d["per_rank"]) == 2 and all(p["ms_per_step"] > 0 for p in d["per_rank"])
+    ex = d["exchange"]
+    assert ex["dp_batch"] == dp_batch and ex["host_collectives_world"] == 2 and ex["all_ranks_on_one_gpu"] is True
+    assert ex["form"].startswith("in-kernel") and ex["selftest_result"] == [0, 0], ex
+    per_rank_rows = 64 if dp_batch == "local" else 32
+    assert d["config"]["minibatch_steps_per_epoch"] == (256 * 32 // per_rank_rows) * 2
+    assert d["value"] == pytest.approx(2 * 256 * 32 / (d["ms_per_step"] * 1e-3), rel=1e-3)
