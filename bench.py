@@ -16,7 +16,7 @@ Prints ONE JSON line (rank 0) with the driver's fields plus
                   per-dispatch duration (HIP events around every launch: the figure rocprofv3 --kernel-trace reports);
   `roofline_hbm_streaming`  the same kernel on a 1.1 GB buffer that cannot sit in the 256 MiB Infinity Cache: the HBM claim;
   `cpu_baseline`  oracle port of the reference loop timed on this box's host cores (rank 0, N=1 only) + the unmodified
-                  reference's own figures recorded in the build container (profiles/r02/cpu_reference_timing.json);
+                  reference's own figures recorded in the build container (profiles/r03/cpu_reference_timing.json);
   `config3_cpo`   BASELINE config 3 (CPO, same sizes) with its own CPU baseline, N=1 only.
 """
 from __future__ import annotations
@@ -42,10 +42,19 @@ GAE_DISPATCHES = 50              # individually event-bracketed launches per tim
 PEER_EXCHANGE_USED = [False]     # set by run_epochs on rank 0 (N > 1): which form of the minibatch exchange ran
 
 
+def profile_path(name: str) -> str:
+    """The newest committed copy of a profile artefact (profiles/r03, else profiles/r02)."""
+    for rnd in ("r03", "r02"):
+        p = os.path.join(ROOT, "profiles", rnd, name)
+        if os.path.exists(p):
+            return p
+    return os.path.join(ROOT, "profiles", "r03", name)
+
+
 def recorded_reference(algo: str):
     """Figures of the UNMODIFIED reference main() recorded in the build container by oracle/time_reference.py (the
     reference tree cannot travel to the GPU box).  Provenance (box, torch, command) is carried along."""
-    path = os.path.join(ROOT, "profiles", "r02", "cpu_reference_timing.json")
+    path = profile_path("cpu_reference_timing.json")
     try:
         recs = [r for r in json.load(open(path)) if r.get("algo") == algo]
     except Exception:
@@ -355,11 +364,11 @@ def main():
     achieved = gae_bytes / disp_avg / 1e9
     pmc = None
     try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r02", "gae_pmc.json")))
+        pj = json.load(open(profile_path("gae_pmc.json")))
         hit = [l for l in pj["launches"] if l["num_envs"] == N and l["folded"] == folded and T == 128]
         if hit:
             pmc = {"hbm_bytes_per_launch": round(hit[0]["hbm_bytes"]), "traffic_over_algorithmic": hit[0]["traffic_over_algorithmic"],
-                   "source": "profiles/r02/gae_pmc.json: " + pj["source"] + "; " + pj["corrections"]}
+                   "source": os.path.relpath(profile_path("gae_pmc.json"), ROOT) + ": " + pj["source"] + "; " + pj["corrections"]}
     except Exception:
         pass
     roofline = {"kernel": "gae_kernel (spo_gae_fused" + (", folded bootstrap form)" if folded else ")"), "bound": "hbm", "achieved": round(achieved, 1),
@@ -376,15 +385,15 @@ def main():
                 "note": "achieved = algorithmic bytes / MEAN per-dispatch duration over the timed epochs (200 untimed dispatches first: "
                         "power-management transient after a light-load phase, DESIGN.md 3.1): every dispatch carries its own "
                         "start/stop HIP events on the launch stream (hipExtLaunchKernelGGL: the dispatch packet's timestamps). "
-                        "rocprof_* = the committed rocprofv3 --kernel-trace of this same command (profiles/r02/"
+                        "rocprof_* = the committed rocprofv3 --kernel-trace of this same command (profiles/r03/"
                         "gae_dispatch_durations.json, same kernel and grid): the profiler's own per-dispatch average is ~8 % "
                         "higher than the unprofiled event pairs, and under the profiler the event pairs themselves read ~2x "
-                        "(profiles/r02/bench_profiled_line.json), so the two figures cannot come from one run. graph_* = hipGraph of "
+                        "(profiles/r03/bench_profiled_line.json), so the two figures cannot come from one run. graph_* = hipGraph of "
                         f"{GAE_REPS} back-to-back launches between two events (dispatch set-up overlapped). traffic: PMC "
                         "counters cannot be read inside this run -> null; traffic_profiled is the committed rocprofv3 "
                         "--pmc measurement (FETCH_SIZE x2 + WRITE_SIZE, separate passes) with its source"}
     try:
-        dj = json.load(open(os.path.join(ROOT, "profiles", "r02", "gae_dispatch_durations.json")))
+        dj = json.load(open(profile_path("gae_dispatch_durations.json")))
         want = f"grid={2 * N * 32}"
         hit = [v for k, v in dj["per_kernel_and_grid_size"].items() if k.endswith(want)] if (T == 128 and folded) else []
         if hit:

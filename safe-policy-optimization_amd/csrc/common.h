@@ -17,6 +17,14 @@ inline int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// hipFuncSetAttribute is per device: "already done" flags are kept per device ordinal (round-2 advice)
+constexpr int SPO_MAX_DEVICES = 64;
+inline int current_device_slot() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return (d >= 0 && d < SPO_MAX_DEVICES) ? d : 0;
+}
+
 inline int hip_check(hipError_t e, const char* what) {
   if (e == hipSuccess) return 0;
   snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));

@@ -1305,7 +1305,8 @@ extern "C" int spo_ma_forward(const float* theta, const spo_ma_net* net, const f
       // one fused MFMA kernel (collect-size batches upwards; below that the plain MFMA GEMM + LayerNorm kernel)
       const int K = L.in_k(k), KP = (K + 15) & ~15;
       const size_t sh = ((size_t)128 * (KP + 4) + 128 * 132 + 256) * sizeof(float);       // W image + max(X tile, output image)
-      static bool attr_done = false;
+      static bool attr_done_dev[spo::SPO_MAX_DEVICES] = {};
+      bool& attr_done = attr_done_dev[spo::current_device_slot()];
       if (!attr_done) {
         if (int rc = spo::hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_block_fwd128_kernel<2>),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (2 * 128 * 132 + 256) * 4),
@@ -1404,7 +1405,8 @@ extern "C" int spo_ma_backward(const float* theta, const spo_ma_net* net, const 
     if (int rc = gemm_dyTx(st, dzc, in, grad + L.W(k), B, L.in_k(k), L.H, slices)) return rc;
     if (k >= 1 && fuse_bwd) {
       const size_t sh = ((size_t)128 * 132 + 2 * 64 * 132 + 128) * sizeof(float);
-      static bool attr_done = false;
+      static bool attr_done_dev[spo::SPO_MAX_DEVICES] = {};
+      bool& attr_done = attr_done_dev[spo::current_device_slot()];
       if (!attr_done) {
         if (int rc = spo::hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dx_lnbwd128_kernel),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh),

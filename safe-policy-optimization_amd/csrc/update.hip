@@ -2413,6 +2413,7 @@ __global__ __launch_bounds__(256, 1) void xr_selftest_kernel(int rank, int world
 
 int pick_kin(int D) { return D <= 16 ? 16 : D <= 32 ? 32 : D <= 64 ? 64 : 128; }
 
+
 unsigned long long* g_prof_buf = nullptr;
 
 // backup rows of the main + helper kernel (one launch of it at a time per process and device; L2-resident)
@@ -2445,12 +2446,13 @@ int launch_update_h(const UpdArgs& a_in, int blocks, hipStream_t st) {
   a.slots = slbase + (size_t)rslot * 32;
   if (int rc = spo::hip_check(hipMemsetAsync(a.slots, 0, sizeof(unsigned long long) * 32, st), "hipMemsetAsync(g_h_slots)")) return rc;
   const size_t sh = UpdHLds<K>::SIZE * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[SPO_MAX_DEVICES] = {};
+  const int dslot = current_device_slot();
+  if (!attr_done[dslot]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_update_h_kernel<K, PROF, XR, XRD>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return spo::hip_check(e, "hipFuncSetAttribute(update_h)");
-    attr_done = true;
+    attr_done[dslot] = true;
   }
   hipLaunchKernelGGL((ppo_update_h_kernel<K, PROF, XR, XRD>), dim3(8 * (blocks - 1) + 1), dim3(512), sh, st, a);
   return 0;
@@ -2476,12 +2478,13 @@ int launch_update(const UpdArgs& a, int blocks, hipStream_t st) {
 #define SPO_LAUNCH(K)                                                                                   \
   {                                                                                                     \
     const size_t sh = UpdLds<K>::SIZE * sizeof(float);                                                  \
-    static bool attr_done = false;                                                                      \
-    if (!attr_done) {                                                                                   \
+    static bool attr_done[SPO_MAX_DEVICES] = {};                                                        \
+    const int dslot = current_device_slot();                                                            \
+    if (!attr_done[dslot]) {                                                                            \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_update_kernel<K, PERSIST, false, AMODE, XR>), \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);          \
       if (e != hipSuccess) return spo::hip_check(e, "hipFuncSetAttribute(update)");                     \
-      attr_done = true;                                                                                 \
+      attr_done[dslot] = true;                                                                          \
     }                                                                                                   \
     hipLaunchKernelGGL((ppo_update_kernel<K, PERSIST, false, AMODE, XR>), dim3(PERSIST ? 8 * (blocks - 1) + 1 : blocks), \
                        dim3(256), sh, st, a);                                                          \
@@ -2815,12 +2818,13 @@ extern "C" int spo_critic_fit_iter_split(float* theta0, float* adam_m0, float* a
 #define SPO_SPLIT(K)                                                                                              \
   {                                                                                                               \
     const size_t sh = UpdLds<K>::SIZE * sizeof(float);                                                            \
-    static bool attr_done = false;                                                                                \
-    if (!attr_done) {                                                                                             \
+    static bool attr_done[SPO_MAX_DEVICES] = {};                                                                  \
+    const int dslot = current_device_slot();                                                                      \
+    if (!attr_done[dslot]) {                                                                                      \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_update_split_kernel<K>),              \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);                    \
       if (e != hipSuccess) return spo::hip_check(e, "hipFuncSetAttribute(update split)");                         \
-      attr_done = true;                                                                                           \
+      attr_done[dslot] = true;                                                                                    \
     }                                                                                                             \
     hipLaunchKernelGGL((ppo_update_split_kernel<K>), dim3(8 * (2 * a.n_nets - 1) + 1), dim3(256), sh, st, a, b);  \
   }

@@ -202,15 +202,22 @@ class PPOLagEngine:
         self.logstd_old.copy_(self.policy.theta[off:off + self.A])
         torch.exp(self.logstd_old, out=self.std_old)      # Normal.stddev of the snapshot (focops.py:283, cup.py:358)
 
-    def kl_to_old(self) -> float:
-        """KL(old || new).sum(-1).mean() over the (global) batch (ppo_lag.py:338-345)."""
+    def kl_launch(self) -> None:
+        """Enqueue the full-batch KL(old || new) of the early-stop test (ppo_lag.py:338-345); kl_read() returns it."""
         obs = self.buffer.data["obs"]
         _abi.check(self.lib.spo_actor_kl(_abi.ptr(self.policy.theta), _abi.ptr(obs), _abi.ptr(self.mean_old),
                                          _abi.ptr(self.logstd_old), _abi.ptr(self.kl_partials),
                                          self.kl_partials.numel(), _abi.ptr(self.kl_sum), self.M, self.D, self.A,
                                          _abi.stream_ptr()), "spo_actor_kl")
         self.comm.all_reduce_sum_(self.kl_sum)
+
+    def kl_read(self) -> float:
         return float(self.kl_sum.item()) / float(self.M * self.comm.world_size)
+
+    def kl_to_old(self) -> float:
+        """KL(old || new).sum(-1).mean() over the (global) batch (ppo_lag.py:338-345)."""
+        self.kl_launch()
+        return self.kl_read()
 
     def learning_iter(self, perm: torch.Tensor) -> torch.Tensor:
         """All minibatches of one pass over the data (ppo_lag.py:298-336).  `perm`: int32 device
@@ -390,9 +397,16 @@ class PPOLagEngine:
             perm_fn = lambda it: torch.randperm(self.M, device=self.dev).to(torch.int32)
         all_losses = []
         stop_iter, kl = 0, 1.0
-        for it in range(c["learning_iters"]):
-            all_losses.append(self.learning_iter(perm_fn(it)))
-            kl = self.kl_to_old()
+        # The host reads the KL back after every pass (the early-stop decision, ppo_lag.py:346-348).  The next pass's shuffle
+        # is enqueued BEFORE that read, so the device generates it while the host waits and the next persistent launch
+        # follows the KL kernels without a gap for the shuffle's own launches.
+        n_it = c["learning_iters"]
+        perm = perm_fn(0) if n_it > 0 else None
+        for it in range(n_it):
+            all_losses.append(self.learning_iter(perm))
+            self.kl_launch()
+            perm = perm_fn(it + 1) if it + 1 < n_it else None
+            kl = self.kl_read()
             stop_iter += 1
             if kl > c["target_kl"]:
                 break
@@ -455,7 +469,7 @@ class WidePPOLagEngine(PPOLagEngine):
         self.logstd_old.copy_(self.policy.theta[off:off + self.A])
         torch.exp(self.logstd_old, out=self.std_old)
 
-    def kl_to_old(self) -> float:
+    def kl_launch(self) -> None:
         obs = self.buffer.data["obs"].view(self.M, self.D)
         off = self.policy.log_std_offset
         ls_new = self.policy.theta[off:off + self.A]
@@ -466,6 +480,8 @@ class WidePPOLagEngine(PPOLagEngine):
                                                  _abi.ptr(ls_new), mu.shape[0], self.A, _abi.ptr(self.kl_partials),
                                                  self.kl_partials.numel(), _abi.ptr(self.kl_sum), int(k > 0), _abi.stream_ptr()),
                        "spo_gauss_kl_sum")
+
+    def kl_read(self) -> float:
         return float(self.kl_sum.item()) / float(self.M)
 
     def minibatch_step(self, idx: torch.Tensor, losses_out: torch.Tensor) -> None:
