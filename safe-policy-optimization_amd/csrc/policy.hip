@@ -256,13 +256,15 @@ struct BoundaryArgs {
 
 // ONE block: finished episodes are appended in env order, the order of the reference's Python
 // loop `for idx, (done, time_out) in enumerate(zip(terminated, truncated))` (ppo_lag.py:199).
-__global__ __launch_bounds__(256) void boundary_kernel(BoundaryArgs a) {
-  __shared__ int wave_cnt[4];
+__global__ __launch_bounds__(1024) void boundary_kernel(BoundaryArgs a) {
+  // one block of up to 16 waves (round 3: 1024 threads -- 4 passes over 4096 envs instead of 16, 24.7 -> ~9 us per step)
+  __shared__ int wave_cnt[16];
   __shared__ int base;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) base = *a.events_count;
   __syncthreads();
-  for (int64_t c0 = 0; c0 < a.N; c0 += 256) {
+  const int nthr = blockDim.x, nwaves = nthr >> 6;
+  for (int64_t c0 = 0; c0 < a.N; c0 += nthr) {
     const int64_t i = c0 + tid;
     const bool in = i < a.N;
     bool fin = false;
@@ -311,7 +313,11 @@ __global__ __launch_bounds__(256) void boundary_kernel(BoundaryArgs a) {
       }
     }
     __syncthreads();
-    if (tid == 0) base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    if (tid == 0) {
+      int add = 0;
+      for (int w = 0; w < nwaves; ++w) add += wave_cnt[w];
+      base += add;
+    }
     __syncthreads();
   }
   if (tid == 0) *a.events_count = base;
@@ -527,7 +533,8 @@ static int boundary_step_impl(const float* reward, const float* cost, const floa
   BoundaryArgs a{reward, cost, terminated, truncated, v_next_r, v_next_c, v_final_r, v_final_c, buf_reward, buf_cost,
                  seg_end, boot_r, boot_c, ep_ret, ep_cost, ep_len, events, events_count,
                  events_capacity, num_envs, T, t, epoch_end, fold_reward, fold_cost, (float)gamma};
-  hipLaunchKernelGGL(boundary_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+  const int bthreads = num_envs >= 1024 ? 1024 : num_envs > 256 ? 512 : 256;
+  hipLaunchKernelGGL(boundary_kernel, dim3(1), dim3(bthreads), 0, (hipStream_t)stream, a);
   SPO_LAUNCH_CHECK("spo_boundary_step");
   return 0;
 }
