@@ -1664,6 +1664,126 @@ extern "C" int spo_debug_ma_gemm(int use_rocblas, int mode, const float* x, cons
 namespace {
 using namespace spo;
 
+// ---- 128 x 128-tile fp32 MFMA GEMM for the wide networks (round 3).  gemm_mfma_kernel above (64 x 64 tiles, scalar staging)
+// serves launch-bound shapes; a [1024, 1024, 512] network at 8 192 rows is a chain of real GEMMs (17 GFLOP each), so:
+//   TRANSB = false:  Y[B, N] = act(X[B, K] W[N, K]^T + bias)            (forward: both operands K-contiguous)
+//   TRANSB = true :  Y[B, N] = (X[B, K] W[K, N]) * (1 - Hm[B, N]^2)      (input gradient dY W with the tanh' factor fused)
+// One workgroup = 128 x 128 outputs, 2 x 2 waves of 64 x 64 (16 accumulator tiles per wave); the reduction runs in chunks of
+// 16 staged through LDS with row stride 20 floats -- a lane's ds_read_b128 at [row][4q] is the operand of four consecutive
+// MFMA steps (k = 4q + r, the enumeration of mlp_mfma.h), and 20 i mod 64 walks all sixteen 4-bank groups, so the sixteen
+// lanes of a read phase never collide.  The next chunk is fetched into registers while the current one is multiplied.
+// Requirements (else the caller falls back to gemm_mfma_kernel): K % 4 == 0 (TRANSB: N % 4 == 0), 16-byte aligned operands.
+constexpr int G2_T = 128, G2_K = 16, G2_LD = 20;
+template <bool TRANSB>
+__global__ __launch_bounds__(256) void gemm128_kernel(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ Y,
+                                                      int64_t B, int K, int N, const float* __restrict__ bias, int tanh_on,
+                                                      const float* __restrict__ Hm, int w_vec) {
+  __shared__ __attribute__((aligned(16))) float As[G2_T * G2_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[G2_T * G2_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int64_t row0 = (int64_t)blockIdx.x * G2_T;
+  const int col0 = blockIdx.y * G2_T;
+  f4v acc[4][4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = f4v{0.f, 0.f, 0.f, 0.f};
+  // staging assignment.  A (and B when it is K-contiguous): thread -> row tid / 2, eight k from (tid & 1) * 8.
+  // TRANSB B: thread -> reduction row tid / 16 of the chunk, eight output columns from (tid & 15) * 8 (stored transposed).
+  const int sa_r = tid >> 1, sa_k = (tid & 1) * 8;
+  const int sb_n = tid >> 4, sb_c = (tid & 15) * 8;
+  f4v pa[2], pb[2];
+  auto fetch = [&](int k0) {
+    const int64_t r = row0 + sa_r;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = k0 + sa_k + 4 * h;
+      pa[h] = (r < B && k < K) ? *reinterpret_cast<const f4v*>(X + r * K + k) : f4v{0.f, 0.f, 0.f, 0.f};
+    }
+    if (!TRANSB) {
+      const int c = col0 + sa_r;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = k0 + sa_k + 4 * h;
+        pb[h] = f4v{0.f, 0.f, 0.f, 0.f};
+        if (c < N && k < K) {
+          const float* src = W + (int64_t)c * K + k;            // a network's slice of the flat vector need not be 16-byte aligned
+          if (w_vec) pb[h] = *reinterpret_cast<const f4v*>(src);
+          else pb[h] = f4v{src[0], src[1], src[2], src[3]};
+        }
+      }
+    } else {
+      const int k = k0 + sb_n;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = col0 + sb_c + 4 * h;
+        pb[h] = f4v{0.f, 0.f, 0.f, 0.f};
+        if (k < K && c < N) {
+          const float* src = W + (int64_t)k * N + c;
+          if (w_vec) pb[h] = *reinterpret_cast<const f4v*>(src);
+          else pb[h] = f4v{src[0], src[1], src[2], src[3]};
+        }
+      }
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += G2_K) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) *reinterpret_cast<f4v*>(As + sa_r * G2_LD + sa_k + 4 * h) = pa[h];
+    if (!TRANSB) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) *reinterpret_cast<f4v*>(Bs + sa_r * G2_LD + sa_k + 4 * h) = pb[h];
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Bs[(sb_c + 4 * h + e) * G2_LD + sb_n] = pb[h][e];
+    }
+    __syncthreads();
+    if (k0 + G2_K < K) fetch(k0 + G2_K);                       // in flight during the 64 MFMAs below
+    f4v a[4], b[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) a[rt] = *reinterpret_cast<const f4v*>(As + (64 * wr + 16 * rt + i) * G2_LD + 4 * q);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) b[ct] = *reinterpret_cast<const f4v*>(Bs + (64 * wc + 16 * ct + i) * G2_LD + 4 * q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][r], b[ct][r], acc[rt][ct], 0, 0, 0);
+    __syncthreads();
+  }
+  // C layout: lane holds rows 4q + e, column i of every 16 x 16 tile
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const int col = col0 + 64 * wc + 16 * ct + i;
+      if (col >= N) continue;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t row = row0 + 64 * wr + 16 * rt + 4 * q + e;
+        if (row >= B) continue;
+        float v = acc[rt][ct][e] + bv;
+        if (tanh_on) v = fast_tanh(v);
+        if (Hm) { const float hv = Hm[row * N + col]; v = v * fmaf(-hv, hv, 1.f); }
+        Y[row * N + col] = v;
+      }
+    }
+}
+// true when the 128-tile kernel applies (big enough to fill tiles, aligned, vectorisable)
+inline bool gemm128_ok(const float* X, int64_t B, int K, int N, bool transb) {
+  if (B < 256 || N < 64 || K < 16) return false;
+  if (((B + G2_T - 1) / G2_T) * ((N + G2_T - 1) / G2_T) < 192) return false;      // too few 128 x 128 tiles to fill 256 CUs
+  if (reinterpret_cast<uintptr_t>(X) & 15) return false;
+  return transb ? (K % 4 == 0 && N % 4 == 0) : (K % 4 == 0);
+}
+inline int w_is_vec(const float* W) { return (reinterpret_cast<uintptr_t>(W) & 15) == 0 ? 1 : 0; }
+
 struct MlpLay {
   int n;                 // Linear layers
   int d[SPO_MLP_MAX_LAYERS + 1];
@@ -1703,7 +1823,15 @@ __global__ __launch_bounds__(256) void mlp_colsum_partial_kernel(const float* __
   if (c >= N) return;
   const int64_t per = (B + CS_SLICES - 1) / CS_SLICES, r0 = s * per, r1 = r0 + per < B ? r0 + per : B;
   float acc = 0.f;
-  for (int64_t r = r0; r < r1; ++r) acc += d[r * N + c];
+  int64_t r = r0;
+  for (; r + 8 <= r1; r += 8) {                       // eight loads in flight, added in row order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = d[(r + u) * N + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  for (; r < r1; ++r) acc += d[r * N + c];
   partial[(int64_t)s * N + c] = acc;
 }
 __global__ __launch_bounds__(256) void mlp_colsum_finish_kernel(const float* __restrict__ partial, int N, float* __restrict__ out) {
@@ -1803,10 +1931,12 @@ __global__ __launch_bounds__(256) void wide_prep_kernel(WideAdamArgs a) {
   __syncthreads();
   if (tid < 3) a.partial[(int64_t)blockIdx.x * 3 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
-__global__ void wide_coef_kernel(WideAdamArgs a, int nblocks) {
-  if (threadIdx.x != 0) return;
+__global__ __launch_bounds__(64) void wide_coef_kernel(WideAdamArgs a, int nblocks) {
+  // one wave: lane l adds the partials l, l + 64, ... in order, then a fixed butterfly over the lanes
   double gs = 0.0, pr = 0.0, pc = 0.0;
-  for (int b = 0; b < nblocks; ++b) { gs += a.partial[b * 3]; pr += a.partial[b * 3 + 1]; pc += a.partial[b * 3 + 2]; }
+  for (int b = threadIdx.x; b < nblocks; b += 64) { gs += a.partial[b * 3]; pr += a.partial[b * 3 + 1]; pc += a.partial[b * 3 + 2]; }
+  gs = wave_sum_d(gs); pr = wave_sum_d(pr); pc = wave_sum_d(pc);
+  if (threadIdx.x != 0) return;
   const float norm = sqrtf((float)gs);
   float coef = a.max_norm / (norm + 1e-6f);                   // clip_grad_norm_ (torch): eps 1e-6
   a.scal[0] = coef > 1.f ? 1.f : coef;
@@ -1926,9 +2056,16 @@ extern "C" int spo_mlp_forward(const float* theta, const spo_mlp_net* net, const
   const float* in = x;
   for (int l = 0; l < L.n; ++l) {
     float* out = ws + L.act_off(l, rows);
-    if (int rc = gemm_xwT(st, in, theta + L.w(l), out, rows, L.d[l], L.d[l + 1])) return rc;
-    const int64_t n = rows * L.d[l + 1];
-    hipLaunchKernelGGL(mlp_bias_act_kernel, dim3(ew_grid(n)), dim3(256), 0, st, out, theta + L.b(l), n, L.d[l + 1], l + 1 < L.n ? 1 : 0);
+    const int K = L.d[l], N = L.d[l + 1];
+    if (gemm128_ok(in, rows, K, N, false)) {
+      // bias + tanh fused into the GEMM epilogue
+      hipLaunchKernelGGL(gemm128_kernel<false>, dim3((unsigned)((rows + G2_T - 1) / G2_T), (unsigned)((N + G2_T - 1) / G2_T)), dim3(256), 0, st,
+                         in, theta + L.w(l), out, rows, K, N, theta + L.b(l), l + 1 < L.n ? 1 : 0, (const float*)nullptr, w_is_vec(theta + L.w(l)));
+    } else {
+      if (int rc = gemm_xwT(st, in, theta + L.w(l), out, rows, K, N)) return rc;
+      const int64_t n = rows * (int64_t)N;
+      hipLaunchKernelGGL(mlp_bias_act_kernel, dim3(ew_grid(n)), dim3(256), 0, st, out, theta + L.b(l), n, N, l + 1 < L.n ? 1 : 0);
+    }
     in = out;
   }
   SPO_LAUNCH_CHECK("spo_mlp_forward");
@@ -1960,9 +2097,15 @@ extern "C" int spo_mlp_backward(const float* theta, const spo_mlp_net* net, cons
     if (int rc = gemm_dyTx(st, dz, hin, grad + L.w(l), rows, K, N, slices)) return rc;
     if (l > 0) {
       float* dh = (dz == dA) ? dB : dA;
-      if (int rc = gemm_dyw(st, dz, theta + L.w(l), dh, rows, K, N)) return rc;
-      const int64_t n = rows * (int64_t)K;
-      hipLaunchKernelGGL(mlp_dtanh_kernel, dim3(ew_grid(n)), dim3(256), 0, st, dh, hin, n);
+      // dH_{l-1} = dZ_l W_l (reduction over this layer's N outputs, K inputs wide) and dZ_{l-1} = dH_{l-1} (1 - h_{l-1}^2)
+      if (gemm128_ok(dz, rows, N, K, true)) {
+        hipLaunchKernelGGL(gemm128_kernel<true>, dim3((unsigned)((rows + G2_T - 1) / G2_T), (unsigned)((K + G2_T - 1) / G2_T)), dim3(256), 0, st,
+                           dz, theta + L.w(l), dh, rows, N, K, (const float*)nullptr, 0, hin, w_is_vec(theta + L.w(l)));
+      } else {
+        if (int rc = gemm_dyw(st, dz, theta + L.w(l), dh, rows, K, N)) return rc;
+        const int64_t n = rows * (int64_t)K;
+        hipLaunchKernelGGL(mlp_dtanh_kernel, dim3(ew_grid(n)), dim3(256), 0, st, dh, hin, n);
+      }
       dz = dh;
     }
   }
