@@ -351,3 +351,27 @@ def test_bench_refuses_to_report_n_gpus_it_does_not_have():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True,
                        timeout=300)
     assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
+
+
+@pytest.mark.parametrize("hidden", [[64, 64], [128, 128], [256, 96], [1024, 1024, 512], [32]])
+def test_wide_network_layout_matches_reference_parameter_order(built_lib, hidden):
+    """The wide-network kernels address one flat vector per network: every Linear's weight [out, in] then its bias, in layer
+    order -- nn.Sequential.parameters() order, so ActorVCritic's parameters stay views of the flat vector for any
+    hidden_sizes (reference model.py:30-48,131-135).  Host-only check of spo_mlp_param_count and of the offsets
+    safepo.common.wide.WideNets derives (reward critic, cost critic, log_std, actor)."""
+    from oracle import restatement as R
+    from safepo import _abi
+    lib = _abi.load(built_lib)
+    D, A = 60, 8
+    ref = R.OraclePolicy(D, A, hidden_sizes=tuple(hidden))
+    n_c = sum(p.numel() for p in ref.reward_critic.parameters())
+    n_a = sum(p.numel() for p in ref.actor.mean.parameters())
+    assert lib.spo_mlp_param_count(_abi.MlpNet.of([D] + hidden + [1])) == n_c
+    assert lib.spo_mlp_param_count(_abi.MlpNet.of([D] + hidden + [A])) == n_a
+    names = [k for k, _ in ref.named_parameters()]
+    assert names[0].startswith("reward_critic") and names[2 * (len(hidden) + 1)].startswith("cost_critic")
+    assert names[4 * (len(hidden) + 1)] == "actor.log_std" and names[4 * (len(hidden) + 1) + 1] == "actor.mean.0.weight"
+    assert sum(p.numel() for p in ref.parameters()) == 2 * n_c + A + n_a
+    assert lib.spo_mlp_workspace_floats(_abi.MlpNet.of([D] + hidden + [A]), 10) == 10 * (sum(hidden) + A)
+    with pytest.raises(_abi.SpoError):
+        _abi.MlpNet.of([D, 1, 1, 1, 1, 1, 1])          # more than 5 Linear layers
