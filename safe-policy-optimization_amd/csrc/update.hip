@@ -360,7 +360,7 @@ __device__ __forceinline__ u4v ld16_sys(const char* p) {
   return v;
 }
 #ifndef SPO_XR16_VB
-#define SPO_XR16_VB 5          // packed words polled together (A/B knob: register budget against poll round trips)
+#define SPO_XR16_VB 15         // packed words polled together: all 15 of a 60-wide network (A/B knob; 5 and 8 measured: profiles/r03/p2p_loopback_poll_batch_ab.txt)
 #endif
 template <int NV, int VB = SPO_XR16_VB>                          // VB: packed words polled together
 __device__ __forceinline__ void xr_allreduce_rd16(const u64* regions, int me, int R, int net, int tid, unsigned gtag,
