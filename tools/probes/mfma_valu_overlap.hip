@@ -32,6 +32,35 @@ __device__ __forceinline__ void valu_loop(int iters, float* out) {
   for (int k = 0; k < 8; ++k) s += x[k];
   out[threadIdx.x] = s;
 }
+// issue cost of single instruction kinds (one wave per SIMD, 8 independent chains): plain FMA, packed FMA, exp2, rcp, sqrt
+template <int OP>
+__global__ __launch_bounds__(256) void probe_op(int iters, float* out, unsigned long long* cyc) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  float x[8];
+  f2 y[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { x[k] = 1.0f + threadIdx.x * 1e-4f + k; y[k] = f2{x[k], x[k] + 0.5f}; }
+  __syncthreads();
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (OP == 0) x[k] = fmaf(x[k], 1.0001f, 0.5f);
+      if (OP == 1) y[k] = __builtin_elementwise_fma(y[k], f2{1.0001f, 0.9999f}, f2{0.5f, 0.25f});
+      if (OP == 2) x[k] = __builtin_amdgcn_exp2f(x[k] * 0.01f);
+      if (OP == 3) x[k] = __builtin_amdgcn_rcpf(x[k]) + 1.0f;
+      if (OP == 4) x[k] = __builtin_amdgcn_sqrtf(x[k]) + 1.0f;
+    }
+  }
+  __syncthreads();
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  float s = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s += x[k] + y[k].x + y[k].y;
+  out[threadIdx.x] = s;
+  if (threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+
 template <int KIND>
 __global__ __launch_bounds__(512) void probe(int mode, int mi, int vi, float* out, unsigned long long* cyc) {
   const int wave = threadIdx.x >> 6;
@@ -93,6 +122,22 @@ int main() {
     else hipLaunchKernelGGL(probe_one<1>, dim3(1), dim3(256), 0, 0, MI, out, cyc);
     hipDeviceSynchronize(); hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
     printf("%s ONE wave, 4 independent VALU after every MFMA: %llu cycles; per MFMA(+4 VALU) %.1f\n", kind ? "bf16 16x16x32" : "f32 16x16x4", h, (double)h / (4.0 * MI));
+  }
+  {
+    const char* names[5] = {"v_fma_f32", "v_pk_fma_f32", "v_mul + v_exp_f32", "v_rcp_f32 + v_add", "v_sqrt_f32 + v_add"};
+    for (int op = 0; op < 5; ++op) {
+      unsigned long long h = 0;
+      for (int rep = 0; rep < 2; ++rep) {
+        if (op == 0) hipLaunchKernelGGL(probe_op<0>, dim3(1), dim3(256), 0, 0, VI, out, cyc);
+        if (op == 1) hipLaunchKernelGGL(probe_op<1>, dim3(1), dim3(256), 0, 0, VI, out, cyc);
+        if (op == 2) hipLaunchKernelGGL(probe_op<2>, dim3(1), dim3(256), 0, 0, VI, out, cyc);
+        if (op == 3) hipLaunchKernelGGL(probe_op<3>, dim3(1), dim3(256), 0, 0, VI, out, cyc);
+        if (op == 4) hipLaunchKernelGGL(probe_op<4>, dim3(1), dim3(256), 0, 0, VI, out, cyc);
+        hipDeviceSynchronize();
+        hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+      }
+      printf("one wave per SIMD, 8 independent chains of %s: %.2f cycles per loop body element\n", names[op], (double)h / (8.0 * VI));
+    }
   }
   printf("note: s_memtime/readcyclecounter counts at a fixed 100 MHz-multiple clock on some parts; compare ratios\n");
   return 0;
