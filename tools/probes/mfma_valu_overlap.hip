@@ -67,7 +67,7 @@ __global__ __launch_bounds__(512) void probe(int mode, int mi, int vi, float* ou
   const bool helper = wave >= 4;
   __syncthreads();
   const unsigned long long t0 = __builtin_readcyclecounter();
-  if (!helper) { if (mode & 1) mfma_loop<KIND>(mi, out); }
+  if (!helper) { if (mode & 1) mfma_loop<KIND>(mi, out); if (mode & 4) valu_loop(vi, out); }
   else { if (mode & 2) valu_loop(vi, out); }
   __syncthreads();
   const unsigned long long t1 = __builtin_readcyclecounter();
@@ -138,6 +138,16 @@ int main() {
       }
       printf("one wave per SIMD, 8 independent chains of %s: %.2f cycles per loop body element\n", names[op], (double)h / (8.0 * VI));
     }
+  }
+  {
+    unsigned long long h = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+      hipLaunchKernelGGL(probe<0>, dim3(1), dim3(512), 0, 0, 6, MI, VI, out, cyc);
+      hipDeviceSynchronize();
+      hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+    }
+    printf("TWO VALU waves per SIMD (mode 6: both waves stream v_fma_f32): %llu cycles; per VALU of one wave %.2f (one VALU wave alone: mode 2 above)\n",
+           h, (double)h / (8.0 * VI));
   }
   printf("note: s_memtime/readcyclecounter counts at a fixed 100 MHz-multiple clock on some parts; compare ratios\n");
   return 0;
