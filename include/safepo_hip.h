@@ -361,6 +361,29 @@ int spo_ma_backward(const float* theta, const spo_ma_net* net, const float* x, i
 int64_t spo_ma_jvp_scratch_floats(const spo_ma_net* net, int64_t rows);
 int spo_ma_jvp(const float* theta, const spo_ma_net* net, const float* tangent, int64_t rows, const float* ws, float* dout,
                float* scratch, void* stream);
+/* Collect step of the multi-agent runner (mappolag.py:411-447: policy.get_actions for every agent): ALL networks of ALL
+ * agents in one launch, each 64-row tile taken through its whole network on chip (feature LayerNorm, blocks, head, and for
+ * actors the Gaussian sample + per-dimension log-probabilities).  Results are bit-identical to spo_ma_forward (+
+ * spo_ma_sample) per network.  Geometry served: hidden 128, in_dim <= 128 and a multiple of 4, out_dim <= 16, n_blocks <= 4,
+ * n_nets <= SPO_MA_COLLECT_MAX_NETS, 16-byte aligned theta / x; anything else returns SPO_MA_COLLECT_UNSUPPORTED without
+ * launching (the caller then runs the per-network entry points).
+ * critics: out[rows, 1] required.  actors: act / logp [rows, out_dim] required, eps [rows, out_dim] unless deterministic,
+ * out (the mean) optional.  scratch: float[spo_ma_collect_scratch_floats(n_nets)] (folded first-block weights). */
+#define SPO_MA_COLLECT_MAX_NETS 16
+#define SPO_MA_COLLECT_UNSUPPORTED 1
+typedef struct spo_ma_collect_net {
+  const float* theta;
+  spo_ma_net net;
+  int32_t deterministic;
+  const float* x;
+  float* out;
+  const float* eps;
+  float* act;
+  float* logp;
+  float std_x_coef, std_y_coef;
+} spo_ma_collect_net;
+int64_t spo_ma_collect_scratch_floats(int32_t n_nets);
+int spo_ma_collect_forward(int32_t n_nets, const spo_ma_collect_net* nets, int64_t rows, float* scratch, void* stream);
 int spo_ma_sample(const float* mean, const float* log_std, const float* eps, float std_x_coef, float std_y_coef,
                   int deterministic, float* act_out, float* logp_out, int64_t rows, int act_dim, void* stream);
 int spo_ma_log_probs(const float* mean, const float* log_std, const float* act, float std_x_coef, float std_y_coef,

@@ -1649,6 +1649,275 @@ extern "C" int spo_debug_ma_gemm(int use_rocblas, int mode, const float* x, cons
 }
 
 // ====================================================================================================================
+// Collect step of the multi-agent runner: every network of every agent in ONE launch (mappolag.py:411-447 calls
+// policy.get_actions per agent: actor + critic + cost critic, 12 networks of 4 agents at BASELINE config 5).  A collect-size
+// batch (8 192 rollout threads) is 128 workgroups per layer kernel: launched network by network and layer by layer
+// (feature LayerNorm, fold, 3 fused blocks, head, sampling: ~60 launches of 5-13 us per step) the chip idles.  Here a
+// workgroup takes 64 rows of ONE network (blockIdx.y) through the WHOLE network: feature LayerNorm in registers -> LDS tile,
+// per block the weights staged to LDS (next block's weights prefetched into registers behind the MFMA loop), fp32 MFMA,
+// bias + ELU + LayerNorm written back IN PLACE as the next block's input tile, head on four lanes per row, and for actors the
+// Gaussian sample + per-dimension log-probabilities.  No activation ever goes to HBM.  Every element is computed with the
+// arithmetic, operand order and cross-lane sums of the per-layer kernels above (ln_fwd_narrow_kernel, fn_fold_kernel,
+// fused_block_fwd128_kernel<1>, head_small_kernel, ma_sample_kernel), so the results are BIT-IDENTICAL to spo_ma_forward +
+// spo_ma_sample (tests: test_ma_collect_forward_is_bit_identical_to_the_per_network_path).
+namespace {
+constexpr int MC_MAX_NETS = SPO_MA_COLLECT_MAX_NETS, MC_MAX_BLOCKS = 4, MC_ROWS = 64;
+struct McNet {
+  const float* theta; const float* x; float* w0f; float* b0f; float* out;
+  const float* eps; float* act; float* logp;
+  int D, O, NB, is_actor, deterministic;
+  int oW[MC_MAX_BLOCKS], ob[MC_MAX_BLOCKS], og[MC_MAX_BLOCKS], obe[MC_MAX_BLOCKS];
+  int ohW, ohb, ols;
+  float xc, yc;
+};
+struct McArgs { McNet n[MC_MAX_NETS]; int64_t rows; };
+
+// fn_fold_kernel for all networks of the launch: grid (128 output rows, networks), 64 lanes
+__global__ void fn_fold_multi_kernel(McArgs A) {
+  const McNet& nt = A.n[blockIdx.y];
+  const float* W0 = nt.theta + nt.oW[0]; const float* b0 = nt.theta + nt.ob[0];
+  const float* gam = nt.theta; const float* bet = nt.theta + nt.D;
+  const int D = nt.D, n = blockIdx.x;
+  float dot = 0.f;
+  for (int c = threadIdx.x; c < D; c += 64) {
+    const float w = W0[(int64_t)n * D + c];
+    nt.w0f[(int64_t)n * D + c] = w * gam[c];
+    dot = fmaf(w, bet[c], dot);
+  }
+  dot = wave_sum_all(dot);
+  if (threadIdx.x == 0) nt.b0f[n] = b0[n] + dot;
+}
+
+// feature LayerNorm of the 64-row tile into the LDS tile (pre-affine, like ln_fwd_narrow_kernel<LPR>)
+template <int LPR>
+__device__ __forceinline__ void mc_input_ln(const float* __restrict__ x, int64_t r0, int64_t B, int D, int LD0, int KP0, float* Xs,
+                                            int tid) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = tid & 63, wave = tid >> 6, sub = lane / LPR, c = (lane % LPR) * 4;
+  const bool col_ok = c < D;
+  const float inv_d = 1.f / (float)D;
+#pragma unroll 2
+  for (int ps = 0; ps < MC_ROWS / (4 * RPW); ++ps) {
+    const int rl = (ps * 4 + wave) * RPW + sub;
+    const int64_t row = r0 + rl;
+    const bool ok = row < B && col_ok;
+    f4w v = {0.f, 0.f, 0.f, 0.f};
+    if (ok) v = *reinterpret_cast<const f4w*>(x + row * D + c);
+    const float mean = group_allsum<LPR>((v[0] + v[1]) + (v[2] + v[3])) * inv_d;
+    f4w d = v - mean;
+    if (!col_ok) d = f4w{0.f, 0.f, 0.f, 0.f};
+    const float var = group_allsum<LPR>((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * inv_d;
+    const float rstd = 1.f / sqrtf(var + LN_EPS);
+    f4w o = d * rstd;
+    if (!ok) o = f4w{0.f, 0.f, 0.f, 0.f};
+    if (c < KP0) *reinterpret_cast<f4w*>(Xs + rl * LD0 + c) = o;
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void ma_collect_kernel(McArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float mc_lds[];
+  float* Ws = mc_lds;                              // [128][LD] weights of the current block; the head's [O][132] at the end
+  float* Xs = mc_lds + FB_N * FB_SLD;              // [64][LD] input tile; = Stg [64][132] ELU outputs / next input, in place
+  float* Sst = Xs + MC_ROWS * FB_SLD;              // [64][2] row mean / rstd
+  const McNet& nt = A.n[blockIdx.y];
+  const float* const theta = nt.theta;
+  const int64_t B = A.rows;
+  const int D = nt.D, O = nt.O, NB = nt.NB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kk = lane >> 4;
+  const int lc4 = (tid & 31) * 4, lrow = tid >> 5;
+  const int64_t r0 = (int64_t)blockIdx.x * MC_ROWS;
+  // block 0's (folded) weights are on their way while the feature LayerNorm runs
+  f4w wv[16];
+  auto fetch_w = [&](const float* W, int K) {
+    const bool lcol_ok = lc4 < K;
+#pragma unroll
+    for (int ps = 0; ps < 16; ++ps) {
+      wv[ps] = f4w{0.f, 0.f, 0.f, 0.f};
+      if (lcol_ok) wv[ps] = *reinterpret_cast<const f4w*>(W + (int64_t)(lrow + 8 * ps) * K + lc4);
+    }
+  };
+  fetch_w(nt.w0f, D);
+  {
+    const int KP0 = (D + 15) & ~15, LD0 = KP0 + 4;
+    if (D <= 64) mc_input_ln<16>(nt.x, r0, B, D, LD0, KP0, Xs, tid);
+    else mc_input_ln<32>(nt.x, r0, B, D, LD0, KP0, Xs, tid);
+  }
+  float hwv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < NB; ++k) {
+    const int K = k == 0 ? D : FB_N, KP = (K + 15) & ~15, LD = KP + 4;
+    const bool lcol_in = lc4 < KP;
+#pragma unroll
+    for (int ps = 0; ps < 16; ++ps)
+      if (lcol_in) *reinterpret_cast<f4w*>(Ws + (lrow + 8 * ps) * LD + lc4) = wv[ps];
+    const float* bias = k == 0 ? nt.b0f : theta + nt.ob[k];
+    float bcol[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) bcol[t] = bias[16 * t + i];
+    __syncthreads();                               // W_k and the input tile are in LDS
+    if (k + 1 < NB) fetch_w(theta + nt.oW[k + 1], FB_N);
+    else {
+      // head weights [O][128] (behind an actor's log_std they are not 16-byte aligned: scalar loads, coalesced)
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        const int f = tid + 256 * h;
+        if (f < O * FB_N) hwv[h] = theta[nt.ohW + f];
+      }
+    }
+    f4w acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = f4w{0.f, 0.f, 0.f, 0.f};
+    const float* xa = Xs + (16 * wave + i) * LD + 4 * kk;
+    const float* wb = Ws + i * LD + 4 * kk;
+    for (int kb = 0; kb < KP / 16; ++kb) {
+      const f4w am = *reinterpret_cast<const f4w*>(xa + 16 * kb);
+      f4w bt[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) bt[t] = *reinterpret_cast<const f4w*>(wb + 16 * t * LD + 16 * kb);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[r], bt[t][r], acc[t], 0, 0, 0);
+    }
+    __syncthreads();                               // every wave is done with W_k and with the input tile
+    const float* g = theta + nt.og[k]; const float* be = theta + nt.obe[k];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int rl = 16 * wave + 4 * kk + e;
+      float v[8], sum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        float z = acc[t][e] + bcol[t];
+        z = z > 0.f ? z : __expf(z) - 1.f;
+        v[t] = z; sum += z;
+      }
+      const float mean = row16_allsum(sum) * (1.f / FB_N);
+      float q = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { const float d = v[t] - mean; q += d * d; }
+      const float rstd = 1.f / sqrtf(row16_allsum(q) * (1.f / FB_N) + LN_EPS);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) Xs[rl * FB_SLD + 16 * t + i] = v[t];
+      if (i == 0) { Sst[2 * rl] = mean; Sst[2 * rl + 1] = rstd; }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the rows are wave-private
+    {
+      const int c4 = (lane & 31) * 4;
+      const f4w g4 = *reinterpret_cast<const f4w*>(g + c4), be4 = *reinterpret_cast<const f4w*>(be + c4);
+#pragma unroll 4
+      for (int jj = 0; jj < 8; ++jj) {
+        const int rl = 16 * wave + 2 * jj + (lane >> 5);
+        const f4w a4 = *reinterpret_cast<const f4w*>(Xs + rl * FB_SLD + c4);
+        const float mean = Sst[2 * rl], rstd = Sst[2 * rl + 1];
+        *reinterpret_cast<f4w*>(Xs + rl * FB_SLD + c4) = (a4 - mean) * rstd * g4 + be4;      // next block's input, in place
+      }
+    }
+  }
+  // ---- head (head_small_kernel's arithmetic: four lanes per row, quarter k0 = 4 part + 16 step), bias, Gaussian sample
+#pragma unroll
+  for (int h = 0; h < 8; ++h) {
+    const int f = tid + 256 * h;
+    if (f < O * FB_N) Ws[(f >> 7) * FB_SLD + (f & 127)] = hwv[h];
+  }
+  __syncthreads();
+  const int rl = tid >> 2, part = tid & 3;
+  const int64_t row = r0 + rl;
+  float hacc[HS_MAXN];
+#pragma unroll
+  for (int n = 0; n < HS_MAXN; ++n) hacc[n] = 0.f;
+  {
+    const float* xr = Xs + rl * FB_SLD;
+    for (int k0 = 4 * part; k0 < FB_N; k0 += 16) {
+      const f4w xv = *reinterpret_cast<const f4w*>(xr + k0);
+#pragma unroll
+      for (int n = 0; n < HS_MAXN; ++n)
+        if (n < O) {
+          const float* wr = Ws + n * FB_SLD + k0;
+          hacc[n] = fmaf(xv[0], wr[0], fmaf(xv[1], wr[1], fmaf(xv[2], wr[2], fmaf(xv[3], wr[3], hacc[n]))));
+        }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < HS_MAXN; ++n) {
+    hacc[n] += __shfl_xor(hacc[n], 1);
+    hacc[n] += __shfl_xor(hacc[n], 2);
+  }
+  if (row < B && part == 0) {
+    const float* hb = theta + nt.ohb;
+#pragma unroll
+    for (int n = 0; n < HS_MAXN; ++n)
+      if (n < O) {
+        const float mu = hacc[n] + hb[n];
+        if (nt.out) nt.out[row * O + n] = mu;
+        if (nt.is_actor) {
+          const int64_t e = row * O + n;
+          const float sd = nt.yc / (1.f + expf(-theta[nt.ols + n] / nt.xc));
+          const float xs = nt.deterministic ? mu : mu + sd * nt.eps[e];
+          nt.act[e] = xs;
+          const float d = xs - mu;
+          nt.logp[e] = -(d * d) / (2.f * sd * sd) - logf(sd) - LOG_SQRT_2PI_F;
+        }
+      }
+  }
+}
+}  // namespace
+
+extern "C" int64_t spo_ma_collect_scratch_floats(int32_t n_nets) {
+  if (n_nets < 1 || n_nets > MC_MAX_NETS) return -1;
+  return (int64_t)n_nets * (FB_N * FB_N + FB_N);
+}
+// 0 = launched; SPO_MA_COLLECT_UNSUPPORTED (positive, nothing launched) = a geometry outside the fused kernel: the caller runs
+// spo_ma_forward + spo_ma_sample per network instead.
+extern "C" int spo_ma_collect_forward(int32_t n_nets, const spo_ma_collect_net* nets, int64_t rows, float* scratch, void* stream) {
+  SPO_REQUIRE(nets && scratch && rows > 0 && n_nets >= 1, "ma_collect_forward: bad args");
+  if (n_nets > MC_MAX_NETS) return SPO_MA_COLLECT_UNSUPPORTED;
+  McArgs args;
+  memset(&args, 0, sizeof(args));
+  args.rows = rows;
+  for (int n = 0; n < n_nets; ++n) {
+    const spo_ma_collect_net& c = nets[n];
+    Lay L;
+    if (int rc = lay_of(&c.net, &L)) return rc;
+    SPO_REQUIRE(c.theta && c.x, "ma_collect_forward: net %d: theta / x is NULL", n);
+    if (L.H != FB_N || L.D > 128 || L.D % 4 != 0 || L.O > HS_MAXN || L.NB > MC_MAX_BLOCKS ||
+        reinterpret_cast<uintptr_t>(c.x) % 16 != 0 || reinterpret_cast<uintptr_t>(c.theta) % 16 != 0)
+      return SPO_MA_COLLECT_UNSUPPORTED;
+    McNet& m = args.n[n];
+    m.theta = c.theta; m.x = c.x; m.out = c.out;
+    m.w0f = scratch + (int64_t)n * (FB_N * FB_N + FB_N); m.b0f = m.w0f + FB_N * FB_N;
+    m.D = L.D; m.O = L.O; m.NB = L.NB; m.is_actor = L.actor;
+    for (int k = 0; k < L.NB; ++k) {
+      m.oW[k] = (int)L.W(k); m.ob[k] = (int)L.b(k); m.og[k] = (int)L.g(k); m.obe[k] = (int)L.be(k);
+      // float4 reads of the block weights and LayerNorm vectors: offsets must be multiples of 4 floats
+      if ((k > 0 && L.W(k) % 4 != 0) || L.g(k) % 4 != 0 || L.be(k) % 4 != 0) return SPO_MA_COLLECT_UNSUPPORTED;
+    }
+    m.ohW = (int)L.hW(); m.ohb = (int)L.hb(); m.ols = L.actor ? (int)L.logstd() : 0;
+    if (L.actor) {
+      SPO_REQUIRE(c.act && c.logp && (c.eps || c.deterministic), "ma_collect_forward: net %d (actor): act / logp / eps is NULL", n);
+      m.eps = c.eps; m.act = c.act; m.logp = c.logp; m.deterministic = c.deterministic ? 1 : 0;
+      m.xc = c.std_x_coef; m.yc = c.std_y_coef;
+    } else {
+      SPO_REQUIRE(c.out, "ma_collect_forward: net %d (critic): out is NULL", n);
+    }
+  }
+  hipStream_t st = (hipStream_t)stream;
+  constexpr size_t sh = ((size_t)FB_N * FB_SLD + MC_ROWS * FB_SLD + 2 * MC_ROWS) * sizeof(float);
+  static bool attr_done_dev[spo::SPO_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[spo::current_device_slot()];
+  if (!attr_done) {
+    if (int rc = spo::hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&ma_collect_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh),
+                                "hipFuncSetAttribute(ma_collect_kernel)")) return rc;
+    attr_done = true;
+  }
+  const int64_t tiles = (rows + MC_ROWS - 1) / MC_ROWS;
+  if (tiles > 0x7fffffffLL) return fail(-1, "ma_collect_forward: %lld rows exceed the launch grid", (long long)rows);
+  hipLaunchKernelGGL(fn_fold_multi_kernel, dim3(FB_N, n_nets), dim3(64), 0, st, args);
+  hipLaunchKernelGGL(ma_collect_kernel, dim3((unsigned)tiles, n_nets), dim3(256), sh, st, args);
+  SPO_LAUNCH_CHECK("spo_ma_collect_forward");
+  return 0;
+}
+
+// ====================================================================================================================
 // Wide single-agent networks: ActorVCritic(obs_dim, act_dim, hidden_sizes) for ANY hidden_sizes (reference
 // safepo/common/model.py:30-48,131; isaac_gym_specific_cfg uses [1024, 1024, 512] with minibatches of 8 192 rows,
 // safepo/single_agent/ppo_lag.py:54-65).  The persistent kernels of update.hip keep a 64-wide network in one CU's LDS for

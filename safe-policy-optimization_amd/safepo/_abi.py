@@ -31,6 +31,16 @@ class MaNet(Structure):
                 ("is_actor", c_int32)]
 
 
+class MaCollectNet(Structure):
+    """spo_ma_collect_net (include/safepo_hip.h): one network of a multi-network collect launch."""
+    _fields_ = [("theta", c_void_p), ("net", MaNet), ("deterministic", c_int32), ("x", c_void_p), ("out", c_void_p),
+                ("eps", c_void_p), ("act", c_void_p), ("logp", c_void_p), ("std_x_coef", c_float), ("std_y_coef", c_float)]
+
+
+MA_COLLECT_MAX_NETS = 16
+MA_COLLECT_UNSUPPORTED = 1
+
+
 class MlpNet(Structure):
     """spo_mlp_net (include/safepo_hip.h): n_layers Linear layers, dims[0] = input ... dims[n_layers] = output."""
     _fields_ = [("n_layers", c_int32), ("dims", c_int32 * 6)]
@@ -105,6 +115,8 @@ PROTOTYPES = {
     "spo_ma_backward_scratch_floats": (c_int64, [POINTER(MaNet), c_int64]),
     "spo_ma_forward": (c_int, [P, POINTER(MaNet), P, c_int64, P, P, P]),
     "spo_ma_backward": (c_int, [P, POINTER(MaNet), P, c_int64, P, P, P, P, P]),
+    "spo_ma_collect_scratch_floats": (c_int64, [c_int32]),
+    "spo_ma_collect_forward": (c_int, [c_int32, POINTER(MaCollectNet), c_int64, P, P]),
     "spo_ma_sample": (c_int, [P, P, P, c_float, c_float, c_int, P, P, c_int64, c_int, P]),
     "spo_ma_log_probs": (c_int, [P, P, P, c_float, c_float, P, c_int64, c_int, P]),
     "spo_ma_actor_loss": (c_int, [P] * 9 + [POINTER(MaLossCfg), c_int64, c_int, c_float, c_int64, P, P, P, P, P]),

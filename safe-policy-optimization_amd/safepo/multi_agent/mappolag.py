@@ -427,7 +427,61 @@ class Runner:
             self.buffer[a].obs[0].copy_(obs[:, a])
 
     @torch.no_grad()
+    def _collect_fused(self, share_obs, obs, rnn, rnn_c, rnn_k, masks):
+        """policy.get_actions of every agent as ONE launch (spo_ma_collect_forward: all networks of all agents, each row tile
+        through its whole network on chip, Gaussian sampling included).  Same results bit for bit as the per-network calls
+        below, same torch.randn draws in the same order.  Returns None when the networks are outside the fused kernel's
+        geometry (hidden != 128, wide observations, ...): the caller then launches network by network."""
+        lib = _abi.load()
+        jobs = []                                            # (net, input, agent, kind)
+        for a in range(self.num_agents):
+            pol = self.trainer[a].policy
+            jobs.append((pol.actor, obs[a], a, "actor"))
+            jobs.append((pol.critic, share_obs[a], a, "critic"))
+            if self.use_cost:
+                jobs.append((pol.cost_critic, share_obs[a], a, "cost"))
+        if len(jobs) > _abi.MA_COLLECT_MAX_NETS:
+            return None
+        arr = (_abi.MaCollectNet * len(jobs))()
+        keep, acts, lps = [], [None] * self.num_agents, [None] * self.num_agents
+        N = obs[0].reshape(-1, self.trainer[0].policy.actor._net.in_dim).shape[0]
+        vals = torch.empty((self.num_agents, N, 1), dtype=torch.float32, device=self.dev)
+        cps = torch.empty((self.num_agents, N, 1), dtype=torch.float32, device=self.dev) if self.use_cost else None
+        for i, (net, x, a, kind) in enumerate(jobs):
+            x = _abi.require_gpu_tensor(torch.as_tensor(x, **net.tpdv).reshape(-1, net._net.in_dim).contiguous(), "x", torch.float32)
+            if x.shape[0] != N:
+                return None
+            keep.append(x)
+            c = arr[i]
+            c.theta, c.net, c.x, c.deterministic = _abi.ptr(net.theta), net._net, _abi.ptr(x), 0
+            if kind == "actor":
+                eps = torch.randn((N, net.act_dim), **net.tpdv)
+                acts[a], lps[a] = torch.empty_like(eps), torch.empty_like(eps)
+                keep.append(eps)
+                c.eps, c.act, c.logp, c.out = _abi.ptr(eps), _abi.ptr(acts[a]), _abi.ptr(lps[a]), None
+                c.std_x_coef, c.std_y_coef = net.std_x_coef, net.std_y_coef
+            else:
+                c.out = _abi.ptr((vals if kind == "critic" else cps)[a])
+        scratch = getattr(self, "_mc_scratch", None)
+        need = int(lib.spo_ma_collect_scratch_floats(len(jobs)))
+        if scratch is None or scratch.numel() < need:
+            scratch = self._mc_scratch = torch.empty(need, dtype=torch.float32, device=self.dev)
+        rc = lib.spo_ma_collect_forward(len(jobs), arr, N, _abi.ptr(scratch), _abi.stream_ptr())
+        if rc == _abi.MA_COLLECT_UNSUPPORTED:
+            return None
+        _abi.check(rc, "spo_ma_collect_forward")
+        tr = lambda xs: torch.transpose(torch.stack(xs), 1, 0)
+        if not self.use_cost:
+            return vals.transpose(1, 0), acts, lps, tr(list(rnn)), tr(list(rnn_c))
+        return vals.transpose(1, 0), acts, lps, tr(list(rnn)), tr(list(rnn_c)), cps.transpose(1, 0), tr(list(rnn_k))
+
+    @torch.no_grad()
     def _collect_eager(self, share_obs, obs, rnn, rnn_c, rnn_k, masks):
+        if self.config.get("collect_fused", True) and not getattr(self, "_fused_unsupported", False):
+            out = self._collect_fused(share_obs, obs, rnn, rnn_c, rnn_k, masks)
+            if out is not None:
+                return out
+            self._fused_unsupported = True                   # geometry: decided once, the networks do not change shape
         vals, acts, lps, o_rnn, o_rnn_c, cps, o_rnn_k = [], [], [], [], [], [], []
         tr = lambda xs: torch.transpose(torch.stack(xs), 1, 0)
         if not self.use_cost:

@@ -2087,6 +2087,108 @@ def test_benchmark_launcher_then_evaluate_round_trip(dev, tmp_path, monkeypatch)
     assert np.isfinite([r, c]).all()
 
 
+@pytest.mark.parametrize("rows", [8192, 2111, 70])
+def test_ma_collect_forward_is_bit_identical_to_the_per_network_path(dev, rows):
+    """f3 collect step: spo_ma_collect_forward takes ALL networks of a step through one launch (feature
+    LayerNorm, blocks, head, Gaussian sample on chip).  From 2 048 rows upwards the per-network path runs the same fused-block
+    arithmetic, so every output must be identical bit for bit; below that the per-network path uses the plain GEMM +
+    LayerNorm kernels and the comparison is at 1e-5.  Also: the unsupported-geometry return value."""
+    from safepo import _abi
+    from safepo.common.model import MultiAgentActor, MultiAgentCritic
+    lib = _abi.load()
+    torch.manual_seed(rows)
+    specs = [(48, 3, 6, True, False), (96, 3, 1, False, False), (20, 1, 2, True, True), (128, 2, 1, False, False),
+             (64, 4, 16, True, False), (96, 3, 1, False, False)]
+    nets, xs = [], []
+    for D, nb, O, actor, det in specs:
+        cfg = _ma_cfg(dev, hidden_size=128, layer_N=nb - 1)
+        net = MultiAgentActor(cfg, _Sp(D), _Sp(O), dev) if actor else MultiAgentCritic(cfg, _Sp(D), dev)
+        with torch.no_grad():
+            net.theta.add_(0.1 * torch.randn_like(net.theta))
+        nets.append(net)
+        xs.append(torch.randn((rows, D), device=dev) * 2 + 0.3)
+    arr = (_abi.MaCollectNet * len(nets))()
+    outs = []
+    for i, ((D, nb, O, actor, det), net, x) in enumerate(zip(specs, nets, xs)):
+        c = arr[i]
+        c.theta, c.net, c.x, c.deterministic = _abi.ptr(net.theta), net._net, _abi.ptr(x), int(det)
+        out = torch.full((rows, O), float("nan"), device=dev)
+        c.out = _abi.ptr(out)
+        rec = {"out": out}
+        if actor:
+            rec["eps"] = torch.randn((rows, O), device=dev)
+            rec["act"], rec["logp"] = torch.full_like(out, float("nan")), torch.full_like(out, float("nan"))
+            c.eps, c.act, c.logp = (None if det else _abi.ptr(rec["eps"])), _abi.ptr(rec["act"]), _abi.ptr(rec["logp"])
+            c.std_x_coef, c.std_y_coef = net.std_x_coef, net.std_y_coef
+        outs.append(rec)
+    scratch = torch.empty(int(lib.spo_ma_collect_scratch_floats(len(nets))), device=dev)
+    _abi.check(lib.spo_ma_collect_forward(len(nets), arr, rows, _abi.ptr(scratch), _abi.stream_ptr()), "collect_forward")
+    torch.cuda.synchronize()
+    exact = rows >= 2048
+    for (D, nb, O, actor, det), net, x, rec in zip(specs, nets, xs, outs):
+        mean = net.net_forward(x)
+        if exact:
+            assert torch.equal(rec["out"], mean), (D, nb, O)
+        else:
+            np.testing.assert_allclose(rec["out"].cpu().numpy(), mean.cpu().numpy(), rtol=1e-5, atol=1e-5)
+        if actor:
+            act, logp = torch.empty_like(mean), torch.empty_like(mean)
+            # sampling from the fused kernel's own mean: the Gaussian arithmetic must agree bit for bit at every size
+            _abi.check(lib.spo_ma_sample(_abi.ptr(rec["out"]), _abi.ptr(net.log_std), None if det else _abi.ptr(rec["eps"]),
+                                         net.std_x_coef, net.std_y_coef, int(det), _abi.ptr(act), _abi.ptr(logp), rows, O,
+                                         _abi.stream_ptr()), "ma_sample")
+            assert torch.equal(rec["act"], act) and torch.equal(rec["logp"], logp), (D, nb, O)
+            if det:
+                assert torch.equal(rec["act"], rec["out"])
+    # geometry outside the fused kernel: a positive return value and nothing launched
+    cfg = _ma_cfg(dev, hidden_size=64, layer_N=1)
+    small = MultiAgentCritic(cfg, _Sp(12), dev)
+    one = (_abi.MaCollectNet * 1)()
+    xo, oo = torch.randn((rows, 12), device=dev), torch.zeros((rows, 1), device=dev)
+    one[0].theta, one[0].net, one[0].x, one[0].out = _abi.ptr(small.theta), small._net, _abi.ptr(xo), _abi.ptr(oo)
+    assert lib.spo_ma_collect_forward(1, one, rows, _abi.ptr(scratch), _abi.stream_ptr()) == _abi.MA_COLLECT_UNSUPPORTED
+    assert float(oo.abs().sum()) == 0.0
+
+
+def test_ma_runner_collect_fused_launch_equals_per_network_collect(dev, tmp_path):
+    """Runner.collect (mappolag.py:411-447) with the one-launch collect against the per-network launches: same seed, same
+    torch.randn draws -> values, actions, log-probabilities and cost predictions equal bit for bit (4 096 threads: both sides
+    on the fused-block arithmetic); then two episodes through the captured graph end to end."""
+    from safepo.multi_agent import mappolag
+    from safepo.common.env import SynthMultiAgentEnv
+    cfg = _ma_cfg(dev, **mappolag.mamujoco_cfg)
+    cfg.update(n_rollout_threads=4096, episode_length=4, hidden_size=128, log_dir=str(tmp_path / "run"), seed=0,
+               env_name="SynthMultiAgent-v0", use_eval=False, collect_graph=False)
+    env = SynthMultiAgentEnv(4096, num_agents=3, obs_dim=48, act_dim=6, trunc_len=4, device=dev)
+    r = mappolag.Runner(env, None, cfg)
+    r.logger.verbose = False
+    r.warmup()
+    got = {}
+    for fused in (True, False):
+        r.config["collect_fused"] = fused
+        r._fused_unsupported = False
+        torch.manual_seed(123)
+        got[fused] = r.collect(0)
+    assert not r._fused_unsupported
+    v1, a1, l1, _, _, c1, _ = got[True]
+    v0, a0, l0, _, _, c0, _ = got[False]
+    assert v1.shape == v0.shape and torch.equal(v1, v0) and torch.equal(c1, c0)
+    for x, y in zip(a1 + l1, a0 + l0):
+        assert torch.equal(x, y)
+    assert float(a1[0].std()) > 0.1
+    # end to end through the captured graph
+    r.config.update(collect_fused=True, collect_graph=True)
+    for ep in range(2):
+        for step in range(4):
+            values, actions, lps, rnn, rnn_c, cps, rnn_k = r.collect(step)
+            obs, share_obs, rewards, costs, dones, infos, _ = env.step(actions)
+            r.insert((obs, share_obs, rewards, costs, dones, infos, values, actions, lps, rnn, rnn_c, cps, rnn_k, costs.mean()))
+        r.compute()
+        r.train()
+    assert getattr(r, "_graph", None) is not None and not getattr(r, "_graph_failed", False)
+    assert all(torch.isfinite(t.policy.actor.theta).all() for t in r.trainer)
+
+
 def test_ma_mappolag_runner_end_to_end_synthetic(dev, tmp_path):
     """safepo.multi_agent.mappolag.train() on the synthetic 4-agent env: collect -> insert -> fused GAE/PopArt -> HAPPO
     sequential updates, logger rows and per-agent checkpoints in the reference's formats; the team reward improves."""
