@@ -250,6 +250,8 @@ class SynthMultiAgentEnv:
         self.share_observation_space = [Box(self.share_dim) for _ in range(num_agents)]
         self.action_space = [Box(act_dim, -1.0, 1.0) for _ in range(num_agents)]
         self._obs = None
+        self._dones = {}
+        self._infos = [{} for _ in range(num_envs)]          # (nothing to report; built once, not 8 192 dicts per step)
 
     def _draw(self):
         obs = torch.randn(self.num_envs, self.num_agents, self.obs_dim, device=self.dev, generator=self.gen)
@@ -262,6 +264,12 @@ class SynthMultiAgentEnv:
         self._obs, share = self._draw()
         return self._obs, share, None
 
+    def _dones_of(self, done: bool):
+        d = self._dones.get(done)
+        if d is None:
+            d = self._dones[done] = torch.full((self.num_envs, self.num_agents), bool(done), device=self.dev)
+        return d
+
     def step(self, actions):
         act = torch.stack([a.reshape(self.num_envs, self.act_dim) for a in actions], dim=1)        # [N, agents, A]
         target = torch.tanh(torch.einsum("nad,adk->nak", self._obs, self.W))
@@ -271,9 +279,9 @@ class SynthMultiAgentEnv:
             .expand(-1, self.num_agents, 1).contiguous()
         self.t += 1
         done = self.t % self.trunc_len == 0
-        dones = torch.full((self.num_envs, self.num_agents), bool(done), device=self.dev)
+        dones = self._dones_of(bool(done))
         self._obs, share = self._draw()
-        return self._obs, share, rewards, costs, dones, [{} for _ in range(self.num_envs)], None
+        return self._obs, share, rewards, costs, dones, self._infos, None
 
 
 def make_ma_synth_env(cfg_train: dict, seed: int = 0, **kw):

@@ -427,11 +427,13 @@ class Runner:
             self.buffer[a].obs[0].copy_(obs[:, a])
 
     @torch.no_grad()
-    def _collect_fused(self, share_obs, obs, rnn, rnn_c, rnn_k, masks):
+    def _collect_fused(self, share_obs, obs, rnn, rnn_c, rnn_k, masks, slots=None):
         """policy.get_actions of every agent as ONE launch (spo_ma_collect_forward: all networks of all agents, each row tile
         through its whole network on chip, Gaussian sampling included).  Same results bit for bit as the per-network calls
         below, same torch.randn draws in the same order.  Returns None when the networks are outside the fused kernel's
-        geometry (hidden != 128, wide observations, ...): the caller then launches network by network."""
+        geometry (hidden != 128, wide observations, ...): the caller then launches network by network.
+        slots: {"value_preds", "cost_preds": [agents, N, 1], "actions", "action_log_probs": [agents, N, A]} -- the buffer rows
+        of this step; the kernel then writes its results where insert() would copy them."""
         lib = _abi.load()
         jobs = []                                            # (net, input, agent, kind)
         for a in range(self.num_agents):
@@ -445,8 +447,15 @@ class Runner:
         arr = (_abi.MaCollectNet * len(jobs))()
         keep, acts, lps = [], [None] * self.num_agents, [None] * self.num_agents
         N = obs[0].reshape(-1, self.trainer[0].policy.actor._net.in_dim).shape[0]
-        vals = torch.empty((self.num_agents, N, 1), dtype=torch.float32, device=self.dev)
-        cps = torch.empty((self.num_agents, N, 1), dtype=torch.float32, device=self.dev) if self.use_cost else None
+        if slots is not None:
+            vals, cps = slots["value_preds"], slots.get("cost_preds")
+            ok = all(t is None or (t.dtype == torch.float32 and t[a].is_contiguous()) for t in (vals, cps, slots["actions"],
+                     slots["action_log_probs"]) for a in range(self.num_agents))
+            if not ok or vals.shape[1:] != (N, 1):
+                return None
+        else:
+            vals = torch.empty((self.num_agents, N, 1), dtype=torch.float32, device=self.dev)
+            cps = torch.empty((self.num_agents, N, 1), dtype=torch.float32, device=self.dev) if self.use_cost else None
         for i, (net, x, a, kind) in enumerate(jobs):
             x = _abi.require_gpu_tensor(torch.as_tensor(x, **net.tpdv).reshape(-1, net._net.in_dim).contiguous(), "x", torch.float32)
             if x.shape[0] != N:
@@ -456,7 +465,12 @@ class Runner:
             c.theta, c.net, c.x, c.deterministic = _abi.ptr(net.theta), net._net, _abi.ptr(x), 0
             if kind == "actor":
                 eps = torch.randn((N, net.act_dim), **net.tpdv)
-                acts[a], lps[a] = torch.empty_like(eps), torch.empty_like(eps)
+                if slots is not None:
+                    acts[a], lps[a] = slots["actions"][a], slots["action_log_probs"][a]
+                    if acts[a].shape != eps.shape or lps[a].shape != eps.shape:
+                        return None
+                else:
+                    acts[a], lps[a] = torch.empty_like(eps), torch.empty_like(eps)
                 keep.append(eps)
                 c.eps, c.act, c.logp, c.out = _abi.ptr(eps), _abi.ptr(acts[a]), _abi.ptr(lps[a]), None
                 c.std_x_coef, c.std_y_coef = net.std_x_coef, net.std_y_coef
@@ -471,9 +485,17 @@ class Runner:
             return None
         _abi.check(rc, "spo_ma_collect_forward")
         tr = lambda xs: torch.transpose(torch.stack(xs), 1, 0)
+        if slots is not None:
+            # recurrent policies are not built: the states handed back are the all-zero inputs, stacked once and reused
+            zr = getattr(self, "_rnn_zero_out", None)
+            if zr is None or zr[0].shape[0] != N:
+                zr = self._rnn_zero_out = tuple(tr([torch.zeros_like(t) for t in grp]) for grp in (rnn, rnn_c, rnn_k))
+            r_out, rc_out, rk_out = zr
+        else:
+            r_out, rc_out, rk_out = tr(list(rnn)), tr(list(rnn_c)), (tr(list(rnn_k)) if self.use_cost else None)
         if not self.use_cost:
-            return vals.transpose(1, 0), acts, lps, tr(list(rnn)), tr(list(rnn_c))
-        return vals.transpose(1, 0), acts, lps, tr(list(rnn)), tr(list(rnn_c)), cps.transpose(1, 0), tr(list(rnn_k))
+            return vals.transpose(1, 0), acts, lps, r_out, rc_out
+        return vals.transpose(1, 0), acts, lps, r_out, rc_out, cps.transpose(1, 0), rk_out
 
     @torch.no_grad()
     def _collect_eager(self, share_obs, obs, rnn, rnn_c, rnn_k, masks):
@@ -506,6 +528,11 @@ class Runner:
         stacked = getattr(self, "_stack", None) is not None
         if not self.config.get("collect_graph", True) or getattr(self, "_graph_failed", False):
             return self._collect_eager(*ins)
+        if (stacked and self.config.get("collect_inplace", True) and self.config.get("collect_fused", True)
+                and getattr(self, "_inplace_ok", True)):
+            out = self._collect_step_graph(step, ins)
+            if out is not None:
+                return out
         if getattr(self, "_graph", None) is None:
             try:
                 if stacked:      # one static [agents, N, ...] tensor per input; the per-agent graph inputs are its views
@@ -545,25 +572,69 @@ class Runner:
         v, acts, lps, r, rc, cp, rk = self._static_out
         return v.clone(), [x.clone() for x in acts], [x.clone() for x in lps], r, rc, cp.clone(), rk
 
+    def _collect_step_graph(self, step, ins):
+        """One captured graph PER STEP INDEX over the one-launch collect, reading the step's rows of the stacked buffers and
+        writing values / actions / log-probabilities / cost predictions straight into the rows insert() fills: a collect step
+        is one graph replay -- no staging copies in, no clones out -- and insert() skips the copies whose source already is
+        the destination.  The tensors handed back are views of the buffer (valid like the reference's until the step is
+        overwritten one episode later).  None = not available (geometry outside the fused kernel, capture failure)."""
+        graphs = self.__dict__.setdefault("_step_graphs", {})
+        ent = graphs.get(step)
+        if ent is None:
+            st = self._stack
+            slots = {"value_preds": st["value_preds"][:, step], "actions": st["actions"][:, step],
+                     "action_log_probs": st["action_log_probs"][:, step]}
+            if self.use_cost:
+                slots["cost_preds"] = st["cost_preds"][:, step]
+            try:
+                if not hasattr(self, "_inplace_ok"):
+                    if self._collect_fused(*ins, slots=slots) is None:   # warm-up + geometry check, once
+                        self._inplace_ok = False
+                        return None
+                    torch.cuda.synchronize(self.dev)
+                    self._inplace_ok = True
+                    self._step_pool = torch.cuda.graph_pool_handle()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self._step_pool):
+                    out = self._collect_fused(*ins, slots=slots)
+                ent = graphs[step] = (g, out)
+            except Exception as e:                                   # noqa: BLE001 -- the single-graph / eager paths stay valid
+                self._inplace_ok = False
+                torch.cuda.synchronize(self.dev)
+                if self.is_root:
+                    print(f"[safepo] per-step collect graph capture failed ({type(e).__name__}: {e}); using the staged graph",
+                          file=sys.stderr)
+                return None
+        ent[0].replay()
+        return ent[1]
+
     def insert(self, data, aver_episode_costs=0):
         (obs, share_obs, rewards, costs, dones, infos, values, actions, action_log_probs, rnn_states, rnn_states_critic,
          cost_preds, rnn_states_cost, done_episodes_costs_aver) = data
         dones_env = torch.all(dones, axis=1)
         keep = (~dones_env).float()
         # mappolag.py:458-472, as mask arithmetic on the device instead of boolean-index assignment
-        masks = keep.view(-1, 1, 1).expand(-1, self.num_agents, 1).contiguous()
-        active_masks = torch.ones(dones.shape[0], self.num_agents, 1, device=self.dev)
-        active_masks[dones == True] = 0.0
-        active_masks[dones_env == True] = 1.0
+        # (boolean-index assignment would run nonzero(): a host synchronisation in every step)
+        masks = keep.view(-1, 1, 1).expand(-1, self.num_agents, 1)
+        active_masks = (dones_env.view(-1, 1) | ~dones).float().unsqueeze(-1)        # 0 for a done agent of a live env
         # (rnn states are zeros throughout: recurrent policies are not built, so there is nothing to reset at episode ends)
         if self._stack is not None:
             st, s0 = self._stack, self.buffer[0].step
             tr = lambda t: t.transpose(0, 1)                                  # [N, agents, ...] -> [agents, N, ...]
             st["share_obs"][:, s0 + 1].copy_(tr(share_obs)); st["obs"][:, s0 + 1].copy_(tr(obs))
-            st["actions"][:, s0].copy_(torch.stack(actions)); st["action_log_probs"][:, s0].copy_(torch.stack(action_log_probs))
-            st["value_preds"][:, s0].copy_(tr(values)); st["rewards"][:, s0].copy_(tr(rewards))
+            def put(dst, src):                                                # src() only when the row is not already in place
+                s = src()
+                if not (s.data_ptr() == dst.data_ptr() and s.shape == dst.shape and s.stride() == dst.stride()):
+                    dst.copy_(s)
+            in_place = lambda xs, f: all(x.data_ptr() == st[f][a, s0].data_ptr() and x.shape == st[f][a, s0].shape
+                                         and x.is_contiguous() for a, x in enumerate(xs))
+            if not in_place(actions, "actions"):
+                st["actions"][:, s0].copy_(torch.stack(actions))
+            if not in_place(action_log_probs, "action_log_probs"):
+                st["action_log_probs"][:, s0].copy_(torch.stack(action_log_probs))
+            put(st["value_preds"][:, s0], lambda: tr(values)); st["rewards"][:, s0].copy_(tr(rewards))
             if self.use_cost:       # happo.py:403-414 / mappo.py:395-406 keep costs out of the buffer
-                st["cost_preds"][:, s0].copy_(tr(cost_preds)); st["costs"][:, s0].copy_(tr(costs))
+                put(st["cost_preds"][:, s0], lambda: tr(cost_preds)); st["costs"][:, s0].copy_(tr(costs))
             st["masks"][:, s0 + 1].copy_(tr(masks)); st["active_masks"][:, s0 + 1].copy_(tr(active_masks))
             for b in self.buffer:
                 b.step = (s0 + 1) % b.episode_length

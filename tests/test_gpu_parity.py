@@ -2185,8 +2185,26 @@ def test_ma_runner_collect_fused_launch_equals_per_network_collect(dev, tmp_path
             r.insert((obs, share_obs, rewards, costs, dones, infos, values, actions, lps, rnn, rnn_c, cps, rnn_k, costs.mean()))
         r.compute()
         r.train()
-    assert getattr(r, "_graph", None) is not None and not getattr(r, "_graph_failed", False)
+    assert r._inplace_ok and sorted(r._step_graphs) == [0, 1, 2, 3] and not getattr(r, "_graph_failed", False)
     assert all(torch.isfinite(t.policy.actor.theta).all() for t in r.trainer)
+    # the per-step graphs write into the buffer rows: a replay under a seed equals the eager one-launch collect under that seed
+    torch.manual_seed(7)
+    r.config["collect_graph"] = False
+    ve, ae, le, _, _, ce, _ = [x.clone() if torch.is_tensor(x) else [y.clone() for y in x] for x in r.collect(2)]
+    r.config["collect_graph"] = True
+    vg, ag, lg, _, _, cg, _ = r.collect(2)
+    assert vg.data_ptr() == r._stack["value_preds"][:, 2].data_ptr() and ag[1].data_ptr() == r.buffer[1].actions[2].data_ptr()
+    assert torch.equal(vg, ve) and torch.equal(cg, ce)                   # values do not depend on the random draws
+    assert all(torch.isfinite(x).all() for x in ag + lg) and ag[0].shape == ae[0].shape
+    # insert() with rows that are already in place must leave them alone and still fill the rest
+    b = r.buffer[0]
+    s0 = b.step
+    vals, acts, lps, rnn, rnn_c, cps, rnn_k = r.collect(s0)
+    keep_act = acts[0].clone()
+    obs, share_obs, rewards, costs, dones, infos, _ = env.step(acts)
+    r.insert((obs, share_obs, rewards, costs, dones, infos, vals, acts, lps, rnn, rnn_c, cps, rnn_k, costs.mean()))
+    assert torch.equal(b.actions[s0], keep_act) and torch.equal(b.rewards[s0], rewards[:, 0])
+    assert torch.equal(b.obs[s0 + 1], obs[:, 0]) and float(b.active_masks[s0 + 1].min()) == 1.0
 
 
 def test_ma_mappolag_runner_end_to_end_synthetic(dev, tmp_path):

@@ -30,7 +30,7 @@ for ep in range(3):
     r.compute(); r.train()
 print({k: round(v / 128 * 1e3, 4) for k, v in T.items()}, "ms per step")
 # graph replay alone
-g = r._graph
+g = r._step_graphs[0][0] if getattr(r, "_step_graphs", None) else r._graph
 sync(); t0 = time.perf_counter()
 for _ in range(200): g.replay()
 sync(); print("graph replay ms", (time.perf_counter() - t0) / 200 * 1e3)
