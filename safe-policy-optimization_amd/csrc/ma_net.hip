@@ -178,6 +178,10 @@ inline int64_t ma_fuse_min_rows() {
   static const int64_t v = [] { const char* e = getenv("SPO_MA_FUSE_MIN_ROWS"); return e ? (int64_t)atoll(e) : (int64_t)SPO_MA_FUSE_MIN_ROWS_DEFAULT; }();
   return v;
 }
+inline bool ma_fuse_head() {       // SPO_MA_FUSE_HEAD=0: A/B knob, the head backward as separate launches
+  static const bool v = [] { const char* e = getenv("SPO_MA_FUSE_HEAD"); return !(e && e[0] == '0'); }();
+  return v;
+}
 int g_ma_gemm_rocblas = 0;      // spo_debug_ma_gemm only: 1 routes the two helpers below through rocBLAS (comparator)
 
 // Row-major helpers.  Y[B,N] (+)= X[B,K] * W[N,K]^T
@@ -564,6 +568,118 @@ __global__ __launch_bounds__(256) void ln_bwd128_kernel(const float* __restrict_
   }
 }
 
+// ---- head backward fused with the top block's LayerNorm/ELU backward (hidden 128, out_dim <= 16).  The per-layer sequence
+// -- dW_head = dout^T y (a 128 x 128-tile MFMA kernel with 1..16 useful columns), colsum(dout), dY = dout W_head (GEMM, 268 MB
+// written at 524 288 rows) and ln_bwd128_kernel (268 MB read back) -- read y / dY / a three times; here half a wave takes a row
+// once: dY = sum_o dout[o] W_head[o] in registers (W_head lives in registers: O float4 per lane), y recomputed from a and the
+// row statistics exactly as the forward formed it, dW_head / db_head accumulated per lane, then the LayerNorm/ELU backward of
+// ln_bwd128_kernel<1> on the dY it just formed.  HBM: a in, dz out (536 MB instead of ~1.6 GB at 524 288 rows).
+// Partials: `partial` as ln_bwd128_kernel (3 x 128 per workgroup); hpw [grid][O][128], hpb [grid][O] for the finish kernel.
+template <int OMAX>
+__global__ __launch_bounds__(256) void head_bwd_lnbwd128_kernel(const float* __restrict__ dout, const float* __restrict__ hW,
+                                                                const float* __restrict__ a, const float* __restrict__ stats,
+                                                                const float* __restrict__ g, const float* __restrict__ be,
+                                                                float* __restrict__ dz, float* __restrict__ partial,
+                                                                float* __restrict__ hpw, float* __restrict__ hpb, int64_t B, int O) {
+  constexpr int D = 128;
+  __shared__ float sh[3][8][D];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = (lane & 31) * 4, sub = lane >> 5;
+  const f4w gg = *reinterpret_cast<const f4w*>(g + c), bb = *reinterpret_cast<const f4w*>(be + c);
+  f4w hw[OMAX], acc[OMAX];
+  float accb[OMAX];
+#pragma unroll
+  for (int o = 0; o < OMAX; ++o) {
+    hw[o] = f4w{0.f, 0.f, 0.f, 0.f};
+    if (o < O) { hw[o][0] = hW[o * D + c]; hw[o][1] = hW[o * D + c + 1]; hw[o][2] = hW[o * D + c + 2]; hw[o][3] = hW[o * D + c + 3]; }
+    acc[o] = f4w{0.f, 0.f, 0.f, 0.f};
+    accb[o] = 0.f;
+  }
+  f4w cg = {0.f, 0.f, 0.f, 0.f}, cb = cg, cz = cg;
+  for (int64_t row = ((int64_t)blockIdx.x * 4 + wave) * 2 + sub; row < B + sub; row += (int64_t)gridDim.x * 8) {
+    const bool ok = row < B;
+    f4w av = {0.f, 0.f, 0.f, 0.f};
+    float mean = 0.f, rstd = 0.f, dov[OMAX];
+#pragma unroll
+    for (int o = 0; o < OMAX; ++o) dov[o] = 0.f;
+    if (ok) {
+      av = *reinterpret_cast<const f4w*>(a + row * D + c);
+      mean = stats[2 * row]; rstd = stats[2 * row + 1];
+#pragma unroll
+      for (int o = 0; o < OMAX; ++o)
+        if (o < O) dov[o] = dout[row * O + o];
+    }
+    const f4w xh = (av - mean) * rstd;
+    const f4w y = xh * gg + bb;                                   // the forward's y = (a - mean) * rstd * g + b
+    f4w d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < OMAX; ++o) {
+      d += hw[o] * dov[o];
+      acc[o] += y * dov[o];
+      accb[o] += dov[o];
+    }
+    const f4w dxh = d * gg;
+    cg += d * xh; cb += d;
+    const float m1 = half_wave_sum((dxh[0] + dxh[1]) + (dxh[2] + dxh[3])) * (1.f / D);
+    const f4w t = dxh * xh;
+    const float m2 = half_wave_sum((t[0] + t[1]) + (t[2] + t[3])) * (1.f / D);
+    f4w dzv = (dxh - m1 - xh * m2) * rstd;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dzv[e] *= av[e] > 0.f ? 1.f : av[e] + 1.f;
+    if (ok) *reinterpret_cast<f4w*>(dz + row * D + c) = dzv;
+    cz += ok ? dzv : f4w{0.f, 0.f, 0.f, 0.f};
+  }
+  *reinterpret_cast<f4w*>(&sh[0][2 * wave + sub][c]) = cg;
+  *reinterpret_cast<f4w*>(&sh[1][2 * wave + sub][c]) = cb;
+  *reinterpret_cast<f4w*>(&sh[2][2 * wave + sub][c]) = cz;
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 3 * D; idx += 256) {
+    const int w = idx / D, jcol = idx % D;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += sh[w][k][jcol];
+    partial[((int64_t)blockIdx.x * 3 + w) * D + jcol] = s;
+  }
+  // head-weight partials: the eight half-waves of the workgroup added in a fixed order, one output row at a time
+#pragma unroll
+  for (int o = 0; o < OMAX; ++o) {
+    if (o >= O) break;                                            // (uniform)
+    __syncthreads();
+    *reinterpret_cast<f4w*>(&sh[0][2 * wave + sub][c]) = acc[o];
+    if ((lane & 31) == 0) sh[1][2 * wave + sub][0] = accb[o];
+    __syncthreads();
+    if (threadIdx.x < D) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += sh[0][k][threadIdx.x];
+      hpw[((int64_t)blockIdx.x * O + o) * D + threadIdx.x] = s;
+    } else if (threadIdx.x == D) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += sh[1][k][0];
+      hpb[(int64_t)blockIdx.x * O + o] = s;
+    }
+  }
+}
+// sums the workgroup partials of head_bwd_lnbwd128_kernel in a fixed order: grid (O), 512 threads = 4 groups x 128 columns
+__global__ __launch_bounds__(512) void head_dw_finish_kernel(const float* __restrict__ hpw, const float* __restrict__ hpb, int nblocks,
+                                                             int O, float* __restrict__ dW, float* __restrict__ db) {
+  constexpr int D = 128;
+  __shared__ float sh[4][D + 1];
+  const int o = blockIdx.x, c = threadIdx.x & 127, q = threadIdx.x >> 7;
+  float s = 0.f, sb = 0.f;
+  for (int b = q; b < nblocks; b += 4) {
+    s += hpw[((int64_t)b * O + o) * D + c];
+    if (c == 0) sb += hpb[(int64_t)b * O + o];
+  }
+  sh[q][c] = s;
+  if (c == 0) sh[q][D] = sb;
+  __syncthreads();
+  if (q == 0) {
+    dW[o * D + c] = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
+    if (c == 0) db[o] = (sh[0][D] + sh[1][D]) + (sh[2][D] + sh[3][D]);
+  }
+}
+
 // ---- input LayerNorm (feature_norm) for narrow observations (dim <= 128, multiple of 4): float4 per lane, LPR lanes per
 // row (16 for dim <= 64, 32 for dim <= 128), 64/LPR rows per wave; the generic kernel spends one wave on a 48-wide row.
 template <int LPR>
@@ -895,11 +1011,22 @@ __global__ void fn_unfold_grad_kernel(const float* __restrict__ W0, const float*
   if (c >= D) return;
   const float gc = gam[c], bc = bet[c];
   float sg = 0.f, sb = 0.f;
-  for (int n = 0; n < H; ++n) {
-    const float w = W0[(int64_t)n * D + c], dwp = dW[(int64_t)n * D + c], dbn = db0[n];
-    sg = fmaf(w, dwp, sg);
-    sb = fmaf(dbn, w, sb);
-    dW[(int64_t)n * D + c] = fmaf(gc, dwp, bc * dbn);
+  // 16 rows of loads in flight per step (one thread walks all H rows of its column: serial latency otherwise, 50 us at
+  // H = 128); the sums keep their row order
+  for (int n0 = 0; n0 < H; n0 += 16) {
+    float w[16], dwp[16], dbn[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int n = n0 + u < H ? n0 + u : H - 1;
+      w[u] = W0[(int64_t)n * D + c]; dwp[u] = dW[(int64_t)n * D + c]; dbn[u] = db0[n];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (n0 + u < H) {
+        sg = fmaf(w[u], dwp[u], sg);
+        sb = fmaf(dbn[u], w[u], sb);
+        dW[(int64_t)(n0 + u) * D + c] = fmaf(gc, dwp[u], bc * dbn[u]);
+      }
   }
   dg[c] = sg; dbeta[c] = sb;
 }
@@ -1374,8 +1501,32 @@ extern "C" int spo_ma_backward(const float* theta, const spo_ma_net* net, const 
   float* partial = scratch + 2 * B * Wd;
   float* slices = partial + 1024 * 3 * Wd;
   const int gr = grid_rows(B);
-  // head
+  // dz of the top block from the head's dX; below it, for hidden 128 at large batch, one fused kernel per block turns
+  // dz_k into dz_{k-1} (dX GEMM + LayerNorm/ELU backward + column partials), otherwise the MFMA GEMM + the LayerNorm kernel.
+  const bool fuse_bwd = (L.H == 128) && (B >= ma_fuse_min_rows());
+  float* dzc = d1;                     // dz of the current block
+  float* other = d0;                   // free buffer (holds dY of the current block until its LayerNorm backward ran)
+  int nparts = gr;
   const float* y_last = ws + L.ws_y(B, L.NB - 1);
+  const bool fuse_head = fuse_bwd && L.O <= 16 && !g_ma_gemm_rocblas && ma_fuse_head();
+  if (fuse_head) {
+    // head weight / bias gradients, the head's dX and the top block's LayerNorm/ELU backward in one pass over the rows
+    const int k = L.NB - 1;
+    const int64_t cap = (int64_t)dw_splits(B, L.H, L.H) * L.H * L.H / ((int64_t)L.O * (L.H + 1));      // `slices` holds the partials
+    const int nb = (int)(cap < gr ? (cap < 1 ? 1 : cap) : gr);
+    float* hpw = slices;
+    float* hpb = slices + (int64_t)nb * L.O * L.H;
+#define SPO_HEAD_BWD(OM)                                                                                                  \
+    hipLaunchKernelGGL(head_bwd_lnbwd128_kernel<OM>, dim3(nb), dim3(256), 0, st, dout, theta + L.hW(), ws + L.ws_a(B, k),  \
+                       ws + L.ws_st(B, k), theta + L.g(k), theta + L.be(k), d1, partial, hpw, hpb, B, L.O)
+    if (L.O == 1) SPO_HEAD_BWD(1);
+    else if (L.O <= 8) SPO_HEAD_BWD(8);
+    else SPO_HEAD_BWD(16);
+#undef SPO_HEAD_BWD
+    hipLaunchKernelGGL(head_dw_finish_kernel, dim3(L.O), dim3(512), 0, st, hpw, hpb, nb, L.O, grad + L.hW(), grad + L.hb());
+    nparts = nb;
+  } else {
+  // head
   if (int rc = gemm_dyTx(st, dout, y_last, grad + L.hW(), B, L.H, L.O, slices)) return rc;
   {
     const int ns = (int)(B / 4096 < 1 ? 1 : B / 4096 > 256 ? 256 : B / 4096);
@@ -1383,12 +1534,6 @@ extern "C" int spo_ma_backward(const float* theta, const spo_ma_net* net, const 
     hipLaunchKernelGGL(colsum_small_finish_kernel, dim3(1), dim3(64), 0, st, partial, L.O, ns, grad + L.hb());
   }
   if (int rc = gemm_dyw(st, dout, theta + L.hW(), d0, B, L.H, L.O)) return rc;
-  // dz of the top block from the head's dX; below it, for hidden 128 at large batch, one fused kernel per block turns
-  // dz_k into dz_{k-1} (dX GEMM + LayerNorm/ELU backward + column partials), otherwise rocBLAS + the LayerNorm kernel.
-  const bool fuse_bwd = (L.H == 128) && (B >= ma_fuse_min_rows());
-  float* dzc = d1;                     // dz of the current block
-  float* other = d0;                   // free buffer (holds dY of the current block until its LayerNorm backward ran)
-  int nparts = gr;
   {
     const int k = L.NB - 1;
     if (L.H == 128)
@@ -1397,6 +1542,7 @@ extern "C" int spo_ma_backward(const float* theta, const spo_ma_net* net, const 
     else
       hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(gr), dim3(256), 0, st, d0, ws + L.ws_a(B, k), ws + L.ws_st(B, k), theta + L.g(k),
                          d1, partial, B, L.H);
+  }
   }
   for (int k = L.NB - 1; k >= 0; --k) {
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((L.H + 63) / 64, 3), dim3(1024), 0, st, partial, nparts, L.H, grad + L.g(k),

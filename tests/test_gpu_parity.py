@@ -1761,7 +1761,8 @@ class _Sp:
 
 
 @pytest.mark.parametrize("D,H,nb,O,actor,B", [(20, 64, 3, 5, True, 97), (33, 64, 3, 1, False, 97), (48, 128, 3, 6, True, 1030), (60, 128, 2, 1, False, 1031), (48, 128, 3, 6, True, 33001), (128, 128, 2, 1, False, 32900),
-                                               (100, 512, 2, 1, False, 259), (7, 33, 1, 2, True, 5)])
+                                               (100, 512, 2, 1, False, 259), (7, 33, 1, 2, True, 5), (64, 128, 2, 16, True, 4100),
+                                               (48, 128, 1, 9, True, 2049)])
 def test_ma_network_forward_backward_vs_oracle(dev, D, H, nb, O, actor, B):
     """LayerNorm -> [Linear, ELU, LayerNorm] x nb -> head: outputs and the full flat gradient (rocBLAS GEMMs + fused
     LayerNorm/ELU kernels) against torch autograd on the CPU restatement."""
