@@ -660,23 +660,45 @@ __global__ __launch_bounds__(256) void head_bwd_lnbwd128_kernel(const float* __r
     }
   }
 }
-// sums the workgroup partials of head_bwd_lnbwd128_kernel in a fixed order: grid (O), 512 threads = 4 groups x 128 columns
+// sums the workgroup partials of head_bwd_lnbwd128_kernel in a fixed order: grid (O, 4 column chunks of 32), 512 threads =
+// 16 groups x 32 columns; group q adds partials q, q + 16, ... (8 loads in flight), the 16 group sums are added in order
 __global__ __launch_bounds__(512) void head_dw_finish_kernel(const float* __restrict__ hpw, const float* __restrict__ hpb, int nblocks,
                                                              int O, float* __restrict__ dW, float* __restrict__ db) {
   constexpr int D = 128;
-  __shared__ float sh[4][D + 1];
-  const int o = blockIdx.x, c = threadIdx.x & 127, q = threadIdx.x >> 7;
+  __shared__ float sh[16][33];
+  const int o = blockIdx.x, cl = threadIdx.x & 31, c = blockIdx.y * 32 + cl, q = threadIdx.x >> 5;
+  const bool with_b = blockIdx.y == 0 && cl == 0;
   float s = 0.f, sb = 0.f;
-  for (int b = q; b < nblocks; b += 4) {
-    s += hpw[((int64_t)b * O + o) * D + c];
-    if (c == 0) sb += hpb[(int64_t)b * O + o];
+  int b = q;
+  for (; b + 7 * 16 < nblocks; b += 8 * 16) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = hpw[((int64_t)(b + 16 * u) * O + o) * D + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+    if (with_b) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sb += hpb[(int64_t)(b + 16 * u) * O + o];
+    }
   }
-  sh[q][c] = s;
-  if (c == 0) sh[q][D] = sb;
+  for (; b < nblocks; b += 16) {
+    s += hpw[((int64_t)b * O + o) * D + c];
+    if (with_b) sb += hpb[(int64_t)b * O + o];
+  }
+  sh[q][cl] = s;
+  if (with_b) sh[q][32] = sb;
   __syncthreads();
   if (q == 0) {
-    dW[o * D + c] = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
-    if (c == 0) db[o] = (sh[0][D] + sh[1][D]) + (sh[2][D] + sh[3][D]);
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[k][cl];
+    dW[o * D + c] = t;
+    if (with_b) {
+      float tb = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) tb += sh[k][32];
+      db[o] = tb;
+    }
   }
 }
 
@@ -1523,7 +1545,7 @@ extern "C" int spo_ma_backward(const float* theta, const spo_ma_net* net, const 
     else if (L.O <= 8) SPO_HEAD_BWD(8);
     else SPO_HEAD_BWD(16);
 #undef SPO_HEAD_BWD
-    hipLaunchKernelGGL(head_dw_finish_kernel, dim3(L.O), dim3(512), 0, st, hpw, hpb, nb, L.O, grad + L.hW(), grad + L.hb());
+    hipLaunchKernelGGL(head_dw_finish_kernel, dim3(L.O, 4), dim3(512), 0, st, hpw, hpb, nb, L.O, grad + L.hW(), grad + L.hb());
     nparts = nb;
   } else {
   // head
@@ -1860,29 +1882,33 @@ __device__ __forceinline__ void mc_input_ln(const float* __restrict__ x, int64_t
   }
 }
 
-__global__ __launch_bounds__(256, 1) void ma_collect_kernel(McArgs A) {
+// K chunk of the weight image: a block's [128][K] weights go through LDS in 64-column chunks (34 KB instead of 67 KB), which
+// brings the workgroup to 69 KB of LDS and two workgroups to a CU -- one fills the other's staging / epilogue bubbles
+constexpr int MC_KC = 64, MC_WLD = MC_KC + 4;
+__global__ __launch_bounds__(256, 2) void ma_collect_kernel(McArgs A) {
   extern __shared__ __attribute__((aligned(16))) float mc_lds[];
-  float* Ws = mc_lds;                              // [128][LD] weights of the current block; the head's [O][132] at the end
-  float* Xs = mc_lds + FB_N * FB_SLD;              // [64][LD] input tile; = Stg [64][132] ELU outputs / next input, in place
+  float* Ws = mc_lds;                              // [128][68] one K chunk of the current block's weights; the head's [O][132] at the end
+  float* Xs = mc_lds + FB_N * MC_WLD;              // [64][LD] input tile; = Stg [64][132] ELU outputs / next input, in place
   float* Sst = Xs + MC_ROWS * FB_SLD;              // [64][2] row mean / rstd
   const McNet& nt = A.n[blockIdx.y];
   const float* const theta = nt.theta;
   const int64_t B = A.rows;
   const int D = nt.D, O = nt.O, NB = nt.NB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kk = lane >> 4;
-  const int lc4 = (tid & 31) * 4, lrow = tid >> 5;
+  const int lc4 = (tid & 15) * 4, lrow = tid >> 4;                // chunk staging: 16 rows x 64 columns per pass, 8 passes
   const int64_t r0 = (int64_t)blockIdx.x * MC_ROWS;
-  // block 0's (folded) weights are on their way while the feature LayerNorm runs
-  f4w wv[16];
-  auto fetch_w = [&](const float* W, int K) {
-    const bool lcol_ok = lc4 < K;
+  f4w wv[8];
+  auto fetch_w = [&](const float* W, int K, int ch) {            // chunk ch of W [128][K] into registers
+    const int gc = MC_KC * ch + lc4;
+    const bool lcol_ok = gc < K;
 #pragma unroll
-    for (int ps = 0; ps < 16; ++ps) {
+    for (int ps = 0; ps < 8; ++ps) {
       wv[ps] = f4w{0.f, 0.f, 0.f, 0.f};
-      if (lcol_ok) wv[ps] = *reinterpret_cast<const f4w*>(W + (int64_t)(lrow + 8 * ps) * K + lc4);
+      if (lcol_ok) wv[ps] = *reinterpret_cast<const f4w*>(W + (int64_t)(lrow + 16 * ps) * K + gc);
     }
   };
-  fetch_w(nt.w0f, D);
+  // block 0's (folded) weights are on their way while the feature LayerNorm runs
+  fetch_w(nt.w0f, D, 0);
   {
     const int KP0 = (D + 15) & ~15, LD0 = KP0 + 4;
     if (D <= 64) mc_input_ln<16>(nt.x, r0, B, D, LD0, KP0, Xs, tid);
@@ -1891,40 +1917,46 @@ __global__ __launch_bounds__(256, 1) void ma_collect_kernel(McArgs A) {
   float hwv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int k = 0; k < NB; ++k) {
     const int K = k == 0 ? D : FB_N, KP = (K + 15) & ~15, LD = KP + 4;
-    const bool lcol_in = lc4 < KP;
-#pragma unroll
-    for (int ps = 0; ps < 16; ++ps)
-      if (lcol_in) *reinterpret_cast<f4w*>(Ws + (lrow + 8 * ps) * LD + lc4) = wv[ps];
+    const int nch = (KP + MC_KC - 1) / MC_KC;
+    const float* Wk = k == 0 ? nt.w0f : theta + nt.oW[k];
     const float* bias = k == 0 ? nt.b0f : theta + nt.ob[k];
     float bcol[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) bcol[t] = bias[16 * t + i];
-    __syncthreads();                               // W_k and the input tile are in LDS
-    if (k + 1 < NB) fetch_w(theta + nt.oW[k + 1], FB_N);
-    else {
-      // head weights [O][128] (behind an actor's log_std they are not 16-byte aligned: scalar loads, coalesced)
-#pragma unroll
-      for (int h = 0; h < 8; ++h) {
-        const int f = tid + 256 * h;
-        if (f < O * FB_N) hwv[h] = theta[nt.ohW + f];
-      }
-    }
     f4w acc[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = f4w{0.f, 0.f, 0.f, 0.f};
-    const float* xa = Xs + (16 * wave + i) * LD + 4 * kk;
-    const float* wb = Ws + i * LD + 4 * kk;
-    for (int kb = 0; kb < KP / 16; ++kb) {
-      const f4w am = *reinterpret_cast<const f4w*>(xa + 16 * kb);
-      f4w bt[8];
+    for (int ch = 0; ch < nch; ++ch) {
+      const int cw = KP - MC_KC * ch < MC_KC ? KP - MC_KC * ch : MC_KC;       // columns of this chunk (multiple of 16)
+      if (lc4 < cw) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) bt[t] = *reinterpret_cast<const f4w*>(wb + 16 * t * LD + 16 * kb);
+        for (int ps = 0; ps < 8; ++ps) *reinterpret_cast<f4w*>(Ws + (lrow + 16 * ps) * MC_WLD + lc4) = wv[ps];
+      }
+      __syncthreads();                             // the chunk (and, for ch == 0, the input tile) is in LDS
+      if (ch + 1 < nch) fetch_w(Wk, K, ch + 1);
+      else if (k + 1 < NB) fetch_w(theta + nt.oW[k + 1], FB_N, 0);
+      else {
+        // head weights [O][128] (behind an actor's log_std they are not 16-byte aligned: scalar loads, coalesced)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+        for (int h = 0; h < 8; ++h) {
+          const int f = tid + 256 * h;
+          if (f < O * FB_N) hwv[h] = theta[nt.ohW + f];
+        }
+      }
+      const float* xa = Xs + (16 * wave + i) * LD + 4 * kk + MC_KC * ch;
+      const float* wb = Ws + i * MC_WLD + 4 * kk;
+      for (int kb = 0; kb < cw / 16; ++kb) {
+        const f4w am = *reinterpret_cast<const f4w*>(xa + 16 * kb);
+        f4w bt[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[r], bt[t][r], acc[t], 0, 0, 0);
+        for (int t = 0; t < 8; ++t) bt[t] = *reinterpret_cast<const f4w*>(wb + 16 * t * MC_WLD + 16 * kb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[r], bt[t][r], acc[t], 0, 0, 0);
+      }
+      __syncthreads();                             // every wave is done with this chunk (after the last: with the input tile)
     }
-    __syncthreads();                               // every wave is done with W_k and with the input tile
     const float* g = theta + nt.og[k]; const float* be = theta + nt.obe[k];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -2046,7 +2078,7 @@ extern "C" int spo_ma_collect_forward(int32_t n_nets, const spo_ma_collect_net* 
     }
   }
   hipStream_t st = (hipStream_t)stream;
-  constexpr size_t sh = ((size_t)FB_N * FB_SLD + MC_ROWS * FB_SLD + 2 * MC_ROWS) * sizeof(float);
+  constexpr size_t sh = ((size_t)FB_N * MC_WLD + MC_ROWS * FB_SLD + 2 * MC_ROWS) * sizeof(float);
   static bool attr_done_dev[spo::SPO_MAX_DEVICES] = {};
   bool& attr_done = attr_done_dev[spo::current_device_slot()];
   if (!attr_done) {
