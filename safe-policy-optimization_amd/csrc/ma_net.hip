@@ -178,6 +178,10 @@ inline int64_t ma_fuse_min_rows() {
   static const int64_t v = [] { const char* e = getenv("SPO_MA_FUSE_MIN_ROWS"); return e ? (int64_t)atoll(e) : (int64_t)SPO_MA_FUSE_MIN_ROWS_DEFAULT; }();
   return v;
 }
+inline bool ma_fwd_wave_private() {       // SPO_MA_FWD_WAVE=0: A/B knob, the four-wave barrier form of the fused block forward
+  static const bool v = [] { const char* e = getenv("SPO_MA_FWD_WAVE"); return !(e && e[0] == '0'); }();
+  return v;
+}
 inline bool ma_fuse_head() {       // SPO_MA_FUSE_HEAD=0: A/B knob, the head backward as separate launches
   static const bool v = [] { const char* e = getenv("SPO_MA_FUSE_HEAD"); return !(e && e[0] == '0'); }();
   return v;
@@ -870,6 +874,120 @@ __global__ __launch_bounds__(256, 1) void fused_block_fwd128_kernel(const float*
   }
 }
 
+// ---- the same block with WAVE-PRIVATE row tiles (round 3; training-size batches).  The kernel above synchronises its four
+// waves twice per tile (stage X together, multiply, epilogue) with one wave per SIMD: every phase of every wave waits for the
+// slowest and nothing hides the global loads / stores.  Here a workgroup is 8 waves around ONE shared weight image; each wave
+// owns 16-row tiles end to end -- its rows prefetched into registers one tile ahead, written to its own 8 KB of LDS, multiplied,
+// ELU + LayerNorm in registers, rows stored through the same LDS region -- and never meets a barrier after the weights are
+// staged, so two waves per SIMD overlap one wave's memory phases with the other's MFMAs.  Per-element arithmetic, operand
+// order and cross-lane sums are those of fused_block_fwd128_kernel (results bit-identical).
+constexpr int FBW_WAVES = 8;
+__global__ __launch_bounds__(64 * FBW_WAVES, 1) void fused_block_fwd128w_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                                              const float* __restrict__ bias, const float* __restrict__ g,
+                                                                              const float* __restrict__ be, float* __restrict__ a_out,
+                                                                              float* __restrict__ y, float* __restrict__ stats,
+                                                                              int64_t B, int K) {
+  extern __shared__ __attribute__((aligned(16))) float fb_lds[];
+  const int KP = (K + 15) & ~15;
+  const int LD = KP + 4;
+  float* Ws = fb_lds;                                          // [128][LD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kk = lane >> 4;
+  float* Xw = fb_lds + FB_N * FB_SLD + wave * (16 * FB_SLD + 32);      // this wave's [16][132] tile (X rows, then the ELU outputs)
+  float* Sw = Xw + 16 * FB_SLD;                                // [16][2] row mean / rstd
+  {
+    // weights: 512 threads, 16 rows x 128 columns per pass, 8 passes
+    const int lc4 = (tid & 31) * 4, lrow = tid >> 5;
+    const bool lcol_ok = lc4 < K, lcol_in = lc4 < KP;
+    f4w wv[8];
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+      wv[ps] = f4w{0.f, 0.f, 0.f, 0.f};
+      if (lcol_ok) wv[ps] = *reinterpret_cast<const f4w*>(W + (int64_t)(lrow + 16 * ps) * K + lc4);
+    }
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps)
+      if (lcol_in) *reinterpret_cast<f4w*>(Ws + (lrow + 16 * ps) * LD + lc4) = wv[ps];
+  }
+  float bcol[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) bcol[t] = bias[16 * t + i];
+  const int c4 = (lane & 31) * 4, rsub = lane >> 5;            // row-major access: half a wave per row, float4 per lane
+  const bool xcol_ok = c4 < K, xcol_in = c4 < KP;
+  const f4w g4 = *reinterpret_cast<const f4w*>(g + c4), be4 = *reinterpret_cast<const f4w*>(be + c4);
+  const int64_t ntiles = (B + 15) / 16;
+  const int64_t tstride = (int64_t)gridDim.x * FBW_WAVES;
+  f4w xv[8];
+  auto fetch_tile = [&](int64_t t) {
+    const int64_t rb = t * 16;
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+      const int rr = 2 * ps + rsub;
+      xv[ps] = f4w{0.f, 0.f, 0.f, 0.f};
+      if (xcol_ok && t < ntiles && rb + rr < B) xv[ps] = *reinterpret_cast<const f4w*>(X + (rb + rr) * K + c4);
+    }
+  };
+  int64_t tile = (int64_t)blockIdx.x * FBW_WAVES + wave;
+  fetch_tile(tile);
+  __syncthreads();                                             // the weight image is complete (the only barrier)
+  for (; tile < ntiles; tile += tstride) {
+    const int64_t r0 = tile * 16;
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps)
+      if (xcol_in) *reinterpret_cast<f4w*>(Xw + (2 * ps + rsub) * LD + c4) = xv[ps];
+    __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0): the tile is wave-private
+    fetch_tile(tile + tstride);                                // in flight during the MFMA loop and the epilogue
+    f4w acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = f4w{0.f, 0.f, 0.f, 0.f};
+    const float* xa = Xw + i * LD + 4 * kk;
+    const float* wb = Ws + i * LD + 4 * kk;
+    for (int kb = 0; kb < KP / 16; ++kb) {
+      const f4w am = *reinterpret_cast<const f4w*>(xa + 16 * kb);
+      f4w bt[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) bt[t] = *reinterpret_cast<const f4w*>(wb + 16 * t * LD + 16 * kb);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[r], bt[t][r], acc[t], 0, 0, 0);
+    }
+    // epilogue: lane holds rows 4*kk + e of the tile, columns 16*t + i
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int rl = 4 * kk + e;
+      float v[8], sum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        float z = acc[t][e] + bcol[t];
+        z = z > 0.f ? z : __expf(z) - 1.f;
+        v[t] = z; sum += z;
+      }
+      const float mean = row16_allsum(sum) * (1.f / FB_N);
+      float q = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { const float d = v[t] - mean; q += d * d; }
+      const float rstd = 1.f / sqrtf(row16_allsum(q) * (1.f / FB_N) + LN_EPS);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) Xw[rl * FB_SLD + 16 * t + i] = v[t];
+      if (i == 0) { Sw[2 * rl] = mean; Sw[2 * rl + 1] = rstd; }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll 4
+    for (int jj = 0; jj < 8; ++jj) {
+      const int rl = 2 * jj + rsub;
+      const int64_t row = r0 + rl;
+      const f4w a4 = *reinterpret_cast<const f4w*>(Xw + rl * FB_SLD + c4);
+      const float mean = Sw[2 * rl], rstd = Sw[2 * rl + 1];
+      if (row < B) {
+        *reinterpret_cast<f4w*>(a_out + row * FB_N + c4) = a4;
+        *reinterpret_cast<f4w*>(y + row * FB_N + c4) = (a4 - mean) * rstd * g4 + be4;
+        if ((lane & 31) == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                        // the LDS reads above are done before the next tile overwrites the region
+  }
+}
+
 // ---- fused block backward for hidden 128: from dz_k (gradient at block k's pre-activation) straight to dz_{k-1}:
 //   dY = dz_k * W_k                              (the dX GEMM, fp32 MFMA)
 //   dz_{k-1} = LayerNorm'(dY; a_{k-1}, stats_{k-1}, gamma_{k-1}) * ELU'(a_{k-1})          (epilogue in registers)
@@ -1004,6 +1122,142 @@ __global__ __launch_bounds__(256, 1) void fused_dx_lnbwd128_kernel(const float* 
     float sacc = 0.f;
 #pragma unroll
     for (int sl = 0; sl < 16; ++sl) sacc += sh[(w * 16 + sl) * FB_N + col];
+    partial[((int64_t)blockIdx.x * 3 + w) * FB_N + col] = sacc;
+  }
+}
+
+// ---- the same backward step with WAVE-PRIVATE 16-row tiles (round 3): 8 waves around one shared W^T image, no barrier after
+// it is staged.  A wave prefetches its next tile's dz and a rows into registers, runs dz -> LDS -> MFMA, then puts the a rows
+// into the SAME 8 KB region (the dz tile is dead once the products are issued), applies the LayerNorm/ELU backward in place
+// and streams the rows out.  Column partials: 32 (wave, kk) slots per column added in a fixed order.
+__global__ __launch_bounds__(64 * FBW_WAVES, 1) void fused_dx_lnbwd128w_kernel(const float* __restrict__ dz, const float* __restrict__ W,
+                                                                             const float* __restrict__ a_prev,
+                                                                             const float* __restrict__ stats_prev,
+                                                                             const float* __restrict__ g_prev, float* __restrict__ dz_out,
+                                                                             float* __restrict__ partial, int64_t B) {
+  extern __shared__ __attribute__((aligned(16))) float fb_lds[];
+  constexpr int LD = FB_N + 4;
+  float* WsT = fb_lds;                                         // [128 c][LD]  W^T: WsT[c][n] = W[n][c]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kk = lane >> 4;
+  float* Tw = fb_lds + FB_N * LD + wave * (16 * LD + 32);      // this wave's [16][LD] tile: dz rows, then a rows -> dz_{k-1} rows
+  float* Sw = Tw + 16 * LD;                                    // [16][2] row mean / rstd
+  {
+    const int lc4 = (tid & 31) * 4, lrow = tid >> 5;           // 512 threads: 16 rows x 128 columns per pass, 8 passes
+    f4w wv[8];
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) wv[ps] = *reinterpret_cast<const f4w*>(W + (int64_t)(lrow + 16 * ps) * FB_N + lc4);
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) WsT[(lc4 + e) * LD + lrow + 16 * ps] = wv[ps][e];
+  }
+  float gcol[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) gcol[t] = g_prev[16 * t + i];
+  float cg[8], cb[8], cz[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) cg[t] = cb[t] = cz[t] = 0.f;
+  const int c4 = (lane & 31) * 4, rsub = lane >> 5;
+  const int64_t ntiles = (B + 15) / 16;
+  const int64_t tstride = (int64_t)gridDim.x * FBW_WAVES;
+  f4w pd[8], pa[8];
+  float pst = 0.f;                                             // lane l < 32: stats word l of the tile (16 rows x {mean, rstd})
+  auto fetch_tile = [&](int64_t t) {
+    const int64_t rb = t * 16;
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+      const int64_t r = rb + 2 * ps + rsub;
+      pd[ps] = pa[ps] = f4w{0.f, 0.f, 0.f, 0.f};
+      if (t < ntiles && r < B) {
+        pd[ps] = *reinterpret_cast<const f4w*>(dz + r * FB_N + c4);
+        pa[ps] = *reinterpret_cast<const f4w*>(a_prev + r * FB_N + c4);
+      }
+    }
+    pst = 0.f;
+    if (lane < 32 && t < ntiles && rb + (lane >> 1) < B) pst = stats_prev[2 * rb + lane];
+  };
+  int64_t tile = (int64_t)blockIdx.x * FBW_WAVES + wave;
+  fetch_tile(tile);
+  __syncthreads();                                             // W^T is staged (the only barrier before the final reduction)
+  for (; tile < ntiles; tile += tstride) {
+    const int64_t r0 = tile * 16;
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) *reinterpret_cast<f4w*>(Tw + (2 * ps + rsub) * LD + c4) = pd[ps];
+    if (lane < 32) Sw[lane] = pst;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    f4w acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = f4w{0.f, 0.f, 0.f, 0.f};
+    const float* da = Tw + i * LD + 4 * kk;
+    const float* wb = WsT + i * LD + 4 * kk;
+#pragma unroll 2
+    for (int kb = 0; kb < FB_N / 16; ++kb) {
+      const f4w a0 = *reinterpret_cast<const f4w*>(da + 16 * kb);
+      f4w bt[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) bt[t] = *reinterpret_cast<const f4w*>(wb + 16 * t * LD + 16 * kb);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], bt[t][r], acc[t], 0, 0, 0);
+    }
+    // the dz tile has been read: the a rows take its place (LDS executes a wave's accesses in order)
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) *reinterpret_cast<f4w*>(Tw + (2 * ps + rsub) * LD + c4) = pa[ps];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    fetch_tile(tile + tstride);                                // in flight during the epilogue and the next tile's staging
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int rl = 4 * kk + e;
+      const bool rok = r0 + rl < B;
+      const float mean = Sw[2 * rl], rstd = Sw[2 * rl + 1];
+      float av[8], xh[8], dxh[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        av[t] = Tw[rl * LD + 16 * t + i];
+        xh[t] = (av[t] - mean) * rstd;
+        const float d = rok ? acc[t][e] : 0.f;
+        dxh[t] = d * gcol[t];
+        cg[t] += d * xh[t]; cb[t] += d;
+        s1 += dxh[t]; s2 += dxh[t] * xh[t];
+      }
+      const float m1 = row16_allsum(s1) * (1.f / FB_N), m2 = row16_allsum(s2) * (1.f / FB_N);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        float v = (dxh[t] - m1 - xh[t] * m2) * rstd;
+        v *= av[t] > 0.f ? 1.f : av[t] + 1.f;
+        v = rok ? v : 0.f;
+        cz[t] += v;
+        Tw[rl * LD + 16 * t + i] = v;
+      }
+      __builtin_amdgcn_sched_barrier(0);                       // one row group at a time: interleaving all four costs 50 spilled registers
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int rl = 2 * jj + rsub;
+      const int64_t row = r0 + rl;
+      const f4w v4 = *reinterpret_cast<const f4w*>(Tw + rl * LD + c4);
+      if (row < B) *reinterpret_cast<f4w*>(dz_out + row * FB_N + c4) = v4;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+  }
+  // column partials: 32 (wave, kk) slots per column, summed in a fixed order (the tiles' LDS is dead; W^T's is reused)
+  __syncthreads();
+  float* sh = fb_lds;                                          // [3][32][128] floats = 48 KB <= the W^T image
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int slot = 4 * wave + kk, col = 16 * t + i;
+    sh[(0 * 32 + slot) * FB_N + col] = cg[t];
+    sh[(1 * 32 + slot) * FB_N + col] = cb[t];
+    sh[(2 * 32 + slot) * FB_N + col] = cz[t];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 3 * FB_N; idx += 64 * FBW_WAVES) {
+    const int w = idx / FB_N, col = idx % FB_N;
+    float sacc = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 32; ++sl) sacc += sh[(w * 32 + sl) * FB_N + col];
     partial[((int64_t)blockIdx.x * 3 + w) * FB_N + col] = sacc;
   }
 }
@@ -1465,7 +1719,19 @@ extern "C" int spo_ma_forward(const float* theta, const spo_ma_net* net, const f
                                     "hipFuncSetAttribute(fused_block_fwd128)")) return rc;
         attr_done = true;
       }
-      if (B >= 256 * 128) {
+      if (B >= 256 * 128 && ma_fwd_wave_private()) {
+        constexpr size_t shw = ((size_t)FB_N * FB_SLD + FBW_WAVES * (16 * FB_SLD + 32)) * sizeof(float);
+        static bool attr_w_dev[spo::SPO_MAX_DEVICES] = {};
+        bool& attr_w = attr_w_dev[spo::current_device_slot()];
+        if (!attr_w) {
+          if (int rc = spo::hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_block_fwd128w_kernel),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shw),
+                                      "hipFuncSetAttribute(fused_block_fwd128w)")) return rc;
+          attr_w = true;
+        }
+        hipLaunchKernelGGL(fused_block_fwd128w_kernel, dim3(256), dim3(64 * FBW_WAVES), shw, st, in, Wk, bk, theta + L.g(k),
+                           theta + L.be(k), a, ws + L.ws_y(B, k), ws + L.ws_st(B, k), B, K);
+      } else if (B >= 256 * 128) {
         const int64_t nt = (B + 127) / 128;
         hipLaunchKernelGGL(fused_block_fwd128_kernel<2>, dim3((unsigned)(nt < 256 ? nt : 256)), dim3(256), sh, st, in, Wk,
                            bk, theta + L.g(k), theta + L.be(k), a, ws + L.ws_y(B, k), ws + L.ws_st(B, k), B, K);
@@ -1581,10 +1847,25 @@ extern "C" int spo_ma_backward(const float* theta, const spo_ma_net* net, const 
                                     "hipFuncSetAttribute(fused_dx_lnbwd128)")) return rc;
         attr_done = true;
       }
+      if (B >= 256 * 128 && ma_fwd_wave_private()) {
+        constexpr size_t shw = ((size_t)FB_N * FB_SLD + FBW_WAVES * (16 * FB_SLD + 32)) * sizeof(float);
+        static bool attr_w_dev[spo::SPO_MAX_DEVICES] = {};
+        bool& attr_w = attr_w_dev[spo::current_device_slot()];
+        if (!attr_w) {
+          if (int rc = spo::hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_dx_lnbwd128w_kernel),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shw),
+                                      "hipFuncSetAttribute(fused_dx_lnbwd128w)")) return rc;
+          attr_w = true;
+        }
+        nparts = 256;
+        hipLaunchKernelGGL(fused_dx_lnbwd128w_kernel, dim3(nparts), dim3(64 * FBW_WAVES), shw, st, dzc, theta + L.W(k),
+                           ws + L.ws_a(B, k - 1), ws + L.ws_st(B, k - 1), theta + L.g(k - 1), other, partial, B);
+      } else {
       const int64_t nt = (B + FBW_ROWS - 1) / FBW_ROWS;
       nparts = (int)(nt < 256 ? nt : 256);
       hipLaunchKernelGGL(fused_dx_lnbwd128_kernel, dim3(nparts), dim3(256), sh, st, dzc, theta + L.W(k), ws + L.ws_a(B, k - 1),
                          ws + L.ws_st(B, k - 1), theta + L.g(k - 1), other, partial, B);
+      }
       float* t = dzc; dzc = other; other = t;
     } else if (k >= 1) {
       if (int rc = gemm_dyw(st, dzc, theta + L.W(k), other, B, L.in_k(k), L.H)) return rc;      // dY of block k-1
