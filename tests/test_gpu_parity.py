@@ -2088,6 +2088,32 @@ def test_benchmark_launcher_then_evaluate_round_trip(dev, tmp_path, monkeypatch)
     assert np.isfinite([r, c]).all()
 
 
+@pytest.mark.parametrize("D,nb,O,actor,B", [(48, 3, 6, True, 33001), (96, 2, 1, False, 40000)])
+def test_ma_block_kernel_forms_agree(dev, tmp_path, D, nb, O, actor, B):
+    """Round-3 forms of the training-size kernels (wave-private row tiles in the block forward / backward, head backward fused
+    with the top LayerNorm backward) against the round-1/2 forms (SPO_MA_FWD_WAVE=0, SPO_MA_FUSE_HEAD=0), each in its own process
+    (the knobs are read once): the forward -- outputs AND every stored activation / statistic -- must be identical bit for bit;
+    the gradients differ only by the order of their row-partial sums."""
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ma_forms_worker.py")
+    res = {}
+    for name, env_over in (("new", {}), ("old", {"SPO_MA_FWD_WAVE": "0", "SPO_MA_FUSE_HEAD": "0"})):
+        env = dict(os.environ)
+        env.pop("SPO_MA_FWD_WAVE", None); env.pop("SPO_MA_FUSE_HEAD", None)
+        env.update(env_over)
+        out = str(tmp_path / f"{name}.npz")
+        r = subprocess.run([sys.executable, worker, out, str(D), str(nb), str(O), str(int(actor)), str(B)], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[name] = np.load(out)
+    assert np.array_equal(res["new"]["out"], res["old"]["out"])
+    assert np.array_equal(res["new"]["ws"], res["old"]["ws"])
+    g_new, g_old = res["new"]["grad"], res["old"]["grad"]
+    scale = np.abs(g_old).max()
+    assert scale > 0 and np.abs(g_new - g_old).max() <= 2e-6 * scale + 1e-9, (np.abs(g_new - g_old).max(), scale)
+
+
 @pytest.mark.parametrize("rows", [8192, 2111, 70])
 def test_ma_collect_forward_is_bit_identical_to_the_per_network_path(dev, rows):
     """f3 collect step: spo_ma_collect_forward takes ALL networks of a step through one launch (feature
