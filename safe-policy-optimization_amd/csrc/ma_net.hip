@@ -211,14 +211,22 @@ int gemm_dyw(hipStream_t st, const float* dY, const float* W, float* dX, int64_t
 // HBM-bound (both operands are read once: 537 MB -> ~0.15 ms), so it is done here: the rows are split over up to 256
 // workgroups per 128x128 output tile, each accumulating its slice with fp32 MFMA from LDS-staged 32-row chunks, and a
 // second kernel adds the slices in a fixed order.
-constexpr int DW_T = 128, DW_R = 32, DW_LD = DW_T + 16;      // row stride 144: the two row-groups of a half-wave land 16 banks apart
+#ifndef SPO_DW_R
+#define SPO_DW_R 32
+#endif
+constexpr int DW_T = 128, DW_R = SPO_DW_R, DW_LD = DW_T + 16;      // row stride 144: the two row-groups of a half-wave land 16 banks apart
 
+inline int64_t dw_max_splits() {            // SPO_DW_MAX_SPLITS: A/B knob (256 = the round-1/2 value)
+  static const int64_t v = [] { const char* e = getenv("SPO_DW_MAX_SPLITS"); const int64_t x = e ? atoll(e) : 512; return x < 1 ? 1 : x; }();
+  return v;
+}
 int dw_splits(int64_t B, int N, int K) {
   const int64_t tiles = (int64_t)((N + DW_T - 1) / DW_T) * ((K + DW_T - 1) / DW_T);
   int64_t s = (B + 255) / 256;                       // at least 256 rows per slice
   const int64_t cap_mem = (int64_t)(1 << 24) / ((int64_t)N * K) > 0 ? (int64_t)(1 << 24) / ((int64_t)N * K) : 1;   // <= 64 MB of slices
   const int64_t cap_grid = 2048 / tiles > 0 ? 2048 / tiles : 1;
-  if (s > 256) s = 256;
+  // two (three) workgroups per CU: 256 slices were ONE workgroup per CU -- one wave per SIMD, every barrier and load exposed
+  if (s > dw_max_splits()) s = dw_max_splits();
   if (s > cap_mem) s = cap_mem;
   if (s > cap_grid) s = cap_grid;
   return (int)(s < 1 ? 1 : s);
@@ -243,10 +251,10 @@ __global__ __launch_bounds__(256, 2) void dw_partial_kernel(const float* __restr
     for (int t = 0; t < 8; ++t) acc[m][t] = f4v{0.f, 0.f, 0.f, 0.f};
   // The next 32-row chunk of both operands is fetched into registers while the current one is multiplied: with one or
   // two workgroups per CU nothing else hides the ~2 us load latency (318 -> ~190 us per call at 524 288 x 128 x 128).
-  f4v py[4], px[4];
+  f4v py[DW_R / 8], px[DW_R / 8];
   auto fetch_chunk = [&](int64_t r0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < DW_R / 8; ++q) {
       const int idx = q * 256 + tid, row = idx >> 5, c4 = (idx & 31) * 4;
       const int64_t r = r0 + row;
       f4v y = {0.f, 0.f, 0.f, 0.f}, x = {0.f, 0.f, 0.f, 0.f};
@@ -267,9 +275,9 @@ __global__ __launch_bounds__(256, 2) void dw_partial_kernel(const float* __restr
   };
   if (r_begin < r_end) fetch_chunk(r_begin);
   for (int64_t r0 = r_begin; r0 < r_end; r0 += DW_R) {
-    // stage 32 rows x 128 columns of both operands (zero beyond the matrix edges)
+    // stage DW_R rows x 128 columns of both operands (zero beyond the matrix edges)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < DW_R / 8; ++q) {
       const int idx = q * 256 + tid, row = idx >> 5, c4 = (idx & 31) * 4;
       *reinterpret_cast<f4v*>(Ys + row * DW_LD + c4) = py[q];
       *reinterpret_cast<f4v*>(Xs + row * DW_LD + c4) = px[q];
