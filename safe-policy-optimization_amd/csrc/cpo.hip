@@ -405,7 +405,8 @@ int launch_cpo(const CpoArgs& a, int blocks, hipStream_t st) {
 #define SPO_LAUNCH(K)                                                                                  \
   {                                                                                                    \
     const size_t sh = CpoLds<K, MODE>::SIZE * sizeof(float);                                           \
-    static bool done = false;                                                                          \
+    static bool done_dev[spo::SPO_MAX_DEVICES] = {};        /* the attribute is per device */           \
+    bool& done = done_dev[spo::current_device_slot()];                                                 \
     if (!done) {                                                                                       \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cpo_actor_kernel<K, MODE>),    \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);         \

@@ -17,6 +17,7 @@
 // through LDS as [feature][batch]).
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include "common.h"
 #include "mlp_mfma.h"
 #include "adam.h"
@@ -2416,10 +2417,35 @@ int pick_kin(int D) { return D <= 16 ? 16 : D <= 32 ? 32 : D <= 64 ? 64 : 128; }
 
 unsigned long long* g_prof_buf = nullptr;
 
-// backup rows of the main + helper kernel (one launch of it at a time per process and device; L2-resident)
-// one set per rank slot: a process may drive several ranks of one device at once (tools/p2p_loopback_bench.py)
-__device__ float4 g_upd_backup[XR_MAX_WORLD][UPD_BACKUP_ROWS * 3 * 512];
-__device__ unsigned long long g_h_slots[XR_MAX_WORLD][32];
+// Scratch of the main + helper kernel: its clip backup rows (L2-resident, read back only on a clipped step) and the
+// cross-workgroup norm granules.  One block per (device, stream), allocated on first use and kept: launches on one stream are
+// ordered and may share a block, launches on different streams (two engines of one process, the ranks of
+// tools/p2p_loopback_bench.py) get different blocks, so concurrent launches never see each other's granules or backups.
+struct HScratch { int dev; void* stream; char* base; };
+constexpr size_t H_BACKUP_BYTES = sizeof(float4) * UPD_BACKUP_ROWS * 3 * 512, H_SLOT_BYTES = sizeof(unsigned long long) * 32;
+constexpr int H_SCRATCH_MAX = 256;
+HScratch g_hs[H_SCRATCH_MAX];
+int g_hs_n = 0;
+std::mutex g_hs_mu;
+int h_scratch_for(hipStream_t st, float** backup, unsigned long long** slots) {
+  const int dev = current_device_slot();
+  std::lock_guard<std::mutex> lk(g_hs_mu);
+  for (int i = 0; i < g_hs_n; ++i)
+    if (g_hs[i].dev == dev && g_hs[i].stream == (void*)st) {
+      *backup = reinterpret_cast<float*>(g_hs[i].base);
+      *slots = reinterpret_cast<unsigned long long*>(g_hs[i].base + H_BACKUP_BYTES);
+      return 0;
+    }
+  if (g_hs_n == H_SCRATCH_MAX)
+    return spo::fail(-1, "update kernel: more than %d (device, stream) pairs have launched the persistent update in this process",
+                     H_SCRATCH_MAX);
+  void* p = nullptr;
+  if (int rc = spo::hip_check(hipMalloc(&p, H_BACKUP_BYTES + H_SLOT_BYTES), "hipMalloc(update scratch)")) return rc;
+  g_hs[g_hs_n++] = HScratch{dev, (void*)st, static_cast<char*>(p)};
+  *backup = reinterpret_cast<float*>(p);
+  *slots = reinterpret_cast<unsigned long long*>(static_cast<char*>(p) + H_BACKUP_BYTES);
+  return 0;
+}
 
 // SPO_UPDATE_FORM: 0 = four-wave kernel everywhere, 2 = main + helper waves (default) where that form applies (persistent PPO step, clipped-surrogate loss, no in-kernel cross-rank exchange, batch <= 64, obs <= 64).
 inline int update_form() {
@@ -2430,21 +2456,13 @@ inline int update_form() {
 template <int K, bool PROF = false, int XR = 0, bool XRD = true>
 int launch_update_h(const UpdArgs& a_in, int blocks, hipStream_t st) {
   UpdArgs a = a_in;
-  const int rslot = XR ? a.xr_rank : 0;
-  float4* bkbase = nullptr;
-  unsigned long long* slbase = nullptr;
-  if (int rc = spo::hip_check(hipGetSymbolAddress(reinterpret_cast<void**>(&bkbase), HIP_SYMBOL(g_upd_backup)),
-                              "hipGetSymbolAddress(g_upd_backup)")) return rc;
-  // [parity][network][helper wave] norm granules of this form (tags restart at 1 with every launch)
-  if (int rc = spo::hip_check(hipGetSymbolAddress(reinterpret_cast<void**>(&slbase), HIP_SYMBOL(g_h_slots)),
-                              "hipGetSymbolAddress(g_h_slots)")) return rc;
-  a.backup = reinterpret_cast<float*>(bkbase + (size_t)rslot * UPD_BACKUP_ROWS * 3 * 512);
+  if (int rc = h_scratch_for(st, &a.backup, &a.slots)) return rc;
   {
     static const int spec_env = [] { const char* e = getenv("SPO_UPDATE_SPEC"); return e ? atoi(e) : 1; }();
     a.spec_mode = spec_env;
   }
-  a.slots = slbase + (size_t)rslot * 32;
-  if (int rc = spo::hip_check(hipMemsetAsync(a.slots, 0, sizeof(unsigned long long) * 32, st), "hipMemsetAsync(g_h_slots)")) return rc;
+  // [parity][network][helper wave] norm granules of this form (tags restart at 1 with every launch)
+  if (int rc = spo::hip_check(hipMemsetAsync(a.slots, 0, H_SLOT_BYTES, st), "hipMemsetAsync(update scratch slots)")) return rc;
   const size_t sh = UpdHLds<K>::SIZE * sizeof(float);
   static bool attr_done[SPO_MAX_DEVICES] = {};
   const int dslot = current_device_slot();

@@ -2434,6 +2434,57 @@ def test_full_size_learning_iteration_is_deterministic(dev):
     assert float(outs[0][4].min()) >= 0.0                      # second moments
 
 
+def test_two_engines_update_concurrently_on_two_streams(dev):
+    """the main + helper update kernel's clip backup rows and norm granules are per (device, stream) scratch, so
+    two engines of one process may run their persistent launches at the same time on two streams.  Two engines with different
+    data and a clip bound that is active on part of the steps (backups restored, steps repeated): three learning iterations each,
+    launched concurrently, must equal the same iterations run one engine after the other, bit for bit."""
+    from safepo.common.engine import PPOLagEngine
+    from safepo.common.model import ActorVCritic
+    N, T, D, A = 256, 128, 60, 8
+    M = N * T
+    cfg = {"hidden_sizes": [64, 64], "gamma": 0.99, "target_kl": 1e9, "batch_size": 64, "learning_iters": 1, "max_grad_norm": 0.9}
+
+    def make(seed):
+        g = torch.Generator(device=dev).manual_seed(seed)
+        torch.manual_seed(seed)
+        pol = ActorVCritic(D, A).to(dev)
+        eng = PPOLagEngine(pol, N, T, cfg, dev)
+        b = eng.buffer
+        act = torch.randn(N, T, A, device=dev, generator=g)
+        b.data["obs"].copy_(torch.randn(N, T, D, device=dev, generator=g)); b.data["act"].copy_(act)
+        b.data["log_prob"].copy_(-A * 0.92 - 0.5 * (act ** 2).sum(-1) + 0.05 * torch.randn(N, T, device=dev, generator=g))
+        b.data["target_value_r"].copy_(torch.randn(N, T, device=dev, generator=g))
+        b.data["target_value_c"].copy_(torch.rand(N, T, device=dev, generator=g))
+        b.adv_mix.copy_(torch.randn(N, T, device=dev, generator=g))
+        perms = [torch.randperm(M, device=dev, generator=g).to(torch.int32) for _ in range(3)]
+        return eng, perms
+    results = {}
+    for mode in ("sequential", "concurrent"):
+        engs = [make(11), make(22)]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        torch.cuda.synchronize()
+        losses = [[], []]
+        if mode == "sequential":
+            for k, (eng, perms) in enumerate(engs):
+                for p in perms:
+                    losses[k].append(eng.learning_iter(p).clone())
+                torch.cuda.synchronize()
+        else:
+            for it in range(3):
+                for k, (eng, perms) in enumerate(engs):
+                    with torch.cuda.stream(streams[k]):
+                        losses[k].append(eng.learning_iter(perms[it]).clone())
+            torch.cuda.synchronize()
+        for eng, _ in engs:
+            eng.check_sync_error()
+        results[mode] = [(e.policy.theta.clone(), e.adam_m.clone(), torch.stack(l)) for (e, _), l in zip(engs, losses)]
+    for k in range(2):
+        for x, y in zip(results["sequential"][k], results["concurrent"][k]):
+            assert torch.equal(x, y), k
+    assert not torch.equal(results["sequential"][0][0], results["sequential"][1][0])
+
+
 def test_full_size_update_parity_drift_envelope(dev):
     """The headline launch against the oracle (ppo_lag.py:297-336): BASELINE config 2 size, 4096 envs x
     128 steps = 524 288 rows, one learning iteration = 8 192 minibatch steps in ONE persistent launch, same initial weights,
