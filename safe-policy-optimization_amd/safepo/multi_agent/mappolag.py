@@ -215,10 +215,14 @@ class MAPPO_L_Trainer:
         opt = pol.actor_optimizer
         ls_off = pol.actor.offset(6)
         rows_g = rows * self.comm.world_size                 # data parallel over rollout threads: equal shards
+        hoisted = getattr(self, "_train_scope", None)         # host scalars train() formed once for all its updates
         if c["use_policy_active_masks"]:
-            asum = active.sum().reshape(1).double()
-            self.comm.all_reduce_sum_(asum)
-            denom = float(asum.item())
+            if hoisted is not None and "active_sum" in hoisted and hoisted["rows"] == rows:
+                denom = hoisted["active_sum"]
+            else:
+                asum = active.sum().reshape(1).double()
+                self.comm.all_reduce_sum_(asum)
+                denom = float(asum.item())
         else:
             denom = float(rows_g)
         _abi.check(lib.spo_ma_actor_loss(_abi.ptr(mean), _abi.ptr(pol.actor.log_std), _abi.ptr(actions_batch), _abi.ptr(old_lp),
@@ -244,7 +248,8 @@ class MAPPO_L_Trainer:
             self._sync_normalizer()
             return value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_mean
         # ---- multiplier (mappolag.py:178-182); aver_episode_costs.mean() is a host scalar of the buffer
-        aver = float(check(aver_episode_costs).float().mean().item())
+        aver = (hoisted["aver_cost"] if hoisted is not None and "aver_cost" in hoisted
+                else float(check(aver_episode_costs).float().mean().item()))
         _abi.check(lib.spo_ma_lamda_update(_abi.ptr(self._lamda), _abi.ptr(self._scalars), aver, float(c["cost_limit"]), float(c["gamma"]),
                                            float(c["lagrangian_coef_rate"]), _abi.stream_ptr()), "spo_ma_lamda_update")
         # ---- critics (mappolag.py:183-197); both share the one PopArt normaliser
@@ -261,9 +266,9 @@ class MAPPO_L_Trainer:
 
         def standardised(returns, preds):
             adv = returns[:-1] - self.value_normalizer.denormalize(preds[:-1])
-            cp = adv.clone()
-            if self.use_cost:
-                cp[buffer.active_masks[:-1] == 0.0] = float("nan")
+            cp = adv
+            if self.use_cost:          # (torch.where, not boolean-index assignment: that one runs nonzero() = a host sync)
+                cp = torch.where(buffer.active_masks[:-1] == 0.0, torch.full_like(adv, float("nan")), adv)
             if self.comm.world_size == 1:
                 return (adv - torch.mean(cp)) / (torch.std(cp) + eps)
             # torch.mean / torch.std (unbiased) of the rows of ALL ranks, NaN-propagating like the single-rank form
@@ -275,24 +280,45 @@ class MAPPO_L_Trainer:
             return (adv - mean.float()) / (torch.sqrt(var.clamp(min=0.0)).float() + eps)
         advantages = standardised(buffer.returns, buffer.value_preds)
         cost_adv = standardised(buffer.cost_returns, buffer.cost_preds) if self.use_cost else None
-        out = None
-        for it in range(c["learning_iters"]):
-            perm = perm_fn(it) if perm_fn is not None else None
-            for sample in buffer.feed_forward_generator(advantages, c["num_mini_batch"], cost_adv=cost_adv, perm=perm):
-                out = self.ppo_update(sample)
-            if not self.use_cost:
-                value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights = out
-                if logger is not None:
-                    logger.store(**{"Loss/Loss_reward_critic": value_loss.item(), "Loss/Loss_actor": policy_loss.item(),
-                                    "Misc/Reward_critic_norm": critic_grad_norm.item(), "Misc/Entropy": dist_entropy.item(),
-                                    "Misc/Ratio": imp_weights.detach().mean().item()})
-                continue
-            value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights, cost_loss, cost_grad_norm = out
-            if logger is not None:
-                logger.store(**{"Loss/Loss_reward_critic": value_loss.item(), "Loss/Loss_cost_critic": cost_loss.item(),
-                                "Loss/Loss_actor": policy_loss.item(), "Misc/Reward_critic_norm": critic_grad_norm.item(),
-                                "Misc/Cost_critic_norm": cost_grad_norm.item(), "Misc/Entropy": dist_entropy.item(),
-                                "Misc/Ratio": imp_weights.detach().mean().item()})
+        # Host scalars every update of this call needs, formed ONCE (each .item() drains the queue: the GPU then idles until
+        # the host has launched the next kernels).  With one minibatch per iteration the minibatch is the whole buffer in
+        # some order, so the active-mask sum is the buffer's; the episode-cost average does not change during training.
+        scope = {}
+        if self.use_cost:
+            scope["aver_cost"] = float(check(buffer.aver_episode_costs).float().mean().item())
+        if c["num_mini_batch"] == 1 and c["use_policy_active_masks"]:
+            asum = buffer.active_masks[:-1].sum().reshape(1).double()
+            self.comm.all_reduce_sum_(asum)
+            scope["active_sum"] = float(asum.item())
+            scope["rows"] = int(buffer.active_masks[:-1].numel())
+        self._train_scope = scope
+        out, rows_logged = None, []
+        try:
+            for it in range(c["learning_iters"]):
+                perm = perm_fn(it) if perm_fn is not None else None
+                for sample in buffer.feed_forward_generator(advantages, c["num_mini_batch"], cost_adv=cost_adv, perm=perm):
+                    out = self.ppo_update(sample)
+                if logger is None:
+                    continue
+                # the iteration's log row stays on the device; all rows come to the host in one copy after the last update
+                if not self.use_cost:
+                    value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights = out
+                    rows_logged.append(torch.stack([t.detach().reshape(()).float() for t in
+                                                    (value_loss, policy_loss, critic_grad_norm, dist_entropy, imp_weights.detach().mean())]))
+                else:
+                    value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights, cost_loss, cost_grad_norm = out
+                    rows_logged.append(torch.stack([t.detach().reshape(()).float() for t in
+                                                    (value_loss, cost_loss, policy_loss, critic_grad_norm, cost_grad_norm, dist_entropy,
+                                                     imp_weights.detach().mean())]))
+        finally:
+            self._train_scope = None
+        if rows_logged:
+            keys = (("Loss/Loss_reward_critic", "Loss/Loss_actor", "Misc/Reward_critic_norm", "Misc/Entropy", "Misc/Ratio")
+                    if not self.use_cost else
+                    ("Loss/Loss_reward_critic", "Loss/Loss_cost_critic", "Loss/Loss_actor", "Misc/Reward_critic_norm",
+                     "Misc/Cost_critic_norm", "Misc/Entropy", "Misc/Ratio"))
+            for row in torch.stack(rows_logged).tolist():
+                logger.store(**dict(zip(keys, row)))
         return out
 
     def prep_training(self):
