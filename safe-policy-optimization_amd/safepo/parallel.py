@@ -8,6 +8,7 @@ per learning iteration the KL sum (1 double) so every rank stops at the same ite
 from __future__ import annotations
 
 import os
+import sys
 
 import numpy as np
 import torch
@@ -60,7 +61,19 @@ def init_from_env(backend: str | None = None) -> Comm:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world)
+        # gloo announces its connections on STDOUT from C++ ("[Gloo] Rank 0 is connected to ..."): a caller that prints a
+        # machine-readable line (bench.py) must not find that in its output -- the descriptor is pointed at stderr meanwhile
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world)
+            if dist.is_initialized():
+                dist.barrier()                                      # (the connections are made lazily: force them now)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     return Comm()
 
 
