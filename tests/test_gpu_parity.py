@@ -2223,6 +2223,9 @@ def test_ma_runner_collect_fused_launch_equals_per_network_collect(dev, tmp_path
     assert vg.data_ptr() == r._stack["value_preds"][:, 2].data_ptr() and ag[1].data_ptr() == r.buffer[1].actions[2].data_ptr()
     assert torch.equal(vg, ve) and torch.equal(cg, ce)                   # values do not depend on the random draws
     assert all(torch.isfinite(x).all() for x in ag + lg) and ag[0].shape == ae[0].shape
+    first = ag[0].clone()
+    r.collect(2)                                                         # a second replay of the same graph draws new noise
+    assert not torch.equal(r.buffer[0].actions[2], first)
     # insert() with rows that are already in place must leave them alone and still fill the rest
     b = r.buffer[0]
     s0 = b.step
