@@ -361,6 +361,18 @@ int spo_ma_backward(const float* theta, const spo_ma_net* net, const float* x, i
 int64_t spo_ma_jvp_scratch_floats(const spo_ma_net* net, int64_t rows);
 int spo_ma_jvp(const float* theta, const spo_ma_net* net, const float* tangent, int64_t rows, const float* ws, float* dout,
                float* scratch, void* stream);
+/* Insert of one environment step into the per-agent buffers (Runner.insert, mappolag.py:449-492) as ONE launch: the
+ * environment's [threads, agents, ...] observations / shared observations / rewards / costs are written to every agent's
+ * time-major buffer row, masks and active masks are formed from the done flags (dones: [threads, agents] bytes, non-zero =
+ * done): masks = 0 where all agents of the thread are done, active_masks = 0 for a done agent of a thread that is not.
+ * Each *_dst addresses the row of agent 0 at the step slot being filled ([threads, dim] contiguous); *_agent_stride is the
+ * distance in floats to the same row of the next agent.  costs / costs_dst may both be NULL (happo / mappo). */
+int spo_ma_insert_step(const float* obs, const float* share_obs, const float* rewards, const float* costs,
+                       const unsigned char* dones, float* obs_dst, int64_t obs_agent_stride, float* share_obs_dst,
+                       int64_t share_obs_agent_stride, float* rewards_dst, int64_t rewards_agent_stride, float* costs_dst,
+                       int64_t costs_agent_stride, float* masks_dst, int64_t masks_agent_stride, float* active_masks_dst,
+                       int64_t active_masks_agent_stride, int64_t num_threads, int32_t num_agents, int32_t obs_dim,
+                       int32_t share_obs_dim, void* stream);
 /* Collect step of the multi-agent runner (mappolag.py:411-447: policy.get_actions for every agent): ALL networks of ALL
  * agents in one launch, each 64-row tile taken through its whole network on chip (feature LayerNorm, blocks, head, and for
  * actors the Gaussian sample + per-dimension log-probabilities).  Results are bit-identical to spo_ma_forward (+

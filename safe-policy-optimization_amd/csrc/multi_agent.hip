@@ -77,3 +77,58 @@ extern "C" int spo_ma_gae(const float* rewards, const float* costs, const float*
   SPO_LAUNCH_CHECK("spo_ma_gae");
   return 0;
 }
+
+// ---------------------------------------------------------------- insert of one environment step into the stacked buffers
+// Runner.insert (reference mappolag.py:449-492): per step the runner copies the environment's [N, agents, ...] outputs into
+// every agent's time-major buffer and forms masks / active masks from the done flags -- a dozen tiny launches per step whose
+// cost is the host's launch time.  One kernel does the six fields: dst(field)[agent][n][:] = src(field)[n][agent][:], with
+//     masks[a][n]        = all_a' done[n][a'] ? 0 : 1                                     (mappolag.py:458-463)
+//     active_masks[a][n] = done[n][a] && !all-done ? 0 : 1                                (mappolag.py:465-467)
+// dst pointers address the (agent 0, step slot) row; agent_stride = floats between two agents' buffers of that field.
+namespace {
+struct InsArgs {
+  const float* obs; const float* share_obs; const float* rewards; const float* costs; const unsigned char* dones;
+  float* obs_d; float* share_d; float* rew_d; float* cost_d; float* mask_d; float* act_d;
+  int64_t obs_s, share_s, rew_s, cost_s, mask_s, act_s;      // agent strides (floats)
+  int64_t N; int A, Do, Ds;
+};
+__global__ __launch_bounds__(256) void ma_insert_kernel(InsArgs a) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);          // one wave per (n, agent) row
+  const int lane = threadIdx.x & 63;
+  if (row >= a.N * a.A) return;
+  const int64_t n = row / a.A;
+  const int ag = (int)(row - n * a.A);
+  for (int c = lane; c < a.Do; c += 64) a.obs_d[ag * a.obs_s + n * a.Do + c] = a.obs[row * a.Do + c];
+  for (int c = lane; c < a.Ds; c += 64) a.share_d[ag * a.share_s + n * a.Ds + c] = a.share_obs[row * a.Ds + c];
+  if (lane == 0) {
+    a.rew_d[ag * a.rew_s + n] = a.rewards[row];
+    if (a.costs) a.cost_d[ag * a.cost_s + n] = a.costs[row];
+    bool all_done = true;
+    for (int k = 0; k < a.A; ++k) all_done = all_done && a.dones[n * a.A + k] != 0;
+    const bool mine = a.dones[row] != 0;
+    a.mask_d[ag * a.mask_s + n] = all_done ? 0.f : 1.f;
+    a.act_d[ag * a.act_s + n] = (mine && !all_done) ? 0.f : 1.f;
+  }
+}
+}  // namespace
+
+extern "C" int spo_ma_insert_step(const float* obs, const float* share_obs, const float* rewards, const float* costs,
+                                  const unsigned char* dones, float* obs_dst, int64_t obs_agent_stride, float* share_obs_dst,
+                                  int64_t share_obs_agent_stride, float* rewards_dst, int64_t rewards_agent_stride, float* costs_dst,
+                                  int64_t costs_agent_stride, float* masks_dst, int64_t masks_agent_stride, float* active_masks_dst,
+                                  int64_t active_masks_agent_stride, int64_t num_threads, int32_t num_agents, int32_t obs_dim,
+                                  int32_t share_obs_dim, void* stream) {
+  SPO_REQUIRE(obs && share_obs && rewards && dones && obs_dst && share_obs_dst && rewards_dst && masks_dst && active_masks_dst,
+              "ma_insert_step: null pointer");
+  SPO_REQUIRE((costs == nullptr) == (costs_dst == nullptr), "ma_insert_step: costs and costs_dst go together");
+  SPO_REQUIRE(num_threads > 0 && num_agents > 0 && num_agents <= 64 && obs_dim > 0 && share_obs_dim > 0, "ma_insert_step: bad sizes");
+  InsArgs a{obs, share_obs, rewards, costs, dones, obs_dst, share_obs_dst, rewards_dst, costs_dst, masks_dst, active_masks_dst,
+            obs_agent_stride, share_obs_agent_stride, rewards_agent_stride, costs_agent_stride, masks_agent_stride,
+            active_masks_agent_stride, num_threads, num_agents, obs_dim, share_obs_dim};
+  const int64_t rows = num_threads * num_agents;
+  const int64_t blocks = (rows + 3) / 4;
+  if (blocks > 0x7fffffffLL) return spo::fail(-1, "ma_insert_step: %lld rows exceed the launch grid", (long long)rows);
+  hipLaunchKernelGGL(ma_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  SPO_LAUNCH_CHECK("spo_ma_insert_step");
+  return 0;
+}

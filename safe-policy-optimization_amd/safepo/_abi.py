@@ -115,6 +115,8 @@ PROTOTYPES = {
     "spo_ma_backward_scratch_floats": (c_int64, [POINTER(MaNet), c_int64]),
     "spo_ma_forward": (c_int, [P, POINTER(MaNet), P, c_int64, P, P, P]),
     "spo_ma_backward": (c_int, [P, POINTER(MaNet), P, c_int64, P, P, P, P, P]),
+    "spo_ma_insert_step": (c_int, [P, P, P, P, P, P, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_int64, P, c_int64, c_int64,
+                                  c_int32, c_int32, c_int32, P]),
     "spo_ma_collect_scratch_floats": (c_int64, [c_int32]),
     "spo_ma_collect_forward": (c_int, [c_int32, POINTER(MaCollectNet), c_int64, P, P]),
     "spo_ma_sample": (c_int, [P, P, P, c_float, c_float, c_int, P, P, c_int64, c_int, P]),

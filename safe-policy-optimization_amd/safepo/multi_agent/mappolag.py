@@ -637,17 +637,32 @@ class Runner:
     def insert(self, data, aver_episode_costs=0):
         (obs, share_obs, rewards, costs, dones, infos, values, actions, action_log_probs, rnn_states, rnn_states_critic,
          cost_preds, rnn_states_cost, done_episodes_costs_aver) = data
-        dones_env = torch.all(dones, axis=1)
-        keep = (~dones_env).float()
-        # mappolag.py:458-472, as mask arithmetic on the device instead of boolean-index assignment
-        # (boolean-index assignment would run nonzero(): a host synchronisation in every step)
-        masks = keep.view(-1, 1, 1).expand(-1, self.num_agents, 1)
-        active_masks = (dones_env.view(-1, 1) | ~dones).float().unsqueeze(-1)        # 0 for a done agent of a live env
+        def torch_masks():
+            # mappolag.py:458-472, as mask arithmetic on the device instead of boolean-index assignment
+            # (boolean-index assignment would run nonzero(): a host synchronisation in every step)
+            dones_env = torch.all(dones, axis=1)
+            keep = (~dones_env).float()
+            return (keep.view(-1, 1, 1).expand(-1, self.num_agents, 1),
+                    (dones_env.view(-1, 1) | ~dones).float().unsqueeze(-1))             # 0 for a done agent of a live env
         # (rnn states are zeros throughout: recurrent policies are not built, so there is nothing to reset at episode ends)
         if self._stack is not None:
             st, s0 = self._stack, self.buffer[0].step
             tr = lambda t: t.transpose(0, 1)                                  # [N, agents, ...] -> [agents, N, ...]
-            st["share_obs"][:, s0 + 1].copy_(tr(share_obs)); st["obs"][:, s0 + 1].copy_(tr(obs))
+            dense = lambda t, dt: torch.is_tensor(t) and t.is_cuda and t.dtype == dt and t.is_contiguous()
+            fused = (self.config.get("insert_fused", True) and dense(obs, torch.float32) and dense(share_obs, torch.float32)
+                     and dense(rewards, torch.float32) and (not self.use_cost or dense(costs, torch.float32))
+                     and dense(dones, torch.bool) and tuple(dones.shape) == (obs.shape[0], self.num_agents)
+                     and rewards.numel() == dones.numel())
+            if fused:
+                # observations, shared observations, rewards, costs and both masks of the step in ONE launch
+                dst = lambda f, slot: (_abi.ptr(st[f][0, slot]), st[f].stride(0))
+                args = (dst("obs", s0 + 1) + dst("share_obs", s0 + 1) + dst("rewards", s0)
+                        + (dst("costs", s0) if self.use_cost else (None, 0)) + dst("masks", s0 + 1) + dst("active_masks", s0 + 1))
+                _abi.check(_abi.load().spo_ma_insert_step(
+                    _abi.ptr(obs), _abi.ptr(share_obs), _abi.ptr(rewards), _abi.ptr(costs) if self.use_cost else None, _abi.ptr(dones),
+                    *args, obs.shape[0], self.num_agents, obs.shape[-1], share_obs.shape[-1], _abi.stream_ptr()), "spo_ma_insert_step")
+            else:
+                st["share_obs"][:, s0 + 1].copy_(tr(share_obs)); st["obs"][:, s0 + 1].copy_(tr(obs))
             def put(dst, src):                                                # src() only when the row is not already in place
                 s = src()
                 if not (s.data_ptr() == dst.data_ptr() and s.shape == dst.shape and s.stride() == dst.stride()):
@@ -658,13 +673,19 @@ class Runner:
                 st["actions"][:, s0].copy_(torch.stack(actions))
             if not in_place(action_log_probs, "action_log_probs"):
                 st["action_log_probs"][:, s0].copy_(torch.stack(action_log_probs))
-            put(st["value_preds"][:, s0], lambda: tr(values)); st["rewards"][:, s0].copy_(tr(rewards))
+            put(st["value_preds"][:, s0], lambda: tr(values))
             if self.use_cost:       # happo.py:403-414 / mappo.py:395-406 keep costs out of the buffer
-                put(st["cost_preds"][:, s0], lambda: tr(cost_preds)); st["costs"][:, s0].copy_(tr(costs))
-            st["masks"][:, s0 + 1].copy_(tr(masks)); st["active_masks"][:, s0 + 1].copy_(tr(active_masks))
+                put(st["cost_preds"][:, s0], lambda: tr(cost_preds))
+            if not fused:
+                st["rewards"][:, s0].copy_(tr(rewards))
+                if self.use_cost:
+                    st["costs"][:, s0].copy_(tr(costs))
+                masks, active_masks = torch_masks()
+                st["masks"][:, s0 + 1].copy_(tr(masks)); st["active_masks"][:, s0 + 1].copy_(tr(active_masks))
             for b in self.buffer:
                 b.step = (s0 + 1) % b.episode_length
             return
+        masks, active_masks = torch_masks()
         for a in range(self.num_agents):
             if not self.use_cost:
                 self.buffer[a].insert(share_obs[:, a], obs[:, a], rnn_states[:, a], rnn_states_critic[:, a], actions[a],

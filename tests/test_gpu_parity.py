@@ -2235,6 +2235,24 @@ def test_ma_runner_collect_fused_launch_equals_per_network_collect(dev, tmp_path
     r.insert((obs, share_obs, rewards, costs, dones, infos, vals, acts, lps, rnn, rnn_c, cps, rnn_k, costs.mean()))
     assert torch.equal(b.actions[s0], keep_act) and torch.equal(b.rewards[s0], rewards[:, 0])
     assert torch.equal(b.obs[s0 + 1], obs[:, 0]) and float(b.active_masks[s0 + 1].min()) == 1.0
+    # the one-launch insert (spo_ma_insert_step) against the torch copies, with done patterns of every kind: no agent, one
+    # agent, all agents of a thread done
+    dones = torch.zeros((4096, 3), dtype=torch.bool, device=dev)
+    dones[5, 1] = True; dones[9] = True; dones[4095, 2] = True; dones[4095, 0] = True
+    snaps = {}
+    for fused in (True, False):
+        r.config["insert_fused"] = fused
+        for bb in r.buffer:
+            bb.step = 1
+        for f in ("obs", "share_obs", "rewards", "costs", "masks", "active_masks"):
+            r._stack[f].fill_(-7.0)
+        r.insert((obs, share_obs, rewards, costs, dones, infos, vals, acts, lps, rnn, rnn_c, cps, rnn_k, costs.mean()))
+        snaps[fused] = {f: r._stack[f].clone() for f in ("obs", "share_obs", "rewards", "costs", "masks", "active_masks")}
+    for f, t in snaps[True].items():
+        assert torch.equal(t, snaps[False][f]), f
+    m, am = snaps[True]["masks"], snaps[True]["active_masks"]
+    assert float(m[:, 2, 9].sum()) == 0.0 and float(m[:, 2, 5].sum()) == 3.0 and float(am[1, 2, 5]) == 0.0 and float(am[:, 2, 9].sum()) == 3.0
+    assert float(am[0, 2, 4095]) == 0.0 and float(am[1, 2, 4095]) == 1.0 and float(m[0, 2, 4095]) == 1.0
 
 
 def test_ma_mappolag_runner_end_to_end_synthetic(dev, tmp_path):
