@@ -2255,6 +2255,45 @@ def test_ma_runner_collect_fused_launch_equals_per_network_collect(dev, tmp_path
     assert float(am[0, 2, 4095]) == 0.0 and float(am[1, 2, 4095]) == 1.0 and float(m[0, 2, 4095]) == 1.0
 
 
+@pytest.mark.parametrize("algo", ["happo", "mappo"])
+def test_ma_unconstrained_runners_through_the_one_launch_collect(dev, tmp_path, algo):
+    """happo / mappo Runners (no cost critic: 2 networks per agent, 5-tuple collect) at hidden 128 through the one-launch
+    collect, the per-step graphs writing into the buffer rows and the one-launch insert (no cost field): same seed ->
+    values / actions / log-probabilities equal to the per-network launches bit for bit; then two episodes end to end."""
+    import importlib
+    from safepo.common.env import SynthMultiAgentEnv
+    M = importlib.import_module(f"safepo.multi_agent.{algo}")
+    cfg = dict(M.default_cfg)
+    cfg.update(M.mamujoco_cfg)
+    cfg.update(device=str(dev), n_rollout_threads=2048, episode_length=4, hidden_size=128, log_dir=str(tmp_path / "run"), seed=0,
+               env_name="SynthMultiAgent-v0", use_eval=False, collect_graph=False)
+    env = SynthMultiAgentEnv(2048, num_agents=2, obs_dim=20, act_dim=3, trunc_len=4, device=dev)
+    r = M.Runner(env, None, cfg)
+    r.logger.verbose = False
+    r.warmup()
+    got = {}
+    for fused in (True, False):
+        r.config["collect_fused"] = fused
+        r._fused_unsupported = False
+        torch.manual_seed(5)
+        got[fused] = r.collect(0)
+    assert not r._fused_unsupported and len(got[True]) == 5
+    assert torch.equal(got[True][0], got[False][0])
+    for x, y in zip(got[True][1] + got[True][2], got[False][1] + got[False][2]):
+        assert torch.equal(x, y)
+    r.config.update(collect_fused=True, collect_graph=True)
+    for ep in range(2):
+        for step in range(4):
+            values, actions, lps, rnn, rnn_c = r.collect(step)
+            obs, share_obs, rewards, costs, dones, infos, _ = env.step(actions)
+            r.insert((obs, share_obs, rewards, costs, dones, infos, values, actions, lps, rnn, rnn_c, None, None, None))
+            assert torch.equal(r.buffer[1].obs[step + 1], obs[:, 1]) and torch.equal(r.buffer[0].rewards[step], rewards[:, 0])
+        r.compute()
+        r.train()
+    assert r._inplace_ok and sorted(r._step_graphs) == [0, 1, 2, 3]
+    assert all(torch.isfinite(t.policy.actor.theta).all() and torch.isfinite(t.policy.critic.theta).all() for t in r.trainer)
+
+
 def test_ma_mappolag_runner_end_to_end_synthetic(dev, tmp_path):
     """safepo.multi_agent.mappolag.train() on the synthetic 4-agent env: collect -> insert -> fused GAE/PopArt -> HAPPO
     sequential updates, logger rows and per-agent checkpoints in the reference's formats; the team reward improves."""
