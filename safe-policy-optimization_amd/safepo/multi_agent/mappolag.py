@@ -605,6 +605,11 @@ class Runner:
         the destination.  The tensors handed back are views of the buffer (valid like the reference's until the step is
         overwritten one episode later).  None = not available (geometry outside the fused kernel, capture failure)."""
         graphs = self.__dict__.setdefault("_step_graphs", {})
+        # the graphs hold raw pointers: parameter vectors or buffers that were re-created since the capture invalidate them
+        key = tuple(n.theta.data_ptr() for t in self.trainer for n in t.policy.networks()) + (self._stack["obs"].data_ptr(),)
+        if getattr(self, "_step_graph_key", key) != key:
+            graphs.clear()
+        self._step_graph_key = key
         ent = graphs.get(step)
         if ent is None:
             st = self._stack

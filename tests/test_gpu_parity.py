@@ -2226,6 +2226,15 @@ def test_ma_runner_collect_fused_launch_equals_per_network_collect(dev, tmp_path
     first = ag[0].clone()
     r.collect(2)                                                         # a second replay of the same graph draws new noise
     assert not torch.equal(r.buffer[0].actions[2], first)
+    # a parameter vector that moved (module.to(), a re-flattened network) invalidates the captured pointers: recaptured
+    act0 = r.trainer[0].policy.actor
+    act0.float()                                                         # nn.Module._apply -> _flatten(): new theta storage
+    with torch.no_grad():
+        act0.theta.mul_(0.0)                                             # mean 0 for every row from now on
+    r.collect(2)
+    assert sorted(r._step_graphs) == [2]
+    assert float((r.buffer[0].actions[2] - r.buffer[0].actions[2].mean()).abs().max()) > 0 and \
+        abs(float(r.buffer[0].actions[2].mean())) < 0.1
     # insert() with rows that are already in place must leave them alone and still fill the rest
     b = r.buffer[0]
     s0 = b.step
