@@ -171,21 +171,28 @@ class MAPPO_L_Trainer:
                                              1, _abi.ptr(self._sums2), rows * self.comm.world_size, _abi.ptr(out), st),
                    "spo_ma_popart_forward")
 
-    def _value_step(self, net, opt, inputs, value_preds, returns, active=None, active_sum=None):
-        """cal_value_loss (mappolag.py:126-138; happo.py:106-122 with `active`) + backward + clip + Adam for one critic."""
-        c, lib = self.config, _abi.load()
-        values, saved = net.net_forward(inputs, keep=True)
-        rows = values.shape[0]
+    def _normed_returns(self, returns):
+        """value_normalizer(return_batch) twice, as cal_value_loss does (two statistics updates, in this order)."""
         returns = returns.reshape(-1).contiguous()
         n1, n2 = torch.empty_like(returns), torch.empty_like(returns)
         self._normalize_returns(returns, n1)                    # value_normalizer(return_batch) for error_clipped ...
         self._normalize_returns(returns, n2)                    # ... and again for error_original: two statistics updates
+        return n1, n2
+
+    def _value_step(self, net, opt, inputs, value_preds, returns, active=None, active_sum=None, normed=None, partial=None):
+        """cal_value_loss (mappolag.py:126-138; happo.py:106-122 with `active`) + backward + clip + Adam for one critic.
+        normed: the two PopArt-normalised copies of `returns` when the caller formed them already (side-stream form)."""
+        c, lib = self.config, _abi.load()
+        values, saved = net.net_forward(inputs, keep=True)
+        rows = values.shape[0]
+        n1, n2 = normed if normed is not None else self._normed_returns(returns)
+        partial = self._partial if partial is None else partial
         dvalues, loss = torch.empty_like(values), torch.empty(1, **self.tpdv)
         denom = float(active_sum) if active is not None else float(rows * self.comm.world_size)
         _abi.check(lib.spo_ma_value_loss(_abi.ptr(values), _abi.ptr(value_preds.reshape(-1).contiguous()), _abi.ptr(n1), _abi.ptr(n2),
                                          _abi.ptr(active) if active is not None else None, denom,
                                          float(c["clip_param"]), float(c["huber_delta"]), float(c["value_loss_coef"]), rows,
-                                         rows * self.comm.world_size, _abi.ptr(dvalues), _abi.ptr(loss), _abi.ptr(self._partial),
+                                         rows * self.comm.world_size, _abi.ptr(dvalues), _abi.ptr(loss), _abi.ptr(partial),
                                          _abi.stream_ptr()), "spo_ma_value_loss")
         self.comm.all_reduce_sum_(loss)
         net.net_backward(saved, dvalues, opt.grad)
@@ -203,6 +210,26 @@ class MAPPO_L_Trainer:
         c, lib, pol = self.config, _abi.load(), self.policy
         f = lambda t: _abi.require_gpu_tensor(check(t).to(**self.tpdv).contiguous(), "sample", torch.float32)
         obs_batch, share_obs_batch, actions_batch = f(obs_batch), f(share_obs_batch), f(actions_batch)
+        side = None
+        if self.use_cost and c.get("train_streams", True) and self.comm.world_size == 1:
+            # The three networks of an update are independent (mappolag.py:140-199 runs them one after the other): the two
+            # critics go to two side streams while the actor runs here, so the small reduction kernels of one network hide
+            # behind the block kernels of another.  The four PopArt statistics updates keep their order: formed first, here.
+            main = torch.cuda.current_stream()
+            if getattr(self, "_side", None) is None:
+                self._side = (torch.cuda.Stream(), torch.cuda.Stream())
+                self._side_partial = (torch.zeros_like(self._partial), torch.zeros_like(self._partial))
+            vp, rb, cpb, crb = f(value_preds_batch), f(return_batch), f(cost_preds_batch), f(cost_returns_batch)
+            normed = (self._normed_returns(rb), self._normed_returns(crb))
+            side = []
+            for k, (net, opt, preds) in enumerate(((pol.critic, pol.critic_optimizer, vp), (pol.cost_critic, pol.cost_optimizer, cpb))):
+                st = self._side[k]
+                st.wait_stream(main)
+                for t in (share_obs_batch, preds) + normed[k]:
+                    t.record_stream(st)
+                with torch.cuda.stream(st):
+                    side.append(self._value_step(net, opt, share_obs_batch, preds, None, normed=normed[k],
+                                                 partial=self._side_partial[k]))
         old_lp, adv, active = f(old_action_log_probs_batch), f(adv_targ).reshape(-1), f(active_masks_batch).reshape(-1)
         if self._zeros is None or self._zeros.numel() != adv.numel():
             self._zeros, self._ones = torch.zeros_like(adv), torch.ones_like(adv)
@@ -253,8 +280,13 @@ class MAPPO_L_Trainer:
         _abi.check(lib.spo_ma_lamda_update(_abi.ptr(self._lamda), _abi.ptr(self._scalars), aver, float(c["cost_limit"]), float(c["gamma"]),
                                            float(c["lagrangian_coef_rate"]), _abi.stream_ptr()), "spo_ma_lamda_update")
         # ---- critics (mappolag.py:183-197); both share the one PopArt normaliser
-        value_loss, critic_grad_norm = self._value_step(pol.critic, pol.critic_optimizer, share_obs_batch, f(value_preds_batch), f(return_batch))
-        cost_loss, cost_grad_norm = self._value_step(pol.cost_critic, pol.cost_optimizer, share_obs_batch, f(cost_preds_batch), f(cost_returns_batch))
+        if side is not None:
+            for st in self._side:
+                torch.cuda.current_stream().wait_stream(st)
+            (value_loss, critic_grad_norm), (cost_loss, cost_grad_norm) = side
+        else:
+            value_loss, critic_grad_norm = self._value_step(pol.critic, pol.critic_optimizer, share_obs_batch, f(value_preds_batch), f(return_batch))
+            cost_loss, cost_grad_norm = self._value_step(pol.cost_critic, pol.cost_optimizer, share_obs_batch, f(cost_preds_batch), f(cost_returns_batch))
         self._sync_normalizer()
         return value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_mean, cost_loss, cost_grad_norm
 

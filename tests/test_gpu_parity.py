@@ -2303,6 +2303,59 @@ def test_ma_unconstrained_runners_through_the_one_launch_collect(dev, tmp_path, 
     assert all(torch.isfinite(t.policy.actor.theta).all() and torch.isfinite(t.policy.critic.theta).all() for t in r.trainer)
 
 
+def test_ma_side_stream_critics_equal_the_sequential_update(dev, tmp_path):
+    """MAPPO_L_Trainer.ppo_update runs the two critics on side streams while the actor runs on the caller's (cfg
+    train_streams, default on; the four PopArt statistics updates keep their order).  One agent's train() over a collected
+    episode with and without the side streams, from the same state: every parameter, Adam moment, the multiplier and the
+    PopArt state must be identical bit for bit."""
+    from safepo.multi_agent import mappolag
+    from safepo.common.env import SynthMultiAgentEnv
+    cfg = _ma_cfg(dev, **mappolag.mamujoco_cfg)
+    cfg.update(n_rollout_threads=4096, episode_length=8, hidden_size=128, log_dir=str(tmp_path / "run"), seed=0,
+               env_name="SynthMultiAgent-v0", use_eval=False)
+    env = SynthMultiAgentEnv(4096, num_agents=2, obs_dim=48, act_dim=6, trunc_len=8, device=dev)
+    r = mappolag.Runner(env, None, cfg)
+    r.logger.verbose = False
+    r.warmup()
+    for step in range(8):
+        values, actions, lps, rnn, rnn_c, cps, rnn_k = r.collect(step)
+        obs, share_obs, rewards, costs, dones, infos, _ = env.step(actions)
+        r.insert((obs, share_obs, rewards, costs, dones, infos, values, actions, lps, rnn, rnn_c, cps, rnn_k, costs.mean()))
+    r.compute()
+    tr, b = r.trainer[0], r.buffer[0]
+    b.update_factor(torch.ones(8, 4096, 1, device=dev))
+    pol = tr.policy
+    opts = (pol.actor_optimizer, pol.critic_optimizer, pol.cost_optimizer)
+
+    def snapshot():
+        return ([n.theta.clone() for n in pol.networks()], [(o.m.clone(), o.v.clone(), o.t) for o in opts],
+                tr._popart_state.clone(), tr._lamda.clone())
+
+    def restore(snap):
+        for n, th in zip(pol.networks(), snap[0]):
+            n.theta.copy_(th)
+        for o, (m, v, t) in zip(opts, snap[1]):
+            o.m.copy_(m); o.v.copy_(v); o.t = t
+        tr._popart_state.copy_(snap[2]); tr._lamda.copy_(snap[3])
+        tr._sync_normalizer()
+    start = snapshot()
+    perms = [torch.randperm(8 * 4096, device=dev) for _ in range(cfg["learning_iters"])]
+    outs = {}
+    for streams in (True, False):
+        restore(start)
+        tr.config["train_streams"] = streams
+        tr.train(b, logger=None, perm_fn=lambda it: perms[it])
+        torch.cuda.synchronize()
+        outs[streams] = snapshot()
+    assert getattr(tr, "_side", None) is not None
+    for x, y in zip(outs[True][0], outs[False][0]):
+        assert torch.equal(x, y)
+    for (m1, v1, t1), (m2, v2, t2) in zip(outs[True][1], outs[False][1]):
+        assert torch.equal(m1, m2) and torch.equal(v1, v2) and t1 == t2
+    assert torch.equal(outs[True][2], outs[False][2]) and torch.equal(outs[True][3], outs[False][3])
+    assert not torch.equal(outs[True][0][0], start[0][0])
+
+
 def test_ma_mappolag_runner_end_to_end_synthetic(dev, tmp_path):
     """safepo.multi_agent.mappolag.train() on the synthetic 4-agent env: collect -> insert -> fused GAE/PopArt -> HAPPO
     sequential updates, logger rows and per-agent checkpoints in the reference's formats; the team reward improves."""
