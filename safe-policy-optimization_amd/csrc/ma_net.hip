@@ -1183,31 +1183,40 @@ __global__ __launch_bounds__(64 * FBW_WAVES, 1) void fused_dx_lnbwd128w_kernel(c
   const int c4 = (lane & 31) * 4, rsub = lane >> 5;
   const int64_t ntiles = (B + 15) / 16;
   const int64_t tstride = (int64_t)gridDim.x * FBW_WAVES;
+  // dz rows: prefetched ONE TILE ahead (issued before the products of the current tile); a rows and row statistics of the
+  // current tile: issued at the same point, they arrive behind its 256 MFMAs
   f4w pd[8], pa[8];
   float pst = 0.f;                                             // lane l < 32: stats word l of the tile (16 rows x {mean, rstd})
-  auto fetch_tile = [&](int64_t t) {
+  auto fetch_dz = [&](int64_t t) {
     const int64_t rb = t * 16;
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps) {
       const int64_t r = rb + 2 * ps + rsub;
-      pd[ps] = pa[ps] = f4w{0.f, 0.f, 0.f, 0.f};
-      if (t < ntiles && r < B) {
-        pd[ps] = *reinterpret_cast<const f4w*>(dz + r * FB_N + c4);
-        pa[ps] = *reinterpret_cast<const f4w*>(a_prev + r * FB_N + c4);
-      }
+      pd[ps] = f4w{0.f, 0.f, 0.f, 0.f};
+      if (t < ntiles && r < B) pd[ps] = *reinterpret_cast<const f4w*>(dz + r * FB_N + c4);
+    }
+  };
+  auto fetch_a = [&](int64_t t) {
+    const int64_t rb = t * 16;
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+      const int64_t r = rb + 2 * ps + rsub;
+      pa[ps] = f4w{0.f, 0.f, 0.f, 0.f};
+      if (t < ntiles && r < B) pa[ps] = *reinterpret_cast<const f4w*>(a_prev + r * FB_N + c4);
     }
     pst = 0.f;
     if (lane < 32 && t < ntiles && rb + (lane >> 1) < B) pst = stats_prev[2 * rb + lane];
   };
   int64_t tile = (int64_t)blockIdx.x * FBW_WAVES + wave;
-  fetch_tile(tile);
+  fetch_dz(tile);
   __syncthreads();                                             // W^T is staged (the only barrier before the final reduction)
   for (; tile < ntiles; tile += tstride) {
     const int64_t r0 = tile * 16;
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps) *reinterpret_cast<f4w*>(Tw + (2 * ps + rsub) * LD + c4) = pd[ps];
-    if (lane < 32) Sw[lane] = pst;
     __builtin_amdgcn_s_waitcnt(0xc07f);
+    fetch_a(tile);
+    fetch_dz(tile + tstride);
     f4w acc[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = f4w{0.f, 0.f, 0.f, 0.f};
@@ -1227,8 +1236,8 @@ __global__ __launch_bounds__(64 * FBW_WAVES, 1) void fused_dx_lnbwd128w_kernel(c
     // the dz tile has been read: the a rows take its place (LDS executes a wave's accesses in order)
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps) *reinterpret_cast<f4w*>(Tw + (2 * ps + rsub) * LD + c4) = pa[ps];
+    if (lane < 32) Sw[lane] = pst;
     __builtin_amdgcn_s_waitcnt(0xc07f);
-    fetch_tile(tile + tstride);                                // in flight during the epilogue and the next tile's staging
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int rl = 4 * kk + e;
