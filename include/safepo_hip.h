@@ -35,8 +35,9 @@ extern "C" {
 
 #define SPO_ABI_VERSION 1
 #define SPO_HIDDEN 64          /* hidden width the MLP kernels are specialised for          */
-#define SPO_MAX_ACT 16         /* act_dim <= 16 (one MFMA output tile)                       */
-#define SPO_MAX_OBS 128        /* obs_dim <= 128                                             */
+#define SPO_MAX_ACT 16         /* act_dim <= 16 (one MFMA output tile; LDS-resident kernels) */
+#define SPO_MAX_OBS 128        /* obs_dim <= 128 (LDS-resident kernels; CPO full-batch kernels: 64) */
+#define SPO_WIDE_MAX_ACT 64    /* act_dim limit of the wide-network path (any obs_dim / hidden_sizes) */
 #define SPO_GAE_PARTIAL_STRIDE 16 /* doubles per block written by spo_gae_fused: 4 waves x 4 */
 
 int spo_abi_version(void);
@@ -165,6 +166,13 @@ int spo_ppo_lag_update_iter(float* theta, float* adam_m, float* adam_v, int64_t 
                             const float* target_r, const float* target_c, const float* adv,
                             const int32_t* perm, int64_t M, const spo_ppo_cfg* cfg_host,
                             float* losses_out, void* sync_ws, void* stream);
+
+/* The main + helper form of the persistent update keeps one ~790 KB scratch block (clip backups, norm granules) per
+ * (device, stream handle) pair, allocated at that pair's first launch (never under stream capture: launch once outside the
+ * capture first) and kept; at most 256 pairs per process.  A process that keeps creating and destroying streams releases a
+ * stream's block before destroying it: returns the number of blocks freed (>= 0) for (current device, stream), or for every
+ * stream of the current device when all != 0.  hipFree synchronises the device -- not for the hot path. */
+int spo_update_scratch_release(void* stream_or_null, int all);
 
 /* Debug self-test of the cross-lane helpers (DPP row sums, gfx950 permlane swaps): in[64] -> out[192]. */
 int spo_debug_crosslane_selftest(const float* in64, float* out192, void* stream);
@@ -320,7 +328,7 @@ int spo_synth_env_step(float* next_obs, float* final_obs, float* reward, float* 
  * [Linear -> ELU -> LayerNorm], then a Linear head (actor: action mean, with a state-independent
  * std = sigmoid(log_std / std_x_coef) * std_y_coef; critics: one value).  One flat fp32 parameter vector per network in the
  * reference's state_dict order (spo_ma_param_offset: which = 0 feature_norm.weight, 1 feature_norm.bias, 2 W_k, 3 b_k,
- * 4 ln_k.weight, 5 ln_k.bias, 6 log_std, 7 head W, 8 head b).  GEMMs run on rocBLAS (dlopen'ed on first use).
+ * 4 ln_k.weight, 5 ln_k.bias, 6 log_std, 7 head W, 8 head b).  GEMMs run on the in-tree fp32 MFMA kernels (rocBLAS is only the comparator of spo_debug_ma_gemm).
  * spo_ma_forward keeps the activations of `rows` rows in ws (spo_ma_workspace_floats) for spo_ma_backward, which turns
  * d(loss)/d(head output) into the flat gradient (log_std's entry is owned by spo_ma_actor_loss).
  * Trainer pieces (safepo/multi_agent/mappolag.py:126-199): spo_ma_actor_loss = clipped surrogate on
@@ -430,7 +438,7 @@ int spo_debug_ma_gemm(int use_rocblas, int mode, const float* x, const float* w,
  * rows * dims[n_layers] floats of ws.  spo_mlp_backward takes d(loss)/d(output) and writes the network's flat gradient;
  * scratch: float[spo_mlp_backward_scratch_floats].
  * spo_wide_ppo_loss (ppo_lag.py:306-323): MSE of both critics (WITHOUT their L2 terms), the clipped surrogate, their output
- * gradients and d(loss)/d(log_std); partial_ws: double[>= 256 * (3 + SPO_MAX_ACT)].
+ * gradients and d(loss)/d(log_std); partial_ws: double[>= 256 * (3 + SPO_WIDE_MAX_ACT) + 512].
  * spo_wide_clip_adam (ppo_lag.py:310-329): adds the critics' L2 gradient 2 * l2_coef * p (cfg->use_critic_norm) and the value
  * coefficient (cfg->use_value_coefficient) to `grad` in place, adds l2_coef * sum p^2 to losses3_inout[0..1], clips the joint
  * norm over all n_params to cfg->max_grad_norm and takes one Adam step with cfg->lr_critic for [0, actor_begin) and
@@ -462,6 +470,53 @@ int spo_wide_ppo_loss(const float* v_r, const float* v_c, const float* mean, con
 int spo_wide_clip_adam(float* theta, float* grad, float* adam_m, float* adam_v, int64_t n_params, int64_t reward_critic_end,
                        int64_t cost_critic_end, int64_t actor_begin, const spo_ppo_cfg* cfg, int64_t adam_step_host,
                        float* losses3_inout, float* scalars4_out, double* partial_ws, int partial_capacity, void* stream);
+
+
+/* ---- round 4: the wide path as the fallback for any (obs_dim, act_dim, hidden_sizes) and every single-agent script.  The
+ * reference's ActorVCritic takes any dims (safepo/common/model.py:131) and its default sweep (safepo/single_agent/benchmark.py:5-44)
+ * pairs cpo / pcpo / rcpo / trpo_lag / focops / cup / ppo_lag / cppo_pid with tasks of 72-88 observations (Car, Doggo, Racecar)
+ * and with HumanoidVelocity (376 observations, 17 actions).  act_dim <= SPO_WIDE_MAX_ACT.
+ * spo_wide_actor_loss -- actor loss of rows [0, rows) of a (possibly chunked) batch of rows_total rows and d(loss)/d(mean):
+ *   mode 0  clipped PPO surrogate -mean(min(ratio*adv, clamp(ratio, 1-p0, 1+p0)*adv))          (ppo_lag.py:316-319)
+ *   mode 1  p0 * mean(ratio*adv), p0 = sign: the CPO / TRPO surrogates                          (cpo.py:356-381)
+ *   mode 2  KL-penalty loss of FOCOPS / CUP's second stage, p0 = kl_bound, p1 = pg_coef (see spo_update_iter_ex); needs
+ *           old_mean[rows, act_dim], old_std[act_dim]; minibatch only (rows == rows_total, accumulate == 0).
+ *   sums_inout double[2 + act_dim] = {sum of the loss terms, sum of the KL indicators, d(loss)/d(log_std)[act_dim]}, added to
+ *   (accumulate != 0) or overwritten; loss_out / d_log_std_out (optional, float) receive the finished loss and d(log_std).
+ *   partial_ws: double[>= 256 * (2 + SPO_WIDE_MAX_ACT)].
+ * spo_wide_critic_loss -- MSE of both critics and their output gradients (critic fit, cpo.py:541-556); losses2[0..1];
+ *   partial_ws: double[>= 512].
+ * spo_mlp_jvp -- forward-mode tangent dout[rows, out] = d(out)/d(theta) . tangent (tangent laid out like the network's theta)
+ *   at the activations spo_mlp_forward left in ws; with spo_wide_fvp_cotangent (d_mean = (J t) / sigma^2 / (rows_total * act_dim))
+ *   and spo_mlp_backward this is one chunk of the Fisher-vector product J^T diag(1/sigma^2) J t / (M * A) of cpo.py:132-157
+ *   (the reference differentiates the KL twice).  scratch: float[spo_mlp_jvp_scratch_floats].
+ * spo_wide_linesearch_sums -- sums3 = {sum ratio*adv_a, sum ratio*adv_b, sum_{rows,dims} KL(old || new)} (cpo.py:473-491) of
+ *   one row chunk, added to (accumulate != 0) or stored into sums3_inout.  partial_ws: double[3 * blocks], blocks <= 512.
+ * spo_wide_clip_adam_ex -- spo_wide_clip_adam with (i) the joint norm taken over [norm_begin, n_params) (0: all parameters;
+ *   actor_begin - act_dim: CUP's actor-only clip, cup.py:385), (ii) Adam applied to [adam_begin, adam_end) only, the
+ *   critics' optimisers at adam_step_critics_host and the actor's at adam_step_actor_host, (iii) scale_rest != 0: gradients
+ *   outside the Adam range multiplied by the clip coefficient in place -- what clip_grad_norm_ over ALL policy parameters does to
+ *   the actor's stale gradient during the critic fit (cpo.py:557).  The critics' L2 term / value coefficient are applied when
+ *   norm_begin == 0 (as in spo_wide_clip_adam). */
+int spo_wide_actor_loss(int mode, const float* mean, const float* log_std, const float* act, const float* logp_old,
+                        const float* adv, const float* old_mean, const float* old_std, int64_t rows, int64_t rows_total,
+                        int act_dim, float p0, float p1, float* d_mean, double* sums_inout, int accumulate, float* loss_out,
+                        float* d_log_std_out, double* partial_ws, int partial_capacity, void* stream);
+int spo_wide_critic_loss(const float* v_r, const float* v_c, const float* tgt_r, const float* tgt_c, int64_t rows, float* d_vr,
+                         float* d_vc, float* losses2, double* partial_ws, int partial_capacity, void* stream);
+int64_t spo_mlp_jvp_scratch_floats(const spo_mlp_net* net, int64_t rows);
+int spo_mlp_jvp(const float* theta, const spo_mlp_net* net, const float* tangent, const float* x, int64_t rows, const float* ws,
+                float* dout, float* scratch, void* stream);
+int spo_wide_fvp_cotangent(const float* jv, const float* log_std, int64_t rows, int64_t rows_total, int act_dim, float* d_mean,
+                           void* stream);
+int spo_wide_linesearch_sums(const float* mean_new, const float* log_std_new, const float* act, const float* logp_old,
+                             const float* adv_a, const float* adv_b, const float* mean_old, const float* log_std_old, int64_t rows,
+                             int act_dim, double* partial_ws, int partial_capacity, double* sums3_inout, int accumulate,
+                             void* stream);
+int spo_wide_clip_adam_ex(float* theta, float* grad, float* adam_m, float* adam_v, int64_t n_params, int64_t reward_critic_end,
+                          int64_t cost_critic_end, int64_t actor_begin, const spo_ppo_cfg* cfg, int64_t adam_step_critics_host,
+                          int64_t adam_step_actor_host, int64_t adam_begin, int64_t adam_end, int64_t norm_begin, int scale_rest,
+                          float* losses3_inout, float* scalars4_out, double* partial_ws, int partial_capacity, void* stream);
 
 #ifdef __cplusplus
 }

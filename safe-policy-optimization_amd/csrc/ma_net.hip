@@ -2767,7 +2767,7 @@ __global__ void gauss_kl_finish_kernel(const double* __restrict__ partial, int n
 
 extern "C" int spo_gauss_sample(const float* mean, const float* log_std, const float* eps, float* act_out, float* logp_out,
                                 int64_t rows, int act_dim, void* stream) {
-  SPO_REQUIRE(mean && log_std && act_out && logp_out && rows > 0 && act_dim >= 1 && act_dim <= SPO_MAX_ACT, "gauss_sample: bad args");
+  SPO_REQUIRE(mean && log_std && act_out && logp_out && rows > 0 && act_dim >= 1 && act_dim <= SPO_WIDE_MAX_ACT, "gauss_sample: bad args");
   hipLaunchKernelGGL(gauss_sample_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mean, log_std, eps,
                      act_out, logp_out, rows, act_dim);
   SPO_LAUNCH_CHECK("spo_gauss_sample");
@@ -2777,7 +2777,7 @@ extern "C" int spo_gauss_kl_sum(const float* mean_old, const float* log_std_old,
                                 int64_t rows, int act_dim, double* partial_ws, int partial_capacity, double* sum_inout, int accumulate,
                                 void* stream) {
   SPO_REQUIRE(mean_old && log_std_old && mean_new && log_std_new && partial_ws && sum_inout && rows > 0 && act_dim >= 1 &&
-                  act_dim <= SPO_MAX_ACT && partial_capacity >= 1, "gauss_kl_sum: bad args");
+                  act_dim <= SPO_WIDE_MAX_ACT && partial_capacity >= 1, "gauss_kl_sum: bad args");
   int64_t blocks = (rows + 255) / 256;
   if (blocks > 512) blocks = 512;
   if (blocks > partial_capacity) blocks = partial_capacity;
@@ -2875,13 +2875,29 @@ extern "C" int spo_mlp_backward(const float* theta, const spo_mlp_net* net, cons
   return 0;
 }
 
+extern "C" int spo_wide_critic_loss(const float* v_r, const float* v_c, const float* tgt_r, const float* tgt_c, int64_t rows,
+                                    float* d_vr, float* d_vc, float* losses2, double* partial_ws, int partial_capacity, void* stream);
+extern "C" int spo_wide_actor_loss(int mode, const float* mean, const float* log_std, const float* act, const float* logp_old,
+                                   const float* adv, const float* old_mean, const float* old_std, int64_t rows, int64_t rows_total,
+                                   int act_dim, float p0, float p1, float* d_mean, double* sums_inout, int accumulate,
+                                   float* loss_out, float* d_log_std_out, double* partial_ws, int partial_capacity, void* stream);
 extern "C" int spo_wide_ppo_loss(const float* v_r, const float* v_c, const float* mean, const float* log_std, const float* act,
                                  const float* logp_old, const float* adv, const float* tgt_r, const float* tgt_c, int64_t rows,
                                  int act_dim, float clip, float* d_vr, float* d_vc, float* d_mean, float* d_log_std,
                                  float* losses3, double* partial_ws, int partial_capacity, void* stream) {
   SPO_REQUIRE(v_r && v_c && mean && log_std && act && logp_old && adv && tgt_r && tgt_c && d_vr && d_vc && d_mean && d_log_std &&
                   losses3 && partial_ws && rows > 0, "wide_ppo_loss: bad args");
-  SPO_REQUIRE(act_dim >= 1 && act_dim <= SPO_MAX_ACT, "wide_ppo_loss: act_dim %d outside [1,%d]", act_dim, SPO_MAX_ACT);
+  SPO_REQUIRE(act_dim >= 1 && act_dim <= SPO_WIDE_MAX_ACT, "wide_ppo_loss: act_dim %d outside [1,%d]", act_dim, SPO_WIDE_MAX_ACT);
+  if (act_dim > SPO_MAX_ACT) {
+    // wider action vectors (HumanoidVelocity: 17): the lanes-per-row kernels of the round-4 section below;
+    // partial_ws = [256 actor rows | 512 critic partials | sums]
+    constexpr int64_t need = 256 * (2 + SPO_WIDE_MAX_ACT) + 512 + (2 + SPO_WIDE_MAX_ACT);
+    SPO_REQUIRE((int64_t)partial_capacity >= need, "wide_ppo_loss: partial workspace too small (%d < %lld)", partial_capacity, (long long)need);
+    double* crit = partial_ws + 256 * (2 + SPO_WIDE_MAX_ACT);
+    if (int rc = spo_wide_critic_loss(v_r, v_c, tgt_r, tgt_c, rows, d_vr, d_vc, losses3, crit, 512, stream)) return rc;
+    return spo_wide_actor_loss(0, mean, log_std, act, logp_old, adv, nullptr, nullptr, rows, rows, act_dim, clip, 0.f, d_mean, crit + 512, 0,
+                               losses3 + 2, d_log_std, partial_ws, 256 * (2 + SPO_WIDE_MAX_ACT), stream);
+  }
   int64_t blocks = (rows + 255) / 256;
   if (blocks > 256) blocks = 256;
   SPO_REQUIRE(partial_capacity >= blocks * WL_NS, "wide_ppo_loss: partial workspace too small (%d < %lld)", partial_capacity, (long long)(blocks * WL_NS));
@@ -2912,5 +2928,404 @@ extern "C" int spo_wide_clip_adam(float* theta, float* grad, float* adam_m, floa
   hipLaunchKernelGGL(wide_coef_kernel, dim3(1), dim3(64), 0, st, a, (int)blocks);
   hipLaunchKernelGGL(wide_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
   SPO_LAUNCH_CHECK("spo_wide_clip_adam");
+  return 0;
+}
+
+// ====================================================================================================================
+// Round 4 -- the wide path as the fallback for ANY (obs_dim, act_dim, hidden_sizes) and for every single-agent script
+// (reference model.py:131 takes any dims; benchmark.py:5-22 pairs cpo / pcpo / rcpo / trpo_lag / focops / cup with Car,
+// Doggo, Racecar (obs 72-88) and HumanoidVelocity (obs 376, act 17)).  The LDS-resident kernels keep their envelope
+// (obs <= 128, act <= 16; CPO full-batch kernels obs <= 64); everything outside it runs here:
+//   spo_wide_actor_loss       clipped surrogate | plain surrogate sign*mean(ratio*adv) | KL-penalty (FOCOPS, CUP stage 2)
+//   spo_wide_critic_loss      MSE of both critics + output gradients (critic fit, cpo.py:541-571)
+//   spo_mlp_jvp               forward-mode tangent d(out)/d(theta).t of the tanh MLP (Fisher-vector product, cpo.py:132-157)
+//   spo_wide_fvp_cotangent    (J t) / sigma^2 / (rows_total * act_dim)
+//   spo_wide_linesearch_sums  sum ratio*adv_a, sum ratio*adv_b, sum KL(old || new)   (cpo.py:473-491)
+//   spo_wide_clip_adam_ex     joint clip over all parameters, Adam on a sub-range with per-optimiser step counts, stale
+//                             gradients outside the range rescaled in place (what clip_grad_norm_ does to actor.grad in the
+//                             critic fit, cpo.py:557; CUP's actor-only second stage, cup.py:385)
+// Actor-side loss kernels use G = pow2ceil(act_dim) lanes per row (act_dim <= SPO_WIDE_MAX_ACT = 64): coalesced loads along the
+// action dimension, segmented xor-shuffle sums, no per-thread arrays.
+namespace {
+using namespace spo;
+
+constexpr int WA_NS = 2 + SPO_WIDE_MAX_ACT;      // partial row of an actor-loss block: loss sum, aux sum, d(log_std)[A]
+enum { WA_CLIP = 0, WA_SURR = 1, WA_KLPEN = 2, WA_KLPEN_COUNT = 3 };
+
+__device__ __forceinline__ float group_sum_f(float v, int G) {
+  for (int o = 1; o < G; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sum of a double over the lanes of the wave that hold the same action index (lanes k, k + G, k + 2G, ...)
+__device__ __forceinline__ double stride_sum_d(double v, int G) {
+  for (int o = G; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+inline int pow2ceil(int a) { int g = 1; while (g < a) g <<= 1; return g; }
+
+struct WaArgs {
+  const float* mean; const float* log_std; const float* act; const float* logp_old; const float* adv;
+  const float* old_mean; const float* old_std;
+  int64_t B; int A, G;
+  float p0, p1;                 // WA_CLIP: clip, -   WA_SURR: sign, -   WA_KLPEN: kl_bound, pg_coef
+  float inv_n;                  // 1 / rows the mean is taken over
+  const double* frac_sum;       // WA_KLPEN: device sum of the indicators (from the WA_KLPEN_COUNT pass), mean = frac_sum * inv_n
+  float* d_mean; double* partial;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void wide_actor_loss_kernel(WaArgs a) {
+  __shared__ double red[4][WA_NS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int A = a.A, G = a.G, k = lane & (G - 1), sub = lane / G, rpw = 64 / G;
+  const bool on = k < A;
+  const float ls = on ? a.log_std[k] : 0.f;
+  const float sd = __expf(ls), ivar = 1.f / (sd * sd);
+  float iso = 1.f, vrat = 1.f, lvrat = 0.f;
+  if (MODE == WA_KLPEN || MODE == WA_KLPEN_COUNT) {
+    iso = on ? 1.f / a.old_std[k] : 1.f;
+    const float sr = sd * iso;                      // kl_normal_normal: var_ratio = (p.scale / q.scale)^2
+    vrat = sr * sr; lvrat = logf(vrat);
+  }
+  const float clip_lo = 1.f - a.p0, clip_hi = 1.f + a.p0;
+  float frac = 0.f;
+  if (MODE == WA_KLPEN) frac = (float)a.frac_sum[0] * a.inv_n;
+  double s_loss = 0.0, s_aux = 0.0, s_dls = 0.0;
+  const int64_t wave_g = (int64_t)blockIdx.x * 4 + wave, nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t r0 = wave_g * rpw; r0 < a.B; r0 += nwaves * rpw) {
+    const int64_t r = r0 + sub;
+    const bool rv = r < a.B;
+    const int64_t rr = rv ? r : a.B - 1;
+    const bool ld = on;
+    const float mu = ld ? a.mean[rr * A + k] : 0.f;
+    const float ac = ld ? a.act[rr * A + k] : 0.f;
+    const float dif = ac - mu;
+    const float term = on ? -(dif * dif) * (0.5f * ivar) - ls - LOG_SQRT_2PI_F : 0.f;
+    const float lp = group_sum_f(term, G);
+    float kl = 0.f, dm = 0.f;
+    if (MODE == WA_KLPEN || MODE == WA_KLPEN_COUNT) {
+      dm = on ? (mu - a.old_mean[rr * A + k]) * iso : 0.f;          // (loc_p - loc_q) / scale_q
+      kl = group_sum_f(on ? 0.5f * (vrat + dm * dm - 1.f - lvrat) : 0.f, G);
+    }
+    if (MODE == WA_KLPEN_COUNT) {
+      if (rv && k == 0) s_aux += (kl <= a.p0) ? 1.0 : 0.0;
+      continue;
+    }
+    const float ad = a.adv[rr];
+    const float ratio = __expf(lp - a.logp_old[rr]);
+    float dlp, wk = 0.f;
+    if (MODE == WA_CLIP) {
+      const float rc = fminf(fmaxf(ratio, clip_lo), clip_hi);
+      const float s1 = ratio * ad, s2 = rc * ad;
+      const bool inr = (ratio >= clip_lo) && (ratio <= clip_hi);
+      float gr;                                        // backward of torch.min / torch.clamp (ties split the gradient)
+      if (s1 < s2) gr = ad;
+      else if (s1 > s2) gr = inr ? ad : 0.f;
+      else gr = 0.5f * ad + (inr ? 0.5f * ad : 0.f);
+      dlp = -(gr * ratio) * a.inv_n;
+      if (rv && k == 0) s_loss += (double)fminf(s1, s2);
+    } else if (MODE == WA_SURR) {
+      dlp = a.p0 * ad * ratio * a.inv_n;               // d(sign * mean(ratio * adv)) / d logp
+      if (rv && k == 0) s_loss += (double)(ratio * ad);
+    } else {
+      const float ind = (kl <= a.p0) ? 1.f : 0.f;
+      const float pg = a.p1 * frac;
+      dlp = -(pg * ad * ratio) * a.inv_n;
+      wk = ind * a.inv_n;
+      if (rv && k == 0) { s_loss += (double)(pg * ratio * ad - ind * kl); s_aux += (double)ind; }      // loss = -mean(this)
+    }
+    if (rv && on) {
+      const float z = dif * ivar;
+      float dmu = dlp * z, dl = dlp * (dif * z - 1.f);
+      if (MODE == WA_KLPEN) { dmu = fmaf(dlp, z, wk * dm * iso); dl = fmaf(dlp, dif * z - 1.f, wk * (vrat - 1.f)); }
+      a.d_mean[r * A + k] = dmu;
+      s_dls += (double)dl;
+    }
+  }
+  s_loss = wave_sum_d(s_loss); s_aux = wave_sum_d(s_aux);
+  s_dls = stride_sum_d(s_dls, G);
+  if (lane == 0) { red[wave][0] = s_loss; red[wave][1] = s_aux; }
+  if (lane < G && lane < A) red[wave][2 + lane] = s_dls;
+  __syncthreads();
+  if (tid < 2 + A) a.partial[(int64_t)blockIdx.x * WA_NS + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+// sums[0] = loss sum, sums[1] = aux sum, sums[2 + k] = d(log_std)[k]; optional float outputs for the unchunked minibatch use
+__global__ void wide_actor_loss_finish_kernel(const double* __restrict__ partial, int nblocks, int A, double* __restrict__ sums,
+                                              int accumulate, float loss_scale, float* __restrict__ loss_out,
+                                              float* __restrict__ d_log_std_out) {
+  const int k = threadIdx.x;
+  if (k >= 2 + A) return;
+  double s = accumulate ? sums[k] : 0.0;
+  for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * WA_NS + k];
+  sums[k] = s;
+  if (k == 0 && loss_out) loss_out[0] = (float)(s * (double)loss_scale);
+  if (k >= 2 && d_log_std_out) d_log_std_out[k - 2] = (float)s;
+}
+
+__global__ __launch_bounds__(256) void wide_critic_loss_kernel(const float* __restrict__ v_r, const float* __restrict__ v_c,
+                                                               const float* __restrict__ tgt_r, const float* __restrict__ tgt_c, int64_t B,
+                                                               float inv_n, float* __restrict__ d_vr, float* __restrict__ d_vc,
+                                                               double* __restrict__ partial) {
+  __shared__ double red[4][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double a0 = 0.0, a1 = 0.0;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + tid; r < B; r += (int64_t)gridDim.x * 256) {
+    const float dr = v_r[r] - tgt_r[r], dc = v_c[r] - tgt_c[r];
+    a0 += (double)(dr * dr); a1 += (double)(dc * dc);
+    d_vr[r] = 2.f * dr * inv_n; d_vc[r] = 2.f * dc * inv_n;
+  }
+  a0 = wave_sum_d(a0); a1 = wave_sum_d(a1);
+  if (lane == 0) { red[wave][0] = a0; red[wave][1] = a1; }
+  __syncthreads();
+  if (tid < 2) partial[(int64_t)blockIdx.x * 2 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+__global__ void wide_critic_loss_finish_kernel(const double* __restrict__ partial, int nblocks, int64_t B, float* __restrict__ losses) {
+  const int k = threadIdx.x;
+  if (k >= 2) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * 2 + k];
+  losses[k] = (float)(s / (double)B);
+}
+
+// tangent epilogue of one layer: y = (y + tb) * (1 - h^2)  (hidden layers) or y + tb (output layer)
+__global__ __launch_bounds__(256) void mlp_jvp_ew_kernel(float* __restrict__ y, const float* __restrict__ tb, const float* __restrict__ h,
+                                                         int64_t n, int N) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float v = y[i] + tb[i % N];
+    if (h) { const float hv = h[i]; v = v * fmaf(-hv, hv, 1.f); }
+    y[i] = v;
+  }
+}
+__global__ __launch_bounds__(256) void wide_fvp_cot_kernel(const float* __restrict__ jv, const float* __restrict__ log_std, int64_t B, int A,
+                                                           float inv_ma, float* __restrict__ d_mean) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < B * A; i += (int64_t)gridDim.x * 256) {
+    const float sd = expf(log_std[i % A]);
+    d_mean[i] = jv[i] * (1.f / (sd * sd)) * inv_ma;
+  }
+}
+
+struct WlsArgs {
+  const float* mean; const float* log_std; const float* act; const float* logp_old; const float* adv_a; const float* adv_b;
+  const float* mean_old; const float* log_std_old; int64_t B; int A, G; double* partial;
+};
+__global__ __launch_bounds__(256) void wide_linesearch_kernel(WlsArgs a) {
+  __shared__ double red[4][3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int A = a.A, G = a.G, k = lane & (G - 1), sub = lane / G, rpw = 64 / G;
+  const bool on = k < A;
+  const float lsv = on ? a.log_std[k] : 0.f;
+  const float sdn = expf(lsv), sdo = on ? expf(a.log_std_old[k]) : 1.f;
+  const float ivar = 1.f / (sdn * sdn), lsd = on ? logf(sdn) + LOG_SQRT_2PI_F : 0.f;
+  const float sr = sdo / sdn, vr = sr * sr, lvr = logf(vr);
+  double s_a = 0.0, s_b = 0.0, s_kl = 0.0;
+  const int64_t wave_g = (int64_t)blockIdx.x * 4 + wave, nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t r0 = wave_g * rpw; r0 < a.B; r0 += nwaves * rpw) {
+    const int64_t r = r0 + sub;
+    const bool rv = r < a.B;
+    const int64_t rr = rv ? r : a.B - 1;
+    const float mu = on ? a.mean[rr * A + k] : 0.f;
+    const float dif = (on ? a.act[rr * A + k] : 0.f) - mu;
+    const float lp = group_sum_f(on ? -(dif * dif) * (0.5f * ivar) - lsd : 0.f, G);
+    const float ratio = expf(lp - a.logp_old[rr]);
+    if (rv && on) {
+      const float dm = (a.mean_old[rr * A + k] - mu) / sdn;
+      s_kl += (double)(0.5f * (vr + dm * dm - 1.f - lvr));
+    }
+    if (rv && k == 0) { s_a += (double)(ratio * a.adv_a[rr]); s_b += (double)(ratio * a.adv_b[rr]); }
+  }
+  s_a = wave_sum_d(s_a); s_b = wave_sum_d(s_b); s_kl = wave_sum_d(s_kl);
+  if (lane == 0) { red[wave][0] = s_a; red[wave][1] = s_b; red[wave][2] = s_kl; }
+  __syncthreads();
+  if (tid < 3) a.partial[(int64_t)blockIdx.x * 3 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+__global__ void wide_sum3_kernel(const double* __restrict__ partial, int n, double* __restrict__ out, int accumulate) {
+  if (threadIdx.x < 3) {
+    double s = accumulate ? out[threadIdx.x] : 0.0;
+    for (int b = 0; b < n; ++b) s += partial[(int64_t)b * 3 + threadIdx.x];
+    out[threadIdx.x] = s;
+  }
+}
+
+// clip + Adam with a sub-range: prep and coefficient as wide_prep_kernel / wide_coef_kernel (the joint norm spans all
+// parameters); Adam touches [adam_begin, adam_end) only, with the critics' clock below actor_begin and the actor's above;
+// outside that range the (stale) gradient is multiplied by the clip coefficient in place when scale_rest != 0.
+struct WideAdamExArgs {
+  WideAdamArgs b; int64_t adam_begin, adam_end; int scale_rest; double pow_b1_a, pow_b2_a;
+};
+__global__ __launch_bounds__(256) void wide_adam_ex_kernel(WideAdamExArgs x) {
+  const WideAdamArgs& a = x.b;
+  const float coef = a.scal[0];
+  float ss_a, ss_c, bc2s_a, bc2s_c;
+  adam_scalars(a.lr_actor, x.pow_b1_a * (double)a.b1, x.pow_b2_a * (double)a.b2, ss_a, bc2s_a);
+  adam_scalars(a.lr_critic, a.pow_b1 * (double)a.b1, a.pow_b2 * (double)a.b2, ss_c, bc2s_c);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.P; i += (int64_t)gridDim.x * 256) {
+    if (i >= x.adam_begin && i < x.adam_end) {
+      const bool act = i >= a.actor_begin;
+      const AdamOut o = adam1(a.theta[i], a.grad[i] * coef, a.m[i], a.v[i], a.b1, a.b2, a.eps, act ? ss_a : ss_c, act ? bc2s_a : bc2s_c);
+      a.theta[i] = o.p; a.m[i] = o.m; a.v[i] = o.v;
+    } else if (x.scale_rest) {
+      a.grad[i] = a.grad[i] * coef;
+    }
+  }
+}
+// prep over a sub-range for the joint norm: CUP's second stage clips over the ACTOR's parameters only (cup.py:385)
+__global__ __launch_bounds__(256) void wide_prep_range_kernel(WideAdamArgs a, int64_t n0, int64_t n1) {
+  __shared__ double red[4][3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double gs = 0.0;
+  for (int64_t i = n0 + (int64_t)blockIdx.x * 256 + tid; i < n1; i += (int64_t)gridDim.x * 256) {
+    const float g = a.grad[i];
+    gs += (double)(g * g);
+  }
+  gs = wave_sum_d(gs);
+  if (lane == 0) { red[wave][0] = gs; red[wave][1] = 0.0; red[wave][2] = 0.0; }
+  __syncthreads();
+  if (tid < 3) a.partial[(int64_t)blockIdx.x * 3 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+}  // namespace
+
+extern "C" int spo_wide_actor_loss(int mode, const float* mean, const float* log_std, const float* act, const float* logp_old,
+                                   const float* adv, const float* old_mean, const float* old_std, int64_t rows, int64_t rows_total,
+                                   int act_dim, float p0, float p1, float* d_mean, double* sums_inout, int accumulate,
+                                   float* loss_out, float* d_log_std_out, double* partial_ws, int partial_capacity, void* stream) {
+  SPO_REQUIRE(mode >= WA_CLIP && mode <= WA_KLPEN, "wide_actor_loss: mode %d outside [0,2]", mode);
+  SPO_REQUIRE(mean && log_std && act && logp_old && adv && d_mean && sums_inout && partial_ws && rows > 0 && rows_total >= rows,
+              "wide_actor_loss: bad args");
+  SPO_REQUIRE(act_dim >= 1 && act_dim <= SPO_WIDE_MAX_ACT, "wide_actor_loss: act_dim %d outside [1,%d]", act_dim, SPO_WIDE_MAX_ACT);
+  SPO_REQUIRE(mode != WA_KLPEN || (old_mean && old_std), "wide_actor_loss: the KL-penalty loss needs old_mean / old_std");
+  const int G = pow2ceil(act_dim);
+  const int64_t rpb = 4 * (64 / G);
+  int64_t blocks = (rows + rpb - 1) / rpb;
+  if (blocks > 256) blocks = 256;
+  SPO_REQUIRE((int64_t)partial_capacity >= blocks * WA_NS, "wide_actor_loss: partial workspace too small (%d < %lld)", partial_capacity,
+              (long long)(blocks * WA_NS));
+  hipStream_t st = (hipStream_t)stream;
+  WaArgs a{mean, log_std, act, logp_old, adv, old_mean, old_std, rows, act_dim, G, p0, p1, 1.f / (float)rows_total, sums_inout + 1, d_mean,
+           partial_ws};
+  float loss_scale = 1.f;
+  if (mode == WA_CLIP) {
+    hipLaunchKernelGGL(wide_actor_loss_kernel<WA_CLIP>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    loss_scale = -1.f / (float)rows_total;
+  } else if (mode == WA_SURR) {
+    hipLaunchKernelGGL(wide_actor_loss_kernel<WA_SURR>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    loss_scale = 1.f / (float)rows_total;
+  } else {
+    // pass 1: the indicator count (the loss couples every row to mean_i(ind_i), focops.py:331); pass 2 reads it from sums[1]
+    SPO_REQUIRE(!accumulate && rows == rows_total, "wide_actor_loss: the KL-penalty loss is a minibatch loss (no row chunks)");
+    hipLaunchKernelGGL(wide_actor_loss_kernel<WA_KLPEN_COUNT>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(wide_actor_loss_finish_kernel, dim3(1), dim3(128), 0, st, partial_ws, (int)blocks, 0, sums_inout, 0, 0.f,
+                       (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(wide_actor_loss_kernel<WA_KLPEN>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    loss_scale = -1.f / (float)rows_total;
+  }
+  hipLaunchKernelGGL(wide_actor_loss_finish_kernel, dim3(1), dim3(128), 0, st, partial_ws, (int)blocks, act_dim, sums_inout, accumulate,
+                     loss_scale, loss_out, d_log_std_out);
+  SPO_LAUNCH_CHECK("spo_wide_actor_loss");
+  return 0;
+}
+
+extern "C" int spo_wide_critic_loss(const float* v_r, const float* v_c, const float* tgt_r, const float* tgt_c, int64_t rows,
+                                    float* d_vr, float* d_vc, float* losses2, double* partial_ws, int partial_capacity, void* stream) {
+  SPO_REQUIRE(v_r && v_c && tgt_r && tgt_c && d_vr && d_vc && losses2 && partial_ws && rows > 0, "wide_critic_loss: bad args");
+  int64_t blocks = (rows + 255) / 256;
+  if (blocks > 256) blocks = 256;
+  SPO_REQUIRE((int64_t)partial_capacity >= blocks * 2, "wide_critic_loss: partial workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(wide_critic_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, st, v_r, v_c, tgt_r, tgt_c, rows, 1.f / (float)rows, d_vr,
+                     d_vc, partial_ws);
+  hipLaunchKernelGGL(wide_critic_loss_finish_kernel, dim3(1), dim3(64), 0, st, partial_ws, (int)blocks, rows, losses2);
+  SPO_LAUNCH_CHECK("spo_wide_critic_loss");
+  return 0;
+}
+
+extern "C" int64_t spo_mlp_jvp_scratch_floats(const spo_mlp_net* net, int64_t rows) {
+  MlpLay L;
+  if (mlp_lay(net, &L) || rows < 1) return -1;
+  return 2 * rows * (int64_t)L.maxdim();
+}
+extern "C" int spo_mlp_jvp(const float* theta, const spo_mlp_net* net, const float* tangent, const float* x, int64_t rows,
+                           const float* ws, float* dout, float* scratch, void* stream) {
+  MlpLay L;
+  if (int rc = mlp_lay(net, &L)) return rc;
+  SPO_REQUIRE(theta && tangent && x && ws && dout && scratch && rows > 0, "mlp_jvp: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const int md = L.maxdim();
+  float* bufA = scratch;
+  float* bufB = scratch + rows * (int64_t)md;
+  const float* dh = nullptr;                      // tangent of the layer input (0 for the observations)
+  for (int l = 0; l < L.n; ++l) {
+    const int K = L.d[l], N = L.d[l + 1];
+    const bool last = l + 1 == L.n;
+    const float* hin = l == 0 ? x : ws + L.act_off(l - 1, rows);
+    float* y = last ? dout : (dh == bufA ? bufB : bufA);
+    // dz_l = h_{l-1} tW_l^T + dh_{l-1} W_l^T + tb_l
+    if (int rc = gemm_xwT(st, hin, tangent + L.w(l), y, rows, K, N, 0.f)) return rc;
+    if (dh) { if (int rc = gemm_xwT(st, dh, theta + L.w(l), y, rows, K, N, 1.f)) return rc; }
+    const int64_t n = rows * (int64_t)N;
+    hipLaunchKernelGGL(mlp_jvp_ew_kernel, dim3(ew_grid(n)), dim3(256), 0, st, y, tangent + L.b(l),
+                       last ? (const float*)nullptr : ws + L.act_off(l, rows), n, N);
+    dh = y;
+  }
+  SPO_LAUNCH_CHECK("spo_mlp_jvp");
+  return 0;
+}
+
+extern "C" int spo_wide_fvp_cotangent(const float* jv, const float* log_std, int64_t rows, int64_t rows_total, int act_dim,
+                                      float* d_mean, void* stream) {
+  SPO_REQUIRE(jv && log_std && d_mean && rows > 0 && rows_total >= rows && act_dim >= 1 && act_dim <= SPO_WIDE_MAX_ACT,
+              "wide_fvp_cotangent: bad args");
+  const float inv_ma = (float)(1.0 / ((double)rows_total * (double)act_dim));
+  hipLaunchKernelGGL(wide_fvp_cot_kernel, dim3(ew_grid(rows * act_dim)), dim3(256), 0, (hipStream_t)stream, jv, log_std, rows, act_dim, inv_ma,
+                     d_mean);
+  SPO_LAUNCH_CHECK("spo_wide_fvp_cotangent");
+  return 0;
+}
+
+extern "C" int spo_wide_linesearch_sums(const float* mean_new, const float* log_std_new, const float* act, const float* logp_old,
+                                        const float* adv_a, const float* adv_b, const float* mean_old, const float* log_std_old,
+                                        int64_t rows, int act_dim, double* partial_ws, int partial_capacity, double* sums3_inout,
+                                        int accumulate, void* stream) {
+  SPO_REQUIRE(mean_new && log_std_new && act && logp_old && adv_a && adv_b && mean_old && log_std_old && partial_ws && sums3_inout &&
+                  rows > 0 && act_dim >= 1 && act_dim <= SPO_WIDE_MAX_ACT, "wide_linesearch_sums: bad args");
+  const int G = pow2ceil(act_dim);
+  const int64_t rpb = 4 * (64 / G);
+  int64_t blocks = (rows + rpb - 1) / rpb;
+  if (blocks > 512) blocks = 512;
+  if (blocks * 3 > partial_capacity) blocks = partial_capacity / 3;
+  SPO_REQUIRE(blocks >= 1, "wide_linesearch_sums: partial capacity too small");
+  WlsArgs a{mean_new, log_std_new, act, logp_old, adv_a, adv_b, mean_old, log_std_old, rows, act_dim, G, partial_ws};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(wide_linesearch_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(wide_sum3_kernel, dim3(1), dim3(64), 0, st, partial_ws, (int)blocks, sums3_inout, accumulate);
+  SPO_LAUNCH_CHECK("spo_wide_linesearch_sums");
+  return 0;
+}
+
+extern "C" int spo_wide_clip_adam_ex(float* theta, float* grad, float* adam_m, float* adam_v, int64_t n_params, int64_t reward_critic_end,
+                                     int64_t cost_critic_end, int64_t actor_begin, const spo_ppo_cfg* cfg, int64_t adam_step_critics_host,
+                                     int64_t adam_step_actor_host, int64_t adam_begin, int64_t adam_end, int64_t norm_begin,
+                                     int scale_rest, float* losses3_inout, float* scalars4_out, double* partial_ws,
+                                     int partial_capacity, void* stream) {
+  SPO_REQUIRE(theta && grad && adam_m && adam_v && cfg && scalars4_out && partial_ws && n_params > 0 && adam_step_critics_host >= 0 &&
+                  adam_step_actor_host >= 0, "wide_clip_adam_ex: bad args");
+  SPO_REQUIRE(0 <= reward_critic_end && reward_critic_end <= cost_critic_end && cost_critic_end <= actor_begin && actor_begin <= n_params,
+              "wide_clip_adam_ex: parameter ranges out of order");
+  SPO_REQUIRE(0 <= adam_begin && adam_begin <= adam_end && adam_end <= n_params && 0 <= norm_begin && norm_begin <= n_params,
+              "wide_clip_adam_ex: optimiser range out of order");
+  int64_t blocks = (n_params + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  SPO_REQUIRE((int64_t)partial_capacity >= blocks * 3, "wide_clip_adam_ex: partial workspace too small");
+  WideAdamArgs a{theta, grad, adam_m, adam_v, n_params, reward_critic_end, cost_critic_end, actor_begin,
+                 cfg->use_critic_norm ? cfg->l2_coef : 0.f, cfg->use_value_coefficient ? 2.f : 1.f, cfg->max_grad_norm, cfg->lr_actor,
+                 cfg->lr_critic, cfg->beta1, cfg->beta2, cfg->adam_eps, pow((double)cfg->beta1, (double)adam_step_critics_host),
+                 pow((double)cfg->beta2, (double)adam_step_critics_host), partial_ws, scalars4_out, losses3_inout};
+  WideAdamExArgs x{a, adam_begin, adam_end, scale_rest, pow((double)cfg->beta1, (double)adam_step_actor_host),
+                   pow((double)cfg->beta2, (double)adam_step_actor_host)};
+  hipStream_t st = (hipStream_t)stream;
+  if (norm_begin == 0) hipLaunchKernelGGL(wide_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(wide_prep_range_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, norm_begin, n_params);
+  hipLaunchKernelGGL(wide_coef_kernel, dim3(1), dim3(64), 0, st, a, (int)blocks);
+  hipLaunchKernelGGL(wide_adam_ex_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x);
+  SPO_LAUNCH_CHECK("spo_wide_clip_adam_ex");
   return 0;
 }

@@ -2437,8 +2437,12 @@ int h_scratch_for(hipStream_t st, float** backup, unsigned long long** slots) {
       return 0;
     }
   if (g_hs_n == H_SCRATCH_MAX)
-    return spo::fail(-1, "update kernel: more than %d (device, stream) pairs have launched the persistent update in this process",
-                     H_SCRATCH_MAX);
+    return spo::fail(-1, "update kernel: more than %d (device, stream) pairs hold update scratch in this process; call "
+                         "spo_update_scratch_release(stream) for streams that are gone", H_SCRATCH_MAX);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+    return spo::fail(-1, "update kernel: first launch on a stream under capture (the scratch block is allocated on first use: "
+                         "launch once outside the capture)");
   void* p = nullptr;
   if (int rc = spo::hip_check(hipMalloc(&p, H_BACKUP_BYTES + H_SLOT_BYTES), "hipMalloc(update scratch)")) return rc;
   g_hs[g_hs_n++] = HScratch{dev, (void*)st, static_cast<char*>(p)};
@@ -2447,6 +2451,26 @@ int h_scratch_for(hipStream_t st, float** backup, unsigned long long** slots) {
   return 0;
 }
 
+}  // namespace
+// Releases the scratch block of (current device, stream) -- or of every stream of the current device when stream_or_null is
+// NULL and all != 0.  The block is keyed by the raw stream handle, so a process that keeps creating and destroying streams
+// should release a stream's block before destroying it (a recycled handle would otherwise silently reuse the block, and after
+// H_SCRATCH_MAX distinct pairs launches fail).  hipFree synchronises the device: not for the hot path.
+extern "C" int spo_update_scratch_release(void* stream_or_null, int all) {
+  const int dev = spo::current_device_slot();
+  std::lock_guard<std::mutex> lk(g_hs_mu);
+  int freed = 0;
+  for (int i = 0; i < g_hs_n;) {
+    if (g_hs[i].dev == dev && (all || g_hs[i].stream == stream_or_null)) {
+      if (int rc = spo::hip_check(hipFree(g_hs[i].base), "hipFree(update scratch)")) return rc;
+      g_hs[i] = g_hs[--g_hs_n];
+      ++freed;
+    } else ++i;
+  }
+  return freed;
+}
+namespace {
+using namespace spo;
 // SPO_UPDATE_FORM: 0 = four-wave kernel everywhere, 2 = main + helper waves (default) where that form applies (persistent PPO step, clipped-surrogate loss, no in-kernel cross-rank exchange, batch <= 64, obs <= 64).
 inline int update_form() {
   static const int v = [] { const char* e = getenv("SPO_UPDATE_FORM"); return e ? atoi(e) : 2; }();

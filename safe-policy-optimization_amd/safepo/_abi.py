@@ -62,6 +62,8 @@ class MaLossCfg(Structure):
 P = c_void_p
 # name -> (restype, argtypes); must list every symbol declared in include/safepo_hip.h
 ACTOR_LOSS_CLIP, ACTOR_LOSS_KL_PENALTY = 0, 1      # include/safepo_hip.h SPO_ACTOR_LOSS_*
+MAX_OBS, MAX_ACT, CPO_MAX_OBS, WIDE_MAX_ACT = 128, 16, 64, 64   # SPO_MAX_OBS, SPO_MAX_ACT, cpo.hip's limit, SPO_WIDE_MAX_ACT
+WIDE_ACTOR_CLIP, WIDE_ACTOR_SURR, WIDE_ACTOR_KLPEN = 0, 1, 2     # spo_wide_actor_loss modes
 GAE_PARTIAL_STRIDE = 16                            # include/safepo_hip.h SPO_GAE_PARTIAL_STRIDE (doubles per workgroup)
 
 PROTOTYPES = {
@@ -80,6 +82,7 @@ PROTOTYPES = {
     "spo_boundary_step": (c_int, [P] * 18 + [c_int, c_int64, c_int64, c_int64, c_int, P]),
     "spo_boundary_step_fold": (c_int, [P] * 18 + [c_int, c_int64, c_int64, c_int64, c_int, P, P, c_double, P]),
     "spo_ppo_lag_update_iter": (c_int, [P, P, P, c_int64] + [P] * 7 + [c_int64, POINTER(PpoCfg), P, P, P]),
+    "spo_update_scratch_release": (c_int, [P, c_int]),
     "spo_debug_crosslane_selftest": (c_int, [P, P, P]),
     "spo_debug_ma_gemm": (c_int, [c_int, c_int, P, P, P, c_int64, c_int, c_int, P]),
     "spo_debug_set_update_profile": (c_int, [P]),
@@ -139,6 +142,14 @@ PROTOTYPES = {
     "spo_gauss_kl_sum": (c_int, [P, P, P, P, c_int64, c_int, P, c_int, P, c_int, P]),
     "spo_wide_ppo_loss": (c_int, [P] * 9 + [c_int64, c_int, c_float] + [P] * 6 + [c_int, P]),
     "spo_wide_clip_adam": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, POINTER(PpoCfg), c_int64, P, P, P, c_int, P]),
+    "spo_wide_actor_loss": (c_int, [c_int] + [P] * 7 + [c_int64, c_int64, c_int, c_float, c_float, P, P, c_int, P, P, P, c_int, P]),
+    "spo_wide_critic_loss": (c_int, [P, P, P, P, c_int64, P, P, P, P, c_int, P]),
+    "spo_mlp_jvp_scratch_floats": (c_int64, [POINTER(MlpNet), c_int64]),
+    "spo_mlp_jvp": (c_int, [P, POINTER(MlpNet), P, P, c_int64, P, P, P, P]),
+    "spo_wide_fvp_cotangent": (c_int, [P, P, c_int64, c_int64, c_int, P, P]),
+    "spo_wide_linesearch_sums": (c_int, [P] * 8 + [c_int64, c_int, P, c_int, P, c_int, P]),
+    "spo_wide_clip_adam_ex": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, POINTER(PpoCfg), c_int64, c_int64, c_int64,
+                                      c_int64, c_int64, c_int, P, P, P, c_int, P]),
     "spo_param_count": (c_int64, [c_int, c_int]),
     "spo_param_offset": (c_int64, [c_int, c_int, c_int]),
     "spo_synth_env_step": (c_int, [P] * 7 + [c_int64, c_int, c_uint64, c_uint64, c_float, c_float, c_int, P]),

@@ -420,25 +420,29 @@ class PPOLagEngine:
                 "losses": all_losses}
 
 
-class WidePPOLagEngine(PPOLagEngine):
-    """The same epoch for an ActorVCritic with hidden_sizes other than [64, 64] (reference model.py:131; the
-    isaac_gym_specific_cfg regime of ppo_lag.py:54-65): collect, boundary logic, GAE, statistics and the KL early stop are
-    shared with PPOLagEngine; the policy step, the bootstrap values, the full-batch actor evaluation and the minibatch step
-    run on the wide-network kernels (safepo.common.wide).  Single GPU."""
+class _WideOps:
+    """Engine pieces shared by the wide-network engines (WidePPOLagEngine here, WideCPOEngine in single_agent/cpo.py): the
+    policy step, bootstrap values, the old-distribution snapshot and the full-batch KL on the wide-network kernels
+    (safepo.common.wide), for any (obs_dim, act_dim <= 64, hidden_sizes).  Mixed in FRONT of PPOLagEngine / CPOEngine."""
+
+    FAMILY = "ppo"
 
     def _require_policy(self, policy) -> None:
-        if policy.kernels_supported():
-            raise ValueError("hidden_sizes [64, 64] runs on PPOLagEngine (persistent kernels)")
+        if policy.kernels_supported(self.FAMILY):
+            raise ValueError(f"this shape runs on the persistent kernels (obs {policy.obs_dim}, act {policy.act_dim}, hidden "
+                             f"{policy.hidden_sizes}): use the plain engine")
+        if policy.act_dim > _abi.WIDE_MAX_ACT:
+            raise _abi.SpoError(f"act_dim {policy.act_dim} outside [1, {_abi.WIDE_MAX_ACT}] (wide-network path)")
         policy.wide          # builds the layout; raises on unsupported depths
 
-    def __init__(self, policy: ActorVCritic, num_envs: int, steps: int, config: dict, device,
-                 comm: Comm | None = None, lr: float = 3e-4, critic_lr: float | None = None):
-        super().__init__(policy, num_envs, steps, config, device, comm=comm, lr=lr, critic_lr=critic_lr)
+    def _wide_init(self) -> None:
         if self.comm.world_size != 1:
             raise NotImplementedError("the wide-network path runs on one GPU in this build")
-        self.wide = policy.wide
+        self.wide = self.policy.wide
         f32 = dict(dtype=torch.float32, device=self.dev)
-        self.loss_partials = torch.zeros(4096, dtype=torch.float64, device=self.dev)
+        # spo_wide_ppo_loss: 256 x (3 + SPO_WIDE_MAX_ACT) + 512 + (2 + SPO_WIDE_MAX_ACT) doubles; spo_wide_clip_adam: <= 1024 x 3
+        self.loss_partials = torch.zeros(256 * (3 + _abi.WIDE_MAX_ACT) + 1024 + 3 * 1024, dtype=torch.float64, device=self.dev)
+        self.actor_sums = torch.zeros(2 + _abi.WIDE_MAX_ACT, dtype=torch.float64, device=self.dev)
         self.scal4 = torch.zeros(4, **f32)
 
     def _values_into(self, obs, out_r, out_c) -> None:
@@ -484,15 +488,34 @@ class WidePPOLagEngine(PPOLagEngine):
     def kl_read(self) -> float:
         return float(self.kl_sum.item()) / float(self.M)
 
+    def check_sync_error(self):
+        return None
+
+
+class WidePPOLagEngine(_WideOps, PPOLagEngine):
+    """The same epoch for an ActorVCritic outside the persistent kernels' envelope -- hidden_sizes other than [64, 64] (reference
+    model.py:131; the isaac_gym_specific_cfg regime of ppo_lag.py:54-65), obs_dim > 128 or act_dim > 16 (HumanoidVelocity:
+    376 / 17): collect, boundary logic, GAE, statistics and the KL early stop are shared with PPOLagEngine; the policy step, the
+    bootstrap values, the full-batch actor evaluation and the minibatch step (clipped surrogate, and the KL-penalty loss of
+    FOCOPS / CUP) run on the wide-network kernels (safepo.common.wide).  Single GPU."""
+
+    def __init__(self, policy: ActorVCritic, num_envs: int, steps: int, config: dict, device,
+                 comm: Comm | None = None, lr: float = 3e-4, critic_lr: float | None = None):
+        super().__init__(policy, num_envs, steps, config, device, comm=comm, lr=lr, critic_lr=critic_lr)
+        self._wide_init()
+
+    def _gather(self, idx):
+        d, b = self.buffer.data, self.buffer
+        return (d["obs"].view(self.M, self.D).index_select(0, idx), d["act"].view(self.M, self.A).index_select(0, idx),
+                d["log_prob"].view(-1).index_select(0, idx), d["target_value_r"].view(-1).index_select(0, idx),
+                d["target_value_c"].view(-1).index_select(0, idx))
+
     def minibatch_step(self, idx: torch.Tensor, losses_out: torch.Tensor) -> None:
         """ppo_lag.py:306-329 on the rows `idx` (int64 device indices into the flat buffer)."""
         w, lib, st = self.wide, self.lib, _abi.stream_ptr
-        d, b = self.buffer.data, self.buffer
         cfg = self._cfg_struct()
-        obs = d["obs"].view(self.M, self.D).index_select(0, idx)
-        act = d["act"].view(self.M, self.A).index_select(0, idx)
-        logp_old, adv = d["log_prob"].view(-1).index_select(0, idx), b.adv_mix.view(-1).index_select(0, idx)
-        tgt_r, tgt_c = d["target_value_r"].view(-1).index_select(0, idx), d["target_value_c"].view(-1).index_select(0, idx)
+        obs, act, logp_old, tgt_r, tgt_c = self._gather(idx)
+        adv = self.buffer.adv_mix.view(-1).index_select(0, idx)
         n = obs.shape[0]
         v_r, ws_r = w.forward("r", obs, slot=1)
         v_c, ws_c = w.forward("c", obs, slot=1)
@@ -523,8 +546,56 @@ class WidePPOLagEngine(PPOLagEngine):
             self.minibatch_step(perm[k * cfg.batch:(k + 1) * cfg.batch], losses[k])
         return losses
 
-    def learning_iter_ex(self, *a, **k):
-        raise NotImplementedError("focops / cup run on hidden_sizes [64, 64] in this build")
+    def minibatch_step_ex(self, idx, adv_all, losses_out, actor_loss, kl_bound, pg_coef, actor_only) -> None:
+        """One FOCOPS minibatch step (focops.py:312-347) or one step of CUP's actor-only second stage (cup.py:370-386) on the
+        wide kernels: spo_update_iter_ex's semantics (include/safepo_hip.h), one minibatch."""
+        w, lib, st = self.wide, self.lib, _abi.stream_ptr
+        cfg = self._cfg_struct()
+        obs, act, logp_old, tgt_r, tgt_c = self._gather(idx)
+        adv = adv_all.view(-1).index_select(0, idx)
+        n = obs.shape[0]
+        g, off_ls, A = self.flat_grad, w.off_ls, self.A
+        part, cap = self.loss_partials, self.loss_partials.numel()
+        if not actor_only:
+            v_r, ws_r = w.forward("r", obs, slot=1)
+            v_c, ws_c = w.forward("c", obs, slot=1)
+            d_vr = torch.empty(n, dtype=torch.float32, device=self.dev)
+            d_vc = torch.empty_like(d_vr)
+            _abi.check(lib.spo_wide_critic_loss(_abi.ptr(v_r), _abi.ptr(v_c), _abi.ptr(tgt_r), _abi.ptr(tgt_c), n, _abi.ptr(d_vr),
+                                                _abi.ptr(d_vc), _abi.ptr(losses_out), _abi.ptr(part), cap, st()), "spo_wide_critic_loss")
+            w.backward("r", obs, ws_r, d_vr, g)
+            w.backward("c", obs, ws_c, d_vc, g)
+        mu, ws_a = w.forward("a", obs, slot=1)
+        d_mu = torch.empty((n, A), dtype=torch.float32, device=self.dev)
+        if actor_loss == _abi.ACTOR_LOSS_KL_PENALTY:
+            old_mean = self.mean_old.index_select(0, idx)
+            mode, p0, p1, om, os_ = _abi.WIDE_ACTOR_KLPEN, float(kl_bound), float(pg_coef), _abi.ptr(old_mean), _abi.ptr(self.std_old)
+        else:
+            mode, p0, p1, om, os_ = _abi.WIDE_ACTOR_CLIP, float(cfg.clip), 0.0, None, None
+        _abi.check(lib.spo_wide_actor_loss(mode, _abi.ptr(mu), _abi.ptr(self.policy.theta[off_ls:]), _abi.ptr(act), _abi.ptr(logp_old),
+                                           _abi.ptr(adv), om, os_, n, n, A, p0, p1, _abi.ptr(d_mu), _abi.ptr(self.actor_sums), 0,
+                                           _abi.ptr(losses_out[2:]), _abi.ptr(g[off_ls:]), _abi.ptr(part), cap, st()),
+                   "spo_wide_actor_loss")
+        w.backward("a", obs, ws_a, d_mu, g)
+        step_c, step_a = self.adam_step, self.adam_step + self.adam_step_actor_extra
+        lo, norm0 = (off_ls, off_ls) if actor_only else (0, 0)
+        _abi.check(lib.spo_wide_clip_adam_ex(_abi.ptr(self.policy.theta), _abi.ptr(g), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), w.P,
+                                             w.off_c, w.off_ls, w.off_ls, cfg, step_c, step_a, lo, w.P, norm0, 0,
+                                             None if actor_only else _abi.ptr(losses_out), _abi.ptr(self.scal4), _abi.ptr(part), cap,
+                                             st()), "spo_wide_clip_adam_ex")
 
-    def check_sync_error(self):
-        return None
+    def learning_iter_ex(self, perm: torch.Tensor, adv: torch.Tensor, actor_loss: int = 0,
+                         kl_bound: float = float("inf"), pg_coef: float = 0.0, actor_only: bool = False) -> torch.Tensor:
+        cfg = self._cfg_struct()
+        perm = _abi.require_gpu_tensor(perm, "perm", torch.int32).long()
+        adv = _abi.require_gpu_tensor(adv, "adv", torch.float32)
+        M = self.M
+        n_mb = (M + cfg.batch - 1) // cfg.batch
+        losses = torch.full((n_mb, 3), float("nan"), dtype=torch.float32, device=self.dev)
+        for k in range(n_mb):
+            self.minibatch_step_ex(perm[k * cfg.batch:(k + 1) * cfg.batch], adv, losses[k], actor_loss, kl_bound, pg_coef, actor_only)
+            if actor_only:
+                self.adam_step_actor_extra += 1
+            else:
+                self.adam_step += 1
+        return losses

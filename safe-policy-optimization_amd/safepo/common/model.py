@@ -87,16 +87,23 @@ class ActorVCritic(nn.Module):
         self._flatten()
         return out
 
-    def kernels_supported(self) -> bool:
-        """True for the shape the persistent LDS-resident kernels are built for (hidden_sizes [64, 64], the default_cfg of
-        every reference script); every other hidden_sizes runs on the wide-network kernels (safepo.common.wide)."""
-        return self.hidden_sizes == [HIDDEN, HIDDEN]
+    def kernels_supported(self, family: str = "ppo") -> bool:
+        """True when this (obs_dim, act_dim, hidden_sizes) lies inside the envelope of the persistent LDS-resident kernels:
+        hidden_sizes [64, 64] (the default_cfg of every reference script), act_dim <= 16 and obs_dim <= 128 for the
+        PPO-family kernels (`family="ppo"`: policy step, minibatch update, KL), obs_dim <= 64 for the full-batch CPO kernels
+        (`family="cpo"`: surrogate gradient, Fisher-vector product, line search).  Everything else -- the reference takes ANY
+        dims (model.py:131; its default sweep includes 72-88-dim Car / Doggo / Racecar observations and HumanoidVelocity's
+        376 / 17, single_agent/benchmark.py:5-22) -- runs on the wide-network kernels (safepo.common.wide)."""
+        if self.hidden_sizes != [HIDDEN, HIDDEN] or self.act_dim > _abi.MAX_ACT:
+            return False
+        return self.obs_dim <= (_abi.CPO_MAX_OBS if family == "cpo" else _abi.MAX_OBS)
 
-    def _require_kernels(self):
-        if not self.kernels_supported():
+    def _require_kernels(self, family: str = "ppo"):
+        if not self.kernels_supported(family):
             raise NotImplementedError(
-                f"this entry point uses the kernels specialised for hidden_sizes=[64, 64] (got {self.hidden_sizes}); "
-                "other widths run through safepo.common.wide / WidePPOLagEngine (PPO-Lagrangian family)")
+                f"this entry point uses the kernels specialised for hidden_sizes=[64, 64], act_dim <= 16, obs_dim <= "
+                f"{_abi.CPO_MAX_OBS if family == 'cpo' else _abi.MAX_OBS} (got obs {self.obs_dim}, act {self.act_dim}, hidden "
+                f"{self.hidden_sizes}); other shapes run through safepo.common.wide (Wide*Engine)")
         n = _abi.load().spo_param_count(self.obs_dim, self.act_dim)
         assert n == self.theta.numel(), (n, self.theta.numel())
 
@@ -104,7 +111,7 @@ class ActorVCritic(nn.Module):
     def wide(self):
         """Host side of the wide-network kernels for this policy (created on first use; hidden_sizes != [64, 64])."""
         w = self.__dict__.get("_wide")
-        if w is None or w.policy.theta is not self.theta:
+        if w is None or w.theta_key != (self.theta.data_ptr(), self.theta.device):      # .to(device) / _flatten() re-made theta
             from safepo.common.wide import WideNets
             w = WideNets(self)
             self.__dict__["_wide"] = w
@@ -190,7 +197,7 @@ class _MATrunk(nn.Module):
 
 class _MAFlatNet(nn.Module):
     """One MAPPO network over a flat fp32 parameter vector (layout: include/safepo_hip.h, section f3).  forward /
-    backward run through spo_ma_forward / spo_ma_backward (rocBLAS GEMMs + fused LayerNorm/ELU kernels); the
+    backward run through spo_ma_forward / spo_ma_backward (in-tree fp32 MFMA GEMMs + fused LayerNorm/ELU kernels); the
     nn.Parameters are views into `theta` so state_dict() keeps the reference's keys and shapes."""
 
     def _finish(self, in_dim, out_dim, is_actor):

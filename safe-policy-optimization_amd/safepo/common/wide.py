@@ -1,4 +1,5 @@
-"""ActorVCritic with hidden_sizes other than [64, 64]: host side of the wide-network kernels.
+"""ActorVCritic outside the persistent kernels' envelope (hidden_sizes other than [64, 64], obs_dim > 128, act_dim > 16): host
+side of the wide-network kernels.
 
 The reference builds its MLPs for any `hidden_sizes` (safepo/common/model.py:30-48,131) and selects
 `[1024, 1024, 512]` with minibatches of steps_per_epoch // 4 rows for Isaac Gym tasks
@@ -22,6 +23,7 @@ class WideNets:
 
     def __init__(self, policy):
         self.policy = policy
+        self.theta_key = (policy.theta.data_ptr(), policy.theta.device)      # ActorVCritic.wide rebuilds when theta moved
         self.lib = _abi.load()
         D, A, hs = policy.obs_dim, policy.act_dim, list(policy.hidden_sizes)
         self.D, self.A = D, A
@@ -79,6 +81,15 @@ class WideNets:
         off = {"r": self.off_r, "c": self.off_c, "a": self.off_a}[which]
         _abi.check(self.lib.spo_mlp_backward(_abi.ptr(self.theta_of(which)), net, _abi.ptr(x), rows, _abi.ptr(ws), _abi.ptr(d_out),
                                              _abi.ptr(grad_flat[off:]), _abi.ptr(sc), _abi.stream_ptr()), "spo_mlp_backward")
+
+    def jvp_scratch(self, rows):
+        key = ("jvp", rows)
+        sc = self._scratch.get(key)
+        if sc is None:
+            sc = torch.empty(int(self.lib.spo_mlp_jvp_scratch_floats(self.net_a, rows)), dtype=torch.float32,
+                             device=self.policy.theta.device)
+            self._scratch[key] = sc
+        return sc
 
     # ------------------------------------------------------------------ reference API pieces
     def values(self, obs):

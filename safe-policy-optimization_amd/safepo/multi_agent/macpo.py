@@ -8,7 +8,7 @@ agent (macpo.py:201-371) instead of clipped-surrogate Adam steps:
   * two conjugate-gradient solves against the Fisher matrix.  The reference differentiates its KL expression twice
     (macpo.py:187-199).  At theta = theta_old the mean enters that expression only through (mu_old - mu)^2, so its
     Hessian is exactly J^T M J with M = 2 / (1e-8 + 2 sigma^2) per action dimension, plus a diagonal block for
-    log_std (sigma is state-independent) -- no second-order autograd: one forward-mode pass (spo_ma_jvp: rocBLAS
+    log_std (sigma is state-independent) -- no second-order autograd: one forward-mode pass (spo_ma_jvp: in-tree MFMA
     GEMMs + a LayerNorm/ELU tangent kernel) and one ordinary backward pass per product;
   * the case analysis for (lam, nu), the step and the backtracking line search on the host, as written.
 

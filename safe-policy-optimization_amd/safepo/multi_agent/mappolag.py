@@ -2,7 +2,7 @@
 
 Same surface -- MAPPO_L_Policy, MAPPO_L_Trainer, Runner, train(args, cfg_train) -- on the MI355X kernels of
 csrc/ma_net.hip and csrc/multi_agent.hip: per-agent actor / critic / cost-critic networks are flat device vectors whose
-forward and backward run as rocBLAS GEMMs with fused LayerNorm/ELU kernels; the clipped HAPPO surrogate, entropy bonus,
+forward and backward run on the in-tree fp32 MFMA GEMM kernels with fused LayerNorm/ELU kernels; the clipped HAPPO surrogate, entropy bonus,
 in-loop multiplier step, PopArt statistics, clipped Huber value losses and clip_grad_norm_ + Adam are single kernels;
 GAE + PopArt de-normalisation for rewards and costs is one kernel per agent (spo_ma_gae).  Everything between the
 environment and the logger stays in HBM; there is no CPU fallback.
@@ -601,7 +601,7 @@ class Runner:
                                        [self._static_stk["masks"][a] for a in range(self.num_agents)])
                 else:
                     self._static_in = tuple([t.clone() for t in group] for group in ins)
-                self._collect_eager(*self._static_in)            # warm-up: rocBLAS handle / workspaces, allocator pools
+                self._collect_eager(*self._static_in)            # warm-up: workspaces, allocator pools
                 torch.cuda.synchronize(self.dev)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):

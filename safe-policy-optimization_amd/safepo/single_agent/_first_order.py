@@ -74,12 +74,11 @@ def run(args, cfg_env, default_cfg: dict, multiplier: str | None = "adam", clip:
     policy = ActorVCritic(obs_dim=obs_space.shape[0], act_dim=act_space.shape[0],
                           hidden_sizes=config["hidden_sizes"]).to(device)
     comm.broadcast_(policy.theta, 0)            # identical replicas
-    # hidden_sizes [64, 64] (default_cfg): persistent LDS-resident kernels; any other width: the wide-network kernels
+    # inside the persistent kernels' envelope (hidden_sizes [64, 64], obs_dim <= 128, act_dim <= 16 -- default_cfg on most tasks):
+    # LDS-resident kernels; any other width / dims (HumanoidVelocity: 376 / 17): the wide-network kernels, all variants
     if policy.kernels_supported():
         engine = PPOLagEngine(policy, n_local, local_steps_per_epoch, config, device, comm=comm, lr=3e-4)
     else:
-        if variant != "ppo":
-            raise NotImplementedError(f"{variant} runs on hidden_sizes [64, 64] in this build (got {config['hidden_sizes']})")
         engine = WidePPOLagEngine(policy, n_local, local_steps_per_epoch, config, device, comm=comm, lr=3e-4)
     if multiplier == "adam":
         upper = {"focops": FOCOPS_NU, "cup": CUP_NU}.get(variant)          # focops.py:136, cup.py:136

@@ -22,7 +22,7 @@ from safepo.common.lagrange import Lagrange
 from safepo.common.logger import EpochLogger
 from safepo.common.model import ActorVCritic
 from safepo.parallel import dp_epoch_stat, init_from_env, require_equal_shards, shard_envs
-from safepo.single_agent.cpo import CPOEngine, _to_dev
+from safepo.single_agent.cpo import _to_dev, make_engine
 from safepo.utils.config import isaac_gym_map
 
 
@@ -52,7 +52,7 @@ def run(args, cfg_env, default_cfg: dict, line_search: bool, use_lagrange: bool)
     policy = ActorVCritic(obs_dim=obs_space.shape[0], act_dim=act_space.shape[0],
                           hidden_sizes=config["hidden_sizes"]).to(device)
     comm.broadcast_(policy.theta, 0)                       # identical replicas
-    engine = CPOEngine(policy, n_local, local_steps_per_epoch, config, device, comm=comm)
+    engine = make_engine(policy, n_local, local_steps_per_epoch, config, device, comm=comm)
     lagrange = Lagrange(cost_limit=args.cost_limit, lagrangian_multiplier_init=args.lagrangian_multiplier_init,
                         lagrangian_multiplier_lr=args.lagrangian_multiplier_lr) if use_lagrange else None
     dict_args = dict(vars(args))

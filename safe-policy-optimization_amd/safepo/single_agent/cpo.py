@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from safepo import _abi
-from safepo.common.engine import PPOLagEngine
+from safepo.common.engine import PPOLagEngine, _WideOps
 from safepo.common.env import make_sa_mujoco_env
 from safepo.common.logger import EpochLogger
 from safepo.common.model import ActorVCritic
@@ -45,6 +45,11 @@ default_cfg = {
 class CPOEngine(PPOLagEngine):
     """Adds the CPO actor update and critic fit on top of the shared collect/GAE engine."""
 
+    FAMILY = "cpo"
+
+    def _require_policy(self, policy) -> None:
+        policy._require_kernels("cpo")
+
     def __init__(self, policy: ActorVCritic, num_envs: int, steps: int, config: dict, device, comm=None):
         super().__init__(policy, num_envs, steps, config, device, comm=comm, lr=1e-3, critic_lr=1e-3)
         # data parallel over env shards (SURVEY.md 8(e) item 4): the actor update is full-batch, so it is EXACT -- the two
@@ -53,41 +58,59 @@ class CPOEngine(PPOLagEngine):
         self._inv_world = 1.0 / self.comm.world_size
         self.ls_off = policy.log_std_offset
         self.Pa = policy.theta.numel() - self.ls_off
-        nparts = self.lib.spo_cpo_num_partials(self.M)
-        self.partial_ws = torch.empty(nparts * self.Pa, dtype=torch.float32, device=self.dev)
-        self.loss_ws = torch.empty(nparts, dtype=torch.float64, device=self.dev)
+        self._alloc_full_batch_workspaces()
         self.loss_sum = torch.zeros(1, dtype=torch.float64, device=self.dev)
         self.ls_partials = torch.empty(3 * 1024, dtype=torch.float64, device=self.dev)
         self.ls_sums = torch.zeros(3, dtype=torch.float64, device=self.dev)
         self.stale_sq = torch.zeros(1, dtype=torch.float32, device=self.dev)
         self._split = None          # two-launch form of the critic fit: None = not tried yet, False = unavailable
 
+    def _alloc_full_batch_workspaces(self) -> None:
+        nparts = self.lib.spo_cpo_num_partials(self.M)
+        self.partial_ws = torch.empty(nparts * self.Pa, dtype=torch.float32, device=self.dev)
+        self.loss_ws = torch.empty(nparts, dtype=torch.float64, device=self.dev)
+
+    def _set_stale_actor_grad(self, vec: torch.Tensor) -> None:
+        """actor.grad as the reference leaves it after the policy update: it still takes part in (and is rescaled by) the
+        critic fit's clip_grad_norm_ over ALL policy parameters (cpo.py:557).  The persistent kernel only needs its norm."""
+        self.stale_sq.copy_(vec.dot(vec).reshape(1))
+
     # ---------------------------------------------------------------- actor flat views (cpo.py:70-78,109-121)
     @property
     def theta_actor(self) -> torch.Tensor:
         return self.policy.theta[self.ls_off:]
 
-    def surrogate_grad(self, adv: torch.Tensor, sign: float):
-        """grad of sign*mean(ratio*adv) wrt the actor parameters, and mean(ratio*adv)."""
+    def _surrogate_grad_local(self, adv: torch.Tensor, sign: float) -> torch.Tensor:
+        """This rank's d/dtheta_actor [sign * mean(ratio*adv)] (mean over the LOCAL rows); self.loss_sum = sum(ratio*adv)."""
         d = self.buffer.data
         g = torch.empty(self.Pa, dtype=torch.float32, device=self.dev)
         _abi.check(self.lib.spo_cpo_surrogate_grad(
             _abi.ptr(self.policy.theta), _abi.ptr(d["obs"]), _abi.ptr(d["act"]), _abi.ptr(d["log_prob"]),
             _abi.ptr(adv), float(sign), self.M, self.D, self.A, _abi.ptr(self.partial_ws), _abi.ptr(self.loss_ws),
             _abi.ptr(g), _abi.ptr(self.loss_sum), _abi.stream_ptr()), "spo_cpo_surrogate_grad")
+        return g
+
+    def surrogate_grad(self, adv: torch.Tensor, sign: float):
+        """grad of sign*mean(ratio*adv) wrt the actor parameters, and mean(ratio*adv)."""
+        g = self._surrogate_grad_local(adv, sign)
         if self.comm.world_size > 1:
             self.comm.all_reduce_sum_(g)
             g *= self._inv_world
             self.comm.all_reduce_sum_(self.loss_sum)
         return g, float(self.loss_sum.item()) / (self.M * self.comm.world_size)
 
-    def fvp(self, v: torch.Tensor) -> torch.Tensor:
-        """cpo.py:132-157: H v + 0.1 v with H the Hessian of mean(KL(old||cur)) at cur == old."""
+    def _fvp_local(self, v: torch.Tensor) -> torch.Tensor:
+        """J^T diag(1/sigma^2) J v / (M*A) over this rank's rows (0 on the log_std entries)."""
         out = torch.empty(self.Pa, dtype=torch.float32, device=self.dev)
-        v = v.contiguous()
         _abi.check(self.lib.spo_cpo_fvp(_abi.ptr(self.policy.theta), _abi.ptr(self.buffer.data["obs"]), _abi.ptr(v),
                                         self.M, self.D, self.A, _abi.ptr(self.partial_ws), _abi.ptr(self.loss_ws),
                                         _abi.ptr(out), _abi.stream_ptr()), "spo_cpo_fvp")
+        return out
+
+    def fvp(self, v: torch.Tensor) -> torch.Tensor:
+        """cpo.py:132-157: H v + 0.1 v with H the Hessian of mean(KL(old||cur)) at cur == old."""
+        v = v.contiguous()
+        out = self._fvp_local(v)
         if self.comm.world_size > 1:
             self.comm.all_reduce_sum_(out)
             out *= self._inv_world
@@ -120,15 +143,19 @@ class CPOEngine(PPOLagEngine):
         d = self.buffer.data
         adv_a = d["adv_r"] if adv_a is None else adv_a
         adv_b = d["adv_c"] if adv_b is None else adv_b
+        self._linesearch_sums_local(adv_a, adv_b)
+        self.comm.all_reduce_sum_(self.ls_sums)
+        s = self.ls_sums.cpu()
+        Mg = self.M * self.comm.world_size
+        return -float(s[0]) / Mg, float(s[1]) / Mg, float(s[2]) / (Mg * self.A)
+
+    def _linesearch_sums_local(self, adv_a, adv_b) -> None:
+        d = self.buffer.data
         _abi.check(self.lib.spo_cpo_linesearch_eval(
             _abi.ptr(self.policy.theta), _abi.ptr(d["obs"]), _abi.ptr(d["act"]), _abi.ptr(d["log_prob"]),
             _abi.ptr(adv_a), _abi.ptr(adv_b), _abi.ptr(self.mean_old), _abi.ptr(self.logstd_old),
             self.M, self.D, self.A, _abi.ptr(self.ls_partials), self.ls_partials.numel(), _abi.ptr(self.ls_sums),
             _abi.stream_ptr()), "spo_cpo_linesearch_eval")
-        self.comm.all_reduce_sum_(self.ls_sums)
-        s = self.ls_sums.cpu()
-        Mg = self.M * self.comm.world_size
-        return -float(s[0]) / Mg, float(s[1]) / Mg, float(s[2]) / (Mg * self.A)
 
     def policy_update(self, ep_costs: float, logger=None) -> dict:
         """cpo.py:350-532.  `ep_costs` = Jc - cost_limit.  Requires compute_gae() to have run."""
@@ -203,7 +230,7 @@ class CPOEngine(PPOLagEngine):
             theta_old, step_direction, grads, optim_case, ep_costs, loss_reward_before, loss_cost_before, logger)
         self.theta_actor.copy_(theta_old + step_frac * step_direction)
         # the actor's .grad keeps the cost gradient b: it takes part in the critic fit's joint clip (cpo.py:557)
-        self.stale_sq.copy_(b_grads.dot(b_grads).reshape(1))
+        self._set_stale_actor_grad(b_grads)
         return {"alpha": float(alpha), "final_step_norm": float(torch.norm(step_direction)), "xHx": float(xHx),
                 "gradient_norm": float(torch.norm(grads)), "H_inv_g": float(x.norm()),
                 "acceptance_step": acceptance_step, "loss_actor": loss_reward_before + loss_cost_before, "kl": kl,
@@ -263,7 +290,7 @@ class CPOEngine(PPOLagEngine):
                 acceptance_step = 0
             self.theta_actor.copy_(theta_old + step_frac * step_direction)
         # actor.grad keeps d(loss_pi)/d(theta) = -grads: part of the critic fit's joint clip_grad_norm_
-        self.stale_sq.copy_(grads.dot(grads).reshape(1))
+        self._set_stale_actor_grad(-grads)
         # Loss/Loss_actor: natural_pg logs the surrogate before the step (natural_pg.py:390), trpo the one of the
         # last line-search candidate (trpo.py:438)
         return {"alpha": float(alpha), "final_step_norm": float(torch.norm(step_direction)), "xHx": float(xHx),
@@ -341,7 +368,7 @@ class CPOEngine(PPOLagEngine):
         step_frac, step_direction, acceptance_step, kl = self._constrained_line_search(
             theta_old, step_direction, grads, 0, ep_costs, loss_reward_before, loss_cost_before, logger)
         self.theta_actor.copy_(theta_old + step_frac * step_direction)
-        self.stale_sq.copy_(b_grads.dot(b_grads).reshape(1))
+        self._set_stale_actor_grad(b_grads)
         return {"alpha": float(alpha), "final_step_norm": float(torch.norm(step_direction)), "xHx": float(xHx),
                 "gradient_norm": float(torch.norm(grads)), "H_inv_g": float(x.norm()),
                 "acceptance_step": acceptance_step, "loss_actor": loss_reward_before + loss_cost_before, "kl": kl,
@@ -385,8 +412,11 @@ class CPOEngine(PPOLagEngine):
         if got != [0, 0, 0, 0]:
             for own in owns:
                 lib.spo_p2p_free(own)
-            raise _abi.SpoError(f"one-grid exchange self-test failed: {got} ({{wrong values, timeout}} per rank) -- the "
-                                "four workgroups of one grid must be co-resident; SPO_CPO_SPLIT=0 selects the one-launch form")
+            # HIP does not promise that the workgroups of a plain launch are co-resident (a shared or busy GPU): degrade to
+            # the one-launch form like the runtime timeout path of _critic_fit_split does, do not abort the training run
+            print(f"[cpo] one-grid exchange self-test failed: {got} ({{wrong values, timeout}} per rank); using the "
+                  "one-launch form of the critic fit", file=sys.stderr)
+            return None
         th = self.policy.theta
         st = {"regions": regions, "owns": owns, "step": 64,
               "sync_ws": torch.zeros(32, dtype=torch.int64, device=self.dev),
@@ -488,6 +518,153 @@ class CPOEngine(PPOLagEngine):
         return {"loss_r": means[0], "loss_c": means[1], "losses": all_losses}
 
 
+class WideCPOEngine(_WideOps, CPOEngine):
+    """CPOEngine for an ActorVCritic outside the envelope of the LDS-resident full-batch kernels (obs_dim > 64, act_dim > 16 or
+    hidden_sizes other than [64, 64]): the reference's default sweep pairs cpo / pcpo / rcpo / trpo_lag with 72-88-dim Car /
+    Doggo / Racecar observations and with HumanoidVelocity's 376 / 17 (single_agent/benchmark.py:5-44; model.py:131 takes any
+    dims).  Same update code (policy_update / trust_region_update / pcpo_update are inherited unchanged); the three full-batch
+    primitives run on the wide-network kernels in row chunks:
+      surrogate gradient   spo_mlp_forward -> spo_wide_actor_loss(mode 1) -> spo_mlp_backward          (cpo.py:356-381)
+      Fisher-vector prod.  spo_mlp_forward -> spo_mlp_jvp -> spo_wide_fvp_cotangent -> spo_mlp_backward (cpo.py:132-157;
+                           J^T diag(1/sigma^2) J v / (M A) applied analytically, no double backward)
+      line search sums     spo_mlp_forward -> spo_wide_linesearch_sums                                  (cpo.py:473-491)
+    The critic fit keeps the persistent two-critic kernel whenever the CRITICS fit it (hidden [64, 64], obs_dim <= 128: their
+    layout does not depend on act_dim), else runs minibatch by minibatch on the wide kernels with the actor's stale gradient
+    kept in the flat gradient vector so the joint clip sees and rescales it (cpo.py:557).  Single GPU."""
+
+    FAMILY = "cpo"          # what _WideOps._require_policy checks the policy against
+    CHUNK = 65536
+
+    def __init__(self, policy: ActorVCritic, num_envs: int, steps: int, config: dict, device, comm=None):
+        super().__init__(policy, num_envs, steps, config, device, comm=comm)
+        self._wide_init()
+        w = self.wide
+        assert self.Pa == w.A + w.Pa
+        self._gtmp = torch.zeros(w.P, dtype=torch.float32, device=self.dev)
+        self._critics_on_persistent_kernel = (list(policy.hidden_sizes) == [64, 64] and policy.obs_dim <= _abi.MAX_OBS)
+
+    def _alloc_full_batch_workspaces(self) -> None:
+        self.partial_ws = self.loss_ws = None           # the LDS-resident kernels' per-workgroup partial vectors: not used here
+
+    def _set_stale_actor_grad(self, vec: torch.Tensor) -> None:
+        super()._set_stale_actor_grad(vec)
+        self.flat_grad[self.ls_off:].copy_(vec)         # the wide critic fit clips over (and rescales) the vector itself
+
+    def _chunks(self):
+        d = self.buffer.data
+        obs, act = d["obs"].view(self.M, self.D), d["act"].view(self.M, self.A)
+        for lo in range(0, self.M, self.CHUNK):
+            hi = min(lo + self.CHUNK, self.M)
+            yield lo, hi, obs[lo:hi], act[lo:hi]
+
+    def _log_std(self):
+        return self.policy.theta[self.ls_off:self.ls_off + self.A]
+
+    def _surrogate_grad_local(self, adv: torch.Tensor, sign: float) -> torch.Tensor:
+        w, lib, d = self.wide, self.lib, self.buffer.data
+        adv, logp_old = adv.reshape(-1), d["log_prob"].view(-1)
+        g = torch.zeros(self.Pa, dtype=torch.float32, device=self.dev)
+        for k, (lo, hi, obs, act) in enumerate(self._chunks()):
+            mu, ws = w.forward("a", obs, slot=2)
+            d_mu = torch.empty((hi - lo, self.A), dtype=torch.float32, device=self.dev)
+            _abi.check(lib.spo_wide_actor_loss(_abi.WIDE_ACTOR_SURR, _abi.ptr(mu), _abi.ptr(self._log_std()), _abi.ptr(act),
+                                               _abi.ptr(logp_old[lo:hi]), _abi.ptr(adv[lo:hi]), None, None, hi - lo, self.M, self.A,
+                                               float(sign), 0.0, _abi.ptr(d_mu), _abi.ptr(self.actor_sums), int(k > 0), None, None,
+                                               _abi.ptr(self.loss_partials), self.loss_partials.numel(), _abi.stream_ptr()),
+                       "spo_wide_actor_loss")
+            w.backward("a", obs, ws, d_mu, self._gtmp)
+            g[self.A:] += self._gtmp[w.off_a:]
+        g[:self.A] = self.actor_sums[2:2 + self.A].to(torch.float32)
+        self.loss_sum.copy_(self.actor_sums[0:1])
+        return g
+
+    def _fvp_local(self, v: torch.Tensor) -> torch.Tensor:
+        w, lib = self.wide, self.lib
+        tangent = v[self.A:].contiguous()
+        out = torch.zeros(self.Pa, dtype=torch.float32, device=self.dev)
+        for lo, hi, obs, _ in self._chunks():
+            rows = hi - lo
+            _, ws = w.forward("a", obs, slot=2)
+            jv = torch.empty((rows, self.A), dtype=torch.float32, device=self.dev)
+            sc = w.jvp_scratch(rows)
+            _abi.check(lib.spo_mlp_jvp(_abi.ptr(w.theta_of("a")), w.net_a, _abi.ptr(tangent), _abi.ptr(obs), rows, _abi.ptr(ws),
+                                       _abi.ptr(jv), _abi.ptr(sc), _abi.stream_ptr()), "spo_mlp_jvp")
+            _abi.check(lib.spo_wide_fvp_cotangent(_abi.ptr(jv), _abi.ptr(self._log_std()), rows, self.M, self.A, _abi.ptr(jv),
+                                                  _abi.stream_ptr()), "spo_wide_fvp_cotangent")
+            w.backward("a", obs, ws, jv, self._gtmp)
+            out[self.A:] += self._gtmp[w.off_a:]
+        return out
+
+    def _linesearch_sums_local(self, adv_a, adv_b) -> None:
+        w, lib, d = self.wide, self.lib, self.buffer.data
+        adv_a, adv_b, logp_old = adv_a.reshape(-1), adv_b.reshape(-1), d["log_prob"].view(-1)
+        for k, (lo, hi, obs, act) in enumerate(self._chunks()):
+            mu, _ = w.forward("a", obs, slot=2)
+            _abi.check(lib.spo_wide_linesearch_sums(_abi.ptr(mu), _abi.ptr(self._log_std()), _abi.ptr(act), _abi.ptr(logp_old[lo:hi]),
+                                                    _abi.ptr(adv_a[lo:hi]), _abi.ptr(adv_b[lo:hi]), _abi.ptr(self.mean_old[lo:hi]),
+                                                    _abi.ptr(self.logstd_old), hi - lo, self.A, _abi.ptr(self.ls_partials),
+                                                    self.ls_partials.numel(), _abi.ptr(self.ls_sums), int(k > 0), _abi.stream_ptr()),
+                       "spo_wide_linesearch_sums")
+
+    def _cfg_struct(self):
+        cfg = super()._cfg_struct()
+        if self._in_persistent_critic_fit:
+            cfg.act_dim = min(cfg.act_dim, _abi.MAX_ACT)      # the two-critic kernel never touches the actor: its layout is act-free
+        return cfg
+
+    _in_persistent_critic_fit = False
+
+    def critic_fit(self, perm_fn=None):
+        """cpo.py:534-571."""
+        if self._critics_on_persistent_kernel:
+            self._in_persistent_critic_fit = True
+            try:
+                return CPOEngine.critic_fit(self, perm_fn)
+            finally:
+                self._in_persistent_critic_fit = False
+        c, w, lib, d = self.cfg, self.wide, self.lib, self.buffer.data
+        cfg = self._cfg_struct()
+        if perm_fn is None:
+            perm_fn = lambda it: torch.randperm(self.M, device=self.dev).to(torch.int32)
+        n_mb = (self.M + cfg.batch - 1) // cfg.batch
+        obs_all = d["obs"].view(self.M, self.D)
+        tr_all, tc_all = d["target_value_r"].view(-1), d["target_value_c"].view(-1)
+        g, part, cap = self.flat_grad, self.loss_partials, self.loss_partials.numel()
+        all_losses = []
+        for it in range(c["learning_iters"]):
+            perm = _abi.require_gpu_tensor(perm_fn(it), "perm", torch.int32).long()
+            losses = torch.empty((n_mb, 3), dtype=torch.float32, device=self.dev)
+            for k in range(n_mb):
+                idx = perm[k * cfg.batch:(k + 1) * cfg.batch]
+                obs, tgt_r, tgt_c = obs_all.index_select(0, idx), tr_all.index_select(0, idx), tc_all.index_select(0, idx)
+                n = obs.shape[0]
+                v_r, ws_r = w.forward("r", obs, slot=1)
+                v_c, ws_c = w.forward("c", obs, slot=1)
+                d_vr = torch.empty(n, dtype=torch.float32, device=self.dev)
+                d_vc = torch.empty_like(d_vr)
+                _abi.check(lib.spo_wide_critic_loss(_abi.ptr(v_r), _abi.ptr(v_c), _abi.ptr(tgt_r), _abi.ptr(tgt_c), n, _abi.ptr(d_vr),
+                                                    _abi.ptr(d_vc), _abi.ptr(losses[k]), _abi.ptr(part), cap, _abi.stream_ptr()),
+                           "spo_wide_critic_loss")
+                w.backward("r", obs, ws_r, d_vr, g)
+                w.backward("c", obs, ws_c, d_vc, g)
+                _abi.check(lib.spo_wide_clip_adam_ex(_abi.ptr(self.policy.theta), _abi.ptr(g), _abi.ptr(self.adam_m),
+                                                     _abi.ptr(self.adam_v), w.P, w.off_c, w.off_ls, w.off_ls, cfg, self.adam_step,
+                                                     self.adam_step, 0, w.off_ls, 0, 1, _abi.ptr(losses[k]), _abi.ptr(self.scal4),
+                                                     _abi.ptr(part), cap, _abi.stream_ptr()), "spo_wide_clip_adam_ex")
+                self.adam_step += 1
+            all_losses.append(losses[:, :2])
+        # keep the norm the persistent kernel would carry in step with the rescaled vector
+        self.stale_sq.copy_(g[self.ls_off:].dot(g[self.ls_off:]).reshape(1))
+        means = torch.cat(all_losses, 0).mean(0).tolist() if all_losses else [float("nan")] * 2
+        return {"loss_r": means[0], "loss_c": means[1], "losses": all_losses}
+
+
+def make_engine(policy, n_local, local_steps_per_epoch, config, device, comm=None):
+    """CPOEngine on the LDS-resident kernels when the policy fits them, WideCPOEngine otherwise (any dims / widths)."""
+    cls = CPOEngine if policy.kernels_supported("cpo") else WideCPOEngine
+    return cls(policy, n_local, local_steps_per_epoch, config, device, comm=comm)
+
+
 def _to_dev(x, dev):
     return torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x, dtype=torch.float32, device=dev).contiguous()
 
@@ -518,7 +695,7 @@ def main(args, cfg_env=None, _update="cpo"):
     policy = ActorVCritic(obs_dim=obs_space.shape[0], act_dim=act_space.shape[0],
                           hidden_sizes=config["hidden_sizes"]).to(device)
     comm.broadcast_(policy.theta, 0)                       # identical replicas
-    engine = CPOEngine(policy, n_local, local_steps_per_epoch, config, device, comm=comm)
+    engine = make_engine(policy, n_local, local_steps_per_epoch, config, device, comm=comm)
     dict_args = dict(vars(args))
     dict_args.update(config)
     is_root = comm.rank == 0

@@ -43,7 +43,8 @@ isaac_gym_specific_cfg = {
     'learning_iters': 8,
     'max_grad_norm': 1.0,
     'use_critic_norm': False,
-}
+    'batch_size': None,        # the reference REPLACES default_cfg for Isaac tasks (ppo_lag.py:77-91), so no batch_size survives:
+}                              # an override of None drops default_cfg's 64 and num_mini_batch decides (steps_per_epoch // 4)
 
 
 def main(args, cfg_env=None):

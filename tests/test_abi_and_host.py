@@ -92,6 +92,29 @@ def test_policy_parameter_layout_matches_reference_order():
     assert pol.theta[2 * 8129 + 8 + 3 * 60 + 5] == 42.0
     with pytest.raises(NotImplementedError):
         ActorVCritic(60, 8, hidden_sizes=[1024, 1024, 512])._require_kernels()
+    # routing by (obs_dim, act_dim) too (round 4): what the persistent kernels cannot hold goes to the wide path, the
+    # full-batch CPO kernels have the narrower envelope (obs_dim <= 64)
+    for (D, A, hs), ppo_ok, cpo_ok in [((60, 8, [64, 64]), True, True), ((72, 2, [64, 64]), True, False),
+                                       ((128, 16, [64, 64]), True, False), ((129, 4, [64, 64]), False, False),
+                                       ((376, 17, [64, 64]), False, False), ((10, 17, [64, 64]), False, False),
+                                       ((60, 8, [128, 128]), False, False)]:
+        p2 = ActorVCritic(D, A, hidden_sizes=hs)
+        assert p2.kernels_supported() is ppo_ok and p2.kernels_supported("cpo") is cpo_ok, (D, A, hs)
+    with pytest.raises(NotImplementedError):
+        ActorVCritic(72, 2)._require_kernels("cpo")
+
+
+def test_isaac_cfg_override_selects_the_num_mini_batch_regime():
+    """passing the exported isaac_gym_specific_cfg itself as cfg_override must give minibatches of
+    steps_per_epoch // num_mini_batch rows (the reference REPLACES default_cfg for Isaac tasks, ppo_lag.py:77-91, so no
+    batch_size of 64 survives) -- the merge of _first_order.run, without a GPU."""
+    from safepo.single_agent import ppo_lag
+    config = dict(ppo_lag.default_cfg)
+    config.update(ppo_lag.isaac_gym_specific_cfg)
+    config = {k: v for k, v in config.items() if v is not None}          # _first_order.run
+    assert "batch_size" not in config and config["num_mini_batch"] == 4 and config["hidden_sizes"] == [1024, 1024, 512]
+    M = config["steps_per_epoch"]
+    assert config.get("batch_size", max(M // config.get("num_mini_batch", 1), 1)) == M // 4 == 8192      # PPOLagEngine._cfg_struct
 
 
 def test_cli_flags_match_reference_table():

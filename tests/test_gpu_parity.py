@@ -1146,15 +1146,19 @@ def test_limits_and_edge_shapes(dev):
     losses = eng.learning_iter(perm.to(torch.int32).to(dev))
     np.testing.assert_allclose(losses.cpu().numpy(), np.asarray(lr), rtol=1e-4, atol=2e-6)
     _assert_params_close(pol.theta.cpu().numpy(), R.flat_params(ref).numpy(), 3e-4, 2, what="64x16")
-    # outside the envelope: loud failures
+    # outside the envelope of the LDS-resident kernels: ROUTED to the wide path (tests/test_gpu_wide_dims.py), not refused;
+    # the C entry points themselves still fail loudly when called with dims they are not built for
+    from safepo.single_agent.cpo import CPOEngine, WideCPOEngine, make_engine, default_cfg as cpo_cfg
+    assert type(make_engine(ActorVCritic(100, 4).to(dev), 2, 8, dict(cpo_cfg), dev)) is WideCPOEngine
+    with pytest.raises(NotImplementedError, match="obs_dim <= 64"):
+        CPOEngine(ActorVCritic(100, 4).to(dev), 2, 8, dict(cpo_cfg), dev)
+    lib, z = _abi.load(), torch.zeros(4096, device=dev)
     with pytest.raises(_abi.SpoError, match="obs_dim"):
-        ActorVCritic(129, 4).to(dev).step(torch.zeros(2, 129, device=dev))
-    from safepo.single_agent.cpo import CPOEngine, default_cfg as cpo_cfg
-    with pytest.raises(_abi.SpoError, match="obs_dim"):
-        e3 = CPOEngine(ActorVCritic(100, 4).to(dev), 2, 8, dict(cpo_cfg), dev)
-        e3.fvp(torch.zeros(e3.Pa, device=dev))
+        _abi.check(lib.spo_values(_abi.ptr(z), _abi.ptr(z), _abi.ptr(z), _abi.ptr(z), 2, 129, 4, None), "spo_values")
     with pytest.raises(_abi.SpoError, match="act_dim"):
-        ActorVCritic(10, 17).to(dev).step(torch.zeros(2, 10, device=dev))
+        _abi.check(lib.spo_values(_abi.ptr(z), _abi.ptr(z), _abi.ptr(z), _abi.ptr(z), 2, 10, 17, None), "spo_values")
+    with pytest.raises(_abi.SpoError, match="obs_dim"):
+        _abi.check(lib.spo_cpo_fvp(_abi.ptr(z), _abi.ptr(z), _abi.ptr(z), 2, 100, 4, _abi.ptr(z), _abi.ptr(z), _abi.ptr(z), None), "spo_cpo_fvp")
     smoke_check(num_envs=1, steps=3, seed=3)     # (M=1 gives std()=NaN in the reference too)
 
 
@@ -1764,7 +1768,7 @@ class _Sp:
                                                (100, 512, 2, 1, False, 259), (7, 33, 1, 2, True, 5), (64, 128, 2, 16, True, 4100),
                                                (48, 128, 1, 9, True, 2049)])
 def test_ma_network_forward_backward_vs_oracle(dev, D, H, nb, O, actor, B):
-    """LayerNorm -> [Linear, ELU, LayerNorm] x nb -> head: outputs and the full flat gradient (rocBLAS GEMMs + fused
+    """LayerNorm -> [Linear, ELU, LayerNorm] x nb -> head: outputs and the full flat gradient (in-tree MFMA GEMMs + fused
     LayerNorm/ELU kernels) against torch autograd on the CPU restatement."""
     from oracle import ma_restatement as MR
     from safepo.common.model import MultiAgentActor, MultiAgentCritic
@@ -1941,7 +1945,7 @@ def test_ma_happo_mappo_runner_end_to_end_synthetic(dev, tmp_path, algo):
 
 @pytest.mark.parametrize("D,H,nb,O,B", [(20, 32, 3, 5, 97), (48, 128, 2, 6, 1030), (33, 64, 1, 3, 260)])
 def test_ma_network_tangent_pass_vs_autograd(dev, D, H, nb, O, B):
-    """spo_ma_jvp (forward-mode pass: rocBLAS GEMMs + LayerNorm/ELU tangent kernel) against torch.func.jvp on the CPU
+    """spo_ma_jvp (forward-mode pass: in-tree MFMA GEMMs + LayerNorm/ELU tangent kernel) against torch.func.jvp on the CPU
     restatement, and the Fisher-vector product built from it against the reference's double-backward form."""
     from torch.func import functional_call, jvp
     from oracle import ma_restatement as MR
@@ -2726,8 +2730,8 @@ def test_wide_kl_and_entrypoint_synthetic(dev, tmp_path):
     assert eng.kl_to_old() == pytest.approx(R.actor_kl(ref, obs, old_mean, old_std), rel=2e-5)
     assert set(ppo_lag.isaac_gym_specific_cfg) >= {"hidden_sizes", "num_mini_batch", "use_value_coefficient", "use_critic_norm"}
     for tag, override in (("w128", {"hidden_sizes": [128, 128], "learning_iters": 2, "batch_size": 256}),
-                          ("isaac_shape", {"hidden_sizes": [96, 64, 32], "num_mini_batch": 4, "batch_size": None, "learning_iters": 2,
-                                           "use_value_coefficient": True, "use_critic_norm": False, "max_grad_norm": 1.0})):
+                          ("isaac_shape", dict(ppo_lag.isaac_gym_specific_cfg, hidden_sizes=[96, 64, 32], learning_iters=2,
+                                               total_steps=2 * 16 * 64, steps_per_epoch=16 * 64))):       # the exported dict itself
         cfg_run = dict(override)                   # "batch_size": None removes default_cfg's key: minibatches of M // num_mini_batch rows
         args = argparse.Namespace(seed=0, use_eval=False, task="SynthSafe-v0", num_envs=16, experiment="t",
                                   log_dir=str(tmp_path / tag / "task" / "run"), device="cuda", device_id=0, write_terminal=True,

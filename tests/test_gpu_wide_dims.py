@@ -1,0 +1,318 @@
+"""GPU parity tests of the round-4 fallback path: ANY (obs_dim, act_dim, hidden_sizes) for every single-agent script.
+
+The reference's `ActorVCritic(obs_dim, act_dim, hidden_sizes)` takes any dims (safepo/common/model.py:131) and its default sweep
+(safepo/single_agent/benchmark.py:5-44) pairs cpo / pcpo / rcpo / trpo_lag / focops / cup / ppo_lag / cppo_pid with 72-88-dim
+Car / Doggo / Racecar observations and with HumanoidVelocity's 376 observations / 17 actions.  Shapes outside the LDS-resident
+kernels' envelope are routed to the wide-network kernels instead of being refused; these tests pin that path to the CPU oracle
+(oracle/restatement.py: the reference's own torch calls) at the north_star tolerance (1e-5 relative for first steps; the
+fp64-yardstick gate for multi-step quantities)."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import restatement as R  # noqa: E402  (checker only)
+from test_gpu_parity import _assert_params_close, _synthetic_update_problem, _wide_pair  # noqa: E402
+
+# (obs_dim, act_dim, hidden_sizes): Car-class observations, HumanoidVelocity, a wide action vector on a narrow net
+SHAPES = [(72, 2, [64, 64]), (376, 17, [64, 64]), (60, 33, [32, 48])]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def test_routing_by_dims_instead_of_errors(dev):
+    """kernels_supported() looks at (obs_dim, act_dim) too: what the persistent kernels cannot hold is ROUTED to the wide
+    engines -- the former SpoError cases of test_limits_and_edge_shapes now compute."""
+    from safepo.common.engine import PPOLagEngine, WidePPOLagEngine
+    from safepo.common.model import ActorVCritic
+    from safepo.single_agent import cpo
+    cases = [((60, 8, [64, 64]), True, True), ((72, 2, [64, 64]), True, False), ((128, 16, [64, 64]), True, False),
+             ((129, 4, [64, 64]), False, False), ((376, 17, [64, 64]), False, False), ((10, 17, [64, 64]), False, False),
+             ((60, 8, [128, 128]), False, False)]
+    for (D, A, hs), ppo_ok, cpo_ok in cases:
+        pol = ActorVCritic(D, A, hidden_sizes=hs)
+        assert pol.kernels_supported("ppo") is ppo_ok and pol.kernels_supported("cpo") is cpo_ok, (D, A, hs)
+    cfg = dict(cpo.default_cfg)
+    for D, A in ((100, 4), (376, 17)):
+        pol = ActorVCritic(D, A).to(dev)
+        eng = cpo.make_engine(pol, 2, 8, cfg, dev)
+        assert type(eng) is cpo.WideCPOEngine
+        hv = eng.fvp(torch.ones(eng.Pa, device=dev))          # the round-3 build raised "cpo: obs_dim outside [1,64]" here
+        assert torch.isfinite(hv).all()
+    assert type(cpo.make_engine(ActorVCritic(60, 8).to(dev), 2, 8, cfg, dev)) is cpo.CPOEngine
+    a, lp, vr, vc = ActorVCritic(129, 4).to(dev).step(torch.zeros(2, 129, device=dev))      # was: SpoError "obs_dim"
+    assert a.shape == (2, 4) and torch.isfinite(lp).all()
+    a, lp, vr, vc = ActorVCritic(10, 17).to(dev).step(torch.zeros(2, 10, device=dev))       # was: SpoError "act_dim"
+    assert a.shape == (2, 17) and torch.isfinite(lp).all()
+    pcfg = {"hidden_sizes": [64, 64], "gamma": 0.99, "target_kl": 1e9, "batch_size": 64, "learning_iters": 1, "max_grad_norm": 40.0}
+    with pytest.raises(NotImplementedError):
+        PPOLagEngine(ActorVCritic(376, 17).to(dev), 1, 64, pcfg, dev)
+    with pytest.raises(ValueError):
+        WidePPOLagEngine(ActorVCritic(60, 8).to(dev), 1, 64, pcfg, dev)
+    from safepo import _abi
+    with pytest.raises(_abi.SpoError, match="act_dim"):
+        WidePPOLagEngine(ActorVCritic(10, 65).to(dev), 1, 64, pcfg, dev)
+
+
+@pytest.mark.parametrize("D,A,hidden", [(376, 17, [64, 64]), (200, 20, [64, 64]), (60, 33, [32, 48]), (129, 4, [64, 64])])
+def test_wide_dims_policy_step_vs_oracle(dev, D, A, hidden):
+    """ActorVCritic.step (model.py:149-170) for dims beyond the persistent kernels' envelope, against the oracle."""
+    n = 131
+    pol, ref = _wide_pair(D, A, hidden, dev, seed=D + A)
+    g = torch.Generator().manual_seed(n)
+    obs, eps = torch.randn(n, D, generator=g), torch.randn(n, A, generator=g)
+    act, logp, v_r, v_c = pol.step(obs.to(dev), eps=eps.to(dev))
+    with torch.no_grad():
+        a_ref, lp_ref, vr_ref, vc_ref = ref.step_with_eps(obs, eps)
+    tol = dict(rtol=2e-5, atol=5e-6)
+    np.testing.assert_allclose(act.cpu().numpy(), a_ref.numpy(), **tol)
+    np.testing.assert_allclose(logp.cpu().numpy(), lp_ref.numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(v_r.cpu().numpy(), vr_ref.numpy(), **tol)
+    np.testing.assert_allclose(v_c.cpu().numpy(), vc_ref.numpy(), **tol)
+
+
+def _cpo_problem(D, A, hidden, M, dev, seed, chunk):
+    from safepo.single_agent import cpo
+    pol, ref = _wide_pair(D, A, hidden, dev, seed=seed)
+    cfg = dict(cpo.default_cfg)
+    cfg["hidden_sizes"] = hidden
+    eng = cpo.make_engine(pol, 1, M, cfg, dev)
+    assert type(eng) is cpo.WideCPOEngine
+    eng.CHUNK = chunk
+    obs, act, logp, tgt_r, tgt_c, adv = _synthetic_update_problem(M, D, A, seed=seed + 1)
+    adv_c = adv.flip(0) * 0.5 + 0.1
+    b = eng.buffer
+    b.data["obs"].copy_(obs.view(1, M, D)); b.data["act"].copy_(act.view(1, M, A)); b.data["log_prob"].copy_(logp.view(1, M))
+    b.data["adv_r"].copy_(adv.view(1, M)); b.data["adv_c"].copy_(adv_c.view(1, M))
+    b.data["target_value_r"].copy_(tgt_r.view(1, M)); b.data["target_value_c"].copy_(tgt_c.view(1, M))
+    data = {"obs": obs, "act": act, "log_prob": logp, "adv_r": adv, "adv_c": adv_c, "target_value_r": tgt_r, "target_value_c": tgt_c}
+    return pol, ref, eng, data
+
+
+@pytest.mark.parametrize("D,A,hidden", SHAPES + [(60, 8, [128, 128])])
+def test_wide_cpo_primitives_vs_oracle(dev, D, A, hidden):
+    """The three full-batch primitives of the second-order scripts on the wide kernels, in row chunks (3 chunks + a ragged
+    tail): both surrogate gradients (cpo.py:356-381) against autograd, the Fisher-vector product against the reference's
+    DOUBLE BACKWARD (cpo.py:132-157) in float32 and float64, the line-search sums (cpo.py:473-491) at the old and at moved
+    parameters."""
+    M = 3000 + 37
+    pol, ref, eng, data = _cpo_problem(D, A, hidden, M, dev, seed=7 + D, chunk=1024)
+    b = eng.buffer
+    for which, key, sign in (("r", "adv_r", -1.0), ("c", "adv_c", 1.0)):
+        ref.actor.zero_grad()
+        loss = R.cpo_surrogate(ref, data, which)
+        loss.backward()
+        g_ref = R.actor_flat_grads(ref.actor).numpy()
+        g, mean = eng.surrogate_grad(b.data[key], sign)
+        np.testing.assert_allclose(g.cpu().numpy(), g_ref, rtol=1e-4, atol=1e-5 * np.abs(g_ref).max())
+        assert sign * mean == pytest.approx(float(loss.detach()), rel=1e-5)
+    v = torch.randn(eng.Pa, generator=torch.Generator().manual_seed(3))
+    hv32 = R.cpo_fvp(v, ref, data["obs"]).double().numpy()
+    hv64 = R.cpo_fvp(v.double(), copy.deepcopy(ref).double(), data["obs"].double()).numpy()
+    hv = eng.fvp(v.to(dev)).double().cpu().numpy()
+    scale = np.abs(hv64).max()
+    d_hip, d_32 = np.abs(hv - hv64).max(), np.abs(hv32 - hv64).max()
+    assert d_hip <= 3.0 * d_32 + 1e-6 * scale, (d_hip, d_32, scale)      # fp64 yardstick: as close as the reference's own fp32
+    np.testing.assert_allclose(hv, hv32, rtol=1e-4, atol=1e-5 * scale)
+    # line search: unchanged parameters -> KL == 0 and the two surrogates; moved parameters -> the oracle's values
+    eng.snapshot_old_distribution()
+    l_r, l_c, kl = eng.linesearch_eval()
+    assert kl == pytest.approx(0.0, abs=1e-9)
+    assert l_r == pytest.approx(float(R.cpo_surrogate(ref, data, "r")), rel=1e-5)
+    assert l_c == pytest.approx(float(R.cpo_surrogate(ref, data, "c")), rel=1e-5)
+    with torch.no_grad():
+        old = ref.actor(data["obs"])
+        old_mean, old_std = old.mean.clone(), old.stddev.clone()
+        delta = 0.02 * torch.randn(eng.Pa, generator=torch.Generator().manual_seed(5))
+        eng.theta_actor.add_(delta.to(dev))
+        R.actor_set_flat_params(ref.actor, R.actor_flat_params(ref.actor) + delta)
+        new = ref.actor(data["obs"])
+        kl_ref = float(torch.distributions.kl_divergence(torch.distributions.Normal(old_mean, old_std), new).mean())
+    l_r, l_c, kl = eng.linesearch_eval()
+    assert kl == pytest.approx(kl_ref, rel=2e-5)
+    assert l_r == pytest.approx(float(R.cpo_surrogate(ref, data, "r")), rel=2e-5, abs=1e-7)
+    assert l_c == pytest.approx(float(R.cpo_surrogate(ref, data, "c")), rel=2e-5, abs=1e-7)
+
+
+@pytest.mark.parametrize("D,A,hidden,ep_costs", [(72, 2, [64, 64], -1.0), (376, 17, [64, 64], 0.3), (376, 17, [64, 64], -1.0)])
+def test_wide_cpo_actor_step_drift_envelope(dev, D, A, hidden, ep_costs):
+    """CPO's whole trust-region step (cpo.py:350-532) through WideCPOEngine under the fp64-yardstick gate of
+    test_cpo_actor_step_drift_envelope: discrete decisions equal, curvature / step length / parameters at most 3x as far from
+    the float64 step as the float32 oracle is."""
+    M = 4096
+    pol, ref32, eng, data32 = _cpo_problem(D, A, hidden, M, dev, seed=14, chunk=1500)
+    ref64 = copy.deepcopy(ref32).double()
+    data64 = {k: v.double() for k, v in data32.items()}
+    tk = eng.cfg["target_kl"]
+    o32 = R.cpo_policy_update(ref32, data32, ep_costs, target_kl=tk)
+    o64 = R.cpo_policy_update(ref64, data64, ep_costs, target_kl=tk)
+    th32 = R.actor_flat_params(ref32.actor).double().numpy()
+    th64 = R.actor_flat_params(ref64.actor).double().numpy()
+    out = eng.policy_update(ep_costs)
+    th_hip = eng.theta_actor.double().cpu().numpy()
+    assert out["case"] == o32["case"] == o64["case"]
+    assert out["acceptance_step"] == o32["accept"] == o64["accept"]
+    for name, hip, v32, v64 in (("xHx", out["xHx"], float(o32["xHx"]), float(o64["xHx"])),
+                                ("alpha", out["alpha"], float(o32["alpha"]), float(o64["alpha"]))):
+        assert abs(hip - v64) <= 3.0 * abs(v32 - v64) + 2e-6 * abs(v64), (name, hip, v32, v64)
+    d_hip, d_32 = np.abs(th_hip - th64), np.abs(th32 - th64)
+    scale = np.abs(th64).max()
+    assert np.linalg.norm(d_hip) <= 3.0 * np.linalg.norm(d_32) + 1e-7 * scale * np.sqrt(th64.size), (np.linalg.norm(d_hip), np.linalg.norm(d_32))
+    assert d_hip.max() <= 3.0 * d_32.max() + 1e-6 * scale, (d_hip.max(), d_32.max())
+    # the stale actor gradient the critic fit's joint clip will see (cpo.py:557) is the cost gradient b
+    np.testing.assert_allclose(eng.flat_grad[eng.ls_off:].cpu().numpy(), out["b"].cpu().numpy())
+
+
+@pytest.mark.parametrize("D,A,hidden,persistent", [(72, 2, [64, 64], True), (376, 17, [64, 64], False), (60, 33, [32, 48], False)])
+def test_wide_cpo_critic_fit_vs_oracle(dev, D, A, hidden, persistent, monkeypatch):
+    """Critic fit (cpo.py:534-571) of WideCPOEngine: on the persistent two-critic kernel when the critics fit it (obs 72: the
+    KIN = 128 instantiation with act_dim irrelevant), minibatch by minibatch on the wide kernels otherwise -- with the stale
+    actor gradient taking part in, and being rescaled by, the joint clip."""
+    M, iters, batch = 1024, 2, 128
+    monkeypatch.setenv("SPO_CPO_SPLIT", "0")
+    pol, ref, eng, data = _cpo_problem(D, A, hidden, M, dev, seed=5, chunk=4096)
+    eng.cfg.update(learning_iters=iters, batch_size=batch)
+    assert eng._critics_on_persistent_kernel is persistent
+    n_act = sum(p.numel() for p in ref.actor.parameters())
+    stale = torch.full((n_act,), 50.0 / np.sqrt(n_act))             # norm 50 > max_grad_norm 40: the clip is active
+    eng._set_stale_actor_grad(stale.to(dev))
+    for p in ref.actor.parameters():
+        p.grad = torch.full_like(p, 50.0 / np.sqrt(n_act))
+    g = torch.Generator().manual_seed(5)
+    perms = [torch.randperm(M, generator=g).to(torch.int32) for _ in range(iters)]
+    fit = eng.critic_fit(perm_fn=lambda it: perms[it].to(dev))
+    fitter = R.CriticFitter(ref)
+    want = []
+    for it in range(iters):
+        pm = perms[it].long()
+        for k in range(M // batch):
+            idx = pm[k * batch:(k + 1) * batch]
+            want.append(fitter.minibatch_step(data["obs"][idx], data["target_value_r"][idx], data["target_value_c"][idx]))
+    got = torch.cat(fit["losses"], 0).cpu().numpy()
+    np.testing.assert_allclose(got[0], np.asarray(want)[0], rtol=1e-5, atol=1e-6)          # first step: 1e-5
+    np.testing.assert_allclose(got, np.asarray(want), rtol=2e-4, atol=2e-6)
+    want_th = torch.cat([p.detach().reshape(-1) for p in ref.parameters()]).numpy()
+    n_crit = want_th.size - n_act
+    _assert_params_close(pol.theta.cpu().numpy()[:n_crit], want_th[:n_crit], 1e-3, iters * (M // batch), rtol=2e-3, atol=2e-5,
+                         what="critics after the fit")
+    # the actor's parameters are untouched by the critic fit; its stale gradient shrank exactly like the oracle's .grad
+    np.testing.assert_array_equal(pol.theta.cpu().numpy()[n_crit:], want_th[n_crit:])
+    want_stale = torch.cat([p.grad.reshape(-1) for p in ref.actor.parameters()])
+    if not persistent:
+        np.testing.assert_allclose(eng.flat_grad[eng.ls_off:].cpu().numpy(), want_stale.numpy(), rtol=2e-4)
+    assert float(eng.stale_sq.item()) == pytest.approx(float(want_stale.dot(want_stale)), rel=1e-3)
+
+
+@pytest.mark.parametrize("D,A,hidden,actor_only", [(376, 17, [64, 64], False), (376, 17, [64, 64], True), (60, 33, [32, 48], False),
+                                                   (60, 8, [128, 128], True)])
+def test_wide_kl_penalty_minibatch_steps_vs_oracle(dev, D, A, hidden, actor_only):
+    """FOCOPS's minibatch step (focops.py:312-347) and CUP's actor-only second stage (cup.py:370-386) on the wide kernels:
+    the test_kl_penalty_minibatch_steps_vs_oracle protocol (indicator active on part of the batch, the actor's optimiser clock
+    ahead of the critics', partial last batch) for shapes the persistent kernels do not hold."""
+    from safepo import _abi
+    from safepo.common.engine import WidePPOLagEngine
+    M = 192 + 22
+    pol, ref = _wide_pair(D, A, hidden, dev, seed=M + D)
+    obs, act, logp, tgt_r, tgt_c, adv = _synthetic_update_problem(M, D, A, seed=M)
+    with torch.no_grad():
+        dist = ref.actor(obs)
+        old_mean = dist.mean + 0.05 * torch.randn(M, A)
+        old_std = dist.stddev[0] * torch.exp(0.05 * torch.randn(A))
+        kl0 = torch.distributions.kl_divergence(dist, torch.distributions.Normal(old_mean, old_std.expand(M, A))).sum(-1)
+    kl_bound = float(kl0.quantile(0.55)) if not actor_only else float("inf")
+    pg_coef = 1 / 1.5 if not actor_only else -0.37
+    cfg = {"hidden_sizes": hidden, "gamma": 0.99, "target_kl": 1e9, "batch_size": 64, "learning_iters": 1, "max_grad_norm": 40.0}
+    eng = WidePPOLagEngine(pol, 1, M, cfg, dev)
+    b = eng.buffer
+    b.data["obs"].copy_(obs.view(1, M, D)); b.data["act"].copy_(act.view(1, M, A)); b.data["log_prob"].copy_(logp.view(1, M))
+    b.data["target_value_r"].copy_(tgt_r.view(1, M)); b.data["target_value_c"].copy_(tgt_c.view(1, M))
+    eng.mean_old.copy_(old_mean); eng.std_old.copy_(old_std)
+    perm = torch.randperm(M, generator=torch.Generator().manual_seed(3))
+    upd = R.KLPenaltyUpdater(ref)
+    for _ in range(5):                              # the actor's Adam clock runs 5 steps ahead (zero gradients: moments stay 0)
+        upd.opt_a.zero_grad()
+        for prm in ref.actor.parameters():
+            prm.grad = torch.zeros_like(prm)
+        upd.opt_a.step()
+    eng.adam_step_actor_extra = 5
+    theta0 = pol.theta.clone()
+    os_full = old_std.expand(M, A)
+    ref_losses, n_masked = [], 0
+    for s0 in range(0, M, 64):
+        idx = perm[s0:s0 + 64]
+        with torch.no_grad():
+            kl_i = torch.distributions.kl_divergence(ref.actor(obs[idx]), torch.distributions.Normal(old_mean[idx], os_full[idx])).sum(-1)
+            n_masked += int((kl_i > kl_bound).sum())
+        if actor_only:
+            l = upd.cup_second_stage_step(obs[idx], act[idx], logp[idx], adv[idx], old_mean[idx], os_full[idx],
+                                          0.37 / ((1 - 0.99 * 0.95) / (1 - 0.99)), 0.99)
+            ref_losses.append([np.nan, np.nan, l])
+        else:
+            ref_losses.append(list(upd.focops_step(obs[idx], act[idx], logp[idx], tgt_r[idx], tgt_c[idx], adv[idx],
+                                                   old_mean[idx], os_full[idx], kl_bound)))
+    if not actor_only:
+        assert 0 < n_masked < M, n_masked
+    losses = eng.learning_iter_ex(perm.to(torch.int32).to(dev), adv.to(dev).contiguous(), _abi.ACTOR_LOSS_KL_PENALTY, kl_bound,
+                                  pg_coef, actor_only)
+    got = losses.cpu().numpy()
+    np.testing.assert_allclose(got[0], np.asarray(ref_losses)[0], rtol=1e-5, atol=2e-6, equal_nan=True)      # first step: 1e-5
+    np.testing.assert_allclose(got, np.asarray(ref_losses), rtol=2e-4, atol=3e-6, equal_nan=True)
+    n_steps = (M + 63) // 64
+    _assert_params_close(pol.theta.cpu().numpy(), R.flat_params(ref).numpy(), 3e-4, n_steps, rtol=5e-4, atol=5e-6, what="theta after one pass")
+    if actor_only:
+        off = pol.log_std_offset
+        assert torch.equal(pol.theta[:off], theta0[:off])
+        assert eng.adam_step == 0 and eng.adam_step_actor_extra == 5 + n_steps
+
+
+@pytest.mark.parametrize("D,A,batch,steps", [(376, 17, 64, 6), (200, 20, 100, 3)])
+def test_wide_dims_ppo_minibatch_steps_vs_oracle(dev, D, A, batch, steps):
+    """ppo_lag.py:306-329 at dims beyond the persistent kernels: per-step losses at 1e-5, parameters after the steps."""
+    from safepo.common.engine import WidePPOLagEngine
+    from test_gpu_parity import _fill_update_problem
+    hidden = [64, 64]
+    pol, ref = _wide_pair(D, A, hidden, dev, seed=3)
+    M = batch * steps
+    cfg = {"hidden_sizes": hidden, "gamma": 0.99, "target_kl": 0.02, "batch_size": batch, "learning_iters": 1, "max_grad_norm": 40.0}
+    eng = WidePPOLagEngine(pol, 1, M, cfg, dev)
+    problem = _synthetic_update_problem(M, D, A, seed=17)
+    _fill_update_problem(eng, problem)
+    perm = torch.randperm(M, generator=torch.Generator().manual_seed(2))
+    losses = eng.learning_iter(perm.to(torch.int32).to(dev)).cpu().numpy()
+    upd = R.PPOLagUpdater(ref, epochs=1, max_grad_norm=40.0)
+    obs, act, logp, tgt_r, tgt_c, adv = problem
+    want = [upd.minibatch_step(*(t[perm[k * batch:(k + 1) * batch]] for t in (obs, act, logp, tgt_r, tgt_c, adv))) for k in range(steps)]
+    np.testing.assert_allclose(losses, np.asarray(want), rtol=1e-5, atol=2e-6)
+    _assert_params_close(pol.theta.cpu().numpy(), R.flat_params(ref).numpy(), 3e-4, steps, rtol=2e-4, atol=2e-6, what=f"wide dims {D}x{A}")
+
+
+@pytest.mark.parametrize("algo", ["ppo_lag", "cppo_pid", "focops", "cup", "cpo", "pcpo", "rcpo", "trpo_lag"])
+def test_default_sweep_algorithms_train_at_humanoid_dims(dev, tmp_path, algo):
+    """`ActorVCritic(376, 17)` trains under every algorithm of the reference's default sweep (benchmark.py:33-44) on the
+    synthetic env: main() end to end -- collect, boundary logic, GAE, update, logger columns."""
+    import argparse
+    import csv
+    import importlib
+    mod = importlib.import_module(f"safepo.single_agent.{algo}")
+    args = argparse.Namespace(seed=0, use_eval=False, task="SynthSafe-v0", num_envs=16, experiment="t",
+                              log_dir=str(tmp_path / algo / "task" / "run"), device="cuda", device_id=0, write_terminal=True,
+                              headless=False, total_steps=2 * 16 * 32, steps_per_epoch=16 * 32, randomize=False, cost_limit=25.0,
+                              lagrangian_multiplier_init=0.001, lagrangian_multiplier_lr=0.035,
+                              cfg_override={"learning_iters": 2, "batch_size": 128},
+                              env_kwargs={"trunc_len": 16, "obs_dim": 376, "act_dim": 17})
+    out = mod.main(args, {})
+    rows = list(csv.DictReader(open(tmp_path / algo / "task" / "run" / "progress.csv")))
+    assert len(rows) == 2
+    assert type(out["engine"]).__name__ in ("WidePPOLagEngine", "WideCPOEngine")
+    assert out["policy"].obs_dim == 376 and out["policy"].act_dim == 17
+    for col in ("Loss/Loss_actor", "Loss/Loss_reward_critic", "Loss/Loss_cost_critic", "Train/KL"):
+        assert np.isfinite(float(rows[-1][col])), (col, rows[-1][col])
