@@ -251,7 +251,9 @@ class OracleMATrainer:
             case = 3 if (rescale < 0 and wrp < 0) else 2 if (rescale < 0) else 1 if wrp >= 0 else 0
         if wrp == 0:
             wrp = 1e-8
-        sqrt = lambda v: float(torch.sqrt(torch.tensor(float(v))))
+        # the reference takes these roots of fp32 tensors; a float64 evaluation (the tests' yardstick) takes them in double
+        f64 = self.actor.head.weight.dtype == torch.float64
+        sqrt = (lambda v: math.sqrt(float(v))) if f64 else (lambda v: float(torch.sqrt(torch.tensor(float(v)))))
         if case in (3, 4):
             lam, nu = sqrt(q / (2 * tkl)), 0.0
         elif case in (1, 2):
