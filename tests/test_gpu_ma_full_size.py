@@ -1,0 +1,134 @@
+"""MAPPO-L parity AT THE SHAPE the driver-visible `config5_mappolag` figure runs: 4 agents x obs 48 /
+act 6, shared observation 96, hidden 128, layer_N 2 (the mamujoco overrides of safepo/multi_agent/mappolag.py on top of the
+reference defaults), 8 192 rollout threads x 64 steps = 524 288 rows per full-batch network step.
+
+Reference: safepo/multi_agent/mappolag.py:135-234 (MAPPO_L_Trainer.ppo_update / train), safepo/common/buffer.py:356-384 (masked GAE
+with PopArt de-normalisation), safepo/common/popart.py:45-133.  The oracle (oracle/ma_restatement.py, pinned to the reference's own
+trainer at 2e-5 by tests/test_oracle_golden.py) takes the same steps in float32 and in float64; gate = the fp64 yardstick of
+tests/ma_yardstick.py."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+THREADS, T, AGENTS, D, A = 8192, 64, 4, 48, 6
+S = D * AGENTS // 2            # SynthMultiAgentEnv's shared observation (tools/ma_bench.py: the bench's shape)
+ROWS = THREADS * T
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+class _Sp:
+    def __init__(self, n):
+        self.shape = (n,)
+
+
+def _cfg(dev, **over):
+    from safepo.multi_agent import mappolag
+    cfg = dict(mappolag.default_cfg)
+    cfg.update(mappolag.mamujoco_cfg)
+    cfg.update(device=str(dev), n_rollout_threads=THREADS, episode_length=T, hidden_size=128, **over)
+    return cfg
+
+
+def _sample(rows, seed):
+    """One full-batch sample with the statistics of a real epoch: standardised advantages, ~3 % inactive rows, old
+    log-probabilities near the current policy's (ratios around 1, a few per cent outside the clip range)."""
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *shape: torch.randn(*shape, generator=g)
+    s = {"share_obs": r(rows, S) * 1.3 + 0.2, "obs": r(rows, D) * 1.5 - 0.1, "actions": r(rows, A) * 0.6,
+         "value_preds": r(rows, 1) * 0.8, "returns": r(rows, 1) * 1.1 + 0.3, "cost_preds": r(rows, 1).abs() * 0.5,
+         "cost_returns": r(rows, 1).abs() * 0.6, "adv": r(rows, 1), "cost_adv": r(rows, 1),
+         "active_masks": (torch.rand(rows, 1, generator=g) > 0.03).float(), "factor": torch.exp(0.05 * r(rows, 1)),
+         "aver_episode_costs": torch.full((THREADS, 1), 31.0)}
+    return s
+
+
+def test_config5_shape_ppo_update_fp64_yardstick(dev):
+    """Five MAPPO_L_Trainer.ppo_update steps of the actor and both critics (PopArt on, in-loop multiplier) over 524 288 rows:
+    per-step losses / gradient norms / entropy / ratio / multiplier / PopArt statistics, the three flat PRE-CLIP gradients of
+    step 1 and step 5, and the parameters after step 1 and step 5 -- |HIP - f64| <= 3 |f32 oracle - f64| + floor."""
+    import ma_yardstick as Y
+    from oracle import ma_restatement as MR
+    from safepo.multi_agent.mappolag import MAPPO_L_Policy, MAPPO_L_Trainer
+    torch.manual_seed(5)
+    cfg = _cfg(dev)
+    pol = MAPPO_L_Policy(cfg, _Sp(D), _Sp(S), _Sp(A))
+    with torch.no_grad():
+        for net in pol.networks():             # LayerNorm affines and heads off their initial values (heads start at gain 0.01 / 0)
+            net.theta.add_(0.05 * torch.randn_like(net.theta))
+    nets0 = Y.nets_like(pol, cfg["std_x_coef"], cfg["std_y_coef"])
+    s = _sample(ROWS, seed=11)
+    with torch.no_grad():                      # old log-probabilities: the current policy's, jittered
+        lp = MR.log_probs(nets0["actor"](s["obs"]), nets0["actor"].std(), s["actions"])
+        s["old_logp"] = lp + 0.03 * torch.randn(ROWS, A, generator=torch.Generator().manual_seed(3))
+    tr = MAPPO_L_Trainer(cfg, pol)
+    sample = (s["share_obs"], s["obs"], None, None, s["actions"], s["value_preds"], s["returns"], None, s["active_masks"],
+              s["old_logp"], s["adv"], None, s["factor"], s["cost_preds"], s["cost_returns"], None, s["cost_adv"],
+              s["aver_episode_costs"])
+    sample = tuple(t.to(dev) if torch.is_tensor(t) else t for t in sample)
+    STEPS, SNAP = 5, (1, 5)
+    rows, theta_hip, grad_hip = [], {}, {}
+    opts = {"actor": pol.actor_optimizer, "critic": pol.critic_optimizer, "cost_critic": pol.cost_optimizer}
+    nets_hip = {"actor": pol.actor, "critic": pol.critic, "cost_critic": pol.cost_critic}
+    for k in range(1, STEPS + 1):
+        vl, cgn, plo, ent, agn, imp, cl, cogn = tr.ppo_update(sample)
+        torch.cuda.synchronize()
+        vn = tr.value_normalizer
+        rows.append([vl.item(), cgn.item(), plo.item(), ent.item(), agn.item(), imp.detach().mean().item(), cl.item(), cogn.item(),
+                     float(tr.lamda_lagr), float(vn.running_mean), float(vn.running_mean_sq), float(vn.debiasing_term)])
+        if k in SNAP:
+            theta_hip[k] = {nm: net.theta.double().cpu().numpy().copy() for nm, net in nets_hip.items()}
+            grad_hip[k] = {nm: o.grad.double().cpu().numpy().copy() for nm, o in opts.items()}      # spo_ma_clip_adam reads it only
+    gkey = {"actor": "actor_grad", "critic": "critic_grad", "cost_critic": "cost_grad"}
+    leg = {}
+    for dtype in (torch.float32, torch.float64):
+        recs, _, snaps = Y.oracle_steps(cfg, nets0, s, "mappolag", STEPS, dtype, snapshots=SNAP)
+        leg[dtype] = (recs, snaps)
+    (r32, sn32), (r64, sn64) = leg[torch.float32], leg[torch.float64]
+    names = ("value_loss", "critic_grad_norm", "policy_loss", "entropy", "actor_grad_norm", "ratio", "cost_loss", "cost_grad_norm", "lamda",
+             "popart_mean", "popart_mean_sq", "popart_debias")
+    Y.gate_rows(rows, [r["row"] for r in r32], [r["row"] for r in r64], 1e-5, "config-5 shape logged scalars", names)
+    np.testing.assert_allclose(rows[0], r32[0]["row"], rtol=1e-5, atol=1e-7)           # first step: 1e-5 against the fp32 oracle
+    o = pol.actor.offset(6)
+    for k in SNAP:
+        for nm in ("actor", "critic", "cost_critic"):
+            g32, g64, gh = (r32[k - 1][gkey[nm]].double().numpy(), r64[k - 1][gkey[nm]].double().numpy(), grad_hip[k][nm])
+            d_hip, d_32 = Y.gate(gh, g32, g64, 1e-6, f"step {k} {nm} flat gradient")
+            t_hip, t_32 = Y.gate(theta_hip[k][nm], sn32[k][nm], sn64[k][nm], 1e-5, f"{nm} parameters after step {k}")
+            print(f"config-5 shape step {k} {nm}: grad max|hip-f64| {d_hip:.2e} vs |f32-f64| {d_32:.2e} (scale {np.abs(g64).max():.2e}); "
+                  f"theta {t_hip:.2e} vs {t_32:.2e}")
+    assert np.isfinite(grad_hip[1]["actor"][o:o + A]).all()
+
+
+def test_config5_shape_masked_gae_popart_bit_exact(dev):
+    """SeparatedReplayBuffer.compute_returns / compute_cost_returns (buffer.py:356-384) at 64 x 8 192 with random masks and a
+    non-trivial PopArt state: the fused kernel's returns are BIT-identical to the restatement's step-by-step fp32 tensor
+    arithmetic (which tests/test_oracle_golden.py pins to the reference buffer)."""
+    from oracle import ma_restatement as MR
+    from safepo.common.buffer import SeparatedReplayBuffer
+    from safepo.common.popart import PopArt
+    g = torch.Generator().manual_seed(9)
+    cfg = _cfg(dev, algorithm_name="mappolag")
+    buf = SeparatedReplayBuffer(cfg, _Sp(D), _Sp(S), _Sp(A))
+    rewards, costs = torch.randn(T, THREADS, 1, generator=g), (torch.rand(T, THREADS, 1, generator=g) < 0.1).float()
+    masks = (torch.rand(T + 1, THREADS, 1, generator=g) > 1 / 16).float()
+    vp, cp = torch.randn(T + 1, THREADS, 1, generator=g) * 0.7, torch.randn(T + 1, THREADS, 1, generator=g).abs() * 0.4
+    buf.rewards.copy_(rewards); buf.costs.copy_(costs); buf.masks.copy_(masks)
+    buf.value_preds.copy_(vp); buf.cost_preds.copy_(cp)
+    norm = PopArt(1)
+    norm.running_mean.fill_(0.013); norm.running_mean_sq.fill_(0.071); norm.debiasing_term.fill_(0.019)
+    orc = MR.OraclePopArt()
+    orc.running_mean, orc.running_mean_sq, orc.debiasing_term = norm.running_mean.clone(), norm.running_mean_sq.clone(), norm.debiasing_term.clone()
+    buf.compute_returns(vp[-1].to(dev), norm)
+    buf.compute_cost_returns(cp[-1].to(dev), norm)
+    want_r = MR.masked_gae(rewards, vp, masks, orc, cfg["gamma"], cfg["gae_lambda"])
+    want_c = MR.masked_gae(costs, cp, masks, orc, cfg["gamma"], cfg["gae_lambda"])
+    assert np.array_equal(buf.returns.cpu().numpy()[:-1].view(np.uint32), want_r.numpy()[:-1].view(np.uint32))
+    assert np.array_equal(buf.cost_returns.cpu().numpy()[:-1].view(np.uint32), want_c.numpy()[:-1].view(np.uint32))
