@@ -308,6 +308,7 @@ def main():
     ap.add_argument("--cpo-cpu-sample-envs", type=int, default=256)
     ap.add_argument("--no-config3", action="store_true", help="skip the CPO (BASELINE config 3) section")
     ap.add_argument("--no-config5", action="store_true", help="skip the MAPPO-L (BASELINE config 5 shape) section")
+    ap.add_argument("--config5-threads", type=int, default=8192, help="rollout threads of the MAPPO-L section (TOTAL over the ranks)")
     ap.add_argument("--no-normalize-obs", action="store_true", help="rollout without the fused observation normaliser (a-2)")
     ap.add_argument("--cpo-steps", type=int, default=3)
     ap.add_argument("--stream-envs", type=int, default=262144, help="extra GAE roofline point that streams from HBM")
@@ -342,6 +343,18 @@ def main():
     elapsed, roll, upd, last, n_ep, eng, cfg = (res[k] for k in ("elapsed", "roll", "upd", "last", "n_ep", "eng", "cfg"))
     res_exchange, res_per_rank = res["exchange"], res["per_rank"]
 
+    def run_config5():
+        try:
+            torch.cuda.empty_cache()
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import ma_bench
+            return ma_bench.run(argparse.Namespace(threads=a.config5_threads, episode_length=64, hidden=128, episodes=2, agents=4),
+                                comm=comm, dev=dev)
+        except Exception as e:  # pragma: no cover
+            return {"error": str(e)[:300]}
+    # BASELINE config 5 on N > 1: every rank runs its shard of the MAPPO-L Runner (collective calls inside), so this sits
+    # BEFORE the non-zero ranks leave; rank 0 reports it below.  (N = 1: after the CPO section, as before.)
+    config5 = run_config5() if (world > 1 and a.algo == "ppo_lag" and not a.no_config5) else None
     if comm.rank != 0:
         if world > 1:
             torch.distributed.destroy_process_group()
@@ -491,16 +504,10 @@ def main():
 
     # BASELINE config 5 (MAPPO-L shape: 4 agents, obs 48, 8 192 rollout threads x 64 steps; one GPU here, the row is
     # "mappo_lag ... 8 x MI355X" in BASELINE.json): the multi-agent Runner of the f3 row, driver-visible (N = 1 only)
-    config5 = None
+    # With --gpus N the 8 192 rollout threads are sharded over the ranks (the BASELINE row itself: strong scaling) and the section
+    # already ran above, before the non-zero ranks left.
     if world == 1 and a.algo == "ppo_lag" and not a.no_config5:
-        try:
-            torch.cuda.empty_cache()
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            import ma_bench
-            config5 = ma_bench.run(argparse.Namespace(threads=8192, episode_length=64, hidden=128, episodes=2, agents=4))
-            config5["n_gpus"] = 1
-        except Exception as e:  # pragma: no cover
-            config5 = {"error": str(e)[:300]}
+        config5 = run_config5()
 
     us_step = upd / a.steps / (n_mb * iters) * 1e6
     line = {

@@ -174,6 +174,11 @@ int spo_ppo_lag_update_iter(float* theta, float* adam_m, float* adam_v, int64_t 
  * stream of the current device when all != 0.  hipFree synchronises the device -- not for the hot path. */
 int spo_update_scratch_release(void* stream_or_null, int all);
 
+/* Measurement aid: counters of the main + helper update kernel summed over the launches of this process since the last reset
+ * (out4_host, host array): {minibatch steps run, steps whose speculative update turned out clipped and was redone, steps
+ * clipped under the conservative protocol, steps run under the conservative protocol}.  Synchronises the device. */
+int spo_debug_update_counters(unsigned long long* out4_host, int reset);
+
 /* Debug self-test of the cross-lane helpers (DPP row sums, gfx950 permlane swaps): in[64] -> out[192]. */
 int spo_debug_crosslane_selftest(const float* in64, float* out192, void* stream);
 

@@ -424,6 +424,128 @@ __device__ __forceinline__ void xr_allreduce_rd16(const u64* regions, int me, in
   for (int v = 0; v < NV; ++v) pk[v] *= inv_world;
 }
 
+// Reduce-scatter + all-gather with the PACKED 16-byte words (round 4).  The lane's NW words are cut into `world` slices by word
+// index (slice c = words [c * cw, (c + 1) * cw), cw = ceil(NW / world)): every lane pushes slice c into slot1[parity][me][net]
+// of rank c's region; rank c's lane adds the `world` copies of its cw words in rank order, scales by 1 / world and pushes the
+// reduced words into red2[parity][net] of EVERY region; every lane then polls its NW reduced words from its own region.  Each
+// word is reduced by exactly one rank, so all replicas hold identical bits.  Against recursive doubling at 8 ranks: TWO
+// hand-offs instead of three, NW + world * cw (31) stores and world * cw + NW (31) polling loads per lane instead of 3 NW (45)
+// each, 1.75 x the gradient on the wire per rank and step instead of 3 x -- at 2 ranks doubling is the cheaper one (one
+// hand-off, 15 + 15).  Any world size <= 8; same tag / parity discipline as the forms above.
+template <int NV>
+__device__ __forceinline__ void xr_allreduce_rs16(const u64* regions, int me, int R, int net, int tid, unsigned gtag,
+                                                  f4 (&pk)[NV], volatile float* dead_word, int* err) {
+  constexpr int NF = 4 * NV, NW = (NF + 2) / 3;
+  constexpr int XB = 16;                                          // (word, source) pairs polled together in the reduce phase
+  static_assert((size_t)NW * 256 * 16 <= XR_SLOT_WORDS * 8, "packed rows must fit the slot");
+  const int par = (int)(gtag & 1u);
+  const int cw = (NW + R - 1) / R;
+  const size_t lane_b = (size_t)tid * 16;
+  // ---- phase 1: word w -> rank w / cw
+  {
+    const size_t slot1_b = (((size_t)(par * XR_MAX_WORLD + me) * 3 + net) * XR_SLOT_WORDS) * 8 + lane_b;
+    int dst = 0, left = cw;
+    char* base = reinterpret_cast<char*>(regions[0]) + slot1_b;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      u4v word;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int f = 3 * w + i;
+        word[i] = f < NF ? __float_as_uint(pk[(f < NF ? f : 0) >> 2][(f < NF ? f : 0) & 3]) : 0u;
+      }
+      word[3] = gtag;
+      st16_sys(base + (size_t)w * 4096, word);
+      if (--left == 0 && w + 1 < NW) { ++dst; left = cw; base = reinterpret_cast<char*>(regions[dst]) + slot1_b; }
+    }
+  }
+  // ---- reduce my slice over the sources in rank order; push the result to every rank
+  const int w_lo = me * cw;
+  const int n_my = (NW - w_lo) < cw ? (NW - w_lo > 0 ? NW - w_lo : 0) : cw;
+  const int lg = R <= 2 ? 1 : R <= 4 ? 2 : 3;                     // sources padded to 2 / 4 / 8 per word
+  const int G = XB >> lg;                                         // words per batch of XB loads
+  const float inv_world = 1.f / (float)R;
+  const char* const src0 = reinterpret_cast<const char*>(regions[me]) + (((size_t)(par * XR_MAX_WORLD) * 3 + net) * XR_SLOT_WORDS) * 8 + lane_b;
+  const size_t red2_b = (XR_SLOT1_WORDS + ((size_t)par * 3 + net) * XR_SLOT_WORDS) * 8 + lane_b;
+#pragma unroll 1
+  for (int b = 0; b * G < n_my; ++b) {
+    u4v x[XB];
+    unsigned spins = 0;
+    for (;;) {
+#pragma unroll
+      for (int jj = 0; jj < XB; ++jj) {
+        const int g = jj >> lg, r = jj & ((1 << lg) - 1);
+        const int wl = b * G + g;
+        x[jj] = u4v{0u, 0u, 0u, gtag};
+        if (r < R && wl < n_my) x[jj] = ld16_sys(src0 + (size_t)r * 3 * XR_SLOT_WORDS * 8 + (size_t)(w_lo + wl) * 4096);
+      }
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      bool ok = true;
+#pragma unroll
+      for (int jj = 0; jj < XB; ++jj) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(x[jj]));                             // the asm outputs are valid only after the wait
+#endif
+        ok = ok && (x[jj][3] == gtag);
+      }
+      if (ok || *dead_word != 0.f) break;
+      if (++spins > XR_SPIN_LIMIT) { *err = 2; *dead_word = 1.f; break; }          // bounded: never hang the GPU
+      __builtin_amdgcn_s_sleep(1);
+    }
+    float run[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jj = 0; jj < XB; ++jj) {
+      const int g = jj >> lg, r = jj & ((1 << lg) - 1);
+      const int wl = b * G + g;
+      if (r < R) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) run[i] = (r == 0) ? __uint_as_float(x[jj][i]) : run[i] + __uint_as_float(x[jj][i]);
+        if (r == R - 1 && wl < n_my) {
+          const u4v word = {__float_as_uint(run[0] * inv_world), __float_as_uint(run[1] * inv_world), __float_as_uint(run[2] * inv_world), gtag};
+          for (int dst = 0; dst < R; ++dst) st16_sys(reinterpret_cast<char*>(regions[dst]) + red2_b + (size_t)(w_lo + wl) * 4096, word);
+        }
+      }
+    }
+  }
+  // ---- the reduced vector: all NW words from my own region
+  const char* const fin = reinterpret_cast<const char*>(regions[me]) + red2_b;
+  constexpr int VB = SPO_XR16_VB;
+#pragma unroll
+  for (int w0 = 0; w0 < NW; w0 += VB) {
+    u4v x[VB];
+    unsigned spins = 0;
+    for (;;) {
+#pragma unroll
+      for (int vv = 0; vv < VB; ++vv)
+        if (w0 + vv < NW) x[vv] = ld16_sys(fin + (size_t)(w0 + vv) * 4096);
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      bool ok = true;
+#pragma unroll
+      for (int vv = 0; vv < VB; ++vv)
+        if (w0 + vv < NW) {
+#if defined(__HIP_DEVICE_COMPILE__)
+          asm volatile("" : "+v"(x[vv]));
+#endif
+          ok = ok && (x[vv][3] == gtag);
+        }
+      if (ok || *dead_word != 0.f) break;
+      if (++spins > XR_SPIN_LIMIT) { *err = 2; *dead_word = 1.f; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int vv = 0; vv < VB; ++vv)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int f = 3 * (w0 + vv) + i;
+        if (w0 + vv < NW && f < NF) pk[f >> 2][f & 3] = __uint_as_float(x[vv][i]);
+      }
+  }
+}
+
 // AMODE: actor loss.  0 = PPO clipped surrogate (ppo_lag.py:316-319; clip = 1e30 gives the plain policy gradient);
 //        1 = KL-penalty form shared by FOCOPS (focops.py:326-337) and CUP's second stage (cup.py:372-383):
 //            loss = mean_i(ind_i * KL_i) - pg_coef * mean_i(ind_i) * mean_j(ratio_j * adv_j),
@@ -920,6 +1042,8 @@ __device__ __forceinline__ void ppo_update_body(const UpdArgs& a, const int wg) 
         xr_allreduce_rd16<NV>(xr_tab, a.xr_rank, a.xr_world, net, tid, gtag, pk, red + 112, a.err);
       else if (XR == 2)
         xr_allreduce_rd<NV>(xr_tab, a.xr_rank, a.xr_world, net, tid, gtag, pk, red + 112, a.err);
+      else if (SPO_XR_PACK16)
+        xr_allreduce_rs16<NV>(xr_tab, a.xr_rank, a.xr_world, net, tid, gtag, pk, red + 112, a.err);
       else
         xr_allreduce<NV>(xr_tab, a.xr_rank, a.xr_world, net, tid, gtag, pk, red + 112, a.err);
 #pragma unroll
@@ -1197,6 +1321,11 @@ __global__ __launch_bounds__(256, 1) void ppo_update_split_kernel(UpdArgs a0, Up
 // (global scratch, written fire-and-forget), redo Adam exactly with the coefficient, and raise a flag that makes the main
 // waves repeat L1 / L2 of the step they had started (one extra barrier round; results identical to the unspeculated order).
 // Every barrier sits in code common to both roles, so the two roles cannot disagree on the number of barriers.
+// Debug / measurement counters of the main + helper kernel (spo_debug_update_counters): minibatch steps run, steps whose
+// speculative update turned out clipped and was redone ("late"), steps clipped under the conservative protocol, steps run
+// under the conservative protocol -- summed over launches by the first helper lane of network 0 at the end of a launch.
+__device__ unsigned long long g_upd_counters[4];
+
 template <int KIN>
 struct UpdHLds {
   using U = UpdLds<KIN>;
@@ -1821,6 +1950,7 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
   __syncthreads();                                                        // B_stage of step 0
   if (PROF) tprev = __builtin_readcyclecounter();
   bool spec = a.spec_mode != 0;                      // deferred validation of the clip (see below); off after a clipped step
+  int n_late = 0, n_redo = 0, n_cons = 0;            // g_upd_counters
   for (int64_t s = 0; s < nsteps; ++s) {
     const int64_t base = s * B;
     const int64_t rem = a.M - base;
@@ -2093,6 +2223,7 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
       bool late = false;
       if (coef != 1.f) {
         // ---- clipped after all: restore every layer, redo it exactly, make the main waves repeat the step they are in
+        ++n_late;
         redo_layers12(coef);
         SPO_REIDX
 #pragma unroll
@@ -2227,9 +2358,11 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
         stale_sq *= coef * coef;
       }
       SPO_STAMP(8)
+      ++n_cons;
       if (coef != 1.f) {
         // ---- the clip is active (rare): layers 1 and 2 were updated with coefficient 1 -- restore them, redo them exactly,
         //      and make the main waves repeat L1 / L2 of the step they have started
+        ++n_redo;
         redo_layers12(coef);
         if (wave == 0 && lane == 0) xw[18] = (int)((s + 1) & 0x3fffffff) + 1;
         redo_next = true;
@@ -2271,6 +2404,10 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
   }
   if (PROF && a.prof && tid == 256 && wg == a.n_nets - 1)
     for (int i = 0; i < NPHASE; ++i) a.prof[NPHASE + i] = pacc[i];
+  if (tid == 256 && wg == 0) {
+    atomicAdd(&g_upd_counters[0], (unsigned long long)nsteps); atomicAdd(&g_upd_counters[1], (unsigned long long)n_late);
+    atomicAdd(&g_upd_counters[2], (unsigned long long)n_redo); atomicAdd(&g_upd_counters[3], (unsigned long long)n_cons);
+  }
   // the last step's verdict (and a possible redo) is complete here; the barrier orders the final weight image before
   // the write-back below
   __syncthreads();
@@ -2389,6 +2526,7 @@ __global__ __launch_bounds__(256, 1) void xr_selftest_kernel(int rank, int world
       if (SPO_XR_PACK16) xr_allreduce_rd16<11>(regions, rank, world, net, tid, gtag, pk, &dead, result + 1);
       else xr_allreduce_rd<11>(regions, rank, world, net, tid, gtag, pk, &dead, result + 1);
     }
+    else if (SPO_XR_PACK16) xr_allreduce_rs16<11>(regions, rank, world, net, tid, gtag, pk, &dead, result + 1);
     else xr_allreduce<11, true>(regions, rank, world, net, tid, gtag, pk, &dead, result + 1);
     const float tri = 0.5f * (float)(world + 1);
 #pragma unroll
@@ -2649,6 +2787,16 @@ static int fill_xr(UpdArgs& a, int rank, int world, void* const* regions, unsign
   a.xr_algo = (algo && !strcmp(algo, "twophase")) ? 0 : 1;
   { const char* dbg = getenv("SPO_A2A_DEBUG"); a.xr_debug = dbg ? atoi(dbg) : 0; }
   for (int r = 0; r < XR_MAX_WORLD; ++r) a.xr_region[r] = r < world ? regions[r] : nullptr;
+  return 0;
+}
+
+extern "C" int spo_debug_update_counters(unsigned long long* out4_host, int reset) {
+  SPO_REQUIRE(out4_host, "update_counters: null pointer");
+  if (int rc = spo::hip_check(hipMemcpyFromSymbol(out4_host, HIP_SYMBOL(g_upd_counters), 32), "hipMemcpyFromSymbol")) return rc;
+  if (reset) {
+    unsigned long long z[4] = {0, 0, 0, 0};
+    return spo::hip_check(hipMemcpyToSymbol(HIP_SYMBOL(g_upd_counters), z, 32), "hipMemcpyToSymbol");
+  }
   return 0;
 }
 

@@ -83,6 +83,7 @@ PROTOTYPES = {
     "spo_boundary_step_fold": (c_int, [P] * 18 + [c_int, c_int64, c_int64, c_int64, c_int, P, P, c_double, P]),
     "spo_ppo_lag_update_iter": (c_int, [P, P, P, c_int64] + [P] * 7 + [c_int64, POINTER(PpoCfg), P, P, P]),
     "spo_update_scratch_release": (c_int, [P, c_int]),
+    "spo_debug_update_counters": (c_int, [P, c_int]),
     "spo_debug_crosslane_selftest": (c_int, [P, P, P]),
     "spo_debug_ma_gemm": (c_int, [c_int, c_int, P, P, P, c_int64, c_int, c_int, P]),
     "spo_debug_set_update_profile": (c_int, [P]),
