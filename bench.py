@@ -101,6 +101,62 @@ def cpu_baseline(sample_envs: int, T: int, threads: int = 4, algo: str = "ppo_la
             "reference_recorded": recorded_reference(algo)}
 
 
+def cpu_baseline_mappolag(sample_threads: int, T: int = 64, agents: int = 4, hidden: int = 128, threads: int = 4):
+    """Oracle port of one MAPPO-L epoch (oracle/ma_restatement.py: the reference's networks, masked GAE with PopArt and
+    MAPPO_L_Trainer.train through torch CPU autograd) on a bounded sample of the config-5 workload: `sample_threads` rollout
+    threads x T steps x `agents` agents, mamujoco overrides (hidden 128, 5 full-batch iterations per agent).  Collect = the three
+    forward passes per agent and step + sampling; compute = the per-step Python GAE recurrences; train = HAPPO-sequential
+    updates.  The synthetic environment and the buffer inserts of the reference Runner are not timed (a lower bound on its time)."""
+    from oracle import ma_restatement as MR
+    from safepo.multi_agent import mappolag
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    cfg = dict(mappolag.default_cfg)
+    cfg.update(mappolag.mamujoco_cfg)
+    cfg.update(hidden_size=hidden, episode_length=T, n_rollout_threads=sample_threads)
+    D, A = 48, 6
+    S = D * agents // 2
+    N, nb = sample_threads, 1 + int(cfg["layer_N"])
+    trainers = [MR.OracleMATrainer(cfg, MR.MANet(D, hidden, nb, A, True, cfg["std_x_coef"], cfg["std_y_coef"]), MR.MANet(S, hidden, nb, 1, False),
+                                   MR.MANet(S, hidden, nb, 1, False)) for _ in range(agents)]
+    g = torch.Generator().manual_seed(1)
+    t0 = time.time()
+    bufs = []
+    for a_ in range(agents):
+        b = {"share_obs": torch.zeros(T + 1, N, S), "obs": torch.zeros(T + 1, N, D), "actions": torch.zeros(T, N, A),
+             "action_log_probs": torch.zeros(T, N, A), "value_preds": torch.zeros(T + 1, N, 1), "cost_preds": torch.zeros(T + 1, N, 1),
+             "rewards": torch.zeros(T, N, 1), "costs": torch.zeros(T, N, 1), "masks": torch.ones(T + 1, N, 1),
+             "active_masks": torch.ones(T + 1, N, 1), "aver_episode_costs": torch.full((N, 1), 30.0)}
+        bufs.append(b)
+    for t in range(T + 1):                                    # Runner.collect (+ the bootstrap values of compute() at t = T)
+        for a_, tr in enumerate(trainers):
+            b = bufs[a_]
+            b["obs"][t], b["share_obs"][t] = torch.randn(N, D, generator=g), torch.randn(N, S, generator=g)
+            with torch.no_grad():
+                b["value_preds"][t], b["cost_preds"][t] = tr.critic(b["share_obs"][t]), tr.cost_critic(b["share_obs"][t])
+                if t < T:
+                    mean, std = tr.actor(b["obs"][t]), tr.actor.std()
+                    act = mean + std * torch.randn(N, A, generator=g)
+                    b["actions"][t], b["action_log_probs"][t] = act, MR.log_probs(mean, std, act)
+                    b["rewards"][t], b["costs"][t] = torch.randn(N, 1, generator=g), (torch.rand(N, 1, generator=g) < 0.2).float()
+    t1 = time.time()
+    for a_, tr in enumerate(trainers):                        # Runner.compute
+        b = bufs[a_]
+        b["returns"] = MR.masked_gae(b["rewards"], b["value_preds"], b["masks"], tr.popart, cfg["gamma"], cfg["gae_lambda"])
+        b["cost_returns"] = MR.masked_gae(b["costs"], b["cost_preds"], b["masks"], tr.popart, cfg["gamma"], cfg["gae_lambda"])
+    t2 = time.time()
+    iters = int(cfg["learning_iters"])
+    order = list(range(agents))
+    MR.runner_train(trainers, bufs, order, {a_: [torch.randperm(T * N, generator=g) for _ in range(iters)] for a_ in order}, cfg)
+    t3 = time.time()
+    steps = N * T
+    host = next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "?")
+    return {"value": round(steps / (t3 - t0), 1), "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"1 epoch of {N} rollout threads x {T} steps x {agents} agents (={steps} env-steps), hidden {hidden}, {iters} full-batch "
+                      f"iterations per agent, torch CPU {threads} threads on {host} ({os.cpu_count()} logical cores); collect {t1 - t0:.2f}s "
+                      f"GAE {t2 - t1:.2f}s train {t3 - t2:.2f}s (environment and buffer inserts not timed)"}
+
+
 FP32_MATRIX_PEAK_TFLOPS = 157.3          # dense FP32 MFMA (= packed-FP32 VALU) peak of one MI355X (MI355X_MICROARCH.md)
 
 
@@ -285,8 +341,10 @@ def run_epochs(algo, a, comm, dev, N, T, D, A, steps, warmup, time_gae):
         form = ("rccl all-reduce between kernels (spo_ppo_lag_grad -> all_reduce -> spo_clip_adam_then_grad)" if px is None else
                 "in-kernel, all-to-all on the helper waves" if os.environ.get("SPO_P2P_A2A", "0") == "1" else
                 "in-kernel, recursive doubling on the helper waves" if os.environ.get("SPO_P2P_HELPER", "0") == "1" else
-                "in-kernel, recursive doubling of tagged words over IPC-mapped peer regions"
-                if (world & (world - 1)) == 0 else "in-kernel, reduce-scatter + all-gather of tagged words over IPC-mapped peer regions")
+                "in-kernel, recursive doubling of packed tagged words over IPC-mapped peer regions"
+                if ((world & (world - 1)) == 0 and (world <= 4 or os.environ.get("SPO_P2P_ALGO") == "doubling")
+                    and os.environ.get("SPO_P2P_ALGO") != "twophase")
+                else "in-kernel, reduce-scatter + all-gather of packed tagged words over IPC-mapped peer regions")
         exchange = {"form": form, "selftest_s": round(getattr(px, "last_selftest_s", float("nan")), 4) if px is not None else None,
                     "selftest_result": list(getattr(px, "last_selftest", ())) if px is not None else None,
                     "host_collectives_backend": dist.get_backend(), "host_collectives_world": dist.get_world_size(),
@@ -309,6 +367,7 @@ def main():
     ap.add_argument("--no-config3", action="store_true", help="skip the CPO (BASELINE config 3) section")
     ap.add_argument("--no-config5", action="store_true", help="skip the MAPPO-L (BASELINE config 5 shape) section")
     ap.add_argument("--config5-threads", type=int, default=8192, help="rollout threads of the MAPPO-L section (TOTAL over the ranks)")
+    ap.add_argument("--config5-cpu-sample-threads", type=int, default=512, help="rollout threads of the MAPPO-L CPU-baseline sample")
     ap.add_argument("--no-normalize-obs", action="store_true", help="rollout without the fused observation normaliser (a-2)")
     ap.add_argument("--cpo-steps", type=int, default=3)
     ap.add_argument("--stream-envs", type=int, default=262144, help="extra GAE roofline point that streams from HBM")
@@ -348,8 +407,17 @@ def main():
             torch.cuda.empty_cache()
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import ma_bench
-            return ma_bench.run(argparse.Namespace(threads=a.config5_threads, episode_length=64, hidden=128, episodes=2, agents=4),
-                                comm=comm, dev=dev)
+            c5 = ma_bench.run(argparse.Namespace(threads=a.config5_threads, episode_length=64, hidden=128, episodes=2, agents=4),
+                              comm=comm, dev=dev)
+            # flops-based roofline of the training phase (85 % of the epoch: full-batch fp32 GEMM chains on in-tree MFMA kernels)
+            c5["roofline"] = {"bound": "mfma", "achieved": c5["train_gemm_tflops"] * world, "unit": "TFLOP/s",
+                              "peak": FP32_MATRIX_PEAK_TFLOPS * world, "frac": round(c5["train_gemm_tflops"] / FP32_MATRIX_PEAK_TFLOPS, 4),
+                              "note": "algorithmic GEMM flops of the training phase (per agent: learning_iters x 3 networks x forward + "
+                                      "backward = 3 x forward) / its wall time, against the dense FP32 matrix peak; tools/ma_bench.py"}
+            if world == 1 and comm.rank == 0 and not a.no_cpu_baseline:
+                c5["cpu_baseline"] = cpu_baseline_mappolag(a.config5_cpu_sample_threads)
+                c5["speedup_vs_cpu_baseline"] = round(c5["env_steps_per_s"] / c5["cpu_baseline"]["value"], 1)
+            return c5
         except Exception as e:  # pragma: no cover
             return {"error": str(e)[:300]}
     # BASELINE config 5 on N > 1: every rank runs its shard of the MAPPO-L Runner (collective calls inside), so this sits
@@ -510,6 +578,16 @@ def main():
         config5 = run_config5()
 
     us_step = upd / a.steps / (n_mb * iters) * 1e6
+    upd_counters = None
+    if a.algo == "ppo_lag" and world == 1:
+        import ctypes
+        from safepo import _abi
+        c4 = (ctypes.c_ulonglong * 4)()
+        if _abi.load().spo_debug_update_counters(c4, 0) == 0 and c4[0]:
+            upd_counters = {"steps_counted": int(c4[0]), "clipped_after_speculation_redone": int(c4[1]),
+                            "clipped_under_conservative_protocol": int(c4[2]), "steps_under_conservative_protocol": int(c4[3]),
+                            "note": "all launches of this process (warm-up, timed epochs, early-stopping epoch); a redone step costs "
+                                    "one repeated forward of the main waves"}
     line = {
         "metric": "env-steps/sec (collect+GAE+update) at num_envs=4096, 1/2/4/8 GPU",
         "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -538,6 +616,7 @@ def main():
                            "us_per_minibatch_step": round(us_step, 3),
                            "mfma_floor_us": round(368 * 32 / 2.4e9 * 1e6, 3),
                            "frac": round((368 * 32 / 2.4e9) / (us_step * 1e-6), 4),
+                           "redo_counters": upd_counters,
                            "simd_sum_floor_us": round((368 * 32 + 2400 * 4) / 2.4e9 * 1e6, 3),
                            "frac_of_simd_sum_floor": round(((368 * 32 + 2400 * 4) / 2.4e9) / (us_step * 1e-6), 4),
                            "note": "mfma_floor = the 368 MFMA issue slots of a main wave at 2.4 GHz; on this part a SIMD's vector "

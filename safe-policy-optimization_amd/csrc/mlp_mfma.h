@@ -59,15 +59,20 @@ __host__ __device__ inline NetGeom net_geom(int D, int A, int net) {
 }
 
 // LDS image of one network (floats).  KIN = obs_dim padded to a multiple of 16.
-template <int KIN>
+// PAD = floats added to every weight row.  4 (LDH): rows 16-byte aligned, and the COLUMN-wise ds_read_b32 of the backward passes
+// conflict-free.  8: the ROW-wise ds_read_b128 operand reads of the forward are conflict-free under gfx950's b128 lane groups
+// ({0-3, 12-15, 20-27}, ...: with stride K + 4 the 16-byte bank quad of lane (j, q) is j + q mod 16 and lanes (12, 0), (11, 1) of
+// one group collide; with K + 8 it is 2j + q mod 16: sixteen different quads per group) -- for the forward-only kernels.
+template <int KIN, int PAD = 4>
 struct NetLds {
-  static constexpr int LD1 = KIN + 4;
+  static constexpr int LD1 = KIN + PAD;
+  static constexpr int LDW = HID + PAD;        // == LDH for PAD = 4
   static constexpr int W1 = 0;
   static constexpr int B1 = W1 + HID * LD1;
   static constexpr int W2 = B1 + HID;
-  static constexpr int B2 = W2 + HID * LDH;
+  static constexpr int B2 = W2 + HID * LDW;
   static constexpr int W3 = B2 + HID;
-  static constexpr int B3 = W3 + OUTP * LDH;
+  static constexpr int B3 = W3 + OUTP * LDW;
   static constexpr int SIZE = B3 + OUTP;       // multiple of 4 floats
 };
 
@@ -75,9 +80,10 @@ struct NetLds {
 // Round 3: no integer division per element (the old form computed i / D and i % D for each of ~8 500 floats: ~40 VALU
 // instructions per element in front of every load, several microseconds per staged network in kernels that stage one per
 // launch): KIN / 4 lanes cover a row, each lane four consecutive columns, rows advance by nthr / (KIN / 4).
-template <int KIN>
+template <int KIN, int PAD = 4>
 __device__ inline void stage_net(const float* __restrict__ theta, const NetGeom g, float* lds, int tid, int nthr) {
-  using L = NetLds<KIN>;
+  using L = NetLds<KIN, PAD>;
+  constexpr int LDH = L::LDW;                 // (shadows the global stride inside this function)
   for (int i = tid; i < L::SIZE / 4; i += nthr) reinterpret_cast<f4*>(lds)[i] = f4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
   const int D = g.D;
@@ -315,7 +321,9 @@ __device__ __forceinline__ f4 out_accum(const float* Wl, const f4 (&in)[HID / 16
 
 // Output layer (one padded 16-row tile): rows 4q+reg = output unit.  Two accumulators (k halves)
 // keep the MFMA pipe busy; they are summed at the end.
+template <int LDW = LDH>
 __device__ __forceinline__ f4 layer_out(const float* Wl, const float* bl, const f4 (&in)[HID / 16], int j, int q) {
+  constexpr int LDH = LDW;                    // (shadows the global stride inside this function)
   f4 acc0 = *reinterpret_cast<const f4*>(bl + 4 * q);
   f4 acc1 = {0.f, 0.f, 0.f, 0.f};
   f4 a[HID / 16];
@@ -345,13 +353,13 @@ __device__ __forceinline__ f4 net_forward(const float* lds_net, const f4 (&x)[KI
 }
 
 // net_forward on the single-buffered layers (same arithmetic, same order: bit-identical results)
-template <int KIN>
+template <int KIN, int PAD = 4>
 __device__ __forceinline__ f4 net_forward_lean(const float* lds_net, const f4 (&x)[KIN / 16], int j, int q) {
-  using L = NetLds<KIN>;
+  using L = NetLds<KIN, PAD>;
   f4 h1[4], h2[4];
   layer_hidden_lean<KIN / 16, true>(lds_net + L::W1, L::LD1, lds_net + L::B1, x, h1, j, q);
-  layer_hidden_lean<4, true>(lds_net + L::W2, LDH, lds_net + L::B2, h1, h2, j, q);
-  return layer_out(lds_net + L::W3, lds_net + L::B3, h2, j, q);
+  layer_hidden_lean<4, true>(lds_net + L::W2, L::LDW, lds_net + L::B2, h1, h2, j, q);
+  return layer_out<L::LDW>(lds_net + L::W3, lds_net + L::B3, h2, j, q);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -156,13 +156,19 @@ struct KlArgs {
 #ifndef SPO_FULL_GRID
 #define SPO_FULL_GRID 768        // persistent grid: three resident workgroups on each of the 256 CUs (A/B knob)
 #endif
+#ifndef SPO_FULL_PAD
+// Weight-row padding of the forward-only full-batch kernel.  8 makes its ds_read_b128 operand reads conflict-free (NetLds in
+// mlp_mfma.h) -- and measured nothing: 123.5 us against 123.4 us for the KL over 524 288 rows (profiles/r04/kl_ab_pad.txt): the
+// conflicts are 43 % of the LDS-active cycles, but with three waves per SIMD the LDS is not what the waves wait for.  Kept at 4.
+#define SPO_FULL_PAD 4
+#endif
 template <int KIN, int MODE>
 __global__ __launch_bounds__(256, SPO_FULL_MINB) void actor_full_kernel(KlArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[NetLds<KIN>::SIZE];
+  __shared__ __attribute__((aligned(16))) float lds[NetLds<KIN, SPO_FULL_PAD>::SIZE];
   __shared__ double red[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
   const int D = a.D, A = a.A;
-  stage_net<KIN>(a.theta, net_geom(D, A, 2), lds, tid, 256);
+  stage_net<KIN, SPO_FULL_PAD>(a.theta, net_geom(D, A, 2), lds, tid, 256);
   __syncthreads();
   const int ls_off = 2 * critic_size(D);
   float sd_new[4], sd_old[4];
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(256, SPO_FULL_MINB) void actor_full_kernel(KlArgs a
       const int64_t nrow = (tile + stride) * 16 + j;                // next tile of this wave (clamped: a harmless re-read at the end)
       load_obs_tiles_raw<KIN>(a.obs + (nrow < a.rows ? nrow : a.rows - 1) * D, D, q, xn);
     }
-    const f4 mu = net_forward_lean<KIN>(lds, x, j, q);
+    const f4 mu = net_forward_lean<KIN, SPO_FULL_PAD>(lds, x, j, q);
     if (MODE == 0) {
       if (valid) {
 #pragma unroll

@@ -1326,6 +1326,14 @@ __global__ __launch_bounds__(256, 1) void ppo_update_split_kernel(UpdArgs a0, Up
 // under the conservative protocol -- summed over launches by the first helper lane of network 0 at the end of a launch.
 __device__ unsigned long long g_upd_counters[4];
 
+#ifndef SPO_H_GATHER
+// 0: the main waves' own prefetch pipeline (rounds 2-3).  1 / 2: the HELPER waves gather the next minibatch (sample index,
+// observation rows, targets) and write its x^T image + column inputs between P1 and P3; the main waves pick the columns up with
+// 16 LDS reads instead of the settle (pad selects, index widening, 16 x^T stores: 1.3 k cycles of a lone wave).  1 issues the
+// row loads after B_stage (not back by P1: the helper stalls at the head of its critical stretch, 11.48 us per step), 2 right
+// behind Xd (a whole backward pass to land): 10.68 against 10.84 us for 0, results bit-identical (profiles/r04/update_ab_gather.txt)
+#define SPO_H_GATHER 2
+#endif
 template <int KIN>
 struct UpdHLds {
   using U = UpdLds<KIN>;
@@ -1333,10 +1341,14 @@ struct UpdHLds {
   static constexpr int NT1 = KIN / 16;
   static constexpr int G1 = U::SIZE;                        // [4 waves][NT1 tiles][64 lanes] float4
   static constexpr int G2 = U::DZ1T;                        // [4][4][64] float4 inside the dZ1^T image (16 384 <= 17 408 B)
-  static constexpr int G3 = G1 + 4 * NT1 * 64 * 4;          // [4][2][64] float4: W3 tile, (unused)
-  static constexpr int GB = G3 + 4 * 2 * 64 * 4;            // [3][256] floats: db1, db2, db3 as the main lanes hold them
+  static constexpr int G3 = G1 + 4 * NT1 * 64 * 4;          // [4][64] float4: W3 tile
+  static constexpr int GB = G3 + 4 * 64 * 4;                // [3][256] floats: db1, db2, db3 as the main lanes hold them
   static constexpr int XW = GB + 3 * 256;                   // 32 floats of helper-to-helper / helper-to-main words
-  static constexpr int SIZE = XW + 32 + 2 * XR_MAX_WORLD;   // + the ranks' exchange-region pointers (8-byte aligned: XW is even)
+  static constexpr int COLS = XW + 32 + 2 * XR_MAX_WORLD;   // (+ the ranks' exchange-region pointers, 8-byte aligned: XW is even)
+  // COLS: [2 + OUTP][64] per-column inputs of the step the main waves are in -- target / logp_old, advantage, act[0..15] --
+  // gathered by the HELPER waves (SPO_H_GATHER) together with the x^T image
+  static constexpr int SIZE = COLS + (2 + OUTP) * 64;
+  static_assert(SIZE * 4 <= 163840, "main + helper form: 160 KB of LDS");
   static_assert(XW % 2 == 0, "pointer table alignment");
   static_assert(4 * 4 * 64 * 4 <= HID * LDB, "G2 must fit the dZ1^T image");
 };
@@ -1646,6 +1658,21 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
   int smp1 = 0;
   fetch((int64_t)a.perm[perm_pos(0)], nxt);
   if (nsteps > 1) smp1 = a.perm[perm_pos(1)];
+  float* const cols = lds + H::COLS;
+  if (SPO_H_GATHER) {
+    // step 0's columns by the main waves themselves (every lane reads back only what lanes of its own wave wrote: no barrier);
+    // from step 1 on the helpers write the x^T image and the column inputs between P1 and P3 of the step before
+    settle_prefetch(nxt);
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) lds[U::XT + (16 * nt + 4 * q + e) * LDB + mycol] = nxt.x[nt][e];
+    if (q == 0) { cols[mycol] = nxt.t0; cols[64 + mycol] = nxt.t1; }
+    if (is_actor) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cols[(2 + 4 * q + r) * 64 + mycol] = nxt.actv[r];
+    }
+  }
   if (PROF) tprev = __builtin_readcyclecounter();
 
   for (int64_t s = 0; s < nsteps; ++s) {
@@ -1657,7 +1684,15 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
     f4 h1[4], h2[4];
     int smp_next = 0;
     int64_t pos2 = 0;
-    {
+    if (SPO_H_GATHER) {
+      // the helpers put this step's x^T image in place before the barrier the previous step ended with: 16 LDS reads instead
+      // of the settle (pad selects, index widening, 16 x^T stores: 1.3 k cycles of a lone wave)
+      SPO_REIDX
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cur.x[nt][e] = lds[U::XT + (16 * nt + 4 * q + e) * LDB + mycol];
+    } else {
       SPO_REIDX
       cur = nxt;
       settle_prefetch(cur);
@@ -1701,8 +1736,14 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
         // ---- rest of the step of the main waves: prefetch, L3, loss, backward, staging
         SPO_REIDX
         SPO_SUB(-1)
-        if (s + 1 < nsteps) fetch((int64_t)smp_next, nxt);
-        if (s + 2 < nsteps) smp1 = a.perm[pos2];
+        if (!SPO_H_GATHER) {
+          if (s + 1 < nsteps) fetch((int64_t)smp_next, nxt);
+          if (s + 2 < nsteps) smp1 = a.perm[pos2];
+        } else {
+          cur.t0 = cols[mycol]; cur.t1 = cols[64 + mycol];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cur.actv[r] = is_actor ? cols[(2 + 4 * q + r) * 64 + mycol] : 0.f;
+        }
         const f4 o = layer_out(lds + L::W3, lds + L::B3, h2, j, q);
         SPO_SUB(0)
         const bool cv = mycol < ncols;
@@ -1929,7 +1970,7 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
       float rs3 = 0.f;
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) rs3 += (az3[r4][0] + az3[r4][1]) + (az3[r4][2] + az3[r4][3]);
-      *reinterpret_cast<f4*>(lds + H::G3 + ((wave * 2 + 0) * 64 + lane) * 4) = w3a + w3b;
+      *reinterpret_cast<f4*>(lds + H::G3 + (wave * 64 + lane) * 4) = w3a + w3b;
       lds[H::GB + 2 * 256 + wave * 64 + lane] = quad_row_sum(rs3);
     }
     SPO_STAMP(9)
@@ -1944,6 +1985,61 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
   // work must be done when the main waves arrive at the next barrier, and the main waves' MFMA streams leave most VALU
   // slots free anyway: static priority for the helpers.
   __builtin_amdgcn_s_setprio(SPO_HELPER_PRIO);
+  // ---- SPO_H_GATHER: the helpers gather the NEXT minibatch's columns.  Lane (wave, l) serves the column main lane (wave, l)
+  // computes on.  The sample index is loaded right after the x^T image of the previous minibatch has been handed over, the
+  // row / target loads are issued in the idle window before B_stage, and the data is written into the x^T image and the COLS
+  // rows between P1 (dW1 has read the old image) and P3 (the main waves start the next forward) -- none of it on the main
+  // waves, whose lone-wave issue rate (5.5-7.5 cycles per instruction, tools/probes/mfma_valu_overlap.hip) made the settle the
+  // most expensive non-matrix phase of the step.
+  ColData<NT1> hx;
+  int hsmp = 0;
+  // (lane indices through an opaque move at every use, like SPO_REIDX: otherwise the compiler computes the sixteen x^T store
+  //  addresses once, keeps them in registers across the whole loop next to the optimiser state, and spills 100 registers)
+  auto h_perm_pos = [&](int64_t s_) -> int64_t {
+    const int64_t base_ = s_ * B;
+    const int64_t rem_ = a.M - base_;
+    const int nc_ = (int)(rem_ < B ? rem_ : B);
+    const int col_ = 16 * wave + pinned(j_);
+    return base_ + (col_ < nc_ ? col_ : 0);
+  };
+  auto h_fetch = [&](int64_t smp) {
+    const int qq = pinned(q_);
+    load_obs_tiles_raw<KIN>(a.obs + smp * D, D, qq, hx.x);
+    if (!is_actor) {
+      hx.t0 = tgt[smp]; hx.t1 = 0.f; hx.actv = f4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      hx.t0 = a.logp_old[smp]; hx.t1 = a.adv[smp];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ai = 4 * qq + r;
+        hx.actv[r] = a.act[smp * A + (ai < A ? ai : 0)];
+      }
+    }
+  };
+  auto h_publish = [&]() {                    // settle (pad selects) + x^T image + column inputs of the next step
+    const int qq = pinned(q_), col_ = 16 * wave + pinned(j_);
+    float* const xt = lds + U::XT + 4 * qq * LDB + col_;          // ONE address register: the rest are immediate offsets
+    float* const cols = lds + H::COLS + col_;
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) hx.x[nt][e] = pinned(hx.x[nt][e]);
+    mask_obs_tiles<KIN>(D, qq, hx.x);
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xt[(16 * nt + e) * LDB] = hx.x[nt][e];
+    if (qq == 0) { cols[0] = pinned(hx.t0); cols[64] = pinned(hx.t1); }
+    if (is_actor) {
+      float* const ca = cols + (2 + 4 * qq) * 64;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float av = pinned(hx.actv[r]);
+        ca[r * 64] = (4 * qq + r) < A ? av : 0.f;
+      }
+    }
+  };
+  if (SPO_H_GATHER && nsteps > 1) h_fetch((int64_t)a.perm[h_perm_pos(1)]);
   // step 0 has nothing to wait for: its forward runs on the weights staged at launch
   __syncthreads();                                                        // Q2 of step 0
   __syncthreads();                                                        // Xd of step 0
@@ -1958,10 +2054,17 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
     const float inv_n = 1.f / (float)ncols;
     const unsigned tag = (unsigned)(s & 0x3fffffff) + 1u;
     bool redo_next = false;
+    bool h_fetched = false;
     // register backups of layer 1 only: it is the one layer updated before the joint norm is known
     float bmb1, bvb1, bpb1;
     __syncthreads();                                                      // P1: G1 complete
     SPO_STAMP(0)
+    if (SPO_H_GATHER) {
+      // dW1 has read the old x^T image: hand the next minibatch over (the main waves pick it up after P3), then start the
+      // index load of the one after it
+      if (s + 1 < nsteps) h_publish();
+      if (s + 2 < nsteps) hsmp = a.perm[h_perm_pos(s + 2)];
+    }
     {
       // ---- layer 1 (W1, b1): L2 term, norm share, SPECULATIVE Adam (clip coefficient 1)
       SPO_REIDX
@@ -2034,7 +2137,7 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
       f4 gx[7];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) gx[nt] = *reinterpret_cast<const f4*>(lds + H::G2 + ((wave * 4 + nt) * 64 + lane) * 4);
-      gx[4] = *reinterpret_cast<const f4*>(lds + H::G3 + ((wave * 2 + 0) * 64 + lane) * 4);
+      gx[4] = *reinterpret_cast<const f4*>(lds + H::G3 + (wave * 64 + lane) * 4);
       gx[5] = f4{lds[H::GB + 1 * 256 + hl], lds[H::GB + 2 * 256 + hl], 0.f, 0.f};
       gx[6] = f4{0.f, 0.f, 0.f, 0.f};
       if (with_ls) {
@@ -2073,7 +2176,7 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
       }
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f4*>(lds + H::G2 + ((wave * 4 + nt) * 64 + lane) * 4) = gx[nt];
-      *reinterpret_cast<f4*>(lds + H::G3 + ((wave * 2 + 0) * 64 + lane) * 4) = gx[4];
+      *reinterpret_cast<f4*>(lds + H::G3 + (wave * 64 + lane) * 4) = gx[4];
       lds[H::GB + 1 * 256 + hl] = gx[5][0];
       lds[H::GB + 2 * 256 + hl] = gx[5][1];
       if (with_ls) {
@@ -2157,7 +2260,7 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
       {
         // ---- output layer (W3, b3, log_std): the same, backups in registers; then the norm share goes out
         SPO_REIDX
-        const f4 gv = *reinterpret_cast<const f4*>(lds + H::G3 + ((wave * 2 + 0) * 64 + lane) * 4);
+        const f4 gv = *reinterpret_cast<const f4*>(lds + H::G3 + (wave * 64 + lane) * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {                                       // pad rows hold p == 0, g == 0
           const int addr = L::W3 + (4 * q + r) * LDH + 16 * wave + j;
@@ -2193,6 +2296,12 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
       }
       SPO_STAMP(5)
       if (s + 1 < nsteps) __syncthreads();                                // Xd of step s + 1: W3 / b3 / log_std in place
+#if SPO_H_GATHER == 2
+      // rows / targets of minibatch s + 2 right behind Xd: a whole backward pass + dW1 of the main waves to land (issued after
+      // B_stage they were not back by P1: the helper stalled on them at the head of its critical P1 -> P3 stretch, 11.5 against
+      // 10.8 us per step)
+      if (s + 2 < nsteps) { h_fetch((int64_t)pinned(hsmp)); h_fetched = true; }
+#endif
       SPO_STAMP(9)
       {
         if (wave == 0 && lane == 0 && s + 1 < nsteps) {
@@ -2272,7 +2381,7 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
           }
         }
         {
-          const f4 gv = *reinterpret_cast<const f4*>(lds + H::G3 + ((wave * 2 + 0) * 64 + lane) * 4);
+          const f4 gv = *reinterpret_cast<const f4*>(lds + H::G3 + (wave * 64 + lane) * 4);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {                                       // pad rows hold p == 0, g == 0
             const float p_ = lds[L::W3 + (4 * q + r) * LDH + 16 * wave + j];
@@ -2401,6 +2510,10 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
       spec = a.spec_mode != 0 && coef == 1.f;
     }
     SPO_STAMP(6)
+    // rows / targets of minibatch s + 2: issued AFTER B_stage(s + 1), in flight while the main waves compute dW1, consumed right
+    // after P1 -- the 22 registers are live only where the helper holds nothing but its optimiser state (issued before the
+    // verdict code they cost 94 spilled registers)
+    if (SPO_H_GATHER && s + 2 < nsteps && !h_fetched) h_fetch((int64_t)pinned(hsmp));
   }
   if (PROF && a.prof && tid == 256 && wg == a.n_nets - 1)
     for (int i = 0; i < NPHASE; ++i) a.prof[NPHASE + i] = pacc[i];
@@ -2783,8 +2896,14 @@ static int fill_xr(UpdArgs& a, int rank, int world, void* const* regions, unsign
   SPO_REQUIRE(regions != nullptr, "p2p: regions is NULL");
   for (int r = 0; r < world; ++r) SPO_REQUIRE(regions[r] != nullptr, "p2p: region of rank %d is NULL", r);
   a.xr_rank = rank; a.xr_world = world; a.xr_step0 = step0;
-  const char* algo = getenv("SPO_P2P_ALGO");                 // "twophase" forces the reduce-scatter form everywhere
-  a.xr_algo = (algo && !strcmp(algo, "twophase")) ? 0 : 1;
+  // Form of the in-kernel exchange.  Default: recursive doubling at 2 and 4 ranks (one / two hand-offs), the packed
+  // reduce-scatter + all-gather at 8 ranks (two hand-offs instead of three, 1.75 x instead of 3 x the gradient on the wire) and at
+  // worlds that are not a power of two.  Loopback on one GPU (profiles/r04/p2p_loopback.txt): doubling 14.4 / 16.8 / 21.4 us per
+  // step at 2 / 4 / 8 ranks, two-phase 17.8 / 18.0 / 19.2.  SPO_P2P_ALGO=twophase | doubling forces one form everywhere.
+  const char* algo = getenv("SPO_P2P_ALGO");
+  if (algo && !strcmp(algo, "twophase")) a.xr_algo = 0;
+  else if (algo && !strcmp(algo, "doubling")) a.xr_algo = 1;
+  else a.xr_algo = world <= 4 ? 1 : 0;
   { const char* dbg = getenv("SPO_A2A_DEBUG"); a.xr_debug = dbg ? atoi(dbg) : 0; }
   for (int r = 0; r < XR_MAX_WORLD; ++r) a.xr_region[r] = r < world ? regions[r] : nullptr;
   return 0;
