@@ -1326,6 +1326,10 @@ __global__ __launch_bounds__(256, 1) void ppo_update_split_kernel(UpdArgs a0, Up
 // under the conservative protocol -- summed over launches by the first helper lane of network 0 at the end of a launch.
 __device__ unsigned long long g_upd_counters[4];
 
+#ifndef SPO_H_W3C_EARLY
+#define SPO_H_W3C_EARLY 1     // 1: the W3 column operands of dO -> dZ2 are read BEFORE the loss arithmetic (their LDS latency hides under the
+                              //    exp / select chain of the loss) instead of after it: 10.68 -> 10.58 us per step, bit-identical
+#endif
 #ifndef SPO_H_GATHER
 // 0: the main waves' own prefetch pipeline (rounds 2-3).  1 / 2: the HELPER waves gather the next minibatch (sample index,
 // observation rows, targets) and write its x^T image + column inputs between P1 and P3; the main waves pick the columns up with
@@ -1758,6 +1762,13 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
           ivar[r] = __builtin_amdgcn_rcpf(sdv * sdv);
           lsd[r] = on ? lsv + LOG_SQRT_2PI : 0.f;
         }
+        float w3c[4][4];
+        if (SPO_H_W3C_EARLY) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) w3c[r][mt] = lds[L::W3 + (4 * q + r) * LDH + 16 * mt + j];
+        }
         f4 dO = {0.f, 0.f, 0.f, 0.f}, dls = {0.f, 0.f, 0.f, 0.f};
         float lsum = 0.f;
         if (!is_actor) {
@@ -1796,11 +1807,12 @@ __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
         f4 dz2[4], dz1[4];
         {
           f4 acc[4];
-          float w3c[4][4];
+          if (!SPO_H_W3C_EARLY) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) w3c[r][mt] = lds[L::W3 + (4 * q + r) * LDH + 16 * mt + j];
+              for (int mt = 0; mt < 4; ++mt) w3c[r][mt] = lds[L::W3 + (4 * q + r) * LDH + 16 * mt + j];
+          }
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) acc[mt] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll

@@ -68,9 +68,9 @@ def test_config5_shape_ppo_update_fp64_yardstick(dev):
     direction of the perturbation, not its size):
       (1) trajectory: the three flat PRE-CLIP gradients of step 1 (identical state: floor 1e-6 of the scale) and the parameters
           after steps 1 and 3 under the yardstick |HIP - f64| <= 3 |f32 oracle - f64| + 1e-5 of the scale, L2 and max-norm;
-      (2) every step on its own ("teacher forcing"): the float64 oracle is put into the HIP state before step k (parameters,
-          PopArt statistics, multiplier) and takes step k -- its losses / gradient norms / entropy / ratio / multiplier / PopArt
-          statistics must equal the HIP step's to 1e-5 (north_star), its pre-clip gradients to 1e-5 of the gradient's scale."""
+      (2) every step on its own ("teacher forcing"): the float64 oracle and the HIP trainer are both put into the HIP state before
+          step k (parameters, PopArt statistics, multiplier) and take step k on the same sample -- losses / gradient norms / entropy /
+          ratio / multiplier / PopArt statistics equal to 1e-5 (north_star), pre-clip gradients to 1e-5 of the gradient's scale."""
     import ma_yardstick as Y
     from oracle import ma_restatement as MR
     from safepo.multi_agent.mappolag import MAPPO_L_Policy, MAPPO_L_Trainer
@@ -82,8 +82,9 @@ def test_config5_shape_ppo_update_fp64_yardstick(dev):
             net.theta.add_(0.05 * torch.randn_like(net.theta))
     nets0 = Y.nets_like(pol, cfg["std_x_coef"], cfg["std_y_coef"])
     s = _sample(ROWS, seed=11)
-    with torch.no_grad():                      # old log-probabilities: the current policy's, jittered
-        lp = MR.log_probs(nets0["actor"](s["obs"]), nets0["actor"].std(), s["actions"])
+    with torch.no_grad():                      # old log-probabilities: the current policy's (in float64, rounded once: the same
+        a64 = Y.to_dtype(nets0["actor"], torch.float64)          # bits on every host, whatever its thread count), jittered
+        lp = MR.log_probs(a64(s["obs"].double()), a64.std(), s["actions"].double()).float()
         s["old_logp"] = lp + 0.03 * torch.randn(ROWS, A, generator=torch.Generator().manual_seed(3))
     tr = MAPPO_L_Trainer(cfg, pol)
     sample = (s["share_obs"], s["obs"], None, None, s["actions"], s["value_preds"], s["returns"], None, s["active_masks"],
@@ -118,30 +119,57 @@ def test_config5_shape_ppo_update_fp64_yardstick(dev):
         for k in SNAP:
             t_hip, t_32 = Y.gate(theta_hip[k][nm], sn32[k][nm], sn64[k][nm], 1e-5, f"{nm} parameters after step {k}")
             print(f"config-5 shape {nm} parameters after step {k}: max|hip-f64| {t_hip:.2e} vs |f32-f64| {t_32:.2e}")
-    # ---- (2) every later step on its own, from the HIP state before it
+    # ---- (2) every later step on its own, from the HIP state before it.  The clipped surrogate is discontinuous in the ratio:
+    # of 524 288 rows a handful sit within fp32 resolution of 1 +- clip_param, and whether such a row's gradient counts is decided
+    # by the last bit of its ratio -- in the reference's fp32 as much as here (one flipped row moves a head gradient by ~2e-5 of
+    # the scale; it made this very comparison fail on one box and pass on another).  So the single-step comparison runs on the
+    # same sample with `factor` zeroed on the rows the float64 oracle finds within 1e-4 of a clip boundary at that state (they
+    # then contribute exactly nothing on either side); everything else about the step is unchanged.
     s64 = Y.to_dtype(s, torch.float64)
     for k in range(2, STEPS + 1):
         th, lam, pa = pre[k]
         tr64, n64 = Y.oracle_trainer(cfg, nets0, "mappolag", torch.float64)
         for nm in n64:
             _load_flat(n64[nm], th[nm])
+        with torch.no_grad():
+            lp64 = MR.log_probs(n64["actor"](s64["obs"]), n64["actor"].std(), s64["actions"])
+            imp64 = torch.prod(torch.exp(lp64 - s64["old_logp"]), dim=-1, keepdim=True)
+            edge = ((imp64 - (1.0 - cfg["clip_param"])).abs() < 1e-4) | ((imp64 - (1.0 + cfg["clip_param"])).abs() < 1e-4)
+        n_edge = int(edge.sum())
+        assert 0 < n_edge < ROWS // 100, n_edge
+        factor_k = torch.where(edge, torch.zeros_like(s["factor"]), s["factor"])
+        sk64 = dict(s64, factor=factor_k.double())
         tr64.lamda = torch.tensor(lam, dtype=torch.float64)
         p = tr64.popart
         p.running_mean, p.running_mean_sq = torch.tensor([pa[0]], dtype=torch.float64), torch.tensor([pa[1]], dtype=torch.float64)
         p.debiasing_term = torch.tensor(pa[2], dtype=torch.float64)
-        rec = tr64.ppo_update(s64)
+        rec = tr64.ppo_update(sk64)
+        # the HIP step from the same state on the same sample
+        for nm, net in nets_hip.items():
+            net.theta.copy_(torch.from_numpy(th[nm]).float().to(dev))
+        tr._lamda.fill_(lam)
+        tr._popart_state.copy_(torch.from_numpy(pa).float().to(dev))
+        tr._sync_normalizer()
+        sample_k = tuple(factor_k.to(dev) if i == 12 else t for i, t in enumerate(sample))
+        vl, cgn, plo, ent, agn, imp, cl, cogn = tr.ppo_update(sample_k)
+        torch.cuda.synchronize()
+        vn = tr.value_normalizer
+        row = [vl.item(), cgn.item(), plo.item(), ent.item(), agn.item(), imp.detach().mean().item(), cl.item(), cogn.item(),
+               float(tr.lamda_lagr), float(vn.running_mean), float(vn.running_mean_sq), float(vn.debiasing_term)]
         # absolute floors: 1e-6 for the three losses (means of O(1) terms with cancellation), 1e-7 for norms / entropy / ratio,
         # 1e-8 for the multiplier, 1e-10 for the PopArt statistics (their values are ~1e-5 here)
         atol = (1e-6, 1e-7, 1e-6, 1e-7, 1e-7, 1e-7, 1e-6, 1e-7, 1e-8, 1e-10, 1e-10, 1e-10)
         for c, nmc in enumerate(names):
-            h, w = rows[k - 1][c], rec["row"][c]
+            h, w = row[c], rec["row"][c]
             assert abs(h - w) <= 1e-5 * abs(w) + atol[c], (f"step {k} {nmc}: HIP {h!r} vs the float64 step from the HIP state {w!r}")
+        worst = 0.0
         for nm in ("actor", "critic", "cost_critic"):
             g64 = rec[gkey[nm]].double().numpy()
-            err = np.abs(grad_hip[k][nm] - g64).max()
+            err = np.abs(opts[nm].grad.double().cpu().numpy() - g64).max()
+            worst = max(worst, err / np.abs(g64).max())
             assert err <= 1e-5 * np.abs(g64).max(), (k, nm, err, np.abs(g64).max())
-        print(f"config-5 shape step {k} from the HIP state: policy loss hip {rows[k - 1][2]:.9e} f64 {rec['row'][2]:.9e}; "
-              f"actor grad max err {np.abs(grad_hip[k]['actor'] - rec['actor_grad'].double().numpy()).max():.2e}")
+        print(f"config-5 shape step {k} from the HIP state ({n_edge} rows at a clip boundary excluded): policy loss hip {row[2]:.9e} "
+              f"f64 {rec['row'][2]:.9e}; worst gradient error {worst:.2e} of its scale")
     o = pol.actor.offset(6)
     assert np.isfinite(grad_hip[1]["actor"][o:o + A]).all()
 
