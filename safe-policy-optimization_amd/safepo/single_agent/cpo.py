@@ -533,7 +533,7 @@ class WideCPOEngine(_WideOps, CPOEngine):
     kept in the flat gradient vector so the joint clip sees and rescales it (cpo.py:557).  Single GPU."""
 
     FAMILY = "cpo"          # what _WideOps._require_policy checks the policy against
-    CHUNK = 65536
+    CHUNK = 65536           # rows per full-batch pass; raised in __init__ for narrow networks (activations stay under ~0.5 GB)
 
     def __init__(self, policy: ActorVCritic, num_envs: int, steps: int, config: dict, device, comm=None):
         super().__init__(policy, num_envs, steps, config, device, comm=comm)
@@ -541,6 +541,10 @@ class WideCPOEngine(_WideOps, CPOEngine):
         w = self.wide
         assert self.Pa == w.A + w.Pa
         self._gtmp = torch.zeros(w.P, dtype=torch.float32, device=self.dev)
+        # one pass of ~40 launches per chunk: a [64, 64] network at 376 observations takes the whole 524 288-row batch in one
+        # chunk (activations 0.3 GB), [1024, 1024, 512] stays at 65 536 rows
+        per_row = sum(policy.hidden_sizes) + policy.act_dim + policy.obs_dim
+        self.CHUNK = max(self.CHUNK, min(self.M, (1 << 27) // max(per_row, 1)))
         self._critics_on_persistent_kernel = (list(policy.hidden_sizes) == [64, 64] and policy.obs_dim <= _abi.MAX_OBS)
 
     def _alloc_full_batch_workspaces(self) -> None:
