@@ -518,6 +518,15 @@ int spo_wide_linesearch_sums(const float* mean_new, const float* log_std_new, co
                              const float* adv_a, const float* adv_b, const float* mean_old, const float* log_std_old, int64_t rows,
                              int act_dim, double* partial_ws, int partial_capacity, double* sums3_inout, int accumulate,
                              void* stream);
+/* spo_wide_clip_adam_dev -- spo_wide_clip_adam_ex with the optimiser clocks on the DEVICE: pow4_dev = double[4] = {beta1^t, beta2^t of
+ * the critics' optimisers, beta1^t, beta2^t of the actor's} before this step; the clocks of the optimisers inside the Adam range
+ * advance on the device.  No argument changes from one minibatch step to the next, so the launch sequence of a step (gathers,
+ * spo_mlp_forward / backward, loss kernels, this) can be captured once as a HIP graph and replayed: the wide path at the reference's
+ * default batch of 64 is launch-bound (~70 launches per step).  The caller keeps pow4_dev in step with its host-side step counts. */
+int spo_wide_clip_adam_dev(float* theta, float* grad, float* adam_m, float* adam_v, int64_t n_params, int64_t reward_critic_end,
+                           int64_t cost_critic_end, int64_t actor_begin, const spo_ppo_cfg* cfg, double* pow4_dev, int64_t adam_begin,
+                           int64_t adam_end, int64_t norm_begin, int scale_rest, float* losses3_inout, float* scalars4_out,
+                           double* partial_ws, int partial_capacity, void* stream);
 int spo_wide_clip_adam_ex(float* theta, float* grad, float* adam_m, float* adam_v, int64_t n_params, int64_t reward_critic_end,
                           int64_t cost_critic_end, int64_t actor_begin, const spo_ppo_cfg* cfg, int64_t adam_step_critics_host,
                           int64_t adam_step_actor_host, int64_t adam_begin, int64_t adam_end, int64_t norm_begin, int scale_rest,

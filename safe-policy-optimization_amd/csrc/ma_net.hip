@@ -3301,6 +3301,61 @@ extern "C" int spo_wide_linesearch_sums(const float* mean_new, const float* log_
   return 0;
 }
 
+// Device-resident optimiser clocks: pow4_dev = {beta1^t, beta2^t of the critics' optimisers, beta1^t, beta2^t of the actor's} BEFORE this
+// step.  The clocks of the optimisers inside [adam_begin, adam_end) advance by one step on the device (one thread, between the
+// norm and the Adam pass), so the launch sequence of a minibatch step has no host-side argument that changes from step to step and
+// can be captured once as a HIP graph and replayed (the wide path at small batches is launch-bound: ~70 launches per step).
+namespace {
+using namespace spo;
+__global__ void wide_pow_advance_kernel(double* pow4, double b1, double b2, int critics, int actor) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (critics) { pow4[0] *= b1; pow4[1] *= b2; }
+  if (actor) { pow4[2] *= b1; pow4[3] *= b2; }
+}
+__global__ __launch_bounds__(256) void wide_adam_dev_kernel(WideAdamExArgs x, const double* __restrict__ pow4) {
+  const WideAdamArgs& a = x.b;
+  const float coef = a.scal[0];
+  float ss_a, ss_c, bc2s_a, bc2s_c;
+  adam_scalars(a.lr_actor, pow4[2], pow4[3], ss_a, bc2s_a);          // pow4 already advanced: beta^(t+1)
+  adam_scalars(a.lr_critic, pow4[0], pow4[1], ss_c, bc2s_c);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.P; i += (int64_t)gridDim.x * 256) {
+    if (i >= x.adam_begin && i < x.adam_end) {
+      const bool act = i >= a.actor_begin;
+      const AdamOut o = adam1(a.theta[i], a.grad[i] * coef, a.m[i], a.v[i], a.b1, a.b2, a.eps, act ? ss_a : ss_c, act ? bc2s_a : bc2s_c);
+      a.theta[i] = o.p; a.m[i] = o.m; a.v[i] = o.v;
+    } else if (x.scale_rest) {
+      a.grad[i] = a.grad[i] * coef;
+    }
+  }
+}
+}  // namespace
+extern "C" int spo_wide_clip_adam_dev(float* theta, float* grad, float* adam_m, float* adam_v, int64_t n_params, int64_t reward_critic_end,
+                                      int64_t cost_critic_end, int64_t actor_begin, const spo_ppo_cfg* cfg, double* pow4_dev,
+                                      int64_t adam_begin, int64_t adam_end, int64_t norm_begin, int scale_rest, float* losses3_inout,
+                                      float* scalars4_out, double* partial_ws, int partial_capacity, void* stream) {
+  SPO_REQUIRE(theta && grad && adam_m && adam_v && cfg && pow4_dev && scalars4_out && partial_ws && n_params > 0, "wide_clip_adam_dev: bad args");
+  SPO_REQUIRE(0 <= reward_critic_end && reward_critic_end <= cost_critic_end && cost_critic_end <= actor_begin && actor_begin <= n_params,
+              "wide_clip_adam_dev: parameter ranges out of order");
+  SPO_REQUIRE(0 <= adam_begin && adam_begin <= adam_end && adam_end <= n_params && 0 <= norm_begin && norm_begin <= n_params,
+              "wide_clip_adam_dev: optimiser range out of order");
+  int64_t blocks = (n_params + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  SPO_REQUIRE((int64_t)partial_capacity >= blocks * 3, "wide_clip_adam_dev: partial workspace too small");
+  WideAdamArgs a{theta, grad, adam_m, adam_v, n_params, reward_critic_end, cost_critic_end, actor_begin,
+                 cfg->use_critic_norm ? cfg->l2_coef : 0.f, cfg->use_value_coefficient ? 2.f : 1.f, cfg->max_grad_norm, cfg->lr_actor,
+                 cfg->lr_critic, cfg->beta1, cfg->beta2, cfg->adam_eps, 1.0, 1.0, partial_ws, scalars4_out, losses3_inout};
+  WideAdamExArgs x{a, adam_begin, adam_end, scale_rest, 1.0, 1.0};
+  hipStream_t st = (hipStream_t)stream;
+  if (norm_begin == 0) hipLaunchKernelGGL(wide_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(wide_prep_range_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, norm_begin, n_params);
+  hipLaunchKernelGGL(wide_coef_kernel, dim3(1), dim3(64), 0, st, a, (int)blocks);
+  hipLaunchKernelGGL(wide_pow_advance_kernel, dim3(1), dim3(64), 0, st, pow4_dev, (double)cfg->beta1, (double)cfg->beta2,
+                     adam_begin < actor_begin ? 1 : 0, adam_end > actor_begin ? 1 : 0);
+  hipLaunchKernelGGL(wide_adam_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, (const double*)pow4_dev);
+  SPO_LAUNCH_CHECK("spo_wide_clip_adam_dev");
+  return 0;
+}
+
 extern "C" int spo_wide_clip_adam_ex(float* theta, float* grad, float* adam_m, float* adam_v, int64_t n_params, int64_t reward_critic_end,
                                      int64_t cost_critic_end, int64_t actor_begin, const spo_ppo_cfg* cfg, int64_t adam_step_critics_host,
                                      int64_t adam_step_actor_host, int64_t adam_begin, int64_t adam_end, int64_t norm_begin,

@@ -151,6 +151,8 @@ PROTOTYPES = {
     "spo_wide_linesearch_sums": (c_int, [P] * 8 + [c_int64, c_int, P, c_int, P, c_int, P]),
     "spo_wide_clip_adam_ex": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, POINTER(PpoCfg), c_int64, c_int64, c_int64,
                                       c_int64, c_int64, c_int, P, P, P, c_int, P]),
+    "spo_wide_clip_adam_dev": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, POINTER(PpoCfg), P, c_int64, c_int64, c_int64, c_int,
+                                       P, P, P, c_int, P]),
     "spo_param_count": (c_int64, [c_int, c_int]),
     "spo_param_offset": (c_int64, [c_int, c_int, c_int]),
     "spo_synth_env_step": (c_int, [P] * 7 + [c_int64, c_int, c_uint64, c_uint64, c_float, c_float, c_int, P]),

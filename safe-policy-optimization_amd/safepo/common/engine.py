@@ -444,6 +444,46 @@ class _WideOps:
         self.loss_partials = torch.zeros(256 * (3 + _abi.WIDE_MAX_ACT) + 1024 + 3 * 1024, dtype=torch.float64, device=self.dev)
         self.actor_sums = torch.zeros(2 + _abi.WIDE_MAX_ACT, dtype=torch.float64, device=self.dev)
         self.scal4 = torch.zeros(4, **f32)
+        # device-resident optimiser clocks {beta1^t, beta2^t} of the critics' and the actor's optimisers (spo_wide_clip_adam_dev):
+        # a minibatch step then has no host argument that changes between steps and is replayed from ONE captured HIP graph
+        self.pow4 = torch.ones(4, dtype=torch.float64, device=self.dev)
+        self._step_graphs = {}
+        self.graph_max_batch = int(os.environ.get("SPO_WIDE_GRAPH_MAX_BATCH", "2048"))     # 0: never (every launch eager)
+
+    # ------------------------------------------------------------------ graph-replayed minibatch steps
+    def _sync_pow4(self) -> None:
+        """Device clocks from the host step counts (start of a pass, after an eager step)."""
+        b1, b2 = float(np.float32(0.9)), float(np.float32(0.999))
+        tc, ta = self.adam_step, self.adam_step + self.adam_step_actor_extra
+        self.pow4.copy_(torch.tensor([b1 ** tc, b2 ** tc, b1 ** ta, b2 ** ta], dtype=torch.float64))
+
+    def _graphed(self, key, idx: torch.Tensor, losses_out: torch.Tensor, body) -> None:
+        """Run `body(idx_static, loss_static)` -- the launch sequence of one minibatch step on static buffers, optimiser clocks
+        on the device -- as a replay of a HIP graph captured on first use (the wide path at small batches is launch-bound: ~70
+        launches per step).  `key` carries everything baked into the captured kernel arguments (the cfg struct's bytes: learning
+        rates change per epoch; the loss options; the batch).  First use: one eager run for the lazy per-kernel set-up (its effects
+        on parameters / moments / clocks undone), then the capture."""
+        ent = self._step_graphs.get(key)
+        if ent is None:
+            if len(self._step_graphs) >= 6:
+                self._step_graphs.clear()
+            n = idx.numel()
+            st = {"idx": torch.zeros(n, dtype=torch.int64, device=self.dev),
+                  "loss": torch.full((3,), float("nan"), dtype=torch.float32, device=self.dev)}
+            st["idx"].copy_(idx)
+            snap = [t.clone() for t in (self.policy.theta, self.adam_m, self.adam_v, self.pow4, self.flat_grad)]
+            body(st["idx"], st["loss"])
+            for t, b in zip((self.policy.theta, self.adam_m, self.adam_v, self.pow4, self.flat_grad), snap):
+                t.copy_(b)
+            torch.cuda.synchronize(self.dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                body(st["idx"], st["loss"])
+            ent = self._step_graphs[key] = (g, st)
+        g, st = ent
+        st["idx"].copy_(idx)
+        g.replay()
+        losses_out.copy_(st["loss"])
 
     def _values_into(self, obs, out_r, out_c) -> None:
         v_r, v_c = self.wide.values(obs)
@@ -510,10 +550,11 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
                 d["log_prob"].view(-1).index_select(0, idx), d["target_value_r"].view(-1).index_select(0, idx),
                 d["target_value_c"].view(-1).index_select(0, idx))
 
-    def minibatch_step(self, idx: torch.Tensor, losses_out: torch.Tensor) -> None:
-        """ppo_lag.py:306-329 on the rows `idx` (int64 device indices into the flat buffer)."""
+    def minibatch_step(self, idx: torch.Tensor, losses_out: torch.Tensor, dev_clock: bool = False, cfg=None) -> None:
+        """ppo_lag.py:306-329 on the rows `idx` (int64 device indices into the flat buffer).  dev_clock: optimiser clocks from
+        self.pow4 on the device (the graph-replayed form; the caller advances self.adam_step)."""
         w, lib, st = self.wide, self.lib, _abi.stream_ptr
-        cfg = self._cfg_struct()
+        cfg = self._cfg_struct() if cfg is None else cfg
         obs, act, logp_old, tgt_r, tgt_c = self._gather(idx)
         adv = self.buffer.adv_mix.view(-1).index_select(0, idx)
         n = obs.shape[0]
@@ -531,6 +572,12 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
         w.backward("r", obs, ws_r, d_vr, g)
         w.backward("c", obs, ws_c, d_vc, g)
         w.backward("a", obs, ws_a, d_mu, g)
+        if dev_clock:
+            _abi.check(lib.spo_wide_clip_adam_dev(_abi.ptr(self.policy.theta), _abi.ptr(g), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), w.P,
+                                                  w.off_c, w.off_ls, w.off_ls, cfg, _abi.ptr(self.pow4), 0, w.P, 0, 0, _abi.ptr(losses_out),
+                                                  _abi.ptr(self.scal4), _abi.ptr(self.loss_partials), self.loss_partials.numel(), st()),
+                       "spo_wide_clip_adam_dev")
+            return
         _abi.check(lib.spo_wide_clip_adam(_abi.ptr(self.policy.theta), _abi.ptr(g), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), w.P,
                                           w.off_c, w.off_ls, w.off_ls, cfg, self.adam_step, _abi.ptr(losses_out), _abi.ptr(self.scal4),
                                           _abi.ptr(self.loss_partials), self.loss_partials.numel(), st()), "spo_wide_clip_adam")
@@ -542,15 +589,27 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
         M = self.M
         n_mb = (M + cfg.batch - 1) // cfg.batch
         losses = torch.empty((n_mb, 3), dtype=torch.float32, device=self.dev)
+        graphed = 0 < cfg.batch <= self.graph_max_batch and n_mb > 2
+        if graphed:
+            self._sync_pow4()
+            key = ("ppo", bytes(cfg))
         for k in range(n_mb):
-            self.minibatch_step(perm[k * cfg.batch:(k + 1) * cfg.batch], losses[k])
+            idx = perm[k * cfg.batch:(k + 1) * cfg.batch]
+            if graphed and idx.numel() == cfg.batch:
+                self._graphed(key, idx, losses[k], lambda i_, l_: self.minibatch_step(i_, l_, dev_clock=True, cfg=cfg))
+                self.adam_step += 1
+            else:                                   # (the ragged last minibatch: its own shapes, host clocks)
+                self.minibatch_step(idx, losses[k], cfg=cfg)
+                if graphed:
+                    self._sync_pow4()
         return losses
 
-    def minibatch_step_ex(self, idx, adv_all, losses_out, actor_loss, kl_bound, pg_coef, actor_only) -> None:
+    def minibatch_step_ex(self, idx, adv_all, losses_out, actor_loss, kl_bound, pg_coef, actor_only, dev_clock: bool = False,
+                          cfg=None) -> None:
         """One FOCOPS minibatch step (focops.py:312-347) or one step of CUP's actor-only second stage (cup.py:370-386) on the
         wide kernels: spo_update_iter_ex's semantics (include/safepo_hip.h), one minibatch."""
         w, lib, st = self.wide, self.lib, _abi.stream_ptr
-        cfg = self._cfg_struct()
+        cfg = self._cfg_struct() if cfg is None else cfg
         obs, act, logp_old, tgt_r, tgt_c = self._gather(idx)
         adv = adv_all.view(-1).index_select(0, idx)
         n = obs.shape[0]
@@ -579,6 +638,12 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
         w.backward("a", obs, ws_a, d_mu, g)
         step_c, step_a = self.adam_step, self.adam_step + self.adam_step_actor_extra
         lo, norm0 = (off_ls, off_ls) if actor_only else (0, 0)
+        if dev_clock:
+            _abi.check(lib.spo_wide_clip_adam_dev(_abi.ptr(self.policy.theta), _abi.ptr(g), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), w.P,
+                                                  w.off_c, w.off_ls, w.off_ls, cfg, _abi.ptr(self.pow4), lo, w.P, norm0, 0,
+                                                  None if actor_only else _abi.ptr(losses_out), _abi.ptr(self.scal4), _abi.ptr(part), cap,
+                                                  st()), "spo_wide_clip_adam_dev")
+            return
         _abi.check(lib.spo_wide_clip_adam_ex(_abi.ptr(self.policy.theta), _abi.ptr(g), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), w.P,
                                              w.off_c, w.off_ls, w.off_ls, cfg, step_c, step_a, lo, w.P, norm0, 0,
                                              None if actor_only else _abi.ptr(losses_out), _abi.ptr(self.scal4), _abi.ptr(part), cap,
@@ -592,10 +657,21 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
         M = self.M
         n_mb = (M + cfg.batch - 1) // cfg.batch
         losses = torch.full((n_mb, 3), float("nan"), dtype=torch.float32, device=self.dev)
+        graphed = 0 < cfg.batch <= self.graph_max_batch and n_mb > 2
+        if graphed:
+            self._sync_pow4()
+            key = ("ex", bytes(cfg), int(actor_loss), float(kl_bound), float(pg_coef), bool(actor_only), adv.data_ptr())
         for k in range(n_mb):
-            self.minibatch_step_ex(perm[k * cfg.batch:(k + 1) * cfg.batch], adv, losses[k], actor_loss, kl_bound, pg_coef, actor_only)
+            idx = perm[k * cfg.batch:(k + 1) * cfg.batch]
+            if graphed and idx.numel() == cfg.batch:
+                self._graphed(key, idx, losses[k], lambda i_, l_: self.minibatch_step_ex(i_, adv, l_, actor_loss, kl_bound, pg_coef,
+                                                                                         actor_only, dev_clock=True, cfg=cfg))
+            else:
+                self.minibatch_step_ex(idx, adv, losses[k], actor_loss, kl_bound, pg_coef, actor_only, cfg=cfg)
             if actor_only:
                 self.adam_step_actor_extra += 1
             else:
                 self.adam_step += 1
+            if graphed and idx.numel() != cfg.batch:
+                self._sync_pow4()
         return losses

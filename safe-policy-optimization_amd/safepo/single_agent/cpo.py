@@ -635,27 +635,44 @@ class WideCPOEngine(_WideOps, CPOEngine):
         tr_all, tc_all = d["target_value_r"].view(-1), d["target_value_c"].view(-1)
         g, part, cap = self.flat_grad, self.loss_partials, self.loss_partials.numel()
         all_losses = []
+        def step(idx, loss3, dev_clock):
+            obs, tgt_r, tgt_c = obs_all.index_select(0, idx), tr_all.index_select(0, idx), tc_all.index_select(0, idx)
+            n = obs.shape[0]
+            v_r, ws_r = w.forward("r", obs, slot=1)
+            v_c, ws_c = w.forward("c", obs, slot=1)
+            d_vr = torch.empty(n, dtype=torch.float32, device=self.dev)
+            d_vc = torch.empty_like(d_vr)
+            _abi.check(lib.spo_wide_critic_loss(_abi.ptr(v_r), _abi.ptr(v_c), _abi.ptr(tgt_r), _abi.ptr(tgt_c), n, _abi.ptr(d_vr),
+                                                _abi.ptr(d_vc), _abi.ptr(loss3), _abi.ptr(part), cap, _abi.stream_ptr()),
+                       "spo_wide_critic_loss")
+            w.backward("r", obs, ws_r, d_vr, g)
+            w.backward("c", obs, ws_c, d_vc, g)
+            if dev_clock:
+                _abi.check(lib.spo_wide_clip_adam_dev(_abi.ptr(self.policy.theta), _abi.ptr(g), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v),
+                                                      w.P, w.off_c, w.off_ls, w.off_ls, cfg, _abi.ptr(self.pow4), 0, w.off_ls, 0, 1,
+                                                      _abi.ptr(loss3), _abi.ptr(self.scal4), _abi.ptr(part), cap, _abi.stream_ptr()),
+                           "spo_wide_clip_adam_dev")
+            else:
+                _abi.check(lib.spo_wide_clip_adam_ex(_abi.ptr(self.policy.theta), _abi.ptr(g), _abi.ptr(self.adam_m),
+                                                     _abi.ptr(self.adam_v), w.P, w.off_c, w.off_ls, w.off_ls, cfg, self.adam_step,
+                                                     self.adam_step, 0, w.off_ls, 0, 1, _abi.ptr(loss3), _abi.ptr(self.scal4),
+                                                     _abi.ptr(part), cap, _abi.stream_ptr()), "spo_wide_clip_adam_ex")
+        graphed = 0 < cfg.batch <= self.graph_max_batch and n_mb > 2         # launch-bound regime: one captured graph per step
+        key = ("critic_fit", bytes(cfg))
         for it in range(c["learning_iters"]):
             perm = _abi.require_gpu_tensor(perm_fn(it), "perm", torch.int32).long()
             losses = torch.empty((n_mb, 3), dtype=torch.float32, device=self.dev)
+            if graphed:
+                self._sync_pow4()
             for k in range(n_mb):
                 idx = perm[k * cfg.batch:(k + 1) * cfg.batch]
-                obs, tgt_r, tgt_c = obs_all.index_select(0, idx), tr_all.index_select(0, idx), tc_all.index_select(0, idx)
-                n = obs.shape[0]
-                v_r, ws_r = w.forward("r", obs, slot=1)
-                v_c, ws_c = w.forward("c", obs, slot=1)
-                d_vr = torch.empty(n, dtype=torch.float32, device=self.dev)
-                d_vc = torch.empty_like(d_vr)
-                _abi.check(lib.spo_wide_critic_loss(_abi.ptr(v_r), _abi.ptr(v_c), _abi.ptr(tgt_r), _abi.ptr(tgt_c), n, _abi.ptr(d_vr),
-                                                    _abi.ptr(d_vc), _abi.ptr(losses[k]), _abi.ptr(part), cap, _abi.stream_ptr()),
-                           "spo_wide_critic_loss")
-                w.backward("r", obs, ws_r, d_vr, g)
-                w.backward("c", obs, ws_c, d_vc, g)
-                _abi.check(lib.spo_wide_clip_adam_ex(_abi.ptr(self.policy.theta), _abi.ptr(g), _abi.ptr(self.adam_m),
-                                                     _abi.ptr(self.adam_v), w.P, w.off_c, w.off_ls, w.off_ls, cfg, self.adam_step,
-                                                     self.adam_step, 0, w.off_ls, 0, 1, _abi.ptr(losses[k]), _abi.ptr(self.scal4),
-                                                     _abi.ptr(part), cap, _abi.stream_ptr()), "spo_wide_clip_adam_ex")
+                if graphed and idx.numel() == cfg.batch:
+                    self._graphed(key, idx, losses[k], lambda i_, l_: step(i_, l_, True))
+                else:
+                    step(idx, losses[k], False)
                 self.adam_step += 1
+                if graphed and idx.numel() != cfg.batch:
+                    self._sync_pow4()
             all_losses.append(losses[:, :2])
         # keep the norm the persistent kernel would carry in step with the rescaled vector
         self.stale_sq.copy_(g[self.ls_off:].dot(g[self.ls_off:]).reshape(1))

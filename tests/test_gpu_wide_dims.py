@@ -333,3 +333,40 @@ def test_default_sweep_algorithms_train_at_humanoid_dims(dev, tmp_path, algo):
     assert out["policy"].obs_dim == 376 and out["policy"].act_dim == 17
     for col in ("Loss/Loss_actor", "Loss/Loss_reward_critic", "Loss/Loss_cost_critic", "Train/KL"):
         assert np.isfinite(float(rows[-1][col])), (col, rows[-1][col])
+
+
+@pytest.mark.parametrize("D,A,hidden", [(60, 8, [128, 128]), (376, 17, [64, 64])])
+def test_wide_steps_replayed_from_a_graph_equal_eager_launches(dev, D, A, hidden):
+    """The wide path at the reference's default batch of 64 is launch-bound (~70 launches per minibatch step), so a step is
+    captured ONCE as a HIP graph (optimiser clocks on the device: spo_wide_clip_adam_dev) and replayed.  Same kernels, same
+    arguments: losses and parameters after two passes equal the eager launches bit for bit -- including the ragged last
+    minibatch, which runs eagerly in between, and the learning-rate change between passes (a new capture)."""
+    import time
+    from safepo.common.engine import WidePPOLagEngine
+    from test_gpu_parity import _fill_update_problem
+    M, batch = 64 * 24 + 19, 64
+    problem = _synthetic_update_problem(M, D, A, seed=23)
+    perms = [torch.randperm(M, generator=torch.Generator().manual_seed(s_)).to(torch.int32).to(dev) for s_ in (1, 2)]
+    out = {}
+    for mode, gmax in (("eager", 0), ("graph", 2048)):
+        pol, _ = _wide_pair(D, A, hidden, dev, seed=31)
+        cfg = {"hidden_sizes": hidden, "gamma": 0.99, "target_kl": 0.02, "batch_size": batch, "learning_iters": 1, "max_grad_norm": 40.0}
+        eng = WidePPOLagEngine(pol, 1, M, cfg, dev)
+        eng.graph_max_batch = gmax
+        _fill_update_problem(eng, problem)
+        eng.learning_iter(perms[0])                 # (first pass: lazy set-up, graph capture)
+        eng.lr_factor = 0.7                         # LinearLR between epochs: a different cfg -> its own capture
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        l2 = eng.learning_iter(perms[1])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        eng.lr_factor = 1.0
+        l3 = eng.learning_iter(perms[0])            # back to the first cfg: its graph is still there
+        torch.cuda.synchronize()
+        out[mode] = (l2.cpu(), l3.cpu(), pol.theta.cpu().clone(), eng.adam_step, dt / (M // batch + 1))
+        assert (len(eng._step_graphs) == 2) == (mode == "graph")
+    assert out["eager"][3] == out["graph"][3] == 3 * (M // batch + 1)
+    for i in range(3):
+        assert torch.equal(out["eager"][i], out["graph"][i]), i
+    print(f"wide minibatch step ({D}, {A}, {hidden}, batch {batch}): eager {out['eager'][4] * 1e6:.0f} us, graph replay {out['graph'][4] * 1e6:.0f} us")
