@@ -258,11 +258,9 @@ def run_epochs(algo, a, comm, dev, N, T, D, A, steps, warmup, time_gae):
     def epoch(timed: bool):
         nonlocal obs
         t0 = time.time()
-        for t in range(T):
-            act = eng.collect_step(t, obs, rms=rms)
-            nobs, rew, cost, term, trunc, info = env.step(act)
-            eng.post_step(t, nobs, rew, cost, term, trunc, info["final_observation"], rms=rms)
-            obs = nobs
+        # T x (collect_step -> env.step -> post_step), the loop of safepo/single_agent/_first_order.py: replayed from one HIP
+        # graph after its first use (engine.rollout_epoch; SPO_ROLLOUT_GRAPH=0: the eager loop)
+        obs = eng.rollout_epoch(env, obs, rms=rms)
         n_ep = eng.drain_episode_events(None)
         torch.cuda.synchronize(dev)
         t1 = time.time()

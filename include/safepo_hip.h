@@ -139,6 +139,18 @@ int spo_boundary_step_fold(const float* reward, const float* cost, const float* 
                            int events_capacity, int64_t num_envs, int64_t T, int64_t t, int epoch_end,
                            float* fold_reward, float* fold_cost, double gamma, void* stream);
 
+/* The same step on num_envs / 256 workgroups instead of one (the one-block kernel is a 24 us latency chain at 4 096 envs).  The
+ * running event count lives in events_prefix (int[T + 1], events_prefix[0] = 0 at the start of an epoch): the kernel of step t
+ * reads events_prefix[t], appends this step's finished episodes in env order and writes events_prefix[t + 1]; after the epoch
+ * events_prefix[T] records are valid.  fold_reward / fold_cost may both be NULL.  Everything else as spo_boundary_step_fold;
+ * results (buffers, masks, event log) are identical. */
+int spo_boundary_step_fold_mb(const float* reward, const float* cost, const float* terminated, const float* truncated,
+                              const float* v_next_r, const float* v_next_c, const float* v_final_r, const float* v_final_c,
+                              float* buf_reward, float* buf_cost, uint8_t* seg_end, float* boot_r, float* boot_c,
+                              double* ep_ret, double* ep_cost, double* ep_len, double* events, int* events_prefix,
+                              int events_capacity, int64_t num_envs, int64_t T, int64_t t, int epoch_end,
+                              float* fold_reward, float* fold_cost, double gamma, void* stream);
+
 /* ---- a-9/a-10: one learning iteration of the PPO-Lagrangian update (ppo_lag.py:297-336):
  * for each consecutive chunk of `batch` indices of perm[M] (last partial chunk kept): gather,
  * 3x MLP fwd, loss_r/loss_c (MSE + 0.001*L2 if use_critic_norm), clipped surrogate, backward,
@@ -327,6 +339,13 @@ int64_t spo_param_offset(int obs_dim, int act_dim, int net /*0 r-critic,1 c-crit
 int spo_synth_env_step(float* next_obs, float* final_obs, float* reward, float* cost, float* terminated,
                        float* truncated, int* t_env, int64_t num_envs, int obs_dim, uint64_t seed,
                        uint64_t step, float p_term, float p_cost, int trunc_len, void* stream);
+
+/* The same with the step counter split into a device-resident base and a host offset: step = *step_base_dev + step_rel.  A launch
+ * captured into a HIP graph (step_rel = the index inside the epoch) then draws fresh numbers at every replay once the host has
+ * moved *step_base_dev to the epoch's first step (the collect loop as one graph replay per step, safepo/common/engine.py). */
+int spo_synth_env_step_rel(float* next_obs, float* final_obs, float* reward, float* cost, float* terminated,
+                           float* truncated, int* t_env, int64_t num_envs, int obs_dim, uint64_t seed,
+                           uint64_t step_rel, const uint64_t* step_base_dev, float p_term, float p_cost, int trunc_len, void* stream);
 
 /* ---- f3: multi-agent MAPPO-L networks and update (csrc/ma_net.hip).
  * Networks: safepo/common/model.py:172-363 + safepo/utils/{mlp,act,distributions}.py -- LayerNorm(obs), then n_blocks x

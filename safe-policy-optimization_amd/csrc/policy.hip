@@ -329,6 +329,76 @@ __global__ __launch_bounds__(1024) void boundary_kernel(BoundaryArgs a) {
   if (tid == 0) *a.events_count = base;
 }
 
+// Multi-workgroup form (round 4).  The one-block kernel above is a latency chain: four passes over 4 096 envs, each with ten
+// dependent loads, six scattered 4-byte stores (stride T * 4 bytes: one cache line per lane) and three barriers -- 24 us per
+// step, the longest kernel of the collect loop.  Here a workgroup takes 256 envs in ONE pass.  The event log must stay in env
+// order (the order of the reference's Python loop), so a finished episode's position is base + (finished episodes of ALL envs
+// before it): a workgroup counts the finished episodes of the envs in front of its chunk itself (b * 256 flag pairs, L2-resident,
+// b loads per thread) instead of waiting for the other workgroups.  The running count lives in a prefix array indexed by the
+// step -- the kernel of step t reads events_prefix[t] and the last workgroup writes events_prefix[t + 1] -- so no workgroup ever
+// reads a word another workgroup of the same launch writes.
+__global__ __launch_bounds__(256) void boundary_mb_kernel(BoundaryArgs a, int* __restrict__ events_prefix) {
+  __shared__ int wave_cnt[4];
+  __shared__ int before_sh[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t c0 = (int64_t)blockIdx.x * 256;
+  const int base = events_prefix[a.t];
+  // finished episodes among the envs in front of this chunk
+  int cnt = 0;
+  for (int64_t i = tid; i < c0; i += 256) cnt += (a.terminated[i] != 0.f || a.truncated[i] != 0.f) ? 1 : 0;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+  if (lane == 0) before_sh[wave] = cnt;
+  const int64_t i = c0 + tid;
+  const bool in = i < a.N;
+  bool fin = false;
+  double ret = 0, cst = 0, len = 0;
+  if (in) {
+    const float rw = a.reward[i], cs = a.cost[i];
+    const bool done = a.terminated[i] != 0.f, tout = a.truncated[i] != 0.f;
+    ret = a.ep_ret[i] + (double)rw;
+    cst = a.ep_cost[i] + (double)cs;
+    len = a.ep_len[i] + 1.0;
+    const bool boundary = a.epoch_end || done || tout;
+    float br = 0.f, bc = 0.f;
+    if (boundary && !done) {
+      if (a.epoch_end) { br = a.v_next_r[i]; bc = a.v_next_c[i]; }
+      if (tout) { br = a.v_final_r[i]; bc = a.v_final_c[i]; }       // final_observation wins (ppo_lag.py:209-213)
+    }
+    const int64_t slot = i * a.T + a.t;
+    a.buf_reward[slot] = rw;
+    a.buf_cost[slot] = cs;
+    a.seg_end[slot] = boundary ? 1 : 0;
+    a.boot_r[slot] = br;
+    a.boot_c[slot] = bc;
+    if (a.fold_reward) {
+      a.fold_reward[slot] = boundary ? __fadd_rn(rw, __fmul_rn(a.gamma32, br)) : rw;
+      a.fold_cost[slot] = boundary ? __fadd_rn(cs, __fmul_rn(a.gamma32, bc)) : cs;
+    }
+    fin = done || tout;
+    a.ep_ret[i] = fin ? 0.0 : ret;
+    a.ep_cost[i] = fin ? 0.0 : cst;
+    a.ep_len[i] = fin ? 0.0 : len;
+  }
+  const unsigned long long ball = __ballot(fin);
+  const int before = __popcll(ball & ((1ull << lane) - 1ull));
+  if (lane == 0) wave_cnt[wave] = __popcll(ball);
+  __syncthreads();
+  const int before_blocks = (before_sh[0] + before_sh[1]) + (before_sh[2] + before_sh[3]);
+  int woff = 0;
+  for (int w = 0; w < wave; ++w) woff += wave_cnt[w];
+  if (fin) {
+    const int pos = base + before_blocks + woff + before;
+    if (pos < a.events_capacity) {
+      double* e = a.events + (int64_t)pos * 4;
+      e[0] = (double)(a.t * a.N + i);
+      e[1] = ret; e[2] = cst; e[3] = len;
+    }
+  }
+  if (blockIdx.x == gridDim.x - 1 && tid == 0)
+    events_prefix[a.t + 1] = base + before_blocks + (wave_cnt[0] + wave_cnt[1]) + (wave_cnt[2] + wave_cnt[3]);
+}
+
 // ---------------------------------------------------------------- synthetic env (bench/test utility)
 __device__ __forceinline__ void philox4x32(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
 #pragma unroll
@@ -349,10 +419,14 @@ __device__ __forceinline__ void normal4(uint64_t seed, uint32_t a, uint32_t b, u
   o[0] = r0 * cosf(t0); o[1] = r0 * sinf(t0); o[2] = r1 * cosf(t1); o[3] = r1 * sinf(t1);
 }
 
+// step_base (optional, device): added to `step` -- a captured launch (step = the index inside the epoch) then draws fresh
+// numbers at every replay once the host has moved the base to the epoch's first step
 __global__ void synth_flags_kernel(float* reward, float* cost, float* terminated, float* truncated, int* t_env,
-                                   int64_t N, uint64_t seed, uint64_t step, float p_term, float p_cost, int trunc_len) {
+                                   int64_t N, uint64_t seed, uint64_t step, float p_term, float p_cost, int trunc_len,
+                                   const unsigned long long* __restrict__ step_base) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
+  if (step_base) step += step_base[0];
   uint32_t ctr[4] = {(uint32_t)i, (uint32_t)step, 0x5eedf1a6u, (uint32_t)(step >> 32)};
   philox4x32(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
   float nrm[4];
@@ -368,10 +442,11 @@ __global__ void synth_flags_kernel(float* reward, float* cost, float* terminated
 }
 
 __global__ void synth_obs_kernel(float* next_obs, float* final_obs, const float* terminated, const float* truncated,
-                                 int64_t N, int D, uint64_t seed, uint64_t step) {
+                                 int64_t N, int D, uint64_t seed, uint64_t step, const unsigned long long* __restrict__ step_base) {
   const int chunks = (D + 3) / 4;
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= N * chunks) return;
+  if (step_base) step += step_base[0];
   const int64_t i = g / chunks;
   const int c = (int)(g % chunks) * 4;
   float o[4], f[4];
@@ -545,6 +620,27 @@ static int boundary_step_impl(const float* reward, const float* cost, const floa
   return 0;
 }
 
+extern "C" int spo_boundary_step_fold_mb(const float* reward, const float* cost, const float* terminated, const float* truncated,
+                                         const float* v_next_r, const float* v_next_c, const float* v_final_r, const float* v_final_c,
+                                         float* buf_reward, float* buf_cost, uint8_t* seg_end, float* boot_r, float* boot_c,
+                                         double* ep_ret, double* ep_cost, double* ep_len, double* events, int* events_prefix,
+                                         int events_capacity, int64_t num_envs, int64_t T, int64_t t, int epoch_end,
+                                         float* fold_reward, float* fold_cost, double gamma, void* stream) {
+  SPO_REQUIRE(reward && cost && terminated && truncated && buf_reward && buf_cost && seg_end && boot_r && boot_c &&
+                  ep_ret && ep_cost && ep_len && events && events_prefix, "boundary_mb: null pointer");
+  SPO_REQUIRE(v_next_r && v_next_c && v_final_r && v_final_c, "boundary_mb: null value pointer");
+  SPO_REQUIRE((fold_reward == nullptr) == (fold_cost == nullptr), "boundary_mb: fold_reward and fold_cost go together");
+  SPO_REQUIRE(t >= 0 && t < T && num_envs > 0, "Buffer overflow");
+  BoundaryArgs a{reward, cost, terminated, truncated, v_next_r, v_next_c, v_final_r, v_final_c, buf_reward, buf_cost,
+                 seg_end, boot_r, boot_c, ep_ret, ep_cost, ep_len, events, nullptr,
+                 events_capacity, num_envs, T, t, epoch_end, fold_reward, fold_cost, (float)gamma};
+  const int64_t blocks = (num_envs + 255) / 256;
+  SPO_REQUIRE(blocks <= 65535 * 16, "boundary_mb: too many envs");
+  hipLaunchKernelGGL(boundary_mb_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, events_prefix);
+  SPO_LAUNCH_CHECK("spo_boundary_step_fold_mb");
+  return 0;
+}
+
 extern "C" int spo_boundary_step(const float* reward, const float* cost, const float* terminated,
                                  const float* truncated, const float* v_next_r, const float* v_next_c,
                                  const float* v_final_r, const float* v_final_c, float* buf_reward, float* buf_cost,
@@ -597,19 +693,33 @@ extern "C" int spo_actor_kl(const float* theta, const float* obs, const float* m
   return 0;
 }
 
-extern "C" int spo_synth_env_step(float* next_obs, float* final_obs, float* reward, float* cost, float* terminated,
-                                  float* truncated, int* t_env, int64_t num_envs, int obs_dim, uint64_t seed,
-                                  uint64_t step, float p_term, float p_cost, int trunc_len, void* stream) {
+static int synth_env_step_impl(float* next_obs, float* final_obs, float* reward, float* cost, float* terminated,
+                               float* truncated, int* t_env, int64_t num_envs, int obs_dim, uint64_t seed, uint64_t step,
+                               const unsigned long long* step_base_dev, float p_term, float p_cost, int trunc_len, void* stream) {
   SPO_REQUIRE(next_obs && final_obs && reward && cost && terminated && truncated && t_env && num_envs > 0 && obs_dim > 0,
               "synth_env: bad args");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(synth_flags_kernel, dim3((unsigned)((num_envs + 255) / 256)), dim3(256), 0, st, reward, cost,
-                     terminated, truncated, t_env, num_envs, seed, step, p_term, p_cost, trunc_len);
+                     terminated, truncated, t_env, num_envs, seed, step, p_term, p_cost, trunc_len, step_base_dev);
   const int64_t work = num_envs * ((obs_dim + 3) / 4);
   hipLaunchKernelGGL(synth_obs_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, next_obs, final_obs,
-                     terminated, truncated, num_envs, obs_dim, seed, step);
+                     terminated, truncated, num_envs, obs_dim, seed, step, step_base_dev);
   SPO_LAUNCH_CHECK("spo_synth_env_step");
   return 0;
+}
+extern "C" int spo_synth_env_step(float* next_obs, float* final_obs, float* reward, float* cost, float* terminated,
+                                  float* truncated, int* t_env, int64_t num_envs, int obs_dim, uint64_t seed,
+                                  uint64_t step, float p_term, float p_cost, int trunc_len, void* stream) {
+  return synth_env_step_impl(next_obs, final_obs, reward, cost, terminated, truncated, t_env, num_envs, obs_dim, seed, step, nullptr,
+                             p_term, p_cost, trunc_len, stream);
+}
+extern "C" int spo_synth_env_step_rel(float* next_obs, float* final_obs, float* reward, float* cost, float* terminated,
+                                      float* truncated, int* t_env, int64_t num_envs, int obs_dim, uint64_t seed,
+                                      uint64_t step_rel, const uint64_t* step_base_dev, float p_term, float p_cost, int trunc_len,
+                                      void* stream) {
+  SPO_REQUIRE(step_base_dev, "synth_env_rel: null step base");
+  return synth_env_step_impl(next_obs, final_obs, reward, cost, terminated, truncated, t_env, num_envs, obs_dim, seed, step_rel,
+                             reinterpret_cast<const unsigned long long*>(step_base_dev), p_term, p_cost, trunc_len, stream);
 }
 
 extern "C" int spo_obs_normalize(float* obs, double* rms_state, int64_t num_envs, int obs_dim, int update, void* stream) {

@@ -25,6 +25,10 @@ from safepo.common.model import ActorVCritic
 from safepo.parallel import Comm, dp_reduce_gradient_
 
 
+def _to_dev(x, dev):
+    return torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x, dtype=torch.float32, device=dev).contiguous()
+
+
 class _Space:
     def __init__(self, dim):
         self.shape = (int(dim),)
@@ -56,7 +60,9 @@ class PPOLagEngine:
         self.ep_ret, self.ep_cost, self.ep_len = torch.zeros(N, **f64), torch.zeros(N, **f64), torch.zeros(N, **f64)
         self.events_cap = N * T
         self.events = torch.zeros((self.events_cap, 4), **f64)
-        self.events_count = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        # running count of logged episodes per step (spo_boundary_step_fold_mb): the kernel of step t reads [t], writes [t + 1]
+        self.events_prefix = torch.zeros(T + 1, dtype=torch.int32, device=self.dev)
+        self._events_last_t, self._events_drained = -1, 0
         # optimiser state (flat, same order as policy.theta)
         P = policy.theta.numel()
         self.adam_m, self.adam_v = torch.zeros(P, **f32), torch.zeros(P, **f32)
@@ -141,26 +147,117 @@ class PPOLagEngine:
             final_obs = _abi.require_gpu_tensor(final_obs, "final_observation", torch.float32)
             self._values_into(final_obs, self.vfinal_r, self.vfinal_c)
         d = b.data
-        _abi.check(self.lib.spo_boundary_step_fold(
+        if t == 0:
+            self._events_drained = 0                  # a new epoch: the log restarts at events_prefix[0] == 0
+        self._events_last_t = t
+        _abi.check(self.lib.spo_boundary_step_fold_mb(
             _abi.ptr(tens[0]), _abi.ptr(tens[1]), _abi.ptr(tens[2]), _abi.ptr(tens[3]),
             _abi.ptr(self.vnext_r), _abi.ptr(self.vnext_c), _abi.ptr(self.vfinal_r), _abi.ptr(self.vfinal_c),
             _abi.ptr(d["reward"]), _abi.ptr(d["cost"]), _abi.ptr(b.seg_end), _abi.ptr(b.boot_r), _abi.ptr(b.boot_c),
             _abi.ptr(self.ep_ret), _abi.ptr(self.ep_cost), _abi.ptr(self.ep_len), _abi.ptr(self.events),
-            _abi.ptr(self.events_count), self.events_cap, self.N, self.T, t, int(epoch_end),
-            _abi.ptr(b.reward_fold), _abi.ptr(b.cost_fold), float(b._gamma), st), "spo_boundary_step_fold")
+            _abi.ptr(self.events_prefix), self.events_cap, self.N, self.T, t, int(epoch_end),
+            _abi.ptr(b.reward_fold), _abi.ptr(b.cost_fold), float(b._gamma), st), "spo_boundary_step_fold_mb")
         if b._fold_cols == t:
             b._fold_cols = t + 1          # column t of this epoch carries its folded bootstrap
         b.advance()
+
+    # ------------------------------------------------------------------ one epoch of collect steps
+    def _rollout_step(self, t: int, env, obs, rms):
+        """collect_step -> env.step -> post_step for step t (ppo_lag.py:162-234).  Host envs: numpy in, numpy out."""
+        act = self.collect_step(t, obs, rms=rms)
+        device_env = getattr(env, "is_device_env", False)
+        next_obs, reward, cost, terminated, truncated, info = env.step(act if device_env else act.detach().squeeze().cpu().numpy())
+        final_obs = None
+        if "final_observation" in info:
+            fo = info["final_observation"]
+            if not torch.is_tensor(fo):
+                fo = np.array([a if a is not None else np.zeros(self.D) for a in fo])
+            final_obs = _to_dev(fo, self.dev)
+        next_obs = _to_dev(next_obs, self.dev)
+        self.post_step(t, next_obs, _to_dev(reward, self.dev), _to_dev(cost, self.dev), _to_dev(terminated, self.dev),
+                       _to_dev(truncated, self.dev), final_obs, rms=rms)
+        return next_obs
+
+    def rollout_epoch(self, env, obs, rms=None):
+        """The T collect steps of one epoch; returns the observation the next epoch starts from.  (Episode statistics:
+        drain_episode_events afterwards.)
+        A device env that declares `graph_safe` (its step is a fixed launch sequence on fixed tensors, its step counter lives on
+        the device: SynthDeviceEnv) has the WHOLE epoch -- per step: noise, policy step, env step, bootstrap values,
+        boundary/fold; normaliser merges where the loop has them -- captured into one HIP graph and replayed: the eager loop is
+        bound by ~9 launches x ~12 us of host work per step, the replay by the device.  The step index and the epoch-end flag
+        are baked into the captured kernel arguments; every array the kernels touch (parameters, buffer, normaliser state,
+        event log, env tensors) is updated in place between epochs, so a replay sees the current contents.  The captured
+        sequence is the steady-state one (the epoch starts from an observation the previous epoch's last step normalised); an
+        epoch that starts from a raw observation (the first after reset()) runs eagerly, and the first epoch of an engine
+        captures the graph on its way out, so that the capture falls into a warm-up epoch.  SPO_ROLLOUT_GRAPH=0 keeps the eager loop.  Host envs (numpy, PCIe
+        every step) always run it."""
+        T, b = self.T, self.buffer
+        steady = not (rms is not None and rms.pending) and b._fold_cols == 0
+        use_graph = getattr(env, "graph_safe", False) and os.environ.get("SPO_ROLLOUT_GRAPH", "1") != "0"
+        if use_graph:
+            obs = _abi.require_gpu_tensor(obs, "obs", torch.float32)
+            key = (id(env), obs.data_ptr(), id(rms))
+            graphs = self.__dict__.setdefault("_rollout_graphs", {})
+        if not (use_graph and steady and key in graphs):
+            # (also the first steady-state epoch runs eagerly: kernels with lazy set-up must have run once before a capture)
+            for t in range(T):
+                obs = self._rollout_step(t, env, obs, rms)
+            if use_graph and key not in graphs and torch.is_tensor(obs) and obs.data_ptr() == key[1]:
+                graphs[key] = self._capture_rollout(env, obs, rms)
+            return obs
+        assert b.ptr == 0, "rollout_epoch starts on an empty buffer"
+        g, post = graphs[key]
+        env.begin_epoch_base()                     # device step base := the epoch's first step (an ordinary launch before the replay)
+        g.replay()
+        # what T eager steps leave behind on the host side
+        b.ptr = T
+        b.ptr_list = [T] * b.num_envs
+        b._fold_cols = post["fold_cols"]
+        if rms is not None:
+            rms.pending = post["pending"]
+        env.step_count += T
+        self._events_last_t, self._events_drained = T - 1, 0
+        return post["obs"]
+
+    def _capture_rollout(self, env, obs, rms):
+        """Capture T steady-state steps starting from `obs`.  Nothing executes during a capture, but the host-side bookkeeping
+        of the steps does: it runs on a scratch copy of that state (empty buffer, normalised observation, step offsets 1..T)
+        which is put back afterwards."""
+        b = self.buffer
+        saved = (b.ptr, b.ptr_list, b._fold_cols, None if rms is None else rms.pending, env.step_count,
+                 self._events_last_t, self._events_drained)
+        b.ptr, b.ptr_list, b._fold_cols = 0, [0] * b.num_envs, 0
+        if rms is not None:
+            rms.pending = False
+        env.begin_epoch_base()
+        torch.cuda.synchronize(self.dev)
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g):
+                cur = obs
+                for t in range(self.T):
+                    cur = self._rollout_step(t, env, cur, rms)
+            post = {"fold_cols": b._fold_cols, "pending": None if rms is None else rms.pending, "obs": cur}
+        finally:
+            b.ptr, b.ptr_list, b._fold_cols = saved[0], saved[1], saved[2]
+            if rms is not None:
+                rms.pending = saved[3]
+            env.step_count = saved[4]
+            self._events_last_t, self._events_drained = saved[5], saved[6]
+        return g, post
 
     def drain_episode_events(self, logger=None):
         """Replay finished episodes on the host in the reference's (step, env) order
         (ppo_lag.py:216-230: deques of 50, running means stored per finished episode).
         One device->host copy per epoch.  Returns the number of finished episodes."""
-        n = int(self.events_count.item())
-        if n > self.events_cap:
-            raise _abi.SpoError(f"episode event log overflow ({n} > {self.events_cap})")
-        ev = self.events[:n].cpu().numpy() if n else np.zeros((0, 4))
-        self.events_count.zero_()
+        if self._events_last_t < 0:
+            return 0
+        hi = int(self.events_prefix[self._events_last_t + 1].item())
+        if hi > self.events_cap:
+            raise _abi.SpoError(f"episode event log overflow ({hi} > {self.events_cap})")
+        lo, self._events_drained = self._events_drained, hi
+        n = hi - lo
+        ev = self.events[lo:hi].cpu().numpy() if n else np.zeros((0, 4))
         for k in range(n):
             self.rew_deque.append(ev[k, 1])
             self.cost_deque.append(ev[k, 2])

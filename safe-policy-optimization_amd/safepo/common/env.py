@@ -72,6 +72,7 @@ class SynthDeviceEnv:
     Returns device tensors, including a dense `final_observation` [N, obs_dim]."""
 
     is_device_env = True
+    graph_safe = True            # step() = a fixed launch sequence on fixed tensors (engine.rollout_epoch may capture it)
 
     def __init__(self, num_envs: int, obs_dim: int = 60, act_dim: int = 8, seed: int = 0, p_term: float = 0.0,
                  p_cost: float = 0.1, trunc_len: int = 64, device="cuda:0", normalize_obs: bool = False,
@@ -90,17 +91,26 @@ class SynthDeviceEnv:
         self.terminated, self.truncated = torch.zeros(N, **f32), torch.zeros(N, **f32)
         self.t_env = torch.zeros(N, dtype=torch.int32, device=self.dev)
         self.step_count = 0
+        # counter-based RNG step = *step_base (device) + (step_count - base_host): identical to step_count, but a captured launch
+        # (engine.rollout_epoch replays one HIP graph per step) carries only the offset inside the epoch
+        self.step_base = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self._base_host = 0
         self.fused_normalizer = None
         self._identity_rms = {"mean": np.zeros(D), "var": np.ones(D), "count": 1e-4}
         self.single_observation_space, self.single_action_space = Box(D), Box(act_dim, -1.0, 1.0)
 
+    def begin_epoch_base(self) -> None:
+        """Move the device-resident part of the step counter to the current step (call outside graph capture / replay)."""
+        self._base_host = self.step_count
+        self.step_base.fill_(self._base_host)
+
     def _advance(self):
         self.step_count += 1
-        _abi.check(self.lib.spo_synth_env_step(
+        _abi.check(self.lib.spo_synth_env_step_rel(
             _abi.ptr(self.obs), _abi.ptr(self.final_obs), _abi.ptr(self.reward), _abi.ptr(self.cost),
             _abi.ptr(self.terminated), _abi.ptr(self.truncated), _abi.ptr(self.t_env), self.num_envs, self.obs_dim,
-            self.seed, self.step_count, self.p_term, self.p_cost, self.trunc_len, _abi.stream_ptr()),
-            "spo_synth_env_step")
+            self.seed, self.step_count - self._base_host, _abi.ptr(self.step_base), self.p_term, self.p_cost, self.trunc_len,
+            _abi.stream_ptr()), "spo_synth_env_step_rel")
         if self.normalizer is not None:
             # raw observations x*scale + shift, then the running normaliser (as the wrapper does in step())
             self.obs.mul_(self.obs_scale).add_(self.obs_shift)

@@ -71,20 +71,7 @@ def run(args, cfg_env, default_cfg: dict, line_search: bool, use_lagrange: bool)
     outs = []
     for epoch in range(epochs):
         rollout_start_time = time.time()
-        for steps in range(local_steps_per_epoch):
-            act = engine.collect_step(steps, obs, rms=rms)
-            action = act if device_env else act.detach().squeeze().cpu().numpy()
-            next_obs, reward, cost, terminated, truncated, info = env.step(action)
-            final_obs = None
-            if "final_observation" in info:
-                fo = info["final_observation"]
-                if not torch.is_tensor(fo):
-                    fo = np.array([a if a is not None else np.zeros(obs.shape[-1]) for a in fo])
-                final_obs = _to_dev(fo, device)
-            next_obs = _to_dev(next_obs, device)
-            engine.post_step(steps, next_obs, _to_dev(reward, device), _to_dev(cost, device),
-                             _to_dev(terminated, device), _to_dev(truncated, device), final_obs, rms=rms)
-            obs = next_obs
+        obs = engine.rollout_epoch(env, obs, rms=rms)      # (one HIP-graph replay for capturable device envs)
         engine.drain_episode_events(logger)
         torch.cuda.synchronize(device)
         rollout_end_time = time.time()

@@ -280,6 +280,41 @@ def test_gae_fed_by_the_boundary_kernels_own_fold_full_size(dev):
     assert _ulp_diff(host(d["target_value_r"])[5:6], ref3[2]).max() <= 1
 
 
+@pytest.mark.parametrize("N,T", [(4096, 6), (1000, 5), (70, 4), (257, 3)])
+def test_boundary_step_on_many_workgroups_equals_the_one_block_kernel(dev, N, T):
+    """spo_boundary_step_fold_mb (num_envs / 256 workgroups, running event count in a per-step prefix array) against the
+    one-block spo_boundary_step_fold on the same random steps: buffers, masks, bootstrap and fold arrays, episode accumulators
+    and the EVENT LOG (env order within a step, the order of the reference's Python loop ppo_lag.py:199-230) bit-identical."""
+    from safepo import _abi
+    lib = _abi.load()
+    g = torch.Generator(device=dev).manual_seed(N + T)
+    f32, f64 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.float64, device=dev)
+
+    def state():
+        return {"reward": torch.zeros((N, T), **f32), "cost": torch.zeros((N, T), **f32), "seg": torch.zeros((N, T), dtype=torch.uint8, device=dev),
+                "boot_r": torch.zeros((N, T), **f32), "boot_c": torch.zeros((N, T), **f32), "fold_r": torch.zeros((N, T), **f32),
+                "fold_c": torch.zeros((N, T), **f32), "ret": torch.zeros(N, **f64), "ecost": torch.zeros(N, **f64), "len": torch.zeros(N, **f64),
+                "events": torch.zeros((N * T, 4), **f64)}
+    A, B = state(), state()
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    prefix = torch.zeros(T + 1, dtype=torch.int32, device=dev)
+    for t in range(T):
+        rew, cost = torch.randn(N, generator=g, **f32), (torch.rand(N, generator=g, **f32) < 0.2).float()
+        term, trunc = (torch.rand(N, generator=g, **f32) < 0.1).float(), (torch.rand(N, generator=g, **f32) < 0.15).float()
+        vals = [torch.randn(N, generator=g, **f32) for _ in range(4)]
+        common = [rew, cost, term, trunc] + vals
+        for S, fn, cnt in ((A, lib.spo_boundary_step_fold, count), (B, lib.spo_boundary_step_fold_mb, prefix)):
+            _abi.check(fn(*[_abi.ptr(x) for x in common], _abi.ptr(S["reward"]), _abi.ptr(S["cost"]), _abi.ptr(S["seg"]), _abi.ptr(S["boot_r"]),
+                          _abi.ptr(S["boot_c"]), _abi.ptr(S["ret"]), _abi.ptr(S["ecost"]), _abi.ptr(S["len"]), _abi.ptr(S["events"]), _abi.ptr(cnt),
+                          N * T, N, T, t, int(t == T - 1), _abi.ptr(S["fold_r"]), _abi.ptr(S["fold_c"]), 0.99, _abi.stream_ptr()), "boundary")
+        assert int(prefix[t + 1]) == int(count[0])
+    n = int(count[0])
+    assert 0 < n < N * T
+    for k in A:
+        assert torch.equal(A[k], B[k]), k
+    assert int(prefix[0]) == 0 and bool((prefix[1:] >= prefix[:-1]).all())
+
+
 def test_gae_segment_mask_edge_cases(dev):
     # every step ends a path / single long path / all-terminated bootstraps / -0.0 deltas
     N, T = 9, 64
@@ -636,6 +671,56 @@ def test_actor_kl_vs_oracle(dev):
 def test_collect_boundary_update_end_to_end(dev, n, steps):
     from smoke_check import smoke_check
     smoke_check(num_envs=n, steps=steps, seed=n)
+
+
+@pytest.mark.parametrize("normalize", [True, False])
+@pytest.mark.parametrize("shape", [(60, 8, [64, 64]), (70, 20, [96, 96])])
+def test_rollout_epoch_replayed_from_a_graph_equals_the_eager_loop(dev, monkeypatch, normalize, shape):
+    """engine.rollout_epoch: T x (collect_step -> env.step -> post_step) replayed from ONE captured HIP graph leaves the
+    buffer, the boundary marks, the episode log, the normaliser state and (after the update) the parameters bit-identical to
+    the eager loop, epoch after epoch (same noise: the graph-safe generator continues the eager Philox sequence).  Both the
+    persistent-kernel engine and the wide-network engine."""
+    from safepo.common.engine import PPOLagEngine, WidePPOLagEngine
+    from safepo.common.env import SynthDeviceEnv
+    from safepo.common.model import ActorVCritic
+    D, A, hidden = shape
+    N, T, epochs = 512, 24, 4
+
+    def run(graph):
+        monkeypatch.setenv("SPO_ROLLOUT_GRAPH", "1" if graph else "0")
+        torch.manual_seed(11)
+        pol = ActorVCritic(D, A, hidden_sizes=hidden).to(dev)
+        cfg = {"hidden_sizes": hidden, "gamma": 0.99, "target_kl": float("inf"), "batch_size": 64, "learning_iters": 2,
+               "max_grad_norm": 40.0}
+        eng = (PPOLagEngine if pol.kernels_supported() else WidePPOLagEngine)(pol, N, T, cfg, dev)
+        env = SynthDeviceEnv(N, D, A, seed=5, p_term=0.02, p_cost=0.1, trunc_len=10, device=dev, normalize_obs=normalize,
+                             obs_scale=2.0, obs_shift=0.5)
+        rms = env.fuse_normalize(True)
+        obs, _ = env.reset()
+        snaps = []
+        for e in range(epochs):
+            obs = eng.rollout_epoch(env, obs, rms=rms)
+            n_ep = eng.drain_episode_events(None)
+            b = eng.buffer
+            snap = {k: v.clone() for k, v in b.data.items()}
+            snap.update(seg_end=b.seg_end.clone(), boot_r=b.boot_r.clone(), boot_c=b.boot_c.clone(), next_obs=obs.clone(),
+                        events=eng.events[:n_ep].clone(), prefix=eng.events_prefix.clone(), ep_ret=eng.ep_ret.clone(),
+                        ep_len=eng.ep_len.clone(), n_ep=torch.tensor(n_ep))
+            if rms is not None:
+                snap["rms"] = rms.state.clone()
+            assert b.ptr == T and env.step_count == 1 + (e + 1) * T
+            eng.update(0.001)
+            snap["theta"] = pol.theta.clone()
+            snaps.append(snap)
+        return snaps, getattr(eng, "_rollout_graphs", {})
+
+    eager, g0 = run(False)
+    graph, g1 = run(True)
+    assert not g0 and len(g1) == 1
+    for e, (x, y) in enumerate(zip(eager, graph)):
+        assert int(x["n_ep"]) == int(y["n_ep"]) and int(x["n_ep"]) > 0
+        for k in x:
+            assert torch.equal(x[k], y[k]), (e, k)
 
 
 def test_ppo_lag_main_entrypoint_synthetic(dev, tmp_path):
