@@ -151,6 +151,19 @@ int spo_boundary_step_fold_mb(const float* reward, const float* cost, const floa
                               int events_capacity, int64_t num_envs, int64_t T, int64_t t, int epoch_end,
                               float* fold_reward, float* fold_cost, double gamma, void* stream);
 
+/* spo_values(theta, final_obs) -> (v_final_r, v_final_c) and spo_boundary_step_fold_mb with those values, in ONE launch (the
+ * post-step half of a collect step, ppo_lag.py:198-234): the bootstrap values of truncated envs go from the critics' accumulators
+ * to the boundary logic through LDS.  v_final_r / v_final_c are still written.  Same results as the two calls (which it makes
+ * itself outside the side-by-side kernel's envelope: obs_dim > 64 or more than 32 768 envs). */
+int spo_values_boundary_step_fold(const float* theta, const float* final_obs, float* v_final_r, float* v_final_c,
+                                  int obs_dim, int act_dim, const float* reward, const float* cost,
+                                  const float* terminated, const float* truncated, const float* v_next_r,
+                                  const float* v_next_c, float* buf_reward, float* buf_cost, uint8_t* seg_end,
+                                  float* boot_r, float* boot_c, double* ep_ret, double* ep_cost, double* ep_len,
+                                  double* events, int* events_prefix, int events_capacity, int64_t num_envs,
+                                  int64_t T, int64_t t, int epoch_end, float* fold_reward, float* fold_cost,
+                                  double gamma, void* stream);
+
 /* ---- a-9/a-10: one learning iteration of the PPO-Lagrangian update (ppo_lag.py:297-336):
  * for each consecutive chunk of `batch` indices of perm[M] (last partial chunk kept): gather,
  * 3x MLP fwd, loss_r/loss_c (MSE + 0.001*L2 if use_critic_norm), clipped surrogate, backward,
@@ -342,10 +355,12 @@ int spo_synth_env_step(float* next_obs, float* final_obs, float* reward, float* 
 
 /* The same with the step counter split into a device-resident base and a host offset: step = *step_base_dev + step_rel.  A launch
  * captured into a HIP graph (step_rel = the index inside the epoch) then draws fresh numbers at every replay once the host has
- * moved *step_base_dev to the epoch's first step (the collect loop as one graph replay per step, safepo/common/engine.py). */
+ * moved *step_base_dev to the epoch's first step (the collect loop as one graph replay, safepo/common/engine.py).  One launch;
+ * affine != 0: next_obs = fl(fl(x * obs_scale) + obs_shift), the raw-observation map of SynthDeviceEnv (obs <= 1024 columns). */
 int spo_synth_env_step_rel(float* next_obs, float* final_obs, float* reward, float* cost, float* terminated,
                            float* truncated, int* t_env, int64_t num_envs, int obs_dim, uint64_t seed,
-                           uint64_t step_rel, const uint64_t* step_base_dev, float p_term, float p_cost, int trunc_len, void* stream);
+                           uint64_t step_rel, const uint64_t* step_base_dev, float p_term, float p_cost, int trunc_len,
+                           int affine, float obs_scale, float obs_shift, void* stream);
 
 /* ---- f3: multi-agent MAPPO-L networks and update (csrc/ma_net.hip).
  * Networks: safepo/common/model.py:172-363 + safepo/utils/{mlp,act,distributions}.py -- LayerNorm(obs), then n_blocks x

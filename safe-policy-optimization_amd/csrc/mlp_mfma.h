@@ -115,6 +115,69 @@ __device__ inline void stage_net(const float* __restrict__ theta, const NetGeom 
   for (int i = tid; i < g.OUT; i += nthr) lds[L::B3 + i] = theta[g.b3() + i];
 }
 
+// stage_net with every global load of a matrix in flight before the first LDS store (round 4).  stage_net's row loops carry
+// predicated loads and stores, which the compiler turns into one dependent L2 round trip per loop iteration -- 4 + 4 + 1 of
+// them with 256 threads, twice that with 128: microseconds, in kernels (policy step, bootstrap values) that do nothing else
+// of that length.  Here the addresses are clamped instead of predicated, NTHR is a compile-time constant so the loops unroll,
+// and W1 (32 registers at KIN = 64, NTHR = 128), then W2 + W3 + biases go out as two batches.  The image is the same except
+// for the pad columns, which no operand read touches (rows 16mt + j, columns 16nt + 4q .. + 3 < K) and are left unwritten.
+template <int KIN, int NTHR>
+__device__ inline void stage_net_batched(const float* __restrict__ theta, const NetGeom g, float* lds, int tid) {
+  using L = NetLds<KIN>;
+  const int D = g.D;
+  {
+    constexpr int TPR = KIN / 4, RSTEP = NTHR / TPR, IT = HID / RSTEP;
+    static_assert(NTHR % TPR == 0 && HID % RSTEP == 0, "stage_net_batched: thread count must tile the rows");
+    const int c0 = (tid % TPR) * 4, r0 = tid / TPR;
+    float w[IT][4];
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+      const float* src = theta + g.w1() + (r0 + k * RSTEP) * D;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[k][e] = src[c0 + e < D ? c0 + e : 0];
+    }
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+      f4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = c0 + e < D ? w[k][e] : 0.f;
+      *reinterpret_cast<f4*>(lds + L::W1 + (r0 + k * RSTEP) * L::LD1 + c0) = v;
+    }
+  }
+  {
+    constexpr int TPR = HID / 4, RSTEP = NTHR / TPR, IT = HID / RSTEP, IT3 = (OUTP + RSTEP - 1) / RSTEP;
+    static_assert(NTHR % TPR == 0 && HID % RSTEP == 0, "stage_net_batched: thread count must tile the rows");
+    const int c0 = (tid % TPR) * 4, r0 = tid / TPR;
+    float w[IT][4], w3[IT3][4];
+#pragma unroll
+    for (int k = 0; k < IT; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[k][e] = theta[g.w2() + (r0 + k * RSTEP) * HID + c0 + e];
+#pragma unroll
+    for (int k = 0; k < IT3; ++k) {
+      const int r = r0 + k * RSTEP;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w3[k][e] = theta[g.w3() + (r < g.OUT ? r : 0) * HID + c0 + e];
+    }
+    const float b1 = theta[g.b1() + (tid < HID ? tid : 0)], b2 = theta[g.b2() + (tid < HID ? tid : 0)];
+    const float b3 = theta[g.b3() + (tid < g.OUT ? tid : 0)];
+#pragma unroll
+    for (int k = 0; k < IT; ++k)
+      *reinterpret_cast<f4*>(lds + L::W2 + (r0 + k * RSTEP) * L::LDW + c0) = f4{w[k][0], w[k][1], w[k][2], w[k][3]};
+#pragma unroll
+    for (int k = 0; k < IT3; ++k) {
+      const int r = r0 + k * RSTEP;
+      if (r < OUTP) {
+        const bool ok = r < g.OUT;
+        *reinterpret_cast<f4*>(lds + L::W3 + r * L::LDW + c0) =
+            f4{ok ? w3[k][0] : 0.f, ok ? w3[k][1] : 0.f, ok ? w3[k][2] : 0.f, ok ? w3[k][3] : 0.f};
+      }
+    }
+    if (tid < HID) { lds[L::B1 + tid] = b1; lds[L::B2 + tid] = b2; }
+    if (tid < OUTP) lds[L::B3 + tid] = tid < g.OUT ? b3 : 0.f;
+  }
+}
+
 // B-operand tiles of one observation row: x[nt][reg] = obs[16*nt + 4*q + reg] (0 beyond D).
 // Loads are UNCONDITIONAL (clamped address, select afterwards): a predicated load compiles to a
 // branch plus `s_waitcnt vmcnt(0)` before the next one, which serialises the HBM latencies.

@@ -138,6 +138,220 @@ __global__ __launch_bounds__(256) void policy_step_kernel(StepArgs a) {
   }
 }
 
+// Round 4: the networks side by side.  The kernel above is a latency chain on 64 of the 256 CUs -- stage critic_r, forward,
+// barrier, stage critic_c, forward, barrier, stage actor, forward: 29 us per collect step at 4 096 envs (14 us for the two
+// critics alone), the longest kernels of the rollout.  Here a workgroup takes ROWS = 16 * RW rows and runs the NNET networks
+// CONCURRENTLY: wave group g (RW waves) stages network g into its own LDS image and carries its forward pass, so one staging
+// phase and one forward pass deep instead of three, on twice as many CUs (RW = 2: 128 workgroups of 6 waves).  The observation
+// rows are loaded (and normalised: the fp64 divide / square root per element, split over the groups by column tile) ONCE into an
+// LDS tile every group reads -- which also removes the read-raw / write-normalised race of an in-place row between groups.
+// Per row the arithmetic is net_forward on the same LDS layout: results are bit-identical to policy_step_kernel.
+// With rms_count_add != 0 workgroup 0 adds the batch size to the normaliser's count (the merge kernel in front of this one has
+// read the old count by then) -- one launch less per step.
+struct BoundaryArgs {
+  const float* reward; const float* cost; const float* terminated; const float* truncated;
+  const float* v_next_r; const float* v_next_c; const float* v_final_r; const float* v_final_c;
+  float* buf_reward; float* buf_cost; uint8_t* seg_end; float* boot_r; float* boot_c;
+  double* ep_ret; double* ep_cost; double* ep_len; double* events; int* events_count; int events_capacity;
+  int64_t N; int64_t T; int64_t t; int epoch_end;
+  float* fold_reward; float* fold_cost; float gamma32;     // optional: reward / cost with gamma * bootstrap folded in at path ends
+};
+
+// BOUNDARY (critics only): the rows are an env step's final observations, and the step's path-boundary logic (boundary_mb_kernel
+// below: reward / cost store, episode accumulators, seg_end / bootstrap marks with the values just computed, ordered episode
+// log) runs in the same launch on the workgroup's ROWS envs -- one launch less per collect step, and the bootstrap values go
+// from the MFMA accumulators to their consumer through LDS.
+struct StepParArgs {
+  StepArgs s;
+  double rms_count_add;
+  BoundaryArgs b;
+  int* events_prefix;
+};
+template <int KIN, bool WITH_ACTOR, int RW, bool BOUNDARY = false>
+__global__ __launch_bounds__((WITH_ACTOR ? 3 : 2) * RW * 64) void policy_step_par_kernel(StepParArgs pa) {
+  static_assert(!(BOUNDARY && WITH_ACTOR) && RW * 16 <= 64, "boundary form: critics only, one wave of envs");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const StepArgs& a = pa.s;
+  using L = NetLds<KIN>;
+  constexpr int NNET = WITH_ACTOR ? 3 : 2, GT = RW * 64, ROWS = RW * 16, LDX = KIN + 4, NT = KIN / 16;
+  float* xs = lds + NNET * L::SIZE;                 // [ROWS][LDX] observation rows as the networks see them
+  const int tid = threadIdx.x, g = tid / GT, gtid = tid % GT, lane = tid & 63, rw = gtid >> 6, j = lane & 15, q = lane >> 4;
+  const int D = a.D, A = a.A;
+  const int rl = rw * 16 + j;                       // row inside the workgroup
+  const int64_t row = (int64_t)blockIdx.x * ROWS + rl;
+  const bool valid = row < a.N;
+  const int64_t rrow = valid ? row : a.N - 1;
+  const int64_t slot = rrow * a.T + a.t;
+  // BOUNDARY: finished episodes among the envs in front of this workgroup's, and (lanes 0 .. ROWS-1) this env's step record --
+  // loaded here, in front of the forward pass they do not depend on
+  int fin_before = 0, ev_base = 0;
+  float b_rwd = 0.f, b_cs = 0.f, b_term = 0.f, b_trunc = 0.f, b_vnr = 0.f, b_vnc = 0.f;
+  double b_ret = 0, b_cst = 0, b_len = 0;
+  if constexpr (BOUNDARY) {
+    const BoundaryArgs& b = pa.b;
+    const int64_t c0 = (int64_t)blockIdx.x * ROWS;
+    for (int64_t i = tid; i < c0; i += NNET * GT) fin_before += (b.terminated[i] != 0.f || b.truncated[i] != 0.f) ? 1 : 0;
+    if (tid < ROWS && c0 + tid < b.N) {
+      const int64_t i = c0 + tid;
+      ev_base = pa.events_prefix[b.t];
+      b_rwd = b.reward[i]; b_cs = b.cost[i]; b_term = b.terminated[i]; b_trunc = b.truncated[i];
+      b_ret = b.ep_ret[i]; b_cst = b.ep_cost[i]; b_len = b.ep_len[i];
+      if (b.epoch_end) { b_vnr = b.v_next_r[i]; b_vnc = b.v_next_c[i]; }
+    }
+  }
+  // this group's share of the observation tile: column tiles nt = g, g + NNET, ...
+  const float* src = (a.rms ? a.obs_io : a.obs) + rrow * D;
+  f4 xin[(NT + NNET - 1) / NNET];
+#pragma unroll
+  for (int k = 0; k < (NT + NNET - 1) / NNET; ++k) {
+    const int c = 16 * (g + k * NNET) + 4 * q;
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+    if (g + k * NNET < NT) {
+      if ((D & 3) == 0) {
+        if (c < D) v = *reinterpret_cast<const f4*>(src + c);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c + e < D) v[e] = src[c + e];
+      }
+    }
+    xin[k] = v;
+  }
+  stage_net_batched<KIN, GT>(a.theta, net_geom(D, A, g), lds + g * L::SIZE, gtid);
+#pragma unroll
+  for (int k = 0; k < (NT + NNET - 1) / NNET; ++k) {
+    const int nt = g + k * NNET;
+    if (nt < NT) {
+      const int c = 16 * nt + 4 * q;
+      f4 v = xin[k];
+      if (a.rms) {
+        // NormalizeObservation.normalize (wrappers.py:42-49 -> gymnasium): (obs - mean) / sqrt(var + 1e-8) in float64 with the
+        // statistics just merged, rounded to fp32 once (the expression of policy_step_kernel)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c + e < D) {
+            v[e] = (float)(((double)v[e] - a.rms[c + e]) / sqrt(a.rms[D + c + e] + a.rms_eps));
+            if (valid) a.obs_io[row * D + c + e] = v[e];
+          }
+      }
+      *reinterpret_cast<f4*>(xs + rl * LDX + c) = v;
+      if (a.buf_obs && valid) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c + e < D) a.buf_obs[slot * D + c + e] = v[e];
+      }
+    }
+  }
+  __syncthreads();
+  f4 x[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) x[nt] = *reinterpret_cast<const f4*>(xs + rl * LDX + 16 * nt + 4 * q);
+  f4 h1[4], h2[4];
+  const f4 o = net_forward<KIN>(lds + g * L::SIZE, x, h1, h2, j, q);
+  if (g < 2) {
+    if (valid && q == 0) {
+      float* v = g == 0 ? a.v_r : a.v_c;
+      float* bv = g == 0 ? a.buf_v_r : a.buf_v_c;
+      v[row] = o[0];
+      if (bv) bv[slot] = o[0];
+    }
+    if (g == 0 && blockIdx.x == 0 && tid == 0 && pa.rms_count_add != 0.0) const_cast<double*>(a.rms)[2 * D] += pa.rms_count_add;
+    if constexpr (!BOUNDARY) return;
+  }
+  if constexpr (BOUNDARY) {
+    const BoundaryArgs& b = pa.b;
+    int* vsh_cnt = reinterpret_cast<int*>(xs + ROWS * LDX);        // [NNET * RW] per-wave counts
+    float* vsh = xs + ROWS * LDX + 8;                              // [2][ROWS] values of the final observations
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) fin_before += __shfl_xor(fin_before, off);
+    if (lane == 0) vsh_cnt[tid >> 6] = fin_before;
+    if (q == 0) vsh[g * ROWS + rl] = o[0];
+    __syncthreads();
+    if (tid >= 64) return;
+    int before_blocks = 0;
+#pragma unroll
+    for (int w = 0; w < NNET * RW; ++w) before_blocks += vsh_cnt[w];
+    const int base = __shfl(ev_base, 0);
+    const int64_t i = (int64_t)blockIdx.x * ROWS + tid;
+    const bool in = tid < ROWS && i < b.N;
+    bool fin = false;
+    double ret = 0, cst = 0, len = 0;
+    if (in) {
+      const float rwd = b_rwd, cs = b_cs;
+      const bool done = b_term != 0.f, tout = b_trunc != 0.f;
+      ret = b_ret + (double)rwd;                // ep_ret += reward  (float64 accumulators, ppo_lag.py:168-170)
+      cst = b_cst + (double)cs;
+      len = b_len + 1.0;
+      const bool boundary = b.epoch_end || done || tout;
+      float br = 0.f, bc = 0.f;
+      if (boundary && !done) {
+        if (b.epoch_end) { br = b_vnr; bc = b_vnc; }
+        if (tout) { br = vsh[tid]; bc = vsh[ROWS + tid]; }          // final_observation wins (ppo_lag.py:209-213)
+      }
+      const int64_t bslot = i * b.T + b.t;
+      b.buf_reward[bslot] = rwd;
+      b.buf_cost[bslot] = cs;
+      b.seg_end[bslot] = boundary ? 1 : 0;
+      b.boot_r[bslot] = br;
+      b.boot_c[bslot] = bc;
+      if (b.fold_reward) {
+        b.fold_reward[bslot] = boundary ? __fadd_rn(rwd, __fmul_rn(b.gamma32, br)) : rwd;
+        b.fold_cost[bslot] = boundary ? __fadd_rn(cs, __fmul_rn(b.gamma32, bc)) : cs;
+      }
+      fin = done || tout;
+      b.ep_ret[i] = fin ? 0.0 : ret;
+      b.ep_cost[i] = fin ? 0.0 : cst;
+      b.ep_len[i] = fin ? 0.0 : len;
+    }
+    const unsigned long long ball = __ballot(fin);
+    if (fin) {
+      const int pos = base + before_blocks + __popcll(ball & ((1ull << lane) - 1ull));
+      if (pos < b.events_capacity) {
+        double* e = b.events + (int64_t)pos * 4;
+        e[0] = (double)(b.t * b.N + i);
+        e[1] = ret; e[2] = cst; e[3] = len;
+      }
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) pa.events_prefix[b.t + 1] = base + before_blocks + __popcll(ball);
+    return;
+  }
+  if constexpr (WITH_ACTOR) {
+    const f4 mu = o;
+    const int ls_off = 2 * critic_size(D);
+    float lp = 0.f;
+    float av[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ai = 4 * q + r;
+      if (ai < A) {
+        const float sd = expf(a.theta[ls_off + ai]);            // std = exp(log_std)   model.py:80
+        float ac = mu[r];
+        if (a.eps) ac = mu[r] + a.eps[rrow * A + ai] * sd;       // rsample: loc + eps*scale
+        const float diff = ac - mu[r];
+        const float var = sd * sd;
+        lp += -(diff * diff) / (2.f * var) - logf(sd) - LOG_SQRT_2PI;   // Normal.log_prob
+        av[r] = ac;
+      }
+    }
+    lp += __shfl_xor(lp, 16);
+    lp += __shfl_xor(lp, 32);                                    // .sum(axis=-1)   model.py:167
+    if (valid) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ai = 4 * q + r;
+        if (ai < A) {
+          a.act[row * A + ai] = av[r];
+          if (a.buf_act) a.buf_act[slot * A + ai] = av[r];
+        }
+      }
+      if (q == 0) {
+        a.logp[row] = lp;
+        if (a.buf_logp) a.buf_logp[slot] = lp;
+      }
+    }
+  }
+}
+
 struct KlArgs {
   const float* theta; const float* obs; const float* mean_old; const float* log_std_old;
   float* mean_out; double* partials; int64_t rows; int D; int A;
@@ -251,14 +465,6 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* partial
   if (threadIdx.x == 0) out[0] = sh[0];
 }
 
-struct BoundaryArgs {
-  const float* reward; const float* cost; const float* terminated; const float* truncated;
-  const float* v_next_r; const float* v_next_c; const float* v_final_r; const float* v_final_c;
-  float* buf_reward; float* buf_cost; uint8_t* seg_end; float* boot_r; float* boot_c;
-  double* ep_ret; double* ep_cost; double* ep_len; double* events; int* events_count; int events_capacity;
-  int64_t N; int64_t T; int64_t t; int epoch_end;
-  float* fold_reward; float* fold_cost; float gamma32;     // optional: reward / cost with gamma * bootstrap folded in at path ends
-};
 
 // ONE block: finished episodes are appended in env order, the order of the reference's Python
 // loop `for idx, (done, time_out) in enumerate(zip(terminated, truncated))` (ppo_lag.py:199).
@@ -459,6 +665,52 @@ __global__ void synth_obs_kernel(float* next_obs, float* final_obs, const float*
   }
 }
 
+// The two kernels above and the env's affine map of the raw observation (x * scale + shift, two elementwise launches) in ONE
+// launch (round 4: four launches of ~5 us each per collect step were the synthetic env's whole cost).  A workgroup owns whole
+// envs -- lane (env, chunk) -- so every chunk lane recomputes its env's flags from the old episode clock, and the chunk-0
+// lane stores them and the new clock after a barrier.  Same counters, same arithmetic (the affine map as two rounded
+// operations, like the two tensor ops it replaces): bit-identical outputs.
+__global__ __launch_bounds__(256) void synth_step_kernel(float* next_obs, float* final_obs, float* reward, float* cost, float* terminated,
+                                                         float* truncated, int* t_env, int64_t N, int D, uint64_t seed, uint64_t step,
+                                                         const unsigned long long* __restrict__ step_base, float p_term, float p_cost,
+                                                         int trunc_len, int affine, float scale, float shift) {
+  const int chunks = (D + 3) / 4;
+  const int epb = 256 / chunks;                        // envs per workgroup
+  const int el = threadIdx.x / chunks, c = (threadIdx.x % chunks) * 4;
+  const int64_t i = (int64_t)blockIdx.x * epb + el;
+  const bool act = el < epb && i < N;
+  if (step_base) step += step_base[0];
+  bool term = false, trunc = false;
+  int te = 0;
+  uint32_t ctr[4] = {(uint32_t)i, (uint32_t)step, 0x5eedf1a6u, (uint32_t)(step >> 32)};
+  if (act) {
+    philox4x32(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+    te = t_env[i] + 1;
+    term = u01(ctr[0]) < p_term;
+    trunc = (te >= trunc_len) && !term;
+  }
+  __syncthreads();                                     // every lane of the env has read the old clock
+  if (act) {
+    if (c == 0) {
+      float nrm[4];
+      normal4(seed, (uint32_t)i, (uint32_t)step, 0x72657761u, (uint32_t)(step >> 32), nrm);
+      reward[i] = nrm[0];
+      cost[i] = u01(ctr[1]) < p_cost ? 1.f : 0.f;
+      terminated[i] = term ? 1.f : 0.f;
+      truncated[i] = trunc ? 1.f : 0.f;
+      t_env[i] = (term || trunc) ? 0 : te;
+    }
+    float o[4], f[4];
+    normal4(seed, (uint32_t)i, (uint32_t)step, 0x6f627330u + (uint32_t)c, (uint32_t)(step >> 32), o);
+    const bool fin = term || trunc;
+    if (fin) normal4(seed, (uint32_t)i, (uint32_t)step, 0x66696e30u + (uint32_t)c, (uint32_t)(step >> 32), f);
+    for (int e = 0; e < 4 && c + e < D; ++e) {
+      next_obs[i * D + c + e] = affine ? __fadd_rn(__fmul_rn(o[e], scale), shift) : o[e];
+      final_obs[i * D + c + e] = fin ? f[e] : 0.f;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- a-2: running observation normaliser
 // gymnasium.wrappers.normalize.RunningMeanStd.update + NormalizeObservation.normalize (the wrapper
 // SafeNormalizeObservation applies inside the env, reference safepo/common/wrappers.py:42-49):
@@ -501,10 +753,93 @@ __global__ __launch_bounds__(256) void obs_normalize_kernel(float* obs, double* 
 }
 __global__ void obs_normalize_count_kernel(double* rms, int D, int64_t N) { rms[2 * D] += (double)N; }
 
+// The merge alone (what the collect step launches every step), for batches of at most 256 * RPT rows: the feature's column is
+// loaded ONCE into registers (RPT independent loads in flight) and serves both passes; the block sums go through wave
+// butterflies and one LDS exchange instead of two eight-barrier trees.  ~11 -> ~7 us per step at 4 096 envs.  Same two-pass
+// mean / variance and the same merge as obs_normalize_kernel; the order of the fp64 partial sums differs (last-bit level).
+template <int RPT>
+__global__ __launch_bounds__(256) void obs_stats_kernel(const float* __restrict__ obs, double* rms, int64_t N, int D) {
+  __shared__ double sh_s[4], sh_q[4];
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* mean = rms; double* var = rms + D; const double* count = rms + 2 * D;
+  float v[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    const int64_t i = tid + 256 * k;
+    v[k] = obs[(i < N ? i : N - 1) * D + f];
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < RPT; ++k)
+    if (tid + 256 * k < N) s += (double)v[k];
+  s = wave_sum_d(s);
+  if (lane == 0) sh_s[wave] = s;
+  __syncthreads();
+  const double bmean = ((sh_s[0] + sh_s[1]) + (sh_s[2] + sh_s[3])) / (double)N;
+  double qv = 0.0;
+#pragma unroll
+  for (int k = 0; k < RPT; ++k)
+    if (tid + 256 * k < N) { const double d = (double)v[k] - bmean; qv += d * d; }
+  qv = wave_sum_d(qv);
+  if (lane == 0) sh_q[wave] = qv;
+  __syncthreads();
+  if (tid == 0) {
+    const double bvar = ((sh_q[0] + sh_q[1]) + (sh_q[2] + sh_q[3])) / (double)N, bn = (double)N, c = *count;
+    const double delta = bmean - mean[f], tot = c + bn;
+    const double m2 = var[f] * c + bvar * bn + delta * delta * c * bn / tot;
+    mean[f] = mean[f] + delta * bn / tot;
+    var[f] = m2 / tot;
+  }
+}
+// statistics merge of one batch without the count (see obs_normalize_count_kernel / policy_step_par_kernel)
+void launch_obs_stats(const float* obs, double* rms, int64_t N, int D, hipStream_t st) {
+  static const bool fast = [] { const char* e = getenv("SPO_OBS_STATS_REG"); return !(e && e[0] == '0'); }();
+  if (fast && N <= 256 * 4) hipLaunchKernelGGL(obs_stats_kernel<4>, dim3(D), dim3(256), 0, st, obs, rms, N, D);
+  else if (fast && N <= 256 * 16) hipLaunchKernelGGL(obs_stats_kernel<16>, dim3(D), dim3(256), 0, st, obs, rms, N, D);
+  else hipLaunchKernelGGL(obs_normalize_kernel, dim3(D), dim3(256), 0, st, const_cast<float*>(obs), rms, N, D, 1, 1e-8, 0);
+}
+
 int pick_kin(int D) { return D <= 16 ? 16 : D <= 32 ? 32 : D <= 64 ? 64 : 128; }
 
+// SPO_STEP_PAR=0: the one-network-at-a-time kernel everywhere (A/B knob; results are bit-identical)
+bool step_par_enabled() {
+  static const bool on = [] { const char* e = getenv("SPO_STEP_PAR"); return !(e && e[0] == '0'); }();
+  return on;
+}
+constexpr int STEP_PAR_RW = 2;
+constexpr int64_t STEP_PAR_MAX_ROWS = 32768;     // beyond this the 64-row kernel's fewer weight stagings win
+
+template <int KIN, bool WITH_ACTOR, bool BOUNDARY = false>
+int launch_step_par(const StepArgs& a, double count_add, hipStream_t st, const BoundaryArgs* b = nullptr, int* events_prefix = nullptr) {
+  constexpr int NNET = WITH_ACTOR ? 3 : 2, RW = STEP_PAR_RW;
+  constexpr size_t sh = (size_t)(NNET * NetLds<KIN>::SIZE + RW * 16 * (KIN + 4) + 8 + 2 * RW * 16) * sizeof(float);
+  static bool done_dev[spo::SPO_MAX_DEVICES] = {};        /* the attribute is per device */
+  bool& done = done_dev[spo::current_device_slot()];
+  if (!done) {
+    if (int rc = spo::hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_step_par_kernel<KIN, WITH_ACTOR, RW, BOUNDARY>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh),
+                                "hipFuncSetAttribute(policy_step_par)")) return rc;
+    done = true;
+  }
+  StepParArgs pa{a, count_add, b ? *b : BoundaryArgs{}, events_prefix};
+  hipLaunchKernelGGL((policy_step_par_kernel<KIN, WITH_ACTOR, RW, BOUNDARY>), dim3((unsigned)((a.N + RW * 16 - 1) / (RW * 16))),
+                     dim3(NNET * RW * 64), sh, st, pa);
+  return 0;
+}
+
+// count_add != 0: the normaliser's count still has to grow by that much (see policy_step_par_kernel); returns 1 when the launch
+// did it, 0 when the caller must (the sequential kernel), < 0 on error
 template <bool WITH_ACTOR>
-int launch_step(const StepArgs& a, hipStream_t st) {
+int launch_step(const StepArgs& a, hipStream_t st, double count_add = 0.0) {
+  if (step_par_enabled() && a.N <= STEP_PAR_MAX_ROWS && a.D <= 64) {
+    int rc;
+    switch (pick_kin(a.D)) {
+      case 16: rc = launch_step_par<16, WITH_ACTOR>(a, count_add, st); break;
+      case 32: rc = launch_step_par<32, WITH_ACTOR>(a, count_add, st); break;
+      default: rc = launch_step_par<64, WITH_ACTOR>(a, count_add, st); break;
+    }
+    return rc ? rc : 1;
+  }
   const unsigned blocks = (unsigned)((a.N + 63) / 64);
   switch (pick_kin(a.D)) {
     case 16: hipLaunchKernelGGL((policy_step_kernel<16, WITH_ACTOR>), dim3(blocks), dim3(256), 0, st, a); break;
@@ -558,7 +893,7 @@ extern "C" int spo_policy_step(const float* theta, const float* obs, const float
   }
   StepArgs a{theta, obs, eps, act, logp, v_r, v_c, buf_obs, buf_act, buf_logp, buf_v_r, buf_v_c,
              num_envs, T > 0 ? T : 1, buf ? t : 0, obs_dim, act_dim, nullptr, nullptr, 0.0};
-  launch_step<true>(a, (hipStream_t)stream);
+  if (int rc = launch_step<true>(a, (hipStream_t)stream); rc < 0) return rc;
   SPO_LAUNCH_CHECK("spo_policy_step");
   return 0;
 }
@@ -576,14 +911,16 @@ extern "C" int spo_policy_step_norm(const float* theta, float* obs_inout, double
     SPO_REQUIRE(t >= 0 && t < T, "Buffer overflow");          /* reference assert, buffer.py:92 */
   }
   hipStream_t st = (hipStream_t)stream;
+  // RunningMeanStd.update(batch): the merge needs the whole batch before any row can be normalised with the NEW statistics; the
+  // count grows after every feature's merge has read the old one -- in the step kernel's workgroup 0 where that kernel can
+  const bool count_in_step = update && step_par_enabled() && num_envs <= STEP_PAR_MAX_ROWS && obs_dim <= 64;
   if (update) {
-    // RunningMeanStd.update(batch): the merge needs the whole batch before any row can be normalised with the NEW statistics
-    hipLaunchKernelGGL(obs_normalize_kernel, dim3(obs_dim), dim3(256), 0, st, obs_inout, rms_state, num_envs, obs_dim, 1, 1e-8, 0);
-    hipLaunchKernelGGL(obs_normalize_count_kernel, dim3(1), dim3(1), 0, st, rms_state, obs_dim, num_envs);
+    launch_obs_stats(obs_inout, rms_state, num_envs, obs_dim, st);
+    if (!count_in_step) hipLaunchKernelGGL(obs_normalize_count_kernel, dim3(1), dim3(1), 0, st, rms_state, obs_dim, num_envs);
   }
   StepArgs a{theta, obs_inout, eps, act, logp, v_r, v_c, buf_obs, buf_act, buf_logp, buf_v_r, buf_v_c,
              num_envs, T > 0 ? T : 1, buf ? t : 0, obs_dim, act_dim, rms_state, obs_inout, 1e-8};
-  launch_step<true>(a, st);
+  if (int rc = launch_step<true>(a, st, count_in_step ? (double)num_envs : 0.0); rc < 0) return rc;
   SPO_LAUNCH_CHECK("spo_policy_step_norm");
   return 0;
 }
@@ -594,7 +931,7 @@ extern "C" int spo_values(const float* theta, const float* obs, float* v_r, floa
   SPO_REQUIRE(theta && obs && v_r && v_c && rows > 0, "values: bad args");
   StepArgs a{theta, obs, nullptr, nullptr, nullptr, v_r, v_c, nullptr, nullptr, nullptr, nullptr, nullptr,
              rows, 1, 0, obs_dim, act_dim, nullptr, nullptr, 0.0};
-  launch_step<false>(a, (hipStream_t)stream);
+  if (int rc = launch_step<false>(a, (hipStream_t)stream); rc < 0) return rc;
   SPO_LAUNCH_CHECK("spo_values");
   return 0;
 }
@@ -638,6 +975,44 @@ extern "C" int spo_boundary_step_fold_mb(const float* reward, const float* cost,
   SPO_REQUIRE(blocks <= 65535 * 16, "boundary_mb: too many envs");
   hipLaunchKernelGGL(boundary_mb_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, events_prefix);
   SPO_LAUNCH_CHECK("spo_boundary_step_fold_mb");
+  return 0;
+}
+
+extern "C" int spo_values_boundary_step_fold(const float* theta, const float* final_obs, float* v_final_r, float* v_final_c,
+                                             int obs_dim, int act_dim, const float* reward, const float* cost,
+                                             const float* terminated, const float* truncated, const float* v_next_r,
+                                             const float* v_next_c, float* buf_reward, float* buf_cost, uint8_t* seg_end,
+                                             float* boot_r, float* boot_c, double* ep_ret, double* ep_cost, double* ep_len,
+                                             double* events, int* events_prefix, int events_capacity, int64_t num_envs,
+                                             int64_t T, int64_t t, int epoch_end, float* fold_reward, float* fold_cost,
+                                             double gamma, void* stream) {
+  if (int rc = check_dims(obs_dim, act_dim)) return rc;
+  SPO_REQUIRE(theta && final_obs && v_final_r && v_final_c, "values_boundary: null pointer");
+  SPO_REQUIRE(reward && cost && terminated && truncated && v_next_r && v_next_c && buf_reward && buf_cost && seg_end && boot_r &&
+              boot_c && ep_ret && ep_cost && ep_len && events && events_prefix, "values_boundary: null pointer");
+  SPO_REQUIRE((fold_reward == nullptr) == (fold_cost == nullptr), "values_boundary: both fold outputs or neither");
+  SPO_REQUIRE(num_envs > 0 && t >= 0 && t < T, "values_boundary: bad step index");
+  hipStream_t st = (hipStream_t)stream;
+  if (!(step_par_enabled() && num_envs <= STEP_PAR_MAX_ROWS && obs_dim <= 64)) {
+    // outside the side-by-side kernel's envelope: the two launches this entry point stands for
+    if (int rc = spo_values(theta, final_obs, v_final_r, v_final_c, num_envs, obs_dim, act_dim, stream)) return rc;
+    return spo_boundary_step_fold_mb(reward, cost, terminated, truncated, v_next_r, v_next_c, v_final_r, v_final_c, buf_reward,
+                                     buf_cost, seg_end, boot_r, boot_c, ep_ret, ep_cost, ep_len, events, events_prefix,
+                                     events_capacity, num_envs, T, t, epoch_end, fold_reward, fold_cost, gamma, stream);
+  }
+  StepArgs a{theta, final_obs, nullptr, nullptr, nullptr, v_final_r, v_final_c, nullptr, nullptr, nullptr, nullptr, nullptr,
+             num_envs, 1, 0, obs_dim, act_dim, nullptr, nullptr, 0.0};
+  BoundaryArgs b{reward, cost, terminated, truncated, v_next_r, v_next_c, v_final_r, v_final_c, buf_reward, buf_cost, seg_end,
+                 boot_r, boot_c, ep_ret, ep_cost, ep_len, events, nullptr, events_capacity, num_envs, T, t, epoch_end,
+                 fold_reward, fold_cost, (float)gamma};
+  int rc;
+  switch (pick_kin(obs_dim)) {
+    case 16: rc = launch_step_par<16, false, true>(a, 0.0, st, &b, events_prefix); break;
+    case 32: rc = launch_step_par<32, false, true>(a, 0.0, st, &b, events_prefix); break;
+    default: rc = launch_step_par<64, false, true>(a, 0.0, st, &b, events_prefix); break;
+  }
+  if (rc) return rc;
+  SPO_LAUNCH_CHECK("spo_values_boundary_step_fold");
   return 0;
 }
 
@@ -716,10 +1091,18 @@ extern "C" int spo_synth_env_step(float* next_obs, float* final_obs, float* rewa
 extern "C" int spo_synth_env_step_rel(float* next_obs, float* final_obs, float* reward, float* cost, float* terminated,
                                       float* truncated, int* t_env, int64_t num_envs, int obs_dim, uint64_t seed,
                                       uint64_t step_rel, const uint64_t* step_base_dev, float p_term, float p_cost, int trunc_len,
-                                      void* stream) {
+                                      int affine, float obs_scale, float obs_shift, void* stream) {
   SPO_REQUIRE(step_base_dev, "synth_env_rel: null step base");
-  return synth_env_step_impl(next_obs, final_obs, reward, cost, terminated, truncated, t_env, num_envs, obs_dim, seed, step_rel,
-                             reinterpret_cast<const unsigned long long*>(step_base_dev), p_term, p_cost, trunc_len, stream);
+  SPO_REQUIRE(next_obs && final_obs && reward && cost && terminated && truncated && t_env && num_envs > 0 && obs_dim > 0,
+              "synth_env_rel: bad args");
+  if (obs_dim > 1024)        // (a workgroup owns whole envs: 256 lanes x 4 columns)
+    return spo::fail(-2, "synth_env_rel: obs_dim %d > 1024", obs_dim);
+  const int epb = 256 / ((obs_dim + 3) / 4);
+  hipLaunchKernelGGL(synth_step_kernel, dim3((unsigned)((num_envs + epb - 1) / epb)), dim3(256), 0, (hipStream_t)stream, next_obs,
+                     final_obs, reward, cost, terminated, truncated, t_env, num_envs, obs_dim, seed, step_rel,
+                     reinterpret_cast<const unsigned long long*>(step_base_dev), p_term, p_cost, trunc_len, affine, obs_scale, obs_shift);
+  SPO_LAUNCH_CHECK("spo_synth_env_step_rel");
+  return 0;
 }
 
 extern "C" int spo_obs_normalize(float* obs, double* rms_state, int64_t num_envs, int obs_dim, int update, void* stream) {

@@ -82,6 +82,8 @@ PROTOTYPES = {
     "spo_boundary_step": (c_int, [P] * 18 + [c_int, c_int64, c_int64, c_int64, c_int, P]),
     "spo_boundary_step_fold": (c_int, [P] * 18 + [c_int, c_int64, c_int64, c_int64, c_int, P, P, c_double, P]),
     "spo_boundary_step_fold_mb": (c_int, [P] * 18 + [c_int, c_int64, c_int64, c_int64, c_int, P, P, c_double, P]),
+    "spo_values_boundary_step_fold": (c_int, [P] * 4 + [c_int, c_int] + [P] * 16 + [c_int, c_int64, c_int64, c_int64, c_int, P, P,
+                                              c_double, P]),
     "spo_ppo_lag_update_iter": (c_int, [P, P, P, c_int64] + [P] * 7 + [c_int64, POINTER(PpoCfg), P, P, P]),
     "spo_update_scratch_release": (c_int, [P, c_int]),
     "spo_debug_update_counters": (c_int, [P, c_int]),
@@ -157,7 +159,8 @@ PROTOTYPES = {
     "spo_param_count": (c_int64, [c_int, c_int]),
     "spo_param_offset": (c_int64, [c_int, c_int, c_int]),
     "spo_synth_env_step": (c_int, [P] * 7 + [c_int64, c_int, c_uint64, c_uint64, c_float, c_float, c_int, P]),
-    "spo_synth_env_step_rel": (c_int, [P] * 7 + [c_int64, c_int, c_uint64, c_uint64, P, c_float, c_float, c_int, P]),
+    "spo_synth_env_step_rel": (c_int, [P] * 7 + [c_int64, c_int, c_uint64, c_uint64, P, c_float, c_float, c_int, c_int, c_float,
+                                       c_float, P]),
 }
 
 _lib = None

@@ -110,10 +110,9 @@ class SynthDeviceEnv:
             _abi.ptr(self.obs), _abi.ptr(self.final_obs), _abi.ptr(self.reward), _abi.ptr(self.cost),
             _abi.ptr(self.terminated), _abi.ptr(self.truncated), _abi.ptr(self.t_env), self.num_envs, self.obs_dim,
             self.seed, self.step_count - self._base_host, _abi.ptr(self.step_base), self.p_term, self.p_cost, self.trunc_len,
-            _abi.stream_ptr()), "spo_synth_env_step_rel")
+            int(self.normalizer is not None), self.obs_scale, self.obs_shift, _abi.stream_ptr()), "spo_synth_env_step_rel")
         if self.normalizer is not None:
-            # raw observations x*scale + shift, then the running normaliser (as the wrapper does in step())
-            self.obs.mul_(self.obs_scale).add_(self.obs_shift)
+            # (raw observations x*scale + shift: inside the kernel), then the running normaliser (as the wrapper does in step())
             if self.fused_normalizer is not None:
                 # fused mode: the observation stays RAW here; the training loop hands `fused_normalizer` to
                 # engine.collect_step / post_step, whose kernels merge the statistics and normalise on load

@@ -398,3 +398,24 @@ def test_wide_network_layout_matches_reference_parameter_order(built_lib, hidden
     assert lib.spo_mlp_workspace_floats(_abi.MlpNet.of([D] + hidden + [A]), 10) == 10 * (sum(hidden) + A)
     with pytest.raises(_abi.SpoError):
         _abi.MlpNet.of([D, 1, 1, 1, 1, 1, 1])          # more than 5 Linear layers
+
+
+def test_episode_log_running_means_equal_the_per_episode_loop():
+    """engine.deque_running_means (the finished-episode statistics of one epoch in one pass) against the reference's loop --
+    append to a deque of 50, np.mean of the deque, per episode (ppo_lag.py:216-230): bit-identical, from an empty deque, across
+    several calls, for batches shorter and longer than the window."""
+    from collections import deque
+    from safepo.common.engine import deque_running_means
+    rng = np.random.default_rng(0)
+    a, b = deque(maxlen=50), deque(maxlen=50)
+    for n in (0, 3, 20, 26, 1, 120, 50, 49, 4096, 7):
+        new = rng.standard_normal(n) * 100.0
+        ref = []
+        for v in new:
+            a.append(v)
+            ref.append(np.mean(a))
+        got = deque_running_means(b, new)
+        assert len(got) == n and all(np.float64(x).tobytes() == np.float64(y).tobytes() for x, y in zip(got, ref)), n
+        assert list(a) == list(b)
+    c = deque(a, maxlen=50)
+    assert deque_running_means(c, rng.standard_normal(70), want_means=False) == [] and len(c) == 50

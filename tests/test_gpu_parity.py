@@ -315,6 +315,47 @@ def test_boundary_step_on_many_workgroups_equals_the_one_block_kernel(dev, N, T)
     assert int(prefix[0]) == 0 and bool((prefix[1:] >= prefix[:-1]).all())
 
 
+@pytest.mark.parametrize("N,T,D", [(4096, 6, 60), (1000, 5, 17), (31, 4, 64), (300, 3, 100)])
+def test_values_and_boundary_in_one_launch_equal_the_two_calls(dev, N, T, D):
+    """spo_values_boundary_step_fold (critics on the final observations + the step's boundary logic in one launch, the values
+    handed over through LDS) against spo_values followed by spo_boundary_step_fold_mb: the values, buffers, masks, bootstrap and
+    fold arrays, episode accumulators and the ordered event log bit-identical (obs_dim 100: its own two-launch fallback)."""
+    from safepo import _abi
+    from safepo.common.model import ActorVCritic
+    lib = _abi.load()
+    A_ = 5
+    torch.manual_seed(N)
+    pol = ActorVCritic(D, A_).to(dev)
+    g = torch.Generator(device=dev).manual_seed(N + T)
+    f32, f64 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.float64, device=dev)
+
+    def state():
+        return {"reward": torch.zeros((N, T), **f32), "cost": torch.zeros((N, T), **f32), "seg": torch.zeros((N, T), dtype=torch.uint8, device=dev),
+                "boot_r": torch.zeros((N, T), **f32), "boot_c": torch.zeros((N, T), **f32), "fold_r": torch.zeros((N, T), **f32),
+                "fold_c": torch.zeros((N, T), **f32), "ret": torch.zeros(N, **f64), "ecost": torch.zeros(N, **f64), "len": torch.zeros(N, **f64),
+                "events": torch.zeros((N * T, 4), **f64), "prefix": torch.zeros(T + 1, dtype=torch.int32, device=dev),
+                "vf_r": torch.zeros(N, **f32), "vf_c": torch.zeros(N, **f32)}
+    X, Y = state(), state()
+    for t in range(T):
+        rew, cost = torch.randn(N, generator=g, **f32), (torch.rand(N, generator=g, **f32) < 0.2).float()
+        term, trunc = (torch.rand(N, generator=g, **f32) < 0.1).float(), (torch.rand(N, generator=g, **f32) < 0.15).float()
+        vnext = [torch.randn(N, generator=g, **f32) for _ in range(2)]
+        fobs = torch.randn((N, D), generator=g, **f32)
+
+        def tail(S):
+            return [_abi.ptr(S["reward"]), _abi.ptr(S["cost"]), _abi.ptr(S["seg"]), _abi.ptr(S["boot_r"]), _abi.ptr(S["boot_c"]),
+                    _abi.ptr(S["ret"]), _abi.ptr(S["ecost"]), _abi.ptr(S["len"]), _abi.ptr(S["events"]), _abi.ptr(S["prefix"]), N * T, N, T, t,
+                    int(t == T - 1), _abi.ptr(S["fold_r"]), _abi.ptr(S["fold_c"]), 0.99, _abi.stream_ptr()]
+        head = [_abi.ptr(x) for x in (rew, cost, term, trunc, vnext[0], vnext[1])]
+        _abi.check(lib.spo_values(_abi.ptr(pol.theta), _abi.ptr(fobs), _abi.ptr(X["vf_r"]), _abi.ptr(X["vf_c"]), N, D, A_, _abi.stream_ptr()), "values")
+        _abi.check(lib.spo_boundary_step_fold_mb(*head, _abi.ptr(X["vf_r"]), _abi.ptr(X["vf_c"]), *tail(X)), "boundary")
+        _abi.check(lib.spo_values_boundary_step_fold(_abi.ptr(pol.theta), _abi.ptr(fobs), _abi.ptr(Y["vf_r"]), _abi.ptr(Y["vf_c"]), D, A_,
+                                                     *head, *tail(Y)), "fused")
+        for k in X:
+            assert torch.equal(X[k], Y[k]), (t, k)
+    assert 0 < int(X["prefix"][T]) < N * T and float(X["boot_r"].abs().sum()) > 0
+
+
 def test_gae_segment_mask_edge_cases(dev):
     # every step ends a path / single long path / all-terminated bootstraps / -0.0 deltas
     N, T = 9, 64
@@ -721,6 +762,32 @@ def test_rollout_epoch_replayed_from_a_graph_equals_the_eager_loop(dev, monkeypa
         assert int(x["n_ep"]) == int(y["n_ep"]) and int(x["n_ep"]) > 0
         for k in x:
             assert torch.equal(x[k], y[k]), (e, k)
+
+
+@pytest.mark.parametrize("D,affine", [(60, True), (60, False), (7, True), (128, True), (376, True)])
+def test_synth_env_one_launch_step_equals_the_two_kernel_form(dev, D, affine):
+    """spo_synth_env_step_rel (flags + observations + the affine map of the raw observation in one launch, device step base)
+    against spo_synth_env_step (two kernels) followed by the two tensor operations it replaces: bit-identical, over steps with
+    terminations and truncations."""
+    from safepo import _abi
+    lib = _abi.load()
+    N, seed = 1000, 77
+    f32 = dict(dtype=torch.float32, device=dev)
+
+    def fresh():
+        return ([torch.zeros((N, D), **f32), torch.zeros((N, D), **f32)] + [torch.zeros(N, **f32) for _ in range(4)]
+                + [torch.zeros(N, dtype=torch.int32, device=dev)])
+    a, b = fresh(), fresh()
+    base = torch.tensor([40], dtype=torch.int64, device=dev)
+    for k in range(1, 30):
+        _abi.check(lib.spo_synth_env_step(*[_abi.ptr(x) for x in a], N, D, seed, 40 + k, 0.05, 0.3, 9, _abi.stream_ptr()), "two-kernel")
+        if affine:
+            a[0].mul_(1.7).add_(-0.3)
+        _abi.check(lib.spo_synth_env_step_rel(*[_abi.ptr(x) for x in b], N, D, seed, k, _abi.ptr(base), 0.05, 0.3, 9, int(affine),
+                                              1.7, -0.3, _abi.stream_ptr()), "one-launch")
+        for x, y, name in zip(a, b, ("obs", "final_obs", "reward", "cost", "terminated", "truncated", "t_env")):
+            assert torch.equal(x, y), (k, name)
+    assert float(a[4].sum()) > 0 and float(a[5].sum()) > 0
 
 
 def test_ppo_lag_main_entrypoint_synthetic(dev, tmp_path):
