@@ -494,6 +494,21 @@ int64_t spo_mlp_backward_scratch_floats(const spo_mlp_net* net, int64_t rows);
 int spo_mlp_forward(const float* theta, const spo_mlp_net* net, const float* x, int64_t rows, float* ws, void* stream);
 int spo_mlp_backward(const float* theta, const spo_mlp_net* net, const float* x, int64_t rows, const float* ws,
                      const float* d_out, float* grad, float* scratch, void* stream);
+/* Up to 128 rows (and layer widths whose row images fit LDS: csrc/mlp_small.hip) spo_mlp_forward / spo_mlp_backward run the
+ * WHOLE network in one launch each (one workgroup, weights staged through LDS layer by layer) instead of a GEMM launch per
+ * layer: the reference's default minibatch of 64 is launch-latency territory.  SPO_MLP_SMALL=0 keeps the per-layer launches.
+ * The _multi forms take `count` (<= 4) networks on the same number of rows -- the networks of a minibatch step -- and put them
+ * into ONE launch (one workgroup per network) when all of them fit, else call the single-network entry point per network. */
+int spo_mlp_forward_multi(int count, const float* const* thetas, const spo_mlp_net* const* nets, const float* const* xs,
+                          int64_t rows, float* const* wss, void* stream);
+int spo_mlp_backward_multi(int count, const float* const* thetas, const spo_mlp_net* const* nets, const float* const* xs,
+                           int64_t rows, const float* const* wss, const float* const* d_outs, float* const* grads,
+                           float* const* scratches, void* stream);
+/* dsts[k][i, :] = srcs[k][idx[i], :] for k < count (<= SPO_GATHER_MAX) row-major arrays of widths[k] floats per row: the
+ * minibatch gather of a step (the reference's DataLoader, ppo_lag.py:298-305) in one launch. */
+#define SPO_GATHER_MAX 8
+int spo_gather_rows(int count, const float* const* srcs, const int* widths, float* const* dsts, const int64_t* idx, int64_t n,
+                    void* stream);
 /* rsample + log-prob of a diagonal Gaussian (model.py:149-170; eps == NULL: deterministic), and the row sum of
  * KL(N(mean_old, exp(log_std_old)) || N(mean_new, exp(log_std_new))).sum(-1) (ppo_lag.py:338-345) added to (accumulate != 0) or
  * stored into *sum_inout -- the full batch is evaluated in row chunks. */

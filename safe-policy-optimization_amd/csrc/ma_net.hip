@@ -21,6 +21,7 @@
 #include "common.h"
 #include "adam.h"
 #include "mlp_mfma.h"
+#include "mlp_small.h"
 #include "../../include/safepo_hip.h"
 
 namespace {
@@ -2815,6 +2816,15 @@ extern "C" int spo_mlp_forward(const float* theta, const spo_mlp_net* net, const
   if (int rc = mlp_lay(net, &L)) return rc;
   SPO_REQUIRE(theta && x && ws && rows > 0, "mlp_forward: bad args");
   hipStream_t st = (hipStream_t)stream;
+  if (spo::mlp_small_ok(net, rows)) {
+    // up to 128 rows: the whole network in one launch (csrc/mlp_small.hip)
+    spo::MlpSmallBatch batch;
+    batch.count = 1;
+    spo::mlp_small_args(theta, net, x, rows, ws, nullptr, nullptr, &batch.a[0]);
+    if (int rc = spo::mlp_small_launch(false, batch, st)) return rc;
+    SPO_LAUNCH_CHECK("spo_mlp_forward");
+    return 0;
+  }
   const float* in = x;
   for (int l = 0; l < L.n; ++l) {
     float* out = ws + L.act_off(l, rows);
@@ -2840,6 +2850,14 @@ extern "C" int spo_mlp_backward(const float* theta, const spo_mlp_net* net, cons
   if (int rc = mlp_lay(net, &L)) return rc;
   SPO_REQUIRE(theta && x && ws && d_out && grad && scratch && rows > 0, "mlp_backward: bad args");
   hipStream_t st = (hipStream_t)stream;
+  if (spo::mlp_small_ok(net, rows)) {
+    spo::MlpSmallBatch batch;
+    batch.count = 1;
+    spo::mlp_small_args(theta, net, x, rows, const_cast<float*>(ws), d_out, grad, &batch.a[0]);
+    if (int rc = spo::mlp_small_launch(true, batch, st)) return rc;
+    SPO_LAUNCH_CHECK("spo_mlp_backward");
+    return 0;
+  }
   const int md = L.maxdim();
   float* dA = scratch;                                   // ping-pong dZ buffers
   float* dB = scratch + rows * (int64_t)md;
@@ -2872,6 +2890,101 @@ extern "C" int spo_mlp_backward(const float* theta, const spo_mlp_net* net, cons
     }
   }
   SPO_LAUNCH_CHECK("spo_mlp_backward");
+  return 0;
+}
+
+// The same for `count` networks on the same number of rows -- the three networks of a minibatch step -- in ONE launch when every
+// network fits the small-row kernel (one workgroup per network), else one call per network.
+extern "C" int spo_mlp_forward_multi(int count, const float* const* thetas, const spo_mlp_net* const* nets, const float* const* xs,
+                                     int64_t rows, float* const* wss, void* stream) {
+  SPO_REQUIRE(count >= 1 && count <= spo::MLP_SMALL_MAX_NETS && thetas && nets && xs && wss && rows > 0, "mlp_forward_multi: bad args");
+  bool small = true;
+  for (int i = 0; i < count; ++i) {
+    SPO_REQUIRE(thetas[i] && nets[i] && xs[i] && wss[i], "mlp_forward_multi: null pointer");
+    small = small && spo::mlp_small_ok(nets[i], rows);
+  }
+  if (!small) {
+    for (int i = 0; i < count; ++i)
+      if (int rc = spo_mlp_forward(thetas[i], nets[i], xs[i], rows, wss[i], stream)) return rc;
+    return 0;
+  }
+  spo::MlpSmallBatch batch;
+  batch.count = count;
+  for (int i = 0; i < count; ++i) {
+    MlpLay L;
+    if (int rc = mlp_lay(nets[i], &L)) return rc;
+    spo::mlp_small_args(thetas[i], nets[i], xs[i], rows, wss[i], nullptr, nullptr, &batch.a[i]);
+  }
+  if (int rc = spo::mlp_small_launch(false, batch, (hipStream_t)stream)) return rc;
+  SPO_LAUNCH_CHECK("spo_mlp_forward_multi");
+  return 0;
+}
+
+extern "C" int spo_mlp_backward_multi(int count, const float* const* thetas, const spo_mlp_net* const* nets, const float* const* xs,
+                                      int64_t rows, const float* const* wss, const float* const* d_outs, float* const* grads,
+                                      float* const* scratches, void* stream) {
+  SPO_REQUIRE(count >= 1 && count <= spo::MLP_SMALL_MAX_NETS && thetas && nets && xs && wss && d_outs && grads && scratches && rows > 0,
+              "mlp_backward_multi: bad args");
+  bool small = true;
+  for (int i = 0; i < count; ++i) {
+    SPO_REQUIRE(thetas[i] && nets[i] && xs[i] && wss[i] && d_outs[i] && grads[i] && scratches[i], "mlp_backward_multi: null pointer");
+    small = small && spo::mlp_small_ok(nets[i], rows);
+  }
+  if (!small) {
+    for (int i = 0; i < count; ++i)
+      if (int rc = spo_mlp_backward(thetas[i], nets[i], xs[i], rows, wss[i], d_outs[i], grads[i], scratches[i], stream)) return rc;
+    return 0;
+  }
+  spo::MlpSmallBatch batch;
+  batch.count = count;
+  for (int i = 0; i < count; ++i) {
+    MlpLay L;
+    if (int rc = mlp_lay(nets[i], &L)) return rc;
+    spo::mlp_small_args(thetas[i], nets[i], xs[i], rows, const_cast<float*>(wss[i]), d_outs[i], grads[i], &batch.a[i]);
+  }
+  if (int rc = spo::mlp_small_launch(true, batch, (hipStream_t)stream)) return rc;
+  SPO_LAUNCH_CHECK("spo_mlp_backward_multi");
+  return 0;
+}
+
+// Rows idx[0 .. n) of up to SPO_GATHER_MAX row-major arrays (widths[k] floats per row) in one launch: the minibatch gather of a
+// step (ppo_lag.py:298-305: the DataLoader's index_select of obs, act, log_prob, targets, advantage) instead of one launch per array.
+namespace {
+struct GatherArgs {
+  const float* src[SPO_GATHER_MAX];
+  float* dst[SPO_GATHER_MAX];
+  int width[SPO_GATHER_MAX];
+  int count;
+  const int64_t* idx;
+  int64_t n;
+};
+__global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs a) {
+  const int k = blockIdx.y;
+  const int w = a.width[k];
+  const float* __restrict__ src = a.src[k];
+  float* __restrict__ dst = a.dst[k];
+  const int64_t total = a.n * w;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e / w;
+    const int c = (int)(e - r * w);
+    dst[e] = src[a.idx[r] * w + c];
+  }
+}
+}  // namespace
+extern "C" int spo_gather_rows(int count, const float* const* srcs, const int* widths, float* const* dsts, const int64_t* idx, int64_t n,
+                               void* stream) {
+  SPO_REQUIRE(count >= 1 && count <= SPO_GATHER_MAX && srcs && widths && dsts && idx && n > 0, "gather_rows: bad args");
+  GatherArgs a;
+  a.count = count; a.idx = idx; a.n = n;
+  int wmax = 1;
+  for (int k = 0; k < count; ++k) {
+    SPO_REQUIRE(srcs[k] && dsts[k] && widths[k] >= 1, "gather_rows: bad array %d", k);
+    a.src[k] = srcs[k]; a.dst[k] = dsts[k]; a.width[k] = widths[k];
+    wmax = widths[k] > wmax ? widths[k] : wmax;
+  }
+  const int64_t blocks = (n * wmax + 255) / 256;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks), (unsigned)count), dim3(256), 0, (hipStream_t)stream, a);
+  SPO_LAUNCH_CHECK("spo_gather_rows");
   return 0;
 }
 

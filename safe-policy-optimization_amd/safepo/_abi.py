@@ -82,6 +82,9 @@ PROTOTYPES = {
     "spo_boundary_step": (c_int, [P] * 18 + [c_int, c_int64, c_int64, c_int64, c_int, P]),
     "spo_boundary_step_fold": (c_int, [P] * 18 + [c_int, c_int64, c_int64, c_int64, c_int, P, P, c_double, P]),
     "spo_boundary_step_fold_mb": (c_int, [P] * 18 + [c_int, c_int64, c_int64, c_int64, c_int, P, P, c_double, P]),
+    "spo_mlp_forward_multi": (c_int, [c_int, P, P, P, c_int64, P, P]),
+    "spo_mlp_backward_multi": (c_int, [c_int, P, P, P, c_int64, P, P, P, P, P]),
+    "spo_gather_rows": (c_int, [c_int, P, P, P, P, c_int64, P]),
     "spo_values_boundary_step_fold": (c_int, [P] * 4 + [c_int, c_int] + [P] * 16 + [c_int, c_int64, c_int64, c_int64, c_int, P, P,
                                               c_double, P]),
     "spo_ppo_lag_update_iter": (c_int, [P, P, P, c_int64] + [P] * 7 + [c_int64, POINTER(PpoCfg), P, P, P]),

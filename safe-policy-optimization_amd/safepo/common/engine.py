@@ -690,23 +690,25 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
         super().__init__(policy, num_envs, steps, config, device, comm=comm, lr=lr, critic_lr=critic_lr)
         self._wide_init()
 
-    def _gather(self, idx):
-        d, b = self.buffer.data, self.buffer
-        return (d["obs"].view(self.M, self.D).index_select(0, idx), d["act"].view(self.M, self.A).index_select(0, idx),
-                d["log_prob"].view(-1).index_select(0, idx), d["target_value_r"].view(-1).index_select(0, idx),
-                d["target_value_c"].view(-1).index_select(0, idx))
+    def _gather(self, idx, adv_all=None, extra=()):
+        """The minibatch rows of obs, act, log_prob, both value targets, the advantage (adv_all; default the mixed one) and any
+        `extra` [M, w] arrays: one launch (the reference's DataLoader batch, ppo_lag.py:298-305)."""
+        d = self.buffer.data
+        adv_all = self.buffer.adv_mix if adv_all is None else adv_all
+        M = self.M
+        out = self.wide.gather_rows(idx, [d["obs"].view(M, self.D), d["act"].view(M, self.A), d["log_prob"].view(M, 1),
+                                          d["target_value_r"].view(M, 1), d["target_value_c"].view(M, 1), adv_all.view(M, 1)]
+                                    + [e.view(M, -1) for e in extra])
+        return [out[0], out[1], out[2].view(-1), out[3].view(-1), out[4].view(-1), out[5].view(-1)] + out[6:]
 
     def minibatch_step(self, idx: torch.Tensor, losses_out: torch.Tensor, dev_clock: bool = False, cfg=None) -> None:
         """ppo_lag.py:306-329 on the rows `idx` (int64 device indices into the flat buffer).  dev_clock: optimiser clocks from
         self.pow4 on the device (the graph-replayed form; the caller advances self.adam_step)."""
         w, lib, st = self.wide, self.lib, _abi.stream_ptr
         cfg = self._cfg_struct() if cfg is None else cfg
-        obs, act, logp_old, tgt_r, tgt_c = self._gather(idx)
-        adv = self.buffer.adv_mix.view(-1).index_select(0, idx)
+        obs, act, logp_old, tgt_r, tgt_c, adv = self._gather(idx)
         n = obs.shape[0]
-        v_r, ws_r = w.forward("r", obs, slot=1)
-        v_c, ws_c = w.forward("c", obs, slot=1)
-        mu, ws_a = w.forward("a", obs, slot=1)
+        (v_r, ws_r), (v_c, ws_c), (mu, ws_a) = w.forward_multi("rca", obs, slot=1)
         d_vr = torch.empty(n, dtype=torch.float32, device=self.dev)
         d_vc, d_mu = torch.empty_like(d_vr), torch.empty((n, self.A), dtype=torch.float32, device=self.dev)
         g = self.flat_grad
@@ -715,9 +717,7 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
                                          _abi.ptr(logp_old), _abi.ptr(adv), _abi.ptr(tgt_r), _abi.ptr(tgt_c), n, self.A, float(cfg.clip),
                                          _abi.ptr(d_vr), _abi.ptr(d_vc), _abi.ptr(d_mu), _abi.ptr(g[off_ls:]), _abi.ptr(losses_out),
                                          _abi.ptr(self.loss_partials), self.loss_partials.numel(), st()), "spo_wide_ppo_loss")
-        w.backward("r", obs, ws_r, d_vr, g)
-        w.backward("c", obs, ws_c, d_vc, g)
-        w.backward("a", obs, ws_a, d_mu, g)
+        w.backward_multi("rca", obs, [ws_r, ws_c, ws_a], [d_vr, d_vc, d_mu], g)
         if dev_clock:
             _abi.check(lib.spo_wide_clip_adam_dev(_abi.ptr(self.policy.theta), _abi.ptr(g), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), w.P,
                                                   w.off_c, w.off_ls, w.off_ls, cfg, _abi.ptr(self.pow4), 0, w.P, 0, 0, _abi.ptr(losses_out),
@@ -756,24 +756,26 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
         wide kernels: spo_update_iter_ex's semantics (include/safepo_hip.h), one minibatch."""
         w, lib, st = self.wide, self.lib, _abi.stream_ptr
         cfg = self._cfg_struct() if cfg is None else cfg
-        obs, act, logp_old, tgt_r, tgt_c = self._gather(idx)
-        adv = adv_all.view(-1).index_select(0, idx)
+        klpen = actor_loss == _abi.ACTOR_LOSS_KL_PENALTY
+        got = self._gather(idx, adv_all, extra=(self.mean_old,) if klpen else ())
+        obs, act, logp_old, tgt_r, tgt_c, adv = got[:6]
         n = obs.shape[0]
         g, off_ls, A = self.flat_grad, w.off_ls, self.A
         part, cap = self.loss_partials, self.loss_partials.numel()
+        nets = "a" if actor_only else "rca"
+        fw = w.forward_multi(nets, obs, slot=1)
+        mu, ws_a = fw[-1]
+        wss, d_outs = [ws for _, ws in fw], []
         if not actor_only:
-            v_r, ws_r = w.forward("r", obs, slot=1)
-            v_c, ws_c = w.forward("c", obs, slot=1)
+            (v_r, _), (v_c, _) = fw[0], fw[1]
             d_vr = torch.empty(n, dtype=torch.float32, device=self.dev)
             d_vc = torch.empty_like(d_vr)
             _abi.check(lib.spo_wide_critic_loss(_abi.ptr(v_r), _abi.ptr(v_c), _abi.ptr(tgt_r), _abi.ptr(tgt_c), n, _abi.ptr(d_vr),
                                                 _abi.ptr(d_vc), _abi.ptr(losses_out), _abi.ptr(part), cap, st()), "spo_wide_critic_loss")
-            w.backward("r", obs, ws_r, d_vr, g)
-            w.backward("c", obs, ws_c, d_vc, g)
-        mu, ws_a = w.forward("a", obs, slot=1)
+            d_outs = [d_vr, d_vc]
         d_mu = torch.empty((n, A), dtype=torch.float32, device=self.dev)
-        if actor_loss == _abi.ACTOR_LOSS_KL_PENALTY:
-            old_mean = self.mean_old.index_select(0, idx)
+        if klpen:
+            old_mean = got[6]
             mode, p0, p1, om, os_ = _abi.WIDE_ACTOR_KLPEN, float(kl_bound), float(pg_coef), _abi.ptr(old_mean), _abi.ptr(self.std_old)
         else:
             mode, p0, p1, om, os_ = _abi.WIDE_ACTOR_CLIP, float(cfg.clip), 0.0, None, None
@@ -781,7 +783,7 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
                                            _abi.ptr(adv), om, os_, n, n, A, p0, p1, _abi.ptr(d_mu), _abi.ptr(self.actor_sums), 0,
                                            _abi.ptr(losses_out[2:]), _abi.ptr(g[off_ls:]), _abi.ptr(part), cap, st()),
                    "spo_wide_actor_loss")
-        w.backward("a", obs, ws_a, d_mu, g)
+        w.backward_multi(nets, obs, wss, d_outs + [d_mu], g)
         step_c, step_a = self.adam_step, self.adam_step + self.adam_step_actor_extra
         lo, norm0 = (off_ls, off_ls) if actor_only else (0, 0)
         if dev_clock:

@@ -82,6 +82,57 @@ class WideNets:
         _abi.check(self.lib.spo_mlp_backward(_abi.ptr(self.theta_of(which)), net, _abi.ptr(x), rows, _abi.ptr(ws), _abi.ptr(d_out),
                                              _abi.ptr(grad_flat[off:]), _abi.ptr(sc), _abi.stream_ptr()), "spo_mlp_backward")
 
+    # ------------------------------------------------------------------ several networks, one launch each way (small row counts)
+    def _bwd_scratch(self, which, rows):
+        key = (which, rows)
+        sc = self._scratch.get(key)
+        if sc is None:
+            n = int(self.lib.spo_mlp_backward_scratch_floats(self.net_of(which), rows))
+            sc = torch.empty(max(n, 1), dtype=torch.float32, device=self.policy.theta.device)
+            if len(self._scratch) > 12:
+                self._scratch.clear()
+            self._scratch[key] = sc
+        return sc
+
+    def forward_multi(self, whichs, x, slot=0):
+        """[(output, workspace)] of the networks `whichs` ("r", "c", "a") on the same rows `x`: spo_mlp_forward_multi -- one
+        launch for all of them at minibatch-sized row counts (csrc/mlp_small.hip), else a call per network."""
+        import ctypes
+        rows, n = x.shape[0], len(whichs)
+        wss = [self._workspace(w, rows, slot) for w in whichs]
+        vp = ctypes.c_void_p * n
+        nets = (ctypes.POINTER(_abi.MlpNet) * n)(*[ctypes.pointer(self.net_of(w)) for w in whichs])
+        _abi.check(self.lib.spo_mlp_forward_multi(n, vp(*[_abi.ptr(self.theta_of(w)) for w in whichs]), nets, vp(*[_abi.ptr(x)] * n), rows,
+                                                  vp(*[_abi.ptr(ws) for ws in wss]), _abi.stream_ptr()), "spo_mlp_forward_multi")
+        outs = []
+        for w, ws in zip(whichs, wss):
+            od = self.A if w == "a" else 1
+            outs.append((ws[ws.numel() - rows * od:].view(rows, od), ws))
+        return outs
+
+    def backward_multi(self, whichs, x, wss, d_outs, grad_flat):
+        """spo_mlp_backward_multi: the flat gradients of the networks `whichs` into their slices of `grad_flat`."""
+        import ctypes
+        rows, n = x.shape[0], len(whichs)
+        off = {"r": self.off_r, "c": self.off_c, "a": self.off_a}
+        vp = ctypes.c_void_p * n
+        nets = (ctypes.POINTER(_abi.MlpNet) * n)(*[ctypes.pointer(self.net_of(w)) for w in whichs])
+        _abi.check(self.lib.spo_mlp_backward_multi(
+            n, vp(*[_abi.ptr(self.theta_of(w)) for w in whichs]), nets, vp(*[_abi.ptr(x)] * n), rows, vp(*[_abi.ptr(ws) for ws in wss]),
+            vp(*[_abi.ptr(d) for d in d_outs]), vp(*[_abi.ptr(grad_flat[off[w]:]) for w in whichs]),
+            vp(*[_abi.ptr(self._bwd_scratch(w, rows)) for w in whichs]), _abi.stream_ptr()), "spo_mlp_backward_multi")
+
+    def gather_rows(self, idx, srcs):
+        """[src[idx] for src in srcs] (row-major float32 arrays, int64 device indices) in one launch (spo_gather_rows)."""
+        import ctypes
+        n, k = idx.numel(), len(srcs)
+        srcs = [s_.view(s_.shape[0], -1) for s_ in srcs]
+        dsts = [torch.empty((n, s_.shape[1]), dtype=torch.float32, device=idx.device) for s_ in srcs]
+        vp = ctypes.c_void_p * k
+        _abi.check(self.lib.spo_gather_rows(k, vp(*[_abi.ptr(s_) for s_ in srcs]), (ctypes.c_int * k)(*[s_.shape[1] for s_ in srcs]),
+                                            vp(*[_abi.ptr(d) for d in dsts]), _abi.ptr(idx), n, _abi.stream_ptr()), "spo_gather_rows")
+        return dsts
+
     def jvp_scratch(self, rows):
         key = ("jvp", rows)
         sc = self._scratch.get(key)

@@ -636,17 +636,16 @@ class WideCPOEngine(_WideOps, CPOEngine):
         g, part, cap = self.flat_grad, self.loss_partials, self.loss_partials.numel()
         all_losses = []
         def step(idx, loss3, dev_clock):
-            obs, tgt_r, tgt_c = obs_all.index_select(0, idx), tr_all.index_select(0, idx), tc_all.index_select(0, idx)
+            obs, tgt_r, tgt_c = w.gather_rows(idx, [obs_all, tr_all.view(-1, 1), tc_all.view(-1, 1)])
+            tgt_r, tgt_c = tgt_r.view(-1), tgt_c.view(-1)
             n = obs.shape[0]
-            v_r, ws_r = w.forward("r", obs, slot=1)
-            v_c, ws_c = w.forward("c", obs, slot=1)
+            (v_r, ws_r), (v_c, ws_c) = w.forward_multi("rc", obs, slot=1)
             d_vr = torch.empty(n, dtype=torch.float32, device=self.dev)
             d_vc = torch.empty_like(d_vr)
             _abi.check(lib.spo_wide_critic_loss(_abi.ptr(v_r), _abi.ptr(v_c), _abi.ptr(tgt_r), _abi.ptr(tgt_c), n, _abi.ptr(d_vr),
                                                 _abi.ptr(d_vc), _abi.ptr(loss3), _abi.ptr(part), cap, _abi.stream_ptr()),
                        "spo_wide_critic_loss")
-            w.backward("r", obs, ws_r, d_vr, g)
-            w.backward("c", obs, ws_c, d_vc, g)
+            w.backward_multi("rc", obs, [ws_r, ws_c], [d_vr, d_vc], g)
             if dev_clock:
                 _abi.check(lib.spo_wide_clip_adam_dev(_abi.ptr(self.policy.theta), _abi.ptr(g), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v),
                                                       w.P, w.off_c, w.off_ls, w.off_ls, cfg, _abi.ptr(self.pow4), 0, w.off_ls, 0, 1,

@@ -45,6 +45,10 @@ def one(hidden, batch, steps, D=60, A=8, **cfg_kw):
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--isaac":
     print(json.dumps(one([1024, 1024, 512], 8192, 8, use_critic_norm=False, use_value_coefficient=True, max_grad_norm=1.0)))
     sys.exit(0)
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--small":
+    # the launch-latency regime: the reference's default batch of 64 on a widened net and on HumanoidVelocity's dims
+    print(json.dumps([one([128, 128], 64, 256), one([64, 64], 64, 256, D=376, A=17)]))
+    sys.exit(0)
 if __name__ == "__main__":
     out = [one([1024, 1024, 512], 8192, 8, use_critic_norm=False, use_value_coefficient=True, max_grad_norm=1.0),
            one([256, 256], 2048, 16), one([128, 128], 64, 256)]
