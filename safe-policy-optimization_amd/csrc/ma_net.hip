@@ -2694,12 +2694,19 @@ __global__ __launch_bounds__(256) void wide_prep_kernel(WideAdamArgs a) {
   __syncthreads();
   if (tid < 3) a.partial[(int64_t)blockIdx.x * 3 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
-__global__ __launch_bounds__(64) void wide_coef_kernel(WideAdamArgs a, int nblocks) {
+// pow4 (optional): the device-resident optimiser clocks {beta1^t, beta2^t of the critics, of the actor}; the clocks named by
+// adv_critics / adv_actor advance here, between the norm and the Adam pass (spo_wide_clip_adam_dev)
+__global__ __launch_bounds__(64) void wide_coef_kernel(WideAdamArgs a, int nblocks, double* pow4 = nullptr, int adv_critics = 0,
+                                                       int adv_actor = 0) {
   // one wave: lane l adds the partials l, l + 64, ... in order, then a fixed butterfly over the lanes
   double gs = 0.0, pr = 0.0, pc = 0.0;
   for (int b = threadIdx.x; b < nblocks; b += 64) { gs += a.partial[b * 3]; pr += a.partial[b * 3 + 1]; pc += a.partial[b * 3 + 2]; }
   gs = wave_sum_d(gs); pr = wave_sum_d(pr); pc = wave_sum_d(pc);
   if (threadIdx.x != 0) return;
+  if (pow4) {
+    if (adv_critics) { pow4[0] *= (double)a.b1; pow4[1] *= (double)a.b2; }
+    if (adv_actor) { pow4[2] *= (double)a.b1; pow4[3] *= (double)a.b2; }
+  }
   const float norm = sqrtf((float)gs);
   float coef = a.max_norm / (norm + 1e-6f);                   // clip_grad_norm_ (torch): eps 1e-6
   a.scal[0] = coef > 1.f ? 1.f : coef;
@@ -3420,11 +3427,6 @@ extern "C" int spo_wide_linesearch_sums(const float* mean_new, const float* log_
 // can be captured once as a HIP graph and replayed (the wide path at small batches is launch-bound: ~70 launches per step).
 namespace {
 using namespace spo;
-__global__ void wide_pow_advance_kernel(double* pow4, double b1, double b2, int critics, int actor) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (critics) { pow4[0] *= b1; pow4[1] *= b2; }
-  if (actor) { pow4[2] *= b1; pow4[3] *= b2; }
-}
 __global__ __launch_bounds__(256) void wide_adam_dev_kernel(WideAdamExArgs x, const double* __restrict__ pow4) {
   const WideAdamArgs& a = x.b;
   const float coef = a.scal[0];
@@ -3461,9 +3463,8 @@ extern "C" int spo_wide_clip_adam_dev(float* theta, float* grad, float* adam_m, 
   hipStream_t st = (hipStream_t)stream;
   if (norm_begin == 0) hipLaunchKernelGGL(wide_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(wide_prep_range_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, norm_begin, n_params);
-  hipLaunchKernelGGL(wide_coef_kernel, dim3(1), dim3(64), 0, st, a, (int)blocks);
-  hipLaunchKernelGGL(wide_pow_advance_kernel, dim3(1), dim3(64), 0, st, pow4_dev, (double)cfg->beta1, (double)cfg->beta2,
-                     adam_begin < actor_begin ? 1 : 0, adam_end > actor_begin ? 1 : 0);
+  hipLaunchKernelGGL(wide_coef_kernel, dim3(1), dim3(64), 0, st, a, (int)blocks, pow4_dev, adam_begin < actor_begin ? 1 : 0,
+                     adam_end > actor_begin ? 1 : 0);
   hipLaunchKernelGGL(wide_adam_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, (const double*)pow4_dev);
   SPO_LAUNCH_CHECK("spo_wide_clip_adam_dev");
   return 0;

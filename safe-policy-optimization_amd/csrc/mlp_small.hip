@@ -178,18 +178,29 @@ __global__ __launch_bounds__(512) void mlp_small_kernel(MlpSmallBatch B) {
       const int UC = imin((big_floats / KP) & ~15, 16 * NT);                   // units per weight chunk (whole tiles)
       for (int u0 = 0; u0 < 16 * NT; u0 += UC) {
         const int uc = imin(UC, 16 * NT - u0);
+        // this wave's first group of the chunk: its biases are requested before the staging copy (one memory round trip, not two)
+        const int tiles = uc >> 4, gs = imin(4, (tiles + CS - 1) / CS);          // tiles per group: every column set gets work
+        f4 bias0[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bias0[i][r] = bias[imin(u0 + 16 * (cs * gs + i) + 4 * q + r, N - 1)];
         __syncthreads();                                                       // the previous chunk's readers are done
         stage_block(W + (int64_t)u0 * K, K, N - u0, K, big, KP, uc, 16 * KT, wave, lane, nwaves);
         __syncthreads();
         SPO_SMALL_STAMP(stamp++);
-        const int tiles = uc >> 4, gs = imin(4, (tiles + CS - 1) / CS);          // tiles per group: every column set gets work
         for (int mt0 = cs * gs; rowwave && mt0 < tiles; mt0 += CS * gs) {
           const int ni = imin(gs, tiles - mt0);                                // tiles of this group (wave-uniform)
           f4 acc[4];
+          if (mt0 == cs * gs) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) acc[i] = bias0[i];
+          } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][r] = bias[imin(u0 + 16 * (mt0 + i) + 4 * q + r, N - 1)];
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[i][r] = bias[imin(u0 + 16 * (mt0 + i) + 4 * q + r, N - 1)];
+          }
           const float* arow = big + (16 * mt0 + j) * KP + 4 * q;
           const float* brow = l > 0 ? cur + rl * LDM + 4 * q : xin;
 #define SPO_FWD_GROUP(NI_)                                                                                            \
