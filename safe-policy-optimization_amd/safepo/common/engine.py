@@ -582,8 +582,6 @@ class _WideOps:
         policy.wide          # builds the layout; raises on unsupported depths
 
     def _wide_init(self) -> None:
-        if self.comm.world_size != 1:
-            raise NotImplementedError("the wide-network path runs on one GPU in this build")
         self.wide = self.policy.wide
         f32 = dict(dtype=torch.float32, device=self.dev)
         # spo_wide_ppo_loss: 256 x (3 + SPO_WIDE_MAX_ACT) + 512 + (2 + SPO_WIDE_MAX_ACT) doubles; spo_wide_clip_adam: <= 1024 x 3
@@ -595,6 +593,25 @@ class _WideOps:
         self.pow4 = torch.ones(4, dtype=torch.float64, device=self.dev)
         self._step_graphs = {}
         self.graph_max_batch = int(os.environ.get("SPO_WIDE_GRAPH_MAX_BATCH", "2048"))     # 0: never (every launch eager)
+        if self.comm.world_size > 1:
+            # data-parallel: the flat gradient of all three networks is all-reduced between the backward pass
+            # and the joint clip (ppo_lag.py:325: clip_grad_norm_ on the reduced gradient), a collective per minibatch step --
+            # steps launch eagerly (a host collective cannot sit inside a captured graph of this process)
+            self.graph_max_batch = 0
+
+    def _mean_over_ranks_(self, losses: torch.Tensor) -> torch.Tensor:
+        """Per-step losses of the GLOBAL minibatches (the critics' L2 terms are the same on every rank)."""
+        if self.comm.world_size > 1:
+            self.comm.all_reduce_sum_(losses)
+            losses.mul_(1.0 / self.comm.world_size)
+        return losses
+
+    def _reduce_flat_grad(self, lo: int = 0, hi: int | None = None) -> None:
+        """Mean over the ranks of flat_grad[lo:hi] (world 1: nothing)."""
+        if self.comm.world_size > 1:
+            g = self.flat_grad[lo:hi]
+            self.comm.all_reduce_sum_(g)
+            g.mul_(1.0 / self.comm.world_size)
 
     # ------------------------------------------------------------------ graph-replayed minibatch steps
     def _sync_pow4(self) -> None:
@@ -670,9 +687,10 @@ class _WideOps:
                                                  _abi.ptr(ls_new), mu.shape[0], self.A, _abi.ptr(self.kl_partials),
                                                  self.kl_partials.numel(), _abi.ptr(self.kl_sum), int(k > 0), _abi.stream_ptr()),
                        "spo_gauss_kl_sum")
+        self.comm.all_reduce_sum_(self.kl_sum)
 
     def kl_read(self) -> float:
-        return float(self.kl_sum.item()) / float(self.M)
+        return float(self.kl_sum.item()) / float(self.M * self.comm.world_size)
 
     def check_sync_error(self):
         return None
@@ -683,12 +701,14 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
     model.py:131; the isaac_gym_specific_cfg regime of ppo_lag.py:54-65), obs_dim > 128 or act_dim > 16 (HumanoidVelocity:
     376 / 17): collect, boundary logic, GAE, statistics and the KL early stop are shared with PPOLagEngine; the policy step, the
     bootstrap values, the full-batch actor evaluation and the minibatch step (clipped surrogate, and the KL-penalty loss of
-    FOCOPS / CUP) run on the wide-network kernels (safepo.common.wide).  Single GPU."""
+    FOCOPS / CUP) run on the wide-network kernels (safepo.common.wide).  Data-parallel: env shards as PPOLagEngine, the flat
+    gradient all-reduced (RCCL) per minibatch step before the joint clip."""
 
     def __init__(self, policy: ActorVCritic, num_envs: int, steps: int, config: dict, device,
                  comm: Comm | None = None, lr: float = 3e-4, critic_lr: float | None = None):
         super().__init__(policy, num_envs, steps, config, device, comm=comm, lr=lr, critic_lr=critic_lr)
         self._wide_init()
+        self.p2p = None                           # (the in-kernel exchange belongs to the persistent kernels)
 
     def _gather(self, idx, adv_all=None, extra=()):
         """The minibatch rows of obs, act, log_prob, both value targets, the advantage (adv_all; default the mixed one) and any
@@ -718,6 +738,7 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
                                          _abi.ptr(d_vr), _abi.ptr(d_vc), _abi.ptr(d_mu), _abi.ptr(g[off_ls:]), _abi.ptr(losses_out),
                                          _abi.ptr(self.loss_partials), self.loss_partials.numel(), st()), "spo_wide_ppo_loss")
         w.backward_multi("rca", obs, [ws_r, ws_c, ws_a], [d_vr, d_vc, d_mu], g)
+        self._reduce_flat_grad()
         if dev_clock:
             _abi.check(lib.spo_wide_clip_adam_dev(_abi.ptr(self.policy.theta), _abi.ptr(g), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), w.P,
                                                   w.off_c, w.off_ls, w.off_ls, cfg, _abi.ptr(self.pow4), 0, w.P, 0, 0, _abi.ptr(losses_out),
@@ -748,7 +769,7 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
                 self.minibatch_step(idx, losses[k], cfg=cfg)
                 if graphed:
                     self._sync_pow4()
-        return losses
+        return self._mean_over_ranks_(losses)
 
     def minibatch_step_ex(self, idx, adv_all, losses_out, actor_loss, kl_bound, pg_coef, actor_only, dev_clock: bool = False,
                           cfg=None) -> None:
@@ -784,6 +805,7 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
                                            _abi.ptr(losses_out[2:]), _abi.ptr(g[off_ls:]), _abi.ptr(part), cap, st()),
                    "spo_wide_actor_loss")
         w.backward_multi(nets, obs, wss, d_outs + [d_mu], g)
+        self._reduce_flat_grad(off_ls if actor_only else 0)
         step_c, step_a = self.adam_step, self.adam_step + self.adam_step_actor_extra
         lo, norm0 = (off_ls, off_ls) if actor_only else (0, 0)
         if dev_clock:
@@ -822,4 +844,4 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
                 self.adam_step += 1
             if graphed and idx.numel() != cfg.batch:
                 self._sync_pow4()
-        return losses
+        return self._mean_over_ranks_(losses)

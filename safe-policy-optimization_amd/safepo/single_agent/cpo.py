@@ -546,6 +546,8 @@ class WideCPOEngine(_WideOps, CPOEngine):
         per_row = sum(policy.hidden_sizes) + policy.act_dim + policy.obs_dim
         self.CHUNK = max(self.CHUNK, min(self.M, (1 << 27) // max(per_row, 1)))
         self._critics_on_persistent_kernel = (list(policy.hidden_sizes) == [64, 64] and policy.obs_dim <= _abi.MAX_OBS)
+        if not self._critics_on_persistent_kernel:
+            self.p2p = None                       # (the in-kernel exchange belongs to the persistent critic fit)
 
     def _alloc_full_batch_workspaces(self) -> None:
         self.partial_ws = self.loss_ws = None           # the LDS-resident kernels' per-workgroup partial vectors: not used here
@@ -646,6 +648,7 @@ class WideCPOEngine(_WideOps, CPOEngine):
                                                 _abi.ptr(d_vc), _abi.ptr(loss3), _abi.ptr(part), cap, _abi.stream_ptr()),
                        "spo_wide_critic_loss")
             w.backward_multi("rc", obs, [ws_r, ws_c], [d_vr, d_vc], g)
+            self._reduce_flat_grad(0, w.off_ls)       # data-parallel: the critics' gradient of the global minibatch
             if dev_clock:
                 _abi.check(lib.spo_wide_clip_adam_dev(_abi.ptr(self.policy.theta), _abi.ptr(g), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v),
                                                       w.P, w.off_c, w.off_ls, w.off_ls, cfg, _abi.ptr(self.pow4), 0, w.off_ls, 0, 1,
@@ -672,7 +675,7 @@ class WideCPOEngine(_WideOps, CPOEngine):
                 self.adam_step += 1
                 if graphed and idx.numel() != cfg.batch:
                     self._sync_pow4()
-            all_losses.append(losses[:, :2])
+            all_losses.append(self._mean_over_ranks_(losses)[:, :2])
         # keep the norm the persistent kernel would carry in step with the rescaled vector
         self.stale_sq.copy_(g[self.ls_off:].dot(g[self.ls_off:]).reshape(1))
         means = torch.cat(all_losses, 0).mean(0).tolist() if all_losses else [float("nan")] * 2

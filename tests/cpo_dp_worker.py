@@ -16,16 +16,17 @@ for p in (ROOT, os.path.join(ROOT, "safe-policy-optimization_amd")):
         sys.path.insert(0, p)
 
 
-def main(out_path):
+def main(out_path, shape="60,8,64,64"):
     from safepo import parallel as P
     from safepo.common.model import ActorVCritic
-    from safepo.single_agent.cpo import CPOEngine, default_cfg
+    from safepo.single_agent.cpo import default_cfg, make_engine
     comm = P.init_from_env(backend="gloo")
     torch.cuda.set_device(0)
     dev = torch.device("cuda:0")
     rank, world = comm.rank, comm.world_size
-    N, T, D, A = 8, 40, 60, 8
-    cfg = dict(default_cfg, learning_iters=2, batch_size=64)
+    dims = [int(v) for v in shape.split(",")]
+    N, T, D, A, hidden = 8, 40, dims[0], dims[1], dims[2:]       # (a shape outside the CPO kernels' envelope: WideCPOEngine)
+    cfg = dict(default_cfg, learning_iters=2, batch_size=64, hidden_sizes=hidden)
     g = torch.Generator().manual_seed(77)
     full = {"obs": torch.randn(N, T, D, generator=g), "act": torch.randn(N, T, A, generator=g),
             "reward": torch.randn(N, T, generator=g), "cost": (torch.rand(N, T, generator=g) < 0.3).float(),
@@ -34,8 +35,8 @@ def main(out_path):
 
     def build(n, lo, comm_):
         torch.manual_seed(21)
-        pol = ActorVCritic(D, A).to(dev)
-        eng = CPOEngine(pol, n, T, cfg, dev, comm=comm_)
+        pol = ActorVCritic(D, A, hidden_sizes=hidden).to(dev)
+        eng = make_engine(pol, n, T, cfg, dev, comm=comm_)
         b = eng.buffer
         for k, v in full.items():
             b.data[k].copy_(v[lo:lo + n])
@@ -45,7 +46,7 @@ def main(out_path):
         return pol, eng
     shard = N // world
     pol, eng = build(shard, rank * shard, comm)
-    res = {"world": world, "p2p": eng.p2p is not None}
+    res = {"world": world, "p2p": eng.p2p is not None, "engine": type(eng).__name__}
     eng.buffer.compute_gae(None, comm)
     out = eng.policy_update(0.4)
     actor_dp = eng.theta_actor.detach().cpu().clone()
@@ -75,4 +76,4 @@ def main(out_path):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(*sys.argv[1:3])

@@ -28,23 +28,25 @@ def shard(rank: int, M: int, D: int, A: int):
     return obs, act, logp, tgt_r, tgt_c, adv, perm
 
 
-def main(out_path: str, use_p2p: str):
+def main(out_path: str, use_p2p: str, shape: str = "60,8,64,64"):
     from safepo import parallel as P
-    from safepo.common.engine import PPOLagEngine
+    from safepo.common.engine import PPOLagEngine, WidePPOLagEngine
     from safepo.common.model import ActorVCritic
     comm = P.init_from_env(backend="gloo")
     torch.cuda.set_device(0)
     dev = torch.device("cuda:0")
     rank, world = comm.rank, comm.world_size
-    M, D, A, GB = 512, 60, 8, 64                       # rows per rank; GLOBAL minibatch of 64 = 32 per rank
-    cfg = {"hidden_sizes": [64, 64], "gamma": 0.99, "target_kl": 1e9, "batch_size": GB, "learning_iters": 1,
+    dims = [int(v) for v in shape.split(",")]
+    D, A, hidden = dims[0], dims[1], dims[2:]          # (a shape outside the persistent kernels' envelope: the wide engine)
+    M, GB = 512, 64                                    # rows per rank; GLOBAL minibatch of 64 = 32 per rank
+    cfg = {"hidden_sizes": hidden, "gamma": 0.99, "target_kl": 1e9, "batch_size": GB, "learning_iters": 1,
            "max_grad_norm": 40.0, "dp_batch": "global"}
     os.environ["SPO_P2P"] = use_p2p
     obs, act, logp, tgt_r, tgt_c, adv, perm = shard(rank, M, D, A)
     torch.manual_seed(7)
-    pol = ActorVCritic(D, A).to(dev)
+    pol = ActorVCritic(D, A, hidden_sizes=hidden).to(dev)
     state0 = {k: v.detach().cpu().clone() for k, v in pol.state_dict().items()}
-    eng = PPOLagEngine(pol, 1, M, cfg, dev, comm=comm)
+    eng = (PPOLagEngine if pol.kernels_supported() else WidePPOLagEngine)(pol, 1, M, cfg, dev, comm=comm)
     assert eng._cfg_struct().batch == GB // world
     b = eng.buffer
     b.data["obs"].copy_(obs.view(1, M, D)); b.data["act"].copy_(act.view(1, M, A))
@@ -55,11 +57,11 @@ def main(out_path: str, use_p2p: str):
     theta = pol.theta.detach().cpu()
     gathered = [torch.empty_like(theta) for _ in range(world)]
     dist.all_gather(gathered, theta)
-    res = {"world": world, "in_kernel_exchange": eng.p2p is not None, "local_batch": GB // world,
+    res = {"world": world, "in_kernel_exchange": eng.p2p is not None, "local_batch": GB // world, "engine": type(eng).__name__,
            "replicas_identical": all(torch.equal(gathered[0], x) for x in gathered[1:])}
     if rank == 0:
         from oracle import restatement as R          # checker only
-        ref = R.OraclePolicy(D, A)
+        ref = R.OraclePolicy(D, A, hidden_sizes=tuple(hidden))
         ref.load_state_dict(state0)
         th0 = R.flat_params(ref).numpy().copy()
         upd = R.PPOLagUpdater(ref, epochs=1, max_grad_norm=cfg["max_grad_norm"])
@@ -86,4 +88,4 @@ def main(out_path: str, use_p2p: str):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "1")
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "1", *(sys.argv[3:4]))

@@ -1879,6 +1879,30 @@ def test_data_parallel_global_batch_equals_reference_minibatches(dev, tmp_path, 
     print("dp_exact", res)
 
 
+@pytest.mark.parametrize("shape", ["100,20,64,64", "60,8,128,128"])
+def test_data_parallel_wide_engine_global_batch_equals_reference_minibatches(dev, tmp_path, shape):
+    """The same exact-semantics check for a policy OUTSIDE the persistent kernels' envelope (act_dim 20; hidden [128, 128]): the
+    wide-network engine all-reduces the flat gradient of the three networks per minibatch step before the joint clip
+    (ppo_lag.py:325), so two ranks x 32 rows reproduce the oracle's 64-row steps on the union of the rows."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    out = tmp_path / "dp_exact_wide.json"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "dp_exact_worker.py"), str(out), "0", shape]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = json.load(open(out))
+    assert res["engine"] == "WidePPOLagEngine" and not res["in_kernel_exchange"] and res["local_batch"] == 32 and res["steps"] == 16, res
+    assert res["replicas_identical"], res
+    assert res["loss_max_rel_diff"] < 1e-4, res
+    assert res["theta_frac_outside"] <= 1e-3 and res["theta_max_abs_diff"] < 1e-5 and res["theta_moved"] > 1e-3, res
+
+
 @pytest.mark.parametrize("B,K,N", [(8192, 48, 128), (8192, 128, 128), (8192, 128, 6), (100, 7, 1), (65, 130, 70), (1, 1, 1)])
 def test_ma_plain_products_run_on_the_mfma_kernel_vs_rocblas_and_torch(dev, B, K, N):
     """f3: every plain product of the multi-agent networks -- collect-size blocks, heads, input gradients,
@@ -2713,10 +2737,13 @@ def test_ma_mappolag_data_parallel_two_ranks_one_gpu(dev, tmp_path):
     assert res["moved"] > 1e-4
 
 
-def test_cpo_data_parallel_two_ranks_one_gpu(dev, tmp_path):
+@pytest.mark.parametrize("shape", ["60,8,64,64", "100,4,64,64", "60,20,96,96"])
+def test_cpo_data_parallel_two_ranks_one_gpu(dev, tmp_path, shape):
     """CPO sharded over envs.  Gradients g and b, every Fisher-vector product and the line-search
     sums are all-reduced means, so two ranks x half the envs reproduce one rank x all envs; the critic fit runs the
-    persistent kernel with the in-kernel exchange and keeps the replicas bit-identical."""
+    persistent kernel with the in-kernel exchange and keeps the replicas bit-identical.  Also for shapes outside the CPO
+    kernels' envelope (WideCPOEngine: obs 100 keeps the persistent critic fit and its in-kernel exchange; act 20 / hidden 96
+    all-reduces the critics' flat gradient per minibatch step)."""
     import json
     import socket
     import subprocess
@@ -2726,11 +2753,12 @@ def test_cpo_data_parallel_two_ranks_one_gpu(dev, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "tests", "cpo_dp_worker.py"), str(out)]
+           "--master-port", str(port), os.path.join(root, "tests", "cpo_dp_worker.py"), str(out), shape]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     res = json.load(open(out))
-    assert res["p2p"] and res["replicas_identical"] and res["finite"], res
+    assert res["engine"] == ("CPOEngine" if shape == "60,8,64,64" else "WideCPOEngine"), res
+    assert res["p2p"] == (shape != "60,20,96,96") and res["replicas_identical"] and res["finite"], res
     assert res["case"][0] == res["case"][1] and res["acceptance_step"][0] == res["acceptance_step"][1], res
     for k in ("xHx", "gradient_norm", "H_inv_g", "alpha", "final_step_norm", "kl"):
         assert res[k][0] == pytest.approx(res[k][1], rel=2e-3), (k, res)
