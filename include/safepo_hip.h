@@ -154,7 +154,7 @@ int spo_boundary_step_fold_mb(const float* reward, const float* cost, const floa
 /* spo_values(theta, final_obs) -> (v_final_r, v_final_c) and spo_boundary_step_fold_mb with those values, in ONE launch (the
  * post-step half of a collect step, ppo_lag.py:198-234): the bootstrap values of truncated envs go from the critics' accumulators
  * to the boundary logic through LDS.  v_final_r / v_final_c are still written.  Same results as the two calls (which it makes
- * itself outside the side-by-side kernel's envelope: obs_dim > 64 or more than 32 768 envs). */
+ * itself outside the side-by-side kernel's envelope: obs_dim > 64 or more than 8 192 envs). */
 int spo_values_boundary_step_fold(const float* theta, const float* final_obs, float* v_final_r, float* v_final_c,
                                   int obs_dim, int act_dim, const float* reward, const float* cost,
                                   const float* terminated, const float* truncated, const float* v_next_r,

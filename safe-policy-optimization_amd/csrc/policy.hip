@@ -993,7 +993,9 @@ extern "C" int spo_values_boundary_step_fold(const float* theta, const float* fi
   SPO_REQUIRE((fold_reward == nullptr) == (fold_cost == nullptr), "values_boundary: both fold outputs or neither");
   SPO_REQUIRE(num_envs > 0 && t >= 0 && t < T, "values_boundary: bad step index");
   hipStream_t st = (hipStream_t)stream;
-  if (!(step_par_enabled() && num_envs <= STEP_PAR_MAX_ROWS && obs_dim <= 64)) {
+  // (every 32-env workgroup counts the finished episodes of the envs in front of it: beyond 8 192 envs the 256-env workgroups
+  //  of spo_boundary_step_fold_mb do an eighth of those loads)
+  if (!(step_par_enabled() && num_envs <= 8192 && obs_dim <= 64)) {
     // outside the side-by-side kernel's envelope: the two launches this entry point stands for
     if (int rc = spo_values(theta, final_obs, v_final_r, v_final_c, num_envs, obs_dim, act_dim, stream)) return rc;
     return spo_boundary_step_fold_mb(reward, cost, terminated, truncated, v_next_r, v_next_c, v_final_r, v_final_c, buf_reward,
