@@ -366,6 +366,7 @@ def main():
     ap.add_argument("--no-config5", action="store_true", help="skip the MAPPO-L (BASELINE config 5 shape) section")
     ap.add_argument("--config5-threads", type=int, default=8192, help="rollout threads of the MAPPO-L section (TOTAL over the ranks)")
     ap.add_argument("--config5-cpu-sample-threads", type=int, default=512, help="rollout threads of the MAPPO-L CPU-baseline sample")
+    ap.add_argument("--no-wide", action="store_true", help="skip the wide-network minibatch-step entry")
     ap.add_argument("--no-normalize-obs", action="store_true", help="rollout without the fused observation normaliser (a-2)")
     ap.add_argument("--cpo-steps", type=int, default=3)
     ap.add_argument("--stream-envs", type=int, default=262144, help="extra GAE roofline point that streams from HBM")
@@ -586,6 +587,20 @@ def main():
                             "clipped_under_conservative_protocol": int(c4[2]), "steps_under_conservative_protocol": int(c4[3]),
                             "note": "all launches of this process (warm-up, timed epochs, early-stopping epoch); a redone step costs "
                                     "one repeated forward of the main waves"}
+    # the fallback path for policies outside the persistent kernels' envelope (any hidden_sizes / dims): us per 64-row
+    # minibatch step of the wide-network engine -- a widened net and HumanoidVelocity's dims (~1 s)
+    wide_entry = None
+    if world == 1 and a.algo == "ppo_lag" and not a.no_wide:
+        try:
+            torch.cuda.empty_cache()
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import wide_bench
+            wide_entry = {"what": "WidePPOLagEngine.minibatch_step at batch 64 (gather, 3 forwards, loss, 3 backwards, joint clip + Adam), "
+                                  "256 steps replayed from one HIP graph; the [64, 64] persistent kernel's step is update_kernel above",
+                          "cases": [dict(wide_bench.one([128, 128], 64, 256), obs_dim=60, act_dim=8),
+                                    dict(wide_bench.one([64, 64], 64, 256, D=376, A=17), obs_dim=376, act_dim=17)]}
+        except Exception as e:  # pragma: no cover
+            wide_entry = {"error": str(e)[:300]}
     line = {
         "metric": "env-steps/sec (collect+GAE+update) at num_envs=4096, 1/2/4/8 GPU",
         "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -627,6 +642,7 @@ def main():
         "cpu_baseline": cpu,
         "config3_cpo": config3,
         "config5_mappolag": config5,
+        "wide_minibatch_step": wide_entry,
         "library": _lib_note(),
         "exchange": res_exchange,
         "per_rank": ([{"rank": r, "ms_per_step": round(e / a.steps * 1e3, 2), "rollout_s_per_epoch": round(ro / a.steps, 4),

@@ -2613,7 +2613,10 @@ __global__ __launch_bounds__(256) void wide_ppo_loss_kernel(const float* __restr
                                                             const float* __restrict__ logp_old, const float* __restrict__ adv,
                                                             const float* __restrict__ tgt_r, const float* __restrict__ tgt_c, int64_t B, int A,
                                                             float clip, float* __restrict__ d_vr, float* __restrict__ d_vc,
-                                                            float* __restrict__ d_mean, double* __restrict__ partial) {
+                                                            float* __restrict__ d_mean, double* __restrict__ partial,
+                                                            float* __restrict__ losses3, float* __restrict__ d_log_std) {
+  // losses3 / d_log_std: given for a one-workgroup launch (minibatch-sized row counts), which finishes the sums itself -- the
+  // same values wide_ppo_loss_finish_kernel forms from one partial row, one launch less
   __shared__ double red[4][WL_NS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float inv_n = 1.f / (float)B, clip_lo = 1.f - clip, clip_hi = 1.f + clip;
@@ -2653,7 +2656,16 @@ __global__ __launch_bounds__(256) void wide_ppo_loss_kernel(const float* __restr
     if (lane == 0) red[wave][k] = v;
   }
   __syncthreads();
-  if (tid < 3 + A) partial[(int64_t)blockIdx.x * WL_NS + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+  if (tid < 3 + A) {
+    const double v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    partial[(int64_t)blockIdx.x * WL_NS + tid] = v;
+    if (losses3) {
+      const double s = 0.0 + v;
+      if (tid < 2) losses3[tid] = (float)(s / (double)B);
+      else if (tid == 2) losses3[2] = (float)(-s / (double)B);
+      else d_log_std[tid - 3] = (float)s;
+    }
+  }
 }
 __global__ void wide_ppo_loss_finish_kernel(const double* __restrict__ partial, int nblocks, int A, int64_t B, float* __restrict__ losses3,
                                             float* __restrict__ d_log_std) {
@@ -3022,9 +3034,11 @@ extern "C" int spo_wide_ppo_loss(const float* v_r, const float* v_c, const float
   if (blocks > 256) blocks = 256;
   SPO_REQUIRE(partial_capacity >= blocks * WL_NS, "wide_ppo_loss: partial workspace too small (%d < %lld)", partial_capacity, (long long)(blocks * WL_NS));
   hipStream_t st = (hipStream_t)stream;
+  const bool one = blocks == 1;
   hipLaunchKernelGGL(wide_ppo_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, st, v_r, v_c, mean, log_std, act, logp_old, adv, tgt_r,
-                     tgt_c, rows, act_dim, clip, d_vr, d_vc, d_mean, partial_ws);
-  hipLaunchKernelGGL(wide_ppo_loss_finish_kernel, dim3(1), dim3(64), 0, st, partial_ws, (int)blocks, act_dim, rows, losses3, d_log_std);
+                     tgt_c, rows, act_dim, clip, d_vr, d_vc, d_mean, partial_ws, one ? losses3 : (float*)nullptr,
+                     one ? d_log_std : (float*)nullptr);
+  if (!one) hipLaunchKernelGGL(wide_ppo_loss_finish_kernel, dim3(1), dim3(64), 0, st, partial_ws, (int)blocks, act_dim, rows, losses3, d_log_std);
   SPO_LAUNCH_CHECK("spo_wide_ppo_loss");
   return 0;
 }
@@ -3185,7 +3199,8 @@ __global__ void wide_actor_loss_finish_kernel(const double* __restrict__ partial
 __global__ __launch_bounds__(256) void wide_critic_loss_kernel(const float* __restrict__ v_r, const float* __restrict__ v_c,
                                                                const float* __restrict__ tgt_r, const float* __restrict__ tgt_c, int64_t B,
                                                                float inv_n, float* __restrict__ d_vr, float* __restrict__ d_vc,
-                                                               double* __restrict__ partial) {
+                                                               double* __restrict__ partial, float* __restrict__ losses) {
+  // losses: given for a one-workgroup launch, which finishes the sums itself (see wide_ppo_loss_kernel)
   __shared__ double red[4][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double a0 = 0.0, a1 = 0.0;
@@ -3197,7 +3212,11 @@ __global__ __launch_bounds__(256) void wide_critic_loss_kernel(const float* __re
   a0 = wave_sum_d(a0); a1 = wave_sum_d(a1);
   if (lane == 0) { red[wave][0] = a0; red[wave][1] = a1; }
   __syncthreads();
-  if (tid < 2) partial[(int64_t)blockIdx.x * 2 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+  if (tid < 2) {
+    const double v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    partial[(int64_t)blockIdx.x * 2 + tid] = v;
+    if (losses) losses[tid] = (float)((0.0 + v) / (double)B);
+  }
 }
 __global__ void wide_critic_loss_finish_kernel(const double* __restrict__ partial, int nblocks, int64_t B, float* __restrict__ losses) {
   const int k = threadIdx.x;
@@ -3352,8 +3371,8 @@ extern "C" int spo_wide_critic_loss(const float* v_r, const float* v_c, const fl
   SPO_REQUIRE((int64_t)partial_capacity >= blocks * 2, "wide_critic_loss: partial workspace too small");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(wide_critic_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, st, v_r, v_c, tgt_r, tgt_c, rows, 1.f / (float)rows, d_vr,
-                     d_vc, partial_ws);
-  hipLaunchKernelGGL(wide_critic_loss_finish_kernel, dim3(1), dim3(64), 0, st, partial_ws, (int)blocks, rows, losses2);
+                     d_vc, partial_ws, blocks == 1 ? losses2 : (float*)nullptr);
+  if (blocks > 1) hipLaunchKernelGGL(wide_critic_loss_finish_kernel, dim3(1), dim3(64), 0, st, partial_ws, (int)blocks, rows, losses2);
   SPO_LAUNCH_CHECK("spo_wide_critic_loss");
   return 0;
 }
