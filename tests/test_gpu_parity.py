@@ -969,6 +969,58 @@ def test_cpo_update_vs_reference_main_trace(dev, golden_dir):
     _assert_params_close(pol.theta.cpu().numpy(), ref_final, 1e-3, 12, rtol=5e-3, atol=5e-5, what="final theta")
 
 
+def test_cpo_trace_epochs_one_by_one_under_the_fp64_yardstick(dev, golden_dir):
+    """The replay above lets the HIP state run free over the epochs and compares at 5e-3 / 2e-2 -- wide enough to hide a
+    0.4 % defect.  Here every epoch of the reference's cpo.main() trace is taken on its own: parameters = the
+    reference's recorded state before the epoch, buffer = its recorded rollout, and the trust-region step is gated by the
+    fp64 yardstick with the reference's OWN recorded float32 numbers as the float32 leg: |HIP - f64| <= 3 |reference - f64| +
+    1e-6 of the value, for x^T H x, alpha, the step norm, the gradient norm, H_inv_g and the actor parameters after the
+    step (float64 = the oracle on the same inputs, cpo.py:350-532); the discrete decisions must coincide."""
+    import copy
+    z = np.load(os.path.join(golden_dir, "cpo_trace.npz"))
+    N, T, epochs = int(z["meta_num_envs"]), int(z["meta_T"]), int(z["meta_epochs"])
+    tkl = float(z["meta_cfg_target_kl"])
+    pol, eng = _cpo_engine(z, "init_sd_", dev, N, T, {"learning_iters": int(z["meta_cfg_learning_iters"]),
+                                                       "batch_size": int(z["e0_batch_size"]), "target_kl": tkl})
+    D, A, M = pol.obs_dim, pol.act_dim, N * T
+    worst = {}
+    for e in range(epochs):
+        sd = {k: torch.from_numpy(z[f"e{e}_sd_before_{k}"].copy()) for k in pol.state_dict()}
+        pol.load_state_dict(sd)
+        _load_epoch_into_engine(z, e, eng, dev)
+        eng.buffer.compute_gae(None)
+        d = eng.buffer.data
+        data64 = {"obs": d["obs"].view(M, D).double().cpu(), "act": d["act"].view(M, A).double().cpu(),
+                  "log_prob": d["log_prob"].view(M).double().cpu(), "adv_r": d["adv_r"].view(M).double().cpu(),
+                  "adv_c": d["adv_c"].view(M).double().cpu()}
+        ref64 = R.OraclePolicy(D, A)
+        ref64.load_state_dict(sd)
+        ref64 = ref64.double()
+        ep_costs = float(z[f"e{e}_get_stats_Metrics_EpCost"]) - float(z["meta_arg_cost_limit"])
+        o64 = R.cpo_policy_update(ref64, data64, ep_costs, target_kl=tkl)
+        out = eng.policy_update(ep_costs)
+        eng.buffer.reset()
+        assert out["case"] == o64["case"] and out["acceptance_step"] == o64["accept"] == int(z[f"e{e}_Misc_AcceptanceStep"])
+        step64 = float((o64["step_frac"] * o64["step_direction"]).norm())
+        for name, hip, ref32, v64 in (("xHx", out["xHx"], float(z[f"e{e}_Misc_xHx"]), float(o64["xHx"])),
+                                      ("alpha", out["alpha"], float(z[f"e{e}_Misc_Alpha"]), float(o64["alpha"])),
+                                      ("gradient_norm", out["gradient_norm"], float(z[f"e{e}_Misc_gradient_norm"]), float(o64["g"].norm())),
+                                      ("H_inv_g", out["H_inv_g"], float(z[f"e{e}_Misc_H_inv_g"]), float(o64["x"].norm())),
+                                      ("final_step_norm", out["final_step_norm"], float(z[f"e{e}_Misc_FinalStepNorm"]), step64)):
+            d_hip, d_ref = abs(hip - v64), abs(ref32 - v64)
+            assert d_hip <= 3.0 * d_ref + 1e-6 * abs(v64), (e, name, hip, ref32, v64)
+            worst[name] = max(worst.get(name, 0.0), d_hip / (abs(v64) + 1e-30))
+        th_hip = eng.theta_actor.double().cpu().numpy()
+        th64 = R.actor_flat_params(ref64.actor).numpy()
+        th32 = np.concatenate([z[f"e{e}_actor_after_{k}"].reshape(-1) for k in pol.actor.state_dict()]).astype(np.float64)
+        d_hip, d_ref = np.abs(th_hip - th64), np.abs(th32 - th64)
+        scale = np.abs(th64).max()
+        assert np.linalg.norm(d_hip) <= 3.0 * np.linalg.norm(d_ref) + 1e-7 * scale * np.sqrt(th64.size), (e, np.linalg.norm(d_hip), np.linalg.norm(d_ref))
+        assert d_hip.max() <= 3.0 * d_ref.max() + 1e-6 * scale, (e, d_hip.max(), d_ref.max())
+        worst["theta"] = max(worst.get("theta", 0.0), float(d_hip.max() / scale))
+    print("cpo trace, per-epoch relative distance to float64:", {k: f"{v:.2e}" for k, v in worst.items()})
+
+
 def test_pcpo_update_vs_reference_main_trace(dev, golden_dir):
     """Replays the reference pcpo.main(): two CG solves, the projection step, line search (incl. an epoch that
     backtracks six times), actor parameters after the step, critic fit with the recorded shuffles."""
