@@ -43,8 +43,8 @@ PEER_EXCHANGE_USED = [False]     # set by run_epochs on rank 0 (N > 1): which fo
 
 
 def profile_path(name: str) -> str:
-    """The newest committed copy of a profile artefact (profiles/r03, else profiles/r02)."""
-    for rnd in ("r03", "r02"):
+    """The newest committed copy of a profile artefact (profiles/r04, else r03, else r02)."""
+    for rnd in ("r04", "r03", "r02"):
         p = os.path.join(ROOT, "profiles", rnd, name)
         if os.path.exists(p):
             return p
@@ -465,10 +465,10 @@ def main():
                 "note": "achieved = algorithmic bytes / MEAN per-dispatch duration over the timed epochs (200 untimed dispatches first: "
                         "power-management transient after a light-load phase, DESIGN.md 3.1): every dispatch carries its own "
                         "start/stop HIP events on the launch stream (hipExtLaunchKernelGGL: the dispatch packet's timestamps). "
-                        "rocprof_* = the committed rocprofv3 --kernel-trace of this same command (profiles/r03/"
+                        "rocprof_* = the committed rocprofv3 --kernel-trace of this same command (profiles/r04/"
                         "gae_dispatch_durations.json, same kernel and grid): the profiler's own per-dispatch average is ~8 % "
                         "higher than the unprofiled event pairs, and under the profiler the event pairs themselves read ~2x "
-                        "(profiles/r03/bench_profiled_line.json), so the two figures cannot come from one run. graph_* = hipGraph of "
+                        "(profiles/r04/bench_profiled_line.json), so the two figures cannot come from one run. graph_* = hipGraph of "
                         f"{GAE_REPS} back-to-back launches between two events (dispatch set-up overlapped). traffic: PMC "
                         "counters cannot be read inside this run -> null; traffic_profiled is the committed rocprofv3 "
                         "--pmc measurement (FETCH_SIZE x2 + WRITE_SIZE, separate passes) with its source"}
