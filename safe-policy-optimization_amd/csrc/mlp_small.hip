@@ -29,23 +29,30 @@ __device__ __forceinline__ int up16(int v) { return (v + 15) & ~15; }
 
 // Cooperative copy of a row-major global matrix block src[r0 + r][c0 + c] (leading dimension ld, `nr` x `nc` valid) into an LDS
 // block dst[r * ldd + c] of RR x CC (CC a multiple of 16), zero outside the valid part.  A wave takes rows r = wave, wave +
-// nwaves, ...; its lanes take columns lane, lane + 64, ... (256 contiguous bytes per load, any alignment); sixteen rows' loads
-// are in flight before the first LDS store.
+// nwaves, ...; its lanes take columns lane, lane + 64, ... (256 contiguous bytes per load, any alignment); the loads of sixteen
+// rows x two column blocks are in flight before the first LDS store.
 __device__ __forceinline__ void stage_block(const float* __restrict__ src, int64_t ld, int nr, int nc, float* dst, int ldd, int RR,
                                             int CC, int wave, int lane, int nwaves) {
-  for (int c = lane; c < CC; c += 64) {
-    const bool cin = c < nc;
+  // two column blocks (lane, lane + 64) x sixteen rows per round trip: up to 32 loads in flight per lane
+  for (int c = lane; c < CC; c += 128) {
+    const int c1 = c + 64;
+    const bool cin0 = c < nc, cin1 = c1 < nc, has1 = c1 < CC;
+    const bool blk1 = (c - lane) + 64 < CC;              // wave-uniform: the second column block exists at all
     for (int r0 = wave; r0 < RR; r0 += 16 * nwaves) {
-      float v[16];
+      float v0[16], v1[16];
 #pragma unroll
-      for (int b = 0; b < 16; ++b) {
-        const int r = r0 + b * nwaves;
-        v[b] = src[(int64_t)imin(r, nr - 1) * ld + imin(c, nc - 1)];
+      for (int b = 0; b < 16; ++b) v0[b] = src[(int64_t)imin(r0 + b * nwaves, nr - 1) * ld + imin(c, nc - 1)];
+      if (blk1) {
+#pragma unroll
+        for (int b = 0; b < 16; ++b) v1[b] = src[(int64_t)imin(r0 + b * nwaves, nr - 1) * ld + imin(c1, nc - 1)];
       }
 #pragma unroll
       for (int b = 0; b < 16; ++b) {
         const int r = r0 + b * nwaves;
-        if (r < RR) dst[r * ldd + c] = (cin && r < nr) ? v[b] : 0.f;
+        if (r < RR) {
+          dst[r * ldd + c] = (cin0 && r < nr) ? v0[b] : 0.f;
+          if (has1) dst[r * ldd + c1] = (cin1 && r < nr) ? v1[b] : 0.f;
+        }
       }
     }
   }

@@ -144,10 +144,8 @@ class WideNets:
 
     # ------------------------------------------------------------------ reference API pieces
     def values(self, obs):
-        v_r, _ = self.forward("r", obs)
-        v_r = v_r.reshape(-1).clone()
-        v_c, _ = self.forward("c", obs)
-        return v_r, v_c.reshape(-1).clone()
+        (v_r, _), (v_c, _) = self.forward_multi("rc", obs)
+        return v_r.reshape(-1).clone(), v_c.reshape(-1).clone()
 
     def actor_mean(self, obs, out=None):
         """mean of policy.actor(obs) for any number of rows (chunked)."""
@@ -161,11 +159,10 @@ class WideNets:
     def step(self, obs, eps):
         """ActorVCritic.step (model.py:149-170): (act, logp, v_r, v_c); eps None = deterministic."""
         n = obs.shape[0]
-        mu, _ = self.forward("a", obs)
+        (v_r, _), (v_c, _), (mu, _) = self.forward_multi("rca", obs)      # (one launch for a handful of envs, csrc/mlp_small.hip)
         act = torch.empty((n, self.A), dtype=torch.float32, device=obs.device)
         logp = torch.empty(n, dtype=torch.float32, device=obs.device)
         ls = self.policy.theta[self.off_ls:self.off_ls + self.A]
         _abi.check(self.lib.spo_gauss_sample(_abi.ptr(mu), _abi.ptr(ls), _abi.ptr(eps), _abi.ptr(act), _abi.ptr(logp), n, self.A,
                                              _abi.stream_ptr()), "spo_gauss_sample")
-        v_r, v_c = self.values(obs)
-        return act, logp, v_r, v_c
+        return act, logp, v_r.reshape(-1).clone(), v_c.reshape(-1).clone()
