@@ -161,7 +161,7 @@ class VectorizedOnPolicyBuffer:
             with torch.cuda.stream(side):
                 _abi.check(launch(), "spo_gae_fused")
                 torch.cuda.synchronize(self._device)
-                with torch.cuda.graph(graph, stream=side):
+                with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
                     for _ in range(reps):
                         launch()
                 graph.replay()

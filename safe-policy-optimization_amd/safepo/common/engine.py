@@ -274,7 +274,9 @@ class PPOLagEngine:
         torch.cuda.synchronize(self.dev)
         g = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(g):
+            # (thread_local: another thread of the process -- the RCCL watchdog of a data-parallel run polling its events -- must
+            #  not invalidate the capture; this thread only launches kernels inside it)
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 cur = obs
                 eps_all = self._epoch_noise()
                 for t in range(self.T):
@@ -640,7 +642,7 @@ class _WideOps:
                 t.copy_(b)
             torch.cuda.synchronize(self.dev)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 body(st["idx"], st["loss"])
             ent = self._step_graphs[key] = (g, st)
         g, st = ent

@@ -604,7 +604,7 @@ class Runner:
                 self._collect_eager(*self._static_in)            # warm-up: workspaces, allocator pools
                 torch.cuda.synchronize(self.dev)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self._static_out = self._collect_eager(*self._static_in)
                 self._graph = g
             except Exception as e:                                   # noqa: BLE001 -- eager launches are always valid
@@ -658,7 +658,7 @@ class Runner:
                     self._inplace_ok = True
                     self._step_pool = torch.cuda.graph_pool_handle()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self._step_pool):
+                with torch.cuda.graph(g, pool=self._step_pool, capture_error_mode="thread_local"):
                     out = self._collect_fused(*ins, slots=slots)
                 ent = graphs[step] = (g, out)
             except Exception as e:                                   # noqa: BLE001 -- the single-graph / eager paths stay valid
