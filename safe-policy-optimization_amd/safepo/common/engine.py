@@ -82,6 +82,7 @@ class PPOLagEngine:
         # running count of logged episodes per step (spo_boundary_step_fold_mb): the kernel of step t reads [t], writes [t + 1]
         self.events_prefix = torch.zeros(T + 1, dtype=torch.int32, device=self.dev)
         self._events_last_t, self._events_drained = -1, 0
+        self._rollout_graphs = {}                 # rollout_epoch: captured epochs by (env, observation tensor, normaliser)
         # optimiser state (flat, same order as policy.theta)
         P = policy.theta.numel()
         self.adam_m, self.adam_v = torch.zeros(P, **f32), torch.zeros(P, **f32)
@@ -232,7 +233,7 @@ class PPOLagEngine:
         if use_graph:
             obs = _abi.require_gpu_tensor(obs, "obs", torch.float32)
             key = (id(env), obs.data_ptr(), id(rms))
-            graphs = self.__dict__.setdefault("_rollout_graphs", {})
+            graphs = self._rollout_graphs
         if not (use_graph and steady and key in graphs):
             # (also the first steady-state epoch runs eagerly: kernels with lazy set-up must have run once before a capture)
             eps_all = self._epoch_noise()
