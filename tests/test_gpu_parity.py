@@ -790,6 +790,30 @@ def test_synth_env_one_launch_step_equals_the_two_kernel_form(dev, D, affine):
     assert float(a[4].sum()) > 0 and float(a[5].sum()) > 0
 
 
+@pytest.mark.parametrize("N,T,D,A", [(4096, 12, 60, 8), (300, 9, 17, 3)])
+def test_side_by_side_collect_kernels_equal_the_sequential_ones(dev, tmp_path, N, T, D, A):
+    """The round-4 collect kernels (policy_step_par_kernel: the three networks side by side, 32 rows per workgroup, batched
+    weight staging; the critics-only form with the boundary logic behind it; the normaliser's count added by the step kernel)
+    against the round-3 ones (SPO_STEP_PAR=0: networks in turn, spo_values + spo_boundary_step_fold_mb): two epochs of the
+    collect loop from the same seeds leave bit-identical buffers, marks, bootstrap values, episode logs, normaliser states and
+    (after the update) parameters.  The selection is read once per process, hence two worker processes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = []
+    for par in ("1", "0"):
+        out = str(tmp_path / f"collect_par{par}.npz")
+        env = dict(os.environ, SPO_STEP_PAR=par, SPO_ROLLOUT_GRAPH="0")
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "collect_worker.py"), out, str(N), str(T), str(D), str(A)],
+                           capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        files.append(np.load(out))
+    x, y = files
+    assert sorted(x.files) == sorted(y.files) and len(x["e0_events"]) > 0
+    for k in x.files:
+        assert np.array_equal(x[k].view(np.uint8), y[k].view(np.uint8)), k
+
+
 def test_ppo_lag_main_entrypoint_synthetic(dev, tmp_path):
     """safepo.single_agent.ppo_lag.main on the device-resident synthetic env: runs, logs the
     reference's columns, writes progress.csv / config.json / torch_save/model0.pt."""
