@@ -509,6 +509,11 @@ int spo_mlp_backward_multi(int count, const float* const* thetas, const spo_mlp_
 #define SPO_GATHER_MAX 8
 int spo_gather_rows(int count, const float* const* srcs, const int* widths, float* const* dsts, const int64_t* idx, int64_t n,
                     void* stream);
+/* The same on the window idx[*cursor_dev .. *cursor_dev + n) of a longer index vector (cursor_dev: device int64, may be NULL =
+ * 0): a launch captured into a HIP graph then walks a permutation, one minibatch per replay, with spo_wide_clip_adam_dev_log
+ * advancing the cursor. */
+int spo_gather_rows_at(int count, const float* const* srcs, const int* widths, float* const* dsts, const int64_t* idx,
+                       const int64_t* cursor_dev, int64_t n, void* stream);
 /* rsample + log-prob of a diagonal Gaussian (model.py:149-170; eps == NULL: deterministic), and the row sum of
  * KL(N(mean_old, exp(log_std_old)) || N(mean_new, exp(log_std_new))).sum(-1) (ppo_lag.py:338-345) added to (accumulate != 0) or
  * stored into *sum_inout -- the full batch is evaluated in row chunks. */
@@ -576,6 +581,14 @@ int spo_wide_clip_adam_dev(float* theta, float* grad, float* adam_m, float* adam
                            int64_t cost_critic_end, int64_t actor_begin, const spo_ppo_cfg* cfg, double* pow4_dev, int64_t adam_begin,
                            int64_t adam_end, int64_t norm_begin, int scale_rest, float* losses3_inout, float* scalars4_out,
                            double* partial_ws, int partial_capacity, void* stream);
+/* spo_wide_clip_adam_dev that also (cursor_dev != NULL) stores the step's three losses log_src_dev[0..2] (after the L2 terms were
+ * added) at loss_log_dev[3 * (*cursor_dev / cursor_step)] and advances *cursor_dev by cursor_step: together with
+ * spo_gather_rows_at a replayed minibatch step takes no host copy in (indices) or out (losses). */
+int spo_wide_clip_adam_dev_log(float* theta, float* grad, float* adam_m, float* adam_v, int64_t n_params, int64_t reward_critic_end,
+                               int64_t cost_critic_end, int64_t actor_begin, const spo_ppo_cfg* cfg, double* pow4_dev, int64_t adam_begin,
+                               int64_t adam_end, int64_t norm_begin, int scale_rest, float* losses3_inout, float* scalars4_out,
+                               double* partial_ws, int partial_capacity, float* loss_log_dev, const float* log_src_dev,
+                               int64_t* cursor_dev, int64_t cursor_step, void* stream);
 int spo_wide_clip_adam_ex(float* theta, float* grad, float* adam_m, float* adam_v, int64_t n_params, int64_t reward_critic_end,
                           int64_t cost_critic_end, int64_t actor_begin, const spo_ppo_cfg* cfg, int64_t adam_step_critics_host,
                           int64_t adam_step_actor_host, int64_t adam_begin, int64_t adam_end, int64_t norm_begin, int scale_rest,

@@ -2708,8 +2708,11 @@ __global__ __launch_bounds__(256) void wide_prep_kernel(WideAdamArgs a) {
 }
 // pow4 (optional): the device-resident optimiser clocks {beta1^t, beta2^t of the critics, of the actor}; the clocks named by
 // adv_critics / adv_actor advance here, between the norm and the Adam pass (spo_wide_clip_adam_dev)
+// loss_log / log_src / cursor (optional, device): the step's three losses log_src[0..2] are stored at loss_log[3 * (*cursor / cursor_step)] and
+// *cursor advances by cursor_step -- the window spo_gather_rows_at reads; a replayed step then needs no host copy in or out
 __global__ __launch_bounds__(64) void wide_coef_kernel(WideAdamArgs a, int nblocks, double* pow4 = nullptr, int adv_critics = 0,
-                                                       int adv_actor = 0) {
+                                                       int adv_actor = 0, float* loss_log = nullptr, const float* log_src = nullptr,
+                                                       int64_t* cursor = nullptr, int64_t cursor_step = 0) {
   // one wave: lane l adds the partials l, l + 64, ... in order, then a fixed butterfly over the lanes
   double gs = 0.0, pr = 0.0, pc = 0.0;
   for (int b = threadIdx.x; b < nblocks; b += 64) { gs += a.partial[b * 3]; pr += a.partial[b * 3 + 1]; pc += a.partial[b * 3 + 2]; }
@@ -2724,6 +2727,14 @@ __global__ __launch_bounds__(64) void wide_coef_kernel(WideAdamArgs a, int nbloc
   a.scal[0] = coef > 1.f ? 1.f : coef;
   a.scal[1] = a.l2 * (float)pr; a.scal[2] = a.l2 * (float)pc; a.scal[3] = norm;
   if (a.losses3) { a.losses3[0] += a.scal[1]; a.losses3[1] += a.scal[2]; }      // logged critic losses include their L2 terms
+  if (cursor) {
+    const int64_t at = cursor[0];
+    if (loss_log && log_src) {
+      float* row = loss_log + 3 * (at / cursor_step);
+      row[0] = log_src[0]; row[1] = log_src[1]; row[2] = log_src[2];
+    }
+    cursor[0] = at + cursor_step;
+  }
 }
 __global__ __launch_bounds__(256) void wide_adam_kernel(WideAdamArgs a) {
   const float coef = a.scal[0];
@@ -2975,6 +2986,7 @@ struct GatherArgs {
   int width[SPO_GATHER_MAX];
   int count;
   const int64_t* idx;
+  const int64_t* cursor;       // optional (device): the window idx[*cursor .. *cursor + n) -- a captured launch then walks a permutation
   int64_t n;
 };
 __global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs a) {
@@ -2982,19 +2994,26 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs a) {
   const int w = a.width[k];
   const float* __restrict__ src = a.src[k];
   float* __restrict__ dst = a.dst[k];
+  const int64_t* __restrict__ idx = a.idx + (a.cursor ? a.cursor[0] : 0);
   const int64_t total = a.n * w;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int64_t r = e / w;
     const int c = (int)(e - r * w);
-    dst[e] = src[a.idx[r] * w + c];
+    dst[e] = src[idx[r] * w + c];
   }
 }
 }  // namespace
+extern "C" int spo_gather_rows_at(int count, const float* const* srcs, const int* widths, float* const* dsts, const int64_t* idx,
+                                  const int64_t* cursor_dev, int64_t n, void* stream);
 extern "C" int spo_gather_rows(int count, const float* const* srcs, const int* widths, float* const* dsts, const int64_t* idx, int64_t n,
                                void* stream) {
+  return spo_gather_rows_at(count, srcs, widths, dsts, idx, nullptr, n, stream);
+}
+extern "C" int spo_gather_rows_at(int count, const float* const* srcs, const int* widths, float* const* dsts, const int64_t* idx,
+                                  const int64_t* cursor_dev, int64_t n, void* stream) {
   SPO_REQUIRE(count >= 1 && count <= SPO_GATHER_MAX && srcs && widths && dsts && idx && n > 0, "gather_rows: bad args");
   GatherArgs a;
-  a.count = count; a.idx = idx; a.n = n;
+  a.count = count; a.idx = idx; a.cursor = cursor_dev; a.n = n;
   int wmax = 1;
   for (int k = 0; k < count; ++k) {
     SPO_REQUIRE(srcs[k] && dsts[k] && widths[k] >= 1, "gather_rows: bad array %d", k);
@@ -3463,10 +3482,25 @@ __global__ __launch_bounds__(256) void wide_adam_dev_kernel(WideAdamExArgs x, co
   }
 }
 }  // namespace
+extern "C" int spo_wide_clip_adam_dev_log(float* theta, float* grad, float* adam_m, float* adam_v, int64_t n_params, int64_t reward_critic_end,
+                                          int64_t cost_critic_end, int64_t actor_begin, const spo_ppo_cfg* cfg, double* pow4_dev,
+                                          int64_t adam_begin, int64_t adam_end, int64_t norm_begin, int scale_rest, float* losses3_inout,
+                                          float* scalars4_out, double* partial_ws, int partial_capacity, float* loss_log_dev,
+                                          const float* log_src_dev, int64_t* cursor_dev, int64_t cursor_step, void* stream);
 extern "C" int spo_wide_clip_adam_dev(float* theta, float* grad, float* adam_m, float* adam_v, int64_t n_params, int64_t reward_critic_end,
                                       int64_t cost_critic_end, int64_t actor_begin, const spo_ppo_cfg* cfg, double* pow4_dev,
                                       int64_t adam_begin, int64_t adam_end, int64_t norm_begin, int scale_rest, float* losses3_inout,
                                       float* scalars4_out, double* partial_ws, int partial_capacity, void* stream) {
+  return spo_wide_clip_adam_dev_log(theta, grad, adam_m, adam_v, n_params, reward_critic_end, cost_critic_end, actor_begin, cfg, pow4_dev,
+                                    adam_begin, adam_end, norm_begin, scale_rest, losses3_inout, scalars4_out, partial_ws, partial_capacity,
+                                    nullptr, nullptr, nullptr, 0, stream);
+}
+extern "C" int spo_wide_clip_adam_dev_log(float* theta, float* grad, float* adam_m, float* adam_v, int64_t n_params, int64_t reward_critic_end,
+                                          int64_t cost_critic_end, int64_t actor_begin, const spo_ppo_cfg* cfg, double* pow4_dev,
+                                          int64_t adam_begin, int64_t adam_end, int64_t norm_begin, int scale_rest, float* losses3_inout,
+                                          float* scalars4_out, double* partial_ws, int partial_capacity, float* loss_log_dev,
+                                          const float* log_src_dev, int64_t* cursor_dev, int64_t cursor_step, void* stream) {
+  SPO_REQUIRE(!cursor_dev || cursor_step > 0, "wide_clip_adam_dev_log: cursor_step must be > 0");
   SPO_REQUIRE(theta && grad && adam_m && adam_v && cfg && pow4_dev && scalars4_out && partial_ws && n_params > 0, "wide_clip_adam_dev: bad args");
   SPO_REQUIRE(0 <= reward_critic_end && reward_critic_end <= cost_critic_end && cost_critic_end <= actor_begin && actor_begin <= n_params,
               "wide_clip_adam_dev: parameter ranges out of order");
@@ -3483,7 +3517,7 @@ extern "C" int spo_wide_clip_adam_dev(float* theta, float* grad, float* adam_m, 
   if (norm_begin == 0) hipLaunchKernelGGL(wide_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(wide_prep_range_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, norm_begin, n_params);
   hipLaunchKernelGGL(wide_coef_kernel, dim3(1), dim3(64), 0, st, a, (int)blocks, pow4_dev, adam_begin < actor_begin ? 1 : 0,
-                     adam_end > actor_begin ? 1 : 0);
+                     adam_end > actor_begin ? 1 : 0, loss_log_dev, log_src_dev, cursor_dev, cursor_step);
   hipLaunchKernelGGL(wide_adam_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, (const double*)pow4_dev);
   SPO_LAUNCH_CHECK("spo_wide_clip_adam_dev");
   return 0;

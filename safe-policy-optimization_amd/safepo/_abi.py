@@ -85,6 +85,7 @@ PROTOTYPES = {
     "spo_mlp_forward_multi": (c_int, [c_int, P, P, P, c_int64, P, P]),
     "spo_mlp_backward_multi": (c_int, [c_int, P, P, P, c_int64, P, P, P, P, P]),
     "spo_gather_rows": (c_int, [c_int, P, P, P, P, c_int64, P]),
+    "spo_gather_rows_at": (c_int, [c_int, P, P, P, P, P, c_int64, P]),
     "spo_values_boundary_step_fold": (c_int, [P] * 4 + [c_int, c_int] + [P] * 16 + [c_int, c_int64, c_int64, c_int64, c_int, P, P,
                                               c_double, P]),
     "spo_ppo_lag_update_iter": (c_int, [P, P, P, c_int64] + [P] * 7 + [c_int64, POINTER(PpoCfg), P, P, P]),
@@ -159,6 +160,8 @@ PROTOTYPES = {
                                       c_int64, c_int64, c_int, P, P, P, c_int, P]),
     "spo_wide_clip_adam_dev": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, POINTER(PpoCfg), P, c_int64, c_int64, c_int64, c_int,
                                        P, P, P, c_int, P]),
+    "spo_wide_clip_adam_dev_log": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, POINTER(PpoCfg), P, c_int64, c_int64, c_int64,
+                                           c_int, P, P, P, c_int, P, P, P, c_int64, P]),
     "spo_param_count": (c_int64, [c_int, c_int]),
     "spo_param_offset": (c_int64, [c_int, c_int, c_int]),
     "spo_synth_env_step": (c_int, [P] * 7 + [c_int64, c_int, c_uint64, c_uint64, c_float, c_float, c_int, P]),

@@ -22,6 +22,7 @@ import torch
 from safepo import _abi
 from safepo.common.buffer import VectorizedOnPolicyBuffer
 from safepo.common.model import ActorVCritic
+from safepo.common.wide import PermWindow
 from safepo.parallel import Comm, dp_reduce_gradient_
 
 
@@ -623,33 +624,48 @@ class _WideOps:
         tc, ta = self.adam_step, self.adam_step + self.adam_step_actor_extra
         self.pow4.copy_(torch.tensor([b1 ** tc, b2 ** tc, b1 ** ta, b2 ** ta], dtype=torch.float64))
 
-    def _graphed(self, key, idx: torch.Tensor, losses_out: torch.Tensor, body) -> None:
-        """Run `body(idx_static, loss_static)` -- the launch sequence of one minibatch step on static buffers, optimiser clocks
-        on the device -- as a replay of a HIP graph captured on first use (the wide path at small batches is launch-bound: ~70
-        launches per step).  `key` carries everything baked into the captured kernel arguments (the cfg struct's bytes: learning
-        rates change per epoch; the loss options; the batch).  First use: one eager run for the lazy per-kernel set-up (its effects
-        on parameters / moments / clocks undone), then the capture."""
+    def _graphed_pass(self, key, perm: torch.Tensor, batch: int, n_full: int, losses: torch.Tensor, body) -> None:
+        """The first `n_full` (whole) minibatches of the permutation `perm` as `n_full` replays of ONE captured HIP graph of
+        `body(window, loss_static)` -- the launch sequence of a minibatch step with the optimiser clocks, the position in the
+        permutation and the loss log on the device (safepo.common.wide.PermWindow, spo_gather_rows_at,
+        spo_wide_clip_adam_dev_log): a replay takes no host copy in or out.  `key` carries everything baked into the captured
+        kernel arguments (the cfg struct's bytes: learning rates change per epoch; the loss options; the batch).  First use: one
+        eager run for the lazy per-kernel set-up (its effects on parameters / moments / clocks / cursor undone), then the
+        capture.  losses[:n_full] receives the steps' losses."""
+        from safepo.common.wide import PermWindow
         ent = self._step_graphs.get(key)
-        if ent is None:
+        if ent is None or ent[1].perm.numel() < perm.numel():
             if len(self._step_graphs) >= 6:
                 self._step_graphs.clear()
-            n = idx.numel()
-            st = {"idx": torch.zeros(n, dtype=torch.int64, device=self.dev),
-                  "loss": torch.full((3,), float("nan"), dtype=torch.float32, device=self.dev)}
-            st["idx"].copy_(idx)
-            snap = [t.clone() for t in (self.policy.theta, self.adam_m, self.adam_v, self.pow4, self.flat_grad)]
-            body(st["idx"], st["loss"])
-            for t, b in zip((self.policy.theta, self.adam_m, self.adam_v, self.pow4, self.flat_grad), snap):
+            win = PermWindow(perm.numel(), batch, self.dev)
+            loss_static = torch.full((3,), float("nan"), dtype=torch.float32, device=self.dev)
+            win.load(perm)
+            state = (self.policy.theta, self.adam_m, self.adam_v, self.pow4, self.flat_grad, win.cursor)
+            snap = [t.clone() for t in state]
+            body(win, loss_static)
+            for t, b in zip(state, snap):
                 t.copy_(b)
             torch.cuda.synchronize(self.dev)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                body(st["idx"], st["loss"])
-            ent = self._step_graphs[key] = (g, st)
-        g, st = ent
-        st["idx"].copy_(idx)
-        g.replay()
-        losses_out.copy_(st["loss"])
+                body(win, loss_static)
+            ent = self._step_graphs[key] = (g, win)
+        g, win = ent
+        win.load(perm)
+        for _ in range(n_full):
+            g.replay()
+        losses[:n_full].copy_(win.loss_log[:n_full])
+
+    def _clip_adam_dev(self, cfg, lo, hi, norm0, scale_rest, losses_out, log_src, window) -> None:
+        """spo_wide_clip_adam_dev(_log): the joint clip + Adam with device-resident optimiser clocks; `window` (a PermWindow: the
+        step is being captured / replayed) adds the loss log and the cursor advance."""
+        w, part = self.wide, self.loss_partials
+        _abi.check(self.lib.spo_wide_clip_adam_dev_log(
+            _abi.ptr(self.policy.theta), _abi.ptr(self.flat_grad), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), w.P, w.off_c, w.off_ls,
+            w.off_ls, cfg, _abi.ptr(self.pow4), lo, hi, norm0, scale_rest, None if losses_out is None else _abi.ptr(losses_out),
+            _abi.ptr(self.scal4), _abi.ptr(part), part.numel(), None if window is None else _abi.ptr(window.loss_log),
+            None if window is None else _abi.ptr(log_src), None if window is None else _abi.ptr(window.cursor),
+            0 if window is None else window.n, _abi.stream_ptr()), "spo_wide_clip_adam_dev_log")
 
     def _values_into(self, obs, out_r, out_c) -> None:
         v_r, v_c = self.wide.values(obs)
@@ -743,10 +759,7 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
         w.backward_multi("rca", obs, [ws_r, ws_c, ws_a], [d_vr, d_vc, d_mu], g)
         self._reduce_flat_grad()
         if dev_clock:
-            _abi.check(lib.spo_wide_clip_adam_dev(_abi.ptr(self.policy.theta), _abi.ptr(g), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), w.P,
-                                                  w.off_c, w.off_ls, w.off_ls, cfg, _abi.ptr(self.pow4), 0, w.P, 0, 0, _abi.ptr(losses_out),
-                                                  _abi.ptr(self.scal4), _abi.ptr(self.loss_partials), self.loss_partials.numel(), st()),
-                       "spo_wide_clip_adam_dev")
+            self._clip_adam_dev(cfg, 0, w.P, 0, 0, losses_out, losses_out, idx if isinstance(idx, PermWindow) else None)
             return
         _abi.check(lib.spo_wide_clip_adam(_abi.ptr(self.policy.theta), _abi.ptr(g), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), w.P,
                                           w.off_c, w.off_ls, w.off_ls, cfg, self.adam_step, _abi.ptr(losses_out), _abi.ptr(self.scal4),
@@ -760,18 +773,14 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
         n_mb = (M + cfg.batch - 1) // cfg.batch
         losses = torch.empty((n_mb, 3), dtype=torch.float32, device=self.dev)
         graphed = 0 < cfg.batch <= self.graph_max_batch and n_mb > 2
+        n_full = M // cfg.batch if graphed else 0
         if graphed:
             self._sync_pow4()
-            key = ("ppo", bytes(cfg))
-        for k in range(n_mb):
-            idx = perm[k * cfg.batch:(k + 1) * cfg.batch]
-            if graphed and idx.numel() == cfg.batch:
-                self._graphed(key, idx, losses[k], lambda i_, l_: self.minibatch_step(i_, l_, dev_clock=True, cfg=cfg))
-                self.adam_step += 1
-            else:                                   # (the ragged last minibatch: its own shapes, host clocks)
-                self.minibatch_step(idx, losses[k], cfg=cfg)
-                if graphed:
-                    self._sync_pow4()
+            self._graphed_pass(("ppo", bytes(cfg)), perm, cfg.batch, n_full, losses,
+                               lambda i_, l_: self.minibatch_step(i_, l_, dev_clock=True, cfg=cfg))
+            self.adam_step += n_full
+        for k in range(n_full, n_mb):               # (eager: everything without graphs; else the ragged last minibatch, host clocks)
+            self.minibatch_step(perm[k * cfg.batch:(k + 1) * cfg.batch], losses[k], cfg=cfg)
         return self._mean_over_ranks_(losses)
 
     def minibatch_step_ex(self, idx, adv_all, losses_out, actor_loss, kl_bound, pg_coef, actor_only, dev_clock: bool = False,
@@ -812,10 +821,8 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
         step_c, step_a = self.adam_step, self.adam_step + self.adam_step_actor_extra
         lo, norm0 = (off_ls, off_ls) if actor_only else (0, 0)
         if dev_clock:
-            _abi.check(lib.spo_wide_clip_adam_dev(_abi.ptr(self.policy.theta), _abi.ptr(g), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), w.P,
-                                                  w.off_c, w.off_ls, w.off_ls, cfg, _abi.ptr(self.pow4), lo, w.P, norm0, 0,
-                                                  None if actor_only else _abi.ptr(losses_out), _abi.ptr(self.scal4), _abi.ptr(part), cap,
-                                                  st()), "spo_wide_clip_adam_dev")
+            self._clip_adam_dev(cfg, lo, w.P, norm0, 0, None if actor_only else losses_out, losses_out,
+                                idx if isinstance(idx, PermWindow) else None)
             return
         _abi.check(lib.spo_wide_clip_adam_ex(_abi.ptr(self.policy.theta), _abi.ptr(g), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), w.P,
                                              w.off_c, w.off_ls, w.off_ls, cfg, step_c, step_a, lo, w.P, norm0, 0,
@@ -831,20 +838,22 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
         n_mb = (M + cfg.batch - 1) // cfg.batch
         losses = torch.full((n_mb, 3), float("nan"), dtype=torch.float32, device=self.dev)
         graphed = 0 < cfg.batch <= self.graph_max_batch and n_mb > 2
+        n_full = M // cfg.batch if graphed else 0
         if graphed:
             self._sync_pow4()
             key = ("ex", bytes(cfg), int(actor_loss), float(kl_bound), float(pg_coef), bool(actor_only), adv.data_ptr())
-        for k in range(n_mb):
-            idx = perm[k * cfg.batch:(k + 1) * cfg.batch]
-            if graphed and idx.numel() == cfg.batch:
-                self._graphed(key, idx, losses[k], lambda i_, l_: self.minibatch_step_ex(i_, adv, l_, actor_loss, kl_bound, pg_coef,
-                                                                                         actor_only, dev_clock=True, cfg=cfg))
+            self._graphed_pass(key, perm, cfg.batch, n_full, losses,
+                               lambda i_, l_: self.minibatch_step_ex(i_, adv, l_, actor_loss, kl_bound, pg_coef, actor_only,
+                                                                     dev_clock=True, cfg=cfg))
+            if actor_only:
+                self.adam_step_actor_extra += n_full
             else:
-                self.minibatch_step_ex(idx, adv, losses[k], actor_loss, kl_bound, pg_coef, actor_only, cfg=cfg)
+                self.adam_step += n_full
+        for k in range(n_full, n_mb):
+            self.minibatch_step_ex(perm[k * cfg.batch:(k + 1) * cfg.batch], adv, losses[k], actor_loss, kl_bound, pg_coef, actor_only,
+                                   cfg=cfg)
             if actor_only:
                 self.adam_step_actor_extra += 1
             else:
                 self.adam_step += 1
-            if graphed and idx.numel() != cfg.batch:
-                self._sync_pow4()
         return self._mean_over_ranks_(losses)

@@ -18,6 +18,25 @@ from safepo import _abi
 KL_CHUNK = 65536        # rows per full-batch actor evaluation (activations of [1024, 1024, 512]: 0.7 GB per chunk)
 
 
+class PermWindow:
+    """The rows perm[cursor : cursor + n] of a device-resident permutation, cursor (int64[1]) on the device too: what a
+    minibatch step replayed from a HIP graph gathers -- spo_gather_rows_at reads the window, spo_wide_clip_adam_dev_log stores
+    the step's losses at loss_log[cursor / n] and moves the cursor on."""
+
+    def __init__(self, capacity: int, n: int, device):
+        self.perm = torch.zeros(capacity, dtype=torch.int64, device=device)
+        self.cursor = torch.zeros(1, dtype=torch.int64, device=device)
+        self.loss_log = torch.full(((capacity + n - 1) // n, 3), float("nan"), dtype=torch.float32, device=device)
+        self.n = int(n)
+
+    def numel(self) -> int:
+        return self.n
+
+    def load(self, perm: torch.Tensor) -> None:
+        self.perm[:perm.numel()].copy_(perm)
+        self.cursor.zero_()
+
+
 class WideNets:
     """The three networks of an ActorVCritic as views of its flat parameter vector, with cached workspaces."""
 
@@ -123,14 +142,18 @@ class WideNets:
             vp(*[_abi.ptr(self._bwd_scratch(w, rows)) for w in whichs]), _abi.stream_ptr()), "spo_mlp_backward_multi")
 
     def gather_rows(self, idx, srcs):
-        """[src[idx] for src in srcs] (row-major float32 arrays, int64 device indices) in one launch (spo_gather_rows)."""
+        """[src[idx] for src in srcs] (row-major float32 arrays, int64 device indices) in one launch (spo_gather_rows).  `idx` may
+        be a PermWindow: the rows perm[cursor : cursor + n] with the cursor on the device (a replayed minibatch step)."""
         import ctypes
+        win = idx if isinstance(idx, PermWindow) else None
         n, k = idx.numel(), len(srcs)
+        dev = self.policy.theta.device
         srcs = [s_.view(s_.shape[0], -1) for s_ in srcs]
-        dsts = [torch.empty((n, s_.shape[1]), dtype=torch.float32, device=idx.device) for s_ in srcs]
+        dsts = [torch.empty((n, s_.shape[1]), dtype=torch.float32, device=dev) for s_ in srcs]
         vp = ctypes.c_void_p * k
-        _abi.check(self.lib.spo_gather_rows(k, vp(*[_abi.ptr(s_) for s_ in srcs]), (ctypes.c_int * k)(*[s_.shape[1] for s_ in srcs]),
-                                            vp(*[_abi.ptr(d) for d in dsts]), _abi.ptr(idx), n, _abi.stream_ptr()), "spo_gather_rows")
+        _abi.check(self.lib.spo_gather_rows_at(k, vp(*[_abi.ptr(s_) for s_ in srcs]), (ctypes.c_int * k)(*[s_.shape[1] for s_ in srcs]),
+                                               vp(*[_abi.ptr(d) for d in dsts]), _abi.ptr(win.perm if win else idx),
+                                               _abi.ptr(win.cursor) if win else None, n, _abi.stream_ptr()), "spo_gather_rows_at")
         return dsts
 
     def jvp_scratch(self, rows):

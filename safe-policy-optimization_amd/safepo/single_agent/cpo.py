@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from safepo import _abi
+from safepo.common.wide import PermWindow
 from safepo.common.engine import PPOLagEngine, _WideOps
 from safepo.common.env import make_sa_mujoco_env
 from safepo.common.logger import EpochLogger
@@ -650,10 +651,7 @@ class WideCPOEngine(_WideOps, CPOEngine):
             w.backward_multi("rc", obs, [ws_r, ws_c], [d_vr, d_vc], g)
             self._reduce_flat_grad(0, w.off_ls)       # data-parallel: the critics' gradient of the global minibatch
             if dev_clock:
-                _abi.check(lib.spo_wide_clip_adam_dev(_abi.ptr(self.policy.theta), _abi.ptr(g), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v),
-                                                      w.P, w.off_c, w.off_ls, w.off_ls, cfg, _abi.ptr(self.pow4), 0, w.off_ls, 0, 1,
-                                                      _abi.ptr(loss3), _abi.ptr(self.scal4), _abi.ptr(part), cap, _abi.stream_ptr()),
-                           "spo_wide_clip_adam_dev")
+                self._clip_adam_dev(cfg, 0, w.off_ls, 0, 1, loss3, loss3, idx if isinstance(idx, PermWindow) else None)
             else:
                 _abi.check(lib.spo_wide_clip_adam_ex(_abi.ptr(self.policy.theta), _abi.ptr(g), _abi.ptr(self.adam_m),
                                                      _abi.ptr(self.adam_v), w.P, w.off_c, w.off_ls, w.off_ls, cfg, self.adam_step,
@@ -664,17 +662,14 @@ class WideCPOEngine(_WideOps, CPOEngine):
         for it in range(c["learning_iters"]):
             perm = _abi.require_gpu_tensor(perm_fn(it), "perm", torch.int32).long()
             losses = torch.empty((n_mb, 3), dtype=torch.float32, device=self.dev)
+            n_full = self.M // cfg.batch if graphed else 0
             if graphed:
                 self._sync_pow4()
-            for k in range(n_mb):
-                idx = perm[k * cfg.batch:(k + 1) * cfg.batch]
-                if graphed and idx.numel() == cfg.batch:
-                    self._graphed(key, idx, losses[k], lambda i_, l_: step(i_, l_, True))
-                else:
-                    step(idx, losses[k], False)
+                self._graphed_pass(key, perm, cfg.batch, n_full, losses, lambda i_, l_: step(i_, l_, True))
+                self.adam_step += n_full
+            for k in range(n_full, n_mb):
+                step(perm[k * cfg.batch:(k + 1) * cfg.batch], losses[k], False)
                 self.adam_step += 1
-                if graphed and idx.numel() != cfg.batch:
-                    self._sync_pow4()
             all_losses.append(self._mean_over_ranks_(losses)[:, :2])
         # keep the norm the persistent kernel would carry in step with the rescaled vector
         self.stale_sq.copy_(g[self.ls_off:].dot(g[self.ls_off:]).reshape(1))
