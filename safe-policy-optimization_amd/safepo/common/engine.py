@@ -649,8 +649,8 @@ class _WideOps:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 body(win, loss_static)
-            ent = self._step_graphs[key] = (g, win)
-        g, win = ent
+            ent = self._step_graphs[key] = (g, win, loss_static)      # (everything the captured kernels address stays alive with it)
+        g, win, _ = ent
         win.load(perm)
         for _ in range(n_full):
             g.replay()
