@@ -649,7 +649,10 @@ class _WideOps:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 body(win, loss_static)
-            ent = self._step_graphs[key] = (g, win, loss_static)      # (everything the captured kernels address stays alive with it)
+            # everything the captured kernels address stays alive with the graph: the static loss buffer, and the workspaces the
+            # warm-up run created outside the capture (the caches of safepo.common.wide evict when they grow)
+            keep = [loss_static] + list(self.wide._ws.values()) + list(self.wide._scratch.values())
+            ent = self._step_graphs[key] = (g, win, keep)
         g, win, _ = ent
         win.load(perm)
         for _ in range(n_full):
