@@ -284,6 +284,9 @@ class PPOLagEngine:
                 for t in range(self.T):
                     cur = self._rollout_step(t, env, cur, rms, eps_all[t])
             post = {"fold_cols": b._fold_cols, "pending": None if rms is None else rms.pending, "obs": cur}
+            wide = getattr(self, "wide", None)
+            if wide is not None:                       # workspaces created by the eager epoch and addressed by the captured kernels
+                post["keep"] = list(wide._ws.values()) + list(wide._scratch.values())
         finally:
             b.ptr, b.ptr_list, b._fold_cols = saved[0], saved[1], saved[2]
             if rms is not None:
