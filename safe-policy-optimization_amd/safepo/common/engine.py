@@ -837,6 +837,9 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
 
     def learning_iter_ex(self, perm: torch.Tensor, adv: torch.Tensor, actor_loss: int = 0,
                          kl_bound: float = float("inf"), pg_coef: float = 0.0, actor_only: bool = False) -> torch.Tensor:
+        if self.comm.world_size != 1:            # (as PPOLagEngine.learning_iter_ex: the indicator fraction of the KL-penalty loss
+            raise NotImplementedError("focops / cup run on one GPU in this build (no data-parallel form of the "   # couples the
+                                      "KL-penalty minibatch step)")                                             # global minibatch)
         cfg = self._cfg_struct()
         perm = _abi.require_gpu_tensor(perm, "perm", torch.int32).long()
         adv = _abi.require_gpu_tensor(adv, "adv", torch.float32)

@@ -531,7 +531,8 @@ class WideCPOEngine(_WideOps, CPOEngine):
       line search sums     spo_mlp_forward -> spo_wide_linesearch_sums                                  (cpo.py:473-491)
     The critic fit keeps the persistent two-critic kernel whenever the CRITICS fit it (hidden [64, 64], obs_dim <= 128: their
     layout does not depend on act_dim), else runs minibatch by minibatch on the wide kernels with the actor's stale gradient
-    kept in the flat gradient vector so the joint clip sees and rescales it (cpo.py:557).  Single GPU."""
+    kept in the flat gradient vector so the joint clip sees and rescales it (cpo.py:557).  Data-parallel like CPOEngine: the
+    full-batch quantities are all-reduced means, the wide critic fit all-reduces the critics' flat gradient per minibatch step."""
 
     FAMILY = "cpo"          # what _WideOps._require_policy checks the policy against
     CHUNK = 65536           # rows per full-batch pass; raised in __init__ for narrow networks (activations stay under ~0.5 GB)
