@@ -666,6 +666,103 @@ def cpo_policy_update(policy: OraclePolicy, data: dict, ep_costs: float, target_
     return out
 
 
+def trust_region_policy_update(policy: OraclePolicy, data: dict, advantage: torch.Tensor, target_kl: float = 0.01,
+                               line_search: bool = False, cg_iters: int = 15, search_steps: int = 15, decay: float = 0.8):
+    """The unconstrained trust-region step of the f4 siblings (actor part):
+    natural_pg.py:350-381 (line_search=False: theta_old + alpha * x, KL of the new policy logged) -- rcpo.py:320-326 runs the
+    same on the Lagrangian mix of the advantages -- and trpo.py:366-428 (line_search=True: backtracking over TRPO_SEARCHING_STEPS
+    = 15 candidates, accepted when the surrogate does not get worse and KL <= target_kl) -- trpo_lag.py:320-327 on the mix.
+    `advantage`: data["adv_r"] or the mixed advantage, in the dtype of the policy."""
+    obs = data["obs"]
+    theta_old = actor_flat_params(policy.actor).clone()
+    policy.actor.zero_grad()
+    dist = policy.actor(obs)
+    logp = dist.log_prob(data["act"]).sum(dim=-1)
+    ratio = torch.exp(logp - data["log_prob"])
+    loss_pi = -(ratio * advantage).mean()
+    loss_before = loss_pi.item()
+    with torch.no_grad():
+        od = policy.actor(obs)
+        old = torch.distributions.Normal(od.mean.clone(), od.stddev.clone())
+    loss_pi.backward()
+    g = -actor_flat_grads(policy.actor)
+    fv = lambda v: cpo_fvp(v, policy, obs)
+    x = cpo_cg(fv, g, cg_iters)
+    xHx = torch.dot(x, fv(x))
+    alpha = torch.sqrt(2 * target_kl / (xHx + 1e-8))
+    step_direction = x * alpha
+    accept, step_frac, loss_actor, final_kl = None, 1.0, loss_before, 0.0
+    if not line_search:
+        actor_set_flat_params(policy.actor, theta_old + step_direction)
+        with torch.no_grad():
+            final_kl = torch.distributions.kl.kl_divergence(old, policy.actor(obs)).mean().item()
+    else:
+        accept = 0
+        for step in range(search_steps):
+            actor_set_flat_params(policy.actor, theta_old + step_frac * step_direction)
+            with torch.no_grad():
+                lp = policy.actor(obs).log_prob(data["act"]).sum(dim=-1)
+                loss_new = -(torch.exp(lp - data["log_prob"]) * advantage).mean()
+                kl = torch.distributions.kl.kl_divergence(old, policy.actor(obs)).mean().item()
+            loss_actor = loss_new.item()
+            improve = loss_before - loss_new.item()
+            if not torch.isfinite(loss_new):
+                pass
+            elif improve < 0:
+                pass
+            elif kl > target_kl:
+                pass
+            else:
+                accept = step + 1
+                final_kl = kl
+                break
+            step_frac *= decay
+        else:
+            step_direction = torch.zeros_like(step_direction)
+            accept = 0
+        actor_set_flat_params(policy.actor, theta_old + step_frac * step_direction)
+    return {"g": g, "x": x, "xHx": xHx, "alpha": alpha, "step_direction": step_direction, "step_frac": step_frac,
+            "accept": accept, "kl": final_kl, "loss_before": loss_before, "loss_actor": loss_actor}
+
+
+def pcpo_policy_update(policy: OraclePolicy, data: dict, ep_costs: float, target_kl: float = 0.01, cg_iters: int = 15,
+                       search_steps: int = 200, decay: float = 0.8):
+    """pcpo.py:352-470 (actor part): the reward step sqrt(2 delta / (q + 1e-8)) * (H x) -- the reference names fvp(x)
+    "H_inv_g" (pcpo.py:370) -- projected onto the cost constraint, - max(0, (sqrt(2 delta / q) r + c) / s) p, then CPO's
+    acceptance rules with optim_case = 0 over PCPO_SEARCHING_STEPS = 200 candidates (pcpo.py:44,407-458).  `ep_costs` = Jc -
+    cost_limit."""
+    obs = data["obs"]
+    theta_old = actor_flat_params(policy.actor).clone()
+    policy.actor.zero_grad()
+    loss_pi_r = cpo_surrogate(policy, data, "r")
+    loss_r_before = loss_pi_r.item()
+    with torch.no_grad():
+        od = policy.actor(obs)
+        old_mean, old_std = od.mean.clone(), od.stddev.clone()
+    loss_pi_r.backward()
+    g = -actor_flat_grads(policy.actor)
+    fv = lambda v: cpo_fvp(v, policy, obs)
+    x = cpo_cg(fv, g, cg_iters)
+    Hx = fv(x)
+    xHx = torch.dot(x, Hx)
+    alpha = torch.sqrt(2 * target_kl / (xHx + 1e-8))
+    policy.actor.zero_grad()
+    loss_pi_c = cpo_surrogate(policy, data, "c")
+    loss_c_before = loss_pi_c.item()
+    loss_pi_c.backward()
+    b = actor_flat_grads(policy.actor).clone()
+    p = cpo_cg(fv, b, cg_iters)
+    q, r, s_ = xHx, g.dot(p), b.dot(p)
+    step = (torch.sqrt(2 * target_kl / (q + 1e-8)) * Hx
+            - torch.clamp_min((torch.sqrt(2 * target_kl / q) * r + ep_costs) / s_, torch.zeros((), dtype=q.dtype)) * p)
+    ls = cpo_line_search(policy, data, old_mean, old_std, theta_old, step, g, loss_r_before, loss_c_before, ep_costs, 0,
+                         target_kl, max_steps=search_steps, decay=decay)
+    out = {"g": g, "b": b, "x": x, "p": p, "Hx": Hx, "xHx": xHx, "alpha": alpha, "case": 0, "step": step,
+           "loss_r_before": loss_r_before, "loss_c_before": loss_c_before}
+    out.update(ls)
+    return out
+
+
 class CriticFitter:
     """cpo.py:534-571: two critics, Adam lr 1e-3, MSE + 0.001*L2, clip_grad_norm_ over ALL
     policy parameters (the actor's .grad still holds the stale cost gradient b and is

@@ -31,6 +31,7 @@ from safepo.utils.config import isaac_gym_map, single_agent_args
 
 STEP_FRACTION = 0.8
 CPO_SEARCHING_STEPS = 15
+PCPO_SEARCHING_STEPS = 200          # reference pcpo.py:44 (its line search keeps halving far longer than CPO's, cpo.py:44)
 CONJUGATE_GRADIENT_ITERS = 15
 
 default_cfg = {
@@ -300,14 +301,14 @@ class CPOEngine(PPOLagEngine):
                 "kl": final_kl, "g": grads, "x": x}
 
     def _constrained_line_search(self, theta_old, step_direction, grads, optim_case, ep_costs, loss_reward_before,
-                                 loss_cost_before, logger=None):
-        """Backtracking search shared by CPO (cpo.py:465-519) and PCPO (pcpo.py:404-458)."""
+                                 loss_cost_before, logger=None, max_steps: int = CPO_SEARCHING_STEPS):
+        """Backtracking search shared by CPO (cpo.py:465-519, 15 candidates) and PCPO (pcpo.py:404-458, 200 candidates)."""
         target_kl = self.cfg["target_kl"]
         step_frac = 1.0
         expected_reward_improve = grads.dot(step_direction)
         kl = 0.0
         acceptance_step = 0
-        for step in range(CPO_SEARCHING_STEPS):
+        for step in range(max_steps):
             self.theta_actor.copy_(theta_old + step_frac * step_direction)
             acceptance_step = step + 1
             loss_reward, loss_cost, kl = self.linesearch_eval()
@@ -367,7 +368,8 @@ class CPOEngine(PPOLagEngine):
                           - torch.clamp_min((torch.sqrt(2 * target_kl / q) * r + ep_costs) / s_,
                                             torch.tensor(0.0, device=self.dev)) * p)
         step_frac, step_direction, acceptance_step, kl = self._constrained_line_search(
-            theta_old, step_direction, grads, 0, ep_costs, loss_reward_before, loss_cost_before, logger)
+            theta_old, step_direction, grads, 0, ep_costs, loss_reward_before, loss_cost_before, logger,
+            max_steps=PCPO_SEARCHING_STEPS)
         self.theta_actor.copy_(theta_old + step_frac * step_direction)
         self._set_stale_actor_grad(b_grads)
         return {"alpha": float(alpha), "final_step_norm": float(torch.norm(step_direction)), "xHx": float(xHx),

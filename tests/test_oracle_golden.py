@@ -408,6 +408,58 @@ def test_lagrangian_trust_region_traces_multiplier_and_mix(golden_dir, algo):
     assert len(set(round(l, 6) for l in lams)) == len(lams) and all(l > 0 for l in lams)
 
 
+@pytest.mark.parametrize("algo,line_search", [("natural_pg", False), ("trpo", True), ("rcpo", False), ("trpo_lag", True)])
+def test_trust_region_restatement_vs_reference_main_trace(golden_dir, algo, line_search):
+    """R.trust_region_policy_update (natural_pg.py:350-381, trpo.py:366-428; rcpo / trpo_lag on the mixed advantage) against
+    the reference mains' own traces, every epoch from the reference's recorded state: curvature, step length, norms, the KL
+    and the loss it logs, the accepted line-search candidate and the actor after the step."""
+    z = _load(golden_dir, f"{algo}_trace.npz")
+    tkl = float(z["meta_cfg_target_kl"])
+    for e in range(int(z["meta_epochs"])):
+        pol = _policy_from(z, f"e{e}_sd_before_")
+        data, _ = _trace_epoch_inputs(z, e)
+        adv = data["adv_r"]
+        if algo in ("rcpo", "trpo_lag"):
+            adv = R.adv_mix(data["adv_r"], data["adv_c"], float(z[f"e{e}_row_Train_LagragianMultiplier"]))
+        out = R.trust_region_policy_update(pol, data, adv, target_kl=tkl, line_search=line_search)
+        assert float(out["xHx"]) == pytest.approx(float(z[f"e{e}_Misc_xHx"]), rel=1e-3)
+        assert float(out["alpha"]) == pytest.approx(float(z[f"e{e}_Misc_Alpha"]), rel=1e-3)
+        assert float(out["x"].norm()) == pytest.approx(float(z[f"e{e}_Misc_H_inv_g"]), rel=1e-3)
+        assert float(out["g"].norm()) == pytest.approx(float(z[f"e{e}_Misc_gradient_norm"]), rel=1e-4)
+        assert float(out["step_direction"].norm()) == pytest.approx(float(z[f"e{e}_Misc_FinalStepNorm"]), rel=1e-3)
+        assert out["kl"] == pytest.approx(float(z[f"e{e}_Train_KL"]), rel=2e-3)
+        assert out["loss_actor"] == pytest.approx(float(z[f"e{e}_Loss_Loss_actor"]), rel=1e-4, abs=1e-7)
+        if line_search:
+            assert out["accept"] == int(z[f"e{e}_Misc_AcceptanceStep"])
+        for k, v in pol.actor.state_dict().items():
+            np.testing.assert_allclose(v.numpy(), z[f"e{e}_actor_after_{k}"], rtol=1e-3, atol=2e-6, err_msg=f"epoch {e} {k}")
+
+
+def test_pcpo_restatement_vs_reference_main_trace(golden_dir):
+    """R.pcpo_policy_update (pcpo.py:352-470) against the reference's pcpo.main() trace, every epoch from the recorded state
+    (incl. the epoch whose line search backtracks six times)."""
+    z = _load(golden_dir, "pcpo_trace.npz")
+    tkl = float(z["meta_cfg_target_kl"])
+    steps = []
+    for e in range(int(z["meta_epochs"])):
+        pol = _policy_from(z, f"e{e}_sd_before_")
+        data, _ = _trace_epoch_inputs(z, e)
+        ep_costs = float(z[f"e{e}_get_stats_Metrics_EpCost"]) - float(z["meta_arg_cost_limit"])
+        out = R.pcpo_policy_update(pol, data, ep_costs, target_kl=tkl)
+        steps.append(out["accept"])
+        assert out["accept"] == int(z[f"e{e}_Misc_AcceptanceStep"])
+        assert float(out["xHx"]) == pytest.approx(float(z[f"e{e}_Misc_xHx"]), rel=1e-3)
+        assert float(out["alpha"]) == pytest.approx(float(z[f"e{e}_Misc_Alpha"]), rel=1e-3)
+        assert float(out["x"].norm()) == pytest.approx(float(z[f"e{e}_Misc_H_inv_g"]), rel=1e-3)
+        assert float(out["g"].norm()) == pytest.approx(float(z[f"e{e}_Misc_gradient_norm"]), rel=1e-4)
+        assert float(out["step_direction"].norm()) == pytest.approx(float(z[f"e{e}_Misc_FinalStepNorm"]), rel=1e-3)
+        assert out["kl"] == pytest.approx(float(z[f"e{e}_Train_KL"]), rel=2e-3)
+        assert out["loss_r_before"] + out["loss_c_before"] == pytest.approx(float(z[f"e{e}_Loss_Loss_actor"]), rel=1e-4, abs=1e-7)
+        for k, v in pol.actor.state_dict().items():
+            np.testing.assert_allclose(v.numpy(), z[f"e{e}_actor_after_{k}"], rtol=1e-3, atol=2e-6, err_msg=f"epoch {e} {k}")
+    assert max(steps) > 1
+
+
 def test_running_mean_std_restatement_vs_independent_two_pass():
     """a-2 (parity unpinned by the reference: gymnasium is not vendored / installed).  The restated RunningMeanStd -- the
     incremental parallel-variance merge, mean 0 / var 1 / count 1e-4 prior -- is pinned here against an
