@@ -207,9 +207,9 @@ int spo_debug_update_counters(unsigned long long* out4_host, int reset);
 /* Debug self-test of the cross-lane helpers (DPP row sums, gfx950 permlane swaps): in[64] -> out[192]. */
 int spo_debug_crosslane_selftest(const float* in64, float* out192, void* stream);
 
-/* Debug aid (not a reference function): pass a device buffer of 40 u64 to make the next
+/* Debug aid (not a reference function): pass a device buffer of 30 u64 to make the next
  * spo_ppo_lag_update_iter launches accumulate shader cycles per phase of the step; NULL disables. */
-int spo_debug_set_update_profile(void* dev_u64_40);
+int spo_debug_set_update_profile(void* dev_u64_30);
 
 /* Split form of the same step for data-parallel training: gradient of ONE
  * minibatch into flat_grad[P] (+ losses[3]); the caller all-reduces flat_grad and then

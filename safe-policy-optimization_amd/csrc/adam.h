@@ -18,42 +18,6 @@ __device__ __forceinline__ AdamOut adam1(float p, float g, float m, float v, flo
   o.p = fmaf(-step_size, o.m * __builtin_amdgcn_rcpf(denom), p);
   return o;
 }
-// The same update over N independent elements, written stage by stage (all first moments, all second moments, all square roots,
-// all denominators, all reciprocals, all parameters) with scheduling barriers between the stages: element for element the
-// arithmetic of adam1 (bit-identical), but the quarter-rate transcendentals of one element no longer sit in front of the next
-// element's -- the compiler otherwise serialises the elements through one temporary register to save registers, and a wave
-// that is alone on its SIMD then pays every sqrt -> fma -> rcp -> mul -> fma chain in full (round 5: the helper waves of
-// ppo_update_h_kernel, whose layer-1 / layer-2 updates gate two barriers of the step).
-template <int N>
-__device__ __forceinline__ void adam_batch(float (&p)[N], const float (&g)[N], float (&m)[N], float (&v)[N], float b1, float b2,
-                                           float eps, float step_size, float inv_bc2_sqrt) {
-  float t[N];
-#pragma unroll
-  for (int i = 0; i < N; ++i) m[i] = fmaf(1.f - b1, g[i] - m[i], m[i]);
-#pragma unroll
-  for (int i = 0; i < N; ++i) v[i] = fmaf(v[i], b2, ((1.f - b2) * g[i]) * g[i]);
-#if defined(__HIP_DEVICE_COMPILE__)
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-  for (int i = 0; i < N; ++i) t[i] = __builtin_amdgcn_sqrtf(v[i]);
-#if defined(__HIP_DEVICE_COMPILE__)
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-  for (int i = 0; i < N; ++i) t[i] = fmaf(t[i], inv_bc2_sqrt, eps);
-#if defined(__HIP_DEVICE_COMPILE__)
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-  for (int i = 0; i < N; ++i) t[i] = __builtin_amdgcn_rcpf(t[i]);
-#if defined(__HIP_DEVICE_COMPILE__)
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-  for (int i = 0; i < N; ++i) p[i] = fmaf(-step_size, m[i] * t[i], p[i]);
-}
-
 // The two per-step scalars of Adam's bias correction: step_size = lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t).  The powers are
 // carried in double (one v_mul_f64 each per step); rounds 1-2 also formed the quotient and the square root in double -- ~40
 // double-precision VALU instructions per helper wave and step (IEEE division and sqrt sequences at half / quarter rate),

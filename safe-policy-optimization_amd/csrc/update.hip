@@ -32,9 +32,6 @@ using namespace spo;
 #ifndef SPO_XR_SCOPE
 #define SPO_XR_SCOPE __HIP_MEMORY_SCOPE_SYSTEM     // scope of the tagged-word exchange accesses (A/B knob: ranks on ONE GPU)
 #endif
-#ifndef SPO_H_RD_VB
-#define SPO_H_RD_VB 4          // rows polled together by the helper waves' recursive doubling (register budget: A/B knob)
-#endif
 #ifndef SPO_HELPER_PRIO
 #define SPO_HELPER_PRIO 2      // s_setprio of the helper waves of ppo_update_h_kernel (A/B knob)
 #endif
@@ -1398,10 +1395,9 @@ struct UpdHLds {
   using U = UpdLds<KIN>;
   static_assert(!U::SPLIT, "main + helper form: obs_dim <= 64");
   static constexpr int NT1 = KIN / 16;
-  static constexpr int G1 = U::SIZE;                        // [4 waves][NT1 tiles][64 lanes] float4 (exchange forms); [4][4][64] float4 =
-                                                            // the W2 tiles where the helper waves compute dW1 themselves (HDW1, round 5)
+  static constexpr int G1 = U::SIZE;                        // [4 waves][NT1 tiles][64 lanes] float4
   static constexpr int G2 = U::DZ1T;                        // [4][4][64] float4 inside the dZ1^T image (16 384 <= 17 408 B)
-  static constexpr int G3 = G1 + 4 * (NT1 > 4 ? NT1 : 4) * 64 * 4;   // [4][64] float4: W3 tile
+  static constexpr int G3 = G1 + 4 * NT1 * 64 * 4;          // [4][64] float4: W3 tile
   static constexpr int GB = G3 + 4 * 64 * 4;                // [3][256] floats: db1, db2, db3 as the main lanes hold them
   static constexpr int XW = GB + 3 * 256;                   // 32 floats of helper-to-helper / helper-to-main words
   static constexpr int COLS = XW + 32 + 2 * XR_MAX_WORLD;   // (+ the ranks' exchange-region pointers, 8-byte aligned: XW is even)
@@ -1536,11 +1532,11 @@ __device__ __forceinline__ void a2a_pull_all(const UpdArgs& a, const unsigned lo
   }
 }
 
-// XR: world size of the in-kernel data-parallel exchange (0 = none); XRD: its form on the helper waves (true = recursive
-// doubling with tagged words, false = flag-based all-to-all) -- separate instantiations: both bodies together spill
-// XRD: 1 = recursive doubling with 8-byte tagged words (rounds 2-4), 0 = flag-based all-to-all, 2 = recursive doubling with
-// PACKED 16-byte words, one poll batch per stage (round 5: xr_rd16_flat)
-template <int KIN, bool PROF = false, int XR = 0, int XRD = 1>
+// XR: world size of the in-kernel data-parallel exchange (0 = none); separate instantiations per form: both exchange bodies
+// together spill.
+// XRD: form of the exchange on the helper waves -- 0 = flag-based all-to-all, 2 = recursive doubling with PACKED 16-byte words,
+// one poll batch per stage (round 5: xr_rd16_flat; the 8-byte-word form of rounds 2-4 spilled 250 registers and is gone)
+template <int KIN, bool PROF = false, int XR = 0, int XRD = 2>
 __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg) {
   // PROF: wave 0 of each role of the LAST workgroup accumulates shader cycles per interval (a.prof rows 0 = main, 1 = helper)
   unsigned long long pacc[NPHASE] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1564,24 +1560,6 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
   using H = UpdHLds<KIN>;
   using L = NetLds<KIN>;
   constexpr int NT1 = KIN / 16;
-#ifndef SPO_H_DW1
-#define SPO_H_DW1 0           // 1: the helper waves compute dW1 themselves while the main waves compute dW2 (round 5 A/B: 11.69 against
-                              //    10.63 us per step -- the helpers' MFMAs go first at their priority and the main waves' dW2 queues behind
-                              //    them, and the layer-1 update behind P1 is no shorter for it); 0: the main waves, G1 tiles through LDS
-#endif
-#ifndef SPO_H_ADAM_BATCH
-#define SPO_H_ADAM_BATCH 1    // 1: layers 1 / 2 of the helpers' speculative update stage by stage over all of a lane's elements
-                              //    (adam_batch: LDS reads up front, transcendentals of different elements back to back); 0: element by element
-#endif
-  constexpr bool HDW1 = SPO_H_DW1 && (XR == 0);          // (the exchange forms keep the round-4 hand-over through LDS)
-#ifndef SPO_H_XSLOT
-#define SPO_H_XSLOT 1         // 1 (round 5): the helpers hand the next minibatch's observation tiles to the main lanes through the lane's
-                              //    own G1 slots (a float4 per tile, written where the helper has just read the gradient tile) and write the
-                              //    x^T image -- needed only by the NEXT dW1 -- in the output-layer section, off the P1 -> P3 stretch they gate;
-                              //    0: x^T image written between P1 and P3, the main lanes read their 16 values back from it (round 4)
-#endif
-  constexpr bool HXS = SPO_H_XSLOT && SPO_H_GATHER && (XR == 0) && !HDW1;
-  constexpr int G2OFF = HDW1 ? H::G1 : H::G2;
   const int tid = threadIdx.x, lane = tid & 63, j_ = lane & 15, q_ = lane >> 4;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool helper = wave8 >= 4;
@@ -1670,10 +1648,10 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
   // Row r of helper wave w: 64 consecutive float4 (a wave's store covers 1 KB), rows 1 KB apart -- four rows sit inside the 4 KB
   // immediate-offset window of one address.  (Rounds 2-4 had the rows 24 KB apart: every row its own 64-bit address, which the
   // compiler hoisted out of the step loop -- ~50 registers of loop-invariant addresses in the helper role, part of them spilled
-  // and reloaded from scratch in front of the very stores they address.)
+  // and reloaded from scratch in front of the very stores they address: 38 -> 10 spilled registers, step time unchanged.)
   f4* const bk = reinterpret_cast<f4*>(a.backup) + ((size_t)(wg * 4 + wave) * UPD_BACKUP_ROWS * 64 + lane);
   constexpr size_t BKS = 64;
-  constexpr int BK_W1 = 0, BK_W2 = 3 * NT1, BK_G1 = BK_W2 + 12, BK_END = BK_G1 + NT1 + 1;   // BK_G1: dW1 tiles + db1 (HDW1)
+  constexpr int BK_W1 = 0, BK_W2 = 3 * NT1, BK_END = BK_W2 + 12;
   static_assert(BK_END <= UPD_BACKUP_ROWS, "backup rows");
 
   // One layer of the helper's work: L2 term + norms, backups, speculative Adam.  G = LDS gradient tiles written by main lane
@@ -1754,10 +1732,6 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
 #pragma unroll
       for (int r = 0; r < 4; ++r) cols[(2 + 4 * q + r) * 64 + mycol] = nxt.actv[r];
     }
-    if constexpr (HXS) {
-#pragma unroll
-      for (int nt = 0; nt < NT1; ++nt) *reinterpret_cast<f4*>(lds + H::G1 + ((wave * NT1 + nt) * 64 + lane) * 4) = nxt.x[nt];
-    }
   }
   if (PROF) tprev = __builtin_readcyclecounter();
 
@@ -1774,16 +1748,10 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
       // the helpers put this step's x^T image in place before the barrier the previous step ended with: 16 LDS reads instead
       // of the settle (pad selects, index widening, 16 x^T stores: 1.3 k cycles of a lone wave)
       SPO_REIDX
-      if constexpr (HXS) {
-        // the lane's own tiles, as the helper lane of the same number loaded them: 4 ds_read_b128 from the lane's G1 slots
-#pragma unroll
-        for (int nt = 0; nt < NT1; ++nt) cur.x[nt] = *reinterpret_cast<const f4*>(lds + H::G1 + ((wave * NT1 + nt) * 64 + lane) * 4);
-      } else {
 #pragma unroll
       for (int nt = 0; nt < NT1; ++nt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) cur.x[nt][e] = lds[U::XT + (16 * nt + 4 * q + e) * LDB + mycol];
-      }
     } else {
       SPO_REIDX
       cur = nxt;
@@ -1831,17 +1799,10 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
         if (!SPO_H_GATHER) {
           if (s + 1 < nsteps) fetch((int64_t)smp_next, nxt);
           if (s + 2 < nsteps) smp1 = a.perm[pos2];
-        } else if (!late_redone) {              // (a repeated step keeps the column inputs it read the first time)
+        } else {
           cur.t0 = cols[mycol]; cur.t1 = cols[64 + mycol];
 #pragma unroll
           for (int r = 0; r < 4; ++r) cur.actv[r] = is_actor ? cols[(2 + 4 * q + r) * 64 + mycol] : 0.f;
-          if constexpr (HXS) {
-            // "picked up": the helper wave of the same number may now replace them (LDS operations of a wave execute in order)
-#if defined(__HIP_DEVICE_COMPILE__)
-            asm volatile("" ::: "memory");
-#endif
-            if (lane == 0) reinterpret_cast<int*>(lds + H::XW)[24 + wave] = (int)(s & 0x3fffffff) + 1;
-          }
         }
         const f4 o = layer_out(lds + L::W3, lds + L::B3, h2, j, q);
         SPO_SUB(0)
@@ -1981,20 +1942,15 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
       if (xw_ro[20] == (int)(s & 0x3fffffff) + 1 && !late_redone) {
         late_redone = true;
         SPO_REIDX
-        if constexpr (HXS) {                                // (the slots hold this step's tiles until this wave's own dW1 writes G1)
-#pragma unroll
-          for (int nt = 0; nt < NT1; ++nt) cur.x[nt] = *reinterpret_cast<const f4*>(lds + H::G1 + ((wave * NT1 + nt) * 64 + lane) * 4);
-        } else {
 #pragma unroll
         for (int nt = 0; nt < NT1; ++nt)
 #pragma unroll
           for (int e = 0; e < 4; ++e) cur.x[nt][e] = lds[U::XT + (16 * nt + 4 * q + e) * LDB + mycol];
-        }
         continue;
       }
       break;
     }
-    auto main_dW1 = [&]() {
+    {
       // ---- dW1 (rows 16 wave .., all NT1 column tiles) -> G1, db1 -> GB[0]
       SPO_REIDX
       f4 az1[4], aW1[NT1];
@@ -2025,9 +1981,12 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
 #pragma unroll
       for (int nt = 0; nt < NT1; ++nt) *reinterpret_cast<f4*>(lds + H::G1 + ((wave * NT1 + nt) * 64 + lane) * 4) = aW1[nt];
       lds[H::GB + 0 * 256 + wave * 64 + lane] = quad_row_sum(rs1);
-    };
-    auto main_dW2 = [&]() {
-      // ---- dW2 -> G2 (HDW1: the G1 region; else inside the dead dZ1^T image), db2 -> GB[1]
+    }
+    SPO_STAMP(7)
+    __syncthreads();                                                      // P1: G1 complete; x^T and dZ1^T are dead
+    SPO_STAMP(8)
+    {
+      // ---- dW2 -> G2 (inside the dead dZ1^T image), db2 -> GB[1]
       SPO_REIDX
       f4 az2[4], aW2[4];
 #pragma unroll
@@ -2055,10 +2014,11 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) rs2 += (az2[r4][0] + az2[r4][1]) + (az2[r4][2] + az2[r4][3]);
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f4*>(lds + G2OFF + ((wave * 4 + nt) * 64 + lane) * 4) = aW2[nt];
+      for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f4*>(lds + H::G2 + ((wave * 4 + nt) * 64 + lane) * 4) = aW2[nt];
       lds[H::GB + 1 * 256 + wave * 64 + lane] = quad_row_sum(rs2);
-    };
-    auto main_dW3 = [&]() {
+    }
+    __builtin_amdgcn_sched_barrier(0);        // keep dW3's operand reads out of dW2's register budget
+    {
       // ---- dW3 -> G3, db3 -> GB[2]
       SPO_REIDX
       f4 az3[4], b3[4];
@@ -2080,23 +2040,6 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
       for (int r4 = 0; r4 < 4; ++r4) rs3 += (az3[r4][0] + az3[r4][1]) + (az3[r4][2] + az3[r4][3]);
       *reinterpret_cast<f4*>(lds + H::G3 + (wave * 64 + lane) * 4) = w3a + w3b;
       lds[H::GB + 2 * 256 + wave * 64 + lane] = quad_row_sum(rs3);
-    };
-    if constexpr (HDW1) {
-      // round 5: the HELPER waves compute dW1 (into their own accumulators, straight into Adam) while the main waves compute
-      // dW2 -- the B_stage -> P1 stretch, where the helpers used to idle, carries two instruction streams per SIMD
-      main_dW2();
-      SPO_STAMP(7)
-      __syncthreads();                                                    // P1: helpers done with x^T / dZ1^T; G2 complete
-      SPO_STAMP(8)
-      main_dW3();
-    } else {
-      main_dW1();
-      SPO_STAMP(7)
-      __syncthreads();                                                    // P1: G1 complete; x^T and dZ1^T are dead
-      SPO_STAMP(8)
-      main_dW2();
-      __builtin_amdgcn_sched_barrier(0);        // keep dW3's operand reads out of dW2's register budget
-      main_dW3();
     }
     SPO_STAMP(9)
     __syncthreads();                                                      // P3: G2, G3 complete (helpers: W1 / b1 updated)
@@ -2141,25 +2084,19 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
       }
     }
   };
-  auto h_publish_xT = [&]() {                 // the x^T image of the next step (B operand of ITS dW1) from the settled tiles
+  auto h_publish = [&]() {                    // settle (pad selects) + x^T image + column inputs of the next step
     const int qq = pinned(q_), col_ = 16 * wave + pinned(j_);
     float* const xt = lds + U::XT + 4 * qq * LDB + col_;          // ONE address register: the rest are immediate offsets
-#pragma unroll
-    for (int nt = 0; nt < NT1; ++nt)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) xt[(16 * nt + e) * LDB] = hx.x[nt][e];
-  };
-  auto h_settle_x = [&]() {                   // pad selects of the gathered observation tiles
-    const int qq = pinned(q_);
+    float* const cols = lds + H::COLS + col_;
 #pragma unroll
     for (int nt = 0; nt < NT1; ++nt)
 #pragma unroll
       for (int e = 0; e < 4; ++e) hx.x[nt][e] = pinned(hx.x[nt][e]);
     mask_obs_tiles<KIN>(D, qq, hx.x);
-  };
-  auto h_publish_cols = [&]() {               // column inputs (target / logp_old, advantage, action) of the gathered minibatch
-    const int qq = pinned(q_), col_ = 16 * wave + pinned(j_);
-    float* const cols = lds + H::COLS + col_;
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xt[(16 * nt + e) * LDB] = hx.x[nt][e];
     if (qq == 0) { cols[0] = pinned(hx.t0); cols[64] = pinned(hx.t1); }
     if (is_actor) {
       float* const ca = cols + (2 + 4 * qq) * 64;
@@ -2170,11 +2107,6 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
       }
     }
   };
-  // HXS: the column inputs and the index of the minibatch after it are handled EARLY, in the helpers' idle window behind the
-  // verdict of the step before (the gathered data has landed by then: the verdict's polling loads were issued behind it) --
-  // carried to P1 the two scalars were spilled, and their two dependent scratch reloads cost 2.3 k cycles at the head of the
-  // P1 -> P3 stretch the helpers gate.  Main wave w raises xw[24 + w] = tag of its step once it has read its column inputs.
-  bool early_cols = false;
   if (SPO_H_GATHER && nsteps > 1) h_fetch((int64_t)a.perm[h_perm_pos(1)]);
   // step 0 has nothing to wait for: its forward runs on the weights staged at launch
   __syncthreads();                                                        // Q2 of step 0
@@ -2193,56 +2125,13 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
     bool h_fetched = false;
     // register backups of layer 1 only: it is the one layer updated before the joint norm is known
     float bmb1, bvb1, bpb1;
-    f4 aW1h[NT1];
-    float gb1h = 0.f;
-    if constexpr (HDW1) {
-      // ---- dW1 on the helper waves (round 5): rows 16 wave .. of dZ1^T x^T, the instruction sequence the main waves ran in
-      //      rounds 1-4 (bit-identical tiles), accumulated where the optimiser state lives -- no G1 tiles through LDS, and the
-      //      main waves compute dW2 meanwhile
-      SPO_REIDX
-      f4 az1[4];
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4)
-        az1[r4] = *reinterpret_cast<const f4*>(lds + U::DZ1T + (16 * wave + j) * LDB + 16 * r4 + 4 * q);
-#pragma unroll
-      for (int nt = 0; nt < NT1; ++nt) aW1h[nt] = f4{0.f, 0.f, 0.f, 0.f};
-      f4 bx[2][NT1];
-#pragma unroll
-      for (int nt = 0; nt < NT1; ++nt)
-        bx[0][nt] = *reinterpret_cast<const f4*>(lds + U::XT + (16 * nt + j) * LDB + 4 * q);
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        if (r4 + 1 < 4) {
-#pragma unroll
-          for (int nt = 0; nt < NT1; ++nt)
-            bx[(r4 + 1) & 1][nt] = *reinterpret_cast<const f4*>(lds + U::XT + (16 * nt + j) * LDB + 16 * (r4 + 1) + 4 * q);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int nt = 0; nt < NT1; ++nt) aW1h[nt] = mfma4(az1[r4][e], bx[r4 & 1][nt][e], aW1h[nt]);
-      }
-      float rs1 = 0.f;
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) rs1 += (az1[r4][0] + az1[r4][1]) + (az1[r4][2] + az1[r4][3]);
-      gb1h = quad_row_sum(rs1);
-      SPO_STAMP(7)
-    }
-    __syncthreads();                                                      // P1: G1 complete (HDW1: every wave is done with x^T / dZ1^T)
+    __syncthreads();                                                      // P1: G1 complete
     SPO_STAMP(0)
-    SPO_SUB(-1)
     if (SPO_H_GATHER) {
       // dW1 has read the old x^T image: hand the next minibatch over (the main waves pick it up after P3), then start the
       // index load of the one after it
-      if (s + 1 < nsteps) {
-        h_settle_x();
-        if constexpr (!HXS) h_publish_xT();
-        SPO_SUB(7)                                         // (profile: wait for the gathered rows + pad selects)
-        if (!early_cols) h_publish_cols();
-      }
-      SPO_SUB(8)                                           // (profile: column inputs)
-      if (!early_cols && s + 2 < nsteps) hsmp = a.perm[h_perm_pos(s + 2)];
-      early_cols = false;
+      if (s + 1 < nsteps) h_publish();
+      if (s + 2 < nsteps) hsmp = a.perm[h_perm_pos(s + 2)];
     }
     {
       // ---- layer 1 (W1, b1): L2 term, norm share, SPECULATIVE Adam (clip coefficient 1)
@@ -2271,10 +2160,6 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
 #pragma unroll
             for (int r = 0; r < 4; ++r) gx[nt][r] = gf[4 * nt + r];
           gx[NT1][0] = gf[4 * NT1];
-        } else if constexpr (XRD == 1) {
-          // recursive doubling with {tag, value} words (one flight per round, no acknowledgement wait), slot rows 0 .. NT1
-          xr_allreduce_rd<NT1 + 1, 0, SPO_H_RD_VB>(xtab, a.xr_rank, XR, net, hl, gtag, gx,
-                                      reinterpret_cast<volatile float*>(lds + H::XW + 21), a.err);
         } else {
 #pragma unroll
         for (int v = 0; v <= NT1; ++v) a2a_push_row<XR>(a, xtab, net, hl, par, v < NT1 ? v : NT1 + 5, gx[v]);
@@ -2291,76 +2176,12 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
         for (int nt = 0; nt < NT1; ++nt) *reinterpret_cast<f4*>(lds + H::G1 + ((wave * NT1 + nt) * 64 + lane) * 4) = gx[nt];
         lds[H::GB + 0 * 256 + hl] = gx[NT1][0];
       }
-      SPO_SUB(0)                                           // (helper row 3 of a.prof: publish / exchange)
       pw1 *= (double)b1c; pw2 *= (double)b2c;
       adam_scalars(lr, pw1, pw2, step_size, inv_bc2s);
       gsq = psq = 0.f;
-      SPO_SUB(1)                                           // scalars
-      if constexpr (SPO_H_ADAM_BATCH) {
-        // every parameter and gradient of the lane first (one LDS round trip), then the L2 terms / norm shares in the element
-        // order of the loop below (bit-identical sums), the backups, and the update stage by stage
-        constexpr int NE = 4 * NT1 + 1;
-        float pe[NE], ge[NE], me[NE], ve[NE];
-#pragma unroll
-        for (int nt = 0; nt < NT1; ++nt) {
-          f4 gv;
-          if constexpr (HDW1) { gv = aW1h[nt]; bk[BKS * (BK_G1 + nt)] = gv; }
-          else gv = *reinterpret_cast<const f4*>(lds + H::G1 + ((wave * NT1 + nt) * 64 + lane) * 4);
-          if constexpr (HXS) {
-            // the slot just read now carries the next step's observation tile to main lane (wave, lane); the exact redo reads
-            // the gradient back from its backup row
-            bk[BKS * (BK_G1 + nt)] = gv;
-            if (s + 1 < nsteps) *reinterpret_cast<f4*>(lds + H::G1 + ((wave * NT1 + nt) * 64 + lane) * 4) = hx.x[nt];
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            pe[4 * nt + r] = lds[L::W1 + (orow + r) * L::LD1 + 16 * nt + j];
-            ge[4 * nt + r] = gv[r]; me[4 * nt + r] = mW1[nt][r]; ve[4 * nt + r] = vW1[nt][r];
-          }
-        }
-        pe[NE - 1] = lds[L::B1 + 16 * wave + j];
-        if constexpr (HDW1) { ge[NE - 1] = gb1h; bk[BKS * (BK_G1 + NT1)] = f4{gb1h, 0.f, 0.f, 0.f}; }
-        else ge[NE - 1] = lds[H::GB + 0 * 256 + wave * 64 + lane];
-        me[NE - 1] = mb1; ve[NE - 1] = vb1;
-        bmb1 = mb1; bvb1 = vb1; bpb1 = pe[NE - 1];
-        if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-        SPO_SUB(2)                                         // LDS reads
-#pragma unroll
-        for (int nt = 0; nt < NT1; ++nt) {
-          bk[BKS * (BK_W1 + 3 * nt + 0)] = mW1[nt];
-          bk[BKS * (BK_W1 + 3 * nt + 1)] = vW1[nt];
-          bk[BKS * (BK_W1 + 3 * nt + 2)] = f4{pe[4 * nt], pe[4 * nt + 1], pe[4 * nt + 2], pe[4 * nt + 3]};
-        }
-        SPO_SUB(3)                                         // backup stores issued
-#pragma unroll
-        for (int i = 0; i < NE; ++i) {
-          const float gg_ = vcoef * fmaf(l2x2, pe[i], ge[i]);
-          ge[i] = gg_;
-          if (i < NE - 1 || own_b) { gsq = fmaf(gg_, gg_, gsq); psq = fmaf(pe[i], pe[i], psq); }   // bias: replicated over q, q == 0 counts
-        }
-        SPO_SUB(4)                                         // L2 terms, norm shares
-        adam_batch<NE>(pe, ge, me, ve, b1c, b2c, eps, step_size, inv_bc2s);
-        SPO_SUB(5)                                         // Adam
-#pragma unroll
-        for (int nt = 0; nt < NT1; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {                                     // pad columns hold p == 0, g == 0: stay 0
-            lds[L::W1 + (orow + r) * L::LD1 + 16 * nt + j] = pe[4 * nt + r];
-            mW1[nt][r] = me[4 * nt + r]; vW1[nt][r] = ve[4 * nt + r];
-          }
-        lds[L::B1 + 16 * wave + j] = pe[NE - 1];
-        mb1 = me[NE - 1]; vb1 = ve[NE - 1];
-        SPO_SUB(6)                                         // LDS writes
-      } else {
 #pragma unroll
       for (int nt = 0; nt < NT1; ++nt) {
-        f4 gv;
-        if constexpr (HDW1) { gv = aW1h[nt]; bk[BKS * (BK_G1 + nt)] = gv; }       // (the exact redo reads the gradient back)
-        else gv = *reinterpret_cast<const f4*>(lds + H::G1 + ((wave * NT1 + nt) * 64 + lane) * 4);
-        if constexpr (HXS) {
-          bk[BKS * (BK_G1 + nt)] = gv;
-          if (s + 1 < nsteps) *reinterpret_cast<f4*>(lds + H::G1 + ((wave * NT1 + nt) * 64 + lane) * 4) = hx.x[nt];
-        }
+        const f4 gv = *reinterpret_cast<const f4*>(lds + H::G1 + ((wave * NT1 + nt) * 64 + lane) * 4);
         bk[BKS * (BK_W1 + 3 * nt + 0)] = mW1[nt];
         bk[BKS * (BK_W1 + 3 * nt + 1)] = vW1[nt];
         f4 pv;
@@ -2371,14 +2192,11 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
       }
       {
         // bias row 16 wave + j: replicated over q (all replicas compute and store identical values; q == 0 counts)
-        float gb;
-        if constexpr (HDW1) { gb = gb1h; bk[BKS * (BK_G1 + NT1)] = f4{gb, 0.f, 0.f, 0.f}; }
-        else gb = lds[H::GB + 0 * 256 + wave * 64 + lane];
+        const float gb = lds[H::GB + 0 * 256 + wave * 64 + lane];
         const float gsq0 = gsq, psq0 = psq;
         bmb1 = mb1; bvb1 = vb1;
         SPO_H_ELEM(L::B1 + 16 * wave + j, gb, mb1, vb1, bpb1)
         if (!own_b) { gsq = gsq0; psq = psq0; }
-      }
       }
     }
     SPO_STAMP(1)
@@ -2397,7 +2215,7 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
       const bool with_ls = is_actor && wave == 0;                        // wave-uniform
       f4 gx[7];
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) gx[nt] = *reinterpret_cast<const f4*>(lds + G2OFF + ((wave * 4 + nt) * 64 + lane) * 4);
+      for (int nt = 0; nt < 4; ++nt) gx[nt] = *reinterpret_cast<const f4*>(lds + H::G2 + ((wave * 4 + nt) * 64 + lane) * 4);
       gx[4] = *reinterpret_cast<const f4*>(lds + H::G3 + (wave * 64 + lane) * 4);
       gx[5] = f4{lds[H::GB + 1 * 256 + hl], lds[H::GB + 2 * 256 + hl], 0.f, 0.f};
       gx[6] = f4{0.f, 0.f, 0.f, 0.f};
@@ -2429,10 +2247,6 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
         gx[5][0] = gf[20]; gx[5][1] = gf[21];
 #pragma unroll
         for (int r = 0; r < 4; ++r) gx[6][r] = gf[22 + r];
-      } else if constexpr (XRD == 1) {
-        // slot rows NT1 + 1 .. NT1 + 7 (the log_std row travels from every wave: zeros except wave 0 of the actor)
-        xr_allreduce_rd<7, NT1 + 1, SPO_H_RD_VB>(xtab, a.xr_rank, XR, net, hl, gtag, gx,
-                                    reinterpret_cast<volatile float*>(lds + H::XW + 21), a.err);
       } else {
 #pragma unroll
       for (int v = 0; v < 6; ++v) a2a_push_row<XR>(a, xtab, net, hl, par, rows7[v], gx[v]);
@@ -2456,7 +2270,7 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
       }
       }
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f4*>(lds + G2OFF + ((wave * 4 + nt) * 64 + lane) * 4) = gx[nt];
+      for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f4*>(lds + H::G2 + ((wave * 4 + nt) * 64 + lane) * 4) = gx[nt];
       *reinterpret_cast<f4*>(lds + H::G3 + (wave * 64 + lane) * 4) = gx[4];
       lds[H::GB + 1 * 256 + hl] = gx[5][0];
       lds[H::GB + 2 * 256 + hl] = gx[5][1];
@@ -2475,9 +2289,7 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int nt = 0; nt < NT1; ++nt) {
-        f4 gv;
-        if constexpr (HDW1 || HXS) gv = bk[BKS * (BK_G1 + nt)];
-        else gv = *reinterpret_cast<const f4*>(lds + H::G1 + ((wave * NT1 + nt) * 64 + lane) * 4);
+        const f4 gv = *reinterpret_cast<const f4*>(lds + H::G1 + ((wave * NT1 + nt) * 64 + lane) * 4);
         mW1[nt] = bk[BKS * (BK_W1 + 3 * nt + 0)]; vW1[nt] = bk[BKS * (BK_W1 + 3 * nt + 1)];
         const f4 pv = bk[BKS * (BK_W1 + 3 * nt + 2)];
 #pragma unroll
@@ -2485,9 +2297,7 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
           SPO_H_REDO(L::W1 + (orow + r) * L::LD1 + 16 * nt + j, gv[r], mW1[nt][r], vW1[nt][r], pv[r], coef)
       }
       mb1 = bmb1; vb1 = bvb1;
-      float g1b;
-      if constexpr (HDW1) g1b = bk[BKS * (BK_G1 + NT1)][0];
-      else g1b = lds[H::GB + 0 * 256 + wave * 64 + lane];
+      const float g1b = lds[H::GB + 0 * 256 + wave * 64 + lane];
       SPO_H_REDO(L::B1 + 16 * wave + j, g1b, mb1, vb1, bpb1, coef)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
@@ -2511,53 +2321,9 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
       {
         // ---- layer 2 (W2, b2): L2 term, norm share, backups, speculative Adam
         SPO_REIDX
-        if constexpr (SPO_H_ADAM_BATCH) {
-          constexpr int NE = 17;
-          float pe[NE], ge[NE], me[NE], ve[NE];
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            const f4 gv = *reinterpret_cast<const f4*>(lds + G2OFF + ((wave * 4 + nt) * 64 + lane) * 4);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              pe[4 * nt + r] = lds[L::W2 + (orow + r) * LDH + 16 * nt + j];
-              ge[4 * nt + r] = gv[r]; me[4 * nt + r] = mW2[nt][r]; ve[4 * nt + r] = vW2[nt][r];
-            }
-          }
-          pe[16] = lds[L::B2 + 16 * wave + j];
-          ge[16] = lds[H::GB + 1 * 256 + wave * 64 + lane];
-          me[16] = mb2; ve[16] = vb2;
-          bpb2 = pe[16]; bmb2 = mb2; bvb2 = vb2;
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            bk[BKS * (BK_W2 + 3 * nt + 0)] = mW2[nt];
-            bk[BKS * (BK_W2 + 3 * nt + 1)] = vW2[nt];
-            bk[BKS * (BK_W2 + 3 * nt + 2)] = f4{pe[4 * nt], pe[4 * nt + 1], pe[4 * nt + 2], pe[4 * nt + 3]};
-          }
-#pragma unroll
-          for (int i = 0; i < NE; ++i) {
-            const float g_ = vcoef * fmaf(l2x2, pe[i], ge[i]);
-            ge[i] = g_;
-            if (i < 16 || own_b) { gsq = fmaf(g_, g_, gsq); psq = fmaf(pe[i], pe[i], psq); }
-          }
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) gg2[nt][r] = ge[4 * nt + r];
-          ggb2 = ge[16];
-          adam_batch<NE>(pe, ge, me, ve, b1c, b2c, eps, step_size, inv_bc2s);
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              lds[L::W2 + (orow + r) * LDH + 16 * nt + j] = pe[4 * nt + r];
-              mW2[nt][r] = me[4 * nt + r]; vW2[nt][r] = ve[4 * nt + r];
-            }
-          lds[L::B2 + 16 * wave + j] = pe[16];
-          mb2 = me[16]; vb2 = ve[16];
-        } else {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-          const f4 gv = *reinterpret_cast<const f4*>(lds + G2OFF + ((wave * 4 + nt) * 64 + lane) * 4);
+          const f4 gv = *reinterpret_cast<const f4*>(lds + H::G2 + ((wave * 4 + nt) * 64 + lane) * 4);
           bk[BKS * (BK_W2 + 3 * nt + 0)] = mW2[nt];
           bk[BKS * (BK_W2 + 3 * nt + 1)] = vW2[nt];
           f4 pv;
@@ -2578,7 +2344,6 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
         bmb2 = mb2; bvb2 = vb2;
         const AdamOut o_ = adam1(bpb2, ggb2, mb2, vb2, b1c, b2c, eps, step_size, inv_bc2s);
         mb2 = o_.m; vb2 = o_.v; lds[L::B2 + 16 * wave + j] = o_.p;
-        }
       }
       SPO_STAMP(3)
       if (s + 1 < nsteps) __syncthreads();                                // Q2 of step s + 1: (speculative) W2 / b2 in place
@@ -2589,7 +2354,6 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
       float bb3p = 0.f, bb3m = mb3, bb3v = vb3;
       {
         // ---- output layer (W3, b3, log_std): the same, backups in registers; then the norm share goes out
-        if constexpr (HXS) { if (s + 1 < nsteps) h_publish_xT(); }     // (read by dW1 of step s + 1, behind two more barriers)
         SPO_REIDX
         const f4 gv = *reinterpret_cast<const f4*>(lds + H::G3 + (wave * 64 + lane) * 4);
 #pragma unroll
@@ -2687,20 +2451,6 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
         if (wave == 0 && lane == 0) xw[20] = (int)((s + 1) & 0x3fffffff) + 1;
         late = true;
       }
-      if constexpr (HXS) {
-        if (h_fetched && !late) {
-          // minibatch s + 2: its column inputs replace those of step s + 1 once main wave `wave` has picked them up
-          const int want = (int)((s + 1) & 0x3fffffff) + 1;
-          unsigned sp3 = 0;
-          while (xw[24 + wave] != want) {
-            if (++sp3 > (1u << 22)) { *a.err = 1; break; }
-            __builtin_amdgcn_s_sleep(1);
-          }
-          h_publish_cols();
-          if (s + 3 < nsteps) hsmp = a.perm[h_perm_pos(s + 3)];
-          early_cols = true;
-        }
-      }
       SPO_STAMP(8)
       if (s + 1 < nsteps) {
         __syncthreads();                                                  // B_stage of step s + 1: the verdict is out
@@ -2717,7 +2467,7 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
         SPO_REIDX
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-          const f4 gv = *reinterpret_cast<const f4*>(lds + G2OFF + ((wave * 4 + nt) * 64 + lane) * 4);
+          const f4 gv = *reinterpret_cast<const f4*>(lds + H::G2 + ((wave * 4 + nt) * 64 + lane) * 4);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float p_ = lds[L::W2 + (orow + r) * LDH + 16 * nt + j];
@@ -2823,7 +2573,6 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
       }
       {
         // ---- output layer (W3, b3, log_std) with the exact coefficient
-        if constexpr (HXS) { if (s + 1 < nsteps) h_publish_xT(); }
         SPO_REIDX
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -2862,7 +2611,7 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
     if (SPO_H_GATHER && s + 2 < nsteps && !h_fetched) h_fetch((int64_t)pinned(hsmp));
   }
   if (PROF && a.prof && tid == 256 && wg == a.n_nets - 1)
-    for (int i = 0; i < NPHASE; ++i) { a.prof[NPHASE + i] = pacc[i]; a.prof[3 * NPHASE + i] = pacc2[i]; }
+    for (int i = 0; i < NPHASE; ++i) a.prof[NPHASE + i] = pacc[i];
   if (tid == 256 && wg == 0) {
     atomicAdd(&g_upd_counters[0], (unsigned long long)nsteps); atomicAdd(&g_upd_counters[1], (unsigned long long)n_late);
     atomicAdd(&g_upd_counters[2], (unsigned long long)n_redo); atomicAdd(&g_upd_counters[3], (unsigned long long)n_cons);
@@ -2928,15 +2677,17 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
 #undef SPO_SUB
 }
 
-template <int KIN, bool PROF = false, int XR = 0, int XRD = 1>
+template <int KIN, bool PROF = false, int XR = 0, int XRD = 2>
 __global__ __launch_bounds__(512) void ppo_update_h_kernel(UpdArgs a) {
   if (blockIdx.x & 7) return;                          // placement hint, see ppo_update_kernel
   ppo_update_h_body<KIN, PROF, XR, XRD>(a, (int)(blockIdx.x >> 3));
 }
 
-// One-grid split form on the main + helper kernel (round 5; cf. ppo_update_split_kernel): both halves of a two-way split of the
-// minibatch in ONE launch -- workgroups [0, n_nets) run rank 0's arguments, [n_nets, 2 n_nets) rank 1's -- exchanging the
-// gradient layer by layer on the HELPER waves (packed words, one hand-off per stage) beside the main waves' MFMAs.
+// One-grid split form on the main + helper kernel (round 5, opt-in: SPO_CPO_SPLIT_FORM=h; cf. ppo_update_split_kernel): both halves of
+// a two-way split of the minibatch in ONE launch -- workgroups [0, n_nets) run rank 0's arguments, [n_nets, 2 n_nets) rank 1's --
+// exchanging the gradient layer by layer on the HELPER waves (packed words, one hand-off per stage).  Measured SLOWER than the
+// four-wave split kernel (15.98 against 14.05 us per 128-row step, profiles/r05/helper_exchange_ab.txt): between P1 and Q2 the
+// helper waves are already what the step waits for, so two hand-offs there cost more than one after the last gradient.
 template <int KIN>
 __global__ __launch_bounds__(512) void ppo_update_h_split_kernel(UpdArgs a0, UpdArgs a1) {
   if (blockIdx.x & 7) return;
@@ -3092,14 +2843,13 @@ inline int update_form() {
   return v;
 }
 
-// SPO_P2P_HELPER: exchange of the data-parallel step on the HELPER waves of the main + helper kernel -- 0 (default) = no (four-wave
-// kernel, one exchange of the whole gradient per step), 1 = recursive doubling with 8-byte tagged words, 2 = with packed words
+// SPO_P2P_HELPER=1 (opt-in): the data-parallel step with its exchange on the HELPER waves of the main + helper kernel (packed words)
 inline int helper_xr_mode() {
   static const int v = [] { const char* e = getenv("SPO_P2P_HELPER"); return e ? atoi(e) : 0; }();
   return v;
 }
 
-template <int K, bool PROF = false, int XR = 0, int XRD = 1>
+template <int K, bool PROF = false, int XR = 0, int XRD = 2>
 int launch_update_h(const UpdArgs& a_in, int blocks, hipStream_t st) {
   UpdArgs a = a_in;
   if (int rc = h_scratch_for(st, &a.backup, &a.slots)) return rc;
@@ -3392,11 +3142,10 @@ extern "C" int spo_ppo_lag_update_iter_dp(float* theta, float* adam_m, float* ad
   // stage cost more than three tagged-word hand-offs there.  Kept for measurement on a real xGMI node.
   static const bool a2a = [] { const char* e = getenv("SPO_P2P_A2A"); return e && e[0] == '1'; }();
   // SPO_P2P_HELPER=1 (opt-in): the main + helper kernel with recursive doubling ON THE HELPER WAVES -- layer 1 exchanged
-  // while the main waves still compute dW2 / dW3, layers 2 / 3 while they settle the next minibatch and run layer 1.
-  // Measured in loopback: 18.9 / 27.2 / 33.9 us per step at 2 / 4 / 8 ranks against 15.8 / 19.2 / 24.2 for the default
-  // below (four-wave kernel, ONE exchange of the whole gradient per step): two exchanges per step are twice the
-  // hand-off rounds, and the overlap does not pay for them.
-  // SPO_P2P_HELPER=2 (round 5): the same with PACKED 16-byte words and one poll batch per stage (xr_rd16_flat).
+  // while the main waves still compute dW2 / dW3, layers 2 / 3 while they settle the next minibatch and run layer 1; round 5:
+  // packed 16-byte words, one poll batch per stage (xr_rd16_flat).  Loopback: 16.2 / 22.4 / 27.9 us per step at 2 / 4 / 8 ranks
+  // against 14.3 / 16.7 / 19.1 for the default below (four-wave kernel, ONE exchange of the whole gradient per step): between P1
+  // and Q2 the helper waves already gate the step, so hand-offs placed there are exposed in full and there are two per step.
   const int helper_xr = helper_xr_mode();
   a.xr_helper_rd = a2a ? 0 : 1;
   if ((a2a || helper_xr) && kin <= 64 && cfg_host->batch <= 64 && update_form() == 2 && a.xr_algo == 1 && (world == 2 || world == 4 || world == 8)) {
@@ -3404,8 +3153,7 @@ extern "C" int spo_ppo_lag_update_iter_dp(float* theta, float* adam_m, float* ad
 #define SPO_H_XR(K, D) (world == 2 ? launch_update_h<K, false, 2, D>(a, 3, st) : world == 4 ? launch_update_h<K, false, 4, D>(a, 3, st) \
                                                                                                : launch_update_h<K, false, 8, D>(a, 3, st))
     if (a2a) rc = kin == 16 ? SPO_H_XR(16, 0) : kin == 32 ? SPO_H_XR(32, 0) : SPO_H_XR(64, 0);
-    else if (helper_xr == 2) rc = kin == 16 ? SPO_H_XR(16, 2) : kin == 32 ? SPO_H_XR(32, 2) : SPO_H_XR(64, 2);
-    else rc = kin == 16 ? SPO_H_XR(16, 1) : kin == 32 ? SPO_H_XR(32, 1) : SPO_H_XR(64, 1);
+    else rc = kin == 16 ? SPO_H_XR(16, 2) : kin == 32 ? SPO_H_XR(32, 2) : SPO_H_XR(64, 2);
 #undef SPO_H_XR
   } else if (a.xr_algo == 1 && (world & (world - 1)) == 0) rc = launch_update<true, 0, 2>(a, 3, st);
   else rc = launch_update<true, 0, 1>(a, 3, st);
@@ -3443,10 +3191,11 @@ extern "C" int spo_critic_fit_iter_dp(float* theta, float* adam_m, float* adam_v
   a.xr_helper_rd = 1;
   if (helper_xr && kin <= 64 && cfg_host->batch <= 64 && update_form() == 2 && a.xr_algo == 1 && (world == 2 || world == 4 || world == 8)) {
     // main + helper form with recursive doubling on the helper waves (see spo_ppo_lag_update_iter_dp)
-#define SPO_H_XR(K, D) (world == 2 ? launch_update_h<K, false, 2, D>(a, 2, st) : world == 4 ? launch_update_h<K, false, 4, D>(a, 2, st) \
-                                                                                               : launch_update_h<K, false, 8, D>(a, 2, st))
-    if (helper_xr == 2) rc = kin == 16 ? SPO_H_XR(16, 2) : kin == 32 ? SPO_H_XR(32, 2) : SPO_H_XR(64, 2);
-    else rc = kin == 16 ? SPO_H_XR(16, 1) : kin == 32 ? SPO_H_XR(32, 1) : SPO_H_XR(64, 1);
+#define SPO_H_XR(K) (world == 2 ? launch_update_h<K, false, 2, 2>(a, 2, st) : world == 4 ? launch_update_h<K, false, 4, 2>(a, 2, st) \
+                                                                                            : launch_update_h<K, false, 8, 2>(a, 2, st))
+    if (kin == 16) rc = SPO_H_XR(16);
+    else if (kin == 32) rc = SPO_H_XR(32);
+    else rc = SPO_H_XR(64);
 #undef SPO_H_XR
   } else if (a.xr_algo == 1 && (world & (world - 1)) == 0) rc = launch_update<true, 0, 2>(a, 2, st);
   else rc = launch_update<true, 0, 1>(a, 2, st);
@@ -3496,9 +3245,9 @@ extern "C" int spo_critic_fit_iter_split(float* theta0, float* adam_m0, float* a
   b.err = reinterpret_cast<int*>(reinterpret_cast<char*>(sync_ws1) + 64);
   b.stale_io = stale_sq_io1;
   const int kin = pick_kin(cfg_host->obs_dim);
-  // SPO_CPO_SPLIT_FORM = h (default, round 5): the main + helper kernel with the exchange on the helper waves; 4w: the four-wave
-  // kernel of rounds 3-4 (one exchange of the whole gradient per step in the waves that also run the optimiser)
-  static const bool split_h = [] { const char* e = getenv("SPO_CPO_SPLIT_FORM"); return !(e && !strcmp(e, "4w")); }();
+  // SPO_CPO_SPLIT_FORM=h (opt-in, round 5): the main + helper kernel with the exchange on the helper waves (ppo_update_h_split_kernel:
+  // 15.98 us per 128-row step); default: the four-wave kernel of rounds 3-4, one exchange of the whole gradient per step (14.05 us)
+  static const bool split_h = [] { const char* e = getenv("SPO_CPO_SPLIT_FORM"); return e && !strcmp(e, "h"); }();
   if (split_h && kin <= 64 && cfg_host->batch <= 64 && update_form() == 2) {
     if (int rc = h_scratch_for(st, &a.backup, &a.slots, 0)) return rc;
     if (int rc = h_scratch_for(st, &b.backup, &b.slots, 1)) return rc;
@@ -3560,8 +3309,8 @@ extern "C" int spo_p2p_selftest_one_grid(void* const* regions2, uint32_t step0, 
 
 // Debug: when set (device pointer to 3*10 u64), spo_ppo_lag_update_iter runs an instrumented build of
 // the kernel that accumulates shader-clock cycles per phase of the step (wave 0 lane 0 per block).
-extern "C" int spo_debug_set_update_profile(void* dev_u64_40) {
-  g_prof_buf = reinterpret_cast<unsigned long long*>(dev_u64_40);
+extern "C" int spo_debug_set_update_profile(void* dev_u64_30) {
+  g_prof_buf = reinterpret_cast<unsigned long long*>(dev_u64_30);
   return 0;
 }
 

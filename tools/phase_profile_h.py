@@ -16,7 +16,7 @@ for k in ("obs", "act", "log_prob", "target_value_r", "target_value_c"):
     b.data[k].normal_()
 b.data["log_prob"].fill_(-8.0)
 b.adv_mix.normal_()
-prof = torch.zeros(40, dtype=torch.int64, device=dev)
+prof = torch.zeros(30, dtype=torch.int64, device=dev)
 lib = _abi.load()
 perm = torch.randperm(N * T, device=dev).to(torch.int32)
 eng.learning_iter(perm)
@@ -25,7 +25,7 @@ torch.cuda.synchronize()
 t0 = time.time(); eng.learning_iter(perm); torch.cuda.synchronize(); dt = time.time() - t0
 lib.spo_debug_set_update_profile(None)
 steps = N * T // 64
-p = prof.cpu().view(4, 10).numpy()
+p = prof.cpu().view(3, 10).numpy()
 print(f"instrumented launch: {dt*1e6/steps:.2f} us/step")
 main = ["settle + x^T", "L1", "wait Q2", "L2", "wait Xd", "L3 loss bwd stage", "wait B_stage", "dW1 -> G1", "wait P1", "dW2 dW3 -> G"]
 helper = ["wait P1", "Adam W1 (speculative)", "wait P3", "norms of W2 W3 + tags", "wait Q2", "Adam W3 b3 log_std", "wait Xd + B_stage", "", "poll norms, coefficient", "Adam W2 (speculative)"]
@@ -34,11 +34,9 @@ if spec:
     helper = ["wait P1", "W1: L2 norm Adam (spec)", "wait P3", "W2: L2 norm Adam (spec)", "wait Q2", "W3 b3 log_std (spec), norm out", "wait B_stage", "",
               "poll norms, verdict", "wait Xd"]
 sub = ["prefetch issue + L3", "loss", "dO -> dZ2", "dZ2 -> dZ1", "stage 4 images + dO", "loss / dls sums"]
-hsub = ["index load of step s+2", "Adam scalars", "LDS reads of p, g", "backup stores", "L2 terms, norm shares", "Adam (batched)", "LDS writes",
-        "wait for rows + pad selects", "column inputs -> LDS"]
-for row, names in ((0, main), (2, sub), (1, helper), (3, hsub)):
+for row, names in ((0, main), (2, sub), (1, helper)):
     tot = p[row].sum()
-    print({0: "main", 1: "helper", 2: "main, inside 'L3 loss bwd stage':", 3: "helper, inside 'W1: L2 norm Adam':"}[row] + f" wave 0 of the actor: total {tot/steps:.0f} cycles/step")
+    print({0: "main", 1: "helper", 2: "main, inside 'L3 loss bwd stage':"}[row] + f" wave 0 of the actor: total {tot/steps:.0f} cycles/step")
     for i, n in enumerate(names):
         if n:
             print(f"   {n:22s} {p[row][i]/steps:8.0f} cyc  {100*p[row][i]/max(tot,1):5.1f}%")
