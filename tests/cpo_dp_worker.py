@@ -59,16 +59,39 @@ def main(out_path, shape="60,8,64,64"):
     res["finite"] = bool(torch.isfinite(theta).all())
     if rank == 0:
         pol1, eng1 = build(N, 0, P.Comm.single())
+        sd0 = {k: v.detach().cpu().clone() for k, v in pol1.state_dict().items()}
         eng1.buffer.compute_gae(None, None)
+        d1 = eng1.buffer.data
+        M = N * T
+        data32 = {"obs": d1["obs"].view(M, D).cpu().clone(), "act": d1["act"].view(M, A).cpu().clone(),
+                  "log_prob": d1["log_prob"].view(M).cpu().clone(), "adv_r": d1["adv_r"].view(M).cpu().clone(),
+                  "adv_c": d1["adv_c"].view(M).cpu().clone()}
         out1 = eng1.policy_update(0.4)
         ref = eng1.theta_actor.detach().cpu()
         d = (actor_dp - ref).abs()
         res["actor_max_abs_diff"] = float(d.max())
         res["actor_frac_outside"] = float((d > 1e-6 + 1e-3 * ref.abs()).float().mean())
+        # the fp64 yardstick beside the two-rank / one-rank comparison (round 5): the oracle's trust-region step on the same
+        # rows in float32 (the reference's arithmetic) and float64; columns = [two ranks, one rank, oracle f32, oracle f64]
+        from oracle import restatement as R
+        o = {}
+        for name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+            rp = R.OraclePolicy(D, A, tuple(hidden))
+            rp.load_state_dict(sd0)
+            rp = rp.to(dt)
+            o[name] = R.cpo_policy_update(rp, {k: v.to(dt) for k, v in data32.items()}, 0.4, target_kl=cfg["target_kl"])
+            o[name]["actor_after"] = R.actor_flat_params(rp.actor).double()
+        orc = lambda k, w: {"xHx": float(w["xHx"]), "gradient_norm": float(w["g"].norm()), "H_inv_g": float(w["x"].norm()),
+                            "alpha": float(w["alpha"]), "final_step_norm": float(w["step_direction"].norm()), "kl": float(w["kl"]),
+                            "loss_actor": float(w["loss_r_before"] + w["loss_c_before"])}[k]
         for k in ("xHx", "gradient_norm", "H_inv_g", "alpha", "final_step_norm", "kl", "loss_actor"):
-            res[k] = [float(out[k]), float(out1[k])]
-        res["case"] = [int(out["case"]), int(out1["case"])]
-        res["acceptance_step"] = [int(out["acceptance_step"]), int(out1["acceptance_step"])]
+            res[k] = [float(out[k]), float(out1[k]), orc(k, o["f32"]), orc(k, o["f64"])]
+        res["case"] = [int(out["case"]), int(out1["case"]), int(o["f32"]["case"]), int(o["f64"]["case"])]
+        res["acceptance_step"] = [int(out["acceptance_step"]), int(out1["acceptance_step"]), int(o["f32"]["accept"]), int(o["f64"]["accept"])]
+        a64 = o["f64"]["actor_after"]
+        dist_to = lambda t: [float((t.double() - a64).abs().max()), float((t.double() - a64).norm())]
+        res["actor_dist_to_f64"] = {"two_ranks": dist_to(actor_dp), "one_rank": dist_to(ref), "f32": dist_to(o["f32"]["actor_after"]),
+                                    "scale": float(a64.abs().max()), "n": int(a64.numel())}
         with open(out_path, "w") as f:
             json.dump(res, f)
     comm.barrier()

@@ -24,14 +24,14 @@ from oracle import restatement as R
 
 
 def oracle_trajectory(state_dict, problem, perm, batch, nsteps, dtype, checkpoints=(), lr=3e-4, max_grad_norm=40.0,
-                      lr_factor=1.0, threads=4, **loss_kw):
+                      lr_factor=1.0, threads=4, hidden_sizes=(64, 64), **loss_kw):
     """Runs `nsteps` consecutive minibatch steps of the oracle (R.PPOLagUpdater.minibatch_step, i.e.
     ppo_lag.py:306-329) in `dtype` from `state_dict` over consecutive chunks of `perm`.
     Returns (losses [nsteps,3] float64, {k: flat theta after k steps, float64})."""
     torch.set_num_threads(threads)
     obs, act, logp, tgt_r, tgt_c, adv = [t.to(dtype) for t in problem]
     D, A = obs.shape[1], act.shape[1]
-    pol = R.OraclePolicy(D, A)
+    pol = R.OraclePolicy(D, A, tuple(hidden_sizes))
     pol.load_state_dict({k: v.detach().cpu().clone() for k, v in state_dict.items()})
     pol = pol.to(dtype)
     upd = R.PPOLagUpdater(pol, epochs=1, lr=lr, max_grad_norm=max_grad_norm, **loss_kw)
@@ -69,15 +69,16 @@ def loss_envelope(hip, f32, f64, c=3.0, floor_rel=3e-7, window=64):
     return worst
 
 
-def theta_envelope(hip, f32, f64, c=3.0, floor_abs=2e-7):
+def theta_envelope(hip, f32, f64, c=3.0, floor_abs=2e-7, floor_abs_max=None):
     """L2 and max-abs distance of the parameter vector from the fp64 trajectory against c x the fp32 reference's own
-    distance (+ floor_abs per element: half an fp32 ulp of an O(1) parameter).  Returns the worse of the two ratios."""
+    distance (+ floor_abs per element: half an fp32 ulp of an O(1) parameter; floor_abs_max: a separate floor for the max-norm
+    gate, see tests/test_gpu_wide_dims.py::_theta_floor).  Returns the worse of the two ratios."""
     hip, f32, f64 = (np.asarray(x, np.float64).reshape(-1) for x in (hip, f32, f64))
     n = f64.size
     dh2, d322 = np.linalg.norm(hip - f64), np.linalg.norm(f32 - f64)
     dhm, d32m = np.abs(hip - f64).max(), np.abs(f32 - f64).max()
     r2 = dh2 / (c * d322 + floor_abs * np.sqrt(n))
-    rm = dhm / (c * d32m + floor_abs)
+    rm = dhm / (c * d32m + (floor_abs if floor_abs_max is None else floor_abs_max))
     return max(r2, rm), {"l2_hip": dh2, "l2_f32": d322, "max_hip": dhm, "max_f32": d32m}
 
 
@@ -161,5 +162,146 @@ def replay_ppo_lag_trace(z, dtype=torch.float64):
         res = R.ppo_lag_update(pol, upd, data, lam, perms, learning_iters=n_perm, batch_size=int(z[f"e{e}_batch_size"]),
                                target_kl=float("inf"))
         out["losses"].append(np.asarray(res["losses"], np.float64))
+        out.setdefault("kl", []).append(float(res["kl"]))
     out["theta_final"] = R.flat_params(pol).double().numpy().copy()
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Round 5: the remaining trace replays under the same yardstick
+# ------------------------------------------------------------------------------------------------------------------------
+def gate_array(hip, f32, f64, what, rel_floor=1e-6, c=3.0):
+    """|hip - f64| <= c |f32 - f64| + rel_floor * max|f64| in max-norm and in L2 (per sqrt(n))."""
+    hip, f32, f64 = (np.asarray(t, np.float64).reshape(-1) for t in (hip, f32, f64))
+    assert hip.shape == f32.shape == f64.shape, (what, hip.shape, f32.shape, f64.shape)
+    assert np.isfinite(hip).all(), f"{what}: non-finite HIP values"
+    sc = max(float(np.abs(f64).max()), 1e-30)
+    dh, d32 = np.abs(hip - f64), np.abs(f32 - f64)
+    assert dh.max() <= c * d32.max() + rel_floor * sc, \
+        f"{what}: max |hip - f64| {dh.max():.3e} > {c} x |f32 - f64| {d32.max():.3e} + {rel_floor:g} x {sc:.3e}"
+    n = np.sqrt(hip.size)
+    assert np.linalg.norm(dh) <= c * np.linalg.norm(d32) + rel_floor * sc * n, \
+        f"{what}: L2 |hip - f64| {np.linalg.norm(dh):.3e} > {c} x |f32 - f64| {np.linalg.norm(d32):.3e} + floor"
+    return float(dh.max() / sc), float(d32.max() / sc)
+
+
+def gate_scalars(rows, what, rel_floor=1e-6, c=3.0, scale=None):
+    """rows: [(name, hip, f32, f64)] of scalars of ONE kind of quantity (e.g. the curvature x^T H x of every epoch of a trace).
+    A single scalar's |f32 - f64| is one draw of the reference's rounding noise -- it can be 0 by chance --, so the yardstick is
+    the largest RELATIVE deviation the reference shows over the group: |hip - f64| / |f64| <= c * max_i(|f32_i - f64_i| / |f64_i|)
+    + rel_floor for every member.  `scale`: measure the deviations against this magnitude instead of |f64| -- for a quantity
+    that is a cancelling sum (a surrogate loss -mean(ratio * adv) over standardised advantages is ~0 +- rounding: relative to
+    itself every evaluation is 100 % off).  Returns (worst hip, yardstick) deviations."""
+    rel = lambda a, b: abs(a - b) / (max(abs(b), 1e-30) if scale is None else scale)
+    yard = max(rel(f32, f64) for _, _, f32, f64 in rows)
+    worst = 0.0
+    for name, hip, f32, f64 in rows:
+        d = rel(hip, f64)
+        assert np.isfinite(hip) and d <= c * yard + rel_floor, \
+            f"{what} / {name}: |hip - f64| / |f64| = {d:.3e} > {c} x {yard:.3e} (largest deviation of the reference's fp32 in the group) + {rel_floor:g}; hip {hip!r} f32 {f32!r} f64 {f64!r}"
+        worst = max(worst, d)
+    return worst, yard
+
+
+def _policy_in(z, prefix, dtype, only=None):
+    names = [k[len(prefix):] for k in z.files if k.startswith(prefix)]
+    D, A = z[prefix + "actor.mean.0.weight"].shape[1], z[prefix + "actor.log_std"].shape[0]
+    pol = R.OraclePolicy(D, A)
+    pol.load_state_dict({k: torch.from_numpy(z[prefix + k].copy()) for k in names})
+    return pol.to(dtype)
+
+
+def _trace_epoch_data(z, e, dtype):
+    """The get() dict of epoch e as the reference saw it: recorded rollout tensors, the oracle's own (bit-pinned) GAE and
+    standardisation of them (tests/test_oracle_golden.py), cast to `dtype`.  Returns (data, shuffles)."""
+    raw = lambda k: z[f"e{e}_raw_{k}"]
+    N, T = raw("reward").shape
+    adv_r, adv_c, tgt_r, tgt_c = R.gae_dense(raw("reward"), raw("cost"), raw("value_r"), raw("value_c"), z[f"e{e}_seg_end"],
+                                              z[f"e{e}_boot_r"], z[f"e{e}_boot_c"], float(z["meta_cfg_gamma"]), 0.95, 0.95)
+    sr, sc = R.adv_standardize(torch.from_numpy(adv_r.reshape(-1)), torch.from_numpy(adv_c.reshape(-1)))
+    flat = lambda k: torch.from_numpy(raw(k).reshape(N * T, *raw(k).shape[2:]))
+    data = {"obs": flat("obs"), "act": flat("act"), "log_prob": flat("log_prob"), "target_value_r": torch.from_numpy(tgt_r.reshape(-1)),
+            "target_value_c": torch.from_numpy(tgt_c.reshape(-1)), "adv_r": sr, "adv_c": sc}
+    n_perm = len([k for k in z.files if k.startswith(f"e{e}_perm")])
+    return {k: v.to(dtype) for k, v in data.items()}, [z[f"e{e}_perm{i}"] for i in range(n_perm)]
+
+
+def replay_second_order_trace(z, algo, dtype=torch.float64):
+    """The trust-region family (cpo, pcpo, natural_pg, trpo, rcpo, trpo_lag) over the epochs of the reference's main() trace in
+    `dtype`, the way the HIP tests replay it: the ACTOR starts every epoch from the reference's recorded parameters (its step has
+    no optimiser state: the epochs are independent), the two CRITICS and their Adam state run free from the initial state through
+    all epochs (cpo.py:534-571 keeps the optimisers), clipped jointly with the stale actor gradient the step left behind.
+    Returns one dict per epoch: the logged scalars, the actor after the step, the critic-fit losses, the critics' parameters
+    before the epoch; plus the critics at the end."""
+    epochs, tkl = int(z["meta_epochs"]), float(z["meta_cfg_target_kl"])
+    iters = int(z["meta_cfg_learning_iters"])
+    pol = _policy_in(z, "init_sd_", dtype)
+    fit = R.CriticFitter(pol)
+    actor_keys = list(pol.actor.state_dict())
+    crit = lambda: torch.cat([p.detach().reshape(-1) for p in list(pol.reward_critic.parameters()) + list(pol.cost_critic.parameters())]).double().numpy().copy()
+    lagrange = None
+    if algo in ("rcpo", "trpo_lag"):
+        lagrange = R.OracleLagrange(float(z["meta_arg_cost_limit"]), float(z["meta_arg_lagrangian_multiplier_init"]),
+                                    float(z["meta_arg_lagrangian_multiplier_lr"]))
+    out = []
+    for e in range(epochs):
+        pol.actor.load_state_dict({k: torch.from_numpy(z[f"e{e}_sd_before_actor.{k}"].copy()).to(dtype) for k in actor_keys})
+        data, perms = _trace_epoch_data(z, e, dtype)
+        rec = {"critics_before": crit()}
+        if algo == "cpo":
+            ep_costs = float(z[f"e{e}_get_stats_Metrics_EpCost"]) - float(z["meta_arg_cost_limit"])
+            o = R.cpo_policy_update(pol, data, ep_costs, target_kl=tkl)
+            stale, step_norm, loss_actor = o["b"], float(o["step_direction"].norm()), o["loss_r_before"] + o["loss_c_before"]
+        elif algo == "pcpo":
+            ep_costs = float(z[f"e{e}_get_stats_Metrics_EpCost"]) - float(z["meta_arg_cost_limit"])
+            o = R.pcpo_policy_update(pol, data, ep_costs, target_kl=tkl)
+            stale, step_norm, loss_actor = o["b"], float(o["step_direction"].norm()), o["loss_r_before"] + o["loss_c_before"]
+        else:
+            adv = data["adv_r"]
+            if lagrange is not None:
+                lagrange.update_lagrange_multiplier(float(z[f"e{e}_get_stats_Metrics_EpCost"]))
+                adv = R.adv_mix(data["adv_r"], data["adv_c"], lagrange.lagrangian_multiplier)
+            o = R.trust_region_policy_update(pol, data, adv, target_kl=tkl, line_search=algo in ("trpo", "trpo_lag"))
+            stale, step_norm, loss_actor = -o["g"], float(o["step_direction"].norm()), o["loss_actor"]
+        rec.update(xHx=float(o["xHx"]), alpha=float(o["alpha"]), gradient_norm=float(o["g"].norm()), H_inv_g=float(o["x"].norm()),
+                   final_step_norm=step_norm, kl=float(o["kl"]), loss_actor=float(loss_actor), accept=o["accept"], case=o.get("case"),
+                   actor_after=R.actor_flat_params(pol.actor).double().numpy().copy())
+        i = 0
+        for _, prm in pol.actor.named_parameters():            # the stale actor gradient takes part in the critics' joint clip
+            prm.grad = stale[i:i + prm.numel()].view(prm.shape).clone()
+            i += prm.numel()
+        bs, M, losses = int(z[f"e{e}_batch_size"]), data["obs"].shape[0], []
+        for it in range(iters):
+            perm = torch.from_numpy(np.asarray(perms[it]).astype(np.int64))
+            for s in range(0, M, bs):
+                idx = perm[s:s + bs]
+                losses.append(fit.minibatch_step(data["obs"][idx], data["target_value_r"][idx], data["target_value_c"][idx]))
+        rec["critic_losses"] = np.asarray(losses, np.float64)
+        out.append(rec)
+    return out, crit()
+
+
+def replay_kl_penalty_trace(z, algo, dtype=torch.float64):
+    """focops.main() / cup.main() of the reference replayed through the oracle in `dtype` (free-running from the initial
+    weights: every network has Adam state): per epoch the per-minibatch losses, the stop iterations, the KL and the flat
+    parameters before the epoch; plus the final parameters.  Mirrors tests/test_oracle_golden.py::test_kl_penalty_family_main_trace."""
+    epochs, iters = int(z["meta_epochs"]), int(z["meta_cfg_learning_iters"])
+    pol = _policy_in(z, "init_sd_", dtype)
+    upd = R.KLPenaltyUpdater(pol, epochs=epochs)
+    lag = R.OracleLagrange(float(z["meta_arg_cost_limit"]), float(z["meta_arg_lagrangian_multiplier_init"]),
+                           float(z["meta_arg_lagrangian_multiplier_lr"]), lagrangian_upper_bound=2.0 if algo == "focops" else 0.2)
+    out = []
+    for e in range(epochs):
+        rec = {"theta_before": R.flat_params(pol).double().numpy().copy()}
+        data, perms = _trace_epoch_data(z, e, dtype)
+        lag.update_lagrange_multiplier(float(z[f"e{e}_get_stats_Metrics_EpCost"]))
+        kw = dict(learning_iters=iters, batch_size=int(z[f"e{e}_batch_size"]), target_kl=float(z["meta_cfg_target_kl"]))
+        perms = perms + [perms[-1]] * (2 * iters)
+        if algo == "focops":
+            o = R.focops_update(pol, upd, data, lag.lagrangian_multiplier, perms, **kw)
+        else:
+            o = R.cup_update(pol, upd, data, lag.lagrangian_multiplier, perms, float(z["meta_cfg_gamma"]), **kw)
+            rec["second_stage_stop_iter"] = o["second_stage_stop_iter"]
+        rec.update(losses=np.asarray(o["losses"], np.float64), stop_iter=o["stop_iter"], kl=float(o["kl"]))
+        out.append(rec)
+    return out, R.flat_params(pol).double().numpy().copy()

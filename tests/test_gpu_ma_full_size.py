@@ -136,7 +136,9 @@ def test_config5_shape_ppo_update_fp64_yardstick(dev):
             imp64 = torch.prod(torch.exp(lp64 - s64["old_logp"]), dim=-1, keepdim=True)
             edge = ((imp64 - (1.0 - cfg["clip_param"])).abs() < 1e-4) | ((imp64 - (1.0 + cfg["clip_param"])).abs() < 1e-4)
         n_edge = int(edge.sum())
-        assert 0 < n_edge < ROWS // 100, n_edge
+        # measured on the MI355X: 165 rows at step 2, 227 at step 3 (profiles/r05/pytest_gpu_final.log prints them); the band is
+        # 2 x 2e-4 wide in a ratio whose density near 1 +- clip is ~0.5 per unit at step 3 -> ~210 of 524 288 expected
+        assert 0 < n_edge <= 300, n_edge
         factor_k = torch.where(edge, torch.zeros_like(s["factor"]), s["factor"])
         sk64 = dict(s64, factor=factor_k.double())
         tr64.lamda = torch.tensor(lam, dtype=torch.float64)

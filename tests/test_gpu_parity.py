@@ -32,9 +32,12 @@ def _ulp_diff(a, b):
 
 
 def _assert_params_close(got, ref, lr, nsteps, rtol=2e-4, atol=2e-6, what=""):
-    """Parameters after Adam steps.  Adam divides by sqrt(v): an element whose gradient is at
-    rounding-noise level gets an O(lr) step of arbitrary sign on BOTH sides, so a handful of
-    elements may differ by up to ~lr per step; everything else must agree to rtol/atol."""
+    """TRAJECTORY check of the free-running multi-epoch replays only (round 5: every other caller moved to the fp64 yardstick,
+    tests/envelope.py, and each of these replays has a yardstick test beside it --
+    test_second_order_family_traces_under_the_fp64_yardstick).  Parameters after Adam steps over several epochs of a
+    free-running HIP state against the reference's recorded state: Adam divides by sqrt(v), so an element whose gradient
+    is at rounding-noise level gets an O(lr) step of arbitrary sign on BOTH sides -- at most 0.1 % of the elements may leave
+    the rtol / atol band, and none by more than the distance Adam can move an element (2 x lr x nsteps)."""
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
     err = np.abs(got - ref)
     bad = err > (atol + rtol * np.abs(ref))
@@ -478,7 +481,7 @@ def test_ppo_lag_update_vs_reference_main_trace(dev, golden_dir):
            "max_grad_norm": float(z["meta_cfg_max_grad_norm"])}
     eng = PPOLagEngine(pol, N, T, cfg, dev)
     t64 = E.replay_ppo_lag_trace(z, torch.float64)
-    ratios = []
+    ratios, kl_rows = [], []
     for e in range(epochs):
         ref_before = np.concatenate([z[f"e{e}_sd_before_{k}"].reshape(-1) for k in pol.state_dict()])
         ratios.append(E.assert_theta_envelope(pol.theta.cpu().numpy(), ref_before, t64["theta_before"][e],
@@ -498,7 +501,9 @@ def test_ppo_lag_update_vs_reference_main_trace(dev, golden_dir):
         if e == 0:
             np.testing.assert_allclose(got[:3], ref[:3], rtol=1e-5, atol=1e-6)       # first steps from identical weights
         ratios.append(E.assert_loss_envelope(got, ref, t64["losses"][e], f"losses of epoch {e}", window=len(ref)))
-        assert out["kl"] == pytest.approx(float(z[f"e{e}_row_Train_KL"]), rel=2e-3, abs=1e-7)
+        kl_rows.append((f"epoch {e}", out["kl"], float(z[f"e{e}_row_Train_KL"]), t64["kl"][e]))
+    # the early-stop KL after each epoch's free-running passes: as far from the float64 replay as the reference's own values are
+    print("KL yardstick (worst hip, reference):", E.gate_scalars(kl_rows, "Train/KL", rel_floor=1e-6))
     ref_final = np.concatenate([z[f"final_sd_{k}"].reshape(-1) for k in pol.state_dict()])
     ratios.append(E.assert_theta_envelope(pol.theta.cpu().numpy(), ref_final, t64["theta_final"], "final theta")[0])
     print("drift envelope ratios (<= 1 passes):", np.round(ratios, 3))
@@ -566,7 +571,12 @@ def test_minibatch_grad_and_step_vs_oracle(dev, M, D, A, batch):
     losses = eng.learning_iter(perm.to(torch.int32).to(dev))
     eng.check_sync_error()
     np.testing.assert_allclose(losses.cpu().numpy(), np.asarray(losses_ref), rtol=1e-4, atol=2e-6)
-    _assert_params_close(pol.theta.cpu().numpy(), R.flat_params(ref).numpy(), 3e-4, len(losses_ref), what="theta")
+    # parameters after the pass: no further from the float64 trajectory than 3 x the float32 oracle is (every element: max-norm)
+    import envelope as E
+    nst = len(losses_ref)
+    _, t64 = E.oracle_trajectory(ref0, (obs, act, logp, tgt_r, tgt_c, adv), perm, batch, nst, torch.float64, [nst],
+                                 max_grad_norm=cfg["max_grad_norm"])
+    E.assert_theta_envelope(pol.theta.cpu().numpy(), R.flat_params(ref).numpy(), t64[nst], f"theta after {nst} steps")
     # optimiser state round-trips through adam_m / adam_v
     m_ref = torch.cat([upd.opt_r.state[p]["exp_avg"].reshape(-1) for p in ref.reward_critic.parameters()])
     np.testing.assert_allclose(eng.adam_m[:m_ref.numel()].cpu().numpy(), m_ref.numpy(), rtol=1e-3, atol=1e-7)
@@ -629,7 +639,14 @@ def test_intermittent_clip_vs_oracle(dev, spec, monkeypatch):
     losses = eng.learning_iter(perm.to(torch.int32).to(dev))
     eng.check_sync_error()
     np.testing.assert_allclose(losses.cpu().numpy(), losses_ref, rtol=1e-4, atol=2e-6)
-    _assert_params_close(pol.theta.cpu().numpy(), R.flat_params(ref).numpy(), 3e-4, len(losses_ref), what="theta")
+    # the same clipped / unclipped sequence in float64 (no step sits on the bound: asserted above) is the yardstick
+    import envelope as E
+    nst = len(losses_ref)
+    ends_all = list(range(1, nst + 1))
+    l64, t64 = E.oracle_trajectory(ref0, (obs, act, logp, tgt_r, tgt_c, adv), perm, batch, nst, torch.float64, ends_all,
+                                   max_grad_norm=bound)
+    E.assert_loss_envelope(losses.cpu().numpy(), losses_ref, l64, "intermittent clip: losses", window=nst)
+    E.assert_theta_envelope(pol.theta.cpu().numpy(), R.flat_params(ref).numpy(), t64[nst], "intermittent clip: theta")
     # launches that END on a clipped step right after an unclipped one (the verdict of the last step has no next forward to
     # hide behind: the helpers restore and redo after the loop) and on an unclipped step right after a clipped one
     ends = [k for k in range(2, len(clipped) + 1) if clipped[k - 1] and not clipped[k - 2]][:2] + \
@@ -646,7 +663,7 @@ def test_intermittent_clip_vs_oracle(dev, spec, monkeypatch):
         l_k = sub.learning_iter(torch.arange(k * batch, dtype=torch.int32, device=dev))
         sub.check_sync_error()
         np.testing.assert_allclose(l_k.cpu().numpy(), losses_ref[:k], rtol=1e-4, atol=2e-6)
-        _assert_params_close(pol.theta.cpu().numpy(), thetas[k - 1], 3e-4, k, what=f"theta after {k} steps")
+        E.assert_theta_envelope(pol.theta.cpu().numpy(), thetas[k - 1], t64[k], f"intermittent clip: theta after {k} steps")
 
 
 def test_split_path_equals_persistent(dev):
@@ -1045,6 +1062,85 @@ def test_cpo_trace_epochs_one_by_one_under_the_fp64_yardstick(dev, golden_dir):
     print("cpo trace, per-epoch relative distance to float64:", {k: f"{v:.2e}" for k, v in worst.items()})
 
 
+@pytest.mark.parametrize("algo", ["cpo", "pcpo", "natural_pg", "trpo", "rcpo", "trpo_lag"])
+def test_second_order_family_traces_under_the_fp64_yardstick(dev, golden_dir, algo):
+    """every trust-region script of the reference under the gate cpo got in round 4, critic fit included.
+    The reference's main() trace is replayed with the ACTOR reset to the reference's recorded parameters at every epoch (its
+    step carries no optimiser state) and the two CRITICS + their Adam state running free through all epochs, on the HIP path and
+    by the oracle in float64 (tests/envelope.py::replay_second_order_trace; in float32 that replay reproduces the reference's
+    recorded numbers bit for bit on the build box).  With the reference's RECORDED float32 numbers as the float32 leg:
+      * x^T H x, alpha, |g|, |H^-1 g|, the step norm, the KL and the logged actor loss: relative distance to float64 at most
+        3 x the largest the reference itself shows for that quantity over the epochs (+ 1e-6);
+      * the actor after the step, the critics before every epoch and at the end: max-norm and L2 gates (3 x + floor);
+      * the critic fit's per-minibatch losses: the loss envelope per epoch;
+      * the discrete decisions (optimisation case, accepted line-search candidate) equal.
+    The free-running replays below (5e-3) stay as trajectory checks."""
+    import envelope as E
+    from safepo.common.lagrange import Lagrange
+    z = np.load(os.path.join(golden_dir, f"{algo}_trace.npz"))
+    N, T, epochs = int(z["meta_num_envs"]), int(z["meta_T"]), int(z["meta_epochs"])
+    iters = int(z["meta_cfg_learning_iters"])
+    pol, eng = _cpo_engine(z, "init_sd_", dev, N, T, {"learning_iters": iters, "batch_size": int(z["e0_batch_size"]),
+                                                       "target_kl": float(z["meta_cfg_target_kl"])})
+    o64, crit64_final = E.replay_second_order_trace(z, algo, torch.float64)
+    lagrange = Lagrange(cost_limit=float(z["meta_arg_cost_limit"]),
+                        lagrangian_multiplier_init=float(z["meta_arg_lagrangian_multiplier_init"]),
+                        lagrangian_multiplier_lr=float(z["meta_arg_lagrangian_multiplier_lr"])) if algo in ("rcpo", "trpo_lag") else None
+    n_act = sum(v.numel() for v in pol.actor.state_dict().values())
+    n_crit = pol.theta.numel() - n_act
+    kinds = {k: [] for k in ("xHx", "alpha", "gradient_norm", "H_inv_g", "final_step_norm", "kl", "loss_actor")}
+    logged = {"xHx": "Misc_xHx", "alpha": "Misc_Alpha", "gradient_norm": "Misc_gradient_norm", "H_inv_g": "Misc_H_inv_g",
+              "final_step_norm": "Misc_FinalStepNorm", "kl": "Train_KL", "loss_actor": "Loss_Loss_actor"}
+    worst = {}
+    for e in range(epochs):
+        ref_before = np.concatenate([z[f"e{e}_sd_before_{k}"].reshape(-1) for k in pol.state_dict()])
+        worst[f"critics before {e}"] = E.gate_array(pol.theta[:n_crit].cpu().numpy(), ref_before[:n_crit], o64[e]["critics_before"],
+                                                    f"{algo}: critics before epoch {e}", rel_floor=1e-6)[0]
+        pol.load_state_dict({"actor." + k: torch.from_numpy(z[f"e{e}_sd_before_actor.{k}"].copy()) for k in pol.actor.state_dict()},
+                            strict=False)
+        _load_epoch_into_engine(z, e, eng, dev)
+        ep_costs = float(z[f"e{e}_get_stats_Metrics_EpCost"]) - float(z["meta_arg_cost_limit"])
+        if algo == "cpo":
+            eng.buffer.compute_gae(None)
+            out = eng.policy_update(ep_costs)
+        elif algo == "pcpo":
+            eng.buffer.compute_gae(None)
+            out = eng.pcpo_update(ep_costs)
+        else:
+            if lagrange is not None:
+                lagrange.update_lagrange_multiplier(float(z[f"e{e}_get_stats_Metrics_EpCost"]))
+                eng.buffer.compute_gae(lagrange.lagrangian_multiplier)
+                adv = eng.buffer.adv_mix.reshape(-1)
+            else:
+                eng.buffer.compute_gae(None)
+                adv = eng.buffer.data["adv_r"].reshape(-1)
+            out = eng.trust_region_update(adv, algo in ("trpo", "trpo_lag"))
+        r64 = o64[e]
+        if r64["accept"] is not None:
+            assert out["acceptance_step"] == r64["accept"] == int(z[f"e{e}_Misc_AcceptanceStep"]), (e, out["acceptance_step"], r64["accept"])
+        if r64["case"] is not None:
+            assert out["case"] == r64["case"], (e, out["case"], r64["case"])
+        for k in kinds:
+            kinds[k].append((f"epoch {e}", float(out[k]), float(z[f"e{e}_{logged[k]}"]), r64[k]))
+        act_ref = np.concatenate([z[f"e{e}_actor_after_{k}"].reshape(-1) for k in pol.actor.state_dict()])
+        worst[f"actor after {e}"] = E.gate_array(eng.theta_actor.cpu().numpy(), act_ref, r64["actor_after"],
+                                                 f"{algo}: actor after the step of epoch {e}", rel_floor=1e-6)[0]
+        perms = [torch.from_numpy(z[f"e{e}_perm{i}"].astype(np.int32)).to(dev) for i in range(iters)]
+        fit = eng.critic_fit(perm_fn=lambda it: perms[it])
+        eng.buffer.reset()
+        got = torch.cat(fit["losses"], 0).cpu().numpy()
+        worst[f"critic losses {e}"] = E.assert_loss_envelope(got, z[f"e{e}_mb_losses"][:, :2], r64["critic_losses"],
+                                                             f"{algo}: critic-fit losses of epoch {e}", window=len(got))
+    ref_final = np.concatenate([z[f"final_sd_{k}"].reshape(-1) for k in pol.state_dict()])
+    worst["critics final"] = E.gate_array(pol.theta[:n_crit].cpu().numpy(), ref_final[:n_crit], crit64_final, f"{algo}: critics at the end",
+                                          rel_floor=1e-6)[0]
+    for k, rows in kinds.items():
+        # (the logged actor loss is a mean over standardised advantages at ratio 1 -- zero up to rounding: measured against
+        #  the advantages' unit scale)
+        worst[k] = E.gate_scalars(rows, f"{algo} {k}", rel_floor=1e-6, scale=1.0 if k == "loss_actor" else None)
+    print(f"{algo}: yardstick report", {k: (f"{v:.2e}" if isinstance(v, float) else tuple(f"{x:.2e}" for x in v)) for k, v in worst.items()})
+
+
 def test_pcpo_update_vs_reference_main_trace(dev, golden_dir):
     """Replays the reference pcpo.main(): two CG solves, the projection step, line search (incl. an epoch that
     backtracks six times), actor parameters after the step, critic fit with the recorded shuffles."""
@@ -1107,25 +1203,34 @@ def test_cpo_critic_fit_two_launch_form_vs_oracle_and_one_launch_form(dev, monke
         return init, pol.theta.cpu().clone(), torch.cat(fit["losses"], 0).cpu()
     init, th_split, loss_split = run(True)
     _, th_one, loss_one = run(False)
-    np.testing.assert_allclose(loss_split.numpy(), loss_one.numpy(), rtol=2e-4, atol=2e-6)
-    _assert_params_close(th_split.numpy(), th_one.numpy(), 1e-3, iters * (M // 128), rtol=2e-4, atol=2e-6, what="split vs one launch")
-    ref = R.OraclePolicy(D, A)
-    ref.load_state_dict(init)
-    # the stale actor gradient: any vector of norm 50 on the actor's .grad (only its norm enters the critics' clip)
-    n_act = sum(p.numel() for p in ref.actor.parameters())
-    for p in ref.actor.parameters():
-        p.grad = torch.full_like(p, 50.0 / np.sqrt(n_act))
-    fitter = R.CriticFitter(ref)
-    want_losses = []
-    for it in range(iters):
-        pm = perms[it].long()
-        for k in range(M // 128):
-            idx = pm[k * 128:(k + 1) * 128]
-            want_losses.append(fitter.minibatch_step(obs[idx], tgt_r[idx], tgt_c[idx]))
-    np.testing.assert_allclose(loss_split.numpy(), np.asarray(want_losses), rtol=2e-3, atol=1e-5)
-    want = torch.cat([p.detach().reshape(-1) for p in ref.parameters()]).numpy()
-    n_crit = th_split.numel() - (n_act)
-    _assert_params_close(th_split.numpy()[:n_crit], want[:n_crit], 1e-3, iters * (M // 128), rtol=2e-3, atol=2e-5, what="split vs oracle")
+
+    def oracle(dtype):
+        ref = R.OraclePolicy(D, A)
+        ref.load_state_dict(init)
+        ref = ref.to(dtype)
+        # the stale actor gradient: any vector of norm 50 on the actor's .grad (only its norm enters the critics' clip)
+        n_act_ = sum(p.numel() for p in ref.actor.parameters())
+        for p in ref.actor.parameters():
+            p.grad = torch.full_like(p, 50.0 / np.sqrt(n_act_))
+        fitter = R.CriticFitter(ref)
+        o_, tr_, tc_ = obs.to(dtype), tgt_r.to(dtype), tgt_c.to(dtype)
+        want_losses = []
+        for it in range(iters):
+            pm = perms[it].long()
+            for k in range(M // 128):
+                idx = pm[k * 128:(k + 1) * 128]
+                want_losses.append(fitter.minibatch_step(o_[idx], tr_[idx], tc_[idx]))
+        return np.asarray(want_losses, np.float64), torch.cat([p.detach().reshape(-1) for p in ref.parameters()]).double().numpy(), n_act_
+    # both forms under the drift envelope (round 5: instead of rtol 2e-4 / 2e-3 with 0.1 % of the parameters exempt): float64 =
+    # the oracle's critic fit in double, float32 = the same in the reference's arithmetic
+    import envelope as E
+    l32, th32, n_act = oracle(torch.float32)
+    l64, th64, _ = oracle(torch.float64)
+    n_crit = th_split.numel() - n_act
+    np.testing.assert_allclose(loss_split.numpy()[:4], l32[:4], rtol=1e-5, atol=1e-6)      # first steps from identical weights
+    for name, th, ls in (("split", th_split, loss_split), ("one launch", th_one, loss_one)):
+        E.assert_loss_envelope(ls.numpy(), l32, l64, f"critic fit, {name} form: losses", window=len(l32))
+        E.assert_theta_envelope(th.numpy()[:n_crit], th32[:n_crit], th64[:n_crit], f"critic fit, {name} form: critics")
 
 
 def test_cpo_full_size_surrogate_gradients_and_fvp_fp64_yardstick(dev):
@@ -1367,13 +1472,16 @@ def test_limits_and_edge_shapes(dev):
     b.data["target_value_r"].copy_(tgt_r.view(1, M)); b.data["target_value_c"].copy_(tgt_c.view(1, M)); b.adv_mix.copy_(adv.view(1, M))
     ref = R.OraclePolicy(64, 16)
     ref.load_state_dict({k: v.cpu().clone() for k, v in pol.state_dict().items()})
+    ref0 = {k: v.clone() for k, v in ref.state_dict().items()}
     upd = R.PPOLagUpdater(ref, epochs=1)
     perm = torch.arange(M)
     lr = [upd.minibatch_step(obs[s:s + 64], act[s:s + 64], logp[s:s + 64] - 10, tgt_r[s:s + 64], tgt_c[s:s + 64], adv[s:s + 64])
           for s in range(0, M, 64)]
     losses = eng.learning_iter(perm.to(torch.int32).to(dev))
     np.testing.assert_allclose(losses.cpu().numpy(), np.asarray(lr), rtol=1e-4, atol=2e-6)
-    _assert_params_close(pol.theta.cpu().numpy(), R.flat_params(ref).numpy(), 3e-4, 2, what="64x16")
+    import envelope as E
+    _, t64 = E.oracle_trajectory(ref0, (obs, act, logp - 10, tgt_r, tgt_c, adv), perm, 64, 2, torch.float64, [2])
+    E.assert_theta_envelope(pol.theta.cpu().numpy(), R.flat_params(ref).numpy(), t64[2], "64x16: theta after 2 steps")
     # outside the envelope of the LDS-resident kernels: ROUTED to the wide path (tests/test_gpu_wide_dims.py), not refused;
     # the C entry points themselves still fail loudly when called with dims they are not built for
     from safepo.single_agent.cpo import CPOEngine, WideCPOEngine, make_engine, default_cfg as cpo_cfg
@@ -1550,10 +1658,14 @@ def test_kl_penalty_family_vs_reference_main_trace(dev, golden_dir, algo):
            "batch_size": int(z["e0_batch_size"]), "learning_iters": int(z["meta_cfg_learning_iters"]),
            "max_grad_norm": float(z["meta_cfg_max_grad_norm"])}
     eng = PPOLagEngine(pol, N, T, cfg, dev)
+    # the drift envelope of the PPO-Lagrangian trace test: T64 = the oracle replaying the recorded inputs in float64, T32 = the
+    # values the reference itself recorded (round 5: instead of rtol 2e-4 ... 5e-4 and a KL at 3e-3)
+    import envelope as E
+    o64, theta64_final = E.replay_kl_penalty_trace(z, algo, torch.float64)
+    ratios, kl_rows = [], []
     for e in range(epochs):
         ref_before = np.concatenate([z[f"e{e}_sd_before_{k}"].reshape(-1) for k in pol.state_dict()])
-        _assert_params_close(pol.theta.cpu().numpy(), ref_before, 3e-4, 40 * max(e, 1), rtol=5e-4, atol=5e-6,
-                             what=f"theta before epoch {e}")
+        ratios.append(E.assert_theta_envelope(pol.theta.cpu().numpy(), ref_before, o64[e]["theta_before"], f"theta before epoch {e}")[0])
         _load_epoch_into_engine(z, e, eng, dev)
         lam = float(z[f"e{e}_row_Train_LagragianMultiplier"])
         n_perm = len([k for k in z.files if k.startswith(f"e{e}_perm")])
@@ -1567,12 +1679,17 @@ def test_kl_penalty_family_vs_reference_main_trace(dev, golden_dir, algo):
             assert out["second_stage_stop_iter"] == int(z[f"e{e}_row_Train_SeconStageStopIter"])
             # parameters between the stages (recorded when the reference builds its second DataLoader)
             assert torch.isnan(torch.cat(out["second_stage_losses"], 0)[:, :2]).all()      # critics untouched
-        assert out["stop_iter"] == int(z[f"e{e}_row_Train_StopIter"]), (out["stop_iter"], out["kl"])
+        assert out["stop_iter"] == int(z[f"e{e}_row_Train_StopIter"]) == o64[e]["stop_iter"], (out["stop_iter"], out["kl"])
         got = torch.cat(out["losses"], 0).cpu().numpy()
-        np.testing.assert_allclose(got, z[f"e{e}_mb_losses"], rtol=2e-4, atol=3e-6)
-        assert out["kl"] == pytest.approx(float(z[f"e{e}_row_Train_KL"]), rel=3e-3, abs=1e-7)
+        ref = z[f"e{e}_mb_losses"]
+        if e == 0:
+            np.testing.assert_allclose(got[:3], ref[:3], rtol=1e-5, atol=1e-6)       # first steps from identical weights
+        ratios.append(E.assert_loss_envelope(got, ref, o64[e]["losses"], f"losses of epoch {e}", window=len(ref)))
+        kl_rows.append((f"epoch {e}", out["kl"], float(z[f"e{e}_row_Train_KL"]), o64[e]["kl"]))
+    print("KL yardstick (worst hip, reference):", E.gate_scalars(kl_rows, f"{algo} Train/KL", rel_floor=1e-6))
     ref_final = np.concatenate([z[f"final_sd_{k}"].reshape(-1) for k in pol.state_dict()])
-    _assert_params_close(pol.theta.cpu().numpy(), ref_final, 3e-4, 120, rtol=5e-4, atol=5e-6, what="final theta")
+    ratios.append(E.assert_theta_envelope(pol.theta.cpu().numpy(), ref_final, theta64_final, "final theta")[0])
+    print(f"{algo}: drift envelope ratios (<= 1 passes):", np.round(ratios, 3))
 
 
 @pytest.mark.parametrize("M,D,A,actor_only", [(192, 60, 8, False), (150, 17, 6, True), (100, 100, 3, True),
@@ -1607,39 +1724,56 @@ def test_kl_penalty_minibatch_steps_vs_oracle(dev, M, D, A, actor_only):
     b.data["target_value_c"].copy_(tgt_c.view(1, M))
     eng.mean_old.copy_(old_mean); eng.std_old.copy_(old_std[0] if old_std.dim() > 1 else old_std)
     perm = torch.randperm(M, generator=torch.Generator().manual_seed(3))
-    # oracle: 5 earlier actor-only steps move the actor's Adam clock ahead (zero gradients leave the moments at 0)
-    upd = R.KLPenaltyUpdater(ref)
-    for _ in range(5):
-        upd.opt_a.zero_grad()
-        for prm in ref.actor.parameters():
-            prm.grad = torch.zeros_like(prm)
-        upd.opt_a.step()
     eng.adam_step_actor_extra = 5
     theta0 = pol.theta.clone()
-    ref_losses, n_masked = [], 0
-    os_full = old_std.expand(M, A) if old_std.dim() == 1 else old_std
-    for s0 in range(0, M, 64):
-        idx = perm[s0:s0 + 64]
-        with torch.no_grad():
-            kl_i = torch.distributions.kl_divergence(ref.actor(obs[idx]), torch.distributions.Normal(old_mean[idx], os_full[idx])).sum(-1)
-            n_masked += int((kl_i > kl_bound).sum())
-        if actor_only:
-            l = upd.cup_second_stage_step(obs[idx], act[idx], logp[idx], adv[idx], old_mean[idx], os_full[idx],
-                                          0.37 / ((1 - 0.99 * 0.95) / (1 - 0.99)), 0.99)
-            ref_losses.append([np.nan, np.nan, l])
-        else:
-            ref_losses.append(list(upd.focops_step(obs[idx], act[idx], logp[idx], tgt_r[idx], tgt_c[idx], adv[idx],
-                                                   old_mean[idx], os_full[idx], kl_bound)))
+    ref0 = {k: v.clone() for k, v in ref.state_dict().items()}
+
+    def oracle(dtype):
+        """One pass in `dtype`; 5 earlier actor-only steps move the actor's Adam clock ahead (zero gradients leave the moments
+        at 0).  Returns (losses, flat parameters, number of masked samples, smallest |KL - bound| met)."""
+        rp = R.OraclePolicy(D, A)
+        rp.load_state_dict(ref0)
+        rp = rp.to(dtype)
+        upd = R.KLPenaltyUpdater(rp)
+        for _ in range(5):
+            upd.opt_a.zero_grad()
+            for prm in rp.actor.parameters():
+                prm.grad = torch.zeros_like(prm)
+            upd.opt_a.step()
+        o_, a_, lp_, tr_, tc_, ad_, om_ = (t.to(dtype) for t in (obs, act, logp, tgt_r, tgt_c, adv, old_mean))
+        os_full = (old_std.expand(M, A) if old_std.dim() == 1 else old_std).to(dtype)
+        out, n_masked, margin = [], 0, float("inf")
+        for s0 in range(0, M, 64):
+            idx = perm[s0:s0 + 64]
+            with torch.no_grad():
+                kl_i = torch.distributions.kl_divergence(rp.actor(o_[idx]), torch.distributions.Normal(om_[idx], os_full[idx])).sum(-1)
+                n_masked += int((kl_i > kl_bound).sum())
+                margin = min(margin, float((kl_i - kl_bound).abs().min()))
+            if actor_only:
+                l = upd.cup_second_stage_step(o_[idx], a_[idx], lp_[idx], ad_[idx], om_[idx], os_full[idx],
+                                              0.37 / ((1 - 0.99 * 0.95) / (1 - 0.99)), 0.99)
+                out.append([np.nan, np.nan, l])
+            else:
+                out.append(list(upd.focops_step(o_[idx], a_[idx], lp_[idx], tr_[idx], tc_[idx], ad_[idx], om_[idx], os_full[idx], kl_bound)))
+        return np.asarray(out, np.float64), R.flat_params(rp).double().numpy(), n_masked, margin
+    ref_losses, th32, n_masked, margin = oracle(torch.float32)
+    l64, th64, n_masked64, _ = oracle(torch.float64)
     if not actor_only:
         assert 0 < n_masked < M, n_masked             # the indicator is exercised on both sides
+        assert n_masked == n_masked64 and margin > 1e-6, (n_masked, n_masked64, margin)     # ... and no sample sits ON the bound
     losses = eng.learning_iter_ex(perm.to(torch.int32).to(dev), torch.as_tensor(adv).to(dev).contiguous(),
                                   _abi.ACTOR_LOSS_KL_PENALTY, kl_bound, pg_coef, actor_only)
     eng.check_sync_error()
     got = losses.cpu().numpy()
-    np.testing.assert_allclose(got, np.asarray(ref_losses), rtol=2e-4, atol=3e-6, equal_nan=True)
     n_steps = (M + 63) // 64
-    _assert_params_close(pol.theta.cpu().numpy(), R.flat_params(ref).numpy(), 3e-4, n_steps, rtol=5e-4, atol=5e-6,
-                         what="theta after one pass")
+    np.testing.assert_allclose(got[:1], ref_losses[:1], rtol=1e-5, atol=1e-6, equal_nan=True)       # first step from identical weights
+    # the pass under the drift envelope (round 5: instead of rtol 2e-4 / 5e-4 with 0.1 % of the parameters exempt)
+    import envelope as E
+    cols = [2] if actor_only else [0, 1, 2]
+    # (floor: the KL-penalty actor loss is a difference of two means of O(1) terms -- rounding is relative to the terms, not to
+    #  the difference; 3e-6 of the loss is still a third of north_star's 1e-5)
+    E.assert_loss_envelope(got[:, cols], ref_losses[:, cols], l64[:, cols], "KL-penalty pass: losses", window=n_steps, floor_rel=3e-6)
+    E.assert_theta_envelope(pol.theta.cpu().numpy(), th32, th64, "KL-penalty pass: theta")
     if actor_only:
         off = int(_abi.load().spo_param_offset(D, A, 2))
         assert torch.equal(pol.theta[:off], theta0[:off])        # critics untouched
@@ -2837,10 +2971,20 @@ def test_cpo_data_parallel_two_ranks_one_gpu(dev, tmp_path, shape):
     res = json.load(open(out))
     assert res["engine"] == ("CPOEngine" if shape == "60,8,64,64" else "WideCPOEngine"), res
     assert res["p2p"] == (shape != "60,20,96,96") and res["replicas_identical"] and res["finite"], res
-    assert res["case"][0] == res["case"][1] and res["acceptance_step"][0] == res["acceptance_step"][1], res
+    assert len(set(res["case"])) == 1 and len(set(res["acceptance_step"])) == 1, res      # two ranks, one rank, oracle f32 / f64
+    # round 5: both HIP runs under the fp64 yardstick (the oracle's step on the same rows in float32 and float64, computed by
+    # the worker) instead of a 2e-3 comparison with each other
+    import envelope as E
     for k in ("xHx", "gradient_norm", "H_inv_g", "alpha", "final_step_norm", "kl"):
-        assert res[k][0] == pytest.approx(res[k][1], rel=2e-3), (k, res)
-    assert res["actor_frac_outside"] <= 2e-3 and res["actor_max_abs_diff"] < 1e-3, res
+        two, one, f32, f64 = res[k]
+        E.gate_scalars([("two ranks", two, f32, f64), ("one rank", one, f32, f64)], f"cpo data-parallel {shape}: {k}", rel_floor=2e-6)
+    two, one, f32, f64 = res["loss_actor"]
+    E.gate_scalars([("two ranks", two, f32, f64), ("one rank", one, f32, f64)], f"cpo data-parallel {shape}: loss_actor", rel_floor=2e-6, scale=1.0)
+    ad = res["actor_dist_to_f64"]
+    for who in ("two_ranks", "one_rank"):
+        assert ad[who][0] <= 3.0 * ad["f32"][0] + 1e-6 * ad["scale"], (who, ad)
+        assert ad[who][1] <= 3.0 * ad["f32"][1] + 1e-7 * ad["scale"] * np.sqrt(ad["n"]), (who, ad)
+    print("cpo data-parallel", shape, "actor |.-f64| max / L2:", ad)
 
 
 def test_full_size_learning_iteration_is_deterministic(dev):
@@ -3009,6 +3153,7 @@ def test_wide_minibatch_steps_vs_oracle(dev, D, A, hidden, batch, steps, cfg_kw)
     the steps; [128, 128] at the default batch of 64 and [1024, 1024, 512] at 8 192 rows with isaac_gym_specific_cfg's options."""
     from safepo.common.engine import WidePPOLagEngine
     pol, ref = _wide_pair(D, A, hidden, dev, seed=3)
+    ref0 = {k: v.clone() for k, v in ref.state_dict().items()}
     M = batch * steps
     cfg = {"hidden_sizes": hidden, "gamma": 0.99, "target_kl": 0.02, "batch_size": batch, "learning_iters": 1, "max_grad_norm": 40.0}
     cfg.update(cfg_kw)
@@ -3025,7 +3170,10 @@ def test_wide_minibatch_steps_vs_oracle(dev, D, A, hidden, batch, steps, cfg_kw)
         ii = perm[k * batch:(k + 1) * batch]
         want.append(upd.minibatch_step(obs[ii], act[ii], logp[ii], tgt_r[ii], tgt_c[ii], adv[ii]))
     np.testing.assert_allclose(losses, np.asarray(want), rtol=1e-5, atol=2e-6)
-    _assert_params_close(pol.theta.cpu().numpy(), R.flat_params(ref).numpy(), 3e-4, steps, rtol=2e-4, atol=2e-6, what=f"wide {hidden}")
+    import envelope as E
+    _, t64 = E.oracle_trajectory(ref0, problem, perm, batch, steps, torch.float64, [steps], max_grad_norm=cfg["max_grad_norm"],
+                                 hidden_sizes=hidden, **kw)
+    E.assert_theta_envelope(pol.theta.cpu().numpy(), R.flat_params(ref).numpy(), t64[steps], f"wide {hidden}: theta after {steps} steps")
     assert eng.adam_step == steps
 
 
