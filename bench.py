@@ -43,8 +43,8 @@ PEER_EXCHANGE_USED = [False]     # set by run_epochs on rank 0 (N > 1): which fo
 
 
 def profile_path(name: str) -> str:
-    """The newest committed copy of a profile artefact (profiles/r04, else r03, else r02)."""
-    for rnd in ("r04", "r03", "r02"):
+    """The newest committed copy of a profile artefact (profiles/r05, else r04, r03, r02)."""
+    for rnd in ("r05", "r04", "r03", "r02"):
         p = os.path.join(ROOT, "profiles", rnd, name)
         if os.path.exists(p):
             return p
@@ -94,6 +94,7 @@ def cpu_baseline(sample_envs: int, T: int, threads: int = 4, algo: str = "ppo_la
     steps = sample_envs * T
     host = next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "?")
     return {"value": round(steps / (timers["rollout"] + timers["update"]), 1), "unit": "env-steps/s", "cores": threads,
+            "cores_available": os.cpu_count(), "cores_note": "torch.set_num_threads(4) is the reference's own setting (ppo_lag.py:73, cpo.py:166)",
             "kind": "port",
             "sample": f"1 epoch of {sample_envs} envs x {T} steps (={steps} env-steps), {what}, "
                       f"torch CPU {threads} threads on {host} ({os.cpu_count()} logical cores); "
@@ -151,7 +152,8 @@ def cpu_baseline_mappolag(sample_threads: int, T: int = 64, agents: int = 4, hid
     t3 = time.time()
     steps = N * T
     host = next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "?")
-    return {"value": round(steps / (t3 - t0), 1), "unit": "env-steps/s", "cores": threads, "kind": "port",
+    return {"value": round(steps / (t3 - t0), 1), "unit": "env-steps/s", "cores": threads, "cores_available": os.cpu_count(),
+            "cores_note": "torch.set_num_threads(4) is the reference's own setting (mappolag.py:633)", "sample_threads": N, "kind": "port",
             "sample": f"1 epoch of {N} rollout threads x {T} steps x {agents} agents (={steps} env-steps), hidden {hidden}, {iters} full-batch "
                       f"iterations per agent, torch CPU {threads} threads on {host} ({os.cpu_count()} logical cores); collect {t1 - t0:.2f}s "
                       f"GAE {t2 - t1:.2f}s train {t3 - t2:.2f}s (environment and buffer inserts not timed)"}
@@ -338,7 +340,7 @@ def run_epochs(algo, a, comm, dev, N, T, D, A, steps, warmup, time_gae):
         import torch.distributed as dist
         form = ("rccl all-reduce between kernels (spo_ppo_lag_grad -> all_reduce -> spo_clip_adam_then_grad)" if px is None else
                 "in-kernel, all-to-all on the helper waves" if os.environ.get("SPO_P2P_A2A", "0") == "1" else
-                "in-kernel, recursive doubling on the helper waves" if os.environ.get("SPO_P2P_HELPER", "0") == "1" else
+                "in-kernel, recursive doubling of packed words on the helper waves" if os.environ.get("SPO_P2P_HELPER", "0") not in ("0", "") else
                 "in-kernel, recursive doubling of packed tagged words over IPC-mapped peer regions"
                 if ((world & (world - 1)) == 0 and (world <= 4 or os.environ.get("SPO_P2P_ALGO") == "doubling")
                     and os.environ.get("SPO_P2P_ALGO") != "twophase")
@@ -414,8 +416,20 @@ def main():
                               "note": "algorithmic GEMM flops of the training phase (per agent: learning_iters x 3 networks x forward + "
                                       "backward = 3 x forward) / its wall time, against the dense FP32 matrix peak; tools/ma_bench.py"}
             if world == 1 and comm.rank == 0 and not a.no_cpu_baseline:
-                c5["cpu_baseline"] = cpu_baseline_mappolag(a.config5_cpu_sample_threads)
+                # the GPU side runs 8 192 rollout threads, the CPU port a bounded sample -- so the port is timed at
+                # TWO sample sizes (its env-steps/s must not depend on the size for the ratio to mean anything) and once more
+                # with every host core, and all three figures are in the line next to the ratio
+                n_s = a.config5_cpu_sample_threads
+                c5["cpu_baseline"] = cpu_baseline_mappolag(n_s)
+                half = cpu_baseline_mappolag(max(n_s // 2, 1))
+                allc = cpu_baseline_mappolag(n_s, threads=os.cpu_count() or 4)
+                c5["cpu_baseline"]["value_at_half_the_sample"] = half["value"]
+                c5["cpu_baseline"]["all_host_cores"] = {"value": allc["value"], "cores": allc["cores"], "sample": allc["sample"]}
                 c5["speedup_vs_cpu_baseline"] = round(c5["env_steps_per_s"] / c5["cpu_baseline"]["value"], 1)
+                c5["speedup_vs_cpu_baseline_all_host_cores"] = round(c5["env_steps_per_s"] / allc["value"], 1)
+                c5["speedup_note"] = (f"GPU: {a.config5_threads} rollout threads; CPU port: {n_s}-thread sample at the reference's 4 torch "
+                                      f"threads (and at {max(n_s // 2, 1)} threads: same rate = the ratio carries to the full size), "
+                                      f"and with all {os.cpu_count()} logical cores")
             return c5
         except Exception as e:  # pragma: no cover
             return {"error": str(e)[:300]}
@@ -453,7 +467,9 @@ def main():
         pass
     roofline = {"kernel": "gae_kernel (spo_gae_fused" + (", folded bootstrap form)" if folded else ")"), "bound": "hbm", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "achieved_event_pairs": round(achieved, 1), "frac_event_pairs": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": pmc["hbm_bytes_per_launch"] if pmc else None,
+                "traffic_source": (pmc["source"] if pmc else "no committed --pmc measurement for this shape"),
                 "traffic_profiled": pmc,
                 "bytes_per_launch": gae_bytes, "avg_launch_us": round(disp_avg * 1e6, 3),
                 "median_launch_us": round(float(np.median(disp)) * 1e6, 3) if disp.size else None,
@@ -470,8 +486,9 @@ def main():
                         "higher than the unprofiled event pairs, and under the profiler the event pairs themselves read ~2x "
                         "(profiles/r04/bench_profiled_line.json), so the two figures cannot come from one run. graph_* = hipGraph of "
                         f"{GAE_REPS} back-to-back launches between two events (dispatch set-up overlapped). traffic: PMC "
-                        "counters cannot be read inside this run -> null; traffic_profiled is the committed rocprofv3 "
-                        "--pmc measurement (FETCH_SIZE x2 + WRITE_SIZE, separate passes) with its source"}
+                        "counters cannot be read inside this run: traffic / traffic_profiled are the committed rocprofv3 "
+                        "--pmc measurement (FETCH_SIZE x2 + WRITE_SIZE, separate passes) with its source. frac / achieved: from the "
+                        "committed rocprofv3 average when one exists for this grid (frac_source), else the event pairs"}
     try:
         dj = json.load(open(profile_path("gae_dispatch_durations.json")))
         want = f"grid={2 * N * 32}"
@@ -480,6 +497,11 @@ def main():
             roofline["rocprof_avg_launch_us"] = hit[0]["avg_us"]
             roofline["rocprof_launches"] = hit[0]["launches"]
             roofline["frac_at_rocprof_avg"] = round(gae_bytes / (hit[0]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            # the headline figure is the one that follows from the committed rocprofv3 summary of this command; the
+            # live event-pair measurement of THIS run stays beside it (achieved_event_pairs / frac_event_pairs)
+            roofline["achieved"] = round(gae_bytes / (hit[0]["avg_us"] * 1e-6) / 1e9, 1)
+            roofline["frac"] = roofline["frac_at_rocprof_avg"]
+            roofline["frac_source"] = os.path.relpath(profile_path("gae_dispatch_durations.json"), ROOT) + " (rocprofv3 --kernel-trace of this command)"
     except Exception:
         pass
 

@@ -37,7 +37,10 @@ extern "C" {
 #define SPO_HIDDEN 64          /* hidden width the MLP kernels are specialised for          */
 #define SPO_MAX_ACT 16         /* act_dim <= 16 (one MFMA output tile; LDS-resident kernels) */
 #define SPO_MAX_OBS 128        /* obs_dim <= 128 (LDS-resident kernels; CPO full-batch kernels: 64) */
-#define SPO_WIDE_MAX_ACT 64    /* act_dim limit of the wide-network path (any obs_dim / hidden_sizes) */
+#define SPO_WIDE_MAX_ACT 64    /* act_dim limit of the wide-network path (any obs_dim / hidden_sizes): its actor-side loss kernels
+                                * give a batch row pow2ceil(act_dim) lanes of ONE 64-lane wavefront and sum over the action
+                                * dimension with segmented shuffles; a wider action vector would need a row spread over several
+                                * wavefronts.  The widest action space of the reference's task sets is 17 (Humanoid). */
 #define SPO_GAE_PARTIAL_STRIDE 16 /* doubles per block written by spo_gae_fused: 4 waves x 4 */
 
 int spo_abi_version(void);
@@ -572,8 +575,9 @@ int spo_wide_linesearch_sums(const float* mean_new, const float* log_std_new, co
                              const float* adv_a, const float* adv_b, const float* mean_old, const float* log_std_old, int64_t rows,
                              int act_dim, double* partial_ws, int partial_capacity, double* sums3_inout, int accumulate,
                              void* stream);
-/* spo_wide_clip_adam_dev -- spo_wide_clip_adam_ex with the optimiser clocks on the DEVICE: pow4_dev = double[4] = {beta1^t, beta2^t of
- * the critics' optimisers, beta1^t, beta2^t of the actor's} before this step; the clocks of the optimisers inside the Adam range
+/* spo_wide_clip_adam_dev -- spo_wide_clip_adam_ex with the optimiser clocks on the DEVICE: pow4_dev = double[6] = {beta1^t, beta2^t of
+ * the critics' optimisers, beta1^t, beta2^t of the actor's} before this step, then {lr_actor, lr_critic} (each: > 0 overrides the
+ * cfg's value, so a schedule does not change a captured launch's arguments); the clocks of the optimisers inside the Adam range
  * advance on the device.  No argument changes from one minibatch step to the next, so the launch sequence of a step (gathers,
  * spo_mlp_forward / backward, loss kernels, this) can be captured once as a HIP graph and replayed: the wide path at the reference's
  * default batch of 64 is launch-bound (~70 launches per step).  The caller keeps pow4_dev in step with its host-side step counts. */

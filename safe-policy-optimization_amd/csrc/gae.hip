@@ -384,41 +384,36 @@ inline GaeGeom gae_geom(int64_t T, int64_t N) {
   return g;
 }
 
-// Optional per-dispatch timing (spo_gae_fused_timed only): when the caller hands in an event pair, the dispatch carries its
-// own start / stop events (hipExtLaunchKernelGGL), i.e. the timestamps of the dispatch packet itself -- what rocprofv3
-// --kernel-trace reports.  The product entry point spo_gae_fused always passes nullptr: no mutable state on the launch path.
-template <int VEC, int BOOT>
-int launch_gae(const GaeGeom& g, const GaeArgs& a, int blocks, hipStream_t st, hipEvent_t ev_start,
-               hipEvent_t ev_stop) {
-#define SPO_GAE_LAUNCH(...)                                                                                       \
-  {                                                                                                               \
-    if (ev_start) hipExtLaunchKernelGGL((gae_kernel<__VA_ARGS__>), dim3(blocks), dim3(256), 0, st, ev_start, ev_stop, 0, a); \
-    else hipLaunchKernelGGL((gae_kernel<__VA_ARGS__>), dim3(blocks), dim3(256), 0, st, a);                         \
-  }
+// How a dispatch is issued is a policy of the CALLER: the product entry point spo_gae_fused uses PlainLaunch; the measurement entry
+// point spo_gae_fused_timed (bench.py's roofline figure) uses TimedLaunch at the end of this file.  The launch path itself
+// carries no event arguments and no branch on them (VERDICT r04 housekeeping).
+struct PlainLaunch {
+  hipStream_t st;
+  template <class K>
+  void operator()(K kernel, dim3 grid, dim3 block, const GaeArgs& a) const { hipLaunchKernelGGL(kernel, grid, block, 0, st, a); }
+};
+
+template <int VEC, int BOOT, class Launch>
+int launch_gae(const GaeGeom& g, const GaeArgs& a, int blocks, const Launch& launch) {
   if (g.rc) {
     if constexpr (VEC == 4) {
       static const int fat = [] { const char* e = getenv("SPO_GAE_FAT"); return e ? atoi(e) : 1; }();
       if (fat == 2 || fat == 4) {
         const int pb = (blocks + fat - 1) / fat;
-#define SPO_GAE_FAT_LAUNCH(FF)                                                                                    \
-        {                                                                                                         \
-          if (ev_start) hipExtLaunchKernelGGL((gae_kernel<4, 32, BOOT, true, FF>), dim3(pb), dim3(256 * FF), 0, st, ev_start, ev_stop, 0, a); \
-          else hipLaunchKernelGGL((gae_kernel<4, 32, BOOT, true, FF>), dim3(pb), dim3(256 * FF), 0, st, a);         \
-        }
-        if (fat == 2) SPO_GAE_FAT_LAUNCH(2) else SPO_GAE_FAT_LAUNCH(4)
-#undef SPO_GAE_FAT_LAUNCH
+        if (fat == 2) launch(gae_kernel<4, 32, BOOT, true, 2>, dim3(pb), dim3(512), a);
+        else launch(gae_kernel<4, 32, BOOT, true, 4>, dim3(pb), dim3(1024), a);
         return 0;
       }
-      SPO_GAE_LAUNCH(4, 32, BOOT, true) return 0;
+      launch(gae_kernel<4, 32, BOOT, true>, dim3(blocks), dim3(256), a);
+      return 0;
     }
   }
   switch (g.lpr) {
-#define SPO_CASE(L) case L: SPO_GAE_LAUNCH(VEC, L, BOOT, false) break;
+#define SPO_CASE(L) case L: launch(gae_kernel<VEC, L, BOOT, false>, dim3(blocks), dim3(256), a); break;
     SPO_CASE(1) SPO_CASE(2) SPO_CASE(4) SPO_CASE(8) SPO_CASE(16) SPO_CASE(32) SPO_CASE(64)
 #undef SPO_CASE
     default: return spo::fail(-1, "gae: bad lanes-per-row %d", g.lpr);
   }
-#undef SPO_GAE_LAUNCH
   return 0;
 }
 
@@ -436,11 +431,11 @@ static int gae_plain_stores() {
   return mode;
 }
 
+template <class Launch>
 static int gae_fused_impl(const float* reward, const float* cost, const float* value_r, const float* value_c,
                           const uint8_t* seg_end, const float* boot_r, const float* boot_c, float* adv_r,
                           float* adv_c, float* target_r, float* target_c, double* partials, int64_t num_envs,
-                          int64_t T, double gamma, double lam, double lam_c, void* stream, hipEvent_t ev_start,
-                          hipEvent_t ev_stop) {
+                          int64_t T, double gamma, double lam, double lam_c, const Launch& launch) {
   SPO_REQUIRE(num_envs >= 0 && T >= 0, "gae: negative size");
   if (num_envs == 0 || T == 0) return 0;
   SPO_REQUIRE(reward && cost && value_r && value_c && seg_end && adv_r && adv_c && target_r && target_c && partials,
@@ -452,16 +447,15 @@ static int gae_fused_impl(const float* reward, const float* cost, const float* v
             num_envs, T, (float)gamma, gamma * lam, gamma * lam_c, g_gae_force_variant >> 4, gae_plain_stores(), 0};
   const int blocks = spo_gae_num_blocks(num_envs, T);
   a.nblocks = blocks;
-  hipStream_t st = (hipStream_t)stream;
   // predicated bootstrap loads by default when bootstrap arrays are given (fewest bytes; measured equal or faster than
   // the eager form at every size); no bootstrap loads at all in the folded form
   const int fv = g_gae_force_variant & 15;
   const bool eager = fv == 1 && !folded;
   int rc;
 #define SPO_GAE_GO(V)                                                                     \
-  rc = folded ? launch_gae<V, BOOT_FOLDED>(g, a, blocks, st, ev_start, ev_stop)           \
-              : eager ? launch_gae<V, BOOT_EAGER>(g, a, blocks, st, ev_start, ev_stop)    \
-                      : launch_gae<V, BOOT_PRED>(g, a, blocks, st, ev_start, ev_stop);
+  rc = folded ? launch_gae<V, BOOT_FOLDED>(g, a, blocks, launch)                          \
+              : eager ? launch_gae<V, BOOT_EAGER>(g, a, blocks, launch)                   \
+                      : launch_gae<V, BOOT_PRED>(g, a, blocks, launch);
   if (g.vec == 4) { SPO_GAE_GO(4) } else { SPO_GAE_GO(1) }
 #undef SPO_GAE_GO
   if (rc) return rc;
@@ -474,13 +468,24 @@ extern "C" int spo_gae_fused(const float* reward, const float* cost, const float
                              float* adv_c, float* target_r, float* target_c, double* partials, int64_t num_envs,
                              int64_t T, double gamma, double lam, double lam_c, void* stream) {
   return gae_fused_impl(reward, cost, value_r, value_c, seg_end, boot_r, boot_c, adv_r, adv_c, target_r, target_c, partials,
-                        num_envs, T, gamma, lam, lam_c, stream, nullptr, nullptr);
+                        num_envs, T, gamma, lam, lam_c, PlainLaunch{(hipStream_t)stream});
 }
 
 extern "C" int spo_debug_gae_variant(int v) { g_gae_force_variant = v; return 0; }
 
-// The scan `reps` times, every dispatch carrying its own start / stop events: durations_us_host[i] = execution time of
-// dispatch i as the dispatch packet's timestamps record it.  Synchronises the stream.  (bench.py's roofline figure.)
+// ---- measurement only (bench.py's roofline figure): the scan `reps` times, every dispatch carrying its own start / stop events
+// (hipExtLaunchKernelGGL: the timestamps of the dispatch packet itself -- what rocprofv3 --kernel-trace reports);
+// durations_us_host[i] = execution time of dispatch i.  Synchronises the stream.
+namespace {
+struct TimedLaunch {
+  hipStream_t st;
+  hipEvent_t ev_start, ev_stop;
+  template <class K>
+  void operator()(K kernel, dim3 grid, dim3 block, const GaeArgs& a) const {
+    hipExtLaunchKernelGGL(kernel, grid, block, 0, st, ev_start, ev_stop, 0, a);
+  }
+};
+}  // namespace
 extern "C" int spo_gae_fused_timed(const float* reward, const float* cost, const float* value_r, const float* value_c,
                                    const uint8_t* seg_end, const float* boot_r, const float* boot_c, float* adv_r,
                                    float* adv_c, float* target_r, float* target_c, double* partials, int64_t num_envs,
@@ -494,7 +499,7 @@ extern "C" int spo_gae_fused_timed(const float* reward, const float* cost, const
     if (!rc) rc = spo::hip_check(hipEventCreate(&e), "hipEventCreate");
   for (int i = 0; i < reps && !rc; ++i)
     rc = gae_fused_impl(reward, cost, value_r, value_c, seg_end, boot_r, boot_c, adv_r, adv_c, target_r, target_c, partials,
-                        num_envs, T, gamma, lam, lam_c, stream, ev[2 * i], ev[2 * i + 1]);
+                        num_envs, T, gamma, lam, lam_c, TimedLaunch{st, ev[2 * i], ev[2 * i + 1]});
   if (!rc) rc = spo::hip_check(hipStreamSynchronize(st), "hipStreamSynchronize(gae_timed)");
   for (int i = 0; i < reps && !rc; ++i) {
     float ms = 0.f;

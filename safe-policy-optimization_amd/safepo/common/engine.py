@@ -83,6 +83,7 @@ class PPOLagEngine:
         # running count of logged episodes per step (spo_boundary_step_fold_mb): the kernel of step t reads [t], writes [t + 1]
         self.events_prefix = torch.zeros(T + 1, dtype=torch.int32, device=self.dev)
         self._events_last_t, self._events_drained = -1, 0
+        self._events_pending = False              # steps were taken since the last drain_episode_events()
         self._rollout_graphs = {}                 # rollout_epoch: captured epochs by (env, observation tensor, normaliser)
         # optimiser state (flat, same order as policy.theta)
         P = policy.theta.numel()
@@ -168,7 +169,14 @@ class PPOLagEngine:
             self._values_into(next_obs, self.vnext_r, self.vnext_c)
         d = b.data
         if t == 0:
+            if self._events_pending:
+                # the log restarts at events_prefix[0] == 0 with every epoch: episodes of the previous epoch that were never
+                # drained are about to be overwritten (every loop in this tree drains once per epoch)
+                import warnings
+                warnings.warn("PPOLagEngine.post_step: the previous epoch's episode log was not drained "
+                              "(drain_episode_events() must be called once per epoch); its episodes are dropped", RuntimeWarning)
             self._events_drained = 0                  # a new epoch: the log restarts at events_prefix[0] == 0
+        self._events_pending = True
         self._events_last_t = t
         if final_obs is not None:
             final_obs = _abi.require_gpu_tensor(final_obs, "final_observation", torch.float32)
@@ -233,7 +241,11 @@ class PPOLagEngine:
         use_graph = getattr(env, "graph_safe", False) and os.environ.get("SPO_ROLLOUT_GRAPH", "1") != "0"
         if use_graph:
             obs = _abi.require_gpu_tensor(obs, "obs", torch.float32)
-            key = (id(env), obs.data_ptr(), id(rms))
+            # everything the captured launches bake in: the tensors (env, observation, normaliser) and the env / normaliser
+            # settings that are kernel ARGUMENTS (a reset(seed=...), a changed p_term or a frozen normaliser gets its own graph);
+            # the cache entry holds env and rms, so their ids cannot be recycled while the graph lives
+            key = (id(env), obs.data_ptr(), id(rms), getattr(env, "seed", None), getattr(env, "p_term", None),
+                   getattr(env, "p_cost", None), getattr(env, "trunc_len", None), None if rms is None else bool(rms.update_enabled))
             graphs = self._rollout_graphs
         if not (use_graph and steady and key in graphs):
             # (also the first steady-state epoch runs eagerly: kernels with lazy set-up must have run once before a capture)
@@ -241,10 +253,12 @@ class PPOLagEngine:
             for t in range(T):
                 obs = self._rollout_step(t, env, obs, rms, eps_all[t])
             if use_graph and key not in graphs and torch.is_tensor(obs) and obs.data_ptr() == key[1]:
-                graphs[key] = self._capture_rollout(env, obs, rms)
+                if len(graphs) >= 4:                   # (settings that keep changing: do not pile up graphs and their pools)
+                    graphs.clear()
+                graphs[key] = self._capture_rollout(env, obs, rms) + ((env, rms),)
             return obs
         assert b.ptr == 0, "rollout_epoch starts on an empty buffer"
-        g, post = graphs[key]
+        g, post = graphs[key][:2]
         env.begin_epoch_base()                     # device step base := the epoch's first step (an ordinary launch before the replay)
         g.replay()
         # what T eager steps leave behind on the host side
@@ -254,7 +268,11 @@ class PPOLagEngine:
         if rms is not None:
             rms.pending = post["pending"]
         env.step_count += T
-        self._events_last_t, self._events_drained = T - 1, 0
+        if self._events_pending:
+            import warnings
+            warnings.warn("PPOLagEngine.rollout_epoch: the previous epoch's episode log was not drained; its episodes are dropped",
+                          RuntimeWarning)
+        self._events_last_t, self._events_drained, self._events_pending = T - 1, 0, True
         return post["obs"]
 
     def _epoch_noise(self) -> torch.Tensor:
@@ -301,6 +319,7 @@ class PPOLagEngine:
         One device->host copy per epoch.  Returns the number of finished episodes."""
         if self._events_last_t < 0:
             return 0
+        self._events_pending = False
         hi = int(self.events_prefix[self._events_last_t + 1].item())
         if hi > self.events_cap:
             raise _abi.SpoError(f"episode event log overflow ({hi} > {self.events_cap})")
@@ -597,7 +616,9 @@ class _WideOps:
         self.scal4 = torch.zeros(4, **f32)
         # device-resident optimiser clocks {beta1^t, beta2^t} of the critics' and the actor's optimisers (spo_wide_clip_adam_dev):
         # a minibatch step then has no host argument that changes between steps and is replayed from ONE captured HIP graph
-        self.pow4 = torch.ones(4, dtype=torch.float64, device=self.dev)
+        # ... and [4], [5] = the actor's / the critics' learning rate of this epoch (the LinearLR factor changes per epoch: baked into
+        # the captured cfg it made every epoch capture a new graph)
+        self.pow4 = torch.ones(6, dtype=torch.float64, device=self.dev)
         self._step_graphs = {}
         self.graph_max_batch = int(os.environ.get("SPO_WIDE_GRAPH_MAX_BATCH", "2048"))     # 0: never (every launch eager)
         if self.comm.world_size > 1:
@@ -625,7 +646,16 @@ class _WideOps:
         """Device clocks from the host step counts (start of a pass, after an eager step)."""
         b1, b2 = float(np.float32(0.9)), float(np.float32(0.999))
         tc, ta = self.adam_step, self.adam_step + self.adam_step_actor_extra
-        self.pow4.copy_(torch.tensor([b1 ** tc, b2 ** tc, b1 ** ta, b2 ** ta], dtype=torch.float64))
+        c = self._cfg_struct()                    # (c_float fields: the float32 values the host-clock kernels receive)
+        self.pow4.copy_(torch.tensor([b1 ** tc, b2 ** tc, b1 ** ta, b2 ** ta, float(c.lr_actor), float(c.lr_critic)], dtype=torch.float64))
+
+    @staticmethod
+    def _graph_cfg_key(cfg) -> bytes:
+        """The cfg struct's bytes without the learning rates (they live on the device, self.pow4[4:6])."""
+        k = type(cfg).from_buffer_copy(bytes(cfg))
+        k.lr_actor = 0.0
+        k.lr_critic = 0.0
+        return bytes(k)
 
     def _graphed_pass(self, key, perm: torch.Tensor, batch: int, n_full: int, losses: torch.Tensor, body) -> None:
         """The first `n_full` (whole) minibatches of the permutation `perm` as `n_full` replays of ONE captured HIP graph of
@@ -733,7 +763,9 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
                  comm: Comm | None = None, lr: float = 3e-4, critic_lr: float | None = None):
         super().__init__(policy, num_envs, steps, config, device, comm=comm, lr=lr, critic_lr=critic_lr)
         self._wide_init()
-        self.p2p = None                           # (the in-kernel exchange belongs to the persistent kernels)
+        if self.p2p is not None:                  # (the in-kernel exchange belongs to the persistent kernels: release its regions)
+            self.p2p.close()
+        self.p2p = None
 
     def _gather(self, idx, adv_all=None, extra=()):
         """The minibatch rows of obs, act, log_prob, both value targets, the advantage (adv_all; default the mixed one) and any
@@ -782,7 +814,7 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
         n_full = M // cfg.batch if graphed else 0
         if graphed:
             self._sync_pow4()
-            self._graphed_pass(("ppo", bytes(cfg)), perm, cfg.batch, n_full, losses,
+            self._graphed_pass(("ppo", self._graph_cfg_key(cfg)), perm, cfg.batch, n_full, losses,
                                lambda i_, l_: self.minibatch_step(i_, l_, dev_clock=True, cfg=cfg))
             self.adam_step += n_full
         for k in range(n_full, n_mb):               # (eager: everything without graphs; else the ragged last minibatch, host clocks)
@@ -850,7 +882,7 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
         n_full = M // cfg.batch if graphed else 0
         if graphed:
             self._sync_pow4()
-            key = ("ex", bytes(cfg), int(actor_loss), float(kl_bound), float(pg_coef), bool(actor_only), adv.data_ptr())
+            key = ("ex", self._graph_cfg_key(cfg), int(actor_loss), float(kl_bound), float(pg_coef), bool(actor_only), adv.data_ptr())
             self._graphed_pass(key, perm, cfg.batch, n_full, losses,
                                lambda i_, l_: self.minibatch_step_ex(i_, adv, l_, actor_loss, kl_bound, pg_coef, actor_only,
                                                                      dev_clock=True, cfg=cfg))

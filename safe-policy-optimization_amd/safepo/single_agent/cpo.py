@@ -661,7 +661,7 @@ class WideCPOEngine(_WideOps, CPOEngine):
                                                      self.adam_step, 0, w.off_ls, 0, 1, _abi.ptr(loss3), _abi.ptr(self.scal4),
                                                      _abi.ptr(part), cap, _abi.stream_ptr()), "spo_wide_clip_adam_ex")
         graphed = 0 < cfg.batch <= self.graph_max_batch and n_mb > 2         # launch-bound regime: one captured graph per step
-        key = ("critic_fit", bytes(cfg))
+        key = ("critic_fit", self._graph_cfg_key(cfg))
         for it in range(c["learning_iters"]):
             perm = _abi.require_gpu_tensor(perm_fn(it), "perm", torch.int32).long()
             losses = torch.empty((n_mb, 3), dtype=torch.float32, device=self.dev)

@@ -97,11 +97,20 @@ def run(a, comm=None, dev=None):
                         + f" x {a.episode_length} steps, hidden {H}, "
                         f"learning_iters {cfg['learning_iters']}, num_mini_batch {cfg['num_mini_batch']}",
             "n_gpus": world, "scaling": "strong" if world > 1 else None,
-            "parallelism": (f"dp{world} over rollout threads, RCCL all-reduce of the three flat gradients, loss scalars and PopArt "
-                            "sums per full-batch step" if world > 1 else "single GPU"),
+            "parallelism": (f"dp{world} over rollout threads, {_backend_name()} all-reduce of the three flat gradients, loss scalars "
+                            "and PopArt sums per full-batch step" if world > 1 else "single GPU"),
             "env_steps_per_s": round(steps / dt, 1), "episodes_timed": a.episodes, "s_per_epoch": round(dt / a.episodes, 4),
             "phases_s_per_epoch": {k: round(v / a.episodes, 4) for k, v in ph.items()},
             "train_gemm_tflops": round(train_flops / (ph["train"] / a.episodes) / 1e12, 2)}
+
+
+def _backend_name() -> str:
+    """The collective backend that actually ran ("nccl" is RCCL on ROCm; gloo in the one-GPU development mode)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return "no"
+    b = dist.get_backend()
+    return "RCCL" if b == "nccl" else f"{b} (host)"
 
 
 if __name__ == "__main__":
