@@ -345,7 +345,9 @@ def run_epochs(algo, a, comm, dev, N, T, D, A, steps, warmup, time_gae):
                 if ((world & (world - 1)) == 0 and (world <= 4 or os.environ.get("SPO_P2P_ALGO") == "doubling")
                     and os.environ.get("SPO_P2P_ALGO") != "twophase")
                 else "in-kernel, reduce-scatter + all-gather of packed tagged words over IPC-mapped peer regions")
-        exchange = {"form": form, "selftest_s": round(getattr(px, "last_selftest_s", float("nan")), 4) if px is not None else None,
+        if px is not None and getattr(px, "form", None) is not None:
+            form = "in-kernel over IPC-mapped peer regions, chosen by the start-up auto-tune: " + px.FORM_NAMES[px.form]
+        exchange = {"form": form, "autotune": getattr(eng, "exchange_autotune", None), "selftest_s": round(getattr(px, "last_selftest_s", float("nan")), 4) if px is not None else None,
                     "selftest_result": list(getattr(px, "last_selftest", ())) if px is not None else None,
                     "host_collectives_backend": dist.get_backend(), "host_collectives_world": dist.get_world_size(),
                     "dp_batch": a.dp_batch, "all_ranks_on_one_gpu": os.environ.get("SPO_BENCH_ONE_GPU", "0") == "1"}

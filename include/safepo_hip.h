@@ -305,7 +305,19 @@ int spo_update_iter_ex(float* theta, float* adam_m, float* adam_v, int64_t adam_
  * spo_p2p_selftest runs `iters` exchange rounds of known patterns on the same grid and protocol:
  * result2_dev[0] = wrong values, result2_dev[1] = 2 after a timeout; it consumes `iters` tags. */
 int64_t spo_p2p_region_bytes(void);
-int spo_debug_xr_profile(unsigned long long* out8_host, int reset);   /* self-test kernel phase cycles (debug) */
+int spo_debug_xr_profile(unsigned long long* out8_host, int reset);   /* Form of the in-kernel gradient exchange (which of the built all-reduce forms runs inside the persistent update
+ * kernel).  spo_p2p_select_form pins one for the process (-1: back to the default policy: environment overrides, else recursive
+ * doubling at 2 / 4 ranks and the two-phase form elsewhere); a form that does not exist at a world size falls back to the policy.
+ * safepo.parallel.PeerExchange.autotune times every valid form at start-up on the actual topology and pins the fastest. */
+#define SPO_XR_FORM_TWOPHASE 0          /* packed reduce-scatter + all-gather, four-wave kernel: two hand-offs at any world size   */
+#define SPO_XR_FORM_DOUBLING 1          /* packed recursive doubling, four-wave kernel: log2(world) hand-offs (power-of-two worlds) */
+#define SPO_XR_FORM_HELPER_A2A 2        /* one-shot all-to-all with flags on the helper waves (worlds 2 / 4 / 8): one hand-off      */
+#define SPO_XR_FORM_HELPER_DOUBLING 3   /* packed recursive doubling on the helper waves, layer by layer (worlds 2 / 4 / 8)          */
+int spo_p2p_select_form(int form);
+int spo_p2p_form_valid(int form, int world);
+int spo_p2p_current_form(int world);
+
+/* self-test kernel phase cycles (debug) */
 int spo_p2p_alloc(void** region_out, void* ipc_handle64_out);
 int spo_p2p_open(const void* ipc_handle64, void** region_out);
 int spo_p2p_close(void* peer_region);

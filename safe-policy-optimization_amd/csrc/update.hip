@@ -3011,20 +3011,48 @@ extern "C" int spo_update_iter_ex(float* theta, float* adam_m, float* adam_v, in
   return 0;
 }
 
+// ---- form of the in-kernel exchange (SPO_XR_FORM_*, include/safepo_hip.h).  spo_p2p_select_form(form) pins it for the process --
+// the start-up auto-tune of safepo.parallel.PeerExchange times every form on the actual topology and pins the fastest (VERDICT
+// r04: loopback on one GPU cannot rank forms whose cost is link parallelism) --, -1 returns to the policy below: the environment
+// (SPO_P2P_A2A=1, SPO_P2P_HELPER=1, SPO_P2P_ALGO=twophase | doubling), else recursive doubling at 2 and 4 ranks (one / two
+// hand-offs) and the packed reduce-scatter + all-gather at 8 ranks and at worlds that are not a power of two (loopback on one GPU,
+// profiles/r05/helper_exchange_ab.txt: doubling 14.3 / 16.7 / 21.4 us per step at 2 / 4 / 8 ranks, two-phase 17.8 / 18.0 / 19.1).
+static int g_xr_form_override = -1;
+extern "C" int spo_p2p_select_form(int form) {
+  SPO_REQUIRE(form >= -1 && form <= SPO_XR_FORM_HELPER_DOUBLING, "p2p_select_form: unknown form %d", form);
+  g_xr_form_override = form;
+  return 0;
+}
+static bool xr_form_valid(int form, int world) {
+  const bool pow2 = (world & (world - 1)) == 0;
+  switch (form) {
+    case SPO_XR_FORM_TWOPHASE: return true;
+    case SPO_XR_FORM_DOUBLING: return pow2;
+    case SPO_XR_FORM_HELPER_A2A: case SPO_XR_FORM_HELPER_DOUBLING: return world == 2 || world == 4 || world == 8;
+    default: return false;
+  }
+}
+extern "C" int spo_p2p_form_valid(int form, int world) { return xr_form_valid(form, world) ? 1 : 0; }
+static int xr_form(int world) {
+  if (g_xr_form_override >= 0 && xr_form_valid(g_xr_form_override, world)) return g_xr_form_override;
+  static const bool a2a = [] { const char* e = getenv("SPO_P2P_A2A"); return e && e[0] == '1'; }();
+  const char* algo = getenv("SPO_P2P_ALGO");
+  const bool pow2 = (world & (world - 1)) == 0;
+  if (algo && !strcmp(algo, "twophase")) return SPO_XR_FORM_TWOPHASE;
+  if (a2a && xr_form_valid(SPO_XR_FORM_HELPER_A2A, world)) return SPO_XR_FORM_HELPER_A2A;
+  if (helper_xr_mode() && xr_form_valid(SPO_XR_FORM_HELPER_DOUBLING, world)) return SPO_XR_FORM_HELPER_DOUBLING;
+  if (algo && !strcmp(algo, "doubling") && pow2) return SPO_XR_FORM_DOUBLING;
+  return (world <= 4 && pow2) ? SPO_XR_FORM_DOUBLING : SPO_XR_FORM_TWOPHASE;
+}
+extern "C" int spo_p2p_current_form(int world) { return xr_form(world); }
+
 // ---- data-parallel persistent form: cross-rank exchange regions and the per-iteration launch
 static int fill_xr(UpdArgs& a, int rank, int world, void* const* regions, unsigned step0) {
   SPO_REQUIRE(world >= 2 && world <= XR_MAX_WORLD && rank >= 0 && rank < world, "p2p: bad rank/world %d/%d", rank, world);
   SPO_REQUIRE(regions != nullptr, "p2p: regions is NULL");
   for (int r = 0; r < world; ++r) SPO_REQUIRE(regions[r] != nullptr, "p2p: region of rank %d is NULL", r);
   a.xr_rank = rank; a.xr_world = world; a.xr_step0 = step0;
-  // Form of the in-kernel exchange.  Default: recursive doubling at 2 and 4 ranks (one / two hand-offs), the packed
-  // reduce-scatter + all-gather at 8 ranks (two hand-offs instead of three, 1.75 x instead of 3 x the gradient on the wire) and at
-  // worlds that are not a power of two.  Loopback on one GPU (profiles/r04/p2p_loopback.txt): doubling 14.4 / 16.8 / 21.4 us per
-  // step at 2 / 4 / 8 ranks, two-phase 17.8 / 18.0 / 19.2.  SPO_P2P_ALGO=twophase | doubling forces one form everywhere.
-  const char* algo = getenv("SPO_P2P_ALGO");
-  if (algo && !strcmp(algo, "twophase")) a.xr_algo = 0;
-  else if (algo && !strcmp(algo, "doubling")) a.xr_algo = 1;
-  else a.xr_algo = world <= 4 ? 1 : 0;
+  a.xr_algo = xr_form(world) == SPO_XR_FORM_TWOPHASE ? 0 : 1;       // (the protocol of the four-wave kernels and of the self-test)
   { const char* dbg = getenv("SPO_A2A_DEBUG"); a.xr_debug = dbg ? atoi(dbg) : 0; }
   for (int r = 0; r < XR_MAX_WORLD; ++r) a.xr_region[r] = r < world ? regions[r] : nullptr;
   return 0;
@@ -3140,15 +3168,15 @@ extern "C" int spo_ppo_lag_update_iter_dp(float* theta, float* adam_m, float* ad
   // one memory system) it measured SLOWER than recursive doubling on the four-wave kernel (18.6 / 23.9 / 33.5 against
   // 15.9 / 18.8 / 24.0 us per step at 2 / 4 / 8 ranks): a store acknowledgement plus a flag flight plus the row loads per
   // stage cost more than three tagged-word hand-offs there.  Kept for measurement on a real xGMI node.
-  static const bool a2a = [] { const char* e = getenv("SPO_P2P_A2A"); return e && e[0] == '1'; }();
   // SPO_P2P_HELPER=1 (opt-in): the main + helper kernel with recursive doubling ON THE HELPER WAVES -- layer 1 exchanged
   // while the main waves still compute dW2 / dW3, layers 2 / 3 while they settle the next minibatch and run layer 1; round 5:
   // packed 16-byte words, one poll batch per stage (xr_rd16_flat).  Loopback: 16.2 / 22.4 / 27.9 us per step at 2 / 4 / 8 ranks
   // against 14.3 / 16.7 / 19.1 for the default below (four-wave kernel, ONE exchange of the whole gradient per step): between P1
   // and Q2 the helper waves already gate the step, so hand-offs placed there are exposed in full and there are two per step.
-  const int helper_xr = helper_xr_mode();
+  const int form = xr_form(world);
+  const bool a2a = form == SPO_XR_FORM_HELPER_A2A;
   a.xr_helper_rd = a2a ? 0 : 1;
-  if ((a2a || helper_xr) && kin <= 64 && cfg_host->batch <= 64 && update_form() == 2 && a.xr_algo == 1 && (world == 2 || world == 4 || world == 8)) {
+  if ((a2a || form == SPO_XR_FORM_HELPER_DOUBLING) && kin <= 64 && cfg_host->batch <= 64 && update_form() == 2) {
     // main + helper form, exchange on the helper waves
 #define SPO_H_XR(K, D) (world == 2 ? launch_update_h<K, false, 2, D>(a, 3, st) : world == 4 ? launch_update_h<K, false, 4, D>(a, 3, st) \
                                                                                                : launch_update_h<K, false, 8, D>(a, 3, st))
@@ -3187,9 +3215,9 @@ extern "C" int spo_critic_fit_iter_dp(float* theta, float* adam_m, float* adam_v
   a.first_net = 0; a.n_nets = 2; a.stale_sq = 0.f; a.stale_io = stale_sq_io;
   int rc = 0;
   const int kin = pick_kin(cfg_host->obs_dim);
-  const int helper_xr = helper_xr_mode();   // opt-in, see above
+  const int form = xr_form(world);          // (the all-to-all form has no two-network instantiation: the helpers' doubling stands in)
   a.xr_helper_rd = 1;
-  if (helper_xr && kin <= 64 && cfg_host->batch <= 64 && update_form() == 2 && a.xr_algo == 1 && (world == 2 || world == 4 || world == 8)) {
+  if ((form == SPO_XR_FORM_HELPER_A2A || form == SPO_XR_FORM_HELPER_DOUBLING) && kin <= 64 && cfg_host->batch <= 64 && update_form() == 2) {
     // main + helper form with recursive doubling on the helper waves (see spo_ppo_lag_update_iter_dp)
 #define SPO_H_XR(K) (world == 2 ? launch_update_h<K, false, 2, 2>(a, 2, st) : world == 4 ? launch_update_h<K, false, 4, 2>(a, 2, st) \
                                                                                             : launch_update_h<K, false, 8, 2>(a, 2, st))

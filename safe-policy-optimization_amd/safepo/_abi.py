@@ -113,6 +113,9 @@ PROTOTYPES = {
     "spo_p2p_close": (c_int, [P]),
     "spo_p2p_free": (c_int, [P]),
     "spo_p2p_selftest": (c_int, [c_int, c_int, POINTER(c_void_p), c_uint32, c_int, P, P]),
+    "spo_p2p_select_form": (c_int, [c_int]),
+    "spo_p2p_form_valid": (c_int, [c_int, c_int]),
+    "spo_p2p_current_form": (c_int, [c_int]),
     "spo_p2p_selftest_one_grid": (c_int, [POINTER(c_void_p), c_uint32, c_int, P, P]),
     "spo_critic_fit_iter_split": (c_int, [P] * 6 + [c_int64, P, P, P, P, P, c_int64, POINTER(PpoCfg)] + [P] * 6
                                   + [POINTER(c_void_p), c_uint32, P]),

@@ -111,9 +111,26 @@ class PPOLagEngine:
             self.comm.all_reduce_max_(rows)
             if rows[0].item() == -rows[1].item():
                 self.p2p = PeerExchange.try_create(self.comm, self.dev)
+                self._autotune_exchange()
         self.rew_deque, self.cost_deque, self.len_deque = deque(maxlen=50), deque(maxlen=50), deque(maxlen=50)
 
     FUSED_POST_STEP = True      # post_step: spo_values_boundary_step_fold (the wide-network engines take the two-launch form)
+
+    def _autotune_exchange(self) -> None:
+        """Which form of the per-minibatch exchange this job uses is MEASURED on the topology it runs on (PeerExchange.autotune)
+        unless the environment names one (SPO_P2P_ALGO / SPO_P2P_A2A / SPO_P2P_HELPER) or SPO_P2P_AUTOTUNE=0; if the kernel /
+        RCCL / kernel form is the fastest, the peer regions are released and that form runs."""
+        px = self.p2p
+        if px is None or os.environ.get("SPO_P2P_AUTOTUNE", "1") == "0":
+            return
+        if any(os.environ.get(k) not in (None, "", "0") for k in ("SPO_P2P_ALGO", "SPO_P2P_A2A", "SPO_P2P_HELPER")):
+            return
+        if not self.policy.kernels_supported("ppo"):
+            return
+        self.exchange_autotune = px.autotune(self.D, self.A)
+        if px.prefer_rccl:
+            px.close()
+            self.p2p = None
 
     def _require_policy(self, policy) -> None:
         policy._require_kernels()
@@ -286,8 +303,9 @@ class PPOLagEngine:
         which is put back afterwards."""
         b = self.buffer
         saved = (b.ptr, b.ptr_list, b._fold_cols, None if rms is None else rms.pending, env.step_count,
-                 self._events_last_t, self._events_drained)
+                 self._events_last_t, self._events_drained, self._events_pending)
         b.ptr, b.ptr_list, b._fold_cols = 0, [0] * b.num_envs, 0
+        self._events_pending = False
         if rms is not None:
             rms.pending = False
         env.begin_epoch_base()
@@ -310,7 +328,7 @@ class PPOLagEngine:
             if rms is not None:
                 rms.pending = saved[3]
             env.step_count = saved[4]
-            self._events_last_t, self._events_drained = saved[5], saved[6]
+            self._events_last_t, self._events_drained, self._events_pending = saved[5], saved[6], saved[7]
         return g, post
 
     def drain_episode_events(self, logger=None):

@@ -218,6 +218,97 @@ class PeerExchange:
         self.last_selftest = (bad, timeout)
         return self.ok
 
+    FORM_NAMES = {0: "two-phase (packed reduce-scatter + all-gather, four-wave kernel)",
+                  1: "recursive doubling of packed words (four-wave kernel)",
+                  2: "one-shot all-to-all with flags (helper waves)",
+                  3: "recursive doubling of packed words (helper waves)"}
+
+    def autotune(self, obs_dim: int, act_dim: int, steps: int = 192, with_rccl: bool = True) -> dict:
+        """Start-up selection of the per-minibatch exchange on THIS topology: every form of the in-kernel
+        exchange that exists at this world size runs `steps` real minibatch steps of the persistent update kernel (64 rows,
+        this policy shape, synthetic rows, scratch parameters) -- and the kernel / RCCL all-reduce / kernel form a few --,
+        the slowest rank's time per step is taken (max-reduce), and the fastest form is pinned on every rank
+        (spo_p2p_select_form).  One-GPU loopback cannot rank forms whose cost is link parallelism (the one-shot all-to-all
+        uses all 7 xGMI links at once there and one memory system here), so the ranking is measured where the job runs.
+        Returns {form name: us per step} (inf: the form timed out) with "chosen"; self.prefer_rccl says whether the RCCL form won."""
+        import time
+        _abi, lib, dev, comm = self._abi, self.lib, self.device, self.comm
+        D, A, B = int(obs_dim), int(act_dim), 64
+        M = steps * B
+        P = int(lib.spo_param_count(D, A))
+        g = torch.Generator(device=dev).manual_seed(4321 + self.rank)
+        f32 = dict(dtype=torch.float32, device=dev)
+        theta0 = torch.randn(P, generator=g, **f32) * 0.1
+        comm.broadcast_(theta0, 0)                          # replicas start identical, as in a job
+        obs, act = torch.randn(M, D, generator=g, **f32), torch.randn(M, A, generator=g, **f32)
+        logp, adv = torch.full((M,), -float(A), **f32), torch.randn(M, generator=g, **f32)
+        tgt_r, tgt_c = torch.randn(M, generator=g, **f32), torch.rand(M, generator=g, **f32)
+        perm = torch.arange(M, dtype=torch.int32, device=dev)
+        losses = torch.empty((steps, 3), **f32)
+        sync_ws = torch.zeros(32, dtype=torch.int64, device=dev)
+        cfg = _abi.PpoCfg(obs_dim=D, act_dim=A, batch=B, use_critic_norm=1, use_value_coefficient=0, clip=0.2, max_grad_norm=40.0,
+                          lr_actor=3e-4, lr_critic=3e-4, beta1=0.9, beta2=0.999, adam_eps=1e-8, l2_coef=0.001)
+        coll_dev = dev if dist.get_backend(comm.group) == "nccl" else torch.device("cpu")
+
+        def slowest(us: float) -> float:
+            t = torch.tensor([us if us == us and us != float("inf") else 1e30], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=comm.group)
+            v = float(t.item())
+            return float("inf") if v >= 1e29 else v
+
+        table = {}
+        for form in (1, 0, 2, 3):
+            if not lib.spo_p2p_form_valid(form, self.world):
+                continue
+            _abi.check(lib.spo_p2p_select_form(form), "spo_p2p_select_form")
+            us = float("inf")
+            for rep in range(2):                            # first launch: lazy per-kernel set-up
+                theta, m, v = theta0.clone(), torch.zeros(P, **f32), torch.zeros(P, **f32)
+                torch.cuda.synchronize(dev)
+                comm.barrier()
+                t0 = time.perf_counter()
+                rc = lib.spo_ppo_lag_update_iter_dp(_abi.ptr(theta), _abi.ptr(m), _abi.ptr(v), 0, _abi.ptr(obs), _abi.ptr(act), _abi.ptr(logp),
+                                                    _abi.ptr(tgt_r), _abi.ptr(tgt_c), _abi.ptr(adv), _abi.ptr(perm), M, cfg, _abi.ptr(losses),
+                                                    _abi.ptr(sync_ws), self.rank, self.world, self.regions, self.step & 0xFFFFFFFF,
+                                                    _abi.stream_ptr())
+                self.step += steps
+                torch.cuda.synchronize(dev)
+                us = (time.perf_counter() - t0) / steps * 1e6
+                err = int(sync_ws[8].item()) & 0xFFFFFFFF
+                if rc or err:                               # a peer never answered inside the bounded waits: not a candidate
+                    sync_ws[8] = 0
+                    us = float("inf")
+            table[form] = slowest(us)
+        rccl_us = None
+        if with_rccl:
+            n_r = 24
+            theta, m, v = theta0.clone(), torch.zeros(P, **f32), torch.zeros(P, **f32)
+            fg, l3 = torch.zeros(P, **f32), torch.zeros(3, **f32)
+            idx = perm[:B]
+            torch.cuda.synchronize(dev)
+            comm.barrier()
+            t0 = time.perf_counter()
+            for k in range(n_r):
+                lib.spo_ppo_lag_grad(_abi.ptr(theta), _abi.ptr(obs), _abi.ptr(act), _abi.ptr(logp), _abi.ptr(tgt_r), _abi.ptr(tgt_c),
+                                     _abi.ptr(adv), _abi.ptr(idx), B, B, cfg, _abi.ptr(fg), _abi.ptr(l3), _abi.stream_ptr())
+                comm.all_reduce_sum_(fg)
+                lib.spo_clip_adam(_abi.ptr(theta), _abi.ptr(m), _abi.ptr(v), _abi.ptr(fg), k, 1.0 / self.world, cfg, _abi.stream_ptr())
+            torch.cuda.synchronize(dev)
+            rccl_us = slowest((time.perf_counter() - t0) / n_r * 1e6)
+        live = {f: u for f, u in table.items() if u != float("inf")}
+        best = min(live, key=lambda f: (live[f], f)) if live else None
+        _abi.check(lib.spo_p2p_select_form(-1 if best is None else best), "spo_p2p_select_form")
+        self.form = best
+        self.prefer_rccl = best is None or (rccl_us is not None and rccl_us < live[best])
+        backend = dist.get_backend(comm.group)
+        out = {self.FORM_NAMES[f]: (round(u, 2) if u != float("inf") else None) for f, u in table.items()}
+        if rccl_us is not None:
+            out[f"kernel / {'RCCL' if backend == 'nccl' else backend} all-reduce / kernel"] = round(rccl_us, 2)
+        out["chosen"] = ("kernel / all-reduce / kernel" if self.prefer_rccl else self.FORM_NAMES[best])
+        out["unit"] = f"us per 64-row minibatch step, slowest rank, {steps} steps per in-kernel form"
+        self.autotune_table = out
+        return out
+
     def close(self) -> None:
         for ptr in self._opened:
             self.lib.spo_p2p_close(ptr)
@@ -235,6 +326,7 @@ class PeerExchange:
         if comm.world_size < 2 or comm.world_size > cls.MAX_WORLD or os.environ.get("SPO_P2P", "1") == "0":
             return None
         px = cls(comm, torch.device(device))
+        px.form, px.prefer_rccl, px.autotune_table = None, False, None
         if px.ok and px.selftest():
             return px
         if verbose and comm.rank == 0:
