@@ -305,7 +305,18 @@ int spo_update_iter_ex(float* theta, float* adam_m, float* adam_v, int64_t adam_
  * spo_p2p_selftest runs `iters` exchange rounds of known patterns on the same grid and protocol:
  * result2_dev[0] = wrong values, result2_dev[1] = 2 after a timeout; it consumes `iters` tags. */
 int64_t spo_p2p_region_bytes(void);
-int spo_debug_xr_profile(unsigned long long* out8_host, int reset);   /* Form of the in-kernel gradient exchange (which of the built all-reduce forms runs inside the persistent update
+int spo_debug_xr_profile(unsigned long long* out8_host, int reset);   /* spo_ppo_lag_update_iter for wide observations / action vectors (round 5; csrc/update_ks.hip): obs_dim <= 512, act_dim <= 32,
+ * batch <= 64, hidden [64, 64], the clipped-surrogate loss, one GPU.  The first layer is split over the input features, 64 per
+ * workgroup: 3 x ceil(obs_dim / 64) persistent workgroups exchange the partial pre-activations inside the step; same
+ * arguments, results and per-step loss log as spo_ppo_lag_update_iter (reference: safepo/single_agent/ppo_lag.py:297-336 with
+ * an ActorVCritic(376, 17), model.py:131; single_agent/benchmark.py:5-22).  spo_ks_supported: 1 when the shape fits. */
+int spo_ks_supported(int obs_dim, int act_dim, int batch);
+int spo_ppo_lag_update_iter_ks(float* theta, float* adam_m, float* adam_v, int64_t adam_step_host, const float* obs,
+                               const float* act, const float* logp_old, const float* target_r, const float* target_c,
+                               const float* adv, const int32_t* perm, int64_t M, const spo_ppo_cfg* cfg_host,
+                               float* losses_out, void* sync_ws, void* stream);
+
+/* Form of the in-kernel gradient exchange (which of the built all-reduce forms runs inside the persistent update
  * kernel).  spo_p2p_select_form pins one for the process (-1: back to the default policy: environment overrides, else recursive
  * doubling at 2 / 4 ranks and the two-phase form elsewhere); a form that does not exist at a world size falls back to the policy.
  * safepo.parallel.PeerExchange.autotune times every valid form at start-up on the actual topology and pins the fastest. */

@@ -822,12 +822,35 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
                                           _abi.ptr(self.loss_partials), self.loss_partials.numel(), st()), "spo_wide_clip_adam")
         self.adam_step += 1
 
+    def _feature_split_kernel_ok(self, cfg) -> bool:
+        """hidden [64, 64] with obs_dim <= 512 / act_dim <= 32 (HumanoidVelocity's 376 / 17) at minibatches of <= 64 rows on one
+        GPU: the persistent feature-split kernel (csrc/update_ks.hip, round 5) instead of the launch-per-layer wide step.
+        SPO_WIDE_KS=0 keeps the wide step."""
+        return (list(self.policy.hidden_sizes) == [64, 64] and self.comm.world_size == 1
+                and os.environ.get("SPO_WIDE_KS", "1") != "0" and bool(self.lib.spo_ks_supported(self.D, self.A, int(cfg.batch))))
+
+    def check_sync_error(self):
+        code = int(self.sync_ws[8].item()) & 0xFFFFFFFF
+        if code:
+            self.sync_ws[8] = 0
+            raise _abi.SpoError("feature-split update kernel: inter-workgroup exchange timed out")
+
     def learning_iter(self, perm: torch.Tensor) -> torch.Tensor:
         cfg = self._cfg_struct()
-        perm = _abi.require_gpu_tensor(perm, "perm", torch.int32).long()
+        perm = _abi.require_gpu_tensor(perm, "perm", torch.int32)
         M = self.M
         n_mb = (M + cfg.batch - 1) // cfg.batch
         losses = torch.empty((n_mb, 3), dtype=torch.float32, device=self.dev)
+        if self._feature_split_kernel_ok(cfg):
+            d, b = self.buffer.data, self.buffer
+            _abi.check(self.lib.spo_ppo_lag_update_iter_ks(
+                _abi.ptr(self.policy.theta), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), self.adam_step, _abi.ptr(d["obs"]),
+                _abi.ptr(d["act"]), _abi.ptr(d["log_prob"]), _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]),
+                _abi.ptr(b.adv_mix), _abi.ptr(perm), M, cfg, _abi.ptr(losses), _abi.ptr(self.sync_ws), _abi.stream_ptr()),
+                "spo_ppo_lag_update_iter_ks")
+            self.adam_step += n_mb
+            return losses
+        perm = perm.long()
         graphed = 0 < cfg.batch <= self.graph_max_batch and n_mb > 2
         n_full = M // cfg.batch if graphed else 0
         if graphed:

@@ -1,0 +1,46 @@
+"""Development aid (GPU box): us per 64-row minibatch step of the feature-split persistent update kernel (csrc/update_ks.hip) for a
+few (obs_dim, act_dim), next to the LDS-resident kernel at 60 / 8 and the launch-per-layer wide step (SPO_WIDE_KS=0).
+    python tools/ks_bench.py [D,A ...]"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "safe-policy-optimization_amd"))
+
+
+def one(D, A, steps=2048, reps=3):
+    from safepo.common.engine import PPOLagEngine, WidePPOLagEngine
+    from safepo.common.model import ActorVCritic
+    dev = torch.device("cuda:0")
+    M = steps * 64
+    cfg = {"hidden_sizes": [64, 64], "gamma": 0.99, "target_kl": 1e9, "batch_size": 64, "learning_iters": 1, "max_grad_norm": 40.0}
+    torch.manual_seed(0)
+    pol = ActorVCritic(D, A).to(dev)
+    eng = (PPOLagEngine if pol.kernels_supported("ppo") else WidePPOLagEngine)(pol, 1, M, cfg, dev)
+    b = eng.buffer
+    g = torch.Generator(device=dev).manual_seed(1)
+    for k in ("obs", "act", "target_value_r", "target_value_c"):
+        b.data[k].normal_(generator=g)
+    b.data["log_prob"].copy_(-0.92 * A - 0.5 * (b.data["act"] ** 2).sum(-1))
+    b.adv_mix.normal_(generator=g)
+    perm = torch.randperm(M, device=dev, generator=g).to(torch.int32)
+    times = []
+    for _ in range(reps + 1):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        losses = eng.learning_iter(perm)
+        torch.cuda.synchronize()
+        times.append(time.time() - t0)
+    eng.check_sync_error()
+    return {"obs_dim": D, "act_dim": A, "engine": type(eng).__name__, "feature_split": os.environ.get("SPO_WIDE_KS", "1") != "0",
+            "us_per_minibatch_step": round(min(times[1:]) * 1e6 / steps, 2), "loss_finite": bool(torch.isfinite(losses).all())}
+
+
+if __name__ == "__main__":
+    shapes = [tuple(int(v) for v in s.split(",")) for s in sys.argv[1:]] or [(60, 8), (60, 20), (200, 20), (376, 17), (512, 32)]
+    for D, A in shapes:
+        print(json.dumps(one(D, A, steps=2048 if os.environ.get("SPO_WIDE_KS", "1") != "0" or D <= 128 and A <= 16 else 256)), flush=True)
