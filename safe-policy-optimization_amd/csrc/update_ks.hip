@@ -8,8 +8,8 @@
 //   grid = 3 networks x S slices (S = ceil(obs_dim / 64) <= 8), one persistent workgroup of 4 waves each, all co-resident;
 //   workgroup (n, k) keeps W1[:, 64k .. 64k+63] of network n (and W2, W3, the biases, log_std: replicated) in LDS, gathers the
 //   matching 64 features of the minibatch rows and computes the PARTIAL pre-activation W1_k x_k;
-//   the S partials of a network are exchanged through uncached device memory (16 floats per lane as 6 packed {f, f, f, tag}
-//   words, one store each; every workgroup polls all S x 6 words and adds them in slice order, so all S replicas hold the same
+//   the S partials of a network are exchanged through device memory (16 floats per lane as 8-byte {tag, value} words written
+//   and polled with agent-scope atomics; every workgroup adds all S partials in slice order, so all S replicas hold the same
 //   bits), then bias + tanh, layers 2 / 3, loss, backward and the weight gradients run replicated -- identical instructions
 //   on identical data -- except dW1, of which a workgroup computes (and owns the Adam state of) its own 64 columns;
 //   the joint clip_grad_norm_ (ppo_lag.py:325) sums one ||g||^2 granule per workgroup: the slice's share of W1, plus
@@ -33,7 +33,6 @@ constexpr int KS_MAX_SLICES = 8;                 // obs_dim <= 512
 constexpr int KS_NO = 2;                         // output tiles of the actor: act_dim <= 32
 constexpr int KS_OUT = 16 * KS_NO;
 constexpr int LDB = 64 + 4;                      // [feature][batch] LDS row stride (floats)
-constexpr int KS_ZW = 6;                         // packed words per lane of a partial pre-activation (16 floats)
 
 struct KsLds {                                   // floats
   static constexpr int W1 = 0;                   // [64][68]: this slice's 64 columns of W1
@@ -55,59 +54,29 @@ static_assert(KsLds::SIZE * 4 <= 163840, "160 KB of LDS");
 // RED: [0..3] loss partials per wave, [4..7] ||g||^2 of the W1 slice, [8..11] of the rest, [12..15] / [16..19] sum p^2 likewise,
 //      [32 + 32 wave + a] d(log_std) partials, [160 + a] log_std mirror, [192 + i] polled ||g||^2 granules, [224 + i] sum p^2 granules
 
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+// partial pre-activations: 16-byte groups of bare floats, [2 parities][3 nets][dst slice]...[256 lanes]
+constexpr size_t KS_ZRS_BYTES = (size_t)2 * 3 * KS_MAX_SLICES * KS_MAX_SLICES * 4 * 256 * 16;   // reduce-scatter slots [dst][src][fq]
+constexpr size_t KS_ZAG_BYTES = (size_t)2 * 3 * KS_MAX_SLICES * 4 * 256 * 16;                   // all-gather slots [dst][fq]
+constexpr size_t KS_ZZERO_OFF = KS_ZRS_BYTES + KS_ZAG_BYTES;      // a row of zeros (never written) and a row nobody reads
+constexpr size_t KS_ZDUMP_OFF = KS_ZZERO_OFF + 4096;
+constexpr size_t KS_Z_BYTES = KS_ZDUMP_OFF + 4096;
+
 struct KsArgs {
   float* theta; float* adam_m; float* adam_v;
   const float* obs; const float* act; const float* logp_old; const float* tgt_r; const float* tgt_c; const float* adv;
   const int32_t* perm; int64_t M;
   spo_ppo_cfg cfg;
   float* losses;                       // [nsteps][3]
-  char* zbuf;                          // partial pre-activations: [2 parities][3 nets][KS_MAX_SLICES][256 lanes][KS_ZW] x 16 B
+  float* zbuf;                         // partial pre-activations (KS_Z_BYTES, all sentinel at launch)
   unsigned long long* gran;            // [2 parities][2 kinds][3 * KS_MAX_SLICES] {tag, value} granules
   int* err;
   double pow_b1, pow_b2;
   unsigned tag_base;                   // tags of this launch: tag_base + step + 1 (never reused: no clearing between launches)
   int S;
+  int force_safe;                      // SPO_KS_SAFE=1: write-through exchange stores whatever the placement (tests)
 };
 
-typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void st16(char* p, const u4v v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  // (s_nop 1: a VMEM store of more than 8 bytes reads its data registers up to two wait states after issue, update.hip st16_sys)
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-#endif
-}
-// The six words of up to three source slices in ONE asm statement that ends with the wait: the compiler does not know that the
-// statement's outputs are loads in flight, so between a bare load statement and a later s_waitcnt statement it is free to copy or
-// spill the destination registers -- saving whatever they held BEFORE the data landed (seen here with 36 words in flight: polls
-// that could never succeed).  Inside one statement nothing can come between.  A lane's six words are 96 contiguous bytes.
-__device__ __forceinline__ void ld6x3(const char* p0, const char* p1, const char* p2, u4v (&a)[KS_ZW], u4v (&b)[KS_ZW], u4v (&c)[KS_ZW]) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile(
-      "global_load_dwordx4 %0, %18, off sc0 sc1\n\t"
-      "global_load_dwordx4 %1, %18, off offset:16 sc0 sc1\n\t"
-      "global_load_dwordx4 %2, %18, off offset:32 sc0 sc1\n\t"
-      "global_load_dwordx4 %3, %18, off offset:48 sc0 sc1\n\t"
-      "global_load_dwordx4 %4, %18, off offset:64 sc0 sc1\n\t"
-      "global_load_dwordx4 %5, %18, off offset:80 sc0 sc1\n\t"
-      "global_load_dwordx4 %6, %19, off sc0 sc1\n\t"
-      "global_load_dwordx4 %7, %19, off offset:16 sc0 sc1\n\t"
-      "global_load_dwordx4 %8, %19, off offset:32 sc0 sc1\n\t"
-      "global_load_dwordx4 %9, %19, off offset:48 sc0 sc1\n\t"
-      "global_load_dwordx4 %10, %19, off offset:64 sc0 sc1\n\t"
-      "global_load_dwordx4 %11, %19, off offset:80 sc0 sc1\n\t"
-      "global_load_dwordx4 %12, %20, off sc0 sc1\n\t"
-      "global_load_dwordx4 %13, %20, off offset:16 sc0 sc1\n\t"
-      "global_load_dwordx4 %14, %20, off offset:32 sc0 sc1\n\t"
-      "global_load_dwordx4 %15, %20, off offset:48 sc0 sc1\n\t"
-      "global_load_dwordx4 %16, %20, off offset:64 sc0 sc1\n\t"
-      "global_load_dwordx4 %17, %20, off offset:80 sc0 sc1\n\t"
-      "s_waitcnt vmcnt(0)"
-      : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]),
-        "=&v"(b[3]), "=&v"(b[4]), "=&v"(b[5]), "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5])
-      : "v"(p0), "v"(p1), "v"(p2)
-      : "memory");
-#endif
-}
 __device__ __forceinline__ float pin(float v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ int pin(int v) { asm volatile("" : "+v"(v)); return v; }
 // (one launch at a time per device: the exchange scratch below is per device, like the kernel's use by one engine on one stream)
@@ -119,13 +88,22 @@ struct KsCol {                         // per-column inputs of one minibatch, pr
   float t0, t1;                        // critic: target ; actor: logp_old, adv
 };
 
-__global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
-  if (blockIdx.x & 7) return;                    // placement hint (update.hip): the working blocks land on one XCD and share its L2
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef SPO_KS_PROF
+__device__ unsigned long long g_ks_prof[16];      // development builds: cycles per interval of the step (thread 0 of the LAST workgroup: the actor's last slice)
+#define KS_STAMP(i) { if (tid == 0 && wg == 3 * a.S - 1) { const unsigned long long _t = __builtin_readcyclecounter(); pacc[i] += _t - tprev; tprev = _t; } }
+#else
+#define KS_STAMP(i)
+#endif
+// FAST: every workgroup of the launch sits on one XCD (checked by the kernel below), stores of the exchange stay plain
+template <bool FAST>
+__device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
+#ifdef SPO_KS_PROF
+  unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+#endif
   using L = KsLds;
   const int wg = (int)(blockIdx.x >> 3);
   const int S = a.S, net = wg / S, ks = wg - net * S;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, q = lane >> 4;
   const int D = a.cfg.obs_dim, A = a.cfg.act_dim, B = a.cfg.batch;
   const NetGeom g = net_geom(D, A, net);
   const bool is_actor = (net == 2), first = (ks == 0);
@@ -158,11 +136,12 @@ __global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
 
   // ---- ownership (C layout of the weight-gradient tiles) and optimiser state in registers
   const int orow = 16 * wave + 4 * q;
-  f4 mW1[4], vW1[4], mW2[4], vW2[4], mW3[KS_NO], vW3[KS_NO], mls[KS_NO], vls[KS_NO];
+  f4 mW1[4], vW1[4], mW2[4], vW2[4], mW3[KS_NO], vW3[KS_NO];
+  float mls = 0.f, vls = 0.f;                                   // log_std[tid] (threads 0 .. act_dim-1 of the actor)
   float mb1, vb1, mb2, vb2, mb3[KS_NO], vb3[KS_NO];
   const bool own_b = (q == 0);
   const bool own_w0 = (wave == 0 && q == 0);                    // b3[16 t + j], and (j == 0) log_std
-  const bool own_ls = is_actor && wave == 0 && j == 0;
+  const bool own_ls = is_actor && tid < A;
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -179,12 +158,11 @@ __global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
       const int o = 16 * t + 4 * q + r;
       const int idx = g.w3() + o * HID + 16 * wave + j;
       mW3[t][r] = o < OUT ? a.adam_m[idx] : 0.f; vW3[t][r] = o < OUT ? a.adam_v[idx] : 0.f;
-      mls[t][r] = (is_actor && o < A) ? a.adam_m[ls_off + o] : 0.f;
-      vls[t][r] = (is_actor && o < A) ? a.adam_v[ls_off + o] : 0.f;
     }
     const int ob = 16 * t + j;
     mb3[t] = ob < OUT ? a.adam_m[g.b3() + ob] : 0.f; vb3[t] = ob < OUT ? a.adam_v[g.b3() + ob] : 0.f;
   }
+  if (own_ls) { mls = a.adam_m[ls_off + tid]; vls = a.adam_v[ls_off + tid]; }
   mb1 = a.adam_m[g.b1() + 16 * wave + j]; vb1 = a.adam_v[g.b1() + 16 * wave + j];
   mb2 = a.adam_m[g.b2() + 16 * wave + j]; vb2 = a.adam_v[g.b2() + 16 * wave + j];
 
@@ -260,6 +238,16 @@ __global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
     }
   };
 
+  const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc(a.zbuf, 0, (int)KS_Z_BYTES, 0x00020000);
+  const unsigned zvoff = (unsigned)tid * 16u;
+  auto zstore = [&](u4 w, unsigned off) {                          // (the cache policy is an immediate)
+    if constexpr (FAST) __builtin_amdgcn_raw_buffer_store_b128(w, zrsrc, zvoff, off, 0);
+    else __builtin_amdgcn_raw_buffer_store_b128(w, zrsrc, zvoff, off, 16);
+  };
+  auto gstore = [&](unsigned long long* dst, unsigned long long w) {
+    if constexpr (FAST) __hip_atomic_store(dst, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(dst, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   KsCol nxt;
   int smp1 = 0;
   fetch((int64_t)a.perm[perm_pos(0)], nxt);
@@ -274,6 +262,9 @@ __global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
     const unsigned tag = a.tag_base + (unsigned)s + 1u;
     const int par = (int)(s & 1);
 
+#ifdef SPO_KS_PROF
+    if (tid == 0 && wg == 3 * a.S - 1) tprev = __builtin_readcyclecounter();
+#endif
     KsCol cur = nxt;
     settle(cur);
     const int smp_next = pin(smp1);
@@ -288,52 +279,109 @@ __global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) z1[mt] = f4{0.f, 0.f, 0.f, 0.f};
     layer_accum<4>(lds + L::W1, LDH, cur.x, z1, j, q);
-    if (s + 1 < nsteps) fetch((int64_t)smp_next, nxt);               // prefetch: next step's columns, then the index after
-    if (s + 2 < nsteps) smp1 = a.perm[pos2];
+    KS_STAMP(0)                                                        // settle, x^T, partial layer 1
     if (S > 1) {
-      // [parity][network][slice][lane][6 words]: a lane's words are 96 contiguous bytes
-      char* const zb = a.zbuf + ((size_t)(par * 3 + net) * KS_MAX_SLICES * 256 + tid) * (KS_ZW * 16);
-      {
-        char* const mine = zb + (size_t)ks * 256 * (KS_ZW * 16);
+      // All-reduce of the 64 x 64 partial pre-activations over the S workgroups of the network, as reduce-scatter + all-gather
+      // (a flat all-to-all moves S^2 x 16 KB per network: 5.3 MB a step at S = 6, measured L2-bandwidth bound at 15 k cycles).
+      // Unit u = 4 fq + wave (one f4 per lane of one wave, 1 KB) belongs to slice (u S) >> 4; its owner sums the S partials in
+      // slice order and broadcasts the sum, so every workgroup continues from identical bits.
+      // Transport: bare floats in ORDINARY device memory, buffer loads / stores with sc1 (agent scope: coherent at the L2 the
+      // co-resident workgroups share; a hand-off is an L2 round trip, ~0.5 us, where the uncached system-scope words of the
+      // cross-GPU protocol cost 3 us).  No tags: a slot holds the sentinel 0xFFFFFFFF (a NaN no arithmetic produces) until its
+      // producer fills it; the consumer checks every dword (torn 16-byte reads are harmless) and puts the sentinel back after
+      // reading.  One private slot per (destination, source, unit) / (destination, unit), two parities.  Why a slot is always
+      // reset before it is refilled -- one lane's traffic: reset at step s -> vmcnt(0) -> its reduce-scatter store of step s+1 to
+      // the unit's owner -> the owner's poll -> the owner's broadcast of step s+1 -> the producer's poll of that -> the
+      // producer's store of step s+2 into the slot.  The builtins are memory operations the compiler tracks (no inline-asm
+      // load whose outputs could be copied while in flight).
+      const unsigned pn = (unsigned)(par * 3 + net) * KS_MAX_SLICES;
+      const u4 sentinel = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the resets of the previous step are acknowledged by the L2
+      // Straight-line memory traffic: a branch between two stores makes the compiler put s_waitcnt vmcnt(0) at the join, and every
+      // one of those is a full store acknowledgement (measured: 9 k cycles for the two hand-offs).  So every wave always issues the
+      // same loads and stores, and the ones that do not apply go to two spare 4 KB rows: ZERO (never written: passes every poll)
+      // and DUMP (never read).
+      int own[4];
 #pragma unroll
-        for (int w = 0; w < KS_ZW; ++w) {
-          u4v word;
+      for (int fq = 0; fq < 4; ++fq) {
+        own[fq] = ((4 * fq + wave) * S) >> 4;
+        u4 w;
 #pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            const int f = 3 * w + i;
-            word[i] = f < 16 ? __float_as_uint(z1[(f < 16 ? f : 0) >> 2][(f < 16 ? f : 0) & 3]) : 0u;
-          }
-          word[3] = tag;
-          st16(mine + w * 16, word);
-        }
+        for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(z1[fq][e]);
+        zstore(w, own[fq] != ks ? (((pn + (unsigned)own[fq]) * KS_MAX_SLICES + (unsigned)ks) * 4u + fq) * 4096u : (unsigned)KS_ZDUMP_OFF);
       }
-      // three source slices per round trip, in slice order (the sum below is the same chain in every workgroup of the network)
-#pragma unroll 1
-      for (int k0 = 0; k0 < S; k0 += 3) {
-        const int k1 = k0 + 1 < S ? k0 + 1 : k0, k2 = k0 + 2 < S ? k0 + 2 : k1;
-        const char* const p0 = zb + (size_t)k0 * 256 * (KS_ZW * 16);
-        const char* const p1 = zb + (size_t)k1 * 256 * (KS_ZW * 16);
-        const char* const p2 = zb + (size_t)k2 * 256 * (KS_ZW * 16);
-        u4v za[KS_ZW], zb2[KS_ZW], zc[KS_ZW];
+      KS_STAMP(1)                                                      // reduce-scatter stores
+      const unsigned mine = ((pn + (unsigned)ks) * KS_MAX_SLICES * 4u) * 4096u;
+      const unsigned ag0 = (unsigned)KS_ZRS_BYTES + (pn * 4u) * 4096u;
+#pragma unroll
+      for (int fq = 0; fq < 4; ++fq)
+        if (own[fq] == ks) {                                           // (wave-uniform; at most one unit per wave from S = 4 up)
+          u4 zw[KS_MAX_SLICES];
+          unsigned spins = 0;
+          for (;;) {
+#pragma unroll
+            for (int k = 0; k < KS_MAX_SLICES; ++k)
+              zw[k] = __builtin_amdgcn_raw_buffer_load_b128(zrsrc, zvoff, (k < S && k != ks) ? mine + (unsigned)(k * 4 + fq) * 4096u : (unsigned)KS_ZZERO_OFF, 16);
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < KS_MAX_SLICES; ++k)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) ok = ok && (zw[k][e] != 0xFFFFFFFFu);
+            if (ok) break;
+            if (++spins > KS_SPIN_LIMIT) { *a.err = 1; break; }      // bounded: never hang the GPU
+            __builtin_amdgcn_s_sleep(1);
+          }
+#pragma unroll
+          for (int k = 0; k < KS_MAX_SLICES; ++k)
+            zstore(sentinel, (k < S && k != ks) ? mine + (unsigned)(k * 4 + fq) * 4096u : (unsigned)KS_ZDUMP_OFF);
+          f4 acc;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t = (ks == 0) ? z1[fq][e] : __uint_as_float(zw[0][e]);
+#pragma unroll
+            for (int k = 1; k < KS_MAX_SLICES; ++k) {
+              const float v = (k == ks) ? z1[fq][e] : __uint_as_float(zw[k][e]);
+              t = (k < S) ? t + v : t;
+            }
+            acc[e] = t;
+          }
+          z1[fq] = acc;
+          u4 w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(acc[e]);
+#pragma unroll
+          for (int c = 0; c < KS_MAX_SLICES; ++c)
+            zstore(w, (c < S && c != ks) ? ag0 + (unsigned)(c * 4 + fq) * 4096u : (unsigned)KS_ZDUMP_OFF);
+        }
+      {
+        u4 zg[4];
         unsigned spins = 0;
         for (;;) {
-          ld6x3(p0, p1, p2, za, zb2, zc);
+#pragma unroll
+          for (int fq = 0; fq < 4; ++fq)
+            zg[fq] = __builtin_amdgcn_raw_buffer_load_b128(zrsrc, zvoff, own[fq] != ks ? ag0 + (unsigned)(ks * 4 + fq) * 4096u : (unsigned)KS_ZZERO_OFF, 16);
           bool ok = true;
 #pragma unroll
-          for (int w = 0; w < KS_ZW; ++w) ok = ok && (za[w][3] == tag) && (zb2[w][3] == tag) && (zc[w][3] == tag);
+          for (int fq = 0; fq < 4; ++fq)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ok = ok && (zg[fq][e] != 0xFFFFFFFFu);
           if (ok) break;
-          if (++spins > KS_SPIN_LIMIT) { *a.err = 1; break; }        // bounded: never hang the GPU
+          if (++spins > KS_SPIN_LIMIT) { *a.err = 1; break; }
           __builtin_amdgcn_s_sleep(1);
         }
 #pragma unroll
-        for (int f = 0; f < 16; ++f) {
-          float acc = k0 == 0 ? __uint_as_float(za[f / 3][f % 3]) : z1[f >> 2][f & 3] + __uint_as_float(za[f / 3][f % 3]);
-          if (k0 + 1 < S) acc += __uint_as_float(zb2[f / 3][f % 3]);
-          if (k0 + 2 < S) acc += __uint_as_float(zc[f / 3][f % 3]);
-          z1[f >> 2][f & 3] = acc;
+        for (int fq = 0; fq < 4; ++fq) {
+          zstore(sentinel, own[fq] != ks ? ag0 + (unsigned)(ks * 4 + fq) * 4096u : (unsigned)KS_ZDUMP_OFF);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) z1[fq][e] = own[fq] != ks ? __uint_as_float(zg[fq][e]) : z1[fq][e];
         }
       }
     }
+    // prefetch AFTER the polls: loads return in order, so a poll issued behind the gather of the next minibatch would wait for
+    // its HBM round trip as well
+    if (s + 1 < nsteps) fetch((int64_t)smp_next, nxt);               // next step's columns, then the index after
+    if (s + 2 < nsteps) smp1 = a.perm[pos2];
+    KS_STAMP(2)                                                        // polls of the partials + sums
     f4 h1[4], h2[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) h1[mt] = fast_tanh4(z1[mt] + *reinterpret_cast<const f4*>(lds + L::B1 + 16 * mt + 4 * q));
@@ -343,6 +391,7 @@ __global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
     o[1] = f4{0.f, 0.f, 0.f, 0.f};
     if (nto > 1) o[1] = layer_out(lds + L::W3 + 16 * LDH, lds + L::B3 + 16, h2, j, q);
 
+    KS_STAMP(3)                                                        // tanh, layers 2 / 3
     // ---- loss and d(loss)/d(output), C layout (rows = output unit 16 t + 4 q + r, col = batch)
     f4 dO[KS_NO], dls[KS_NO];
     float lsum = 0.f;
@@ -441,6 +490,7 @@ __global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
         for (int r = 0; r < 4; ++r) dz1[mt][r] = acc[mt][r] * fmaf(-h1[mt][r], h1[mt][r], 1.f);
     }
 
+    KS_STAMP(4)                                                        // loss, backward
     // ---- stage [feature][batch] images for the weight-gradient products
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -470,6 +520,7 @@ __global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
       }
     }
     __syncthreads();
+    KS_STAMP(5)                                                        // staging + barrier
 
     // ---- dW[o][i] = sum_b dZ[b][o] * Hprev[b][i]; wave w owns rows 16w .. 16w+15 (W1 slice, W2) / h2 units 16w .. (W3)
     f4 aW1[4], aW2[4], aW3[KS_NO];
@@ -547,20 +598,14 @@ __global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
       }
       db1 = quad_row_sum(rs1); db2 = quad_row_sum(rs2);
     }
+    KS_STAMP(6)                                                        // weight gradients
     const float loss_data = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;
-    if (is_actor) {
-#pragma unroll
-      for (int t = 0; t < KS_NO; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int ai = 16 * t + 4 * q + r;
-          dls[t][r] = (red[32 + ai] + red[64 + ai]) + (red[96 + ai] + red[128 + ai]);       // 0 on pad rows
-        }
-    }
+    const float dl = own_ls ? (red[32 + tid] + red[64 + tid]) + (red[96 + tid] + red[128 + tid]) : 0.f;   // d(loss)/d(log_std[tid])
+    const float pl = own_ls ? red[160 + tid] : 0.f;
 
     // ---- L2 regulariser of the critics (weights AND biases, ppo_lag.py:310-314), norm shares: the W1 slice / everything else
     float gsq1 = 0.f, psq1 = 0.f, gsqr = 0.f, psqr = 0.f;
-    f4 pW1[4], pW2[4], pW3[KS_NO], pls[KS_NO];
+    f4 pW1[4], pW2[4], pW3[KS_NO];
     float pb3[KS_NO];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
@@ -574,7 +619,6 @@ __global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         pW3[t][r] = lds[L::W3 + (16 * t + 4 * q + r) * LDH + 16 * wave + j];
-        pls[t][r] = is_actor ? red[160 + 16 * t + 4 * q + r] : 0.f;
       }
       pb3[t] = lds[L::B3 + 16 * t + j];
     }
@@ -597,9 +641,10 @@ __global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
         aW3[t][r] = g3; gsqr = fmaf(g3, g3, gsqr); psqr = fmaf(p3, p3, psqr);
       }
     {
-      // biases and log_std are replicated across lanes; each replica runs the same Adam, only one of them counts towards the norms
+      // biases are replicated across lanes; each replica runs the same Adam, only one of them counts towards the norms
       db1 = vcoef * fmaf(l2x2, pb1, db1); db2 = vcoef * fmaf(l2x2, pb2, db2);
-      const float wb = own_b ? 1.f : 0.f, w0 = own_w0 ? 1.f : 0.f, wls = own_ls ? 1.f : 0.f;
+      const float wb = own_b ? 1.f : 0.f, w0 = own_w0 ? 1.f : 0.f;
+      gsqr = fmaf(dl, dl, gsqr);
       gsqr += wb * (db1 * db1 + db2 * db2);
       psqr += wb * (pb1 * pb1 + pb2 * pb2);
 #pragma unroll
@@ -607,8 +652,6 @@ __global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
         db3[t] = vcoef * fmaf(l2x2, pb3[t], db3[t]);
         gsqr += w0 * (db3[t] * db3[t]);
         psqr += w0 * (pb3[t] * pb3[t]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) gsqr = fmaf(wls * dls[t][r], dls[t][r], gsqr);
       }
     }
     gsq1 = wave_sum_lane63(gsq1); psq1 = wave_sum_lane63(psq1);
@@ -616,6 +659,7 @@ __global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
     if (lane == 63) { red[4 + wave] = gsq1; red[8 + wave] = gsqr; red[12 + wave] = psq1; red[16 + wave] = psqr; }
     __syncthreads();
 
+    KS_STAMP(7)                                                        // L2 terms, norm shares, barrier
     // ---- joint clip_grad_norm_ over all networks (ppo_lag.py:325): one granule per workgroup
     unsigned long long* const gg = a.gran + (size_t)par * 2 * 3 * KS_MAX_SLICES;
     unsigned long long* const gp = gg + 3 * KS_MAX_SLICES;
@@ -623,10 +667,8 @@ __global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
     if (tid == 0) {
       const float gs = ((red[4] + red[5]) + (red[6] + red[7])) + (first ? ((red[8] + red[9]) + (red[10] + red[11])) : 0.f);
       const float ps = ((red[12] + red[13]) + (red[14] + red[15])) + (first ? ((red[16] + red[17]) + (red[18] + red[19])) : 0.f);
-      __hip_atomic_store(gg + net * KS_MAX_SLICES + ks, ((unsigned long long)tag << 32) | __float_as_uint(gs), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(gp + net * KS_MAX_SLICES + ks, ((unsigned long long)tag << 32) | __float_as_uint(ps), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
+      gstore(gg + net * KS_MAX_SLICES + ks, ((unsigned long long)tag << 32) | __float_as_uint(gs));
+      gstore(gp + net * KS_MAX_SLICES + ks, ((unsigned long long)tag << 32) | __float_as_uint(ps));
     }
     pw1 *= (double)b1c; pw2 *= (double)b2c;
     float step_size, inv_bc2s;
@@ -649,6 +691,7 @@ __global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
       red[192 + tid] = val;                                            // [192 + 24 kind + 8 net + slice]
     }
     __syncthreads();
+    KS_STAMP(8)                                                        // granule exchange
     float total_sq = 0.f;
     for (int i = 0; i < 3 * KS_MAX_SLICES; ++i) total_sq += red[192 + i];   // fixed order: identical in every workgroup
     const float norm = sqrtf(total_sq);
@@ -682,14 +725,11 @@ __global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
       float np3;
       KS_ADAM(np3, pb3[t], db3[t], mb3[t], vb3[t])
       lds[L::B3 + 16 * t + j] = np3;
-      if (is_actor) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float nl;
-          KS_ADAM(nl, pls[t][r], dls[t][r], mls[t][r], vls[t][r])
-          red[160 + 16 * t + 4 * q + r] = nl;
-        }
-      }
+    }
+    if (own_ls) {
+      float nl;
+      KS_ADAM(nl, pl, dl, mls, vls)
+      red[160 + tid] = nl;
     }
     {
       float np1, np2;
@@ -700,7 +740,12 @@ __global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
     }
 #undef KS_ADAM
     __syncthreads();
+    KS_STAMP(9)                                                        // Adam + barrier
   }
+#ifdef SPO_KS_PROF
+  if (tid == 0 && wg == 3 * a.S - 1)
+    for (int i = 0; i < 16; ++i) g_ks_prof[i] = i == 15 ? (unsigned long long)FAST : pacc[i];
+#endif
 
   // ---- write back: every workgroup its W1 columns, slice 0 everything else (flat reference order)
 #pragma unroll
@@ -730,10 +775,6 @@ __global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
           a.theta[idx] = lds[L::W3 + o * LDH + 16 * wave + j];
           st_m[idx] = mW3[t][r]; st_v[idx] = vW3[t][r];
         }
-        if (own_ls && o < A) {
-          a.theta[ls_off + o] = red[160 + o];
-          st_m[ls_off + o] = mls[t][r]; st_v[ls_off + o] = vls[t][r];
-        }
       }
       const int ob = 16 * t + j;
       if (own_w0 && ob < OUT) {
@@ -741,6 +782,7 @@ __global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
         st_m[g.b3() + ob] = mb3[t]; st_v[g.b3() + ob] = vb3[t];
       }
     }
+    if (own_ls) { a.theta[ls_off + tid] = red[160 + tid]; st_m[ls_off + tid] = mls; st_v[ls_off + tid] = vls; }
     if (own_b) {
       const int ob = 16 * wave + j;
       a.theta[g.b1() + ob] = lds[L::B1 + ob]; st_m[g.b1() + ob] = mb1; st_v[g.b1() + ob] = vb1;
@@ -749,11 +791,46 @@ __global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
   }
 }
 
-// Exchange scratch of the kernel: the partial pre-activation words (uncached: visible to the other workgroups' polling loads
-// without a cache flush) and the norm granules.  One block per device, allocated on first use, zeroed once (tags never repeat).
-struct KsScratch { char* z; unsigned long long* gran; };
-constexpr size_t KS_Z_BYTES = (size_t)2 * 3 * KS_MAX_SLICES * 256 * KS_ZW * 16;
-constexpr size_t KS_G_BYTES = (size_t)2 * 2 * 3 * KS_MAX_SLICES * 8;
+__global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
+  if (blockIdx.x & 7) return;                    // placement hint (update.hip): the working blocks land on one XCD and share its L2
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const red = lds + KsLds::RED;
+  const int wg = (int)(blockIdx.x >> 3), tid = threadIdx.x, S = a.S;
+  // ---- placement census: do all workgroups of the launch share one XCD (one L2)?  Observed: block b runs on XCD b % 8, which is
+  // what the grid of 8-block strides asks for -- but nothing promises it, so it is checked, once per launch, over words every
+  // placement delivers (sc1 stores and loads).  Co-resident: stores of the exchange stay plain (the line stays in the shared L2,
+  // the sc1 poll is an L2 hit: a hand-off ~0.5 us); otherwise they are sc1 write-through (2.4 us a hand-off measured).
+  bool fast;
+  {
+    unsigned long long* const xid = a.gran + 2 * 2 * 3 * KS_MAX_SLICES;
+    const unsigned myx = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;      // HW_REG_XCC_ID
+    if (tid == 0) {
+      red[250] = 0.f;
+      __hip_atomic_store(xid + wg, ((unsigned long long)a.tag_base << 32) | myx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (tid < 3 * S) {
+      unsigned long long v = __hip_atomic_load(xid + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned spins = 0;
+      while ((unsigned)(v >> 32) != a.tag_base) {
+        if (++spins > KS_SPIN_LIMIT) { *a.err = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+        v = __hip_atomic_load(xid + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if ((unsigned)v != myx) red[250] = 1.f;
+    }
+    __syncthreads();
+    fast = (red[250] == 0.f) && !a.force_safe;
+    __syncthreads();
+  }
+  if (fast) ks_body<true>(a, lds);
+  else ks_body<false>(a, lds);
+}
+
+// Exchange scratch of the kernel: the partial pre-activation words and the norm granules, ordinary device memory (agent-scope
+// atomics).  One block per device, allocated on first use, zeroed once (tags never repeat).
+struct KsScratch { float* z; unsigned long long* gran; };
+constexpr size_t KS_G_BYTES = (size_t)(2 * 2 * 3 * KS_MAX_SLICES + 3 * KS_MAX_SLICES) * 8;   // granules + the placement census
 KsScratch g_ks[SPO_MAX_DEVICES] = {};
 unsigned g_ks_tag[SPO_MAX_DEVICES] = {};
 std::mutex g_ks_mu;
@@ -763,14 +840,10 @@ int ks_scratch(KsScratch* out, unsigned* tag_base, unsigned nsteps) {
   std::lock_guard<std::mutex> lk(g_ks_mu);
   if (!g_ks[dev].z) {
     void* p = nullptr;
-    hipError_t e = hipExtMallocWithFlags(&p, KS_Z_BYTES + KS_G_BYTES, hipDeviceMallocUncached);
-    if (e != hipSuccess) {
-      (void)hipGetLastError();
-      e = hipExtMallocWithFlags(&p, KS_Z_BYTES + KS_G_BYTES, hipDeviceMallocFinegrained);
-    }
-    if (e != hipSuccess) return spo::hip_check(e, "hipExtMallocWithFlags(ks scratch)");
+    if (int rc = spo::hip_check(hipMalloc(&p, KS_Z_BYTES + KS_G_BYTES), "hipMalloc(ks scratch)")) return rc;
     if (int rc = spo::hip_check(hipMemset(p, 0, KS_Z_BYTES + KS_G_BYTES), "hipMemset(ks scratch)")) { (void)hipFree(p); return rc; }
-    g_ks[dev].z = static_cast<char*>(p);
+    if (int rc = spo::hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize(ks scratch)")) { (void)hipFree(p); return rc; }
+    g_ks[dev].z = static_cast<float*>(p);
     g_ks[dev].gran = reinterpret_cast<unsigned long long*>(static_cast<char*>(p) + KS_Z_BYTES);
     g_ks_tag[dev] = 16u;
   }
@@ -781,6 +854,12 @@ int ks_scratch(KsScratch* out, unsigned* tag_base, unsigned nsteps) {
 }
 
 }  // namespace
+
+#ifdef SPO_KS_PROF
+extern "C" int spo_debug_ks_profile(unsigned long long* out16_host) {
+  return spo::hip_check(hipMemcpyFromSymbol(out16_host, HIP_SYMBOL(g_ks_prof), 128), "hipMemcpyFromSymbol");
+}
+#endif
 
 extern "C" int spo_ks_supported(int obs_dim, int act_dim, int batch) {
   return (obs_dim >= 1 && obs_dim <= 64 * KS_MAX_SLICES && act_dim >= 1 && act_dim <= KS_OUT && batch >= 1 && batch <= 64) ? 1 : 0;
@@ -807,11 +886,14 @@ extern "C" int spo_ppo_lag_update_iter_ks(float* theta, float* adam_m, float* ad
   a.pow_b1 = pow((double)cfg_host->beta1, (double)adam_step_host);
   a.pow_b2 = pow((double)cfg_host->beta2, (double)adam_step_host);
   a.S = (cfg_host->obs_dim + 63) / 64;
+  { const char* e = getenv("SPO_KS_SAFE"); a.force_safe = (e && *e && *e != '0') ? 1 : 0; }
   const int64_t nsteps = (M + cfg_host->batch - 1) / cfg_host->batch;
   SPO_REQUIRE(nsteps < (1ll << 31), "update_iter_ks: too many minibatch steps in one launch");
   KsScratch sc;
   if (int rc = ks_scratch(&sc, &a.tag_base, (unsigned)nsteps)) return rc;
   a.zbuf = sc.z; a.gran = sc.gran;
+  // every slot starts as the sentinel (a launch leaves them that way unless it stopped on an error: cheap enough to not care)
+  if (int rc = spo::hip_check(hipMemsetAsync(sc.z, 0xFF, KS_ZZERO_OFF, st), "hipMemsetAsync(ks partials)")) return rc;
   const size_t sh = KsLds::SIZE * sizeof(float);
   static bool attr_done[SPO_MAX_DEVICES] = {};
   const int dslot = current_device_slot();
