@@ -619,10 +619,14 @@ def main():
             torch.cuda.empty_cache()
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import wide_bench
-            wide_entry = {"what": "WidePPOLagEngine.minibatch_step at batch 64 (gather, 3 forwards, loss, 3 backwards, joint clip + Adam), "
-                                  "256 steps replayed from one HIP graph; the [64, 64] persistent kernel's step is update_kernel above",
+            wide_entry = {"what": "one 64-row minibatch step of WidePPOLagEngine.learning_iter (gather, 3 forwards, loss, 3 backwards, joint "
+                                  "clip + Adam) outside the 3-workgroup persistent kernel's dims (its step is update_kernel above): hidden "
+                                  "[64, 64] with obs_dim <= 512 / act_dim <= 32 takes the persistent feature-split kernel, anything else "
+                                  "the launch-per-layer step",
                           "cases": [dict(wide_bench.one([128, 128], 64, 256), obs_dim=60, act_dim=8),
-                                    dict(wide_bench.one([64, 64], 64, 256, D=376, A=17), obs_dim=376, act_dim=17)]}
+                                    dict(wide_bench.one([64, 64], 64, 4096, D=376, A=17), obs_dim=376, act_dim=17),
+                                    dict(wide_bench.one([64, 64], 64, 256, D=376, A=17, force_wide=True), obs_dim=376, act_dim=17,
+                                         note="SPO_WIDE_KS=0: the path rounds 3-4 took at these dims")]}
         except Exception as e:  # pragma: no cover
             wide_entry = {"error": str(e)[:300]}
     line = {

@@ -183,7 +183,7 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
     const int ncols = (int)(rem < B ? rem : B);
     return base + (mycol < ncols ? mycol : 0);
   };
-  auto fetch = [&](int64_t smp, KsCol& cd) {
+  auto fetch_obs = [&](int64_t smp, KsCol& cd) {
     {
       // this slice's 64 features of the row (clamped addresses, NO select: see load_obs_tiles_raw); 16-byte loads only when every
       // row AND every slice start is 16-byte aligned (obs_dim a multiple of 4)
@@ -204,6 +204,8 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
           }
       }
     }
+  };
+  auto fetch_rest = [&](int64_t smp, KsCol& cd) {
     if (!is_actor) {
       cd.t0 = tgt[smp]; cd.t1 = 0.f;
 #pragma unroll
@@ -215,7 +217,9 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int ai = 16 * t + 4 * q + r;
-          cd.actv[t][r] = a.act[smp * A + (ai < A ? ai : 0)];         // unconditional loads; pads selected at pick-up
+          // (unconditional within an instruction that has any live lane: pads selected at pick-up; rows past act_dim in every
+          // lane -- 16 t + r >= act_dim -- are not loaded at all: 5 gathers instead of 8 at act_dim 17)
+          cd.actv[t][r] = (16 * t + r < A) ? a.act[smp * A + (ai < A ? ai : 0)] : 0.f;
         }
     }
   };
@@ -250,7 +254,8 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
   };
   KsCol nxt;
   int smp1 = 0;
-  fetch((int64_t)a.perm[perm_pos(0)], nxt);
+  fetch_obs((int64_t)a.perm[perm_pos(0)], nxt);
+  fetch_rest((int64_t)a.perm[perm_pos(0)], nxt);
   if (nsteps > 1) smp1 = a.perm[perm_pos(1)];
 
   for (int64_t s = 0; s < nsteps; ++s) {
@@ -378,14 +383,25 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
       }
     }
     // prefetch AFTER the polls: loads return in order, so a poll issued behind the gather of the next minibatch would wait for
-    // its HBM round trip as well
-    if (s + 1 < nsteps) fetch((int64_t)smp_next, nxt);               // next step's columns, then the index after
-    if (s + 2 < nsteps) smp1 = a.perm[pos2];
+    // its HBM round trip as well.  In two halves with the layer-2 products in between: fourteen gathers in a row fill the
+    // address queue and the wave sits on the issue (2.4 k cycles measured).
+    if (s + 1 < nsteps) fetch_obs((int64_t)smp_next, nxt);
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     KS_STAMP(2)                                                        // polls of the partials + sums
     f4 h1[4], h2[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) h1[mt] = fast_tanh4(z1[mt] + *reinterpret_cast<const f4*>(lds + L::B1 + 16 * mt + 4 * q));
     layer_hidden<4, true>(lds + L::W2, LDH, lds + L::B2, h1, h2, j, q);
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    if (s + 1 < nsteps) fetch_rest((int64_t)smp_next, nxt);          // next step's scalars and actions, then the index after
+    if (s + 2 < nsteps) smp1 = a.perm[pos2];
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     f4 o[KS_NO];
     o[0] = layer_out(lds + L::W3, lds + L::B3, h2, j, q);
     o[1] = f4{0.f, 0.f, 0.f, 0.f};

@@ -349,6 +349,43 @@ def test_wide_dims_ppo_minibatch_steps_vs_oracle(dev, D, A, batch, steps):
                             floor_abs_max=_theta_floor(3e-4, steps))
 
 
+def test_feature_split_kernel_full_size_drift_envelope_at_humanoid_dims(dev):
+    """The persistent feature-split kernel (csrc/update_ks.hip) at BASELINE config 2's size with HumanoidVelocity's dims:
+    4096 envs x 128 steps = 524 288 rows of 376 observations / 17 actions, one learning iteration = 8 192 minibatch steps of 64
+    rows in ONE launch of 18 workgroups (ppo_lag.py:297-336).  Same gate as test_full_size_update_parity_drift_envelope has at
+    60 / 8: the first 8 steps at 1e-5 against the fp32 oracle; every 64-step window of the per-minibatch losses and the
+    parameters after 8 / 64 / 512 / 2 048 / 8 192 steps no further from the oracle's float64 trajectory than 3x the fp32 oracle
+    (= the reference's arithmetic) is itself; every shorter launch a bit-exact prefix of the longest (the exchange between the
+    workgroups does not depend on timing)."""
+    import envelope as E
+    from safepo.common.engine import WidePPOLagEngine
+    from test_gpu_parity import _fill_update_problem, _hip_prefix_runs
+    D, A, hidden, batch = 376, 17, [64, 64], 64
+    M = 4096 * 128
+    pol, ref = _wide_pair(D, A, hidden, dev, seed=5)
+    sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    cfg = {"hidden_sizes": hidden, "gamma": 0.99, "target_kl": 1e9, "batch_size": batch, "learning_iters": 1, "max_grad_norm": 40.0}
+    eng = WidePPOLagEngine(pol, 1, M, cfg, dev)
+    assert eng._feature_split_kernel_ok(eng._cfg_struct())
+    problem = _synthetic_update_problem(M, D, A, seed=2025)
+    _fill_update_problem(eng, problem)
+    perm = torch.randperm(M, generator=torch.Generator().manual_seed(8))
+    ks = (8, 64, 512, 2048, 8192)
+    runs = _hip_prefix_runs(eng, pol, pol.theta.clone(), perm.to(torch.int32).to(dev), batch, ks)
+    assert eng.adam_step == 8192
+    kmax = max(ks)
+    l32, t32 = E.oracle_trajectory(sd0, problem, perm, batch, kmax, torch.float32, ks, hidden_sizes=hidden)
+    l64, t64 = E.oracle_trajectory(sd0, problem, perm, batch, kmax, torch.float64, ks, hidden_sizes=hidden)
+    lh = runs[kmax][1]
+    np.testing.assert_allclose(lh[:8], l32[:8], rtol=1e-5, atol=1e-6, err_msg="first 8 steps")
+    rep = {"loss": E.assert_loss_envelope(lh, l32, l64, "feature-split full size")}
+    for k in ks:
+        assert np.array_equal(runs[k][1], lh[:k]), f"the {k}-step launch is not a prefix of the {kmax}-step launch"
+        rep[k] = E.assert_theta_envelope(runs[k][0], t32[k], t64[k], f"feature-split full size: theta after {k} steps",
+                                         floor_abs_max=_theta_floor(3e-4, k))
+    print("feature-split kernel, 376 / 17, drift envelope (ratio <= 1 passes):", rep)
+
+
 @pytest.mark.parametrize("algo", ["ppo_lag", "cppo_pid", "focops", "cup", "cpo", "pcpo", "rcpo", "trpo_lag"])
 def test_default_sweep_algorithms_train_at_humanoid_dims(dev, tmp_path, algo):
     """`ActorVCritic(376, 17)` trains under every algorithm of the reference's default sweep (benchmark.py:33-44) on the

@@ -12,8 +12,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "safe-policy-optimization_amd"))
 
 
-def one(hidden, batch, steps, D=60, A=8, **cfg_kw):
+def one(hidden, batch, steps, D=60, A=8, force_wide=False, **cfg_kw):
+    """force_wide: keep the launch-per-layer wide step where the engine would take the persistent feature-split kernel."""
     from safepo.common.engine import WidePPOLagEngine
+    prev = os.environ.get("SPO_WIDE_KS")
+    if force_wide:
+        os.environ["SPO_WIDE_KS"] = "0"
+    try:
+        return _one(WidePPOLagEngine, hidden, batch, steps, D, A, **cfg_kw)
+    finally:
+        if force_wide:
+            os.environ.pop("SPO_WIDE_KS", None) if prev is None else os.environ.__setitem__("SPO_WIDE_KS", prev)
+
+
+def _one(WidePPOLagEngine, hidden, batch, steps, D, A, **cfg_kw):
     from safepo.common.model import ActorVCritic
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -38,8 +50,14 @@ def one(hidden, batch, steps, D=60, A=8, **cfg_kw):
     sizes = [D] + list(hidden)
     mac = sum(a * c for a, c in zip(sizes[:-1], sizes[1:]))
     flops = 3 * 2.0 * batch * (2 * (mac + sizes[-1]) + (mac + sizes[-1] * A))        # fwd + 2x bwd, two critics + actor
-    return {"hidden_sizes": hidden, "batch": batch, "us_per_minibatch_step": round(dt * 1e6, 1), "tflops": round(flops / dt / 1e12, 2),
-            "params": int(pol.theta.numel())}
+    ks = eng._feature_split_kernel_ok(eng._cfg_struct())
+    if ks:
+        eng.check_sync_error()
+    return {"hidden_sizes": hidden, "batch": batch, "us_per_minibatch_step": round(dt * 1e6, 2 if ks else 1), "tflops": round(flops / dt / 1e12, 2),
+            "params": int(pol.theta.numel()),
+            "kernel": (f"ppo_update_ks_kernel: ONE persistent launch for the {steps} steps, 3 networks x {(D + 63) // 64} feature slices = "
+                       f"{3 * ((D + 63) // 64)} workgroups (csrc/update_ks.hip)") if ks else
+                      "launch-per-layer wide step (csrc/ma_net.hip kernels), full minibatches replayed from one HIP graph"}
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--isaac":
