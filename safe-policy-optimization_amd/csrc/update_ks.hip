@@ -252,6 +252,53 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
     if constexpr (FAST) __hip_atomic_store(dst, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else __hip_atomic_store(dst, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
+  // ---- deferred half of the optimiser step.  W1 / b1 are updated at the end of step s (the next partial layer 1 needs them); the
+  // rest -- W2, W3, b2, b3, log_std -- is first read by layer 2 of step s+1, BEHIND the exchange of the partials, so its Adam runs
+  // inside the two hand-offs of step s+1 (the store acknowledgements and the peers' latency pass under ~2.3 k cycles of vector work
+  // instead of under a spin).  The gradients wait in registers, the parameters are re-read from the LDS image.
+  f4 gW2[4], gW3[KS_NO];
+  float gb2 = 0.f, gb3[KS_NO], gpb3[KS_NO], gls = 0.f, pcoef = 0.f, pstep = 0.f, pinv = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) gW2[nt] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < KS_NO; ++t) { gW3[t] = f4{0.f, 0.f, 0.f, 0.f}; gb3[t] = 0.f; gpb3[t] = 0.f; }
+#define KS_ADAM(DST, P, G, M, V, COEF, SS, IB)                                         \
+  {                                                                                    \
+    const AdamOut _o = adam1((P), (G) * (COEF), (M), (V), b1c, b2c, eps, (SS), (IB));  \
+    (M) = _o.m; (V) = _o.v; (DST) = _o.p;                                              \
+  }
+  auto adam_w2 = [&]() {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* const w = lds + L::W2 + (orow + r) * LDH + 16 * nt + j;
+        KS_ADAM(*w, *w, gW2[nt][r], mW2[nt][r], vW2[nt][r], pcoef, pstep, pinv)
+      }
+  };
+  auto adam_w3_rest = [&]() {
+#pragma unroll
+    for (int t = 0; t < KS_NO; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {                                    // pad rows stay exactly 0
+        float* const w = lds + L::W3 + (16 * t + 4 * q + r) * LDH + 16 * wave + j;
+        KS_ADAM(*w, *w, gW3[t][r], mW3[t][r], vW3[t][r], pcoef, pstep, pinv)
+      }
+      float np3;
+      // b3[16 t + j] has a replica in EVERY wave (own moments each): the old value comes along in a register -- read from
+      // the image here, a later wave would pick up an earlier wave's update and apply the step twice
+      KS_ADAM(np3, gpb3[t], gb3[t], mb3[t], vb3[t], pcoef, pstep, pinv)
+      lds[L::B3 + 16 * t + j] = np3;         // (every replica writes the same bits)
+    }
+    if (own_ls) {
+      float nl;
+      KS_ADAM(nl, red[160 + tid], gls, mls, vls, pcoef, pstep, pinv)
+      red[160 + tid] = nl;
+    }
+    float np2;
+    KS_ADAM(np2, lds[L::B2 + 16 * wave + j], gb2, mb2, vb2, pcoef, pstep, pinv)
+    lds[L::B2 + 16 * wave + j] = np2;
+  };
   KsCol nxt;
   int smp1 = 0;
   fetch_obs((int64_t)a.perm[perm_pos(0)], nxt);
@@ -274,17 +321,27 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
     settle(cur);
     const int smp_next = pin(smp1);
     const int64_t pos2 = (s + 2 < nsteps) ? perm_pos(s + 2) : 0;
+    auto stage_xt = [&]() {                 // x^T image of this slice (B operand of the dW1 product, read after the staging barrier)
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+      for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) lds[L::XT + (16 * nt + 4 * q + e) * LDB + mycol] = cur.x[nt][e];
+        for (int e = 0; e < 4; ++e) lds[L::XT + (16 * nt + 4 * q + e) * LDB + mycol] = cur.x[nt][e];
+    };
 
     // ---- layer 1: this slice's partial pre-activation, then the sum over the slices (slice order: identical bits everywhere)
     f4 z1[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) z1[mt] = f4{0.f, 0.f, 0.f, 0.f};
     layer_accum<4>(lds + L::W1, LDH, cur.x, z1, j, q);
-    KS_STAMP(0)                                                        // settle, x^T, partial layer 1
+    KS_STAMP(0)                                                        // settle, partial layer 1
+    const unsigned pn = (unsigned)(par * 3 + net) * KS_MAX_SLICES;
+    const u4 sentinel = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    const unsigned mine = ((pn + (unsigned)ks) * KS_MAX_SLICES * 4u) * 4096u;
+    const unsigned ag0 = (unsigned)KS_ZRS_BYTES + (pn * 4u) * 4096u;
+    int own[4];
+#pragma unroll
+    for (int fq = 0; fq < 4; ++fq) own[fq] = ((4 * fq + wave) * S) >> 4;
+    if (S == 1) stage_xt();
     if (S > 1) {
       // All-reduce of the 64 x 64 partial pre-activations over the S workgroups of the network, as reduce-scatter + all-gather
       // (a flat all-to-all moves S^2 x 16 KB per network: 5.3 MB a step at S = 6, measured L2-bandwidth bound at 15 k cycles).
@@ -299,25 +356,23 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
       // the unit's owner -> the owner's poll -> the owner's broadcast of step s+1 -> the producer's poll of that -> the
       // producer's store of step s+2 into the slot.  The builtins are memory operations the compiler tracks (no inline-asm
       // load whose outputs could be copied while in flight).
-      const unsigned pn = (unsigned)(par * 3 + net) * KS_MAX_SLICES;
-      const u4 sentinel = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the resets of the previous step are acknowledged by the L2
       // Straight-line memory traffic: a branch between two stores makes the compiler put s_waitcnt vmcnt(0) at the join, and every
       // one of those is a full store acknowledgement (measured: 9 k cycles for the two hand-offs).  So every wave always issues the
       // same loads and stores, and the ones that do not apply go to two spare 4 KB rows: ZERO (never written: passes every poll)
       // and DUMP (never read).
-      int own[4];
 #pragma unroll
       for (int fq = 0; fq < 4; ++fq) {
-        own[fq] = ((4 * fq + wave) * S) >> 4;
         u4 w;
 #pragma unroll
         for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(z1[fq][e]);
         zstore(w, own[fq] != ks ? (((pn + (unsigned)own[fq]) * KS_MAX_SLICES + (unsigned)ks) * 4u + fq) * 4096u : (unsigned)KS_ZDUMP_OFF);
       }
       KS_STAMP(1)                                                      // reduce-scatter stores
-      const unsigned mine = ((pn + (unsigned)ks) * KS_MAX_SLICES * 4u) * 4096u;
-      const unsigned ag0 = (unsigned)KS_ZRS_BYTES + (pn * 4u) * 4096u;
+      stage_xt();                                                      // (under the hand-off's latency)
+    }
+    if (s > 0) adam_w2();                                              // deferred from step s-1, under the first hand-off
+    if (S > 1) {
 #pragma unroll
       for (int fq = 0; fq < 4; ++fq)
         if (own[fq] == ks) {                                           // (wave-uniform; at most one unit per wave from S = 4 up)
@@ -336,6 +391,9 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
             if (++spins > KS_SPIN_LIMIT) { *a.err = 1; break; }      // bounded: never hang the GPU
             __builtin_amdgcn_s_sleep(1);
           }
+#ifdef SPO_KS_PROF
+          if (tid == 0 && wg == 3 * a.S - 1) pacc[10] += spins + 1;
+#endif
 #pragma unroll
           for (int k = 0; k < KS_MAX_SLICES; ++k)
             zstore(sentinel, (k < S && k != ks) ? mine + (unsigned)(k * 4 + fq) * 4096u : (unsigned)KS_ZDUMP_OFF);
@@ -358,6 +416,9 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
           for (int c = 0; c < KS_MAX_SLICES; ++c)
             zstore(w, (c < S && c != ks) ? ag0 + (unsigned)(c * 4 + fq) * 4096u : (unsigned)KS_ZDUMP_OFF);
         }
+    }
+    if (s > 0) adam_w3_rest();                                         // ... and under the second
+    if (S > 1) {
       {
         u4 zg[4];
         unsigned spins = 0;
@@ -374,6 +435,9 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
           if (++spins > KS_SPIN_LIMIT) { *a.err = 1; break; }
           __builtin_amdgcn_s_sleep(1);
         }
+#ifdef SPO_KS_PROF
+        if (tid == 0 && wg == 3 * a.S - 1) pacc[11] += spins + 1;
+#endif
 #pragma unroll
         for (int fq = 0; fq < 4; ++fq) {
           zstore(sentinel, own[fq] != ks ? ag0 + (unsigned)(ks * 4 + fq) * 4096u : (unsigned)KS_ZDUMP_OFF);
@@ -382,6 +446,7 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
         }
       }
     }
+    if (s > 0) __syncthreads();                                        // W2, W3, b2, b3, log_std of step s-1's update are in place
     // prefetch AFTER the polls: loads return in order, so a poll issued behind the gather of the next minibatch would wait for
     // its HBM round trip as well.  In two halves with the layer-2 products in between: fourteen gathers in a row fill the
     // address queue and the wave sits on the issue (2.4 k cycles measured).
@@ -617,7 +682,6 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
     KS_STAMP(6)                                                        // weight gradients
     const float loss_data = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;
     const float dl = own_ls ? (red[32 + tid] + red[64 + tid]) + (red[96 + tid] + red[128 + tid]) : 0.f;   // d(loss)/d(log_std[tid])
-    const float pl = own_ls ? red[160 + tid] : 0.f;
 
     // ---- L2 regulariser of the critics (weights AND biases, ppo_lag.py:310-314), norm shares: the W1 slice / everything else
     float gsq1 = 0.f, psq1 = 0.f, gsqr = 0.f, psqr = 0.f;
@@ -720,44 +784,27 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
     }
     (void)nwg;
 
-    // ---- Adam (torch.optim.Adam, ppo_lag.py:104-117), parameters back into the LDS image
-#define KS_ADAM(DST, P, G, M, V)                                                       \
-  {                                                                                    \
-    const AdamOut _o = adam1((P), (G) * coef, (M), (V), b1c, b2c, eps, step_size, inv_bc2s);  \
-    (M) = _o.m; (V) = _o.v; (DST) = _o.p;                                              \
-  }
+    // ---- Adam (torch.optim.Adam, ppo_lag.py:104-117), parameters back into the LDS image: layer 1 now, the rest deferred (above)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {                                    // pad columns stay exactly 0
-        KS_ADAM(lds[L::W1 + (orow + r) * LDH + 16 * nt + j], pW1[nt][r], aW1[nt][r], mW1[nt][r], vW1[nt][r])
-        KS_ADAM(lds[L::W2 + (orow + r) * LDH + 16 * nt + j], pW2[nt][r], aW2[nt][r], mW2[nt][r], vW2[nt][r])
-      }
-#pragma unroll
-    for (int t = 0; t < KS_NO; ++t) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)                                      // pad rows stay exactly 0
-        KS_ADAM(lds[L::W3 + (16 * t + 4 * q + r) * LDH + 16 * wave + j], pW3[t][r], aW3[t][r], mW3[t][r], vW3[t][r])
-      float np3;
-      KS_ADAM(np3, pb3[t], db3[t], mb3[t], vb3[t])
-      lds[L::B3 + 16 * t + j] = np3;
-    }
-    if (own_ls) {
-      float nl;
-      KS_ADAM(nl, pl, dl, mls, vls)
-      red[160 + tid] = nl;
-    }
+      for (int r = 0; r < 4; ++r)                                      // pad columns stay exactly 0
+        KS_ADAM(lds[L::W1 + (orow + r) * LDH + 16 * nt + j], pW1[nt][r], aW1[nt][r], mW1[nt][r], vW1[nt][r], coef, step_size, inv_bc2s)
     {
-      float np1, np2;
-      KS_ADAM(np1, pb1, db1, mb1, vb1)
-      KS_ADAM(np2, pb2, db2, mb2, vb2)
+      float np1;
+      KS_ADAM(np1, pb1, db1, mb1, vb1, coef, step_size, inv_bc2s)
       lds[L::B1 + 16 * wave + j] = np1;
-      lds[L::B2 + 16 * wave + j] = np2;
     }
-#undef KS_ADAM
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) gW2[nt] = aW2[nt];
+#pragma unroll
+    for (int t = 0; t < KS_NO; ++t) { gW3[t] = aW3[t]; gb3[t] = db3[t]; gpb3[t] = pb3[t]; }
+    gb2 = db2; gls = dl; pcoef = coef; pstep = step_size; pinv = inv_bc2s;
     __syncthreads();
     KS_STAMP(9)                                                        // Adam + barrier
   }
+  if (nsteps > 0) { adam_w2(); adam_w3_rest(); __syncthreads(); }     // the last step's deferred half
+#undef KS_ADAM
 #ifdef SPO_KS_PROF
   if (tid == 0 && wg == 3 * a.S - 1)
     for (int i = 0; i < 16; ++i) g_ks_prof[i] = i == 15 ? (unsigned long long)FAST : pacc[i];

@@ -1,7 +1,7 @@
 # GPU box: PMC passes over the full-batch actor kernels (tools/fvp_ab.py); one small counter group per pass
 set -x
 cd /tmp && export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r03/fvp_pmc
+O=$GRAFT_REPO_ROOT/gpurun_out/${SPO_ROUND:-r05}/fvp_pmc
 mkdir -p $O
 i=0
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE" \
@@ -17,7 +17,7 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE
 done
 python - <<'PY'
 import csv, glob, os, collections, json
-O = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "r03", "fvp_pmc")
+O = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", os.environ.get("SPO_ROUND", "r05"), "fvp_pmc")
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(O + "/pass*.csv")):
     for r in csv.DictReader(open(f)):

@@ -46,10 +46,11 @@ def one(D, A, steps=2048, reps=3):
                 names = ["settle + partial L1", "partial stores", "partial polls + sums", "tanh, L2, L3", "loss + backward", "staging + barrier",
                          "weight gradients", "L2 terms, norms", "granule exchange", "Adam + barrier"]
                 prof = {n: round(buf[i] / steps) for i, n in enumerate(names)}
+                prof["poll iterations per step: owner / broadcast"] = (round(buf[10] / steps, 2), round(buf[11] / steps, 2))
         except AttributeError:
             pass
     if prof:
-        print("   cycles per step (thread 0 of the last workgroup):", prof, "total", sum(prof.values()), "co-resident" if buf[15] else "write-through")
+        print("   cycles per step (thread 0 of the last workgroup):", prof, "total", sum(v for v in prof.values() if not isinstance(v, tuple)), "co-resident" if buf[15] else "write-through")
     return {"obs_dim": D, "act_dim": A, "engine": type(eng).__name__, "feature_split": os.environ.get("SPO_WIDE_KS", "1") != "0",
             "us_per_minibatch_step": round(min(times[1:]) * 1e6 / steps, 2), "loss_finite": bool(torch.isfinite(losses).all())}
 

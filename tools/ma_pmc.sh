@@ -1,8 +1,8 @@
 # GPU box: PMC passes over the MAPPO-L training kernels (tools/ma_bench.py --episodes 1); one small counter group per pass
-# (separate runs, --kernel-trace only); per-kernel means -> gpurun_out/r03/ma_pmc/summary.json
+# (separate runs, --kernel-trace only); per-kernel means -> gpurun_out/${SPO_ROUND:-r05}/ma_pmc/summary.json
 set -x
 cd /tmp && export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r03/ma_pmc
+O=$GRAFT_REPO_ROOT/gpurun_out/${SPO_ROUND:-r05}/ma_pmc
 mkdir -p $O
 i=0
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE" \
@@ -18,7 +18,7 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE
 done
 python - <<'PY'
 import csv, glob, os, collections, json
-O = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "r03", "ma_pmc")
+O = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", os.environ.get("SPO_ROUND", "r05"), "ma_pmc")
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(O + "/pass*.csv")):
     for r in csv.DictReader(open(f)):

@@ -1,8 +1,8 @@
 # GPU box: PMC passes over the persistent update launch (tools/update_ab.py --one = 4 launches of 8192 minibatch steps).
-# One small counter group per pass (separate runs, --kernel-trace only); results -> gpurun_out/${SPO_ROUND:-r04}/update_pmc/*.csv
+# One small counter group per pass (separate runs, --kernel-trace only); results -> gpurun_out/${SPO_ROUND:-r05}/update_pmc/*.csv
 set -x
 cd /tmp && export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/${SPO_ROUND:-r04}/update_pmc
+O=$GRAFT_REPO_ROOT/gpurun_out/${SPO_ROUND:-r05}/update_pmc
 mkdir -p $O
 i=0
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE" \
@@ -19,7 +19,7 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE
 done
 python - <<'PY'
 import csv, glob, os, collections, json
-O = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", os.environ.get("SPO_ROUND", "r04"), "update_pmc")
+O = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", os.environ.get("SPO_ROUND", "r05"), "update_pmc")
 agg = collections.defaultdict(list)
 for f in sorted(glob.glob(O + "/pass*.csv")):
     for r in csv.DictReader(open(f)):
