@@ -67,6 +67,7 @@ def env_step():
 
 def post():
     eng.buffer.ptr = 0
+    eng._events_pending = False         # (timing loop: step 0 over and over, the episode log is not what is measured)
     eng.post_step(0, env.obs, env.reward, env.cost, env.terminated, env.truncated, env.final_obs, rms=None)
 
 
