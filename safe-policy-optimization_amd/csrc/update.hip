@@ -109,6 +109,9 @@ struct UpdArgs {
   int xr_debug;                        // SPO_A2A_DEBUG bits (development): 1 no row stores, 2 no flag stores/waits, 4 no row loads
   unsigned xr_step0;                   // global optimiser-step count before this launch (same on every rank)
   void* xr_region[XR_MAX_WORLD];       // every rank's exchange region (own + IPC-mapped peers), indexed by rank
+                                       // (one-grid split form: [2], [3] = the library's CACHED pair for the shared-L2 exchange)
+  unsigned long long* xr_census;       // one-grid split form: placement census words (or NULL)
+  unsigned xr_census_tag;
   float* backup;                       // main + helper form: [UPD_BACKUP_ROWS][3 workgroups][512 lanes] float4 backup rows
   int xr_helper_rd;                    // main + helper form, XR > 0: 1 = recursive doubling with tagged words on the helper
                                        // waves (default), 0 = flag-based all-to-all (SPO_P2P_A2A=1)
@@ -357,10 +360,26 @@ __device__ __forceinline__ u4v ld16_sys(const char* p) {
 #endif
   return v;
 }
+// Both ends of the hand-off on ONE XCD (the one-grid split critic fit, checked by a placement census): ordinary cached memory,
+// PLAIN stores (the line stays in the XCD's L2 -- an sc1 store writes it through and drops it) and sc1 loads (bypass the reader's
+// L1, served by that L2): a hand-off costs an L2 round trip, ~0.5 us, instead of ~2.1 us through uncached memory (round 5,
+// csrc/update_ks.hip).
+__device__ __forceinline__ void st16_l2(char* p, const u4v v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#endif
+}
+__device__ __forceinline__ u4v ld16_l2(const char* p) {
+  u4v v = {0u, 0u, 0u, 0u};
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+#endif
+  return v;
+}
 #ifndef SPO_XR16_VB
 #define SPO_XR16_VB 15         // packed words polled together: all 15 of a 60-wide network (A/B knob; 5 and 8 measured: profiles/r03/p2p_loopback_poll_batch_ab.txt)
 #endif
-template <int NV, int VB = SPO_XR16_VB>                          // VB: packed words polled together
+template <int NV, int VB = SPO_XR16_VB, bool LOCAL = false>    // VB: packed words polled together; LOCAL: shared-L2 flavour
 __device__ __forceinline__ void xr_allreduce_rd16(const u64* regions, int me, int R, int net, int tid, unsigned gtag,
                                                   f4 (&pk)[NV], volatile float* dead_word, int* err) {
   constexpr int NF = 4 * NV, NW = (NF + 2) / 3;
@@ -380,7 +399,7 @@ __device__ __forceinline__ void xr_allreduce_rd16(const u64* regions, int me, in
         word[i] = f < NF ? __float_as_uint(pk[(f < NF ? f : 0) >> 2][(f < NF ? f : 0) & 3]) : 0u;
       }
       word[3] = gtag;
-      st16_sys(p + (size_t)w * 4096, word);
+      if (LOCAL) st16_l2(p + (size_t)w * 4096, word); else st16_sys(p + (size_t)w * 4096, word);
     }
     const char* const src = reinterpret_cast<const char*>(regions[me]) + slot_b;
 #pragma unroll
@@ -390,7 +409,7 @@ __device__ __forceinline__ void xr_allreduce_rd16(const u64* regions, int me, in
       for (;;) {
 #pragma unroll
         for (int vv = 0; vv < VB; ++vv)
-          if (w0 + vv < NW) x[vv] = ld16_sys(src + (size_t)(w0 + vv) * 4096);
+          if (w0 + vv < NW) x[vv] = LOCAL ? ld16_l2(src + (size_t)(w0 + vv) * 4096) : ld16_sys(src + (size_t)(w0 + vv) * 4096);
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -1090,7 +1109,9 @@ __device__ __forceinline__ void ppo_update_body(const UpdArgs& a, const int wg) 
       pk[NT1 + 4] = aW3; pk[NT1 + 5] = f4{db1, db2, db3, 0.f}; pk[NT1 + 6] = dls;
       const u64* const xr_tab = reinterpret_cast<const u64*>(red + 144);
       const unsigned gtag = a.xr_step0 + (unsigned)s + 1u;
-      if (XR == 2 && SPO_XR_PACK16)
+      if (XR == 4)      // one-grid split form, all workgroups on one XCD: the library's cached pair of regions (table slots 2, 3)
+        xr_allreduce_rd16<NV, SPO_XR16_VB, true>(xr_tab + 2, a.xr_rank, a.xr_world, net, tid, gtag, pk, red + 112, a.err);
+      else if (XR == 2 && SPO_XR_PACK16)
         xr_allreduce_rd16<NV>(xr_tab, a.xr_rank, a.xr_world, net, tid, gtag, pk, red + 112, a.err);
       else if (XR == 2)
         xr_allreduce_rd<NV>(xr_tab, a.xr_rank, a.xr_world, net, tid, gtag, pk, red + 112, a.err);
@@ -1344,12 +1365,45 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
 // launch -- workgroups [0, n_nets) run rank 0's arguments, [n_nets, 2 n_nets) rank 1's (own replica, rows, outputs, granules,
 // error word) -- so they are co-resident by construction (one grid of four workgroups) instead of by the luck of two
 // streams landing on two hardware queues.  Recursive doubling at world 2: one hand-off per step.
+// Round 5: when a placement census finds all of them on ONE XCD (the grid of 8-block strides asks for it, nothing promises it) and
+// the host supplied a cached pair of regions (xr_region[2], [3]), the exchange runs through that XCD's L2 (XR = 4) instead of
+// through the uncached regions.
 template <int KIN>
 __global__ __launch_bounds__(256, 1) void ppo_update_split_kernel(UpdArgs a0, UpdArgs a1) {
   if (blockIdx.x & 7) return;
   const int wg = (int)(blockIdx.x >> 3);
-  if (wg < a0.n_nets) ppo_update_body<KIN, true, false, 0, 2>(a0, wg);
-  else ppo_update_body<KIN, true, false, 0, 2>(a1, wg - a0.n_nets);
+  extern __shared__ __attribute__((aligned(16))) float lds_split[];       // (the bodies' image: its first word serves the census)
+  int& s_other = *reinterpret_cast<int*>(lds_split);
+  bool local = false;
+  if (a0.xr_region[2] != nullptr && a0.xr_census != nullptr) {
+    const int nwg = 2 * a0.n_nets, tid = threadIdx.x;
+    const unsigned myx = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;      // HW_REG_XCC_ID
+    if (tid == 0) {
+      s_other = 0;
+      __hip_atomic_store(a0.xr_census + wg, ((unsigned long long)a0.xr_census_tag << 32) | myx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (tid < nwg) {
+      unsigned long long v = __hip_atomic_load(a0.xr_census + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned spins = 0;
+      while ((unsigned)(v >> 32) != a0.xr_census_tag) {
+        if (++spins > (1u << 22)) { s_other = 1; break; }              // (a census that never completes: the uncached form)
+        __builtin_amdgcn_s_sleep(1);
+        v = __hip_atomic_load(a0.xr_census + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if ((unsigned)v != myx) s_other = 1;
+    }
+    __syncthreads();
+    local = (s_other == 0);
+    __syncthreads();
+  }
+  if (local) {
+    if (wg < a0.n_nets) ppo_update_body<KIN, true, false, 0, 4>(a0, wg);
+    else ppo_update_body<KIN, true, false, 0, 4>(a1, wg - a0.n_nets);
+  } else {
+    if (wg < a0.n_nets) ppo_update_body<KIN, true, false, 0, 2>(a0, wg);
+    else ppo_update_body<KIN, true, false, 0, 2>(a1, wg - a0.n_nets);
+  }
 }
 
 // =====================================================================================================================
@@ -3239,6 +3293,34 @@ extern "C" int spo_critic_fit_iter_dp(float* theta, float* adam_m, float* adam_v
 // One grid of four workgroups is co-resident by construction, so -- unlike two launches on two streams (round 1 / 2: the
 // second stream could land on the first one's hardware queue and never run beside it) -- the form never depends on HIP's
 // queue assignment.  cpo.py:534-571: identical arithmetic to the mean over the 128 rows up to the order of the sums.
+// Cached pair of exchange regions + census words of the one-grid split form (round 5), one block per device, allocated on
+// first use.  Cleared by every launch (tags restart with every engine; 13 MB at HBM speed is ~5 us against a 0.5 s launch).
+struct SplitLocal { char* base; unsigned tag; };
+static SplitLocal g_split_local[SPO_MAX_DEVICES] = {};
+static std::mutex g_split_local_mu;
+static int split_local_for(hipStream_t st, UpdArgs& a, UpdArgs& b) {
+  static const bool off = [] { const char* e = getenv("SPO_CPO_SPLIT_L2"); return e && !strcmp(e, "0"); }();
+  if (off) return 0;
+  const int dev = current_device_slot();
+  std::lock_guard<std::mutex> lk(g_split_local_mu);
+  SplitLocal& sl = g_split_local[dev];
+  if (!sl.base) {
+    void* p = nullptr;
+    if (int rc = spo::hip_check(hipMalloc(&p, 2 * XR_REGION_BYTES + 256), "hipMalloc(split exchange, cached)")) return rc;
+    if (int rc = spo::hip_check(hipMemset(p, 0, 2 * XR_REGION_BYTES + 256), "hipMemset(split exchange)")) { (void)hipFree(p); return rc; }
+    sl.base = static_cast<char*>(p); sl.tag = 1u;
+  }
+  if (int rc = spo::hip_check(hipMemsetAsync(sl.base, 0, 2 * XR_REGION_BYTES, st),
+                              "hipMemsetAsync(split exchange)")) return rc;
+  for (UpdArgs* u : {&a, &b}) {
+    u->xr_region[2] = sl.base; u->xr_region[3] = sl.base + XR_REGION_BYTES;
+    u->xr_census = reinterpret_cast<unsigned long long*>(sl.base + 2 * XR_REGION_BYTES);
+    u->xr_census_tag = sl.tag;
+  }
+  sl.tag += 1u;
+  return 0;
+}
+
 extern "C" int spo_critic_fit_iter_split(float* theta0, float* adam_m0, float* adam_v0, float* theta1, float* adam_m1,
                                          float* adam_v1, int64_t adam_step_host, const float* obs, const float* target_r,
                                          const float* target_c, const int32_t* perm0, const int32_t* perm1, int64_t M_half,
@@ -3302,6 +3384,7 @@ extern "C" int spo_critic_fit_iter_split(float* theta0, float* adam_m0, float* a
     SPO_LAUNCH_CHECK("spo_critic_fit_iter_split");
     return 0;
   }
+  if (int rc = split_local_for(st, a, b)) return rc;   // (SPO_CPO_SPLIT_L2=0: the uncached regions whatever the placement)
 #define SPO_SPLIT(K)                                                                                              \
   {                                                                                                               \
     const size_t sh = UpdLds<K>::SIZE * sizeof(float);                                                            \
