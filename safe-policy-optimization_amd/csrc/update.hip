@@ -566,7 +566,7 @@ __device__ __forceinline__ void xr_allreduce_rs16(const u64* regions, int me, in
 // travel as ceil(NF / 3) words {f0, f1, f2, tag} starting at word W0 of the slot, ALL of them polled together (one dependent
 // round trip per hand-off), so a stage of the step (layer 1 = 4 NT1 + 1 floats, layers 2 / 3 = 26 floats) is 6 + 9 words
 // instead of the 20 + 28 eight-byte words in two poll batches each of xr_allreduce_rd.  Same slot / tag / parity discipline.
-template <int NF, int W0>
+template <int NF, int W0, bool LOCAL = false>
 __device__ __forceinline__ void xr_rd16_flat(const u64* regions, int me, int R, int net, int tid, unsigned gtag,
                                              float (&pf)[NF], volatile float* dead_word, int* err) {
   constexpr int NW = (NF + 2) / 3;
@@ -583,14 +583,14 @@ __device__ __forceinline__ void xr_rd16_flat(const u64* regions, int me, int R, 
 #pragma unroll
       for (int i = 0; i < 3; ++i) word[i] = (3 * w + i) < NF ? __float_as_uint(pf[(3 * w + i) < NF ? 3 * w + i : 0]) : 0u;
       word[3] = gtag;
-      st16_sys(p + (size_t)w * 4096, word);
+      if (LOCAL) st16_l2(p + (size_t)w * 4096, word); else st16_sys(p + (size_t)w * 4096, word);
     }
     const char* const src = reinterpret_cast<const char*>(regions[me]) + slot_b;
     u4v x[NW];
     unsigned spins = 0;
     for (;;) {
 #pragma unroll
-      for (int w = 0; w < NW; ++w) x[w] = ld16_sys(src + (size_t)w * 4096);
+      for (int w = 0; w < NW; ++w) x[w] = LOCAL ? ld16_l2(src + (size_t)w * 4096) : ld16_sys(src + (size_t)w * 4096);
 #if defined(__HIP_DEVICE_COMPILE__)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -1365,13 +1365,9 @@ __global__ __launch_bounds__(256, 1) void ppo_update_kernel(UpdArgs a) {
 // launch -- workgroups [0, n_nets) run rank 0's arguments, [n_nets, 2 n_nets) rank 1's (own replica, rows, outputs, granules,
 // error word) -- so they are co-resident by construction (one grid of four workgroups) instead of by the luck of two
 // streams landing on two hardware queues.  Recursive doubling at world 2: one hand-off per step.
-// Round 5: when a placement census finds all of them on ONE XCD (the grid of 8-block strides asks for it, nothing promises it) and
-// the host supplied a cached pair of regions (xr_region[2], [3]), the exchange runs through that XCD's L2 (XR = 4) instead of
-// through the uncached regions.
-template <int KIN>
-__global__ __launch_bounds__(256, 1) void ppo_update_split_kernel(UpdArgs a0, UpdArgs a1) {
-  if (blockIdx.x & 7) return;
-  const int wg = (int)(blockIdx.x >> 3);
+// Placement census of the one-grid split forms: true when every workgroup of the launch reports the same XCC id (words any
+// placement delivers: agent-scope atomics) and the host supplied the cached pair of regions.
+__device__ __forceinline__ bool split_census(const UpdArgs& a0, const int wg) {
   extern __shared__ __attribute__((aligned(16))) float lds_split[];       // (the bodies' image: its first word serves the census)
   int& s_other = *reinterpret_cast<int*>(lds_split);
   bool local = false;
@@ -1397,6 +1393,17 @@ __global__ __launch_bounds__(256, 1) void ppo_update_split_kernel(UpdArgs a0, Up
     local = (s_other == 0);
     __syncthreads();
   }
+  return local;
+}
+
+// Round 5: when a placement census finds all of them on ONE XCD (the grid of 8-block strides asks for it, nothing promises it) and
+// the host supplied a cached pair of regions (xr_region[2], [3]), the exchange runs through that XCD's L2 (XR = 4) instead of
+// through the uncached regions.
+template <int KIN>
+__global__ __launch_bounds__(256, 1) void ppo_update_split_kernel(UpdArgs a0, UpdArgs a1) {
+  if (blockIdx.x & 7) return;
+  const int wg = (int)(blockIdx.x >> 3);
+  const bool local = split_census(a0, wg);
   if (local) {
     if (wg < a0.n_nets) ppo_update_body<KIN, true, false, 0, 4>(a0, wg);
     else ppo_update_body<KIN, true, false, 0, 4>(a1, wg - a0.n_nets);
@@ -2199,15 +2206,15 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
 #pragma unroll
         for (int nt = 0; nt < NT1; ++nt) gx[nt] = *reinterpret_cast<const f4*>(lds + H::G1 + ((wave * NT1 + nt) * 64 + lane) * 4);
         gx[NT1] = f4{lds[H::GB + 0 * 256 + hl], 0.f, 0.f, 0.f};
-        if constexpr (XRD == 2) {
-          // packed words, one poll batch: words 0 .. NWA - 1 of the slot
+        if constexpr (XRD == 2 || XRD == 3) {
+          // packed words, one poll batch: words 0 .. NWA - 1 of the slot (XRD = 3: through the XCD's L2, cached regions [2], [3])
           float gf[4 * NT1 + 1];
 #pragma unroll
           for (int nt = 0; nt < NT1; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) gf[4 * nt + r] = gx[nt][r];
           gf[4 * NT1] = gx[NT1][0];
-          xr_rd16_flat<4 * NT1 + 1, 0>(xtab, a.xr_rank, XR, net, hl, gtag, gf,
+          xr_rd16_flat<4 * NT1 + 1, 0, XRD == 3>(xtab + (XRD == 3 ? 2 : 0), a.xr_rank, XR, net, hl, gtag, gf,
                                        reinterpret_cast<volatile float*>(lds + H::XW + 21), a.err);
 #pragma unroll
           for (int nt = 0; nt < NT1; ++nt)
@@ -2281,7 +2288,7 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
         }
       }
       const int rows7[7] = {NT1 + 0, NT1 + 1, NT1 + 2, NT1 + 3, NT1 + 4, NT1 + 7, NT1 + 6};
-      if constexpr (XRD == 2) {
+      if constexpr (XRD == 2 || XRD == 3) {
         // packed words NWA .. NWA + 8 of the slot: W2 tiles, W3 tile, db2, db3, the log_std row (zeros except wave 0 of the actor)
         constexpr int NWA = (4 * NT1 + 1 + 2) / 3;
         float gf[26];
@@ -2292,7 +2299,7 @@ __device__ __forceinline__ void ppo_update_h_body(const UpdArgs& a, const int wg
         gf[20] = gx[5][0]; gf[21] = gx[5][1];
 #pragma unroll
         for (int r = 0; r < 4; ++r) gf[22 + r] = gx[6][r];
-        xr_rd16_flat<26, NWA>(xtab, a.xr_rank, XR, net, hl, gtag, gf,
+        xr_rd16_flat<26, NWA, XRD == 3>(xtab + (XRD == 3 ? 2 : 0), a.xr_rank, XR, net, hl, gtag, gf,
                               reinterpret_cast<volatile float*>(lds + H::XW + 21), a.err);
 #pragma unroll
         for (int nt = 0; nt < 5; ++nt)
@@ -2746,8 +2753,13 @@ template <int KIN>
 __global__ __launch_bounds__(512) void ppo_update_h_split_kernel(UpdArgs a0, UpdArgs a1) {
   if (blockIdx.x & 7) return;
   const int wg = (int)(blockIdx.x >> 3);
-  if (wg < a0.n_nets) ppo_update_h_body<KIN, false, 2, 2>(a0, wg);
-  else ppo_update_h_body<KIN, false, 2, 2>(a1, wg - a0.n_nets);
+  if (split_census(a0, wg)) {
+    if (wg < a0.n_nets) ppo_update_h_body<KIN, false, 2, 3>(a0, wg);
+    else ppo_update_h_body<KIN, false, 2, 3>(a1, wg - a0.n_nets);
+  } else {
+    if (wg < a0.n_nets) ppo_update_h_body<KIN, false, 2, 2>(a0, wg);
+    else ppo_update_h_body<KIN, false, 2, 2>(a1, wg - a0.n_nets);
+  }
 }
 
 // Split form, second half: joint clip + Adam over the flat vector (one workgroup; P ~ 25k).
@@ -3364,6 +3376,7 @@ extern "C" int spo_critic_fit_iter_split(float* theta0, float* adam_m0, float* a
     static const int spec_env = [] { const char* e = getenv("SPO_UPDATE_SPEC"); return e ? atoi(e) : 1; }();
     a.spec_mode = b.spec_mode = spec_env;
     a.xr_helper_rd = b.xr_helper_rd = 1;
+    if (int rc = split_local_for(st, a, b)) return rc;
     if (int rc = spo::hip_check(hipMemsetAsync(a.slots, 0, H_SLOT_BYTES, st), "hipMemsetAsync(update scratch slots)")) return rc;
     if (int rc = spo::hip_check(hipMemsetAsync(b.slots, 0, H_SLOT_BYTES, st), "hipMemsetAsync(update scratch slots)")) return rc;
 #define SPO_SPLIT_H(K)                                                                                            \
