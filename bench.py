@@ -42,6 +42,21 @@ GAE_DISPATCHES = 50              # individually event-bracketed launches per tim
 PEER_EXCHANGE_USED = [False]     # set by run_epochs on rank 0 (N > 1): which form of the minibatch exchange ran
 
 
+def _critic_fit_cases():
+    """us per 128-row minibatch step of the second-order scripts' critic fit (cpo.py:541-571) at HumanoidVelocity's dims: the
+    feature-split persistent kernel with two networks against the launch-per-layer wide path (SPO_WIDE_KS=0)."""
+    import ks_cfit_bench
+    out = [dict(ks_cfit_bench.one(376, 17, 128 * 2048), kernel="critic_fit_ks_kernel: ONE persistent launch per learning iteration, "
+                "2 networks x 6 feature slices = 12 workgroups, a 128-row minibatch as two 64-column chunks (csrc/update_ks.hip)")]
+    prev = os.environ.get("SPO_WIDE_KS")
+    os.environ["SPO_WIDE_KS"] = "0"
+    try:
+        out.append(dict(ks_cfit_bench.one(376, 17, 128 * 256), kernel="launch-per-layer wide step (SPO_WIDE_KS=0), HIP-graph replay"))
+    finally:
+        os.environ.pop("SPO_WIDE_KS", None) if prev is None else os.environ.__setitem__("SPO_WIDE_KS", prev)
+    return out
+
+
 def profile_path(name: str) -> str:
     """The newest committed copy of a profile artefact (profiles/r05, else r04, r03, r02)."""
     for rnd in ("r05", "r04", "r03", "r02"):
@@ -626,7 +641,8 @@ def main():
                           "cases": [dict(wide_bench.one([128, 128], 64, 256), obs_dim=60, act_dim=8),
                                     dict(wide_bench.one([64, 64], 64, 4096, D=376, A=17), obs_dim=376, act_dim=17),
                                     dict(wide_bench.one([64, 64], 64, 256, D=376, A=17, force_wide=True), obs_dim=376, act_dim=17,
-                                         note="SPO_WIDE_KS=0: the path rounds 3-4 took at these dims")]}
+                                         note="SPO_WIDE_KS=0: the path rounds 3-4 took at these dims")],
+                          "critic_fit_cases": _critic_fit_cases()}
         except Exception as e:  # pragma: no cover
             wide_entry = {"error": str(e)[:300]}
     line = {

@@ -305,7 +305,9 @@ int spo_update_iter_ex(float* theta, float* adam_m, float* adam_v, int64_t adam_
  * spo_p2p_selftest runs `iters` exchange rounds of known patterns on the same grid and protocol:
  * result2_dev[0] = wrong values, result2_dev[1] = 2 after a timeout; it consumes `iters` tags. */
 int64_t spo_p2p_region_bytes(void);
-int spo_debug_xr_profile(unsigned long long* out8_host, int reset);   /* spo_ppo_lag_update_iter for wide observations / action vectors (round 5; csrc/update_ks.hip): obs_dim <= 512, act_dim <= 32,
+int spo_debug_xr_profile(unsigned long long* out8_host, int reset);
+
+/* spo_ppo_lag_update_iter for wide observations / action vectors (round 5; csrc/update_ks.hip): obs_dim <= 512, act_dim <= 32,
  * batch <= 64, hidden [64, 64], the clipped-surrogate loss, one GPU.  The first layer is split over the input features, 64 per
  * workgroup: 3 x ceil(obs_dim / 64) persistent workgroups exchange the partial pre-activations inside the step; same
  * arguments, results and per-step loss log as spo_ppo_lag_update_iter (reference: safepo/single_agent/ppo_lag.py:297-336 with
@@ -315,6 +317,14 @@ int spo_ppo_lag_update_iter_ks(float* theta, float* adam_m, float* adam_v, int64
                                const float* act, const float* logp_old, const float* target_r, const float* target_c,
                                const float* adv, const int32_t* perm, int64_t M, const spo_ppo_cfg* cfg_host,
                                float* losses_out, void* sync_ws, void* stream);
+/* spo_critic_fit_iter on the same feature-split kernel (two networks): the critic fit of the second-order scripts
+ * (safepo/single_agent/cpo.py:541-571) for obs_dim <= 512, hidden [64, 64], batch <= 128 (a minibatch is taken as two 64-column
+ * chunks whose gradients accumulate before the optimiser step), one GPU.  Same arguments and results as spo_critic_fit_iter;
+ * cfg_host->act_dim only locates the critics in the flat parameter vector. */
+int spo_critic_fit_ks_supported(int obs_dim, int batch);
+int spo_critic_fit_iter_ks(float* theta, float* adam_m, float* adam_v, int64_t adam_step_host, const float* obs,
+                           const float* target_r, const float* target_c, const int32_t* perm, int64_t M,
+                           const spo_ppo_cfg* cfg_host, float* stale_sq_io, float* losses_out, void* sync_ws, void* stream);
 
 /* Form of the in-kernel gradient exchange (which of the built all-reduce forms runs inside the persistent update
  * kernel).  spo_p2p_select_form pins one for the process (-1: back to the default policy: environment overrides, else recursive

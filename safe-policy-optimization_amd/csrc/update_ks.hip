@@ -74,6 +74,8 @@ struct KsArgs {
   double pow_b1, pow_b2;
   unsigned tag_base;                   // tags of this launch: tag_base + step + 1 (never reused: no clearing between launches)
   int S;
+  int n_nets;                          // 3: PPO-family step; 2: the critic fit of the second-order scripts (CFIT instantiation)
+  float* stale_io;                     // critic fit: ||actor.grad||^2 that the joint clip still sees and rescales (cpo.py:557), in / out
   int force_safe;                      // SPO_KS_SAFE=1: write-through exchange stores whatever the placement (tests)
 };
 
@@ -90,12 +92,14 @@ struct KsCol {                         // per-column inputs of one minibatch, pr
 
 #ifdef SPO_KS_PROF
 __device__ unsigned long long g_ks_prof[16];      // development builds: cycles per interval of the step (thread 0 of the LAST workgroup: the actor's last slice)
-#define KS_STAMP(i) { if (tid == 0 && wg == 3 * a.S - 1) { const unsigned long long _t = __builtin_readcyclecounter(); pacc[i] += _t - tprev; tprev = _t; } }
+#define KS_STAMP(i) { if (tid == 0 && wg == a.n_nets * a.S - 1) { const unsigned long long _t = __builtin_readcyclecounter(); pacc[i] += _t - tprev; tprev = _t; } }
 #else
 #define KS_STAMP(i)
 #endif
 // FAST: every workgroup of the launch sits on one XCD (checked by the kernel below), stores of the exchange stay plain
-template <bool FAST>
+// CFIT: the critic fit of the second-order scripts (cpo.py:541-571): two networks, minibatches of up to 128 rows taken as two
+// 64-column chunks whose weight gradients accumulate before the one optimiser step, the actor's stale gradient in the joint norm.
+template <bool FAST, bool CFIT>
 __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
 #ifdef SPO_KS_PROF
   unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
@@ -177,11 +181,17 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
   const int64_t nsteps = (a.M + B - 1) / B;
   const int mycol = 16 * wave + j;
 
-  auto perm_pos = [&](int64_t s) -> int64_t {
-    const int64_t base = s * B;
+  const int H = CFIT ? (B + 63) / 64 : 1;                       // 64-column chunks per minibatch (<= 2)
+  const int64_t nchunks = nsteps * H;
+  auto perm_pos = [&](int64_t e2) -> int64_t {                   // row of the permutation this lane's column takes in chunk e2
+    const int64_t s2 = (CFIT && H == 2) ? (e2 >> 1) : e2;
+    const int h2 = (CFIT && H == 2) ? (int)(e2 & 1) : 0;
+    const int64_t base = s2 * B;
     const int64_t rem = a.M - base;
-    const int ncols = (int)(rem < B ? rem : B);
-    return base + (mycol < ncols ? mycol : 0);
+    const int nst = (int)(rem < B ? rem : B);
+    int nc = nst - 64 * h2; nc = nc < 0 ? 0 : (nc > 64 ? 64 : nc);
+    const int64_t pos = base + 64 * h2 + (mycol < nc ? mycol : 0);
+    return pos < a.M ? pos : a.M - 1;                             // (an empty second chunk: any valid row, every column masked)
   };
   auto fetch_obs = [&](int64_t smp, KsCol& cd) {
     {
@@ -303,24 +313,31 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
   int smp1 = 0;
   fetch_obs((int64_t)a.perm[perm_pos(0)], nxt);
   fetch_rest((int64_t)a.perm[perm_pos(0)], nxt);
-  if (nsteps > 1) smp1 = a.perm[perm_pos(1)];
+  if (nchunks > 1) smp1 = a.perm[perm_pos(1)];
+  float stale_sq = (CFIT && a.stale_io) ? *a.stale_io : 0.f;
+  f4 aW1[4], aW2[4], aW3[KS_NO];                                // weight-gradient accumulators (across the chunks of a minibatch)
+  float db1 = 0.f, db2 = 0.f, db3[KS_NO];
 
-  for (int64_t s = 0; s < nsteps; ++s) {
+  for (int64_t e = 0; e < nchunks; ++e) {
+    const int64_t s = (CFIT && H == 2) ? (e >> 1) : e;
+    const int h = (CFIT && H == 2) ? (int)(e & 1) : 0;
     const int64_t base = s * B;
     const int64_t rem = a.M - base;
-    const int ncols = (int)(rem < B ? rem : B);
-    const float inv_n = 1.f / (float)ncols;
+    const int ncols_step = (int)(rem < B ? rem : B);
+    int ncols = ncols_step - 64 * h; ncols = ncols < 0 ? 0 : (ncols > 64 ? 64 : ncols);
+    const float inv_n = 1.f / (float)ncols_step;
     const bool cv = mycol < ncols;
-    const unsigned tag = a.tag_base + (unsigned)s + 1u;
-    const int par = (int)(s & 1);
+    const unsigned tag = a.tag_base + (unsigned)s + 1u;           // (granules: one exchange per minibatch step)
+    const int par = (int)(e & 1);                                  // (partials: one exchange per chunk)
+    const int gpar = (int)(s & 1);
 
 #ifdef SPO_KS_PROF
-    if (tid == 0 && wg == 3 * a.S - 1) tprev = __builtin_readcyclecounter();
+    if (tid == 0 && wg == a.n_nets * a.S - 1) tprev = __builtin_readcyclecounter();
 #endif
     KsCol cur = nxt;
     settle(cur);
     const int smp_next = pin(smp1);
-    const int64_t pos2 = (s + 2 < nsteps) ? perm_pos(s + 2) : 0;
+    const int64_t pos2 = (e + 2 < nchunks) ? perm_pos(e + 2) : 0;
     auto stage_xt = [&]() {                 // x^T image of this slice (B operand of the dW1 product, read after the staging barrier)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
@@ -371,7 +388,7 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
       KS_STAMP(1)                                                      // reduce-scatter stores
       stage_xt();                                                      // (under the hand-off's latency)
     }
-    if (s > 0) adam_w2();                                              // deferred from step s-1, under the first hand-off
+    if (s > 0 && h == 0) adam_w2();                                    // deferred from step s-1, under the first hand-off
     if (S > 1) {
 #pragma unroll
       for (int fq = 0; fq < 4; ++fq)
@@ -392,7 +409,7 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
             __builtin_amdgcn_s_sleep(1);
           }
 #ifdef SPO_KS_PROF
-          if (tid == 0 && wg == 3 * a.S - 1) pacc[10] += spins + 1;
+          if (tid == 0 && wg == a.n_nets * a.S - 1) pacc[10] += spins + 1;
 #endif
 #pragma unroll
           for (int k = 0; k < KS_MAX_SLICES; ++k)
@@ -417,7 +434,7 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
             zstore(w, (c < S && c != ks) ? ag0 + (unsigned)(c * 4 + fq) * 4096u : (unsigned)KS_ZDUMP_OFF);
         }
     }
-    if (s > 0) adam_w3_rest();                                         // ... and under the second
+    if (s > 0 && h == 0) adam_w3_rest();                               // ... and under the second
     if (S > 1) {
       {
         u4 zg[4];
@@ -436,7 +453,7 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
           __builtin_amdgcn_s_sleep(1);
         }
 #ifdef SPO_KS_PROF
-        if (tid == 0 && wg == 3 * a.S - 1) pacc[11] += spins + 1;
+        if (tid == 0 && wg == a.n_nets * a.S - 1) pacc[11] += spins + 1;
 #endif
 #pragma unroll
         for (int fq = 0; fq < 4; ++fq) {
@@ -446,11 +463,11 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
         }
       }
     }
-    if (s > 0) __syncthreads();                                        // W2, W3, b2, b3, log_std of step s-1's update are in place
+    if (s > 0 && h == 0) __syncthreads();                              // W2, W3, b2, b3, log_std of step s-1's update are in place
     // prefetch AFTER the polls: loads return in order, so a poll issued behind the gather of the next minibatch would wait for
     // its HBM round trip as well.  In two halves with the layer-2 products in between: fourteen gathers in a row fill the
     // address queue and the wave sits on the issue (2.4 k cycles measured).
-    if (s + 1 < nsteps) fetch_obs((int64_t)smp_next, nxt);
+    if (e + 1 < nchunks) fetch_obs((int64_t)smp_next, nxt);
 #if defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -462,8 +479,8 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_sched_barrier(0);
 #endif
-    if (s + 1 < nsteps) fetch_rest((int64_t)smp_next, nxt);          // next step's scalars and actions, then the index after
-    if (s + 2 < nsteps) smp1 = a.perm[pos2];
+    if (e + 1 < nchunks) fetch_rest((int64_t)smp_next, nxt);         // next chunk's scalars and actions, then the index after
+    if (e + 2 < nchunks) smp1 = a.perm[pos2];
 #if defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -589,7 +606,7 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
       for (int r = 0; r < 4; ++r) lds[L::DOT + (16 * t + 4 * q + r) * LDB + mycol] = dO[t][r];
     {
       const float ls = wave_sum_lane63(lsum);
-      if (lane == 63) red[wave] = ls;
+      if (lane == 63) red[wave] = (CFIT && h > 0) ? red[wave] + ls : ls;
       if (is_actor) {
 #pragma unroll
         for (int t = 0; t < KS_NO; ++t)
@@ -604,8 +621,6 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
     KS_STAMP(5)                                                        // staging + barrier
 
     // ---- dW[o][i] = sum_b dZ[b][o] * Hprev[b][i]; wave w owns rows 16w .. 16w+15 (W1 slice, W2) / h2 units 16w .. (W3)
-    f4 aW1[4], aW2[4], aW3[KS_NO];
-    float db1, db2, db3[KS_NO];
     {
       f4 az1[4], az2[4];
 #pragma unroll
@@ -613,8 +628,10 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
         az1[r4] = *reinterpret_cast<const f4*>(lds + L::DZ1T + (16 * wave + j) * LDB + 16 * r4 + 4 * q);
         az2[r4] = *reinterpret_cast<const f4*>(lds + L::DZ2T + (16 * wave + j) * LDB + 16 * r4 + 4 * q);
       }
+      if (!CFIT || h == 0) {
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) { aW1[nt] = f4{0.f, 0.f, 0.f, 0.f}; aW2[nt] = f4{0.f, 0.f, 0.f, 0.f}; }
+        for (int nt = 0; nt < 4; ++nt) { aW1[nt] = f4{0.f, 0.f, 0.f, 0.f}; aW2[nt] = f4{0.f, 0.f, 0.f, 0.f}; }
+      }
       f4 bh[2][4];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) bh[0][nt] = *reinterpret_cast<const f4*>(lds + L::H1T + (16 * nt + j) * LDB + 4 * q);
@@ -635,8 +652,7 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
       for (int r4 = 0; r4 < 4; ++r4) b3[r4] = *reinterpret_cast<const f4*>(lds + L::H2T + (16 * wave + j) * LDB + 16 * r4 + 4 * q);
 #pragma unroll
       for (int t = 0; t < KS_NO; ++t) {
-        aW3[t] = f4{0.f, 0.f, 0.f, 0.f};
-        db3[t] = 0.f;
+        if (!CFIT || h == 0) { aW3[t] = f4{0.f, 0.f, 0.f, 0.f}; db3[t] = 0.f; }
         if (t < nto) {
           f4 az3[4];
 #pragma unroll
@@ -649,11 +665,11 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
               w3a = mfma4(az3[r4][e], b3[r4][e], w3a);
               w3b = mfma4(az3[r4 + 1][e], b3[r4 + 1][e], w3b);
             }
-          aW3[t] = w3a + w3b;
+          if (CFIT && h > 0) aW3[t] = aW3[t] + (w3a + w3b); else aW3[t] = w3a + w3b;
           float rs3 = 0.f;
 #pragma unroll
           for (int r4 = 0; r4 < 4; ++r4) rs3 += (az3[r4][0] + az3[r4][1]) + (az3[r4][2] + az3[r4][3]);
-          db3[t] = quad_row_sum(rs3);
+          if (CFIT && h > 0) db3[t] += quad_row_sum(rs3); else db3[t] = quad_row_sum(rs3);
         }
       }
       f4 bx[2][4];
@@ -677,9 +693,11 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
         rs1 += (az1[r4][0] + az1[r4][1]) + (az1[r4][2] + az1[r4][3]);
         rs2 += (az2[r4][0] + az2[r4][1]) + (az2[r4][2] + az2[r4][3]);
       }
-      db1 = quad_row_sum(rs1); db2 = quad_row_sum(rs2);
+      if (CFIT && h > 0) { db1 += quad_row_sum(rs1); db2 += quad_row_sum(rs2); }
+      else { db1 = quad_row_sum(rs1); db2 = quad_row_sum(rs2); }
     }
     KS_STAMP(6)                                                        // weight gradients
+    if (CFIT && h + 1 < H) { __syncthreads(); continue; }             // (the images are free for the minibatch's second chunk)
     const float loss_data = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;
     const float dl = own_ls ? (red[32 + tid] + red[64 + tid]) + (red[96 + tid] + red[128 + tid]) : 0.f;   // d(loss)/d(log_std[tid])
 
@@ -741,9 +759,9 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
 
     KS_STAMP(7)                                                        // L2 terms, norm shares, barrier
     // ---- joint clip_grad_norm_ over all networks (ppo_lag.py:325): one granule per workgroup
-    unsigned long long* const gg = a.gran + (size_t)par * 2 * 3 * KS_MAX_SLICES;
+    unsigned long long* const gg = a.gran + (size_t)gpar * 2 * 3 * KS_MAX_SLICES;
     unsigned long long* const gp = gg + 3 * KS_MAX_SLICES;
-    const int nwg = 3 * S;
+    const int nwg = a.n_nets * S;
     if (tid == 0) {
       const float gs = ((red[4] + red[5]) + (red[6] + red[7])) + (first ? ((red[8] + red[9]) + (red[10] + red[11])) : 0.f);
       const float ps = ((red[12] + red[13]) + (red[14] + red[15])) + (first ? ((red[16] + red[17]) + (red[18] + red[19])) : 0.f);
@@ -757,7 +775,7 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
       const int kind = tid / (3 * KS_MAX_SLICES), idx = tid - kind * 3 * KS_MAX_SLICES;
       const int n2 = idx / KS_MAX_SLICES, k2 = idx - n2 * KS_MAX_SLICES;
       float val = 0.f;
-      if (k2 < S) {
+      if (k2 < S && n2 < a.n_nets) {
         unsigned long long* const src = (kind ? gp : gg) + idx;
         unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
@@ -772,11 +790,12 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
     }
     __syncthreads();
     KS_STAMP(8)                                                        // granule exchange
-    float total_sq = 0.f;
+    float total_sq = CFIT ? stale_sq : 0.f;
     for (int i = 0; i < 3 * KS_MAX_SLICES; ++i) total_sq += red[192 + i];   // fixed order: identical in every workgroup
     const float norm = sqrtf(total_sq);
     float coef = a.cfg.max_grad_norm / (norm + 1e-6f);                // clip_grad_norm_ (torch): eps 1e-6
     coef = coef > 1.f ? 1.f : coef;
+    if (CFIT) stale_sq *= coef * coef;                                // the stale actor gradient is rescaled in place too
     if (tid == 0 && first) {
       float pp = 0.f;
       for (int k2 = 0; k2 < KS_MAX_SLICES; ++k2) pp += red[192 + 3 * KS_MAX_SLICES + net * KS_MAX_SLICES + k2];
@@ -804,9 +823,10 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
     KS_STAMP(9)                                                        // Adam + barrier
   }
   if (nsteps > 0) { adam_w2(); adam_w3_rest(); __syncthreads(); }     // the last step's deferred half
+  if (CFIT && a.stale_io && tid == 0 && wg == 0) *a.stale_io = stale_sq;
 #undef KS_ADAM
 #ifdef SPO_KS_PROF
-  if (tid == 0 && wg == 3 * a.S - 1)
+  if (tid == 0 && wg == a.n_nets * a.S - 1)
     for (int i = 0; i < 16; ++i) g_ks_prof[i] = i == 15 ? (unsigned long long)FAST : pacc[i];
 #endif
 
@@ -854,8 +874,8 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
   }
 }
 
-__global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
-  if (blockIdx.x & 7) return;                    // placement hint (update.hip): the working blocks land on one XCD and share its L2
+template <bool CFIT>
+__device__ __forceinline__ void ks_entry(const KsArgs& a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const red = lds + KsLds::RED;
   const int wg = (int)(blockIdx.x >> 3), tid = threadIdx.x, S = a.S;
@@ -872,7 +892,7 @@ __global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
       __hip_atomic_store(xid + wg, ((unsigned long long)a.tag_base << 32) | myx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    if (tid < 3 * S) {
+    if (tid < a.n_nets * S) {
       unsigned long long v = __hip_atomic_load(xid + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       unsigned spins = 0;
       while ((unsigned)(v >> 32) != a.tag_base) {
@@ -886,8 +906,17 @@ __global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
     fast = (red[250] == 0.f) && !a.force_safe;
     __syncthreads();
   }
-  if (fast) ks_body<true>(a, lds);
-  else ks_body<false>(a, lds);
+  if (fast) ks_body<true, CFIT>(a, lds);
+  else ks_body<false, CFIT>(a, lds);
+}
+
+__global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
+  if (blockIdx.x & 7) return;                    // placement hint (update.hip): the working blocks land on one XCD and share its L2
+  ks_entry<false>(a);
+}
+__global__ __launch_bounds__(256, 1) void critic_fit_ks_kernel(KsArgs a) {
+  if (blockIdx.x & 7) return;
+  ks_entry<true>(a);
 }
 
 // Exchange scratch of the kernel: the partial pre-activation words and the norm granules, ordinary device memory (agent-scope
@@ -928,6 +957,38 @@ extern "C" int spo_ks_supported(int obs_dim, int act_dim, int batch) {
   return (obs_dim >= 1 && obs_dim <= 64 * KS_MAX_SLICES && act_dim >= 1 && act_dim <= KS_OUT && batch >= 1 && batch <= 64) ? 1 : 0;
 }
 
+static int ks_launch(KsArgs& a, const spo_ppo_cfg* cfg_host, int64_t adam_step_host, int64_t M, void* sync_ws, hipStream_t st,
+                     bool cfit) {
+  if (int rc = spo::hip_check(hipMemsetAsync(sync_ws, 0, 64, st), "hipMemsetAsync(sync_ws)")) return rc;
+  a.cfg = *cfg_host; a.M = M;
+  a.err = reinterpret_cast<int*>(reinterpret_cast<char*>(sync_ws) + 64);
+  a.pow_b1 = pow((double)cfg_host->beta1, (double)adam_step_host);
+  a.pow_b2 = pow((double)cfg_host->beta2, (double)adam_step_host);
+  a.S = (cfg_host->obs_dim + 63) / 64;
+  a.n_nets = cfit ? 2 : 3;
+  { const char* e = getenv("SPO_KS_SAFE"); a.force_safe = (e && *e && *e != '0') ? 1 : 0; }
+  const int64_t nsteps = (M + cfg_host->batch - 1) / cfg_host->batch;
+  SPO_REQUIRE(nsteps < (1ll << 30), "update_iter_ks: too many minibatch steps in one launch");
+  KsScratch sc;
+  if (int rc = ks_scratch(&sc, &a.tag_base, (unsigned)nsteps)) return rc;
+  a.zbuf = sc.z; a.gran = sc.gran;
+  // every slot starts as the sentinel (a launch leaves them that way unless it stopped on an error: cheap enough to not care)
+  if (int rc = spo::hip_check(hipMemsetAsync(sc.z, 0xFF, KS_ZZERO_OFF, st), "hipMemsetAsync(ks partials)")) return rc;
+  const size_t sh = KsLds::SIZE * sizeof(float);
+  static bool attr_done[SPO_MAX_DEVICES][2] = {};
+  const int dslot = current_device_slot();
+  if (!attr_done[dslot][cfit ? 1 : 0]) {
+    const void* fn = cfit ? reinterpret_cast<const void*>(&critic_fit_ks_kernel) : reinterpret_cast<const void*>(&ppo_update_ks_kernel);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (e != hipSuccess) return spo::hip_check(e, "hipFuncSetAttribute(update_ks)");
+    attr_done[dslot][cfit ? 1 : 0] = true;
+  }
+  const dim3 grid(8 * (a.n_nets * a.S - 1) + 1);
+  if (cfit) hipLaunchKernelGGL(critic_fit_ks_kernel, grid, dim3(256), sh, st, a);
+  else hipLaunchKernelGGL(ppo_update_ks_kernel, grid, dim3(256), sh, st, a);
+  return 0;
+}
+
 extern "C" int spo_ppo_lag_update_iter_ks(float* theta, float* adam_m, float* adam_v, int64_t adam_step_host, const float* obs,
                                           const float* act, const float* logp_old, const float* target_r, const float* target_c,
                                           const float* adv, const int32_t* perm, int64_t M, const spo_ppo_cfg* cfg_host,
@@ -939,33 +1000,37 @@ extern "C" int spo_ppo_lag_update_iter_ks(float* theta, float* adam_m, float* ad
   SPO_REQUIRE(theta && adam_m && adam_v && obs && act && logp_old && target_r && target_c && adv && perm && losses_out && sync_ws,
               "update_iter_ks: null pointer");
   SPO_REQUIRE(M > 0 && adam_step_host >= 0, "update_iter_ks: bad sizes");
-  hipStream_t st = (hipStream_t)stream;
-  if (int rc = spo::hip_check(hipMemsetAsync(sync_ws, 0, 64, st), "hipMemsetAsync(sync_ws)")) return rc;
   KsArgs a{};
   a.theta = theta; a.adam_m = adam_m; a.adam_v = adam_v;
   a.obs = obs; a.act = act; a.logp_old = logp_old; a.tgt_r = target_r; a.tgt_c = target_c; a.adv = adv;
-  a.perm = perm; a.M = M; a.cfg = *cfg_host; a.losses = losses_out;
-  a.err = reinterpret_cast<int*>(reinterpret_cast<char*>(sync_ws) + 64);
-  a.pow_b1 = pow((double)cfg_host->beta1, (double)adam_step_host);
-  a.pow_b2 = pow((double)cfg_host->beta2, (double)adam_step_host);
-  a.S = (cfg_host->obs_dim + 63) / 64;
-  { const char* e = getenv("SPO_KS_SAFE"); a.force_safe = (e && *e && *e != '0') ? 1 : 0; }
-  const int64_t nsteps = (M + cfg_host->batch - 1) / cfg_host->batch;
-  SPO_REQUIRE(nsteps < (1ll << 31), "update_iter_ks: too many minibatch steps in one launch");
-  KsScratch sc;
-  if (int rc = ks_scratch(&sc, &a.tag_base, (unsigned)nsteps)) return rc;
-  a.zbuf = sc.z; a.gran = sc.gran;
-  // every slot starts as the sentinel (a launch leaves them that way unless it stopped on an error: cheap enough to not care)
-  if (int rc = spo::hip_check(hipMemsetAsync(sc.z, 0xFF, KS_ZZERO_OFF, st), "hipMemsetAsync(ks partials)")) return rc;
-  const size_t sh = KsLds::SIZE * sizeof(float);
-  static bool attr_done[SPO_MAX_DEVICES] = {};
-  const int dslot = current_device_slot();
-  if (!attr_done[dslot]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_update_ks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    if (e != hipSuccess) return spo::hip_check(e, "hipFuncSetAttribute(update_ks)");
-    attr_done[dslot] = true;
-  }
-  hipLaunchKernelGGL(ppo_update_ks_kernel, dim3(8 * (3 * a.S - 1) + 1), dim3(256), sh, st, a);
+  a.perm = perm; a.losses = losses_out;
+  if (int rc = ks_launch(a, cfg_host, adam_step_host, M, sync_ws, (hipStream_t)stream, false)) return rc;
   SPO_LAUNCH_CHECK("spo_ppo_lag_update_iter_ks");
+  return 0;
+}
+
+extern "C" int spo_critic_fit_ks_supported(int obs_dim, int batch) {
+  return (obs_dim >= 1 && obs_dim <= 64 * KS_MAX_SLICES && batch >= 1 && batch <= 128) ? 1 : 0;
+}
+
+extern "C" int spo_critic_fit_iter_ks(float* theta, float* adam_m, float* adam_v, int64_t adam_step_host, const float* obs,
+                                      const float* target_r, const float* target_c, const int32_t* perm, int64_t M,
+                                      const spo_ppo_cfg* cfg_host, float* stale_sq_io, float* losses_out, void* sync_ws,
+                                      void* stream) {
+  SPO_REQUIRE(cfg_host, "critic_fit_iter_ks: cfg is NULL");
+  SPO_REQUIRE(spo_critic_fit_ks_supported(cfg_host->obs_dim, cfg_host->batch),
+              "critic_fit_iter_ks: obs_dim %d / batch %d outside [1,%d] / [1,128]", cfg_host->obs_dim, cfg_host->batch,
+              64 * KS_MAX_SLICES);
+  SPO_REQUIRE(cfg_host->act_dim >= 1, "critic_fit_iter_ks: act_dim %d (the flat parameter layout needs the actor's size)",
+              cfg_host->act_dim);
+  SPO_REQUIRE(theta && adam_m && adam_v && obs && target_r && target_c && perm && losses_out && sync_ws,
+              "critic_fit_iter_ks: null pointer");
+  SPO_REQUIRE(M > 0 && adam_step_host >= 0, "critic_fit_iter_ks: bad sizes");
+  KsArgs a{};
+  a.theta = theta; a.adam_m = adam_m; a.adam_v = adam_v;
+  a.obs = obs; a.tgt_r = target_r; a.tgt_c = target_c;
+  a.perm = perm; a.losses = losses_out; a.stale_io = stale_sq_io;
+  if (int rc = ks_launch(a, cfg_host, adam_step_host, M, sync_ws, (hipStream_t)stream, true)) return rc;
+  SPO_LAUNCH_CHECK("spo_critic_fit_iter_ks");
   return 0;
 }

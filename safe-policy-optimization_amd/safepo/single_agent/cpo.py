@@ -556,6 +556,10 @@ class WideCPOEngine(_WideOps, CPOEngine):
     def _alloc_full_batch_workspaces(self) -> None:
         self.partial_ws = self.loss_ws = None           # the LDS-resident kernels' per-workgroup partial vectors: not used here
 
+    def _feature_split_critic_fit_ok(self, cfg) -> bool:
+        return (list(self.policy.hidden_sizes) == [64, 64] and self.comm.world_size == 1
+                and os.environ.get("SPO_WIDE_KS", "1") != "0" and bool(self.lib.spo_critic_fit_ks_supported(self.D, int(cfg.batch))))
+
     def _set_stale_actor_grad(self, vec: torch.Tensor) -> None:
         super()._set_stale_actor_grad(vec)
         self.flat_grad[self.ls_off:].copy_(vec)         # the wide critic fit clips over (and rescales) the vector itself
@@ -637,6 +641,28 @@ class WideCPOEngine(_WideOps, CPOEngine):
         if perm_fn is None:
             perm_fn = lambda it: torch.randperm(self.M, device=self.dev).to(torch.int32)
         n_mb = (self.M + cfg.batch - 1) // cfg.batch
+        if self._feature_split_critic_fit_ok(cfg):
+            # hidden [64, 64] critics with obs_dim <= 512 (HumanoidVelocity): every learning iteration is ONE launch of the
+            # persistent feature-split kernel with two networks (csrc/update_ks.hip, round 5); it carries the NORM of the actor's
+            # stale gradient like the LDS-resident critic fit, the vector is rescaled to match afterwards
+            stale0 = self.stale_sq.clone()
+            all_losses = []
+            for it in range(c["learning_iters"]):
+                perm = _abi.require_gpu_tensor(perm_fn(it), "perm", torch.int32)
+                losses = torch.empty((n_mb, 3), dtype=torch.float32, device=self.dev)
+                _abi.check(lib.spo_critic_fit_iter_ks(
+                    _abi.ptr(self.policy.theta), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), self.adam_step,
+                    _abi.ptr(d["obs"]), _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]), _abi.ptr(perm),
+                    self.M, cfg, _abi.ptr(self.stale_sq), _abi.ptr(losses), _abi.ptr(self.sync_ws), _abi.stream_ptr()),
+                    "spo_critic_fit_iter_ks")
+                self.adam_step += n_mb
+                all_losses.append(losses[:, :2])
+            if int(self.sync_ws[8].item()) & 0xFFFFFFFF:
+                self.sync_ws[8] = 0
+                raise _abi.SpoError("feature-split critic fit: inter-workgroup exchange timed out")
+            self.flat_grad[self.ls_off:].mul_(torch.sqrt(self.stale_sq / stale0.clamp_min(1e-38)))
+            means = torch.cat(all_losses, 0).mean(0).tolist() if all_losses else [float("nan")] * 2
+            return {"loss_r": means[0], "loss_c": means[1], "losses": all_losses}
         obs_all = d["obs"].view(self.M, self.D)
         tr_all, tc_all = d["target_value_r"].view(-1), d["target_value_c"].view(-1)
         g, part, cap = self.flat_grad, self.loss_partials, self.loss_partials.numel()

@@ -200,16 +200,35 @@ def test_wide_cpo_actor_step_drift_envelope(dev, D, A, hidden, ep_costs):
     np.testing.assert_allclose(eng.flat_grad[eng.ls_off:].cpu().numpy(), out["b"].cpu().numpy())
 
 
-@pytest.mark.parametrize("D,A,hidden,persistent", [(72, 2, [64, 64], True), (376, 17, [64, 64], False), (60, 33, [32, 48], False)])
+@pytest.mark.parametrize("D,A,hidden,persistent", [(72, 2, [64, 64], True), (376, 17, [64, 64], False), (60, 33, [32, 48], False),
+                                                   (376, 17, [64, 64], "wide")])
 def test_wide_cpo_critic_fit_vs_oracle(dev, D, A, hidden, persistent, monkeypatch):
     """Critic fit (cpo.py:534-571) of WideCPOEngine: on the persistent two-critic kernel when the critics fit it (obs 72: the
-    KIN = 128 instantiation with act_dim irrelevant), minibatch by minibatch on the wide kernels otherwise -- with the stale
-    actor gradient taking part in, and being rescaled by, the joint clip."""
-    M, iters, batch = 1024, 2, 128
+    KIN = 128 instantiation with act_dim irrelevant); on the persistent FEATURE-SPLIT kernel for hidden [64, 64] critics up to
+    512 observations (376: round 5, csrc/update_ks.hip with two networks, a 128-row minibatch as two 64-column chunks);
+    minibatch by minibatch on the wide kernels otherwise ("wide": SPO_WIDE_KS=0 keeps that path at 376) -- with the stale actor
+    gradient taking part in, and being rescaled by, the joint clip."""
+    if persistent == "wide":
+        monkeypatch.setenv("SPO_WIDE_KS", "0")
+        persistent = False
+    _critic_fit_check(dev, D, A, hidden, persistent, monkeypatch, M=1024, iters=2, batch=128)
+
+
+@pytest.mark.parametrize("D,A,M,batch", [(376, 17, 1024 + 37, 128), (200, 4, 900, 100), (130, 2, 640 + 5, 64), (512, 32, 512, 128),
+                                         (129, 1, 300, 128)])
+def test_feature_split_critic_fit_shapes_vs_oracle(dev, D, A, M, batch, monkeypatch):
+    """The feature-split critic fit at other slice counts (2 ... 8), minibatches that are not two full chunks (100 = 64 + 36 rows,
+    64 = one chunk) and a ragged last minibatch (also one that leaves the second chunk EMPTY: 37 of 128 rows)."""
+    _critic_fit_check(dev, D, A, [64, 64], False, monkeypatch, M=M, iters=2, batch=batch, expect_ks=True)
+
+
+def _critic_fit_check(dev, D, A, hidden, persistent, monkeypatch, M, iters, batch, expect_ks=None):
     monkeypatch.setenv("SPO_CPO_SPLIT", "0")
     pol, ref, eng, data = _cpo_problem(D, A, hidden, M, dev, seed=5, chunk=4096)
     eng.cfg.update(learning_iters=iters, batch_size=batch)
     assert eng._critics_on_persistent_kernel is persistent
+    if expect_ks is not None:
+        assert eng._feature_split_critic_fit_ok(eng._cfg_struct()) is expect_ks
     n_act = sum(p.numel() for p in ref.actor.parameters())
     stale = torch.full((n_act,), 50.0 / np.sqrt(n_act))             # norm 50 > max_grad_norm 40: the clip is active
     eng._set_stale_actor_grad(stale.to(dev))
@@ -226,7 +245,7 @@ def test_wide_cpo_critic_fit_vs_oracle(dev, D, A, hidden, persistent, monkeypatc
         out = []
         for it in range(iters):
             pm = perms[it].long()
-            for k in range(M // batch):
+            for k in range((M + batch - 1) // batch):
                 idx = pm[k * batch:(k + 1) * batch]
                 out.append(fitter.minibatch_step(o_[idx], tr_[idx], tc_[idx]))
         return np.asarray(out, np.float64), torch.cat([p.detach().reshape(-1) for p in rf.parameters()]).double().numpy()
@@ -239,7 +258,7 @@ def test_wide_cpo_critic_fit_vs_oracle(dev, D, A, hidden, persistent, monkeypatc
     n_crit = want_th.size - n_act
     E.assert_loss_envelope(got, want, l64, "wide critic fit: losses", window=len(want))
     E.assert_theta_envelope(pol.theta.cpu().numpy()[:n_crit], want_th[:n_crit], th64[:n_crit], "wide critic fit: critics",
-                            floor_abs_max=_theta_floor(1e-3, iters * (M // batch)))
+                            floor_abs_max=_theta_floor(1e-3, iters * ((M + batch - 1) // batch)))
     want_th = want_th.astype(np.float32)
     # the actor's parameters are untouched by the critic fit; its stale gradient shrank exactly like the oracle's .grad
     np.testing.assert_array_equal(pol.theta.cpu().numpy()[n_crit:], want_th[n_crit:])
