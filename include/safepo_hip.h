@@ -317,6 +317,14 @@ int spo_ppo_lag_update_iter_ks(float* theta, float* adam_m, float* adam_v, int64
                                const float* act, const float* logp_old, const float* target_r, const float* target_c,
                                const float* adv, const int32_t* perm, int64_t M, const spo_ppo_cfg* cfg_host,
                                float* losses_out, void* sync_ws, void* stream);
+/* spo_update_iter_ex on the feature-split kernel: the KL-penalty actor loss of FOCOPS (focops.py:326-337) and CUP's second stage
+ * (cup.py:372-383), separate optimiser clocks, actor-only mode -- same arguments and semantics as spo_update_iter_ex, shapes as
+ * spo_ks_supported, one GPU. */
+int spo_update_iter_ex_ks(float* theta, float* adam_m, float* adam_v, int64_t adam_step_critics_host,
+                          int64_t adam_step_actor_host, const float* obs, const float* act, const float* logp_old,
+                          const float* target_r, const float* target_c, const float* adv, const int32_t* perm, int64_t M,
+                          const spo_ppo_cfg* cfg_host, int actor_loss, const float* old_mean, const float* old_std,
+                          float kl_bound, float pg_coef, int actor_only, float* losses_out, void* sync_ws, void* stream);
 /* spo_critic_fit_iter on the same feature-split kernel (two networks): the critic fit of the second-order scripts
  * (safepo/single_agent/cpo.py:541-571) for obs_dim <= 512, hidden [64, 64], batch <= 128 (a minibatch is taken as two 64-column
  * chunks whose gradients accumulate before the optimiser step), one GPU.  Same arguments and results as spo_critic_fit_iter;

@@ -74,7 +74,9 @@ struct KsArgs {
   double pow_b1, pow_b2;
   unsigned tag_base;                   // tags of this launch: tag_base + step + 1 (never reused: no clearing between launches)
   int S;
-  int n_nets;                          // 3: PPO-family step; 2: the critic fit of the second-order scripts (CFIT instantiation)
+  int n_nets, first_net;               // 3 / 0: a full step; 2 / 0: the critic fit (CFIT instantiation); 1 / 2: actor only (CUP's second stage)
+  const float* old_mean; const float* old_std; float kl_bound, pg_coef;   // KL-penalty actor loss (AMODE 1: FOCOPS, CUP)
+  double pow_b1_actor, pow_b2_actor;   // the actor's own optimiser clock (spo_update_iter_ex)
   float* stale_io;                     // critic fit: ||actor.grad||^2 that the joint clip still sees and rescales (cpo.py:557), in / out
   int force_safe;                      // SPO_KS_SAFE=1: write-through exchange stores whatever the placement (tests)
 };
@@ -84,9 +86,11 @@ __device__ __forceinline__ int pin(int v) { asm volatile("" : "+v"(v)); return v
 // (one launch at a time per device: the exchange scratch below is per device, like the kernel's use by one engine on one stream)
 constexpr unsigned KS_SPIN_LIMIT = 1u << 22;
 
+template <int AMODE>
 struct KsCol {                         // per-column inputs of one minibatch, prefetched one step ahead (raw loads; settled at pick-up)
   f4 x[4];                             // this slice's observation tiles (B operand of layer 1)
   f4 actv[KS_NO];                      // actor: act[16 t + 4 q ..]
+  f4 omv[AMODE == 1 ? KS_NO : 1];      // actor, KL-penalty loss: old_mean[16 t + 4 q ..]
   float t0, t1;                        // critic: target ; actor: logp_old, adv
 };
 
@@ -99,14 +103,16 @@ __device__ unsigned long long g_ks_prof[16];      // development builds: cycles 
 // FAST: every workgroup of the launch sits on one XCD (checked by the kernel below), stores of the exchange stay plain
 // CFIT: the critic fit of the second-order scripts (cpo.py:541-571): two networks, minibatches of up to 128 rows taken as two
 // 64-column chunks whose weight gradients accumulate before the one optimiser step, the actor's stale gradient in the joint norm.
-template <bool FAST, bool CFIT>
+// AMODE 1: the KL-penalty actor loss of FOCOPS (focops.py:326-337) and CUP's second stage (cup.py:372-383), as update.hip's AMODE.
+template <bool FAST, bool CFIT, int AMODE>
 __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
+  using Col = KsCol<AMODE>;
 #ifdef SPO_KS_PROF
   unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
 #endif
   using L = KsLds;
   const int wg = (int)(blockIdx.x >> 3);
-  const int S = a.S, net = wg / S, ks = wg - net * S;
+  const int S = a.S, net = a.first_net + wg / S, ks = wg - (wg / S) * S;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, q = lane >> 4;
   const int D = a.cfg.obs_dim, A = a.cfg.act_dim, B = a.cfg.batch;
   const NetGeom g = net_geom(D, A, net);
@@ -171,7 +177,7 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
   mb2 = a.adam_m[g.b2() + 16 * wave + j]; vb2 = a.adam_v[g.b2() + 16 * wave + j];
 
   const float b1c = a.cfg.beta1, b2c = a.cfg.beta2, eps = a.cfg.adam_eps;
-  double pw1 = a.pow_b1, pw2 = a.pow_b2;
+  double pw1 = is_actor ? a.pow_b1_actor : a.pow_b1, pw2 = is_actor ? a.pow_b2_actor : a.pow_b2;
   const float lr = is_actor ? a.cfg.lr_actor : a.cfg.lr_critic;
   const float l2 = (!is_actor && a.cfg.use_critic_norm) ? a.cfg.l2_coef : 0.f;
   const float l2x2 = 2.f * l2;
@@ -193,7 +199,7 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
     const int64_t pos = base + 64 * h2 + (mycol < nc ? mycol : 0);
     return pos < a.M ? pos : a.M - 1;                             // (an empty second chunk: any valid row, every column masked)
   };
-  auto fetch_obs = [&](int64_t smp, KsCol& cd) {
+  auto fetch_obs = [&](int64_t smp, Col& cd) {
     {
       // this slice's 64 features of the row (clamped addresses, NO select: see load_obs_tiles_raw); 16-byte loads only when every
       // row AND every slice start is 16-byte aligned (obs_dim a multiple of 4)
@@ -215,7 +221,7 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
       }
     }
   };
-  auto fetch_rest = [&](int64_t smp, KsCol& cd) {
+  auto fetch_rest = [&](int64_t smp, Col& cd) {
     if (!is_actor) {
       cd.t0 = tgt[smp]; cd.t1 = 0.f;
 #pragma unroll
@@ -230,10 +236,11 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
           // (unconditional within an instruction that has any live lane: pads selected at pick-up; rows past act_dim in every
           // lane -- 16 t + r >= act_dim -- are not loaded at all: 5 gathers instead of 8 at act_dim 17)
           cd.actv[t][r] = (16 * t + r < A) ? a.act[smp * A + (ai < A ? ai : 0)] : 0.f;
+          if (AMODE == 1) cd.omv[t][r] = (16 * t + r < A) ? a.old_mean[smp * A + (ai < A ? ai : 0)] : 0.f;
         }
     }
   };
-  auto settle = [&](KsCol& cd) {
+  auto settle = [&](Col& cd) {
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -248,6 +255,10 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
         for (int r = 0; r < 4; ++r) {
           const float av = pin(cd.actv[t][r]);
           cd.actv[t][r] = (16 * t + 4 * q + r) < A ? av : 0.f;
+          if (AMODE == 1) {
+            const float ov = pin(cd.omv[t][r]);
+            cd.omv[t][r] = (16 * t + 4 * q + r) < A ? ov : 0.f;
+          }
         }
     }
   };
@@ -309,7 +320,15 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
     KS_ADAM(np2, lds[L::B2 + 16 * wave + j], gb2, mb2, vb2, pcoef, pstep, pinv)
     lds[L::B2 + 16 * wave + j] = np2;
   };
-  KsCol nxt;
+  float iso[KS_NO][4];                                            // 1 / sigma_old of my action rows (KL-penalty loss)
+#pragma unroll
+  for (int t = 0; t < KS_NO; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ai = 16 * t + 4 * q + r;
+      iso[t][r] = (AMODE == 1 && is_actor && ai < A) ? 1.f / a.old_std[ai] : 1.f;
+    }
+  Col nxt;
   int smp1 = 0;
   fetch_obs((int64_t)a.perm[perm_pos(0)], nxt);
   fetch_rest((int64_t)a.perm[perm_pos(0)], nxt);
@@ -334,7 +353,7 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
 #ifdef SPO_KS_PROF
     if (tid == 0 && wg == a.n_nets * a.S - 1) tprev = __builtin_readcyclecounter();
 #endif
-    KsCol cur = nxt;
+    Col cur = nxt;
     settle(cur);
     const int smp_next = pin(smp1);
     const int64_t pos2 = (e + 2 < nchunks) ? perm_pos(e + 2) : 0;
@@ -520,6 +539,40 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
       lp = quad_row_sum(lp);                                          // .sum(dim=-1)
       const float adv = cur.t1;
       const float ratio = __expf(lp - cur.t0);                        // ppo_lag.py:317
+      if (AMODE == 1) {
+        // loss = mean_i(ind_i KL_i) - pg_coef mean_i(ind_i) mean_j(ratio_j adv_j): the reference subtracts a [B] tensor from a
+        // [B, 1] tensor, its loss is the mean of a B x B matrix = this product of means (update.hip, AMODE)
+        float klp = 0.f, dm[KS_NO][4], vrat[KS_NO][4];
+#pragma unroll
+        for (int t = 0; t < KS_NO; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ai = 16 * t + 4 * q + r;
+            const float sdv = __expf(ai < A ? red[160 + ai] : 0.f);
+            const float sr = sdv * iso[t][r];                          // kl_normal_normal: var_ratio = (p.scale / q.scale)^2
+            vrat[t][r] = sr * sr;
+            dm[t][r] = (o[t][r] - cur.omv[t][r]) * iso[t][r];         // (loc_p - loc_q) / scale_q ; pad rows: 0
+            klp += amask[t][r] * (0.5f * (vrat[t][r] + dm[t][r] * dm[t][r] - 1.f - logf(vrat[t][r])));
+          }
+        const float kl = quad_row_sum(klp);                            // .sum(-1, keepdim=True)
+        const float ind = (kl <= a.kl_bound) ? 1.f : 0.f;
+        const float cnt = wave_sum_lane63((q == 0 && cv) ? ind : 0.f);
+        if (lane == 63) red[20 + wave] = cnt;
+        __syncthreads();                                               // the actor's workgroups only (block-uniform branch)
+        const float frac = ((red[20] + red[21]) + (red[22] + red[23])) * inv_n;
+        const float pg = a.pg_coef * frac;
+        const float dlp = cv ? -(pg * adv * ratio) * inv_n : 0.f;
+        const float wk = cv ? ind * inv_n : 0.f;
+        lsum = ((q == 0 && cv) ? 1.f : 0.f) * (pg * ratio * adv - ind * kl);      // loss = -mean(this)
+#pragma unroll
+        for (int t = 0; t < KS_NO; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float zz = dif[t][r] * ivar[t][r];
+            dO[t][r] = fmaf(dlp, zz, wk * dm[t][r] * iso[t][r]);
+            dls[t][r] = amask[t][r] * fmaf(dlp, dif[t][r] * zz - 1.f, wk * (vrat[t][r] - 1.f));
+          }
+      } else {
       const float rc = fminf(fmaxf(ratio, clip_lo), clip_hi);         // torch.clamp
       const float s1 = ratio * adv, s2 = rc * adv;
       const bool inr = (ratio >= clip_lo) && (ratio <= clip_hi);
@@ -537,6 +590,7 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
           dO[t][r] = dlp * zz;                                        // pad rows: zz == 0
           dls[t][r] = (dlp * amask[t][r]) * (dif[t][r] * zz - 1.f);
         }
+      }
     }
 
     // ---- backward through the MLP (transposed chaining, weights read as columns)
@@ -775,7 +829,7 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
       const int kind = tid / (3 * KS_MAX_SLICES), idx = tid - kind * 3 * KS_MAX_SLICES;
       const int n2 = idx / KS_MAX_SLICES, k2 = idx - n2 * KS_MAX_SLICES;
       float val = 0.f;
-      if (k2 < S && n2 < a.n_nets) {
+      if (k2 < S && n2 >= a.first_net && n2 < a.first_net + a.n_nets) {
         unsigned long long* const src = (kind ? gp : gg) + idx;
         unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
@@ -874,7 +928,7 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
   }
 }
 
-template <bool CFIT>
+template <bool CFIT, int AMODE>
 __device__ __forceinline__ void ks_entry(const KsArgs& a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const red = lds + KsLds::RED;
@@ -906,17 +960,21 @@ __device__ __forceinline__ void ks_entry(const KsArgs& a) {
     fast = (red[250] == 0.f) && !a.force_safe;
     __syncthreads();
   }
-  if (fast) ks_body<true, CFIT>(a, lds);
-  else ks_body<false, CFIT>(a, lds);
+  if (fast) ks_body<true, CFIT, AMODE>(a, lds);
+  else ks_body<false, CFIT, AMODE>(a, lds);
 }
 
 __global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
   if (blockIdx.x & 7) return;                    // placement hint (update.hip): the working blocks land on one XCD and share its L2
-  ks_entry<false>(a);
+  ks_entry<false, 0>(a);
+}
+__global__ __launch_bounds__(256, 1) void klpen_update_ks_kernel(KsArgs a) {
+  if (blockIdx.x & 7) return;
+  ks_entry<false, 1>(a);
 }
 __global__ __launch_bounds__(256, 1) void critic_fit_ks_kernel(KsArgs a) {
   if (blockIdx.x & 7) return;
-  ks_entry<true>(a);
+  ks_entry<true, 0>(a);
 }
 
 // Exchange scratch of the kernel: the partial pre-activation words and the norm granules, ordinary device memory (agent-scope
@@ -957,15 +1015,17 @@ extern "C" int spo_ks_supported(int obs_dim, int act_dim, int batch) {
   return (obs_dim >= 1 && obs_dim <= 64 * KS_MAX_SLICES && act_dim >= 1 && act_dim <= KS_OUT && batch >= 1 && batch <= 64) ? 1 : 0;
 }
 
-static int ks_launch(KsArgs& a, const spo_ppo_cfg* cfg_host, int64_t adam_step_host, int64_t M, void* sync_ws, hipStream_t st,
-                     bool cfit) {
+// kind: 0 = clipped-surrogate step, 1 = critic fit, 2 = KL-penalty actor loss; the caller sets n_nets / first_net
+static int ks_launch(KsArgs& a, const spo_ppo_cfg* cfg_host, int64_t adam_step_host, int64_t adam_step_actor_host, int64_t M,
+                     void* sync_ws, hipStream_t st, int kind) {
   if (int rc = spo::hip_check(hipMemsetAsync(sync_ws, 0, 64, st), "hipMemsetAsync(sync_ws)")) return rc;
   a.cfg = *cfg_host; a.M = M;
   a.err = reinterpret_cast<int*>(reinterpret_cast<char*>(sync_ws) + 64);
   a.pow_b1 = pow((double)cfg_host->beta1, (double)adam_step_host);
   a.pow_b2 = pow((double)cfg_host->beta2, (double)adam_step_host);
+  a.pow_b1_actor = pow((double)cfg_host->beta1, (double)adam_step_actor_host);
+  a.pow_b2_actor = pow((double)cfg_host->beta2, (double)adam_step_actor_host);
   a.S = (cfg_host->obs_dim + 63) / 64;
-  a.n_nets = cfit ? 2 : 3;
   { const char* e = getenv("SPO_KS_SAFE"); a.force_safe = (e && *e && *e != '0') ? 1 : 0; }
   const int64_t nsteps = (M + cfg_host->batch - 1) / cfg_host->batch;
   SPO_REQUIRE(nsteps < (1ll << 30), "update_iter_ks: too many minibatch steps in one launch");
@@ -975,16 +1035,19 @@ static int ks_launch(KsArgs& a, const spo_ppo_cfg* cfg_host, int64_t adam_step_h
   // every slot starts as the sentinel (a launch leaves them that way unless it stopped on an error: cheap enough to not care)
   if (int rc = spo::hip_check(hipMemsetAsync(sc.z, 0xFF, KS_ZZERO_OFF, st), "hipMemsetAsync(ks partials)")) return rc;
   const size_t sh = KsLds::SIZE * sizeof(float);
-  static bool attr_done[SPO_MAX_DEVICES][2] = {};
+  static bool attr_done[SPO_MAX_DEVICES][3] = {};
   const int dslot = current_device_slot();
-  if (!attr_done[dslot][cfit ? 1 : 0]) {
-    const void* fn = cfit ? reinterpret_cast<const void*>(&critic_fit_ks_kernel) : reinterpret_cast<const void*>(&ppo_update_ks_kernel);
+  if (!attr_done[dslot][kind]) {
+    const void* fn = kind == 1 ? reinterpret_cast<const void*>(&critic_fit_ks_kernel)
+                   : kind == 2 ? reinterpret_cast<const void*>(&klpen_update_ks_kernel)
+                               : reinterpret_cast<const void*>(&ppo_update_ks_kernel);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return spo::hip_check(e, "hipFuncSetAttribute(update_ks)");
-    attr_done[dslot][cfit ? 1 : 0] = true;
+    attr_done[dslot][kind] = true;
   }
   const dim3 grid(8 * (a.n_nets * a.S - 1) + 1);
-  if (cfit) hipLaunchKernelGGL(critic_fit_ks_kernel, grid, dim3(256), sh, st, a);
+  if (kind == 1) hipLaunchKernelGGL(critic_fit_ks_kernel, grid, dim3(256), sh, st, a);
+  else if (kind == 2) hipLaunchKernelGGL(klpen_update_ks_kernel, grid, dim3(256), sh, st, a);
   else hipLaunchKernelGGL(ppo_update_ks_kernel, grid, dim3(256), sh, st, a);
   return 0;
 }
@@ -1003,9 +1066,37 @@ extern "C" int spo_ppo_lag_update_iter_ks(float* theta, float* adam_m, float* ad
   KsArgs a{};
   a.theta = theta; a.adam_m = adam_m; a.adam_v = adam_v;
   a.obs = obs; a.act = act; a.logp_old = logp_old; a.tgt_r = target_r; a.tgt_c = target_c; a.adv = adv;
-  a.perm = perm; a.losses = losses_out;
-  if (int rc = ks_launch(a, cfg_host, adam_step_host, M, sync_ws, (hipStream_t)stream, false)) return rc;
+  a.perm = perm; a.losses = losses_out; a.n_nets = 3; a.first_net = 0;
+  if (int rc = ks_launch(a, cfg_host, adam_step_host, adam_step_host, M, sync_ws, (hipStream_t)stream, 0)) return rc;
   SPO_LAUNCH_CHECK("spo_ppo_lag_update_iter_ks");
+  return 0;
+}
+
+extern "C" int spo_update_iter_ex_ks(float* theta, float* adam_m, float* adam_v, int64_t adam_step_critics_host,
+                                     int64_t adam_step_actor_host, const float* obs, const float* act, const float* logp_old,
+                                     const float* target_r, const float* target_c, const float* adv, const int32_t* perm, int64_t M,
+                                     const spo_ppo_cfg* cfg_host, int actor_loss, const float* old_mean, const float* old_std,
+                                     float kl_bound, float pg_coef, int actor_only, float* losses_out, void* sync_ws, void* stream) {
+  SPO_REQUIRE(cfg_host, "update_iter_ex_ks: cfg is NULL");
+  SPO_REQUIRE(spo_ks_supported(cfg_host->obs_dim, cfg_host->act_dim, cfg_host->batch),
+              "update_iter_ex_ks: obs_dim %d / act_dim %d / batch %d outside [1,%d] / [1,%d] / [1,64]", cfg_host->obs_dim,
+              cfg_host->act_dim, cfg_host->batch, 64 * KS_MAX_SLICES, KS_OUT);
+  SPO_REQUIRE(theta && adam_m && adam_v && obs && act && logp_old && adv && perm && losses_out && sync_ws,
+              "update_iter_ex_ks: null pointer");
+  SPO_REQUIRE(actor_loss == SPO_ACTOR_LOSS_CLIP || actor_loss == SPO_ACTOR_LOSS_KL_PENALTY,
+              "update_iter_ex_ks: unknown actor_loss %d", actor_loss);
+  SPO_REQUIRE(actor_loss == SPO_ACTOR_LOSS_CLIP || (old_mean && old_std), "update_iter_ex_ks: old distribution is NULL");
+  SPO_REQUIRE(actor_only || (target_r && target_c), "update_iter_ex_ks: critic targets are NULL");
+  SPO_REQUIRE(M > 0 && adam_step_critics_host >= 0 && adam_step_actor_host >= 0, "update_iter_ex_ks: bad sizes");
+  KsArgs a{};
+  a.theta = theta; a.adam_m = adam_m; a.adam_v = adam_v;
+  a.obs = obs; a.act = act; a.logp_old = logp_old; a.tgt_r = target_r; a.tgt_c = target_c; a.adv = adv;
+  a.perm = perm; a.losses = losses_out;
+  a.old_mean = old_mean; a.old_std = old_std; a.kl_bound = kl_bound; a.pg_coef = pg_coef;
+  a.n_nets = actor_only ? 1 : 3; a.first_net = actor_only ? 2 : 0;
+  if (int rc = ks_launch(a, cfg_host, adam_step_critics_host, adam_step_actor_host, M, sync_ws, (hipStream_t)stream,
+                         actor_loss == SPO_ACTOR_LOSS_KL_PENALTY ? 2 : 0)) return rc;
+  SPO_LAUNCH_CHECK("spo_update_iter_ex_ks");
   return 0;
 }
 
@@ -1029,8 +1120,8 @@ extern "C" int spo_critic_fit_iter_ks(float* theta, float* adam_m, float* adam_v
   KsArgs a{};
   a.theta = theta; a.adam_m = adam_m; a.adam_v = adam_v;
   a.obs = obs; a.tgt_r = target_r; a.tgt_c = target_c;
-  a.perm = perm; a.losses = losses_out; a.stale_io = stale_sq_io;
-  if (int rc = ks_launch(a, cfg_host, adam_step_host, M, sync_ws, (hipStream_t)stream, true)) return rc;
+  a.perm = perm; a.losses = losses_out; a.stale_io = stale_sq_io; a.n_nets = 2; a.first_net = 0;
+  if (int rc = ks_launch(a, cfg_host, adam_step_host, adam_step_host, M, sync_ws, (hipStream_t)stream, 1)) return rc;
   SPO_LAUNCH_CHECK("spo_critic_fit_iter_ks");
   return 0;
 }

@@ -914,11 +914,27 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
             raise NotImplementedError("focops / cup run on one GPU in this build (no data-parallel form of the "   # couples the
                                       "KL-penalty minibatch step)")                                             # global minibatch)
         cfg = self._cfg_struct()
-        perm = _abi.require_gpu_tensor(perm, "perm", torch.int32).long()
         adv = _abi.require_gpu_tensor(adv, "adv", torch.float32)
         M = self.M
         n_mb = (M + cfg.batch - 1) // cfg.batch
         losses = torch.full((n_mb, 3), float("nan"), dtype=torch.float32, device=self.dev)
+        if self._feature_split_kernel_ok(cfg):
+            # FOCOPS / CUP at HumanoidVelocity-class dims: one launch of the persistent feature-split kernel (round 5)
+            perm = _abi.require_gpu_tensor(perm, "perm", torch.int32)
+            d = self.buffer.data
+            _abi.check(self.lib.spo_update_iter_ex_ks(
+                _abi.ptr(self.policy.theta), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), self.adam_step,
+                self.adam_step + self.adam_step_actor_extra, _abi.ptr(d["obs"]), _abi.ptr(d["act"]),
+                _abi.ptr(d["log_prob"]), _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]), _abi.ptr(adv),
+                _abi.ptr(perm), M, cfg, int(actor_loss), _abi.ptr(self.mean_old), _abi.ptr(self.std_old),
+                float(kl_bound), float(pg_coef), int(actor_only), _abi.ptr(losses), _abi.ptr(self.sync_ws),
+                _abi.stream_ptr()), "spo_update_iter_ex_ks")
+            if actor_only:
+                self.adam_step_actor_extra += n_mb
+            else:
+                self.adam_step += n_mb
+            return losses
+        perm = _abi.require_gpu_tensor(perm, "perm", torch.int32).long()
         graphed = 0 < cfg.batch <= self.graph_max_batch and n_mb > 2
         n_full = M // cfg.batch if graphed else 0
         if graphed:

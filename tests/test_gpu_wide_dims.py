@@ -272,11 +272,14 @@ def _critic_fit_check(dev, D, A, hidden, persistent, monkeypatch, M, iters, batc
 
 
 @pytest.mark.parametrize("D,A,hidden,actor_only", [(376, 17, [64, 64], False), (376, 17, [64, 64], True), (60, 33, [32, 48], False),
-                                                   (60, 8, [128, 128], True)])
+                                                   (60, 8, [128, 128], True), (130, 8, [64, 64], False), (512, 32, [64, 64], True),
+                                                   (200, 20, [64, 64], False), (129, 1, [64, 64], True)])
 def test_wide_kl_penalty_minibatch_steps_vs_oracle(dev, D, A, hidden, actor_only):
-    """FOCOPS's minibatch step (focops.py:312-347) and CUP's actor-only second stage (cup.py:370-386) on the wide kernels:
-    the test_kl_penalty_minibatch_steps_vs_oracle protocol (indicator active on part of the batch, the actor's optimiser clock
-    ahead of the critics', partial last batch) for shapes the persistent kernels do not hold."""
+    """FOCOPS's minibatch step (focops.py:312-347) and CUP's actor-only second stage (cup.py:370-386) for shapes the
+    three-workgroup persistent kernel does not hold: the test_kl_penalty_minibatch_steps_vs_oracle protocol (indicator active on
+    part of the batch, the actor's optimiser clock ahead of the critics', partial last batch).  hidden [64, 64] with obs_dim <= 512
+    / act_dim <= 32 runs on the persistent feature-split kernel (spo_update_iter_ex_ks, round 5: 2 ... 8 feature slices here, the
+    actor alone in CUP's stage), other widths on the launch-per-layer wide kernels."""
     from safepo import _abi
     from safepo.common.engine import WidePPOLagEngine
     M = 192 + 22
@@ -291,6 +294,7 @@ def test_wide_kl_penalty_minibatch_steps_vs_oracle(dev, D, A, hidden, actor_only
     pg_coef = 1 / 1.5 if not actor_only else -0.37
     cfg = {"hidden_sizes": hidden, "gamma": 0.99, "target_kl": 1e9, "batch_size": 64, "learning_iters": 1, "max_grad_norm": 40.0}
     eng = WidePPOLagEngine(pol, 1, M, cfg, dev)
+    assert eng._feature_split_kernel_ok(eng._cfg_struct()) is (hidden == [64, 64])
     b = eng.buffer
     b.data["obs"].copy_(obs.view(1, M, D)); b.data["act"].copy_(act.view(1, M, A)); b.data["log_prob"].copy_(logp.view(1, M))
     b.data["target_value_r"].copy_(tgt_r.view(1, M)); b.data["target_value_c"].copy_(tgt_c.view(1, M))

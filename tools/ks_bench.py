@@ -28,11 +28,19 @@ def one(D, A, steps=2048, reps=3):
     b.data["log_prob"].copy_(-0.92 * A - 0.5 * (b.data["act"] ** 2).sum(-1))
     b.adv_mix.normal_(generator=g)
     perm = torch.randperm(M, device=dev, generator=g).to(torch.int32)
+    mode = os.environ.get("KS_BENCH_MODE", "ppo")           # ppo | focops | cup2 (CUP's actor-only second stage)
+    if mode != "ppo":
+        from safepo import _abi
+        eng.snapshot_old_distribution()
+        run = lambda: eng.learning_iter_ex(perm, b.adv_mix.view(-1), _abi.ACTOR_LOSS_KL_PENALTY, 0.02 if mode == "focops" else float("inf"),
+                                           1 / 1.5 if mode == "focops" else -0.3, mode == "cup2")
+    else:
+        run = lambda: eng.learning_iter(perm)
     times = []
     for _ in range(reps + 1):
         torch.cuda.synchronize()
         t0 = time.time()
-        losses = eng.learning_iter(perm)
+        losses = run()
         torch.cuda.synchronize()
         times.append(time.time() - t0)
     eng.check_sync_error()
@@ -51,7 +59,7 @@ def one(D, A, steps=2048, reps=3):
             pass
     if prof:
         print("   cycles per step (thread 0 of the last workgroup):", prof, "total", sum(v for v in prof.values() if not isinstance(v, tuple)), "co-resident" if buf[15] else "write-through")
-    return {"obs_dim": D, "act_dim": A, "engine": type(eng).__name__, "feature_split": os.environ.get("SPO_WIDE_KS", "1") != "0",
+    return {"obs_dim": D, "act_dim": A, "engine": type(eng).__name__, "mode": mode, "feature_split": os.environ.get("SPO_WIDE_KS", "1") != "0",
             "us_per_minibatch_step": round(min(times[1:]) * 1e6 / steps, 2), "loss_finite": bool(torch.isfinite(losses).all())}
 
 
