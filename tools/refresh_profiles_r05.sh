@@ -32,10 +32,14 @@ python tools/phase_profile_h.py > $O/update_phase_cycles_h.txt 2>&1; tail -4 $O/
 { timeout 120 python tools/ks_bench.py 60,20 130,8 376,17 512,32
   echo "-- SPO_KS_SAFE=1 (write-through exchange stores: what any placement gets)"; SPO_KS_SAFE=1 timeout 120 python tools/ks_bench.py 376,17
   echo "-- SPO_WIDE_KS=0 (the launch-per-layer wide step of rounds 3-4)"; SPO_WIDE_KS=0 timeout 120 python tools/ks_bench.py 376,17
+  echo "-- FOCOPS step / CUP second stage (KL-penalty loss; actor alone), then the same with SPO_WIDE_KS=0"
+  for m in focops cup2; do KS_BENCH_MODE=$m timeout 120 python tools/ks_bench.py 376,17; KS_BENCH_MODE=$m SPO_WIDE_KS=0 timeout 120 python tools/ks_bench.py 376,17; done
+  echo "-- critic fit of the second-order scripts (128-row minibatches), then SPO_WIDE_KS=0 on fewer rows"
+  timeout 120 python tools/ks_cfit_bench.py 376,17 200,8; KS_CFIT_ROWS=32768 SPO_WIDE_KS=0 timeout 120 python tools/ks_cfit_bench.py 376,17
   V=$GRAFT_REPO_ROOT/safe-policy-optimization_amd/safepo/_lib/variants/libsafepo_hip_ksprof.so
   if [ -f $V ]; then echo "-- instrumented build (-DSPO_KS_PROF=1)"; SPO_LIB_PATH=$V SPO_LIB_OVERRIDE=1 SPO_KS_PROF=1 timeout 120 python tools/ks_bench.py 60,20 376,17; fi
 } 2>&1 | grep -v "amdgpu.ids\|WARNING" > $O/feature_split_bench.txt; cat $O/feature_split_bench.txt
-( timeout 300 python tools/p2p_loopback_bench.py 2 4 8 2>&1 | grep '^{\|^xr profile' | sed 's/^/default   /'; SPO_P2P_ALGO=doubling timeout 300 python tools/p2p_loopback_bench.py 8 2>&1 | grep '^{' | sed 's/^/doubling  /'; SPO_P2P_ALGO=twophase timeout 300 python tools/p2p_loopback_bench.py 2 4 2>&1 | grep '^{' | sed 's/^/twophase  /'; SPO_P2P_HELPER=2 SPO_P2P_ALGO=doubling timeout 300 python tools/p2p_loopback_bench.py 2 4 8 2>&1 | grep '^{' | sed 's/^/helper-rd /' ) > $O/p2p_loopback.txt; cat $O/p2p_loopback.txt
+( timeout 300 python tools/p2p_loopback_bench.py 2 4 8 2>&1 | grep '^{' | sed 's/^/default   /'; SPO_P2P_ALGO=doubling timeout 300 python tools/p2p_loopback_bench.py 8 2>&1 | grep '^{' | sed 's/^/doubling  /'; SPO_P2P_ALGO=twophase timeout 300 python tools/p2p_loopback_bench.py 2 4 2>&1 | grep '^{' | sed 's/^/twophase  /'; SPO_P2P_HELPER=2 SPO_P2P_ALGO=doubling timeout 300 python tools/p2p_loopback_bench.py 2 4 8 2>&1 | grep '^{' | sed 's/^/helper-rd /' ) > $O/p2p_loopback.txt; cat $O/p2p_loopback.txt
 SPO_BENCH_ONE_GPU=1 timeout 500 python bench.py --gpus 2 --steps 1 --warmup 1 --no-cpu-baseline --config5-threads 1024 > $O/bench_dp2_one_gpu.json 2> $O/bench_dp2_one_gpu.err; tail -c 300 $O/bench_dp2_one_gpu.json
 # counter passes over the other kernels
 bash tools/update_pmc.sh > $O/update_pmc.log 2>&1; cp $O/update_pmc/summary.json $O/update_kernel_pmc.json
