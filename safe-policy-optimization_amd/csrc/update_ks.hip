@@ -1,23 +1,30 @@
-// PPO-Lagrangian minibatch update for WIDE OBSERVATIONS (obs_dim <= 512, act_dim <= 32, hidden [64, 64]), gfx950 -- round 5.
+// Persistent minibatch update for WIDE OBSERVATIONS (obs_dim <= 512, act_dim <= 32, hidden [64, 64]), gfx950 -- round 5.
 //
-// The persistent kernels of update.hip keep one network in one CU's LDS; HumanoidVelocity's 376-wide first layer (96 KB of W1
-// next to the staging images) does not fit, so that shape ran on the launch-per-layer wide path at 95 us per 64-row step against
-// 10.6 us (ppo_lag.py:297-336; the reference takes any dims, model.py:131, and its default sweep includes 376 / 17,
-// single_agent/benchmark.py:5-22).  Here the FIRST LAYER IS SPLIT OVER THE INPUT FEATURES:
+// The persistent kernels of update.hip keep one network in one CU's LDS; HumanoidVelocity's 376-wide first layer does not fit, so
+// that shape ran on the launch-per-layer wide path at 95 us per 64-row step against 10.6 us (ppo_lag.py:297-336; the reference
+// takes any dims, model.py:131, and its default sweep includes 376 / 17, single_agent/benchmark.py:5-22).  Here the FIRST LAYER IS
+// SPLIT OVER THE INPUT FEATURES:
 //
-//   grid = 3 networks x S slices (S = ceil(obs_dim / 64) <= 8), one persistent workgroup of 4 waves each, all co-resident;
+//   grid = n_nets networks x S slices (S = ceil(obs_dim / 64) <= 8), one persistent workgroup of 4 waves each, all co-resident;
 //   workgroup (n, k) keeps W1[:, 64k .. 64k+63] of network n (and W2, W3, the biases, log_std: replicated) in LDS, gathers the
 //   matching 64 features of the minibatch rows and computes the PARTIAL pre-activation W1_k x_k;
-//   the S partials of a network are exchanged through device memory (16 floats per lane as 8-byte {tag, value} words written
-//   and polled with agent-scope atomics; every workgroup adds all S partials in slice order, so all S replicas hold the same
-//   bits), then bias + tanh, layers 2 / 3, loss, backward and the weight gradients run replicated -- identical instructions
-//   on identical data -- except dW1, of which a workgroup computes (and owns the Adam state of) its own 64 columns;
-//   the joint clip_grad_norm_ (ppo_lag.py:325) sums one ||g||^2 granule per workgroup: the slice's share of W1, plus
-//   everything else from slice 0 only.
+//   the S partials of a network are all-reduced through device memory as reduce-scatter + all-gather of bare floats (NaN
+//   sentinel instead of tags, 16-byte buffer loads / stores; a unit's owner sums in slice order and broadcasts, so all S replicas
+//   continue from the same bits) -- through the XCD's L2 when a placement census finds the workgroups co-resident (plain
+//   stores, sc1 polls), write-through otherwise;
+//   then bias + tanh, layers 2 / 3, loss, backward and the weight gradients run replicated -- identical instructions on
+//   identical data -- except dW1, of which a workgroup computes (and owns the Adam state of) its own 64 columns;
+//   the joint clip_grad_norm_ (ppo_lag.py:325) sums one ||g||^2 granule per workgroup: the slice's share of W1, plus everything
+//   else from slice 0 only;  Adam of W1 / b1 at the end of the step, of the rest inside the next step's hand-offs.
 //
-// The arithmetic per element is that of ppo_update_kernel (same MFMA chaining, loss, Adam); the first layer's dot products
-// are summed slice by slice instead of in one chain (rounding-level difference, tests: 1e-5 on the first steps + the fp64
-// drift envelope).  Two output tiles for the actor (act_dim <= 32).  Clipped-surrogate loss, batch <= 64, one GPU.
+// Three instantiations of one body: the clipped-surrogate step (ppo_update_ks_kernel: spo_ppo_lag_update_iter_ks), the KL-penalty
+// actor loss of FOCOPS / CUP with separate optimiser clocks and an actor-only launch (klpen_update_ks_kernel, AMODE 1:
+// spo_update_iter_ex_ks), and the second-order scripts' critic fit (critic_fit_ks_kernel, CFIT: two networks, minibatches of up
+// to 128 rows as two 64-column chunks, the actor's stale gradient norm in the joint clip: spo_critic_fit_iter_ks).
+//
+// The arithmetic per element is that of ppo_update_kernel (same MFMA chaining, loss, Adam); the first layer's dot products are
+// summed slice by slice instead of in one chain (rounding-level difference; tests: 1e-5 on the first steps + the fp64 drift
+// envelope up to 8 192 steps at 524 288 rows x 376).  Two output tiles for the actor (act_dim <= 32).  One GPU.
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -52,7 +59,8 @@ struct KsLds {                                   // floats
 };
 static_assert(KsLds::SIZE * 4 <= 163840, "160 KB of LDS");
 // RED: [0..3] loss partials per wave, [4..7] ||g||^2 of the W1 slice, [8..11] of the rest, [12..15] / [16..19] sum p^2 likewise,
-//      [32 + 32 wave + a] d(log_std) partials, [160 + a] log_std mirror, [192 + i] polled ||g||^2 granules, [224 + i] sum p^2 granules
+//      [20..23] indicator counts per wave (KL-penalty loss), [32 + 32 wave + a] d(log_std) partials, [160 + a] log_std mirror,
+//      [192 + i] polled ||g||^2 granules, [216 + i] sum p^2 granules, [250] placement census
 
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 // partial pre-activations: 16-byte groups of bare floats, [2 parities][3 nets][dst slice]...[256 lanes]
@@ -815,7 +823,6 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
     // ---- joint clip_grad_norm_ over all networks (ppo_lag.py:325): one granule per workgroup
     unsigned long long* const gg = a.gran + (size_t)gpar * 2 * 3 * KS_MAX_SLICES;
     unsigned long long* const gp = gg + 3 * KS_MAX_SLICES;
-    const int nwg = a.n_nets * S;
     if (tid == 0) {
       const float gs = ((red[4] + red[5]) + (red[6] + red[7])) + (first ? ((red[8] + red[9]) + (red[10] + red[11])) : 0.f);
       const float ps = ((red[12] + red[13]) + (red[14] + red[15])) + (first ? ((red[16] + red[17]) + (red[18] + red[19])) : 0.f);
@@ -855,7 +862,6 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
       for (int k2 = 0; k2 < KS_MAX_SLICES; ++k2) pp += red[192 + 3 * KS_MAX_SLICES + net * KS_MAX_SLICES + k2];
       a.losses[s * 3 + net] = is_actor ? -loss_data : loss_data + l2 * pp;
     }
-    (void)nwg;
 
     // ---- Adam (torch.optim.Adam, ppo_lag.py:104-117), parameters back into the LDS image: layer 1 now, the rest deferred (above)
 #pragma unroll
