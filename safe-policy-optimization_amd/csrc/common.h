@@ -42,4 +42,6 @@ inline int hip_check(hipError_t e, const char* what) {
     if (!(cond)) return ::spo::fail(-1, __VA_ARGS__);             \
   } while (0)
 
+// exchange scratch of the feature-split kernels (update_ks.hip), freed together with the update kernels' by spo_update_scratch_release
+int ks_scratch_release(int dev, void* stream_or_null, int all);
 }  // namespace spo

@@ -2883,6 +2883,24 @@ int h_scratch_for(hipStream_t st, float** backup, unsigned long long** slots, in
   return 0;
 }
 
+struct SplitLocal { int dev; void* stream; char* base; unsigned tag; };
+constexpr int SPLIT_LOCAL_MAX = 8;
+SplitLocal g_split_local[SPLIT_LOCAL_MAX] = {};
+int g_split_local_n = 0;
+std::mutex g_split_local_mu;
+int split_local_release(int dev, void* stream_or_null, int all) {
+  std::lock_guard<std::mutex> lk(g_split_local_mu);
+  int freed = 0;
+  for (int i = 0; i < g_split_local_n;) {
+    if (g_split_local[i].dev == dev && (all || g_split_local[i].stream == stream_or_null)) {
+      (void)spo::hip_check(hipFree(g_split_local[i].base), "hipFree(split exchange)");
+      g_split_local[i] = g_split_local[--g_split_local_n];
+      ++freed;
+    } else ++i;
+  }
+  return freed;
+}
+
 }  // namespace
 // Releases the scratch block of (current device, stream) -- or of every stream of the current device when stream_or_null is
 // NULL and all != 0.  The block is keyed by the raw stream handle, so a process that keeps creating and destroying streams
@@ -2899,6 +2917,8 @@ extern "C" int spo_update_scratch_release(void* stream_or_null, int all) {
       ++freed;
     } else ++i;
   }
+  freed += split_local_release(dev, stream_or_null, all);
+  freed += spo::ks_scratch_release(dev, stream_or_null, all);
   return freed;
 }
 namespace {
@@ -3305,31 +3325,32 @@ extern "C" int spo_critic_fit_iter_dp(float* theta, float* adam_m, float* adam_v
 // One grid of four workgroups is co-resident by construction, so -- unlike two launches on two streams (round 1 / 2: the
 // second stream could land on the first one's hardware queue and never run beside it) -- the form never depends on HIP's
 // queue assignment.  cpo.py:534-571: identical arithmetic to the mean over the 128 rows up to the order of the sums.
-// Cached pair of exchange regions + census words of the one-grid split form (round 5), one block per device, allocated on
-// first use.  Cleared by every launch (tags restart with every engine; 13 MB at HBM speed is ~5 us against a 0.5 s launch).
-struct SplitLocal { char* base; unsigned tag; };
-static SplitLocal g_split_local[SPO_MAX_DEVICES] = {};
-static std::mutex g_split_local_mu;
+// Cached pair of exchange regions + census words of the one-grid split form (round 5), one block per (device, stream),
+// allocated on first use, released by spo_update_scratch_release.  Cleared by every launch (tags restart with every engine;
+// 13 MB at HBM speed is ~5 us against a 0.5 s launch).
 static int split_local_for(hipStream_t st, UpdArgs& a, UpdArgs& b) {
   static const bool off = [] { const char* e = getenv("SPO_CPO_SPLIT_L2"); return e && !strcmp(e, "0"); }();
   if (off) return 0;
   const int dev = current_device_slot();
   std::lock_guard<std::mutex> lk(g_split_local_mu);
-  SplitLocal& sl = g_split_local[dev];
-  if (!sl.base) {
+  SplitLocal* sl = nullptr;
+  for (int i = 0; i < g_split_local_n; ++i)
+    if (g_split_local[i].dev == dev && g_split_local[i].stream == (void*)st) sl = &g_split_local[i];
+  if (!sl) {
+    if (g_split_local_n == SPLIT_LOCAL_MAX) return 0;               // (table full: the uncached regions, as before round 5)
     void* p = nullptr;
     if (int rc = spo::hip_check(hipMalloc(&p, 2 * XR_REGION_BYTES + 256), "hipMalloc(split exchange, cached)")) return rc;
     if (int rc = spo::hip_check(hipMemset(p, 0, 2 * XR_REGION_BYTES + 256), "hipMemset(split exchange)")) { (void)hipFree(p); return rc; }
-    sl.base = static_cast<char*>(p); sl.tag = 1u;
+    g_split_local[g_split_local_n] = SplitLocal{dev, (void*)st, static_cast<char*>(p), 1u};
+    sl = &g_split_local[g_split_local_n++];
   }
-  if (int rc = spo::hip_check(hipMemsetAsync(sl.base, 0, 2 * XR_REGION_BYTES, st),
-                              "hipMemsetAsync(split exchange)")) return rc;
+  if (int rc = spo::hip_check(hipMemsetAsync(sl->base, 0, 2 * XR_REGION_BYTES, st), "hipMemsetAsync(split exchange)")) return rc;
   for (UpdArgs* u : {&a, &b}) {
-    u->xr_region[2] = sl.base; u->xr_region[3] = sl.base + XR_REGION_BYTES;
-    u->xr_census = reinterpret_cast<unsigned long long*>(sl.base + 2 * XR_REGION_BYTES);
-    u->xr_census_tag = sl.tag;
+    u->xr_region[2] = sl->base; u->xr_region[3] = sl->base + XR_REGION_BYTES;
+    u->xr_census = reinterpret_cast<unsigned long long*>(sl->base + 2 * XR_REGION_BYTES);
+    u->xr_census_tag = sl->tag;
   }
-  sl.tag += 1u;
+  sl->tag += 1u;
   return 0;
 }
 

@@ -987,29 +987,57 @@ __global__ __launch_bounds__(256, 1) void critic_fit_ks_kernel(KsArgs a) {
 // atomics).  One block per device, allocated on first use, zeroed once (tags never repeat).
 struct KsScratch { float* z; unsigned long long* gran; };
 constexpr size_t KS_G_BYTES = (size_t)(2 * 2 * 3 * KS_MAX_SLICES + 3 * KS_MAX_SLICES) * 8;   // granules + the placement census
-KsScratch g_ks[SPO_MAX_DEVICES] = {};
-unsigned g_ks_tag[SPO_MAX_DEVICES] = {};
+// One block per (device, stream), like the update kernels' scratch in update.hip: launches on one stream are ordered and share
+// it, two engines on two streams get two blocks and may run concurrently.  Released by spo_update_scratch_release.
+struct KsEntry { int dev; void* stream; char* base; unsigned tag; };
+constexpr int KS_SCRATCH_MAX = 16;
+KsEntry g_ks[KS_SCRATCH_MAX] = {};
+int g_ks_n = 0;
 std::mutex g_ks_mu;
 
-int ks_scratch(KsScratch* out, unsigned* tag_base, unsigned nsteps) {
+int ks_scratch(hipStream_t st, KsScratch* out, unsigned* tag_base, unsigned nsteps) {
   const int dev = current_device_slot();
   std::lock_guard<std::mutex> lk(g_ks_mu);
-  if (!g_ks[dev].z) {
+  KsEntry* e = nullptr;
+  for (int i = 0; i < g_ks_n; ++i)
+    if (g_ks[i].dev == dev && g_ks[i].stream == (void*)st) e = &g_ks[i];
+  if (!e) {
+    if (g_ks_n == KS_SCRATCH_MAX)
+      return spo::fail(-1, "feature-split update kernel: more than %d (device, stream) pairs hold exchange scratch in this process; "
+                           "call spo_update_scratch_release(stream) for streams that are gone", KS_SCRATCH_MAX);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+      return spo::fail(-1, "feature-split update kernel: first launch on a stream under capture (the scratch block is allocated on "
+                           "first use: launch once outside the capture)");
     void* p = nullptr;
     if (int rc = spo::hip_check(hipMalloc(&p, KS_Z_BYTES + KS_G_BYTES), "hipMalloc(ks scratch)")) return rc;
     if (int rc = spo::hip_check(hipMemset(p, 0, KS_Z_BYTES + KS_G_BYTES), "hipMemset(ks scratch)")) { (void)hipFree(p); return rc; }
     if (int rc = spo::hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize(ks scratch)")) { (void)hipFree(p); return rc; }
-    g_ks[dev].z = static_cast<float*>(p);
-    g_ks[dev].gran = reinterpret_cast<unsigned long long*>(static_cast<char*>(p) + KS_Z_BYTES);
-    g_ks_tag[dev] = 16u;
+    g_ks[g_ks_n] = KsEntry{dev, (void*)st, static_cast<char*>(p), 16u};
+    e = &g_ks[g_ks_n++];
   }
-  *out = g_ks[dev];
-  *tag_base = g_ks_tag[dev];
-  g_ks_tag[dev] += nsteps + 2u;                    // (wraps after 4e9 steps: a tag then meets words 2^32 steps old)
+  out->z = reinterpret_cast<float*>(e->base);
+  out->gran = reinterpret_cast<unsigned long long*>(e->base + KS_Z_BYTES);
+  *tag_base = e->tag;
+  e->tag += nsteps + 2u;                           // (wraps after 4e9 steps: a tag then meets words 2^32 steps old)
   return 0;
 }
 
 }  // namespace
+
+// (called by spo_update_scratch_release, update.hip)
+int spo::ks_scratch_release(int dev, void* stream_or_null, int all) {
+  std::lock_guard<std::mutex> lk(g_ks_mu);
+  int freed = 0;
+  for (int i = 0; i < g_ks_n;) {
+    if (g_ks[i].dev == dev && (all || g_ks[i].stream == stream_or_null)) {
+      (void)spo::hip_check(hipFree(g_ks[i].base), "hipFree(ks scratch)");
+      g_ks[i] = g_ks[--g_ks_n];
+      ++freed;
+    } else ++i;
+  }
+  return freed;
+}
 
 #ifdef SPO_KS_PROF
 extern "C" int spo_debug_ks_profile(unsigned long long* out16_host) {
@@ -1036,7 +1064,7 @@ static int ks_launch(KsArgs& a, const spo_ppo_cfg* cfg_host, int64_t adam_step_h
   const int64_t nsteps = (M + cfg_host->batch - 1) / cfg_host->batch;
   SPO_REQUIRE(nsteps < (1ll << 30), "update_iter_ks: too many minibatch steps in one launch");
   KsScratch sc;
-  if (int rc = ks_scratch(&sc, &a.tag_base, (unsigned)nsteps)) return rc;
+  if (int rc = ks_scratch(st, &sc, &a.tag_base, (unsigned)nsteps)) return rc;
   a.zbuf = sc.z; a.gran = sc.gran;
   // every slot starts as the sentinel (a launch leaves them that way unless it stopped on an error: cheap enough to not care)
   if (int rc = spo::hip_check(hipMemsetAsync(sc.z, 0xFF, KS_ZZERO_OFF, st), "hipMemsetAsync(ks partials)")) return rc;

@@ -409,6 +409,56 @@ def test_feature_split_kernel_full_size_drift_envelope_at_humanoid_dims(dev):
     print("feature-split kernel, 376 / 17, drift envelope (ratio <= 1 passes):", rep)
 
 
+def test_two_feature_split_engines_update_concurrently_on_two_streams(dev):
+    """The feature-split kernels' exchange scratch (partial-sum slots, norm granules, placement census) is per (device, stream),
+    like the three-workgroup kernel's: two engines of one process launched at the same time on two streams -- 9 + 9 co-resident
+    workgroups exchanging through their own blocks -- must equal the same iterations run one engine after the other, bit for bit."""
+    from safepo.common.engine import WidePPOLagEngine
+    from test_gpu_parity import _fill_update_problem
+    D, A, hidden, M = 130, 8, [64, 64], 64 * 96
+    cfg = {"hidden_sizes": hidden, "gamma": 0.99, "target_kl": 1e9, "batch_size": 64, "learning_iters": 1, "max_grad_norm": 40.0}
+
+    def make(seed):
+        pol, _ = _wide_pair(D, A, hidden, dev, seed=seed)
+        eng = WidePPOLagEngine(pol, 1, M, cfg, dev)
+        assert eng._feature_split_kernel_ok(eng._cfg_struct())
+        _fill_update_problem(eng, _synthetic_update_problem(M, D, A, seed=seed + 100))
+        g = torch.Generator().manual_seed(seed)
+        return eng, [torch.randperm(M, generator=g).to(torch.int32).to(dev) for _ in range(3)]
+    results = {}
+    for mode in ("sequential", "concurrent"):
+        engs = [make(11), make(22)]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        torch.cuda.synchronize()
+        losses = [[], []]
+        if mode == "sequential":
+            for k, (eng, perms) in enumerate(engs):
+                with torch.cuda.stream(streams[k]):
+                    for p_ in perms:
+                        losses[k].append(eng.learning_iter(p_).clone())
+                torch.cuda.synchronize()
+        else:
+            for it in range(3):
+                for k, (eng, perms) in enumerate(engs):
+                    with torch.cuda.stream(streams[k]):
+                        losses[k].append(eng.learning_iter(perms[it]).clone())
+            torch.cuda.synchronize()
+        for eng, _ in engs:
+            eng.check_sync_error()
+        results[mode] = [(e.policy.theta.clone(), e.adam_m.clone(), torch.stack(l)) for (e, _), l in zip(engs, losses)]
+    for k in range(2):
+        for x, y in zip(results["sequential"][k], results["concurrent"][k]):
+            assert torch.equal(x, y), k
+    assert not torch.equal(results["sequential"][0][0], results["sequential"][1][0])
+    freed = int(_abi_lib().spo_update_scratch_release(None, 1))
+    assert freed >= 2, freed                      # both streams' blocks are handed back (anything else of this process with them)
+
+
+def _abi_lib():
+    from safepo import _abi
+    return _abi.load()
+
+
 @pytest.mark.parametrize("algo", ["ppo_lag", "cppo_pid", "focops", "cup", "cpo", "pcpo", "rcpo", "trpo_lag"])
 def test_default_sweep_algorithms_train_at_humanoid_dims(dev, tmp_path, algo):
     """`ActorVCritic(376, 17)` trains under every algorithm of the reference's default sweep (benchmark.py:33-44) on the
