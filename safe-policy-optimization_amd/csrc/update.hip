@@ -3111,6 +3111,7 @@ extern "C" int spo_p2p_select_form(int form) {
 }
 static bool xr_form_valid(int form, int world) {
   const bool pow2 = (world & (world - 1)) == 0;
+  if (world < 2 || world > XR_MAX_WORLD) return false;
   switch (form) {
     case SPO_XR_FORM_TWOPHASE: return true;
     case SPO_XR_FORM_DOUBLING: return pow2;

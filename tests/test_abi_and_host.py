@@ -51,6 +51,35 @@ def test_argument_errors_without_gpu(built_lib):
     assert b"obs_dim" in lib.spo_last_error()
 
 
+def test_feature_split_entry_points_shape_envelope_and_argument_errors(built_lib):
+    """Round 5: the persistent feature-split kernels (csrc/update_ks.hip) say which shapes they take without touching a GPU, and
+    their entry points refuse bad arguments before any launch; the exchange-form selectors know which forms exist per world size."""
+    import ctypes
+    from safepo import _abi
+    lib = _abi.load(built_lib)
+    assert lib.spo_ks_supported(376, 17, 64) == 1 and lib.spo_ks_supported(512, 32, 1) == 1 and lib.spo_ks_supported(1, 1, 64) == 1
+    assert lib.spo_ks_supported(513, 17, 64) == 0 and lib.spo_ks_supported(376, 33, 64) == 0 and lib.spo_ks_supported(376, 17, 65) == 0
+    assert lib.spo_critic_fit_ks_supported(376, 128) == 1 and lib.spo_critic_fit_ks_supported(512, 64) == 1
+    assert lib.spo_critic_fit_ks_supported(513, 128) == 0 and lib.spo_critic_fit_ks_supported(376, 129) == 0
+    cfg = _abi.PpoCfg(obs_dim=600, act_dim=17, batch=64, use_critic_norm=1, use_value_coefficient=0, clip=0.2, max_grad_norm=40.0,
+                      lr_actor=3e-4, lr_critic=3e-4, beta1=0.9, beta2=0.999, adam_eps=1e-8, l2_coef=0.001)
+    assert lib.spo_ppo_lag_update_iter_ks(None, None, None, 0, None, None, None, None, None, None, None, 64, ctypes.byref(cfg),
+                                          None, None, None) < 0
+    assert b"obs_dim 600" in lib.spo_last_error()
+    cfg.obs_dim = 376
+    assert lib.spo_ppo_lag_update_iter_ks(None, None, None, 0, None, None, None, None, None, None, None, 64, ctypes.byref(cfg),
+                                          None, None, None) < 0
+    assert b"null pointer" in lib.spo_last_error()
+    cfg.batch = 200
+    assert lib.spo_critic_fit_iter_ks(None, None, None, 0, None, None, None, None, 64, ctypes.byref(cfg), None, None, None, None) < 0
+    assert b"batch 200" in lib.spo_last_error()
+    # forms of the in-kernel exchange: doubling needs a power-of-two world, the helper-wave forms exist at 2 / 4 / 8
+    for world in (2, 4, 8):
+        assert all(lib.spo_p2p_form_valid(f, world) == 1 for f in (0, 1, 2, 3)), world
+    assert lib.spo_p2p_form_valid(0, 3) == 1 and lib.spo_p2p_form_valid(1, 3) == 0 and lib.spo_p2p_form_valid(1, 6) == 0
+    assert lib.spo_p2p_form_valid(7, 2) == 0 and lib.spo_p2p_form_valid(0, 9) == 0
+
+
 def test_missing_library_fails_loudly(tmp_path):
     from safepo import _abi
     with pytest.raises(_abi.SpoError, match="no CPU fallback"):
