@@ -69,17 +69,45 @@ def loss_envelope(hip, f32, f64, c=3.0, floor_rel=3e-7, window=64):
     return worst
 
 
-def theta_envelope(hip, f32, f64, c=3.0, floor_abs=2e-7, floor_abs_max=None):
+def adam_noise_directions(dh, d32, frac=1e-4, factor=30.0, slack=10.0):
+    """Elements on which THE REFERENCE ITSELF is an outlier against float64: Adam divides by sqrt(v) + eps, so an element whose
+    gradient is of the size of eps (1e-8) turns rounding noise of the gradient into steps of either sign -- in the reference's
+    float32 as much as anywhere (measured on the reference's own ppo_lag.main() at 376 / 17, tests/golden/ppo_lag_trace_humanoid:
+    ONE of 74 947 parameters, a first-layer weight of the cost critic, sits 4.7e-6 from float64 in the reference's recorded
+    run after 6 steps where every other element sits ~1e-8; the launch-per-layer HIP path lands 9.2e-6 away on it, the feature-split
+    kernel 2.8e-5).  Such an element says nothing about rounding quality, and one of them can dominate an L2 norm.  They are
+    identified by the reference's behaviour alone -- at most `frac` of the elements, each at least `factor` x the RMS distance of
+    the rest -- gated on their own (|hip - f64| <= slack x the reference's distance on THAT element) and left out of the norms.
+    Returns (mask, ok)."""
+    n = d32.size
+    k = max(1, int(np.ceil(frac * n)))
+    order = np.argsort(d32)
+    typ = float(np.sqrt(np.mean(d32[order[:n - k]] ** 2))) if n > k else 0.0
+    mask = np.zeros(n, bool)
+    cand = order[n - k:]
+    mask[cand] = d32[cand] > factor * max(typ, 1e-12)
+    return mask, bool((dh[mask] <= slack * d32[mask]).all())
+
+
+def theta_envelope(hip, f32, f64, c=3.0, floor_abs=2e-7, floor_abs_max=None, noise_directions=False):
     """L2 and max-abs distance of the parameter vector from the fp64 trajectory against c x the fp32 reference's own
     distance (+ floor_abs per element: half an fp32 ulp of an O(1) parameter; floor_abs_max: a separate floor for the max-norm
-    gate, see tests/test_gpu_wide_dims.py::_theta_floor).  Returns the worse of the two ratios."""
+    gate, see tests/test_gpu_wide_dims.py::_theta_floor).  noise_directions: adam_noise_directions() first.  Returns the worse
+    of the two ratios."""
     hip, f32, f64 = (np.asarray(x, np.float64).reshape(-1) for x in (hip, f32, f64))
+    info = {}
+    if noise_directions:
+        mask, ok = adam_noise_directions(np.abs(hip - f64), np.abs(f32 - f64))
+        info["noise_directions"] = int(mask.sum())
+        if not ok:
+            return float("inf"), {"noise_directions": int(mask.sum()), "worst": float((np.abs(hip - f64)[mask] / np.abs(f32 - f64)[mask]).max())}
+        hip, f32, f64 = hip[~mask], f32[~mask], f64[~mask]
     n = f64.size
     dh2, d322 = np.linalg.norm(hip - f64), np.linalg.norm(f32 - f64)
     dhm, d32m = np.abs(hip - f64).max(), np.abs(f32 - f64).max()
     r2 = dh2 / (c * d322 + floor_abs * np.sqrt(n))
     rm = dhm / (c * d32m + (floor_abs if floor_abs_max is None else floor_abs_max))
-    return max(r2, rm), {"l2_hip": dh2, "l2_f32": d322, "max_hip": dhm, "max_f32": d32m}
+    return max(r2, rm), dict(info, l2_hip=dh2, l2_f32=d322, max_hip=dhm, max_f32=d32m)
 
 
 def assert_loss_envelope(hip, f32, f64, what, **kw):
@@ -170,11 +198,23 @@ def replay_ppo_lag_trace(z, dtype=torch.float64):
 # ------------------------------------------------------------------------------------------------------------------------
 # Round 5: the remaining trace replays under the same yardstick
 # ------------------------------------------------------------------------------------------------------------------------
-def gate_array(hip, f32, f64, what, rel_floor=1e-6, c=3.0):
-    """|hip - f64| <= c |f32 - f64| + rel_floor * max|f64| in max-norm and in L2 (per sqrt(n))."""
+def theta_floor(lr, nsteps):
+    """Max-norm floor for parameter gates after `nsteps` Adam steps at wide input layers (tests/test_gpu_wide_dims.py::_theta_floor:
+    half an ulp of an O(1) parameter + 0.3 % of the distance Adam can move an element in that many steps; the L2 gate keeps the
+    plain floor)."""
+    return 2e-7 + 3e-3 * lr * nsteps
+
+
+def gate_array(hip, f32, f64, what, rel_floor=1e-6, c=3.0, noise_directions=False):
+    """|hip - f64| <= c |f32 - f64| + rel_floor * max|f64| in max-norm and in L2 (per sqrt(n)); noise_directions:
+    adam_noise_directions() first (parameters after Adam steps at wide input layers)."""
     hip, f32, f64 = (np.asarray(t, np.float64).reshape(-1) for t in (hip, f32, f64))
     assert hip.shape == f32.shape == f64.shape, (what, hip.shape, f32.shape, f64.shape)
     assert np.isfinite(hip).all(), f"{what}: non-finite HIP values"
+    if noise_directions:
+        mask, ok = adam_noise_directions(np.abs(hip - f64), np.abs(f32 - f64))
+        assert ok, f"{what}: an Adam noise direction of the reference is more than 10 x further from float64 on the HIP path"
+        hip, f32, f64 = hip[~mask], f32[~mask], f64[~mask]
     sc = max(float(np.abs(f64).max()), 1e-30)
     dh, d32 = np.abs(hip - f64), np.abs(f32 - f64)
     assert dh.max() <= c * d32.max() + rel_floor * sc, \

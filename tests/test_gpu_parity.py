@@ -408,8 +408,9 @@ def test_gae_full_size_properties(dev):
     assert abs(float(data["adv_r"].mean())) < 1e-5 and abs(float(data["adv_r"].std()) - 1) < 1e-4
 
 
-def _policy_from_npz(z, prefix, dev, obs_dim=60, act_dim=8):
+def _policy_from_npz(z, prefix, dev):
     from safepo.common.model import ActorVCritic
+    obs_dim, act_dim = z[prefix + "actor.mean.0.weight"].shape[1], z[prefix + "actor.log_std"].shape[0]
     pol = ActorVCritic(obs_dim, act_dim).to(dev)
     sd = {k[len(prefix):]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith(prefix)}
     pol.load_state_dict(sd)
@@ -466,26 +467,33 @@ def _load_epoch_into_engine(z, e, eng, dev):
     b.ptr = T
 
 
-def test_ppo_lag_update_vs_reference_main_trace(dev, golden_dir):
-    """3 epochs of the reference ppo_lag.main(): same buffers, same shuffles, same initial weights ->
+@pytest.mark.parametrize("fname", ["ppo_lag_trace.npz", "ppo_lag_trace_humanoid.npz"])
+def test_ppo_lag_update_vs_reference_main_trace(dev, golden_dir, fname):
+    """The epochs of the reference ppo_lag.main(): same buffers, same shuffles, same initial weights ->
     per-minibatch losses, early-stop iteration, KL and parameters after every epoch.  Trajectory quantities are gated by
     the drift envelope (tests/envelope.py): T32 = the values the reference itself recorded, T64 = the oracle replaying
-    the same recorded inputs in float64; the HIP path may be at most 3x as far from T64 as the reference is."""
+    the same recorded inputs in float64; the HIP path may be at most 3x as far from T64 as the reference is.
+    `_humanoid` (round 5): the reference's own run with ActorVCritic(376, 17) (oracle/make_golden_humanoid.py) -- the update runs
+    on the persistent feature-split kernel (csrc/update_ks.hip) behind WidePPOLagEngine."""
     import envelope as E
-    from safepo.common.engine import PPOLagEngine
-    z = np.load(os.path.join(golden_dir, "ppo_lag_trace.npz"))
+    from safepo.common.engine import PPOLagEngine, WidePPOLagEngine
+    z = np.load(os.path.join(golden_dir, fname))
     N, T, epochs = int(z["meta_num_envs"]), int(z["meta_T"]), int(z["meta_epochs"])
     pol = _policy_from_npz(z, "init_sd_", dev)
     cfg = {"hidden_sizes": [64, 64], "gamma": float(z["meta_cfg_gamma"]), "target_kl": float(z["meta_cfg_target_kl"]),
            "batch_size": int(z["e0_batch_size"]), "learning_iters": int(z["meta_cfg_learning_iters"]),
            "max_grad_norm": float(z["meta_cfg_max_grad_norm"])}
-    eng = PPOLagEngine(pol, N, T, cfg, dev)
+    wide = not pol.kernels_supported("ppo")
+    eng = (WidePPOLagEngine if wide else PPOLagEngine)(pol, N, T, cfg, dev)
+    assert wide == fname.endswith("_humanoid.npz") and (not wide or eng._feature_split_kernel_ok(eng._cfg_struct()))
     t64 = E.replay_ppo_lag_trace(z, torch.float64)
     ratios, kl_rows = [], []
+    steps_done = 0
+    tk = lambda: ({"floor_abs_max": E.theta_floor(3e-4, max(steps_done, 1)), "noise_directions": True} if wide else {})
     for e in range(epochs):
         ref_before = np.concatenate([z[f"e{e}_sd_before_{k}"].reshape(-1) for k in pol.state_dict()])
         ratios.append(E.assert_theta_envelope(pol.theta.cpu().numpy(), ref_before, t64["theta_before"][e],
-                                              f"theta before epoch {e}")[0])
+                                              f"theta before epoch {e}", **tk())[0])
         _load_epoch_into_engine(z, e, eng, dev)
         lam = float(z[f"e{e}_row_Train_LagragianMultiplier"])
         n_perm = len([k for k in z.files if k.startswith(f"e{e}_perm")])
@@ -497,6 +505,7 @@ def test_ppo_lag_update_vs_reference_main_trace(dev, golden_dir):
         np.testing.assert_allclose(b.data["adv_r"].cpu().numpy().reshape(-1), z[f"e{e}_get_adv_r"], rtol=1e-5, atol=2e-6)
         got = torch.cat(out["losses"], 0).cpu().numpy()
         ref = z[f"e{e}_mb_losses"]
+        steps_done += len(ref)
         assert out["stop_iter"] == int(z[f"e{e}_row_Train_StopIter"]), (out["stop_iter"], out["kl"])
         if e == 0:
             np.testing.assert_allclose(got[:3], ref[:3], rtol=1e-5, atol=1e-6)       # first steps from identical weights
@@ -505,7 +514,7 @@ def test_ppo_lag_update_vs_reference_main_trace(dev, golden_dir):
     # the early-stop KL after each epoch's free-running passes: as far from the float64 replay as the reference's own values are
     print("KL yardstick (worst hip, reference):", E.gate_scalars(kl_rows, "Train/KL", rel_floor=1e-6))
     ref_final = np.concatenate([z[f"final_sd_{k}"].reshape(-1) for k in pol.state_dict()])
-    ratios.append(E.assert_theta_envelope(pol.theta.cpu().numpy(), ref_final, t64["theta_final"], "final theta")[0])
+    ratios.append(E.assert_theta_envelope(pol.theta.cpu().numpy(), ref_final, t64["theta_final"], "final theta", **tk())[0])
     print("drift envelope ratios (<= 1 passes):", np.round(ratios, 3))
 
 
@@ -869,6 +878,9 @@ def _cpo_engine(z, prefix, dev, N, T, cfg_over=None):
     pol = _policy_from_npz(z, prefix, dev)
     cfg = dict(default_cfg)
     cfg.update(cfg_over or {})
+    if not pol.kernels_supported("cpo"):                    # (dims outside the LDS-resident kernels: the wide engine)
+        from safepo.single_agent.cpo import make_engine
+        return pol, make_engine(pol, N, T, cfg, dev)
     return pol, CPOEngine(pol, N, T, cfg, dev)
 
 
@@ -1062,7 +1074,7 @@ def test_cpo_trace_epochs_one_by_one_under_the_fp64_yardstick(dev, golden_dir):
     print("cpo trace, per-epoch relative distance to float64:", {k: f"{v:.2e}" for k, v in worst.items()})
 
 
-@pytest.mark.parametrize("algo", ["cpo", "pcpo", "natural_pg", "trpo", "rcpo", "trpo_lag"])
+@pytest.mark.parametrize("algo", ["cpo", "pcpo", "natural_pg", "trpo", "rcpo", "trpo_lag", "cpo_humanoid"])
 def test_second_order_family_traces_under_the_fp64_yardstick(dev, golden_dir, algo):
     """every trust-region script of the reference under the gate cpo got in round 4, critic fit included.
     The reference's main() trace is replayed with the ACTOR reset to the reference's recorded parameters at every epoch (its
@@ -1077,11 +1089,21 @@ def test_second_order_family_traces_under_the_fp64_yardstick(dev, golden_dir, al
     The free-running replays below (5e-3) stay as trajectory checks."""
     import envelope as E
     from safepo.common.lagrange import Lagrange
-    z = np.load(os.path.join(golden_dir, f"{algo}_trace.npz"))
+    # "cpo_humanoid" (round 5): the reference's cpo.main() with ActorVCritic(376, 17) -- WideCPOEngine: surrogate gradients,
+    # Fisher-vector products and line search on the wide kernels, the critic fit on the feature-split kernel
+    fname = "cpo_trace_humanoid.npz" if algo == "cpo_humanoid" else f"{algo}_trace.npz"
+    algo = "cpo" if algo == "cpo_humanoid" else algo
+    z = np.load(os.path.join(golden_dir, fname))
     N, T, epochs = int(z["meta_num_envs"]), int(z["meta_T"]), int(z["meta_epochs"])
     iters = int(z["meta_cfg_learning_iters"])
     pol, eng = _cpo_engine(z, "init_sd_", dev, N, T, {"learning_iters": iters, "batch_size": int(z["e0_batch_size"]),
                                                        "target_kl": float(z["meta_cfg_target_kl"])})
+    wide = type(eng).__name__ == "WideCPOEngine"
+    assert wide == fname.endswith("_humanoid.npz")
+    # wide: tests/envelope.py::adam_noise_directions; max-norm floor 5e-6 of the critics' scale after Adam steps behind a 376-wide
+    # first layer (an MFMA accumulator chains 94 sequential products where the reference's blocked sgemm sums 16-wide partials:
+    # tests/test_gpu_wide_dims.py::_theta_floor measures the same factor of ~5 on the maximum with the L2 distance inside 3 x)
+    nd = {"noise_directions": True, "rel_floor": 5e-6} if wide else {"rel_floor": 1e-6}
     o64, crit64_final = E.replay_second_order_trace(z, algo, torch.float64)
     lagrange = Lagrange(cost_limit=float(z["meta_arg_cost_limit"]),
                         lagrangian_multiplier_init=float(z["meta_arg_lagrangian_multiplier_init"]),
@@ -1095,7 +1117,7 @@ def test_second_order_family_traces_under_the_fp64_yardstick(dev, golden_dir, al
     for e in range(epochs):
         ref_before = np.concatenate([z[f"e{e}_sd_before_{k}"].reshape(-1) for k in pol.state_dict()])
         worst[f"critics before {e}"] = E.gate_array(pol.theta[:n_crit].cpu().numpy(), ref_before[:n_crit], o64[e]["critics_before"],
-                                                    f"{algo}: critics before epoch {e}", rel_floor=1e-6)[0]
+                                                    f"{algo}: critics before epoch {e}", **nd)[0]
         pol.load_state_dict({"actor." + k: torch.from_numpy(z[f"e{e}_sd_before_actor.{k}"].copy()) for k in pol.actor.state_dict()},
                             strict=False)
         _load_epoch_into_engine(z, e, eng, dev)
@@ -1133,7 +1155,7 @@ def test_second_order_family_traces_under_the_fp64_yardstick(dev, golden_dir, al
                                                              f"{algo}: critic-fit losses of epoch {e}", window=len(got))
     ref_final = np.concatenate([z[f"final_sd_{k}"].reshape(-1) for k in pol.state_dict()])
     worst["critics final"] = E.gate_array(pol.theta[:n_crit].cpu().numpy(), ref_final[:n_crit], crit64_final, f"{algo}: critics at the end",
-                                          rel_floor=1e-6)[0]
+                                          **nd)[0]
     for k, rows in kinds.items():
         # (the logged actor loss is a mean over standardised advantages at ratio 1 -- zero up to rounding: measured against
         #  the advantages' unit scale)
@@ -1645,27 +1667,32 @@ def test_sibling_entrypoints_synthetic(dev, tmp_path, algo):
     if algo == "cppo_pid":
         assert float(rows[1]["Train/LagragianMultiplier"]) > 0.0          # cost 4/episode > limit 0.5
 
-@pytest.mark.parametrize("algo", ["focops", "cup"])
-def test_kl_penalty_family_vs_reference_main_trace(dev, golden_dir, algo):
-    """3 epochs of the reference focops.main() / cup.main(): same buffers, shuffles and initial weights ->
+@pytest.mark.parametrize("algo,suffix", [("focops", ""), ("cup", ""), ("focops", "_humanoid")])
+def test_kl_penalty_family_vs_reference_main_trace(dev, golden_dir, algo, suffix):
+    """The epochs of the reference focops.main() / cup.main(): same buffers, shuffles and initial weights ->
     per-minibatch losses (critics + the KL-penalty actor loss with its indicator), early-stop iterations of both
-    stages, KL and parameters after every epoch."""
-    from safepo.common.engine import PPOLagEngine
-    z = np.load(os.path.join(golden_dir, f"{algo}_trace.npz"))
+    stages, KL and parameters after every epoch.  `_humanoid` (round 5): focops.main() with ActorVCritic(376, 17), on the
+    feature-split kernel's KL-penalty instantiation."""
+    from safepo.common.engine import PPOLagEngine, WidePPOLagEngine
+    z = np.load(os.path.join(golden_dir, f"{algo}_trace{suffix}.npz"))
     N, T, epochs = int(z["meta_num_envs"]), int(z["meta_T"]), int(z["meta_epochs"])
     pol = _policy_from_npz(z, "init_sd_", dev)
     cfg = {"hidden_sizes": [64, 64], "gamma": float(z["meta_cfg_gamma"]), "target_kl": float(z["meta_cfg_target_kl"]),
            "batch_size": int(z["e0_batch_size"]), "learning_iters": int(z["meta_cfg_learning_iters"]),
            "max_grad_norm": float(z["meta_cfg_max_grad_norm"])}
-    eng = PPOLagEngine(pol, N, T, cfg, dev)
+    wide = not pol.kernels_supported("ppo")
+    eng = (WidePPOLagEngine if wide else PPOLagEngine)(pol, N, T, cfg, dev)
+    assert wide == bool(suffix)
     # the drift envelope of the PPO-Lagrangian trace test: T64 = the oracle replaying the recorded inputs in float64, T32 = the
     # values the reference itself recorded (round 5: instead of rtol 2e-4 ... 5e-4 and a KL at 3e-3)
     import envelope as E
     o64, theta64_final = E.replay_kl_penalty_trace(z, algo, torch.float64)
     ratios, kl_rows = [], []
+    steps_done = 0
+    tk = lambda: ({"floor_abs_max": E.theta_floor(3e-4, max(steps_done, 1)), "noise_directions": True} if wide else {})
     for e in range(epochs):
         ref_before = np.concatenate([z[f"e{e}_sd_before_{k}"].reshape(-1) for k in pol.state_dict()])
-        ratios.append(E.assert_theta_envelope(pol.theta.cpu().numpy(), ref_before, o64[e]["theta_before"], f"theta before epoch {e}")[0])
+        ratios.append(E.assert_theta_envelope(pol.theta.cpu().numpy(), ref_before, o64[e]["theta_before"], f"theta before epoch {e}", **tk())[0])
         _load_epoch_into_engine(z, e, eng, dev)
         lam = float(z[f"e{e}_row_Train_LagragianMultiplier"])
         n_perm = len([k for k in z.files if k.startswith(f"e{e}_perm")])
@@ -1682,13 +1709,14 @@ def test_kl_penalty_family_vs_reference_main_trace(dev, golden_dir, algo):
         assert out["stop_iter"] == int(z[f"e{e}_row_Train_StopIter"]) == o64[e]["stop_iter"], (out["stop_iter"], out["kl"])
         got = torch.cat(out["losses"], 0).cpu().numpy()
         ref = z[f"e{e}_mb_losses"]
+        steps_done += len(ref)
         if e == 0:
             np.testing.assert_allclose(got[:3], ref[:3], rtol=1e-5, atol=1e-6)       # first steps from identical weights
         ratios.append(E.assert_loss_envelope(got, ref, o64[e]["losses"], f"losses of epoch {e}", window=len(ref)))
         kl_rows.append((f"epoch {e}", out["kl"], float(z[f"e{e}_row_Train_KL"]), o64[e]["kl"]))
     print("KL yardstick (worst hip, reference):", E.gate_scalars(kl_rows, f"{algo} Train/KL", rel_floor=1e-6))
     ref_final = np.concatenate([z[f"final_sd_{k}"].reshape(-1) for k in pol.state_dict()])
-    ratios.append(E.assert_theta_envelope(pol.theta.cpu().numpy(), ref_final, theta64_final, "final theta")[0])
+    ratios.append(E.assert_theta_envelope(pol.theta.cpu().numpy(), ref_final, theta64_final, "final theta", **tk())[0])
     print(f"{algo}: drift envelope ratios (<= 1 passes):", np.round(ratios, 3))
 
 

@@ -15,7 +15,8 @@ def _load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name))
 
 
-def _policy_from(z, prefix, obs_dim=60, act_dim=8):
+def _policy_from(z, prefix):
+    obs_dim, act_dim = z[prefix + "actor.mean.0.weight"].shape[1], z[prefix + "actor.log_std"].shape[0]
     pol = R.OraclePolicy(obs_dim, act_dim)
     sd = {k[len(prefix):]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith(prefix)}
     pol.load_state_dict(sd)
@@ -82,11 +83,13 @@ def _epoch_data(z, e):
     return N, T, adv_r, adv_c, tgt_r, tgt_c
 
 
-def test_ppo_lag_main_trace(golden_dir):
-    """Replays 3 epochs of the reference ppo_lag.main() (recorded buffers, shuffles and initial
+@pytest.mark.parametrize("fname", ["ppo_lag_trace.npz", "ppo_lag_trace_humanoid.npz"])
+def test_ppo_lag_main_trace(golden_dir, fname):
+    """Replays the epochs of the reference ppo_lag.main() (recorded buffers, shuffles and initial
     weights) through the oracle: GAE bits, get() standardisation, lambda, per-minibatch losses,
-    early-stop iteration, KL and parameters after every epoch."""
-    z = _load(golden_dir, "ppo_lag_trace.npz")
+    early-stop iteration, KL and parameters after every epoch.  `_humanoid`: the same run at HumanoidVelocity's dims,
+    ActorVCritic(376, 17) (oracle/make_golden_humanoid.py, round 5)."""
+    z = _load(golden_dir, fname)
     epochs = int(z["meta_epochs"])
     pol = _policy_from(z, "init_sd_")
     upd = R.PPOLagUpdater(pol, epochs=epochs)
@@ -111,7 +114,7 @@ def test_ppo_lag_main_trace(golden_dir):
                 "target_value_c": torch.from_numpy(tgt_c.reshape(-1)), "adv_r": sr, "adv_c": sc}
         n_perm = len([k for k in z.files if k.startswith(f"e{e}_perm")])
         perms = [z[f"e{e}_perm{i}"] for i in range(n_perm)]
-        perms += [perms[-1]] * (6 - n_perm)
+        perms += [perms[-1]] * (int(z["meta_cfg_learning_iters"]) - n_perm)
         out = R.ppo_lag_update(pol, upd, data, lag.lagrangian_multiplier, perms,
                                learning_iters=int(z["meta_cfg_learning_iters"]),
                                batch_size=int(z[f"e{e}_batch_size"]), target_kl=float(z["meta_cfg_target_kl"]))
@@ -122,12 +125,13 @@ def test_ppo_lag_main_trace(golden_dir):
         np.testing.assert_allclose(v.numpy(), z[f"final_sd_{k}"], rtol=2e-5, atol=2e-7, err_msg=k)
 
 
-def test_cpo_main_trace(golden_dir):
+@pytest.mark.parametrize("fname", ["cpo_trace.npz", "cpo_trace_humanoid.npz"])
+def test_cpo_main_trace(golden_dir, fname):
     """Replays the reference cpo.main(): FVP known answers, the actor update (CG, case analysis,
-    line search) and the critic fit, epoch by epoch."""
-    z = _load(golden_dir, "cpo_trace.npz")
+    line search) and the critic fit, epoch by epoch.  `_humanoid`: the same run with ActorVCritic(376, 17) (no FVP vectors)."""
+    z = _load(golden_dir, fname)
     # FVP known-answer vectors recorded from the reference's fvp()
-    for i in range(3):
+    for i in range(3 if "fvp_in0" in z.files else 0):
         pol = R.OraclePolicy(60, 8)
         pol.actor.load_state_dict({k[len(f"fvp_sd{i}_"):]: torch.from_numpy(z[k].copy())
                                    for k in z.files if k.startswith(f"fvp_sd{i}_")})
@@ -175,7 +179,8 @@ def test_cpo_main_trace(golden_dir):
                 losses.append(fit.minibatch_step(data["obs"][idx], data["target_value_r"][idx],
                                                  data["target_value_c"][idx]))
         np.testing.assert_allclose(np.asarray(losses), z[f"e{e}_mb_losses"][:, :2], rtol=1e-4, atol=1e-7)
-    assert cases[1] in (0, 1), "epoch 1 of the fixture is an infeasible-recovery case"
+    if fname == "cpo_trace.npz":
+        assert cases[1] in (0, 1), "epoch 1 of the fixture is an infeasible-recovery case"
     for k, v in pol.state_dict().items():
         np.testing.assert_allclose(v.numpy(), z[f"final_sd_{k}"], rtol=1e-3, atol=5e-6, err_msg=k)
 
@@ -191,11 +196,12 @@ def _trace_epoch_inputs(z, e):
     return data, [z[f"e{e}_perm{i}"] for i in range(n_perm)]
 
 
-@pytest.mark.parametrize("algo,upper", [("focops", 2.0), ("cup", 0.2)])
-def test_kl_penalty_family_main_trace(golden_dir, algo, upper):
+@pytest.mark.parametrize("algo,upper,suffix", [("focops", 2.0, ""), ("cup", 0.2, ""), ("focops", 2.0, "_humanoid")])
+def test_kl_penalty_family_main_trace(golden_dir, algo, upper, suffix):
     """Replays the reference focops.main() / cup.main() through the restatement: the [B,1] x [B] broadcast of the
-    KL-penalty losses, the per-sample indicator, CUP's actor-only second stage with its own optimiser clock."""
-    z = _load(golden_dir, f"{algo}_trace.npz")
+    KL-penalty losses, the per-sample indicator, CUP's actor-only second stage with its own optimiser clock.
+    `_humanoid`: focops.main() with ActorVCritic(376, 17)."""
+    z = _load(golden_dir, f"{algo}_trace{suffix}.npz")
     epochs, iters = int(z["meta_epochs"]), int(z["meta_cfg_learning_iters"])
     pol = _policy_from(z, "init_sd_")
     upd = R.KLPenaltyUpdater(pol, epochs=epochs)
