@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE -- tests/golden/*_trace_humanoid.npz: complete runs of the UNMODIFIED reference's main() (ppo_lag, focops,
-cpo) at HumanoidVelocity's dims -- ActorVCritic(376, 17), the shape of the reference's default sweep
+cup, cpo) at HumanoidVelocity's dims -- ActorVCritic(376, 17), the shape of the reference's default sweep
 (safepo/single_agent/benchmark.py:5-22) that the round-5 feature-split kernels serve -- on the seeded host SynthEnv, recorded
 exactly like the 60 / 8 traces of oracle/make_golden.py (same recorder, same keys).
 
@@ -23,6 +23,9 @@ if __name__ == "__main__":
                    args_over={"cost_limit": 1.0, "lagrangian_multiplier_init": 0.5})
     G.golden_trace("focops", "focops_trace_humanoid.npz", num_envs=4, T=48, epochs=2, env_kw=env_kw,
                    cfg_over={"learning_iters": 4, "target_kl": 0.0006},
+                   args_over={"cost_limit": 1.0, "lagrangian_multiplier_init": 0.5})
+    G.golden_trace("cup", "cup_trace_humanoid.npz", num_envs=4, T=48, epochs=2, env_kw=env_kw,
+                   cfg_over={"learning_iters": 4, "target_kl": 0.002},
                    args_over={"cost_limit": 1.0, "lagrangian_multiplier_init": 0.5})
     G.golden_trace("cpo", "cpo_trace_humanoid.npz", num_envs=4, T=48, epochs=2, env_kw=env_kw,
                    cfg_over={"learning_iters": 2, "batch_size": 64}, args_over={"cost_limit": 3.0})

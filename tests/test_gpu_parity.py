@@ -1667,12 +1667,12 @@ def test_sibling_entrypoints_synthetic(dev, tmp_path, algo):
     if algo == "cppo_pid":
         assert float(rows[1]["Train/LagragianMultiplier"]) > 0.0          # cost 4/episode > limit 0.5
 
-@pytest.mark.parametrize("algo,suffix", [("focops", ""), ("cup", ""), ("focops", "_humanoid")])
+@pytest.mark.parametrize("algo,suffix", [("focops", ""), ("cup", ""), ("focops", "_humanoid"), ("cup", "_humanoid")])
 def test_kl_penalty_family_vs_reference_main_trace(dev, golden_dir, algo, suffix):
     """The epochs of the reference focops.main() / cup.main(): same buffers, shuffles and initial weights ->
     per-minibatch losses (critics + the KL-penalty actor loss with its indicator), early-stop iterations of both
-    stages, KL and parameters after every epoch.  `_humanoid` (round 5): focops.main() with ActorVCritic(376, 17), on the
-    feature-split kernel's KL-penalty instantiation."""
+    stages, KL and parameters after every epoch.  `_humanoid` (round 5): focops.main() / cup.main() with ActorVCritic(376, 17), on the
+    feature-split kernel's KL-penalty instantiation (CUP's second stage: its actor-only launch)."""
     from safepo.common.engine import PPOLagEngine, WidePPOLagEngine
     z = np.load(os.path.join(golden_dir, f"{algo}_trace{suffix}.npz"))
     N, T, epochs = int(z["meta_num_envs"]), int(z["meta_T"]), int(z["meta_epochs"])

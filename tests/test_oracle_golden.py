@@ -196,11 +196,12 @@ def _trace_epoch_inputs(z, e):
     return data, [z[f"e{e}_perm{i}"] for i in range(n_perm)]
 
 
-@pytest.mark.parametrize("algo,upper,suffix", [("focops", 2.0, ""), ("cup", 0.2, ""), ("focops", 2.0, "_humanoid")])
+@pytest.mark.parametrize("algo,upper,suffix", [("focops", 2.0, ""), ("cup", 0.2, ""), ("focops", 2.0, "_humanoid"),
+                                               ("cup", 0.2, "_humanoid")])
 def test_kl_penalty_family_main_trace(golden_dir, algo, upper, suffix):
     """Replays the reference focops.main() / cup.main() through the restatement: the [B,1] x [B] broadcast of the
     KL-penalty losses, the per-sample indicator, CUP's actor-only second stage with its own optimiser clock.
-    `_humanoid`: focops.main() with ActorVCritic(376, 17)."""
+    `_humanoid`: focops.main() / cup.main() with ActorVCritic(376, 17)."""
     z = _load(golden_dir, f"{algo}_trace{suffix}.npz")
     epochs, iters = int(z["meta_epochs"]), int(z["meta_cfg_learning_iters"])
     pol = _policy_from(z, "init_sd_")
