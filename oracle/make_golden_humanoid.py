@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE -- tests/golden/*_trace_humanoid.npz: complete runs of the UNMODIFIED reference's main() (ppo_lag, focops,
 cup, cpo) at HumanoidVelocity's dims -- ActorVCritic(376, 17), the shape of the reference's default sweep
 (safepo/single_agent/benchmark.py:5-22) that the round-5 feature-split kernels serve -- on the seeded host SynthEnv, recorded
-exactly like the 60 / 8 traces of oracle/make_golden.py (same recorder, same keys).
+exactly like the 60 / 8 traces of oracle/make_golden.py (same recorder, same keys); plus ppo_lag / cpo at Car-class dims (72 / 2).
 
     python oracle/make_golden_humanoid.py
 """
@@ -27,5 +27,13 @@ if __name__ == "__main__":
     G.golden_trace("cup", "cup_trace_humanoid.npz", num_envs=4, T=48, epochs=2, env_kw=env_kw,
                    cfg_over={"learning_iters": 4, "target_kl": 0.002},
                    args_over={"cost_limit": 1.0, "lagrangian_multiplier_init": 0.5})
+    # Car-class dims of the same sweep (72 observations, 2 actions: the 128-wide instantiation of the LDS-resident kernels;
+    # CPO's actor on the wide kernels with the critic fit on the persistent two-critic kernel)
+    car_kw = dict(obs_dim=72, act_dim=2, p_term=0.03, p_cost=0.3, trunc_len=20)
+    G.golden_trace("ppo_lag", "ppo_lag_trace_car.npz", num_envs=4, T=48, epochs=2, env_kw=car_kw,
+                   cfg_over={"learning_iters": 4, "target_kl": 0.004},
+                   args_over={"cost_limit": 1.0, "lagrangian_multiplier_init": 0.5})
+    G.golden_trace("cpo", "cpo_trace_car.npz", num_envs=4, T=48, epochs=2, env_kw=car_kw,
+                   cfg_over={"learning_iters": 2, "batch_size": 64}, args_over={"cost_limit": 3.0})
     G.golden_trace("cpo", "cpo_trace_humanoid.npz", num_envs=4, T=48, epochs=2, env_kw=env_kw,
                    cfg_over={"learning_iters": 2, "batch_size": 64}, args_over={"cost_limit": 3.0})

@@ -467,14 +467,15 @@ def _load_epoch_into_engine(z, e, eng, dev):
     b.ptr = T
 
 
-@pytest.mark.parametrize("fname", ["ppo_lag_trace.npz", "ppo_lag_trace_humanoid.npz"])
+@pytest.mark.parametrize("fname", ["ppo_lag_trace.npz", "ppo_lag_trace_humanoid.npz", "ppo_lag_trace_car.npz"])
 def test_ppo_lag_update_vs_reference_main_trace(dev, golden_dir, fname):
     """The epochs of the reference ppo_lag.main(): same buffers, same shuffles, same initial weights ->
     per-minibatch losses, early-stop iteration, KL and parameters after every epoch.  Trajectory quantities are gated by
     the drift envelope (tests/envelope.py): T32 = the values the reference itself recorded, T64 = the oracle replaying
     the same recorded inputs in float64; the HIP path may be at most 3x as far from T64 as the reference is.
     `_humanoid` (round 5): the reference's own run with ActorVCritic(376, 17) (oracle/make_golden_humanoid.py) -- the update runs
-    on the persistent feature-split kernel (csrc/update_ks.hip) behind WidePPOLagEngine."""
+    on the persistent feature-split kernel (csrc/update_ks.hip) behind WidePPOLagEngine.  `_car`: the same at Car-class dims (72 / 2: the
+    128-wide instantiation of the three-workgroup kernel)."""
     import envelope as E
     from safepo.common.engine import PPOLagEngine, WidePPOLagEngine
     z = np.load(os.path.join(golden_dir, fname))
@@ -1074,7 +1075,7 @@ def test_cpo_trace_epochs_one_by_one_under_the_fp64_yardstick(dev, golden_dir):
     print("cpo trace, per-epoch relative distance to float64:", {k: f"{v:.2e}" for k, v in worst.items()})
 
 
-@pytest.mark.parametrize("algo", ["cpo", "pcpo", "natural_pg", "trpo", "rcpo", "trpo_lag", "cpo_humanoid"])
+@pytest.mark.parametrize("algo", ["cpo", "pcpo", "natural_pg", "trpo", "rcpo", "trpo_lag", "cpo_humanoid", "cpo_car"])
 def test_second_order_family_traces_under_the_fp64_yardstick(dev, golden_dir, algo):
     """every trust-region script of the reference under the gate cpo got in round 4, critic fit included.
     The reference's main() trace is replayed with the ACTOR reset to the reference's recorded parameters at every epoch (its
@@ -1091,15 +1092,16 @@ def test_second_order_family_traces_under_the_fp64_yardstick(dev, golden_dir, al
     from safepo.common.lagrange import Lagrange
     # "cpo_humanoid" (round 5): the reference's cpo.main() with ActorVCritic(376, 17) -- WideCPOEngine: surrogate gradients,
     # Fisher-vector products and line search on the wide kernels, the critic fit on the feature-split kernel
-    fname = "cpo_trace_humanoid.npz" if algo == "cpo_humanoid" else f"{algo}_trace.npz"
-    algo = "cpo" if algo == "cpo_humanoid" else algo
+    # "cpo_car": the same at Car-class dims (72 / 2): wide actor step, critic fit on the persistent two-critic kernel (KIN = 128)
+    fname = {"cpo_humanoid": "cpo_trace_humanoid.npz", "cpo_car": "cpo_trace_car.npz"}.get(algo, f"{algo}_trace.npz")
+    algo = "cpo" if algo.startswith("cpo_") else algo
     z = np.load(os.path.join(golden_dir, fname))
     N, T, epochs = int(z["meta_num_envs"]), int(z["meta_T"]), int(z["meta_epochs"])
     iters = int(z["meta_cfg_learning_iters"])
     pol, eng = _cpo_engine(z, "init_sd_", dev, N, T, {"learning_iters": iters, "batch_size": int(z["e0_batch_size"]),
                                                        "target_kl": float(z["meta_cfg_target_kl"])})
     wide = type(eng).__name__ == "WideCPOEngine"
-    assert wide == fname.endswith("_humanoid.npz")
+    assert wide == fname.endswith(("_humanoid.npz", "_car.npz"))
     # wide: tests/envelope.py::adam_noise_directions; max-norm floor 5e-6 of the critics' scale after Adam steps behind a 376-wide
     # first layer (an MFMA accumulator chains 94 sequential products where the reference's blocked sgemm sums 16-wide partials:
     # tests/test_gpu_wide_dims.py::_theta_floor measures the same factor of ~5 on the maximum with the L2 distance inside 3 x)
