@@ -73,7 +73,7 @@ def adam_noise_directions(dh, d32, frac=1e-4, factor=30.0, slack=10.0):
     """Elements on which THE REFERENCE ITSELF is an outlier against float64: Adam divides by sqrt(v) + eps, so an element whose
     gradient is of the size of eps (1e-8) turns rounding noise of the gradient into steps of either sign -- in the reference's
     float32 as much as anywhere (measured on the reference's own ppo_lag.main() at 376 / 17, tests/golden/ppo_lag_trace_humanoid:
-    ONE of 74 947 parameters, a first-layer weight of the cost critic, sits 4.7e-6 from float64 in the reference's recorded
+    ONE of 86 116 parameters, a first-layer weight of the cost critic, sits 4.7e-6 from float64 in the reference's recorded
     run after 6 steps where every other element sits ~1e-8; the launch-per-layer HIP path lands 9.2e-6 away on it, the feature-split
     kernel 2.8e-5).  Such an element says nothing about rounding quality, and one of them can dominate an L2 norm.  They are
     identified by the reference's behaviour alone -- at most `frac` of the elements, each at least `factor` x the RMS distance of

@@ -57,3 +57,36 @@ def test_reference_trace_is_inside_its_own_envelope(golden_dir):
         assert np.array_equal(r32["losses"][e], z[f"e{e}_mb_losses"])
     d = np.abs(ref_final - r64["theta_final"])
     assert 0 < d.max() < 1e-6
+
+
+def test_adam_noise_directions_are_singled_out_by_the_reference_and_defects_still_fail(golden_dir):
+    """tests/envelope.py::adam_noise_directions on the reference's own run at HumanoidVelocity's dims
+    (ppo_lag_trace_humanoid.npz, round 5): after the first epoch ONE of the 86 116 parameters -- a first-layer weight of the
+    cost critic whose gradient is of the size of Adam's eps -- sits ~5e-6 from the float64 replay in the reference's recorded
+    parameters while the rest sit ~1e-8; the gate finds exactly such elements from the reference's behaviour, lets another
+    implementation be up to 10 x as far on THEM, and keeps its power everywhere else: a real defect (every element moved by
+    5e-7, far below the noise direction's own excursion) still fails with the option on."""
+    import os
+    z = np.load(os.path.join(golden_dir, "ppo_lag_trace_humanoid.npz"))
+    r64 = E.replay_ppo_lag_trace(z, torch.float64)
+    names = [k[len("init_sd_"):] for k in z.files if k.startswith("init_sd_")]
+    f32 = np.concatenate([z["e1_sd_before_" + k].reshape(-1) for k in names]).astype(np.float64)     # the reference's own float32 run
+    f64 = r64["theta_before"][1]
+    d32 = np.abs(f32 - f64)
+    mask, _ = E.adam_noise_directions(d32, d32)
+    assert 1 <= mask.sum() <= 9 and d32[mask].min() > 25 * np.sqrt(np.mean(d32[~mask] ** 2))
+    worst = int(np.argmax(d32))
+    assert mask[worst] and d32[worst] > 1e-6 > 50 * np.median(d32)
+    # another correct implementation: the reference's values, 6 x further out on the noise direction only
+    other = f32.copy()
+    other[worst] = f64[worst] + 6.0 * (f32[worst] - f64[worst])
+    assert E.theta_envelope(other, f32, f64)[0] > 1.0                                   # the plain gate: one element sinks the L2 norm
+    assert E.theta_envelope(other, f32, f64, noise_directions=True)[0] <= 1.0
+    other[worst] = f64[worst] + 12.0 * (f32[worst] - f64[worst])                         # ... but not arbitrarily far
+    assert E.theta_envelope(other, f32, f64, noise_directions=True)[0] == float("inf")
+    # a defect of 5e-7 on every element is an order of magnitude SMALLER than the noise direction's excursion and still fails
+    rng = np.random.default_rng(0)
+    defect = f32 + 5e-7 * rng.choice([-1.0, 1.0], size=f32.size)
+    assert E.theta_envelope(defect, f32, f64, noise_directions=True)[0] > 1.0
+    ratio, _ = E.theta_envelope(f32, f32, f64, noise_directions=True)
+    assert ratio < 0.5
