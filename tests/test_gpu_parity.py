@@ -1075,7 +1075,7 @@ def test_cpo_trace_epochs_one_by_one_under_the_fp64_yardstick(dev, golden_dir):
     print("cpo trace, per-epoch relative distance to float64:", {k: f"{v:.2e}" for k, v in worst.items()})
 
 
-@pytest.mark.parametrize("algo", ["cpo", "pcpo", "natural_pg", "trpo", "rcpo", "trpo_lag", "cpo_humanoid", "cpo_car"])
+@pytest.mark.parametrize("algo", ["cpo", "pcpo", "natural_pg", "trpo", "rcpo", "trpo_lag", "cpo_humanoid", "cpo_car", "cpo_humanoid_b128"])
 def test_second_order_family_traces_under_the_fp64_yardstick(dev, golden_dir, algo):
     """every trust-region script of the reference under the gate cpo got in round 4, critic fit included.
     The reference's main() trace is replayed with the ACTOR reset to the reference's recorded parameters at every epoch (its
@@ -1093,7 +1093,9 @@ def test_second_order_family_traces_under_the_fp64_yardstick(dev, golden_dir, al
     # "cpo_humanoid" (round 5): the reference's cpo.main() with ActorVCritic(376, 17) -- WideCPOEngine: surrogate gradients,
     # Fisher-vector products and line search on the wide kernels, the critic fit on the feature-split kernel
     # "cpo_car": the same at Car-class dims (72 / 2): wide actor step, critic fit on the persistent two-critic kernel (KIN = 128)
-    fname = {"cpo_humanoid": "cpo_trace_humanoid.npz", "cpo_car": "cpo_trace_car.npz"}.get(algo, f"{algo}_trace.npz")
+    # "cpo_humanoid_b128": 376 / 17 with the reference's default 128-row critic-fit minibatches (the kernel's two-chunk path)
+    fname = {"cpo_humanoid": "cpo_trace_humanoid.npz", "cpo_car": "cpo_trace_car.npz",
+             "cpo_humanoid_b128": "cpo_trace_humanoid_b128.npz"}.get(algo, f"{algo}_trace.npz")
     algo = "cpo" if algo.startswith("cpo_") else algo
     z = np.load(os.path.join(golden_dir, fname))
     N, T, epochs = int(z["meta_num_envs"]), int(z["meta_T"]), int(z["meta_epochs"])
@@ -1101,7 +1103,7 @@ def test_second_order_family_traces_under_the_fp64_yardstick(dev, golden_dir, al
     pol, eng = _cpo_engine(z, "init_sd_", dev, N, T, {"learning_iters": iters, "batch_size": int(z["e0_batch_size"]),
                                                        "target_kl": float(z["meta_cfg_target_kl"])})
     wide = type(eng).__name__ == "WideCPOEngine"
-    assert wide == fname.endswith(("_humanoid.npz", "_car.npz"))
+    assert wide == fname.endswith(("_humanoid.npz", "_car.npz", "_b128.npz"))
     # wide: tests/envelope.py::adam_noise_directions; max-norm floor 5e-6 of the critics' scale after Adam steps behind a 376-wide
     # first layer (an MFMA accumulator chains 94 sequential products where the reference's blocked sgemm sums 16-wide partials:
     # tests/test_gpu_wide_dims.py::_theta_floor measures the same factor of ~5 on the maximum with the L2 distance inside 3 x)

@@ -125,7 +125,7 @@ def test_ppo_lag_main_trace(golden_dir, fname):
         np.testing.assert_allclose(v.numpy(), z[f"final_sd_{k}"], rtol=2e-5, atol=2e-7, err_msg=k)
 
 
-@pytest.mark.parametrize("fname", ["cpo_trace.npz", "cpo_trace_humanoid.npz", "cpo_trace_car.npz"])
+@pytest.mark.parametrize("fname", ["cpo_trace.npz", "cpo_trace_humanoid.npz", "cpo_trace_car.npz", "cpo_trace_humanoid_b128.npz"])
 def test_cpo_main_trace(golden_dir, fname):
     """Replays the reference cpo.main(): FVP known answers, the actor update (CG, case analysis,
     line search) and the critic fit, epoch by epoch.  `_humanoid`: the same run with ActorVCritic(376, 17) (no FVP vectors)."""
