@@ -35,6 +35,12 @@ if __name__ == "__main__":
                    args_over={"cost_limit": 1.0, "lagrangian_multiplier_init": 0.5})
     G.golden_trace("cpo", "cpo_trace_car.npz", num_envs=4, T=48, epochs=2, env_kw=car_kw,
                    cfg_over={"learning_iters": 2, "batch_size": 64}, args_over={"cost_limit": 3.0})
+    # two more of the sweep's second-order scripts (smaller runs: 2 envs): PCPO's projection step and TRPO-Lagrangian
+    G.golden_trace("pcpo", "pcpo_trace_humanoid.npz", num_envs=2, T=48, epochs=2, env_kw=env_kw,
+                   cfg_over={"learning_iters": 2, "batch_size": 64}, args_over={"cost_limit": 3.0})
+    G.golden_trace("trpo_lag", "trpo_lag_trace_humanoid.npz", num_envs=2, T=48, epochs=2, env_kw=env_kw,
+                   cfg_over={"learning_iters": 2, "batch_size": 64},
+                   args_over={"cost_limit": 1.0, "lagrangian_multiplier_init": 0.5})
     # the reference's default critic-fit minibatch of 128 rows (192 rows per epoch = one full + one 64-row minibatch): the
     # feature-split critic fit's two-chunk path
     G.golden_trace("cpo", "cpo_trace_humanoid_b128.npz", num_envs=4, T=48, epochs=2, env_kw=env_kw,

@@ -1075,7 +1075,8 @@ def test_cpo_trace_epochs_one_by_one_under_the_fp64_yardstick(dev, golden_dir):
     print("cpo trace, per-epoch relative distance to float64:", {k: f"{v:.2e}" for k, v in worst.items()})
 
 
-@pytest.mark.parametrize("algo", ["cpo", "pcpo", "natural_pg", "trpo", "rcpo", "trpo_lag", "cpo_humanoid", "cpo_car", "cpo_humanoid_b128"])
+@pytest.mark.parametrize("algo", ["cpo", "pcpo", "natural_pg", "trpo", "rcpo", "trpo_lag", "cpo_humanoid", "cpo_car", "cpo_humanoid_b128",
+                                  "pcpo_humanoid", "trpo_lag_humanoid"])
 def test_second_order_family_traces_under_the_fp64_yardstick(dev, golden_dir, algo):
     """every trust-region script of the reference under the gate cpo got in round 4, critic fit included.
     The reference's main() trace is replayed with the ACTOR reset to the reference's recorded parameters at every epoch (its
@@ -1094,9 +1095,11 @@ def test_second_order_family_traces_under_the_fp64_yardstick(dev, golden_dir, al
     # Fisher-vector products and line search on the wide kernels, the critic fit on the feature-split kernel
     # "cpo_car": the same at Car-class dims (72 / 2): wide actor step, critic fit on the persistent two-critic kernel (KIN = 128)
     # "cpo_humanoid_b128": 376 / 17 with the reference's default 128-row critic-fit minibatches (the kernel's two-chunk path)
-    fname = {"cpo_humanoid": "cpo_trace_humanoid.npz", "cpo_car": "cpo_trace_car.npz",
-             "cpo_humanoid_b128": "cpo_trace_humanoid_b128.npz"}.get(algo, f"{algo}_trace.npz")
-    algo = "cpo" if algo.startswith("cpo_") else algo
+    # "pcpo_humanoid", "trpo_lag_humanoid": pcpo.main() / trpo_lag.main() at 376 / 17 (projection step; line search + multiplier)
+    algo, fname = {"cpo_humanoid": ("cpo", "cpo_trace_humanoid.npz"), "cpo_car": ("cpo", "cpo_trace_car.npz"),
+                   "cpo_humanoid_b128": ("cpo", "cpo_trace_humanoid_b128.npz"),
+                   "pcpo_humanoid": ("pcpo", "pcpo_trace_humanoid.npz"),
+                   "trpo_lag_humanoid": ("trpo_lag", "trpo_lag_trace_humanoid.npz")}.get(algo, (algo, f"{algo}_trace.npz"))
     z = np.load(os.path.join(golden_dir, fname))
     N, T, epochs = int(z["meta_num_envs"]), int(z["meta_T"]), int(z["meta_epochs"])
     iters = int(z["meta_cfg_learning_iters"])

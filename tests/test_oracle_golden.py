@@ -415,12 +415,16 @@ def test_lagrangian_trust_region_traces_multiplier_and_mix(golden_dir, algo):
     assert len(set(round(l, 6) for l in lams)) == len(lams) and all(l > 0 for l in lams)
 
 
-@pytest.mark.parametrize("algo,line_search", [("natural_pg", False), ("trpo", True), ("rcpo", False), ("trpo_lag", True)])
+@pytest.mark.parametrize("algo,line_search", [("natural_pg", False), ("trpo", True), ("rcpo", False), ("trpo_lag", True),
+                                              ("trpo_lag_humanoid", True)])
 def test_trust_region_restatement_vs_reference_main_trace(golden_dir, algo, line_search):
     """R.trust_region_policy_update (natural_pg.py:350-381, trpo.py:366-428; rcpo / trpo_lag on the mixed advantage) against
     the reference mains' own traces, every epoch from the reference's recorded state: curvature, step length, norms, the KL
-    and the loss it logs, the accepted line-search candidate and the actor after the step."""
-    z = _load(golden_dir, f"{algo}_trace.npz")
+    and the loss it logs, the accepted line-search candidate and the actor after the step.  `_humanoid`: trpo_lag.main() with
+    ActorVCritic(376, 17)."""
+    fname = f"{algo}_trace.npz" if not algo.endswith("_humanoid") else f"{algo[:-9]}_trace_humanoid.npz"
+    algo = algo[:-9] if algo.endswith("_humanoid") else algo
+    z = _load(golden_dir, fname)
     tkl = float(z["meta_cfg_target_kl"])
     for e in range(int(z["meta_epochs"])):
         pol = _policy_from(z, f"e{e}_sd_before_")
@@ -442,10 +446,11 @@ def test_trust_region_restatement_vs_reference_main_trace(golden_dir, algo, line
             np.testing.assert_allclose(v.numpy(), z[f"e{e}_actor_after_{k}"], rtol=1e-3, atol=2e-6, err_msg=f"epoch {e} {k}")
 
 
-def test_pcpo_restatement_vs_reference_main_trace(golden_dir):
+@pytest.mark.parametrize("fname", ["pcpo_trace.npz", "pcpo_trace_humanoid.npz"])
+def test_pcpo_restatement_vs_reference_main_trace(golden_dir, fname):
     """R.pcpo_policy_update (pcpo.py:352-470) against the reference's pcpo.main() trace, every epoch from the recorded state
-    (incl. the epoch whose line search backtracks six times)."""
-    z = _load(golden_dir, "pcpo_trace.npz")
+    (incl. the epoch whose line search backtracks six times).  `_humanoid`: pcpo.main() with ActorVCritic(376, 17)."""
+    z = _load(golden_dir, fname)
     tkl = float(z["meta_cfg_target_kl"])
     steps = []
     for e in range(int(z["meta_epochs"])):
@@ -464,7 +469,8 @@ def test_pcpo_restatement_vs_reference_main_trace(golden_dir):
         assert out["loss_r_before"] + out["loss_c_before"] == pytest.approx(float(z[f"e{e}_Loss_Loss_actor"]), rel=1e-4, abs=1e-7)
         for k, v in pol.actor.state_dict().items():
             np.testing.assert_allclose(v.numpy(), z[f"e{e}_actor_after_{k}"], rtol=1e-3, atol=2e-6, err_msg=f"epoch {e} {k}")
-    assert max(steps) > 1
+    if fname == "pcpo_trace.npz":
+        assert max(steps) > 1
 
 
 def test_running_mean_std_restatement_vs_independent_two_pass():
