@@ -5,12 +5,8 @@ evaluated in the persistent update kernel (spo_update_iter_ex, SPO_ACTOR_LOSS_KL
 """
 from __future__ import annotations
 
-import os
-import sys
-import time
-
 from safepo.single_agent import _first_order
-from safepo.utils.config import single_agent_args
+from safepo.utils.config import run_as_script
 
 default_cfg = {
     'hidden_sizes': [64, 64],
@@ -27,17 +23,4 @@ def main(args, cfg_env=None):
 
 
 if __name__ == "__main__":
-    args, cfg_env = single_agent_args()
-    relpath = time.strftime("%Y-%m-%d-%H-%M-%S")
-    subfolder = "-".join(["seed", str(args.seed).zfill(3)])
-    relpath = "-".join([subfolder, relpath])
-    algo = os.path.basename(__file__).split(".")[0]
-    args.log_dir = os.path.join(args.log_dir, args.experiment, args.task, algo, relpath)
-    if not args.write_terminal:
-        os.makedirs(args.log_dir, exist_ok=True)
-        with open(os.path.join(args.log_dir, f"seed{args.seed}_terminal.log"), "w", encoding="utf-8") as f_out, \
-                open(os.path.join(args.log_dir, f"seed{args.seed}_error.log"), "w", encoding="utf-8") as f_err:
-            sys.stdout, sys.stderr = f_out, f_err
-            main(args, cfg_env)
-    else:
-        main(args, cfg_env)
+    run_as_script(main, __file__)

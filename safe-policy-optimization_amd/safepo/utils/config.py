@@ -125,3 +125,25 @@ def multi_agent_args(algo: str, argv=None):
     relpath = "-".join(["-".join(["seed", str(args.seed).zfill(3)]), time.strftime("%Y-%m-%d-%H-%M-%S")])
     cfg_train["log_dir"] = "../runs/" + args.experiment + "/" + args.task + "/" + algo + "/" + relpath
     return args, {}, cfg_train
+
+
+def run_as_script(main, script_file):
+    """The `if __name__ == "__main__":` block that every single-agent script of the reference repeats verbatim (e.g.
+    ppo_lag.py:392-409): parse the reference's flags, build log_dir = <log_dir>/<experiment>/<task>/<algo>/seed-XXX-<time>, and run
+    main() with stdout / stderr redirected into seed<N>_terminal.log / seed<N>_error.log unless --write-terminal is set."""
+    import os
+    import sys
+    import time
+    args, cfg_env = single_agent_args()
+    relpath = time.strftime("%Y-%m-%d-%H-%M-%S")
+    subfolder = "-".join(["seed", str(args.seed).zfill(3)])
+    relpath = "-".join([subfolder, relpath])
+    algo = os.path.basename(script_file).split(".")[0]
+    args.log_dir = os.path.join(args.log_dir, args.experiment, args.task, algo, relpath)
+    if not args.write_terminal:
+        os.makedirs(args.log_dir, exist_ok=True)
+        with open(os.path.join(args.log_dir, f"seed{args.seed}_terminal.log"), "w", encoding="utf-8") as f_out, \
+                open(os.path.join(args.log_dir, f"seed{args.seed}_error.log"), "w", encoding="utf-8") as f_err:
+            sys.stdout, sys.stderr = f_out, f_err
+            return main(args, cfg_env)
+    return main(args, cfg_env)
