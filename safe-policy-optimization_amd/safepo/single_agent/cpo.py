@@ -27,7 +27,7 @@ from safepo.common.env import make_sa_mujoco_env
 from safepo.common.logger import EpochLogger
 from safepo.common.model import ActorVCritic
 from safepo.parallel import dp_epoch_stat, init_from_env, require_equal_shards, shard_envs
-from safepo.utils.config import isaac_gym_map, single_agent_args
+from safepo.utils.config import isaac_gym_map, run_as_script
 
 STEP_FRACTION = 0.8
 CPO_SEARCHING_STEPS = 15
