@@ -202,6 +202,13 @@ int spo_ppo_lag_update_iter(float* theta, float* adam_m, float* adam_v, int64_t 
  * stream of the current device when all != 0.  hipFree synchronises the device -- not for the hot path. */
 int spo_update_scratch_release(void* stream_or_null, int all);
 
+/* Round 6: the ROW-SPLIT form of the persistent update (csrc/update_rs.hip) -- the rows of every minibatch divided over R
+ * co-XCD workgroups per network (R = 2 up to 64 rows, 4 up to 128), partial weight gradients all-reduced in one hand-off through
+ * the XCD's L2, replicated Adam.  spo_ppo_lag_update_iter (n_nets 3; ppo_lag.py:297-336) and spo_critic_fit_iter (n_nets 2;
+ * cpo.py:534-571) run on it where this returns 1 (obs_dim <= 64, act_dim <= 16, batch <= 64 / 128) unless SPO_UPDATE_FORM=2
+ * (the main + helper form) or 0 (the four-wave form) is set in the environment.  Same arguments, same results to rounding. */
+int spo_update_rs_supported(int obs_dim, int act_dim, int batch, int n_nets);
+
 /* Measurement aid: counters of the main + helper update kernel summed over the launches of this process since the last reset
  * (out4_host, host array): {minibatch steps run, steps whose speculative update turned out clipped and was redone, steps
  * clipped under the conservative protocol, steps run under the conservative protocol}.  Synchronises the device. */

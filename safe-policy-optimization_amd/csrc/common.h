@@ -44,4 +44,6 @@ inline int hip_check(hipError_t e, const char* what) {
 
 // exchange scratch of the feature-split kernels (update_ks.hip), freed together with the update kernels' by spo_update_scratch_release
 int ks_scratch_release(int dev, void* stream_or_null, int all);
+// ... and of the row-split kernel (update_rs.hip)
+int rs_scratch_release(int dev, void* stream_or_null, int all);
 }  // namespace spo

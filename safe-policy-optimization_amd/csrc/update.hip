@@ -22,6 +22,7 @@
 #include "mlp_mfma.h"
 #include "adam.h"
 #include "../../include/safepo_hip.h"
+#include "update_rs.h"
 
 namespace {
 using namespace spo;
@@ -2919,13 +2920,16 @@ extern "C" int spo_update_scratch_release(void* stream_or_null, int all) {
   }
   freed += split_local_release(dev, stream_or_null, all);
   freed += spo::ks_scratch_release(dev, stream_or_null, all);
+  freed += spo::rs_scratch_release(dev, stream_or_null, all);
   return freed;
 }
 namespace {
 using namespace spo;
-// SPO_UPDATE_FORM: 0 = four-wave kernel everywhere, 2 = main + helper waves (default) where that form applies (persistent PPO step, clipped-surrogate loss, no in-kernel cross-rank exchange, batch <= 64, obs <= 64).
+// SPO_UPDATE_FORM: 0 = four-wave kernel everywhere, 2 = main + helper waves where that form applies (persistent PPO step,
+// clipped-surrogate loss, no in-kernel cross-rank exchange, batch <= 64, obs <= 64), 3 (default, round 6) = the row-split kernel
+// (update_rs.hip) for the one-GPU PPO-Lagrangian step and the critic fit where spo_update_rs_supported, form 2 elsewhere.
 inline int update_form() {
-  static const int v = [] { const char* e = getenv("SPO_UPDATE_FORM"); return e ? atoi(e) : 2; }();
+  static const int v = [] { const char* e = getenv("SPO_UPDATE_FORM"); return e ? atoi(e) : 3; }();
   return v;
 }
 
@@ -2961,7 +2965,7 @@ int launch_update_h(const UpdArgs& a_in, int blocks, hipStream_t st) {
 template <bool PERSIST, int AMODE = 0, int XR = 0>
 int launch_update(const UpdArgs& a, int blocks, hipStream_t st) {
   const int kin = pick_kin(a.cfg.obs_dim);
-  if (PERSIST && AMODE == 0 && XR == 0 && kin <= 64 && a.cfg.batch <= 64 && update_form() == 2) {
+  if (PERSIST && AMODE == 0 && XR == 0 && kin <= 64 && a.cfg.batch <= 64 && update_form() >= 2) {
     if (a.prof && kin == 64) return launch_update_h<64, true>(a, blocks, st);
     if (kin == 16) return launch_update_h<16>(a, blocks, st);
     if (kin == 32) return launch_update_h<32>(a, blocks, st);
@@ -3016,6 +3020,12 @@ extern "C" int spo_ppo_lag_update_iter(float* theta, float* adam_m, float* adam_
   SPO_REQUIRE(M > 0 && adam_step_host >= 0, "update_iter: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   if (int rc = spo::hip_check(hipMemsetAsync(sync_ws, 0, 64, st), "hipMemsetAsync(sync_ws)")) return rc;
+  if (update_form() >= 3 && spo_update_rs_supported(cfg_host->obs_dim, cfg_host->act_dim, cfg_host->batch, 3)) {
+    if (int rc = spo::rs_update_launch(theta, adam_m, adam_v, adam_step_host, obs, act, logp_old, target_r, target_c, adv, perm, M,
+                                       cfg_host, 3, nullptr, losses_out, sync_ws, g_prof_buf, stream)) return rc;
+    SPO_LAUNCH_CHECK("spo_ppo_lag_update_iter (row-split)");
+    return 0;
+  }
   UpdArgs a{};
   a.theta = theta; a.adam_m = adam_m; a.adam_v = adam_v;
   a.obs = obs; a.act = act; a.logp_old = logp_old; a.tgt_r = target_r; a.tgt_c = target_c; a.adv = adv;
@@ -3042,6 +3052,12 @@ extern "C" int spo_critic_fit_iter(float* theta, float* adam_m, float* adam_v, i
   SPO_REQUIRE(M > 0 && adam_step_host >= 0, "critic_fit_iter: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   if (int rc = spo::hip_check(hipMemsetAsync(sync_ws, 0, 64, st), "hipMemsetAsync(sync_ws)")) return rc;
+  if (update_form() >= 3 && spo_update_rs_supported(cfg_host->obs_dim, cfg_host->act_dim, cfg_host->batch, 2)) {
+    if (int rc = spo::rs_update_launch(theta, adam_m, adam_v, adam_step_host, obs, nullptr, nullptr, target_r, target_c, nullptr,
+                                       perm, M, cfg_host, 2, stale_sq_io, losses_out, sync_ws, nullptr, stream)) return rc;
+    SPO_LAUNCH_CHECK("spo_critic_fit_iter (row-split)");
+    return 0;
+  }
   UpdArgs a{};
   a.theta = theta; a.adam_m = adam_m; a.adam_v = adam_v;
   a.obs = obs; a.tgt_r = target_r; a.tgt_c = target_c; a.perm = perm; a.M = M; a.cfg = *cfg_host;
@@ -3263,7 +3279,7 @@ extern "C" int spo_ppo_lag_update_iter_dp(float* theta, float* adam_m, float* ad
   const int form = xr_form(world);
   const bool a2a = form == SPO_XR_FORM_HELPER_A2A;
   a.xr_helper_rd = a2a ? 0 : 1;
-  if ((a2a || form == SPO_XR_FORM_HELPER_DOUBLING) && kin <= 64 && cfg_host->batch <= 64 && update_form() == 2) {
+  if ((a2a || form == SPO_XR_FORM_HELPER_DOUBLING) && kin <= 64 && cfg_host->batch <= 64 && update_form() >= 2) {
     // main + helper form, exchange on the helper waves
 #define SPO_H_XR(K, D) (world == 2 ? launch_update_h<K, false, 2, D>(a, 3, st) : world == 4 ? launch_update_h<K, false, 4, D>(a, 3, st) \
                                                                                                : launch_update_h<K, false, 8, D>(a, 3, st))
@@ -3304,7 +3320,7 @@ extern "C" int spo_critic_fit_iter_dp(float* theta, float* adam_m, float* adam_v
   const int kin = pick_kin(cfg_host->obs_dim);
   const int form = xr_form(world);          // (the all-to-all form has no two-network instantiation: the helpers' doubling stands in)
   a.xr_helper_rd = 1;
-  if ((form == SPO_XR_FORM_HELPER_A2A || form == SPO_XR_FORM_HELPER_DOUBLING) && kin <= 64 && cfg_host->batch <= 64 && update_form() == 2) {
+  if ((form == SPO_XR_FORM_HELPER_A2A || form == SPO_XR_FORM_HELPER_DOUBLING) && kin <= 64 && cfg_host->batch <= 64 && update_form() >= 2) {
     // main + helper form with recursive doubling on the helper waves (see spo_ppo_lag_update_iter_dp)
 #define SPO_H_XR(K) (world == 2 ? launch_update_h<K, false, 2, 2>(a, 2, st) : world == 4 ? launch_update_h<K, false, 4, 2>(a, 2, st) \
                                                                                             : launch_update_h<K, false, 8, 2>(a, 2, st))
@@ -3392,7 +3408,7 @@ extern "C" int spo_critic_fit_iter_split(float* theta0, float* adam_m0, float* a
   // SPO_CPO_SPLIT_FORM=h (opt-in, round 5): the main + helper kernel with the exchange on the helper waves (ppo_update_h_split_kernel:
   // 15.98 us per 128-row step); default: the four-wave kernel of rounds 3-4, one exchange of the whole gradient per step (14.05 us)
   static const bool split_h = [] { const char* e = getenv("SPO_CPO_SPLIT_FORM"); return e && !strcmp(e, "h"); }();
-  if (split_h && kin <= 64 && cfg_host->batch <= 64 && update_form() == 2) {
+  if (split_h && kin <= 64 && cfg_host->batch <= 64 && update_form() >= 2) {
     if (int rc = h_scratch_for(st, &a.backup, &a.slots, 0)) return rc;
     if (int rc = h_scratch_for(st, &b.backup, &b.slots, 1)) return rc;
     static const int spec_env = [] { const char* e = getenv("SPO_UPDATE_SPEC"); return e ? atoi(e) : 1; }();

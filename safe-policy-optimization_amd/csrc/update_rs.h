@@ -1,0 +1,13 @@
+// Internal interface of the row-split persistent update kernel (update_rs.hip), called from update.hip's entry points.
+#pragma once
+#include <cstdint>
+#include "../../include/safepo_hip.h"
+
+namespace spo {
+// n_nets 3: one learning iteration of the PPO-Lagrangian step (clipped surrogate); 2: the critic fit (act / logp_old / adv unused).
+// prof: optional device [3][12] u64 cycle accumulators (instrumented instantiation, obs_dim in (32, 64], batch <= 64).
+int rs_update_launch(float* theta, float* adam_m, float* adam_v, int64_t adam_step_host, const float* obs, const float* act,
+                     const float* logp_old, const float* target_r, const float* target_c, const float* adv, const int32_t* perm,
+                     int64_t M, const spo_ppo_cfg* cfg_host, int n_nets, float* stale_sq_io, float* losses_out, void* sync_ws,
+                     unsigned long long* prof, void* stream);
+}  // namespace spo

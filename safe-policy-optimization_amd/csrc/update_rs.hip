@@ -1,0 +1,900 @@
+// Row-split persistent minibatch update (round 6), gfx950.
+//
+// The persistent kernels of update.hip keep one network on ONE CU for a whole learning iteration (ppo_lag.py:297-336, cpo.py:534-571):
+// every cycle of the step -- forward, backward, weight gradients, Adam -- is issued by that CU's four SIMDs, and the two waves of a
+// SIMD (matrix stream, optimiser stream) ADD (tools/probes/mfma_valu_overlap.hip).  Here the ROWS of a minibatch are divided over
+// R workgroups per network (R = 2 for 64-row minibatches, R = 4 for the 128-row critic fit), all on one XCD:
+//
+//   grid = n_nets networks x R row groups, one persistent workgroup of 6 waves each, all co-resident;
+//   workgroup (n, h) keeps a full replica of network n in LDS and takes rows [32 h, 32 h + 32) of every minibatch;
+//   waves 2, 3 -- alone on their SIMDs (waves i and i + 4 of a workgroup share a SIMD) -- are the COLUMN waves: 16 batch columns
+//   each through forward, loss and backward (transposed MFMA chaining, mlp_mfma.h), nothing else on their SIMD;
+//   waves 0, 1, 4, 5 (two per SIMD on the other two SIMDs) are the OPTIMISER waves: the weight-gradient products over the
+//   workgroup's 32 rows straight into the accumulator layout that owns the Adam moments (no staging of gradients), the exchange,
+//   L2 terms, the joint clip and Adam;
+//   the R partial gradients of a network are ALL-REDUCED IN ONE HAND-OFF through the XCD's L2: every optimiser lane stores its
+//   16-byte groups into a private slot of each peer (plain stores when a placement census finds the workgroups on one XCD,
+//   write-through otherwise; NaN sentinel instead of tags, slots reset by their consumer, two parities: update_ks.hip) and adds
+//   own + peer (R = 2: commutative; R = 4: (own + h^1) + (h^2 + h^3), the same tree in every workgroup), so the R replicas continue
+//   from identical bits and run the identical Adam -- no second hand-off to return parameters;
+//   the joint clip_grad_norm_ (ppo_lag.py:325) sums tagged ||g||^2 granules, one per optimiser wave, of the workgroups with the
+//   same row-group index; layer 2 / 3 gradients travel while the column waves are still in the backward pass, only layer 1's
+//   exchange is exposed.
+//
+// Per step and row group (b = workgroup barrier; both roles run the same sequence):
+//   column : x^T | b1 | L1, h1^T | b2 | L2, h2^T | b3 | L3, loss, dO, dZ2, images | b4 | gather s+1, dZ1, image | b5 | settle s+1
+//   optimis: ...W1 | b1 | Adam W2 | b2 | Adam W3, b3, log_std | b3 | loss log | b4 | dW3, dW2 -> peers | b5 | dW1 -> peers, poll,
+//            sum, L2 terms, norm share -> granule, poll norms, clip coefficient, Adam W1 ...
+//
+// Arithmetic per element is that of ppo_update_kernel (same MFMA chaining, loss, Adam); the batch sum of a weight gradient is
+// formed as (rows 0..31) + (rows 32..63) instead of one chain (rounding-level difference: tests at 1e-5 on the first steps and the
+// fp64 drift envelopes at full size).  One GPU; clipped-surrogate actor loss; obs_dim <= 64, act_dim <= 16, batch <= 32 R.
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include "common.h"
+#include "mlp_mfma.h"
+#include "adam.h"
+#include "../../include/safepo_hip.h"
+#include "update_rs.h"
+
+namespace {
+using namespace spo;
+
+constexpr int LDC = 32 + 4;                      // [feature][batch] LDS row stride (floats): 32 batch columns per workgroup
+constexpr int RS_NS = 16;                        // exchange slots (16-byte groups per lane) per (destination, source): NT1 + 8 <= 12 used
+constexpr int RS_MAX_R = 4;
+constexpr unsigned RS_SPIN_LIMIT = 1u << 22;
+constexpr int RS_NPHASE = 12;
+
+template <int KIN>
+struct RsLds {                                   // floats
+  using L = NetLds<KIN>;
+  static constexpr int LS = L::SIZE;             // log_std mirror (16)
+  static constexpr int XT = LS + 16;             // two x^T images (double-buffered across steps)
+  static constexpr int H1T = XT + 2 * KIN * LDC;
+  static constexpr int H2T = H1T + HID * LDC;
+  static constexpr int DZ2T = H2T + HID * LDC;
+  static constexpr int DZ1T = DZ2T + HID * LDC;
+  static constexpr int DOT = DZ1T + HID * LDC;
+  static constexpr int RED = DOT + OUTP * LDC;
+  static constexpr int SIZE = RED + 128;
+  static_assert(SIZE * 4 <= 163840, "160 KB of LDS");
+};
+// RED: [0..1] loss partials of the column waves, [16 + 16 c + a] d(log_std) partials of column wave c, [88 + w] sum p^2 of
+//      optimiser wave w, [96] placement census, [97] dead flag (a poll timed out: stop waiting), [100 + ...] spare
+
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+struct RsArgs {
+  float* theta; float* adam_m; float* adam_v;
+  const float* obs; const float* act; const float* logp_old; const float* tgt_r; const float* tgt_c; const float* adv;
+  const int32_t* perm; int64_t M;
+  spo_ppo_cfg cfg;
+  float* losses;                       // [nsteps][3]
+  float* zbuf;                         // exchange slots (all sentinel at launch)
+  unsigned long long* gran;            // [2 parities][RS_MAX_R row groups][3 nets][4 waves] {tag, value} + the placement census
+  int* err;
+  double pow_b1, pow_b2;
+  unsigned tag_base;                   // tags of this launch: tag_base + step + 1 (never reused: no clearing between launches)
+  int n_nets, first_net;               // 3 / 0: a PPO-Lagrangian step; 2 / 0: the critic fit
+  float* stale_io;                     // critic fit: ||actor.grad||^2 that the joint clip still sees and rescales (cpo.py:557), in / out
+  int force_safe;                      // SPO_RS_SAFE=1: write-through exchange stores whatever the placement (tests)
+  unsigned long long* prof;            // optional [3][RS_NPHASE] cycle accumulators (instrumented instantiation)
+};
+constexpr size_t rs_z_bytes(int R) { return (size_t)2 * 3 * R * R * RS_NS * 4096; }
+constexpr int RS_GRAN_WORDS = 2 * RS_MAX_R * 3 * 4;
+constexpr int RS_CENSUS_WORDS = 3 * RS_MAX_R;
+
+__device__ __forceinline__ float pin(float v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ int pin(int v) { asm volatile("" : "+v"(v)); return v; }
+
+template <int NT1>
+struct RsCol {                         // per-column inputs of one minibatch, prefetched one step ahead (raw loads; settled at pick-up)
+  f4 x[NT1];
+  f4 actv;
+  float t0, t1;                        // critic: target ; actor: logp_old, adv
+};
+
+// FAST: every workgroup of the launch sits on one XCD (checked by the kernel), stores of the exchange stay plain
+template <int KIN, int R, bool FAST, bool PROF>
+__device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
+  using L = NetLds<KIN>;
+  using S = RsLds<KIN>;
+  constexpr int NT1 = KIN / 16;
+  unsigned long long pacc[RS_NPHASE] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = 0;
+#define RS_STAMP(i)                                            \
+  if (PROF) {                                                  \
+    const unsigned long long _t = __builtin_readcyclecounter(); \
+    pacc[i] += _t - tprev; tprev = _t;                         \
+  }
+  const int wg = (int)(blockIdx.x >> 3);
+  const int netl = wg / R, hf = wg - netl * R, net = a.first_net + netl;
+  const int tid = threadIdx.x, lane = tid & 63, j_ = lane & 15, q_ = lane >> 4;
+  const int wave6 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_col = (wave6 == 2 || wave6 == 3);
+  const int D = a.cfg.obs_dim, A = a.cfg.act_dim, B = a.cfg.batch;
+  const NetGeom g = net_geom(D, A, net);
+  const bool is_actor = (net == 2);
+  const int OUT = g.OUT;
+  const int ls_off = g.off - A;                  // actor only
+  float* const red = lds + S::RED;
+  const int64_t nsteps = (a.M + B - 1) / B;
+
+  stage_net<KIN>(a.theta, g, lds, tid, 384);
+  if (tid < 16) lds[S::LS + tid] = (is_actor && tid < A) ? a.theta[ls_off + tid] : 0.f;
+  if (tid < 128) red[tid] = 0.f;
+  __syncthreads();
+
+  if (is_col) {
+    // =========================================================================================================== column waves
+    const int c = wave6 - 2;
+    int j = j_, q = q_;
+    int lcol = 16 * c + j_;                      // column inside the workgroup's 32
+    const int gcol = 32 * hf + 16 * c + j_;      // column inside the minibatch
+#define RS_REIDX { j = pin(j_); q = pin(q_); lcol = 16 * c + j; }
+    const float clip_lo = 1.f - a.cfg.clip, clip_hi = 1.f + a.cfg.clip;
+    const float* tgt = (net == 0) ? a.tgt_r : a.tgt_c;
+    auto perm_pos = [&](int64_t s_) -> int64_t {
+      const int64_t base_ = s_ * B;
+      const int64_t rem_ = a.M - base_;
+      const int nc_ = (int)(rem_ < B ? rem_ : B);
+      return base_ + (gcol < nc_ ? gcol : 0);
+    };
+    auto fetch = [&](int64_t smp, RsCol<NT1>& cd) {
+      load_obs_tiles_raw<KIN>(a.obs + smp * D, D, q, cd.x);
+      if (!is_actor) {
+        cd.t0 = tgt[smp]; cd.t1 = 0.f; cd.actv = f4{0.f, 0.f, 0.f, 0.f};
+      } else {
+        cd.t0 = a.logp_old[smp]; cd.t1 = a.adv[smp];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ai = 4 * q + r;
+          cd.actv[r] = a.act[smp * A + (ai < A ? ai : 0)];
+        }
+      }
+    };
+    auto settle = [&](RsCol<NT1>& cd) {
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cd.x[nt][e] = pin(cd.x[nt][e]);
+      mask_obs_tiles<KIN>(D, q, cd.x);
+      cd.t0 = pin(cd.t0);
+      if (is_actor) {
+        cd.t1 = pin(cd.t1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ai = 4 * q + r;
+          const float av = pin(cd.actv[r]);
+          cd.actv[r] = ai < A ? av : 0.f;
+        }
+      }
+    };
+    RsCol<NT1> nxt;
+    int smp1 = 0;
+    fetch((int64_t)a.perm[perm_pos(0)], nxt);
+    if (nsteps > 1) smp1 = a.perm[perm_pos(1)];
+    if (PROF) tprev = __builtin_readcyclecounter();
+
+    for (int64_t s = 0; s < nsteps; ++s) {
+      const int64_t base = s * B;
+      const int64_t rem = a.M - base;
+      const int ncols = (int)(rem < B ? rem : B);
+      const float inv_n = 1.f / (float)ncols;
+      const bool cv = gcol < ncols;
+      RsCol<NT1> cur;
+      f4 h1[4], h2[4];
+      RS_REIDX
+      cur = nxt;
+      settle(cur);
+      const int smp_next = pin(smp1);
+      const int64_t pos2 = (s + 2 < nsteps) ? perm_pos(s + 2) : 0;
+      {
+        float* const xt = lds + S::XT + (int)(s & 1) * KIN * LDC;
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xt[(16 * nt + 4 * q + e) * LDC + lcol] = cur.x[nt][e];
+      }
+      RS_STAMP(0)                                                        // settle + x^T
+      __syncthreads();                                                    // b1: W1 / b1 of the previous step's update in place
+      RS_STAMP(1)
+      {
+        RS_REIDX
+        layer_hidden<NT1, true>(lds + L::W1, L::LD1, lds + L::B1, cur.x, h1, j, q);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lds[S::H1T + (16 * mt + 4 * q + r) * LDC + lcol] = h1[mt][r];
+      }
+      RS_STAMP(2)                                                        // L1
+      __syncthreads();                                                    // b2: W2 / b2 in place
+      RS_STAMP(3)
+      {
+        RS_REIDX
+        layer_hidden<4, true>(lds + L::W2, LDH, lds + L::B2, h1, h2, j, q);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lds[S::H2T + (16 * mt + 4 * q + r) * LDC + lcol] = h2[mt][r];
+      }
+      RS_STAMP(4)                                                        // L2
+      __syncthreads();                                                    // b3: W3 / b3 / log_std in place
+      RS_STAMP(5)
+      f4 dz2[4];
+      {
+        RS_REIDX
+        const f4 o = layer_out(lds + L::W3, lds + L::B3, h2, j, q);
+        float ivar[4], lsd[4], amask[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ai = 4 * q + r;
+          const bool on = is_actor && ai < A;
+          const float lsv = on ? lds[S::LS + ai] : 0.f;
+          const float sdv = __expf(lsv);
+          amask[r] = on ? 1.f : 0.f;
+          ivar[r] = __builtin_amdgcn_rcpf(sdv * sdv);
+          lsd[r] = on ? lsv + LOG_SQRT_2PI : 0.f;
+        }
+        float w3c[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) w3c[r][mt] = lds[L::W3 + (4 * q + r) * LDH + 16 * mt + j];
+        f4 dO = {0.f, 0.f, 0.f, 0.f}, dls = {0.f, 0.f, 0.f, 0.f};
+        float lsum = 0.f;
+        if (!is_actor) {
+          // mse_loss(critic(obs), target)  (ppo_lag.py:307-309)
+          const float diff = o[0] - cur.t0;
+          const float lm = (q == 0 && cv) ? 1.f : 0.f;
+          lsum = lm * diff * diff;
+          dO[0] = lm * (2.f * diff * inv_n);
+        } else {
+          float lp = 0.f, dif[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            dif[r] = cur.actv[r] - o[r];
+            lp += -(dif[r] * dif[r]) * (0.5f * ivar[r]) - lsd[r];
+          }
+          lp = quad_row_sum(lp);
+          const float adv = cur.t1;
+          const float ratio = __expf(lp - cur.t0);                        // ppo_lag.py:317
+          const float rc = fminf(fmaxf(ratio, clip_lo), clip_hi);         // torch.clamp
+          const float s1 = ratio * adv, s2 = rc * adv;
+          const bool inr = (ratio >= clip_lo) && (ratio <= clip_hi);
+          float gr;                                                       // backward of torch.min(s1, s2): ties split the gradient
+          if (s1 < s2) gr = adv;
+          else if (s1 > s2) gr = inr ? adv : 0.f;
+          else gr = 0.5f * adv + (inr ? 0.5f * adv : 0.f);
+          const float dlp = cv ? -(gr * ratio) * inv_n : 0.f;             // loss_pi = -mean(min(...))
+          lsum = ((q == 0 && cv) ? 1.f : 0.f) * fminf(s1, s2);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float z = dif[r] * ivar[r];
+            dO[r] = dlp * z;
+            dls[r] = (dlp * amask[r]) * (dif[r] * z - 1.f);
+          }
+        }
+        // loss / d(log_std) partials of this wave's 16 columns: they travel with the layer-2 / 3 gradients
+        {
+          const float ls = wave_sum_lane63(lsum);
+          if (lane == 63) red[c] = ls;
+          if (is_actor) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float t = row_sum_lane15(dls[r]);
+              if (j == 15) red[16 + 16 * c + 4 * q + r] = t;
+            }
+          }
+        }
+        // dO -> dZ2
+        f4 acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma4(w3c[r][mt], dO[r], acc[mt]);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dz2[mt][r] = acc[mt][r] * fmaf(-h2[mt][r], h2[mt][r], 1.f);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lds[S::DZ2T + (16 * mt + 4 * q + r) * LDC + lcol] = dz2[mt][r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds[S::DOT + (4 * q + r) * LDC + lcol] = dO[r];
+      }
+      RS_STAMP(6)                                                        // L3, loss, dO -> dZ2, images
+      __syncthreads();                                                    // b4: h1^T, h2^T, dZ2^T, dO^T complete
+      RS_STAMP(7)
+      {
+        RS_REIDX
+        // rows of the next minibatch, the index of the one after it: in flight under the last backward product
+        if (s + 1 < nsteps) fetch((int64_t)smp_next, nxt);
+        if (s + 2 < nsteps) smp1 = a.perm[pos2];
+        f4 acc[4], dz1[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = f4{0.f, 0.f, 0.f, 0.f};
+        float w2c[2][4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) w2c[0][r][mt] = lds[L::W2 + (4 * q + r) * LDH + 16 * mt + j];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          if (nt + 1 < 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int mt = 0; mt < 4; ++mt)
+                w2c[(nt + 1) & 1][r][mt] = lds[L::W2 + (16 * (nt + 1) + 4 * q + r) * LDH + 16 * mt + j];
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma4(w2c[nt & 1][r][mt], dz2[nt][r], acc[mt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dz1[mt][r] = acc[mt][r] * fmaf(-h1[mt][r], h1[mt][r], 1.f);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lds[S::DZ1T + (16 * mt + 4 * q + r) * LDC + lcol] = dz1[mt][r];
+      }
+      RS_STAMP(8)                                                        // dZ2 -> dZ1, image
+      __syncthreads();                                                    // b5: dZ1^T complete
+      RS_STAMP(9)
+    }
+    if (PROF && a.prof && lane == 0 && c == 0 && wg == a.n_nets * R - 1)
+      for (int i = 0; i < RS_NPHASE; ++i) a.prof[i] = pacc[i];
+    __syncthreads();                                                      // after the loop: the last update is complete
+#undef RS_REIDX
+    return;
+  }
+
+  // ============================================================================================================= optimiser waves
+  const int ow = wave6 < 2 ? wave6 : wave6 - 2;                           // 0 .. 3: rows [16 ow, 16 ow + 16) of the weight-gradient tiles
+  const int ol = ow * 64 + lane;                                          // 0 .. 255
+  int j = j_, q = q_, orow = 16 * ow + 4 * q_;
+#define RS_REIDX { j = pin(j_); q = pin(q_); orow = 16 * ow + 4 * q; }
+  float* const st_m = a.adam_m; float* const st_v = a.adam_v;
+  f4 mW1[NT1], vW1[NT1], mW2[4], vW2[4], mW3, vW3, mls, vls;
+  float mb1, vb1, mb2, vb2, mb3 = 0.f, vb3 = 0.f;
+  const bool own_b = (q_ == 0);
+  const bool own_b3 = (ow == 0 && q_ == 0 && j_ < OUT);
+  const bool own_ls = is_actor && ow == 0 && j_ == 0;
+#pragma unroll
+  for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * nt + j;
+      const int idx = g.w1() + (orow + r) * D + i;
+      mW1[nt][r] = i < D ? a.adam_m[idx] : 0.f;
+      vW1[nt][r] = i < D ? a.adam_v[idx] : 0.f;
+    }
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int idx = g.w2() + (orow + r) * HID + 16 * nt + j;
+      mW2[nt][r] = a.adam_m[idx];
+      vW2[nt][r] = a.adam_v[idx];
+    }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = 4 * q + r;
+    const int idx = g.w3() + o * HID + 16 * ow + j;
+    mW3[r] = o < OUT ? a.adam_m[idx] : 0.f;
+    vW3[r] = o < OUT ? a.adam_v[idx] : 0.f;
+    mls[r] = (is_actor && o < A) ? a.adam_m[ls_off + o] : 0.f;
+    vls[r] = (is_actor && o < A) ? a.adam_v[ls_off + o] : 0.f;
+  }
+  mb1 = a.adam_m[g.b1() + 16 * ow + j]; vb1 = a.adam_v[g.b1() + 16 * ow + j];
+  mb2 = a.adam_m[g.b2() + 16 * ow + j]; vb2 = a.adam_v[g.b2() + 16 * ow + j];
+  if (j < OUT) { mb3 = a.adam_m[g.b3() + j]; vb3 = a.adam_v[g.b3() + j]; }
+
+  const float b1c = a.cfg.beta1, b2c = a.cfg.beta2, eps = a.cfg.adam_eps;
+  double pw1 = a.pow_b1, pw2 = a.pow_b2;
+  const float lr = is_actor ? a.cfg.lr_actor : a.cfg.lr_critic;
+  const float l2 = (!is_actor && a.cfg.use_critic_norm) ? a.cfg.l2_coef : 0.f;
+  const float l2x2 = 2.f * l2;
+  const float vcoef = (net == 0 && a.cfg.use_value_coefficient) ? 2.f : 1.f;
+  float stale_sq = a.stale_io ? *a.stale_io : 0.f;
+  volatile float* const dead = red + 97;
+
+  // ---- exchange transport (update_ks.hip): bare floats, 16-byte buffer loads / stores, NaN sentinel
+  const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc(a.zbuf, 0, (int)rs_z_bytes(R), 0x00020000);
+  const unsigned zvoff = (unsigned)ol * 16u;
+  auto zstore = [&](u4 w, unsigned off) {                          // (the cache policy is an immediate)
+    if constexpr (FAST) __builtin_amdgcn_raw_buffer_store_b128(w, zrsrc, zvoff, off, 0);
+    else __builtin_amdgcn_raw_buffer_store_b128(w, zrsrc, zvoff, off, 16);
+  };
+  auto gstore = [&](unsigned long long* dst, unsigned long long w) {
+    if constexpr (FAST) __hip_atomic_store(dst, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(dst, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // slot row of (parity, destination row group, source row group, k): 256 lanes x 16 bytes
+  auto slot = [&](int par, int dst, int src, int k) -> unsigned {
+    return (unsigned)(((((par * 3 + net) * R + dst) * R + src) * RS_NS + k)) * 4096u;
+  };
+  const u4 sentinel = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+  // push NF groups to every peer (slots k0 ..), no branch between the stores
+#define RS_PUSH(V, NF, K0, PAR)                                                                        \
+  {                                                                                                    \
+    _Pragma("unroll") for (int d_ = 1; d_ < R; ++d_)                                                   \
+      _Pragma("unroll") for (int k_ = 0; k_ < (NF); ++k_) {                                            \
+        u4 w_;                                                                                         \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) w_[e_] = __float_as_uint((V)[k_][e_]);        \
+        zstore(w_, slot((PAR), hf ^ d_, hf, (K0) + k_));                                               \
+      }                                                                                                \
+  }
+  // poll the NF groups of peer h ^ d for d in [D0, D1), put the sentinel back; ACC += sum of those peers (D1 - D0 <= 2)
+#define RS_POLL(ACC, NF, K0, PAR, D0, D1, PROFSLOT)                                                    \
+  {                                                                                                    \
+    u4 zw_[(D1) - (D0)][NF];                                                                           \
+    unsigned spins_ = 0;                                                                               \
+    for (;;) {                                                                                         \
+      _Pragma("unroll") for (int d_ = (D0); d_ < (D1); ++d_)                                           \
+        _Pragma("unroll") for (int k_ = 0; k_ < (NF); ++k_)                                            \
+          zw_[d_ - (D0)][k_] = __builtin_amdgcn_raw_buffer_load_b128(zrsrc, zvoff, slot((PAR), hf, hf ^ d_, (K0) + k_), 16); \
+      bool ok_ = true;                                                                                 \
+      _Pragma("unroll") for (int d_ = 0; d_ < (D1) - (D0); ++d_)                                       \
+        _Pragma("unroll") for (int k_ = 0; k_ < (NF); ++k_)                                            \
+          _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) ok_ = ok_ && (zw_[d_][k_][e_] != 0xFFFFFFFFu); \
+      if (ok_) break;                                                                                  \
+      if (*dead != 0.f) break;                                                                         \
+      if (++spins_ > RS_SPIN_LIMIT) { *a.err = 1; *dead = 1.f; break; }   /* bounded, and sticky: never hang the GPU */ \
+      __builtin_amdgcn_s_sleep(1);                                                                     \
+    }                                                                                                  \
+    if (PROF && (PROFSLOT) >= 0) pacc[(PROFSLOT) < 0 ? 0 : (PROFSLOT)] += spins_;                      \
+    _Pragma("unroll") for (int d_ = (D0); d_ < (D1); ++d_)                                             \
+      _Pragma("unroll") for (int k_ = 0; k_ < (NF); ++k_) zstore(sentinel, slot((PAR), hf, hf ^ d_, (K0) + k_)); \
+    _Pragma("unroll") for (int k_ = 0; k_ < (NF); ++k_)                                                \
+      _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                               \
+        if constexpr ((D1) - (D0) == 1) (ACC)[k_][e_] = (ACC)[k_][e_] + __uint_as_float(zw_[0][k_][e_]); \
+        else (ACC)[k_][e_] = (ACC)[k_][e_] + (__uint_as_float(zw_[0][k_][e_]) + __uint_as_float(zw_[((D1) - (D0)) - 1][k_][e_])); \
+      }                                                                                                \
+  }
+  // all-reduce: own + peer (R = 2), (own + h^1) + (h^2 + h^3) (R = 4: the same tree in every workgroup, every node commutative)
+#define RS_POLL_SUM(V, NF, K0, PAR, PROFSLOT)                                                          \
+  {                                                                                                    \
+    RS_POLL(V, NF, K0, PAR, 1, 2, PROFSLOT)                                                            \
+    if constexpr (R == 4) RS_POLL(V, NF, K0, PAR, 2, 4, PROFSLOT)                                      \
+  }
+
+#define RS_ADAM(ADDR, G, M, V)                                                             \
+  {                                                                                        \
+    const AdamOut o_ = adam1(lds[ADDR], (G), (M), (V), b1c, b2c, eps, step_size, inv_bc2s); \
+    (M) = o_.m; (V) = o_.v; lds[ADDR] = o_.p;                                              \
+  }
+
+  // step 0 has nothing to wait for: its forward runs on the weights staged at launch
+  __syncthreads();                                                        // b1 of step 0
+  __syncthreads();                                                        // b2
+  __syncthreads();                                                        // b3
+  if (PROF) tprev = __builtin_readcyclecounter();
+  float last_loss = 0.f;
+  for (int64_t s = 0; s < nsteps; ++s) {
+    const int64_t base = s * B;
+    const int64_t rem = a.M - base;
+    const int ncols = (int)(rem < B ? rem : B);
+    const float inv_n = 1.f / (float)ncols;
+    const unsigned tag = a.tag_base + (unsigned)s + 1u;
+    const int par = (int)(s & 1);
+    unsigned long long* const grow = a.gran + ((size_t)par * RS_MAX_R + hf) * 12;   // [parity][row group][network][wave]
+    f4 gA[7];                                                             // W2 tiles, W3 tile, {db2, db3, loss partial, -}, d(log_std)
+    f4 gB[NT1 + 1];                                                       // W1 tiles, {db1, -, -, -}
+    __syncthreads();                                                      // b4: h1^T, h2^T, dZ2^T, dO^T complete
+    RS_STAMP(0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the resets of the previous step are acknowledged by the L2
+    {
+      // ---- dW2, dW3 over this workgroup's 32 rows; db2, db3
+      RS_REIDX
+      f4 az2[2];
+#pragma unroll
+      for (int r4 = 0; r4 < 2; ++r4)
+        az2[r4] = *reinterpret_cast<const f4*>(lds + S::DZ2T + (16 * ow + j) * LDC + 16 * r4 + 4 * q);
+      f4 bh[2][4];
+#pragma unroll
+      for (int r4 = 0; r4 < 2; ++r4)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          bh[r4][nt] = *reinterpret_cast<const f4*>(lds + S::H1T + (16 * nt + j) * LDC + 16 * r4 + 4 * q);
+      f4 az3[2], b3[2];
+#pragma unroll
+      for (int r4 = 0; r4 < 2; ++r4) {
+        az3[r4] = *reinterpret_cast<const f4*>(lds + S::DOT + j * LDC + 16 * r4 + 4 * q);
+        b3[r4] = *reinterpret_cast<const f4*>(lds + S::H2T + (16 * ow + j) * LDC + 16 * r4 + 4 * q);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) gA[nt] = f4{0.f, 0.f, 0.f, 0.f};
+      f4 w3a = {0.f, 0.f, 0.f, 0.f}, w3b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r4 = 0; r4 < 2; ++r4)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) gA[nt] = mfma4(az2[r4][e], bh[r4][nt][e], gA[nt]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        w3a = mfma4(az3[0][e], b3[0][e], w3a);
+        w3b = mfma4(az3[1][e], b3[1][e], w3b);
+      }
+      gA[4] = w3a + w3b;
+      float rs2 = 0.f, rs3 = 0.f;
+#pragma unroll
+      for (int r4 = 0; r4 < 2; ++r4) {
+        rs2 += (az2[r4][0] + az2[r4][1]) + (az2[r4][2] + az2[r4][3]);
+        rs3 += (az3[r4][0] + az3[r4][1]) + (az3[r4][2] + az3[r4][3]);
+      }
+      gA[5] = f4{quad_row_sum(rs2), quad_row_sum(rs3), red[0] + red[1], 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gA[6][r] = red[16 + 4 * q + r] + red[32 + 4 * q + r];
+      RS_PUSH(gA, 7, NT1 + 1, par)
+    }
+    RS_STAMP(1)                                                            // dW2, dW3, stores
+    __syncthreads();                                                      // b5: dZ1^T complete
+    RS_STAMP(2)
+    {
+      // ---- dW1, db1
+      RS_REIDX
+      const float* const xt = lds + S::XT + par * KIN * LDC;
+      f4 az1[2];
+#pragma unroll
+      for (int r4 = 0; r4 < 2; ++r4)
+        az1[r4] = *reinterpret_cast<const f4*>(lds + S::DZ1T + (16 * ow + j) * LDC + 16 * r4 + 4 * q);
+      f4 bx[2][NT1];
+#pragma unroll
+      for (int r4 = 0; r4 < 2; ++r4)
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt)
+          bx[r4][nt] = *reinterpret_cast<const f4*>(xt + (16 * nt + j) * LDC + 16 * r4 + 4 * q);
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt) gB[nt] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r4 = 0; r4 < 2; ++r4)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int nt = 0; nt < NT1; ++nt) gB[nt] = mfma4(az1[r4][e], bx[r4][nt][e], gB[nt]);
+      float rs1 = 0.f;
+#pragma unroll
+      for (int r4 = 0; r4 < 2; ++r4) rs1 += (az1[r4][0] + az1[r4][1]) + (az1[r4][2] + az1[r4][3]);
+      gB[NT1] = f4{quad_row_sum(rs1), 0.f, 0.f, 0.f};
+      RS_PUSH(gB, NT1 + 1, 0, par)
+    }
+    RS_STAMP(3)                                                            // dW1, stores
+    // ---- the peers' partials: layers 2 / 3 have been travelling since b4, layer 1 is the exposed hand-off
+    RS_POLL_SUM(gA, 7, NT1 + 1, par, 10)
+    RS_POLL_SUM(gB, NT1 + 1, 0, par, 11)
+    RS_STAMP(4)                                                            // polls + sums
+    // ---- L2 regulariser of the critics (weights AND biases, ppo_lag.py:310-314), norm shares
+    float gsq = 0.f, psq = 0.f;
+    float gb1, gb2, gb3 = 0.f;
+    {
+      RS_REIDX
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                                       // pad columns hold p == 0, g == 0
+          const float p_ = lds[L::W1 + (orow + r) * L::LD1 + 16 * nt + j];
+          const float g_ = vcoef * fmaf(l2x2, p_, gB[nt][r]);
+          gB[nt][r] = g_; gsq = fmaf(g_, g_, gsq); psq = fmaf(p_, p_, psq);
+        }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p_ = lds[L::W2 + (orow + r) * LDH + 16 * nt + j];
+          const float g_ = vcoef * fmaf(l2x2, p_, gA[nt][r]);
+          gA[nt][r] = g_; gsq = fmaf(g_, g_, gsq); psq = fmaf(p_, p_, psq);
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {                                         // pad rows hold p == 0, g == 0
+        const float p_ = lds[L::W3 + (4 * q + r) * LDH + 16 * ow + j];
+        const float g_ = vcoef * fmaf(l2x2, p_, gA[4][r]);
+        gA[4][r] = g_; gsq = fmaf(g_, g_, gsq); psq = fmaf(p_, p_, psq);
+      }
+      {
+        // biases are replicated over q (all replicas run the same Adam, q == 0 counts towards the norms)
+        const float pb1 = lds[L::B1 + 16 * ow + j], pb2 = lds[L::B2 + 16 * ow + j];
+        gb1 = vcoef * fmaf(l2x2, pb1, gB[NT1][0]);
+        gb2 = vcoef * fmaf(l2x2, pb2, gA[5][0]);
+        if (own_b) { gsq = fmaf(gb1, gb1, gsq); psq = fmaf(pb1, pb1, psq); gsq = fmaf(gb2, gb2, gsq); psq = fmaf(pb2, pb2, psq); }
+        if (ow == 0) {
+          const float pb3 = lds[L::B3 + j];
+          gb3 = vcoef * fmaf(l2x2, pb3, gA[5][1]);
+          if (q == 0) { gsq = fmaf(gb3, gb3, gsq); psq = fmaf(pb3, pb3, psq); }
+          if (own_ls) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gsq = fmaf(gA[6][r], gA[6][r], gsq);   // 0 on pad rows
+          }
+        }
+      }
+      const float wg_sq = wave_sum_lane63(gsq), wp_sq = wave_sum_lane63(psq);
+      if (lane == 63) {
+        gstore(grow + 4 * netl + ow, ((unsigned long long)tag << 32) | __float_as_uint(wg_sq));
+        red[88 + ow] = wp_sq;                                              // sum p^2 shares: read after the next barrier
+      }
+    }
+    const float loss_data = gA[5][2] * inv_n;
+    pw1 *= (double)b1c; pw2 *= (double)b2c;
+    float step_size, inv_bc2s;
+    adam_scalars(lr, pw1, pw2, step_size, inv_bc2s);
+    RS_STAMP(5)                                                            // L2 terms, norm share out
+    // ---- joint clip_grad_norm_ over all networks (ppo_lag.py:325): the granules of the workgroups with my row-group index
+    float coef;
+    {
+      float mine = 0.f;
+      const int ngr = 4 * a.n_nets;
+      if (lane < ngr) {                                                     // lane k polls granule k (network k / 4, wave k % 4)
+        unsigned long long v = __hip_atomic_load(grow + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned sp2 = 0;
+        while ((unsigned)(v >> 32) != tag) {
+          if (*dead != 0.f) break;
+          if (++sp2 > RS_SPIN_LIMIT) { *a.err = 1; *dead = 1.f; break; }
+          __builtin_amdgcn_s_sleep(1);
+          v = __hip_atomic_load(grow + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        mine = __uint_as_float((unsigned)v);
+      }
+      float total_sq = stale_sq;
+      for (int kk = 0; kk < ngr; ++kk) total_sq += __shfl(mine, kk);        // fixed order: identical in every wave and workgroup
+      const float norm = sqrtf(total_sq);
+      coef = a.cfg.max_grad_norm / (norm + 1e-6f);                        // clip_grad_norm_ (torch): eps 1e-6
+      coef = coef > 1.f ? 1.f : coef;
+      stale_sq *= coef * coef;
+    }
+    RS_STAMP(6)                                                            // poll norms, coefficient
+    {
+      // ---- Adam (torch.optim.Adam, ppo_lag.py:104-117): layer 1 first -- the next forward starts with it
+      RS_REIDX
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          RS_ADAM(L::W1 + (orow + r) * L::LD1 + 16 * nt + j, gB[nt][r] * coef, mW1[nt][r], vW1[nt][r])
+      RS_ADAM(L::B1 + 16 * ow + j, gb1 * coef, mb1, vb1)
+    }
+    RS_STAMP(7)                                                            // Adam W1
+    if (s + 1 < nsteps) __syncthreads();                                  // b1 of step s + 1
+    {
+      RS_REIDX
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          RS_ADAM(L::W2 + (orow + r) * LDH + 16 * nt + j, gA[nt][r] * coef, mW2[nt][r], vW2[nt][r])
+      RS_ADAM(L::B2 + 16 * ow + j, gb2 * coef, mb2, vb2)
+    }
+    RS_STAMP(8)                                                            // wait b1 + Adam W2
+    if (s + 1 < nsteps) __syncthreads();                                  // b2 of step s + 1
+    {
+      RS_REIDX
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        RS_ADAM(L::W3 + (4 * q + r) * LDH + 16 * ow + j, gA[4][r] * coef, mW3[r], vW3[r])
+      if (ow == 0) {
+        RS_ADAM(L::B3 + j, gb3 * coef, mb3, vb3)
+        if (is_actor) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ai = 4 * q + r;
+            RS_ADAM(S::LS + ai, gA[6][r] * coef, mls[r], vls[r])             // (replicated over j: identical values)
+          }
+        }
+      }
+      if (ow == 0 && lane == 0 && hf == 0 && s + 1 < nsteps) {
+        const float pp = (red[88] + red[89]) + (red[90] + red[91]);        // (written before b1)
+        a.losses[s * 3 + net] = is_actor ? -loss_data : loss_data + l2 * pp;
+      }
+      last_loss = loss_data;                                               // the last step has no barrier before this point: below
+    }
+    RS_STAMP(9)                                                            // wait b2 + Adam W3 ...
+    if (s + 1 < nsteps) __syncthreads();                                  // b3 of step s + 1
+  }
+  if (PROF && a.prof && lane == 0 && ow == 0 && wg == a.n_nets * R - 1)
+    for (int i = 0; i < RS_NPHASE; ++i) a.prof[RS_NPHASE + i] = pacc[i];
+  __syncthreads();                                                        // after the loop: orders the final image before the write-back
+  if (ow == 0 && lane == 0 && hf == 0 && nsteps > 0) {
+    const float pp = (red[88] + red[89]) + (red[90] + red[91]);
+    a.losses[(nsteps - 1) * 3 + net] = is_actor ? -last_loss : last_loss + l2 * pp;
+  }
+#undef RS_ADAM
+#undef RS_PUSH
+#undef RS_POLL_SUM
+#undef RS_POLL
+  // ---- write back (row group 0 of every network; a launch that timed out leaves theta and the optimiser state untouched)
+  if (hf == 0 && *dead == 0.f) {
+    RS_REIDX
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * nt + j;
+        if (i < D) {
+          const int idx = g.w1() + (orow + r) * D + i;
+          a.theta[idx] = lds[L::W1 + (orow + r) * L::LD1 + i];
+          st_m[idx] = mW1[nt][r]; st_v[idx] = vW1[nt][r];
+        }
+      }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int idx = g.w2() + (orow + r) * HID + 16 * nt + j;
+        a.theta[idx] = lds[L::W2 + (orow + r) * LDH + 16 * nt + j];
+        st_m[idx] = mW2[nt][r]; st_v[idx] = vW2[nt][r];
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = 4 * q + r;
+      if (o < OUT) {
+        const int idx = g.w3() + o * HID + 16 * ow + j;
+        a.theta[idx] = lds[L::W3 + o * LDH + 16 * ow + j];
+        st_m[idx] = mW3[r]; st_v[idx] = vW3[r];
+      }
+      if (own_ls && o < A) {
+        a.theta[ls_off + o] = lds[S::LS + o];
+        st_m[ls_off + o] = mls[r]; st_v[ls_off + o] = vls[r];
+      }
+    }
+    if (own_b) {
+      const int o = 16 * ow + j;
+      a.theta[g.b1() + o] = lds[L::B1 + o]; st_m[g.b1() + o] = mb1; st_v[g.b1() + o] = vb1;
+      a.theta[g.b2() + o] = lds[L::B2 + o]; st_m[g.b2() + o] = mb2; st_v[g.b2() + o] = vb2;
+    }
+    if (own_b3) { a.theta[g.b3() + j] = lds[L::B3 + j]; st_m[g.b3() + j] = mb3; st_v[g.b3() + j] = vb3; }
+    if (ol == 0 && wg == 0 && a.stale_io) *a.stale_io = stale_sq;
+  }
+#undef RS_REIDX
+#undef RS_STAMP
+}
+
+template <int KIN, int R, bool PROF>
+__global__ __launch_bounds__(384) void ppo_update_rs_kernel(RsArgs a) {
+  if (blockIdx.x & 7) return;                    // placement hint (update.hip): the working blocks land on one XCD and share its L2
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const red = lds + RsLds<KIN>::RED;
+  const int wg = (int)(blockIdx.x >> 3), tid = threadIdx.x;
+  // ---- placement census (update_ks.hip): do all workgroups of the launch share one XCD (one L2)?  Checked, once per launch,
+  // over words every placement delivers; not co-resident (or SPO_RS_SAFE=1): write-through exchange stores, same results.
+  bool fast;
+  {
+    unsigned long long* const xid = a.gran + RS_GRAN_WORDS;
+    const unsigned myx = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;      // HW_REG_XCC_ID
+    if (tid == 0) {
+      red[96] = 0.f;
+      __hip_atomic_store(xid + wg, ((unsigned long long)a.tag_base << 32) | myx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (tid < a.n_nets * R) {
+      unsigned long long v = __hip_atomic_load(xid + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned spins = 0;
+      while ((unsigned)(v >> 32) != a.tag_base) {
+        if (++spins > RS_SPIN_LIMIT) { *a.err = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+        v = __hip_atomic_load(xid + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if ((unsigned)v != myx) red[96] = 1.f;
+    }
+    __syncthreads();
+    fast = (red[96] == 0.f) && !a.force_safe;
+    __syncthreads();
+  }
+  if (fast) rs_body<KIN, R, true, PROF>(a, lds);
+  else rs_body<KIN, R, false, PROF>(a, lds);
+}
+
+// Exchange scratch: the partial-gradient slots and the norm granules, ordinary device memory.  One block per (device, stream),
+// allocated on first use (update_ks.hip's scheme): launches on one stream are ordered and share it.
+struct RsEntry { int dev; void* stream; char* base; unsigned tag; };
+constexpr int RS_SCRATCH_MAX = 16;
+RsEntry g_rs[RS_SCRATCH_MAX] = {};
+int g_rs_n = 0;
+std::mutex g_rs_mu;
+constexpr size_t RS_Z_MAX = rs_z_bytes(RS_MAX_R);
+constexpr size_t RS_G_BYTES = (size_t)(RS_GRAN_WORDS + RS_CENSUS_WORDS) * 8;
+
+int rs_scratch(hipStream_t st, float** z, unsigned long long** gran, unsigned* tag_base, unsigned nsteps) {
+  const int dev = current_device_slot();
+  std::lock_guard<std::mutex> lk(g_rs_mu);
+  RsEntry* e = nullptr;
+  for (int i = 0; i < g_rs_n; ++i)
+    if (g_rs[i].dev == dev && g_rs[i].stream == (void*)st) e = &g_rs[i];
+  if (!e) {
+    if (g_rs_n == RS_SCRATCH_MAX)
+      return spo::fail(-1, "row-split update kernel: more than %d (device, stream) pairs hold exchange scratch in this process; "
+                           "call spo_update_scratch_release(stream) for streams that are gone", RS_SCRATCH_MAX);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+      return spo::fail(-1, "row-split update kernel: first launch on a stream under capture (the scratch block is allocated on "
+                           "first use: launch once outside the capture)");
+    void* p = nullptr;
+    if (int rc = spo::hip_check(hipMalloc(&p, RS_Z_MAX + RS_G_BYTES), "hipMalloc(rs scratch)")) return rc;
+    if (int rc = spo::hip_check(hipMemset(p, 0, RS_Z_MAX + RS_G_BYTES), "hipMemset(rs scratch)")) { (void)hipFree(p); return rc; }
+    if (int rc = spo::hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize(rs scratch)")) { (void)hipFree(p); return rc; }
+    g_rs[g_rs_n] = RsEntry{dev, (void*)st, static_cast<char*>(p), 16u};
+    e = &g_rs[g_rs_n++];
+  }
+  *z = reinterpret_cast<float*>(e->base);
+  *gran = reinterpret_cast<unsigned long long*>(e->base + RS_Z_MAX);
+  *tag_base = e->tag;
+  e->tag += nsteps + 2u;                           // (wraps after 4e9 steps: a tag then meets words 2^32 steps old)
+  return 0;
+}
+
+template <int KIN, int R, bool PROF>
+int rs_launch_k(const RsArgs& a, hipStream_t st) {
+  const size_t sh = RsLds<KIN>::SIZE * sizeof(float);
+  static bool attr_done[SPO_MAX_DEVICES] = {};
+  const int dslot = current_device_slot();
+  if (!attr_done[dslot]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_update_rs_kernel<KIN, R, PROF>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (e != hipSuccess) return spo::hip_check(e, "hipFuncSetAttribute(update_rs)");
+    attr_done[dslot] = true;
+  }
+  hipLaunchKernelGGL((ppo_update_rs_kernel<KIN, R, PROF>), dim3(8 * (a.n_nets * R - 1) + 1), dim3(384), sh, st, a);
+  return 0;
+}
+
+}  // namespace
+
+int spo::rs_scratch_release(int dev, void* stream_or_null, int all) {
+  std::lock_guard<std::mutex> lk(g_rs_mu);
+  int freed = 0;
+  for (int i = 0; i < g_rs_n;) {
+    if (g_rs[i].dev == dev && (all || g_rs[i].stream == stream_or_null)) {
+      (void)spo::hip_check(hipFree(g_rs[i].base), "hipFree(rs scratch)");
+      g_rs[i] = g_rs[--g_rs_n];
+      ++freed;
+    } else ++i;
+  }
+  return freed;
+}
+
+// Does the row-split kernel take this shape?  n_nets 3 = the PPO-Lagrangian step (clipped surrogate), 2 = the critic fit.
+extern "C" int spo_update_rs_supported(int obs_dim, int act_dim, int batch, int n_nets) {
+  if (obs_dim < 1 || obs_dim > 64 || act_dim < 1 || act_dim > SPO_MAX_ACT || batch < 1) return 0;
+  if (n_nets == 3) return batch <= 64 ? 1 : 0;
+  if (n_nets == 2) return batch <= 128 ? 1 : 0;
+  return 0;
+}
+
+// Called by spo_ppo_lag_update_iter / spo_critic_fit_iter (update.hip) when the shape is supported and SPO_UPDATE_FORM selects it.
+int spo::rs_update_launch(float* theta, float* adam_m, float* adam_v, int64_t adam_step_host, const float* obs, const float* act,
+                          const float* logp_old, const float* target_r, const float* target_c, const float* adv,
+                          const int32_t* perm, int64_t M, const spo_ppo_cfg* cfg_host, int n_nets, float* stale_sq_io,
+                          float* losses_out, void* sync_ws, unsigned long long* prof, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  RsArgs a{};
+  a.theta = theta; a.adam_m = adam_m; a.adam_v = adam_v;
+  a.obs = obs; a.act = act; a.logp_old = logp_old; a.tgt_r = target_r; a.tgt_c = target_c; a.adv = adv;
+  a.perm = perm; a.M = M; a.cfg = *cfg_host; a.losses = losses_out;
+  a.err = reinterpret_cast<int*>(reinterpret_cast<char*>(sync_ws) + 64);
+  a.pow_b1 = pow((double)cfg_host->beta1, (double)adam_step_host);
+  a.pow_b2 = pow((double)cfg_host->beta2, (double)adam_step_host);
+  a.n_nets = n_nets; a.first_net = 0; a.stale_io = stale_sq_io; a.prof = prof;
+  { const char* e = getenv("SPO_RS_SAFE"); a.force_safe = (e && *e && *e != '0') ? 1 : 0; }
+  const int64_t nsteps = (M + cfg_host->batch - 1) / cfg_host->batch;
+  SPO_REQUIRE(nsteps < (1ll << 30), "update_rs: too many minibatch steps in one launch");
+  if (int rc = rs_scratch(st, &a.zbuf, &a.gran, &a.tag_base, (unsigned)nsteps)) return rc;
+  const int R = cfg_host->batch <= 64 ? 2 : 4;
+  // every slot starts as the sentinel (a launch leaves them that way unless it stopped on an error)
+  if (int rc = spo::hip_check(hipMemsetAsync(a.zbuf, 0xFF, R == 2 ? rs_z_bytes(2) : rs_z_bytes(4), st), "hipMemsetAsync(rs slots)")) return rc;
+  const int kin = cfg_host->obs_dim <= 16 ? 16 : cfg_host->obs_dim <= 32 ? 32 : 64;
+#define RS_GO(K)                                                                                  \
+  {                                                                                               \
+    if (R == 2) { if (prof && K == 64) return rs_launch_k<K, 2, (K == 64)>(a, st); return rs_launch_k<K, 2, false>(a, st); } \
+    return rs_launch_k<K, 4, false>(a, st);                                                       \
+  }
+  if (kin == 16) RS_GO(16) else if (kin == 32) RS_GO(32) else RS_GO(64)
+#undef RS_GO
+}
