@@ -3164,6 +3164,11 @@ static int fill_xr(UpdArgs& a, int rank, int world, void* const* regions, unsign
 extern "C" int spo_debug_update_counters(unsigned long long* out4_host, int reset) {
   SPO_REQUIRE(out4_host, "update_counters: null pointer");
   if (int rc = spo::hip_check(hipMemcpyFromSymbol(out4_host, HIP_SYMBOL(g_upd_counters), 32), "hipMemcpyFromSymbol")) return rc;
+  {
+    unsigned long long rs2[2] = {0, 0};                                 // the row-split form's steps / late redos count with the first two
+    if (int rc = spo::rs_counters(rs2, reset)) return rc;
+    out4_host[0] += rs2[0]; out4_host[1] += rs2[1];
+  }
   if (reset) {
     unsigned long long z[4] = {0, 0, 0, 0};
     return spo::hip_check(hipMemcpyToSymbol(HIP_SYMBOL(g_upd_counters), z, 32), "hipMemcpyToSymbol");

@@ -10,4 +10,6 @@ int rs_update_launch(float* theta, float* adam_m, float* adam_v, int64_t adam_st
                      const float* logp_old, const float* target_r, const float* target_c, const float* adv, const int32_t* perm,
                      int64_t M, const spo_ppo_cfg* cfg_host, int n_nets, float* stale_sq_io, float* losses_out, void* sync_ws,
                      unsigned long long* prof, void* stream);
+// {minibatch steps run, steps redone after a late clip verdict} of the row-split kernel since the last reset
+int rs_counters(unsigned long long* out2_host, int reset);
 }  // namespace spo

@@ -62,7 +62,8 @@ struct RsLds {                                   // floats
   static_assert(SIZE * 4 <= 163840, "160 KB of LDS");
 };
 // RED: [0..1] loss partials of the column waves, [16 + 16 c + a] d(log_std) partials of column wave c, [88 + w] sum p^2 of
-//      optimiser wave w, [96] placement census, [97] dead flag (a poll timed out: stop waiting), [100 + ...] spare
+//      optimiser wave w, [96] placement census, [97] dead flag (a poll timed out: stop waiting), [98] (int) index of the step
+//      whose L1 the column waves must repeat (its predecessor was clipped)
 
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
@@ -85,6 +86,10 @@ struct RsArgs {
 constexpr size_t rs_z_bytes(int R) { return (size_t)2 * 3 * R * R * RS_NS * 4096; }
 constexpr int RS_GRAN_WORDS = 2 * RS_MAX_R * 3 * 4;
 constexpr int RS_CENSUS_WORDS = 3 * RS_MAX_R;
+
+// minibatch steps run / steps whose speculative layer-1 update turned out clipped and was redone, summed over the launches of the
+// process (first optimiser lane of workgroup 0); read through spo_debug_update_counters
+__device__ unsigned long long g_rs_counters[2];
 
 __device__ __forceinline__ float pin(float v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ int pin(int v) { asm volatile("" : "+v"(v)); return v; }
@@ -212,6 +217,16 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
       RS_STAMP(2)                                                        // L1
       __syncthreads();                                                    // b2: W2 / b2 in place
       RS_STAMP(3)
+      if (reinterpret_cast<const int*>(red)[98] == (int)(s & 0x3fffffff) && s > 0) {
+        // the previous step turned out clipped: W1 / b1 were restored and redone exactly while this L1 ran -- once more, on the
+        // exact weights (complete before b2)
+        RS_REIDX
+        layer_hidden<NT1, true>(lds + L::W1, L::LD1, lds + L::B1, cur.x, h1, j, q);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lds[S::H1T + (16 * mt + 4 * q + r) * LDC + lcol] = h1[mt][r];
+      }
       {
         RS_REIDX
         layer_hidden<4, true>(lds + L::W2, LDH, lds + L::B2, h1, h2, j, q);
@@ -480,6 +495,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
   __syncthreads();                                                        // b3
   if (PROF) tprev = __builtin_readcyclecounter();
   float last_loss = 0.f;
+  int n_redo = 0;
   for (int64_t s = 0; s < nsteps; ++s) {
     const int64_t base = s * B;
     const int64_t rem = a.M - base;
@@ -538,23 +554,37 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
       for (int r = 0; r < 4; ++r) gA[6][r] = red[16 + 4 * q + r] + red[32 + 4 * q + r];
       RS_PUSH(gA, 7, NT1 + 1, par)
     }
-    RS_STAMP(1)                                                            // dW2, dW3, stores
-    __syncthreads();                                                      // b5: dZ1^T complete
-    RS_STAMP(2)
+    // ---- off the critical path, before the last image arrives: the x^T operands of dW1 (complete since the step began), this
+    // lane's W1 / b1 parameters (L2 term, backup), the optimiser scalars of the step
+    f4 bx[2][NT1], pW1[NT1];
+    float pb1;
     {
-      // ---- dW1, db1
       RS_REIDX
       const float* const xt = lds + S::XT + par * KIN * LDC;
-      f4 az1[2];
-#pragma unroll
-      for (int r4 = 0; r4 < 2; ++r4)
-        az1[r4] = *reinterpret_cast<const f4*>(lds + S::DZ1T + (16 * ow + j) * LDC + 16 * r4 + 4 * q);
-      f4 bx[2][NT1];
 #pragma unroll
       for (int r4 = 0; r4 < 2; ++r4)
 #pragma unroll
         for (int nt = 0; nt < NT1; ++nt)
           bx[r4][nt] = *reinterpret_cast<const f4*>(xt + (16 * nt + j) * LDC + 16 * r4 + 4 * q);
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pW1[nt][r] = lds[L::W1 + (orow + r) * L::LD1 + 16 * nt + j];
+      pb1 = lds[L::B1 + 16 * ow + j];
+    }
+    pw1 *= (double)b1c; pw2 *= (double)b2c;
+    float step_size, inv_bc2s;
+    adam_scalars(lr, pw1, pw2, step_size, inv_bc2s);
+    RS_STAMP(1)                                                            // dW2, dW3, stores, preloads
+    __syncthreads();                                                      // b5: dZ1^T complete
+    RS_STAMP(2)
+    {
+      // ---- dW1, db1
+      RS_REIDX
+      f4 az1[2];
+#pragma unroll
+      for (int r4 = 0; r4 < 2; ++r4)
+        az1[r4] = *reinterpret_cast<const f4*>(lds + S::DZ1T + (16 * ow + j) * LDC + 16 * r4 + 4 * q);
 #pragma unroll
       for (int nt = 0; nt < NT1; ++nt) gB[nt] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -570,23 +600,13 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
       RS_PUSH(gB, NT1 + 1, 0, par)
     }
     RS_STAMP(3)                                                            // dW1, stores
-    // ---- the peers' partials: layers 2 / 3 have been travelling since b4, layer 1 is the exposed hand-off
-    RS_POLL_SUM(gA, 7, NT1 + 1, par, 10)
-    RS_POLL_SUM(gB, NT1 + 1, 0, par, 11)
-    RS_STAMP(4)                                                            // polls + sums
-    // ---- L2 regulariser of the critics (weights AND biases, ppo_lag.py:310-314), norm shares
+    // ---- while layer 1's partials travel: the peers' layer-2 / 3 partials (sent at b4: long there), their L2 terms and norm share
     float gsq = 0.f, psq = 0.f;
     float gb1, gb2, gb3 = 0.f;
+    RS_POLL_SUM(gA, 7, NT1 + 1, par, 10)
     {
+      // L2 regulariser of the critics (weights AND biases, ppo_lag.py:310-314)
       RS_REIDX
-#pragma unroll
-      for (int nt = 0; nt < NT1; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {                                       // pad columns hold p == 0, g == 0
-          const float p_ = lds[L::W1 + (orow + r) * L::LD1 + 16 * nt + j];
-          const float g_ = vcoef * fmaf(l2x2, p_, gB[nt][r]);
-          gB[nt][r] = g_; gsq = fmaf(g_, g_, gsq); psq = fmaf(p_, p_, psq);
-        }
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -603,10 +623,9 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
       }
       {
         // biases are replicated over q (all replicas run the same Adam, q == 0 counts towards the norms)
-        const float pb1 = lds[L::B1 + 16 * ow + j], pb2 = lds[L::B2 + 16 * ow + j];
-        gb1 = vcoef * fmaf(l2x2, pb1, gB[NT1][0]);
+        const float pb2 = lds[L::B2 + 16 * ow + j];
         gb2 = vcoef * fmaf(l2x2, pb2, gA[5][0]);
-        if (own_b) { gsq = fmaf(gb1, gb1, gsq); psq = fmaf(pb1, pb1, psq); gsq = fmaf(gb2, gb2, gsq); psq = fmaf(pb2, pb2, psq); }
+        if (own_b) { gsq = fmaf(gb2, gb2, gsq); psq = fmaf(pb2, pb2, psq); }
         if (ow == 0) {
           const float pb3 = lds[L::B3 + j];
           gb3 = vcoef * fmaf(l2x2, pb3, gA[5][1]);
@@ -617,17 +636,47 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
           }
         }
       }
+    }
+    const float loss_data = gA[5][2] * inv_n;
+    RS_STAMP(4)                                                            // layers 2 / 3: poll, sums, L2 terms
+    RS_POLL_SUM(gB, NT1 + 1, 0, par, 11)
+    RS_STAMP(5)                                                            // layer 1: poll, sums
+    // ---- layer 1: L2 term, norm share out, then Adam at once with clip coefficient 1 -- max_grad_norm almost never binds, and the
+    // next forward waits for nothing else.  Backups in registers; the joint norm is checked behind b1 (below).
+    f4 bmW1[NT1], bvW1[NT1];
+    float bmb1, bvb1;
+    {
+      RS_REIDX
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                                       // pad columns hold p == 0, g == 0
+          const float p_ = pW1[nt][r];
+          const float g_ = vcoef * fmaf(l2x2, p_, gB[nt][r]);
+          gB[nt][r] = g_; gsq = fmaf(g_, g_, gsq); psq = fmaf(p_, p_, psq);
+        }
+      gb1 = vcoef * fmaf(l2x2, pb1, gB[NT1][0]);
+      if (own_b) { gsq = fmaf(gb1, gb1, gsq); psq = fmaf(pb1, pb1, psq); }
       const float wg_sq = wave_sum_lane63(gsq), wp_sq = wave_sum_lane63(psq);
       if (lane == 63) {
         gstore(grow + 4 * netl + ow, ((unsigned long long)tag << 32) | __float_as_uint(wg_sq));
         red[88 + ow] = wp_sq;                                              // sum p^2 shares: read after the next barrier
       }
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt) {
+        bmW1[nt] = mW1[nt]; bvW1[nt] = vW1[nt];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const AdamOut o_ = adam1(pW1[nt][r], gB[nt][r], mW1[nt][r], vW1[nt][r], b1c, b2c, eps, step_size, inv_bc2s);
+          mW1[nt][r] = o_.m; vW1[nt][r] = o_.v; lds[L::W1 + (orow + r) * L::LD1 + 16 * nt + j] = o_.p;
+        }
+      }
+      bmb1 = mb1; bvb1 = vb1;
+      const AdamOut o_ = adam1(pb1, gb1, mb1, vb1, b1c, b2c, eps, step_size, inv_bc2s);
+      mb1 = o_.m; vb1 = o_.v; lds[L::B1 + 16 * ow + j] = o_.p;
     }
-    const float loss_data = gA[5][2] * inv_n;
-    pw1 *= (double)b1c; pw2 *= (double)b2c;
-    float step_size, inv_bc2s;
-    adam_scalars(lr, pw1, pw2, step_size, inv_bc2s);
-    RS_STAMP(5)                                                            // L2 terms, norm share out
+    RS_STAMP(6)                                                            // L2 term, norm share out, Adam W1 (coefficient 1)
+    if (s + 1 < nsteps) __syncthreads();                                  // b1 of step s + 1
     // ---- joint clip_grad_norm_ over all networks (ppo_lag.py:325): the granules of the workgroups with my row-group index
     float coef;
     {
@@ -651,19 +700,26 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
       coef = coef > 1.f ? 1.f : coef;
       stale_sq *= coef * coef;
     }
-    RS_STAMP(6)                                                            // poll norms, coefficient
-    {
-      // ---- Adam (torch.optim.Adam, ppo_lag.py:104-117): layer 1 first -- the next forward starts with it
+    RS_STAMP(7)                                                            // wait b1, poll norms, coefficient
+    if (coef != 1.f) {
+      // ---- clipped after all (rare): layer 1 restored and redone exactly.  The column waves are inside L1 of the next step on the
+      // speculative weights; the flag makes them repeat it behind b2 -- by then this redo is complete, no extra barrier.
       RS_REIDX
+      ++n_redo;
 #pragma unroll
-      for (int nt = 0; nt < NT1; ++nt)
+      for (int nt = 0; nt < NT1; ++nt) {
+        mW1[nt] = bmW1[nt]; vW1[nt] = bvW1[nt];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          RS_ADAM(L::W1 + (orow + r) * L::LD1 + 16 * nt + j, gB[nt][r] * coef, mW1[nt][r], vW1[nt][r])
-      RS_ADAM(L::B1 + 16 * ow + j, gb1 * coef, mb1, vb1)
+        for (int r = 0; r < 4; ++r) {
+          const AdamOut o_ = adam1(pW1[nt][r], gB[nt][r] * coef, mW1[nt][r], vW1[nt][r], b1c, b2c, eps, step_size, inv_bc2s);
+          mW1[nt][r] = o_.m; vW1[nt][r] = o_.v; lds[L::W1 + (orow + r) * L::LD1 + 16 * nt + j] = o_.p;
+        }
+      }
+      mb1 = bmb1; vb1 = bvb1;
+      const AdamOut o_ = adam1(pb1, gb1 * coef, mb1, vb1, b1c, b2c, eps, step_size, inv_bc2s);
+      mb1 = o_.m; vb1 = o_.v; lds[L::B1 + 16 * ow + j] = o_.p;
+      if (ol == 0) reinterpret_cast<volatile int*>(red)[98] = (int)((s + 1) & 0x3fffffff);
     }
-    RS_STAMP(7)                                                            // Adam W1
-    if (s + 1 < nsteps) __syncthreads();                                  // b1 of step s + 1
     {
       RS_REIDX
 #pragma unroll
@@ -673,7 +729,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
           RS_ADAM(L::W2 + (orow + r) * LDH + 16 * nt + j, gA[nt][r] * coef, mW2[nt][r], vW2[nt][r])
       RS_ADAM(L::B2 + 16 * ow + j, gb2 * coef, mb2, vb2)
     }
-    RS_STAMP(8)                                                            // wait b1 + Adam W2
+    RS_STAMP(8)                                                            // (redo,) Adam W2
     if (s + 1 < nsteps) __syncthreads();                                  // b2 of step s + 1
     {
       RS_REIDX
@@ -702,6 +758,9 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
   if (PROF && a.prof && lane == 0 && ow == 0 && wg == a.n_nets * R - 1)
     for (int i = 0; i < RS_NPHASE; ++i) a.prof[RS_NPHASE + i] = pacc[i];
   __syncthreads();                                                        // after the loop: orders the final image before the write-back
+  if (ol == 0 && wg == 0) {
+    atomicAdd(&g_rs_counters[0], (unsigned long long)nsteps); atomicAdd(&g_rs_counters[1], (unsigned long long)n_redo);
+  }
   if (ow == 0 && lane == 0 && hf == 0 && nsteps > 0) {
     const float pp = (red[88] + red[89]) + (red[90] + red[91]);
     a.losses[(nsteps - 1) * 3 + net] = is_actor ? -last_loss : last_loss + l2 * pp;
@@ -858,6 +917,15 @@ int spo::rs_scratch_release(int dev, void* stream_or_null, int all) {
     } else ++i;
   }
   return freed;
+}
+
+int spo::rs_counters(unsigned long long* out2_host, int reset) {
+  if (int rc = spo::hip_check(hipMemcpyFromSymbol(out2_host, HIP_SYMBOL(g_rs_counters), 16), "hipMemcpyFromSymbol")) return rc;
+  if (reset) {
+    unsigned long long z[2] = {0, 0};
+    return spo::hip_check(hipMemcpyToSymbol(HIP_SYMBOL(g_rs_counters), z, 16), "hipMemcpyToSymbol");
+  }
+  return 0;
 }
 
 // Does the row-split kernel take this shape?  n_nets 3 = the PPO-Lagrangian step (clipped surrogate), 2 = the critic fit.
