@@ -32,6 +32,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 #include "common.h"
 #include "mlp_mfma.h"
 #include "adam.h"
@@ -101,6 +102,34 @@ struct RsCol {                         // per-column inputs of one minibatch, pr
   float t0, t1;                        // critic: target ; actor: logp_old, adv
 };
 
+// Half of a hidden layer for one column tile: output tiles 2 FH, 2 FH + 1 of out[] (rows 16 mt + 4 q + reg, col batch) = tanh?(W in + b);
+// the other two entries of out[] are left alone (they are the partner wave's).  Two independent accumulator chains (dependent
+// distance 64 cycles >= the 40-cycle accumulator latency), A tiles double-buffered like layer_hidden.
+template <int NT_IN, int FH, bool TANH>
+__device__ __forceinline__ void layer_half(const float* Wl, int ld, const float* bl, const f4 (&in)[NT_IN], f4 (&out)[HID / 16],
+                                           int j, int q) {
+  constexpr int M0 = 2 * FH;
+  f4 acc[2], a[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) a[0][t] = *reinterpret_cast<const f4*>(Wl + (16 * (M0 + t) + j) * ld + 4 * q);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) acc[t] = *reinterpret_cast<const f4*>(bl + 16 * (M0 + t) + 4 * q);
+#pragma unroll
+  for (int nt = 0; nt < NT_IN; ++nt) {
+    if (nt + 1 < NT_IN) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        a[(nt + 1) & 1][t] = *reinterpret_cast<const f4*>(Wl + (16 * (M0 + t) + j) * ld + 16 * (nt + 1) + 4 * q);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[t] = mfma4(a[nt & 1][t][r], in[nt][r], acc[t]);
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) out[M0 + t] = TANH ? fast_tanh4(acc[t]) : acc[t];
+}
+
 // FAST: every workgroup of the launch sits on one XCD (checked by the kernel), stores of the exchange stay plain
 template <int KIN, int R, bool FAST, bool PROF>
 __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
@@ -117,8 +146,8 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
   const int wg = (int)(blockIdx.x >> 3);
   const int netl = wg / R, hf = wg - netl * R, net = a.first_net + netl;
   const int tid = threadIdx.x, lane = tid & 63, j_ = lane & 15, q_ = lane >> 4;
-  const int wave6 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool is_col = (wave6 == 2 || wave6 == 3);
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_col = wave8 >= 4;                // waves 0 .. 3: optimiser (one per SIMD), 4 .. 7: column (wave i + 4 shares wave i's SIMD)
   const int D = a.cfg.obs_dim, A = a.cfg.act_dim, B = a.cfg.batch;
   const NetGeom g = net_geom(D, A, net);
   const bool is_actor = (net == 2);
@@ -127,18 +156,21 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
   float* const red = lds + S::RED;
   const int64_t nsteps = (a.M + B - 1) / B;
 
-  stage_net<KIN>(a.theta, g, lds, tid, 384);
+  stage_net<KIN>(a.theta, g, lds, tid, 512);
   if (tid < 16) lds[S::LS + tid] = (is_actor && tid < A) ? a.theta[ls_off + tid] : 0.f;
   if (tid < 128) red[tid] = 0.f;
   __syncthreads();
 
   if (is_col) {
     // =========================================================================================================== column waves
-    const int c = wave6 - 2;
+    // column wave cw: column tile ct = cw & 1 (16 batch columns), feature half fh = cw >> 1 (output tiles 2 fh, 2 fh + 1 of every
+    // hidden layer / backward product).  Two separate instantiations of the loop (fh is a constant in each: every register array
+    // is indexed statically).
+    const int cw = wave8 - 4, ct = cw & 1, fh_rt = cw >> 1;
     int j = j_, q = q_;
-    int lcol = 16 * c + j_;                      // column inside the workgroup's 32
-    const int gcol = 32 * hf + 16 * c + j_;      // column inside the minibatch
-#define RS_REIDX { j = pin(j_); q = pin(q_); lcol = 16 * c + j; }
+    int lcol = 16 * ct + j_;                     // column inside the workgroup's 32
+    const int gcol = 32 * hf + 16 * ct + j_;     // column inside the minibatch
+#define RS_REIDX { j = pin(j_); q = pin(q_); lcol = 16 * ct + j; }
     const float clip_lo = 1.f - a.cfg.clip, clip_hi = 1.f + a.cfg.clip;
     const float* tgt = (net == 0) ? a.tgt_r : a.tgt_c;
     auto perm_pos = [&](int64_t s_) -> int64_t {
@@ -177,6 +209,9 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
         }
       }
     };
+    auto col_loop = [&](auto FHC) {
+    constexpr int FH = decltype(FHC)::value;
+    constexpr int M0 = 2 * FH, P0 = 2 - M0;      // own output tiles M0, M0 + 1; the partner wave's P0, P0 + 1
     RsCol<NT1> nxt;
     int smp1 = 0;
     fetch((int64_t)a.perm[perm_pos(0)], nxt);
@@ -196,7 +231,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
       settle(cur);
       const int smp_next = pin(smp1);
       const int64_t pos2 = (s + 2 < nsteps) ? perm_pos(s + 2) : 0;
-      {
+      if (FH == 0) {
         float* const xt = lds + S::XT + (int)(s & 1) * KIN * LDC;
 #pragma unroll
         for (int nt = 0; nt < NT1; ++nt)
@@ -208,40 +243,54 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
       RS_STAMP(1)
       {
         RS_REIDX
-        layer_hidden<NT1, true>(lds + L::W1, L::LD1, lds + L::B1, cur.x, h1, j, q);
+        layer_half<NT1, FH, true>(lds + L::W1, L::LD1, lds + L::B1, cur.x, h1, j, q);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) lds[S::H1T + (16 * mt + 4 * q + r) * LDC + lcol] = h1[mt][r];
+          for (int r = 0; r < 4; ++r) lds[S::H1T + (16 * (M0 + t) + 4 * q + r) * LDC + lcol] = h1[M0 + t][r];
       }
-      RS_STAMP(2)                                                        // L1
-      __syncthreads();                                                    // b2: W2 / b2 in place
+      RS_STAMP(2)                                                        // L1 (own half)
+      __syncthreads();                                                    // b2: W2 / b2 in place; both halves of h1^T written
       RS_STAMP(3)
       if (reinterpret_cast<const int*>(red)[98] == (int)(s & 0x3fffffff) && s > 0) {
-        // the previous step turned out clipped: W1 / b1 were restored and redone exactly while this L1 ran -- once more, on the
-        // exact weights (complete before b2)
+        // the previous step turned out clipped: W1 / b1 were restored and redone exactly while this L1 ran (complete before b2) --
+        // once more on the exact weights, and one more barrier for the two halves (the optimiser waves run it too)
         RS_REIDX
-        layer_hidden<NT1, true>(lds + L::W1, L::LD1, lds + L::B1, cur.x, h1, j, q);
+        layer_half<NT1, FH, true>(lds + L::W1, L::LD1, lds + L::B1, cur.x, h1, j, q);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) lds[S::H1T + (16 * mt + 4 * q + r) * LDC + lcol] = h1[mt][r];
+          for (int r = 0; r < 4; ++r) lds[S::H1T + (16 * (M0 + t) + 4 * q + r) * LDC + lcol] = h1[M0 + t][r];
+        __syncthreads();
       }
       {
         RS_REIDX
-        layer_hidden<4, true>(lds + L::W2, LDH, lds + L::B2, h1, h2, j, q);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) lds[S::H2T + (16 * mt + 4 * q + r) * LDC + lcol] = h2[mt][r];
+          for (int r = 0; r < 4; ++r) h1[P0 + t][r] = lds[S::H1T + (16 * (P0 + t) + 4 * q + r) * LDC + lcol];
+        layer_half<4, FH, true>(lds + L::W2, LDH, lds + L::B2, h1, h2, j, q);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lds[S::H2T + (16 * (M0 + t) + 4 * q + r) * LDC + lcol] = h2[M0 + t][r];
       }
-      RS_STAMP(4)                                                        // L2
-      __syncthreads();                                                    // b3: W3 / b3 / log_std in place
+      RS_STAMP(4)                                                        // partner's h1, L2 (own half)
+      __syncthreads();                                                    // b3: W3 / b3 / log_std in place; both halves of h2^T written
       RS_STAMP(5)
       f4 dz2[4];
       {
         RS_REIDX
-        const f4 o = layer_out(lds + L::W3, lds + L::B3, h2, j, q);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h2[P0 + t][r] = lds[S::H2T + (16 * (P0 + t) + 4 * q + r) * LDC + lcol];
+        float w3c[4][2];                                                 // issued early: their latency hides under the output layer and the loss
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) w3c[r][t] = lds[L::W3 + (4 * q + r) * LDH + 16 * (M0 + t) + j];
+        const f4 o = layer_out(lds + L::W3, lds + L::B3, h2, j, q);      // (both halves of a column tile: the same 8 products)
         float ivar[4], lsd[4], amask[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -253,11 +302,6 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
           ivar[r] = __builtin_amdgcn_rcpf(sdv * sdv);
           lsd[r] = on ? lsv + LOG_SQRT_2PI : 0.f;
         }
-        float w3c[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt) w3c[r][mt] = lds[L::W3 + (4 * q + r) * LDH + 16 * mt + j];
         f4 dO = {0.f, 0.f, 0.f, 0.f}, dls = {0.f, 0.f, 0.f, 0.f};
         float lsum = 0.f;
         if (!is_actor) {
@@ -292,38 +336,38 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
             dls[r] = (dlp * amask[r]) * (dif[r] * z - 1.f);
           }
         }
-        // loss / d(log_std) partials of this wave's 16 columns: they travel with the layer-2 / 3 gradients
-        {
+        // dO -> dZ2 (own half)
+        f4 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[t] = mfma4(w3c[r][t], dO[r], acc[t]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dz2[M0 + t][r] = acc[t][r] * fmaf(-h2[M0 + t][r], h2[M0 + t][r], 1.f);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lds[S::DZ2T + (16 * (M0 + t) + 4 * q + r) * LDC + lcol] = dz2[M0 + t][r];
+        if (FH == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lds[S::DOT + (4 * q + r) * LDC + lcol] = dO[r];
+          // loss / d(log_std) partials of this column tile: they travel with the layer-2 / 3 gradients
           const float ls = wave_sum_lane63(lsum);
-          if (lane == 63) red[c] = ls;
+          if (lane == 63) red[ct] = ls;
           if (is_actor) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float t = row_sum_lane15(dls[r]);
-              if (j == 15) red[16 + 16 * c + 4 * q + r] = t;
+              if (j == 15) red[16 + 16 * ct + 4 * q + r] = t;
             }
           }
         }
-        // dO -> dZ2
-        f4 acc[4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[mt] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma4(w3c[r][mt], dO[r], acc[mt]);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) dz2[mt][r] = acc[mt][r] * fmaf(-h2[mt][r], h2[mt][r], 1.f);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) lds[S::DZ2T + (16 * mt + 4 * q + r) * LDC + lcol] = dz2[mt][r];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) lds[S::DOT + (4 * q + r) * LDC + lcol] = dO[r];
       }
-      RS_STAMP(6)                                                        // L3, loss, dO -> dZ2, images
+      RS_STAMP(6)                                                        // partner's h2, L3, loss, dO -> dZ2 (own half), images
       __syncthreads();                                                    // b4: h1^T, h2^T, dZ2^T, dO^T complete
       RS_STAMP(7)
       {
@@ -331,42 +375,49 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
         // rows of the next minibatch, the index of the one after it: in flight under the last backward product
         if (s + 1 < nsteps) fetch((int64_t)smp_next, nxt);
         if (s + 2 < nsteps) smp1 = a.perm[pos2];
-        f4 acc[4], dz1[4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[mt] = f4{0.f, 0.f, 0.f, 0.f};
-        float w2c[2][4][4];
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dz2[P0 + t][r] = lds[S::DZ2T + (16 * (P0 + t) + 4 * q + r) * LDC + lcol];
+        f4 acc[2], dz1[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+        float w2c[2][4][2];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt) w2c[0][r][mt] = lds[L::W2 + (4 * q + r) * LDH + 16 * mt + j];
+          for (int t = 0; t < 2; ++t) w2c[0][r][t] = lds[L::W2 + (4 * q + r) * LDH + 16 * (M0 + t) + j];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
           if (nt + 1 < 4) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-              for (int mt = 0; mt < 4; ++mt)
-                w2c[(nt + 1) & 1][r][mt] = lds[L::W2 + (16 * (nt + 1) + 4 * q + r) * LDH + 16 * mt + j];
+              for (int t = 0; t < 2; ++t)
+                w2c[(nt + 1) & 1][r][t] = lds[L::W2 + (16 * (nt + 1) + 4 * q + r) * LDH + 16 * (M0 + t) + j];
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma4(w2c[nt & 1][r][mt], dz2[nt][r], acc[mt]);
+            for (int t = 0; t < 2; ++t) acc[t] = mfma4(w2c[nt & 1][r][t], dz2[nt][r], acc[t]);
         }
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dz1[mt][r] = acc[mt][r] * fmaf(-h1[mt][r], h1[mt][r], 1.f);
+          for (int r = 0; r < 4; ++r) dz1[t][r] = acc[t][r] * fmaf(-h1[M0 + t][r], h1[M0 + t][r], 1.f);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) lds[S::DZ1T + (16 * mt + 4 * q + r) * LDC + lcol] = dz1[mt][r];
+          for (int r = 0; r < 4; ++r) lds[S::DZ1T + (16 * (M0 + t) + 4 * q + r) * LDC + lcol] = dz1[t][r];
       }
-      RS_STAMP(8)                                                        // dZ2 -> dZ1, image
+      RS_STAMP(8)                                                        // partner's dZ2, dZ2 -> dZ1 (own half), image
       __syncthreads();                                                    // b5: dZ1^T complete
       RS_STAMP(9)
     }
-    if (PROF && a.prof && lane == 0 && c == 0 && wg == a.n_nets * R - 1)
+    };
+    if (fh_rt == 0) col_loop(std::integral_constant<int, 0>{});
+    else col_loop(std::integral_constant<int, 1>{});
+    if (PROF && a.prof && lane == 0 && cw == 0 && wg == a.n_nets * R - 1)
       for (int i = 0; i < RS_NPHASE; ++i) a.prof[i] = pacc[i];
     __syncthreads();                                                      // after the loop: the last update is complete
 #undef RS_REIDX
@@ -374,7 +425,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
   }
 
   // ============================================================================================================= optimiser waves
-  const int ow = wave6 < 2 ? wave6 : wave6 - 2;                           // 0 .. 3: rows [16 ow, 16 ow + 16) of the weight-gradient tiles
+  const int ow = wave8;                                                   // 0 .. 3: rows [16 ow, 16 ow + 16) of the weight-gradient tiles
   const int ol = ow * 64 + lane;                                          // 0 .. 255
   int j = j_, q = q_, orow = 16 * ow + 4 * q_;
 #define RS_REIDX { j = pin(j_); q = pin(q_); orow = 16 * ow + 4 * q; }
@@ -731,6 +782,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
     }
     RS_STAMP(8)                                                            // (redo,) Adam W2
     if (s + 1 < nsteps) __syncthreads();                                  // b2 of step s + 1
+    if (coef != 1.f && s + 1 < nsteps) __syncthreads();                   // (the column waves repeat L1: their halves meet at one more barrier)
     {
       RS_REIDX
 #pragma unroll
@@ -817,7 +869,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
 }
 
 template <int KIN, int R, bool PROF>
-__global__ __launch_bounds__(384) void ppo_update_rs_kernel(RsArgs a) {
+__global__ __launch_bounds__(512) void ppo_update_rs_kernel(RsArgs a) {
   if (blockIdx.x & 7) return;                    // placement hint (update.hip): the working blocks land on one XCD and share its L2
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const red = lds + RsLds<KIN>::RED;
@@ -900,7 +952,7 @@ int rs_launch_k(const RsArgs& a, hipStream_t st) {
     if (e != hipSuccess) return spo::hip_check(e, "hipFuncSetAttribute(update_rs)");
     attr_done[dslot] = true;
   }
-  hipLaunchKernelGGL((ppo_update_rs_kernel<KIN, R, PROF>), dim3(8 * (a.n_nets * R - 1) + 1), dim3(384), sh, st, a);
+  hipLaunchKernelGGL((ppo_update_rs_kernel<KIN, R, PROF>), dim3(8 * (a.n_nets * R - 1) + 1), dim3(512), sh, st, a);
   return 0;
 }
 
