@@ -471,6 +471,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
   const float l2 = (!is_actor && a.cfg.use_critic_norm) ? a.cfg.l2_coef : 0.f;
   const float l2x2 = 2.f * l2;
   const float vcoef = (net == 0 && a.cfg.use_value_coefficient) ? 2.f : 1.f;
+  const bool has_l2 = (l2 != 0.f) || (vcoef != 1.f);                      // (uniform over the workgroup)
   float stale_sq = a.stale_io ? *a.stale_io : 0.f;
   volatile float* const dead = red + 97;
 
@@ -501,19 +502,28 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
       }                                                                                                \
   }
   // poll the NF groups of peer h ^ d for d in [D0, D1), put the sentinel back; ACC += sum of those peers (D1 - D0 <= 2)
-#define RS_POLL(ACC, NF, K0, PAR, D0, D1, PROFSLOT)                                                    \
+#define RS_LOADS(ZW, NF, K0, PAR, D0, D1)                                                              \
   {                                                                                                    \
-    u4 zw_[(D1) - (D0)][NF];                                                                           \
+    _Pragma("unroll") for (int d_ = (D0); d_ < (D1); ++d_)                                             \
+      _Pragma("unroll") for (int k_ = 0; k_ < (NF); ++k_)                                              \
+        (ZW)[d_ - (D0)][k_] = __builtin_amdgcn_raw_buffer_load_b128(zrsrc, zvoff, slot((PAR), hf, hf ^ d_, (K0) + k_), 16); \
+  }
+  // ZW: u4 [D1 - D0][NF]; PRE: its loads were issued by the caller (RS_LOADS) -- the first look costs no round trip.
+  // A slot is complete when none of its dwords is the sentinel: unsigned max over all dwords != 0xFFFFFFFF (v_max3_u32).
+#define RS_POLL(ACC, ZW, NF, K0, PAR, D0, D1, PROFSLOT, PRE)                                           \
+  {                                                                                                    \
     unsigned spins_ = 0;                                                                               \
-    for (;;) {                                                                                         \
-      _Pragma("unroll") for (int d_ = (D0); d_ < (D1); ++d_)                                           \
-        _Pragma("unroll") for (int k_ = 0; k_ < (NF); ++k_)                                            \
-          zw_[d_ - (D0)][k_] = __builtin_amdgcn_raw_buffer_load_b128(zrsrc, zvoff, slot((PAR), hf, hf ^ d_, (K0) + k_), 16); \
-      bool ok_ = true;                                                                                 \
+    for (bool first_ = (PRE);; first_ = false) {                                                       \
+      if (!first_) RS_LOADS(ZW, NF, K0, PAR, D0, D1)                                                   \
+      unsigned mx_ = 0u;                                                                               \
       _Pragma("unroll") for (int d_ = 0; d_ < (D1) - (D0); ++d_)                                       \
-        _Pragma("unroll") for (int k_ = 0; k_ < (NF); ++k_)                                            \
-          _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) ok_ = ok_ && (zw_[d_][k_][e_] != 0xFFFFFFFFu); \
-      if (ok_) break;                                                                                  \
+        _Pragma("unroll") for (int k_ = 0; k_ < (NF); ++k_) {                                          \
+          const unsigned m01_ = (ZW)[d_][k_][0] > (ZW)[d_][k_][1] ? (ZW)[d_][k_][0] : (ZW)[d_][k_][1]; \
+          const unsigned m23_ = (ZW)[d_][k_][2] > (ZW)[d_][k_][3] ? (ZW)[d_][k_][2] : (ZW)[d_][k_][3]; \
+          const unsigned m4_ = m01_ > m23_ ? m01_ : m23_;                                              \
+          mx_ = mx_ > m4_ ? mx_ : m4_;                                                                 \
+        }                                                                                              \
+      if (mx_ != 0xFFFFFFFFu) break;                                                                   \
       if (*dead != 0.f) break;                                                                         \
       if (++spins_ > RS_SPIN_LIMIT) { *a.err = 1; *dead = 1.f; break; }   /* bounded, and sticky: never hang the GPU */ \
       __builtin_amdgcn_s_sleep(1);                                                                     \
@@ -523,15 +533,19 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
       _Pragma("unroll") for (int k_ = 0; k_ < (NF); ++k_) zstore(sentinel, slot((PAR), hf, hf ^ d_, (K0) + k_)); \
     _Pragma("unroll") for (int k_ = 0; k_ < (NF); ++k_)                                                \
       _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                               \
-        if constexpr ((D1) - (D0) == 1) (ACC)[k_][e_] = (ACC)[k_][e_] + __uint_as_float(zw_[0][k_][e_]); \
-        else (ACC)[k_][e_] = (ACC)[k_][e_] + (__uint_as_float(zw_[0][k_][e_]) + __uint_as_float(zw_[((D1) - (D0)) - 1][k_][e_])); \
+        if constexpr ((D1) - (D0) == 1) (ACC)[k_][e_] = (ACC)[k_][e_] + __uint_as_float((ZW)[0][k_][e_]); \
+        else (ACC)[k_][e_] = (ACC)[k_][e_] + (__uint_as_float((ZW)[0][k_][e_]) + __uint_as_float((ZW)[((D1) - (D0)) - 1][k_][e_])); \
       }                                                                                                \
   }
-  // all-reduce: own + peer (R = 2), (own + h^1) + (h^2 + h^3) (R = 4: the same tree in every workgroup, every node commutative)
-#define RS_POLL_SUM(V, NF, K0, PAR, PROFSLOT)                                                          \
+  // all-reduce: own + peer (R = 2), (own + h^1) + (h^2 + h^3) (R = 4: the same tree in every workgroup, every node commutative).
+  // ZW1: u4 [1][NF] for peer h^1 (PRE: already loaded)
+#define RS_POLL_SUM(V, ZW1, NF, K0, PAR, PROFSLOT, PRE)                                                \
   {                                                                                                    \
-    RS_POLL(V, NF, K0, PAR, 1, 2, PROFSLOT)                                                            \
-    if constexpr (R == 4) RS_POLL(V, NF, K0, PAR, 2, 4, PROFSLOT)                                      \
+    RS_POLL(V, ZW1, NF, K0, PAR, 1, 2, PROFSLOT, PRE)                                                  \
+    if constexpr (R == 4) {                                                                            \
+      u4 zw23_[2][NF];                                                                                 \
+      RS_POLL(V, zw23_, NF, K0, PAR, 2, 4, PROFSLOT, false)                                            \
+    }                                                                                                  \
   }
 
 #define RS_ADAM(ADDR, G, M, V)                                                             \
@@ -557,26 +571,23 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
     unsigned long long* const grow = a.gran + ((size_t)par * RS_MAX_R + hf) * 12;   // [parity][row group][network][wave]
     f4 gA[7];                                                             // W2 tiles, W3 tile, {db2, db3, loss partial, -}, d(log_std)
     f4 gB[NT1 + 1];                                                       // W1 tiles, {db1, -, -, -}
-    __syncthreads();                                                      // b4: h1^T, h2^T, dZ2^T, dO^T complete
-    RS_STAMP(0)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the resets of the previous step are acknowledged by the L2
+    RS_STAMP(0)
+    __syncthreads();                                                      // b4: h1^T, h2^T, dZ2^T, dO^T complete
+    RS_STAMP(1)
+    float gsq = 0.f, psq = 0.f;
+    float gb1, gb2, gb3 = 0.f;
     {
       // ---- dW2, dW3 over this workgroup's 32 rows; db2, db3
       RS_REIDX
-      f4 az2[2];
+      f4 az2[2], az3[2], bh[2][4], b3[2];
 #pragma unroll
-      for (int r4 = 0; r4 < 2; ++r4)
+      for (int r4 = 0; r4 < 2; ++r4) {
         az2[r4] = *reinterpret_cast<const f4*>(lds + S::DZ2T + (16 * ow + j) * LDC + 16 * r4 + 4 * q);
-      f4 bh[2][4];
-#pragma unroll
-      for (int r4 = 0; r4 < 2; ++r4)
+        az3[r4] = *reinterpret_cast<const f4*>(lds + S::DOT + j * LDC + 16 * r4 + 4 * q);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
           bh[r4][nt] = *reinterpret_cast<const f4*>(lds + S::H1T + (16 * nt + j) * LDC + 16 * r4 + 4 * q);
-      f4 az3[2], b3[2];
-#pragma unroll
-      for (int r4 = 0; r4 < 2; ++r4) {
-        az3[r4] = *reinterpret_cast<const f4*>(lds + S::DOT + j * LDC + 16 * r4 + 4 * q);
         b3[r4] = *reinterpret_cast<const f4*>(lds + S::H2T + (16 * ow + j) * LDC + 16 * r4 + 4 * q);
       }
 #pragma unroll
@@ -605,8 +616,8 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
       for (int r = 0; r < 4; ++r) gA[6][r] = red[16 + 4 * q + r] + red[32 + 4 * q + r];
       RS_PUSH(gA, 7, NT1 + 1, par)
     }
-    // ---- off the critical path, before the last image arrives: the x^T operands of dW1 (complete since the step began), this
-    // lane's W1 / b1 parameters (L2 term, backup), the optimiser scalars of the step
+    // ---- the optimiser waits for the last image here anyway (the column waves' last backward product is longer than dW2 / dW3):
+    // the x^T operands of dW1 (complete since b1), this lane's W1 / b1 parameters (L2 term, backup), the optimiser scalars of the step
     f4 bx[2][NT1], pW1[NT1];
     float pb1;
     {
@@ -626,9 +637,12 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
     pw1 *= (double)b1c; pw2 *= (double)b2c;
     float step_size, inv_bc2s;
     adam_scalars(lr, pw1, pw2, step_size, inv_bc2s);
-    RS_STAMP(1)                                                            // dW2, dW3, stores, preloads
+    RS_STAMP(2)                                                            // dW2, dW3, stores, preloads
     __syncthreads();                                                      // b5: dZ1^T complete
-    RS_STAMP(2)
+    RS_STAMP(3)
+    // the first peer's layer-2 / 3 partials (sent at b4: long there): their round trip runs under the dW1 products
+    u4 zwA[1][7];
+    RS_LOADS(zwA, 7, NT1 + 1, par, 1, 2)
     {
       // ---- dW1, db1
       RS_REIDX
@@ -650,12 +664,11 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
       gB[NT1] = f4{quad_row_sum(rs1), 0.f, 0.f, 0.f};
       RS_PUSH(gB, NT1 + 1, 0, par)
     }
-    RS_STAMP(3)                                                            // dW1, stores
+    RS_STAMP(4)                                                            // dW1, stores
     // ---- while layer 1's partials travel: the peers' layer-2 / 3 partials (sent at b4: long there), their L2 terms and norm share
-    float gsq = 0.f, psq = 0.f;
-    float gb1, gb2, gb3 = 0.f;
-    RS_POLL_SUM(gA, 7, NT1 + 1, par, 10)
-    {
+    // (before b5 this work would come straight out of the column waves' last backward product: the two waves of a SIMD add)
+    RS_POLL_SUM(gA, zwA, 7, NT1 + 1, par, 10, true)
+    if (has_l2) {
       // L2 regulariser of the critics (weights AND biases, ppo_lag.py:310-314)
       RS_REIDX
 #pragma unroll
@@ -681,38 +694,67 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
           const float pb3 = lds[L::B3 + j];
           gb3 = vcoef * fmaf(l2x2, pb3, gA[5][1]);
           if (q == 0) { gsq = fmaf(gb3, gb3, gsq); psq = fmaf(pb3, pb3, psq); }
-          if (own_ls) {
+        }
+      }
+    } else {
+      // no regulariser, coefficient 1 (the actor; the cost critic without use_critic_norm): the gradient as it is, no sum p^2
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gsq = fmaf(gA[6][r], gA[6][r], gsq);   // 0 on pad rows
-          }
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gsq = fmaf(gA[nt][r], gA[nt][r], gsq);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gsq = fmaf(gA[4][r], gA[4][r], gsq);
+      gb2 = gA[5][0];
+      if (own_b) gsq = fmaf(gb2, gb2, gsq);
+      if (ow == 0) {
+        gb3 = gA[5][1];
+        if (q_ == 0) gsq = fmaf(gb3, gb3, gsq);
+        if (own_ls) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gsq = fmaf(gA[6][r], gA[6][r], gsq);   // 0 on pad rows
         }
       }
     }
     const float loss_data = gA[5][2] * inv_n;
-    RS_STAMP(4)                                                            // layers 2 / 3: poll, sums, L2 terms
-    RS_POLL_SUM(gB, NT1 + 1, 0, par, 11)
-    RS_STAMP(5)                                                            // layer 1: poll, sums
+    RS_STAMP(5)                                                            // layers 2 / 3: poll, sums, L2 terms
+    {
+      u4 zwB[1][NT1 + 1];
+      RS_POLL_SUM(gB, zwB, NT1 + 1, 0, par, 11, false)
+    }
     // ---- layer 1: L2 term, norm share out, then Adam at once with clip coefficient 1 -- max_grad_norm almost never binds, and the
     // next forward waits for nothing else.  Backups in registers; the joint norm is checked behind b1 (below).
     f4 bmW1[NT1], bvW1[NT1];
     float bmb1, bvb1;
+    unsigned long long gv0 = 0;
     {
       RS_REIDX
+      if (has_l2) {
 #pragma unroll
-      for (int nt = 0; nt < NT1; ++nt)
+        for (int nt = 0; nt < NT1; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {                                       // pad columns hold p == 0, g == 0
-          const float p_ = pW1[nt][r];
-          const float g_ = vcoef * fmaf(l2x2, p_, gB[nt][r]);
-          gB[nt][r] = g_; gsq = fmaf(g_, g_, gsq); psq = fmaf(p_, p_, psq);
-        }
-      gb1 = vcoef * fmaf(l2x2, pb1, gB[NT1][0]);
-      if (own_b) { gsq = fmaf(gb1, gb1, gsq); psq = fmaf(pb1, pb1, psq); }
+          for (int r = 0; r < 4; ++r) {                                     // pad columns hold p == 0, g == 0
+            const float p_ = pW1[nt][r];
+            const float g_ = vcoef * fmaf(l2x2, p_, gB[nt][r]);
+            gB[nt][r] = g_; gsq = fmaf(g_, g_, gsq); psq = fmaf(p_, p_, psq);
+          }
+        gb1 = vcoef * fmaf(l2x2, pb1, gB[NT1][0]);
+        if (own_b) { gsq = fmaf(gb1, gb1, gsq); psq = fmaf(pb1, pb1, psq); }
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gsq = fmaf(gB[nt][r], gB[nt][r], gsq);
+        gb1 = gB[NT1][0];
+        if (own_b) gsq = fmaf(gb1, gb1, gsq);
+      }
       const float wg_sq = wave_sum_lane63(gsq), wp_sq = wave_sum_lane63(psq);
       if (lane == 63) {
         gstore(grow + 4 * netl + ow, ((unsigned long long)tag << 32) | __float_as_uint(wg_sq));
         red[88 + ow] = wp_sq;                                              // sum p^2 shares: read after the next barrier
       }
+      // first look at the norm granules now: for the network that publishes last (the one the step waits for) they are all there
+      // by the time Adam has run, and the poll behind b1 costs no round trip
+      if (lane < 4 * a.n_nets) gv0 = __hip_atomic_load(grow + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
       for (int nt = 0; nt < NT1; ++nt) {
         bmW1[nt] = mW1[nt]; bvW1[nt] = vW1[nt];
@@ -734,7 +776,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
       float mine = 0.f;
       const int ngr = 4 * a.n_nets;
       if (lane < ngr) {                                                     // lane k polls granule k (network k / 4, wave k % 4)
-        unsigned long long v = __hip_atomic_load(grow + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long v = gv0;
         unsigned sp2 = 0;
         while ((unsigned)(v >> 32) != tag) {
           if (*dead != 0.f) break;
@@ -821,6 +863,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
 #undef RS_PUSH
 #undef RS_POLL_SUM
 #undef RS_POLL
+#undef RS_LOADS
   // ---- write back (row group 0 of every network; a launch that timed out leaves theta and the optimiser state untouched)
   if (hf == 0 && *dead == 0.f) {
     RS_REIDX

@@ -34,8 +34,8 @@ p = prof.cpu().view(-1)[:36].view(3, 12).numpy()
 print(f"plain launch: {dt0*1e6/steps:.2f} us/step; instrumented launch: {dt*1e6/steps:.2f} us/step")
 col = ["settle + x^T image", "wait b1 (W1 in place)", "L1 half + h1^T", "wait b2 (W2)", "h1 halves, L2 half + h2^T", "wait b3 (W3)",
        "h2 halves, L3, loss, dO->dZ2 half", "wait b4", "gather issue, dZ2->dZ1 half", "wait b5", "", ""]
-opt = ["wait b4 (images)", "dW2 dW3 + stores, preloads", "wait b5 (dZ1^T)", "dW1 + stores", "layers 2/3: poll, sums, L2 terms",
-       "layer 1: poll, sums", "L2 term W1, share out, Adam W1", "wait b1 + poll norms", "(redo,) Adam W2", "wait b2 + Adam W3 b3 log_std",
+opt = ["wait b3 + loss log + preloads", "wait b4 (images)", "dW2 dW3 + stores", "wait b5 (dZ1^T)", "dW1 + stores",
+       "layers 2/3: poll, sums, L2 terms", "layer 1: poll, sums, L2, share out, Adam W1", "wait b1 + norms, coefficient", "(redo,) Adam W2", "wait b2 + Adam W3 b3 log_std",
        "(poll retries, layers 2/3)", "(poll retries, layer 1)"]
 for row, names, title in ((0, col, "column wave 0"), (1, opt, "optimiser wave 0")):
     tot = p[row][:10].sum()
