@@ -83,6 +83,7 @@ struct RsArgs {
   float* stale_io;                     // critic fit: ||actor.grad||^2 that the joint clip still sees and rescales (cpo.py:557), in / out
   int force_safe;                      // SPO_RS_SAFE=1: write-through exchange stores whatever the placement (tests)
   unsigned long long* prof;            // optional [3][RS_NPHASE] cycle accumulators (instrumented instantiation)
+  int prof_wg;                         // ... of this workgroup (SPO_RS_PROF_WG; default: the last one = the actor's last row group)
 };
 constexpr size_t rs_z_bytes(int R) { return (size_t)2 * 3 * R * R * RS_NS * 4096; }
 constexpr int RS_GRAN_WORDS = 2 * RS_MAX_R * 3 * 4;
@@ -417,7 +418,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
     };
     if (fh_rt == 0) col_loop(std::integral_constant<int, 0>{});
     else col_loop(std::integral_constant<int, 1>{});
-    if (PROF && a.prof && lane == 0 && cw == 0 && wg == a.n_nets * R - 1)
+    if (PROF && a.prof && lane == 0 && cw == 0 && wg == a.prof_wg)
       for (int i = 0; i < RS_NPHASE; ++i) a.prof[i] = pacc[i];
     __syncthreads();                                                      // after the loop: the last update is complete
 #undef RS_REIDX
@@ -753,8 +754,12 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
         red[88 + ow] = wp_sq;                                              // sum p^2 shares: read after the next barrier
       }
       // first look at the norm granules now: for the network that publishes last (the one the step waits for) they are all there
-      // by the time Adam has run, and the poll behind b1 costs no round trip
+      // by the time Adam has run, and the poll behind b1 costs no round trip; this wave's own share does not travel at all
       if (lane < 4 * a.n_nets) gv0 = __hip_atomic_load(grow + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      {
+        const unsigned own_bits = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(wg_sq), 63);
+        if (lane == 4 * netl + ow) gv0 = ((unsigned long long)tag << 32) | own_bits;
+      }
 #pragma unroll
       for (int nt = 0; nt < NT1; ++nt) {
         bmW1[nt] = mW1[nt]; bvW1[nt] = vW1[nt];
@@ -774,6 +779,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
     float coef;
     {
       float mine = 0.f;
+      unsigned sp_n = 0;
       const int ngr = 4 * a.n_nets;
       if (lane < ngr) {                                                     // lane k polls granule k (network k / 4, wave k % 4)
         unsigned long long v = gv0;
@@ -785,9 +791,19 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
           v = __hip_atomic_load(grow + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         mine = __uint_as_float((unsigned)v);
+        sp_n = sp2;
       }
+      if (PROF) {                                                            // (x 1000: the slot also counts layer-2 / 3 poll retries)
+        unsigned mxs = sp_n;
+        for (int off = 32; off >= 1; off >>= 1) { const unsigned o2 = __shfl_xor(mxs, off); mxs = mxs > o2 ? mxs : o2; }
+        pacc[10] += 1000u * mxs;
+      }
+      // fixed order: identical in every wave and workgroup.  v_readlane with constant lane numbers (a ds_bpermute per term -- __shfl --
+      // cost the lone optimiser wave ~1.4 k cycles here); lanes past 4 n_nets hold 0.f: adding them changes nothing
       float total_sq = stale_sq;
-      for (int kk = 0; kk < ngr; ++kk) total_sq += __shfl(mine, kk);        // fixed order: identical in every wave and workgroup
+#pragma unroll
+      for (int kk = 0; kk < 12; ++kk)
+        total_sq += __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(mine), kk));
       const float norm = sqrtf(total_sq);
       coef = a.cfg.max_grad_norm / (norm + 1e-6f);                        // clip_grad_norm_ (torch): eps 1e-6
       coef = coef > 1.f ? 1.f : coef;
@@ -849,7 +865,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
     RS_STAMP(9)                                                            // wait b2 + Adam W3 ...
     if (s + 1 < nsteps) __syncthreads();                                  // b3 of step s + 1
   }
-  if (PROF && a.prof && lane == 0 && ow == 0 && wg == a.n_nets * R - 1)
+  if (PROF && a.prof && lane == 0 && ow == 0 && wg == a.prof_wg)
     for (int i = 0; i < RS_NPHASE; ++i) a.prof[RS_NPHASE + i] = pacc[i];
   __syncthreads();                                                        // after the loop: orders the final image before the write-back
   if (ol == 0 && wg == 0) {
@@ -1046,6 +1062,7 @@ int spo::rs_update_launch(float* theta, float* adam_m, float* adam_v, int64_t ad
   a.pow_b2 = pow((double)cfg_host->beta2, (double)adam_step_host);
   a.n_nets = n_nets; a.first_net = 0; a.stale_io = stale_sq_io; a.prof = prof;
   { const char* e = getenv("SPO_RS_SAFE"); a.force_safe = (e && *e && *e != '0') ? 1 : 0; }
+  { const char* e = getenv("SPO_RS_PROF_WG"); a.prof_wg = (e && *e) ? atoi(e) : n_nets * (cfg_host->batch <= 64 ? 2 : 4) - 1; }
   const int64_t nsteps = (M + cfg_host->batch - 1) / cfg_host->batch;
   SPO_REQUIRE(nsteps < (1ll << 30), "update_rs: too many minibatch steps in one launch");
   if (int rc = rs_scratch(st, &a.zbuf, &a.gran, &a.tag_base, (unsigned)nsteps)) return rc;
