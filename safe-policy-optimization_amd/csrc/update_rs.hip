@@ -213,10 +213,22 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
     auto col_loop = [&](auto FHC) {
     constexpr int FH = decltype(FHC)::value;
     constexpr int M0 = 2 * FH, P0 = 2 - M0;      // own output tiles M0, M0 + 1; the partner wave's P0, P0 + 1
-    RsCol<NT1> nxt;
-    int smp1 = 0;
+    // Pipeline of the column inputs, all of it behind this wave's half of L1 -- where it would otherwise wait for the optimiser waves
+    // (W2) -- and nothing in the stretch between b5 and b1, where the SIMD belongs to the optimiser wave: in step s the rows of
+    // minibatch s + 1 (requested during step s - 1: a whole step to land; barriers do not drain loads) are picked up (pad selects,
+    // x^T image), the rows of minibatch s + 2 are requested, the sample index for s + 3 is loaded.
+    RsCol<NT1> nxt, raw;
+    int smp2 = 0;
     fetch((int64_t)a.perm[perm_pos(0)], nxt);
-    if (nsteps > 1) smp1 = a.perm[perm_pos(1)];
+    if (nsteps > 1) fetch((int64_t)a.perm[perm_pos(1)], raw);
+    if (nsteps > 2) smp2 = a.perm[perm_pos(2)];
+    settle(nxt);
+    if (FH == 0) {
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lds[S::XT + (16 * nt + 4 * q + e) * LDC + lcol] = nxt.x[nt][e];
+    }
     if (PROF) tprev = __builtin_readcyclecounter();
 
     for (int64_t s = 0; s < nsteps; ++s) {
@@ -229,16 +241,6 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
       f4 h1[4], h2[4];
       RS_REIDX
       cur = nxt;
-      settle(cur);
-      const int smp_next = pin(smp1);
-      const int64_t pos2 = (s + 2 < nsteps) ? perm_pos(s + 2) : 0;
-      if (FH == 0) {
-        float* const xt = lds + S::XT + (int)(s & 1) * KIN * LDC;
-#pragma unroll
-        for (int nt = 0; nt < NT1; ++nt)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) xt[(16 * nt + 4 * q + e) * LDC + lcol] = cur.x[nt][e];
-      }
       RS_STAMP(0)                                                        // settle + x^T
       __syncthreads();                                                    // b1: W1 / b1 of the previous step's update in place
       RS_STAMP(1)
@@ -250,7 +252,21 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) lds[S::H1T + (16 * (M0 + t) + 4 * q + r) * LDC + lcol] = h1[M0 + t][r];
       }
-      RS_STAMP(2)                                                        // L1 (own half)
+      if (s + 1 < nsteps) {
+        RS_REIDX
+        settle(raw);
+        nxt = raw;
+        if (s + 2 < nsteps) fetch((int64_t)pin(smp2), raw);
+        if (s + 3 < nsteps) smp2 = a.perm[perm_pos(s + 3)];
+        if (FH == 0) {
+          float* const xt = lds + S::XT + (int)((s + 1) & 1) * KIN * LDC;
+#pragma unroll
+          for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xt[(16 * nt + 4 * q + e) * LDC + lcol] = nxt.x[nt][e];
+        }
+      }
+      RS_STAMP(2)                                                        // L1 (own half), next minibatch's columns
       __syncthreads();                                                    // b2: W2 / b2 in place; both halves of h1^T written
       RS_STAMP(3)
       if (reinterpret_cast<const int*>(red)[98] == (int)(s & 0x3fffffff) && s > 0) {
@@ -373,9 +389,6 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
       RS_STAMP(7)
       {
         RS_REIDX
-        // rows of the next minibatch, the index of the one after it: in flight under the last backward product
-        if (s + 1 < nsteps) fetch((int64_t)smp_next, nxt);
-        if (s + 2 < nsteps) smp1 = a.perm[pos2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
