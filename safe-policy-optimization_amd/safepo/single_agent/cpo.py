@@ -392,7 +392,14 @@ class CPOEngine(PPOLagEngine):
             return self._split or None
         self._split = False
         batch = int(self.cfg.get("batch_size", 0))
-        if (self.comm.world_size != 1 or batch != 128 or self.M % batch != 0 or os.environ.get("SPO_CPO_SPLIT", "1") == "0"):
+        mode = os.environ.get("SPO_CPO_SPLIT", "auto")
+        if self.comm.world_size != 1 or batch != 128 or self.M % batch != 0 or mode == "0":
+            return None
+        # round 6: spo_critic_fit_iter runs the ROW-SPLIT kernel (csrc/update_rs.hip: four workgroups of 32 rows per critic, ONE
+        # replica, one hand-off through the XCD's L2) where the shape fits -- faster than this two-replica form, which stays for
+        # SPO_UPDATE_FORM < 3, for shapes the row-split kernel does not take, and on request (SPO_CPO_SPLIT=force: tests)
+        if (mode != "force" and int(os.environ.get("SPO_UPDATE_FORM", "3")) >= 3
+                and self.lib.spo_update_rs_supported(self.D, self.A, batch, 2)):
             return None
         import ctypes
         lib = self.lib

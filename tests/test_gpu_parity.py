@@ -1219,7 +1219,7 @@ def test_cpo_critic_fit_two_launch_form_vs_oracle_and_one_launch_form(dev, monke
     cfg.update(learning_iters=iters, batch_size=128)
 
     def run(split: bool):
-        monkeypatch.setenv("SPO_CPO_SPLIT", "1" if split else "0")
+        monkeypatch.setenv("SPO_CPO_SPLIT", "force" if split else "0")   # "0": spo_critic_fit_iter = the row-split kernel (round 6)
         torch.manual_seed(11)
         pol = ActorVCritic(D, A).to(dev)
         eng = CPOEngine(pol, 1, M, cfg, dev)
@@ -1360,7 +1360,7 @@ def test_cpo_full_size_critic_fit_drift_envelope(dev, form, monkeypatch):
     import envelope as E
     from safepo.single_agent.cpo import CPOEngine, default_cfg
     from safepo.common.model import ActorVCritic
-    monkeypatch.setenv("SPO_CPO_SPLIT", "1" if form == "split_one_grid" else "0")
+    monkeypatch.setenv("SPO_CPO_SPLIT", "force" if form == "split_one_grid" else "0")   # one_launch: the row-split kernel (round 6)
     torch.set_num_threads(8)
     N, T, D, A, batch = 4096, 128, 60, 8, 128
     M = N * T
