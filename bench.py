@@ -370,6 +370,44 @@ def run_epochs(algo, a, comm, dev, N, T, D, A, steps, warmup, time_gae):
             "epoch": epoch, "gae_graph": gae_graph, "gae_disp": gae_disp, "per_rank": per_rank, "exchange": exchange}
 
 
+def _update_kernel_entry(us_step, upd_counters, world):
+    """The kernel that owns ~99 % of config 2's GPU time, named by the form that ran (SPO_UPDATE_FORM, csrc/update.hip)."""
+    form = int(os.environ.get("SPO_UPDATE_FORM", "3"))
+    if world == 1 and form >= 3:
+        mfma, other = 192, 2860          # per SIMD and step: 72 (optimiser wave) + 120 (column wave) MFMAs; other instructions of both
+        return {"kernel": "ppo_update_rs_kernel<64, 2> (persistent; row-split: 3 networks x 2 row groups of 32 rows = 6 co-XCD workgroups, "
+                          "4 optimiser + 4 column waves each; one L2 hand-off per layer group and step; csrc/update_rs.hip)",
+                "bound": "issue time of a SIMD (matrix + vector instructions of its two waves add) along the step's dependency chain",
+                "us_per_minibatch_step": round(us_step, 3),
+                "mfma_floor_us": round(mfma * 32 / 2.4e9 * 1e6, 3),
+                "frac": round((mfma * 32 / 2.4e9) / (us_step * 1e-6), 4),
+                "redo_counters": upd_counters,
+                "simd_sum_floor_us": round((mfma * 32 + other * 4) / 2.4e9 * 1e6, 3),
+                "frac_of_simd_sum_floor": round(((mfma * 32 + other * 4) / 2.4e9) / (us_step * 1e-6), 4),
+                "previous_form_us_per_minibatch_step": 10.51,
+                "note": "mfma_floor = the 192 v_mfma_f32_16x16x4_f32 issue slots (32 cycles each) of a SIMD per step at 2.4 GHz: 120 of "
+                        "its column wave (half of the output features of 16 of the row group's 32 columns through forward / backward) "
+                        "+ 72 of its optimiser wave (weight-gradient products over 32 rows); a SIMD's vector instructions do not "
+                        "overlap its matrix instructions (tools/probes/mfma_valu_overlap.hip), so the floor of a step is MFMA cycles + "
+                        "~2860 other instructions of the two waves x 4 cycles = simd_sum_floor (instruction counts: tools/"
+                        "isa_scratch_map.py on the built kernel); interval budget: profiles/r06/update_phase_cycles_rs.txt; "
+                        "previous_form = ppo_update_h_kernel (SPO_UPDATE_FORM=2, one workgroup per network), rounds 2-5; DESIGN.md 3.3.2"}
+    return {"kernel": "ppo_update_h_kernel<64> (persistent; 4 main + 4 helper waves per network)"
+                      + (" with the in-kernel cross-rank gradient exchange" if world > 1 else ""),
+            "bound": "fp32 MFMA issue of one CU per network + per-step latency chain",
+            "us_per_minibatch_step": round(us_step, 3),
+            "mfma_floor_us": round(368 * 32 / 2.4e9 * 1e6, 3),
+            "frac": round((368 * 32 / 2.4e9) / (us_step * 1e-6), 4),
+            "redo_counters": upd_counters,
+            "simd_sum_floor_us": round((368 * 32 + 2400 * 4) / 2.4e9 * 1e6, 3),
+            "frac_of_simd_sum_floor": round(((368 * 32 + 2400 * 4) / 2.4e9) / (us_step * 1e-6), 4),
+            "note": "mfma_floor = the 368 MFMA issue slots of a main wave at 2.4 GHz; on this part a SIMD's vector "
+                    "instructions do not overlap its matrix instructions (tools/probes/mfma_valu_overlap.hip, "
+                    "profiles/r03/mfma_valu_overlap.txt: two waves together take exactly the sum of each alone), so the "
+                    "floor of one step on one CU is MFMA cycles + ~2400 VALU instructions of the main and helper wave "
+                    "x 4 cycles = simd_sum_floor; DESIGN.md 3.3"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -670,19 +708,7 @@ def main():
         "early_stopping_epoch": faithful,
         # the kernel that owns 99 % of the GPU time is not HBM- but latency/matrix-bound: 327 680 strictly sequential
         # optimiser steps, each at least 368 v_mfma_f32_16x16x4_f32 (32 cycles each) per wave on one CU per network
-        "update_kernel": ({"kernel": "ppo_update_h_kernel<64> (persistent; 4 main + 4 helper waves per network)",
-                           "bound": "fp32 MFMA issue of one CU per network + per-step latency chain",
-                           "us_per_minibatch_step": round(us_step, 3),
-                           "mfma_floor_us": round(368 * 32 / 2.4e9 * 1e6, 3),
-                           "frac": round((368 * 32 / 2.4e9) / (us_step * 1e-6), 4),
-                           "redo_counters": upd_counters,
-                           "simd_sum_floor_us": round((368 * 32 + 2400 * 4) / 2.4e9 * 1e6, 3),
-                           "frac_of_simd_sum_floor": round(((368 * 32 + 2400 * 4) / 2.4e9) / (us_step * 1e-6), 4),
-                           "note": "mfma_floor = the 368 MFMA issue slots of a main wave at 2.4 GHz; on this part a SIMD's vector "
-                                   "instructions do not overlap its matrix instructions (tools/probes/mfma_valu_overlap.hip, "
-                                   "profiles/r03/mfma_valu_overlap.txt: two waves together take exactly the sum of each alone), so the "
-                                   "floor of one step on one CU is MFMA cycles + ~2400 VALU instructions of the main and helper wave "
-                                   "x 4 cycles = simd_sum_floor; DESIGN.md 3.3"}
+        "update_kernel": (_update_kernel_entry(us_step, upd_counters, world)
                           if a.algo == "ppo_lag" else None),
         ("kl_kernel" if a.algo == "ppo_lag" else "cpo_fvp"): kl_entry,
         "cpu_baseline": cpu,

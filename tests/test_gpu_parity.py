@@ -530,7 +530,10 @@ def _synthetic_update_problem(M, D, A, seed):
 
 
 @pytest.mark.parametrize("M,D,A,batch", [(256, 60, 8, 64), (150, 60, 8, 64), (200, 12, 2, 64), (64, 33, 5, 64),
-                                         (300, 60, 8, 128), (40, 20, 3, 64), (150, 100, 4, 64), (130, 128, 16, 64)])
+                                         (300, 60, 8, 128), (40, 20, 3, 64), (150, 100, 4, 64), (130, 128, 16, 64),
+                                         # round 6, the row-split kernel's edges: a second row group without rows (batch <= 32), a
+                                         # ragged one (batch 33 / 50), one-feature and 64-feature observations, act_dim 1 and 16
+                                         (100, 5, 1, 20), (77, 64, 16, 7), (165, 16, 3, 33), (250, 1, 2, 50), (96, 48, 16, 32)])
 def test_minibatch_grad_and_step_vs_oracle(dev, M, D, A, batch):
     """First-minibatch gradient (pre-clip), losses, and parameters after one full pass
     (partial last batch included) against torch autograd + Adam on the CPU oracle."""
@@ -1888,7 +1891,7 @@ def test_end_to_end_learning_on_action_dependent_env(dev):
     assert costs[-1] < costs[0]                                    # and the cost (|a_0| > 0.5 rate) comes down
 
 
-@pytest.mark.parametrize("form", ["main_plus_helper_waves", "four_wave_form"])
+@pytest.mark.parametrize("form", ["row_split_form", "main_plus_helper_waves", "four_wave_form"])
 def test_long_trajectory_parity_1024_steps(dev, form):
     """1 024 consecutive optimiser steps (one pass over 65 536 samples) against the CPU oracle with the drift envelope:
     per-minibatch losses along the whole trajectory and the parameters after 8 / 64 / 512 / 1 024 steps stay within
@@ -1896,11 +1899,13 @@ def test_long_trajectory_parity_1024_steps(dev, form):
     the 8 192-step case is test_full_size_update_parity_drift_envelope).  Both forms of the persistent kernel: the
     four-wave form still serves the critic fit of the second-order scripts, the KL-penalty losses, obs_dim > 64 and the
     data-parallel launches (SPO_UPDATE_FORM is read once per process, so that form runs in a child process)."""
-    if form == "four_wave_form":
+    if form != "row_split_form":
+        # (the row-split kernel of round 6 is the default form; the other two still serve the data-parallel launches, the KL-penalty
+        # losses, obs_dim > 64 and SPO_UPDATE_FORM=2 / 0: each in a child process, the switch is read once per process)
         import subprocess, sys
-        env = dict(os.environ, SPO_UPDATE_FORM="0")
+        env = dict(os.environ, SPO_UPDATE_FORM="0" if form == "four_wave_form" else "2")
         r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__, "-k",
-                            "test_long_trajectory_parity_1024_steps and main_plus_helper_waves"], env=env,
+                            "test_long_trajectory_parity_1024_steps and row_split_form"], env=env,
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         return
@@ -3135,6 +3140,89 @@ def test_full_size_update_parity_drift_envelope(dev):
     assert eng.adam_step == 8192
     rep = _assert_trajectory_in_envelope(runs, problem, sd0, perm, 64, ks, "full-size learning iteration")
     print("drift envelope (ratio <= 1 passes):", rep)
+
+
+def test_row_split_kernel_is_the_default_and_exchange_modes_agree(dev, monkeypatch):
+    """Round 6: spo_ppo_lag_update_iter runs the row-split kernel (csrc/update_rs.hip) where spo_update_rs_supported.  Its exchange
+    stores are plain when the placement census finds the six workgroups on one XCD and write-through otherwise (SPO_RS_SAFE=1
+    forces that): correctness must not depend on placement, so both modes give the same bits -- over three consecutive launches
+    on one stream (tags and slot parities carry over from launch to launch), with the clip active on part of the steps (the
+    speculative layer-1 update is restored and redone, the column waves repeat L1), and the debug counters see steps and redos."""
+    import ctypes
+    from safepo import _abi
+    from safepo.common.engine import PPOLagEngine
+    from safepo.common.model import ActorVCritic
+    lib = _abi.load()
+    assert lib.spo_update_rs_supported(60, 8, 64, 3) == 1 and lib.spo_update_rs_supported(64, 16, 1, 3) == 1
+    assert lib.spo_update_rs_supported(65, 8, 64, 3) == 0 and lib.spo_update_rs_supported(60, 17, 64, 3) == 0
+    assert lib.spo_update_rs_supported(60, 8, 65, 3) == 0 and lib.spo_update_rs_supported(60, 8, 128, 2) == 1
+    assert lib.spo_update_rs_supported(60, 8, 129, 2) == 0 and lib.spo_update_rs_supported(60, 8, 64, 1) == 0
+    if int(os.environ.get("SPO_UPDATE_FORM", "3")) < 3:
+        pytest.skip("SPO_UPDATE_FORM selects an older form in this process")
+    M, D, A, batch = 64 * 37 + 19, 60, 8, 64
+    problem = _synthetic_update_problem(M, D, A, seed=31)
+    cfg = {"hidden_sizes": [64, 64], "gamma": 0.99, "target_kl": 1e9, "batch_size": batch, "learning_iters": 1, "max_grad_norm": 1.2}
+    g = torch.Generator().manual_seed(9)
+    perms = [torch.randperm(M, generator=g).to(torch.int32).to(dev) for _ in range(3)]
+    outs = {}
+    for mode in ("fast", "safe"):
+        monkeypatch.setenv("SPO_RS_SAFE", "1" if mode == "safe" else "0")
+        torch.manual_seed(4)
+        pol = ActorVCritic(D, A).to(dev)
+        eng = PPOLagEngine(pol, 1, M, cfg, dev)
+        _fill_update_problem(eng, problem)
+        c4 = (ctypes.c_ulonglong * 4)()
+        _abi.check(lib.spo_debug_update_counters(c4, 1), "counters")
+        losses = [eng.learning_iter(p).clone() for p in perms]
+        eng.check_sync_error()
+        _abi.check(lib.spo_debug_update_counters(c4, 1), "counters")
+        nst = (M + batch - 1) // batch
+        assert int(c4[0]) == 3 * nst, (list(c4), nst)
+        assert 0 < int(c4[1]) < 3 * nst, list(c4)            # clipped on part of the steps: the late-verdict path ran
+        outs[mode] = (pol.theta.clone(), eng.adam_m.clone(), eng.adam_v.clone(), torch.stack(losses))
+    for x, y in zip(outs["fast"], outs["safe"]):
+        assert torch.equal(x, y)
+    assert torch.isfinite(outs["fast"][0]).all() and torch.isfinite(outs["fast"][3]).all()
+
+
+@pytest.mark.parametrize("M,D,batch", [(128 * 9 + 70, 60, 128), (100 * 7, 33, 100), (65 * 5 + 3, 64, 65), (64 * 6 + 10, 12, 64),
+                                       (30 * 8, 60, 30)])
+def test_row_split_critic_fit_shapes_vs_oracle(dev, M, D, batch, monkeypatch):
+    """The second-order scripts' critic fit (cpo.py:541-571) on the row-split kernel: four row groups per critic above 64 rows per
+    minibatch, two up to 64 -- ragged and partial minibatches, the stale actor gradient in (and rescaled by) the joint clip --
+    against the restatement in float32 (first steps at 1e-5) and under the float64 yardstick after the pass."""
+    import envelope as E
+    from safepo.single_agent.cpo import CPOEngine, default_cfg
+    from safepo.common.model import ActorVCritic
+    if int(os.environ.get("SPO_UPDATE_FORM", "3")) < 3:
+        pytest.skip("SPO_UPDATE_FORM selects an older form in this process")
+    monkeypatch.setenv("SPO_CPO_SPLIT", "0")
+    A = 4
+    obs, _a, _l, tgt_r, tgt_c, _adv = _synthetic_update_problem(M, D, A, seed=M)
+    perm = torch.randperm(M, generator=torch.Generator().manual_seed(2)).to(torch.int32)
+    torch.manual_seed(M + 1)
+    pol = ActorVCritic(D, A).to(dev)
+    cfg = dict(default_cfg)
+    cfg.update(learning_iters=1, batch_size=batch)
+    eng = CPOEngine(pol, 1, M, cfg, dev)
+    assert eng.lib.spo_update_rs_supported(D, A, batch, 2) == 1
+    bd = eng.buffer.data
+    bd["obs"].copy_(obs.view(1, M, D)); bd["target_value_r"].copy_(tgt_r.view(1, M)); bd["target_value_c"].copy_(tgt_c.view(1, M))
+    sd0 = {k: v.detach().cpu().clone() for k, v in pol.state_dict().items()}
+    eng.stale_sq.fill_(2500.0)                         # a stale actor gradient of norm 50: the joint clip (40) is active
+    fit = eng.critic_fit(perm_fn=lambda it: perm.to(dev))
+    assert eng._split in (None, False)
+    nst = (M + batch - 1) // batch
+    lh = torch.cat(fit["losses"], 0).double().cpu().numpy()
+    assert lh.shape == (nst, 2)
+    n_crit = pol.log_std_offset
+    l32, t32 = _oracle_critic_trajectory(sd0, obs, tgt_r, tgt_c, perm, batch, nst, torch.float32, (nst,), 50.0)
+    l64, t64 = _oracle_critic_trajectory(sd0, obs, tgt_r, tgt_c, perm, batch, nst, torch.float64, (nst,), 50.0)
+    np.testing.assert_allclose(lh[:4], l32[:4], rtol=1e-5, atol=1e-6)
+    E.assert_loss_envelope(lh, l32, l64, f"row-split critic fit {M}/{D}/{batch}", window=nst)
+    E.assert_theta_envelope(pol.theta[:n_crit].double().cpu().numpy(), t32[nst], t64[nst], f"row-split critic fit {M}/{D}/{batch}")
+    # the stale norm was rescaled by every step's clip coefficient (cpo.py:557): strictly smaller, still positive
+    assert 0.0 < float(eng.stale_sq.item()) < 2500.0
 
 
 # ---------------------------------------------------------------------------------------------------------------------
