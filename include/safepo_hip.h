@@ -33,7 +33,8 @@
 extern "C" {
 #endif
 
-#define SPO_ABI_VERSION 1
+#define SPO_ABI_VERSION 2        /* 2 (round 6): pow4_dev of spo_wide_clip_adam_dev(_log) is double[6], a negative learning-rate entry
+                                 * means "the cfg's"; spo_update_rs_supported; the row-split form behind spo_ppo_lag_update_iter */
 #define SPO_HIDDEN 64          /* hidden width the MLP kernels are specialised for          */
 #define SPO_MAX_ACT 16         /* act_dim <= 16 (one MFMA output tile; LDS-resident kernels) */
 #define SPO_MAX_OBS 128        /* obs_dim <= 128 (LDS-resident kernels; CPO full-batch kernels: 64) */
@@ -624,8 +625,8 @@ int spo_wide_linesearch_sums(const float* mean_new, const float* log_std_new, co
                              int act_dim, double* partial_ws, int partial_capacity, double* sums3_inout, int accumulate,
                              void* stream);
 /* spo_wide_clip_adam_dev -- spo_wide_clip_adam_ex with the optimiser clocks on the DEVICE: pow4_dev = double[6] = {beta1^t, beta2^t of
- * the critics' optimisers, beta1^t, beta2^t of the actor's} before this step, then {lr_actor, lr_critic} (each: > 0 overrides the
- * cfg's value, so a schedule does not change a captured launch's arguments); the clocks of the optimisers inside the Adam range
+ * the critics' optimisers, beta1^t, beta2^t of the actor's} before this step, then {lr_actor, lr_critic} (each: >= 0 overrides the
+ * cfg's value, so a schedule does not change a captured launch's arguments; negative: the cfg's -- ABI 2); the clocks of the optimisers inside the Adam range
  * advance on the device.  No argument changes from one minibatch step to the next, so the launch sequence of a step (gathers,
  * spo_mlp_forward / backward, loss kernels, this) can be captured once as a HIP graph and replayed: the wide path at the reference's
  * default batch of 64 is launch-bound (~70 launches per step).  The caller keeps pow4_dev in step with its host-side step counts. */

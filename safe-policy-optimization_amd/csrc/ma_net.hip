@@ -3460,7 +3460,7 @@ extern "C" int spo_wide_linesearch_sums(const float* mean_new, const float* log_
 }
 
 // Device-resident optimiser clocks: pow4_dev = double[6] = {beta1^t, beta2^t of the critics' optimisers, beta1^t, beta2^t of the actor's}
-// BEFORE this step, then {lr_actor, lr_critic} (0: take the cfg's).  The clocks of the optimisers inside [adam_begin, adam_end) advance by one step on the device (one thread, between the
+// BEFORE this step, then {lr_actor, lr_critic} (negative: take the cfg's).  The clocks of the optimisers inside [adam_begin, adam_end) advance by one step on the device (one thread, between the
 // norm and the Adam pass), so the launch sequence of a minibatch step has no host-side argument that changes from step to step and
 // can be captured once as a HIP graph and replayed (the wide path at small batches is launch-bound: ~70 launches per step).
 namespace {
@@ -3471,7 +3471,8 @@ __global__ __launch_bounds__(256) void wide_adam_dev_kernel(WideAdamExArgs x, co
   float ss_a, ss_c, bc2s_a, bc2s_c;
   // learning rates: device-resident next to the clocks when set (> 0) -- the actor's follows a per-epoch schedule, and a value baked
   // into a captured launch would make every epoch capture a new graph
-  const float lr_a = pow4[4] > 0.0 ? (float)pow4[4] : a.lr_actor, lr_c = pow4[5] > 0.0 ? (float)pow4[5] : a.lr_critic;
+  // (a NEGATIVE entry means "take the cfg's": a scheduled or frozen learning rate of exactly 0 is honoured -- ABI 2)
+  const float lr_a = pow4[4] >= 0.0 ? (float)pow4[4] : a.lr_actor, lr_c = pow4[5] >= 0.0 ? (float)pow4[5] : a.lr_critic;
   adam_scalars(lr_a, pow4[2], pow4[3], ss_a, bc2s_a);                 // pow4 already advanced: beta^(t+1)
   adam_scalars(lr_c, pow4[0], pow4[1], ss_c, bc2s_c);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.P; i += (int64_t)gridDim.x * 256) {

@@ -1391,6 +1391,24 @@ __device__ __forceinline__ bool split_census(const UpdArgs& a0, const int wg) {
       if ((unsigned)v != myx) s_other = 1;
     }
     __syncthreads();
+    // Second round: every workgroup publishes its OWN verdict and takes the AND of all of them, so a census that timed
+    // out in one workgroup only cannot leave that workgroup on the uncached body while its peers run the L2 body (each would spin on
+    // words the other never writes: a clean error instead -- and, with everybody resident, a clean agreement on the uncached form)
+    if (tid == 0)
+      __hip_atomic_store(a0.xr_census + 16 + wg, ((unsigned long long)a0.xr_census_tag << 32) | (s_other == 0 ? 1u : 0u),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (tid < nwg) {
+      unsigned long long v = __hip_atomic_load(a0.xr_census + 16 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned spins = 0;
+      while ((unsigned)(v >> 32) != a0.xr_census_tag) {
+        if (++spins > (1u << 22)) { s_other = 1; *a0.err = 3; break; }   // (a peer workgroup is not resident: the launch cannot work)
+        __builtin_amdgcn_s_sleep(1);
+        v = __hip_atomic_load(a0.xr_census + 16 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if ((unsigned)v != 1u) s_other = 1;
+    }
+    __syncthreads();
     local = (s_other == 0);
     __syncthreads();
   }
@@ -3360,6 +3378,10 @@ static int split_local_for(hipStream_t st, UpdArgs& a, UpdArgs& b) {
     if (g_split_local[i].dev == dev && g_split_local[i].stream == (void*)st) sl = &g_split_local[i];
   if (!sl) {
     if (g_split_local_n == SPLIT_LOCAL_MAX) return 0;               // (table full: the uncached regions, as before round 5)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;        // (allocation + memset would invalidate a capture)
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+      return spo::fail(-1, "split critic fit: first launch on a stream under capture (the cached exchange regions are allocated on "
+                           "first use: launch once outside the capture)");
     void* p = nullptr;
     if (int rc = spo::hip_check(hipMalloc(&p, 2 * XR_REGION_BYTES + 256), "hipMalloc(split exchange, cached)")) return rc;
     if (int rc = spo::hip_check(hipMemset(p, 0, 2 * XR_REGION_BYTES + 256), "hipMemset(split exchange)")) { (void)hipFree(p); return rc; }

@@ -130,6 +130,10 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
   const int c_lo = 64 * ks, DS = (D - c_lo) < 64 ? (D - c_lo) : 64;      // this slice's columns [c_lo, c_lo + DS)
   float* const red = lds + L::RED;
   float* const st_m = a.adam_m; float* const st_v = a.adam_v;
+  // red[251]: set by the first poll of this workgroup that times out: from then on nobody in the workgroup waits
+  // again (one bounded wait per launch, not three per step), the step loop ends at its next top, and the launch leaves theta and
+  // the optimiser state untouched -- the caller sees the error word and can fall back to the launch-per-layer path
+  volatile float* const dead = red + 251;
 
   // ---- stage the slice of the network (pads zeroed)
   for (int i = tid; i < L::XT / 4; i += 256) reinterpret_cast<f4*>(lds)[i] = f4{0.f, 0.f, 0.f, 0.f};
@@ -346,6 +350,7 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
   float db1 = 0.f, db2 = 0.f, db3[KS_NO];
 
   for (int64_t e = 0; e < nchunks; ++e) {
+    if (*dead != 0.f) break;                                           // (uniform: written before the barrier that ended the last chunk)
     const int64_t s = (CFIT && H == 2) ? (e >> 1) : e;
     const int h = (CFIT && H == 2) ? (int)(e & 1) : 0;
     const int64_t base = s * B;
@@ -432,7 +437,8 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) ok = ok && (zw[k][e] != 0xFFFFFFFFu);
             if (ok) break;
-            if (++spins > KS_SPIN_LIMIT) { *a.err = 1; break; }      // bounded: never hang the GPU
+            if (*dead != 0.f) break;                                 // (a poll of this workgroup has timed out: stop waiting)
+            if (++spins > KS_SPIN_LIMIT) { *a.err = 1; *dead = 1.f; break; }      // bounded AND sticky: never hang the GPU
             __builtin_amdgcn_s_sleep(1);
           }
 #ifdef SPO_KS_PROF
@@ -441,16 +447,19 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
 #pragma unroll
           for (int k = 0; k < KS_MAX_SLICES; ++k)
             zstore(sentinel, (k < S && k != ks) ? mine + (unsigned)(k * 4 + fq) * 4096u : (unsigned)KS_ZDUMP_OFF);
+          // the S partials in a FIXED PAIRWISE order, ((0 + 1) + (2 + 3)) + ((4 + 5) + (6 + 7)) with 0.f for slices past S (x + 0.f
+          // is exact): round 6 -- the sequential order of round 5 put up to seven roundings in a row on top of each slice's
+          // 64-product MFMA chain; a blocked sgemm (the reference's arithmetic) sums short partials pairwise as well
           f4 acc;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float t = (ks == 0) ? z1[fq][e] : __uint_as_float(zw[0][e]);
+            float v[KS_MAX_SLICES];
 #pragma unroll
-            for (int k = 1; k < KS_MAX_SLICES; ++k) {
-              const float v = (k == ks) ? z1[fq][e] : __uint_as_float(zw[k][e]);
-              t = (k < S) ? t + v : t;
+            for (int k = 0; k < KS_MAX_SLICES; ++k) {
+              const float x = (k == ks) ? z1[fq][e] : __uint_as_float(zw[k][e]);
+              v[k] = (k < S) ? x : 0.f;
             }
-            acc[e] = t;
+            acc[e] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
           }
           z1[fq] = acc;
           u4 w;
@@ -476,7 +485,8 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) ok = ok && (zg[fq][e] != 0xFFFFFFFFu);
           if (ok) break;
-          if (++spins > KS_SPIN_LIMIT) { *a.err = 1; break; }
+          if (*dead != 0.f) break;
+          if (++spins > KS_SPIN_LIMIT) { *a.err = 1; *dead = 1.f; break; }
           __builtin_amdgcn_s_sleep(1);
         }
 #ifdef SPO_KS_PROF
@@ -841,7 +851,8 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
         unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
         while ((unsigned)(v >> 32) != tag) {
-          if (++spins > KS_SPIN_LIMIT) { *a.err = 1; break; }         // bounded: never hang the GPU
+          if (*dead != 0.f) break;
+          if (++spins > KS_SPIN_LIMIT) { *a.err = 1; *dead = 1.f; break; }         // bounded AND sticky: never hang the GPU
           __builtin_amdgcn_s_sleep(1);
           v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -882,6 +893,9 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
     __syncthreads();
     KS_STAMP(9)                                                        // Adam + barrier
   }
+  __syncthreads();
+  const bool timed_out = (*dead != 0.f);                               // (uniform over the workgroup)
+  if (timed_out) return;                                               // no write-back: theta, adam_m, adam_v, *stale_io as they were
   if (nsteps > 0) { adam_w2(); adam_w3_rest(); __syncthreads(); }     // the last step's deferred half
   if (CFIT && a.stale_io && tid == 0 && wg == 0) *a.stale_io = stale_sq;
 #undef KS_ADAM
@@ -948,7 +962,7 @@ __device__ __forceinline__ void ks_entry(const KsArgs& a) {
     unsigned long long* const xid = a.gran + 2 * 2 * 3 * KS_MAX_SLICES;
     const unsigned myx = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;      // HW_REG_XCC_ID
     if (tid == 0) {
-      red[250] = 0.f;
+      red[250] = 0.f; red[251] = 0.f;
       __hip_atomic_store(xid + wg, ((unsigned long long)a.tag_base << 32) | myx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();

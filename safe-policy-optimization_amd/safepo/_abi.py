@@ -66,6 +66,8 @@ MAX_OBS, MAX_ACT, CPO_MAX_OBS, WIDE_MAX_ACT = 128, 16, 64, 64   # SPO_MAX_OBS, S
 WIDE_ACTOR_CLIP, WIDE_ACTOR_SURR, WIDE_ACTOR_KLPEN = 0, 1, 2     # spo_wide_actor_loss modes
 GAE_PARTIAL_STRIDE = 16                            # include/safepo_hip.h SPO_GAE_PARTIAL_STRIDE (doubles per workgroup)
 
+ABI_VERSION = 2          # include/safepo_hip.h SPO_ABI_VERSION
+
 PROTOTYPES = {
     "spo_abi_version": (c_int, []),
     "spo_last_error": (c_char_p, []),
@@ -207,8 +209,9 @@ def load(path: str | None = None):
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.spo_abi_version() != 1:
-        raise SpoError(f"ABI version mismatch: library {lib.spo_abi_version()} != binding 1")
+    if lib.spo_abi_version() != ABI_VERSION:
+        raise SpoError(f"ABI version mismatch: library {lib.spo_abi_version()} != binding {ABI_VERSION} (stale "
+                       "libsafepo_hip.so: rebuild with `python -c 'import __graft_entry__ as g; g.build()'`)")
     if path is None:
         _lib = lib
         global _lib_loaded_from

@@ -261,8 +261,8 @@ class PeerExchange:
             if not lib.spo_p2p_form_valid(form, self.world):
                 continue
             _abi.check(lib.spo_p2p_select_form(form), "spo_p2p_select_form")
-            us = float("inf")
-            for rep in range(2):                            # first launch: lazy per-kernel set-up
+            us, failed = float("inf"), False
+            for rep in range(2):                            # first launch: lazy per-kernel set-up (untimed); an error in EITHER disqualifies
                 theta, m, v = theta0.clone(), torch.zeros(P, **f32), torch.zeros(P, **f32)
                 torch.cuda.synchronize(dev)
                 comm.barrier()
@@ -277,26 +277,41 @@ class PeerExchange:
                 err = int(sync_ws[8].item()) & 0xFFFFFFFF
                 if rc or err:                               # a peer never answered inside the bounded waits: not a candidate
                     sync_ws[8] = 0
-                    us = float("inf")
-            table[form] = slowest(us)
+                    failed = True
+            table[form] = slowest(float("inf") if failed else us)
         rccl_us = None
         if with_rccl:
-            n_r = 24
+            # (the same treatment as the in-kernel forms -- an untimed warm-up pass for the lazy RCCL / kernel set-up, then a
+            # timed pass of comparable length)
+            n_warm, n_r = 16, min(steps, 96)
             theta, m, v = theta0.clone(), torch.zeros(P, **f32), torch.zeros(P, **f32)
             fg, l3 = torch.zeros(P, **f32), torch.zeros(3, **f32)
             idx = perm[:B]
+
+            def rccl_steps(n, k0):
+                for k in range(k0, k0 + n):
+                    lib.spo_ppo_lag_grad(_abi.ptr(theta), _abi.ptr(obs), _abi.ptr(act), _abi.ptr(logp), _abi.ptr(tgt_r), _abi.ptr(tgt_c),
+                                         _abi.ptr(adv), _abi.ptr(idx), B, B, cfg, _abi.ptr(fg), _abi.ptr(l3), _abi.stream_ptr())
+                    comm.all_reduce_sum_(fg)
+                    lib.spo_clip_adam(_abi.ptr(theta), _abi.ptr(m), _abi.ptr(v), _abi.ptr(fg), k, 1.0 / self.world, cfg, _abi.stream_ptr())
+            rccl_steps(n_warm, 0)
             torch.cuda.synchronize(dev)
             comm.barrier()
             t0 = time.perf_counter()
-            for k in range(n_r):
-                lib.spo_ppo_lag_grad(_abi.ptr(theta), _abi.ptr(obs), _abi.ptr(act), _abi.ptr(logp), _abi.ptr(tgt_r), _abi.ptr(tgt_c),
-                                     _abi.ptr(adv), _abi.ptr(idx), B, B, cfg, _abi.ptr(fg), _abi.ptr(l3), _abi.stream_ptr())
-                comm.all_reduce_sum_(fg)
-                lib.spo_clip_adam(_abi.ptr(theta), _abi.ptr(m), _abi.ptr(v), _abi.ptr(fg), k, 1.0 / self.world, cfg, _abi.stream_ptr())
+            rccl_steps(n_r, n_warm)
             torch.cuda.synchronize(dev)
             rccl_us = slowest((time.perf_counter() - t0) / n_r * 1e6)
         live = {f: u for f, u in table.items() if u != float("inf")}
         best = min(live, key=lambda f: (live[f], f)) if live else None
+        # Reproducibility: the forms add the ranks' gradients in different orders, so WHICH form runs decides the bits of a
+        # seeded run.  The deterministic default policy (csrc/update.hip xr_form: doubling at 2 / 4 ranks, packed two-phase otherwise)
+        # is kept unless the measured winner beats it by more than `margin` (timing noise does not flip the choice between two
+        # near-equal forms); the choice is logged on rank 0 and lands in the run's config through engine.exchange_autotune.
+        _abi.check(lib.spo_p2p_select_form(-1), "spo_p2p_select_form")
+        default_form = int(lib.spo_p2p_current_form(self.world))
+        margin = float(os.environ.get("SPO_P2P_AUTOTUNE_MARGIN", "0.05"))
+        if best is not None and default_form in live and live[default_form] <= live[best] * (1.0 + margin):
+            best = default_form
         _abi.check(lib.spo_p2p_select_form(-1 if best is None else best), "spo_p2p_select_form")
         self.form = best
         self.prefer_rccl = best is None or (rccl_us is not None and rccl_us < live[best])
@@ -306,7 +321,13 @@ class PeerExchange:
             out[f"kernel / {'RCCL' if backend == 'nccl' else backend} all-reduce / kernel"] = round(rccl_us, 2)
         out["chosen"] = ("kernel / all-reduce / kernel" if self.prefer_rccl else self.FORM_NAMES[best])
         out["unit"] = f"us per 64-row minibatch step, slowest rank, {steps} steps per in-kernel form"
+        out["default_form"] = self.FORM_NAMES.get(default_form, str(default_form))
+        out["margin"] = margin
         self.autotune_table = out
+        if self.rank == 0:
+            import sys
+            print(f"[safepo] per-minibatch gradient exchange: {out['chosen']} (start-up auto-tune over {len(table)} in-kernel form(s)"
+                  f"{' + the all-reduce form' if rccl_us is not None else ''}; SPO_P2P_AUTOTUNE=0 keeps the default policy)", file=sys.stderr)
         return out
 
     def close(self) -> None:

@@ -91,6 +91,12 @@ def run(args, cfg_env, default_cfg: dict, multiplier: str | None = "adam", clip:
 
     dict_args = dict(vars(args))
     dict_args.update(config)
+    if comm.world_size > 1:
+        # which form of the per-minibatch gradient exchange this data-parallel run uses (it decides the order the ranks' gradients
+        # are added in, hence the bits of a seeded run): recorded with the run
+        tab = getattr(engine, "exchange_autotune", None)
+        dict_args["gradient_exchange"] = (tab or {}).get("chosen") or ("in-kernel, default policy" if getattr(engine, "p2p", None) is not None
+                                                                        else "kernel / all-reduce / kernel")
     is_root = comm.rank == 0
     log_dir = args.log_dir if is_root else os.path.join(args.log_dir, f"rank{comm.rank}")
     logger = EpochLogger(log_dir=log_dir, seed=str(args.seed), verbose=is_root)

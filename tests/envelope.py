@@ -97,10 +97,18 @@ def theta_envelope(hip, f32, f64, c=3.0, floor_abs=2e-7, floor_abs_max=None, noi
     hip, f32, f64 = (np.asarray(x, np.float64).reshape(-1) for x in (hip, f32, f64))
     info = {}
     if noise_directions:
+        # round 6: the exemption is taken only where the gate fails without it, and the measured numbers are printed
+        strict, _ = theta_envelope(hip, f32, f64, c=c, floor_abs=floor_abs, floor_abs_max=floor_abs_max, noise_directions=False)
+        if strict <= 1.0:
+            return strict, {"noise_directions": 0, "strict_ratio": strict}
         mask, ok = adam_noise_directions(np.abs(hip - f64), np.abs(f32 - f64))
         info["noise_directions"] = int(mask.sum())
+        info["strict_ratio"] = strict
+        worst = float((np.abs(hip - f64)[mask] / np.abs(f32 - f64)[mask]).max()) if mask.any() else 0.0
+        print(f"[envelope] Adam-noise-direction exemption IN USE: ratio without it {strict:.2f}; {int(mask.sum())} of {hip.size} "
+              f"elements singled out by the reference's own distance, worst |hip-f64| / |f32-f64| on them {worst:.2f} (gate 10)")
         if not ok:
-            return float("inf"), {"noise_directions": int(mask.sum()), "worst": float((np.abs(hip - f64)[mask] / np.abs(f32 - f64)[mask]).max())}
+            return float("inf"), {"noise_directions": int(mask.sum()), "worst": worst}
         hip, f32, f64 = hip[~mask], f32[~mask], f64[~mask]
     n = f64.size
     dh2, d322 = np.linalg.norm(hip - f64), np.linalg.norm(f32 - f64)
@@ -212,7 +220,18 @@ def gate_array(hip, f32, f64, what, rel_floor=1e-6, c=3.0, noise_directions=Fals
     assert hip.shape == f32.shape == f64.shape, (what, hip.shape, f32.shape, f64.shape)
     assert np.isfinite(hip).all(), f"{what}: non-finite HIP values"
     if noise_directions:
-        mask, ok = adam_noise_directions(np.abs(hip - f64), np.abs(f32 - f64))
+        # round 6: first the gate WITHOUT the exemption and at the narrow kernels' floor (1e-6); the exemption and the
+        # wider floor are taken only where that fails, with the measured numbers in the test log
+        sc0 = max(float(np.abs(f64).max()), 1e-30)
+        dh0, d320 = np.abs(hip - f64), np.abs(f32 - f64)
+        n0 = np.sqrt(hip.size)
+        strict = max(dh0.max() / (c * d320.max() + 1e-6 * sc0), np.linalg.norm(dh0) / (c * np.linalg.norm(d320) + 1e-6 * sc0 * n0))
+        if strict <= 1.0:
+            return float(dh0.max() / sc0), float(d320.max() / sc0)
+        mask, ok = adam_noise_directions(dh0, d320)
+        worst = float((dh0[mask] / d320[mask]).max()) if mask.any() else 0.0
+        print(f"[envelope] {what}: exemption IN USE (rel_floor {rel_floor:g}): ratio without it at 1e-6 {strict:.2f}; {int(mask.sum())} of "
+              f"{hip.size} elements singled out by the reference's own distance, worst |hip-f64| / |f32-f64| on them {worst:.2f} (gate 10)")
         assert ok, f"{what}: an Adam noise direction of the reference is more than 10 x further from float64 on the HIP path"
         hip, f32, f64 = hip[~mask], f32[~mask], f64[~mask]
     sc = max(float(np.abs(f64).max()), 1e-30)

@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported_and_bound(built_lib):
     lib = _abi.load(built_lib)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.spo_abi_version() == 1
+    assert lib.spo_abi_version() == _abi.ABI_VERSION == 2
     # geometry helpers are host functions: 2*8129 + 8592 = 24850
     assert lib.spo_param_count(60, 8) == 24850
     assert [lib.spo_param_offset(60, 8, k) for k in range(3)] == [0, 8129, 16258]

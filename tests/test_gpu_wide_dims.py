@@ -29,6 +29,14 @@ def _theta_floor(lr, nsteps):
     distance stays inside 3x.  (Rounds 1-4 exempted 0.1 % of the parameters up to 2 x lr x nsteps: 600x this.)"""
     return 2e-7 + 3e-3 * lr * nsteps
 
+def _floor_users(hip, f32, f64):
+    """WHICH elements need the widened max-norm floor -- those further from float64 than 3 x the fp32 oracle's maximum
+    + the plain 2e-7.  Returns (indices, fraction of the vector)."""
+    hip, f32, f64 = (np.asarray(t, np.float64).reshape(-1) for t in (hip, f32, f64))
+    idx = np.nonzero(np.abs(hip - f64) > 3.0 * np.abs(f32 - f64).max() + 2e-7)[0]
+    return idx, idx.size / hip.size
+
+
 # (obs_dim, act_dim, hidden_sizes): Car-class observations, HumanoidVelocity, a wide action vector on a narrow net
 SHAPES = [(72, 2, [64, 64]), (376, 17, [64, 64]), (60, 33, [32, 48])]
 
@@ -402,11 +410,226 @@ def test_feature_split_kernel_full_size_drift_envelope_at_humanoid_dims(dev):
     lh = runs[kmax][1]
     np.testing.assert_allclose(lh[:8], l32[:8], rtol=1e-5, atol=1e-6, err_msg="first 8 steps")
     rep = {"loss": E.assert_loss_envelope(lh, l32, l64, "feature-split full size")}
+    users = {}
     for k in ks:
         assert np.array_equal(runs[k][1], lh[:k]), f"the {k}-step launch is not a prefix of the {kmax}-step launch"
         rep[k] = E.assert_theta_envelope(runs[k][0], t32[k], t64[k], f"feature-split full size: theta after {k} steps",
                                          floor_abs_max=_theta_floor(3e-4, k))
+        users[k], frac = _floor_users(runs[k][0], t32[k], t64[k])
+        #  the widened floor must be serving a handful of Adam-amplified elements, not a systematic offset: at most
+        # 0.1 % of the vector may need it at any checkpoint
+        assert frac <= 1e-3, f"after {k} steps {users[k].size} elements ({frac:.2%}) need the widened max-norm floor"
+    # ... and not one and the same parameter at every checkpoint (a replica of b3 / log_std or the Adam state of a slice edge going
+    # wrong would show up as the SAME index every time)
+    nonempty = [set(v.tolist()) for v in users.values() if v.size]
+    if len(nonempty) >= 3:
+        assert len(set.intersection(*nonempty)) == 0, f"the same parameters need the floor at every checkpoint: {set.intersection(*nonempty)}"
     print("feature-split kernel, 376 / 17, drift envelope (ratio <= 1 passes):", rep)
+    print("elements beyond 3 x the fp32 oracle's maximum + 2e-7 per checkpoint:", {k: v.tolist()[:8] for k, v in users.items()})
+
+
+def test_feature_split_critic_fit_full_size_drift_envelope_at_humanoid_dims(dev, monkeypatch):
+    """critic_fit_ks_kernel at BASELINE size with HumanoidVelocity's observations -- 524 288 rows x 376, ONE
+    launch of 4 096 minibatch steps of 128 rows (two 64-column chunks each, cpo.py:541-571; the stale actor gradient of norm 50 in
+    the joint clip) on 12 workgroups.  Same gate as the three-workgroup kernel's test_cpo_full_size_critic_fit_drift_envelope:
+    first 8 steps at 1e-5, per-step losses and the critics after 8 / 64 / 512 / 4 096 steps under the float64 yardstick, every
+    shorter launch a bit-exact prefix of the longest."""
+    import envelope as E
+    from safepo.single_agent import cpo
+    from test_gpu_parity import _oracle_critic_trajectory
+    monkeypatch.setenv("SPO_CPO_SPLIT", "0")
+    torch.set_num_threads(8)
+    D, A, hidden, batch = 376, 17, [64, 64], 128
+    N, T = 4096, 128
+    M = N * T
+    ks = (8, 64, 512, 4096)
+    pol, ref = _wide_pair(D, A, hidden, dev, seed=6)
+    sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    cfg = dict(cpo.default_cfg)
+    cfg.update(learning_iters=1, batch_size=batch)
+    eng = cpo.make_engine(pol, N, T, cfg, dev)
+    assert type(eng) is cpo.WideCPOEngine and eng._feature_split_critic_fit_ok(eng._cfg_struct())
+    obs, _a, _l, tgt_r, tgt_c, _adv = _synthetic_update_problem(M, D, A, seed=2027)
+    bd = eng.buffer.data
+    bd["obs"].copy_(obs.view(N, T, D)); bd["target_value_r"].copy_(tgt_r.view(N, T)); bd["target_value_c"].copy_(tgt_c.view(N, T))
+    perm = torch.randperm(M, generator=torch.Generator().manual_seed(9)).to(torch.int32)
+    perm_dev = perm.to(dev)
+    theta0 = pol.theta.clone()
+    n_act = sum(p.numel() for p in ref.actor.parameters())
+    n_crit = theta0.numel() - n_act
+    stale = torch.full((n_act,), 50.0 / np.sqrt(n_act)).to(dev)
+    hip = {}
+    for k in ks:
+        pol.theta.copy_(theta0); eng.adam_m.zero_(); eng.adam_v.zero_(); eng.adam_step = 0
+        eng._set_stale_actor_grad(stale)
+        eng.M = k * batch
+        fit = eng.critic_fit(perm_fn=lambda it: perm_dev[:k * batch].contiguous())
+        eng.check_sync_error()
+        hip[k] = (pol.theta[:n_crit].double().cpu().numpy(), torch.cat(fit["losses"], 0).double().cpu().numpy())
+    eng.M = M
+    kmax = max(ks)
+    l32, t32 = _oracle_critic_trajectory(sd0, obs, tgt_r, tgt_c, perm, batch, kmax, torch.float32, ks, 50.0)
+    l64, t64 = _oracle_critic_trajectory(sd0, obs, tgt_r, tgt_c, perm, batch, kmax, torch.float64, ks, 50.0)
+    lh = hip[kmax][1]
+    np.testing.assert_allclose(lh[:8], l32[:8], rtol=1e-5, atol=1e-6, err_msg="first 8 critic-fit steps")
+    rep = {"loss": E.assert_loss_envelope(lh, l32, l64, "feature-split critic fit, full size")}
+    for k in ks:
+        assert np.array_equal(hip[k][1], lh[:k]), f"the {k}-step launch is not a prefix of the {kmax}-step launch"
+        rep[k] = E.assert_theta_envelope(hip[k][0], t32[k], t64[k], f"feature-split critic fit: critics after {k} steps",
+                                         floor_abs_max=_theta_floor(1e-3, k))
+    print("critic_fit_ks_kernel, 376 / 17, 524 288 rows, drift envelope (ratio <= 1 passes):",
+          {k: (round(v[0], 3), f"max |hip-f64| {v[1]['max_hip']:.2e} vs f32 {v[1]['max_f32']:.2e}") if k != "loss" else round(v, 3)
+           for k, v in rep.items()})
+
+
+def _kl_penalty_trajectory(sd, problem, old_mean, old_std, perm, batch, nsteps, dtype, checkpoints, actor_only, kl_bound, pg_coef,
+                           hidden, actor_clock_ahead):
+    """`nsteps` consecutive FOCOPS steps (focops.py:312-347) or CUP second-stage steps (cup.py:370-386) of the oracle in `dtype`;
+    returns (losses [nsteps, 3] with NaN where a network is not fitted, {k: flat theta after k steps}) as float64."""
+    obs, act, logp, tgt_r, tgt_c, adv = [t.to(dtype) for t in problem]
+    M, D, A = obs.shape[0], obs.shape[1], act.shape[1]
+    rp = R.OraclePolicy(D, A, hidden_sizes=tuple(hidden))
+    rp.load_state_dict({k: v.detach().cpu().clone() for k, v in sd.items()})
+    rp = rp.to(dtype)
+    upd = R.KLPenaltyUpdater(rp)
+    for _ in range(actor_clock_ahead):              # the actor's Adam clock runs ahead (zero gradients: moments stay 0)
+        upd.opt_a.zero_grad()
+        for prm in rp.actor.parameters():
+            prm.grad = torch.zeros_like(prm)
+        upd.opt_a.step()
+    om, osd = old_mean.to(dtype), old_std.to(dtype)
+    perm = torch.as_tensor(perm, dtype=torch.long)
+    out, thetas = np.full((nsteps, 3), np.nan), {}
+    for s_ in range(nsteps):
+        idx = perm[s_ * batch:(s_ + 1) * batch]
+        os_b = osd.expand(idx.numel(), A)
+        if actor_only:
+            out[s_, 2] = upd.cup_second_stage_step(obs[idx], act[idx], logp[idx], adv[idx], om[idx], os_b,
+                                                   -pg_coef / ((1 - 0.99 * 0.95) / (1 - 0.99)), 0.99)
+        else:
+            out[s_] = upd.focops_step(obs[idx], act[idx], logp[idx], tgt_r[idx], tgt_c[idx], adv[idx], om[idx], os_b, kl_bound)
+        if (s_ + 1) in checkpoints:
+            thetas[s_ + 1] = R.flat_params(rp).double().numpy().copy()
+    return out, thetas
+
+
+@pytest.mark.parametrize("actor_only", [False, True])
+def test_feature_split_kl_penalty_full_size_drift_envelope_at_humanoid_dims(dev, actor_only):
+    """klpen_update_ks_kernel at BASELINE size with HumanoidVelocity's dims -- 524 288 rows x 376 / 17, ONE launch
+    of 8 192 minibatch steps of 64 rows: FOCOPS' step (focops.py:312-347: both critics + the KL-penalty actor loss, 18 workgroups)
+    and CUP's actor-only second stage (cup.py:370-386: 6 workgroups, the actor's own optimiser clock).  First 8 steps at 1e-5,
+    per-step losses and the parameters after 8 / 64 / 512 / 2 048 / 8 192 steps under the float64 yardstick, prefixes bit-exact.
+    The indicator [KL <= bound] is on for every sample here (bound = inf): over 8 192 steps a sample within rounding of a finite
+    bound would flip between the float32 and float64 legs and the yardstick would measure that, not the kernel; the indicator's
+    arithmetic on part of a batch is test_wide_kl_penalty_minibatch_steps_vs_oracle's."""
+    import envelope as E
+    from safepo import _abi
+    from safepo.common.engine import WidePPOLagEngine
+    from test_gpu_parity import _fill_update_problem
+    torch.set_num_threads(8)
+    D, A, hidden, batch = 376, 17, [64, 64], 64
+    M = 4096 * 128
+    pol, ref = _wide_pair(D, A, hidden, dev, seed=7 + int(actor_only))
+    sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    problem = _synthetic_update_problem(M, D, A, seed=2028)
+    obs, act, logp, tgt_r, tgt_c, adv = problem
+    g = torch.Generator().manual_seed(12)
+    with torch.no_grad():
+        dist = ref.actor(obs)
+        old_mean = dist.mean + 0.05 * torch.randn(M, A, generator=g)
+        old_std = dist.stddev[0] * torch.exp(0.05 * torch.randn(A, generator=g))
+    kl_bound = float("inf")
+    pg_coef = -0.37 if actor_only else 1 / 1.5
+    ahead = 5
+    cfg = {"hidden_sizes": hidden, "gamma": 0.99, "target_kl": 1e9, "batch_size": batch, "learning_iters": 1, "max_grad_norm": 40.0}
+    eng = WidePPOLagEngine(pol, 1, M, cfg, dev)
+    assert eng._feature_split_kernel_ok(eng._cfg_struct())
+    _fill_update_problem(eng, problem)
+    eng.mean_old.copy_(old_mean); eng.std_old.copy_(old_std)
+    perm = torch.randperm(M, generator=torch.Generator().manual_seed(10))
+    perm_dev = perm.to(torch.int32).to(dev)
+    adv_dev = adv.to(dev).contiguous()
+    theta0 = pol.theta.clone()
+    ks = (8, 64, 512, 2048, 8192)
+    hip = {}
+    for k in ks:
+        pol.theta.copy_(theta0); eng.adam_m.zero_(); eng.adam_v.zero_(); eng.adam_step = 0; eng.adam_step_actor_extra = ahead
+        eng.M = k * batch
+        losses = eng.learning_iter_ex(perm_dev[:k * batch].contiguous(), adv_dev, _abi.ACTOR_LOSS_KL_PENALTY, kl_bound, pg_coef, actor_only)
+        eng.check_sync_error()
+        hip[k] = (pol.theta.double().cpu().numpy(), losses.double().cpu().numpy())
+    eng.M = M
+    kmax = max(ks)
+    args = (sd0, problem, old_mean, old_std, perm, batch, kmax)
+    l32, t32 = _kl_penalty_trajectory(*args, torch.float32, ks, actor_only, kl_bound, pg_coef, hidden, ahead)
+    l64, t64 = _kl_penalty_trajectory(*args, torch.float64, ks, actor_only, kl_bound, pg_coef, hidden, ahead)
+    cols = [2] if actor_only else [0, 1, 2]
+    lh = hip[kmax][1]
+    np.testing.assert_allclose(lh[:8, cols], l32[:8, cols], rtol=1e-5, atol=2e-6, err_msg="first 8 steps")
+    what = "feature-split KL-penalty kernel, full size" + (" (actor only)" if actor_only else "")
+    rep = {"loss": E.assert_loss_envelope(lh[:, cols], l32[:, cols], l64[:, cols], what, floor_rel=3e-6)}
+    for k in ks:
+        assert np.array_equal(hip[k][1], lh[:k], equal_nan=True), f"the {k}-step launch is not a prefix of the {kmax}-step launch"
+        rep[k] = E.assert_theta_envelope(hip[k][0], t32[k], t64[k], f"{what}: theta after {k} steps", floor_abs_max=_theta_floor(3e-4, k))
+    if actor_only:
+        off = pol.log_std_offset
+        assert torch.equal(pol.theta[:off], theta0[:off])            # the critics are not touched by CUP's second stage
+    print(f"klpen_update_ks_kernel ({'actor only' if actor_only else 'full step'}), 376 / 17, 524 288 rows, drift envelope (ratio <= 1 passes):",
+          {k: (round(v[0], 3), f"max |hip-f64| {v[1]['max_hip']:.2e} vs f32 {v[1]['max_f32']:.2e}") if k != "loss" else round(v, 3)
+           for k, v in rep.items()})
+
+
+def test_feature_split_kernels_three_consecutive_launches_on_one_stream(dev, monkeypatch):
+    """the exchange tags (tag_base, never cleared) and slot parities carry over from launch to launch.  Three
+    consecutive launches on one stream of the critic fit (three passes of cpo.py:541-571) and of the KL-penalty step (three passes
+    of focops.py:312-347) against the oracle running the same three passes."""
+    import envelope as E
+    from safepo import _abi
+    from safepo.common.engine import WidePPOLagEngine
+    from test_gpu_parity import _fill_update_problem
+    _critic_fit_check(dev, 376, 17, [64, 64], False, monkeypatch, M=128 * 9 + 50, iters=3, batch=128, expect_ks=True)
+    D, A, hidden, batch, M, passes = 200, 20, [64, 64], 64, 64 * 11 + 20, 3
+    pol, ref = _wide_pair(D, A, hidden, dev, seed=3)
+    sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    problem = _synthetic_update_problem(M, D, A, seed=88)
+    obs, act, logp, tgt_r, tgt_c, adv = problem
+    g = torch.Generator().manual_seed(13)
+    with torch.no_grad():
+        dist = ref.actor(obs)
+        old_mean = dist.mean + 0.05 * torch.randn(M, A, generator=g)
+        old_std = dist.stddev[0] * torch.exp(0.05 * torch.randn(A, generator=g))
+    cfg = {"hidden_sizes": hidden, "gamma": 0.99, "target_kl": 1e9, "batch_size": batch, "learning_iters": 1, "max_grad_norm": 40.0}
+    eng = WidePPOLagEngine(pol, 1, M, cfg, dev)
+    assert eng._feature_split_kernel_ok(eng._cfg_struct())
+    _fill_update_problem(eng, problem)
+    eng.mean_old.copy_(old_mean); eng.std_old.copy_(old_std)
+    perms = [torch.randperm(M, generator=g) for _ in range(passes)]
+    nst = (M + batch - 1) // batch
+    got = [eng.learning_iter_ex(p_.to(torch.int32).to(dev), adv.to(dev).contiguous(), _abi.ACTOR_LOSS_KL_PENALTY, float("inf"), 1 / 1.5,
+                                False).double().cpu().numpy() for p_ in perms]
+    eng.check_sync_error()
+    # the oracle: the same passes; the ragged last minibatch of a pass is its own (short) minibatch, as in the reference's loop
+    def oracle(dtype):
+        o, ac, lp, tr, tc, ad = [t.to(dtype) for t in problem]
+        rp = R.OraclePolicy(D, A, hidden_sizes=tuple(hidden))
+        rp.load_state_dict({k: v.clone() for k, v in sd0.items()})
+        rp = rp.to(dtype)
+        upd = R.KLPenaltyUpdater(rp)
+        om, osd = old_mean.to(dtype), old_std.to(dtype)
+        out = []
+        for p_ in perms:
+            for s0 in range(0, M, batch):
+                idx = p_[s0:s0 + batch]
+                out.append(upd.focops_step(o[idx], ac[idx], lp[idx], tr[idx], tc[idx], ad[idx], om[idx], osd.expand(idx.numel(), A), float("inf")))
+        return np.asarray(out, np.float64), R.flat_params(rp).double().numpy()
+    l32, t32 = oracle(torch.float32)
+    l64, t64 = oracle(torch.float64)
+    lh = np.concatenate(got, 0)
+    assert lh.shape == (passes * nst, 3)
+    np.testing.assert_allclose(lh[:4], l32[:4], rtol=1e-5, atol=2e-6)
+    E.assert_loss_envelope(lh, l32, l64, "three KL-penalty launches: losses", window=nst, floor_rel=3e-6)
+    E.assert_theta_envelope(pol.theta.double().cpu().numpy(), t32, t64, "three KL-penalty launches: theta",
+                            floor_abs_max=_theta_floor(3e-4, passes * nst))
 
 
 def test_two_feature_split_engines_update_concurrently_on_two_streams(dev):
