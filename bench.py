@@ -351,23 +351,27 @@ def run_epochs(algo, a, comm, dev, N, T, D, A, steps, warmup, time_gae):
     px = getattr(eng, "p2p", None)
     PEER_EXCHANGE_USED[0] = px is not None
     exchange = None
+    replicas_identical = None
     if world > 1:
         import torch.distributed as dist
-        form = ("rccl all-reduce between kernels (spo_ppo_lag_grad -> all_reduce -> spo_clip_adam_then_grad)" if px is None else
-                "in-kernel, all-to-all on the helper waves" if os.environ.get("SPO_P2P_A2A", "0") == "1" else
-                "in-kernel, recursive doubling of packed words on the helper waves" if os.environ.get("SPO_P2P_HELPER", "0") not in ("0", "") else
-                "in-kernel, recursive doubling of packed tagged words over IPC-mapped peer regions"
-                if ((world & (world - 1)) == 0 and (world <= 4 or os.environ.get("SPO_P2P_ALGO") == "doubling")
-                    and os.environ.get("SPO_P2P_ALGO") != "twophase")
-                else "in-kernel, reduce-scatter + all-gather of packed tagged words over IPC-mapped peer regions")
-        if px is not None and getattr(px, "form", None) is not None:
-            form = "in-kernel over IPC-mapped peer regions, chosen by the start-up auto-tune: " + px.FORM_NAMES[px.form]
+        # data-parallel replicas must hold identical bits under whatever exchange form ran: element-wise max == min over the ranks
+        th = eng.policy.theta.detach()
+        hi, lo = th.clone(), (-th).clone()
+        comm.all_reduce_max_(hi); comm.all_reduce_max_(lo)
+        replicas_identical = bool(torch.equal(hi, -lo))
+        if px is None:
+            form = "rccl all-reduce between kernels (spo_ppo_lag_grad -> all_reduce -> spo_clip_adam_then_grad)"
+        else:
+            cur = int(px.lib.spo_p2p_current_form(world))          # what spo_ppo_lag_update_iter_dp runs (environment / auto-tune / policy)
+            how = ("chosen by the start-up auto-tune" if getattr(px, "form", None) is not None else "environment or default policy")
+            form = f"in-kernel over IPC-mapped peer regions ({how}): " + px.FORM_NAMES.get(cur, str(cur))
         exchange = {"form": form, "autotune": getattr(eng, "exchange_autotune", None), "selftest_s": round(getattr(px, "last_selftest_s", float("nan")), 4) if px is not None else None,
                     "selftest_result": list(getattr(px, "last_selftest", ())) if px is not None else None,
                     "host_collectives_backend": dist.get_backend(), "host_collectives_world": dist.get_world_size(),
                     "dp_batch": a.dp_batch, "all_ranks_on_one_gpu": os.environ.get("SPO_BENCH_ONE_GPU", "0") == "1"}
     return {"elapsed": float(tmax.item()), "roll": roll, "upd": upd, "last": last, "n_ep": n_ep, "eng": eng, "cfg": cfg,
-            "epoch": epoch, "gae_graph": gae_graph, "gae_disp": gae_disp, "per_rank": per_rank, "exchange": exchange}
+            "epoch": epoch, "gae_graph": gae_graph, "gae_disp": gae_disp, "per_rank": per_rank, "exchange": exchange,
+            "replicas_identical": replicas_identical}
 
 
 def _update_kernel_entry(us_step, upd_counters, world):
@@ -458,6 +462,7 @@ def main():
     res = run_epochs(a.algo, a, comm, dev, N, T, D, A, a.steps, a.warmup, time_gae=True)
     elapsed, roll, upd, last, n_ep, eng, cfg = (res[k] for k in ("elapsed", "roll", "upd", "last", "n_ep", "eng", "cfg"))
     res_exchange, res_per_rank = res["exchange"], res["per_rank"]
+    res_replicas_identical = res.get("replicas_identical")
 
     def run_config5():
         try:
@@ -657,7 +662,7 @@ def main():
 
     us_step = upd / a.steps / (n_mb * iters) * 1e6
     upd_counters = None
-    if a.algo == "ppo_lag" and world == 1:
+    if a.algo == "ppo_lag":                      # (N > 1: rank 0's process)
         import ctypes
         from safepo import _abi
         c4 = (ctypes.c_ulonglong * 4)()
@@ -717,6 +722,7 @@ def main():
         "wide_minibatch_step": wide_entry,
         "library": _lib_note(),
         "exchange": res_exchange,
+        "replicas_identical_after_run": res_replicas_identical,
         "per_rank": ([{"rank": r, "ms_per_step": round(e / a.steps * 1e3, 2), "rollout_s_per_epoch": round(ro / a.steps, 4),
                        "update_s_per_epoch": round(u / a.steps, 4),
                        "update_us_per_minibatch_step": round(u / a.steps / (n_mb * iters) * 1e6, 3)}

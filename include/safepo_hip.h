@@ -350,6 +350,9 @@ int spo_critic_fit_iter_ks(float* theta, float* adam_m, float* adam_v, int64_t a
 #define SPO_XR_FORM_DOUBLING 1          /* packed recursive doubling, four-wave kernel: log2(world) hand-offs (power-of-two worlds) */
 #define SPO_XR_FORM_HELPER_A2A 2        /* one-shot all-to-all with flags on the helper waves (worlds 2 / 4 / 8): one hand-off      */
 #define SPO_XR_FORM_HELPER_DOUBLING 3   /* packed recursive doubling on the helper waves, layer by layer (worlds 2 / 4 / 8)          */
+#define SPO_XR_FORM_ROW_SPLIT 4         /* round 6: the row-split kernel (spo_update_rs_supported); the rank's gradient goes to every
+                                         * other rank at once as tagged 16-byte words -- ONE cross-rank hand-off on world - 1 links,
+                                         * XOR-butterfly sum (worlds 2 / 4 / 8; SPO_P2P_ALGO=rowsplit)                                */
 int spo_p2p_select_form(int form);
 int spo_p2p_form_valid(int form, int world);
 int spo_p2p_current_form(int world);

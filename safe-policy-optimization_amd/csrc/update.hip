@@ -82,7 +82,9 @@ constexpr size_t A2A_DATA_F4 = (size_t)2 * XR_MAX_WORLD * 3 * A2A_ROWS * 256;   
 constexpr size_t A2A_FLAG_WORDS = (size_t)2 * XR_MAX_WORLD * 3 * 2 * 4;             // [parity][source][network][stage][wave]
 constexpr size_t A2A_DATA_OFF = XR_V1_BYTES;
 constexpr size_t A2A_FLAG_OFF = A2A_DATA_OFF + A2A_DATA_F4 * 16;
-constexpr size_t XR_REGION_BYTES = A2A_FLAG_OFF + A2A_FLAG_WORDS * 8;
+// ... and (round 6) the row-split kernel's cross-rank words (update_rs.hip, SPO_XR_FORM_ROW_SPLIT) in a section of their own
+constexpr size_t RSX_OFF = (A2A_FLAG_OFF + A2A_FLAG_WORDS * 8 + 4095) & ~(size_t)4095;
+constexpr size_t XR_REGION_BYTES = RSX_OFF + spo::RSX_BYTES;
 
 struct UpdArgs {
   float* theta; float* adam_m; float* adam_v;
@@ -3139,7 +3141,7 @@ extern "C" int spo_update_iter_ex(float* theta, float* adam_m, float* adam_v, in
 // profiles/r05/helper_exchange_ab.txt: doubling 14.3 / 16.7 / 21.4 us per step at 2 / 4 / 8 ranks, two-phase 17.8 / 18.0 / 19.1).
 static int g_xr_form_override = -1;
 extern "C" int spo_p2p_select_form(int form) {
-  SPO_REQUIRE(form >= -1 && form <= SPO_XR_FORM_HELPER_DOUBLING, "p2p_select_form: unknown form %d", form);
+  SPO_REQUIRE(form >= -1 && form <= SPO_XR_FORM_ROW_SPLIT, "p2p_select_form: unknown form %d", form);
   g_xr_form_override = form;
   return 0;
 }
@@ -3150,6 +3152,7 @@ static bool xr_form_valid(int form, int world) {
     case SPO_XR_FORM_TWOPHASE: return true;
     case SPO_XR_FORM_DOUBLING: return pow2;
     case SPO_XR_FORM_HELPER_A2A: case SPO_XR_FORM_HELPER_DOUBLING: return world == 2 || world == 4 || world == 8;
+    case SPO_XR_FORM_ROW_SPLIT: return (world == 2 || world == 4 || world == 8) && update_form() >= 3;
     default: return false;
   }
 }
@@ -3160,6 +3163,7 @@ static int xr_form(int world) {
   const char* algo = getenv("SPO_P2P_ALGO");
   const bool pow2 = (world & (world - 1)) == 0;
   if (algo && !strcmp(algo, "twophase")) return SPO_XR_FORM_TWOPHASE;
+  if (algo && !strcmp(algo, "rowsplit") && xr_form_valid(SPO_XR_FORM_ROW_SPLIT, world)) return SPO_XR_FORM_ROW_SPLIT;
   if (a2a && xr_form_valid(SPO_XR_FORM_HELPER_A2A, world)) return SPO_XR_FORM_HELPER_A2A;
   if (helper_xr_mode() && xr_form_valid(SPO_XR_FORM_HELPER_DOUBLING, world)) return SPO_XR_FORM_HELPER_DOUBLING;
   if (algo && !strcmp(algo, "doubling") && pow2) return SPO_XR_FORM_DOUBLING;
@@ -3289,6 +3293,14 @@ extern "C" int spo_ppo_lag_update_iter_dp(float* theta, float* adam_m, float* ad
   a.first_net = 0; a.n_nets = 3; a.stale_sq = 0.f; a.stale_io = nullptr;
   int rc = 0;
   const int kin = pick_kin(cfg_host->obs_dim);
+  // SPO_XR_FORM_ROW_SPLIT (round 6): the row-split kernel with a one-hand-off all-to-all of the rank's gradient behind the row
+  // groups' L2 hand-off (csrc/update_rs.hip, XW)
+  if (xr_form(world) == SPO_XR_FORM_ROW_SPLIT && spo_update_rs_supported(cfg_host->obs_dim, cfg_host->act_dim, cfg_host->batch, 3)) {
+    if (int rc2 = spo::rs_update_launch_dp(theta, adam_m, adam_v, adam_step_host, obs, act, logp_old, target_r, target_c, adv, perm, M,
+                                           cfg_host, losses_out, sync_ws, rank, world, regions, step0, RSX_OFF, stream)) return rc2;
+    SPO_LAUNCH_CHECK("spo_ppo_lag_update_iter_dp (row-split)");
+    return 0;
+  }
   // SPO_P2P_A2A=1 (opt-in): main + helper kernel with the flag-based all-to-all exchange on the helper waves.  One exchange
   // round at any world size, layer by layer beside the main waves' MFMAs -- but in single-GPU loopback (all ranks sharing
   // one memory system) it measured SLOWER than recursive doubling on the four-wave kernel (18.6 / 23.9 / 33.5 against

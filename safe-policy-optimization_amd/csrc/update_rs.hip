@@ -64,7 +64,7 @@ struct RsLds {                                   // floats
 };
 // RED: [0..1] loss partials of the column waves, [16 + 16 c + a] d(log_std) partials of column wave c, [88 + w] sum p^2 of
 //      optimiser wave w, [96] placement census, [97] dead flag (a poll timed out: stop waiting), [98] (int) index of the step
-//      whose L1 the column waves must repeat (its predecessor was clipped)
+//      whose L1 the column waves must repeat (its predecessor was clipped), [100..115] the ranks' exchange-region pointers (data-parallel form)
 
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
@@ -84,6 +84,12 @@ struct RsArgs {
   int force_safe;                      // SPO_RS_SAFE=1: write-through exchange stores whatever the placement (tests)
   unsigned long long* prof;            // optional [3][RS_NPHASE] cycle accumulators (instrumented instantiation)
   int prof_wg;                         // ... of this workgroup (SPO_RS_PROF_WG; default: the last one = the actor's last row group)
+  // data-parallel form (XW > 0 instantiations): the ranks' exchange regions (spo_p2p_alloc / spo_p2p_open: uncached, IPC-mapped),
+  // this rank, the global optimiser-step count before this launch (same on every rank: tags), the row-split section's offset
+  void* xr_region[8];
+  int xr_rank;
+  unsigned xr_step0;
+  unsigned long long rsx_off;
 };
 constexpr size_t rs_z_bytes(int R) { return (size_t)2 * 3 * R * R * RS_NS * 4096; }
 constexpr int RS_GRAN_WORDS = 2 * RS_MAX_R * 3 * 4;
@@ -102,6 +108,40 @@ struct RsCol {                         // per-column inputs of one minibatch, pr
   f4 actv;
   float t0, t1;                        // critic: target ; actor: logp_old, adv
 };
+
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+// System-scope 16-byte word at (uniform base) + (32-bit lane offset): the base travels in SGPRs (readfirstlane pins it there), so a
+// store / load costs no 64-bit address registers -- with one VGPR pair per (peer, word) the compiler keeps W x 15 addresses alive
+// across the step loop and spills the optimiser state.  s_nop 4: an SGPR written by a VALU instruction (v_readfirstlane) needs 5
+// wait states before a VMEM instruction reads it, and the hazard recogniser does not look inside inline assembly; s_nop 1 behind a
+// store of more than 8 bytes: its data registers are read up to two wait states after issue (update.hip).
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+  const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void st16_sys(const char* base_uniform, unsigned lane_byte_off, const u4v v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(lane_byte_off), "v"(v), "s"(base_uniform) : "memory");
+#endif
+}
+__device__ __forceinline__ u4v ld16_sys(const char* base_uniform, unsigned lane_byte_off) {
+  u4v v = {0u, 0u, 0u, 0u};
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc0 sc1" : "=v"(v) : "v"(lane_byte_off), "s"(base_uniform) : "memory");
+#endif
+  return v;
+}
+__device__ __forceinline__ void wait_vm0() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+__device__ __forceinline__ void pin_u4(u4v& v) {                 // (an inline-asm load's outputs are valid only after the wait)
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(v));
+#endif
+}
 
 // Half of a hidden layer for one column tile: output tiles 2 FH, 2 FH + 1 of out[] (rows 16 mt + 4 q + reg, col batch) = tanh?(W in + b);
 // the other two entries of out[] are left alone (they are the partner wave's).  Two independent accumulator chains (dependent
@@ -132,7 +172,12 @@ __device__ __forceinline__ void layer_half(const float* Wl, int ld, const float*
 }
 
 // FAST: every workgroup of the launch sits on one XCD (checked by the kernel), stores of the exchange stay plain
-template <int KIN, int R, bool FAST, bool PROF>
+// XW: world size of the data-parallel form (0: one GPU).  After the row groups of a rank have summed their partials (the L2 hand-off),
+// every workgroup holds the rank's gradient; it then pushes it as tagged 16-byte words {f, f, f, global step} -- one system-scope
+// store each, untorn -- into a private slot of the same row group's workgroup on EVERY other rank (one hand-off on W - 1 links at
+// once), polls the W - 1 slots of its own region and adds the W contributions in rank order (its own at its
+// position): the same expression on every rank, so all replicas continue from identical bits; then the mean over the ranks.  Tags are the global optimiser-step count, slots double-buffered by its parity (update.hip).
+template <int KIN, int R, bool FAST, bool PROF, int XW = 0>
 __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
   using L = NetLds<KIN>;
   using S = RsLds<KIN>;
@@ -160,6 +205,8 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
   stage_net<KIN>(a.theta, g, lds, tid, 512);
   if (tid < 16) lds[S::LS + tid] = (is_actor && tid < A) ? a.theta[ls_off + tid] : 0.f;
   if (tid < 128) red[tid] = 0.f;
+  __syncthreads();
+  if (XW > 0 && tid < 8) reinterpret_cast<unsigned long long*>(red + 100)[tid] = reinterpret_cast<unsigned long long>(a.xr_region[tid]);
   __syncthreads();
 
   if (is_col) {
@@ -562,6 +609,74 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
     }                                                                                                  \
   }
 
+  // ---- cross-rank stage (XW > 0): NFL floats of this lane, words W0 .. of the row-split section of the exchange regions
+  const unsigned gtag0 = a.xr_step0 + 1u;
+  // (region pointers from an LDS copy of the kernel-argument table: indexing the table itself with a run-time rank would move the
+  //  whole argument block to scratch)
+  const unsigned long long* const xtab = reinterpret_cast<const unsigned long long*>(red + 100);
+  auto rsx_slot = [&](int rank_, int par_, int src_, int w_) -> const char* {      // (uniform: the lane offset ol * 16 goes separately)
+    return uniform_ptr(reinterpret_cast<const char*>(xtab[rank_]) + a.rsx_off +
+                       ((((size_t)(par_ * 2 + hf) * 3 + net) * 8 + src_) * 16 + w_) * 4096);
+  };
+  const unsigned xlane = (unsigned)ol * 16u;
+#define RSX_PUSH(FL, NFL, W0, GTAG)                                                                    \
+  {                                                                                                    \
+    constexpr int NW_ = ((NFL) + 2) / 3;                                                               \
+    const int xpar_ = (int)((GTAG) & 1u);                                                              \
+    _Pragma("unroll") for (int d_ = 1; d_ < XW; ++d_) {                                                \
+      _Pragma("unroll") for (int w_ = 0; w_ < NW_; ++w_) {                                             \
+        u4v word_;                                                                                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_)                                               \
+          word_[i_] = (3 * w_ + i_) < (NFL) ? __float_as_uint((FL)[(3 * w_ + i_) < (NFL) ? 3 * w_ + i_ : 0]) : 0u; \
+        word_[3] = (GTAG);                                                                             \
+        st16_sys(rsx_slot(a.xr_rank ^ d_, xpar_, a.xr_rank, (W0) + w_), xlane, word_);                  \
+      }                                                                                                \
+    }                                                                                                  \
+  }
+  // the NFL floats rank SRC sent to this workgroup (its words W0 ..), polled until every word carries this step's tag
+#define RSX_POLL(OUT_, NFL, W0, GTAG, SRC)                                                             \
+  {                                                                                                    \
+    constexpr int NW_ = ((NFL) + 2) / 3;                                                               \
+    const int xpar_ = (int)((GTAG) & 1u);                                                              \
+    u4v x_[NW_];                                                                                       \
+    unsigned spins_ = 0;                                                                               \
+    for (;;) {                                                                                         \
+      _Pragma("unroll") for (int w_ = 0; w_ < NW_; ++w_)                                               \
+        x_[w_] = ld16_sys(rsx_slot(a.xr_rank, xpar_, (SRC), (W0) + w_), xlane);                        \
+      wait_vm0();                                                                                      \
+      bool ok_ = true;                                                                                 \
+      _Pragma("unroll") for (int w_ = 0; w_ < NW_; ++w_) {                                             \
+        pin_u4(x_[w_]);                                                                                \
+        ok_ = ok_ && (x_[w_][3] == (GTAG));                                                            \
+      }                                                                                                \
+      if (ok_ || *dead != 0.f) break;                                                                  \
+      if (++spins_ > RS_SPIN_LIMIT) { *a.err = 2; *dead = 1.f; break; }   /* bounded, and sticky */    \
+      __builtin_amdgcn_s_sleep(1);                                                                     \
+    }                                                                                                  \
+    _Pragma("unroll") for (int f_ = 0; f_ < (NFL); ++f_) (OUT_)[f_] = __uint_as_float(x_[f_ / 3][f_ % 3]); \
+  }
+  // all-reduce (mean) of FL[NFL] over the XW ranks: the ranks' contributions added IN RANK ORDER, ((v0 + v1) + v2) + ..., this
+  // rank's own at its position -- the same expression on every rank, hence identical bits; one source in flight at a time (two
+  // sources, or the butterfly tree's partial sums, do not fit beside the optimiser state of a 256-register wave at 4 / 8 ranks)
+#define RSX_REDUCE(FL, NFL, W0, GTAG)                                                                  \
+  {                                                                                                    \
+    float acc_[NFL], t_[NFL];                                                                          \
+    if (a.xr_rank == 0) {                                                 /* (uniform) */              \
+      _Pragma("unroll") for (int f_ = 0; f_ < (NFL); ++f_) acc_[f_] = (FL)[f_];                        \
+    } else {                                                                                           \
+      RSX_POLL(acc_, NFL, W0, GTAG, 0)                                                                 \
+    }                                                                                                  \
+    _Pragma("unroll 1") for (int r_ = 1; r_ < XW; ++r_) {                 /* (a loop, not XW copies: registers) */ \
+      if (r_ == a.xr_rank) {                                                                           \
+        _Pragma("unroll") for (int f_ = 0; f_ < (NFL); ++f_) acc_[f_] = acc_[f_] + (FL)[f_];           \
+      } else {                                                                                         \
+        RSX_POLL(t_, NFL, W0, GTAG, r_)                                                                \
+        _Pragma("unroll") for (int f_ = 0; f_ < (NFL); ++f_) acc_[f_] = acc_[f_] + t_[f_];             \
+      }                                                                                                \
+    }                                                                                                  \
+    _Pragma("unroll") for (int f_ = 0; f_ < (NFL); ++f_) (FL)[f_] = acc_[f_] * (1.f / (float)XW);      \
+  }
+
 #define RS_ADAM(ADDR, G, M, V)                                                             \
   {                                                                                        \
     const AdamOut o_ = adam1(lds[ADDR], (G), (M), (V), b1c, b2c, eps, step_size, inv_bc2s); \
@@ -682,58 +797,99 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
     // ---- while layer 1's partials travel: the peers' layer-2 / 3 partials (sent at b4: long there), their L2 terms and norm share
     // (before b5 this work would come straight out of the column waves' last backward product: the two waves of a SIMD add)
     RS_POLL_SUM(gA, zwA, 7, NT1 + 1, par, 10, true)
-    if (has_l2) {
-      // L2 regulariser of the critics (weights AND biases, ppo_lag.py:310-314)
-      RS_REIDX
+    const unsigned gtag = gtag0 + (unsigned)s;                             // (data-parallel form: the global step's tag)
+    constexpr int NFA = 26, NFB = 4 * NT1 + 1;                             // floats that cross ranks: layers 2 / 3 (+ db2, db3, d log_std), layer 1 (+ db1)
+    float fA[NFA];
+    if constexpr (XW > 0) {
+      // the rank's layer-2 / 3 gradient goes to the other ranks now; it is picked up behind layer 1's (below)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+      for (int k = 0; k < 5; ++k)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p_ = lds[L::W2 + (orow + r) * LDH + 16 * nt + j];
-          const float g_ = vcoef * fmaf(l2x2, p_, gA[nt][r]);
-          gA[nt][r] = g_; gsq = fmaf(g_, g_, gsq); psq = fmaf(p_, p_, psq);
-        }
+        for (int e = 0; e < 4; ++e) fA[4 * k + e] = gA[k][e];
+      fA[20] = gA[5][0]; fA[21] = gA[5][1];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {                                         // pad rows hold p == 0, g == 0
-        const float p_ = lds[L::W3 + (4 * q + r) * LDH + 16 * ow + j];
-        const float g_ = vcoef * fmaf(l2x2, p_, gA[4][r]);
-        gA[4][r] = g_; gsq = fmaf(g_, g_, gsq); psq = fmaf(p_, p_, psq);
-      }
-      {
-        // biases are replicated over q (all replicas run the same Adam, q == 0 counts towards the norms)
-        const float pb2 = lds[L::B2 + 16 * ow + j];
-        gb2 = vcoef * fmaf(l2x2, pb2, gA[5][0]);
-        if (own_b) { gsq = fmaf(gb2, gb2, gsq); psq = fmaf(pb2, pb2, psq); }
-        if (ow == 0) {
-          const float pb3 = lds[L::B3 + j];
-          gb3 = vcoef * fmaf(l2x2, pb3, gA[5][1]);
-          if (q == 0) { gsq = fmaf(gb3, gb3, gsq); psq = fmaf(pb3, pb3, psq); }
-        }
-      }
-    } else {
-      // no regulariser, coefficient 1 (the actor; the cost critic without use_critic_norm): the gradient as it is, no sum p^2
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) gsq = fmaf(gA[nt][r], gA[nt][r], gsq);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) gsq = fmaf(gA[4][r], gA[4][r], gsq);
-      gb2 = gA[5][0];
-      if (own_b) gsq = fmaf(gb2, gb2, gsq);
-      if (ow == 0) {
-        gb3 = gA[5][1];
-        if (q_ == 0) gsq = fmaf(gb3, gb3, gsq);
-        if (own_ls) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) gsq = fmaf(gA[6][r], gA[6][r], gsq);   // 0 on pad rows
-        }
-      }
+      for (int e = 0; e < 4; ++e) fA[22 + e] = gA[6][e];
+      RSX_PUSH(fA, NFA, 0, gtag)
     }
+    auto l2_terms_a = [&]() {
+    if (has_l2) {
+        // L2 regulariser of the critics (weights AND biases, ppo_lag.py:310-314)
+        RS_REIDX
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p_ = lds[L::W2 + (orow + r) * LDH + 16 * nt + j];
+            const float g_ = vcoef * fmaf(l2x2, p_, gA[nt][r]);
+            gA[nt][r] = g_; gsq = fmaf(g_, g_, gsq); psq = fmaf(p_, p_, psq);
+          }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                                         // pad rows hold p == 0, g == 0
+          const float p_ = lds[L::W3 + (4 * q + r) * LDH + 16 * ow + j];
+          const float g_ = vcoef * fmaf(l2x2, p_, gA[4][r]);
+          gA[4][r] = g_; gsq = fmaf(g_, g_, gsq); psq = fmaf(p_, p_, psq);
+        }
+        {
+          // biases are replicated over q (all replicas run the same Adam, q == 0 counts towards the norms)
+          const float pb2 = lds[L::B2 + 16 * ow + j];
+          gb2 = vcoef * fmaf(l2x2, pb2, gA[5][0]);
+          if (own_b) { gsq = fmaf(gb2, gb2, gsq); psq = fmaf(pb2, pb2, psq); }
+          if (ow == 0) {
+            const float pb3 = lds[L::B3 + j];
+            gb3 = vcoef * fmaf(l2x2, pb3, gA[5][1]);
+            if (q == 0) { gsq = fmaf(gb3, gb3, gsq); psq = fmaf(pb3, pb3, psq); }
+          }
+        }
+      } else {
+        // no regulariser, coefficient 1 (the actor; the cost critic without use_critic_norm): the gradient as it is, no sum p^2
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gsq = fmaf(gA[nt][r], gA[nt][r], gsq);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gsq = fmaf(gA[4][r], gA[4][r], gsq);
+        gb2 = gA[5][0];
+        if (own_b) gsq = fmaf(gb2, gb2, gsq);
+        if (ow == 0) {
+          gb3 = gA[5][1];
+          if (q_ == 0) gsq = fmaf(gb3, gb3, gsq);
+          if (own_ls) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gsq = fmaf(gA[6][r], gA[6][r], gsq);   // 0 on pad rows
+          }
+        }
+      }
+    };
+    if constexpr (XW == 0) l2_terms_a();
     const float loss_data = gA[5][2] * inv_n;
     RS_STAMP(5)                                                            // layers 2 / 3: poll, sums, L2 terms
     {
       u4 zwB[1][NT1 + 1];
       RS_POLL_SUM(gB, zwB, NT1 + 1, 0, par, 11, false)
+    }
+    if constexpr (XW > 0) {
+      float fB[NFB];
+#pragma unroll
+      for (int k = 0; k < NT1; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fB[4 * k + e] = gB[k][e];
+      fB[4 * NT1] = gB[NT1][0];
+      RSX_PUSH(fB, NFB, 9, gtag)
+      RSX_REDUCE(fA, NFA, 0, gtag)                                         // (sent before layer 1's local hand-off: long there)
+#pragma unroll
+      for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gA[k][e] = fA[4 * k + e];
+      gA[5][0] = fA[20]; gA[5][1] = fA[21];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gA[6][e] = fA[22 + e];
+      l2_terms_a();
+      RSX_REDUCE(fB, NFB, 9, gtag)                                         // the exposed cross-rank hand-off
+#pragma unroll
+      for (int k = 0; k < NT1; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gB[k][e] = fB[4 * k + e];
+      gB[NT1][0] = fB[4 * NT1];
     }
     // ---- layer 1: L2 term, norm share out, then Adam at once with clip coefficient 1 -- max_grad_norm almost never binds, and the
     // next forward waits for nothing else.  Backups in registers; the joint norm is checked behind b1 (below).
@@ -893,6 +1049,9 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
 #undef RS_POLL_SUM
 #undef RS_POLL
 #undef RS_LOADS
+#undef RSX_PUSH
+#undef RSX_POLL
+#undef RSX_REDUCE
   // ---- write back (row group 0 of every network; a launch that timed out leaves theta and the optimiser state untouched)
   if (hf == 0 && *dead == 0.f) {
     RS_REIDX
@@ -940,7 +1099,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
 #undef RS_STAMP
 }
 
-template <int KIN, int R, bool PROF>
+template <int KIN, int R, bool PROF, int XW = 0>
 __global__ __launch_bounds__(512) void ppo_update_rs_kernel(RsArgs a) {
   if (blockIdx.x & 7) return;                    // placement hint (update.hip): the working blocks land on one XCD and share its L2
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -971,8 +1130,8 @@ __global__ __launch_bounds__(512) void ppo_update_rs_kernel(RsArgs a) {
     fast = (red[96] == 0.f) && !a.force_safe;
     __syncthreads();
   }
-  if (fast) rs_body<KIN, R, true, PROF>(a, lds);
-  else rs_body<KIN, R, false, PROF>(a, lds);
+  if (fast) rs_body<KIN, R, true, PROF, XW>(a, lds);
+  else rs_body<KIN, R, false, PROF, XW>(a, lds);
 }
 
 // Exchange scratch: the partial-gradient slots and the norm granules, ordinary device memory.  One block per (device, stream),
@@ -1013,18 +1172,18 @@ int rs_scratch(hipStream_t st, float** z, unsigned long long** gran, unsigned* t
   return 0;
 }
 
-template <int KIN, int R, bool PROF>
+template <int KIN, int R, bool PROF, int XW = 0>
 int rs_launch_k(const RsArgs& a, hipStream_t st) {
   const size_t sh = RsLds<KIN>::SIZE * sizeof(float);
   static bool attr_done[SPO_MAX_DEVICES] = {};
   const int dslot = current_device_slot();
   if (!attr_done[dslot]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_update_rs_kernel<KIN, R, PROF>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_update_rs_kernel<KIN, R, PROF, XW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return spo::hip_check(e, "hipFuncSetAttribute(update_rs)");
     attr_done[dslot] = true;
   }
-  hipLaunchKernelGGL((ppo_update_rs_kernel<KIN, R, PROF>), dim3(8 * (a.n_nets * R - 1) + 1), dim3(512), sh, st, a);
+  hipLaunchKernelGGL((ppo_update_rs_kernel<KIN, R, PROF, XW>), dim3(8 * (a.n_nets * R - 1) + 1), dim3(512), sh, st, a);
   return 0;
 }
 
@@ -1090,4 +1249,36 @@ int spo::rs_update_launch(float* theta, float* adam_m, float* adam_v, int64_t ad
   }
   if (kin == 16) RS_GO(16) else if (kin == 32) RS_GO(32) else RS_GO(64)
 #undef RS_GO
+}
+
+// Data-parallel form (one rank of `world` = 2, 4 or 8): the same kernel with the cross-rank stage (rs_body, XW).  Called by
+// spo_ppo_lag_update_iter_dp when SPO_XR_FORM_ROW_SPLIT is the form (update.hip); rsx_off = offset of the row-split section in
+// every rank's exchange region.
+int spo::rs_update_launch_dp(float* theta, float* adam_m, float* adam_v, int64_t adam_step_host, const float* obs, const float* act,
+                             const float* logp_old, const float* target_r, const float* target_c, const float* adv,
+                             const int32_t* perm, int64_t M, const spo_ppo_cfg* cfg_host, float* losses_out, void* sync_ws,
+                             int rank, int world, void* const* regions, uint32_t step0, size_t rsx_off, void* stream) {
+  SPO_REQUIRE(world == 2 || world == 4 || world == 8, "update_rs (data-parallel): world size %d is not 2, 4 or 8", world);
+  SPO_REQUIRE(cfg_host->batch <= 64, "update_rs (data-parallel): batch %d > 64", cfg_host->batch);
+  hipStream_t st = (hipStream_t)stream;
+  RsArgs a{};
+  a.theta = theta; a.adam_m = adam_m; a.adam_v = adam_v;
+  a.obs = obs; a.act = act; a.logp_old = logp_old; a.tgt_r = target_r; a.tgt_c = target_c; a.adv = adv;
+  a.perm = perm; a.M = M; a.cfg = *cfg_host; a.losses = losses_out;
+  a.err = reinterpret_cast<int*>(reinterpret_cast<char*>(sync_ws) + 64);
+  a.pow_b1 = pow((double)cfg_host->beta1, (double)adam_step_host);
+  a.pow_b2 = pow((double)cfg_host->beta2, (double)adam_step_host);
+  a.n_nets = 3; a.first_net = 0; a.stale_io = nullptr; a.prof = nullptr; a.prof_wg = -1;
+  { const char* e = getenv("SPO_RS_SAFE"); a.force_safe = (e && *e && *e != '0') ? 1 : 0; }
+  for (int r = 0; r < 8; ++r) a.xr_region[r] = r < world ? regions[r] : nullptr;
+  a.xr_rank = rank; a.xr_step0 = step0; a.rsx_off = rsx_off;
+  const int64_t nsteps = (M + cfg_host->batch - 1) / cfg_host->batch;
+  SPO_REQUIRE(nsteps < (1ll << 30), "update_rs: too many minibatch steps in one launch");
+  if (int rc = rs_scratch(st, &a.zbuf, &a.gran, &a.tag_base, (unsigned)nsteps)) return rc;
+  if (int rc = spo::hip_check(hipMemsetAsync(a.zbuf, 0xFF, rs_z_bytes(2), st), "hipMemsetAsync(rs slots)")) return rc;
+  const int kin = cfg_host->obs_dim <= 16 ? 16 : cfg_host->obs_dim <= 32 ? 32 : 64;
+#define RS_GO_DP(K) (world == 2 ? rs_launch_k<K, 2, false, 2>(a, st) : world == 4 ? rs_launch_k<K, 2, false, 4>(a, st) \
+                                                                                     : rs_launch_k<K, 2, false, 8>(a, st))
+  return kin == 16 ? RS_GO_DP(16) : kin == 32 ? RS_GO_DP(32) : RS_GO_DP(64);
+#undef RS_GO_DP
 }

@@ -221,7 +221,8 @@ class PeerExchange:
     FORM_NAMES = {0: "two-phase (packed reduce-scatter + all-gather, four-wave kernel)",
                   1: "recursive doubling of packed words (four-wave kernel)",
                   2: "one-shot all-to-all with flags (helper waves)",
-                  3: "recursive doubling of packed words (helper waves)"}
+                  3: "recursive doubling of packed words (helper waves)",
+                  4: "row-split kernel, one-hand-off all-to-all of tagged words behind the row groups' L2 hand-off"}
 
     def autotune(self, obs_dim: int, act_dim: int, steps: int = 192, with_rccl: bool = True) -> dict:
         """Start-up selection of the per-minibatch exchange on THIS topology: every form of the in-kernel
@@ -257,8 +258,9 @@ class PeerExchange:
             return float("inf") if v >= 1e29 else v
 
         table = {}
-        for form in (1, 0, 2, 3):
-            if not lib.spo_p2p_form_valid(form, self.world):
+        only = os.environ.get("SPO_P2P_AUTOTUNE_FORMS")          # (development: restrict the table, e.g. "1,4")
+        for form in (1, 0, 2, 3, 4):
+            if not lib.spo_p2p_form_valid(form, self.world) or (only and str(form) not in only.split(",")):
                 continue
             _abi.check(lib.spo_p2p_select_form(form), "spo_p2p_select_form")
             us, failed = float("inf"), False

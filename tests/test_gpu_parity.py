@@ -2073,11 +2073,12 @@ def test_multi_agent_masked_gae_popart_bit_exact(dev, golden_dir, tag):
     assert np.array_equal(buf.cost_returns.cpu().numpy().view(np.uint32), z[f"{tag}_cost_returns"].view(np.uint32))
 
 
-@pytest.mark.parametrize("algo", ["pair", "twophase", "a2a", "helper16"])
+@pytest.mark.parametrize("algo", ["pair", "twophase", "a2a", "helper16", "rowsplit"])
 def test_in_kernel_gradient_exchange_two_ranks_one_gpu(dev, tmp_path, algo):
     """SURVEY.md 8(e) in-kernel form: two ranks (two processes, this one GPU, regions mapped through IPC handles) run
     the data-parallel persistent kernel.  Replicas must stay bit-identical and match the kernel / all-reduce / kernel
-    form of the same steps."""
+    form of the same steps.  "rowsplit" (round 6): the row-split kernel, its one-hand-off all-to-all of tagged words behind the
+    row groups' L2 hand-off (SPO_XR_FORM_ROW_SPLIT; 2 x 6 co-resident workgroups here)."""
     import json
     import socket
     import subprocess
@@ -3365,6 +3366,14 @@ def test_bench_self_launches_two_ranks_on_one_gpu(dev, dp_batch):
     ex = d["exchange"]
     assert ex["dp_batch"] == dp_batch and ex["host_collectives_world"] == 2 and ex["all_ranks_on_one_gpu"] is True
     assert ex["form"].startswith("in-kernel") and ex["selftest_result"] == [0, 0], ex
+    # the start-up auto-tune ran on every rank, pinned ONE form everywhere (the line's `form` is what rank 0's library
+    # reports as current; `chosen` is the table's verdict, which the max-reduce over the ranks makes the same on all of them), and
+    # lists the round-6 form
+    tab = ex["autotune"]
+    assert tab and tab.get("chosen") and "default_form" in tab, tab
+    assert any(k.startswith("row-split kernel") and v is not None for k, v in tab.items() if k not in ("chosen", "unit", "default_form", "margin")), tab
+    assert tab["chosen"] in ex["form"] or tab["chosen"].startswith("kernel /"), (tab["chosen"], ex["form"])
+    assert d.get("replicas_identical_after_run") is True, d.get("replicas_identical_after_run")
     per_rank_rows = 64 if dp_batch == "local" else 32
     assert d["config"]["minibatch_steps_per_epoch"] == (256 * 32 // per_rank_rows) * 2
     assert d["value"] == pytest.approx(2 * 256 * 32 / (d["ms_per_step"] * 1e-3), rel=1e-3)

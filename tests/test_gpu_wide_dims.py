@@ -419,11 +419,17 @@ def test_feature_split_kernel_full_size_drift_envelope_at_humanoid_dims(dev):
         #  the widened floor must be serving a handful of Adam-amplified elements, not a systematic offset: at most
         # 0.1 % of the vector may need it at any checkpoint
         assert frac <= 1e-3, f"after {k} steps {users[k].size} elements ({frac:.2%}) need the widened max-norm floor"
-    # ... and not one and the same parameter at every checkpoint (a replica of b3 / log_std or the Adam state of a slice edge going
-    # wrong would show up as the SAME index every time)
-    nonempty = [set(v.tolist()) for v in users.values() if v.size]
-    if len(nonempty) >= 3:
-        assert len(set.intersection(*nonempty)) == 0, f"the same parameters need the floor at every checkpoint: {set.intersection(*nonempty)}"
+    # ... and they must be what the floor's rationale says they are -- elements whose gradient is far below the typical size, where
+    # Adam's normalised step turns rounding noise of the gradient into full-size steps of either sign (the shorter launches are
+    # prefixes of the longest, so an element that left the narrow gate early stays out: the same index at later checkpoints is
+    # expected; a replica of b3 / log_std or the Adam state of a slice edge going wrong would NOT have a small second moment)
+    last = users[kmax]
+    if last.size:
+        v_all = eng.adam_v.double().cpu().numpy()
+        ratio_v = float(v_all[last].max() / np.median(v_all[v_all > 0]))
+        print(f"second moment of the elements beyond the narrow gate after {kmax} steps / median second moment: {ratio_v:.3e} "
+              f"(indices {last.tolist()[:8]})")
+        assert ratio_v < 0.25, f"elements {last.tolist()[:8]} need the widened floor although their gradients are not small ({ratio_v:.3e})"
     print("feature-split kernel, 376 / 17, drift envelope (ratio <= 1 passes):", rep)
     print("elements beyond 3 x the fp32 oracle's maximum + 2e-7 per checkpoint:", {k: v.tolist()[:8] for k, v in users.items()})
 

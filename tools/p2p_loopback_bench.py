@@ -78,6 +78,17 @@ def main(world=2, M=8192, iters=3, D=60, A=8):
                     _abi.ptr(losses[r]), _abi.ptr(eng.sync_ws), r, world, regions, step0 & 0xFFFFFFFF,
                     _abi.stream_ptr()), "dp")
             eng.adam_step += n_mb
+    # every stream's scratch blocks (row-split kernel: exchange slots, granules) are allocated at the stream's first launch, with a
+    # device synchronisation: do that now, one rank after the other, not between the ranks' first data-parallel launches
+    for r, eng in enumerate(engines):
+        with torch.cuda.stream(streams[r]):
+            th0, m0, v0, st0 = eng.policy.theta.clone(), eng.adam_m.clone(), eng.adam_v.clone(), eng.adam_step
+            eng.learning_iter(perms[r][:128].contiguous()) if False else None
+            eng.M, keep = 128, eng.M
+            eng.learning_iter(perms[r][:128].contiguous() % 128)
+            eng.M = keep
+            eng.policy.theta.copy_(th0); eng.adam_m.copy_(m0); eng.adam_v.copy_(v0); eng.adam_step = st0
+        torch.cuda.synchronize()
     torch.cuda.synchronize()
     step0 = xstep
     launch_all(step0); step0 += n_mb
@@ -109,8 +120,8 @@ def main(world=2, M=8192, iters=3, D=60, A=8):
 
 if __name__ == "__main__":
     worlds = [int(a) for a in sys.argv[1:]] or [2, 4, 8]
-    if len(worlds) == 1:
-        main(world=worlds[0])
+    if len(worlds) == 1 and os.environ.get("GPU_MAX_HW_QUEUES"):
+        main(world=worlds[0], M=int(os.environ.get("SPO_LOOPBACK_M", "8192")))
     else:
         # one process per world size: the W streams of a run must land on W different hardware queues, and streams left over
         # from an earlier world size in the same process shift that assignment (GPU_MAX_HW_QUEUES=24 gives 8 ranks room)
