@@ -42,15 +42,15 @@
 namespace {
 using namespace spo;
 
-constexpr int LDC = 32 + 4;                      // [feature][batch] LDS row stride (floats): 32 batch columns per workgroup
 constexpr int RS_NS = 16;                        // exchange slots (16-byte groups per lane) per (destination, source): NT1 + 8 <= 12 used
 constexpr int RS_MAX_R = 4;
 constexpr unsigned RS_SPIN_LIMIT = 1u << 22;
 constexpr int RS_NPHASE = 12;
 
-template <int KIN>
-struct RsLds {                                   // floats
+template <int KIN, int NCT>
+struct RsLds {                                   // floats; NCT = 16-column tiles per workgroup (2: 32 rows of a minibatch, 1: 16)
   using L = NetLds<KIN>;
+  static constexpr int LDC = 16 * NCT + 4;       // [feature][batch] LDS row stride
   static constexpr int LS = L::SIZE;             // log_std mirror (16)
   static constexpr int XT = LS + 16;             // two x^T images (double-buffered across steps)
   static constexpr int H1T = XT + 2 * KIN * LDC;
@@ -143,32 +143,32 @@ __device__ __forceinline__ void pin_u4(u4v& v) {                 // (an inline-a
 #endif
 }
 
-// Half of a hidden layer for one column tile: output tiles 2 FH, 2 FH + 1 of out[] (rows 16 mt + 4 q + reg, col batch) = tanh?(W in + b);
-// the other two entries of out[] are left alone (they are the partner wave's).  Two independent accumulator chains (dependent
-// distance 64 cycles >= the 40-cycle accumulator latency), A tiles double-buffered like layer_hidden.
-template <int NT_IN, int FH, bool TANH>
-__device__ __forceinline__ void layer_half(const float* Wl, int ld, const float* bl, const f4 (&in)[NT_IN], f4 (&out)[HID / 16],
+// A part of a hidden layer for one column tile: output tiles M0 .. M0 + NOWN - 1 of out[] (rows 16 mt + 4 q + reg, col batch) =
+// tanh?(W in + b); the other entries of out[] are left alone (they are the partner waves').  NOWN = 2: two independent accumulator
+// chains (dependent distance 64 cycles >= the 40-cycle accumulator latency); NOWN = 1: one chain (each element the same fmaf
+// chain as in layer_hidden).  A tiles double-buffered like layer_hidden.
+template <int NT_IN, int M0, int NOWN, bool TANH>
+__device__ __forceinline__ void layer_part(const float* Wl, int ld, const float* bl, const f4 (&in)[NT_IN], f4 (&out)[HID / 16],
                                            int j, int q) {
-  constexpr int M0 = 2 * FH;
-  f4 acc[2], a[2][2];
+  f4 acc[NOWN], a[2][NOWN];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) a[0][t] = *reinterpret_cast<const f4*>(Wl + (16 * (M0 + t) + j) * ld + 4 * q);
+  for (int t = 0; t < NOWN; ++t) a[0][t] = *reinterpret_cast<const f4*>(Wl + (16 * (M0 + t) + j) * ld + 4 * q);
 #pragma unroll
-  for (int t = 0; t < 2; ++t) acc[t] = *reinterpret_cast<const f4*>(bl + 16 * (M0 + t) + 4 * q);
+  for (int t = 0; t < NOWN; ++t) acc[t] = *reinterpret_cast<const f4*>(bl + 16 * (M0 + t) + 4 * q);
 #pragma unroll
   for (int nt = 0; nt < NT_IN; ++nt) {
     if (nt + 1 < NT_IN) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < NOWN; ++t)
         a[(nt + 1) & 1][t] = *reinterpret_cast<const f4*>(Wl + (16 * (M0 + t) + j) * ld + 16 * (nt + 1) + 4 * q);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) acc[t] = mfma4(a[nt & 1][t][r], in[nt][r], acc[t]);
+      for (int t = 0; t < NOWN; ++t) acc[t] = mfma4(a[nt & 1][t][r], in[nt][r], acc[t]);
   }
 #pragma unroll
-  for (int t = 0; t < 2; ++t) out[M0 + t] = TANH ? fast_tanh4(acc[t]) : acc[t];
+  for (int t = 0; t < NOWN; ++t) out[M0 + t] = TANH ? fast_tanh4(acc[t]) : acc[t];
 }
 
 // FAST: every workgroup of the launch sits on one XCD (checked by the kernel), stores of the exchange stay plain
@@ -177,11 +177,16 @@ __device__ __forceinline__ void layer_half(const float* Wl, int ld, const float*
 // store each, untorn -- into a private slot of the same row group's workgroup on EVERY other rank (one hand-off on W - 1 links at
 // once), polls the W - 1 slots of its own region and adds the W contributions in rank order (its own at its
 // position): the same expression on every rank, so all replicas continue from identical bits; then the mean over the ranks.  Tags are the global optimiser-step count, slots double-buffered by its parity (update.hip).
-template <int KIN, int R, bool FAST, bool PROF, int XW = 0>
+// NCT: 16-column tiles per workgroup -- 2: 32 rows of every minibatch, the four column waves are 2 column tiles x 2 feature halves;
+// 1: 16 rows, the four column waves are the four feature quarters of the one tile (the PPO-Lagrangian step at R = 4: half the
+// matrix work per SIMD again).
+template <int KIN, int R, bool FAST, bool PROF, int XW = 0, int NCT = 2>
 __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
   using L = NetLds<KIN>;
-  using S = RsLds<KIN>;
+  using S = RsLds<KIN, NCT>;
+  constexpr int LDC = S::LDC;
   constexpr int NT1 = KIN / 16;
+  constexpr int NOWN = NCT, NPART = 4 / NCT;      // output tiles per column wave, waves per column tile
   unsigned long long pacc[RS_NPHASE] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = 0;
 #define RS_STAMP(i)                                            \
@@ -214,10 +219,10 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
     // column wave cw: column tile ct = cw & 1 (16 batch columns), feature half fh = cw >> 1 (output tiles 2 fh, 2 fh + 1 of every
     // hidden layer / backward product).  Two separate instantiations of the loop (fh is a constant in each: every register array
     // is indexed statically).
-    const int cw = wave8 - 4, ct = cw & 1, fh_rt = cw >> 1;
+    const int cw = wave8 - 4, ct = cw % NCT, part_rt = cw / NCT;
     int j = j_, q = q_;
-    int lcol = 16 * ct + j_;                     // column inside the workgroup's 32
-    const int gcol = 32 * hf + 16 * ct + j_;     // column inside the minibatch
+    int lcol = 16 * ct + j_;                     // column inside the workgroup's 16 NCT
+    const int gcol = 16 * NCT * hf + 16 * ct + j_;     // column inside the minibatch
 #define RS_REIDX { j = pin(j_); q = pin(q_); lcol = 16 * ct + j; }
     const float clip_lo = 1.f - a.cfg.clip, clip_hi = 1.f + a.cfg.clip;
     const float* tgt = (net == 0) ? a.tgt_r : a.tgt_c;
@@ -257,9 +262,10 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
         }
       }
     };
-    auto col_loop = [&](auto FHC) {
-    constexpr int FH = decltype(FHC)::value;
-    constexpr int M0 = 2 * FH, P0 = 2 - M0;      // own output tiles M0, M0 + 1; the partner wave's P0, P0 + 1
+    auto col_loop = [&](auto PARTC) {
+    constexpr int PART = decltype(PARTC)::value;
+    constexpr int M0 = PART * NOWN;              // own output tiles M0 .. M0 + NOWN - 1; the others are the partner waves'
+#define RS_OWN(MT) ((MT) >= M0 && (MT) < M0 + NOWN)
     // Pipeline of the column inputs, all of it behind this wave's half of L1 -- where it would otherwise wait for the optimiser waves
     // (W2) -- and nothing in the stretch between b5 and b1, where the SIMD belongs to the optimiser wave: in step s the rows of
     // minibatch s + 1 (requested during step s - 1: a whole step to land; barriers do not drain loads) are picked up (pad selects,
@@ -270,7 +276,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
     if (nsteps > 1) fetch((int64_t)a.perm[perm_pos(1)], raw);
     if (nsteps > 2) smp2 = a.perm[perm_pos(2)];
     settle(nxt);
-    if (FH == 0) {
+    if (PART == 0) {
 #pragma unroll
       for (int nt = 0; nt < NT1; ++nt)
 #pragma unroll
@@ -293,9 +299,9 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
       RS_STAMP(1)
       {
         RS_REIDX
-        layer_half<NT1, FH, true>(lds + L::W1, L::LD1, lds + L::B1, cur.x, h1, j, q);
+        layer_part<NT1, M0, NOWN, true>(lds + L::W1, L::LD1, lds + L::B1, cur.x, h1, j, q);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NOWN; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) lds[S::H1T + (16 * (M0 + t) + 4 * q + r) * LDC + lcol] = h1[M0 + t][r];
       }
@@ -305,7 +311,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
         nxt = raw;
         if (s + 2 < nsteps) fetch((int64_t)pin(smp2), raw);
         if (s + 3 < nsteps) smp2 = a.perm[perm_pos(s + 3)];
-        if (FH == 0) {
+        if (PART == 0) {
           float* const xt = lds + S::XT + (int)((s + 1) & 1) * KIN * LDC;
 #pragma unroll
           for (int nt = 0; nt < NT1; ++nt)
@@ -320,9 +326,9 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
         // the previous step turned out clipped: W1 / b1 were restored and redone exactly while this L1 ran (complete before b2) --
         // once more on the exact weights, and one more barrier for the two halves (the optimiser waves run it too)
         RS_REIDX
-        layer_half<NT1, FH, true>(lds + L::W1, L::LD1, lds + L::B1, cur.x, h1, j, q);
+        layer_part<NT1, M0, NOWN, true>(lds + L::W1, L::LD1, lds + L::B1, cur.x, h1, j, q);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NOWN; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) lds[S::H1T + (16 * (M0 + t) + 4 * q + r) * LDC + lcol] = h1[M0 + t][r];
         __syncthreads();
@@ -330,12 +336,14 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
       {
         RS_REIDX
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int mt = 0; mt < 4; ++mt)
+          if (!RS_OWN(mt)) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) h1[P0 + t][r] = lds[S::H1T + (16 * (P0 + t) + 4 * q + r) * LDC + lcol];
-        layer_half<4, FH, true>(lds + L::W2, LDH, lds + L::B2, h1, h2, j, q);
+            for (int r = 0; r < 4; ++r) h1[mt][r] = lds[S::H1T + (16 * mt + 4 * q + r) * LDC + lcol];
+          }
+        layer_part<4, M0, NOWN, true>(lds + L::W2, LDH, lds + L::B2, h1, h2, j, q);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NOWN; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) lds[S::H2T + (16 * (M0 + t) + 4 * q + r) * LDC + lcol] = h2[M0 + t][r];
       }
@@ -346,14 +354,16 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
       {
         RS_REIDX
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int mt = 0; mt < 4; ++mt)
+          if (!RS_OWN(mt)) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) h2[P0 + t][r] = lds[S::H2T + (16 * (P0 + t) + 4 * q + r) * LDC + lcol];
-        float w3c[4][2];                                                 // issued early: their latency hides under the output layer and the loss
+            for (int r = 0; r < 4; ++r) h2[mt][r] = lds[S::H2T + (16 * mt + 4 * q + r) * LDC + lcol];
+          }
+        float w3c[4][NOWN];                                                 // issued early: their latency hides under the output layer and the loss
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int t = 0; t < 2; ++t) w3c[r][t] = lds[L::W3 + (4 * q + r) * LDH + 16 * (M0 + t) + j];
+          for (int t = 0; t < NOWN; ++t) w3c[r][t] = lds[L::W3 + (4 * q + r) * LDH + 16 * (M0 + t) + j];
         const f4 o = layer_out(lds + L::W3, lds + L::B3, h2, j, q);      // (both halves of a column tile: the same 8 products)
         float ivar[4], lsd[4], amask[4];
 #pragma unroll
@@ -401,22 +411,22 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
           }
         }
         // dO -> dZ2 (own half)
-        f4 acc[2];
+        f4 acc[NOWN];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NOWN; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int t = 0; t < 2; ++t) acc[t] = mfma4(w3c[r][t], dO[r], acc[t]);
+          for (int t = 0; t < NOWN; ++t) acc[t] = mfma4(w3c[r][t], dO[r], acc[t]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NOWN; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) dz2[M0 + t][r] = acc[t][r] * fmaf(-h2[M0 + t][r], h2[M0 + t][r], 1.f);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NOWN; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) lds[S::DZ2T + (16 * (M0 + t) + 4 * q + r) * LDC + lcol] = dz2[M0 + t][r];
-        if (FH == 0) {
+        if (PART == 0) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) lds[S::DOT + (4 * q + r) * LDC + lcol] = dO[r];
           // loss / d(log_std) partials of this column tile: they travel with the layer-2 / 3 gradients
@@ -437,37 +447,39 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
       {
         RS_REIDX
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int mt = 0; mt < 4; ++mt)
+          if (!RS_OWN(mt)) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dz2[P0 + t][r] = lds[S::DZ2T + (16 * (P0 + t) + 4 * q + r) * LDC + lcol];
-        f4 acc[2], dz1[2];
+            for (int r = 0; r < 4; ++r) dz2[mt][r] = lds[S::DZ2T + (16 * mt + 4 * q + r) * LDC + lcol];
+          }
+        f4 acc[NOWN], dz1[NOWN];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
-        float w2c[2][4][2];
+        for (int t = 0; t < NOWN; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+        float w2c[2][4][NOWN];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int t = 0; t < 2; ++t) w2c[0][r][t] = lds[L::W2 + (4 * q + r) * LDH + 16 * (M0 + t) + j];
+          for (int t = 0; t < NOWN; ++t) w2c[0][r][t] = lds[L::W2 + (4 * q + r) * LDH + 16 * (M0 + t) + j];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
           if (nt + 1 < 4) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-              for (int t = 0; t < 2; ++t)
+              for (int t = 0; t < NOWN; ++t)
                 w2c[(nt + 1) & 1][r][t] = lds[L::W2 + (16 * (nt + 1) + 4 * q + r) * LDH + 16 * (M0 + t) + j];
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) acc[t] = mfma4(w2c[nt & 1][r][t], dz2[nt][r], acc[t]);
+            for (int t = 0; t < NOWN; ++t) acc[t] = mfma4(w2c[nt & 1][r][t], dz2[nt][r], acc[t]);
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NOWN; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) dz1[t][r] = acc[t][r] * fmaf(-h1[M0 + t][r], h1[M0 + t][r], 1.f);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NOWN; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) lds[S::DZ1T + (16 * (M0 + t) + 4 * q + r) * LDC + lcol] = dz1[t][r];
       }
@@ -476,8 +488,11 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
       RS_STAMP(9)
     }
     };
-    if (fh_rt == 0) col_loop(std::integral_constant<int, 0>{});
-    else col_loop(std::integral_constant<int, 1>{});
+    if (part_rt == 0) col_loop(std::integral_constant<int, 0>{});
+    else if (part_rt == 1) col_loop(std::integral_constant<int, 1>{});
+    else if (NPART == 4 && part_rt == 2) col_loop(std::integral_constant<int, NPART == 4 ? 2 : 0>{});
+    else col_loop(std::integral_constant<int, NPART == 4 ? 3 : 0>{});
+#undef RS_OWN
     if (PROF && a.prof && lane == 0 && cw == 0 && wg == a.prof_wg)
       for (int i = 0; i < RS_NPHASE; ++i) a.prof[i] = pacc[i];
     __syncthreads();                                                      // after the loop: the last update is complete
@@ -709,9 +724,9 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
     {
       // ---- dW2, dW3 over this workgroup's 32 rows; db2, db3
       RS_REIDX
-      f4 az2[2], az3[2], bh[2][4], b3[2];
+      f4 az2[NCT], az3[NCT], bh[NCT][4], b3[NCT];
 #pragma unroll
-      for (int r4 = 0; r4 < 2; ++r4) {
+      for (int r4 = 0; r4 < NCT; ++r4) {
         az2[r4] = *reinterpret_cast<const f4*>(lds + S::DZ2T + (16 * ow + j) * LDC + 16 * r4 + 4 * q);
         az3[r4] = *reinterpret_cast<const f4*>(lds + S::DOT + j * LDC + 16 * r4 + 4 * q);
 #pragma unroll
@@ -723,7 +738,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
       for (int nt = 0; nt < 4; ++nt) gA[nt] = f4{0.f, 0.f, 0.f, 0.f};
       f4 w3a = {0.f, 0.f, 0.f, 0.f}, w3b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r4 = 0; r4 < 2; ++r4)
+      for (int r4 = 0; r4 < NCT; ++r4)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -731,12 +746,12 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         w3a = mfma4(az3[0][e], b3[0][e], w3a);
-        w3b = mfma4(az3[1][e], b3[1][e], w3b);
+        if constexpr (NCT > 1) w3b = mfma4(az3[NCT - 1][e], b3[NCT - 1][e], w3b);
       }
       gA[4] = w3a + w3b;
       float rs2 = 0.f, rs3 = 0.f;
 #pragma unroll
-      for (int r4 = 0; r4 < 2; ++r4) {
+      for (int r4 = 0; r4 < NCT; ++r4) {
         rs2 += (az2[r4][0] + az2[r4][1]) + (az2[r4][2] + az2[r4][3]);
         rs3 += (az3[r4][0] + az3[r4][1]) + (az3[r4][2] + az3[r4][3]);
       }
@@ -747,13 +762,13 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
     }
     // ---- the optimiser waits for the last image here anyway (the column waves' last backward product is longer than dW2 / dW3):
     // the x^T operands of dW1 (complete since b1), this lane's W1 / b1 parameters (L2 term, backup), the optimiser scalars of the step
-    f4 bx[2][NT1], pW1[NT1];
+    f4 bx[NCT][NT1], pW1[NT1];
     float pb1;
     {
       RS_REIDX
       const float* const xt = lds + S::XT + par * KIN * LDC;
 #pragma unroll
-      for (int r4 = 0; r4 < 2; ++r4)
+      for (int r4 = 0; r4 < NCT; ++r4)
 #pragma unroll
         for (int nt = 0; nt < NT1; ++nt)
           bx[r4][nt] = *reinterpret_cast<const f4*>(xt + (16 * nt + j) * LDC + 16 * r4 + 4 * q);
@@ -775,21 +790,21 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
     {
       // ---- dW1, db1
       RS_REIDX
-      f4 az1[2];
+      f4 az1[NCT];
 #pragma unroll
-      for (int r4 = 0; r4 < 2; ++r4)
+      for (int r4 = 0; r4 < NCT; ++r4)
         az1[r4] = *reinterpret_cast<const f4*>(lds + S::DZ1T + (16 * ow + j) * LDC + 16 * r4 + 4 * q);
 #pragma unroll
       for (int nt = 0; nt < NT1; ++nt) gB[nt] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r4 = 0; r4 < 2; ++r4)
+      for (int r4 = 0; r4 < NCT; ++r4)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int nt = 0; nt < NT1; ++nt) gB[nt] = mfma4(az1[r4][e], bx[r4][nt][e], gB[nt]);
       float rs1 = 0.f;
 #pragma unroll
-      for (int r4 = 0; r4 < 2; ++r4) rs1 += (az1[r4][0] + az1[r4][1]) + (az1[r4][2] + az1[r4][3]);
+      for (int r4 = 0; r4 < NCT; ++r4) rs1 += (az1[r4][0] + az1[r4][1]) + (az1[r4][2] + az1[r4][3]);
       gB[NT1] = f4{quad_row_sum(rs1), 0.f, 0.f, 0.f};
       RS_PUSH(gB, NT1 + 1, 0, par)
     }
@@ -1099,11 +1114,11 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
 #undef RS_STAMP
 }
 
-template <int KIN, int R, bool PROF, int XW = 0>
+template <int KIN, int R, bool PROF, int XW = 0, int NCT = 2>
 __global__ __launch_bounds__(512) void ppo_update_rs_kernel(RsArgs a) {
   if (blockIdx.x & 7) return;                    // placement hint (update.hip): the working blocks land on one XCD and share its L2
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* const red = lds + RsLds<KIN>::RED;
+  float* const red = lds + RsLds<KIN, NCT>::RED;
   const int wg = (int)(blockIdx.x >> 3), tid = threadIdx.x;
   // ---- placement census (update_ks.hip): do all workgroups of the launch share one XCD (one L2)?  Checked, once per launch,
   // over words every placement delivers; not co-resident (or SPO_RS_SAFE=1): write-through exchange stores, same results.
@@ -1130,8 +1145,8 @@ __global__ __launch_bounds__(512) void ppo_update_rs_kernel(RsArgs a) {
     fast = (red[96] == 0.f) && !a.force_safe;
     __syncthreads();
   }
-  if (fast) rs_body<KIN, R, true, PROF, XW>(a, lds);
-  else rs_body<KIN, R, false, PROF, XW>(a, lds);
+  if (fast) rs_body<KIN, R, true, PROF, XW, NCT>(a, lds);
+  else rs_body<KIN, R, false, PROF, XW, NCT>(a, lds);
 }
 
 // Exchange scratch: the partial-gradient slots and the norm granules, ordinary device memory.  One block per (device, stream),
@@ -1172,18 +1187,18 @@ int rs_scratch(hipStream_t st, float** z, unsigned long long** gran, unsigned* t
   return 0;
 }
 
-template <int KIN, int R, bool PROF, int XW = 0>
+template <int KIN, int R, bool PROF, int XW = 0, int NCT = 2>
 int rs_launch_k(const RsArgs& a, hipStream_t st) {
-  const size_t sh = RsLds<KIN>::SIZE * sizeof(float);
+  const size_t sh = RsLds<KIN, NCT>::SIZE * sizeof(float);
   static bool attr_done[SPO_MAX_DEVICES] = {};
   const int dslot = current_device_slot();
   if (!attr_done[dslot]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_update_rs_kernel<KIN, R, PROF, XW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_update_rs_kernel<KIN, R, PROF, XW, NCT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return spo::hip_check(e, "hipFuncSetAttribute(update_rs)");
     attr_done[dslot] = true;
   }
-  hipLaunchKernelGGL((ppo_update_rs_kernel<KIN, R, PROF, XW>), dim3(8 * (a.n_nets * R - 1) + 1), dim3(512), sh, st, a);
+  hipLaunchKernelGGL((ppo_update_rs_kernel<KIN, R, PROF, XW, NCT>), dim3(8 * (a.n_nets * R - 1) + 1), dim3(512), sh, st, a);
   return 0;
 }
 
@@ -1234,17 +1249,24 @@ int spo::rs_update_launch(float* theta, float* adam_m, float* adam_v, int64_t ad
   a.pow_b2 = pow((double)cfg_host->beta2, (double)adam_step_host);
   a.n_nets = n_nets; a.first_net = 0; a.stale_io = stale_sq_io; a.prof = prof;
   { const char* e = getenv("SPO_RS_SAFE"); a.force_safe = (e && *e && *e != '0') ? 1 : 0; }
-  { const char* e = getenv("SPO_RS_PROF_WG"); a.prof_wg = (e && *e) ? atoi(e) : n_nets * (cfg_host->batch <= 64 ? 2 : 4) - 1; }
   const int64_t nsteps = (M + cfg_host->batch - 1) / cfg_host->batch;
   SPO_REQUIRE(nsteps < (1ll << 30), "update_rs: too many minibatch steps in one launch");
   if (int rc = rs_scratch(st, &a.zbuf, &a.gran, &a.tag_base, (unsigned)nsteps)) return rc;
-  const int R = cfg_host->batch <= 64 ? 2 : 4;
+  // Rows of a minibatch per workgroup: 32 (two row groups up to 64 rows, four up to 128: the critic fit's 128-row minibatches) or,
+  // opt-in, 16 (SPO_RS_ROWS=16: four row groups up to 64 rows, the column waves as four feature quarters of one column tile --
+  // measured SLOWER, 9.46 against 7.9 us per step: the matrix work per SIMD halves again, but three peers' partials to poll, add
+  // and reset put 10.9 k cycles between b5 and b1 where the two-row-group form has 5.4 k; profiles/r06/update_ab_rs.txt)
+  static const int rows_env = [] { const char* e = getenv("SPO_RS_ROWS"); return e ? atoi(e) : 32; }();
+  const bool rows16 = cfg_host->batch <= 64 && rows_env == 16;
+  const int R = (cfg_host->batch <= 64 && !rows16) ? 2 : 4;
+  { const char* e = getenv("SPO_RS_PROF_WG"); a.prof_wg = (e && *e) ? atoi(e) : n_nets * R - 1; }
   // every slot starts as the sentinel (a launch leaves them that way unless it stopped on an error)
   if (int rc = spo::hip_check(hipMemsetAsync(a.zbuf, 0xFF, R == 2 ? rs_z_bytes(2) : rs_z_bytes(4), st), "hipMemsetAsync(rs slots)")) return rc;
   const int kin = cfg_host->obs_dim <= 16 ? 16 : cfg_host->obs_dim <= 32 ? 32 : 64;
 #define RS_GO(K)                                                                                  \
   {                                                                                               \
-    if (R == 2) { if (prof && K == 64) return rs_launch_k<K, 2, (K == 64)>(a, st); return rs_launch_k<K, 2, false>(a, st); } \
+    if (rows16) { if (prof && K == 64) return rs_launch_k<K, 4, (K == 64), 0, 1>(a, st); return rs_launch_k<K, 4, false, 0, 1>(a, st); } \
+    if (R == 2) return rs_launch_k<K, 2, false>(a, st);                                           \
     return rs_launch_k<K, 4, false>(a, st);                                                       \
   }
   if (kin == 16) RS_GO(16) else if (kin == 32) RS_GO(32) else RS_GO(64)
