@@ -58,8 +58,8 @@ def _critic_fit_cases():
 
 
 def profile_path(name: str) -> str:
-    """The newest committed copy of a profile artefact (profiles/r05, else r04, r03, r02)."""
-    for rnd in ("r05", "r04", "r03", "r02"):
+    """The newest committed copy of a profile artefact (profiles/r06, else r05, r04, r03, r02)."""
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         p = os.path.join(ROOT, "profiles", rnd, name)
         if os.path.exists(p):
             return p
@@ -586,9 +586,23 @@ def main():
         g_s = big.time_scan(reps)
         b = GAE_BYTES_PER_ELEM * Ns * T
         del big
-        return {"num_envs": Ns, "bytes_per_launch": b, "avg_launch_us": round(d_s * 1e6, 1),
-                "achieved": round(b / d_s / 1e9, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": round(b / d_s / 1e9 / HBM_PEAK_GBS, 4),
-                "graph_avg_launch_us": round(g_s * 1e6, 1), "graph_frac": round(b / g_s / 1e9 / HBM_PEAK_GBS, 4)}
+        out = {"num_envs": Ns, "bytes_per_launch": b, "avg_launch_us": round(d_s * 1e6, 1),
+               "achieved": round(b / d_s / 1e9, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": round(b / d_s / 1e9 / HBM_PEAK_GBS, 4),
+               "graph_avg_launch_us": round(g_s * 1e6, 1), "graph_frac": round(b / g_s / 1e9 / HBM_PEAK_GBS, 4)}
+        # like the headline point: frac / achieved follow from the committed rocprofv3 per-dispatch average of
+        # this command when the summary holds this grid; the in-run event pairs stay beside it
+        try:
+            dj_ = json.load(open(profile_path("gae_dispatch_durations.json")))
+            hit_ = [v for k, v in dj_["per_kernel_and_grid_size"].items() if k.endswith(f"grid={2 * Ns * 32}") or k.endswith(f"grid={Ns * 32}")]
+            if hit_ and T == 128:
+                out["achieved_event_pairs"], out["frac_event_pairs"] = out["achieved"], out["frac"]
+                out["rocprof_avg_launch_us"], out["rocprof_launches"] = hit_[0]["avg_us"], hit_[0]["launches"]
+                out["achieved"] = round(b / (hit_[0]["avg_us"] * 1e-6) / 1e9, 1)
+                out["frac"] = round(out["achieved"] / HBM_PEAK_GBS, 4)
+                out["frac_source"] = os.path.relpath(profile_path("gae_dispatch_durations.json"), ROOT) + " (rocprofv3 --kernel-trace of this command)"
+        except Exception:
+            pass
+        return out
     stream, mid = None, None
     try:
         mid = scan_point(32768, 20)

@@ -786,7 +786,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
     RS_STAMP(3)
     // the first peer's layer-2 / 3 partials (sent at b4: long there): their round trip runs under the dW1 products
     u4 zwA[1][7];
-    RS_LOADS(zwA, 7, NT1 + 1, par, 1, 2)
+    if constexpr (R == 2) RS_LOADS(zwA, 7, NT1 + 1, par, 1, 2)            // (R = 4: 28 more live registers across dW1 spill the wave)
     {
       // ---- dW1, db1
       RS_REIDX
@@ -811,7 +811,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
     RS_STAMP(4)                                                            // dW1, stores
     // ---- while layer 1's partials travel: the peers' layer-2 / 3 partials (sent at b4: long there), their L2 terms and norm share
     // (before b5 this work would come straight out of the column waves' last backward product: the two waves of a SIMD add)
-    RS_POLL_SUM(gA, zwA, 7, NT1 + 1, par, 10, true)
+    RS_POLL_SUM(gA, zwA, 7, NT1 + 1, par, 10, (R == 2))
     const unsigned gtag = gtag0 + (unsigned)s;                             // (data-parallel form: the global step's tag)
     constexpr int NFA = 26, NFB = 4 * NT1 + 1;                             // floats that cross ranks: layers 2 / 3 (+ db2, db3, d log_std), layer 1 (+ db1)
     float fA[NFA];

@@ -1,3 +1,4 @@
+# GPU box: PMC passes over the persistent update launch (UPD_KERNEL: kernel-name substring, default the row-split kernel of round 6)
 # GPU box: PMC passes over the persistent update launch (tools/update_ab.py --one = 4 launches of 8192 minibatch steps).
 # One small counter group per pass (separate runs, --kernel-trace only); results -> gpurun_out/${SPO_ROUND:-r05}/update_pmc/*.csv
 set -x
@@ -15,7 +16,7 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE
   rm -rf /tmp/upmc$i
   timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/upmc$i -- python $GRAFT_REPO_ROOT/tools/update_ab.py --one > /tmp/upmc$i.log 2>&1
   f=$(find /tmp/upmc$i -name "*counter_collection.csv" | head -1)
-  if [ -n "$f" ]; then grep -E "Counter_Name|ppo_update_h_kernel" "$f" | head -400 > $O/pass$i.csv; else echo "pass $i ($grp): no counter file"; tail -3 /tmp/upmc$i.log; fi
+  if [ -n "$f" ]; then grep -E "Counter_Name|${UPD_KERNEL:-ppo_update_rs_kernel}" "$f" | head -400 > $O/pass$i.csv; else echo "pass $i ($grp): no counter file"; tail -3 /tmp/upmc$i.log; fi
 done
 python - <<'PY'
 import csv, glob, os, collections, json
@@ -23,7 +24,7 @@ O = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", os.environ.get("SP
 agg = collections.defaultdict(list)
 for f in sorted(glob.glob(O + "/pass*.csv")):
     for r in csv.DictReader(open(f)):
-        if "ppo_update_h_kernel" in r.get("Kernel_Name", ""):
+        if os.environ.get("UPD_KERNEL", "ppo_update_rs_kernel") in r.get("Kernel_Name", ""):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {k: {"mean_per_launch": sum(v) / len(v), "launches": len(v)} for k, v in agg.items()}
 json.dump(out, open(O + "/summary.json", "w"), indent=1)
