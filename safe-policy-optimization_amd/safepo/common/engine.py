@@ -564,7 +564,9 @@ class PPOLagEngine:
             raise _abi.SpoError("update kernel: a peer rank never answered the in-kernel gradient exchange "
                                 "(set SPO_P2P=0 to use the RCCL form)")
         if code:
-            raise _abi.SpoError("update kernel: inter-workgroup exchange timed out")
+            raise _abi.SpoError("update kernel: inter-workgroup exchange timed out (the workgroups of the persistent launch were not "
+                                "co-resident; the row-split kernel leaves theta and the optimiser state as they were -- "
+                                "SPO_UPDATE_FORM=2 selects the one-workgroup-per-network kernel)")
 
     def drop_peer_exchange(self):
         """Leave the in-kernel gradient exchange for the RCCL form of the minibatch step (after a peer timeout): close the
