@@ -66,6 +66,18 @@ def profile_path(name: str) -> str:
     return os.path.join(ROOT, "profiles", "r03", name)
 
 
+def recorded_port_full_size(algo: str):
+    """The oracle port timed ONCE at the full workload size in the build container (profiles/r06/cpu_port_full_size.json, round 6):
+    the sample's linearity as a measurement -- same box as reference_recorded's full-size figure."""
+    try:
+        rec = json.load(open(profile_path("cpu_port_full_size.json")))
+        if rec.get("algo") != algo:
+            return None
+        return {k: rec[k] for k in ("num_envs", "num_steps", "port_env_steps_per_s", "time_rollout_s", "time_update_s", "threads", "box", "date")}
+    except Exception:
+        return None
+
+
 def recorded_reference(algo: str):
     """Figures of the UNMODIFIED reference main() recorded in the build container by oracle/time_reference.py (the
     reference tree cannot travel to the GPU box).  Provenance (box, torch, command) is carried along."""
@@ -114,7 +126,8 @@ def cpu_baseline(sample_envs: int, T: int, threads: int = 4, algo: str = "ppo_la
             "sample": f"1 epoch of {sample_envs} envs x {T} steps (={steps} env-steps), {what}, "
                       f"torch CPU {threads} threads on {host} ({os.cpu_count()} logical cores); "
                       f"rollout {timers['rollout']:.2f}s update {timers['update']:.2f}s wall {wall:.2f}s",
-            "reference_recorded": recorded_reference(algo)}
+            "reference_recorded": recorded_reference(algo),
+            "port_full_size_recorded": recorded_port_full_size(algo)}
 
 
 def cpu_baseline_mappolag(sample_threads: int, T: int = 64, agents: int = 4, hidden: int = 128, threads: int = 4):

@@ -2073,7 +2073,7 @@ def test_multi_agent_masked_gae_popart_bit_exact(dev, golden_dir, tag):
     assert np.array_equal(buf.cost_returns.cpu().numpy().view(np.uint32), z[f"{tag}_cost_returns"].view(np.uint32))
 
 
-@pytest.mark.parametrize("algo", ["pair", "twophase", "a2a", "helper16", "rowsplit"])
+@pytest.mark.parametrize("algo", ["pair", "twophase", "a2a", "helper16", "rowsplit", "rowsplit_4_ranks"])
 def test_in_kernel_gradient_exchange_two_ranks_one_gpu(dev, tmp_path, algo):
     """SURVEY.md 8(e) in-kernel form: two ranks (two processes, this one GPU, regions mapped through IPC handles) run
     the data-parallel persistent kernel.  Replicas must stay bit-identical and match the kernel / all-reduce / kernel
@@ -2086,12 +2086,14 @@ def test_in_kernel_gradient_exchange_two_ranks_one_gpu(dev, tmp_path, algo):
     s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
     out = tmp_path / "p2p.json"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    nproc = 4 if algo.endswith("_4_ranks") else 2           # (four ranks: the rank-order sum over more than one peer; 24 workgroups)
+    algo = algo.replace("_4_ranks", "")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SPO_P2P_ALGO="pair" if algo in ("a2a", "helper16") else algo)
     if algo == "a2a":
         env["SPO_P2P_A2A"] = "1"        # main + helper kernel with the flag-based all-to-all exchange on the helper waves
     if algo == "helper16":
         env["SPO_P2P_HELPER"] = "2"     # main + helper kernel, packed-word recursive doubling on the helper waves (round 5)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "p2p_worker.py"), str(out), "1000", "2"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
