@@ -1,6 +1,7 @@
 """Debug tool: interval breakdown of the main + helper form of the persistent update kernel (actor workgroup, wave 0 of each
 role).  Usage (GPU box): python tools/phase_profile_h.py"""
 import os, sys, time, torch
+os.environ["SPO_UPDATE_FORM"] = "2"       # this tool reads the MAIN + HELPER kernel's counters (the row-split kernel: tools/phase_profile_rs.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "safe-policy-optimization_amd"))
 from safepo import _abi
