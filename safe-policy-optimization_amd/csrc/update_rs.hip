@@ -51,8 +51,8 @@ template <int KIN, int NCT>
 struct RsLds {                                   // floats; NCT = 16-column tiles per workgroup (2: 32 rows of a minibatch, 1: 16)
   using L = NetLds<KIN>;
   static constexpr int LDC = 16 * NCT + 4;       // [feature][batch] LDS row stride
-  static constexpr int LS = L::SIZE;             // log_std mirror (16)
-  static constexpr int XT = LS + 16;             // two x^T images (double-buffered across steps)
+  static constexpr int LS = L::SIZE;             // log_std mirror (16), then 1 / sigma^2 (16) and log_std + log sqrt(2 pi) (16) per action
+  static constexpr int XT = LS + 48;             // two x^T images (double-buffered across steps)
   static constexpr int H1T = XT + 2 * KIN * LDC;
   static constexpr int H2T = H1T + HID * LDC;
   static constexpr int DZ2T = H2T + HID * LDC;
@@ -208,7 +208,16 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
   const int64_t nsteps = (a.M + B - 1) / B;
 
   stage_net<KIN>(a.theta, g, lds, tid, 512);
-  if (tid < 16) lds[S::LS + tid] = (is_actor && tid < A) ? a.theta[ls_off + tid] : 0.f;
+  if (tid < 16) {
+    // the Gaussian's per-action constants of the actor's loss, kept beside log_std by its owner (the optimiser lanes that run its
+    // Adam): the four column waves no longer recompute exp / rcp per lane and step
+    const bool on = is_actor && tid < A;
+    const float lsv = on ? a.theta[ls_off + tid] : 0.f;
+    const float sdv = __expf(lsv);
+    lds[S::LS + tid] = lsv;
+    lds[S::LS + 16 + tid] = __builtin_amdgcn_rcpf(sdv * sdv);
+    lds[S::LS + 32 + tid] = on ? lsv + LOG_SQRT_2PI : 0.f;
+  }
   if (tid < 128) red[tid] = 0.f;
   __syncthreads();
   if (XW > 0 && tid < 8) reinterpret_cast<unsigned long long*>(red + 100)[tid] = reinterpret_cast<unsigned long long>(a.xr_region[tid]);
@@ -369,12 +378,9 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int ai = 4 * q + r;
-          const bool on = is_actor && ai < A;
-          const float lsv = on ? lds[S::LS + ai] : 0.f;
-          const float sdv = __expf(lsv);
-          amask[r] = on ? 1.f : 0.f;
-          ivar[r] = __builtin_amdgcn_rcpf(sdv * sdv);
-          lsd[r] = on ? lsv + LOG_SQRT_2PI : 0.f;
+          amask[r] = (is_actor && ai < A) ? 1.f : 0.f;
+          ivar[r] = lds[S::LS + 16 + ai];                                 // 1 / exp(log_std)^2 (1 on pad rows and for the critics)
+          lsd[r] = lds[S::LS + 32 + ai];                                  // log_std + log sqrt(2 pi) (0 on pad rows)
         }
         f4 dO = {0.f, 0.f, 0.f, 0.f}, dls = {0.f, 0.f, 0.f, 0.f};
         float lsum = 0.f;
@@ -1037,6 +1043,12 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
           for (int r = 0; r < 4; ++r) {
             const int ai = 4 * q + r;
             RS_ADAM(S::LS + ai, gA[6][r] * coef, mls[r], vls[r])             // (replicated over j: identical values)
+            if (ai < A) {                                                    // ... and the loss constants that follow from it
+              const float lsv = lds[S::LS + ai];
+              const float sdv = __expf(lsv);
+              lds[S::LS + 16 + ai] = __builtin_amdgcn_rcpf(sdv * sdv);
+              lds[S::LS + 32 + ai] = lsv + LOG_SQRT_2PI;
+            }
           }
         }
       }
