@@ -333,6 +333,15 @@ int spo_update_iter_ex_ks(float* theta, float* adam_m, float* adam_v, int64_t ad
                           const float* target_r, const float* target_c, const float* adv, const int32_t* perm, int64_t M,
                           const spo_ppo_cfg* cfg_host, int actor_loss, const float* old_mean, const float* old_std,
                           float kl_bound, float pg_coef, int actor_only, float* losses_out, void* sync_ws, void* stream);
+/* One minibatch's gradient on the feature-split kernel (round 6: the data-parallel step at these dims): the RAW
+ * data gradient (no L2 term, no value coefficient) of the three networks on rows idx[0 .. n), n <= 64, into flat_grad (theta's
+ * layout, log_std included) and the three data losses into losses3 -- ppo_lag.py:306-324 up to loss.backward(), the part
+ * spo_mlp_forward / spo_wide_ppo_loss / spo_mlp_backward take 20 launches for.  theta is not written.  The caller averages
+ * flat_grad over the ranks (the global minibatch is the concatenation of the ranks' rows; the reference itself is one process) and
+ * applies spo_wide_clip_adam. */
+int spo_ppo_lag_grad_ks(const float* theta, const float* obs, const float* act, const float* logp_old, const float* target_r,
+                        const float* target_c, const float* adv, const int32_t* idx, int n, const spo_ppo_cfg* cfg_host,
+                        float* flat_grad, float* losses3, void* sync_ws, void* stream);
 /* spo_critic_fit_iter on the same feature-split kernel (two networks): the critic fit of the second-order scripts
  * (safepo/single_agent/cpo.py:541-571) for obs_dim <= 512, hidden [64, 64], batch <= 128 (a minibatch is taken as two 64-column
  * chunks whose gradients accumulate before the optimiser step), one GPU.  Same arguments and results as spo_critic_fit_iter;

@@ -87,6 +87,7 @@ struct KsArgs {
   double pow_b1_actor, pow_b2_actor;   // the actor's own optimiser clock (spo_update_iter_ex)
   float* stale_io;                     // critic fit: ||actor.grad||^2 that the joint clip still sees and rescales (cpo.py:557), in / out
   int force_safe;                      // SPO_KS_SAFE=1: write-through exchange stores whatever the placement (tests)
+  float* flat_grad;                    // GRAD instantiation (data-parallel step): the minibatch's raw gradient, theta's layout
 };
 
 __device__ __forceinline__ float pin(float v) { asm volatile("" : "+v"(v)); return v; }
@@ -112,7 +113,11 @@ __device__ unsigned long long g_ks_prof[16];      // development builds: cycles 
 // CFIT: the critic fit of the second-order scripts (cpo.py:541-571): two networks, minibatches of up to 128 rows taken as two
 // 64-column chunks whose weight gradients accumulate before the one optimiser step, the actor's stale gradient in the joint norm.
 // AMODE 1: the KL-penalty actor loss of FOCOPS (focops.py:326-337) and CUP's second stage (cup.py:372-383), as update.hip's AMODE.
-template <bool FAST, bool CFIT, int AMODE>
+// GRAD (round 6): ONE minibatch, forward / loss / backward / weight gradients only -- the raw gradient of the
+// three networks (no L2 term, no value coefficient: spo_wide_clip_adam adds them) goes to a.flat_grad in theta's layout and the
+// three data losses to a.losses; no norm exchange, no Adam, theta untouched.  The per-minibatch kernel of the data-parallel step at
+// these dims: kernel -> all-reduce of the flat gradient -> spo_wide_clip_adam on every rank.
+template <bool FAST, bool CFIT, int AMODE, bool GRAD = false>
 __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
   using Col = KsCol<AMODE>;
 #ifdef SPO_KS_PROF
@@ -772,6 +777,33 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
     if (CFIT && h + 1 < H) { __syncthreads(); continue; }             // (the images are free for the minibatch's second chunk)
     const float loss_data = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;
     const float dl = own_ls ? (red[32 + tid] + red[64 + tid]) + (red[96 + tid] + red[128 + tid]) : 0.f;   // d(loss)/d(log_std[tid])
+    if constexpr (GRAD) {
+      float* const fg = a.flat_grad;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * nt + j;
+          if (i < DS) fg[g.w1() + (orow + r) * D + c_lo + i] = aW1[nt][r];           // every slice its own columns of W1
+          if (first) fg[g.w2() + (orow + r) * HID + i] = aW2[nt][r];                  // the rest: slice 0 (the slices hold the same bits)
+        }
+      if (first) {
+#pragma unroll
+        for (int t = 0; t < KS_NO; ++t) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int o = 16 * t + 4 * q + r;
+            if (o < OUT) fg[g.w3() + o * HID + 16 * wave + j] = aW3[t][r];
+          }
+          const int ob = 16 * t + j;
+          if (own_w0 && ob < OUT) fg[g.b3() + ob] = db3[t];
+        }
+        if (own_b) { fg[g.b1() + 16 * wave + j] = db1; fg[g.b2() + 16 * wave + j] = db2; }
+        if (own_ls) fg[ls_off + tid] = dl;
+        if (tid == 0) a.losses[net] = is_actor ? -loss_data : loss_data;
+      }
+      return;
+    }
 
     // ---- L2 regulariser of the critics (weights AND biases, ppo_lag.py:310-314), norm shares: the W1 slice / everything else
     float gsq1 = 0.f, psq1 = 0.f, gsqr = 0.f, psqr = 0.f;
@@ -948,7 +980,7 @@ __device__ __forceinline__ void ks_body(const KsArgs& a, float* const lds) {
   }
 }
 
-template <bool CFIT, int AMODE>
+template <bool CFIT, int AMODE, bool GRAD = false>
 __device__ __forceinline__ void ks_entry(const KsArgs& a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const red = lds + KsLds::RED;
@@ -980,8 +1012,8 @@ __device__ __forceinline__ void ks_entry(const KsArgs& a) {
     fast = (red[250] == 0.f) && !a.force_safe;
     __syncthreads();
   }
-  if (fast) ks_body<true, CFIT, AMODE>(a, lds);
-  else ks_body<false, CFIT, AMODE>(a, lds);
+  if (fast) ks_body<true, CFIT, AMODE, GRAD>(a, lds);
+  else ks_body<false, CFIT, AMODE, GRAD>(a, lds);
 }
 
 __global__ __launch_bounds__(256, 1) void ppo_update_ks_kernel(KsArgs a) {
@@ -996,6 +1028,10 @@ __global__ __launch_bounds__(256, 1) void critic_fit_ks_kernel(KsArgs a) {
   if (blockIdx.x & 7) return;
   ks_entry<true, 0>(a);
 }
+__global__ __launch_bounds__(256, 1) void ppo_grad_ks_kernel(KsArgs a) {
+  if (blockIdx.x & 7) return;
+  ks_entry<false, 0, true>(a);
+}
 
 // Exchange scratch of the kernel: the partial pre-activation words and the norm granules, ordinary device memory (agent-scope
 // atomics).  One block per device, allocated on first use, zeroed once (tags never repeat).
@@ -1003,13 +1039,13 @@ struct KsScratch { float* z; unsigned long long* gran; };
 constexpr size_t KS_G_BYTES = (size_t)(2 * 2 * 3 * KS_MAX_SLICES + 3 * KS_MAX_SLICES) * 8;   // granules + the placement census
 // One block per (device, stream), like the update kernels' scratch in update.hip: launches on one stream are ordered and share
 // it, two engines on two streams get two blocks and may run concurrently.  Released by spo_update_scratch_release.
-struct KsEntry { int dev; void* stream; char* base; unsigned tag; };
+struct KsEntry { int dev; void* stream; char* base; unsigned tag; bool primed; };   // primed: the slots have been set to the sentinel once
 constexpr int KS_SCRATCH_MAX = 16;
 KsEntry g_ks[KS_SCRATCH_MAX] = {};
 int g_ks_n = 0;
 std::mutex g_ks_mu;
 
-int ks_scratch(hipStream_t st, KsScratch* out, unsigned* tag_base, unsigned nsteps) {
+int ks_scratch(hipStream_t st, KsScratch* out, unsigned* tag_base, unsigned nsteps, bool** primed = nullptr) {
   const int dev = current_device_slot();
   std::lock_guard<std::mutex> lk(g_ks_mu);
   KsEntry* e = nullptr;
@@ -1027,12 +1063,13 @@ int ks_scratch(hipStream_t st, KsScratch* out, unsigned* tag_base, unsigned nste
     if (int rc = spo::hip_check(hipMalloc(&p, KS_Z_BYTES + KS_G_BYTES), "hipMalloc(ks scratch)")) return rc;
     if (int rc = spo::hip_check(hipMemset(p, 0, KS_Z_BYTES + KS_G_BYTES), "hipMemset(ks scratch)")) { (void)hipFree(p); return rc; }
     if (int rc = spo::hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize(ks scratch)")) { (void)hipFree(p); return rc; }
-    g_ks[g_ks_n] = KsEntry{dev, (void*)st, static_cast<char*>(p), 16u};
+    g_ks[g_ks_n] = KsEntry{dev, (void*)st, static_cast<char*>(p), 16u, false};
     e = &g_ks[g_ks_n++];
   }
   out->z = reinterpret_cast<float*>(e->base);
   out->gran = reinterpret_cast<unsigned long long*>(e->base + KS_Z_BYTES);
   *tag_base = e->tag;
+  if (primed) *primed = &e->primed;
   e->tag += nsteps + 2u;                           // (wraps after 4e9 steps: a tag then meets words 2^32 steps old)
   return 0;
 }
@@ -1063,7 +1100,7 @@ extern "C" int spo_ks_supported(int obs_dim, int act_dim, int batch) {
   return (obs_dim >= 1 && obs_dim <= 64 * KS_MAX_SLICES && act_dim >= 1 && act_dim <= KS_OUT && batch >= 1 && batch <= 64) ? 1 : 0;
 }
 
-// kind: 0 = clipped-surrogate step, 1 = critic fit, 2 = KL-penalty actor loss; the caller sets n_nets / first_net
+// kind: 0 = clipped-surrogate step, 1 = critic fit, 2 = KL-penalty actor loss, 3 = one minibatch's gradient only; the caller sets n_nets / first_net
 static int ks_launch(KsArgs& a, const spo_ppo_cfg* cfg_host, int64_t adam_step_host, int64_t adam_step_actor_host, int64_t M,
                      void* sync_ws, hipStream_t st, int kind) {
   if (int rc = spo::hip_check(hipMemsetAsync(sync_ws, 0, 64, st), "hipMemsetAsync(sync_ws)")) return rc;
@@ -1078,15 +1115,22 @@ static int ks_launch(KsArgs& a, const spo_ppo_cfg* cfg_host, int64_t adam_step_h
   const int64_t nsteps = (M + cfg_host->batch - 1) / cfg_host->batch;
   SPO_REQUIRE(nsteps < (1ll << 30), "update_iter_ks: too many minibatch steps in one launch");
   KsScratch sc;
-  if (int rc = ks_scratch(st, &sc, &a.tag_base, (unsigned)nsteps)) return rc;
+  bool* primed = nullptr;
+  if (int rc = ks_scratch(st, &sc, &a.tag_base, (unsigned)nsteps, &primed)) return rc;
   a.zbuf = sc.z; a.gran = sc.gran;
-  // every slot starts as the sentinel (a launch leaves them that way unless it stopped on an error: cheap enough to not care)
-  if (int rc = spo::hip_check(hipMemsetAsync(sc.z, 0xFF, KS_ZZERO_OFF, st), "hipMemsetAsync(ks partials)")) return rc;
+  // every slot starts as the sentinel (a launch leaves them that way unless it stopped on an error: cheap enough to not care for the
+  // one launch per learning iteration of the persistent forms; the per-minibatch gradient launch -- kind 3 -- relies on the consumers'
+  // resets after the block's first launch: 25 MB of memset per minibatch step would cost more than the kernel)
+  if (kind != 3 || !*primed) {
+    if (int rc = spo::hip_check(hipMemsetAsync(sc.z, 0xFF, KS_ZZERO_OFF, st), "hipMemsetAsync(ks partials)")) return rc;
+    *primed = true;
+  }
   const size_t sh = KsLds::SIZE * sizeof(float);
-  static bool attr_done[SPO_MAX_DEVICES][3] = {};
+  static bool attr_done[SPO_MAX_DEVICES][4] = {};
   const int dslot = current_device_slot();
   if (!attr_done[dslot][kind]) {
     const void* fn = kind == 1 ? reinterpret_cast<const void*>(&critic_fit_ks_kernel)
+                   : kind == 3 ? reinterpret_cast<const void*>(&ppo_grad_ks_kernel)
                    : kind == 2 ? reinterpret_cast<const void*>(&klpen_update_ks_kernel)
                                : reinterpret_cast<const void*>(&ppo_update_ks_kernel);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
@@ -1094,7 +1138,8 @@ static int ks_launch(KsArgs& a, const spo_ppo_cfg* cfg_host, int64_t adam_step_h
     attr_done[dslot][kind] = true;
   }
   const dim3 grid(8 * (a.n_nets * a.S - 1) + 1);
-  if (kind == 1) hipLaunchKernelGGL(critic_fit_ks_kernel, grid, dim3(256), sh, st, a);
+  if (kind == 3) hipLaunchKernelGGL(ppo_grad_ks_kernel, grid, dim3(256), sh, st, a);
+  else if (kind == 1) hipLaunchKernelGGL(critic_fit_ks_kernel, grid, dim3(256), sh, st, a);
   else if (kind == 2) hipLaunchKernelGGL(klpen_update_ks_kernel, grid, dim3(256), sh, st, a);
   else hipLaunchKernelGGL(ppo_update_ks_kernel, grid, dim3(256), sh, st, a);
   return 0;
@@ -1117,6 +1162,30 @@ extern "C" int spo_ppo_lag_update_iter_ks(float* theta, float* adam_m, float* ad
   a.perm = perm; a.losses = losses_out; a.n_nets = 3; a.first_net = 0;
   if (int rc = ks_launch(a, cfg_host, adam_step_host, adam_step_host, M, sync_ws, (hipStream_t)stream, 0)) return rc;
   SPO_LAUNCH_CHECK("spo_ppo_lag_update_iter_ks");
+  return 0;
+}
+
+// Data-parallel step at the feature-split kernels' dims (round 6): the RAW gradient of one minibatch (rows
+// idx[0 .. n), n <= 64) of all three networks into flat_grad (theta's layout; log_std included) and the three data losses into
+// losses3 -- what spo_mlp_forward / spo_wide_ppo_loss / spo_mlp_backward produce on the launch-per-layer path, in ONE launch of
+// 3 x ceil(obs_dim / 64) workgroups.  The caller all-reduces flat_grad and applies spo_wide_clip_adam (L2 terms, joint clip, Adam).
+extern "C" int spo_ppo_lag_grad_ks(const float* theta, const float* obs, const float* act, const float* logp_old,
+                                   const float* target_r, const float* target_c, const float* adv, const int32_t* idx, int n,
+                                   const spo_ppo_cfg* cfg_host, float* flat_grad, float* losses3, void* sync_ws, void* stream) {
+  SPO_REQUIRE(cfg_host, "ppo_lag_grad_ks: cfg is NULL");
+  SPO_REQUIRE(spo_ks_supported(cfg_host->obs_dim, cfg_host->act_dim, cfg_host->batch) && n >= 1 && n <= 64,
+              "ppo_lag_grad_ks: obs_dim %d / act_dim %d / rows %d outside [1,%d] / [1,%d] / [1,64]", cfg_host->obs_dim,
+              cfg_host->act_dim, n, 64 * KS_MAX_SLICES, KS_OUT);
+  SPO_REQUIRE(theta && obs && act && logp_old && target_r && target_c && adv && idx && flat_grad && losses3 && sync_ws,
+              "ppo_lag_grad_ks: null pointer");
+  KsArgs a{};
+  a.theta = const_cast<float*>(theta); a.adam_m = const_cast<float*>(theta); a.adam_v = const_cast<float*>(theta);   // (moments: loaded, never used or stored)
+  a.obs = obs; a.act = act; a.logp_old = logp_old; a.tgt_r = target_r; a.tgt_c = target_c; a.adv = adv;
+  a.perm = idx; a.losses = losses3; a.n_nets = 3; a.first_net = 0; a.flat_grad = flat_grad;
+  spo_ppo_cfg c = *cfg_host;
+  c.batch = n;                                        // one minibatch of exactly the rows given
+  if (int rc = ks_launch(a, &c, 0, 0, n, sync_ws, (hipStream_t)stream, 3)) return rc;
+  SPO_LAUNCH_CHECK("spo_ppo_lag_grad_ks");
   return 0;
 }
 

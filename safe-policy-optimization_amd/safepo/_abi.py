@@ -94,6 +94,7 @@ PROTOTYPES = {
     "spo_ks_supported": (c_int, [c_int, c_int, c_int]),
     "spo_update_rs_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "spo_ppo_lag_update_iter_ks": (c_int, [P, P, P, c_int64] + [P] * 7 + [c_int64, POINTER(PpoCfg), P, P, P]),
+    "spo_ppo_lag_grad_ks": (c_int, [P] * 8 + [c_int, POINTER(PpoCfg), P, P, P, P]),
     "spo_update_iter_ex_ks": (c_int, [P, P, P, c_int64, c_int64, P, P, P, P, P, P, P, c_int64, POINTER(PpoCfg), c_int, P, P,
                                    c_float, c_float, c_int, P, P, P]),
     "spo_critic_fit_ks_supported": (c_int, [c_int, c_int]),

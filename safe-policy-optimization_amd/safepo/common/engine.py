@@ -831,6 +831,13 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
         return (list(self.policy.hidden_sizes) == [64, 64] and self.comm.world_size == 1
                 and os.environ.get("SPO_WIDE_KS", "1") != "0" and bool(self.lib.spo_ks_supported(self.D, self.A, int(cfg.batch))))
 
+    def _feature_split_grad_ok(self, cfg) -> bool:
+        """The same dims under data parallelism (world_size > 1): the feature-split kernel computes one minibatch's gradient
+        per launch (spo_ppo_lag_grad_ks) and the optimiser step stays outside, behind the all-reduce.  SPO_WIDE_KS=0: the
+        launch-per-layer step."""
+        return (list(self.policy.hidden_sizes) == [64, 64] and self.comm.world_size > 1
+                and os.environ.get("SPO_WIDE_KS", "1") != "0" and bool(self.lib.spo_ks_supported(self.D, self.A, int(cfg.batch))))
+
     def check_sync_error(self):
         code = int(self.sync_ws[8].item()) & 0xFFFFFFFF
         if code:
@@ -852,6 +859,23 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
                 "spo_ppo_lag_update_iter_ks")
             self.adam_step += n_mb
             return losses
+        if self._feature_split_grad_ok(cfg):
+            # data-parallel at the feature-split kernel's dims (round 6): per minibatch step ONE launch for the forward / loss /
+            # backward of the three networks (spo_ppo_lag_grad_ks), the all-reduce of the flat gradient, the joint clip + Adam
+            d, b, w, g = self.buffer.data, self.buffer, self.wide, self.flat_grad
+            for k in range(n_mb):
+                idx = perm[k * cfg.batch:(k + 1) * cfg.batch]
+                _abi.check(self.lib.spo_ppo_lag_grad_ks(
+                    _abi.ptr(self.policy.theta), _abi.ptr(d["obs"]), _abi.ptr(d["act"]), _abi.ptr(d["log_prob"]),
+                    _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]), _abi.ptr(b.adv_mix), _abi.ptr(idx), idx.numel(),
+                    cfg, _abi.ptr(g), _abi.ptr(losses[k]), _abi.ptr(self.sync_ws), _abi.stream_ptr()), "spo_ppo_lag_grad_ks")
+                self._reduce_flat_grad()
+                _abi.check(self.lib.spo_wide_clip_adam(
+                    _abi.ptr(self.policy.theta), _abi.ptr(g), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v), w.P, w.off_c, w.off_ls,
+                    w.off_ls, cfg, self.adam_step, _abi.ptr(losses[k]), _abi.ptr(self.scal4), _abi.ptr(self.loss_partials),
+                    self.loss_partials.numel(), _abi.stream_ptr()), "spo_wide_clip_adam")
+                self.adam_step += 1
+            return self._mean_over_ranks_(losses)
         perm = perm.long()
         graphed = 0 < cfg.batch <= self.graph_max_batch and n_mb > 2
         n_full = M // cfg.batch if graphed else 0

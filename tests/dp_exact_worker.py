@@ -58,7 +58,8 @@ def main(out_path: str, use_p2p: str, shape: str = "60,8,64,64"):
     gathered = [torch.empty_like(theta) for _ in range(world)]
     dist.all_gather(gathered, theta)
     res = {"world": world, "in_kernel_exchange": eng.p2p is not None, "local_batch": GB // world, "engine": type(eng).__name__,
-           "replicas_identical": all(torch.equal(gathered[0], x) for x in gathered[1:])}
+           "replicas_identical": all(torch.equal(gathered[0], x) for x in gathered[1:]),
+           "grad_kernel": bool(getattr(eng, "_feature_split_grad_ok", lambda c: False)(eng._cfg_struct()))}
     if rank == 0:
         from oracle import restatement as R          # checker only
         ref = R.OraclePolicy(D, A, hidden_sizes=tuple(hidden))

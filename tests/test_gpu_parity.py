@@ -2134,11 +2134,13 @@ def test_data_parallel_global_batch_equals_reference_minibatches(dev, tmp_path, 
     print("dp_exact", res)
 
 
-@pytest.mark.parametrize("shape", ["100,20,64,64", "60,8,128,128"])
+@pytest.mark.parametrize("shape", ["100,20,64,64", "60,8,128,128", "376,17,64,64", "130,8,64,64", "100,20,64,64,launch_per_layer"])
 def test_data_parallel_wide_engine_global_batch_equals_reference_minibatches(dev, tmp_path, shape):
     """The same exact-semantics check for a policy OUTSIDE the persistent kernels' envelope (act_dim 20; hidden [128, 128]): the
     wide-network engine all-reduces the flat gradient of the three networks per minibatch step before the joint clip
-    (ppo_lag.py:325), so two ranks x 32 rows reproduce the oracle's 64-row steps on the union of the rows."""
+    (ppo_lag.py:325), so two ranks x 32 rows reproduce the oracle's 64-row steps on the union of the rows.  Hidden [64, 64] with
+    obs_dim <= 512 / act_dim <= 32 (HumanoidVelocity's 376 / 17): the gradient of a step comes from ONE launch of the
+    feature-split kernel (spo_ppo_lag_grad_ks, round 6); `launch_per_layer` (SPO_WIDE_KS=0) keeps the 20-launch form covered."""
     import json
     import socket
     import subprocess
@@ -2147,12 +2149,16 @@ def test_data_parallel_wide_engine_global_batch_equals_reference_minibatches(dev
     out = tmp_path / "dp_exact_wide.json"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    per_layer = shape.endswith(",launch_per_layer")
+    if per_layer:
+        shape, env["SPO_WIDE_KS"] = shape[:-len(",launch_per_layer")], "0"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "dp_exact_worker.py"), str(out), "0", shape]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     res = json.load(open(out))
     assert res["engine"] == "WidePPOLagEngine" and not res["in_kernel_exchange"] and res["local_batch"] == 32 and res["steps"] == 16, res
+    assert res["grad_kernel"] == (shape.endswith(",64,64") and not per_layer), res
     assert res["replicas_identical"], res
     assert res["loss_max_rel_diff"] < 1e-4, res
     assert res["theta_frac_outside"] <= 1e-3 and res["theta_max_abs_diff"] < 1e-5 and res["theta_moved"] > 1e-3, res

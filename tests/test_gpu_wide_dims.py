@@ -380,6 +380,76 @@ def test_wide_dims_ppo_minibatch_steps_vs_oracle(dev, D, A, batch, steps):
                             floor_abs_max=_theta_floor(3e-4, steps))
 
 
+@pytest.mark.parametrize("D,A", [(376, 17), (130, 8), (512, 32), (129, 1), (200, 20)])
+def test_feature_split_gradient_launch_vs_fp64_autograd(dev, D, A):
+    """spo_ppo_lag_grad_ks (round 6: the data-parallel step at the feature-split kernel's dims): the raw gradient and the data losses
+    of ONE minibatch (ppo_lag.py:306-324 without the L2 terms, which spo_wide_clip_adam adds) against float64 autograd on the
+    oracle policy -- full, ragged and one-row minibatches, launched back to back on one stream (only the block's first launch sets
+    the exchange slots to the sentinel; the later ones rely on the consumers' resets), with a persistent launch of the same
+    kernel family in between; theta is not written.  Then the launch-per-layer gradient of the same rows for scale."""
+    from safepo import _abi
+    from safepo.common.engine import WidePPOLagEngine
+    from test_gpu_parity import _fill_update_problem
+    hidden, M = [64, 64], 64 * 5 + 1
+    pol, ref = _wide_pair(D, A, hidden, dev, seed=11)
+    cfg_d = {"hidden_sizes": hidden, "gamma": 0.99, "target_kl": 0.02, "batch_size": 64, "learning_iters": 1, "max_grad_norm": 40.0}
+    eng = WidePPOLagEngine(pol, 1, M, cfg_d, dev)
+    problem = _synthetic_update_problem(M, D, A, seed=23)
+    _fill_update_problem(eng, problem)
+    lib, d, b = eng.lib, eng.buffer.data, eng.buffer
+    cfg = eng._cfg_struct()
+    ref64 = copy.deepcopy(ref).double()
+    theta0 = pol.theta.clone()
+    perm = torch.randperm(M, generator=torch.Generator().manual_seed(5))
+    cases = [perm[:64], perm[64:64 + 37], perm[128:129], perm[129:129 + 64], perm[200:232]]
+    outs = []
+    for k, idx in enumerate(cases):
+        idx_dev = idx.to(torch.int32).to(dev)
+        g = torch.full_like(eng.flat_grad, float("nan"))
+        l3 = torch.full((3,), float("nan"), device=dev)
+        _abi.check(lib.spo_ppo_lag_grad_ks(_abi.ptr(pol.theta), _abi.ptr(d["obs"]), _abi.ptr(d["act"]), _abi.ptr(d["log_prob"]),
+                                           _abi.ptr(d["target_value_r"]), _abi.ptr(d["target_value_c"]), _abi.ptr(b.adv_mix),
+                                           _abi.ptr(idx_dev), idx_dev.numel(), cfg, _abi.ptr(g), _abi.ptr(l3), _abi.ptr(eng.sync_ws),
+                                           _abi.stream_ptr()), "spo_ppo_lag_grad_ks")
+        outs.append((g, l3))
+        if k == 2:      # a persistent launch of the update kernel on the same scratch block between two gradient launches
+            snap = [t.clone() for t in (pol.theta, eng.adam_m, eng.adam_v)]
+            eng.learning_iter(perm.to(torch.int32).to(dev))
+            for t, s_ in zip((pol.theta, eng.adam_m, eng.adam_v), snap):
+                t.copy_(s_)
+            eng.adam_step = 0
+    eng.check_sync_error()
+    assert torch.equal(pol.theta, theta0)
+    worst = 0.0
+    for idx, (g, l3) in zip(cases, outs):
+        rows = [t[idx].double() for t in problem]
+        ref64.zero_grad()
+        total, loss_pi, loss_r, loss_c = R.ppo_lag_losses(ref64, *rows, use_critic_norm=False)
+        total.backward()
+        want = R.flat_grads(ref64).numpy()
+        got = g.cpu().numpy().astype(np.float64)
+        assert np.isfinite(got).all(), f"{int(np.isnan(got).sum())} gradient elements never written (rows {idx.numel()})"
+        np.testing.assert_allclose(l3.cpu().numpy(), [loss_r.item(), loss_c.item(), loss_pi.item()], rtol=1e-5, atol=2e-6)
+        err = np.abs(got - want).max() / np.abs(want).max()
+        worst = max(worst, err)
+        assert err < 2e-6, (idx.numel(), err)
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=3e-6 * np.abs(want).max())
+    # the launch-per-layer gradient of the first minibatch (the path this launch replaces under data parallelism)
+    obs, act, logp_old, tgt_r, tgt_c, adv = eng._gather(cases[0].to(dev))
+    w, n = eng.wide, 64
+    (v_r, ws_r), (v_c, ws_c), (mu, ws_a) = w.forward_multi("rca", obs, slot=1)
+    d_vr = torch.empty(n, device=dev); d_vc = torch.empty(n, device=dev); d_mu = torch.empty((n, A), device=dev)
+    g2, l3b = torch.zeros_like(eng.flat_grad), torch.zeros(3, device=dev)
+    _abi.check(lib.spo_wide_ppo_loss(_abi.ptr(v_r), _abi.ptr(v_c), _abi.ptr(mu), _abi.ptr(pol.theta[w.off_ls:]), _abi.ptr(act),
+                                     _abi.ptr(logp_old), _abi.ptr(adv), _abi.ptr(tgt_r), _abi.ptr(tgt_c), n, A, float(cfg.clip),
+                                     _abi.ptr(d_vr), _abi.ptr(d_vc), _abi.ptr(d_mu), _abi.ptr(g2[w.off_ls:]), _abi.ptr(l3b),
+                                     _abi.ptr(eng.loss_partials), eng.loss_partials.numel(), _abi.stream_ptr()), "spo_wide_ppo_loss")
+    w.backward_multi("rca", obs, [ws_r, ws_c, ws_a], [d_vr, d_vc, d_mu], g2)
+    rel = float((outs[0][0] - g2).abs().max() / g2.abs().max())
+    print(f"grad_ks {D}x{A}: worst max-norm error vs fp64 autograd {worst:.2e}; vs the launch-per-layer gradient {rel:.2e}")
+    assert rel < 4e-6
+
+
 def test_feature_split_kernel_full_size_drift_envelope_at_humanoid_dims(dev):
     """The persistent feature-split kernel (csrc/update_ks.hip) at BASELINE config 2's size with HumanoidVelocity's dims:
     4096 envs x 128 steps = 524 288 rows of 376 observations / 17 actions, one learning iteration = 8 192 minibatch steps of 64
