@@ -709,7 +709,8 @@ def main():
             wide_entry = {"what": "one 64-row minibatch step of WidePPOLagEngine.learning_iter (gather, 3 forwards, loss, 3 backwards, joint "
                                   "clip + Adam) outside the 3-workgroup persistent kernel's dims (its step is update_kernel above): hidden "
                                   "[64, 64] with obs_dim <= 512 / act_dim <= 32 takes the persistent feature-split kernel, anything else "
-                                  "the launch-per-layer step",
+                                  "the row-group gradient kernel (csrc/mlp_rows.hip, round 6: one launch for gather + forwards + "
+                                  "loss + backwards, two for clip + Adam; rounds 4-5: launch-per-network, 89 us at [128, 128])",
                           "cases": [dict(wide_bench.one([128, 128], 64, 256), obs_dim=60, act_dim=8),
                                     dict(wide_bench.one([64, 64], 64, 4096, D=376, A=17), obs_dim=376, act_dim=17),
                                     dict(wide_bench.one([64, 64], 64, 256, D=376, A=17, force_wide=True), obs_dim=376, act_dim=17,

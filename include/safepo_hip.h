@@ -568,6 +568,36 @@ int spo_mlp_forward_multi(int count, const float* const* thetas, const spo_mlp_n
 int spo_mlp_backward_multi(int count, const float* const* thetas, const spo_mlp_net* const* nets, const float* const* xs,
                            int64_t rows, const float* const* wss, const float* const* d_outs, float* const* grads,
                            float* const* scratches, void* stream);
+/* Round 6: the forward / loss / backward of a whole PPO-Lagrangian minibatch (ppo_lag.py:298-324: DataLoader batch, both critics'
+ * MSE, the clipped surrogate, loss.backward()) for ANY hidden_sizes at up to 256 rows in ONE launch, split over the rows
+ * (csrc/mlp_rows.hip): networks x ceil(rows / 16) workgroups, each carrying 16 rows of one network through every layer both ways
+ * with the activations in LDS and the weights read as MFMA operands straight from global memory; the rows are
+ * idx[*cursor_dev + i] (cursor_dev NULL: idx[i]; idx NULL: the rows themselves) of the FULL arrays obs [M, obs_dim], act, logp_old,
+ * targets, adv -- no gather launch.  theta = [reward critic | cost critic | log_std | actor] (the ActorVCritic layout), `critic` /
+ * `actor` describe the networks; actor NULL: the two critics only (the critic fit of cpo.py:541-556).  Every workgroup writes its
+ * row group's partial gradient (theta's layout, WITHOUT the L2 terms) and loss sums into parts (float[spo_wide_grad_rows_part_floats]);
+ * spo_wide_reduce_parts adds the groups in fixed order into grad[n_params] and forms losses_out[0 .. n_losses) = {MSE reward critic,
+ * MSE cost critic, clipped surrogate}: what spo_gather_rows + spo_mlp_forward_multi + spo_wide_ppo_loss + spo_mlp_backward_multi
+ * leave in `grad` / losses3, and where the data-parallel all-reduce and spo_wide_clip_adam take over.  SPO_WIDE_ROWS=0 makes
+ * spo_wide_grad_rows_supported return 0 (callers then keep the launch-per-network path). */
+int spo_wide_grad_rows_supported(const spo_mlp_net* critic, const spo_mlp_net* actor, int64_t rows);
+int64_t spo_wide_grad_rows_part_floats(int64_t n_params, int64_t rows);
+int spo_wide_ppo_grad_rows(const float* theta, const spo_mlp_net* critic, const spo_mlp_net* actor, const float* obs,
+                           const float* act, const float* logp_old, const float* target_r, const float* target_c, const float* adv,
+                           const int64_t* idx, const int64_t* cursor_dev, int64_t rows, float clip, float* parts, void* stream);
+int spo_wide_reduce_parts(const float* parts, int64_t rows, int64_t n_params, int n_losses, float* grad, float* losses_out,
+                          void* stream);
+/* spo_wide_reduce_parts + spo_wide_clip_adam_dev_log (all parameters in the norm and in the Adam range: ppo_lag.py:310-329) in TWO
+ * launches instead of four: the group sum rides in the pass that adds the L2 gradient and forms the norm partials; every workgroup
+ * of the Adam pass forms the clip coefficient from the partials itself and reads the optimiser clocks before the last workgroup to
+ * finish (a device counter in the last 4 floats of `parts`, which must be ZERO when the buffer is first used) advances them, logs
+ * the losses and moves the cursor.  Element for element the arithmetic of the four launches.  One GPU (a data-parallel step
+ * all-reduces between the sum and the clip). */
+int spo_wide_rows_clip_adam_dev_log(float* parts, int64_t rows, float* theta, float* grad, float* adam_m, float* adam_v,
+                                    int64_t n_params, int64_t reward_critic_end, int64_t cost_critic_end, int64_t actor_begin,
+                                    const spo_ppo_cfg* cfg, double* pow4_dev, float* losses3_out, float* scalars4_out,
+                                    double* partial_ws, int partial_capacity, float* loss_log_dev, int64_t* cursor_dev,
+                                    int64_t cursor_step, void* stream);
 /* dsts[k][i, :] = srcs[k][idx[i], :] for k < count (<= SPO_GATHER_MAX) row-major arrays of widths[k] floats per row: the
  * minibatch gather of a step (the reference's DataLoader, ppo_lag.py:298-305) in one launch. */
 #define SPO_GATHER_MAX 8

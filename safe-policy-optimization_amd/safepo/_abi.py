@@ -86,6 +86,12 @@ PROTOTYPES = {
     "spo_boundary_step_fold_mb": (c_int, [P] * 18 + [c_int, c_int64, c_int64, c_int64, c_int, P, P, c_double, P]),
     "spo_mlp_forward_multi": (c_int, [c_int, P, P, P, c_int64, P, P]),
     "spo_mlp_backward_multi": (c_int, [c_int, P, P, P, c_int64, P, P, P, P, P]),
+    "spo_wide_grad_rows_supported": (c_int, [POINTER(MlpNet), POINTER(MlpNet), c_int64]),
+    "spo_wide_grad_rows_part_floats": (c_int64, [c_int64, c_int64]),
+    "spo_wide_ppo_grad_rows": (c_int, [P, POINTER(MlpNet), POINTER(MlpNet)] + [P] * 8 + [c_int64, c_float, P, P]),
+    "spo_wide_reduce_parts": (c_int, [P, c_int64, c_int64, c_int, P, P, P]),
+    "spo_wide_rows_clip_adam_dev_log": (c_int, [P, c_int64, P, P, P, P, c_int64, c_int64, c_int64, c_int64, POINTER(PpoCfg), P, P, P, P,
+                                                c_int, P, P, c_int64, P]),
     "spo_gather_rows": (c_int, [c_int, P, P, P, P, c_int64, P]),
     "spo_gather_rows_at": (c_int, [c_int, P, P, P, P, P, c_int64, P]),
     "spo_values_boundary_step_fold": (c_int, [P] * 4 + [c_int, c_int] + [P] * 16 + [c_int, c_int64, c_int64, c_int64, c_int, P, P,

@@ -702,13 +702,29 @@ class _WideOps:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 body(win, loss_static)
+            # a second capture of `unroll` consecutive steps (round 6): a graph launch costs ~8 us of GPU idle time between the last
+            # kernel of one replay and the first of the next -- a quarter of a 3-kernel step -- and nothing in a step's launches
+            # depends on the host, so eight steps are one launch (SPO_WIDE_GRAPH_UNROLL=1: one step per launch, as rounds 4-5)
+            unroll = max(1, int(os.environ.get("SPO_WIDE_GRAPH_UNROLL", "8")))
+            g_many = None
+            if unroll > 1:
+                g_many = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_many, capture_error_mode="thread_local"):
+                    for _ in range(unroll):
+                        body(win, loss_static)
             # everything the captured kernels address stays alive with the graph: the static loss buffer, and the workspaces the
             # warm-up run created outside the capture (the caches of safepo.common.wide evict when they grow)
-            keep = [loss_static] + list(self.wide._ws.values()) + list(self.wide._scratch.values())
+            keep = [loss_static, g_many, unroll] + list(self.wide._ws.values()) + list(self.wide._scratch.values())
             ent = self._step_graphs[key] = (g, win, keep)
-        g, win, _ = ent
+        g, win, keep = ent
+        g_many, unroll = keep[1], keep[2]
         win.load(perm)
-        for _ in range(n_full):
+        done = 0
+        if g_many is not None:
+            for _ in range(n_full // unroll):
+                g_many.replay()
+            done = (n_full // unroll) * unroll
+        for _ in range(n_full - done):
             g.replay()
         losses[:n_full].copy_(win.loss_log[:n_full])
 
@@ -803,18 +819,38 @@ class WidePPOLagEngine(_WideOps, PPOLagEngine):
         self.pow4 on the device (the graph-replayed form; the caller advances self.adam_step)."""
         w, lib, st = self.wide, self.lib, _abi.stream_ptr
         cfg = self._cfg_struct() if cfg is None else cfg
-        obs, act, logp_old, tgt_r, tgt_c, adv = self._gather(idx)
-        n = obs.shape[0]
-        (v_r, ws_r), (v_c, ws_c), (mu, ws_a) = w.forward_multi("rca", obs, slot=1)
-        d_vr = torch.empty(n, dtype=torch.float32, device=self.dev)
-        d_vc, d_mu = torch.empty_like(d_vr), torch.empty((n, self.A), dtype=torch.float32, device=self.dev)
         g = self.flat_grad
         off_ls = w.off_ls
-        _abi.check(lib.spo_wide_ppo_loss(_abi.ptr(v_r), _abi.ptr(v_c), _abi.ptr(mu), _abi.ptr(self.policy.theta[off_ls:]), _abi.ptr(act),
-                                         _abi.ptr(logp_old), _abi.ptr(adv), _abi.ptr(tgt_r), _abi.ptr(tgt_c), n, self.A, float(cfg.clip),
-                                         _abi.ptr(d_vr), _abi.ptr(d_vc), _abi.ptr(d_mu), _abi.ptr(g[off_ls:]), _abi.ptr(losses_out),
-                                         _abi.ptr(self.loss_partials), self.loss_partials.numel(), st()), "spo_wide_ppo_loss")
-        w.backward_multi("rca", obs, [ws_r, ws_c, ws_a], [d_vr, d_vc, d_mu], g)
+        if w.rows_grad_ok(idx.numel()):
+            # round 6: gather + forward + loss + backward of the three networks in ONE launch split over the rows (csrc/mlp_rows.hip)
+            d, M = self.buffer.data, self.M
+            # one GPU, device-resident clocks (the replayed step): the group sum rides in the optimiser's first pass and the clip
+            # coefficient in its second -- gradient launch + two optimiser launches (SPO_WIDE_ROWS_FUSED=0: sum, norm, coefficient
+            # and Adam as the four launches of the other paths; same numbers)
+            fused = dev_clock and self.comm.world_size == 1 and os.environ.get("SPO_WIDE_ROWS_FUSED", "1") != "0"
+            parts = w.grad_rows(idx, d["obs"].view(M, self.D), d["act"].view(M, self.A), d["log_prob"].view(M),
+                                d["target_value_r"].view(M), d["target_value_c"].view(M), self.buffer.adv_mix.view(M), float(cfg.clip),
+                                g, losses_out, reduce=not fused)
+            if fused:
+                win = idx if isinstance(idx, PermWindow) else None
+                part = self.loss_partials
+                _abi.check(lib.spo_wide_rows_clip_adam_dev_log(
+                    _abi.ptr(parts), idx.numel(), _abi.ptr(self.policy.theta), _abi.ptr(g), _abi.ptr(self.adam_m), _abi.ptr(self.adam_v),
+                    w.P, w.off_c, w.off_ls, w.off_ls, cfg, _abi.ptr(self.pow4), _abi.ptr(losses_out), _abi.ptr(self.scal4), _abi.ptr(part),
+                    part.numel(), None if win is None else _abi.ptr(win.loss_log), None if win is None else _abi.ptr(win.cursor),
+                    0 if win is None else win.n, st()), "spo_wide_rows_clip_adam_dev_log")
+                return
+        else:
+            obs, act, logp_old, tgt_r, tgt_c, adv = self._gather(idx)
+            n = obs.shape[0]
+            (v_r, ws_r), (v_c, ws_c), (mu, ws_a) = w.forward_multi("rca", obs, slot=1)
+            d_vr = torch.empty(n, dtype=torch.float32, device=self.dev)
+            d_vc, d_mu = torch.empty_like(d_vr), torch.empty((n, self.A), dtype=torch.float32, device=self.dev)
+            _abi.check(lib.spo_wide_ppo_loss(_abi.ptr(v_r), _abi.ptr(v_c), _abi.ptr(mu), _abi.ptr(self.policy.theta[off_ls:]), _abi.ptr(act),
+                                             _abi.ptr(logp_old), _abi.ptr(adv), _abi.ptr(tgt_r), _abi.ptr(tgt_c), n, self.A, float(cfg.clip),
+                                             _abi.ptr(d_vr), _abi.ptr(d_vc), _abi.ptr(d_mu), _abi.ptr(g[off_ls:]), _abi.ptr(losses_out),
+                                             _abi.ptr(self.loss_partials), self.loss_partials.numel(), st()), "spo_wide_ppo_loss")
+            w.backward_multi("rca", obs, [ws_r, ws_c, ws_a], [d_vr, d_vc, d_mu], g)
         self._reduce_flat_grad()
         if dev_clock:
             self._clip_adam_dev(cfg, 0, w.P, 0, 0, losses_out, losses_out, idx if isinstance(idx, PermWindow) else None)

@@ -141,6 +141,35 @@ class WideNets:
             vp(*[_abi.ptr(d) for d in d_outs]), vp(*[_abi.ptr(grad_flat[off[w]:]) for w in whichs]),
             vp(*[_abi.ptr(self._bwd_scratch(w, rows)) for w in whichs]), _abi.stream_ptr()), "spo_mlp_backward_multi")
 
+    # ------------------------------------------------------------------ a whole minibatch gradient in one launch (round 6)
+    def rows_grad_ok(self, rows, critics_only=False) -> bool:
+        """csrc/mlp_rows.hip holds this shape: <= 256 rows, every level's images in one CU's LDS (SPO_WIDE_ROWS=0: never)."""
+        return bool(self.lib.spo_wide_grad_rows_supported(self.net_c, None if critics_only else self.net_a, int(rows)))
+
+    def grad_rows(self, idx, obs, act, logp_old, tgt_r, tgt_c, adv, clip, grad_flat, losses_out, critics_only=False, reduce=True):
+        """ppo_lag.py:298-324 on the rows `idx` of the full [M, .] arrays (int64 device indices, or a PermWindow: the rows
+        perm[cursor : cursor + n] with the cursor on the device): spo_wide_ppo_grad_rows (networks x ceil(n / 16) workgroups, one
+        launch) + spo_wide_reduce_parts -> the flat data gradient in grad_flat[:n_params] and the data losses in losses_out.
+        reduce=False: the row groups' partial gradients only (returned: spo_wide_rows_clip_adam_dev_log sums them itself)."""
+        win = idx if isinstance(idx, PermWindow) else None
+        n = idx.numel()
+        P = 2 * self.Pc if critics_only else self.P
+        key = ("parts", n, critics_only)
+        parts = self._scratch.get(key)
+        if parts is None:
+            # (zeros: the tail holds the arrival counter of spo_wide_rows_clip_adam_dev_log)
+            parts = torch.zeros(int(self.lib.spo_wide_grad_rows_part_floats(P, n)), dtype=torch.float32, device=self.policy.theta.device)
+            self._scratch[key] = parts
+        _abi.check(self.lib.spo_wide_ppo_grad_rows(
+            _abi.ptr(self.policy.theta), self.net_c, None if critics_only else self.net_a, _abi.ptr(obs),
+            None if critics_only else _abi.ptr(act), None if critics_only else _abi.ptr(logp_old), _abi.ptr(tgt_r), _abi.ptr(tgt_c),
+            None if critics_only else _abi.ptr(adv), _abi.ptr(win.perm if win else idx), _abi.ptr(win.cursor) if win else None, n,
+            float(clip), _abi.ptr(parts), _abi.stream_ptr()), "spo_wide_ppo_grad_rows")
+        if reduce:
+            _abi.check(self.lib.spo_wide_reduce_parts(_abi.ptr(parts), n, P, 2 if critics_only else 3, _abi.ptr(grad_flat),
+                                                      _abi.ptr(losses_out), _abi.stream_ptr()), "spo_wide_reduce_parts")
+        return parts
+
     def gather_rows(self, idx, srcs):
         """[src[idx] for src in srcs] (row-major float32 arrays, int64 device indices) in one launch (spo_gather_rows).  `idx` may
         be a PermWindow: the rows perm[cursor : cursor + n] with the cursor on the device (a replayed minibatch step)."""

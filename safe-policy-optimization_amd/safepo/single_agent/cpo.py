@@ -675,16 +675,21 @@ class WideCPOEngine(_WideOps, CPOEngine):
         g, part, cap = self.flat_grad, self.loss_partials, self.loss_partials.numel()
         all_losses = []
         def step(idx, loss3, dev_clock):
-            obs, tgt_r, tgt_c = w.gather_rows(idx, [obs_all, tr_all.view(-1, 1), tc_all.view(-1, 1)])
-            tgt_r, tgt_c = tgt_r.view(-1), tgt_c.view(-1)
-            n = obs.shape[0]
-            (v_r, ws_r), (v_c, ws_c) = w.forward_multi("rc", obs, slot=1)
-            d_vr = torch.empty(n, dtype=torch.float32, device=self.dev)
-            d_vc = torch.empty_like(d_vr)
-            _abi.check(lib.spo_wide_critic_loss(_abi.ptr(v_r), _abi.ptr(v_c), _abi.ptr(tgt_r), _abi.ptr(tgt_c), n, _abi.ptr(d_vr),
-                                                _abi.ptr(d_vc), _abi.ptr(loss3), _abi.ptr(part), cap, _abi.stream_ptr()),
-                       "spo_wide_critic_loss")
-            w.backward_multi("rc", obs, [ws_r, ws_c], [d_vr, d_vc], g)
+            if w.rows_grad_ok(idx.numel(), critics_only=True):
+                # round 6: gather + both critics' forward / MSE / backward in one launch split over 16-row groups (csrc/mlp_rows.hip),
+                # then the fixed-order sum of the groups into g[:2 Pc] (the actor's stale gradient behind it is not touched)
+                w.grad_rows(idx, obs_all, None, None, tr_all, tc_all, None, 0.0, g, loss3, critics_only=True)
+            else:
+                obs, tgt_r, tgt_c = w.gather_rows(idx, [obs_all, tr_all.view(-1, 1), tc_all.view(-1, 1)])
+                tgt_r, tgt_c = tgt_r.view(-1), tgt_c.view(-1)
+                n = obs.shape[0]
+                (v_r, ws_r), (v_c, ws_c) = w.forward_multi("rc", obs, slot=1)
+                d_vr = torch.empty(n, dtype=torch.float32, device=self.dev)
+                d_vc = torch.empty_like(d_vr)
+                _abi.check(lib.spo_wide_critic_loss(_abi.ptr(v_r), _abi.ptr(v_c), _abi.ptr(tgt_r), _abi.ptr(tgt_c), n, _abi.ptr(d_vr),
+                                                    _abi.ptr(d_vc), _abi.ptr(loss3), _abi.ptr(part), cap, _abi.stream_ptr()),
+                           "spo_wide_critic_loss")
+                w.backward_multi("rc", obs, [ws_r, ws_c], [d_vr, d_vc], g)
             self._reduce_flat_grad(0, w.off_ls)       # data-parallel: the critics' gradient of the global minibatch
             if dev_clock:
                 self._clip_adam_dev(cfg, 0, w.off_ls, 0, 1, loss3, loss3, idx if isinstance(idx, PermWindow) else None)

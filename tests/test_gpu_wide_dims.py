@@ -450,6 +450,68 @@ def test_feature_split_gradient_launch_vs_fp64_autograd(dev, D, A):
     assert rel < 4e-6
 
 
+@pytest.mark.parametrize("D,A,hidden", [(60, 8, [128, 128]), (33, 3, [256, 96]), (17, 2, [32]), (61, 5, [100, 50, 30]), (376, 17, [128, 128]),
+                                        (60, 8, [64, 64, 64, 64]), (5, 64, [48]), (60, 8, [256, 256])])
+def test_row_group_gradient_launch_vs_fp64_autograd(dev, D, A, hidden):
+    """csrc/mlp_rows.hip (round 6): gather + forward + loss + backward of the three networks of a minibatch for any hidden_sizes in
+    one launch split over 16-row groups, then the fixed-order sum of the groups' partial gradients -- against float64 autograd of
+    ppo_lag.py:306-324 (without the L2 terms: spo_wide_clip_adam adds them) on the oracle policy.  Full, ragged, one-row, multi-group
+    and maximum (256-row) minibatches; widths that are not multiples of 16 or 4 (scalar weight loads), 1 to 4 hidden layers, a
+    64-wide action vector; the index window read through a device cursor as a replayed step does; the critics-only form of the
+    critic fit (cpo.py:541-556); theta not written."""
+    from safepo import _abi
+    from safepo.common.engine import WidePPOLagEngine
+    from safepo.common.wide import PermWindow
+    from test_gpu_parity import _fill_update_problem
+    M = 700
+    pol, ref = _wide_pair(D, A, hidden, dev, seed=13)
+    cfg_d = {"hidden_sizes": hidden, "gamma": 0.99, "target_kl": 0.02, "batch_size": 64, "learning_iters": 1, "max_grad_norm": 40.0}
+    eng = WidePPOLagEngine(pol, 1, M, cfg_d, dev)
+    w = eng.wide
+    assert w.rows_grad_ok(64) and w.rows_grad_ok(256) and not w.rows_grad_ok(257)
+    problem = _synthetic_update_problem(M, D, A, seed=29)
+    _fill_update_problem(eng, problem)
+    d, b = eng.buffer.data, eng.buffer
+    ref64 = copy.deepcopy(ref).double()
+    theta0 = pol.theta.clone()
+    perm = torch.randperm(M, generator=torch.Generator().manual_seed(6))
+    arrays = (d["obs"].view(M, D), d["act"].view(M, A), d["log_prob"].view(M), d["target_value_r"].view(M), d["target_value_c"].view(M),
+              b.adv_mix.view(M))
+    worst = 0.0
+    for lo, n, windowed in ((0, 64, False), (64, 37, False), (101, 1, False), (102, 100, True), (202, 256, False), (458, 16, True), (474, 17, False)):
+        idx = perm[lo:lo + n]
+        g = torch.full_like(eng.flat_grad, float("nan"))
+        l3 = torch.full((3,), float("nan"), device=dev)
+        if windowed:
+            win = PermWindow(M, n, dev)
+            win.load(perm.to(dev))
+            win.cursor.fill_(lo)
+            w.grad_rows(win, *arrays, 0.2, g, l3)
+        else:
+            w.grad_rows(idx.to(dev), *arrays, 0.2, g, l3)
+        rows = [t[idx].double() for t in problem]
+        ref64.zero_grad()
+        total, loss_pi, loss_r, loss_c = R.ppo_lag_losses(ref64, *rows, use_critic_norm=False)
+        total.backward()
+        want = R.flat_grads(ref64).numpy()
+        got = g.cpu().numpy().astype(np.float64)
+        assert np.isfinite(got).all(), f"{int(np.isnan(got).sum())} gradient elements never written (rows {n})"
+        np.testing.assert_allclose(l3.cpu().numpy(), [loss_r.item(), loss_c.item(), loss_pi.item()], rtol=1e-5, atol=2e-6)
+        err = np.abs(got - want).max() / np.abs(want).max()
+        worst = max(worst, err)
+        # (the log-probability is a sum of act_dim fp32 terms of size ~1 under an exp: the ratio's rounding grows with act_dim)
+        gate = 3e-6 * max(1.0, A / 8.0)
+        assert err < gate, (n, err)
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=gate * np.abs(want).max())
+        if n == 64:                                      # critics only: the same numbers for the two critics, nothing beyond them
+            g2 = torch.full_like(eng.flat_grad, float("nan"))
+            l2 = torch.full((2,), float("nan"), device=dev)
+            w.grad_rows(idx.to(dev), *arrays, 0.2, g2, l2, critics_only=True)
+            assert torch.equal(g2[:2 * w.Pc], g[:2 * w.Pc]) and torch.isnan(g2[2 * w.Pc:]).all() and torch.equal(l2, l3[:2])
+    assert torch.equal(pol.theta, theta0)
+    print(f"row-group gradient {D}x{A} {hidden}: worst max-norm error vs fp64 autograd {worst:.2e}")
+
+
 def test_feature_split_kernel_full_size_drift_envelope_at_humanoid_dims(dev):
     """The persistent feature-split kernel (csrc/update_ks.hip) at BASELINE config 2's size with HumanoidVelocity's dims:
     4096 envs x 128 steps = 524 288 rows of 376 observations / 17 actions, one learning iteration = 8 192 minibatch steps of 64

@@ -53,10 +53,16 @@ def _one(WidePPOLagEngine, hidden, batch, steps, D, A, **cfg_kw):
     ks = eng._feature_split_kernel_ok(eng._cfg_struct())
     if ks:
         eng.check_sync_error()
+    rows = (not ks) and eng.wide.rows_grad_ok(batch)
+    fused = rows and os.environ.get("SPO_WIDE_ROWS_FUSED", "1") != "0"
+    unroll = max(1, int(os.environ.get("SPO_WIDE_GRAPH_UNROLL", "8")))
+    rows_label = (f"row-group gradient kernel: 3 networks x {(batch + 15) // 16} workgroups of 16 rows in one launch (csrc/mlp_rows.hip) + "
+                  + ("2 optimiser launches" if fused else "group sum + 3 optimiser launches")
+                  + f", {unroll} steps per replayed HIP graph")
     return {"hidden_sizes": hidden, "batch": batch, "us_per_minibatch_step": round(dt * 1e6, 2 if ks else 1), "tflops": round(flops / dt / 1e12, 2),
             "params": int(pol.theta.numel()),
             "kernel": (f"ppo_update_ks_kernel: ONE persistent launch for the {steps} steps, 3 networks x {(D + 63) // 64} feature slices = "
-                       f"{3 * ((D + 63) // 64)} workgroups (csrc/update_ks.hip)") if ks else
+                       f"{3 * ((D + 63) // 64)} workgroups (csrc/update_ks.hip)") if ks else rows_label if rows else
                       "launch-per-layer wide step (csrc/ma_net.hip kernels), full minibatches replayed from one HIP graph"}
 
 
