@@ -180,8 +180,33 @@ __device__ __forceinline__ void layer_part(const float* Wl, int ld, const float*
 // NCT: 16-column tiles per workgroup -- 2: 32 rows of every minibatch, the four column waves are 2 column tiles x 2 feature halves;
 // 1: 16 rows, the four column waves are the four feature quarters of the one tile (the PPO-Lagrangian step at R = 4: half the
 // matrix work per SIMD again).
+// A pointer's value in a scalar-register pair of its own (see rs_body): through a VGPR, which the register coalescer does not
+// see through, back into the global address space (a pointer rebuilt from integers would otherwise be dereferenced with flat_*).
+template <class T>
+__device__ __forceinline__ T* own_sgprs(T* p) {
+  const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+  unsigned vlo, vhi;
+  asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(vlo), "=v"(vhi) : "s"((unsigned)u), "s"((unsigned)(u >> 32)));
+  const unsigned lo = __builtin_amdgcn_readfirstlane(vlo), hi = __builtin_amdgcn_readfirstlane(vhi);
+  typedef T __attribute__((address_space(1))) * gp;
+  return (T*)(gp)(((unsigned long long)hi << 32) | lo);
+}
+
 template <int KIN, int R, bool FAST, bool PROF, int XW = 0, int NCT = 2>
 __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
+  // The launch's pointers as INDIVIDUAL scalar-register pairs.  Read straight from the argument struct they arrive as one
+  // s_load_dwordx16 -- a 16-register tuple that the allocator can only spill and restore WHOLE: 16 v_readlane at each of 41 places
+  // in the step loop, 656 of the loop's ~4 000 instructions, to get at one 64-bit pointer each time (round 6, ISA census).  A plain
+  // copy (or an empty asm on an "s" operand) is coalesced back into the tuple; a trip through a VGPR is not (own_sgprs).
+  float* const p_theta = own_sgprs(a.theta);
+  float* const p_adam_m = own_sgprs(a.adam_m);
+  float* const p_adam_v = own_sgprs(a.adam_v);
+  const float* const p_obs = own_sgprs(a.obs);
+  const float* const p_act = own_sgprs(a.act);
+  const float* const p_logp_old = own_sgprs(a.logp_old);
+  const float* const p_tgt_r = own_sgprs(a.tgt_r);
+  const float* const p_tgt_c = own_sgprs(a.tgt_c);
+  const float* const p_adv = own_sgprs(a.adv);
   using L = NetLds<KIN>;
   using S = RsLds<KIN, NCT>;
   constexpr int LDC = S::LDC;
@@ -207,12 +232,12 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
   float* const red = lds + S::RED;
   const int64_t nsteps = (a.M + B - 1) / B;
 
-  stage_net<KIN>(a.theta, g, lds, tid, 512);
+  stage_net<KIN>(p_theta, g, lds, tid, 512);
   if (tid < 16) {
     // the Gaussian's per-action constants of the actor's loss, kept beside log_std by its owner (the optimiser lanes that run its
     // Adam): the four column waves no longer recompute exp / rcp per lane and step
     const bool on = is_actor && tid < A;
-    const float lsv = on ? a.theta[ls_off + tid] : 0.f;
+    const float lsv = on ? p_theta[ls_off + tid] : 0.f;
     const float sdv = __expf(lsv);
     lds[S::LS + tid] = lsv;
     lds[S::LS + 16 + tid] = __builtin_amdgcn_rcpf(sdv * sdv);
@@ -234,7 +259,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
     const int gcol = 16 * NCT * hf + 16 * ct + j_;     // column inside the minibatch
 #define RS_REIDX { j = pin(j_); q = pin(q_); lcol = 16 * ct + j; }
     const float clip_lo = 1.f - a.cfg.clip, clip_hi = 1.f + a.cfg.clip;
-    const float* tgt = (net == 0) ? a.tgt_r : a.tgt_c;
+    const float* tgt = (net == 0) ? p_tgt_r : p_tgt_c;
     auto perm_pos = [&](int64_t s_) -> int64_t {
       const int64_t base_ = s_ * B;
       const int64_t rem_ = a.M - base_;
@@ -242,15 +267,15 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
       return base_ + (gcol < nc_ ? gcol : 0);
     };
     auto fetch = [&](int64_t smp, RsCol<NT1>& cd) {
-      load_obs_tiles_raw<KIN>(a.obs + smp * D, D, q, cd.x);
+      load_obs_tiles_raw<KIN>(p_obs + smp * D, D, q, cd.x);
       if (!is_actor) {
         cd.t0 = tgt[smp]; cd.t1 = 0.f; cd.actv = f4{0.f, 0.f, 0.f, 0.f};
       } else {
-        cd.t0 = a.logp_old[smp]; cd.t1 = a.adv[smp];
+        cd.t0 = p_logp_old[smp]; cd.t1 = p_adv[smp];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int ai = 4 * q + r;
-          cd.actv[r] = a.act[smp * A + (ai < A ? ai : 0)];
+          cd.actv[r] = p_act[smp * A + (ai < A ? ai : 0)];
         }
       }
     };
@@ -511,7 +536,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
   const int ol = ow * 64 + lane;                                          // 0 .. 255
   int j = j_, q = q_, orow = 16 * ow + 4 * q_;
 #define RS_REIDX { j = pin(j_); q = pin(q_); orow = 16 * ow + 4 * q; }
-  float* const st_m = a.adam_m; float* const st_v = a.adam_v;
+  float* const st_m = p_adam_m; float* const st_v = p_adam_v;
   f4 mW1[NT1], vW1[NT1], mW2[4], vW2[4], mW3, vW3, mls, vls;
   float mb1, vb1, mb2, vb2, mb3 = 0.f, vb3 = 0.f;
   const bool own_b = (q_ == 0);
@@ -523,29 +548,29 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
     for (int r = 0; r < 4; ++r) {
       const int i = 16 * nt + j;
       const int idx = g.w1() + (orow + r) * D + i;
-      mW1[nt][r] = i < D ? a.adam_m[idx] : 0.f;
-      vW1[nt][r] = i < D ? a.adam_v[idx] : 0.f;
+      mW1[nt][r] = i < D ? p_adam_m[idx] : 0.f;
+      vW1[nt][r] = i < D ? p_adam_v[idx] : 0.f;
     }
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int idx = g.w2() + (orow + r) * HID + 16 * nt + j;
-      mW2[nt][r] = a.adam_m[idx];
-      vW2[nt][r] = a.adam_v[idx];
+      mW2[nt][r] = p_adam_m[idx];
+      vW2[nt][r] = p_adam_v[idx];
     }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int o = 4 * q + r;
     const int idx = g.w3() + o * HID + 16 * ow + j;
-    mW3[r] = o < OUT ? a.adam_m[idx] : 0.f;
-    vW3[r] = o < OUT ? a.adam_v[idx] : 0.f;
-    mls[r] = (is_actor && o < A) ? a.adam_m[ls_off + o] : 0.f;
-    vls[r] = (is_actor && o < A) ? a.adam_v[ls_off + o] : 0.f;
+    mW3[r] = o < OUT ? p_adam_m[idx] : 0.f;
+    vW3[r] = o < OUT ? p_adam_v[idx] : 0.f;
+    mls[r] = (is_actor && o < A) ? p_adam_m[ls_off + o] : 0.f;
+    vls[r] = (is_actor && o < A) ? p_adam_v[ls_off + o] : 0.f;
   }
-  mb1 = a.adam_m[g.b1() + 16 * ow + j]; vb1 = a.adam_v[g.b1() + 16 * ow + j];
-  mb2 = a.adam_m[g.b2() + 16 * ow + j]; vb2 = a.adam_v[g.b2() + 16 * ow + j];
-  if (j < OUT) { mb3 = a.adam_m[g.b3() + j]; vb3 = a.adam_v[g.b3() + j]; }
+  mb1 = p_adam_m[g.b1() + 16 * ow + j]; vb1 = p_adam_v[g.b1() + 16 * ow + j];
+  mb2 = p_adam_m[g.b2() + 16 * ow + j]; vb2 = p_adam_v[g.b2() + 16 * ow + j];
+  if (j < OUT) { mb3 = p_adam_m[g.b3() + j]; vb3 = p_adam_v[g.b3() + j]; }
 
   const float b1c = a.cfg.beta1, b2c = a.cfg.beta2, eps = a.cfg.adam_eps;
   double pw1 = a.pow_b1, pw2 = a.pow_b2;
@@ -1089,7 +1114,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
         const int i = 16 * nt + j;
         if (i < D) {
           const int idx = g.w1() + (orow + r) * D + i;
-          a.theta[idx] = lds[L::W1 + (orow + r) * L::LD1 + i];
+          p_theta[idx] = lds[L::W1 + (orow + r) * L::LD1 + i];
           st_m[idx] = mW1[nt][r]; st_v[idx] = vW1[nt][r];
         }
       }
@@ -1098,7 +1123,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int idx = g.w2() + (orow + r) * HID + 16 * nt + j;
-        a.theta[idx] = lds[L::W2 + (orow + r) * LDH + 16 * nt + j];
+        p_theta[idx] = lds[L::W2 + (orow + r) * LDH + 16 * nt + j];
         st_m[idx] = mW2[nt][r]; st_v[idx] = vW2[nt][r];
       }
 #pragma unroll
@@ -1106,20 +1131,20 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
       const int o = 4 * q + r;
       if (o < OUT) {
         const int idx = g.w3() + o * HID + 16 * ow + j;
-        a.theta[idx] = lds[L::W3 + o * LDH + 16 * ow + j];
+        p_theta[idx] = lds[L::W3 + o * LDH + 16 * ow + j];
         st_m[idx] = mW3[r]; st_v[idx] = vW3[r];
       }
       if (own_ls && o < A) {
-        a.theta[ls_off + o] = lds[S::LS + o];
+        p_theta[ls_off + o] = lds[S::LS + o];
         st_m[ls_off + o] = mls[r]; st_v[ls_off + o] = vls[r];
       }
     }
     if (own_b) {
       const int o = 16 * ow + j;
-      a.theta[g.b1() + o] = lds[L::B1 + o]; st_m[g.b1() + o] = mb1; st_v[g.b1() + o] = vb1;
-      a.theta[g.b2() + o] = lds[L::B2 + o]; st_m[g.b2() + o] = mb2; st_v[g.b2() + o] = vb2;
+      p_theta[g.b1() + o] = lds[L::B1 + o]; st_m[g.b1() + o] = mb1; st_v[g.b1() + o] = vb1;
+      p_theta[g.b2() + o] = lds[L::B2 + o]; st_m[g.b2() + o] = mb2; st_v[g.b2() + o] = vb2;
     }
-    if (own_b3) { a.theta[g.b3() + j] = lds[L::B3 + j]; st_m[g.b3() + j] = mb3; st_v[g.b3() + j] = vb3; }
+    if (own_b3) { p_theta[g.b3() + j] = lds[L::B3 + j]; st_m[g.b3() + j] = mb3; st_v[g.b3() + j] = vb3; }
     if (ol == 0 && wg == 0 && a.stale_io) *a.stale_io = stale_sq;
   }
 #undef RS_REIDX

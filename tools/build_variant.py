@@ -18,7 +18,7 @@ objs = []
 for src in G.HIP_SOURCES:
     if src in srcs:
         obj = os.path.join(vdir, f"{src[:-4]}_{name}.o")
-        cmd = [G._hipcc()] + G.HIPCC_FLAGS + flags + ["-c", os.path.join(G.CSRC, src), "-o", obj]
+        cmd = [G._hipcc()] + G.HIPCC_FLAGS + G.EXTRA_FLAGS.get(src, []) + flags + ["-c", os.path.join(G.CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             sys.exit(r.stderr)
