@@ -80,6 +80,40 @@ def test_feature_split_entry_points_shape_envelope_and_argument_errors(built_lib
     assert lib.spo_p2p_form_valid(7, 2) == 0 and lib.spo_p2p_form_valid(0, 9) == 0
 
 
+def test_round6_entry_points_shape_envelope_and_argument_errors(built_lib):
+    """Round 6 without a GPU: which shapes the row-group gradient kernel (csrc/mlp_rows.hip) and the row-split kernel
+    (csrc/update_rs.hip) take, the size of the partial-gradient buffer, and that the new entry points refuse bad arguments before
+    any launch."""
+    import ctypes
+    from safepo import _abi
+    lib = _abi.load(built_lib)
+    net = _abi.MlpNet.of
+    ok = lib.spo_wide_grad_rows_supported
+    assert ok(net([60, 128, 128, 1]), net([60, 128, 128, 8]), 64) == 1 and ok(net([60, 128, 128, 1]), net([60, 128, 128, 8]), 256) == 1
+    assert ok(net([60, 128, 128, 1]), net([60, 128, 128, 8]), 257) == 0 and ok(net([60, 128, 128, 1]), net([60, 128, 128, 8]), 0) == 0
+    assert ok(net([60, 256, 256, 1]), net([60, 256, 256, 8]), 64) == 1            # 157.4 KB of the 160 KB
+    assert ok(net([376, 256, 256, 1]), net([376, 256, 256, 17]), 64) == 0         # the images do not fit a CU's LDS
+    assert ok(net([60, 1024, 1024, 512, 1]), net([60, 1024, 1024, 512, 8]), 64) == 0
+    assert ok(net([60, 128, 1]), None, 128) == 1                                  # the two critics alone (critic fit)
+    assert ok(net([60, 128, 2]), None, 64) == 0 and ok(net([60, 128, 1]), net([61, 128, 8]), 64) == 0
+    assert ok(net([60, 128, 1]), net([60, 128, 65]), 64) == 0                     # act_dim beyond SPO_WIDE_MAX_ACT
+    P = 2 * (60 * 128 + 128 + 128 + 1) + 8 + (60 * 128 + 128 + 128 * 8 + 8)
+    assert lib.spo_wide_grad_rows_part_floats(P, 64) == 4 * ((P + 4 + 3) // 4 * 4) + 4
+    assert lib.spo_wide_grad_rows_part_floats(P, 17) == 2 * ((P + 4 + 3) // 4 * 4) + 4 and lib.spo_wide_grad_rows_part_floats(0, 64) < 0
+    assert lib.spo_wide_ppo_grad_rows(None, net([60, 128, 1]), None, None, None, None, None, None, None, None, None, 64, 0.2, None, None) < 0
+    assert b"null pointer" in lib.spo_last_error()
+    assert lib.spo_wide_reduce_parts(None, 64, P, 3, None, None, None) < 0 and b"bad args" in lib.spo_last_error()
+    assert lib.spo_update_rs_supported(60, 8, 64, 3) == 1 and lib.spo_update_rs_supported(64, 16, 128, 2) == 1
+    assert lib.spo_update_rs_supported(65, 8, 64, 3) == 0 and lib.spo_update_rs_supported(60, 17, 64, 3) == 0
+    assert lib.spo_update_rs_supported(60, 8, 65, 3) == 0 and lib.spo_update_rs_supported(60, 8, 129, 2) == 0
+    cfg = _abi.PpoCfg(obs_dim=376, act_dim=17, batch=64, use_critic_norm=1, use_value_coefficient=0, clip=0.2, max_grad_norm=40.0,
+                      lr_actor=3e-4, lr_critic=3e-4, beta1=0.9, beta2=0.999, adam_eps=1e-8, l2_coef=0.001)
+    assert lib.spo_ppo_lag_grad_ks(None, None, None, None, None, None, None, None, 65, ctypes.byref(cfg), None, None, None, None) < 0
+    assert b"rows 65" in lib.spo_last_error()
+    assert lib.spo_ppo_lag_grad_ks(None, None, None, None, None, None, None, None, 64, ctypes.byref(cfg), None, None, None, None) < 0
+    assert b"null pointer" in lib.spo_last_error()
+
+
 def test_missing_library_fails_loudly(tmp_path):
     from safepo import _abi
     with pytest.raises(_abi.SpoError, match="no CPU fallback"):
