@@ -1,6 +1,7 @@
 """Development aid (GPU box): the compute side of ONE data-parallel minibatch step at the feature-split kernel's dims (hidden
-[64, 64], obs_dim <= 512): spo_ppo_lag_grad_ks + spo_wide_clip_adam (round 6) next to the launch-per-layer step it replaces
-(gather, 3 forwards, loss, 3 backwards, clip + Adam), both launched eagerly as under data parallelism (a host collective sits
+[64, 64], obs_dim <= 512): spo_ppo_lag_grad_ks + spo_wide_clip_adam (round 6) next to what the wide engine's eager minibatch step
+launches otherwise -- the row-group gradient kernel (csrc/mlp_rows.hip), or with SPO_WIDE_ROWS=0 the launch-per-layer step of
+rounds 4-5 (gather, 3 forwards, loss, 3 backwards, clip + Adam) -- all launched eagerly as under data parallelism (a host collective sits
 between the gradient and the clip; none here: world 1, so the numbers are the launches alone).
     python tools/ks_grad_bench.py [D,A ...]"""
 import json
@@ -53,7 +54,10 @@ def one(D, A, steps=512, reps=3):
             eng.minibatch_step(perm64[k * 64:(k + 1) * 64], losses[k], cfg=cfg)
 
     out = {"obs_dim": D, "act_dim": A, "steps": steps}
-    for name, fn in (("grad_kernel_plus_clip_adam", grad_kernel_pass), ("launch_per_layer", per_layer_pass)):
+    # what WidePPOLagEngine.minibatch_step launches eagerly in this process: the row-group gradient kernel of round 6
+    # (csrc/mlp_rows.hip) + group sum + clip / Adam, or -- SPO_WIDE_ROWS=0 -- the launch-per-network step of rounds 4-5
+    other = "row_group_kernel_step" if eng.wide.rows_grad_ok(64) else "launch_per_layer"
+    for name, fn in (("grad_kernel_plus_clip_adam", grad_kernel_pass), (other, per_layer_pass)):
         ts = []
         for _ in range(reps + 1):
             torch.cuda.synchronize()

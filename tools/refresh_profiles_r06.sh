@@ -42,7 +42,7 @@ bash tools/r06_loopback.sh > /dev/null 2>&1; cat $O/p2p_loopback.txt
 HSA_ENABLE_IPC_MODE_LEGACY=0 SPO_BENCH_ONE_GPU=1 timeout 500 python bench.py --gpus 2 --steps 1 --warmup 1 --no-cpu-baseline --config5-threads 1024 > $O/bench_dp2_one_gpu.json 2> $O/bench_dp2_one_gpu.err; tail -c 300 $O/bench_dp2_one_gpu.json
 # the wide path's row-group gradient kernel (item 6) and the feature-split gradient launch (item 4b); tests left to tools/r06_final.sh
 sed -e '/pytest/d' tools/r06_rows.sh > /tmp/r06_rows_notests.sh; bash /tmp/r06_rows_notests.sh > /dev/null 2>&1; cat $O/wide_step.txt | cut -c1-200
-timeout 300 python tools/ks_grad_bench.py 376,17 130,8 2>&1 | grep -v "amdgpu.ids\|WARNING" > $O/dp_feature_split_step.txt; cat $O/dp_feature_split_step.txt
+{ timeout 300 python tools/ks_grad_bench.py 376,17 130,8; echo "-- SPO_WIDE_ROWS=0"; SPO_WIDE_ROWS=0 timeout 300 python tools/ks_grad_bench.py 376,17 130,8; } 2>&1 | grep -v "amdgpu.ids\|WARNING" > $O/dp_feature_split_step.txt; cat $O/dp_feature_split_step.txt
 bash tools/update_pmc.sh > $O/update_pmc.log 2>&1; cp $O/update_pmc/summary.json $O/update_kernel_pmc.json; tail -5 $O/update_pmc.log
 bash tools/kl_pmc.sh > $O/kl_pmc.log 2>&1; cp $O/kl_pmc/summary.json $O/kl_kernel_pmc.json; tail -2 $O/kl_pmc.log
 bash tools/fvp_pmc.sh > $O/fvp_pmc.log 2>&1; cp $O/fvp_pmc/summary.json $O/fvp_kernel_pmc.json; tail -1 $O/fvp_pmc.log
