@@ -352,16 +352,19 @@ int spo_critic_fit_iter_ks(float* theta, float* adam_m, float* adam_v, int64_t a
                            const spo_ppo_cfg* cfg_host, float* stale_sq_io, float* losses_out, void* sync_ws, void* stream);
 
 /* Form of the in-kernel gradient exchange (which of the built all-reduce forms runs inside the persistent update
- * kernel).  spo_p2p_select_form pins one for the process (-1: back to the default policy: environment overrides, else recursive
- * doubling at 2 / 4 ranks and the two-phase form elsewhere); a form that does not exist at a world size falls back to the policy.
+ * kernel).  spo_p2p_select_form pins one for the process (-1: back to the default policy: environment overrides, else the row-split
+ * form at 2 / 4 / 8 ranks -- shapes outside the row-split kernel run the four-wave kernel -- recursive doubling at 2 / 4 ranks and
+ * the two-phase form elsewhere); a form that does not exist at a world size falls back to the policy.
  * safepo.parallel.PeerExchange.autotune times every valid form at start-up on the actual topology and pins the fastest. */
 #define SPO_XR_FORM_TWOPHASE 0          /* packed reduce-scatter + all-gather, four-wave kernel: two hand-offs at any world size   */
 #define SPO_XR_FORM_DOUBLING 1          /* packed recursive doubling, four-wave kernel: log2(world) hand-offs (power-of-two worlds) */
 #define SPO_XR_FORM_HELPER_A2A 2        /* one-shot all-to-all with flags on the helper waves (worlds 2 / 4 / 8): one hand-off      */
 #define SPO_XR_FORM_HELPER_DOUBLING 3   /* packed recursive doubling on the helper waves, layer by layer (worlds 2 / 4 / 8)          */
-#define SPO_XR_FORM_ROW_SPLIT 4         /* round 6: the row-split kernel (spo_update_rs_supported); the rank's gradient goes to every
-                                         * other rank at once as tagged 16-byte words -- ONE cross-rank hand-off on world - 1 links,
-                                         * XOR-butterfly sum (worlds 2 / 4 / 8; SPO_P2P_ALGO=rowsplit)                                */
+#define SPO_XR_FORM_ROW_SPLIT 4         /* round 6: the row-split kernel (spo_update_rs_supported), tagged 16-byte words behind the row
+                                         * groups' L2 hand-off.  2 ranks: the gradient goes to the peer at once (ONE cross-rank hand-off);
+                                         * 4 / 8 ranks: reduce-scatter + all-gather -- every word to its owner rank, which adds the
+                                         * world's contributions in rank order (all polled in one batch) and sends the finished word to
+                                         * everyone: two hand-offs on world - 1 links each (SPO_P2P_ALGO=rowsplit)                     */
 int spo_p2p_select_form(int form);
 int spo_p2p_form_valid(int form, int world);
 int spo_p2p_current_form(int world);

@@ -46,4 +46,20 @@ inline int hip_check(hipError_t e, const char* what) {
 int ks_scratch_release(int dev, void* stream_or_null, int all);
 // ... and of the row-split kernel (update_rs.hip)
 int rs_scratch_release(int dev, void* stream_or_null, int all);
+// A pointer's value in a scalar-register pair of its own.  The persistent kernels' arguments arrive as wide scalar loads
+// (s_load_dwordx8 / x16): register TUPLES that the allocator can only spill and restore whole -- 16 v_readlane to get at one
+// 64-bit pointer (update_rs.hip, round 6: 656 of the step loop's 766).  A plain copy, or an empty asm on an "s" operand, is
+// coalesced back into the tuple; a trip through a VGPR is not.  The result is cast back into the global address space (a pointer
+// rebuilt from integers would otherwise be dereferenced with flat_* instructions).
+#ifdef __HIPCC__
+template <class T>
+__device__ __forceinline__ T* own_sgprs(T* p) {
+  const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+  unsigned vlo, vhi;
+  asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(vlo), "=v"(vhi) : "s"((unsigned)u), "s"((unsigned)(u >> 32)));
+  const unsigned lo = __builtin_amdgcn_readfirstlane(vlo), hi = __builtin_amdgcn_readfirstlane(vhi);
+  typedef T __attribute__((address_space(1))) * gp;
+  return (T*)(gp)(((unsigned long long)hi << 32) | lo);
+}
+#endif
 }  // namespace spo

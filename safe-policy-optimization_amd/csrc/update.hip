@@ -3167,7 +3167,17 @@ static int xr_form(int world) {
   if (a2a && xr_form_valid(SPO_XR_FORM_HELPER_A2A, world)) return SPO_XR_FORM_HELPER_A2A;
   if (helper_xr_mode() && xr_form_valid(SPO_XR_FORM_HELPER_DOUBLING, world)) return SPO_XR_FORM_HELPER_DOUBLING;
   if (algo && !strcmp(algo, "doubling") && pow2) return SPO_XR_FORM_DOUBLING;
+  // round 6: where it exists (2 / 4 / 8 ranks, SPO_UPDATE_FORM >= 3) the row-split form is the default -- loopback 10.9 / 14.8 / 15.1 us
+  // per step at 2 / 4 / 8 ranks against 14.1 / 16.6 / 18.3 for the policy below (profiles/r06/p2p_loopback.txt); shapes the row-split
+  // kernel does not take run the four-wave kernel under that policy (xr_four_wave_form)
+  if (!(algo && *algo) && xr_form_valid(SPO_XR_FORM_ROW_SPLIT, world)) return SPO_XR_FORM_ROW_SPLIT;
   return (world <= 4 && pow2) ? SPO_XR_FORM_DOUBLING : SPO_XR_FORM_TWOPHASE;
+}
+// the form of the four-wave / main + helper kernels when the selected form is the row-split kernel's and the shape is not its own
+static int xr_four_wave_form(int world) {
+  const int f = xr_form(world);
+  if (f != SPO_XR_FORM_ROW_SPLIT) return f;
+  return (world <= 4 && (world & (world - 1)) == 0) ? SPO_XR_FORM_DOUBLING : SPO_XR_FORM_TWOPHASE;
 }
 extern "C" int spo_p2p_current_form(int world) { return xr_form(world); }
 
@@ -3177,7 +3187,7 @@ static int fill_xr(UpdArgs& a, int rank, int world, void* const* regions, unsign
   SPO_REQUIRE(regions != nullptr, "p2p: regions is NULL");
   for (int r = 0; r < world; ++r) SPO_REQUIRE(regions[r] != nullptr, "p2p: region of rank %d is NULL", r);
   a.xr_rank = rank; a.xr_world = world; a.xr_step0 = step0;
-  a.xr_algo = xr_form(world) == SPO_XR_FORM_TWOPHASE ? 0 : 1;       // (the protocol of the four-wave kernels and of the self-test)
+  a.xr_algo = xr_four_wave_form(world) == SPO_XR_FORM_TWOPHASE ? 0 : 1;   // (the protocol of the four-wave kernels and of the self-test)
   { const char* dbg = getenv("SPO_A2A_DEBUG"); a.xr_debug = dbg ? atoi(dbg) : 0; }
   for (int r = 0; r < XR_MAX_WORLD; ++r) a.xr_region[r] = r < world ? regions[r] : nullptr;
   return 0;
@@ -3311,7 +3321,7 @@ extern "C" int spo_ppo_lag_update_iter_dp(float* theta, float* adam_m, float* ad
   // packed 16-byte words, one poll batch per stage (xr_rd16_flat).  Loopback: 16.2 / 22.4 / 27.9 us per step at 2 / 4 / 8 ranks
   // against 14.3 / 16.7 / 19.1 for the default below (four-wave kernel, ONE exchange of the whole gradient per step): between P1
   // and Q2 the helper waves already gate the step, so hand-offs placed there are exposed in full and there are two per step.
-  const int form = xr_form(world);
+  const int form = xr_four_wave_form(world);
   const bool a2a = form == SPO_XR_FORM_HELPER_A2A;
   a.xr_helper_rd = a2a ? 0 : 1;
   if ((a2a || form == SPO_XR_FORM_HELPER_DOUBLING) && kin <= 64 && cfg_host->batch <= 64 && update_form() >= 2) {
@@ -3353,7 +3363,7 @@ extern "C" int spo_critic_fit_iter_dp(float* theta, float* adam_m, float* adam_v
   a.first_net = 0; a.n_nets = 2; a.stale_sq = 0.f; a.stale_io = stale_sq_io;
   int rc = 0;
   const int kin = pick_kin(cfg_host->obs_dim);
-  const int form = xr_form(world);          // (the all-to-all form has no two-network instantiation: the helpers' doubling stands in)
+  const int form = xr_four_wave_form(world);  // (the all-to-all form has no two-network instantiation: the helpers' doubling stands in)
   a.xr_helper_rd = 1;
   if ((form == SPO_XR_FORM_HELPER_A2A || form == SPO_XR_FORM_HELPER_DOUBLING) && kin <= 64 && cfg_host->batch <= 64 && update_form() >= 2) {
     // main + helper form with recursive doubling on the helper waves (see spo_ppo_lag_update_iter_dp)

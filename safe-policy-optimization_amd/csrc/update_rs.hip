@@ -42,6 +42,9 @@
 namespace {
 using namespace spo;
 
+#ifndef SPO_RS_XR_TWO_PHASE_MIN
+#define SPO_RS_XR_TWO_PHASE_MIN 4     // data-parallel form: all-to-all of every word below this world size, reduce-scatter + all-gather from it on (A/B knob)
+#endif
 constexpr int RS_NS = 16;                        // exchange slots (16-byte groups per lane) per (destination, source): NT1 + 8 <= 12 used
 constexpr int RS_MAX_R = 4;
 constexpr unsigned RS_SPIN_LIMIT = 1u << 22;
@@ -180,18 +183,6 @@ __device__ __forceinline__ void layer_part(const float* Wl, int ld, const float*
 // NCT: 16-column tiles per workgroup -- 2: 32 rows of every minibatch, the four column waves are 2 column tiles x 2 feature halves;
 // 1: 16 rows, the four column waves are the four feature quarters of the one tile (the PPO-Lagrangian step at R = 4: half the
 // matrix work per SIMD again).
-// A pointer's value in a scalar-register pair of its own (see rs_body): through a VGPR, which the register coalescer does not
-// see through, back into the global address space (a pointer rebuilt from integers would otherwise be dereferenced with flat_*).
-template <class T>
-__device__ __forceinline__ T* own_sgprs(T* p) {
-  const unsigned long long u = reinterpret_cast<unsigned long long>(p);
-  unsigned vlo, vhi;
-  asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(vlo), "=v"(vhi) : "s"((unsigned)u), "s"((unsigned)(u >> 32)));
-  const unsigned lo = __builtin_amdgcn_readfirstlane(vlo), hi = __builtin_amdgcn_readfirstlane(vhi);
-  typedef T __attribute__((address_space(1))) * gp;
-  return (T*)(gp)(((unsigned long long)hi << 32) | lo);
-}
-
 template <int KIN, int R, bool FAST, bool PROF, int XW = 0, int NCT = 2>
 __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
   // The launch's pointers as INDIVIDUAL scalar-register pairs.  Read straight from the argument struct they arrive as one
@@ -656,6 +647,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
   }
 
   // ---- cross-rank stage (XW > 0): NFL floats of this lane, words W0 .. of the row-split section of the exchange regions
+  constexpr bool XTP = XW >= SPO_RS_XR_TWO_PHASE_MIN;                      // two-phase form (below) from this world size on
   const unsigned gtag0 = a.xr_step0 + 1u;
   // (region pointers from an LDS copy of the kernel-argument table: indexing the table itself with a run-time rank would move the
   //  whole argument block to scratch)
@@ -721,6 +713,92 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
       }                                                                                                \
     }                                                                                                  \
     _Pragma("unroll") for (int f_ = 0; f_ < (NFL); ++f_) (FL)[f_] = acc_[f_] * (1.f / (float)XW);      \
+  }
+
+  // ---- two-phase form of the cross-rank stage (XW >= SPO_RS_XR_TWO_PHASE_MIN): word gw of a lane belongs to rank gw mod XW.
+  // SCATTER: every rank sends each word to its owner only; REDUCE_OWN: the owner polls the XW - 1 contributions of a word TOGETHER
+  // (XW loads in flight: one round trip, where the all-to-all form above polls XW - 1 sources of ALL words one after the other: its
+  // poll buffer for two sources at once does not fit beside the optimiser state), adds them in rank order with its own at its
+  // position, takes the mean and sends the finished word to every other rank; GATHER: a rank picks up the words it does not own, one
+  // batch, one round trip.  Two cross-rank hand-offs instead of one, but 2 exposed round trips instead of XW - 1, and 13 + 14
+  // words per lane and step on the links instead of 15 (XW - 1).  A word is reduced by exactly one rank: the replicas continue
+  // from identical bits by construction.  Slots: the all-to-all form's [parity][row group][network][source][word] -- at the
+  // owner, [source = sender] holds a contribution; elsewhere [source = owner] holds the finished word (disjoint entries).
+#define RSX2_SCATTER(FL, NFL, W0, GTAG)                                                                \
+  {                                                                                                    \
+    constexpr int NW_ = ((NFL) + 2) / 3;                                                               \
+    const int xpar_ = (int)((GTAG) & 1u);                                                              \
+    _Pragma("unroll") for (int w_ = 0; w_ < NW_; ++w_) {                                               \
+      const int o_ = ((W0) + w_) % (XW > 0 ? XW : 1);                                                  \
+      if (o_ != a.xr_rank) {                                              /* (uniform) */              \
+        u4v word_;                                                                                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_)                                               \
+          word_[i_] = (3 * w_ + i_) < (NFL) ? __float_as_uint((FL)[(3 * w_ + i_) < (NFL) ? 3 * w_ + i_ : 0]) : 0u; \
+        word_[3] = (GTAG);                                                                             \
+        st16_sys(rsx_slot(o_, xpar_, a.xr_rank, (W0) + w_), xlane, word_);                             \
+      }                                                                                                \
+    }                                                                                                  \
+  }
+#define RSX2_REDUCE_OWN(FL, NFL, W0, GTAG)                                                             \
+  {                                                                                                    \
+    constexpr int NW_ = ((NFL) + 2) / 3;                                                               \
+    constexpr int XW_ = XW > 0 ? XW : 1;                                                               \
+    const int xpar_ = (int)((GTAG) & 1u);                                                              \
+    _Pragma("unroll") for (int w_ = 0; w_ < NW_; ++w_) {                                               \
+      if ((((W0) + w_) % XW_) == a.xr_rank) {                             /* (uniform) this rank's word */ \
+        u4v x_[XW_];                                                                                   \
+        unsigned spins_ = 0;                                                                           \
+        for (;;) {                                                                                     \
+          _Pragma("unroll") for (int s_ = 0; s_ < XW_; ++s_)              /* (its own entry is never written: loaded, ignored) */ \
+            x_[s_] = ld16_sys(rsx_slot(a.xr_rank, xpar_, s_, (W0) + w_), xlane);                       \
+          wait_vm0();                                                                                  \
+          bool ok_ = true;                                                                             \
+          _Pragma("unroll") for (int s_ = 0; s_ < XW_; ++s_) {                                         \
+            pin_u4(x_[s_]);                                                                            \
+            ok_ = ok_ && (s_ == a.xr_rank || x_[s_][3] == (GTAG));                                     \
+          }                                                                                            \
+          if (ok_ || *dead != 0.f) break;                                                              \
+          if (++spins_ > RS_SPIN_LIMIT) { *a.err = 2; *dead = 1.f; break; }   /* bounded, and sticky */ \
+          __builtin_amdgcn_s_sleep(1);                                                                 \
+        }                                                                                              \
+        u4v red_;                                                                                      \
+        _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) {                                             \
+          const float own_ = (3 * w_ + i_) < (NFL) ? (FL)[(3 * w_ + i_) < (NFL) ? 3 * w_ + i_ : 0] : 0.f; \
+          float acc_ = a.xr_rank == 0 ? own_ : __uint_as_float(x_[0][i_]);                             \
+          _Pragma("unroll") for (int s_ = 1; s_ < XW_; ++s_)                                           \
+            acc_ = acc_ + (s_ == a.xr_rank ? own_ : __uint_as_float(x_[s_][i_]));                      \
+          acc_ = acc_ * (1.f / (float)XW_);                                                            \
+          if ((3 * w_ + i_) < (NFL)) (FL)[(3 * w_ + i_) < (NFL) ? 3 * w_ + i_ : 0] = acc_;             \
+          red_[i_] = __float_as_uint(acc_);                                                            \
+        }                                                                                              \
+        red_[3] = (GTAG);                                                                              \
+        _Pragma("unroll") for (int d_ = 1; d_ < XW_; ++d_)                                             \
+          st16_sys(rsx_slot(a.xr_rank ^ d_, xpar_, a.xr_rank, (W0) + w_), xlane, red_);                \
+      }                                                                                                \
+    }                                                                                                  \
+  }
+#define RSX2_GATHER(FL, NFL, W0, GTAG)                                                                 \
+  {                                                                                                    \
+    constexpr int NW_ = ((NFL) + 2) / 3;                                                               \
+    constexpr int XW_ = XW > 0 ? XW : 1;                                                               \
+    const int xpar_ = (int)((GTAG) & 1u);                                                              \
+    u4v x_[NW_];                                                                                       \
+    unsigned spins_ = 0;                                                                               \
+    for (;;) {                                                                                         \
+      _Pragma("unroll") for (int w_ = 0; w_ < NW_; ++w_)                  /* [source = the word's owner] */ \
+        x_[w_] = ld16_sys(rsx_slot(a.xr_rank, xpar_, ((W0) + w_) % XW_, (W0) + w_), xlane);            \
+      wait_vm0();                                                                                      \
+      bool ok_ = true;                                                                                 \
+      _Pragma("unroll") for (int w_ = 0; w_ < NW_; ++w_) {                                             \
+        pin_u4(x_[w_]);                                                                                \
+        ok_ = ok_ && ((((W0) + w_) % XW_) == a.xr_rank || x_[w_][3] == (GTAG));                        \
+      }                                                                                                \
+      if (ok_ || *dead != 0.f) break;                                                                  \
+      if (++spins_ > RS_SPIN_LIMIT) { *a.err = 2; *dead = 1.f; break; }   /* bounded, and sticky */    \
+      __builtin_amdgcn_s_sleep(1);                                                                     \
+    }                                                                                                  \
+    _Pragma("unroll") for (int f_ = 0; f_ < (NFL); ++f_)                                               \
+      (FL)[f_] = ((((W0) + f_ / 3) % XW_) == a.xr_rank) ? (FL)[f_] : __uint_as_float(x_[f_ / 3][f_ % 3]); \
   }
 
 #define RS_ADAM(ADDR, G, M, V)                                                             \
@@ -855,7 +933,8 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
       fA[20] = gA[5][0]; fA[21] = gA[5][1];
 #pragma unroll
       for (int e = 0; e < 4; ++e) fA[22 + e] = gA[6][e];
-      RSX_PUSH(fA, NFA, 0, gtag)
+      if constexpr (XTP) RSX2_SCATTER(fA, NFA, 0, gtag)
+      else RSX_PUSH(fA, NFA, 0, gtag)
     }
     auto l2_terms_a = [&]() {
     if (has_l2) {
@@ -920,8 +999,15 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) fB[4 * k + e] = gB[k][e];
       fB[4 * NT1] = gB[NT1][0];
-      RSX_PUSH(fB, NFB, 9, gtag)
-      RSX_REDUCE(fA, NFA, 0, gtag)                                         // (sent before layer 1's local hand-off: long there)
+      if constexpr (XTP) {
+        RSX2_SCATTER(fB, NFB, 9, gtag)
+        RSX2_REDUCE_OWN(fA, NFA, 0, gtag)                                  // (its contributions were sent before layer 1's local hand-off)
+        RSX2_REDUCE_OWN(fB, NFB, 9, gtag)                                  // exposed round trip 1
+        RSX2_GATHER(fA, NFA, 0, gtag)
+      } else {
+        RSX_PUSH(fB, NFB, 9, gtag)
+        RSX_REDUCE(fA, NFA, 0, gtag)                                       // (sent before layer 1's local hand-off: long there)
+      }
 #pragma unroll
       for (int k = 0; k < 5; ++k)
 #pragma unroll
@@ -930,7 +1016,8 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) gA[6][e] = fA[22 + e];
       l2_terms_a();
-      RSX_REDUCE(fB, NFB, 9, gtag)                                         // the exposed cross-rank hand-off
+      if constexpr (XTP) RSX2_GATHER(fB, NFB, 9, gtag)                     // exposed round trip 2
+      else RSX_REDUCE(fB, NFB, 9, gtag)                                    // the exposed cross-rank hand-off
 #pragma unroll
       for (int k = 0; k < NT1; ++k)
 #pragma unroll
@@ -1101,6 +1188,9 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
 #undef RS_POLL_SUM
 #undef RS_POLL
 #undef RS_LOADS
+#undef RSX2_SCATTER
+#undef RSX2_REDUCE_OWN
+#undef RSX2_GATHER
 #undef RSX_PUSH
 #undef RSX_POLL
 #undef RSX_REDUCE

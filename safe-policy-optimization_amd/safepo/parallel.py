@@ -222,7 +222,8 @@ class PeerExchange:
                   1: "recursive doubling of packed words (four-wave kernel)",
                   2: "one-shot all-to-all with flags (helper waves)",
                   3: "recursive doubling of packed words (helper waves)",
-                  4: "row-split kernel, one-hand-off all-to-all of tagged words behind the row groups' L2 hand-off"}
+                  4: "row-split kernel, tagged words behind the row groups' L2 hand-off: one-hand-off all-to-all at 2 ranks, "
+                     "reduce-scatter + all-gather (two hand-offs, every poll one batch) from 4 ranks on"}
 
     def autotune(self, obs_dim: int, act_dim: int, steps: int = 192, with_rccl: bool = True) -> dict:
         """Start-up selection of the per-minibatch exchange on THIS topology: every form of the in-kernel
@@ -306,7 +307,7 @@ class PeerExchange:
         live = {f: u for f, u in table.items() if u != float("inf")}
         best = min(live, key=lambda f: (live[f], f)) if live else None
         # Reproducibility: the forms add the ranks' gradients in different orders, so WHICH form runs decides the bits of a
-        # seeded run.  The deterministic default policy (csrc/update.hip xr_form: doubling at 2 / 4 ranks, packed two-phase otherwise)
+        # seeded run.  The deterministic default policy (csrc/update.hip xr_form: the row-split form at 2 / 4 / 8 ranks; on the four-wave kernel doubling at 2 / 4 ranks, packed two-phase otherwise)
         # is kept unless the measured winner beats it by more than `margin` (timing noise does not flip the choice between two
         # near-equal forms); the choice is logged on rank 0 and lands in the run's config through engine.exchange_autotune.
         _abi.check(lib.spo_p2p_select_form(-1), "spo_p2p_select_form")

@@ -2073,12 +2073,13 @@ def test_multi_agent_masked_gae_popart_bit_exact(dev, golden_dir, tag):
     assert np.array_equal(buf.cost_returns.cpu().numpy().view(np.uint32), z[f"{tag}_cost_returns"].view(np.uint32))
 
 
-@pytest.mark.parametrize("algo", ["pair", "twophase", "a2a", "helper16", "rowsplit", "rowsplit_4_ranks"])
+@pytest.mark.parametrize("algo", ["pair", "twophase", "a2a", "helper16", "rowsplit", "rowsplit_4_ranks", "rowsplit_8_ranks"])
 def test_in_kernel_gradient_exchange_two_ranks_one_gpu(dev, tmp_path, algo):
     """SURVEY.md 8(e) in-kernel form: two ranks (two processes, this one GPU, regions mapped through IPC handles) run
     the data-parallel persistent kernel.  Replicas must stay bit-identical and match the kernel / all-reduce / kernel
     form of the same steps.  "rowsplit" (round 6): the row-split kernel, its one-hand-off all-to-all of tagged words behind the
-    row groups' L2 hand-off (SPO_XR_FORM_ROW_SPLIT; 2 x 6 co-resident workgroups here)."""
+    row groups' L2 hand-off (SPO_XR_FORM_ROW_SPLIT; 2 x 6 co-resident workgroups here); at 4 and 8 ranks the same form runs as
+    reduce-scatter + all-gather (every word reduced by its owner rank in rank order, then broadcast: 24 / 48 workgroups)."""
     import json
     import socket
     import subprocess
@@ -2086,8 +2087,8 @@ def test_in_kernel_gradient_exchange_two_ranks_one_gpu(dev, tmp_path, algo):
     s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
     out = tmp_path / "p2p.json"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    nproc = 4 if algo.endswith("_4_ranks") else 2           # (four ranks: the rank-order sum over more than one peer; 24 workgroups)
-    algo = algo.replace("_4_ranks", "")
+    nproc = 8 if algo.endswith("_8_ranks") else 4 if algo.endswith("_4_ranks") else 2     # (rank-order sums over more than one peer)
+    algo = algo.replace("_4_ranks", "").replace("_8_ranks", "")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SPO_P2P_ALGO="pair" if algo in ("a2a", "helper16") else algo)
     if algo == "a2a":
         env["SPO_P2P_A2A"] = "1"        # main + helper kernel with the flag-based all-to-all exchange on the helper waves
