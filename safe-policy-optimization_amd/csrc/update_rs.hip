@@ -715,7 +715,8 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
     _Pragma("unroll") for (int f_ = 0; f_ < (NFL); ++f_) (FL)[f_] = acc_[f_] * (1.f / (float)XW);      \
   }
 
-  // ---- two-phase form of the cross-rank stage (XW >= SPO_RS_XR_TWO_PHASE_MIN): word gw of a lane belongs to rank gw mod XW.
+  // ---- two-phase form of the cross-rank stage (XW >= SPO_RS_XR_TWO_PHASE_MIN): word gw of a lane belongs to rank (gw / G) mod XW,
+  // G = 8 / XW consecutive words (a unit) sharing an owner, so that a unit's contributions are ONE poll batch of 8 loads.
   // SCATTER: every rank sends each word to its owner only; REDUCE_OWN: the owner polls the XW - 1 contributions of a word TOGETHER
   // (XW loads in flight: one round trip, where the all-to-all form above polls XW - 1 sources of ALL words one after the other: its
   // poll buffer for two sources at once does not fit beside the optimiser state), adds them in rank order with its own at its
@@ -724,12 +725,14 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
   // words per lane and step on the links instead of 15 (XW - 1).  A word is reduced by exactly one rank: the replicas continue
   // from identical bits by construction.  Slots: the all-to-all form's [parity][row group][network][source][word] -- at the
   // owner, [source = sender] holds a contribution; elsewhere [source = owner] holds the finished word (disjoint entries).
+#define RSX2_OWNER(GW) (((GW) / XG_) % XW_)
 #define RSX2_SCATTER(FL, NFL, W0, GTAG)                                                                \
   {                                                                                                    \
     constexpr int NW_ = ((NFL) + 2) / 3;                                                               \
+    constexpr int XW_ = XW > 0 ? XW : 1, XG_ = XW_ >= 8 ? 1 : 8 / XW_;                                 \
     const int xpar_ = (int)((GTAG) & 1u);                                                              \
     _Pragma("unroll") for (int w_ = 0; w_ < NW_; ++w_) {                                               \
-      const int o_ = ((W0) + w_) % (XW > 0 ? XW : 1);                                                  \
+      const int o_ = RSX2_OWNER((W0) + w_);                                                            \
       if (o_ != a.xr_rank) {                                              /* (uniform) */              \
         u4v word_;                                                                                     \
         _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_)                                               \
@@ -739,66 +742,80 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
       }                                                                                                \
     }                                                                                                  \
   }
+  // (a unit = XG_ consecutive words of one owner: 8 / XW, so that a unit's XG_ x XW contributions are one poll batch of 8 loads)
 #define RSX2_REDUCE_OWN(FL, NFL, W0, GTAG)                                                             \
   {                                                                                                    \
     constexpr int NW_ = ((NFL) + 2) / 3;                                                               \
-    constexpr int XW_ = XW > 0 ? XW : 1;                                                               \
+    constexpr int XW_ = XW > 0 ? XW : 1, XG_ = XW_ >= 8 ? 1 : 8 / XW_;                                 \
     const int xpar_ = (int)((GTAG) & 1u);                                                              \
-    _Pragma("unroll") for (int w_ = 0; w_ < NW_; ++w_) {                                               \
-      if ((((W0) + w_) % XW_) == a.xr_rank) {                             /* (uniform) this rank's word */ \
-        u4v x_[XW_];                                                                                   \
+    _Pragma("unroll") for (int u_ = (W0) / XG_; u_ * XG_ < (W0) + NW_; ++u_) {                         \
+      if ((u_ % XW_) == a.xr_rank) {                                      /* (uniform) this rank's unit */ \
+        u4v x_[XG_][XW_];                                                                              \
         unsigned spins_ = 0;                                                                           \
         for (;;) {                                                                                     \
-          _Pragma("unroll") for (int s_ = 0; s_ < XW_; ++s_)              /* (its own entry is never written: loaded, ignored) */ \
-            x_[s_] = ld16_sys(rsx_slot(a.xr_rank, xpar_, s_, (W0) + w_), xlane);                       \
+          _Pragma("unroll") for (int g_ = 0; g_ < XG_; ++g_)                                           \
+            _Pragma("unroll") for (int s_ = 0; s_ < XW_; ++s_) {          /* (its own entry is never written: loaded, ignored) */ \
+              const int gw_ = u_ * XG_ + g_;                                                           \
+              if (gw_ >= (W0) && gw_ < (W0) + NW_) x_[g_][s_] = ld16_sys(rsx_slot(a.xr_rank, xpar_, s_, gw_), xlane); \
+            }                                                                                          \
           wait_vm0();                                                                                  \
           bool ok_ = true;                                                                             \
-          _Pragma("unroll") for (int s_ = 0; s_ < XW_; ++s_) {                                         \
-            pin_u4(x_[s_]);                                                                            \
-            ok_ = ok_ && (s_ == a.xr_rank || x_[s_][3] == (GTAG));                                     \
-          }                                                                                            \
+          _Pragma("unroll") for (int g_ = 0; g_ < XG_; ++g_)                                           \
+            _Pragma("unroll") for (int s_ = 0; s_ < XW_; ++s_) {                                       \
+              const int gw_ = u_ * XG_ + g_;                                                           \
+              if (gw_ >= (W0) && gw_ < (W0) + NW_) {                                                   \
+                pin_u4(x_[g_][s_]);                                                                    \
+                ok_ = ok_ && (s_ == a.xr_rank || x_[g_][s_][3] == (GTAG));                             \
+              }                                                                                        \
+            }                                                                                          \
           if (ok_ || *dead != 0.f) break;                                                              \
           if (++spins_ > RS_SPIN_LIMIT) { *a.err = 2; *dead = 1.f; break; }   /* bounded, and sticky */ \
           __builtin_amdgcn_s_sleep(1);                                                                 \
         }                                                                                              \
-        u4v red_;                                                                                      \
-        _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) {                                             \
-          const float own_ = (3 * w_ + i_) < (NFL) ? (FL)[(3 * w_ + i_) < (NFL) ? 3 * w_ + i_ : 0] : 0.f; \
-          float acc_ = a.xr_rank == 0 ? own_ : __uint_as_float(x_[0][i_]);                             \
-          _Pragma("unroll") for (int s_ = 1; s_ < XW_; ++s_)                                           \
-            acc_ = acc_ + (s_ == a.xr_rank ? own_ : __uint_as_float(x_[s_][i_]));                      \
-          acc_ = acc_ * (1.f / (float)XW_);                                                            \
-          if ((3 * w_ + i_) < (NFL)) (FL)[(3 * w_ + i_) < (NFL) ? 3 * w_ + i_ : 0] = acc_;             \
-          red_[i_] = __float_as_uint(acc_);                                                            \
+        _Pragma("unroll") for (int g_ = 0; g_ < XG_; ++g_) {                                           \
+          const int gw_ = u_ * XG_ + g_;                                                               \
+          if (gw_ >= (W0) && gw_ < (W0) + NW_) {                                                       \
+            const int w_ = gw_ - (W0);                                                                 \
+            u4v red_;                                                                                  \
+            _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) {                                         \
+              const float own_ = (3 * w_ + i_) < (NFL) ? (FL)[(3 * w_ + i_) < (NFL) ? 3 * w_ + i_ : 0] : 0.f; \
+              float acc_ = a.xr_rank == 0 ? own_ : __uint_as_float(x_[g_][0][i_]);                     \
+              _Pragma("unroll") for (int s_ = 1; s_ < XW_; ++s_)                                       \
+                acc_ = acc_ + (s_ == a.xr_rank ? own_ : __uint_as_float(x_[g_][s_][i_]));              \
+              acc_ = acc_ * (1.f / (float)XW_);                                                        \
+              if ((3 * w_ + i_) < (NFL)) (FL)[(3 * w_ + i_) < (NFL) ? 3 * w_ + i_ : 0] = acc_;         \
+              red_[i_] = __float_as_uint(acc_);                                                        \
+            }                                                                                          \
+            red_[3] = (GTAG);                                                                          \
+            _Pragma("unroll") for (int d_ = 1; d_ < XW_; ++d_)                                         \
+              st16_sys(rsx_slot(a.xr_rank ^ d_, xpar_, a.xr_rank, gw_), xlane, red_);                  \
+          }                                                                                            \
         }                                                                                              \
-        red_[3] = (GTAG);                                                                              \
-        _Pragma("unroll") for (int d_ = 1; d_ < XW_; ++d_)                                             \
-          st16_sys(rsx_slot(a.xr_rank ^ d_, xpar_, a.xr_rank, (W0) + w_), xlane, red_);                \
       }                                                                                                \
     }                                                                                                  \
   }
 #define RSX2_GATHER(FL, NFL, W0, GTAG)                                                                 \
   {                                                                                                    \
     constexpr int NW_ = ((NFL) + 2) / 3;                                                               \
-    constexpr int XW_ = XW > 0 ? XW : 1;                                                               \
+    constexpr int XW_ = XW > 0 ? XW : 1, XG_ = XW_ >= 8 ? 1 : 8 / XW_;                                 \
     const int xpar_ = (int)((GTAG) & 1u);                                                              \
     u4v x_[NW_];                                                                                       \
     unsigned spins_ = 0;                                                                               \
     for (;;) {                                                                                         \
       _Pragma("unroll") for (int w_ = 0; w_ < NW_; ++w_)                  /* [source = the word's owner] */ \
-        x_[w_] = ld16_sys(rsx_slot(a.xr_rank, xpar_, ((W0) + w_) % XW_, (W0) + w_), xlane);            \
+        x_[w_] = ld16_sys(rsx_slot(a.xr_rank, xpar_, RSX2_OWNER((W0) + w_), (W0) + w_), xlane);        \
       wait_vm0();                                                                                      \
       bool ok_ = true;                                                                                 \
       _Pragma("unroll") for (int w_ = 0; w_ < NW_; ++w_) {                                             \
         pin_u4(x_[w_]);                                                                                \
-        ok_ = ok_ && ((((W0) + w_) % XW_) == a.xr_rank || x_[w_][3] == (GTAG));                        \
+        ok_ = ok_ && (RSX2_OWNER((W0) + w_) == a.xr_rank || x_[w_][3] == (GTAG));                      \
       }                                                                                                \
       if (ok_ || *dead != 0.f) break;                                                                  \
       if (++spins_ > RS_SPIN_LIMIT) { *a.err = 2; *dead = 1.f; break; }   /* bounded, and sticky */    \
       __builtin_amdgcn_s_sleep(1);                                                                     \
     }                                                                                                  \
     _Pragma("unroll") for (int f_ = 0; f_ < (NFL); ++f_)                                               \
-      (FL)[f_] = ((((W0) + f_ / 3) % XW_) == a.xr_rank) ? (FL)[f_] : __uint_as_float(x_[f_ / 3][f_ % 3]); \
+      (FL)[f_] = (RSX2_OWNER((W0) + f_ / 3) == a.xr_rank) ? (FL)[f_] : __uint_as_float(x_[f_ / 3][f_ % 3]); \
   }
 
 #define RS_ADAM(ADDR, G, M, V)                                                             \
@@ -1188,6 +1205,7 @@ __device__ __forceinline__ void rs_body(const RsArgs& a, float* const lds) {
 #undef RS_POLL_SUM
 #undef RS_POLL
 #undef RS_LOADS
+#undef RSX2_OWNER
 #undef RSX2_SCATTER
 #undef RSX2_REDUCE_OWN
 #undef RSX2_GATHER
