@@ -591,11 +591,10 @@ int spo_wide_ppo_grad_rows(const float* theta, const spo_mlp_net* critic, const 
 int spo_wide_reduce_parts(const float* parts, int64_t rows, int64_t n_params, int n_losses, float* grad, float* losses_out,
                           void* stream);
 /* spo_wide_reduce_parts + spo_wide_clip_adam_dev_log (all parameters in the norm and in the Adam range: ppo_lag.py:310-329) in TWO
- * launches instead of four: the group sum rides in the pass that adds the L2 gradient and forms the norm partials; every workgroup
- * of the Adam pass forms the clip coefficient from the partials itself and reads the optimiser clocks before the last workgroup to
- * finish (a device counter in the last 4 floats of `parts`, which must be ZERO when the buffer is first used) advances them, logs
- * the losses and moves the cursor.  Element for element the arithmetic of the four launches.  One GPU (a data-parallel step
- * all-reduces between the sum and the clip). */
+ * launches instead of four: the group sum rides in the pass that adds the L2 gradient and forms the norm partials (its first
+ * workgroup also advances the optimiser clocks and the cursor); every workgroup of the Adam pass forms the clip coefficient from the
+ * partials itself, the first one logs the losses.  Element for element the arithmetic of the four launches.  One GPU (a
+ * data-parallel step all-reduces between the sum and the clip). */
 int spo_wide_rows_clip_adam_dev_log(float* parts, int64_t rows, float* theta, float* grad, float* adam_m, float* adam_v,
                                     int64_t n_params, int64_t reward_critic_end, int64_t cost_critic_end, int64_t actor_begin,
                                     const spo_ppo_cfg* cfg, double* pow4_dev, float* losses3_out, float* scalars4_out,

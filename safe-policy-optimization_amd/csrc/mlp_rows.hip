@@ -23,7 +23,7 @@
 // fp32 v_mfma_f32_16x16x4_f32 throughout (bitwise an fmaf chain); results differ from the launch-per-layer path in summation
 // order only.
 // Measured (hidden [128, 128], 60 / 8, 64 rows, one MI355X, profiles/r06/wide_step.txt, wide_rows_phase_cycles.txt): the kernel
-// 19.6 us of which ~4 us are MFMA issue time (1 120 useful v_mfma per workgroup, two waves per SIMD), the rest the serial chain of
+// 19-19.6 us (of a 30.1 us step) of which ~4 us are MFMA issue time (1 120 useful v_mfma per workgroup, two waves per SIMD), the rest the serial chain of
 // a stage -- B-operand reads, the MFMA chain, tanh, image stores, barrier -- nine times, plus cursor -> index -> observation rows
 // (three dependent round trips, 2.7 us).  What did NOT help, each measured: warming the XCD's L2 with the parameters at the
 // kernel's start (32.3 against 32.6 us per step), eight-tile load batches without the prefetch (slower: the loads are not the
@@ -495,17 +495,19 @@ __global__ __launch_bounds__(256) void mlp_rows_reduce_kernel(const float* __res
 // ---- the optimiser behind the row groups in TWO launches (world size 1, device-resident clocks: the replayed step).
 // The launch-per-network step ended in wide_prep_kernel -> wide_coef_kernel -> wide_adam_dev_kernel (csrc/ma_net.hip): with the
 // group sum in front, four launches of ~4.5 us that each do < 1 us of work.  Here (1) the group sum, the critics' L2 gradient, the
-// value coefficient and the norm partials are one pass over the parameters, and (2) every workgroup of the Adam pass forms the clip
-// coefficient itself from the partials (fixed order: the same value in every workgroup) and reads the optimiser clocks BEFORE
-// anyone advances them; the last workgroup to finish (a device counter) does what wide_coef_kernel's single thread did: advance
-// the clocks, add the L2 terms to the logged losses, store the loss row, move the cursor.  Same arithmetic, element for element,
-// as spo_wide_reduce_parts + spo_wide_clip_adam_dev_log.
+// value coefficient and the norm partials are one pass over the parameters, whose first workgroup also advances the optimiser
+// clocks and the cursor (nobody in that launch reads them), and (2) every workgroup of the Adam pass forms the clip coefficient
+// itself from the partials (fixed order: the same value in every workgroup) and reads the advanced clocks; its first workgroup adds
+// the L2 terms to the logged losses and stores the loss row.  (A first form kept everything wide_coef_kernel's single lane did in
+// the Adam pass behind a device counter -- the last workgroup to arrive wrote the clocks: one same-address atomic per workgroup,
+// +20 us a step with 290 workgroups, still +1.5 us with 19 large ones.)  Same arithmetic, element for element, as
+// spo_wide_reduce_parts + spo_wide_clip_adam_dev_log.
 struct MrOptArgs {
   const float* parts; int R; int64_t stride;
   float* theta; float* grad; float* m; float* v; int64_t P, r_end, c_end, actor_begin; int64_t rows;
   float l2, vcoef_r, max_norm, lr_actor, lr_critic, b1, b2, eps;
   double* partial; float* scal; float* losses3; double* pow4;
-  float* loss_log; int64_t* cursor; int64_t cursor_step; unsigned* counter; int nblocks;
+  float* loss_log; int64_t* cursor; int64_t cursor_step; int nblocks;
 };
 __global__ __launch_bounds__(256) void mlp_rows_prep_kernel(MrOptArgs a) {
   __shared__ double red[4][3];
@@ -532,10 +534,15 @@ __global__ __launch_bounds__(256) void mlp_rows_prep_kernel(MrOptArgs a) {
     for (int g = 0; g < a.R; ++g) s += (double)a.parts[(int64_t)g * a.stride + a.P + k];
     a.losses3[k] = (float)((k == 2 ? -s : s) / (double)a.rows);
   }
+  // the optimiser clocks and the cursor advance HERE (one lane): nobody in this launch reads them, the gradient launch that did is
+  // over, and the Adam pass behind this one reads the advanced clocks as wide_adam_dev_kernel does -- no counter, no atomics
+  if (blockIdx.x == 0 && tid == 128) {
+    a.pow4[0] *= (double)a.b1; a.pow4[1] *= (double)a.b2; a.pow4[2] *= (double)a.b1; a.pow4[3] *= (double)a.b2;
+    if (a.cursor) a.cursor[0] += a.cursor_step;
+  }
 }
-__global__ __launch_bounds__(1024) void mlp_rows_adam_kernel(MrOptArgs a) {
+__global__ __launch_bounds__(256) void mlp_rows_adam_kernel(MrOptArgs a) {
   __shared__ float sh[4];
-  __shared__ unsigned last;
   const int tid = threadIdx.x;
   if (tid < 64) {
     // wide_coef_kernel's sum: lane l adds the partials l, l + 64, ... in order, then a fixed butterfly over the lanes
@@ -551,34 +558,24 @@ __global__ __launch_bounds__(1024) void mlp_rows_adam_kernel(MrOptArgs a) {
   }
   __syncthreads();
   const float coef = sh[0];
-  const double p0 = a.pow4[0] * (double)a.b1, p1 = a.pow4[1] * (double)a.b2, p2 = a.pow4[2] * (double)a.b1, p3 = a.pow4[3] * (double)a.b2;
   const float lr_a = a.pow4[4] >= 0.0 ? (float)a.pow4[4] : a.lr_actor, lr_c = a.pow4[5] >= 0.0 ? (float)a.pow4[5] : a.lr_critic;
   float ss_a, ss_c, bc2s_a, bc2s_c;
-  adam_scalars(lr_a, p2, p3, ss_a, bc2s_a);
-  adam_scalars(lr_c, p0, p1, ss_c, bc2s_c);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + tid; i < a.P; i += (int64_t)gridDim.x * blockDim.x) {
+  adam_scalars(lr_a, a.pow4[2], a.pow4[3], ss_a, bc2s_a);            // (advanced by the pass in front: beta^(t+1))
+  adam_scalars(lr_c, a.pow4[0], a.pow4[1], ss_c, bc2s_c);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < a.P; i += (int64_t)gridDim.x * 256) {
     const bool act = i >= a.actor_begin;
     const AdamOut o = adam1(a.theta[i], a.grad[i] * coef, a.m[i], a.v[i], a.b1, a.b2, a.eps, act ? ss_a : ss_c, act ? bc2s_a : bc2s_c);
     a.theta[i] = o.p; a.m[i] = o.m; a.v[i] = o.v;
   }
-  // every lane of this workgroup has consumed the clocks (its Adam stores depend on them): count the workgroup in; the last one
-  // to arrive writes what all of them read (no fence: nothing another workgroup WROTE is read here but the counter itself)
-  __syncthreads();
-  if (tid == 0) last = atomicAdd(a.counter, 1u) == (unsigned)gridDim.x - 1u ? 1u : 0u;
-  __syncthreads();
-  if (last && tid == 0) {
-    a.counter[0] = 0u;
-    a.pow4[0] = p0; a.pow4[1] = p1; a.pow4[2] = p2; a.pow4[3] = p3;
+  // what wide_coef_kernel's single lane wrote besides the clocks: nobody else in this launch reads any of it
+  if (blockIdx.x == 0 && tid == 0) {
     a.scal[0] = sh[0]; a.scal[1] = sh[1]; a.scal[2] = sh[2]; a.scal[3] = sh[3];
     const float l0 = a.losses3[0] + sh[1], l1 = a.losses3[1] + sh[2], l2v = a.losses3[2];   // logged critic losses include their L2 terms
     a.losses3[0] = l0; a.losses3[1] = l1;
-    if (a.cursor) {
-      const int64_t at = a.cursor[0];
-      if (a.loss_log) {
-        float* row = a.loss_log + 3 * (at / a.cursor_step);
-        row[0] = l0; row[1] = l1; row[2] = l2v;
-      }
-      a.cursor[0] = at + a.cursor_step;
+    if (a.cursor && a.loss_log) {
+      const int64_t at = a.cursor[0] - a.cursor_step;               // (the step's position: the cursor moved on in the pass in front)
+      float* row = a.loss_log + 3 * (at / a.cursor_step);
+      row[0] = l0; row[1] = l1; row[2] = l2v;
     }
   }
 }
@@ -631,7 +628,7 @@ extern "C" int spo_wide_grad_rows_supported(const spo_mlp_net* critic, const spo
 
 extern "C" int64_t spo_wide_grad_rows_part_floats(int64_t n_params, int64_t rows) {
   if (n_params < 1 || rows < 1) return -1;
-  return ((rows + 15) / 16) * mr_stride(n_params) + 4;       // (+ the optimiser launch's arrival counter: zero before first use)
+  return ((rows + 15) / 16) * mr_stride(n_params) + 4;
 }
 
 // n_nets = 3: reward critic, cost critic, actor (theta = [critic | critic | log_std | actor], the ActorVCritic layout of
@@ -697,8 +694,7 @@ extern "C" int spo_wide_reduce_parts(const float* parts, int64_t rows, int64_t n
 }
 
 // spo_wide_reduce_parts + spo_wide_clip_adam_dev_log (full ranges: the PPO-Lagrangian step, ppo_lag.py:310-329) in two launches --
-// see mlp_rows_prep_kernel / mlp_rows_adam_kernel.  parts: the buffer spo_wide_ppo_grad_rows filled, ZERO-initialised when it was
-// allocated (its last 4 floats hold a device counter that every launch leaves at zero).  grad receives the clipped step's
+// see mlp_rows_prep_kernel / mlp_rows_adam_kernel.  parts: the buffer spo_wide_ppo_grad_rows filled.  grad receives the clipped step's
 // pre-clip gradient (with the L2 terms), losses3_out the step's losses, pow4_dev / cursor_dev advance as in
 // spo_wide_clip_adam_dev_log (loss_log_dev row = the three losses).
 extern "C" int spo_wide_rows_clip_adam_dev_log(float* parts, int64_t rows, float* theta, float* grad, float* adam_m, float* adam_v,
@@ -719,14 +715,10 @@ extern "C" int spo_wide_rows_clip_adam_dev_log(float* parts, int64_t rows, float
   MrOptArgs a{parts, R, stride, theta, grad, adam_m, adam_v, n_params, reward_critic_end, cost_critic_end, actor_begin, rows,
               cfg->use_critic_norm ? cfg->l2_coef : 0.f, cfg->use_value_coefficient ? 2.f : 1.f, cfg->max_grad_norm, cfg->lr_actor,
               cfg->lr_critic, cfg->beta1, cfg->beta2, cfg->adam_eps, partial_ws, scalars4_out, losses3_out, pow4_dev, loss_log_dev,
-              cursor_dev, cursor_step, reinterpret_cast<unsigned*>(parts + (int64_t)R * stride), (int)blocks};
+              cursor_dev, cursor_step, (int)blocks};
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(mlp_rows_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
-  // few, large workgroups for the Adam pass: its tail is one same-address atomic per workgroup, served one after the other by the
-  // memory side (290 workgroups of 256 lanes: +20 us a step, measured)
-  int64_t ablocks = (n_params + 4095) / 4096;
-  ablocks = ablocks > 32 ? 32 : ablocks;
-  hipLaunchKernelGGL(mlp_rows_adam_kernel, dim3((unsigned)ablocks), dim3(1024), 0, st, a);
+  hipLaunchKernelGGL(mlp_rows_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
   SPO_LAUNCH_CHECK("spo_wide_rows_clip_adam_dev_log");
   return 0;
 }

@@ -157,7 +157,6 @@ class WideNets:
         key = ("parts", n, critics_only)
         parts = self._scratch.get(key)
         if parts is None:
-            # (zeros: the tail holds the arrival counter of spo_wide_rows_clip_adam_dev_log)
             parts = torch.zeros(int(self.lib.spo_wide_grad_rows_part_floats(P, n)), dtype=torch.float32, device=self.policy.theta.device)
             self._scratch[key] = parts
         _abi.check(self.lib.spo_wide_ppo_grad_rows(
