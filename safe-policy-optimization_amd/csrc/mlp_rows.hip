@@ -412,30 +412,35 @@ __global__ __launch_bounds__(512) void mlp_rows_grad_kernel(MrArgs a) {
       }
       pb[u] = s;
     }
+    if (l == 1) MR_STAMP(26);
     // (2) weight gradient dW[u][k] = sum_rows dZ[row][u] h[row][k]: tiles (unit tile, input tile) dealt to the waves; the reduction
     //     index is the row -- four MFMAs per tile
     {
       const float* za = ZTc + j * MR_TS + 4 * q;
       const float* hb = lds + Li.ht + j * MR_TS + 4 * q;
       const int ntile = NT * KT;
+      // (the tile's coordinates advance without a division -- p / KT with a run-time KT is ~40 scalar instructions per tile -- and
+      //  the store offsets are 32-bit on the uniform base.  Four tiles per round with their sixteen MFMAs interleaved, and the
+      //  stores left out altogether, measured the same 0.3 us per tile: neither the dependent MFMAs nor the stores are the bound.)
+      int mt = wave / KT, nt = wave - mt * KT;
 #pragma unroll 2
-      for (int p = wave; p < ntile; p += 8) {
-        const int mt = p / KT, nt = p - mt * KT;
+      for (int p = wave; p < ntile; p += 8, nt += 8) {
+        while (nt >= KT) { nt -= KT; ++mt; }
         const f4 av = *reinterpret_cast<const f4*>(za + 16 * mt * MR_TS);
         const f4 bv = *reinterpret_cast<const f4*>(hb + 16 * nt * MR_TS);
         f4 acc = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc = mfma4(av[r], bv[r], acc);
-        const int col = 16 * nt + j;
+        const int col = 16 * nt + j, u0 = 16 * mt + 4 * q;
         if (col < K) {
+          const unsigned off = (unsigned)(u0 * K + col);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int u = 16 * mt + 4 * q + r;
-            if (u < N) pW[(int64_t)u * K + col] = acc[r];
-          }
+          for (int r = 0; r < 4; ++r)
+            if (u0 + r < N) pW[off + (unsigned)(r * K)] = acc[r];
         }
       }
     }
+    if (l == 1) MR_STAMP(27);
     // (3) dZ of the layer below: dH = dZ W, dZ' = dH (1 - h^2); wave w takes the input-unit tiles w, w + 8, ...; the first
     //     tile's weights were requested a stage ahead (pt)
     if (l > 0) {
@@ -465,12 +470,14 @@ __global__ __launch_bounds__(512) void mlp_rows_grad_kernel(MrArgs a) {
         for (int r = 0; r < 4; ++r) ZTn[(u0 + r) * MR_TS + j] = dz[r];
       }
     }
+    if (l == 1) MR_STAMP(28);
     if (l > 1) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) pt[i][r] = npt[i][r];
     }
+    if (l == 1) MR_STAMP(29);
     __syncthreads();
     MR_STAMP(stamp++);
     cur ^= 1;

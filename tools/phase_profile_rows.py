@@ -34,6 +34,12 @@ def main():
         fine = [buf[32 * w + k] for k in range(32)]
         out[tag]["forward layers, wave 0: [MFMAs issued, stores done, next layer's registers copied] us after the layer's start"] = [
             [round((fine[16 + 4 * l + i] - st[2 + l]) * 0.01, 2) for i in range(3)] for l in range(min(n, 4))]
+    for w, tag in ((0, "first workgroup"), (1, "last workgroup")):
+        fine = [buf[32 * w + k] for k in range(32)]
+        if fine[26] and n >= 2:
+            t0 = buf[32 * w + 2 + n + 1 + (n - 1 - 1)]          # start of backward layer 1 = end of the stage before it
+            out[tag]["backward layer 1, wave 0: [bias sums done, weight-gradient tiles issued, dZ below stored, registers copied] us after the stage's start"] = [
+                round((fine[k] - t0) * 0.01, 2) for k in (26, 27, 28, 29)]
     print(json.dumps(out, indent=1))
 
 
